@@ -1,0 +1,80 @@
+"""ctypes binding of libeasydgl_hip.so (C ABI declared in include/easydgl_hip.h).
+
+The product path has NO fallback: importing this module without the built library raises, and
+every op raises if handed a non-GPU tensor."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_long, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeasydgl_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32
+
+P, I, F, L, U32, I64 = c_void_p, c_int, c_float, c_long, c_uint32, c_int64
+
+# name -> (restype, argtypes) — must list EVERY symbol include/easydgl_hip.h declares
+SIGNATURES = {
+    "edgl_last_error": (c_char_p, []),
+    "edgl_version": (I, []),
+    "edgl_rng_advance": (I, [P, P]),
+    "edgl_encode_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I64, F, F, P, U32, P, P, P, I, P]),
+    "edgl_encode_bwd_workspace": (L, [I, I, I]),
+    "edgl_encode_bwd": (I, [P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
+    "edgl_gemm": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, I, P]),
+    "edgl_colsum": (I, [P, I, I, I, P, I, P, I, I, P]),
+    "edgl_bimau_pack_bytes": (L, [I, I, I, I]),
+    "edgl_bimau_pack": (I, [P, P, P, P, I, I, I, P, I, P]),
+    "edgl_bimau_fwd": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, I, P]),
+    "edgl_bimau_bwd_workspace": (L, [I, I, I, I, I, I]),
+    "edgl_bimau_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, I, P]),
+    "edgl_add_layernorm_fwd": (I, [P, P, I, P, P, I, I, I, F, P, U32, P, I, P, P, I, P]),
+    "edgl_add_layernorm_bwd": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, I, P]),
+    "edgl_score_chunks": (I, [I]),
+    "edgl_score_lse_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, P]),
+    "edgl_ce_loss_fwd": (I, [P, P, P, I, P, P, P]),
+    "edgl_score_bwd_workspace": (L, [I, I, I]),
+    "edgl_score_ce_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, I, P]),
+    "edgl_mask_topk": (I, [P, I, I, I, P, I, I, P, P, P]),
+    "edgl_topk_merge": (I, [P, P, I, I, I, P, P, P]),
+    "edgl_rank_metrics": (I, [P, I, I, P, P, P]),
+    "edgl_tpp_workspace": (I, []),
+    "edgl_tpp_fwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P]),
+    "edgl_tpp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, P, P]),
+    "edgl_adam_step": (I, [P, P, P, P, L, F, F, F, F, P, F, P, I, P, P]),
+    "edgl_l2_loss": (I, [P, P, I, F, P, I, P, P]),
+    "edgl_cast": (I, [P, P, L, I, P]),
+    "edgl_cast_back": (I, [P, P, L, I, I, P]),
+    "edgl_add": (I, [P, P, P, L, I, P]),
+    "edgl_add_cols": (I, [P, I, P, I, L, I, I, P]),
+    "edgl_gelu_bwd": (I, [P, P, P, L, I, P]),
+}
+
+
+class EdglError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m easydgl_amd.build` (hipcc --offload-arch=gfx950). "
+            "easydgl_amd has no CPU / PyTorch fallback by design.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI drift: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.edgl_last_error()
+        raise EdglError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,222 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libeasydgl_hip.so.
+// Written for MI355X only: 64-wide wavefronts, MFMA 16x16 tiles, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/easydgl_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __bf16 bf16;
+
+#define EDGL_WAVE 64
+
+// ----------------------------------------------------------------------------------------------
+// host-side error helpers
+// ----------------------------------------------------------------------------------------------
+extern "C" void edgl_set_error(const char* fmt, ...);
+
+#define EDGL_REQUIRE(cond, code, ...)            \
+    do {                                         \
+        if (!(cond)) {                           \
+            edgl_set_error(__VA_ARGS__);         \
+            return (code);                       \
+        }                                        \
+    } while (0)
+
+#define EDGL_LAUNCH_CHECK()                                              \
+    do {                                                                 \
+        hipError_t e_ = hipGetLastError();                               \
+        if (e_ != hipSuccess) {                                          \
+            edgl_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return EDGL_ERR_LAUNCH;                                      \
+        }                                                                \
+    } while (0)
+
+static inline int edgl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ----------------------------------------------------------------------------------------------
+// element types: activations / GEMM operands are float (exact-f32 MFMA path) or bf16
+// ----------------------------------------------------------------------------------------------
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int VEC = 4;   // elements per 16-byte vector
+    static constexpr int KB = 16;   // contraction elements consumed by one mma16 K-block
+};
+template <> struct ElemTraits<bf16> {
+    static constexpr int VEC = 8;
+    static constexpr int KB = 32;
+};
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+
+// 16-byte vector of T
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { float v[4]; };
+template <> struct Vec16<bf16> { bf16 v[8]; };
+
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T* p) {
+    Vec16<T> r;
+    *reinterpret_cast<uint4*>(&r) = *reinterpret_cast<const uint4*>(p);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const Vec16<T>& r) {
+    *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(&r);
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
+    Vec16<T> r;
+    *reinterpret_cast<uint4*>(&r) = make_uint4(0, 0, 0, 0);
+    return r;
+}
+
+// ----------------------------------------------------------------------------------------------
+// MFMA 16x16 primitives.  One "K-block" contracts KB elements:
+//   float : 4 x v_mfma_f32_16x16x4_f32  (exact f32; lane holds A[i=l&15][k=(l>>4)*4+r], r=0..3,
+//           MFMA #r pairs register r of A with register r of B, so any k permutation agrees)
+//   bf16  : 1 x v_mfma_f32_16x16x32_bf16 (lane holds 8 consecutive k at (l>>4)*8)
+// D layout (both): acc[r] = D[row=(l>>4)*4+r][col=l&15].
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mma_kblock(const Vec16<float>& a, const Vec16<float>& b, f32x4 acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[r], b.v[r], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ f32x4 mma_kblock(const Vec16<bf16>& a, const Vec16<bf16>& b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                   *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
+}
+
+// 4-element (K=16) fragments used by the attention kernels: lane holds k=(l>>4)*4+j, j=0..3.
+template <typename T> struct Frag4;
+template <> struct Frag4<float> { float v[4]; };
+template <> struct Frag4<bf16> { bf16 v[4]; };
+
+__device__ __forceinline__ f32x4 mma16(const Frag4<float>& a, const Frag4<float>& b, f32x4 acc) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[r], b.v[r], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ f32x4 mma16(const Frag4<bf16>& a, const Frag4<bf16>& b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(&a),
+                                                     *reinterpret_cast<const s16x4*>(&b), acc, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ Frag4<T> frag_from_acc(const f32x4& c) {
+    Frag4<T> f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f.v[r] = from_f32<T>(c[r]);
+    return f;
+}
+template <typename T> __device__ __forceinline__ Frag4<T> frag_ld(const T* p) {  // 4 contiguous elements
+    Frag4<T> f;
+    if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<uint4*>(&f) = *reinterpret_cast<const uint4*>(p);
+    } else {
+        *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<const uint2*>(p);
+    }
+    return f;
+}
+template <typename T> __device__ __forceinline__ Frag4<T> frag_zero() {
+    Frag4<T> f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f.v[r] = from_f32<T>(0.f);
+    return f;
+}
+
+
+// ---- helpers on the MFMA register layout L(first,second): reg r of lane l = X[(l>>4)*4+r][l&15] ----
+__device__ __forceinline__ float group_sum4(float v) {  // sum over the 4 lane groups (same lane&15)
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float group_max4(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ Frag4<T> identity_frag(int lane) {
+    Frag4<T> f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.v[j] = from_f32<T>(((lane >> 4) * 4 + j) == (lane & 15) ? 1.f : 0.f);
+    return f;
+}
+// L(a,b) -> L(b,a): one MFMA against the identity (A operand = the tile itself)
+template <typename T>
+__device__ __forceinline__ f32x4 transpose_tile(const f32x4& x, const Frag4<T>& ident) {
+    return mma16(frag_from_acc<T>(x), ident, f32x4{0.f, 0.f, 0.f, 0.f});
+}
+
+// ----------------------------------------------------------------------------------------------
+// wave / block reductions
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// all threads get the block-wide sum; `red` holds >= blockDim/64 floats
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// ----------------------------------------------------------------------------------------------
+// counter-based dropout RNG: keep(idx) is a pure function of (seed, step, stream, idx) so the
+// backward kernels regenerate the forward mask instead of storing it.
+// rng_state (device): [0] = seed, [1] = step counter (advanced by edgl_rng_advance once per step).
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t edgl_mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+struct DropKey { uint32_t k0, k1, thresh; float scale; };
+__device__ __forceinline__ DropKey make_dropkey(const uint64_t* rng_state, uint32_t stream, float rate) {
+    DropKey k;
+    uint64_t seed = rng_state ? rng_state[0] : 0ull, step = rng_state ? rng_state[1] : 0ull;
+    k.k0 = edgl_mix32((uint32_t)seed ^ (stream * 0x9E3779B9u) ^ 0xA511E9B3u);
+    k.k1 = edgl_mix32((uint32_t)(seed >> 32) + (uint32_t)step * 0x85ebca6bu + (uint32_t)(step >> 32) + stream);
+    // drop iff hash < thresh ; thresh = rate * 2^32
+    double t = (double)rate * 4294967296.0;
+    k.thresh = rate <= 0.f ? 0u : (t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t);
+    k.scale = rate <= 0.f ? 1.f : 1.f / (1.f - rate);
+    return k;
+}
+__device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t idx) {
+    uint32_t h = edgl_mix32(((uint32_t)idx) * 0x9E3779B1u ^ k.k0);
+    h = edgl_mix32(h + (uint32_t)(idx >> 32) * 0x7feb352du + k.k1);
+    return h >= k.thresh;
+}
+__device__ __forceinline__ float drop_apply(const DropKey& k, uint64_t idx, float x) {
+    return k.thresh == 0u ? x : (drop_keep(k, idx) ? x * k.scale : 0.f);
+}
+
+// ----------------------------------------------------------------------------------------------
+// math
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) {  // EasyDGL.py:31 exact erf GELU
+    return x * (0.5f * (1.0f + erff(x * 0.70710678118654752440f)));
+}
+__device__ __forceinline__ float dgelu_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }

@@ -1,0 +1,563 @@
+// K3 backward.  Two kernels:
+//   A) attention part, one wave per (b, head): recomputes S, P, H, Z, lambda, G in registers, then
+//      dA -> dG/dP1 -> dlambda -> dz -> du -> dH -> dP2 -> dS -> dQ, and accumulates dK/dV/dT_ over
+//      its query tiles in MFMA accumulators (written once, no atomics).  Products that contract
+//      over the QUERY index use operands transposed by one MFMA against the identity.
+//   B) intensity weight gradients: row tiles of (Hin, dz) written by A are re-expanded
+//      (Zpre = Hin.W1, sigmoid) in the orientation whose MFMA contraction runs over rows, giving
+//      dW1 / db1 / dw partials per workgroup, reduced deterministically by a third tiny kernel.
+#include "bimau_common.h"
+
+namespace {
+using namespace bimau;
+
+constexpr int KB_BLOCKS = 256;  // workgroups of kernel B (each 4 waves)
+
+struct BwdP {
+    const void* qkvt; const int64_t* ids; const float* spans; const uint8_t* marks; const char* pack;
+    const void* d_out; const float* d_lam_ext;
+    int B, T, C, H, E;
+    float rate; const uint64_t* rng; uint32_t stream_id;
+    void* d_qkvt;
+    void* hin_ws; float* dz_ws; float* dsc_part; float* wpart;
+    int waves;
+};
+
+template <typename T>
+__device__ __forceinline__ void st_frag(T* dst, const f32x4& a) {
+    Frag4<T> f = frag_from_acc<T>(a);
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&f);
+    else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&f);
+}
+
+template <typename T, int DT, int NT>
+__global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
+    constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PackDims pd = pack_dims<T>(dh, p.E);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.pack);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < (int)(pd.bytes / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    const T* W1T = reinterpret_cast<const T*>(smem);
+    const T* W1R = reinterpret_cast<const T*>(smem + pd.off_w1r);
+    const float* fW = reinterpret_cast<const float*>(smem + pd.off_f32);
+    const float* w1s = fW; const float* b1s = fW + pd.JE; const float* wvs = fW + 2 * pd.JE;
+    const float* scs = fW + 3 * pd.JE; const float* iscs = scs + EP;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long job = (long)blockIdx.x * p.waves + wave;
+    if (job >= (long)p.B * p.H) return;
+    const int b = (int)(job / p.H), head = (int)(job % p.H);
+    const long bp = (long)head * p.B + b;
+
+    constexpr size_t WAVE_ELEMS = 3 * (size_t)Tp * dh + 2 * (size_t)dh * LDT + (size_t)Tp * EP + (size_t)EP * LDT;
+    T* Ks = reinterpret_cast<T*>(smem + pd.bytes) + (size_t)wave * WAVE_ELEMS;  // K  [Tp][dh]
+    T* Ts = Ks + Tp * dh;                                                       // T_ [Tp][dh]
+    T* Vs = Ts + Tp * dh;                                                       // V  [Tp][dh]
+    T* KTs = Vs + Tp * dh;                                                      // K^T  [dh][LDT]
+    T* TTs = KTs + dh * LDT;                                                    // T_^T [dh][LDT]
+    T* Ms = TTs + dh * LDT;                                                     // marks   [Tp][16]
+    T* MTs = Ms + Tp * EP;                                                      // marks^T [16][LDT]
+    const T* qkvt = reinterpret_cast<const T*>(p.qkvt) + (long)b * p.T * 4 * p.C;
+    const T* dout = reinterpret_cast<const T*>(p.d_out) + (long)b * p.T * p.C;
+    T* dqkvt = reinterpret_cast<T*>(p.d_qkvt) + (long)b * p.T * 4 * p.C;
+    const int ldq = 4 * p.C;
+    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, KTs, LDT, lane);
+    stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, Ts, TTs, LDT, lane);
+    stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, Vs, nullptr, LDT, lane);
+    stage_marks<T>(p.marks + (long)b * p.T * p.E, p.E, p.T, Tp, Ms, MTs, LDT, lane);
+    const KeyBits kb = load_keybits<NT>(p.ids + (long)b * p.T, p.T, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const float cscale = rsqrtf((float)dh);
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 dKa[DT][NT], dVa[DT][NT], dTa[DT][NT];  // L(first=u, second=k)
+#pragma unroll
+    for (int u = 0; u < DT; ++u)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) { dKa[u][kt] = zero4; dVa[u][kt] = zero4; dTa[u][kt] = zero4; }
+    float dsc_acc[4] = {0.f, 0.f, 0.f, 0.f};
+
+    for (int qt = 0; qt < NT; ++qt) {
+        const int q = qt * 16 + l15;
+        const bool qok = q < p.T;
+        Frag4<T> qf[DT], dof[DT];
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) {
+            qf[ub] = qok ? frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4) : frag_zero<T>();
+            dof[ub] = qok ? frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4) : frag_zero<T>();
+        }
+        // ---- recompute S, P ---------------------------------------------------------------------
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 a = zero4;
+#pragma unroll
+            for (int ub = 0; ub < DT; ++ub)
+                a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
+            s[kt] = a;
+        }
+        masked_softmax<NT>(s, kb, cscale);  // s = P^T, L(first=k, second=q)
+        // ---- H^T and the intensity MLP ----------------------------------------------------------
+        Frag4<T> hf[DT];
+        {
+            Frag4<T> pf[NT];
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) pf[kt] = frag_from_acc<T>(s[kt]);
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) {
+                f32x4 a = zero4;
+#pragma unroll
+                for (int kt = 0; kt < NT; ++kt)
+                    a = mma16(frag_ld<T>(TTs + (ut * 16 + l15) * LDT + kt * 16 + g4), pf[kt], a);
+                hf[ut] = frag_from_acc<T>(a);
+                if (qok) {  // Hin rows for kernel B (T-rounded, identical to what Z is computed from)
+                    T* dst = reinterpret_cast<T*>(p.hin_ws) + (bp * p.T + q) * dh + ut * 16 + g4;
+                    if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&hf[ut]);
+                    else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&hf[ut]);
+                }
+            }
+        }
+        const float span = qok ? p.spans[(long)b * p.T + q] : 0.f;
+        f32x4 zt[16][DT];  // sigmoid outputs Z^T[j][q], j = e*dh + d*16 + g4 + r
+        float zp[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            zp[e] = 0.f;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) zt[e][d] = zero4;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (e < p.E) {
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int jt = e * DT + d;
+                    f32x4 a = zero4;
+#pragma unroll
+                    for (int ub = 0; ub < DT; ++ub)
+                        a = mma16(frag_ld<T>(W1T + (jt * 16 + l15) * pd.LDW + ub * 16 + g4), hf[ub], a);
+                    const float4 ws = *reinterpret_cast<const float4*>(w1s + jt * 16 + g4);
+                    const float4 bs = *reinterpret_cast<const float4*>(b1s + jt * 16 + g4);
+                    const float4 wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
+                    f32x4 zz;
+                    zz[0] = sigmoid_f(a[0] + span * ws.x + bs.x);
+                    zz[1] = sigmoid_f(a[1] + span * ws.y + bs.y);
+                    zz[2] = sigmoid_f(a[2] + span * ws.z + bs.z);
+                    zz[3] = sigmoid_f(a[3] + span * ws.w + bs.w);
+                    zt[e][d] = zz;
+                    zp[e] += zz[0] * wv.x + zz[1] * wv.y + zz[2] * wv.z + zz[3] * wv.w;
+                }
+            }
+        }
+        float z4[4], lam4[4], sg4[4];
+        reduce_scatter16(zp, z4, lane);
+        Frag4<T> lf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sc = scs[g4 + i], isc = iscs[g4 + i];
+            const float x = z4[i] * isc;
+            lam4[i] = sc * __logf(1.0f + __expf(x));
+            sg4[i] = sigmoid_f(x);
+            lf.v[i] = from_f32<T>(lam4[i]);
+        }
+        // ---- G, dA, dG -> dlambda, dP1, and dV accumulation ----------------------------------------
+        Frag4<T> dOT[DT];  // L(first=q, second=v): A operand contracting over q
+#pragma unroll
+        for (int vt = 0; vt < DT; ++vt) dOT[vt] = frag_from_acc<T>(mma16(dof[vt], ident, zero4));
+        f32x4 dp[NT];
+        f32x4 dlamT = zero4;  // L(first=e, second=q)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, zero4);
+            f32x4 da = zero4;
+#pragma unroll
+            for (int vb = 0; vb < DT; ++vb)
+                da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), dof[vb], da);
+            f32x4 ap, dg, d1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kt * 16 + g4 + r;
+                const bool diag = (k == q);
+                const float gv = diag ? 1.0f : gacc[r];
+                const float pv = s[kt][r];
+                float fac = 1.0f;
+                if (dk.thresh != 0u) fac = drop_keep(dk, (uint64_t)((bp * p.T + q) * p.T + k)) ? dk.scale : 0.f;
+                ap[r] = fac * gv * pv;                    // A' = D*G'*P
+                const float dad = da[r] * fac;
+                dg[r] = diag ? 0.f : dad * pv;            // set_diag blocks the gradient
+                d1[r] = dad * gv;                         // dP through A'
+            }
+            dp[kt] = d1;
+            dlamT = mma16(frag_ld<T>(MTs + l15 * LDT + kt * 16 + g4), frag_from_acc<T>(dg), dlamT);
+            const Frag4<T> apT = frag_from_acc<T>(transpose_tile<T>(ap, ident));  // L(first=q, second=k)
+#pragma unroll
+            for (int vt = 0; vt < DT; ++vt) dVa[vt][kt] = mma16(dOT[vt], apT, dVa[vt][kt]);
+        }
+        // ---- dlambda -> dz, dscaling ---------------------------------------------------------------
+        float dz4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float dl = dlamT[i];
+            if (p.d_lam_ext && qok && (g4 + i) < p.E) dl += p.d_lam_ext[(bp * p.T + q) * p.E + g4 + i];
+            dz4[i] = dl * sg4[i];
+            if (qok && (g4 + i) < p.E) dsc_acc[i] += dl * (lam4[i] - z4[i] * sg4[i]);
+        }
+        if (qok) *reinterpret_cast<float4*>(p.dz_ws + (bp * p.T + q) * EP + g4) = make_float4(dz4[0], dz4[1], dz4[2], dz4[3]);
+        float dz16[16];
+        all_gather16(dz4, dz16, lane);
+        // ---- du -> dH^T[u][q] = sum_j W1[u][j] du[q][j] -----------------------------------------------
+        f32x4 dH[DT];
+#pragma unroll
+        for (int ut = 0; ut < DT; ++ut) dH[ut] = zero4;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (e < p.E) {
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int jt = e * DT + d;
+                    const float4 wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
+                    const f32x4 zz = zt[e][d];
+                    f32x4 du;
+                    du[0] = dz16[e] * wv.x * zz[0] * (1.0f - zz[0]);
+                    du[1] = dz16[e] * wv.y * zz[1] * (1.0f - zz[1]);
+                    du[2] = dz16[e] * wv.z * zz[2] * (1.0f - zz[2]);
+                    du[3] = dz16[e] * wv.w * zz[3] * (1.0f - zz[3]);
+                    const Frag4<T> duf = frag_from_acc<T>(du);
+#pragma unroll
+                    for (int ut = 0; ut < DT; ++ut)
+                        dH[ut] = mma16(frag_ld<T>(W1R + (ut * 16 + l15) * pd.LDR + jt * 16 + g4), duf, dH[ut]);
+                }
+            }
+        }
+        // ---- dP2 = dH.T_^T ; dS = P*(dP - rowsum(dP*P)) * c --------------------------------------------
+        Frag4<T> dhf[DT];
+#pragma unroll
+        for (int ut = 0; ut < DT; ++ut) dhf[ut] = frag_from_acc<T>(dH[ut]);
+        float rowdot = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 a = dp[kt];
+#pragma unroll
+            for (int ub = 0; ub < DT; ++ub)
+                a = mma16(frag_ld<T>(Ts + (kt * 16 + l15) * dh + ub * 16 + g4), dhf[ub], a);
+            dp[kt] = a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rowdot += a[r] * s[kt][r];
+        }
+        rowdot = group_sum4(rowdot);
+        // transposed operands for the query-contracting products
+        Frag4<T> QT[DT], dHT[DT];
+#pragma unroll
+        for (int ut = 0; ut < DT; ++ut) {
+            QT[ut] = frag_from_acc<T>(mma16(qf[ut], ident, zero4));
+            dHT[ut] = frag_from_acc<T>(transpose_tile<T>(dH[ut], ident));
+        }
+        f32x4 dQ[DT];
+#pragma unroll
+        for (int ut = 0; ut < DT; ++ut) dQ[ut] = zero4;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[r] = s[kt][r] * (dp[kt][r] - rowdot) * cscale;
+            const Frag4<T> dsf = frag_from_acc<T>(ds);
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut)
+                dQ[ut] = mma16(frag_ld<T>(KTs + (ut * 16 + l15) * LDT + kt * 16 + g4), dsf, dQ[ut]);
+            const Frag4<T> dsT = frag_from_acc<T>(transpose_tile<T>(ds, ident));
+            const Frag4<T> pT = frag_from_acc<T>(transpose_tile<T>(s[kt], ident));
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) {
+                dKa[ut][kt] = mma16(QT[ut], dsT, dKa[ut][kt]);
+                dTa[ut][kt] = mma16(dHT[ut], pT, dTa[ut][kt]);
+            }
+        }
+        if (qok) {
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) st_frag<T>(dqkvt + (long)q * ldq + head * dh + ut * 16 + g4, dQ[ut]);
+        }
+    }
+    // ---- write dK / dV / dT_ (L(first=u, second=k): 4 consecutive channels of key row k) ----------
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const int k = kt * 16 + l15;
+        if (k < p.T) {
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) {
+                T* row = dqkvt + (long)k * ldq + head * dh + ut * 16 + g4;
+                st_frag<T>(row + p.C, dKa[ut][kt]);
+                st_frag<T>(row + 2 * p.C, dVa[ut][kt]);
+                st_frag<T>(row + 3 * p.C, dTa[ut][kt]);
+            }
+        }
+    }
+    // ---- dscaling partial: sum over the 16 query lanes -----------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = dsc_acc[i];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (l15 == 0) p.dsc_part[job * EP + g4 + i] = v;
+    }
+}
+
+// ---------------- kernel B: intensity weight gradients ---------------------------------------------
+struct WgP {
+    const void* hin_ws; const float* dz_ws; const float* spans; const char* pack;
+    long R; int B, T, E; float* wpart;
+};
+
+template <typename T, int DT>
+__global__ __launch_bounds__(256) void intensity_wgrad_kernel(WgP p) {
+    constexpr int dh = 16 * DT;
+    constexpr int ECH = 16 / (DT * DT);  // marks per workgroup row (gridDim.y = 16/ECH)
+    const int e0 = blockIdx.y * ECH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PackDims pd = pack_dims<T>(dh, p.E);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.pack);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < (int)(pd.bytes / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    const int JE = pd.JE, NPAR = (dh + 3) * JE;
+    float* accs = reinterpret_cast<float*>(smem + pd.bytes);  // [NPAR] block accumulator
+    for (int i = threadIdx.x; i < NPAR; i += blockDim.x) accs[i] = 0.f;
+    const T* W1T = reinterpret_cast<const T*>(smem);
+    const float* fW = reinterpret_cast<const float*>(smem + pd.off_f32);
+    const float* w1s = fW; const float* b1s = fW + JE; const float* wvs = fW + 2 * JE;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long ntile = (p.R + 15) / 16;
+    const T* hin = reinterpret_cast<const T*>(p.hin_ws);
+
+    f32x4 dW[ECH][DT][DT];  // [e-e0][d][ub]: tile (j-tile = e*DT+d, u-tile = ub), L(first=j, second=u)
+    float adb[ECH][DT], adws[ECH][DT], adw[ECH][DT];
+#pragma unroll
+    for (int e = 0; e < ECH; ++e)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            adb[e][d] = 0.f; adws[e][d] = 0.f; adw[e][d] = 0.f;
+#pragma unroll
+            for (int ub = 0; ub < DT; ++ub) dW[e][d][ub] = zero4;
+        }
+
+    for (long rt = (long)blockIdx.x * 4 + wave; rt < ntile; rt += (long)gridDim.x * 4) {
+        const long rowA = rt * 16 + l15;  // row on the lane axis (A operand)
+        Frag4<T> hA[DT], hB[DT];
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) {
+            hA[ub] = rowA < p.R ? frag_ld<T>(hin + rowA * dh + ub * 16 + g4) : frag_zero<T>();
+            hB[ub] = frag_from_acc<T>(mma16(hA[ub], ident, zero4));  // L(first=row, second=u)
+        }
+        float spn[4];
+        long rr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rr[r] = rt * 16 + g4 + r;
+            if (rr[r] < p.R) {
+                const long bpq = rr[r] / p.T;      // b' = head*B + b
+                const int q = (int)(rr[r] % p.T), bb = (int)(bpq % p.B);
+                spn[r] = p.spans[(long)bb * p.T + q];
+            } else {
+                spn[r] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int ee = 0; ee < ECH; ++ee) {
+            const int e = e0 + ee;
+            if (e < p.E) {
+                float dzr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dzr[r] = rr[r] < p.R ? p.dz_ws[rr[r] * EP + e] : 0.f;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int jt = e * DT + d, j = jt * 16 + l15;
+                    f32x4 a = zero4;  // Zpre[row][j], L(first=row, second=j)
+#pragma unroll
+                    for (int ub = 0; ub < DT; ++ub)
+                        a = mma16(hA[ub], frag_ld<T>(W1T + (jt * 16 + l15) * pd.LDW + ub * 16 + g4), a);
+                    const float ws = w1s[j], bs = b1s[j], wv = wvs[j];
+                    f32x4 du;
+                    float sdb = 0.f, sdws = 0.f, sdw = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = sigmoid_f(a[r] + spn[r] * ws + bs);
+                        const float t2 = dzr[r] * z;
+                        du[r] = t2 * wv * (1.0f - z);
+                        sdb += du[r]; sdws += du[r] * spn[r]; sdw += t2;
+                    }
+                    adb[ee][d] += sdb; adws[ee][d] += sdws; adw[ee][d] += sdw;
+                    const Frag4<T> duf = frag_from_acc<T>(du);  // as A operand: A[m=j][kk=row]
+#pragma unroll
+                    for (int ub = 0; ub < DT; ++ub) dW[ee][d][ub] = mma16(duf, hB[ub], dW[ee][d][ub]);
+                }
+            }
+        }
+    }
+    // ---- block reduction: waves take turns adding into the LDS accumulator (deterministic) -----------
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int ee = 0; ee < ECH; ++ee) {
+                const int e = e0 + ee;
+                if (e < p.E) {
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        const int jt = e * DT + d;
+                        const float sb = group_sum4(adb[ee][d]), sws = group_sum4(adws[ee][d]), sw = group_sum4(adw[ee][d]);
+                        if (lane < 16) {
+                            const int j = jt * 16 + l15;
+                            accs[dh * JE + j] += sws;          // dW1[dh][j]   (interval row)
+                            accs[(dh + 1) * JE + j] += sb;     // db1[j]
+                            accs[(dh + 2) * JE + j] += sw;     // dw.flatten()[j]
+                        }
+#pragma unroll
+                        for (int ub = 0; ub < DT; ++ub)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int j = jt * 16 + g4 + r, u = ub * 16 + l15;
+                                accs[u * JE + j] += dW[ee][d][ub][r];  // dW1[u][j]
+                            }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < NPAR; i += blockDim.x) {
+        const int e = (i % JE) / dh;  // every entry belongs to exactly one mark e -> one blockIdx.y
+        if (e >= e0 && e < e0 + ECH) p.wpart[(long)blockIdx.x * NPAR + i] = accs[i];
+    }
+}
+
+__global__ void intensity_grad_reduce_kernel(const float* wpart, int nblk, int dh, int E, const float* dsc_part,
+                                             long njobs, float* dW1, float* db1, float* dw, float* dscaling) {
+    const int JE = dh * E, NPAR = (dh + 3) * JE;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NPAR) {
+        float a = 0.f;
+        for (int k = 0; k < nblk; ++k) a += wpart[(long)k * NPAR + i];
+        if (i < (dh + 1) * JE) dW1[i] = a;
+        else if (i < (dh + 2) * JE) db1[i - (dh + 1) * JE] = a;
+        else dw[i - (dh + 2) * JE] = a;
+    } else if (i < NPAR + E) {
+        const int e = i - NPAR;
+        float a = 0.f;
+        for (long k = 0; k < njobs; ++k) a += dsc_part[k * EP + e];
+        dscaling[e] = a;
+    }
+}
+
+struct WsLayout { size_t hin, dz, dsc, wpart, total; };
+template <typename T>
+WsLayout ws_layout(int B, int T_, int C, int H, int E) {
+    const int dh = C / H;
+    const size_t R = (size_t)B * H * T_;
+    WsLayout w;
+    size_t o = 0;
+    w.hin = o; o += (R * dh * sizeof(T) + 255) & ~(size_t)255;
+    w.dz = o; o += (R * EP * sizeof(float) + 255) & ~(size_t)255;
+    w.dsc = o; o += ((size_t)B * H * EP * sizeof(float) + 255) & ~(size_t)255;
+    w.wpart = o; o += ((size_t)KB_BLOCKS * (dh + 3) * dh * E * sizeof(float) + 255) & ~(size_t)255;
+    w.total = o;
+    return w;
+}
+
+template <typename T, int DT, int NT>
+int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscaling, hipStream_t st) {
+    constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
+    const PackDims pd = pack_dims<T>(dh, p.E);
+    const WsLayout wl = ws_layout<T>(p.B, p.T, p.C, p.H, p.E);
+    p.hin_ws = ws + wl.hin; p.dz_ws = reinterpret_cast<float*>(ws + wl.dz);
+    p.dsc_part = reinterpret_cast<float*>(ws + wl.dsc); p.wpart = reinterpret_cast<float*>(ws + wl.wpart);
+    const size_t wave_bytes = (3 * (size_t)Tp * dh + 2 * (size_t)dh * LDT + (size_t)Tp * EP + (size_t)EP * LDT) * sizeof(T);
+    int waves = 4;
+    while (waves > 1 && pd.bytes + waves * wave_bytes > 150 * 1024) waves >>= 1;
+    const size_t smem = pd.bytes + waves * wave_bytes;
+    EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: needs %zu B of LDS", smem);
+    p.waves = waves;
+    auto kern = bimau_bwd_kernel<T, DT, NT>;
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const long jobs = (long)p.B * p.H;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
+    EDGL_LAUNCH_CHECK();
+
+    WgP wp{p.hin_ws, p.dz_ws, p.spans, p.pack, (long)p.B * p.H * p.T, p.B, p.T, p.E, p.wpart};
+    const int NPAR = (dh + 3) * dh * p.E;
+    const size_t smem_b = pd.bytes + (size_t)NPAR * sizeof(float);
+    EDGL_REQUIRE(smem_b <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: weight-grad kernel needs %zu B of LDS", smem_b);
+    auto kb = intensity_wgrad_kernel<T, DT>;
+    hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
+    hipLaunchKernelGGL(kb, dim3(KB_BLOCKS, DT * DT), dim3(256), smem_b, st, wp);
+    EDGL_LAUNCH_CHECK();
+    const int total = NPAR + p.E;
+    hipLaunchKernelGGL(intensity_grad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.wpart, KB_BLOCKS, dh,
+                       p.E, p.dsc_part, jobs, dW1, db1, dw, dscaling);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+template <typename T, int DT>
+int dispatch_nt(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dsc, hipStream_t st) {
+    switch ((p.T + 15) / 16) {
+        case 1: return launch_bwd<T, DT, 1>(p, ws, dW1, db1, dw, dsc, st);
+        case 2: return launch_bwd<T, DT, 2>(p, ws, dW1, db1, dw, dsc, st);
+        case 3: return launch_bwd<T, DT, 3>(p, ws, dW1, db1, dw, dsc, st);
+        case 4: return launch_bwd<T, DT, 4>(p, ws, dW1, db1, dw, dsc, st);
+        case 5: return launch_bwd<T, DT, 5>(p, ws, dW1, db1, dw, dsc, st);
+        case 6: return launch_bwd<T, DT, 6>(p, ws, dW1, db1, dw, dsc, st);
+        case 7: return launch_bwd<T, DT, 7>(p, ws, dW1, db1, dw, dsc, st);
+        case 8: return launch_bwd<T, DT, 8>(p, ws, dW1, db1, dw, dsc, st);
+    }
+    edgl_set_error("edgl_bimau_bwd: T=%d not supported (T <= 128)", p.T);
+    return EDGL_ERR_SHAPE;
+}
+
+}  // namespace
+
+extern "C" long edgl_bimau_bwd_workspace(int B, int T, int C, int H, int E, int dtype) {
+    if (H <= 0 || C % H) return -1;
+    return (long)(dtype == EDGL_BF16 ? ws_layout<bf16>(B, T, C, H, E).total : ws_layout<float>(B, T, C, H, E).total);
+}
+
+extern "C" int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks,
+                              const void* pack, const void* d_out, const float* d_lam_ext, int B, int T, int C, int H,
+                              int E, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* d_qkvt,
+                              float* dW1, float* db1, float* dw, float* dscaling, void* workspace, int dtype,
+                              void* stream) {
+    EDGL_REQUIRE(qkvt && ids && spans && marks && pack && d_out && d_qkvt && dW1 && db1 && dw && dscaling && workspace,
+                 EDGL_ERR_NULL, "edgl_bimau_bwd: null pointer");
+    EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
+                 "edgl_bimau_bwd: bad shape B=%d T=%d C=%d H=%d E=%d", B, T, C, H, E);
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_bimau_bwd: dropout without rng_state");
+    BwdP p{};
+    p.qkvt = qkvt; p.ids = ids; p.spans = spans; p.marks = marks; p.pack = (const char*)pack; p.d_out = d_out;
+    p.d_lam_ext = d_lam_ext; p.B = B; p.T = T; p.C = C; p.H = H; p.E = E; p.rate = drop_rate; p.rng = rng_state;
+    p.stream_id = stream_id; p.d_qkvt = d_qkvt;
+    hipStream_t st = (hipStream_t)stream;
+    const int dh = C / H;
+    char* ws = (char*)workspace;
+    if (dtype == EDGL_F32) {
+        if (dh == 16) return dispatch_nt<float, 1>(p, ws, dW1, db1, dw, dscaling, st);
+        if (dh == 32) return dispatch_nt<float, 2>(p, ws, dW1, db1, dw, dscaling, st);
+    } else if (dtype == EDGL_BF16) {
+        if (dh == 16) return dispatch_nt<bf16, 1>(p, ws, dW1, db1, dw, dscaling, st);
+        if (dh == 32) return dispatch_nt<bf16, 2>(p, ws, dW1, db1, dw, dscaling, st);
+    } else {
+        edgl_set_error("edgl_bimau_bwd: bad dtype %d", dtype);
+        return EDGL_ERR_DTYPE;
+    }
+    edgl_set_error("edgl_bimau_bwd: head dim %d not supported (16 or 32)", dh);
+    return EDGL_ERR_SHAPE;
+}

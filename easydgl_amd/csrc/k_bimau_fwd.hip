@@ -1,0 +1,249 @@
+// K3 forward: fused BiMAU attention — BiMAU.__call__ (temporal.py:404-452) with MAU.intensity
+// (temporal.py:281-315) inlined.  See bimau_common.h for the register-layout scheme.
+#include "bimau_common.h"
+
+namespace {
+using namespace bimau;
+
+struct FwdP {
+    const void* qkvt; const void* resid; int ld_res;
+    const int64_t* ids; const float* spans; const uint8_t* marks;
+    const char* pack;
+    int B, T, C, H, E;
+    float rate; const uint64_t* rng; uint32_t stream_id;
+    void* out; float* lam;
+    int waves;
+};
+
+// DT = dh/16, NT = ceil(T/16)
+template <typename T, int DT, int NT>
+__global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
+    constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PackDims pd = pack_dims<T>(dh, p.E);
+    // ---- workgroup-shared intensity weights -------------------------------------------------
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.pack);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < (int)(pd.bytes / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    const T* W1T = reinterpret_cast<const T*>(smem);
+    const float* fW = reinterpret_cast<const float*>(smem + pd.off_f32);
+    const float* w1s = fW; const float* b1s = fW + pd.JE; const float* wvs = fW + 2 * pd.JE;
+    const float* scs = fW + 3 * pd.JE; const float* iscs = scs + EP;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long job = (long)blockIdx.x * p.waves + wave;
+    if (job >= (long)p.B * p.H) return;
+    const int b = (int)(job / p.H), head = (int)(job % p.H);
+    const long bp = (long)head * p.B + b;  // head-major index b' (temporal.py:413-416)
+
+    // ---- wave-private LDS: K row-major, T_^T, V^T, marks row-major -----------------------------
+    constexpr size_t WAVE_ELEMS = (size_t)Tp * dh + 2 * (size_t)dh * LDT + (size_t)Tp * EP;
+    T* Ks = reinterpret_cast<T*>(smem + pd.bytes) + (size_t)wave * WAVE_ELEMS;
+    T* TTs = Ks + Tp * dh;
+    T* VTs = TTs + dh * LDT;
+    T* Ms = VTs + dh * LDT;
+    const T* qkvt = reinterpret_cast<const T*>(p.qkvt) + (long)b * p.T * 4 * p.C;
+    const int ldq = 4 * p.C;
+    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, nullptr, LDT, lane);           // K  (split order Q,K,V,T: temporal.py:410)
+    stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, nullptr, TTs, LDT, lane);      // T_
+    stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, nullptr, VTs, LDT, lane);      // V
+    stage_marks<T>(p.marks + (long)b * p.T * p.E, p.E, p.T, Tp, Ms, nullptr, LDT, lane);
+    const KeyBits kb = load_keybits<NT>(p.ids + (long)b * p.T, p.T, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const float cscale = rsqrtf((float)dh);
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+
+    for (int qt = 0; qt < NT; ++qt) {
+        const int q = qt * 16 + l15;
+        const bool qok = q < p.T;
+        // ---- S^T[k][q] = sum_u K[k][u] Q[q][u] ------------------------------------------------
+        Frag4<T> qf[DT];
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub)
+            qf[ub] = qok ? frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4) : frag_zero<T>();
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ub = 0; ub < DT; ++ub)
+                a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
+            s[kt] = a;
+        }
+        masked_softmax<NT>(s, kb, cscale);  // s := P^T
+        // ---- H^T[u][q] = sum_k T_[k][u] P[q][k] -----------------------------------------------
+        Frag4<T> pf[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) pf[kt] = frag_from_acc<T>(s[kt]);
+        Frag4<T> hf[DT];
+#pragma unroll
+        for (int ut = 0; ut < DT; ++ut) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+                a = mma16(frag_ld<T>(TTs + (ut * 16 + l15) * LDT + kt * 16 + g4), pf[kt], a);
+            hf[ut] = frag_from_acc<T>(a);
+        }
+        // ---- intensity MLP (temporal.py:287-306): Zpre^T[j][q], channel j = e*dh + u' ------------
+        const float span = qok ? p.spans[(long)b * p.T + q] : 0.f;
+        float zp[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) zp[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (e < p.E) {
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const int jt = e * DT + d;
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ub = 0; ub < DT; ++ub)
+                        a = mma16(frag_ld<T>(W1T + (jt * 16 + l15) * pd.LDW + ub * 16 + g4), hf[ub], a);
+                    const float4 ws = *reinterpret_cast<const float4*>(w1s + jt * 16 + g4);
+                    const float4 bs = *reinterpret_cast<const float4*>(b1s + jt * 16 + g4);
+                    const float4 wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
+                    zp[e] += sigmoid_f(a[0] + span * ws.x + bs.x) * wv.x + sigmoid_f(a[1] + span * ws.y + bs.y) * wv.y +
+                             sigmoid_f(a[2] + span * ws.z + bs.z) * wv.z + sigmoid_f(a[3] + span * ws.w + bs.w) * wv.w;
+                }
+            }
+        }
+        float z4[4];
+        reduce_scatter16(zp, z4, lane);  // lane group g now owns e = 4g + i
+        Frag4<T> lf;
+        float lam4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sc = scs[g4 + i], isc = iscs[g4 + i];
+            lam4[i] = sc * __logf(1.0f + __expf(z4[i] * isc));  // temporal.py:305-306
+            lf.v[i] = from_f32<T>(lam4[i]);
+        }
+        if (qok) {
+            float* dst = p.lam + (bp * p.T + q) * p.E + g4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (g4 + i < p.E) dst[i] = lam4[i];
+        }
+        // ---- G^T[k][q] = sum_e marks[k][e] lam[q][e]; diag := 1; A' = dropout(G * P) ------------
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kt * 16 + g4 + r;
+                const float gv = (k == q) ? 1.0f : gacc[r];  // temporal.py:438-439
+                float a = gv * s[kt][r];                      // temporal.py:441
+                a = drop_apply(dk, (uint64_t)((bp * p.T + q) * p.T + k), a);  // temporal.py:442
+                s[kt][r] = a;
+            }
+            pf[kt] = frag_from_acc<T>(s[kt]);
+        }
+        // ---- O^T[v][q] = sum_k V[k][v] A'[q][k]; + residual (temporal.py:443-447) ----------------
+#pragma unroll
+        for (int vt = 0; vt < DT; ++vt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+                a = mma16(frag_ld<T>(VTs + (vt * 16 + l15) * LDT + kt * 16 + g4), pf[kt], a);
+            if (qok) {
+                const int col = head * dh + vt * 16 + g4;
+                const Frag4<T> rf = frag_ld<T>(reinterpret_cast<const T*>(p.resid) + ((long)b * p.T + q) * p.ld_res + col);
+                Frag4<T> of;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) of.v[r] = from_f32<T>(a[r] + to_f32(rf.v[r]));
+                T* dst = reinterpret_cast<T*>(p.out) + ((long)b * p.T + q) * p.C + col;
+                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&of);
+                else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&of);
+            }
+        }
+    }
+}
+
+template <typename T, int DT, int NT>
+int launch_fwd(FwdP p, hipStream_t st) {
+    constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
+    const PackDims pd = pack_dims<T>(dh, p.E);
+    const size_t wave_bytes = ((size_t)Tp * dh + 2 * (size_t)dh * LDT + (size_t)Tp * EP) * sizeof(T);
+    int waves = 4;
+    while (waves > 1 && pd.bytes + waves * wave_bytes > 64 * 1024) waves >>= 1;
+    const size_t smem = pd.bytes + waves * wave_bytes;
+    EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_fwd: needs %zu B of LDS (dh=%d E=%d T=%d)", smem, dh,
+                 p.E, p.T);
+    p.waves = waves;
+    auto kern = bimau_fwd_kernel<T, DT, NT>;
+    if (smem > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const long jobs = (long)p.B * p.H;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+template <typename T, int DT>
+int dispatch_nt(FwdP p, hipStream_t st) {
+    const int nt = (p.T + 15) / 16;
+    switch (nt) {
+        case 1: return launch_fwd<T, DT, 1>(p, st);
+        case 2: return launch_fwd<T, DT, 2>(p, st);
+        case 3: return launch_fwd<T, DT, 3>(p, st);
+        case 4: return launch_fwd<T, DT, 4>(p, st);
+        case 5: return launch_fwd<T, DT, 5>(p, st);
+        case 6: return launch_fwd<T, DT, 6>(p, st);
+        case 7: return launch_fwd<T, DT, 7>(p, st);
+        case 8: return launch_fwd<T, DT, 8>(p, st);
+    }
+    edgl_set_error("edgl_bimau_fwd: T=%d not supported (T <= 128)", p.T);
+    return EDGL_ERR_SHAPE;
+}
+
+template <typename T>
+int dispatch_dt(FwdP p, hipStream_t st) {
+    const int dh = p.C / p.H;
+    if (dh == 16) return dispatch_nt<T, 1>(p, st);
+    if (dh == 32) return dispatch_nt<T, 2>(p, st);
+    edgl_set_error("edgl_bimau_fwd: head dim %d not supported (16 or 32)", dh);
+    return EDGL_ERR_SHAPE;
+}
+
+}  // namespace
+
+extern "C" long edgl_bimau_pack_bytes(int C, int H, int E, int dtype) {
+    const int dh = C / (H > 0 ? H : 1);
+    return (long)(dtype == EDGL_BF16 ? bimau::pack_dims<bf16>(dh, E).bytes : bimau::pack_dims<float>(dh, E).bytes);
+}
+
+extern "C" int edgl_bimau_pack(const float* W1, const float* b1, const float* w, const float* scaling, int C, int H,
+                               int E, void* pack, int dtype, void* stream) {
+    EDGL_REQUIRE(W1 && b1 && w && scaling && pack, EDGL_ERR_NULL, "edgl_bimau_pack: null pointer");
+    EDGL_REQUIRE(H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE, "edgl_bimau_pack: bad C=%d H=%d E=%d", C, H, E);
+    const int dh = C / H;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((bimau::pack_kernel<float>), dim3(16), dim3(256), 0, st, W1, b1, w, scaling, dh, E, (char*)pack);
+    else if (dtype == EDGL_BF16) hipLaunchKernelGGL((bimau::pack_kernel<bf16>), dim3(16), dim3(256), 0, st, W1, b1, w, scaling, dh, E, (char*)pack);
+    else { edgl_set_error("edgl_bimau_pack: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
+                              const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
+                              float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* out,
+                              float* lam_out, int dtype, void* stream) {
+    EDGL_REQUIRE(qkvt && resid && ids && spans && marks && pack && out && lam_out, EDGL_ERR_NULL,
+                 "edgl_bimau_fwd: null pointer");
+    EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
+                 "edgl_bimau_fwd: bad shape B=%d T=%d C=%d H=%d E=%d", B, T, C, H, E);
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_bimau_fwd: dropout without rng_state");
+    EDGL_REQUIRE(ld_res % 4 == 0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: ld_res must be a multiple of 4");
+    FwdP p{qkvt, resid, ld_res, ids, spans, marks, (const char*)pack, B, T, C, H, E, drop_rate, rng_state, stream_id,
+           out, lam_out, 4};
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_F32) return dispatch_dt<float>(p, st);
+    if (dtype == EDGL_BF16) return dispatch_dt<bf16>(p, st);
+    edgl_set_error("edgl_bimau_fwd: bad dtype %d", dtype);
+    return EDGL_ERR_DTYPE;
+}

@@ -1,0 +1,229 @@
+// K2/K4: MFMA tile GEMM for the dense layers of the hot path (tf.layers.dense in temporal.py:409,
+// EasyDGL.py:113,120,125,138) and their backward products.
+//   C[M,N] = epilogue( sum_k A(m,k) B(k,n) )
+// 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 4x4 MFMA 16x16 tiles),
+// operands staged through LDS k-contiguous ([row][k], 16-byte padded rows) so every fragment is one
+// ds_read_b128; operands whose contraction index is the slow dimension in HBM are transposed in
+// registers (VECxVEC blocks) on the way in, so HBM reads stay coalesced.
+// float -> v_mfma_f32_16x16x4_f32 (exact f32), bf16 -> v_mfma_f32_16x16x32_bf16, f32 accumulate.
+#include "gemm_tile.h"
+
+namespace {
+using namespace tile;
+
+struct GemmP {
+    const void* A; const void* B; void* C;
+    int M, N, K, lda, ldb, ldc;
+    const float* bias; void* aux;
+    int flags;
+    int kper;          // K range per split (multiple of BK)
+    float* partial;    // split-K partials [splits][M][N] or nullptr
+    int vec_ok;        // operands 16-byte aligned with ld % VEC == 0
+};
+
+template <typename T>
+__device__ __forceinline__ void epilogue_store4(const GemmP& p, float v[4], int m, int n) {
+    // 4 consecutive n for one m
+    if (m >= p.M) return;
+    const bool full = (n + 3 < p.N);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (!full && n + r >= p.N) continue;
+        float x = v[r];
+        if (p.flags & EDGL_EPI_BIAS) x += p.bias[n + r];
+        const long idx = (long)m * p.ldc + n + r;
+        if (p.flags & EDGL_EPI_SAVE_PRE) reinterpret_cast<T*>(p.aux)[idx] = from_f32<T>(x);
+        if (p.flags & EDGL_EPI_GELU) x = gelu_f(x);
+        if (p.flags & EDGL_EPI_MUL_DGELU) x *= dgelu_f(to_f32(reinterpret_cast<const T*>(p.aux)[idx]));
+        if (p.flags & EDGL_EPI_OUT_F32) {
+            float* c = reinterpret_cast<float*>(p.C);
+            c[idx] = (p.flags & EDGL_EPI_ACCUM) ? c[idx] + x : x;
+        } else {
+            reinterpret_cast<T*>(p.C)[idx] = from_f32<T>(x);
+        }
+    }
+}
+
+template <typename T, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+    constexpr int VEC = ElemTraits<T>::VEC, KB = ElemTraits<T>::KB, BK = 2 * KB, LDK = BK + VEC;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* As = reinterpret_cast<T*>(smem_raw);
+    T* Bs = As + BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.kper;
+    const int kend = min(p.K, kbeg + p.kper);
+    const T* A = reinterpret_cast<const T*>(p.A);
+    const T* Bp = reinterpret_cast<const T*>(p.B);
+    const bool vok = p.vec_ok != 0;
+
+    f32x4 acc[4][4];  // acc[j][i]: rows <-> n (j), cols <-> m (i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Stager<T, A_KC> sa;
+    Stager<T, B_KC> sb;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        sa.load(A, p.lda, m0, p.M, kbeg, kend, vok);
+        sb.load(Bp, p.ldb, n0, p.N, kbeg, kend, vok);
+        sa.store(As);
+        sb.store(Bs);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            sa.load(A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, vok);
+            sb.load(Bp, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, vok);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            Vec16<T> af[4], bf[4];
+            const int koff = kb * KB + (lane >> 4) * VEC;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = ld16<T>(As + (wm * 64 + i * 16 + (lane & 15)) * LDK + koff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = ld16<T>(Bs + (wn * 64 + j * 16 + (lane & 15)) * LDK + koff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = mma_kblock(bf[j], af[i], acc[j][i]);
+        }
+        __syncthreads();
+        if (more) {
+            sa.store(As);
+            sb.store(Bs);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds, for tile (j,i): n = n0+wn*64+j*16+(lane>>4)*4 + r, m = m0+wm*64+i*16+(lane&15)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+            if (p.partial) {
+                if (m < p.M) {
+                    float* dst = p.partial + ((long)blockIdx.z * p.M + m) * p.N + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < p.N) dst[r] = v[r];
+                }
+            } else {
+                epilogue_store4<T>(p, v, m, n);
+            }
+        }
+}
+
+template <typename T>
+__global__ void splitk_reduce_kernel(GemmP p, int splits) {
+    const long total4 = (long)p.M * ((p.N + 3) / 4);
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(q / ((p.N + 3) / 4)), n = (int)(q % ((p.N + 3) / 4)) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < splits; ++s) {
+            const float* src = p.partial + ((long)s * p.M + m) * p.N + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) v[r] += src[r];
+        }
+        epilogue_store4<T>(p, v, m, n);
+    }
+}
+
+template <typename T>
+int launch_gemm(GemmP p, int a_kc, int b_kc, int splitk, hipStream_t st) {
+    constexpr int VEC = ElemTraits<T>::VEC, BK = 2 * ElemTraits<T>::KB, LDK = BK + VEC;
+    const size_t smem = (size_t)(BM + BN) * LDK * sizeof(T);
+    if (splitk < 1) splitk = 1;
+    int kper = ((p.K + splitk - 1) / splitk + BK - 1) / BK * BK;
+    if (kper < BK) kper = BK;
+    splitk = (p.K + kper - 1) / kper;
+    if (splitk < 1) splitk = 1;
+    p.kper = kper;
+    if (splitk == 1) p.partial = nullptr;
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, splitk);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(NT), smem, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(NT), smem, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(NT), smem, st, p);
+    else hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(NT), smem, st, p);
+    EDGL_LAUNCH_CHECK();
+    if (splitk > 1) {
+        const long total4 = (long)p.M * ((p.N + 3) / 4);
+        int blocks = (int)std::min<long>((total4 + 255) / 256, 4096);
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(blocks), dim3(256), 0, st, p, splitk);
+        EDGL_LAUNCH_CHECK();
+    }
+    return EDGL_OK;
+}
+
+// ---- column sums (bias gradients) -------------------------------------------------------------
+template <typename T>
+__global__ void colsum_partial_kernel(const T* X, int M, int N, int ld, float* part, int rows_per_block) {
+    // block (bx, by): columns [bx*256 + tid], rows [by*rows_per_block, ...)
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += to_f32(X[(long)r * ld + n]);
+    part[(long)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_final_kernel(const float* part, int nparts, int N, float* out, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < nparts; ++i) s += part[(long)i * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+}  // namespace
+
+extern "C" int edgl_gemm(const void* A, const void* Bm, void* Cm, int M, int N, int K, int lda, int ldb,
+                         int ldc, int a_kc, int b_kc, const float* bias, void* aux, int epi_flags, int splitk,
+                         float* workspace, int dtype, void* stream) {
+    EDGL_REQUIRE(A && Bm && Cm, EDGL_ERR_NULL, "edgl_gemm: null operand");
+    EDGL_REQUIRE(M > 0 && N > 0 && K > 0, EDGL_ERR_SHAPE, "edgl_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    EDGL_REQUIRE(!(epi_flags & EDGL_EPI_BIAS) || bias, EDGL_ERR_NULL, "edgl_gemm: bias flag without bias");
+    EDGL_REQUIRE(!(epi_flags & (EDGL_EPI_SAVE_PRE | EDGL_EPI_MUL_DGELU)) || aux, EDGL_ERR_NULL,
+                 "edgl_gemm: aux flag without aux");
+    EDGL_REQUIRE(!(epi_flags & EDGL_EPI_ACCUM) || (epi_flags & EDGL_EPI_OUT_F32), EDGL_ERR_DTYPE,
+                 "edgl_gemm: ACCUM needs OUT_F32");
+    EDGL_REQUIRE(splitk <= 1 || workspace, EDGL_ERR_WORKSPACE, "edgl_gemm: split-K needs a workspace");
+    GemmP p;
+    p.A = A; p.B = Bm; p.C = Cm; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = bias; p.aux = aux; p.flags = epi_flags; p.kper = K; p.partial = workspace;
+    const int vec = (dtype == EDGL_BF16) ? 8 : 4;
+    p.vec_ok = (lda % vec == 0) && (ldb % vec == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)Bm & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_F32) return launch_gemm<float>(p, a_kc, b_kc, splitk, st);
+    if (dtype == EDGL_BF16) return launch_gemm<bf16>(p, a_kc, b_kc, splitk, st);
+    edgl_set_error("edgl_gemm: bad dtype %d", dtype);
+    return EDGL_ERR_DTYPE;
+}
+
+extern "C" int edgl_colsum(const void* X, int M, int N, int ld, float* out, int accumulate, float* workspace,
+                           int x_f32, int dtype, void* stream) {
+    EDGL_REQUIRE(X && out && workspace, EDGL_ERR_NULL, "edgl_colsum: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    int nparts = std::min(256, std::max(1, M / 64));
+    int rpb = (M + nparts - 1) / nparts;
+    nparts = (M + rpb - 1) / rpb;
+    dim3 grid((N + 255) / 256, nparts);
+    if (x_f32 || dtype == EDGL_F32)
+        hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)X, M, N, ld, workspace, rpb);
+    else
+        hipLaunchKernelGGL((colsum_partial_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)X, M, N, ld, workspace, rpb);
+    EDGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, nparts, N, out, accumulate);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}

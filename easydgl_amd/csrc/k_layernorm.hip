@@ -1,0 +1,259 @@
+// K4-LN: y = LayerNorm_joint(dropout(x) + resid) and its backward.
+// The reference's layernorm (Base.py:12-67, begin_norm_axis=1) takes ONE mean/variance per sample
+// over all T*C elements (tf.nn.moments over axes [1,2], population variance, eps 1e-12), with
+// gamma/beta over the last axis.  One workgroup per sample; each thread owns a fixed 16-byte column
+// vector and strides over rows, so per-channel dgamma/dbeta partials stay in registers.
+// Two-pass moments (mean, then centred second moment) as tf.nn.moments does.
+#include "edgl_common.h"
+
+namespace {
+
+constexpr int LN_THREADS = 512;
+
+struct LnP {
+    const void* x; const void* resid; int ld_res;
+    const float* gamma; const float* beta;
+    int B, T, C;
+    float rate; const uint64_t* rng; uint32_t stream_id;
+    const int64_t* gpos; int Mg;
+    void* y; float* stats;
+    // backward
+    const void* dy; void* dsum; void* dx_drop; float* part;
+};
+
+template <typename T>
+__device__ __forceinline__ void load_sum(const LnP& p, const DropKey& dk, int b, int t, int c0, float s[ElemTraits<T>::VEC]) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const long row = (long)b * p.T + t;
+    Vec16<T> xv = ld16<T>(reinterpret_cast<const T*>(p.x) + row * p.C + c0);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = drop_apply(dk, (uint64_t)(row * p.C + c0 + j), to_f32(xv.v[j]));
+    if (p.resid) {
+        Vec16<T> rv = ld16<T>(reinterpret_cast<const T*>(p.resid) + row * p.ld_res + c0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s[j] += to_f32(rv.v[j]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(LnP p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    __shared__ float red[LN_THREADS / 64];
+    const int b = blockIdx.x, cpv = p.C / VEC;
+    const int rows_par = LN_THREADS / cpv, active = rows_par * cpv;
+    const int tid = threadIdx.x;
+    const bool on = tid < active;
+    const int cv = tid % cpv, tr = tid / cpv, c0 = cv * VEC;
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const float n = (float)p.T * (float)p.C;
+
+    float acc = 0.f;
+    if (on)
+        for (int t = tr; t < p.T; t += rows_par) {
+            float s[VEC];
+            load_sum<T>(p, dk, b, t, c0, s);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc += s[j];
+        }
+    const float mean = block_sum(acc, red) / n;
+    acc = 0.f;
+    if (on)
+        for (int t = tr; t < p.T; t += rows_par) {
+            float s[VEC];
+            load_sum<T>(p, dk, b, t, c0, s);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { const float d = s[j] - mean; acc += d * d; }
+        }
+    const float var = block_sum(acc, red) / n;
+    const float rstd = rsqrtf(var + 1e-12f);
+    if (tid == 0) { p.stats[2 * b] = mean; p.stats[2 * b + 1] = rstd; }
+    if (!on) return;
+    float g[VEC], be[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { g[j] = p.gamma[c0 + j]; be[j] = p.beta[c0 + j]; }
+    T* y = reinterpret_cast<T*>(p.y);
+    if (p.gpos) {
+        for (int jrow = tr; jrow < p.Mg; jrow += rows_par) {
+            const int t = (int)p.gpos[(long)b * p.Mg + jrow];
+            float s[VEC];
+            load_sum<T>(p, dk, b, t, c0, s);
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o.v[j] = from_f32<T>((s[j] - mean) * rstd * g[j] + be[j]);
+            st16<T>(y + ((long)b * p.Mg + jrow) * p.C + c0, o);
+        }
+    } else {
+        for (int t = tr; t < p.T; t += rows_par) {
+            float s[VEC];
+            load_sum<T>(p, dk, b, t, c0, s);
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o.v[j] = from_f32<T>((s[j] - mean) * rstd * g[j] + be[j]);
+            st16<T>(y + ((long)b * p.T + t) * p.C + c0, o);
+        }
+    }
+}
+
+// dy row for position t of sample b (zero vector if the row was not gathered)
+template <typename T>
+__device__ __forceinline__ bool load_dy(const LnP& p, const int* rowmap, int b, int t, int c0, float d[ElemTraits<T>::VEC]) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    long row;
+    if (p.gpos) {
+        const int j = rowmap[t];
+        if (j < 0) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) d[q] = 0.f;
+            return false;
+        }
+        row = (long)b * p.Mg + j;
+    } else {
+        row = (long)b * p.T + t;
+    }
+    Vec16<T> v = ld16<T>(reinterpret_cast<const T*>(p.dy) + row * p.C + c0);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) d[q] = to_f32(v.v[q]);
+    return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);            // [8]
+    float* cred = red + 8;                                      // [rows_par][2][C] channel partials
+    const int b = blockIdx.x, cpv = p.C / VEC;
+    const int rows_par = LN_THREADS / cpv, active = rows_par * cpv;
+    int* rowmap = reinterpret_cast<int*>(cred + (size_t)rows_par * 2 * p.C);  // [T]
+    const int tid = threadIdx.x;
+    const bool on = tid < active;
+    const int cv = tid % cpv, tr = tid / cpv, c0 = cv * VEC;
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const float n = (float)p.T * (float)p.C;
+    const float mean = p.stats[2 * b], rstd = p.stats[2 * b + 1];
+
+    if (p.gpos) {
+        for (int t = tid; t < p.T; t += LN_THREADS) rowmap[t] = -1;
+        __syncthreads();
+        for (int j = tid; j < p.Mg; j += LN_THREADS) rowmap[(int)p.gpos[(long)b * p.Mg + j]] = j;
+        __syncthreads();
+    }
+    float g[VEC];
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) g[j] = p.gamma[c0 + j];
+    }
+    float s1 = 0.f, s2 = 0.f, dga[VEC], dbe[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { dga[j] = 0.f; dbe[j] = 0.f; }
+    if (on)
+        for (int t = tr; t < p.T; t += rows_par) {
+            float d[VEC];
+            if (!load_dy<T>(p, rowmap, b, t, c0, d)) continue;
+            float s[VEC];
+            load_sum<T>(p, dk, b, t, c0, s);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (s[j] - mean) * rstd, gg = d[j] * g[j];
+                s1 += gg; s2 += gg * xh; dga[j] += d[j] * xh; dbe[j] += d[j];
+            }
+        }
+    const float m1 = block_sum(s1, red) / n;
+    const float m2 = block_sum(s2, red) / n;
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            cred[((size_t)tr * 2 + 0) * p.C + c0 + j] = dga[j];
+            cred[((size_t)tr * 2 + 1) * p.C + c0 + j] = dbe[j];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * p.C; i += LN_THREADS) {
+        float a = 0.f;
+        for (int r = 0; r < rows_par; ++r) a += cred[(size_t)r * 2 * p.C + i];
+        p.part[(long)b * 2 * p.C + i] = a;
+    }
+    if (!on) return;
+    T* dsum = reinterpret_cast<T*>(p.dsum);
+    T* dxd = reinterpret_cast<T*>(p.dx_drop);
+    for (int t = tr; t < p.T; t += rows_par) {
+        float d[VEC], s[VEC];
+        load_dy<T>(p, rowmap, b, t, c0, d);
+        load_sum<T>(p, dk, b, t, c0, s);
+        const long row = (long)b * p.T + t;
+        Vec16<T> o, od;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (s[j] - mean) * rstd;
+            const float v = rstd * (d[j] * g[j] - m1 - xh * m2);
+            o.v[j] = from_f32<T>(v);
+            od.v[j] = from_f32<T>(drop_apply(dk, (uint64_t)(row * p.C + c0 + j), v));
+        }
+        if (dsum) st16<T>(dsum + row * p.C + c0, o);
+        if (dxd) st16<T>(dxd + row * p.C + c0, od);
+    }
+}
+
+__global__ void ln_param_reduce_kernel(const float* part, int B, int C, float* dgamma, float* dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * C) return;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += part[(long)b * 2 * C + i];
+    if (i < C) dgamma[i] = a; else dbeta[i - C] = a;
+}
+
+int check_ln_shape(int B, int T, int C, int dtype, const char* who) {
+    const int vec = dtype == EDGL_BF16 ? 8 : 4;
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
+    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % vec == 0 && C / vec <= LN_THREADS, EDGL_ERR_SHAPE,
+                 "%s: unsupported shape B=%d T=%d C=%d (C must be a multiple of %d, <= %d)", who, B, T, C, vec,
+                 vec * LN_THREADS);
+    return EDGL_OK;
+}
+
+}  // namespace
+
+extern "C" int edgl_add_layernorm_fwd(const void* x, const void* resid, int ld_res, const float* gamma,
+                                      const float* beta, int B, int T, int C, float drop_rate,
+                                      const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                                      int Mg, void* y, float* stats, int dtype, void* stream) {
+    EDGL_REQUIRE(x && gamma && beta && y && stats, EDGL_ERR_NULL, "edgl_add_layernorm_fwd: null pointer");
+    int rc = check_ln_shape(B, T, C, dtype, "edgl_add_layernorm_fwd");
+    if (rc) return rc;
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_add_layernorm_fwd: dropout without rng_state");
+    LnP p{};
+    p.x = x; p.resid = resid; p.ld_res = ld_res; p.gamma = gamma; p.beta = beta; p.B = B; p.T = T; p.C = C;
+    p.rate = drop_rate; p.rng = rng_state; p.stream_id = stream_id; p.gpos = gather_pos; p.Mg = Mg; p.y = y;
+    p.stats = stats;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(B), dim3(LN_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((ln_fwd_kernel<bf16>), dim3(B), dim3(LN_THREADS), 0, st, p);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_res, const float* gamma,
+                                      const float* stats, const void* dy, int B, int T, int C, float drop_rate,
+                                      const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                                      int Mg, void* dsum, void* dx_drop, float* dgamma, float* dbeta,
+                                      float* workspace, int dtype, void* stream) {
+    EDGL_REQUIRE(x && gamma && stats && dy && dgamma && dbeta && workspace, EDGL_ERR_NULL,
+                 "edgl_add_layernorm_bwd: null pointer");
+    int rc = check_ln_shape(B, T, C, dtype, "edgl_add_layernorm_bwd");
+    if (rc) return rc;
+    LnP p{};
+    p.x = x; p.resid = resid; p.ld_res = ld_res; p.gamma = gamma; p.B = B; p.T = T; p.C = C;
+    p.rate = drop_rate; p.rng = rng_state; p.stream_id = stream_id; p.gpos = gather_pos; p.Mg = Mg;
+    p.stats = const_cast<float*>(stats); p.dy = dy; p.dsum = dsum; p.dx_drop = dx_drop; p.part = workspace;
+    const int vec = dtype == EDGL_BF16 ? 8 : 4;
+    const int rows_par = LN_THREADS / (C / vec);
+    const size_t smem = (8 + (size_t)rows_par * 2 * C) * sizeof(float) + (size_t)T * sizeof(int);
+    EDGL_REQUIRE(smem <= 150 * 1024, EDGL_ERR_SHAPE, "edgl_add_layernorm_bwd: LDS need %zu too large", smem);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(B), dim3(LN_THREADS), smem, st, p);
+    else hipLaunchKernelGGL((ln_bwd_kernel<bf16>), dim3(B), dim3(LN_THREADS), smem, st, p);
+    EDGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, workspace, B, C, dgamma, dbeta);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}

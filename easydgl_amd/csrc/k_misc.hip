@@ -1,0 +1,296 @@
+// Small kernels around the hot path: error plumbing, dropout-RNG step, the TPP likelihood
+// regulariser (K8: temporal.py:317-333 + EasyDGL.py:157-175), TF-form Adam over the flat
+// parameter arena (Base.py:142-144), the l2 term (coding.py:34-40) and f32 -> dtype casts.
+#include <cstdarg>
+#include <cstdio>
+
+#include "edgl_common.h"
+
+namespace {
+thread_local char g_err[512] = "";
+constexpr int RED_BLOCKS = 64;
+}  // namespace
+
+extern "C" void edgl_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* edgl_last_error(void) { return g_err; }
+extern "C" int edgl_version(void) { return 100; }
+
+namespace {
+
+__global__ void rng_advance_kernel(uint64_t* st) { st[1] += 1ull; }
+
+// ---------------------------------------------------------------------------------------------
+// K8 TPP regulariser
+// ---------------------------------------------------------------------------------------------
+struct TppP {
+    const float* lam; const int64_t* mpos; const int64_t* labels; const float* ts; const uint8_t* mtab;
+    int B, T, H, E, M; float coef;
+};
+
+__device__ __forceinline__ float raw_span(const float* ts_row, int pos, int T) {
+    // EasyDGL.py:161-162 on RAW seconds: span[t] = clip(ts[t]-ts[t-1], 0, 100), span[0] := span[1]
+    if (T < 2) return 0.f;
+    const int t1 = pos == 0 ? 1 : pos;
+    return fminf(fmaxf(ts_row[t1] - ts_row[t1 - 1], 0.f), 100.f);
+}
+
+// per-row terms; returns (event_ll, non_event, n_marks); optionally the pieces needed by the backward
+__device__ __forceinline__ void tpp_row(const TppP& p, long j, float& ev_ll, float& non_ev, float& nmk, float* ev_out,
+                                        float* span_out, float* g_out, int* b_out, int* pos_out, int64_t* lab_out) {
+    const long bp = j / p.M;
+    const int m = (int)(j % p.M), b = (int)(bp % p.B);
+    const int pos = (int)p.mpos[(long)b * p.M + m];
+    const int64_t lab = p.labels[(long)b * p.M + m];
+    const uint8_t* nm = p.mtab + lab * p.E;
+    const float* lm = p.lam + (bp * p.T + pos) * p.E;
+    float cnt = 0.f, ev = 0.f, ent = 0.f;
+    for (int e = 0; e < p.E; ++e) { const float f = (float)nm[e]; cnt += f; ev += lm[e] * f; ent += lm[e]; }
+    const float g = cnt > 0.f ? 1.f : 0.f;  // sign(sum nm), temporal.py:321
+    ev *= g; ent *= g;
+    const float sp = raw_span(p.ts + (long)b * p.T, pos, p.T);
+    ev_ll = __logf(ev == 0.f ? 1.f : ev);  // :324
+    non_ev = ent * sp * 0.5f;              // :327-328
+    nmk = cnt;
+    if (ev_out) { *ev_out = ev; *span_out = sp; *g_out = g; *b_out = b; *pos_out = pos; *lab_out = lab; }
+}
+
+__global__ __launch_bounds__(256) void tpp_partial_kernel(TppP p, float* part) {
+    __shared__ float red[8];
+    const long n = (long)p.H * p.B * p.M;
+    float a = 0.f, bsum = 0.f, c = 0.f;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) {
+        float e, ne, k;
+        tpp_row(p, j, e, ne, k, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        a += e; bsum += ne; c += k;
+    }
+    a = block_sum(a, red); bsum = block_sum(bsum, red); c = block_sum(c, red);
+    if (threadIdx.x == 0) { part[blockIdx.x * 3] = a; part[blockIdx.x * 3 + 1] = bsum; part[blockIdx.x * 3 + 2] = c; }
+}
+__global__ void tpp_final_kernel(const float* part, int nblk, float coef, float* sums, float* reg_out, int accumulate) {
+    if (threadIdx.x != 0) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int i = 0; i < nblk; ++i) { a += part[i * 3]; b += part[i * 3 + 1]; c += part[i * 3 + 2]; }
+    sums[0] = a; sums[1] = b; sums[2] = c;
+    const float reg = coef * (-(a - b) / c);  // temporal.py:331-332, EasyDGL.py:175
+    reg_out[0] = accumulate ? reg_out[0] + reg : reg;
+}
+__global__ __launch_bounds__(256) void tpp_bwd_kernel(TppP p, const float* sums, const float* gscale, float* d_lam) {
+    const long n = (long)p.H * p.B * p.M;
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float k = -gs * p.coef / sums[2];
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) {
+        float e, ne, cnt, ev, sp, g; int b, pos; int64_t lab;
+        tpp_row(p, j, e, ne, cnt, &ev, &sp, &g, &b, &pos, &lab);
+        const long bp = j / p.M;
+        const uint8_t* nm = p.mtab + lab * p.E;
+        float* dst = d_lam + (bp * p.T + pos) * p.E;
+        for (int q = 0; q < p.E; ++q) {
+            const float dev = (ev != 0.f) ? (float)nm[q] / ev : 0.f;
+            dst[q] = k * g * (dev - sp * 0.5f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (TF form) over the flat arena
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_prepare_kernel(uint64_t* st, float lr, float b1, float b2) {
+    st[0] += 1ull;
+    const double t = (double)st[0];
+    const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    reinterpret_cast<float*>(st + 1)[0] = lr_t;
+}
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, long n, float b1,
+                                                   float b2, float eps, const uint64_t* st, float l2,
+                                                   const int64_t* seg, int nseg, bf16* shadow) {
+    const float lr_t = reinterpret_cast<const float*>(st + 1)[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float wi = w[i];
+        if (l2 != 0.f)
+            for (int s = 0; s < nseg; ++s)
+                if (i >= seg[2 * s] && i < seg[2 * s + 1]) { gi += l2 * wi; break; }
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float wn = wi - lr_t * mi / (sqrtf(vi) + eps);
+        m[i] = mi; v[i] = vi; w[i] = wn;
+        if (SHADOW) shadow[i] = (bf16)wn;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* w, const int64_t* seg, int nseg, float* part) {
+    __shared__ float red[8];
+    float a = 0.f;
+    for (int s = 0; s < nseg; ++s) {
+        const long lo = seg[2 * s], hi = seg[2 * s + 1];
+        for (long i = lo + (long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long)gridDim.x * blockDim.x) a += w[i] * w[i];
+    }
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+__global__ void sumsq_final_kernel(const float* part, int nblk, float scale, float* out, int accumulate) {
+    if (threadIdx.x != 0) return;
+    float a = 0.f;
+    for (int i = 0; i < nblk; ++i) a += part[i];
+    out[0] = accumulate ? out[0] + scale * a : scale * a;
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* src, T* dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = from_f32<T>(src[i]);
+}
+template <typename T>
+__global__ void cast_back_kernel(const T* src, float* dst, long n, int accumulate) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = accumulate ? dst[i] + to_f32(src[i]) : to_f32(src[i]);
+}
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
+}
+// dst[r, :ncols] += src[r, :ncols] with independent row strides (residual gradients into the first C channels)
+template <typename T>
+__global__ void add_cols_kernel(T* dst, int ld_dst, const T* src, int ld_src, long rows, int ncols) {
+    const long total = rows * ncols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / ncols; const int c = (int)(i % ncols);
+        dst[r * ld_dst + c] = from_f32<T>(to_f32(dst[r * ld_dst + c]) + to_f32(src[r * ld_src + c]));
+    }
+}
+
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* dy, const T* pre, T* dz, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dz[i] = from_f32<T>(to_f32(dy[i]) * dgelu_f(to_f32(pre[i])));
+}
+
+inline int grid_for(long n) { return (int)std::min<long>((n + 255) / 256, 4096); }
+
+}  // namespace
+
+extern "C" int edgl_rng_advance(uint64_t* rng_state, void* stream) {
+    EDGL_REQUIRE(rng_state, EDGL_ERR_NULL, "edgl_rng_advance: null state");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_tpp_workspace(void) { return RED_BLOCKS * 3 + 4; }
+
+extern "C" int edgl_tpp_fwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                            const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
+                            float* reg_out, int accumulate, void* stream) {
+    EDGL_REQUIRE(lam && masked_pos && labels && ts_raw && mark_table && sums && reg_out, EDGL_ERR_NULL,
+                 "edgl_tpp_fwd: null pointer");
+    TppP p{lam, masked_pos, labels, ts_raw, mark_table, B, T, H, E, M, coef};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tpp_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, p, sums + 4);
+    EDGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tpp_final_kernel, dim3(1), dim3(64), 0, st, sums + 4, RED_BLOCKS, coef, sums, reg_out, accumulate);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                            const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef,
+                            const float* sums, const float* gscale, float* d_lam, void* stream) {
+    EDGL_REQUIRE(lam && masked_pos && labels && ts_raw && mark_table && sums && d_lam, EDGL_ERR_NULL,
+                 "edgl_tpp_bwd: null pointer");
+    TppP p{lam, masked_pos, labels, ts_raw, mark_table, B, T, H, E, M, coef};
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(d_lam, 0, (size_t)H * B * T * E * sizeof(float), st) != hipSuccess) {
+        edgl_set_error("edgl_tpp_bwd: memset failed");
+        return EDGL_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(tpp_bwd_kernel, dim3(grid_for((long)H * B * M)), dim3(256), 0, st, p, sums, gscale, d_lam);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr, float beta1,
+                              float beta2, float eps, uint64_t* step_state, float l2, const int64_t* seg, int nseg,
+                              void* shadow, void* stream) {
+    EDGL_REQUIRE(param && grad && m && v && step_state, EDGL_ERR_NULL, "edgl_adam_step: null pointer");
+    EDGL_REQUIRE(l2 == 0.f || nseg == 0 || seg, EDGL_ERR_NULL, "edgl_adam_step: l2 without segments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, step_state, lr, beta1, beta2);
+    EDGL_LAUNCH_CHECK();
+    if (shadow)
+        hipLaunchKernelGGL((adam_kernel<true>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
+                           step_state, l2, seg, nseg, (bf16*)shadow);
+    else
+        hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
+                           step_state, l2, seg, nseg, (bf16*)nullptr);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_l2_loss(const float* param, const int64_t* seg, int nseg, float l2, float* out, int accumulate,
+                            float* workspace, void* stream) {
+    EDGL_REQUIRE(param && seg && out && workspace, EDGL_ERR_NULL, "edgl_l2_loss: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, param, seg, nseg, workspace);
+    EDGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, workspace, RED_BLOCKS, 0.5f * l2, out, accumulate);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_cast(const float* src, void* dst, long n, int dtype, void* stream) {
+    EDGL_REQUIRE(src && dst, EDGL_ERR_NULL, "edgl_cast: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_BF16) hipLaunchKernelGGL((cast_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, src, (bf16*)dst, n);
+    else if (dtype == EDGL_F32) hipLaunchKernelGGL((cast_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, src, (float*)dst, n);
+    else { edgl_set_error("edgl_cast: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_cast_back(const void* src, float* dst, long n, int accumulate, int dtype, void* stream) {
+    EDGL_REQUIRE(src && dst, EDGL_ERR_NULL, "edgl_cast_back: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_BF16) hipLaunchKernelGGL((cast_back_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16*)src, dst, n, accumulate);
+    else if (dtype == EDGL_F32) hipLaunchKernelGGL((cast_back_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)src, dst, n, accumulate);
+    else { edgl_set_error("edgl_cast_back: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_add(const void* a, const void* b, void* out, long n, int dtype, void* stream) {
+    EDGL_REQUIRE(a && b && out, EDGL_ERR_NULL, "edgl_add: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_BF16) hipLaunchKernelGGL((add_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)out, n);
+    else if (dtype == EDGL_F32) hipLaunchKernelGGL((add_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n);
+    else { edgl_set_error("edgl_add: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_add_cols(void* dst, int ld_dst, const void* src, int ld_src, long rows, int ncols, int dtype,
+                             void* stream) {
+    EDGL_REQUIRE(dst && src, EDGL_ERR_NULL, "edgl_add_cols: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long n = rows * ncols;
+    if (dtype == EDGL_BF16) hipLaunchKernelGGL((add_cols_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (bf16*)dst, ld_dst, (const bf16*)src, ld_src, rows, ncols);
+    else if (dtype == EDGL_F32) hipLaunchKernelGGL((add_cols_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (float*)dst, ld_dst, (const float*)src, ld_src, rows, ncols);
+    else { edgl_set_error("edgl_add_cols: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_gelu_bwd(const void* dy, const void* pre, void* dz, long n, int dtype, void* stream) {
+    EDGL_REQUIRE(dy && pre && dz, EDGL_ERR_NULL, "edgl_gelu_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_BF16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)pre, (bf16*)dz, n);
+    else if (dtype == EDGL_F32) hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)dy, (const float*)pre, (float*)dz, n);
+    else { edgl_set_error("edgl_gelu_bwd: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}

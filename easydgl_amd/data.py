@@ -1,0 +1,58 @@
+"""Batch construction for the EasyDGL path — the semantics of the reference's MAUPostProcessor
+(src/dataloader.py:159-206) without its per-example Python py_func (dataloader.py:34-36,183):
+masked positions for a whole batch are drawn at once on the device."""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+
+def mask_last(tokens: torch.Tensor, timestamps: torch.Tensor, mask_id: int) -> Tuple[Dict[str, torch.Tensor], torch.Tensor]:
+    """MAUPostProcessor.mask_last (dataloader.py:166-179): position T-1 := MASK, labels = the full sequence."""
+    masked = tokens.clone()
+    masked[:, -1] = mask_id
+    return {"seqs_i": masked, "seqs_t": timestamps}, tokens
+
+
+def draw_masked_positions(batch: int, seqslen: int, masklen: int, generator: torch.Generator = None,
+                          device="cpu") -> torch.Tensor:
+    """`masklen` DISTINCT positions in [1, seqslen) per row (np.random.choice(seqslen-1, masklen,
+    replace=False) + 1, dataloader.py:34-36 with ignore_head = 1), vectorised: top-k of i.i.d. uniforms."""
+    if masklen > seqslen - 1:
+        raise ValueError("masklen must be <= seqslen - 1")
+    u = torch.rand((batch, seqslen - 1), generator=generator, device=device)
+    return (u.topk(masklen, dim=1).indices + 1).to(torch.int64)
+
+
+def mask_random(tokens: torch.Tensor, timestamps: torch.Tensor, mask_id: int, masked_positions: torch.Tensor):
+    """MAUPostProcessor.mask_random (dataloader.py:181-201)."""
+    labels = tokens.gather(1, masked_positions)
+    masked = tokens.scatter(1, masked_positions, mask_id)
+    return {"seqs_i": masked, "seqs_t": timestamps, "masked_positions": masked_positions}, labels
+
+
+def synthetic_batch(num_items: int, seqslen: int, batch: int, seed: int = 9876, min_len: int = 5):
+    """SURVEY.md §8d synthetic sequences: row length ~ U{min_len..T}, left zero padding, Zipf(1.1) item ids
+    clipped to [1, num_items-1], float32 timestamps 9.5e8 + cumsum(Exp(mean 3 days)).  T = seqslen + 1."""
+    rng = np.random.default_rng(seed)
+    T = seqslen + 1
+    ids = np.zeros((batch, T), dtype=np.int64)
+    ts = np.zeros((batch, T), dtype=np.float32)
+    lens = rng.integers(min(min_len, T), T + 1, size=batch)
+    for b in range(batch):
+        n = int(lens[b])
+        ids[b, T - n:] = np.clip(rng.zipf(1.1, size=n), 1, num_items - 1)
+        ts[b, T - n:] = (9.5e8 + np.cumsum(rng.exponential(3 * 86400.0, size=n))).astype(np.float32)
+    return ids, ts
+
+
+def synthetic_mark_table(num_items: int, num_events: int, multi_hot: bool = False) -> np.ndarray:
+    """[num_items, E] 0/1 table: mark (i mod E) for item i >= 1 (+ a second mark when multi_hot); row 0 = pad."""
+    tab = np.zeros((num_items, num_events), dtype=np.uint8)
+    idx = np.arange(1, num_items)
+    tab[idx, idx % num_events] = 1
+    if multi_hot:
+        tab[idx, (idx * 7 + 3) % num_events] = 1
+    return tab

@@ -1,0 +1,38 @@
+"""Mirror of src/module/temporal.py:BiMAU (the Bi-level Modulating Attention Unit used by EasyDGL)."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import ops
+from .coding import glorot_uniform_
+
+
+class BiMAU(nn.Module):
+    """temporal.py:393-452 + MAU.intensity (temporal.py:281-315).
+
+    Parameters (TF names in brackets): ``dense_kernel`` [Cin, 4C] ~N(0, 0.02) and ``dense_bias`` [4C]
+    (TMAU/dense); ``st_kernel`` [dh+1, dh*E] glorot and ``st_bias`` [dh*E]
+    (TMAU/sequential_temporal_combined/dense); ``weight`` [E, dh] glorot; ``scaling`` [E] zeros.
+    ``__call__(queries, keys, masks, intervals, marks, is_training)`` keeps the reference's signature:
+    keys are ignored exactly as in the reference (BiMAU projects Q,K,V,T from ``queries``), ``masks`` is the
+    [B,T] item-id tensor (a key is masked where id == 0)."""
+
+    def __init__(self, in_units, num_units, num_heads, num_events, dropout_rate, gen=None):
+        super().__init__()
+        self.num_units, self.num_heads, self.num_events, self.dropout_rate = num_units, num_heads, num_events, dropout_rate
+        dh = num_units // num_heads
+        self.dense_kernel = nn.Parameter(torch.randn(in_units, 4 * num_units, generator=gen) * 0.02)
+        self.dense_bias = nn.Parameter(torch.zeros(4 * num_units))
+        self.st_kernel = nn.Parameter(glorot_uniform_(torch.empty(dh + 1, dh * num_events), gen))
+        self.st_bias = nn.Parameter(torch.zeros(dh * num_events))
+        self.weight = nn.Parameter(glorot_uniform_(torch.empty(num_events, dh), gen))
+        self.scaling = nn.Parameter(torch.zeros(num_events))
+        self.compute = lambda p: p  # replaced by the owning model (bf16 shadow lookup)
+
+    def forward(self, queries, keys, masks, intervals, marks, is_training, drop: ops.Drop = ops.NO_DROP):
+        C = self.num_units
+        qkvt = ops.LinearFn.apply(queries, self.dense_kernel, self.dense_bias, self.compute(self.dense_kernel), False)
+        resid = queries[:, :, :C]
+        return ops.BiMAUFn.apply(qkvt, resid, self.st_kernel, self.st_bias, self.weight, self.scaling, masks, intervals,
+                                 marks, self.num_heads, drop if is_training else ops.NO_DROP)

@@ -1,0 +1,416 @@
+"""torch.autograd.Function wrappers over the C ABI (include/easydgl_hip.h).
+
+PyTorch is plumbing here: it owns device memory, the stream and the autograd tape; every op body is
+a call into libeasydgl_hip.so.  There is no CPU path — handing a CPU tensor to any op raises."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, check, lib
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.EdglError("easydgl_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise _lib.EdglError("easydgl_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise _lib.EdglError(f"unsupported activation dtype {t.dtype}")
+
+
+@dataclass
+class Drop:
+    """Dropout description handed to a kernel: rate, device RNG state (int64[2]: seed, step), stream id."""
+    rate: float = 0.0
+    state: Optional[torch.Tensor] = None
+    stream_id: int = 0
+
+    @property
+    def active(self) -> bool:
+        return self.rate > 0.0
+
+    def ptr(self):
+        return _ptr(self.state) if self.active else None
+
+
+NO_DROP = Drop()
+
+
+def rng_advance(state: torch.Tensor) -> None:
+    check(lib.edgl_rng_advance(_ptr(state), _stream()), "edgl_rng_advance")
+
+
+# ------------------------------------------------------------------------------------------------
+# plain helpers (no autograd)
+# ------------------------------------------------------------------------------------------------
+def gemm(A, Bm, M, N, K, lda, ldb, a_kc, b_kc, out_dtype, bias=None, aux=None, flags=0, splitk=1, ws=None,
+         out=None, code=None):
+    code = _code(A) if code is None else code
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=out_dtype)
+    if out.dtype == torch.float32:
+        flags |= _lib.EPI_OUT_F32
+    if splitk > 1 and ws is None:
+        ws = torch.empty(splitk * M * N, device=A.device, dtype=torch.float32)
+    check(lib.edgl_gemm(_ptr(A), _ptr(Bm), _ptr(out), M, N, K, lda, ldb, out.stride(0), int(a_kc), int(b_kc),
+                        _ptr(bias), _ptr(aux), flags, splitk, _ptr(ws), code, _stream()), "edgl_gemm")
+    return out
+
+
+def colsum(X, M, N):
+    out = torch.empty(N, device=X.device, dtype=torch.float32)
+    ws = torch.empty(256 * N, device=X.device, dtype=torch.float32)
+    check(lib.edgl_colsum(_ptr(X), M, N, X.stride(0) if X.dim() == 2 else N, _ptr(out), 0, _ptr(ws),
+                          int(X.dtype == torch.float32), _code(X) if X.dtype != torch.float32 else F32, _stream()),
+          "edgl_colsum")
+    return out
+
+
+def cast_to(src_f32: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty(src_f32.shape, device=src_f32.device, dtype=dtype)
+    check(lib.edgl_cast(_ptr(src_f32), _ptr(out), src_f32.numel(), _DT[dtype], _stream()), "edgl_cast")
+    return out
+
+
+def _splitk_for(m_out: int, n_out: int, kc: int) -> int:
+    tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+    return int(max(1, min(kc // 512, max(1, 768 // tiles))))
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 encode
+# ------------------------------------------------------------------------------------------------
+class EncodeFn(torch.autograd.Function):
+    """EasyDGL.py:70-95.  item_c is the compute copy of the item table (the f32 master itself, or its
+    bf16 shadow); gradients flow to the masters."""
+
+    @staticmethod
+    def forward(ctx, item_master, pos_tab, mark_emb, item_c, ids, ts, mark_table, tscale, mask_id, time_scale,
+                drop: Drop, act_dtype):
+        B, T = ids.shape
+        I, C = item_c.shape
+        E = mark_table.shape[1]
+        x0 = torch.empty((B, T, 3 * C), device=ids.device, dtype=act_dtype)
+        spans = torch.empty((B, T), device=ids.device, dtype=torch.float32)
+        marks = torch.empty((B, T, E), device=ids.device, dtype=torch.uint8)
+        check(lib.edgl_encode_fwd(_ptr(ids), _ptr(ts), _ptr(item_c), _ptr(pos_tab), _ptr(mark_emb), _ptr(mark_table),
+                                  _ptr(tscale), B, T, C, E, I, int(mask_id), float(time_scale), float(drop.rate),
+                                  drop.ptr(), drop.stream_id, _ptr(x0), _ptr(spans), _ptr(marks), _DT[act_dtype],
+                                  _stream()), "edgl_encode_fwd")
+        ctx.save_for_backward(ids, marks)
+        ctx.meta = (B, T, C, E, I, drop, item_master.shape, pos_tab.shape, mark_emb.shape)
+        ctx.mark_non_differentiable(spans, marks)
+        return x0, spans, marks
+
+    @staticmethod
+    def backward(ctx, dx0, _ds, _dm):
+        ids, marks = ctx.saved_tensors
+        B, T, C, E, I, drop, ishape, pshape, mshape = ctx.meta
+        dx0 = dx0.contiguous()
+        d_item = torch.zeros(ishape, device=dx0.device, dtype=torch.float32)
+        d_pos = torch.zeros(pshape, device=dx0.device, dtype=torch.float32)
+        d_mark = torch.empty(mshape, device=dx0.device, dtype=torch.float32)
+        ws = torch.empty(lib.edgl_encode_bwd_workspace(B, T, C), device=dx0.device, dtype=torch.float32)
+        check(lib.edgl_encode_bwd(_ptr(ids), _ptr(marks), _ptr(dx0), B, T, C, E, I, float(drop.rate), drop.ptr(),
+                                  drop.stream_id, _ptr(d_item), _ptr(d_pos), _ptr(d_mark), _ptr(ws), _code(dx0),
+                                  _stream()), "edgl_encode_bwd")
+        return (d_item, d_pos, d_mark) + (None,) * 9
+
+
+# ------------------------------------------------------------------------------------------------
+# K2/K4 dense
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """tf.layers.dense: y = act(x @ W + b), W [in, out] (Appendix A).  w_c is W in the activation dtype."""
+
+    @staticmethod
+    def forward(ctx, x, w_master, bias, w_c, gelu: bool):
+        K, N = w_c.shape
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        flags = _lib.EPI_BIAS | (_lib.EPI_GELU | _lib.EPI_SAVE_PRE if gelu else 0)
+        pre = torch.empty((M, N), device=x.device, dtype=x.dtype) if gelu else None
+        y = gemm(x2, w_c, M, N, K, K, N, True, False, x.dtype, bias=bias, aux=pre, flags=flags)
+        ctx.save_for_backward(x2, w_c, pre)
+        ctx.meta = (M, N, K, gelu, x.shape)
+        return y.reshape(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w_c, pre = ctx.saved_tensors
+        M, N, K, gelu, xshape = ctx.meta
+        dz = dy.reshape(M, N).contiguous()
+        if gelu:
+            out = torch.empty_like(dz)
+            check(lib.edgl_gelu_bwd(_ptr(dz), _ptr(pre), _ptr(out), dz.numel(), _code(dz), _stream()), "edgl_gelu_bwd")
+            dz = out
+        # dX[M,K] = dz[M,N] . W^T : B(kk=n, nn=k) = W[k][n] -> stored [K rows][N contiguous] = k-contiguous operand
+        dx = gemm(dz, w_c, M, K, N, N, N, True, True, dz.dtype)
+        # dW[K,N] = X^T . dz : both operands have the contraction (rows) as the slow dimension
+        dw = gemm(x2, dz, K, N, M, K, N, False, False, torch.float32, splitk=_splitk_for(K, N, M))
+        db = colsum(dz, M, N)
+        return dx.reshape(xshape), dw, db, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# K3 BiMAU
+# ------------------------------------------------------------------------------------------------
+class BiMAUFn(torch.autograd.Function):
+    """Fused attention of BiMAU.__call__ (temporal.py:413-447) given qkvt = dense(x)."""
+
+    @staticmethod
+    def forward(ctx, qkvt, resid, W1, b1, w, scaling, ids, spans, marks, H, drop: Drop):
+        B, T, C4 = qkvt.shape
+        C = C4 // 4
+        E = w.shape[0]
+        code = _code(qkvt)
+        pack = torch.empty(lib.edgl_bimau_pack_bytes(C, H, E, code), device=qkvt.device, dtype=torch.uint8)
+        check(lib.edgl_bimau_pack(_ptr(W1), _ptr(b1), _ptr(w), _ptr(scaling), C, H, E, _ptr(pack), code, _stream()),
+              "edgl_bimau_pack")
+        out = torch.empty((B, T, C), device=qkvt.device, dtype=qkvt.dtype)
+        lam = torch.empty((H * B, T, E), device=qkvt.device, dtype=torch.float32)
+        if resid.stride(-1) != 1 or resid.stride(0) != T * resid.stride(1):
+            raise _lib.EdglError("BiMAU residual must be a row-strided view of a contiguous [B,T,*] tensor")
+        check(lib.edgl_bimau_fwd(_ptr(qkvt), resid.data_ptr(), resid.stride(1), _ptr(ids), _ptr(spans), _ptr(marks),
+                                 _ptr(pack), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(out),
+                                 _ptr(lam), code, _stream()), "edgl_bimau_fwd")
+        ctx.save_for_backward(qkvt, ids, spans, marks, pack)
+        ctx.meta = (B, T, C, H, E, drop, code, W1.shape, b1.shape, w.shape, scaling.shape)
+        return out, lam
+
+    @staticmethod
+    def backward(ctx, d_out, d_lam):
+        qkvt, ids, spans, marks, pack = ctx.saved_tensors
+        B, T, C, H, E, drop, code, s1, s2, s3, s4 = ctx.meta
+        d_out = d_out.contiguous()
+        dev = d_out.device
+        d_qkvt = torch.empty_like(qkvt)
+        dW1 = torch.empty(s1, device=dev, dtype=torch.float32)
+        db1 = torch.empty(s2, device=dev, dtype=torch.float32)
+        dw = torch.empty(s3, device=dev, dtype=torch.float32)
+        dsc = torch.empty(s4, device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), device=dev, dtype=torch.uint8)
+        dl = d_lam.contiguous() if d_lam is not None else None
+        check(lib.edgl_bimau_bwd(_ptr(qkvt), _ptr(ids), _ptr(spans), _ptr(marks), _ptr(pack), _ptr(d_out), _ptr(dl),
+                                 B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(d_qkvt), _ptr(dW1),
+                                 _ptr(db1), _ptr(dw), _ptr(dsc), _ptr(ws), code, _stream()), "edgl_bimau_bwd")
+        return d_qkvt, d_out, dW1, db1, dw, dsc, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# K4-LN
+# ------------------------------------------------------------------------------------------------
+class AddLayerNormFn(torch.autograd.Function):
+    """y = layernorm_joint(dropout(x) + resid) (Base.py:12-67; EasyDGL.py:114-116,126-128,139), optionally
+    emitting only the rows gather_pos [B,Mg] (EasyDGL.py:142-146)."""
+
+    @staticmethod
+    def forward(ctx, x, resid, gamma, beta, drop: Drop, gather_pos):
+        B, T, C = x.shape
+        code = _code(x)
+        stats = torch.empty((B, 2), device=x.device, dtype=torch.float32)
+        Mg = 0 if gather_pos is None else gather_pos.shape[1]
+        y = torch.empty((B * Mg, C) if gather_pos is not None else (B, T, C), device=x.device, dtype=x.dtype)
+        rptr, ld = (None, 0)
+        if resid is not None:
+            if resid.stride(-1) != 1 or resid.stride(0) != T * resid.stride(1):
+                raise _lib.EdglError("layernorm residual must be a row-strided view of a contiguous [B,T,*] tensor")
+            rptr, ld = resid.data_ptr(), resid.stride(1)
+        check(lib.edgl_add_layernorm_fwd(_ptr(x), rptr, ld, _ptr(gamma), _ptr(beta), B, T, C, float(drop.rate),
+                                         drop.ptr(), drop.stream_id, _ptr(gather_pos), Mg, _ptr(y), _ptr(stats), code,
+                                         _stream()), "edgl_add_layernorm_fwd")
+        ctx.save_for_backward(x, resid, gamma, stats, gather_pos)
+        ctx.meta = (B, T, C, drop, code, Mg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, resid, gamma, stats, gather_pos = ctx.saved_tensors
+        B, T, C, drop, code, Mg = ctx.meta
+        dy = dy.contiguous()
+        dsum = torch.empty_like(x)
+        dxd = torch.empty_like(x) if drop.active else None
+        dg = torch.empty(C, device=x.device, dtype=torch.float32)
+        db = torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(B * 2 * C, device=x.device, dtype=torch.float32)
+        rptr, ld = (None, 0) if resid is None else (resid.data_ptr(), resid.stride(1))
+        check(lib.edgl_add_layernorm_bwd(_ptr(x), rptr, ld, _ptr(gamma), _ptr(stats), _ptr(dy), B, T, C,
+                                         float(drop.rate), drop.ptr(), drop.stream_id, _ptr(gather_pos), Mg,
+                                         _ptr(dsum), _ptr(dxd), _ptr(dg), _ptr(db), _ptr(ws), code, _stream()),
+              "edgl_add_layernorm_bwd")
+        dx = dxd if drop.active else dsum
+        return dx, (dsum if resid is not None else None), dg, db, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# K5 scoring + CE
+# ------------------------------------------------------------------------------------------------
+def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False):
+    R, C = rows.shape
+    I = table_c.shape[0]
+    dev = rows.device
+    lse = torch.empty(R, device=dev, dtype=torch.float32)
+    lab_logit = torch.zeros(R, device=dev, dtype=torch.float32)
+    logits = torch.empty((R, i1 - i0), device=dev, dtype=torch.float32) if want_logits else None
+    ws = torch.empty(2 * R * lib.edgl_score_chunks(i1 - i0), device=dev, dtype=torch.float32)
+    check(lib.edgl_score_lse_fwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), R, C, I, i0, i1, _ptr(lse),
+                                 _ptr(lab_logit), _ptr(logits), _ptr(ws), _code(rows), _stream()), "edgl_score_lse_fwd")
+    return lse, lab_logit, logits
+
+
+class ScoreCEFn(torch.autograd.Function):
+    """EasyDGL.py:149-155,177-185 without the [R, I] logits tensor."""
+
+    @staticmethod
+    def forward(ctx, rows, table_master, out_bias, table_c, labels):
+        R, C = rows.shape
+        I = table_c.shape[0]
+        lse, lab_logit, _ = score_lse(rows, table_c, out_bias, labels, 0, I)
+        loss = torch.empty(1, device=rows.device, dtype=torch.float32)
+        coef = torch.empty(R, device=rows.device, dtype=torch.float32)
+        check(lib.edgl_ce_loss_fwd(_ptr(lse), _ptr(lab_logit), _ptr(labels), R, _ptr(loss), _ptr(coef), _stream()),
+              "edgl_ce_loss_fwd")
+        ctx.save_for_backward(rows, table_c, out_bias, labels, lse, coef)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, table_c, out_bias, labels, lse, coef = ctx.saved_tensors
+        R, C = rows.shape
+        I = table_c.shape[0]
+        dev = rows.device
+        g = g.reshape(1).to(torch.float32).contiguous()
+        d_rows = torch.empty_like(rows)
+        d_table = torch.empty((I, C), device=dev, dtype=torch.float32)
+        d_bias = torch.empty(I - 1, device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.edgl_score_bwd_workspace(R, C, I), device=dev, dtype=torch.float32)
+        check(lib.edgl_score_ce_bwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), _ptr(lse), _ptr(coef),
+                                    _ptr(g), R, C, I, 0, I, _ptr(d_rows), _ptr(d_table), _ptr(d_bias), _ptr(ws),
+                                    _code(rows), _stream()), "edgl_score_ce_bwd")
+        return d_rows, d_table, d_bias, None, None
+
+
+class ScoreLogitsFn(torch.autograd.Function):
+    """Materialised logits [R, I] (EasyDGL.py:149-151) for API parity with the reference's __call__."""
+
+    @staticmethod
+    def forward(ctx, rows, table_master, out_bias, table_c):
+        I = table_c.shape[0]
+        _, _, logits = score_lse(rows, table_c, out_bias, None, 0, I, want_logits=True)
+        ctx.save_for_backward(rows, table_c)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        rows, table_c = ctx.saved_tensors
+        R, C = rows.shape
+        I = table_c.shape[0]
+        dl = dl.contiguous()
+        dl[:, 0] = 0  # column 0 is the constant -1000 (Base.py:110) over a constant zero row
+        dlc = dl if rows.dtype == torch.float32 else cast_to(dl, rows.dtype)
+        tab = table_c.clone()
+        tab[0] = 0  # coding.py:56-57
+        d_rows = gemm(dlc, tab, R, C, I, I, C, True, False, rows.dtype)
+        d_table = gemm(dlc, rows, I, C, R, I, C, False, False, torch.float32, splitk=_splitk_for(I, C, R))
+        d_table[0] = 0
+        d_bias = dl.sum(0)[1:]
+        return d_rows, d_table, d_bias, None
+
+
+# ------------------------------------------------------------------------------------------------
+# K8 TPP regulariser, l2
+# ------------------------------------------------------------------------------------------------
+class TppFn(torch.autograd.Function):
+    """ct_reg/h * MAU.biased_likelihood on the gathered intensities (EasyDGL.py:157-175)."""
+
+    @staticmethod
+    def forward(ctx, lam, masked_pos, labels, ts_raw, mark_table, H, coef):
+        HB, T, E = lam.shape
+        B, M = masked_pos.shape
+        sums = torch.empty(lib.edgl_tpp_workspace(), device=lam.device, dtype=torch.float32)
+        reg = torch.empty(1, device=lam.device, dtype=torch.float32)
+        check(lib.edgl_tpp_fwd(_ptr(lam), _ptr(masked_pos), _ptr(labels), _ptr(ts_raw), _ptr(mark_table), B, T, H, E, M,
+                               float(coef), _ptr(sums), _ptr(reg), 0, _stream()), "edgl_tpp_fwd")
+        ctx.save_for_backward(lam, masked_pos, labels, ts_raw, mark_table, sums)
+        ctx.meta = (B, T, H, E, M, coef)
+        return reg.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lam, masked_pos, labels, ts_raw, mark_table, sums = ctx.saved_tensors
+        B, T, H, E, M, coef = ctx.meta
+        g = g.reshape(1).to(torch.float32).contiguous()
+        d_lam = torch.empty_like(lam)
+        check(lib.edgl_tpp_bwd(_ptr(lam), _ptr(masked_pos), _ptr(labels), _ptr(ts_raw), _ptr(mark_table), B, T, H, E, M,
+                               float(coef), _ptr(sums), _ptr(g), _ptr(d_lam), _stream()), "edgl_tpp_bwd")
+        return d_lam, None, None, None, None, None, None
+
+
+class L2Fn(torch.autograd.Function):
+    """l2_reg * sum(w^2)/2 over one raw embedding table (coding.py:34-40)."""
+
+    @staticmethod
+    def forward(ctx, w, l2):
+        seg = torch.tensor([0, w.numel()], device=w.device, dtype=torch.int64)
+        out = torch.empty(1, device=w.device, dtype=torch.float32)
+        ws = torch.empty(64, device=w.device, dtype=torch.float32)
+        check(lib.edgl_l2_loss(_ptr(w), _ptr(seg), 1, float(l2), _ptr(out), 0, _ptr(ws), _stream()), "edgl_l2_loss")
+        ctx.save_for_backward(w)
+        ctx.l2 = l2
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        return w * (g * ctx.l2), None
+
+
+# ------------------------------------------------------------------------------------------------
+# K6/K7 evaluation
+# ------------------------------------------------------------------------------------------------
+def mask_topk(logits: torch.Tensor, i0: int, seen: Optional[torch.Tensor], K: int):
+    R, n = logits.shape
+    val = torch.empty((R, K), device=logits.device, dtype=torch.float32)
+    idx = torch.empty((R, K), device=logits.device, dtype=torch.int32)
+    T = 0 if seen is None else seen.shape[1]
+    check(lib.edgl_mask_topk(_ptr(logits), R, n, i0, _ptr(seen), T, K, _ptr(val), _ptr(idx), _stream()), "edgl_mask_topk")
+    return val, idx
+
+
+def topk_merge(cand_val: torch.Tensor, cand_idx: torch.Tensor):
+    S, R, K = cand_val.shape
+    val = torch.empty((R, K), device=cand_val.device, dtype=torch.float32)
+    idx = torch.empty((R, K), device=cand_val.device, dtype=torch.int32)
+    check(lib.edgl_topk_merge(_ptr(cand_val), _ptr(cand_idx), S, R, K, _ptr(val), _ptr(idx), _stream()), "edgl_topk_merge")
+    return val, idx
+
+
+def rank_metrics(topk_idx: torch.Tensor, label: torch.Tensor, metrics: torch.Tensor) -> None:
+    R, K = topk_idx.shape
+    check(lib.edgl_rank_metrics(_ptr(topk_idx), R, K, _ptr(label), _ptr(metrics), _stream()), "edgl_rank_metrics")
+
+
+def adam_step(param, grad, m, v, lr, state, l2, seg, shadow, beta1=0.9, beta2=0.999, eps=1e-8):
+    check(lib.edgl_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), float(lr), beta1, beta2, eps,
+                             _ptr(state), float(l2), _ptr(seg), 0 if seg is None else seg.numel() // 2, _ptr(shadow),
+                             _stream()), "edgl_adam_step")

@@ -1,0 +1,9 @@
+"""Mirror of src/util.py:ranking — the model factory that is the reference's only plugin API."""
+
+
+def ranking(FLAGS):
+    """util.py:61-96.  Only the models on the accelerated path exist here."""
+    if FLAGS.model == "EasyDGL":
+        from .model import EasyDGL
+        return EasyDGL(FLAGS.num_items, FLAGS)
+    raise NotImplementedError("The ranking model: {0} not implemented".format(FLAGS.model))

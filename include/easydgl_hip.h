@@ -1,0 +1,220 @@
+/*
+ * libeasydgl_hip.so — C ABI of the MI355X (gfx950) kernels for EasyDGL's temporal-point-process
+ * self-modulating-attention hot path.
+ *
+ * The reference (cchao0116/EasyDGL) has NO FFI: its hot path is a TensorFlow-1.x graph.  Each entry
+ * point below therefore replaces a *group of TF ops*; the comment on each cites the reference lines
+ * (paths relative to the reference repo root) whose arithmetic it reproduces.  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all buffers;
+ *    kernels never allocate, never synchronise, and launch on `stream` (a hipStream_t);
+ *  - returns 0 on success, a negative EDGL_ERR_* otherwise (edgl_last_error() gives the text);
+ *  - activations / GEMM operands are `dtype` (EDGL_F32 exact-f32 MFMA path, or EDGL_BF16 with f32
+ *    accumulation); statistics, losses, gradients of parameters and optimizer state are always f32;
+ *  - tensors are dense row-major; B = batch, T = positions (= seqslen+1), C = num_units,
+ *    H = num_heads, dh = C/H, E = num_events, I = item-table rows (= num_items+1), M = masklen;
+ *  - head-major stacking b' = head*B + b for every [H*B, ...] tensor (temporal.py:413-416);
+ *  - dropout masks are a pure function of (rng_state[0]=seed, rng_state[1]=step, stream_id, element
+ *    index); backward kernels regenerate them.  rng_state may be NULL when the rate is 0.
+ */
+#ifndef EASYDGL_HIP_H
+#define EASYDGL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { EDGL_F32 = 0, EDGL_BF16 = 1 } edgl_dtype;
+
+enum {
+    EDGL_OK = 0,
+    EDGL_ERR_SHAPE = -1,       /* unsupported / inconsistent shape */
+    EDGL_ERR_DTYPE = -2,
+    EDGL_ERR_LAUNCH = -3,      /* hipGetLastError() != hipSuccess after a launch */
+    EDGL_ERR_NULL = -4,
+    EDGL_ERR_WORKSPACE = -5
+};
+
+/* GEMM epilogue flags */
+enum {
+    EDGL_EPI_BIAS = 1,        /* + bias[n]                                   */
+    EDGL_EPI_GELU = 2,        /* erf-GELU (EasyDGL.py:19-32)                 */
+    EDGL_EPI_SAVE_PRE = 4,    /* aux[m,n] = pre-activation (dtype)           */
+    EDGL_EPI_MUL_DGELU = 8,   /* *= gelu'(aux[m,n])                          */
+    EDGL_EPI_ACCUM = 16,      /* C += result (f32 C only)                    */
+    EDGL_EPI_OUT_F32 = 32     /* C is f32 regardless of dtype                */
+};
+
+const char* edgl_last_error(void);
+int edgl_version(void);
+
+/* ---- dropout RNG state ----------------------------------------------------------------------- */
+/* rng_state[1] += 1 on the device (one launch per training step, graph-capturable). */
+int edgl_rng_advance(uint64_t* rng_state, void* stream);
+
+/* ---- K1: input encoding — EasyDGL.py:70-95, coding.py:60-64,76-79,137-149 ---------------------
+ * x0[b,t,:]   = [ item_tab[id]*sqrt(C) + sincos(ts/time_scale) | pos_tab[t] | nmarks*mark_emb[1] ]
+ *               followed by hidden dropout (EasyDGL.py:92);
+ * spans[b,t]  = clip(ts'[t]-ts'[t-1],0,100), spans[b,0]=spans[b,1] with ts' = ts/time_scale (:73-74);
+ * marks[b,t,:] = mark_table[id (MASK->0)] (:76-77); item row 0 and mark_emb row 0 act as zeros
+ *               (coding.py:56-57).
+ * item_tab is `dtype` (master f32 or its bf16 shadow); pos_tab / mark_emb are f32; mark_table holds
+ * 0/1 bytes [>= num_items, E]; tscale f32 [C/2] = float32(10000^(2j/C)) (coding.py:134-135, computed on
+ * the host exactly as the reference does). */
+int edgl_encode_fwd(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
+                    const float* mark_emb, const uint8_t* mark_table, const float* tscale, int B, int T, int C,
+                    int E, int I, int64_t mask_id, float time_scale, float drop_rate,
+                    const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans, uint8_t* marks,
+                    int dtype, void* stream);
+
+/* Backward of K1 (SURVEY Appendix C "Embedding side"): d_item[id] += sqrt(C)*dX0[:, :C] for id != 0
+ * (f32 atomics into d_item, which must be pre-initialised by the caller), d_pos[t] and d_mark_emb[1]
+ * are written via per-block partials reduced deterministically (d_mark_emb [E,C]: only row 1 is
+ * non-zero).  workspace: edgl_encode_bwd_workspace(B,T,C) floats. */
+long edgl_encode_bwd_workspace(int B, int T, int C);
+int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const void* dx0, int B, int T, int C, int E,
+                    int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, float* d_item,
+                    float* d_pos, float* d_mark_emb, float* workspace, int dtype, void* stream);
+
+/* ---- K2/K4: dense layers — tf.layers.dense (temporal.py:409, EasyDGL.py:113,120,125,138) ------
+ * C[M,N] = epilogue( sum_k A(m,k) * B(k,n) ).
+ * a_kc != 0: A stored [M, lda] with k contiguous; else stored [K, lda] with m contiguous.
+ * b_kc != 0: B stored [N, ldb] with k contiguous; else stored [K, ldb] with n contiguous.
+ * A, B are `dtype`; C is `dtype` unless EDGL_EPI_OUT_F32.  bias f32[N].  aux is `dtype` [M,ldc].
+ * splitk > 1 needs workspace >= splitk*M*N floats (partials reduced by a second launch). */
+int edgl_gemm(const void* A, const void* Bm, void* Cm, int M, int N, int K, int lda, int ldb, int ldc,
+              int a_kc, int b_kc, const float* bias, void* aux, int epi_flags, int splitk, float* workspace,
+              int dtype, void* stream);
+
+/* out[n] (+)= sum_m X[m, n]  — bias gradients.  X `dtype` (or f32 if x_f32) [M, ld]; out f32[N]. */
+int edgl_colsum(const void* X, int M, int N, int ld, float* out, int accumulate, float* workspace,
+                int x_f32, int dtype, void* stream);
+
+/* ---- K3: fused BiMAU attention — temporal.py:404-452 + MAU.intensity temporal.py:281-315 -------
+ * qkvt [B,T,4C] = dense(x) already computed (K2), split order Q,K,V,T (temporal.py:410).  Per
+ * (b, head): S=QK^T/sqrt(dh), key mask (ids[b,k]==0 -> -2^32+1), softmax, H=P.T_, intensity MLP ->
+ * lam[b',q,:E], G=lam.marks^T with diag:=1, attention dropout, O=(G*P).V;
+ * out[b,q,head*dh+:] = O + resid[b,q,head*dh+:] (:447); resid has row stride ld_res (first C channels
+ * of the block input).  The intensity weights W1 [dh+1, dh*E], b1 [dh*E], w [E,dh], scaling [E] (f32)
+ * are first packed by edgl_bimau_pack into `pack` (edgl_bimau_pack_bytes bytes, reusable by fwd and
+ * bwd until the weights change).  lam_out f32 [H*B,T,E].  Supported: dh in {16,32}, E<=16, T<=128. */
+long edgl_bimau_pack_bytes(int C, int H, int E, int dtype);
+int edgl_bimau_pack(const float* W1, const float* b1, const float* w, const float* scaling, int C, int H, int E,
+                    void* pack, int dtype, void* stream);
+int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
+                   const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E, float drop_rate,
+                   const uint64_t* rng_state, uint32_t stream_id, void* out, float* lam_out, int dtype,
+                   void* stream);
+
+/* Backward.  d_out [B,T,C] `dtype`; d_lam_ext f32 [H*B,T,E] or NULL (gradient
+ * from the TPP regulariser).  Writes d_qkvt [B,T,4C] `dtype` and the f32 weight gradients dW1
+ * [dh+1,dh*E], db1 [dh*E], dw [E,dh], dscaling [E] (overwritten; per-workgroup partials in
+ * `workspace` — edgl_bimau_bwd_workspace BYTES — are reduced in a fixed order).  The residual
+ * gradient (d_out itself) is NOT added here — the caller routes it. */
+long edgl_bimau_bwd_workspace(int B, int T, int C, int H, int E, int dtype);
+int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks,
+                   const void* pack, const void* d_out, const float* d_lam_ext, int B, int T, int C, int H,
+                   int E, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* d_qkvt,
+                   float* dW1, float* db1, float* dw, float* dscaling, void* workspace, int dtype,
+                   void* stream);
+
+/* ---- K4-LN: y = layernorm_joint(dropout(x) + resid) — Base.py:12-67 (moments over (T,C) per
+ * sample, eps 1e-12), EasyDGL.py:114-116,126-128,139.  resid may be NULL (ld_res ignored).
+ * stats f32 [B,2] = (mean, rstd).  If gather_pos != NULL (int64 [B,Mg]) only rows
+ * y_g[b*Mg+j,:] = y[b, gather_pos[b,j], :] are written (EasyDGL.py:142-146 batch_gather). */
+int edgl_add_layernorm_fwd(const void* x, const void* resid, int ld_res, const float* gamma,
+                           const float* beta, int B, int T, int C, float drop_rate,
+                           const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                           int Mg, void* y, float* stats, int dtype, void* stream);
+
+/* Backward: given dy (dense [B,T,C], or gathered [B*Mg,C] when gather_pos != NULL), recomputes
+ * xhat from (x, resid, stats) and writes dx (gradient w.r.t. dropout(x)+resid input sum, i.e. the
+ * caller uses it for the residual; d_x_pre = dx * dropmask is written to dx_drop) and per-sample
+ * partials of dgamma/dbeta into workspace [B,2,C] reduced into dgamma/dbeta (overwritten). */
+int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_res, const float* gamma,
+                           const float* stats, const void* dy, int B, int T, int C, float drop_rate,
+                           const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                           int Mg, void* dsum, void* dx_drop, float* dgamma, float* dbeta,
+                           float* workspace, int dtype, void* stream);
+
+/* ---- K5: tied-embedding scoring + cross-entropy — EasyDGL.py:149-155,177-185, Base.py:106-110 --
+ * rows [R,C] `dtype`; table [I,C] `dtype` (row 0 acts as zeros, column 0 logit == -1000); out_bias
+ * f32 [I-1]; labels int64 [R] (may be NULL for eval).  The item range [i0, i1) lets a rank score its
+ * shard only.  The [R, I] logits are never materialised unless `logits` (f32 [R, i1-i0]) is given.
+ * fwd: online (max, sumexp) per row and item chunk -> row_lse f32 [R] (log-sum-exp over [i0,i1)),
+ * label_logit f32 [R] (written only for rows whose label lies in [i0,i1); pre-zero when sharded).
+ * workspace >= 2*R*edgl_score_chunks(i1-i0) floats.  C: power of two, 32..256 (bf16) / 32..128 (f32). */
+int edgl_score_chunks(int n_items);
+int edgl_score_lse_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
+                       int R, int C, int I, int i0, int i1, float* row_lse, float* label_logit,
+                       float* logits, float* workspace, int dtype, void* stream);
+/* loss = sum_r w_r * (-log(p_y + 1e-5)) / (sum w + 1e-5), w_r = [label != 0]; also writes the
+ * per-row coefficient coef[r] = (w_r/W) * p_y/(p_y+1e-5) used by the backward.  loss_out f32[1]. */
+int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
+                     float* loss_out, float* coef, void* stream);
+/* backward of the CE: dl[r,j] = g * coef[r] * (p[r,j] - [j==label_r]) (g = d loss, device scalar or
+ * NULL for 1), never materialised:  d_rows[R,C] (`dtype`) = dl . table ;  d_table[I,C] (f32,
+ * overwritten for rows [i0,i1), row 0 := 0) = dl^T . rows ;  d_bias[I-1] f32 = colsum(dl)[1:].
+ * workspace >= edgl_score_bwd_workspace(R, C, i1-i0) floats. */
+long edgl_score_bwd_workspace(int R, int C, int n_items);
+int edgl_score_ce_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
+                      const float* row_lse, const float* coef, const float* gscale, int R, int C, int I,
+                      int i0, int i1, void* d_rows, float* d_table, float* d_bias, float* workspace,
+                      int dtype, void* stream);
+
+/* ---- K6: evaluation — Base.py:150-207 ----------------------------------------------------------
+ * logits f32 [R, n] for the item range starting at i0; seen [R,T] int64 item ids to mask with -inf
+ * (Base.py:156-163; NULL = no masking); top-K by (value desc, index asc) (tf.nn.top_k tie rule).
+ * out_val f32 [R,K], out_idx int32 [R,K] (GLOBAL item ids = i0 + local). K <= 128. */
+int edgl_mask_topk(float* logits, int R, int n, int i0, const int64_t* seen, int T, int K, float* out_val,
+                   int32_t* out_idx, void* stream);
+/* ---- K7: merge of per-shard candidates (after an RCCL all-gather): cand_val/idx [S, R, K] ->
+ * global top-K per row by (value desc, global index asc). */
+int edgl_topk_merge(const float* cand_val, const int32_t* cand_idx, int S, int R, int K, float* out_val,
+                    int32_t* out_idx, void* stream);
+/* HR@k / NDCG@k sums for k in {10,50,100} (Base.py:181-201): metrics f32 [6] += per-batch sums in
+ * the order H10,H50,H100,N10,N50,N100; label int64 [R]. */
+int edgl_rank_metrics(const int32_t* topk_idx, int R, int K, const int64_t* label, float* metrics,
+                      void* stream);
+
+/* ---- K8: TPP likelihood regulariser — temporal.py:317-333 + EasyDGL.py:157-175 -----------------
+ * lam f32 [H*B,T,E]; masked_pos int64 [B,M]; labels int64 [B,M]; ts_raw f32 [B,T] (raw seconds);
+ * mark_table uint8 [NI,E].  reg_out f32[1] (+)= coef * biased_mle with coef = ct_reg/H;
+ * sums f32[edgl_tpp_workspace()] scratch (sums[0..2] = event-ll, non-event, #marks are reused by
+ * the backward).  bwd zero-fills and writes d_lam f32 [H*B,T,E] (zero except at masked positions), scaled by
+ * the device scalar gscale (NULL = 1). */
+int edgl_tpp_workspace(void);
+int edgl_tpp_fwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                 const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
+                 float* reg_out, int accumulate, void* stream);
+int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                 const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef,
+                 const float* sums, const float* gscale, float* d_lam, void* stream);
+
+/* ---- optimizer — tf.train.AdamOptimizer (Base.py:142-144) over a flat f32 arena ----------------
+ * step_state: device uint64[2]: [0] = step count (incremented by this call, so the first call is
+ * t = 1), [1] = scratch holding lr_t = lr*sqrt(1-b2^t)/(1-b1^t).  theta -= lr_t * m/(sqrt(v)+eps).
+ * l2 (coding.py:34-40) enters as grad += l2 * w on the element ranges [seg[2s], seg[2s+1]) (device
+ * int64 pairs).  If shadow != NULL the updated weights are also written there as bf16. */
+int edgl_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr, float beta1,
+                   float beta2, float eps, uint64_t* step_state, float l2, const int64_t* seg, int nseg,
+                   void* shadow, void* stream);
+/* l2 part of the loss: out[0] (+)= 0.5*l2*sum(w[seg]^2)  (EasyDGL.py:158); workspace >= 64 floats. */
+int edgl_l2_loss(const float* param, const int64_t* seg, int nseg, float l2, float* out, int accumulate,
+                 float* workspace, void* stream);
+/* element-wise helpers on `dtype` buffers */
+int edgl_cast(const float* src, void* dst, long n, int dtype, void* stream);                 /* dst = (dtype)src      */
+int edgl_cast_back(const void* src, float* dst, long n, int accumulate, int dtype, void* stream); /* dst (+)= (f32)src */
+int edgl_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);      /* out = a + b           */
+int edgl_gelu_bwd(const void* dy, const void* pre, void* dz, long n, int dtype, void* stream); /* dz = dy*gelu'(pre), EasyDGL.py:19-32 */
+int edgl_add_cols(void* dst, int ld_dst, const void* src, int ld_src, long rows, int ncols, int dtype,
+                  void* stream);                                                             /* dst[:, :n] += src[:, :n] */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EASYDGL_HIP_H */

@@ -1,0 +1,114 @@
+"""Whole-model parity: the HIP EasyDGL (through the reference's model interface) vs the fp64 oracle on the
+same seeded inputs and weights.  Stated tolerances: f32 path rtol 1e-4 on logits / loss,
+1e-3 on gradients; bf16 path <= 2e-2 relative on logits (3e-2 used for the loss / 1e-1 for gradients, which
+go through bf16 activations end to end)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import easydgl_oracle as O
+from oracle import torch_ref as R
+from tests._util import assert_close, build_model, make_problem, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(),                                                                          # C=32 h=2 (dh=16) nb=2 E=4 T=11
+    dict(num_units=64, num_heads=2, num_blocks=1, seqslen=30, masklen=6, num_events=7, num_items=300),   # dh=32, T=31
+    dict(num_units=128, num_heads=8, num_blocks=1, seqslen=100, masklen=20, num_events=16, num_items=2000),  # headline shape
+]
+
+
+@pytest.mark.parametrize("mode,ltol,gtol", [("f32", 1e-4, 1e-3), ("bf16", 3e-2, 1e-1)])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_forward_loss_and_gradients(mode, ltol, gtol, case):
+    prob = make_problem(seed=10 + case, batch=4, **CASES[case])
+    cfg = prob["cfg"]
+    m = build_model(prob, mode)
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    # ---- EasyDGL.__call__(features, is_training=True): logits [B*M, I]
+    logits = m(feats, True)
+    want_logits, want_lams = O.forward(cfg, prob["params"], prob["mark_table"], prob["feats"], True)
+    assert logits.shape == want_logits.shape
+    assert_close(logits.detach().cpu().numpy(), want_logits, ltol, "train logits")
+    assert float((logits[:, 0] + 1000).abs().max()) == 0.0
+    for a, b in zip(m._last_lams, want_lams):
+        assert_close(a.detach().cpu().numpy(), b, ltol, "lambda")
+    # ---- the loss EasyDGL.train minimises, and its gradients
+    m.zero_grad_arena()
+    loss = m.train_loss(feats, labels)
+    loss.backward()
+    p64 = R.to_torch_params(prob["params"])
+    ref_loss, _ = R.train_loss(cfg, p64, prob["mark_table"], prob["feats"], prob["labels"])
+    ref_loss.backward()
+    assert_close(loss.item(), ref_loss.item(), ltol, "train loss")
+    worst = {}
+    for name, p in m.tf_variable_map().items():
+        worst[name] = rel_err(p.grad.cpu().numpy(), p64[name].grad.numpy())
+    bad = {k: v for k, v in worst.items() if v > gtol}
+    assert not bad, f"gradient mismatch (rel to max |ref|): {bad}"
+    # ---- eval logits (last position)
+    elog = m(to_dev(prob["efeats"]), False)
+    want_e, _ = O.forward(cfg, prob["params"], prob["mark_table"], prob["efeats"], False)
+    assert_close(elog.cpu().numpy(), want_e, ltol, "eval logits")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_eval_metrics_and_topk(mode):
+    prob = make_problem(seed=3, batch=16, num_items=600, seqslen=20, num_units=32, num_heads=2, num_blocks=1)
+    cfg = prob["cfg"]
+    m = build_model(prob, mode)
+    ef, el = to_dev(prob["efeats"]), torch.as_tensor(prob["elabels"]).cuda()
+    val, idx = m.eval_topk(ef, mask_seen=True)
+    want_metrics, want_idx = O.evaluate(cfg, prob["params"], prob["mark_table"], prob["efeats"], prob["elabels"])
+    got = idx.cpu().numpy()
+    if mode == "f32":
+        # ranking on logits == ranking on softmax probs away from fp ties
+        agree = (got == want_idx).mean()
+        assert agree > 0.98, agree
+    else:
+        overlap = np.mean([len(set(got[r, :50]) & set(want_idx[r, :50])) / 50 for r in range(got.shape[0])])
+        assert overlap > 0.9, overlap
+    seen = prob["efeats"]["seqs_i"]
+    for r in range(got.shape[0]):
+        assert not (set(got[r]) & set(seen[r]))          # Base.py:156-163
+    m.reset_metrics()
+    m.eval_step(ef, el)
+    mets = m.metrics()
+    per = O.ranking_metrics(got, prob["elabels"][:, -1])
+    for k in mets:
+        assert abs(mets[k] - per[k].mean()) < 1e-5
+    if mode == "f32":
+        for k in mets:
+            assert abs(mets[k] - want_metrics[k]) <= 1.0 / 16 + 1e-6
+
+
+def test_train_steps_follow_the_oracle_trajectory():
+    """Three optimizer steps (dropout off): loss sequence and final weights vs the fp64 torch restatement
+    with TF-form Adam (Base.py:142-144)."""
+    prob = make_problem(seed=21, batch=6)
+    cfg = prob["cfg"]
+    m = build_model(prob, "f32")
+    p64 = R.to_torch_params(prob["params"])
+    opt = R.TFAdam(p64, cfg.learning_rate)
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    for step in range(3):
+        got = float(m.train_step(feats, labels))
+        ref, _ = R.train_loss(cfg, p64, prob["mark_table"], prob["feats"], prob["labels"])
+        ref.backward()
+        opt.step()
+        assert abs(got - float(ref)) <= 2e-4 * abs(float(ref)), (step, got, float(ref))
+    for name, p in m.tf_variable_map().items():
+        # Adam's first steps move every weight by ~lr regardless of gradient scale, so compare absolutely
+        d = np.abs(p.detach().cpu().numpy() - p64[name].detach().numpy()).max()
+        assert d < 2e-4, (name, d)
+
+
+def test_training_reduces_loss_with_dropout_bf16():
+    prob = make_problem(seed=5, batch=32, num_items=400, seqslen=20, num_units=64, num_heads=4, num_blocks=1,
+                        masklen=4, num_events=8, learning_rate=2e-3)
+    m = build_model(prob, "bf16", hidden_drop=0.1, att_drop=0.1)
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    losses = [float(m.train_step(feats, labels)) for _ in range(30)]
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0] - 0.5, losses

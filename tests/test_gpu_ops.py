@@ -1,0 +1,367 @@
+"""Per-op parity of the HIP kernels (through the C ABI) against the fp64 oracle.
+Tolerances: f32 path (exact-f32 MFMA) 2e-5 relative to the tensor's max magnitude unless stated; bf16 path 2e-2."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import easydgl_oracle as O
+from oracle import torch_ref as R
+from tests._util import assert_close, rel_err
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [("f32", torch.float32, 3e-5), ("bf16", torch.bfloat16, 2.5e-2)]
+
+
+def ops():
+    from easydgl_amd import ops as _ops
+    return _ops
+
+
+def _rand(shape, rng, scale=1.0):
+    return rng.standard_normal(shape) * scale
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 104), (1000, 384, 40), (64, 256, 1024)])
+def test_gemm_layouts(name, dt, tol, a_kc, b_kc, M, N, K):
+    o = ops()
+    rng = np.random.default_rng(M + N + K)
+    A, Bm = _rand((M, K), rng), _rand((K, N), rng)
+    At = torch.tensor(A if a_kc else A.T.copy(), dtype=dt).cuda().contiguous()
+    Bt = torch.tensor(Bm.T.copy() if b_kc else Bm, dtype=dt).cuda().contiguous()
+    ref = At.double().cpu().numpy() if a_kc else At.double().cpu().numpy().T
+    refB = Bt.double().cpu().numpy().T if b_kc else Bt.double().cpu().numpy()
+    want = ref @ refB
+    got = o.gemm(At, Bt, M, N, K, At.stride(0), Bt.stride(0), a_kc, b_kc, torch.float32)
+    assert_close(got.cpu().numpy(), want, 2e-6 if name == "f32" else 1e-5, f"gemm {name} {a_kc}{b_kc}")
+
+
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+def test_gemm_epilogues_and_splitk(name, dt, tol):
+    o = ops()
+    from easydgl_amd import _lib
+    rng = np.random.default_rng(5)
+    M, N, K = 300, 96, 2000
+    A = torch.tensor(_rand((M, K), rng, 0.1), dtype=dt).cuda()
+    W = torch.tensor(_rand((K, N), rng, 0.1), dtype=dt).cuda()
+    b = torch.tensor(_rand((N,), rng), dtype=torch.float32).cuda()
+    z = A.double().cpu().numpy() @ W.double().cpu().numpy() + b.double().cpu().numpy()
+    pre = torch.empty((M, N), dtype=dt, device="cuda")
+    y = o.gemm(A, W, M, N, K, K, N, True, False, dt, bias=b, aux=pre,
+               flags=_lib.EPI_BIAS | _lib.EPI_GELU | _lib.EPI_SAVE_PRE)
+    assert_close(pre.float().cpu().numpy(), z, tol, "pre-activation")
+    assert_close(y.float().cpu().numpy(), O.gelu(z), tol, "gelu")
+    ys = o.gemm(A, W, M, N, K, K, N, True, False, torch.float32, bias=b, flags=_lib.EPI_BIAS, splitk=7)
+    assert_close(ys.cpu().numpy(), z, 1e-5, "split-K")
+    acc = torch.ones((M, N), dtype=torch.float32, device="cuda")
+    o.gemm(A, W, M, N, K, K, N, True, False, torch.float32, flags=_lib.EPI_ACCUM, out=acc)
+    assert_close(acc.cpu().numpy(), z - b.double().cpu().numpy() + 1.0, 1e-5, "accumulate")
+    cs = o.colsum(pre, M, N)
+    assert_close(cs.cpu().numpy(), pre.double().cpu().numpy().sum(0), 1e-5, "colsum")
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+@pytest.mark.parametrize("B,T,C,gather,resid", [(3, 11, 32, False, True), (5, 101, 128, True, True), (2, 7, 64, False, False)])
+def test_layernorm_fwd_bwd(name, dt, tol, B, T, C, gather, resid):
+    o = ops()
+    rng = np.random.default_rng(B * T)
+    x = torch.tensor(_rand((B, T, C), rng), dtype=dt).cuda().requires_grad_()
+    big = torch.tensor(_rand((B, T, 3 * C), rng), dtype=dt).cuda().requires_grad_() if resid else None
+    g = torch.tensor(1 + 0.1 * _rand((C,), rng), dtype=torch.float32).cuda().requires_grad_()
+    be = torch.tensor(0.1 * _rand((C,), rng), dtype=torch.float32).cuda().requires_grad_()
+    gp = None
+    if gather:
+        gp = torch.tensor(np.stack([rng.choice(T - 1, 4, replace=False) + 1 for _ in range(B)]), dtype=torch.int64).cuda()
+    y = o.AddLayerNormFn.apply(x, big[:, :, :C] if resid else None, g, be, o.NO_DROP, gp)
+    dy = torch.tensor(_rand(tuple(y.shape), rng), dtype=dt).cuda()
+    y.backward(dy)
+    # fp64 reference on the same (possibly bf16-rounded) inputs
+    xr = x.detach().double().cpu().requires_grad_()
+    br = big.detach().double().cpu().requires_grad_() if resid else None
+    gr, ber = g.detach().double().cpu().requires_grad_(), be.detach().double().cpu().requires_grad_()
+    s = xr + (br[:, :, :C] if resid else 0)
+    yr = R.layernorm(s, gr, ber)
+    if gather:
+        yr = yr[torch.arange(B)[:, None], gp.cpu()].reshape(-1, C)
+    yr.backward(dy.double().cpu())
+    assert_close(y.detach().float().cpu().numpy(), yr.detach().numpy(), tol, "ln y")
+    assert_close(x.grad.float().cpu().numpy(), xr.grad.numpy(), tol * 3, "ln dx")
+    if resid:
+        assert_close(big.grad.float().cpu().numpy(), br.grad.numpy(), tol * 3, "ln dresid")
+    assert_close(g.grad.cpu().numpy(), gr.grad.numpy(), tol * 3, "ln dgamma")
+    assert_close(be.grad.cpu().numpy(), ber.grad.numpy(), tol * 3, "ln dbeta")
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+def test_encode_fwd_bwd(name, dt, tol):
+    o = ops()
+    cfg = O.Config(num_items=40, seqslen=12, num_units=32, num_heads=2, time_scale=86400.0, num_events=5)
+    rng = np.random.default_rng(3)
+    p = O.init_params(cfg, rng)
+    mt = O.synthetic_mark_table(cfg.num_items, cfg.num_events, multi_hot=True)
+    ids, ts = O.synthetic_sequences(cfg, 6, rng, min_len=2)
+    ids[0, -1] = cfg.mask_id
+    item = torch.tensor(p["CSTMA/item_embs/lookup_table"], dtype=torch.float32).cuda().requires_grad_()
+    pos = torch.tensor(p["CSTMA/spatial_embs/embedding/lookup_table"], dtype=torch.float32).cuda().requires_grad_()
+    mk = torch.tensor(p["CSTMA/mark_embs/lookup_table"], dtype=torch.float32).cuda().requires_grad_()
+    item_c = item.detach().to(dt)
+    tscale = torch.tensor(O.time_sinusoid_scale(cfg.num_units)).cuda()
+    x0, spans, marks = o.EncodeFn.apply(item, pos, mk, item_c, torch.tensor(ids).cuda(), torch.tensor(ts).cuda(),
+                                        torch.tensor(mt.astype(np.uint8)).cuda(), tscale, cfg.mask_id, cfg.time_scale,
+                                        o.NO_DROP, dt)
+    pp = dict(p)
+    pp["CSTMA/item_embs/lookup_table"] = item_c.double().cpu().numpy()
+    want_x0, want_sp, want_mk, _ = O.input_encode(cfg, pp, mt, ids, ts)
+    np.testing.assert_array_equal(marks.cpu().numpy(), want_mk)
+    np.testing.assert_array_equal(spans.cpu().numpy(), want_sp.astype(np.float32))
+    assert_close(x0.float().cpu().numpy(), want_x0, 2e-6 if name == "f32" else 8e-3, "x0")
+    G = torch.tensor(_rand(tuple(x0.shape), rng), dtype=dt).cuda()
+    x0.backward(G)
+    # reference gradients
+    Gd = G.double().cpu().numpy()
+    C = cfg.num_units
+    d_item = np.zeros_like(p["CSTMA/item_embs/lookup_table"])
+    np.add.at(d_item, ids.reshape(-1), math.sqrt(C) * Gd[..., :C].reshape(-1, C))
+    d_item[0] = 0
+    d_pos = Gd[..., C:2 * C].sum(0)
+    d_mk = np.zeros_like(p["CSTMA/mark_embs/lookup_table"])
+    d_mk[1] = (want_mk.sum(-1)[..., None] * Gd[..., 2 * C:]).sum((0, 1))
+    assert_close(item.grad.cpu().numpy(), d_item, 1e-5, "d_item")
+    assert_close(pos.grad.cpu().numpy(), d_pos, 1e-5, "d_pos")
+    assert_close(mk.grad.cpu().numpy(), d_mk, 1e-5, "d_mark")
+
+
+def test_time_code_matches_oracle_at_large_arguments():
+    """coding.py:141-145 with Netflix-scale timestamps (float32 seconds ~1e9 / 86400)."""
+    o = ops()
+    cfg = O.Config(num_items=10, seqslen=63, num_units=128, num_heads=8, time_scale=86400.0, num_events=2)
+    rng = np.random.default_rng(1)
+    p = O.init_params(cfg, rng)
+    mt = O.synthetic_mark_table(cfg.num_items, 2)
+    ids, ts = O.synthetic_sequences(cfg, 4, rng, min_len=60)
+    item = torch.zeros((cfg.I, 128), dtype=torch.float32).cuda()
+    x0, _, _ = o.EncodeFn.apply(item, torch.zeros((cfg.T, 128)).cuda(), torch.zeros((2, 128)).cuda(), item,
+                                torch.tensor(ids).cuda(), torch.tensor(ts).cuda(), torch.tensor(mt.astype(np.uint8)).cuda(),
+                                torch.tensor(O.time_sinusoid_scale(128)).cuda(), cfg.mask_id, cfg.time_scale, o.NO_DROP,
+                                torch.float32)
+    want = O.time_sinusoid_code(O.scaled_times(ts, cfg.time_scale), 128)
+    assert np.abs(x0[..., :128].cpu().numpy() - want).max() < 5e-7
+
+
+# ---------------------------------------------------------------------------------------------------
+def _bimau_case(B, T, C, H, E, seed, cin_mult=3):
+    cfg = O.Config(num_items=30, seqslen=T - 1, num_units=C, num_heads=H, num_events=E, time_scale=1.0)
+    rng = np.random.default_rng(seed)
+    dh = C // H
+    cin = cin_mult * C
+    x = _rand((B, T, cin), rng)
+    ids = rng.integers(1, cfg.num_items, size=(B, T))
+    for b in range(B):
+        ids[b, :rng.integers(0, T // 2 + 1)] = 0
+    if B > 2:
+        ids[2, :] = 0  # a fully padded sample: uniform attention (temporal.py:425-429)
+    mt = O.synthetic_mark_table(cfg.num_items, E, multi_hot=True)
+    marks = mt[ids]
+    spans = rng.uniform(0, 5, size=(B, T))
+    W = dict(Wq=_rand((cin, 4 * C), rng, 0.15), bq=_rand((4 * C,), rng, 0.1), W1=O.glorot_uniform(rng, (dh + 1, dh * E)),
+             b1=_rand((dh * E,), rng, 0.1), w=O.glorot_uniform(rng, (E, dh)), sc=_rand((E,), rng, 0.2))
+    return cfg, x, ids, marks, spans, W
+
+
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+@pytest.mark.parametrize("B,T,C,H,E", [(3, 11, 32, 2, 4), (2, 31, 64, 2, 7), (2, 101, 128, 8, 16), (1, 128, 32, 2, 2)])
+def test_bimau_fwd_bwd(name, dt, tol, B, T, C, H, E):
+    o = ops()
+    cfg, x, ids, marks, spans, W = _bimau_case(B, T, C, H, E, seed=T + C)
+    xt = torch.tensor(x, dtype=dt).cuda().requires_grad_()
+    Wq = torch.tensor(W["Wq"], dtype=torch.float32).cuda().requires_grad_()
+    Wq_c = Wq.detach().to(dt)
+    bq = torch.tensor(W["bq"], dtype=torch.float32).cuda().requires_grad_()
+    W1, b1, w, sc = (torch.tensor(W[k], dtype=torch.float32).cuda().requires_grad_() for k in ("W1", "b1", "w", "sc"))
+    qkvt = o.LinearFn.apply(xt, Wq, bq, Wq_c, False)
+    out, lam = o.BiMAUFn.apply(qkvt, xt[:, :, :C], W1, b1, w, sc, torch.tensor(ids).cuda(),
+                               torch.tensor(spans, dtype=torch.float32).cuda(), torch.tensor(marks.astype(np.uint8)).cuda(),
+                               H, o.NO_DROP)
+    rng = np.random.default_rng(9)
+    G1 = torch.tensor(_rand((B, T, C), rng), dtype=dt).cuda()
+    G2 = torch.tensor(_rand((H * B, T, E), rng, 0.3), dtype=torch.float32).cuda()
+    ((out.float() * G1.float()).sum() + (lam * G2).sum()).backward()
+    # fp64 reference evaluated on the rounded inputs the kernel saw
+    xr = xt.detach().double().cpu().requires_grad_()
+    pr = {"dense/kernel": Wq_c.double().cpu().requires_grad_(), "dense/bias": bq.detach().double().cpu().requires_grad_(),
+          "sequential_temporal_combined/dense/kernel": W1.detach().double().cpu().requires_grad_(),
+          "sequential_temporal_combined/dense/bias": b1.detach().double().cpu().requires_grad_(),
+          "sequential_temporal_combined/weight": w.detach().double().cpu().requires_grad_(),
+          "sequential_temporal_combined/scaling": sc.detach().double().cpu().requires_grad_()}
+    km3 = torch.tensor((ids != 0).astype(np.float64)).unsqueeze(1).repeat(H, T, 1)
+    out_r, lam_r = R.bimau(C, H, xr, km3, torch.tensor(spans), torch.tensor(marks, dtype=torch.float64), pr, "", 0.0, False)
+    ((out_r * G1.double().cpu()).sum() + (lam_r * G2.double().cpu()).sum()).backward()
+    ftol = 3e-5 if name == "f32" else 3e-2
+    assert_close(lam.cpu().numpy(), lam_r.detach().numpy(), ftol, "lambda")
+    assert_close(out.float().detach().cpu().numpy(), out_r.detach().numpy(), ftol, "out")
+    gtol = 2e-4 if name == "f32" else 6e-2
+    assert_close(xt.grad.float().cpu().numpy(), xr.grad.numpy(), gtol, "dx")
+    assert_close(Wq.grad.cpu().numpy(), pr["dense/kernel"].grad.numpy(), gtol, "dWqkvt")
+    assert_close(bq.grad.cpu().numpy(), pr["dense/bias"].grad.numpy(), gtol, "dbqkvt")
+    assert_close(W1.grad.cpu().numpy(), pr["sequential_temporal_combined/dense/kernel"].grad.numpy(), gtol, "dW1")
+    assert_close(b1.grad.cpu().numpy(), pr["sequential_temporal_combined/dense/bias"].grad.numpy(), gtol, "db1")
+    assert_close(w.grad.cpu().numpy(), pr["sequential_temporal_combined/weight"].grad.numpy(), gtol, "dw")
+    assert_close(sc.grad.cpu().numpy(), pr["sequential_temporal_combined/scaling"].grad.numpy(), gtol, "dscaling")
+
+
+def test_bimau_fully_masked_row_is_uniform():
+    """KAT temporal.py:425-429 through the kernel: all keys padded -> P = 1/T -> out = mean_k(G*V) + resid."""
+    o = ops()
+    B, T, C, H, E = 1, 9, 32, 2, 2
+    rng = np.random.default_rng(0)
+    qkvt = torch.tensor(_rand((B, T, 4 * C), rng), dtype=torch.float32).cuda()
+    resid = torch.zeros((B, T, C)).cuda()
+    dh = C // H
+    W1 = torch.zeros((dh + 1, dh * E)).cuda(); b1 = torch.zeros(dh * E).cuda()
+    w = torch.zeros((E, dh)).cuda(); sc = torch.zeros(E).cuda()
+    ids = torch.zeros((B, T), dtype=torch.int64).cuda()
+    marks = torch.ones((B, T, E), dtype=torch.uint8).cuda()
+    out, lam = o.BiMAUFn.apply(qkvt, resid, W1, b1, w, sc, ids, torch.ones((B, T)).cuda(), marks, H, o.NO_DROP)
+    np.testing.assert_allclose(lam.cpu().numpy(), math.log(2.0), rtol=1e-6)   # temporal.py:299-306
+    V = qkvt[0, :, 2 * C:3 * C].double().cpu().numpy()
+    G = np.full((T, T), E * math.log(2.0)); G[np.arange(T), np.arange(T)] = 1.0   # temporal.py:438-439
+    want = (G / T) @ V
+    np.testing.assert_allclose(out[0].cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+@pytest.mark.parametrize("R_,C,I", [(37, 32, 300), (260, 128, 2701), (130, 64, 5200)])
+def test_score_ce_fwd_bwd(name, dt, tol, R_, C, I):
+    o = ops()
+    rng = np.random.default_rng(R_)
+    rows = torch.tensor(_rand((R_, C), rng, 0.5), dtype=dt).cuda().requires_grad_()
+    tab = torch.tensor(_rand((I, C), rng, 0.3), dtype=torch.float32).cuda().requires_grad_()
+    tab_c = tab.detach().to(dt)
+    bias = torch.tensor(_rand((I - 1,), rng, 0.2), dtype=torch.float32).cuda().requires_grad_()
+    labels = rng.integers(0, I, size=R_)
+    labels[:3] = 0
+    lab = torch.tensor(labels, dtype=torch.int64).cuda()
+    loss = o.ScoreCEFn.apply(rows, tab, bias, tab_c, lab)
+    (loss * 1.7).backward()
+    rr = rows.detach().double().cpu().requires_grad_()
+    tr = tab_c.double().cpu().requires_grad_()
+    br = bias.detach().double().cpu().requires_grad_()
+    logits = rr @ R.zero_padded(tr).t() + torch.cat([torch.full((1,), -1000.0, dtype=torch.float64), br])
+    lp = torch.log(torch.softmax(logits, -1) + 1e-5)
+    wgt = (torch.tensor(labels) != 0).double()
+    ref = (wgt * -lp[torch.arange(R_), torch.tensor(labels)]).sum() / (wgt.sum() + 1e-5)
+    (ref * 1.7).backward()
+    assert_close(loss.item(), ref.item(), 2e-5 if name == "f32" else 5e-3, "ce loss")
+    gt = 1e-4 if name == "f32" else 3e-2
+    assert_close(rows.grad.float().cpu().numpy(), rr.grad.numpy(), gt, "d_rows")
+    assert_close(tab.grad.cpu().numpy(), tr.grad.numpy(), gt, "d_table")
+    assert_close(bias.grad.cpu().numpy(), br.grad.numpy(), gt, "d_bias")
+    assert float(tab.grad[0].abs().max()) == 0.0
+    # materialised logits path (EasyDGL.py:149-151)
+    lg = o.ScoreLogitsFn.apply(rows.detach(), tab.detach(), bias.detach(), tab_c)
+    assert_close(lg.cpu().numpy(), logits.detach().numpy(), 1e-5 if name == "f32" else 1e-5, "logits")
+    assert float((lg[:, 0] + 1000.0).abs().max()) == 0.0
+
+
+def test_topk_ties_masking_merge_and_metrics():
+    o = ops()
+    rng = np.random.default_rng(4)
+    R_, n, K, T = 9, 3000, 100, 12
+    x = rng.standard_normal((R_, n)).astype(np.float32)
+    x[0, :] = 0.5                      # all ties -> lowest indices
+    x[1, 100:400] = 7.0                # 300-way tie at the top
+    x[2, 5] = np.inf
+    seen = rng.integers(0, n, size=(R_, T))
+    seen[3, :] = np.argsort(-x[3])[:T]  # mask exactly the current top-T of row 3
+    want_x = x.copy()
+    want_x[np.arange(R_)[:, None], seen] = -np.inf
+    want = O.top_k(want_x, K)
+    val, idx = o.mask_topk(torch.tensor(x).cuda(), 0, torch.tensor(seen).cuda(), K)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    np.testing.assert_array_equal(val.cpu().numpy(), np.take_along_axis(want_x, want, 1))
+    # sharded: 4 contiguous shards, local top-K with global ids, merged (K7)
+    S = 4
+    bounds = np.linspace(0, n, S + 1).astype(int)
+    cv, ci = [], []
+    for s in range(S):
+        lo, hi = bounds[s], bounds[s + 1]
+        v, i = o.mask_topk(torch.tensor(x[:, lo:hi].copy()).cuda(), int(lo), torch.tensor(seen).cuda(), K)
+        cv.append(v); ci.append(i)
+    mv, mi = o.topk_merge(torch.stack(cv), torch.stack(ci))
+    np.testing.assert_array_equal(mi.cpu().numpy(), want)
+    # metrics (Base.py:181-201)
+    labels = np.array([want[r, r * 11 % K] for r in range(R_)])
+    labels[4] = n - 1 if (n - 1) not in want[4] else n - 2
+    met = torch.zeros(6).cuda()
+    o.rank_metrics(idx, torch.tensor(labels).cuda(), met)
+    per = O.ranking_metrics(want, labels)
+    np.testing.assert_allclose(met.cpu().numpy(), [per[k].sum() for k in ("H10", "H50", "H100", "N10", "N50", "N100")], rtol=1e-5)
+
+
+def test_tpp_regulariser_fwd_bwd():
+    o = ops()
+    rng = np.random.default_rng(2)
+    B, T, H, E, M, NI = 5, 14, 2, 4, 3, 30
+    lam = torch.tensor(rng.uniform(0.2, 2.0, size=(H * B, T, E)), dtype=torch.float32).cuda().requires_grad_()
+    mp = torch.tensor(np.stack([rng.choice(T - 1, M, replace=False) + 1 for _ in range(B)])).cuda()
+    labels = rng.integers(1, NI, size=(B, M)); labels[0, 0] = 0
+    ts = np.cumsum(rng.exponential(40.0, size=(B, T)), axis=1).astype(np.float32) + 9.5e8
+    mt = O.synthetic_mark_table(NI, E, multi_hot=True)
+    coef = 0.37
+    reg = o.TppFn.apply(lam, mp, torch.tensor(labels).cuda(), torch.tensor(ts).cuda(),
+                        torch.tensor(mt.astype(np.uint8)).cuda(), H, coef)
+    (reg * 2.0).backward()
+    lr = lam.detach().double().cpu().requires_grad_()
+    sp = torch.tensor(O.spans_from_times(ts))[torch.arange(B)[:, None], mp.cpu()].repeat(H, 1)
+    nm = torch.tensor(mt[labels], dtype=torch.float64).repeat(H, 1, 1)
+    lg = lr[torch.arange(H * B)[:, None], mp.cpu().repeat(H, 1)]
+    ref = coef * R.biased_likelihood(lg, nm, sp)
+    (ref * 2.0).backward()
+    assert_close(reg.item(), ref.item(), 1e-5, "tpp reg")
+    assert_close(lam.grad.cpu().numpy(), lr.grad.numpy(), 1e-5, "tpp dlam")
+
+
+def test_adam_matches_tf_form():
+    o = ops()
+    rng = np.random.default_rng(6)
+    n = 1000
+    w0, g = rng.standard_normal(n), rng.standard_normal(n) * 0.1
+    w = torch.tensor(w0, dtype=torch.float32).cuda()
+    m = torch.zeros(n).cuda(); v = torch.zeros(n).cuda()
+    st = torch.zeros(2, dtype=torch.int64).cuda()
+    shadow = torch.empty(n, dtype=torch.bfloat16).cuda()
+    wn, mn, vn = w0.copy(), np.zeros(n), np.zeros(n)
+    for t in range(1, 5):
+        gt = torch.tensor(g * t, dtype=torch.float32).cuda()
+        o.adam_step(w, gt, m, v, 1e-2, st, 0.0, None, shadow)
+        wn, mn, vn = O.adam_tf(wn, np.float32(g * t).astype(np.float64), mn, vn, t, 1e-2)
+    assert int(st[0]) == 4
+    assert_close(w.cpu().numpy(), wn, 2e-6, "adam w")
+    assert_close(shadow.float().cpu().numpy(), wn, 5e-3, "adam shadow")
+
+
+def test_dropout_is_consistent_between_forward_and_backward():
+    o = ops()
+    B, T, C = 6, 50, 64
+    x = torch.randn((B, T, C), device="cuda").requires_grad_()
+    g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+    st = torch.tensor([1234, 7], dtype=torch.int64).cuda()
+    drop = o.Drop(0.25, st, 3)
+    y1 = o.AddLayerNormFn.apply(x, None, g, b, drop, None)
+    y2 = o.AddLayerNormFn.apply(x, None, g, b, drop, None)
+    assert torch.equal(y1, y2)                       # same (seed, step, stream) -> same mask
+    o.rng_advance(st)
+    y3 = o.AddLayerNormFn.apply(x, None, g, b, drop, None)
+    assert not torch.equal(y1, y3)                   # next step -> new mask
+    (y3 * torch.randn_like(y3)).sum().backward()
+    # gradient w.r.t. x is exactly zero where the element was dropped; keep-rate ~ 0.75
+    zero_frac = float((x.grad == 0).float().mean())
+    assert abs(zero_frac - 0.25) < 0.02
