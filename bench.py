@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py — sequences/sec of ONE EasyDGL optimizer step (forward + backward + TF-Adam) on the headline
+configuration of BASELINE.json: per-GPU batch 512, seqslen 100 (T=101 positions), num_units 128, 8 heads,
+1 block, num_items 20000 (I=20001 table rows), masklen 20, 16 mark types, dropout 0.1/0.1, bf16 activations
+with f32 accumulation / master weights.  Synthetic data, random-init weights.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `value` = N * 512 * K / (max-over-ranks wall time of the K timed steps).
+`roofline` is the dominant kernel's achieved MFMA rate (algorithmic FLOPs per launch / mean launch time,
+HIP events on the launch stream inside the timed region).  `cpu_baseline` times the restated reference
+graph (oracle/torch_ref.py, float32, reference op order) on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HEADLINE = dict(num_items=20000, seqslen=100, num_units=128, num_heads=8, num_blocks=1, masklen=20,
+                num_events=16, batch=512, time_scale=86400.0, learning_rate=5e-4, l2_reg=1e-4, ct_reg=1e-7,
+                hidden_dropout_rate=0.1, attention_probs_dropout_rate=0.1)
+
+# the kernel(s) whose launches are bracketed with HIP events inside the timed region
+DOMINANT_CALL = "edgl_score_ce_bwd"
+
+
+def flops_per_seq(c):
+    """SURVEY.md §8d algorithmic FLOPs per sequence, forward; fwd+bwd = 3x."""
+    T, C, h, E, M, I, nb = c["seqslen"] + 1, c["num_units"], c["num_heads"], c["num_events"], c["masklen"], c["num_items"] + 1, c["num_blocks"]
+    dh = C // h
+    f = 0.0
+    for i in range(nb):
+        cin = 3 * C if i == 0 else C
+        f += 2 * T * cin * 4 * C                  # F_qkvt
+    f += nb * 6 * T * T * C                        # F_attn
+    f += nb * 2 * T * C * E * (dh + 2)             # F_int
+    f += nb * 2 * h * T * T * E                    # F_mark
+    f += nb * 2 * T * C * C                        # F_proj
+    f += nb * 8 * T * C * C                        # F_ffn
+    f += 2 * T * C * C                             # F_head
+    f += 2 * M * C * I                             # F_score (train)
+    return f
+
+
+def make_model_and_batch(c, dtype, device, seed):
+    from types import SimpleNamespace
+    import easydgl_amd
+    from easydgl_amd import data as D
+    F = SimpleNamespace(model="EasyDGL", num_items=c["num_items"], num_units=c["num_units"], num_heads=c["num_heads"],
+                        num_blocks=c["num_blocks"], seqslen=c["seqslen"], masklen=c["masklen"], time_scale=c["time_scale"],
+                        learning_rate=c["learning_rate"], l2_reg=c["l2_reg"], ct_reg=c["ct_reg"],
+                        hidden_dropout_rate=c["hidden_dropout_rate"],
+                        attention_probs_dropout_rate=c["attention_probs_dropout_rate"],
+                        mark_table=D.synthetic_mark_table(c["num_items"], c["num_events"]), compute_dtype=dtype,
+                        num_train_steps=None, num_warmup_steps=None, seed=9876)
+    model = easydgl_amd.ranking(F).finalize(device)
+    ids, ts = D.synthetic_batch(c["num_items"], c["seqslen"], c["batch"], seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    mp = D.draw_masked_positions(c["batch"], c["seqslen"] + 1, c["masklen"], generator=g)
+    feats, labels = D.mask_random(torch.tensor(ids), torch.tensor(ts), c["num_items"], mp)
+    feats = {k: v.to(device).contiguous() for k, v in feats.items()}
+    return model, feats, labels.to(device).contiguous()
+
+
+def cpu_baseline(c, budget_s=15.0):
+    """Restated reference graph on the host (TensorFlow is not installable offline): float32, reference op
+    order incl. the materialised [hB,T,T(,E)] and [B*M,I] tensors, all host cores; bounded sample."""
+    from oracle import easydgl_oracle as O
+    from oracle import torch_ref as R
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    bs = 16
+    cfg = O.Config(num_items=c["num_items"], seqslen=c["seqslen"], num_units=c["num_units"], num_heads=c["num_heads"],
+                   num_blocks=c["num_blocks"], masklen=c["masklen"], time_scale=c["time_scale"], ct_reg=c["ct_reg"],
+                   l2_reg=c["l2_reg"], learning_rate=c["learning_rate"], num_events=c["num_events"])
+    rng = np.random.default_rng(9876)
+    params = R.to_torch_params(O.init_params(cfg, rng), dtype=torch.float32)
+    mt = O.synthetic_mark_table(cfg.num_items, cfg.num_events)
+    ids, ts = O.synthetic_sequences(cfg, bs, rng)
+    feats, labels = O.mask_random(cfg, ids, ts, O.draw_masked_positions(cfg, bs, rng))
+    opt = R.TFAdam(params, cfg.learning_rate)
+    R.cpu_train_step(cfg, params, opt, mt, feats, labels, torch.float32, 0.1, 0.1)   # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        R.cpu_train_step(cfg, params, opt, mt, feats, labels, torch.float32, 0.1, 0.1)
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n * bs / dt, 3), "unit": "sequences/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n} optimizer steps of batch {bs} (same shapes as the GPU workload), float32, "
+                      f"oracle/torch_ref.py restatement of the TensorFlow graph (TF not installable offline)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--op-table", action="store_true", help="after the timed region, print a per-C-call time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    c = dict(HEADLINE)
+    from easydgl_amd import _lib, parallel
+    model, feats, labels = make_model_and_batch(c, args.dtype, dev, seed=9876 + rank)
+
+    def step():
+        from easydgl_amd import ops
+        ops.rng_advance(model._rng_state)
+        model.zero_grad_arena()
+        loss = model.train_loss(feats, labels)
+        loss.backward()
+        if world > 1:
+            parallel.allreduce_mean_(model._grad_arena)
+        model.optimizer_step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.profiler.start(only=[DOMINANT_CALL])
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.profiler.stop()
+    dom = _lib.profiler.summary().get(DOMINANT_CALL, (0, 0.0))
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not np.isfinite(float(loss)):
+        raise RuntimeError("loss is not finite")
+
+    if rank == 0:
+        T, C, I, M = c["seqslen"] + 1, c["num_units"], c["num_items"] + 1, c["masklen"]
+        R = c["batch"] * M
+        # edgl_score_ce_bwd: two logit recomputations + d_rows + d_table products, 2*R*C*I FLOPs each
+        dom_flops = 4 * 2.0 * R * C * I
+        dom_ms = dom[1] / max(1, dom[0])
+        peak = 2500.0 if args.dtype == "bf16" else 157.3
+        ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "sequences/sec (fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K",
+            "value": round(world * c["batch"] * args.steps / dt, 2),
+            "unit": "sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "EasyDGL optimizer step, per-GPU batch 512, seqslen 100 (T=101), num_units 128, 8 heads, "
+                                   "1 block, num_items 20000 (I=20001), masklen 20, 16 marks, dropout 0.1/0.1, ct_reg 1e-7, l2 1e-4",
+                       "global_batch": world * c["batch"], "parallelism": f"dp{world}",
+                       "algorithmic_gflop_per_step": round(3 * flops_per_seq(c) * c["batch"] / 1e9, 1)},
+            "loss": round(float(loss), 5),
+            "roofline": {"bound": "mfma", "kernel": "score_bwd_dy_kernel+score_bwd_dw_kernel (edgl_score_ce_bwd)",
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "avg_launch_ms": round(dom_ms, 4), "traffic": None},
+            "whole_step_mfma_frac": round(3 * flops_per_seq(c) * c["batch"] / (dt / args.steps) / 1e12 / peak, 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(c)
+        if args.op_table:
+            _lib.profiler.start()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            _lib.profiler.stop()
+            rows = sorted(_lib.profiler.summary().items(), key=lambda kv: -kv[1][1])
+            tot = sum(v[1] for _, v in rows)
+            print("per-call GPU time over 5 steps (HIP events):", file=sys.stderr)
+            for k, (n, ms) in rows:
+                print(f"  {k:28s} calls {n:4d}  {ms / 5:9.3f} ms/step  {100 * ms / tot:5.1f}%", file=sys.stderr)
+            print(f"  total {tot / 5:.3f} ms/step", file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

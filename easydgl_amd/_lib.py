@@ -71,7 +71,61 @@ def _load() -> ctypes.CDLL:
     return lib
 
 
-lib = _load()
+_cdll = _load()
+
+
+class _Profiler:
+    """Optional per-call HIP-event bracketing (torch events on the current stream — the stream every kernel
+    of this library is launched on).  Disabled -> zero overhead beyond one attribute test."""
+
+    def __init__(self):
+        self.enabled = False
+        self.only = None          # set of C function names to bracket (None = all)
+        self.records = {}         # name -> list[(start_event, end_event)]
+
+    def start(self, only=None):
+        self.enabled, self.only, self.records = True, (set(only) if only else None), {}
+
+    def stop(self):
+        self.enabled = False
+
+    def summary(self):
+        """name -> (calls, total_ms); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, evs in self.records.items():
+            out[name] = (len(evs), sum(a.elapsed_time(b) for a, b in evs))
+        return out
+
+
+profiler = _Profiler()
+
+
+class _LibProxy:
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._wrapped = {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if not name.startswith("edgl_"):
+            return fn
+
+        def call(*args, _fn=fn, _name=name):
+            if profiler.enabled and (profiler.only is None or _name in profiler.only):
+                import torch
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                rc = _fn(*args)
+                b.record()
+                profiler.records.setdefault(_name, []).append((a, b))
+                return rc
+            return _fn(*args)
+
+        self.__dict__[name] = call
+        return call
+
+
+lib = _LibProxy(_cdll)
 
 
 def check(rc: int, what: str = "") -> None:

@@ -268,7 +268,12 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
         for (int kt = 0; kt < NT; ++kt) {
             f32x4 ds;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ds[r] = s[kt][r] * (dp[kt][r] - rowdot) * cscale;
+            for (int r = 0; r < 4; ++r) {
+                // tf.where(mask==0, paddings, S) (temporal.py:425-426) passes no gradient to a padded key's
+                // score; P is non-zero there only for fully padded rows (uniform softmax)
+                const bool padded = (kb.pad >> (kt * 4 + r)) & 1u;
+                ds[r] = padded ? 0.f : s[kt][r] * (dp[kt][r] - rowdot) * cscale;
+            }
             const Frag4<T> dsf = frag_from_acc<T>(ds);
 #pragma unroll
             for (int ut = 0; ut < DT; ++ut)

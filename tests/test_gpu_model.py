@@ -50,7 +50,7 @@ def test_forward_loss_and_gradients(mode, ltol, gtol, case):
     # ---- eval logits (last position)
     elog = m(to_dev(prob["efeats"]), False)
     want_e, _ = O.forward(cfg, prob["params"], prob["mark_table"], prob["efeats"], False)
-    assert_close(elog.cpu().numpy(), want_e, ltol, "eval logits")
+    assert_close(elog.detach().cpu().numpy(), want_e, ltol, "eval logits")
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])

@@ -121,7 +121,7 @@ def test_encode_fwd_bwd(name, dt, tol):
     want_x0, want_sp, want_mk, _ = O.input_encode(cfg, pp, mt, ids, ts)
     np.testing.assert_array_equal(marks.cpu().numpy(), want_mk)
     np.testing.assert_array_equal(spans.cpu().numpy(), want_sp.astype(np.float32))
-    assert_close(x0.float().cpu().numpy(), want_x0, 2e-6 if name == "f32" else 8e-3, "x0")
+    assert_close(x0.detach().float().cpu().numpy(), want_x0, 2e-6 if name == "f32" else 8e-3, "x0")
     G = torch.tensor(_rand(tuple(x0.shape), rng), dtype=dt).cuda()
     x0.backward(G)
     # reference gradients
@@ -204,7 +204,7 @@ def test_bimau_fwd_bwd(name, dt, tol, B, T, C, H, E):
     out_r, lam_r = R.bimau(C, H, xr, km3, torch.tensor(spans), torch.tensor(marks, dtype=torch.float64), pr, "", 0.0, False)
     ((out_r * G1.double().cpu()).sum() + (lam_r * G2.double().cpu()).sum()).backward()
     ftol = 3e-5 if name == "f32" else 3e-2
-    assert_close(lam.cpu().numpy(), lam_r.detach().numpy(), ftol, "lambda")
+    assert_close(lam.detach().cpu().numpy(), lam_r.detach().numpy(), ftol, "lambda")
     assert_close(out.float().detach().cpu().numpy(), out_r.detach().numpy(), ftol, "out")
     gtol = 2e-4 if name == "f32" else 6e-2
     assert_close(xt.grad.float().cpu().numpy(), xr.grad.numpy(), gtol, "dx")
