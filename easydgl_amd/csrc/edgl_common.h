@@ -37,6 +37,10 @@ extern "C" void edgl_set_error(const char* fmt, ...);
 
 static inline int edgl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// out[n] (+)= sum_{p<P} part[p*ld + n], fixed summation order (k_misc.hip).  Used for every
+// "per-workgroup partials -> parameter gradient" reduction.
+int edgl_reduce_rows(const float* part, int P, int N, long ld, float* out, int accumulate, hipStream_t st);
+
 // ----------------------------------------------------------------------------------------------
 // element types: activations / GEMM operands are float (exact-f32 MFMA path) or bf16
 // ----------------------------------------------------------------------------------------------

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
 // ---------------- kernel B: intensity weight gradients ---------------------------------------------
 struct WgP {
     const void* hin_ws; const float* dz_ws; const float* spans; const char* pack;
-    long R; int B, T, E; float* wpart;
+    long R; int B, T, E; float* wpart; const float* dsc_part; long njobs;
 };
 
 template <typename T, int DT>
@@ -332,9 +332,9 @@ __global__ __launch_bounds__(256) void intensity_wgrad_kernel(WgP p) {
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (int i = threadIdx.x; i < (int)(pd.bytes / 16); i += blockDim.x) dst[i] = src[i];
     }
-    const int JE = pd.JE, NPAR = (dh + 3) * JE;
-    float* accs = reinterpret_cast<float*>(smem + pd.bytes);  // [NPAR] block accumulator
-    for (int i = threadIdx.x; i < NPAR; i += blockDim.x) accs[i] = 0.f;
+    const int JE = pd.JE, NPAR = (dh + 3) * JE, NPARX = NPAR + EP;
+    float* accs = reinterpret_cast<float*>(smem + pd.bytes);  // [NPAR + 16] block accumulator
+    for (int i = threadIdx.x; i < NPARX; i += blockDim.x) accs[i] = 0.f;
     const T* W1T = reinterpret_cast<const T*>(smem);
     const float* fW = reinterpret_cast<const float*>(smem + pd.off_f32);
     const float* w1s = fW; const float* b1s = fW + JE; const float* wvs = fW + 2 * JE;
@@ -442,25 +442,15 @@ __global__ __launch_bounds__(256) void intensity_wgrad_kernel(WgP p) {
     }
     for (int i = threadIdx.x; i < NPAR; i += blockDim.x) {
         const int e = (i % JE) / dh;  // every entry belongs to exactly one mark e -> one blockIdx.y
-        if (e >= e0 && e < e0 + ECH) p.wpart[(long)blockIdx.x * NPAR + i] = accs[i];
+        if (e >= e0 && e < e0 + ECH) p.wpart[(long)blockIdx.x * NPARX + i] = accs[i];
     }
-}
-
-__global__ void intensity_grad_reduce_kernel(const float* wpart, int nblk, int dh, int E, const float* dsc_part,
-                                             long njobs, float* dW1, float* db1, float* dw, float* dscaling) {
-    const int JE = dh * E, NPAR = (dh + 3) * JE;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < NPAR) {
+    // dscaling: fold this block's slice of kernel A's per-(b,head) partials into the same partial row
+    if (blockIdx.y == 0 && threadIdx.x < EP) {
+        const long per = (p.njobs + gridDim.x - 1) / gridDim.x;
+        const long j0 = blockIdx.x * per, j1 = min(p.njobs, j0 + per);
         float a = 0.f;
-        for (int k = 0; k < nblk; ++k) a += wpart[(long)k * NPAR + i];
-        if (i < (dh + 1) * JE) dW1[i] = a;
-        else if (i < (dh + 2) * JE) db1[i - (dh + 1) * JE] = a;
-        else dw[i - (dh + 2) * JE] = a;
-    } else if (i < NPAR + E) {
-        const int e = i - NPAR;
-        float a = 0.f;
-        for (long k = 0; k < njobs; ++k) a += dsc_part[k * EP + e];
-        dscaling[e] = a;
+        for (long j = j0; j < j1; ++j) a += p.dsc_part[j * EP + threadIdx.x];
+        p.wpart[(long)blockIdx.x * NPARX + NPAR + threadIdx.x] = a;
     }
 }
 
@@ -474,7 +464,7 @@ WsLayout ws_layout(int B, int T_, int C, int H, int E) {
     w.hin = o; o += (R * dh * sizeof(T) + 255) & ~(size_t)255;
     w.dz = o; o += (R * EP * sizeof(float) + 255) & ~(size_t)255;
     w.dsc = o; o += ((size_t)B * H * EP * sizeof(float) + 255) & ~(size_t)255;
-    w.wpart = o; o += ((size_t)KB_BLOCKS * (dh + 3) * dh * E * sizeof(float) + 255) & ~(size_t)255;
+    w.wpart = o; o += ((size_t)KB_BLOCKS * ((dh + 3) * dh * E + EP) * sizeof(float) + 255) & ~(size_t)255;
     w.total = o;
     return w;
 }
@@ -498,18 +488,22 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
     EDGL_LAUNCH_CHECK();
 
-    WgP wp{p.hin_ws, p.dz_ws, p.spans, p.pack, (long)p.B * p.H * p.T, p.B, p.T, p.E, p.wpart};
-    const int NPAR = (dh + 3) * dh * p.E;
-    const size_t smem_b = pd.bytes + (size_t)NPAR * sizeof(float);
+    WgP wp{p.hin_ws, p.dz_ws, p.spans, p.pack, (long)p.B * p.H * p.T, p.B, p.T, p.E, p.wpart, p.dsc_part, jobs};
+    const int JE = dh * p.E, NPAR = (dh + 3) * JE, NPARX = NPAR + EP;
+    const size_t smem_b = pd.bytes + (size_t)NPARX * sizeof(float);
     EDGL_REQUIRE(smem_b <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: weight-grad kernel needs %zu B of LDS", smem_b);
     auto kb = intensity_wgrad_kernel<T, DT>;
     hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
     hipLaunchKernelGGL(kb, dim3(KB_BLOCKS, DT * DT), dim3(256), smem_b, st, wp);
     EDGL_LAUNCH_CHECK();
-    const int total = NPAR + p.E;
-    hipLaunchKernelGGL(intensity_grad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.wpart, KB_BLOCKS, dh,
-                       p.E, p.dsc_part, jobs, dW1, db1, dw, dscaling);
-    EDGL_LAUNCH_CHECK();
+    int rc = edgl_reduce_rows(p.wpart, KB_BLOCKS, (dh + 1) * JE, NPARX, dW1, 0, st);
+    if (rc) return rc;
+    rc = edgl_reduce_rows(p.wpart + (dh + 1) * JE, KB_BLOCKS, JE, NPARX, db1, 0, st);
+    if (rc) return rc;
+    rc = edgl_reduce_rows(p.wpart + (dh + 2) * JE, KB_BLOCKS, JE, NPARX, dw, 0, st);
+    if (rc) return rc;
+    rc = edgl_reduce_rows(p.wpart + NPAR, KB_BLOCKS, p.E, NPARX, dscaling, 0, st);
+    if (rc) return rc;
     return EDGL_OK;
 }
 

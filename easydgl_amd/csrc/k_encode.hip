@@ -76,63 +76,117 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
 struct EncBwdP {
     const int64_t* ids; const uint8_t* marks; const void* dx0;
     int B, T, C, E, I; float rate; const uint64_t* rng; uint32_t stream_id;
-    float* d_item; float* part; int nchunk;
+    float* d_item; float* part_pos; float* part_mk; int nchunk;
 };
 
-// grid (T, nchunk); thread c accumulates over the b-range of its chunk for position t
+// d_pos / d_mark: grid (T, nchunk): the block owns position t for the b-range of its chunk.  Thread = 4
+// consecutive channels of the position and mark sections (8/16-byte loads); 256/(C/4) rows in flight; block
+// partials reduced in a fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void encode_bwd_kernel(EncBwdP p) {
+    extern __shared__ float sm[];  // [rows_par][2][C]
+    __shared__ float s_nm[64];
     const int t = blockIdx.x, chunk = blockIdx.y;
     const int bper = (p.B + p.nchunk - 1) / p.nchunk;
     const int b0 = chunk * bper, b1 = min(p.B, b0 + bper);
+    const int cpr = p.C / 4, rows_par = 256 / cpr;
+    const int cv = threadIdx.x % cpr, rl = threadIdx.x / cpr, c0 = cv * 4;
+    const bool on = threadIdx.x < rows_par * cpr;
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    float apos[4] = {0.f, 0.f, 0.f, 0.f}, amk[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int bb = b0; bb < b1; bb += 64) {
+        __syncthreads();
+        if (threadIdx.x < 64 && bb + threadIdx.x < b1) {
+            const uint8_t* mrow = p.marks + ((long)(bb + threadIdx.x) * p.T + t) * p.E;
+            int nm = 0;
+            for (int e = 0; e < p.E; ++e) nm += mrow[e];
+            s_nm[threadIdx.x] = (float)nm;
+        }
+        __syncthreads();
+        if (on)
+            for (int b = bb + rl; b < min(b1, bb + 64); b += rows_par) {
+                const long row = (long)b * p.T + t;
+                const T* d = reinterpret_cast<const T*>(p.dx0) + row * 3 * p.C;
+                const uint64_t base = (uint64_t)row * 3 * p.C;
+                const Frag4<T> g1 = frag_ld<T>(d + p.C + c0), g2 = frag_ld<T>(d + 2 * p.C + c0);
+                const float nm = s_nm[b - bb];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v1 = drop_apply(dk, base + p.C + c0 + j, to_f32(g1.v[j]));
+                    const float v2 = drop_apply(dk, base + 2 * p.C + c0 + j, to_f32(g2.v[j]));
+                    apos[j] += v1;
+                    amk[j] += nm * v2;
+                }
+            }
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sm[(rl * 2 + 0) * p.C + c0 + j] = apos[j];
+            sm[(rl * 2 + 1) * p.C + c0 + j] = amk[j];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * p.C; i += 256) {
+        float a = 0.f;
+        for (int r = 0; r < rows_par; ++r) a += sm[r * 2 * p.C + i];
+        const long slot = (long)chunk * p.T + t;
+        if (i < p.C) p.part_pos[slot * p.C + i] = a;
+        else p.part_mk[slot * p.C + (i - p.C)] = a;
+    }
+}
+
+// d_item[id] += sqrt(C) * dX0[row, :C] (coding.py:62-63).  Item popularity is heavy-tailed (the synthetic
+// Zipf(1.1) stream puts ~1/3 of all tokens on one id), so raw global atomics serialise on the hot rows.  Each
+// block takes SROWS consecutive (b,t) rows, finds for every row the first row of the block with the same id
+// (its "leader"), accumulates into LDS (ds_add_f32) per leader, and issues ONE global atomic per distinct id
+// and channel — the hottest row receives (#blocks) adds instead of (#tokens).
+constexpr int SROWS = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
+    extern __shared__ float acc[];  // [SROWS][C]
+    __shared__ int s_id[SROWS];
+    __shared__ int s_lead[SROWS];
+    const long rows = (long)p.B * p.T, r0 = (long)blockIdx.x * SROWS;
+    const int tid = threadIdx.x;
+    if (tid < SROWS) s_id[tid] = (r0 + tid < rows) ? (int)p.ids[r0 + tid] : 0;
+    for (int i = tid; i < SROWS * p.C; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    if (tid < SROWS) {
+        const int id = s_id[tid];
+        int lead = tid;
+        for (int j = 0; j < tid; ++j)
+            if (s_id[j] == id) { lead = j; break; }
+        s_lead[tid] = lead;
+    }
+    __syncthreads();
+    const int cpr = p.C / 4, rows_par = 256 / cpr;
+    const int cv = tid % cpr, rl = tid / cpr, c0 = cv * 4;
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const float sq = sqrtf((float)p.C);
-    for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-        float apos = 0.f, amk = 0.f;
-        for (int b = b0; b < b1; ++b) {
-            const long row = (long)b * p.T + t;
-            const T* d = reinterpret_cast<const T*>(p.dx0) + row * 3 * p.C;
-            const uint64_t base = (uint64_t)row * 3 * p.C;
-            const float g0 = drop_apply(dk, base + c, to_f32(d[c]));
-            const float g1 = drop_apply(dk, base + p.C + c, to_f32(d[p.C + c]));
-            const float g2 = drop_apply(dk, base + 2 * p.C + c, to_f32(d[2 * p.C + c]));
-            const int64_t id = p.ids[row];
-            if (id != 0) atomicAdd(p.d_item + id * p.C + c, sq * g0);
-            apos += g1;
-            int nm = 0;
-            const uint8_t* mrow = p.marks + row * p.E;
-            for (int e = 0; e < p.E; ++e) nm += mrow[e];
-            amk += (float)nm * g2;
+    if (tid < rows_par * cpr)
+        for (int r = rl; r < SROWS; r += rows_par) {
+            if (s_id[r] == 0) continue;  // padding rows and rows past the end
+            const long row = r0 + r;
+            const Frag4<T> g0 = frag_ld<T>(reinterpret_cast<const T*>(p.dx0) + row * 3 * p.C + c0);
+            float* dst = acc + s_lead[r] * p.C + c0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                atomicAdd(dst + j, sq * drop_apply(dk, (uint64_t)row * 3 * p.C + c0 + j, to_f32(g0.v[j])));
         }
-        float* dst = p.part + (((long)chunk * p.T + t) * 2) * p.C;
-        dst[c] = apos;
-        dst[p.C + c] = amk;
+    __syncthreads();
+    for (int i = tid; i < SROWS * p.C; i += 256) {
+        const int r = i / p.C, c = i % p.C;
+        if (s_lead[r] == r && s_id[r] != 0) atomicAdd(p.d_item + (long)s_id[r] * p.C + c, acc[i]);
     }
 }
 
-__global__ void encode_bwd_final_kernel(const float* part, int nchunk, int T, int C, int E, float* d_pos, float* d_mark) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    // first T*C outputs: d_pos ; next E*C: d_mark_emb (only row 1 is non-zero)
-    if (i < T * C) {
-        const int t = i / C, c = i % C;
-        float a = 0.f;
-        for (int k = 0; k < nchunk; ++k) a += part[(((long)k * T + t) * 2) * C + c];
-        d_pos[i] = a;
-    } else if (i < T * C + E * C) {
-        const int q = i - T * C, e = q / C, c = q % C;
-        float a = 0.f;
-        if (e == 1)
-            for (int k = 0; k < nchunk; ++k)
-                for (int t = 0; t < T; ++t) a += part[(((long)k * T + t) * 2 + 1) * C + c];
-        d_mark[q] = a;
-    }
-}
-
-constexpr int ENC_NCHUNK = 8;
+constexpr int ENC_NCHUNK = 16;
 
 }  // namespace
 
-extern "C" long edgl_encode_bwd_workspace(int B, int T, int C) { (void)B; return (long)ENC_NCHUNK * T * 2 * C; }
+extern "C" long edgl_encode_bwd_workspace(int B, int T, int C) { (void)B; return 2L * ENC_NCHUNK * T * C; }
 
 extern "C" int edgl_encode_fwd(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
                                const float* mark_emb, const uint8_t* mark_table, const float* tscale, int B, int T,
@@ -163,15 +217,39 @@ extern "C" int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const v
     EDGL_REQUIRE(ids && marks && dx0 && d_item && d_pos && d_mark_emb && workspace, EDGL_ERR_NULL,
                  "edgl_encode_bwd: null pointer");
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_encode_bwd: bad dtype %d", dtype);
-    EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, workspace, ENC_NCHUNK};
+    EDGL_REQUIRE(C % 4 == 0 && C / 4 <= 256, EDGL_ERR_SHAPE, "edgl_encode_bwd: C=%d unsupported", C);
+    float* part_pos = workspace;
+    float* part_mk = workspace + (long)ENC_NCHUNK * T * C;
+    EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, part_pos, part_mk, ENC_NCHUNK};
     hipStream_t st = (hipStream_t)stream;
+    const int rows_par = 256 / (C / 4);
     dim3 grid(T, ENC_NCHUNK);
-    if (dtype == EDGL_F32) hipLaunchKernelGGL((encode_bwd_kernel<float>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((encode_bwd_kernel<bf16>), grid, dim3(256), 0, st, p);
+    const size_t smem = (size_t)rows_par * 2 * C * sizeof(float);
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((encode_bwd_kernel<float>), grid, dim3(256), smem, st, p);
+    else hipLaunchKernelGGL((encode_bwd_kernel<bf16>), grid, dim3(256), smem, st, p);
     EDGL_LAUNCH_CHECK();
-    const int total = T * C + E * C;
-    hipLaunchKernelGGL(encode_bwd_final_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, ENC_NCHUNK,
-                       T, C, E, d_pos, d_mark_emb);
-    EDGL_LAUNCH_CHECK();
+    {
+        const size_t smem_s = (size_t)SROWS * C * sizeof(float);
+        EDGL_REQUIRE(smem_s <= 150 * 1024, EDGL_ERR_SHAPE, "edgl_encode_bwd: C=%d too large for the scatter stage", C);
+        const unsigned nb = (unsigned)(((long)B * T + SROWS - 1) / SROWS);
+        if (dtype == EDGL_F32) {
+            hipFuncSetAttribute((const void*)encode_scatter_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
+            hipLaunchKernelGGL((encode_scatter_kernel<float>), dim3(nb), dim3(256), smem_s, st, p);
+        } else {
+            hipFuncSetAttribute((const void*)encode_scatter_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
+            hipLaunchKernelGGL((encode_scatter_kernel<bf16>), dim3(nb), dim3(256), smem_s, st, p);
+        }
+        EDGL_LAUNCH_CHECK();
+    }
+    int rc = edgl_reduce_rows(part_pos, ENC_NCHUNK, T * C, (long)T * C, d_pos, 0, st);
+    if (rc) return rc;
+    if (hipMemsetAsync(d_mark_emb, 0, (size_t)E * C * sizeof(float), st) != hipSuccess) {
+        edgl_set_error("edgl_encode_bwd: memset failed");
+        return EDGL_ERR_LAUNCH;
+    }
+    if (E > 1) {  // only row 1 of the mark-embedding table is ever indexed (EasyDGL.py:87-88)
+        rc = edgl_reduce_rows(part_mk, ENC_NCHUNK * T, C, C, d_mark_emb + C, 0, st);
+        if (rc) return rc;
+    }
     return EDGL_OK;
 }

@@ -167,22 +167,44 @@ int launch_gemm(GemmP p, int a_kc, int b_kc, int splitk, hipStream_t st) {
 }
 
 // ---- column sums (bias gradients) -------------------------------------------------------------
+// block = (N/VEC column vectors) x (256/(N/VEC) row lanes); 16-byte loads; per-block partial [N]
 template <typename T>
-__global__ void colsum_partial_kernel(const T* X, int M, int N, int ld, float* part, int rows_per_block) {
-    // block (bx, by): columns [bx*256 + tid], rows [by*rows_per_block, ...)
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* X, int M, int N, int ld, float* part, int rows_per_block) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    extern __shared__ float sm[];  // [rows_par][N]
+    const int cpv = N / VEC, rows_par = 256 / cpv;
+    const int cv = threadIdx.x % cpv, tr = threadIdx.x / cpv;
+    const bool on = threadIdx.x < rows_par * cpv;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    if (on)
+        for (int r = r0 + tr; r < r1; r += rows_par) {
+            const Vec16<T> v = ld16<T>(X + (long)r * ld + cv * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += to_f32(v.v[j]);
+        }
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sm[tr * N + cv * VEC + j] = acc[j];
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float s = 0.f;
+        for (int t = 0; t < rows_par; ++t) s += sm[t * N + n];
+        part[(long)blockIdx.x * N + n] = s;
+    }
+}
+// generic fallback (N not a multiple of the vector width)
+template <typename T>
+__global__ void colsum_partial_scalar_kernel(const T* X, int M, int N, int ld, float* part, int rows_per_block) {
+    const int n = blockIdx.y * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += to_f32(X[(long)r * ld + n]);
-    part[(long)blockIdx.y * N + n] = s;
-}
-__global__ void colsum_final_kernel(const float* part, int nparts, int N, float* out, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int i = 0; i < nparts; ++i) s += part[(long)i * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    part[(long)blockIdx.x * N + n] = s;
 }
 
 }  // namespace
@@ -210,20 +232,27 @@ extern "C" int edgl_gemm(const void* A, const void* Bm, void* Cm, int M, int N, 
     return EDGL_ERR_DTYPE;
 }
 
+template <typename T>
+int run_colsum(const T* X, int M, int N, int ld, float* out, int accumulate, float* workspace, hipStream_t st) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    int nparts = std::min(256, std::max(1, M / 64));
+    const int rpb = (M + nparts - 1) / nparts;
+    nparts = (M + rpb - 1) / rpb;
+    const bool vec = (N % VEC == 0) && (ld % VEC == 0) && (N / VEC <= 256) && (((uintptr_t)X & 15) == 0);
+    if (vec) {
+        const int rows_par = 256 / (N / VEC);
+        hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(nparts), dim3(256), (size_t)rows_par * N * sizeof(float), st, X, M, N, ld, workspace, rpb);
+    } else {
+        hipLaunchKernelGGL((colsum_partial_scalar_kernel<T>), dim3(nparts, (N + 255) / 256), dim3(256), 0, st, X, M, N, ld, workspace, rpb);
+    }
+    EDGL_LAUNCH_CHECK();
+    return edgl_reduce_rows(workspace, nparts, N, N, out, accumulate, st);
+}
+
 extern "C" int edgl_colsum(const void* X, int M, int N, int ld, float* out, int accumulate, float* workspace,
                            int x_f32, int dtype, void* stream) {
     EDGL_REQUIRE(X && out && workspace, EDGL_ERR_NULL, "edgl_colsum: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    int nparts = std::min(256, std::max(1, M / 64));
-    int rpb = (M + nparts - 1) / nparts;
-    nparts = (M + rpb - 1) / rpb;
-    dim3 grid((N + 255) / 256, nparts);
-    if (x_f32 || dtype == EDGL_F32)
-        hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)X, M, N, ld, workspace, rpb);
-    else
-        hipLaunchKernelGGL((colsum_partial_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)X, M, N, ld, workspace, rpb);
-    EDGL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, workspace, nparts, N, out, accumulate);
-    EDGL_LAUNCH_CHECK();
-    return EDGL_OK;
+    if (x_f32 || dtype == EDGL_F32) return run_colsum<float>((const float*)X, M, N, ld, out, accumulate, workspace, st);
+    return run_colsum<bf16>((const bf16*)X, M, N, ld, out, accumulate, workspace, st);
 }

@@ -194,14 +194,6 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
     }
 }
 
-__global__ void ln_param_reduce_kernel(const float* part, int B, int C, float* dgamma, float* dbeta) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * C) return;
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += part[(long)b * 2 * C + i];
-    if (i < C) dgamma[i] = a; else dbeta[i - C] = a;
-}
-
 int check_ln_shape(int B, int T, int C, int dtype, const char* who) {
     const int vec = dtype == EDGL_BF16 ? 8 : 4;
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
@@ -253,7 +245,7 @@ extern "C" int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_r
     if (dtype == EDGL_F32) hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(B), dim3(LN_THREADS), smem, st, p);
     else hipLaunchKernelGGL((ln_bwd_kernel<bf16>), dim3(B), dim3(LN_THREADS), smem, st, p);
     EDGL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, workspace, B, C, dgamma, dbeta);
-    EDGL_LAUNCH_CHECK();
-    return EDGL_OK;
+    rc = edgl_reduce_rows(workspace, B, C, 2L * C, dgamma, 0, st);
+    if (rc) return rc;
+    return edgl_reduce_rows(workspace + C, B, C, 2L * C, dbeta, 0, st);
 }

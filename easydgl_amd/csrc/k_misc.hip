@@ -165,6 +165,32 @@ __global__ void add_cols_kernel(T* dst, int ld_dst, const T* src, int ld_src, lo
     }
 }
 
+// 32 columns x 8 row lanes per block; each thread keeps 4 independent partial sums in flight
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* part, int P, int N, long ld, float* out, int accumulate) {
+    __shared__ float sm[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + tx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (n < N) {
+        int p = ty;
+        for (; p + 24 < P; p += 32) {
+            a0 += part[(long)p * ld + n];
+            a1 += part[(long)(p + 8) * ld + n];
+            a2 += part[(long)(p + 16) * ld + n];
+            a3 += part[(long)(p + 24) * ld + n];
+        }
+        for (; p < P; p += 8) a0 += part[(long)p * ld + n];
+    }
+    sm[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += sm[i][tx];
+        out[n] = accumulate ? out[n] + s : s;
+    }
+}
+
 template <typename T>
 __global__ void gelu_bwd_kernel(const T* dy, const T* pre, T* dz, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -174,6 +200,12 @@ __global__ void gelu_bwd_kernel(const T* dy, const T* pre, T* dz, long n) {
 inline int grid_for(long n) { return (int)std::min<long>((n + 255) / 256, 4096); }
 
 }  // namespace
+
+int edgl_reduce_rows(const float* part, int P, int N, long ld, float* out, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 31) / 32), dim3(256), 0, st, part, P, N, ld, out, accumulate);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
 
 extern "C" int edgl_rng_advance(uint64_t* rng_state, void* stream) {
     EDGL_REQUIRE(rng_state, EDGL_ERR_NULL, "edgl_rng_advance: null state");

@@ -2,180 +2,245 @@
 //   logits[r, n] = rows[r,:] . table[n,:] + bias[n]   (EasyDGL.py:149-150; table row 0 acts as zeros,
 //   bias = concat([-1000], output_bias) — coding.py:56-57, Base.py:106-110)
 // Training never materialises the [R, I] logits: the forward keeps an online (max, sum-exp) per row
-// (EasyDGL.py:155 softmax), the backward recomputes logit tiles and feeds dl = coef*(p - onehot)
-// straight back into MFMA as an operand:
-//   score_fwd    : grid (row tiles, item chunks)  -> per-chunk (max, sumexp), label logit
-//   score_bwd_dy : grid (row tiles, item chunks)  -> d_rows partial slabs   (contract over items)
-//   score_bwd_dw : grid (item tiles)              -> d_table, d_bias        (contract over rows)
-// 128x128 logit tiles, full-K (K = C <= 256) operand tiles resident in LDS, the streamed operand
-// prefetched through registers.  Operands needed "contraction-major" for the second product are
-// produced from the same LDS tile by one MFMA against the identity (register-layout transpose).
-#include "gemm_tile.h"
+// (EasyDGL.py:155), the backward recomputes logit tiles and feeds dl = coef*(p - onehot) straight back into
+// MFMA as an operand.  All three kernels share one structure:
+//   * a workgroup = 8 waves (512 threads) owns 256 "x" vectors (rows, or table rows) whose MFMA fragments
+//     stay in REGISTERS for the whole kernel; each wave owns a 32-x strip and the full width of every
+//     streamed tile, so no cross-wave reduction is ever needed;
+//   * the other operand ("z": item tiles, or row tiles) streams through LDS in 128-z tiles, double buffered,
+//     prefetched through registers, one barrier per tile;
+//   * logit tile in the swapped orientation  D[z][x]  (register layout L(first=z, second=x)), so that dl is
+//     directly the A operand of the second product  out[x][c] += sum_z dl[x][z] Z[z][c]; its B operand is
+//     read from a second LDS image of the same tile in [c][z] order, filled from a pre-transposed copy of the
+//     operand in HBM (tableT [C][ldt] / rowsT [C][ldr]) — no in-kernel transposes, full-rate 16x16x32 MFMA.
+//   score_fwd_kernel : x = rows,  z = items   -> per-chunk (max, sumexp) [+ optional logits]
+//   score_bwd<ROLE_Y>: x = rows,  z = items   -> d_rows slabs
+//   score_bwd<ROLE_W>: x = items, z = rows    -> d_table slabs, d_bias slabs
+#include "edgl_common.h"
 
 namespace {
-using namespace tile;
 
-constexpr int CHUNK = 2560;  // items per forward/backward chunk (20 tiles of 128)
+constexpr int SNT = 512;   // threads per workgroup
+constexpr int XB = 256;    // x vectors per workgroup (32 per wave)
+constexpr int ZB = 128;    // z vectors per streamed tile
 
 template <typename T, int CT>
-struct FullTile {  // 128 rows x C (=16*CT) elements, LDS row stride LDC
+struct SC {
     static constexpr int VEC = ElemTraits<T>::VEC;
+    static constexpr int KB = ElemTraits<T>::KB;
     static constexpr int C = 16 * CT;
-    static constexpr int LDC = C + VEC;
-    static constexpr int CV = C / VEC;            // vectors per row
-    static constexpr int PER = 128 * CV / NT;     // vectors per thread
-    Vec16<T> reg[PER];
-    __device__ __forceinline__ void load(const T* base, int row0, int rows_total, bool zero_row0) {
+    static constexpr int NKB = C / KB;
+    static constexpr int LDC = C + VEC;       // Z  image: [ZB][LDC]   (row z, k contiguous)
+    static constexpr int LDZ = ZB + VEC;      // ZT image: [C][LDZ]    (row c, z contiguous)
+    static constexpr int CV = C / VEC;
+    static constexpr int PER_Z = ZB * CV / SNT;          // 16-byte vectors per thread, Z image
+    static constexpr int PER_ZT = C * (ZB / VEC) / SNT;  // same count, ZT image
+    static constexpr size_t Z_BYTES = (size_t)ZB * LDC * sizeof(T);
+    static constexpr size_t ZT_BYTES = (size_t)C * LDZ * sizeof(T);
+    static constexpr size_t INFO_BYTES = 3 * ZB * sizeof(float);
+};
+
+struct ScoreP {
+    const void* rows; const void* rowsT; int ldr;      // rows [R][C], rowsT [C][ldr]
+    const void* table; const void* tableT; int ldt;    // table [I][C], tableT [C][ldt]
+    const float* out_bias; const int64_t* labels;
+    int R, C, I, i0, i1;
+    float* row_lse; float* part; float* logits;         // fwd
+    int zchunk, nchunk;                                 // z vectors per block (multiple of ZB), #chunks
+    const float* coef; const float* gscale;             // bwd
+    float* slabs; float* bias_slabs;
+};
+
+// ---- streamed tile: global -> registers -> LDS -------------------------------------------------
+template <typename T, int CT, bool WITH_T>
+struct ZStream {
+    using S = SC<T, CT>;
+    Vec16<T> rz[S::PER_Z];
+    Vec16<T> rt[WITH_T ? S::PER_ZT : 1];
+    // Z image rows [z0, z0+ZB) of src [*, C]; rows >= zend (or global row 0 when zero_row0) read as zeros
+    __device__ __forceinline__ void load(const T* src, const T* srcT, int ldT, int z0, int zend, bool zero_row0) {
+        load_z(src, z0, zend, zero_row0);
+        load_t(srcT, ldT, z0, zend, zero_row0);
+    }
+    __device__ __forceinline__ void load_z(const T* src, int z0, int zend, bool zero_row0) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int v = threadIdx.x + i * NT;
-            const int row = v / CV, cv = v % CV;
-            const int gr = row0 + row;
-            reg[i] = (gr < rows_total && !(zero_row0 && gr == 0)) ? ld16<T>(base + (long)gr * C + cv * VEC) : zero16<T>();
+        for (int i = 0; i < S::PER_Z; ++i) {
+            const int v = threadIdx.x + i * SNT;
+            const int row = v / S::CV, cv = v % S::CV, gz = z0 + row;
+            rz[i] = (gz < zend && !(zero_row0 && gz == 0)) ? ld16<T>(src + (long)gz * S::C + cv * S::VEC) : zero16<T>();
         }
     }
-    __device__ __forceinline__ void store(T* S) {
+    __device__ __forceinline__ void load_t(const T* srcT, int ldT, int z0, int zend, bool zero_row0) {
+        if constexpr (WITH_T) {
+            constexpr int ZV = ZB / S::VEC;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int v = threadIdx.x + i * NT;
-            const int row = v / CV, cv = v % CV;
-            st16<T>(S + row * LDC + cv * VEC, reg[i]);
+            for (int i = 0; i < S::PER_ZT; ++i) {
+                const int v = threadIdx.x + i * SNT;
+                const int c = v / ZV, zv = v % ZV, gz = z0 + zv * S::VEC;
+                const T* p = srcT + (long)c * ldT + gz;
+                if (gz + S::VEC <= zend && !(zero_row0 && gz == 0)) {
+                    rt[i] = ld16<T>(p);
+                } else {
+                    Vec16<T> t = zero16<T>();
+#pragma unroll
+                    for (int j = 0; j < S::VEC; ++j)
+                        if (gz + j < zend && !(zero_row0 && gz + j == 0)) t.v[j] = p[j];
+                    rt[i] = t;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(T* Zs, T* ZTs) {
+#pragma unroll
+        for (int i = 0; i < S::PER_Z; ++i) {
+            const int v = threadIdx.x + i * SNT;
+            st16<T>(Zs + (v / S::CV) * S::LDC + (v % S::CV) * S::VEC, rz[i]);
+        }
+        if constexpr (WITH_T) {
+            constexpr int ZV = ZB / S::VEC;
+#pragma unroll
+            for (int i = 0; i < S::PER_ZT; ++i) {
+                const int v = threadIdx.x + i * SNT;
+                st16<T>(ZTs + (v / ZV) * S::LDZ + (v % ZV) * S::VEC, rt[i]);
+            }
         }
     }
 };
 
-// logit tile: SWAP  -> acc[j][i] = L(first = item n, second = row m)
-//             !SWAP -> acc[i][j] = L(first = row m, second = item n)
-template <typename T, int CT, bool SWAP>
-__device__ __forceinline__ void logit_tile(const T* As, const T* Bs, int wm, int wn, int lane, f32x4 (&acc)[4][4]) {
-    constexpr int VEC = ElemTraits<T>::VEC, KB = ElemTraits<T>::KB, LDC = 16 * CT + VEC, NKB = 16 * CT / KB;
+// x fragments of this wave's 32-x strip, kept in registers
+template <typename T, int CT>
+__device__ __forceinline__ void load_xfrags(const T* X, int x0, int xend, bool zero_row0, int lane,
+                                            Vec16<T> (&xf)[2][SC<T, CT>::NKB]) {
+    using S = SC<T, CT>;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int ix = 0; ix < 2; ++ix) {
+        const int gx = x0 + ix * 16 + (lane & 15);
+        const bool ok = gx < xend && !(zero_row0 && gx == 0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-        Vec16<T> af[4], bf[4];
-        const int koff = kb * KB + (lane >> 4) * VEC;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = ld16<T>(As + (wm * 64 + i * 16 + (lane & 15)) * LDC + koff);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = ld16<T>(Bs + (wn * 64 + j * 16 + (lane & 15)) * LDC + koff);
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if constexpr (SWAP) acc[a][b] = mma_kblock(bf[a], af[b], acc[a][b]);
-                else acc[a][b] = mma_kblock(af[a], bf[b], acc[a][b]);
-            }
+        for (int kb = 0; kb < S::NKB; ++kb)
+            xf[ix][kb] = ok ? ld16<T>(X + (long)gx * S::C + kb * S::KB + (lane >> 4) * S::VEC) : zero16<T>();
     }
 }
 
-struct ScoreP {
-    const void* rows; const void* table; const float* out_bias; const int64_t* labels;
-    int R, C, I, i0, i1;
-    float* row_lse; float* label_logit; float* part;  // part [R][nchunk][2]
-    float* logits;                                    // optional [R, i1-i0]
-    int nchunk;
-    // backward
-    const float* coef; const float* gscale; void* d_rows; float* d_table; float* d_bias; float* slabs;
-};
-
-__device__ __forceinline__ float bias_of(const ScoreP& p, int n) { return n == 0 ? -1000.0f : p.out_bias[n - 1]; }
+// D[z][x] half tile of the wave (64 z = 4 jz tiles starting at jz0): acc[j][ix], L(first = z, second = x).
+// The 128-z tile is processed in two halves so that only 32 accumulator registers are live at a time.
+template <typename T, int CT>
+__device__ __forceinline__ void logit_half(const T* Zs, int jz0, const Vec16<T> (&xf)[2][SC<T, CT>::NKB], int lane,
+                                           f32x4 (&acc)[4][2]) {
+    using S = SC<T, CT>;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kb = 0; kb < S::NKB; ++kb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const Vec16<T> zf = ld16<T>(Zs + ((jz0 + j) * 16 + (lane & 15)) * S::LDC + kb * S::KB + (lane >> 4) * S::VEC);
+            acc[j][0] = mma_kblock(zf, xf[0][kb], acc[j][0]);
+            acc[j][1] = mma_kblock(zf, xf[1][kb], acc[j][1]);
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
-// forward: online log-sum-exp per row over this block's item chunk
+// forward: online log-sum-exp per row over this block's item chunk (+ optional logits)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int CT>
-__global__ __launch_bounds__(NT) void score_fwd_kernel(ScoreP p) {
-    constexpr int LDC = 16 * CT + ElemTraits<T>::VEC;
+__global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
+    using S = SC<T, CT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* As = reinterpret_cast<T*>(smem);
-    T* Bs = As + 128 * LDC;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
-    const int m0 = blockIdx.x * 128;
-    const int c_lo = p.i0 + blockIdx.y * CHUNK, c_hi = min(p.i1, c_lo + CHUNK);
+    constexpr size_t BUF = S::Z_BYTES + ZB * sizeof(float);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int m0 = blockIdx.x * XB + wave * 32;
+    const int c_lo = p.i0 + blockIdx.y * p.zchunk, c_hi = min(p.i1, c_lo + p.zchunk);
     const T* rows = reinterpret_cast<const T*>(p.rows);
     const T* table = reinterpret_cast<const T*>(p.table);
 
-    FullTile<T, CT> ft;
-    ft.load(rows, m0, p.R, false);
-    ft.store(As);
-    ft.load(table, c_lo, c_hi, true);
-    ft.store(Bs);
-    __syncthreads();
-
-    float rmax[4], rsum[4];
-    int64_t lab[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        rmax[i] = -INFINITY; rsum[i] = 0.f;
-        const int m = m0 + wm * 64 + i * 16 + l15;
-        lab[i] = (m < p.R && p.labels) ? p.labels[m] : -1;
+    Vec16<T> xf[2][S::NKB];
+    load_xfrags<T, CT>(rows, m0, p.R, false, lane, xf);
+    ZStream<T, CT, false> zs;
+    const int ntile = (c_hi - c_lo + ZB - 1) / ZB;
+    zs.load(table, nullptr, 0, c_lo, c_hi, true);
+    {
+        T* Zs = reinterpret_cast<T*>(smem);
+        float* info = reinterpret_cast<float*>(smem + S::Z_BYTES);
+        zs.store(Zs, nullptr);
+        if (tid < ZB) { const int n = c_lo + tid; info[tid] = (n < c_hi && n > 0) ? p.out_bias[n - 1] : 0.f; }
     }
-    const int ntile = (c_hi - c_lo + 127) / 128;
+    __syncthreads();
+    float rmax[2] = {-INFINITY, -INFINITY}, rsum[2] = {0.f, 0.f};
     for (int it = 0; it < ntile; ++it) {
-        const int n0 = c_lo + it * 128;
+        const int n0 = c_lo + it * ZB;
         const bool more = it + 1 < ntile;
-        if (more) ft.load(table, n0 + 128, c_hi, true);
-        f32x4 acc[4][4];
-        logit_tile<T, CT, true>(As, Bs, wm, wn, lane, acc);
+        const char* cur = smem + (size_t)(it & 1) * BUF;
+        char* nxt = smem + (size_t)((it + 1) & 1) * BUF;
+        if (more) zs.load(table, nullptr, 0, n0 + ZB, c_hi, true);
+        const T* Zs = reinterpret_cast<const T*>(cur);
+        const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + l15;
-            float v[16];
-            float tmax = -INFINITY;
+        for (int half = 0; half < 2; ++half) {
+            f32x4 acc[4][2];
+            logit_half<T, CT>(Zs, half * 4, xf, lane, acc);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int ix = 0; ix < 2; ++ix) {
+                const int m = m0 + ix * 16 + l15;
+                float tmax = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wn * 64 + j * 16 + g4 + r;
-                    float x = -INFINITY;
-                    if (n < c_hi) {
-                        x = (n == 0) ? -1000.0f : acc[j][i][r] + p.out_bias[n - 1];
-                        if (n == lab[i]) p.label_logit[m] = x;
-                        if (p.logits && m < p.R) p.logits[(long)m * (p.i1 - p.i0) + (n - p.i0)] = x;
+                for (int j = 0; j < 4; ++j) {
+                    const int jz = half * 4 + j;
+                    const float4 bz = *reinterpret_cast<const float4*>(info + jz * 16 + g4);
+                    const float bb[4] = {bz.x, bz.y, bz.z, bz.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n0 + jz * 16 + g4 + r;
+                        float x = acc[j][ix][r] + bb[r];
+                        x = (n == 0) ? -1000.0f : x;       // zero-padded row . y + (-1000)  (Base.py:110)
+                        x = (n < c_hi) ? x : -INFINITY;
+                        acc[j][ix][r] = x;
+                        tmax = fmaxf(tmax, x);
                     }
-                    v[j * 4 + r] = x;
-                    tmax = fmaxf(tmax, x);
                 }
-            const float nm = fmaxf(rmax[i], tmax);
-            if (nm > -INFINITY) {
-                float s = rsum[i] * __expf(rmax[i] - nm);
+                if (p.logits && m < p.R) {
+                    float* dst = p.logits + (long)m * (p.i1 - p.i0) + (n0 - p.i0);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) s += __expf(v[q] - nm);
-                rsum[i] = s;
-                rmax[i] = nm;
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int zz = (half * 4 + j) * 16 + g4 + r;
+                            if (n0 + zz < c_hi) dst[zz] = acc[j][ix][r];
+                        }
+                }
+                const float nm = fmaxf(rmax[ix], tmax);
+                if (nm > -INFINITY) {
+                    float sacc = rsum[ix] * __expf(rmax[ix] - nm);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc += __expf(acc[j][ix][r] - nm);
+                    rsum[ix] = sacc;
+                    rmax[ix] = nm;
+                }
+            }
+        }
+        if (more) {
+            zs.store(reinterpret_cast<T*>(nxt), nullptr);
+            if (tid < ZB) {
+                const int n = n0 + ZB + tid;
+                reinterpret_cast<float*>(nxt + S::Z_BYTES)[tid] = (n < c_hi && n > 0) ? p.out_bias[n - 1] : 0.f;
             }
         }
         __syncthreads();
-        if (more) ft.store(Bs);
-        __syncthreads();
     }
-    // combine the 4 lane groups (same row, different columns) and the two wn waves
-    float* red = reinterpret_cast<float*>(smem);  // [2 wn][128 rows][2] reuse As (all tiles done)
+    // the 4 lane groups of a wave hold disjoint z subsets of the same x: combine them
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float mx = group_max4(rmax[i]);
-        float s = (rmax[i] > -INFINITY) ? rsum[i] * __expf(rmax[i] - mx) : 0.f;
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (lane < 16) {
-            const int lr = wm * 64 + i * 16 + l15;
-            red[(wn * 128 + lr) * 2] = mx;
-            red[(wn * 128 + lr) * 2 + 1] = s;
-        }
-    }
-    __syncthreads();
-    if (tid < 128) {
-        const int m = m0 + tid;
-        if (m < p.R) {
-            const float ma = red[tid * 2], sa = red[tid * 2 + 1], mb = red[(128 + tid) * 2], sb = red[(128 + tid) * 2 + 1];
-            const float mx = fmaxf(ma, mb);
-            float s = 0.f;
-            if (ma > -INFINITY) s += sa * __expf(ma - mx);
-            if (mb > -INFINITY) s += sb * __expf(mb - mx);
+    for (int ix = 0; ix < 2; ++ix) {
+        const float mx = group_max4(rmax[ix]);
+        float s = (rmax[ix] > -INFINITY) ? rsum[ix] * __expf(rmax[ix] - mx) : 0.f;
+        s = group_sum4(s);
+        const int m = m0 + ix * 16 + l15;
+        if (lane < 16 && m < p.R) {
             p.part[((long)m * p.nchunk + blockIdx.y) * 2] = mx;
             p.part[((long)m * p.nchunk + blockIdx.y) * 2 + 1] = s;
         }
@@ -195,258 +260,239 @@ __global__ void lse_combine_kernel(const float* part, int R, int nchunk, float* 
     row_lse[m] = mx + __logf(s);
 }
 
+// label logit: one wave per row (a [R] gather-dot; keeps the label test out of the MFMA epilogue)
+template <typename T>
+__global__ __launch_bounds__(256) void label_logit_kernel(const T* rows, const T* table, const float* out_bias,
+                                                          const int64_t* labels, int R, int C, int i0, int i1, float* out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const int64_t lab = labels[r];
+    if (lab < i0 || lab >= i1) return;
+    float a = 0.f;
+    if (lab != 0)
+        for (int c = lane; c < C; c += 64) a += to_f32(rows[(long)r * C + c]) * to_f32(table[lab * C + c]);
+    a = wave_sum(a);
+    if (lane == 0) out[r] = (lab == 0) ? -1000.0f : a + out_bias[lab - 1];
+}
+
 // ---------------------------------------------------------------------------------------------
-// backward 1: d_rows[m, :] = sum_n dl[m, n] table[n, :]    (block = row tile x item chunk)
+// backward: ROLE_Y (x = rows, z = items) -> d_rows ; ROLE_W (x = items, z = rows) -> d_table, d_bias
 // ---------------------------------------------------------------------------------------------
-template <typename T, int CT>
-__global__ __launch_bounds__(NT) void score_bwd_dy_kernel(ScoreP p) {
-    constexpr int LDC = 16 * CT + ElemTraits<T>::VEC;
+enum { ROLE_Y = 0, ROLE_W = 1 };
+
+template <typename T, int CT, int ROLE>
+__global__ __launch_bounds__(SNT) void score_bwd_kernel(ScoreP p) {
+    using S = SC<T, CT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* As = reinterpret_cast<T*>(smem);
-    T* Bs = As + 128 * LDC;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
-    const int m0 = blockIdx.x * 128;
-    const int c_lo = p.i0 + blockIdx.y * CHUNK, c_hi = min(p.i1, c_lo + CHUNK);
+    constexpr size_t BUF = S::Z_BYTES + S::ZT_BYTES + S::INFO_BYTES;
+    constexpr bool DOUBLE = 2 * BUF <= 160 * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const T* rows = reinterpret_cast<const T*>(p.rows);
+    const T* rowsT = reinterpret_cast<const T*>(p.rowsT);
     const T* table = reinterpret_cast<const T*>(p.table);
-    const Frag4<T> ident = identity_frag<T>(lane);
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    FullTile<T, CT> ft;
-    ft.load(rows, m0, p.R, false);
-    ft.store(As);
-    ft.load(table, c_lo, c_hi, true);
-    ft.store(Bs);
-    __syncthreads();
-
-    const float gs = p.gscale ? p.gscale[0] : 1.0f;
-    float lse[4], cf[4];
-    int64_t lab[4];
+    const T* tableT = reinterpret_cast<const T*>(p.tableT);
+    // x side
+    const int xbase = (ROLE == ROLE_Y ? 0 : p.i0) + blockIdx.x * XB + wave * 32;
+    const int xend = ROLE == ROLE_Y ? p.R : p.i1;
+    Vec16<T> xf[2][S::NKB];
+    load_xfrags<T, CT>(ROLE == ROLE_Y ? rows : table, xbase, xend, ROLE == ROLE_W, lane, xf);
+    float x_lse[2], x_cf[2], x_bias[2];
+    int x_lab[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
-        const bool ok = m < p.R;
-        lse[i] = ok ? p.row_lse[m] : INFINITY;
-        cf[i] = ok ? p.coef[m] * gs : 0.f;
-        lab[i] = ok ? p.labels[m] : -1;
+    for (int ix = 0; ix < 2; ++ix) {
+        const int gx = xbase + ix * 16 + l15;
+        const bool ok = gx < xend;
+        if (ROLE == ROLE_Y) {
+            x_cf[ix] = ok ? p.coef[gx] : 0.f;
+            // coef*exp(x - lse) = exp(x - (lse - log coef)); coef == 0 (label 0 / row past the end) -> +inf -> 0
+            x_lse[ix] = x_cf[ix] > 0.f ? p.row_lse[gx] - __logf(x_cf[ix]) : INFINITY;
+            x_lab[ix] = ok ? (int)p.labels[gx] : -1;
+            x_bias[ix] = 0.f;
+        } else {
+            x_bias[ix] = (ok && gx > 0) ? p.out_bias[gx - 1] : 0.f;
+            x_lse[ix] = 0.f; x_cf[ix] = 0.f; x_lab[ix] = ok ? gx : -2;   // x_lab = own item id
+        }
     }
-    f32x4 dy[4][CT];  // [row tile i][channel tile ct], L(first = m, second = c)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) dy[i][ct] = zero4;
+    // z side
+    const int z_lo = (ROLE == ROLE_Y ? p.i0 : 0) + blockIdx.y * p.zchunk;
+    const int z_hi = min(ROLE == ROLE_Y ? p.i1 : p.R, z_lo + p.zchunk);
+    const T* zsrc = ROLE == ROLE_Y ? table : rows;
+    const T* zsrcT = ROLE == ROLE_Y ? tableT : rowsT;
+    const int ldT = ROLE == ROLE_Y ? p.ldt : p.ldr;
 
-    const int ntile = (c_hi - c_lo + 127) / 128;
+    auto fill_info = [&](char* buf, int z0) {
+        float* info = reinterpret_cast<float*>(buf + S::Z_BYTES + S::ZT_BYTES);
+        if (tid < ZB) {
+            const int gz = z0 + tid;
+            const bool ok = gz < z_hi;
+            if (ROLE == ROLE_Y) {
+                info[tid] = (ok && gz > 0) ? p.out_bias[gz - 1] : 0.f;
+            } else {
+                const float cf = ok ? p.coef[gz] : 0.f;
+                info[tid] = cf > 0.f ? p.row_lse[gz] - __logf(cf) : INFINITY;
+                info[ZB + tid] = cf;
+                reinterpret_cast<int*>(info)[2 * ZB + tid] = ok ? (int)p.labels[gz] : -1;
+            }
+        }
+    };
+
+    f32x4 out[2][CT];
+#pragma unroll
+    for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) out[ix][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbias[2] = {0.f, 0.f};
+
+    ZStream<T, CT, true> zs;
+    const int ntile = (z_hi - z_lo + ZB - 1) / ZB;
+    if (ntile > 0) {
+        zs.load(zsrc, zsrcT, ldT, z_lo, z_hi, ROLE == ROLE_Y);
+        zs.store(reinterpret_cast<T*>(smem), reinterpret_cast<T*>(smem + S::Z_BYTES));
+        fill_info(smem, z_lo);
+    }
+    __syncthreads();
     for (int it = 0; it < ntile; ++it) {
-        const int n0 = c_lo + it * 128;
+        const int z0 = z_lo + it * ZB;
         const bool more = it + 1 < ntile;
-        if (more) ft.load(table, n0 + 128, c_hi, true);
-        f32x4 acc[4][4];
-        logit_tile<T, CT, true>(As, Bs, wm, wn, lane, acc);  // acc[j][i] = L(first=n, second=m)
-        Frag4<T> dl[4][4];
+        char* cur = smem + (DOUBLE ? (size_t)(it & 1) * BUF : 0);
+        char* nxt = smem + (DOUBLE ? (size_t)((it + 1) & 1) * BUF : 0);
+        if (more) zs.load_z(zsrc, z0 + ZB, z_hi, ROLE == ROLE_Y);
+        const T* Zs = reinterpret_cast<const T*>(cur);
+        const T* ZTs = reinterpret_cast<const T*>(cur + S::Z_BYTES);
+        const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES + S::ZT_BYTES);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int half = 0; half < 2; ++half) {
+            f32x4 acc[4][2];
+            logit_half<T, CT>(Zs, half * 4, xf, lane, acc);
+            // ---- dl[z][x] in place ------------------------------------------------------------------
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wn * 64 + j * 16 + g4 + r;
-                    float d = 0.f;
-                    if (n < c_hi) {
-                        const float x = (n == 0) ? -1000.0f : acc[j][i][r] + p.out_bias[n - 1];
-                        d = cf[i] * (__expf(x - lse[i]) - (n == lab[i] ? 1.0f : 0.0f));
-                    }
-                    dl[j][i].v[r] = from_f32<T>(d);
+            for (int j = 0; j < 4; ++j) {
+                const int jz = half * 4 + j;
+                float zb[4];   // ROLE_Y: bias[z] ; ROLE_W: lse[z] - log coef[z]
+                int zlab[4];
+                {
+                    const float4 t = *reinterpret_cast<const float4*>(info + jz * 16 + g4);
+                    zb[0] = t.x; zb[1] = t.y; zb[2] = t.z; zb[3] = t.w;
                 }
+                if (ROLE == ROLE_W) {
+                    const int4 c4 = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(info) + 2 * ZB + jz * 16 + g4);
+                    zlab[0] = c4.x; zlab[1] = c4.y; zlab[2] = c4.z; zlab[3] = c4.w;
+                }
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gz = z0 + jz * 16 + g4 + r;
+                        float d;
+                        if (ROLE == ROLE_Y) {
+                            float x = acc[j][ix][r] + zb[r];
+                            x = (gz == 0) ? -1000.0f : x;
+                            d = __expf(x - x_lse[ix]);
+                            if (gz == x_lab[ix]) d -= x_cf[ix];
+                            d = (gz < z_hi) ? d : 0.f;
+                        } else {
+                            float x = acc[j][ix][r] + x_bias[ix];
+                            x = (x_lab[ix] == 0) ? -1000.0f : x;
+                            d = __expf(x - zb[r]);
+                            if (x_lab[ix] == zlab[r]) d -= info[ZB + jz * 16 + g4 + r];   // rare: ~1 hit per tile
+                            d = (x_lab[ix] >= 0) ? d : 0.f;     // x beyond the table shard
+                            dbias[ix] += d;
+                        }
+                        acc[j][ix][r] = d;
+                    }
             }
-        // dy[m][c] += sum_n dl[m][n] table[n][c]: A = dl (A[m'=m][kk=n]), B = table tile transposed to L(n, c)
+            // ---- out[x][c] += sum_z dl[x][z] Z[z][c] --------------------------------------------------
+            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+                for (int jp = 0; jp < 2; ++jp) {
+                    bf16x8 af[2];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const Frag4<T> tf = frag_ld<T>(Bs + (wn * 64 + j * 16 + l15) * LDC + ct * 16 + g4);  // L(first=c, second=n)
-                const Frag4<T> tT = frag_from_acc<T>(mma16(tf, ident, zero4));                        // L(first=n, second=c)
+                    for (int ix = 0; ix < 2; ++ix)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dy[i][ct] = mma16(dl[j][i], tT, dy[i][ct]);
-            }
-        __syncthreads();
-        if (more) ft.store(Bs);
-        __syncthreads();
-    }
-    // dy regs: reg r <-> m = ...+g4+r, lane l15 <-> c.  Combine the two wn waves through LDS, then write the slab.
-    float* red = reinterpret_cast<float*>(smem);  // [2 wm][64 m][C] floats  (<= 2*64*256*4 = 128 KB worst; fits the tile area for CT<=8 ... checked on host)
-    if (wn == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[((wm * 64 + i * 16 + g4 + r) * (16 * CT)) + ct * 16 + l15] = dy[i][ct][r];
-    }
-    __syncthreads();
-    if (wn == 0) {
-        float* slab = p.slabs + (long)blockIdx.y * p.R * (16 * CT);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + g4 + r;
-                if (m < p.R) {
+                        for (int r = 0; r < 4; ++r) {
+                            af[ix][r] = (bf16)acc[2 * jp][ix][r];
+                            af[ix][4 + r] = (bf16)acc[2 * jp + 1][ix][r];
+                        }
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        const int c = ct * 16 + l15;
-                        slab[(long)m * (16 * CT) + c] = dy[i][ct][r] + red[((wm * 64 + i * 16 + g4 + r) * (16 * CT)) + c];
+                        const T* zt = ZTs + (ct * 16 + l15) * S::LDZ + (half * 2 + jp) * 32 + g4;
+                        bf16x8 bfr;
+                        *reinterpret_cast<uint2*>(&bfr) = *reinterpret_cast<const uint2*>(zt);
+                        *(reinterpret_cast<uint2*>(&bfr) + 1) = *reinterpret_cast<const uint2*>(zt + 16);
+                        out[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr, out[0][ct], 0, 0, 0);
+                        out[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr, out[1][ct], 0, 0, 0);
                     }
                 }
-            }
-    }
-}
-
-template <typename T>
-__global__ void slab_reduce_kernel(const float* slabs, int nslab, long n, T* out) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float a = 0.f;
-        for (int s = 0; s < nslab; ++s) a += slabs[(long)s * n + i];
-        out[i] = from_f32<T>(a);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// backward 2: d_table[n, :] = sum_m dl[m, n] rows[m, :],  d_bias[n-1] = sum_m dl[m, n]
-//             (block = one item tile, loops over all row tiles)
-// ---------------------------------------------------------------------------------------------
-template <typename T, int CT>
-__global__ __launch_bounds__(NT) void score_bwd_dw_kernel(ScoreP p) {
-    constexpr int LDC = 16 * CT + ElemTraits<T>::VEC;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* As = reinterpret_cast<T*>(smem);
-    T* Bs = As + 128 * LDC;
-    float* rowinfo = reinterpret_cast<float*>(Bs + 128 * LDC);  // [128][2] (lse, coef) + labels as int
-    int* rowlab = reinterpret_cast<int*>(rowinfo + 256);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
-    const int n0 = p.i0 + blockIdx.x * 128;
-    const T* rows = reinterpret_cast<const T*>(p.rows);
-    const T* table = reinterpret_cast<const T*>(p.table);
-    const Frag4<T> ident = identity_frag<T>(lane);
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const float gs = p.gscale ? p.gscale[0] : 1.0f;
-
-    FullTile<T, CT> ft;
-    ft.load(table, n0, p.i1, true);
-    ft.store(Bs);
-    ft.load(rows, 0, p.R, false);
-    ft.store(As);
-    if (tid < 128) {
-        const bool ok = tid < p.R;
-        rowinfo[tid * 2] = ok ? p.row_lse[tid] : INFINITY;
-        rowinfo[tid * 2 + 1] = ok ? p.coef[tid] * gs : 0.f;
-        rowlab[tid] = ok ? (int)p.labels[tid] : -1;
-    }
-    __syncthreads();
-
-    float bj[4];  // bias of this lane's 4 item columns (j tiles), n = n0 + wn*64 + j*16 + l15
-    float dbias[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + l15;
-        bj[j] = (n < p.i1 && n > 0) ? p.out_bias[n - 1] : 0.f;
-    }
-    f32x4 dw[4][CT];  // [item tile j][channel tile ct], L(first = n, second = c)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) dw[j][ct] = zero4;
-
-    const int ntile = (p.R + 127) / 128;
-    for (int mt = 0; mt < ntile; ++mt) {
-        const int m0 = mt * 128;
-        const bool more = mt + 1 < ntile;
-        if (more) ft.load(rows, m0 + 128, p.R, false);
-        f32x4 acc[4][4];
-        logit_tile<T, CT, false>(As, Bs, wm, wn, lane, acc);  // acc[i][j] = L(first=m, second=n)
-        Frag4<T> dl[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lr = wm * 64 + i * 16 + g4 + r;
-                const float lse = rowinfo[lr * 2], cf = rowinfo[lr * 2 + 1];
-                const int lab = rowlab[lr];
+            } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wn * 64 + j * 16 + l15;
-                    float d = 0.f;
-                    if (n < p.i1) {
-                        const float x = (n == 0) ? -1000.0f : acc[i][j][r] + bj[j];
-                        d = cf * (__expf(x - lse) - (n == lab ? 1.0f : 0.0f));
-                    }
-                    dbias[j] += d;
-                    dl[i][j].v[r] = from_f32<T>(d);
-                }
-            }
-        // dw[n][c] += sum_m dl[m][n] rows[m][c]: A = dl (A[m'=n][kk=m]), B = rows tile transposed to L(m, c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const Frag4<T> yf = frag_ld<T>(As + (wm * 64 + i * 16 + l15) * LDC + ct * 16 + g4);  // L(first=c, second=m)
-                const Frag4<T> yT = frag_from_acc<T>(mma16(yf, ident, zero4));                        // L(first=m, second=c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dw[j][ct] = mma16(dl[i][j], yT, dw[j][ct]);
-            }
-        __syncthreads();
-        if (more) {
-            ft.store(As);
-            const int m = m0 + 128 + tid;
-            if (tid < 128) {
-                const bool ok = m < p.R;
-                rowinfo[tid * 2] = ok ? p.row_lse[m] : INFINITY;
-                rowinfo[tid * 2 + 1] = ok ? p.coef[m] * gs : 0.f;
-                rowlab[tid] = ok ? (int)p.labels[m] : -1;
-            }
-        }
-        __syncthreads();
-    }
-    // combine the two wm waves (same items, different rows) through LDS
-    float* red = reinterpret_cast<float*>(smem);  // [2 wn][64 n][C] + [128] bias
-    float* redb = red + 2 * 64 * 16 * CT;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dbias[j] = group_sum4(dbias[j]);
-    if (wm == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[((wn * 64 + j * 16 + g4 + r) * (16 * CT)) + ct * 16 + l15] = dw[j][ct][r];
-            if (lane < 16) redb[wn * 64 + j * 16 + l15] = dbias[j];
-        }
-    }
-    __syncthreads();
-    if (wm == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 64 + j * 16 + g4 + r;
-                if (n < p.i1) {
+                    const Frag4<T> a0 = frag_from_acc<T>(acc[j][0]), a1 = frag_from_acc<T>(acc[j][1]);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        const int c = ct * 16 + l15;
-                        const float v = dw[j][ct][r] + red[((wn * 64 + j * 16 + g4 + r) * (16 * CT)) + c];
-                        p.d_table[(long)n * (16 * CT) + c] = (n == 0) ? 0.f : v;
+                        const Frag4<T> bfr = frag_ld<T>(ZTs + (ct * 16 + l15) * S::LDZ + (half * 4 + j) * 16 + g4);
+                        out[0][ct] = mma16(a0, bfr, out[0][ct]);
+                        out[1][ct] = mma16(a1, bfr, out[1][ct]);
                     }
                 }
             }
-            if (lane < 16) {
-                const int n = n0 + wn * 64 + j * 16 + l15;
-                if (n < p.i1 && n > 0) p.d_bias[n - 1] = dbias[j] + redb[wn * 64 + j * 16 + l15];
+        }
+        if (!DOUBLE) __syncthreads();
+        if (more) {
+            zs.load_t(zsrcT, ldT, z0 + ZB, z_hi, ROLE == ROLE_Y);   // short-lived: the other wave of the SIMD covers it
+            zs.store(reinterpret_cast<T*>(nxt), reinterpret_cast<T*>(nxt + S::Z_BYTES));
+            fill_info(nxt, z0 + ZB);
+        }
+        __syncthreads();
+    }
+    // ---- write the slab: out regs r <-> x = ix*16 + g4 + r, lane l15 <-> c = ct*16 + l15 ----------------
+    const long nx = ROLE == ROLE_Y ? p.R : p.I;
+    float* slab = p.slabs + (long)blockIdx.y * nx * S::C;
+#pragma unroll
+    for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gx = xbase + ix * 16 + g4 + r;
+            if (gx < xend) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) slab[(long)gx * S::C + ct * 16 + l15] = out[ix][ct][r];
             }
         }
+    if (ROLE == ROLE_W) {
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix) {
+            const float v = group_sum4(dbias[ix]);
+            const int gx = xbase + ix * 16 + l15;
+            if (lane < 16 && gx < xend && gx > 0) p.bias_slabs[(long)blockIdx.y * (p.I - 1) + gx - 1] = v;
+        }
+    }
+}
+
+// out[i] = (T) sum_s slabs[s][i]; `zero_first` elements at the front are forced to 0 (table row 0)
+template <typename TO>
+__global__ void slab_reduce_kernel(const float* slabs, int nslab, long n, long lo, long hi, long zero_first,
+                                   const float* gscale, TO* out) {
+    const float gs = gscale ? gscale[0] : 1.0f;   // upstream d(loss) scalar
+    for (long i = lo + (long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < nslab; ++s) a += slabs[(long)s * n + i];
+        out[i] = from_f32<TO>(i < zero_first ? 0.f : a * gs);
+    }
+}
+
+// [rows, C] -> [C, ld] transposed copy (operand images for the second MFMA product)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* src, long rows, int C, T* dst, long ld) {
+    __shared__ T tile[64][65];
+    const long r0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i / 64, c = i % 64;
+        tile[r][c] = (r0 + r < rows && c0 + c < C) ? src[(r0 + r) * C + c0 + c] : from_f32<T>(0.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i / 64, r = i % 64;
+        if (c0 + c < C && r0 + r < ld) dst[(long)(c0 + c) * ld + r0 + r] = tile[r][c];
     }
 }
 
@@ -638,69 +684,143 @@ __global__ void rank_metrics_kernel(const int32_t* topk, int R, int K, const int
     }
 }
 
-template <typename T, int CT>
-size_t score_smem() { return (size_t)2 * 128 * (16 * CT + ElemTraits<T>::VEC) * sizeof(T); }
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct Chunking { int nchunk, zchunk; };
+inline Chunking pick_chunks(int xblocks, int ztotal, int target_blocks) {
+    const int ntiles = std::max(1, (ztotal + ZB - 1) / ZB);
+    int nchunk = std::min(ntiles, std::max(1, target_blocks / std::max(1, xblocks)));
+    const int per = (ntiles + nchunk - 1) / nchunk;
+    nchunk = (ntiles + per - 1) / per;
+    return Chunking{nchunk, per * ZB};
+}
+inline int xblocks_of(int n) { return (n + XB - 1) / XB; }
+inline long up8(long v) { return (v + 7) / 8 * 8; }
+
+struct BwdPlan {
+    Chunking y, w;
+    long off_rowsT, off_tableT, off_slabY, off_slabW, off_slabB, total;  // float offsets
+};
+inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize) {
+    BwdPlan b;
+    b.y = pick_chunks(xblocks_of(R), n_items, 512);
+    b.w = pick_chunks(xblocks_of(n_items), R, 512);
+    long o = 0;
+    auto take = [&](long floats) { const long at = o; o += (floats + 63) / 64 * 64; return at; };
+    b.off_rowsT = take(((long)C * up8(R) * (long)esize + 3) / 4);
+    b.off_tableT = take(((long)C * up8(I) * (long)esize + 3) / 4);
+    b.off_slabY = take((long)b.y.nchunk * R * C);
+    b.off_slabW = take((long)b.w.nchunk * I * C);
+    b.off_slabB = take((long)b.w.nchunk * (I - 1));
+    b.total = o;
+    return b;
+}
 
 template <typename T, int CT>
 int run_fwd(ScoreP p, hipStream_t st) {
-    const size_t smem = score_smem<T, CT>();
+    using S = SC<T, CT>;
+    const size_t smem = 2 * (S::Z_BYTES + ZB * sizeof(float));
     auto k = score_fwd_kernel<T, CT>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, dim3((p.R + 127) / 128, p.nchunk), dim3(NT), smem, st, p);
-    EDGL_LAUNCH_CHECK();
-    return EDGL_OK;
-}
-template <typename T, int CT>
-int run_bwd(ScoreP p, hipStream_t st) {
-    const size_t tile = score_smem<T, CT>();
-    const size_t red1 = (size_t)2 * 64 * 16 * CT * sizeof(float);
-    const size_t smem1 = std::max(tile, red1);
-    auto k1 = score_bwd_dy_kernel<T, CT>;
-    hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem1);
-    hipLaunchKernelGGL(k1, dim3((p.R + 127) / 128, p.nchunk), dim3(NT), smem1, st, p);
-    EDGL_LAUNCH_CHECK();
-    const long n = (long)p.R * p.C;
-    hipLaunchKernelGGL((slab_reduce_kernel<T>), dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st,
-                       p.slabs, p.nchunk, n, reinterpret_cast<T*>(p.d_rows));
-    EDGL_LAUNCH_CHECK();
-    const size_t smem2 = std::max(tile + 128 * 3 * sizeof(float), red1 + 128 * sizeof(float));
-    auto k2 = score_bwd_dw_kernel<T, CT>;
-    hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-    hipLaunchKernelGGL(k2, dim3((p.i1 - p.i0 + 127) / 128), dim3(NT), smem2, st, p);
+    hipLaunchKernelGGL(k, dim3(xblocks_of(p.R), p.nchunk), dim3(SNT), smem, st, p);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
 
-template <typename T>
-int dispatch_ct(ScoreP p, bool bwd, hipStream_t st) {
-    const int maxc = sizeof(T) == 4 ? 128 : 256;
-    EDGL_REQUIRE(p.C % 32 == 0 && p.C >= 32 && p.C <= maxc && (p.C & (p.C - 1)) == 0, EDGL_ERR_SHAPE,
-                 "edgl_score: C=%d unsupported (power of two in [32, %d])", p.C, maxc);
-    switch (p.C / 16) {
-        case 2: return bwd ? run_bwd<T, 2>(p, st) : run_fwd<T, 2>(p, st);
-        case 4: return bwd ? run_bwd<T, 4>(p, st) : run_fwd<T, 4>(p, st);
-        case 8: return bwd ? run_bwd<T, 8>(p, st) : run_fwd<T, 8>(p, st);
-        case 16:
-            if constexpr (sizeof(T) == 2) return bwd ? run_bwd<T, 16>(p, st) : run_fwd<T, 16>(p, st);
+template <typename T, int CT>
+int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_table, float* d_bias, hipStream_t st) {
+    using S = SC<T, CT>;
+    constexpr size_t BUF = S::Z_BYTES + S::ZT_BYTES + S::INFO_BYTES;
+    const size_t smem = (2 * BUF <= 160 * 1024) ? 2 * BUF : BUF;
+    EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_score_ce_bwd: C=%d needs %zu B of LDS", p.C, smem);
+    // operand images for the second product: rowsT [C][ldr], tableT [C][ldt]
+    T* rowsT = reinterpret_cast<T*>(ws + plan.off_rowsT);
+    T* tableT = reinterpret_cast<T*>(ws + plan.off_tableT);
+    p.ldr = (int)up8(p.R); p.ldt = (int)up8(p.I);
+    hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)((p.ldr + 63) / 64), (p.C + 63) / 64), dim3(256), 0, st,
+                       reinterpret_cast<const T*>(p.rows), (long)p.R, p.C, rowsT, (long)p.ldr);
+    EDGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)((p.ldt + 63) / 64), (p.C + 63) / 64), dim3(256), 0, st,
+                       reinterpret_cast<const T*>(p.table), (long)p.I, p.C, tableT, (long)p.ldt);
+    EDGL_LAUNCH_CHECK();
+    p.rowsT = rowsT; p.tableT = tableT;
+    // d_rows
+    {
+        ScoreP q = p;
+        q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY;
+        auto k = score_bwd_kernel<T, CT, ROLE_Y>;
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, dim3(xblocks_of(p.R), q.nchunk), dim3(SNT), smem, st, q);
+        EDGL_LAUNCH_CHECK();
+        const long n = (long)p.R * p.C;
+        hipLaunchKernelGGL((slab_reduce_kernel<T>), dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st,
+                           q.slabs, q.nchunk, n, 0L, n, 0L, p.gscale, reinterpret_cast<T*>(d_rows));
+        EDGL_LAUNCH_CHECK();
     }
-    edgl_set_error("edgl_score: C=%d unsupported", p.C);
-    return EDGL_ERR_SHAPE;
+    // d_table, d_bias
+    {
+        ScoreP q = p;
+        q.zchunk = plan.w.zchunk; q.nchunk = plan.w.nchunk; q.slabs = ws + plan.off_slabW; q.bias_slabs = ws + plan.off_slabB;
+        auto k = score_bwd_kernel<T, CT, ROLE_W>;
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0), q.nchunk), dim3(SNT), smem, st, q);
+        EDGL_LAUNCH_CHECK();
+        const long n = (long)p.I * p.C, lo = (long)p.i0 * p.C, hi = (long)p.i1 * p.C;
+        hipLaunchKernelGGL((slab_reduce_kernel<float>), dim3((unsigned)std::min<long>((hi - lo + 255) / 256, 2048)), dim3(256), 0,
+                           st, q.slabs, q.nchunk, n, lo, hi, (long)p.C, p.gscale, d_table);
+        EDGL_LAUNCH_CHECK();
+        const long nb = p.I - 1, blo = std::max(p.i0, 1) - 1, bhi = p.i1 - 1;
+        if (bhi > blo) {
+            hipLaunchKernelGGL((slab_reduce_kernel<float>), dim3((unsigned)std::min<long>((bhi - blo + 255) / 256, 2048)), dim3(256),
+                               0, st, q.bias_slabs, q.nchunk, nb, blo, bhi, 0L, p.gscale, d_bias);
+            EDGL_LAUNCH_CHECK();
+        }
+    }
+    return EDGL_OK;
 }
 
 int check_score(const void* rows, const void* table, const float* out_bias, int R, int C, int I, int i0, int i1,
                 int dtype, const char* who) {
     EDGL_REQUIRE(rows && table && out_bias, EDGL_ERR_NULL, "%s: null pointer", who);
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
-    EDGL_REQUIRE(R > 0 && I > 1 && i0 >= 0 && i1 <= I && i0 < i1, EDGL_ERR_SHAPE, "%s: bad shape R=%d I=%d [%d,%d)", who,
-                 R, I, i0, i1);
-    EDGL_REQUIRE(((uintptr_t)rows & 15) == 0 && ((uintptr_t)table & 15) == 0, EDGL_ERR_SHAPE, "%s: operands must be 16-byte aligned", who);
-    (void)C;
+    EDGL_REQUIRE(R > 0 && I > 1 && i0 >= 0 && i1 <= I && i0 < i1 && (i0 % 8) == 0, EDGL_ERR_SHAPE,
+                 "%s: bad shape R=%d I=%d [%d,%d) (i0 must be a multiple of 8)", who, R, I, i0, i1);
+    EDGL_REQUIRE(((uintptr_t)rows & 15) == 0 && ((uintptr_t)table & 15) == 0, EDGL_ERR_SHAPE,
+                 "%s: operands must be 16-byte aligned", who);
+    const int maxc = dtype == EDGL_F32 ? 128 : 256;
+    EDGL_REQUIRE(C >= 32 && C <= maxc && (C & (C - 1)) == 0, EDGL_ERR_SHAPE, "%s: C=%d unsupported (power of two in [32, %d])",
+                 who, C, maxc);
     return EDGL_OK;
+}
+
+#define SCORE_DISPATCH(T, CALL)                                      \
+    switch (C / 16) {                                                \
+        case 2: return CALL(T, 2);                                   \
+        case 4: return CALL(T, 4);                                   \
+        case 8: return CALL(T, 8);                                   \
+        case 16: if constexpr (sizeof(T) == 2) return CALL(T, 16);   \
+    }                                                                \
+    edgl_set_error("edgl_score: C=%d unsupported", C);               \
+    return EDGL_ERR_SHAPE;
+
+template <typename T>
+int fwd_dispatch(ScoreP p, int C, hipStream_t st) {
+#define CALL_FWD(T, CT) run_fwd<T, CT>(p, st)
+    SCORE_DISPATCH(T, CALL_FWD)
+#undef CALL_FWD
+}
+template <typename T>
+int bwd_dispatch(ScoreP p, int C, const BwdPlan& plan, float* ws, void* d_rows, float* d_table, float* d_bias, hipStream_t st) {
+#define CALL_BWD(T, CT) run_bwd<T, CT>(p, plan, ws, d_rows, d_table, d_bias, st)
+    SCORE_DISPATCH(T, CALL_BWD)
+#undef CALL_BWD
 }
 
 }  // namespace
 
-extern "C" int edgl_score_chunks(int n_items) { return (n_items + CHUNK - 1) / CHUNK; }
+extern "C" int edgl_score_chunks(int R, int n_items) { return pick_chunks(xblocks_of(R), n_items, 1024).nchunk; }
 
 extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                                   int R, int C, int I, int i0, int i1, float* row_lse, float* label_logit,
@@ -710,13 +830,21 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
     EDGL_REQUIRE(row_lse && workspace && (!labels || label_logit), EDGL_ERR_NULL, "edgl_score_lse_fwd: null output");
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
-    p.i1 = i1; p.row_lse = row_lse; p.label_logit = label_logit; p.part = workspace; p.logits = logits;
-    p.nchunk = edgl_score_chunks(i1 - i0);
+    p.i1 = i1; p.row_lse = row_lse; p.part = workspace; p.logits = logits;
+    const Chunking ch = pick_chunks(xblocks_of(R), i1 - i0, 1024);
+    p.nchunk = ch.nchunk; p.zchunk = ch.zchunk;
     hipStream_t st = (hipStream_t)stream;
-    rc = dtype == EDGL_F32 ? dispatch_ct<float>(p, false, st) : dispatch_ct<bf16>(p, false, st);
+    rc = dtype == EDGL_F32 ? fwd_dispatch<float>(p, C, st) : fwd_dispatch<bf16>(p, C, st);
     if (rc) return rc;
     hipLaunchKernelGGL(lse_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, st, workspace, R, p.nchunk, row_lse);
     EDGL_LAUNCH_CHECK();
+    if (labels) {
+        if (dtype == EDGL_F32)
+            hipLaunchKernelGGL((label_logit_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, st, (const float*)rows, (const float*)table, out_bias, labels, R, C, i0, i1, label_logit);
+        else
+            hipLaunchKernelGGL((label_logit_kernel<bf16>), dim3((R + 3) / 4), dim3(256), 0, st, (const bf16*)rows, (const bf16*)table, out_bias, labels, R, C, i0, i1, label_logit);
+        EDGL_LAUNCH_CHECK();
+    }
     return EDGL_OK;
 }
 
@@ -728,7 +856,9 @@ extern "C" int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, 
     return EDGL_OK;
 }
 
-extern "C" long edgl_score_bwd_workspace(int R, int C, int n_items) { return (long)edgl_score_chunks(n_items) * R * C; }
+extern "C" long edgl_score_bwd_workspace(int R, int C, int I, int n_items, int dtype) {
+    return bwd_plan(R, C, I, n_items, dtype == EDGL_BF16 ? 2 : 4).total;
+}
 
 extern "C" int edgl_score_ce_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                                  const float* row_lse, const float* coef, const float* gscale, int R, int C, int I,
@@ -740,10 +870,11 @@ extern "C" int edgl_score_ce_bwd(const void* rows, const void* table, const floa
                  "edgl_score_ce_bwd: null pointer");
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
-    p.i1 = i1; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale; p.d_rows = d_rows;
-    p.d_table = d_table; p.d_bias = d_bias; p.slabs = workspace; p.nchunk = edgl_score_chunks(i1 - i0);
+    p.i1 = i1; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
+    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
     hipStream_t st = (hipStream_t)stream;
-    return dtype == EDGL_F32 ? dispatch_ct<float>(p, true, st) : dispatch_ct<bf16>(p, true, st);
+    return dtype == EDGL_F32 ? bwd_dispatch<float>(p, C, plan, workspace, d_rows, d_table, d_bias, st)
+                             : bwd_dispatch<bf16>(p, C, plan, workspace, d_rows, d_table, d_bias, st);
 }
 
 extern "C" int edgl_mask_topk(float* logits, int R, int n, int i0, const int64_t* seen, int T, int K, float* out_val,

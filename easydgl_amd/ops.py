@@ -272,7 +272,7 @@ def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False):
     lse = torch.empty(R, device=dev, dtype=torch.float32)
     lab_logit = torch.zeros(R, device=dev, dtype=torch.float32)
     logits = torch.empty((R, i1 - i0), device=dev, dtype=torch.float32) if want_logits else None
-    ws = torch.empty(2 * R * lib.edgl_score_chunks(i1 - i0), device=dev, dtype=torch.float32)
+    ws = torch.empty(2 * R * lib.edgl_score_chunks(R, i1 - i0), device=dev, dtype=torch.float32)
     check(lib.edgl_score_lse_fwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), R, C, I, i0, i1, _ptr(lse),
                                  _ptr(lab_logit), _ptr(logits), _ptr(ws), _code(rows), _stream()), "edgl_score_lse_fwd")
     return lse, lab_logit, logits
@@ -303,7 +303,7 @@ class ScoreCEFn(torch.autograd.Function):
         d_rows = torch.empty_like(rows)
         d_table = torch.empty((I, C), device=dev, dtype=torch.float32)
         d_bias = torch.empty(I - 1, device=dev, dtype=torch.float32)
-        ws = torch.empty(lib.edgl_score_bwd_workspace(R, C, I), device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.edgl_score_bwd_workspace(R, C, I, I, _code(rows)), device=dev, dtype=torch.float32)
         check(lib.edgl_score_ce_bwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), _ptr(lse), _ptr(coef),
                                     _ptr(g), R, C, I, 0, I, _ptr(d_rows), _ptr(d_table), _ptr(d_bias), _ptr(ws),
                                     _code(rows), _stream()), "edgl_score_ce_bwd")

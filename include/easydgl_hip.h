@@ -147,8 +147,9 @@ int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_res, const f
  * shard only.  The [R, I] logits are never materialised unless `logits` (f32 [R, i1-i0]) is given.
  * fwd: online (max, sumexp) per row and item chunk -> row_lse f32 [R] (log-sum-exp over [i0,i1)),
  * label_logit f32 [R] (written only for rows whose label lies in [i0,i1); pre-zero when sharded).
- * workspace >= 2*R*edgl_score_chunks(i1-i0) floats.  C: power of two, 32..256 (bf16) / 32..128 (f32). */
-int edgl_score_chunks(int n_items);
+ * workspace >= 2*R*edgl_score_chunks(R, i1-i0) floats.  C: power of two, 32..256 (bf16) / 32..128 (f32);
+ * i0 must be a multiple of 8. */
+int edgl_score_chunks(int R, int n_items);
 int edgl_score_lse_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                        int R, int C, int I, int i0, int i1, float* row_lse, float* label_logit,
                        float* logits, float* workspace, int dtype, void* stream);
@@ -159,8 +160,9 @@ int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64
 /* backward of the CE: dl[r,j] = g * coef[r] * (p[r,j] - [j==label_r]) (g = d loss, device scalar or
  * NULL for 1), never materialised:  d_rows[R,C] (`dtype`) = dl . table ;  d_table[I,C] (f32,
  * overwritten for rows [i0,i1), row 0 := 0) = dl^T . rows ;  d_bias[I-1] f32 = colsum(dl)[1:].
- * workspace >= edgl_score_bwd_workspace(R, C, i1-i0) floats. */
-long edgl_score_bwd_workspace(int R, int C, int n_items);
+ * workspace >= edgl_score_bwd_workspace(R, C, I, i1-i0, dtype) floats (holds the transposed operand
+ * images rowsT/tableT and the per-chunk partial slabs, reduced in a fixed order). */
+long edgl_score_bwd_workspace(int R, int C, int I, int n_items, int dtype);
 int edgl_score_ce_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                       const float* row_lse, const float* coef, const float* gscale, int R, int C, int I,
                       int i0, int i1, void* d_rows, float* d_table, float* d_bias, float* workspace,
