@@ -26,6 +26,8 @@ SIGNATURES = {
     "edgl_encode_bwd": (I, [P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
     "edgl_gemm": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, I, P]),
     "edgl_colsum": (I, [P, I, I, I, P, I, P, I, I, P]),
+    "edgl_gemm_dw_workspace": (L, [I, I, I, I]),
+    "edgl_gemm_dw": (I, [P, P, P, P, I, I, I, I, I, I, P, I, P]),
     "edgl_bimau_pack_bytes": (L, [I, I, I, I]),
     "edgl_bimau_pack": (I, [P, P, P, P, I, I, I, P, I, P]),
     "edgl_bimau_fwd": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, I, P]),

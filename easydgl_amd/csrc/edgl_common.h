@@ -40,6 +40,12 @@ static inline int edgl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // out[n] (+)= sum_{p<P} part[p*ld + n], fixed summation order (k_misc.hip).  Used for every
 // "per-workgroup partials -> parameter gradient" reduction.
 int edgl_reduce_rows(const float* part, int P, int N, long ld, float* out, int accumulate, hipStream_t st);
+// bf16 fast paths (k_gemm2.hip): return 1 if taken, 0 if the shape does not qualify, <0 on error
+int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int b_kc,
+                         const float* bias, void* aux, int flags, hipStream_t st);
+long edgl_gemm2_tn_workspace(int R, int Kf, int N);
+int edgl_gemm2_try_tn(const void* X, const void* Y, float* C, int R, int Kf, int N, int ldx, int ldy, int ldc, float* dbias,
+                      int accumulate, float* workspace, hipStream_t st);
 
 // ----------------------------------------------------------------------------------------------
 // element types: activations / GEMM operands are float (exact-f32 MFMA path) or bf16

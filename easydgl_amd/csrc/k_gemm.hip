@@ -22,16 +22,60 @@ struct GemmP {
 };
 
 template <typename T>
+__device__ __forceinline__ void store4(T* dst, const float x[4]) {
+    Frag4<T> f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f.v[r] = from_f32<T>(x[r]);
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&f);
+    else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&f);
+}
+
+template <typename T>
 __device__ __forceinline__ void epilogue_store4(const GemmP& p, float v[4], int m, int n) {
     // 4 consecutive n for one m
     if (m >= p.M) return;
-    const bool full = (n + 3 < p.N);
+    const long idx0 = (long)m * p.ldc + n;
+    if (n + 3 < p.N && (p.ldc & 3) == 0) {
+        // vector path: one 8/16-byte store per lane instead of four scalar stores
+        float x[4] = {v[0], v[1], v[2], v[3]};
+        if (p.flags & EDGL_EPI_BIAS) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
+        }
+        if (p.flags & EDGL_EPI_SAVE_PRE) store4<T>(reinterpret_cast<T*>(p.aux) + idx0, x);
+        if (p.flags & EDGL_EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+        }
+        if (p.flags & EDGL_EPI_MUL_DGELU) {
+            const Frag4<T> a = frag_ld<T>(reinterpret_cast<const T*>(p.aux) + idx0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] *= dgelu_f(to_f32(a.v[r]));
+        }
+        if (p.flags & EDGL_EPI_OUT_F32) {
+            float* c = reinterpret_cast<float*>(p.C) + idx0;
+            if (p.flags & EDGL_EPI_ACCUM) {
+                const float4 o = *reinterpret_cast<const float4*>(c);
+                x[0] += o.x; x[1] += o.y; x[2] += o.z; x[3] += o.w;
+            }
+            *reinterpret_cast<float4*>(c) = make_float4(x[0], x[1], x[2], x[3]);
+        } else {
+            T* c = reinterpret_cast<T*>(p.C) + idx0;
+            if (p.flags & EDGL_EPI_ACCUM) {
+                const Frag4<T> o = frag_ld<T>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] += to_f32(o.v[r]);
+            }
+            store4<T>(c, x);
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (!full && n + r >= p.N) continue;
+        if (n + r >= p.N) continue;
         float x = v[r];
         if (p.flags & EDGL_EPI_BIAS) x += p.bias[n + r];
-        const long idx = (long)m * p.ldc + n + r;
+        const long idx = idx0 + r;
         if (p.flags & EDGL_EPI_SAVE_PRE) reinterpret_cast<T*>(p.aux)[idx] = from_f32<T>(x);
         if (p.flags & EDGL_EPI_GELU) x = gelu_f(x);
         if (p.flags & EDGL_EPI_MUL_DGELU) x *= dgelu_f(to_f32(reinterpret_cast<const T*>(p.aux)[idx]));
@@ -39,7 +83,8 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float v[4], int 
             float* c = reinterpret_cast<float*>(p.C);
             c[idx] = (p.flags & EDGL_EPI_ACCUM) ? c[idx] + x : x;
         } else {
-            reinterpret_cast<T*>(p.C)[idx] = from_f32<T>(x);
+            T* c = reinterpret_cast<T*>(p.C);
+            c[idx] = from_f32<T>((p.flags & EDGL_EPI_ACCUM) ? to_f32(c[idx]) + x : x);
         }
     }
 }
@@ -114,9 +159,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
             if (p.partial) {
                 if (m < p.M) {
                     float* dst = p.partial + ((long)blockIdx.z * p.M + m) * p.N + n;
+                    if (n + 3 < p.N && (p.N & 3) == 0) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < p.N) dst[r] = v[r];
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.N) dst[r] = v[r];
+                    }
                 }
             } else {
                 epilogue_store4<T>(p, v, m, n);
@@ -217,8 +266,6 @@ extern "C" int edgl_gemm(const void* A, const void* Bm, void* Cm, int M, int N, 
     EDGL_REQUIRE(!(epi_flags & EDGL_EPI_BIAS) || bias, EDGL_ERR_NULL, "edgl_gemm: bias flag without bias");
     EDGL_REQUIRE(!(epi_flags & (EDGL_EPI_SAVE_PRE | EDGL_EPI_MUL_DGELU)) || aux, EDGL_ERR_NULL,
                  "edgl_gemm: aux flag without aux");
-    EDGL_REQUIRE(!(epi_flags & EDGL_EPI_ACCUM) || (epi_flags & EDGL_EPI_OUT_F32), EDGL_ERR_DTYPE,
-                 "edgl_gemm: ACCUM needs OUT_F32");
     EDGL_REQUIRE(splitk <= 1 || workspace, EDGL_ERR_WORKSPACE, "edgl_gemm: split-K needs a workspace");
     GemmP p;
     p.A = A; p.B = Bm; p.C = Cm; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -226,6 +273,10 @@ extern "C" int edgl_gemm(const void* A, const void* Bm, void* Cm, int M, int N, 
     const int vec = (dtype == EDGL_BF16) ? 8 : 4;
     p.vec_ok = (lda % vec == 0) && (ldb % vec == 0) && (((uintptr_t)A & 15) == 0) && (((uintptr_t)Bm & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_BF16 && a_kc) {   // dense forward / dX shapes: register-resident A strips (k_gemm2.hip)
+        const int r = edgl_gemm2_try_strip(A, Bm, Cm, M, N, K, lda, ldb, ldc, b_kc, bias, aux, epi_flags, st);
+        if (r != 0) return r < 0 ? r : EDGL_OK;
+    }
     if (dtype == EDGL_F32) return launch_gemm<float>(p, a_kc, b_kc, splitk, st);
     if (dtype == EDGL_BF16) return launch_gemm<bf16>(p, a_kc, b_kc, splitk, st);
     edgl_set_error("edgl_gemm: bad dtype %d", dtype);
@@ -255,4 +306,30 @@ extern "C" int edgl_colsum(const void* X, int M, int N, int ld, float* out, int 
     hipStream_t st = (hipStream_t)stream;
     if (x_f32 || dtype == EDGL_F32) return run_colsum<float>((const float*)X, M, N, ld, out, accumulate, workspace, st);
     return run_colsum<bf16>((const bf16*)X, M, N, ld, out, accumulate, workspace, st);
+}
+
+// dW[Kf,N] (+)= X[R,Kf]^T . dY[R,N] and (optionally) dbias[N] (+)= colsum(dY): the weight/bias gradients of a
+// dense layer (tf.layers.dense backward).  bf16: transposing-read TN kernel; f32: generic kernel + colsum.
+extern "C" long edgl_gemm_dw_workspace(int R, int Kf, int N, int dtype) {
+    const long tn = edgl_gemm2_tn_workspace(R, Kf, N);
+    const long generic = 64L * Kf * N + 256L * N;
+    return dtype == EDGL_BF16 ? std::max(tn, generic) : generic;
+}
+
+extern "C" int edgl_gemm_dw(const void* X, const void* dY, float* dW, float* dbias, int R, int Kf, int N, int ldx, int ldy,
+                            int accumulate, float* workspace, int dtype, void* stream) {
+    EDGL_REQUIRE(X && dY && dW && workspace, EDGL_ERR_NULL, "edgl_gemm_dw: null pointer");
+    EDGL_REQUIRE(R > 0 && Kf > 0 && N > 0, EDGL_ERR_SHAPE, "edgl_gemm_dw: bad shape R=%d Kf=%d N=%d", R, Kf, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_BF16) {
+        const int r = edgl_gemm2_try_tn(X, dY, dW, R, Kf, N, ldx, ldy, N, dbias, accumulate, workspace, st);
+        if (r != 0) return r < 0 ? r : EDGL_OK;
+    }
+    const int tiles = ((Kf + 127) / 128) * ((N + 127) / 128);
+    const int splitk = std::max(1, std::min(64, std::min(R / 256, 320 / tiles)));
+    int rc = edgl_gemm(X, dY, dW, Kf, N, R, ldx, ldy, N, 0, 0, nullptr, nullptr,
+                       EDGL_EPI_OUT_F32 | (accumulate ? EDGL_EPI_ACCUM : 0), splitk, workspace, dtype, stream);
+    if (rc) return rc;
+    if (dbias) rc = edgl_colsum(dY, R, N, ldy, dbias, accumulate, workspace, 0, dtype, stream);
+    return rc;
 }

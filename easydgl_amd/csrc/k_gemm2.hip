@@ -1,0 +1,344 @@
+// bf16 fast paths of edgl_gemm for the shapes of the hot path (M = B*T rows huge; K, N in {128..512}).
+// Both kernels rely on gfx950's LDS transpose read (ds_read_b64_tr_b16): when lane (G=l>>4, s=l&15)
+// points at T[k0 + 4G + (s>>2)][z0 + 4*(s&3) ..+3] of a row-major LDS tile, it receives
+// T[k0 + 4G + j][z0 + (l&15)], j = 0..3 — i.e. the MFMA A/B fragment whose CONTRACTION index runs along the
+// tile's rows (measured on MI355X with tools/probe_tr.hip).  A 16x16x32 MFMA takes two such reads
+// (rows k0..k0+15 and k0+16..k0+31); both operands are read with the same k-slot order, so it is consistent.
+//
+//   strip_gemm_kernel : C[M,N] = epi(A[M,K] . B)   (dense forward and dX)
+//       a wave keeps a 32-row strip of A as MFMA fragments in registers for the whole kernel (A is read from
+//       HBM exactly once), B streams through LDS in 64-column tiles (double buffered, one barrier per tile);
+//       B is either [N][K] (k contiguous: plain ds_read_b128) or [K][N] (n contiguous: transpose reads), so
+//       neither the forward (x.W) nor dX (dz.W^T) needs a transposed copy of the weights.
+//   tn_gemm_kernel    : C[Kf,N] (+ bias-gradient row) = X[R,Kf]^T . dY[R,N]   (dW, db)
+//       contraction over the R rows with both operands row-major: tiles are staged row-major with coalesced
+//       16-byte copies and BOTH operands are fetched with transpose reads; split over R with f32 partial slabs
+//       reduced in a fixed order; the column sums of dY (bias gradient) ride along as one extra output row.
+#include "edgl_common.h"
+
+typedef __attribute__((ext_vector_type(4))) short tr_s16x4;
+
+namespace gemm2 {
+
+__device__ __forceinline__ uint2 tr_read(const bf16* tile, int ld, int k0, int z0, int lane) {
+    const int G = lane >> 4, s = lane & 15;
+    const bf16* p = tile + (k0 + 4 * G + (s >> 2)) * ld + z0 + 4 * (s & 3);
+    tr_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_s16x4*)p);
+    return *reinterpret_cast<uint2*>(&v);
+}
+// 8-slot fragment for the 16x16x32 MFMA: slots 0-3 <-> k0+4G+j, slots 4-7 <-> k0+16+4G+j
+__device__ __forceinline__ bf16x8 tr_frag32(const bf16* tile, int ld, int k0, int z0, int lane) {
+    bf16x8 f;
+    *reinterpret_cast<uint2*>(&f) = tr_read(tile, ld, k0, z0, lane);
+    *(reinterpret_cast<uint2*>(&f) + 1) = tr_read(tile, ld, k0 + 16, z0, lane);
+    return f;
+}
+
+struct EpiP {
+    const float* bias; void* aux; int flags;
+};
+__device__ __forceinline__ void epi_store4(const EpiP& e, bf16* C, void* Cany, long idx, int n, float x[4]) {
+    if (e.flags & EDGL_EPI_BIAS) {
+        const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
+        x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
+    }
+    if (e.flags & EDGL_EPI_SAVE_PRE) {
+        Frag4<bf16> f = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(e.aux) + idx) = *reinterpret_cast<uint2*>(&f);
+    }
+    if (e.flags & EDGL_EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+    }
+    if (e.flags & EDGL_EPI_MUL_DGELU) {
+        const Frag4<bf16> a = frag_ld<bf16>(reinterpret_cast<const bf16*>(e.aux) + idx);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] *= dgelu_f(to_f32(a.v[r]));
+    }
+    if (e.flags & EDGL_EPI_OUT_F32) {
+        float* c = reinterpret_cast<float*>(Cany) + idx;
+        if (e.flags & EDGL_EPI_ACCUM) {
+            const float4 o = *reinterpret_cast<const float4*>(c);
+            x[0] += o.x; x[1] += o.y; x[2] += o.z; x[3] += o.w;
+        }
+        *reinterpret_cast<float4*>(c) = make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+        if (e.flags & EDGL_EPI_ACCUM) {
+            const Frag4<bf16> o = frag_ld<bf16>(C + idx);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] += to_f32(o.v[r]);
+        }
+        Frag4<bf16> f = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
+        *reinterpret_cast<uint2*>(C + idx) = *reinterpret_cast<uint2*>(&f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// strip GEMM
+// ------------------------------------------------------------------------------------------------
+constexpr int S_NT = 256;   // 4 waves x 32 rows = 128 rows per workgroup
+constexpr int S_ZB = 64;    // output columns per streamed tile
+
+struct StripP {
+    const bf16* A; const bf16* B; void* C;
+    int M, N, K, lda, ldb, ldc;
+    EpiP epi;
+};
+
+// NKB = K/32 ; B_KC: B stored [N][ldb] (k contiguous) else [K][ldb] (n contiguous)
+template <int NKB, bool B_KC>
+__global__ __launch_bounds__(S_NT) void strip_gemm_kernel(StripP p) {
+    constexpr int K = 32 * NKB;
+    constexpr int LDZ_KC = K + 8;        // [S_ZB][K+8]   rows n
+    constexpr int LDZ_TR = S_ZB + 16;    // [K][S_ZB+16]  rows k
+    constexpr int ZELEMS = B_KC ? S_ZB * LDZ_KC : K * LDZ_TR;
+    constexpr int NVEC = K * S_ZB / 8;   // 16-byte vectors per tile
+    constexpr int PER = NVEC / S_NT;     // per thread (K/32 * 8 / ... ) = K/32
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* const Zbase = reinterpret_cast<bf16*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, g4 = G * 4, l15 = lane & 15;
+    const int m0 = blockIdx.x * 128 + wave * 32;
+
+    // ---- A strip fragments (k-slot order must match the B fragments) ------------------------------------
+    bf16x8 xf[2][NKB];
+#pragma unroll
+    for (int ix = 0; ix < 2; ++ix) {
+        const int m = m0 + ix * 16 + l15;
+        const bf16* row = p.A + (long)m * p.lda;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            bf16x8 f;
+            if (m < p.M) {
+                if constexpr (B_KC) {
+                    *reinterpret_cast<uint4*>(&f) = *reinterpret_cast<const uint4*>(row + kb * 32 + G * 8);
+                } else {
+                    *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<const uint2*>(row + kb * 32 + g4);
+                    *(reinterpret_cast<uint2*>(&f) + 1) = *reinterpret_cast<const uint2*>(row + kb * 32 + 16 + g4);
+                }
+            } else {
+                *reinterpret_cast<uint4*>(&f) = make_uint4(0, 0, 0, 0);
+            }
+            xf[ix][kb] = f;
+        }
+    }
+    // ---- B tile streaming ------------------------------------------------------------------------------------
+    uint4 pre[PER];
+    auto load_tile = [&](int n0) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int v = tid + i * S_NT;
+            if constexpr (B_KC) {
+                const int row = v / (K / 8), kv = v % (K / 8);      // row = n
+                pre[i] = *reinterpret_cast<const uint4*>(p.B + (long)(n0 + row) * p.ldb + kv * 8);
+            } else {
+                const int row = v / (S_ZB / 8), nv = v % (S_ZB / 8);  // row = k
+                pre[i] = *reinterpret_cast<const uint4*>(p.B + (long)row * p.ldb + n0 + nv * 8);
+            }
+        }
+    };
+    auto store_tile = [&](bf16* Z) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int v = tid + i * S_NT;
+            if constexpr (B_KC) {
+                const int row = v / (K / 8), kv = v % (K / 8);
+                *reinterpret_cast<uint4*>(Z + row * LDZ_KC + kv * 8) = pre[i];
+            } else {
+                const int row = v / (S_ZB / 8), nv = v % (S_ZB / 8);
+                *reinterpret_cast<uint4*>(Z + row * LDZ_TR + nv * 8) = pre[i];
+            }
+        }
+    };
+    const int ntile = p.N / S_ZB;
+    load_tile(0);
+    store_tile(Zbase);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const int n0 = it * S_ZB;
+        const bool more = it + 1 < ntile;
+        if (more) load_tile(n0 + S_ZB);
+        const bf16* Z = Zbase + (it & 1) * ZELEMS;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int jz = 0; jz < 4; ++jz) { acc[jz][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[jz][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int jz = 0; jz < 4; ++jz) {
+                bf16x8 zf;
+                if constexpr (B_KC) zf = *reinterpret_cast<const bf16x8*>(Z + (jz * 16 + l15) * LDZ_KC + kb * 32 + G * 8);
+                else zf = tr_frag32(Z, LDZ_TR, kb * 32, jz * 16, lane);
+                acc[jz][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[0][kb], acc[jz][0], 0, 0, 0);
+                acc[jz][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[1][kb], acc[jz][1], 0, 0, 0);
+            }
+        }
+        // acc[jz][ix]: L(first = n, second = m): lane holds 4 consecutive n of row m
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix) {
+            const int m = m0 + ix * 16 + l15;
+            if (m < p.M) {
+#pragma unroll
+                for (int jz = 0; jz < 4; ++jz) {
+                    const int n = n0 + jz * 16 + g4;
+                    float x[4] = {acc[jz][ix][0], acc[jz][ix][1], acc[jz][ix][2], acc[jz][ix][3]};
+                    epi_store4(p.epi, reinterpret_cast<bf16*>(p.C), p.C, (long)m * p.ldc + n, n, x);
+                }
+            }
+        }
+        if (more) store_tile(Zbase + ((it + 1) & 1) * ZELEMS);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN GEMM (dW / db)
+// ------------------------------------------------------------------------------------------------
+constexpr int T_NT = 256, T_BR = 64, T_LD = 128 + 16;
+
+struct TnP {
+    const bf16* X; const bf16* Y; int R, Kf, N, ldx, ldy;
+    int rows_per_split;
+    float* partial;   // [splits][Kf + 1][N]  (row Kf = column sums of Y)
+    int with_colsum;
+};
+
+__global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
+    __shared__ __attribute__((aligned(16))) bf16 Xs[T_BR * T_LD];
+    __shared__ __attribute__((aligned(16))) bf16 Ys[T_BR * T_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int kf0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int r_lo = blockIdx.z * p.rows_per_split, r_hi = min(p.R, r_lo + p.rows_per_split);
+    f32x4 acc[4][4];   // [i: kf tile][j: n tile], L(first = kf, second = n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;   // thread t < 128: column n0 + t of Y
+    uint4 px[4], py[4];
+    auto load = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = tid + i * T_NT, row = v >> 4, cv = v & 15, gr = r0 + row;
+            const bool okx = gr < r_hi && kf0 + cv * 8 < p.Kf, oky = gr < r_hi && n0 + cv * 8 < p.N;
+            px[i] = okx ? *reinterpret_cast<const uint4*>(p.X + (long)gr * p.ldx + kf0 + cv * 8) : make_uint4(0, 0, 0, 0);
+            py[i] = oky ? *reinterpret_cast<const uint4*>(p.Y + (long)gr * p.ldy + n0 + cv * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = tid + i * T_NT, row = v >> 4, cv = v & 15;
+            *reinterpret_cast<uint4*>(Xs + row * T_LD + cv * 8) = px[i];
+            *reinterpret_cast<uint4*>(Ys + row * T_LD + cv * 8) = py[i];
+        }
+    };
+    const int nstep = (r_hi - r_lo + T_BR - 1) / T_BR;
+    if (nstep > 0) { load(r_lo); store(); }
+    __syncthreads();
+    for (int st = 0; st < nstep; ++st) {
+        const bool more = st + 1 < nstep;
+        if (more) load(r_lo + (st + 1) * T_BR);
+#pragma unroll
+        for (int rb = 0; rb < T_BR / 32; ++rb) {
+            bf16x8 af[4], bf_[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = tr_frag32(Xs, T_LD, rb * 32, wm * 64 + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf_[j] = tr_frag32(Ys, T_LD, rb * 32, wn * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
+        }
+        if (p.with_colsum && blockIdx.y == 0 && tid < 128) {
+#pragma unroll 8
+            for (int r = 0; r < T_BR; ++r) csum += to_f32(Ys[r * T_LD + tid]);
+        }
+        __syncthreads();
+        if (more) store();
+        __syncthreads();
+    }
+    float* out = p.partial + (long)blockIdx.z * (p.Kf + 1) * p.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kf = kf0 + wm * 64 + i * 16 + g4 + r;
+            if (kf < p.Kf) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + l15;
+                    if (n < p.N) out[(long)kf * p.N + n] = acc[i][j][r];
+                }
+            }
+        }
+    if (p.with_colsum && blockIdx.y == 0 && tid < 128 && n0 + tid < p.N) out[(long)p.Kf * p.N + n0 + tid] = csum;
+}
+
+}  // namespace gemm2
+
+// ------------------------------------------------------------------------------------------------
+// host entry points used by edgl_gemm (k_gemm.hip) and exported for the training engine
+// ------------------------------------------------------------------------------------------------
+using namespace gemm2;
+
+template <int NKB, bool B_KC>
+static int launch_strip(const StripP& p, hipStream_t st) {
+    constexpr int K = 32 * NKB;
+    constexpr size_t zel = B_KC ? (size_t)S_ZB * (K + 8) : (size_t)K * (S_ZB + 16);
+    const size_t smem = 2 * zel * sizeof(bf16);
+    auto k = strip_gemm_kernel<NKB, B_KC>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k, dim3((p.M + 127) / 128), dim3(S_NT), smem, st, p);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+// returns 1 if the fast path was taken, 0 if the shape does not qualify, <0 on error
+int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int b_kc,
+                         const float* bias, void* aux, int flags, hipStream_t st) {
+    const bool ok = (K % 32 == 0) && K >= 32 && K <= 512 && (N % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
+                    (ldc % 4 == 0) && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 &&
+                    (!aux || ((uintptr_t)aux & 7) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
+    if (!ok) return 0;
+    StripP p{(const bf16*)A, (const bf16*)B, C, M, N, K, lda, ldb, ldc, EpiP{bias, aux, flags}};
+    int rc;
+#define STRIP_CASE(NKB)                                                             \
+    case NKB: rc = b_kc ? launch_strip<NKB, true>(p, st) : launch_strip<NKB, false>(p, st); break;
+    switch (K / 32) {
+        STRIP_CASE(1) STRIP_CASE(2) STRIP_CASE(4) STRIP_CASE(8) STRIP_CASE(12) STRIP_CASE(16)
+        default: return 0;
+    }
+#undef STRIP_CASE
+    return rc ? rc : 1;
+}
+
+// C[Kf,N] = X^T . Y (f32, overwritten or accumulated); if dbias != nullptr also dbias[N] = colsum(Y).
+// workspace floats: edgl_gemm2_tn_workspace(R, Kf, N).
+static int tn_splits(int R, int Kf, int N) {
+    const int tiles = ((Kf + 127) / 128) * ((N + 127) / 128);
+    int splits = std::max(1, std::min(384 / tiles, R / 128));
+    return splits;
+}
+long edgl_gemm2_tn_workspace(int R, int Kf, int N) { return (long)tn_splits(R, Kf, N) * (Kf + 1) * N; }
+
+int edgl_gemm2_try_tn(const void* X, const void* Y, float* C, int R, int Kf, int N, int ldx, int ldy, int ldc, float* dbias,
+                      int accumulate, float* workspace, hipStream_t st) {
+    const bool ok = (Kf % 8 == 0) && (N % 8 == 0) && (ldx % 8 == 0) && (ldy % 8 == 0) && ldc == N &&
+                    (((uintptr_t)X | (uintptr_t)Y) & 15) == 0 && workspace;
+    if (!ok) return 0;
+    int splits = tn_splits(R, Kf, N);
+    int rps = ((R + splits - 1) / splits + T_BR - 1) / T_BR * T_BR;
+    splits = (R + rps - 1) / rps;
+    TnP p{(const bf16*)X, (const bf16*)Y, R, Kf, N, ldx, ldy, rps, workspace, dbias ? 1 : 0};
+    hipLaunchKernelGGL(tn_gemm_kernel, dim3((N + 127) / 128, (Kf + 127) / 128, splits), dim3(T_NT), 0, st, p);
+    EDGL_LAUNCH_CHECK();
+    int rc = edgl_reduce_rows(workspace, splits, Kf * N, (long)(Kf + 1) * N, C, accumulate, st);
+    if (rc) return rc;
+    if (dbias) {
+        rc = edgl_reduce_rows(workspace + (long)Kf * N, splits, N, (long)(Kf + 1) * N, dbias, accumulate, st);
+        if (rc) return rc;
+    }
+    return 1;
+}

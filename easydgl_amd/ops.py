@@ -92,9 +92,19 @@ def cast_to(src_f32: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tenso
     return out
 
 
+def dense_grads(x2, dz, M, K, N):
+    code = _code(x2)
+    dw = torch.empty((K, N), device=x2.device, dtype=torch.float32)
+    db = torch.empty(N, device=x2.device, dtype=torch.float32)
+    ws = torch.empty(lib.edgl_gemm_dw_workspace(M, K, N, code), device=x2.device, dtype=torch.float32)
+    check(lib.edgl_gemm_dw(_ptr(x2), _ptr(dz), _ptr(dw), _ptr(db), M, K, N, x2.stride(0), dz.stride(0), 0, _ptr(ws), code,
+                           _stream()), "edgl_gemm_dw")
+    return dw, db
+
+
 def _splitk_for(m_out: int, n_out: int, kc: int) -> int:
     tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
-    return int(max(1, min(kc // 512, max(1, 768 // tiles))))
+    return int(max(1, min(kc // 256, max(1, 320 // tiles))))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -166,9 +176,8 @@ class LinearFn(torch.autograd.Function):
             dz = out
         # dX[M,K] = dz[M,N] . W^T : B(kk=n, nn=k) = W[k][n] -> stored [K rows][N contiguous] = k-contiguous operand
         dx = gemm(dz, w_c, M, K, N, N, N, True, True, dz.dtype)
-        # dW[K,N] = X^T . dz : both operands have the contraction (rows) as the slow dimension
-        dw = gemm(x2, dz, K, N, M, K, N, False, False, torch.float32, splitk=_splitk_for(K, N, M))
-        db = colsum(dz, M, N)
+        # dW[K,N] = X^T . dz and db = colsum(dz): contraction over the rows of two row-major operands
+        dw, db = dense_grads(x2, dz, M, K, N)
         return dx.reshape(xshape), dw, db, None, None
 
 

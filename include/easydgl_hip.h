@@ -45,7 +45,7 @@ enum {
     EDGL_EPI_GELU = 2,        /* erf-GELU (EasyDGL.py:19-32)                 */
     EDGL_EPI_SAVE_PRE = 4,    /* aux[m,n] = pre-activation (dtype)           */
     EDGL_EPI_MUL_DGELU = 8,   /* *= gelu'(aux[m,n])                          */
-    EDGL_EPI_ACCUM = 16,      /* C += result (f32 C only)                    */
+    EDGL_EPI_ACCUM = 16,      /* C += result                                 */
     EDGL_EPI_OUT_F32 = 32     /* C is f32 regardless of dtype                */
 };
 
@@ -89,6 +89,13 @@ int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const void* dx0, i
 int edgl_gemm(const void* A, const void* Bm, void* Cm, int M, int N, int K, int lda, int ldb, int ldc,
               int a_kc, int b_kc, const float* bias, void* aux, int epi_flags, int splitk, float* workspace,
               int dtype, void* stream);
+
+/* Weight / bias gradients of a dense layer: dW[Kf,N] (+)= X[R,Kf]^T . dY[R,N] (f32), and if dbias != NULL
+ * dbias[N] (+)= colsum(dY).  workspace >= edgl_gemm_dw_workspace floats; per-split partials are reduced in a
+ * fixed order. */
+long edgl_gemm_dw_workspace(int R, int Kf, int N, int dtype);
+int edgl_gemm_dw(const void* X, const void* dY, float* dW, float* dbias, int R, int Kf, int N, int ldx, int ldy,
+                 int accumulate, float* workspace, int dtype, void* stream);
 
 /* out[n] (+)= sum_m X[m, n]  — bias gradients.  X `dtype` (or f32 if x_f32) [M, ld]; out f32[N]. */
 int edgl_colsum(const void* X, int M, int N, int ld, float* out, int accumulate, float* workspace,
