@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", default="engine", choices=["engine", "graph", "autograd"],
+                    help="engine: static launch sequence issued eagerly (dominant kernel bracketed with HIP events); "
+                         "graph: the same sequence replayed as one HIP graph; autograd: torch.autograd over the ops")
     ap.add_argument("--op-table", action="store_true", help="after the timed region, print a per-C-call time table to stderr")
     args = ap.parse_args()
 
@@ -125,16 +128,24 @@ def main():
     from easydgl_amd import _lib, parallel
     model, feats, labels = make_model_and_batch(c, args.dtype, dev, seed=9876 + rank)
 
-    def step():
-        from easydgl_amd import ops
-        ops.rng_advance(model._rng_state)
-        model.zero_grad_arena()
-        loss = model.train_loss(feats, labels)
-        loss.backward()
-        if world > 1:
-            parallel.allreduce_mean_(model._grad_arena)
-        model.optimizer_step()
-        return loss
+    if args.path == "autograd":
+        def step():
+            from easydgl_amd import ops
+            ops.rng_advance(model._rng_state)
+            model.zero_grad_arena()
+            loss = model.train_loss(feats, labels)
+            loss.backward()
+            if world > 1:
+                parallel.allreduce_mean_(model._grad_arena)
+            model.optimizer_step()
+            return loss.detach()
+    else:
+        from easydgl_amd.engine import TrainEngine
+        eng = TrainEngine(model, c["batch"], use_graph=(args.path == "graph"))
+        eng.load_batch(feats, labels)
+
+        def step():
+            return eng.step()
 
     for _ in range(args.warmup):
         step()
@@ -180,7 +191,7 @@ def main():
                                    "1 block, num_items 20000 (I=20001), masklen 20, 16 marks, dropout 0.1/0.1, ct_reg 1e-7, l2 1e-4",
                        "global_batch": world * c["batch"], "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_step": round(3 * flops_per_seq(c) * c["batch"] / 1e9, 1)},
-            "loss": round(float(loss), 5),
+            "loss": round(float(loss), 5), "path": args.path,
             "roofline": {"bound": "mfma", "kernel": "score_bwd_dy_kernel+score_bwd_dw_kernel (edgl_score_ce_bwd)",
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "avg_launch_ms": round(dom_ms, 4), "traffic": None},

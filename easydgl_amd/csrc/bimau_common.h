@@ -115,7 +115,7 @@ __device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyBits& kb
             sum += e;
         }
     sum = group_sum4(sum);
-    const float inv = 1.0f / sum;
+    const float inv = fast_rcp(sum);
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll

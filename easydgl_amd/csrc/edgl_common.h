@@ -210,8 +210,11 @@ __device__ __forceinline__ DropKey make_dropkey(const uint64_t* rng_state, uint3
     return k;
 }
 __device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t idx) {
-    uint32_t h = edgl_mix32(((uint32_t)idx) * 0x9E3779B1u ^ k.k0);
-    h = edgl_mix32(h + (uint32_t)(idx >> 32) * 0x7feb352du + k.k1);
+    // one multiply / xor-shift round per element; (seed, step, op) enter through k0/k1, the upper index bits
+    // (tensors beyond 2^32 elements) through the additive term
+    uint32_t h = ((uint32_t)idx ^ k.k0) * 0x9E3779B1u;
+    h += (uint32_t)(idx >> 32) * 0x7feb352du + k.k1;
+    h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
     return h >= k.thresh;
 }
 __device__ __forceinline__ float drop_apply(const DropKey& k, uint64_t idx, float x) {
@@ -229,4 +232,6 @@ __device__ __forceinline__ float dgelu_f(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division sequence: sigmoid sits in the inner loop of the intensity MLP
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }

@@ -1,0 +1,274 @@
+"""Static training engine for the EasyDGL hot path.
+
+`model.train_step` (autograd over the ops) is the flexible path; this engine is the production path for a
+fixed batch shape: every activation / gradient / workspace buffer is allocated once (sized for the 288 GB of
+an MI355X, nothing is freed or reallocated per step), the forward and backward kernels are issued in a fixed
+order straight through the C ABI, parameter gradients land directly in the flat gradient arena (each written
+exactly once, except the item table: scoring writes it, the embedding scatter adds to it), GELU' rides in the
+epilogue of the dX GEMM, bias gradients ride in the dW kernel, the l2 gradient is folded into the Adam
+kernel — and the whole step can be captured into ONE HIP graph (dropout step / Adam step live in device memory).
+
+The arithmetic is the same as `EasyDGL.train_loss` + backward; tests/test_gpu_engine.py checks gradients and
+weights against the autograd path and the fp64 oracle.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, lib
+from .ops import _ptr, _stream
+
+EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32
+
+
+class TrainEngine:
+    def __init__(self, model, batch: int, use_graph: bool = True, process_group=None):
+        self.m = model
+        self.B = batch
+        self.use_graph = use_graph
+        self.group = process_group
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        m = model
+        dev = m._arena.device
+        self.dev = dev
+        self.dt = m.act_dtype
+        self.code = ops._DT[self.dt]
+        B, T, C, H, E, M, I = batch, m.seqslen, m.num_units, m.num_heads, m.num_events, m.masklen, m.num_items
+        self.T, self.C, self.H, self.E, self.M, self.I = T, C, H, E, M, I
+        self.R = B * M
+        self.rows = B * T
+        nb = len(m.layers)
+        e = lambda *s, dtype=None: torch.empty(s, device=dev, dtype=dtype or self.dt)  # noqa: E731
+        f32 = torch.float32
+        # ---- static inputs ----------------------------------------------------------------------------------
+        self.ids = torch.zeros((B, T), device=dev, dtype=torch.int64)
+        self.ts = torch.zeros((B, T), device=dev, dtype=f32)
+        self.mpos = torch.zeros((B, M), device=dev, dtype=torch.int64)
+        self.labels = torch.zeros((B, M), device=dev, dtype=torch.int64)
+        # ---- forward activations --------------------------------------------------------------------------------
+        self.x0 = e(B, T, 3 * C)
+        self.spans = e(B, T, dtype=f32)
+        self.marks = e(B, T, E, dtype=torch.uint8)
+        self.blk = []
+        for i in range(nb):
+            d = dict(qkvt=e(B, T, 4 * C), att=e(B, T, C), lam=e(H * B, T, E, dtype=f32), ao=e(B, T, C), a1=e(B, T, C),
+                     st1=e(B, 2, dtype=f32), pre_f=e(B, T, 2 * C), f=e(B, T, 2 * C), o=e(B, T, C), y=e(B, T, C),
+                     st2=e(B, 2, dtype=f32),
+                     pack=e(lib.edgl_bimau_pack_bytes(C, H, E, self.code), dtype=torch.uint8),
+                     dlam=e(H * B, T, E, dtype=f32), tpp=e(lib.edgl_tpp_workspace(), dtype=f32))
+            self.blk.append(d)
+        self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
+        self.hrows = e(self.R, C)
+        self.lse, self.lab_logit, self.coef = e(self.R, dtype=f32), e(self.R, dtype=f32), e(self.R, dtype=f32)
+        self.loss = e(1, dtype=f32)
+        # ---- backward temporaries -------------------------------------------------------------------------------
+        self.d_rows = e(self.R, C)
+        self.G1, self.G2, self.G3, self.G4 = e(B, T, C), e(B, T, C), e(B, T, C), e(B, T, C)
+        self.G2c, self.G4c, self.G3c = e(B, T, 2 * C), e(B, T, 4 * C), e(B, T, 3 * C)
+        # ---- workspaces -----------------------------------------------------------------------------------------------
+        wsz = [2 * self.R * lib.edgl_score_chunks(self.R, I),
+               lib.edgl_score_bwd_workspace(self.R, C, I, I, self.code),
+               lib.edgl_encode_bwd_workspace(B, T, C), B * 2 * C, 64]
+        for (kf, n) in ((3 * C, 4 * C), (C, 4 * C), (C, C), (C, 2 * C), (2 * C, C)):
+            wsz.append(lib.edgl_gemm_dw_workspace(self.rows, kf, n, self.code))
+        self.ws = e(max(wsz), dtype=f32)
+        self.ws_bimau = e(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, self.code), dtype=torch.uint8)
+        segs = []
+        params = dict(m.named_parameters())
+        for n in m.l2_param_names():
+            segs += [m._offsets[n], m._offsets[n] + params[n].numel()]
+        self.l2_seg = torch.tensor(segs, device=dev, dtype=torch.int64)
+        self.nseg = len(segs) // 2
+
+    # ---- thin call helpers ------------------------------------------------------------------------------------------
+    def _gemm(self, A, Bm, Cm, M, N, K, lda, ldb, ldc, b_kc, bias=None, aux=None, flags=0):
+        check(lib.edgl_gemm(_ptr(A), _ptr(Bm), _ptr(Cm), M, N, K, lda, ldb, ldc, 1, int(b_kc), _ptr(bias), _ptr(aux), flags,
+                            1, None, self.code, _stream()), "edgl_gemm")
+
+    def _dense_fwd(self, x, dense_kernel, dense_bias, out, K, N, gelu=False, pre=None):
+        flags = EPI_BIAS | ((EPI_GELU | EPI_SAVE_PRE) if gelu else 0)
+        self._gemm(x, self.m.compute(dense_kernel), out, self.rows, N, K, K, N, N, False, bias=dense_bias, aux=pre, flags=flags)
+
+    def _dense_dx(self, dz, kernel, out, K_in, N, flags=0, aux=None):
+        """out[rows, K_in] (=|+=) dz[rows, N] . kernel[K_in, N]^T"""
+        self._gemm(dz, self.m.compute(kernel), out, self.rows, K_in, N, N, N, K_in, True, aux=aux, flags=flags)
+
+    def _dense_dw(self, x, dz, kernel, bias, K_in, N):
+        check(lib.edgl_gemm_dw(_ptr(x), _ptr(dz), _ptr(kernel.grad), _ptr(bias.grad), self.rows, K_in, N, K_in, N, 0,
+                               _ptr(self.ws), self.code, _stream()), "edgl_gemm_dw")
+
+    def _ln_fwd(self, x, resid, ld_res, ln, drop, y, stats, gpos=None):
+        B, T, C = self.B, self.T, self.C
+        check(lib.edgl_add_layernorm_fwd(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
+                                         _ptr(ln.beta), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
+                                         _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(y), _ptr(stats),
+                                         self.code, _stream()), "edgl_add_layernorm_fwd")
+
+    def _ln_bwd(self, x, resid, ld_res, ln, stats, dy, drop, dsum, dx_drop, gpos=None):
+        B, T, C = self.B, self.T, self.C
+        check(lib.edgl_add_layernorm_bwd(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
+                                         _ptr(stats), _ptr(dy), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
+                                         _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(dsum), _ptr(dx_drop),
+                                         _ptr(ln.gamma.grad), _ptr(ln.beta.grad), _ptr(self.ws), self.code, _stream()),
+              "edgl_add_layernorm_bwd")
+
+    # ---- one optimizer step, as a fixed launch sequence ----------------------------------------------------------------
+    def _issue(self):
+        m, st = self.m, _stream()
+        B, T, C, H, E, M, I, R = self.B, self.T, self.C, self.H, self.E, self.M, self.I, self.R
+        code = self.code
+        hd, ad = m.hidden_dropout_rate, m.attention_probs_dropout_rate
+        drop = lambda rate, sid: ops.Drop(rate, m._rng_state, sid) if rate > 0 else ops.NO_DROP  # noqa: E731
+        tab = m.item_embs.lookup_table
+        tab_c = m.compute(tab)
+        ops.rng_advance(m._rng_state)
+        # ================= forward (EasyDGL.py:70-151) =================
+        d0 = drop(hd, 1)
+        check(lib.edgl_encode_fwd(_ptr(self.ids), _ptr(self.ts), _ptr(tab_c), _ptr(m.pcoding.pembs.lookup_table),
+                                  _ptr(m.mark_embs.lookup_table), _ptr(m.mark_lookup_table), _ptr(m.tcoding.scale), B, T, C,
+                                  E, I, int(m.mask), float(m.time_scale), float(d0.rate), d0.ptr(), d0.stream_id,
+                                  _ptr(self.x0), _ptr(self.spans), _ptr(self.marks), code, st), "edgl_encode_fwd")
+        x, cin = self.x0, 3 * C
+        for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
+            att = blk.attention
+            self._dense_fwd(x, att.dense_kernel, att.dense_bias, b["qkvt"], cin, 4 * C)
+            check(lib.edgl_bimau_pack(_ptr(att.st_kernel), _ptr(att.st_bias), _ptr(att.weight), _ptr(att.scaling), C, H, E,
+                                      _ptr(b["pack"]), code, st), "edgl_bimau_pack")
+            da = drop(ad, 10 + 4 * i)
+            check(lib.edgl_bimau_fwd(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
+                                     _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
+                                     _ptr(b["lam"]), code, st), "edgl_bimau_fwd")
+            self._dense_fwd(b["att"], blk.att_out.kernel, blk.att_out.bias, b["ao"], C, C)
+            self._ln_fwd(b["ao"], x, cin, blk.att_ln, drop(hd, 11 + 4 * i), b["a1"], b["st1"])
+            self._dense_fwd(b["a1"], blk.inter.kernel, blk.inter.bias, b["f"], C, 2 * C, gelu=True, pre=b["pre_f"])
+            self._dense_fwd(b["f"], blk.out.kernel, blk.out.bias, b["o"], 2 * C, C)
+            self._ln_fwd(b["o"], b["a1"], C, blk.out_ln, drop(hd, 12 + 4 * i), b["y"], b["st2"])
+            x, cin = b["y"], C
+        self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, C, C, gelu=True, pre=self.pre_t)
+        self._ln_fwd(self.so, None, 0, m.transform_ln, ops.NO_DROP, self.hrows, self.st3, gpos=self.mpos)
+        lab = self.labels.view(-1)
+        check(lib.edgl_score_lse_fwd(_ptr(self.hrows), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
+                                     _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st), "edgl_score_lse_fwd")
+        check(lib.edgl_ce_loss_fwd(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef), st),
+              "edgl_ce_loss_fwd")
+        if m.l2_reg != 0.0:
+            check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss), 1,
+                                   _ptr(self.ws), st), "edgl_l2_loss")
+        if m.ct_reg != 0.0:
+            coef = m.ct_reg / H
+            for b in self.blk:
+                check(lib.edgl_tpp_fwd(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
+                                       _ptr(m.mark_lookup_table), B, T, H, E, M, float(coef), _ptr(b["tpp"]), _ptr(self.loss),
+                                       1, st), "edgl_tpp_fwd")
+                check(lib.edgl_tpp_bwd(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
+                                       _ptr(m.mark_lookup_table), B, T, H, E, M, float(coef), _ptr(b["tpp"]), None,
+                                       _ptr(b["dlam"]), st), "edgl_tpp_bwd")
+        # ================= backward =================
+        check(lib.edgl_score_ce_bwd(_ptr(self.hrows), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
+                                    _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.d_rows), _ptr(tab.grad),
+                                    _ptr(m.output_bias.grad), _ptr(self.ws), code, st), "edgl_score_ce_bwd")
+        # head: LN (gathered rows) -> gelu' -> dense
+        self._ln_bwd(self.so, None, 0, m.transform_ln, self.st3, self.d_rows, ops.NO_DROP, self.G1, None, gpos=self.mpos)
+        n = self.rows * C
+        check(lib.edgl_gelu_bwd(_ptr(self.G1), _ptr(self.pre_t), _ptr(self.G1), n, code, st), "edgl_gelu_bwd")
+        y_last = self.blk[-1]["y"] if self.blk else self.x0
+        self._dense_dw(y_last, self.G1, m.transform.kernel, m.transform.bias, C, C)
+        self._dense_dx(self.G1, m.transform.kernel, self.G2, C, C)
+        dY = self.G2
+        for i in reversed(range(len(self.blk))):
+            blk, b = m.layers[i], self.blk[i]
+            x_in, cin = (self.x0, 3 * C) if i == 0 else (self.blk[i - 1]["y"], C)
+            dh2, dh1 = drop(hd, 12 + 4 * i), drop(hd, 11 + 4 * i)
+            # y = LN(drop(o) + a1)
+            self._ln_bwd(b["o"], b["a1"], C, blk.out_ln, b["st2"], dY, dh2, self.G3, self.G4 if dh2.active else None)
+            d_o = self.G4 if dh2.active else self.G3
+            self._dense_dw(b["f"], d_o, blk.out.kernel, blk.out.bias, 2 * C, C)
+            # d_pre_f = (d_o . Wout^T) * gelu'(pre_f)   — GELU' fused into the GEMM epilogue
+            self._dense_dx(d_o, blk.out.kernel, self.G2c, 2 * C, C, flags=EPI_MUL_DGELU, aux=b["pre_f"])
+            self._dense_dw(b["a1"], self.G2c, blk.inter.kernel, blk.inter.bias, C, 2 * C)
+            # d_a1 = dsum (in G3) + d_pre_f . Wi^T        — accumulated by the GEMM epilogue
+            if dh2.active:
+                pass  # G3 holds dsum already
+            self._dense_dx(self.G2c, blk.inter.kernel, self.G3, C, 2 * C, flags=EPI_ACCUM)
+            # a1 = LN(drop(ao) + x_in[:, :, :C])
+            self._ln_bwd(b["ao"], x_in, cin, blk.att_ln, b["st1"], self.G3, dh1, self.G1, self.G4 if dh1.active else None)
+            d_ao = self.G4 if dh1.active else self.G1
+            self._dense_dw(b["att"], d_ao, blk.att_out.kernel, blk.att_out.bias, C, C)
+            self._dense_dx(d_ao, blk.att_out.kernel, self.G2, C, C)          # G2 = d_att
+            att = blk.attention
+            da = drop(ad, 10 + 4 * i)
+            check(lib.edgl_bimau_bwd(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
+                                     _ptr(self.G2), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, B, T, C, H, E,
+                                     float(da.rate), da.ptr(), da.stream_id, _ptr(self.G4c), _ptr(att.st_kernel.grad),
+                                     _ptr(att.st_bias.grad), _ptr(att.weight.grad), _ptr(att.scaling.grad),
+                                     _ptr(self.ws_bimau), code, st), "edgl_bimau_bwd")
+            self._dense_dw(x_in, self.G4c, att.dense_kernel, att.dense_bias, cin, 4 * C)
+            d_in = self.G3c if i == 0 else self.G3
+            self._dense_dx(self.G4c, att.dense_kernel, d_in, cin, 4 * C)
+            # both residual branches feed the first C channels of the block input (temporal.py:447, EasyDGL.py:116)
+            check(lib.edgl_add_cols(_ptr(d_in), cin, _ptr(self.G1), C, self.rows, C, code, st), "edgl_add_cols")
+            check(lib.edgl_add_cols(_ptr(d_in), cin, _ptr(self.G2), C, self.rows, C, code, st), "edgl_add_cols")
+            if i > 0:  # next (earlier) block consumes d_in as its dY; keep it out of the scratch set it will overwrite
+                self.G2.copy_(self.G3)
+                dY = self.G2
+            else:
+                dY = d_in
+        d0 = drop(hd, 1)
+        check(lib.edgl_encode_bwd(_ptr(self.ids), _ptr(self.marks), _ptr(dY), B, T, C, E, I, float(d0.rate), d0.ptr(),
+                                  d0.stream_id, _ptr(tab.grad), _ptr(m.pcoding.pembs.lookup_table.grad),
+                                  _ptr(m.mark_embs.lookup_table.grad), _ptr(self.ws), code, st), "edgl_encode_bwd")
+
+    def _optimizer(self):
+        m = self.m
+        ops.adam_step(m._arena, m._grad_arena, m._adam_m, m._adam_v, m.learning_rate, m._adam_state, m.l2_reg,
+                      self.l2_seg if m.l2_reg != 0.0 else None, m._shadow)
+
+    # ---- public API --------------------------------------------------------------------------------------------------------
+    def load_batch(self, features: Dict[str, torch.Tensor], labels: torch.Tensor) -> None:
+        self.ids.copy_(features["seqs_i"]); self.ts.copy_(features["seqs_t"])
+        self.mpos.copy_(features["masked_positions"]); self.labels.copy_(labels)
+
+    def step(self, features=None, labels=None) -> torch.Tensor:
+        """One optimizer step on the (optionally refreshed) static batch; returns the loss (device scalar)."""
+        if features is not None:
+            self.load_batch(features, labels)
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size(self.group) > 1
+        if not self.use_graph:
+            self._issue()
+            if distributed:
+                from . import parallel
+                parallel.allreduce_mean_(self.m._grad_arena, self.group)
+            self._optimizer()
+            return self.loss
+        if self.graph is None:
+            # warm-up on a side stream (allocator / lazy module init), then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._issue()
+                if not distributed:
+                    self._optimizer()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            # the warm-up was a real step; undo nothing: training simply started one step earlier
+            if distributed:
+                from . import parallel
+                parallel.allreduce_mean_(self.m._grad_arena, self.group)
+                self._optimizer()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._issue()
+                if not distributed:
+                    self._optimizer()
+            self._distributed = distributed
+            return self.loss
+        self.graph.replay()
+        if self._distributed:
+            from . import parallel
+            parallel.allreduce_mean_(self.m._grad_arena, self.group)
+            self._optimizer()
+        return self.loss
