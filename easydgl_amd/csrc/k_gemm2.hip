@@ -14,6 +14,8 @@
 //       contraction over the R rows with both operands row-major: tiles are staged row-major with coalesced
 //       16-byte copies and BOTH operands are fetched with transpose reads; split over R with f32 partial slabs
 //       reduced in a fixed order; the column sums of dY (bias gradient) ride along as one extra output row.
+#include <cstdlib>
+
 #include "edgl_common.h"
 
 typedef __attribute__((ext_vector_type(4))) short tr_s16x4;
@@ -83,110 +85,145 @@ struct StripP {
     const bf16* A; const bf16* B; void* C;
     int M, N, K, lda, ldb, ldc;
     EpiP epi;
+    int dbg;   // EDGL_DBG ablation bits (profiling only): 1 skip epilogue stores, 2 skip MFMA loop, 4 skip B streaming
 };
 
-// NKB = K/32 ; B_KC: B stored [N][ldb] (k contiguous) else [K][ldb] (n contiguous)
+// Weights-resident strip GEMM.  A workgroup (8 waves) loads ONE column slice of B (<= 128 output columns, all K)
+// into LDS once, then its waves independently walk 32-row strips of A: strip fragments -> registers, MFMA against
+// the LDS-resident weights, epilogue, next strip.  There is no barrier and no shared traffic in the main loop, so
+// the two waves of a SIMD hide each other's memory latency, and A is touched only by the (<= 4) column-slice
+// workgroups that run side by side on the same rows.
+// NKB = K/32 ; B_KC: B stored [N][ldb] (k contiguous) else [K][ldb] (n contiguous, read with transpose reads)
+constexpr int W_NT = 512;
 template <int NKB, bool B_KC>
-__global__ __launch_bounds__(S_NT) void strip_gemm_kernel(StripP p) {
+__global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
     constexpr int K = 32 * NKB;
-    constexpr int LDZ_KC = K + 8;        // [S_ZB][K+8]   rows n
-    constexpr int LDZ_TR = S_ZB + 16;    // [K][S_ZB+16]  rows k
-    constexpr int ZELEMS = B_KC ? S_ZB * LDZ_KC : K * LDZ_TR;
-    constexpr int NVEC = K * S_ZB / 8;   // 16-byte vectors per tile
-    constexpr int PER = NVEC / S_NT;     // per thread (K/32 * 8 / ... ) = K/32
+    constexpr int NP = 128;                 // columns per slice (gridDim.y slices)
+    constexpr int LDW_KC = K + 8;           // [NP][K+8]    rows n
+    constexpr int LDW_TR = NP + 16;         // [K][NP+16]   rows k
+    constexpr int WELEMS = B_KC ? NP * LDW_KC : K * LDW_TR;
+    constexpr int LDO = 64 + 8;             // per-wave output staging [16][64+8] (one 16-row tile at a time)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* const Zbase = reinterpret_cast<bf16*>(smem);
+    bf16* const Ws = reinterpret_cast<bf16*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, g4 = G * 4, l15 = lane & 15;
-    const int m0 = blockIdx.x * 128 + wave * 32;
-
-    // ---- A strip fragments (k-slot order must match the B fragments) ------------------------------------
-    bf16x8 xf[2][NKB];
-#pragma unroll
-    for (int ix = 0; ix < 2; ++ix) {
-        const int m = m0 + ix * 16 + l15;
-        const bf16* row = p.A + (long)m * p.lda;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            bf16x8 f;
-            if (m < p.M) {
-                if constexpr (B_KC) {
-                    *reinterpret_cast<uint4*>(&f) = *reinterpret_cast<const uint4*>(row + kb * 32 + G * 8);
-                } else {
-                    *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<const uint2*>(row + kb * 32 + g4);
-                    *(reinterpret_cast<uint2*>(&f) + 1) = *reinterpret_cast<const uint2*>(row + kb * 32 + 16 + g4);
-                }
-            } else {
-                *reinterpret_cast<uint4*>(&f) = make_uint4(0, 0, 0, 0);
-            }
-            xf[ix][kb] = f;
+    bf16* const Ostage = Ws + WELEMS + wave * 16 * LDO;
+    const int nbase = blockIdx.y * NP;
+    const int ncols = min(NP, p.N - nbase);          // multiple of 64
+    // ---- weights slice -> LDS (once) ----------------------------------------------------------------------------
+    if constexpr (B_KC) {
+        for (int v = tid; v < NP * (K / 8); v += W_NT) {
+            const int row = v / (K / 8), kv = v % (K / 8);
+            uint4 d = make_uint4(0, 0, 0, 0);
+            if (row < ncols) d = *reinterpret_cast<const uint4*>(p.B + (long)(nbase + row) * p.ldb + kv * 8);
+            *reinterpret_cast<uint4*>(Ws + row * LDW_KC + kv * 8) = d;
+        }
+    } else {
+        for (int v = tid; v < K * (NP / 8); v += W_NT) {
+            const int row = v / (NP / 8), nv = v % (NP / 8);
+            uint4 d = make_uint4(0, 0, 0, 0);
+            if (nv * 8 < ncols) d = *reinterpret_cast<const uint4*>(p.B + (long)row * p.ldb + nbase + nv * 8);
+            *reinterpret_cast<uint4*>(Ws + row * LDW_TR + nv * 8) = d;
         }
     }
-    // ---- B tile streaming ------------------------------------------------------------------------------------
-    uint4 pre[PER];
-    auto load_tile = [&](int n0) {
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int v = tid + i * S_NT;
-            if constexpr (B_KC) {
-                const int row = v / (K / 8), kv = v % (K / 8);      // row = n
-                pre[i] = *reinterpret_cast<const uint4*>(p.B + (long)(n0 + row) * p.ldb + kv * 8);
-            } else {
-                const int row = v / (S_ZB / 8), nv = v % (S_ZB / 8);  // row = k
-                pre[i] = *reinterpret_cast<const uint4*>(p.B + (long)row * p.ldb + n0 + nv * 8);
-            }
-        }
-    };
-    auto store_tile = [&](bf16* Z) {
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int v = tid + i * S_NT;
-            if constexpr (B_KC) {
-                const int row = v / (K / 8), kv = v % (K / 8);
-                *reinterpret_cast<uint4*>(Z + row * LDZ_KC + kv * 8) = pre[i];
-            } else {
-                const int row = v / (S_ZB / 8), nv = v % (S_ZB / 8);
-                *reinterpret_cast<uint4*>(Z + row * LDZ_TR + nv * 8) = pre[i];
-            }
-        }
-    };
-    const int ntile = p.N / S_ZB;
-    load_tile(0);
-    store_tile(Zbase);
     __syncthreads();
-    for (int it = 0; it < ntile; ++it) {
-        const int n0 = it * S_ZB;
-        const bool more = it + 1 < ntile;
-        if (more) load_tile(n0 + S_ZB);
-        const bf16* Z = Zbase + (it & 1) * ZELEMS;
-        f32x4 acc[4][2];
-#pragma unroll
-        for (int jz = 0; jz < 4; ++jz) { acc[jz][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[jz][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-            for (int jz = 0; jz < 4; ++jz) {
-                bf16x8 zf;
-                if constexpr (B_KC) zf = *reinterpret_cast<const bf16x8*>(Z + (jz * 16 + l15) * LDZ_KC + kb * 32 + G * 8);
-                else zf = tr_frag32(Z, LDZ_TR, kb * 32, jz * 16, lane);
-                acc[jz][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[0][kb], acc[jz][0], 0, 0, 0);
-                acc[jz][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[1][kb], acc[jz][1], 0, 0, 0);
-            }
-        }
-        // acc[jz][ix]: L(first = n, second = m): lane holds 4 consecutive n of row m
+    const bool staged = !(p.epi.flags & (EDGL_EPI_OUT_F32 | EDGL_EPI_ACCUM | EDGL_EPI_MUL_DGELU));
+    const int nstrip = (p.M + 31) / 32;
+    for (int strip = blockIdx.x * 8 + wave; strip < nstrip; strip += gridDim.x * 8) {
+        const int m0 = strip * 32;
+        // ---- A strip fragments (k-slot order = B fragment order) ---------------------------------------------------
+        bf16x8 xf[2][NKB];
 #pragma unroll
         for (int ix = 0; ix < 2; ++ix) {
             const int m = m0 + ix * 16 + l15;
-            if (m < p.M) {
+            const bf16* row = p.A + (long)m * p.lda;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                bf16x8 f;
+                if (m < p.M) {
+                    if constexpr (B_KC) {
+                        *reinterpret_cast<uint4*>(&f) = *reinterpret_cast<const uint4*>(row + kb * 32 + G * 8);
+                    } else {
+                        *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<const uint2*>(row + kb * 32 + g4);
+                        *(reinterpret_cast<uint2*>(&f) + 1) = *reinterpret_cast<const uint2*>(row + kb * 32 + 16 + g4);
+                    }
+                } else {
+                    *reinterpret_cast<uint4*>(&f) = make_uint4(0, 0, 0, 0);
+                }
+                xf[ix][kb] = f;
+            }
+        }
+        for (int nc = 0; nc < ncols; nc += 64) {
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int jz = 0; jz < 4; ++jz) { acc[jz][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[jz][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if (!(p.dbg & 2))
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
                 for (int jz = 0; jz < 4; ++jz) {
-                    const int n = n0 + jz * 16 + g4;
-                    float x[4] = {acc[jz][ix][0], acc[jz][ix][1], acc[jz][ix][2], acc[jz][ix][3]};
-                    epi_store4(p.epi, reinterpret_cast<bf16*>(p.C), p.C, (long)m * p.ldc + n, n, x);
+                    bf16x8 zf;
+                    if constexpr (B_KC) zf = *reinterpret_cast<const bf16x8*>(Ws + (nc + jz * 16 + l15) * LDW_KC + kb * 32 + G * 8);
+                    else zf = tr_frag32(Ws, LDW_TR, kb * 32, nc + jz * 16, lane);
+                    acc[jz][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[0][kb], acc[jz][0], 0, 0, 0);
+                    acc[jz][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[1][kb], acc[jz][1], 0, 0, 0);
+                }
+            }
+            const int n0 = nbase + nc;
+            // ---- epilogue.  acc[jz][ix] = L(first = n, second = m): a lane holds 4 consecutive n of one row, which
+            //      would make every global store a 16-row x 32-byte scatter.  Simple epilogues (bias / GELU / cast)
+            //      therefore go through a wave-private LDS image and leave as whole 128-byte row segments.
+            if (p.dbg & 1) continue;
+            if (staged) {
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+#pragma unroll
+                    for (int jz = 0; jz < 4; ++jz) {
+                        const int n = n0 + jz * 16 + g4;
+                        float x[4] = {acc[jz][ix][0], acc[jz][ix][1], acc[jz][ix][2], acc[jz][ix][3]};
+                        if (p.epi.flags & EDGL_EPI_BIAS) {
+                            const float4 bb = *reinterpret_cast<const float4*>(p.epi.bias + n);
+                            x[0] += bb.x; x[1] += bb.y; x[2] += bb.z; x[3] += bb.w;
+                        }
+                        if (p.epi.flags & EDGL_EPI_SAVE_PRE) {   // pre-activation image (2 GEMMs per step)
+                            const int m = m0 + ix * 16 + l15;
+                            if (m < p.M) {
+                                Frag4<bf16> f = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
+                                *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.epi.aux) + (long)m * p.ldc + n) = *reinterpret_cast<uint2*>(&f);
+                            }
+                        }
+                        if (p.epi.flags & EDGL_EPI_GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+                        }
+                        Frag4<bf16> f = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
+                        *reinterpret_cast<uint2*>(Ostage + l15 * LDO + jz * 16 + g4) = *reinterpret_cast<uint2*>(&f);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // 16 rows x 128 B: 8 lanes per row, 8 rows per instruction, 2 instructions
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int lrow = q * 8 + (lane >> 3), cv = lane & 7, m = m0 + ix * 16 + lrow;
+                        const uint4 d = *reinterpret_cast<const uint4*>(Ostage + lrow * LDO + cv * 8);
+                        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n0 + cv * 8) = d;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    const int m = m0 + ix * 16 + l15;
+                    if (m < p.M) {
+#pragma unroll
+                        for (int jz = 0; jz < 4; ++jz) {
+                            const int n = n0 + jz * 16 + g4;
+                            float x[4] = {acc[jz][ix][0], acc[jz][ix][1], acc[jz][ix][2], acc[jz][ix][3]};
+                            epi_store4(p.epi, reinterpret_cast<bf16*>(p.C), p.C, (long)m * p.ldc + n, n, x);
+                        }
+                    }
                 }
             }
         }
-        if (more) store_tile(Zbase + ((it + 1) & 1) * ZELEMS);
-        __syncthreads();
     }
 }
 
@@ -286,13 +323,18 @@ using namespace gemm2;
 template <int NKB, bool B_KC>
 static int launch_strip(const StripP& p, hipStream_t st) {
     constexpr int K = 32 * NKB;
-    constexpr size_t zel = B_KC ? (size_t)S_ZB * (K + 8) : (size_t)K * (S_ZB + 16);
-    const size_t smem = 2 * zel * sizeof(bf16);
+    constexpr size_t wel = B_KC ? (size_t)128 * (K + 8) : (size_t)K * (128 + 16);
+    const size_t smem = (wel + (size_t)8 * 16 * (64 + 8)) * sizeof(bf16);
+    if (smem > 160 * 1024) return 0;
     auto k = strip_gemm_kernel<NKB, B_KC>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, dim3((p.M + 127) / 128), dim3(S_NT), smem, st, p);
+    const int nparts = (p.N + 127) / 128;
+    const int per_cu = std::max(1, (int)((160 * 1024) / smem));
+    const int nstrip8 = (p.M + 255) / 256;
+    const int gx = std::max(1, std::min(nstrip8, (256 * std::min(per_cu, 2)) / nparts));
+    hipLaunchKernelGGL(k, dim3(gx, nparts), dim3(W_NT), smem, st, p);
     EDGL_LAUNCH_CHECK();
-    return EDGL_OK;
+    return 1;
 }
 
 // returns 1 if the fast path was taken, 0 if the shape does not qualify, <0 on error
@@ -302,7 +344,8 @@ int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, in
                     (ldc % 4 == 0) && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 &&
                     (!aux || ((uintptr_t)aux & 7) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
     if (!ok) return 0;
-    StripP p{(const bf16*)A, (const bf16*)B, C, M, N, K, lda, ldb, ldc, EpiP{bias, aux, flags}};
+    static const int dbg = getenv("EDGL_DBG") ? atoi(getenv("EDGL_DBG")) : 0;
+    StripP p{(const bf16*)A, (const bf16*)B, C, M, N, K, lda, ldb, ldc, EpiP{bias, aux, flags}, dbg};
     int rc;
 #define STRIP_CASE(NKB)                                                             \
     case NKB: rc = b_kc ? launch_strip<NKB, true>(p, st) : launch_strip<NKB, false>(p, st); break;
@@ -311,7 +354,7 @@ int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, in
         default: return 0;
     }
 #undef STRIP_CASE
-    return rc ? rc : 1;
+    return rc;
 }
 
 // C[Kf,N] = X^T . Y (f32, overwritten or accumulated); if dbias != nullptr also dbias[N] = colsum(Y).
