@@ -18,11 +18,17 @@
 namespace bimau {
 
 constexpr int EP = 16;  // marks padded to one MFMA K-block
+constexpr float NLOG2E = -1.4426950408889634f;
+
+// sigmoid of a pre-activation that was already multiplied by -log2(e)
+__device__ __forceinline__ float sigmoid_pre(float xs) { return fast_rcp(1.0f + __builtin_amdgcn_exp2f(xs)); }
 
 // ---- intensity-weight pack (built once per launch by pack_kernel, copied to LDS by every WG) ---
-// T-typed: W1T [JE][LDW]  (W1T[j][u] = W1[u][j], u < dh)        -> A operand of Zpre^T = W1^T.H^T
-//          W1R [dh][LDR]  (W1R[u][j] = W1[u][j])                -> A operand of dH^T = W1.du^T
-// f32:     w1s [JE] = W1[dh][j] (interval weight), b1 [JE], wv [JE] = w.flatten(), sc[16]=exp(scaling)
+// T-typed: W1T [JE][LDW]  (W1T[j][u] = -log2e * W1[u][j], u < dh) -> A operand of Zpre'^T = W1T.H^T
+//          W1R [dh][LDR]  (W1R[u][j] = W1[u][j], unscaled)       -> A operand of dH^T = W1.du^T
+// f32:     w1s [JE] = -log2e * W1[dh][j] (interval weight), b1 [JE] = -log2e * b1, wv [JE] = w.flatten(),
+//          sc[16] = exp(scaling), isc[16] = 1/sc.
+// The -log2(e) factor turns sigmoid(x) into rcp(1 + exp2(x')) — one v_exp_f32 and one v_rcp_f32, no multiply.
 struct PackDims {
     int dh, E, JE, LDW, LDR;
     size_t off_w1r, off_f32, bytes;  // byte offsets
@@ -52,15 +58,15 @@ __global__ void pack_kernel(const float* W1, const float* b1, const float* w, co
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     for (int i = tid; i < d.JE * d.LDW; i += nth) {
         const int j = i / d.LDW, u = i % d.LDW;
-        w1t[i] = from_f32<T>(u < dh ? W1[(long)u * d.JE + j] : 0.f);
+        w1t[i] = from_f32<T>(u < dh ? NLOG2E * W1[(long)u * d.JE + j] : 0.f);
     }
     for (int i = tid; i < dh * d.LDR; i += nth) {
         const int u = i / d.LDR, j = i % d.LDR;
         w1r[i] = from_f32<T>(j < d.JE ? W1[(long)u * d.JE + j] : 0.f);
     }
     for (int j = tid; j < d.JE; j += nth) {
-        f[j] = W1[(long)dh * d.JE + j];
-        f[d.JE + j] = b1[j];
+        f[j] = NLOG2E * W1[(long)dh * d.JE + j];
+        f[d.JE + j] = NLOG2E * b1[j];
         f[2 * d.JE + j] = w[j];
     }
     for (int e = tid; e < EP; e += nth) {
@@ -70,37 +76,42 @@ __global__ void pack_kernel(const float* W1, const float* b1, const float* w, co
     }
 }
 
-// per-wave key bookkeeping: bit (kt*4+r) for key k = kt*16 + (lane>>4)*4 + r
-struct KeyBits { uint32_t real, pad; };
+// per-lane key mask, ADDITIVE: madd[kt][r] for key k = kt*16 + (lane>>4)*4 + r is
+//   0           real, unpadded key
+//   -2^32       padded key (ids == 0): c*s + (-2^32) == float32(-2^32+1) exactly for |c*s| < 256, which is what
+//               tf.where(mask == 0, -2**32+1, s) leaves (temporal.py:425-426)
+//   -inf        k >= T (tile padding: excluded from the softmax)
+// `pad` keeps the padded-key bits for the backward (no gradient flows into a padded score).
 template <int NT>
-__device__ __forceinline__ KeyBits load_keybits(const int64_t* ids_row, int T, int lane) {
-    KeyBits kb{0u, 0u};
+struct KeyMask { f32x4 madd[NT]; uint32_t pad; };
+template <int NT>
+__device__ __forceinline__ KeyMask<NT> load_keymask(const int64_t* ids_row, int T, int lane) {
+    KeyMask<NT> km;
+    km.pad = 0u;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = kt * 16 + (lane >> 4) * 4 + r;
+            float v = -INFINITY;
             if (k < T) {
-                kb.real |= 1u << (kt * 4 + r);
-                if (ids_row[k] == 0) kb.pad |= 1u << (kt * 4 + r);
+                v = 0.f;
+                if (ids_row[k] == 0) { v = -4294967296.0f; km.pad |= 1u << (kt * 4 + r); }
             }
+            km.madd[kt][r] = v;
         }
-    return kb;
+    return km;
 }
 
 // S^T tiles -> normalised P^T tiles (temporal.py:422-429).  s[kt][r] in: raw Q.K; out: softmax.
 template <int NT>
-__device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyBits& kb, float cscale) {
-    const float PADV = -4294967296.0f;  // float32(-2**32+1), temporal.py:425
+__device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale) {
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t bit = 1u << (kt * 4 + r);
-            float v = s[kt][r] * cscale;
-            v = (kb.pad & bit) ? PADV : v;
-            v = (kb.real & bit) ? v : -INFINITY;
+            const float v = fmaf(s[kt][r], cscale, km.madd[kt][r]);
             s[kt][r] = v;
             mx = fmaxf(mx, v);
         }
@@ -110,6 +121,7 @@ __device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyBits& kb
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            // (s - mx) first: exact 0 for the row maximum even at the -2^32 padding magnitude
             const float e = __expf(s[kt][r] - mx);
             s[kt][r] = e;
             sum += e;
@@ -155,6 +167,24 @@ __device__ __forceinline__ void all_gather16(const float (&in)[4], float (&out)[
         const float other = __shfl_xor(y[i], 32, 64);
         out[i] = b5 ? other : y[i];
         out[i + 8] = b5 ? y[i] : other;
+    }
+}
+
+// A/B fragment with the CONTRACTION index along the rows of a tile: v[j] = X[k0 + 4G + j][z0 + (l&15)].
+//   bf16: one ds_read_b64_tr_b16 on the ROW-MAJOR tile rm[k][z] (ld_rm elements per row)
+//   f32 : no 32-bit transpose read exists -> plain read of a separately staged transposed image tr[z][k]
+template <typename T>
+__device__ __forceinline__ Frag4<T> kfrag(const T* rm, int ld_rm, const T* tr, int ld_tr, int k0, int z0, int lane) {
+    if constexpr (sizeof(T) == 2) {
+        const int G = lane >> 4, s = lane & 15;
+        typedef __attribute__((ext_vector_type(4))) short s4;
+        const T* p = rm + (k0 + 4 * G + (s >> 2)) * ld_rm + z0 + 4 * (s & 3);
+        s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
+        Frag4<T> f;
+        *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<uint2*>(&v);
+        return f;
+    } else {
+        return frag_ld<T>(tr + (z0 + (lane & 15)) * ld_tr + k0 + (lane >> 4) * 4);
     }
 }
 

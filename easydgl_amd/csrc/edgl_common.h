@@ -217,6 +217,11 @@ __device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t idx) {
     h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
     return h >= k.thresh;
 }
+__device__ __forceinline__ bool drop_keep32(const DropKey& k, uint32_t idx) {   // == drop_keep(k, idx) for idx < 2^32
+    uint32_t h = (idx ^ k.k0) * 0x9E3779B1u + k.k1;
+    h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
+    return h >= k.thresh;
+}
 __device__ __forceinline__ float drop_apply(const DropKey& k, uint64_t idx, float x) {
     return k.thresh == 0u ? x : (drop_keep(k, idx) ? x * k.scale : 0.f);
 }

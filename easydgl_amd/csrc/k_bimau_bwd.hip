@@ -53,23 +53,27 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
     const int b = (int)(job / p.H), head = (int)(job % p.H);
     const long bp = (long)head * p.B + b;
 
-    constexpr size_t WAVE_ELEMS = 3 * (size_t)Tp * dh + 2 * (size_t)dh * LDT + (size_t)Tp * EP + (size_t)EP * LDT;
+    // bf16: K, T_, V row-major [Tp][dh] + marks [Tp][16]; every product that contracts over the KEY index reads its
+    // operand with transpose reads (kfrag).  f32: additionally K^T, T_^T, marks^T images (no 32-bit transpose read).
+    constexpr bool TR = sizeof(T) == 2;
+    constexpr size_t EXTRA = TR ? 0 : 2 * (size_t)dh * LDT + (size_t)EP * LDT;
+    constexpr size_t WAVE_ELEMS = 3 * (size_t)Tp * dh + (size_t)Tp * EP + EXTRA;
     T* Ks = reinterpret_cast<T*>(smem + pd.bytes) + (size_t)wave * WAVE_ELEMS;  // K  [Tp][dh]
     T* Ts = Ks + Tp * dh;                                                       // T_ [Tp][dh]
     T* Vs = Ts + Tp * dh;                                                       // V  [Tp][dh]
-    T* KTs = Vs + Tp * dh;                                                      // K^T  [dh][LDT]
-    T* TTs = KTs + dh * LDT;                                                    // T_^T [dh][LDT]
-    T* Ms = TTs + dh * LDT;                                                     // marks   [Tp][16]
-    T* MTs = Ms + Tp * EP;                                                      // marks^T [16][LDT]
+    T* Ms = Vs + Tp * dh;                                                       // marks   [Tp][16]
+    T* KTs = Ms + Tp * EP;                                                      // f32 only: K^T  [dh][LDT]
+    T* TTs = KTs + dh * LDT;                                                    // f32 only: T_^T [dh][LDT]
+    T* MTs = TTs + dh * LDT;                                                    // f32 only: marks^T [16][LDT]
     const T* qkvt = reinterpret_cast<const T*>(p.qkvt) + (long)b * p.T * 4 * p.C;
     const T* dout = reinterpret_cast<const T*>(p.d_out) + (long)b * p.T * p.C;
     T* dqkvt = reinterpret_cast<T*>(p.d_qkvt) + (long)b * p.T * 4 * p.C;
     const int ldq = 4 * p.C;
-    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, KTs, LDT, lane);
-    stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, Ts, TTs, LDT, lane);
+    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, TR ? nullptr : KTs, LDT, lane);
+    stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, Ts, TR ? nullptr : TTs, LDT, lane);
     stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, Vs, nullptr, LDT, lane);
-    stage_marks<T>(p.marks + (long)b * p.T * p.E, p.E, p.T, Tp, Ms, MTs, LDT, lane);
-    const KeyBits kb = load_keybits<NT>(p.ids + (long)b * p.T, p.T, lane);
+    stage_marks<T>(p.marks + (long)b * p.T * p.E, p.E, p.T, Tp, Ms, TR ? nullptr : MTs, LDT, lane);
+    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, kb, cscale);  // s = P^T, L(first=k, second=q)
+        masked_softmax<NT>(s, km, cscale);  // s = P^T, L(first=k, second=q)
         // ---- H^T and the intensity MLP ----------------------------------------------------------
         Frag4<T> hf[DT];
         {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
                 f32x4 a = zero4;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
-                    a = mma16(frag_ld<T>(TTs + (ut * 16 + l15) * LDT + kt * 16 + g4), pf[kt], a);
+                    a = mma16(kfrag<T>(Ts, dh, TTs, LDT, kt * 16, ut * 16, lane), pf[kt], a);
                 hf[ut] = frag_from_acc<T>(a);
                 if (qok) {  // Hin rows for kernel B (T-rounded, identical to what Z is computed from)
                     T* dst = reinterpret_cast<T*>(p.hin_ws) + (bp * p.T + q) * dh + ut * 16 + g4;
@@ -149,10 +153,10 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
                     const float4 bs = *reinterpret_cast<const float4*>(b1s + jt * 16 + g4);
                     const float4 wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
                     f32x4 zz;
-                    zz[0] = sigmoid_f(a[0] + span * ws.x + bs.x);
-                    zz[1] = sigmoid_f(a[1] + span * ws.y + bs.y);
-                    zz[2] = sigmoid_f(a[2] + span * ws.z + bs.z);
-                    zz[3] = sigmoid_f(a[3] + span * ws.w + bs.w);
+                    zz[0] = sigmoid_pre(a[0] + fmaf(span, ws.x, bs.x));
+                    zz[1] = sigmoid_pre(a[1] + fmaf(span, ws.y, bs.y));
+                    zz[2] = sigmoid_pre(a[2] + fmaf(span, ws.z, bs.z));
+                    zz[3] = sigmoid_pre(a[3] + fmaf(span, ws.w, bs.w));
                     zt[e][d] = zz;
                     zp[e] += zz[0] * wv.x + zz[1] * wv.y + zz[2] * wv.z + zz[3] * wv.w;
                 }
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
         for (int vt = 0; vt < DT; ++vt) dOT[vt] = frag_from_acc<T>(mma16(dof[vt], ident, zero4));
         f32x4 dp[NT];
         f32x4 dlamT = zero4;  // L(first=e, second=q)
+        const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);   // dropout element index of (b', q, k=0)
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             const f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, zero4);
@@ -182,22 +187,27 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
 #pragma unroll
             for (int vb = 0; vb < DT; ++vb)
                 da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), dof[vb], da);
-            f32x4 ap, dg, d1;
+            f32x4 ap, dg, d1, gv = gacc;
+            if (kt == qt) {   // only this key tile can hold k == q: G' diag := 1 (temporal.py:438-439)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = kt * 16 + g4 + r;
-                const bool diag = (k == q);
-                const float gv = diag ? 1.0f : gacc[r];
                 const float pv = s[kt][r];
                 float fac = 1.0f;
-                if (dk.thresh != 0u) fac = drop_keep(dk, (uint64_t)((bp * p.T + q) * p.T + k)) ? dk.scale : 0.f;
-                ap[r] = fac * gv * pv;                    // A' = D*G'*P
+                if (dk.thresh != 0u) fac = drop_keep32(dk, dbase + kt * 16 + g4 + r) ? dk.scale : 0.f;
+                ap[r] = fac * gv[r] * pv;                 // A' = D*G'*P
                 const float dad = da[r] * fac;
-                dg[r] = diag ? 0.f : dad * pv;            // set_diag blocks the gradient
-                d1[r] = dad * gv;                         // dP through A'
+                dg[r] = dad * pv;
+                d1[r] = dad * gv[r];                      // dP through A'
+            }
+            if (kt == qt) {   // set_diag blocks the gradient into lambda
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dg[r] = (g4 + r == l15) ? 0.f : dg[r];
             }
             dp[kt] = d1;
-            dlamT = mma16(frag_ld<T>(MTs + l15 * LDT + kt * 16 + g4), frag_from_acc<T>(dg), dlamT);
+            dlamT = mma16(kfrag<T>(Ms, EP, MTs, LDT, kt * 16, 0, lane), frag_from_acc<T>(dg), dlamT);
             const Frag4<T> apT = frag_from_acc<T>(transpose_tile<T>(ap, ident));  // L(first=q, second=k)
 #pragma unroll
             for (int vt = 0; vt < DT; ++vt) dVa[vt][kt] = mma16(dOT[vt], apT, dVa[vt][kt]);
@@ -271,13 +281,13 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
             for (int r = 0; r < 4; ++r) {
                 // tf.where(mask==0, paddings, S) (temporal.py:425-426) passes no gradient to a padded key's
                 // score; P is non-zero there only for fully padded rows (uniform softmax)
-                const bool padded = (kb.pad >> (kt * 4 + r)) & 1u;
+                const bool padded = (km.pad >> (kt * 4 + r)) & 1u;
                 ds[r] = padded ? 0.f : s[kt][r] * (dp[kt][r] - rowdot) * cscale;
             }
             const Frag4<T> dsf = frag_from_acc<T>(ds);
 #pragma unroll
             for (int ut = 0; ut < DT; ++ut)
-                dQ[ut] = mma16(frag_ld<T>(KTs + (ut * 16 + l15) * LDT + kt * 16 + g4), dsf, dQ[ut]);
+                dQ[ut] = mma16(kfrag<T>(Ks, dh, KTs, LDT, kt * 16, ut * 16, lane), dsf, dQ[ut]);
             const Frag4<T> dsT = frag_from_acc<T>(transpose_tile<T>(ds, ident));
             const Frag4<T> pT = frag_from_acc<T>(transpose_tile<T>(s[kt], ident));
 #pragma unroll
@@ -397,7 +407,7 @@ __global__ __launch_bounds__(256) void intensity_wgrad_kernel(WgP p) {
                     float sdb = 0.f, sdws = 0.f, sdw = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float z = sigmoid_f(a[r] + spn[r] * ws + bs);
+                        const float z = sigmoid_pre(a[r] + fmaf(spn[r], ws, bs));
                         const float t2 = dzr[r] * z;
                         du[r] = t2 * wv * (1.0f - z);
                         sdb += du[r]; sdws += du[r] * spn[r]; sdw += t2;
@@ -476,9 +486,9 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     const WsLayout wl = ws_layout<T>(p.B, p.T, p.C, p.H, p.E);
     p.hin_ws = ws + wl.hin; p.dz_ws = reinterpret_cast<float*>(ws + wl.dz);
     p.dsc_part = reinterpret_cast<float*>(ws + wl.dsc); p.wpart = reinterpret_cast<float*>(ws + wl.wpart);
-    const size_t wave_bytes = (3 * (size_t)Tp * dh + 2 * (size_t)dh * LDT + (size_t)Tp * EP + (size_t)EP * LDT) * sizeof(T);
+    const size_t wave_bytes = (3 * (size_t)Tp * dh + (size_t)Tp * EP + (sizeof(T) == 2 ? 0 : 2 * (size_t)dh * LDT + (size_t)EP * LDT)) * sizeof(T);
     int waves = 4;
-    while (waves > 1 && pd.bytes + waves * wave_bytes > 150 * 1024) waves >>= 1;
+    while (waves > 1 && pd.bytes + waves * wave_bytes > 80 * 1024) waves >>= 1;
     const size_t smem = pd.bytes + waves * wave_bytes;
     EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: needs %zu B of LDS", smem);
     p.waves = waves;
@@ -540,6 +550,7 @@ extern "C" int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float*
     EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
                  "edgl_bimau_bwd: bad shape B=%d T=%d C=%d H=%d E=%d", B, T, C, H, E);
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_bimau_bwd: dropout without rng_state");
+    EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "edgl_bimau_bwd: H*B*T*T must be < 2^32");
     BwdP p{};
     p.qkvt = qkvt; p.ids = ids; p.spans = spans; p.marks = marks; p.pack = (const char*)pack; p.d_out = d_out;
     p.d_lam_ext = d_lam_ext; p.B = B; p.T = T; p.C = C; p.H = H; p.E = E; p.rate = drop_rate; p.rng = rng_state;

@@ -39,19 +39,22 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     const int b = (int)(job / p.H), head = (int)(job % p.H);
     const long bp = (long)head * p.B + b;  // head-major index b' (temporal.py:413-416)
 
-    // ---- wave-private LDS: K row-major, T_^T, V^T, marks row-major -----------------------------
-    constexpr size_t WAVE_ELEMS = (size_t)Tp * dh + 2 * (size_t)dh * LDT + (size_t)Tp * EP;
+    // ---- wave-private LDS.  bf16: K, T_, V row-major [Tp][dh] + marks [Tp][16]; products that contract over the
+    //      KEY index fetch their operand with transpose reads (kfrag).  f32: T_ and V are staged transposed instead.
+    constexpr bool TR = sizeof(T) == 2;
+    constexpr size_t KV_ELEMS = TR ? (size_t)Tp * dh : (size_t)dh * LDT;
+    constexpr size_t WAVE_ELEMS = (size_t)Tp * dh + 2 * KV_ELEMS + (size_t)Tp * EP;
     T* Ks = reinterpret_cast<T*>(smem + pd.bytes) + (size_t)wave * WAVE_ELEMS;
-    T* TTs = Ks + Tp * dh;
-    T* VTs = TTs + dh * LDT;
-    T* Ms = VTs + dh * LDT;
+    T* Ts = Ks + Tp * dh;       // T_ : row-major (bf16) or transposed [dh][LDT] (f32)
+    T* Vs = Ts + KV_ELEMS;      // V  : same
+    T* Ms = Vs + KV_ELEMS;
     const T* qkvt = reinterpret_cast<const T*>(p.qkvt) + (long)b * p.T * 4 * p.C;
     const int ldq = 4 * p.C;
     stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, nullptr, LDT, lane);           // K  (split order Q,K,V,T: temporal.py:410)
-    stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, nullptr, TTs, LDT, lane);      // T_
-    stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, nullptr, VTs, LDT, lane);      // V
+    stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Ts : nullptr, TR ? nullptr : Ts, LDT, lane);   // T_
+    stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Vs : nullptr, TR ? nullptr : Vs, LDT, lane);   // V
     stage_marks<T>(p.marks + (long)b * p.T * p.E, p.E, p.T, Tp, Ms, nullptr, LDT, lane);
-    const KeyBits kb = load_keybits<NT>(p.ids + (long)b * p.T, p.T, lane);
+    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, kb, cscale);  // s := P^T
+        masked_softmax<NT>(s, km, cscale);  // s := P^T
         // ---- H^T[u][q] = sum_k T_[k][u] P[q][k] -----------------------------------------------
         Frag4<T> pf[NT];
 #pragma unroll
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
-                a = mma16(frag_ld<T>(TTs + (ut * 16 + l15) * LDT + kt * 16 + g4), pf[kt], a);
+                a = mma16(kfrag<T>(Ts, dh, Ts, LDT, kt * 16, ut * 16, lane), pf[kt], a);
             hf[ut] = frag_from_acc<T>(a);
         }
         // ---- intensity MLP (temporal.py:287-306): Zpre^T[j][q], channel j = e*dh + u' ------------
@@ -108,8 +111,8 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                     const float4 ws = *reinterpret_cast<const float4*>(w1s + jt * 16 + g4);
                     const float4 bs = *reinterpret_cast<const float4*>(b1s + jt * 16 + g4);
                     const float4 wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
-                    zp[e] += sigmoid_f(a[0] + span * ws.x + bs.x) * wv.x + sigmoid_f(a[1] + span * ws.y + bs.y) * wv.y +
-                             sigmoid_f(a[2] + span * ws.z + bs.z) * wv.z + sigmoid_f(a[3] + span * ws.w + bs.w) * wv.w;
+                    zp[e] += sigmoid_pre(a[0] + fmaf(span, ws.x, bs.x)) * wv.x + sigmoid_pre(a[1] + fmaf(span, ws.y, bs.y)) * wv.y +
+                             sigmoid_pre(a[2] + fmaf(span, ws.z, bs.z)) * wv.z + sigmoid_pre(a[3] + fmaf(span, ws.w, bs.w)) * wv.w;
                 }
             }
         }
@@ -130,15 +133,18 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                 if (g4 + i < p.E) dst[i] = lam4[i];
         }
         // ---- G^T[k][q] = sum_e marks[k][e] lam[q][e]; diag := 1; A' = dropout(G * P) ------------
+        const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);   // element index of (b', q, k=0); < 2^32 (host-checked)
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, f32x4{0.f, 0.f, 0.f, 0.f});
+            if (kt == qt) {   // only this key tile can contain k == q (temporal.py:438-439)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gacc[r] = (g4 + r == l15) ? 1.0f : gacc[r];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = kt * 16 + g4 + r;
-                const float gv = (k == q) ? 1.0f : gacc[r];  // temporal.py:438-439
-                float a = gv * s[kt][r];                      // temporal.py:441
-                a = drop_apply(dk, (uint64_t)((bp * p.T + q) * p.T + k), a);  // temporal.py:442
+                float a = gacc[r] * s[kt][r];                 // temporal.py:441
+                if (dk.thresh != 0u) a = drop_keep32(dk, dbase + kt * 16 + g4 + r) ? a * dk.scale : 0.f;  // temporal.py:442
                 s[kt][r] = a;
             }
             pf[kt] = frag_from_acc<T>(s[kt]);
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
-                a = mma16(frag_ld<T>(VTs + (vt * 16 + l15) * LDT + kt * 16 + g4), pf[kt], a);
+                a = mma16(kfrag<T>(Vs, dh, Vs, LDT, kt * 16, vt * 16, lane), pf[kt], a);
             if (qok) {
                 const int col = head * dh + vt * 16 + g4;
                 const Frag4<T> rf = frag_ld<T>(reinterpret_cast<const T*>(p.resid) + ((long)b * p.T + q) * p.ld_res + col);
@@ -168,7 +174,7 @@ template <typename T, int DT, int NT>
 int launch_fwd(FwdP p, hipStream_t st) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     const PackDims pd = pack_dims<T>(dh, p.E);
-    const size_t wave_bytes = ((size_t)Tp * dh + 2 * (size_t)dh * LDT + (size_t)Tp * EP) * sizeof(T);
+    const size_t wave_bytes = ((size_t)Tp * dh + 2 * (sizeof(T) == 2 ? (size_t)Tp * dh : (size_t)dh * LDT) + (size_t)Tp * EP) * sizeof(T);
     int waves = 4;
     while (waves > 1 && pd.bytes + waves * wave_bytes > 64 * 1024) waves >>= 1;
     const size_t smem = pd.bytes + waves * wave_bytes;
@@ -239,6 +245,7 @@ extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, c
                  "edgl_bimau_fwd: bad shape B=%d T=%d C=%d H=%d E=%d", B, T, C, H, E);
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_bimau_fwd: dropout without rng_state");
     EDGL_REQUIRE(ld_res % 4 == 0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: ld_res must be a multiple of 4");
+    EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: H*B*T*T must be < 2^32");
     FwdP p{qkvt, resid, ld_res, ids, spans, marks, (const char*)pack, B, T, C, H, E, drop_rate, rng_state, stream_id,
            out, lam_out, 4};
     hipStream_t st = (hipStream_t)stream;

@@ -99,7 +99,7 @@ template <int NKB, bool B_KC>
 __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
     constexpr int K = 32 * NKB;
     constexpr int NP = 128;                 // columns per slice (gridDim.y slices)
-    constexpr int LDW_KC = K + 8;           // [NP][K+8]    rows n
+    constexpr int LDW_KC = K + 16;          // [NP][K+16]   rows n (+32 B: conflict-free b128 reads)
     constexpr int LDW_TR = NP + 16;         // [K][NP+16]   rows k
     constexpr int WELEMS = B_KC ? NP * LDW_KC : K * LDW_TR;
     constexpr int LDO = 64 + 8;             // per-wave output staging [16][64+8] (one 16-row tile at a time)
@@ -323,7 +323,7 @@ using namespace gemm2;
 template <int NKB, bool B_KC>
 static int launch_strip(const StripP& p, hipStream_t st) {
     constexpr int K = 32 * NKB;
-    constexpr size_t wel = B_KC ? (size_t)128 * (K + 8) : (size_t)K * (128 + 16);
+    constexpr size_t wel = B_KC ? (size_t)128 * (K + 16) : (size_t)K * (128 + 16);
     const size_t smem = (wel + (size_t)8 * 16 * (64 + 8)) * sizeof(bf16);
     if (smem > 160 * 1024) return 0;
     auto k = strip_gemm_kernel<NKB, B_KC>;

@@ -9,6 +9,7 @@
 namespace {
 thread_local char g_err[512] = "";
 constexpr int RED_BLOCKS = 64;
+constexpr int SUMSQ_BLOCKS = 1024;
 }  // namespace
 
 extern "C" void edgl_set_error(const char* fmt, ...) {
@@ -135,10 +136,10 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* w, cons
     if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 __global__ void sumsq_final_kernel(const float* part, int nblk, float scale, float* out, int accumulate) {
-    if (threadIdx.x != 0) return;
     float a = 0.f;
-    for (int i = 0; i < nblk; ++i) a += part[i];
-    out[0] = accumulate ? out[0] + scale * a : scale * a;
+    for (int i = threadIdx.x; i < nblk; i += 64) a += part[i];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + scale * a : scale * a;
 }
 
 template <typename T>
@@ -268,9 +269,9 @@ extern "C" int edgl_l2_loss(const float* param, const int64_t* seg, int nseg, fl
                             float* workspace, void* stream) {
     EDGL_REQUIRE(param && seg && out && workspace, EDGL_ERR_NULL, "edgl_l2_loss: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, param, seg, nseg, workspace);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, st, param, seg, nseg, workspace);
     EDGL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, workspace, RED_BLOCKS, 0.5f * l2, out, accumulate);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, st, workspace, SUMSQ_BLOCKS, 0.5f * l2, out, accumulate);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

@@ -30,7 +30,7 @@ struct SC {
     static constexpr int KB = ElemTraits<T>::KB;
     static constexpr int C = 16 * CT;
     static constexpr int NKB = C / KB;
-    static constexpr int LDC = C + VEC;       // Z  image: [ZB][LDC]   (row z, k contiguous)
+    static constexpr int LDC = C + 2 * VEC;   // Z  image: [ZB][LDC]   (row z, k contiguous); +32 B: conflict-free b128 reads
     static constexpr int LDZ = ZB + VEC;      // ZT image: [C][LDZ]    (row c, z contiguous)
     static constexpr int CV = C / VEC;
     static constexpr int PER_Z = ZB * CV / SNT;          // 16-byte vectors per thread, Z image
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
         if (more) zs.load(table, nullptr, 0, n0 + ZB, c_hi, true);
         const T* Zs = reinterpret_cast<const T*>(cur);
         const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES);
+        const bool edge = (n0 == 0) || (n0 + ZB > c_hi);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 acc[4][2];
@@ -194,10 +195,12 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
                     const float bb[4] = {bz.x, bz.y, bz.z, bz.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int n = n0 + jz * 16 + g4 + r;
                         float x = acc[j][ix][r] + bb[r];
-                        x = (n == 0) ? -1000.0f : x;       // zero-padded row . y + (-1000)  (Base.py:110)
-                        x = (n < c_hi) ? x : -INFINITY;
+                        if (edge) {   // only the tile holding column 0 or the chunk tail needs per-element tests
+                            const int n = n0 + jz * 16 + g4 + r;
+                            x = (n == 0) ? -1000.0f : x;       // zero-padded row . y + (-1000)  (Base.py:110)
+                            x = (n < c_hi) ? x : -INFINITY;
+                        }
                         acc[j][ix][r] = x;
                         tmax = fmaxf(tmax, x);
                     }
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(SNT) void score_bwd_kernel(ScoreP p) {
         const T* Zs = reinterpret_cast<const T*>(cur);
         const T* ZTs = reinterpret_cast<const T*>(cur + S::Z_BYTES);
         const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES + S::ZT_BYTES);
+        const bool edge = (ROLE == ROLE_Y) && ((z0 == 0) || (z0 + ZB > z_hi));
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 acc[4][2];
@@ -386,10 +390,10 @@ __global__ __launch_bounds__(SNT) void score_bwd_kernel(ScoreP p) {
                         float d;
                         if (ROLE == ROLE_Y) {
                             float x = acc[j][ix][r] + zb[r];
-                            x = (gz == 0) ? -1000.0f : x;
+                            if (edge) x = (gz == 0) ? -1000.0f : x;
                             d = __expf(x - x_lse[ix]);
                             if (gz == x_lab[ix]) d -= x_cf[ix];
-                            d = (gz < z_hi) ? d : 0.f;
+                            if (edge) d = (gz < z_hi) ? d : 0.f;
                         } else {
                             float x = acc[j][ix][r] + x_bias[ix];
                             x = (x_lab[ix] == 0) ? -1000.0f : x;

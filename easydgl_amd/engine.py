@@ -71,7 +71,7 @@ class TrainEngine:
         # ---- workspaces -----------------------------------------------------------------------------------------------
         wsz = [2 * self.R * lib.edgl_score_chunks(self.R, I),
                lib.edgl_score_bwd_workspace(self.R, C, I, I, self.code),
-               lib.edgl_encode_bwd_workspace(B, T, C), B * 2 * C, 64]
+               lib.edgl_encode_bwd_workspace(B, T, C), B * 2 * C, 1024]
         for (kf, n) in ((3 * C, 4 * C), (C, 4 * C), (C, C), (C, 2 * C), (2 * C, C)):
             wsz.append(lib.edgl_gemm_dw_workspace(self.rows, kf, n, self.code))
         self.ws = e(max(wsz), dtype=f32)

@@ -382,7 +382,7 @@ class L2Fn(torch.autograd.Function):
     def forward(ctx, w, l2):
         seg = torch.tensor([0, w.numel()], device=w.device, dtype=torch.int64)
         out = torch.empty(1, device=w.device, dtype=torch.float32)
-        ws = torch.empty(64, device=w.device, dtype=torch.float32)
+        ws = torch.empty(1024, device=w.device, dtype=torch.float32)
         check(lib.edgl_l2_loss(_ptr(w), _ptr(seg), 1, float(l2), _ptr(out), 0, _ptr(ws), _stream()), "edgl_l2_loss")
         ctx.save_for_backward(w)
         ctx.l2 = l2

@@ -212,7 +212,7 @@ int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const int64_t* lab
 int edgl_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr, float beta1,
                    float beta2, float eps, uint64_t* step_state, float l2, const int64_t* seg, int nseg,
                    void* shadow, void* stream);
-/* l2 part of the loss: out[0] (+)= 0.5*l2*sum(w[seg]^2)  (EasyDGL.py:158); workspace >= 64 floats. */
+/* l2 part of the loss: out[0] (+)= 0.5*l2*sum(w[seg]^2)  (EasyDGL.py:158); workspace >= 1024 floats. */
 int edgl_l2_loss(const float* param, const int64_t* seg, int nseg, float l2, float* out, int accumulate,
                  float* workspace, void* stream);
 /* element-wise helpers on `dtype` buffers */
