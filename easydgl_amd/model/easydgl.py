@@ -190,6 +190,30 @@ class EasyDGL(Sequential):
         _, _, logits = ops.score_lse(rows, self.compute(tab), self.output_bias, None, 0, self.num_items, want_logits=True)
         return ops.mask_topk(logits, 0, features["seqs_i"] if mask_seen else None, K)
 
+    @torch.no_grad()
+    def eval_topk_sharded(self, features, mask_seen=True, K=100, group=None, world=None, rank=None):
+        """Row-sharded full-catalogue scoring: this rank scores the batch against its contiguous
+        shard of the item table, masks seen ids that fall in the shard, keeps a local top-K with GLOBAL ids; one
+        packed all-gather + merge kernel give the global top-K.  `world`/`rank` may be passed explicitly to
+        emulate S shards in one process (tests); with torch.distributed they come from the process group."""
+        from .. import parallel
+        rows, _ = self.encoder(features, False, self._gather_pos(features, False))
+        tab_c = self.compute(self.item_embs.lookup_table)
+        seen = features["seqs_i"] if mask_seen else None
+
+        def local_topk(i0, i1):
+            if i1 <= i0:
+                R = rows.shape[0]
+                return (torch.full((R, K), float("-inf"), device=rows.device),
+                        torch.full((R, K), -1, device=rows.device, dtype=torch.int32))
+            _, _, logits = ops.score_lse(rows, tab_c, self.output_bias, None, i0, i1, want_logits=True)
+            return ops.mask_topk(logits, i0, seen, K)
+
+        if world is not None:   # in-process emulation of `world` shards
+            vals, idxs = zip(*(local_topk(*parallel.shard_bounds(self.num_items, world, r)) for r in range(world)))
+            return ops.topk_merge(torch.stack(vals), torch.stack(idxs))
+        return parallel.sharded_topk(local_topk, ops.topk_merge, self.num_items, K, group)
+
     def reset_metrics(self):
         self._metrics = torch.zeros(6, device=self._arena.device, dtype=torch.float32)
         self._metric_count = 0

@@ -18,11 +18,14 @@ import torch
 import torch.distributed as dist
 
 
-def shard_bounds(num_rows: int, world: int, rank: int) -> Tuple[int, int]:
-    """Contiguous row shard [i0, i1) of the item table for `rank` (last shards may be one row shorter)."""
-    base, rem = divmod(num_rows, world)
-    i0 = rank * base + min(rank, rem)
-    return i0, i0 + base + (1 if rank < rem else 0)
+def shard_bounds(num_rows: int, world: int, rank: int, align: int = 8) -> Tuple[int, int]:
+    """Contiguous row shard [i0, i1) of the item table for `rank`.  Shard starts are multiples of `align`
+    (the scoring kernels read 16-byte vectors of the transposed table), sizes differ by at most `align`."""
+    blocks = (num_rows + align - 1) // align
+    base, rem = divmod(blocks, world)
+    b0 = rank * base + min(rank, rem)
+    b1 = b0 + base + (1 if rank < rem else 0)
+    return min(b0 * align, num_rows), min(b1 * align, num_rows)
 
 
 def sharded_topk(local_topk: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]],

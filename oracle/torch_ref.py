@@ -217,4 +217,4 @@ def cpu_train_step(cfg, p, opt: TFAdam, mark_table, features, labels, dtype=torc
     loss, _ = train_loss(cfg, p, mark_table, features, labels, dtype, hidden_drop, att_drop)
     loss.backward()
     opt.step()
-    return float(loss)
+    return float(loss.detach())

@@ -92,7 +92,9 @@ def test_shard_bounds_cover_the_table():
         b = [shard_bounds(n, w, r) for r in range(w)]
         assert b[0][0] == 0 and b[-1][1] == n
         assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
-        assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+        assert all(lo % 8 == 0 for lo, hi in b if hi > lo)      # empty shards may start at num_rows
+        if n > 8 * w:
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) < 16
 
 
 def test_graft_entry_build():

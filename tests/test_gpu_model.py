@@ -112,3 +112,15 @@ def test_training_reduces_loss_with_dropout_bf16():
     losses = [float(m.train_step(feats, labels)) for _ in range(30)]
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0] - 0.5, losses
+
+
+@pytest.mark.parametrize("shards", [2, 8])
+def test_sharded_eval_matches_unsharded(shards):
+    """K7: row-sharded scoring + local top-K + merge == single-shard top-K (same values, same ids)."""
+    prob = make_problem(seed=9, batch=12, num_items=1500, seqslen=20, num_units=32, num_heads=2, num_blocks=1)
+    m = build_model(prob, "f32")
+    ef = to_dev(prob["efeats"])
+    v0, i0 = m.eval_topk(ef, mask_seen=True)
+    v1, i1 = m.eval_topk_sharded(ef, mask_seen=True, world=shards)
+    assert torch.equal(i0, i1)
+    assert torch.allclose(v0, v1, rtol=0, atol=0)
