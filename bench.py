@@ -28,8 +28,11 @@ HEADLINE = dict(num_items=20000, seqslen=100, num_units=128, num_heads=8, num_bl
                 num_events=16, batch=512, time_scale=86400.0, learning_rate=5e-4, l2_reg=1e-4, ct_reg=1e-7,
                 hidden_dropout_rate=0.1, attention_probs_dropout_rate=0.1)
 
-# the kernel(s) whose launches are bracketed with HIP events inside the timed region
-DOMINANT_CALL = "edgl_score_ce_bwd"
+# the ONE kernel whose every launch in the timed region is bracketed with HIP events on its launch stream
+# (library hook edgl_profile_next): score_bwd_kernel<ROLE_Y> — d_rows of the fused scoring/CE backward, the
+# kernel family that carries 76 % of the step's algorithmic FLOPs.
+DOMINANT_KERNEL_ID = 0   # EDGL_KERNEL_SCORE_BWD_ROWS
+DOMINANT_KERNEL = "score_bwd_kernel<bf16, C/16=8, ROLE_Y> (d_rows = dl . table, logits recomputed)"
 
 
 def flops_per_seq(c):
@@ -155,17 +158,24 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    _lib.profiler.start(only=[DOMINANT_CALL])
+    evs = []
+    for _ in range(args.steps):          # pre-created HIP event pairs (handles exist after a first record)
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); b_.record()
+        evs.append((a, b_))
+    torch.cuda.synchronize()
+    bracket = args.path != "graph"       # a captured graph cannot carry per-launch timing events
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if bracket:
+            _lib.lib.edgl_profile_next(DOMINANT_KERNEL_ID, evs[i][0].cuda_event, evs[i][1].cuda_event)
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    _lib.profiler.stop()
-    dom = _lib.profiler.summary().get(DOMINANT_CALL, (0, 0.0))
+    dom = (len(evs), sum(a.elapsed_time(b_) for a, b_ in evs)) if bracket else (0, 0.0)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,10 +186,14 @@ def main():
     if rank == 0:
         T, C, I, M = c["seqslen"] + 1, c["num_units"], c["num_items"] + 1, c["masklen"]
         R = c["batch"] * M
-        # edgl_score_ce_bwd: two logit recomputations + d_rows + d_table products, 2*R*C*I FLOPs each
-        dom_flops = 4 * 2.0 * R * C * I
+        # per launch: recompute the [R, I] logits (2*R*C*I) + d_rows = dl . table (2*R*C*I)
+        dom_flops = 2 * 2.0 * R * C * I
         dom_ms = dom[1] / max(1, dom[0])
         peak = 2500.0 if args.dtype == "bf16" else 157.3
+        traffic = None   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+        if args.dtype == "bf16" and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         out = {
             "metric": "sequences/sec (fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K",
@@ -194,9 +208,9 @@ def main():
                        "global_batch": world * c["batch"], "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_step": round(3 * flops_per_seq(c) * c["batch"] / 1e9, 1)},
             "loss": round(float(loss), 5), "path": args.path,
-            "roofline": {"bound": "mfma", "kernel": "score_bwd_dy_kernel+score_bwd_dw_kernel (edgl_score_ce_bwd)",
+            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL,
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "avg_launch_ms": round(dom_ms, 4), "traffic": None},
+                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "traffic": traffic},
             "whole_step_mfma_frac": round(3 * flops_per_seq(c) * c["batch"] / (dt / args.steps) / 1e12 / peak, 4),
         }
         if not args.no_cpu_baseline and world == 1:

@@ -20,6 +20,7 @@ P, I, F, L, U32, I64 = c_void_p, c_int, c_float, c_long, c_uint32, c_int64
 SIGNATURES = {
     "edgl_last_error": (c_char_p, []),
     "edgl_version": (I, []),
+    "edgl_profile_next": (I, [I, P, P]),
     "edgl_rng_advance": (I, [P, P]),
     "edgl_encode_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I64, F, F, P, U32, P, P, P, I, P]),
     "edgl_encode_bwd_workspace": (L, [I, I, I]),

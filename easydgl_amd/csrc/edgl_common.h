@@ -40,6 +40,9 @@ static inline int edgl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // out[n] (+)= sum_{p<P} part[p*ld + n], fixed summation order (k_misc.hip).  Used for every
 // "per-workgroup partials -> parameter gradient" reduction.
 int edgl_reduce_rows(const float* part, int P, int N, long ld, float* out, int accumulate, hipStream_t st);
+// one-shot HIP-event bracket around a single kernel launch (edgl_profile_next); ids in easydgl_hip.h
+void edgl_prof_begin(int kernel_id, hipStream_t st);
+void edgl_prof_end(int kernel_id, hipStream_t st);
 // bf16 fast paths (k_gemm2.hip): return 1 if taken, 0 if the shape does not qualify, <0 on error
 int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int b_kc,
                          const float* bias, void* aux, int flags, hipStream_t st);

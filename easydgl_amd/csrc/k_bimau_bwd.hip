@@ -495,7 +495,9 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     auto kern = bimau_bwd_kernel<T, DT, NT>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const long jobs = (long)p.B * p.H;
+    edgl_prof_begin(EDGL_KERNEL_BIMAU_BWD, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
+    edgl_prof_end(EDGL_KERNEL_BIMAU_BWD, st);
     EDGL_LAUNCH_CHECK();
 
     WgP wp{p.hin_ws, p.dz_ws, p.spans, p.pack, (long)p.B * p.H * p.T, p.B, p.T, p.E, p.wpart, p.dsc_part, jobs};

@@ -19,6 +19,22 @@ extern "C" void edgl_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* edgl_last_error(void) { return g_err; }
+
+// ---- one-shot event bracket -----------------------------------------------------------------------------------
+namespace {
+struct ProfSlot { int id = -1; hipEvent_t e0 = nullptr, e1 = nullptr; };
+thread_local ProfSlot g_prof;
+}  // namespace
+extern "C" int edgl_profile_next(int kernel_id, void* ev_start, void* ev_stop) {
+    g_prof.id = kernel_id; g_prof.e0 = (hipEvent_t)ev_start; g_prof.e1 = (hipEvent_t)ev_stop;
+    return EDGL_OK;
+}
+void edgl_prof_begin(int kernel_id, hipStream_t st) {
+    if (g_prof.id == kernel_id && g_prof.e0) (void)hipEventRecord(g_prof.e0, st);
+}
+void edgl_prof_end(int kernel_id, hipStream_t st) {
+    if (g_prof.id == kernel_id && g_prof.e1) { (void)hipEventRecord(g_prof.e1, st); g_prof.id = -1; }
+}
 extern "C" int edgl_version(void) { return 100; }
 
 namespace {

@@ -16,6 +16,8 @@
 //   score_fwd_kernel : x = rows,  z = items   -> per-chunk (max, sumexp) [+ optional logits]
 //   score_bwd<ROLE_Y>: x = rows,  z = items   -> d_rows slabs
 //   score_bwd<ROLE_W>: x = items, z = rows    -> d_table slabs, d_bias slabs
+#include <cstdlib>
+
 #include "edgl_common.h"
 
 namespace {
@@ -24,7 +26,7 @@ constexpr int SNT = 512;   // threads per workgroup
 constexpr int XB = 256;    // x vectors per workgroup (32 per wave)
 constexpr int ZB = 128;    // z vectors per streamed tile
 
-template <typename T, int CT>
+template <typename T, int CT, int NTHR = SNT>
 struct SC {
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int KB = ElemTraits<T>::KB;
@@ -33,8 +35,8 @@ struct SC {
     static constexpr int LDC = C + 2 * VEC;   // Z  image: [ZB][LDC]   (row z, k contiguous); +32 B: conflict-free b128 reads
     static constexpr int LDZ = ZB + VEC;      // ZT image: [C][LDZ]    (row c, z contiguous)
     static constexpr int CV = C / VEC;
-    static constexpr int PER_Z = ZB * CV / SNT;          // 16-byte vectors per thread, Z image
-    static constexpr int PER_ZT = C * (ZB / VEC) / SNT;  // same count, ZT image
+    static constexpr int PER_Z = ZB * CV / NTHR;          // 16-byte vectors per thread, Z image
+    static constexpr int PER_ZT = C * (ZB / VEC) / NTHR;  // same count, ZT image
     static constexpr size_t Z_BYTES = (size_t)ZB * LDC * sizeof(T);
     static constexpr size_t ZT_BYTES = (size_t)C * LDZ * sizeof(T);
     static constexpr size_t INFO_BYTES = 3 * ZB * sizeof(float);
@@ -49,12 +51,13 @@ struct ScoreP {
     int zchunk, nchunk;                                 // z vectors per block (multiple of ZB), #chunks
     const float* coef; const float* gscale;             // bwd
     float* slabs; float* bias_slabs;
+    int dbg;   // EDGL_DBG ablation bits (profiling only): 1 skip dl math, 2 skip second product, 4 skip z streaming, 8 skip logit MFMA
 };
 
 // ---- streamed tile: global -> registers -> LDS -------------------------------------------------
-template <typename T, int CT, bool WITH_T>
+template <typename T, int CT, bool WITH_T, int NTHR = SNT>
 struct ZStream {
-    using S = SC<T, CT>;
+    using S = SC<T, CT, NTHR>;
     Vec16<T> rz[S::PER_Z];
     Vec16<T> rt[WITH_T ? S::PER_ZT : 1];
     // Z image rows [z0, z0+ZB) of src [*, C]; rows >= zend (or global row 0 when zero_row0) read as zeros
@@ -65,7 +68,7 @@ struct ZStream {
     __device__ __forceinline__ void load_z(const T* src, int z0, int zend, bool zero_row0) {
 #pragma unroll
         for (int i = 0; i < S::PER_Z; ++i) {
-            const int v = threadIdx.x + i * SNT;
+            const int v = threadIdx.x + i * NTHR;
             const int row = v / S::CV, cv = v % S::CV, gz = z0 + row;
             rz[i] = (gz < zend && !(zero_row0 && gz == 0)) ? ld16<T>(src + (long)gz * S::C + cv * S::VEC) : zero16<T>();
         }
@@ -75,7 +78,7 @@ struct ZStream {
             constexpr int ZV = ZB / S::VEC;
 #pragma unroll
             for (int i = 0; i < S::PER_ZT; ++i) {
-                const int v = threadIdx.x + i * SNT;
+                const int v = threadIdx.x + i * NTHR;
                 const int c = v / ZV, zv = v % ZV, gz = z0 + zv * S::VEC;
                 const T* p = srcT + (long)c * ldT + gz;
                 if (gz + S::VEC <= zend && !(zero_row0 && gz == 0)) {
@@ -93,14 +96,14 @@ struct ZStream {
     __device__ __forceinline__ void store(T* Zs, T* ZTs) {
 #pragma unroll
         for (int i = 0; i < S::PER_Z; ++i) {
-            const int v = threadIdx.x + i * SNT;
+            const int v = threadIdx.x + i * NTHR;
             st16<T>(Zs + (v / S::CV) * S::LDC + (v % S::CV) * S::VEC, rz[i]);
         }
         if constexpr (WITH_T) {
             constexpr int ZV = ZB / S::VEC;
 #pragma unroll
             for (int i = 0; i < S::PER_ZT; ++i) {
-                const int v = threadIdx.x + i * SNT;
+                const int v = threadIdx.x + i * NTHR;
                 st16<T>(ZTs + (v / ZV) * S::LDZ + (v % ZV) * S::VEC, rt[i]);
             }
         }
@@ -283,19 +286,24 @@ __global__ __launch_bounds__(256) void label_logit_kernel(const T* rows, const T
 // ---------------------------------------------------------------------------------------------
 enum { ROLE_Y = 0, ROLE_W = 1 };
 
-template <typename T, int CT, int ROLE>
-__global__ __launch_bounds__(SNT) void score_bwd_kernel(ScoreP p) {
-    using S = SC<T, CT>;
+// NW = 8: one workgroup per CU, double-buffered LDS, register prefetch across the compute phase.
+// NW = 4: two independent 4-wave workgroups per CU, single LDS buffer, next tile fetched at the tile boundary —
+//         the two workgroups drift apart, so one's MFMA phase overlaps the other's exp/VALU and load phases.
+template <typename T, int CT, int ROLE, int NW>
+__global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
+    constexpr int NTHR = 64 * NW, XBW = 32 * NW;
+    using S = SC<T, CT, NTHR>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr size_t BUF = S::Z_BYTES + S::ZT_BYTES + S::INFO_BYTES;
-    constexpr bool DOUBLE = 2 * BUF <= 160 * 1024;
+    constexpr bool DOUBLE = (NW == 8) && (2 * BUF <= 160 * 1024);
+    constexpr bool PREFETCH = (NW == 8);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const T* rows = reinterpret_cast<const T*>(p.rows);
     const T* rowsT = reinterpret_cast<const T*>(p.rowsT);
     const T* table = reinterpret_cast<const T*>(p.table);
     const T* tableT = reinterpret_cast<const T*>(p.tableT);
     // x side
-    const int xbase = (ROLE == ROLE_Y ? 0 : p.i0) + blockIdx.x * XB + wave * 32;
+    const int xbase = (ROLE == ROLE_Y ? 0 : p.i0) + blockIdx.x * XBW + wave * 32;
     const int xend = ROLE == ROLE_Y ? p.R : p.i1;
     Vec16<T> xf[2][S::NKB];
     load_xfrags<T, CT>(ROLE == ROLE_Y ? rows : table, xbase, xend, ROLE == ROLE_W, lane, xf);
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(SNT) void score_bwd_kernel(ScoreP p) {
         for (int ct = 0; ct < CT; ++ct) out[ix][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbias[2] = {0.f, 0.f};
 
-    ZStream<T, CT, true> zs;
+    ZStream<T, CT, true, NTHR> zs;
     const int ntile = (z_hi - z_lo + ZB - 1) / ZB;
     if (ntile > 0) {
         zs.load(zsrc, zsrcT, ldT, z_lo, z_hi, ROLE == ROLE_Y);
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(SNT) void score_bwd_kernel(ScoreP p) {
         const bool more = it + 1 < ntile;
         char* cur = smem + (DOUBLE ? (size_t)(it & 1) * BUF : 0);
         char* nxt = smem + (DOUBLE ? (size_t)((it + 1) & 1) * BUF : 0);
-        if (more) zs.load_z(zsrc, z0 + ZB, z_hi, ROLE == ROLE_Y);
+        if (PREFETCH && more && !(p.dbg & 4)) zs.load_z(zsrc, z0 + ZB, z_hi, ROLE == ROLE_Y);
         const T* Zs = reinterpret_cast<const T*>(cur);
         const T* ZTs = reinterpret_cast<const T*>(cur + S::Z_BYTES);
         const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES + S::ZT_BYTES);
@@ -367,8 +375,13 @@ __global__ __launch_bounds__(SNT) void score_bwd_kernel(ScoreP p) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             f32x4 acc[4][2];
-            logit_half<T, CT>(Zs, half * 4, xf, lane, acc);
+            if (!(p.dbg & 8)) logit_half<T, CT>(Zs, half * 4, xf, lane, acc);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[j][0] = f32x4{0.1f, 0.2f, 0.3f, 0.4f}; acc[j][1] = acc[j][0]; }
+            }
             // ---- dl[z][x] in place ------------------------------------------------------------------
+            if (!(p.dbg & 1))
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int jz = half * 4 + j;
@@ -406,6 +419,7 @@ __global__ __launch_bounds__(SNT) void score_bwd_kernel(ScoreP p) {
                     }
             }
             // ---- out[x][c] += sum_z dl[x][z] Z[z][c] --------------------------------------------------
+            if (p.dbg & 2) { out[0][0] += acc[0][0]; out[1][0] += acc[3][1]; continue; }
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
@@ -441,7 +455,8 @@ __global__ __launch_bounds__(SNT) void score_bwd_kernel(ScoreP p) {
             }
         }
         if (!DOUBLE) __syncthreads();
-        if (more) {
+        if (more && !(p.dbg & 4)) {
+            if (!PREFETCH) zs.load_z(zsrc, z0 + ZB, z_hi, ROLE == ROLE_Y);
             zs.load_t(zsrcT, ldT, z0 + ZB, z_hi, ROLE == ROLE_Y);   // short-lived: the other wave of the SIMD covers it
             zs.store(reinterpret_cast<T*>(nxt), reinterpret_cast<T*>(nxt + S::Z_BYTES));
             fill_info(nxt, z0 + ZB);
@@ -700,7 +715,10 @@ inline Chunking pick_chunks(int xblocks, int ztotal, int target_blocks) {
     nchunk = (ntiles + per - 1) / per;
     return Chunking{nchunk, per * ZB};
 }
-inline int xblocks_of(int n) { return (n + XB - 1) / XB; }
+inline int xblocks_of(int n, int xb = XB) { return (n + xb - 1) / xb; }
+inline int score_nw() { static const int nw = getenv("EDGL_SCORE_NW") ? atoi(getenv("EDGL_SCORE_NW")) : 8; return nw == 4 ? 4 : 8; }
+inline int score_ftarget() { static const int t = getenv("EDGL_SCORE_FTARGET") ? atoi(getenv("EDGL_SCORE_FTARGET")) : 256; return t; }
+inline int score_target() { static const int t = getenv("EDGL_SCORE_TARGET") ? atoi(getenv("EDGL_SCORE_TARGET")) : 256; return t; }
 inline long up8(long v) { return (v + 7) / 8 * 8; }
 
 struct BwdPlan {
@@ -709,8 +727,9 @@ struct BwdPlan {
 };
 inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize) {
     BwdPlan b;
-    b.y = pick_chunks(xblocks_of(R), n_items, 512);
-    b.w = pick_chunks(xblocks_of(n_items), R, 512);
+    const int xb = 32 * score_nw();
+    b.y = pick_chunks(xblocks_of(R, xb), n_items, score_target());
+    b.w = pick_chunks(xblocks_of(n_items, xb), R, score_target());
     long o = 0;
     auto take = [&](long floats) { const long at = o; o += (floats + 63) / 64 * 64; return at; };
     b.off_rowsT = take(((long)C * up8(R) * (long)esize + 3) / 4);
@@ -750,13 +769,23 @@ int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_tab
                        reinterpret_cast<const T*>(p.table), (long)p.I, p.C, tableT, (long)p.ldt);
     EDGL_LAUNCH_CHECK();
     p.rowsT = rowsT; p.tableT = tableT;
+    const int nw = score_nw();
+    const size_t smem_nw = nw == 8 ? smem : BUF;
     // d_rows
     {
         ScoreP q = p;
         q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY;
-        auto k = score_bwd_kernel<T, CT, ROLE_Y>;
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(k, dim3(xblocks_of(p.R), q.nchunk), dim3(SNT), smem, st, q);
+        edgl_prof_begin(EDGL_KERNEL_SCORE_BWD_ROWS, st);
+        if (nw == 8) {
+            auto k = score_bwd_kernel<T, CT, ROLE_Y, 8>;
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 256), q.nchunk), dim3(512), smem_nw, st, q);
+        } else {
+            auto k = score_bwd_kernel<T, CT, ROLE_Y, 4>;
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 128), q.nchunk), dim3(256), smem_nw, st, q);
+        }
+        edgl_prof_end(EDGL_KERNEL_SCORE_BWD_ROWS, st);
         EDGL_LAUNCH_CHECK();
         const long n = (long)p.R * p.C;
         hipLaunchKernelGGL((slab_reduce_kernel<T>), dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st,
@@ -767,9 +796,15 @@ int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_tab
     {
         ScoreP q = p;
         q.zchunk = plan.w.zchunk; q.nchunk = plan.w.nchunk; q.slabs = ws + plan.off_slabW; q.bias_slabs = ws + plan.off_slabB;
-        auto k = score_bwd_kernel<T, CT, ROLE_W>;
-        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0), q.nchunk), dim3(SNT), smem, st, q);
+        if (nw == 8) {
+            auto k = score_bwd_kernel<T, CT, ROLE_W, 8>;
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, 256), q.nchunk), dim3(512), smem_nw, st, q);
+        } else {
+            auto k = score_bwd_kernel<T, CT, ROLE_W, 4>;
+            hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, 128), q.nchunk), dim3(256), smem_nw, st, q);
+        }
         EDGL_LAUNCH_CHECK();
         const long n = (long)p.I * p.C, lo = (long)p.i0 * p.C, hi = (long)p.i1 * p.C;
         hipLaunchKernelGGL((slab_reduce_kernel<float>), dim3((unsigned)std::min<long>((hi - lo + 255) / 256, 2048)), dim3(256), 0,
@@ -824,7 +859,7 @@ int bwd_dispatch(ScoreP p, int C, const BwdPlan& plan, float* ws, void* d_rows, 
 
 }  // namespace
 
-extern "C" int edgl_score_chunks(int R, int n_items) { return pick_chunks(xblocks_of(R), n_items, 1024).nchunk; }
+extern "C" int edgl_score_chunks(int R, int n_items) { return pick_chunks(xblocks_of(R), n_items, score_ftarget()).nchunk; }
 
 extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                                   int R, int C, int I, int i0, int i1, float* row_lse, float* label_logit,
@@ -835,7 +870,7 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.row_lse = row_lse; p.part = workspace; p.logits = logits;
-    const Chunking ch = pick_chunks(xblocks_of(R), i1 - i0, 1024);
+    const Chunking ch = pick_chunks(xblocks_of(R), i1 - i0, score_ftarget());
     p.nchunk = ch.nchunk; p.zchunk = ch.zchunk;
     hipStream_t st = (hipStream_t)stream;
     rc = dtype == EDGL_F32 ? fwd_dispatch<float>(p, C, st) : fwd_dispatch<bf16>(p, C, st);
@@ -876,6 +911,8 @@ extern "C" int edgl_score_ce_bwd(const void* rows, const void* table, const floa
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
     const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
+    static const int dbg = getenv("EDGL_DBG") ? atoi(getenv("EDGL_DBG")) : 0;
+    p.dbg = dbg;
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float>(p, C, plan, workspace, d_rows, d_table, d_bias, st)
                              : bwd_dispatch<bf16>(p, C, plan, workspace, d_rows, d_table, d_bias, st);

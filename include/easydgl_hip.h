@@ -52,6 +52,11 @@ enum {
 const char* edgl_last_error(void);
 int edgl_version(void);
 
+/* Profiling hook (measurement only): the NEXT launch of kernel `kernel_id` on the calling thread records the two
+ * hipEvent_t handles immediately before / after that single kernel on its launch stream, then the slot clears. */
+enum { EDGL_KERNEL_SCORE_BWD_ROWS = 0, EDGL_KERNEL_BIMAU_BWD = 1 };
+int edgl_profile_next(int kernel_id, void* ev_start, void* ev_stop);
+
 /* ---- dropout RNG state ----------------------------------------------------------------------- */
 /* rng_state[1] += 1 on the device (one launch per training step, graph-capturable). */
 int edgl_rng_advance(uint64_t* rng_state, void* stream);
