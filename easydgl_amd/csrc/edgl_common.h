@@ -200,7 +200,7 @@ __device__ __forceinline__ uint32_t edgl_mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
     return h;
 }
-struct DropKey { uint32_t k0, k1, thresh; float scale; };
+struct DropKey { uint32_t k0, k1, thresh, t16; float scale; };
 __device__ __forceinline__ DropKey make_dropkey(const uint64_t* rng_state, uint32_t stream, float rate) {
     DropKey k;
     uint64_t seed = rng_state ? rng_state[0] : 0ull, step = rng_state ? rng_state[1] : 0ull;
@@ -210,6 +210,7 @@ __device__ __forceinline__ DropKey make_dropkey(const uint64_t* rng_state, uint3
     double t = (double)rate * 4294967296.0;
     k.thresh = rate <= 0.f ? 0u : (t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t);
     k.scale = rate <= 0.f ? 1.f : 1.f / (1.f - rate);
+    k.t16 = rate <= 0.f ? 0u : (uint32_t)(rate * 65536.0f + 0.5f);   // 16-bit threshold for the paired form
     return k;
 }
 __device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t idx) {
@@ -224,6 +225,13 @@ __device__ __forceinline__ bool drop_keep32(const DropKey& k, uint32_t idx) {   
     uint32_t h = (idx ^ k.k0) * 0x9E3779B1u + k.k1;
     h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
     return h >= k.thresh;
+}
+// Paired form for the attention matrix: ONE hash decides two neighbouring elements (idx_even, idx_even+1) with
+// 16-bit thresholds (|p_eff - p| < 8e-6).  Forward and backward kernels must both use it.
+__device__ __forceinline__ uint32_t drop_hash_pair(const DropKey& k, uint32_t idx_even) {
+    uint32_t h = (idx_even ^ k.k0) * 0x9E3779B1u + k.k1;
+    h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
+    return h;
 }
 __device__ __forceinline__ float drop_apply(const DropKey& k, uint64_t idx, float x) {
     return k.thresh == 0u ? x : (drop_keep(k, idx) ? x * k.scale : 0.f);

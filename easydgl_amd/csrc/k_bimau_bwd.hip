@@ -192,11 +192,18 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
             }
+            float facs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (dk.thresh != 0u) {   // same paired hash as the forward kernel
+                const uint32_t h0 = drop_hash_pair(dk, dbase + kt * 16 + g4), h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2);
+                facs[0] = (h0 & 0xffffu) >= dk.t16 ? dk.scale : 0.f;
+                facs[1] = (h0 >> 16) >= dk.t16 ? dk.scale : 0.f;
+                facs[2] = (h1 & 0xffffu) >= dk.t16 ? dk.scale : 0.f;
+                facs[3] = (h1 >> 16) >= dk.t16 ? dk.scale : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = s[kt][r];
-                float fac = 1.0f;
-                if (dk.thresh != 0u) fac = drop_keep32(dk, dbase + kt * 16 + g4 + r) ? dk.scale : 0.f;
+                const float fac = facs[r];
                 ap[r] = fac * gv[r] * pv;                 // A' = D*G'*P
                 const float dad = da[r] * fac;
                 dg[r] = dad * pv;
@@ -508,6 +515,9 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
     hipLaunchKernelGGL(kb, dim3(KB_BLOCKS, DT * DT), dim3(256), smem_b, st, wp);
     EDGL_LAUNCH_CHECK();
+    if (db1 == dW1 + (dh + 1) * JE && dw == db1 + JE && dscaling == dw + JE) {   // flat-arena layout: one reduction
+        return edgl_reduce_rows(p.wpart, KB_BLOCKS, NPAR + p.E, NPARX, dW1, 0, st);
+    }
     int rc = edgl_reduce_rows(p.wpart, KB_BLOCKS, (dh + 1) * JE, NPARX, dW1, 0, st);
     if (rc) return rc;
     rc = edgl_reduce_rows(p.wpart + (dh + 1) * JE, KB_BLOCKS, JE, NPARX, db1, 0, st);

@@ -142,10 +142,13 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                 for (int r = 0; r < 4; ++r) gacc[r] = (g4 + r == l15) ? 1.0f : gacc[r];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = gacc[r] * s[kt][r];                 // temporal.py:441
-                if (dk.thresh != 0u) a = drop_keep32(dk, dbase + kt * 16 + g4 + r) ? a * dk.scale : 0.f;  // temporal.py:442
-                s[kt][r] = a;
+            for (int r = 0; r < 4; ++r) s[kt][r] = gacc[r] * s[kt][r];     // temporal.py:441
+            if (dk.thresh != 0u) {                                          // temporal.py:442
+                const uint32_t h0 = drop_hash_pair(dk, dbase + kt * 16 + g4), h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2);
+                s[kt][0] = (h0 & 0xffffu) >= dk.t16 ? s[kt][0] * dk.scale : 0.f;
+                s[kt][1] = (h0 >> 16) >= dk.t16 ? s[kt][1] * dk.scale : 0.f;
+                s[kt][2] = (h1 & 0xffffu) >= dk.t16 ? s[kt][2] * dk.scale : 0.f;
+                s[kt][3] = (h1 >> 16) >= dk.t16 ? s[kt][3] * dk.scale : 0.f;
             }
             pf[kt] = frag_from_acc<T>(s[kt]);
         }

@@ -377,6 +377,10 @@ int edgl_gemm2_try_tn(const void* X, const void* Y, float* C, int R, int Kf, int
     TnP p{(const bf16*)X, (const bf16*)Y, R, Kf, N, ldx, ldy, rps, workspace, dbias ? 1 : 0};
     hipLaunchKernelGGL(tn_gemm_kernel, dim3((N + 127) / 128, (Kf + 127) / 128, splits), dim3(T_NT), 0, st, p);
     EDGL_LAUNCH_CHECK();
+    if (dbias && dbias == C + (long)Kf * N) {   // (dW, db) contiguous, as in the flat gradient arena: one reduction
+        const int rc = edgl_reduce_rows(workspace, splits, (Kf + 1) * N, (long)(Kf + 1) * N, C, accumulate, st);
+        return rc ? rc : 1;
+    }
     int rc = edgl_reduce_rows(workspace, splits, Kf * N, (long)(Kf + 1) * N, C, accumulate, st);
     if (rc) return rc;
     if (dbias) {

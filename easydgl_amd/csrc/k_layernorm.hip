@@ -163,8 +163,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
     if (on) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            cred[((size_t)tr * 2 + 0) * p.C + c0 + j] = dga[j];
-            cred[((size_t)tr * 2 + 1) * p.C + c0 + j] = dbe[j];
+            cred[((size_t)tr * 2 + 0) * p.C + c0 + j] = dbe[j];   // [dbeta | dgamma]: the arena stores beta before gamma
+            cred[((size_t)tr * 2 + 1) * p.C + c0 + j] = dga[j];
         }
     }
     __syncthreads();
@@ -245,7 +245,8 @@ extern "C" int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_r
     if (dtype == EDGL_F32) hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(B), dim3(LN_THREADS), smem, st, p);
     else hipLaunchKernelGGL((ln_bwd_kernel<bf16>), dim3(B), dim3(LN_THREADS), smem, st, p);
     EDGL_LAUNCH_CHECK();
-    rc = edgl_reduce_rows(workspace, B, C, 2L * C, dgamma, 0, st);
+    if (dgamma == dbeta + C) return edgl_reduce_rows(workspace, B, 2 * C, 2L * C, dbeta, 0, st);
+    rc = edgl_reduce_rows(workspace, B, C, 2L * C, dbeta, 0, st);
     if (rc) return rc;
-    return edgl_reduce_rows(workspace + C, B, C, 2L * C, dbeta, 0, st);
+    return edgl_reduce_rows(workspace + C, B, C, 2L * C, dgamma, 0, st);
 }
