@@ -186,8 +186,11 @@ def main():
     if rank == 0:
         T, C, I, M = c["seqslen"] + 1, c["num_units"], c["num_items"] + 1, c["masklen"]
         R = c["batch"] * M
-        # per launch: recompute the [R, I] logits (2*R*C*I) + d_rows = dl . table (2*R*C*I)
-        dom_flops = 2 * 2.0 * R * C * I
+        # rows with label 0 (masked slots that fell on padding) have weight 0 in the loss (EasyDGL.py:180) and are not
+        # scored; only the weighted rows count as algorithmic work
+        R_w = int((labels != 0).sum().item())
+        # per launch: recompute the [R_w, I] logits (2*R_w*C*I) + d_rows = dl . table (2*R_w*C*I)
+        dom_flops = 2 * 2.0 * R_w * C * I
         dom_ms = dom[1] / max(1, dom[0])
         peak = 2500.0 if args.dtype == "bf16" else 157.3
         traffic = None   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
@@ -210,7 +213,8 @@ def main():
             "loss": round(float(loss), 5), "path": args.path,
             "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL,
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "traffic": traffic},
+                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "rows_scored": R_w,
+                         "rows_total": R, "traffic": traffic},
             "whole_step_mfma_frac": round(3 * flops_per_seq(c) * c["batch"] / (dt / args.steps) / 1e12 / peak, 4),
         }
         if not args.no_cpu_baseline and world == 1:

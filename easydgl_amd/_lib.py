@@ -35,12 +35,14 @@ SIGNATURES = {
     "edgl_bimau_bwd_workspace": (L, [I, I, I, I, I, I]),
     "edgl_bimau_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, I, P]),
     "edgl_add_layernorm_fwd": (I, [P, P, I, P, P, I, I, I, F, P, U32, P, I, P, P, I, P]),
-    "edgl_add_layernorm_bwd": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, I, P]),
+    "edgl_add_layernorm_bwd": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, P, I, P]),
     "edgl_score_chunks": (I, [I, I]),
-    "edgl_score_lse_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, P]),
+    "edgl_compact_rows": (I, [P, P, I, I, P, P, P, P, P, I, P]),
+    "edgl_scatter_rows": (I, [P, P, I, I, P, I, P]),
+    "edgl_score_lse_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_ce_loss_fwd": (I, [P, P, P, I, P, P, P]),
     "edgl_score_bwd_workspace": (L, [I, I, I, I, I]),
-    "edgl_score_ce_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, I, P]),
+    "edgl_score_ce_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_mask_topk": (I, [P, I, I, I, P, I, I, P, P, P]),
     "edgl_topk_merge": (I, [P, P, I, I, I, P, P, P]),
     "edgl_rank_metrics": (I, [P, I, I, P, P, P]),

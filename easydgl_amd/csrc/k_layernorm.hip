@@ -19,6 +19,7 @@ struct LnP {
     void* y; float* stats;
     // backward
     const void* dy; void* dsum; void* dx_drop; float* part;
+    const int32_t* dy_rowmap;   // gathered mode: compact row of (b, j), or -1 (row carries no gradient)
 };
 
 template <typename T>
@@ -94,26 +95,32 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(LnP p) {
     }
 }
 
-// dy row for position t of sample b (zero vector if the row was not gathered)
+// dy row for position t of sample b (zero vector if no gathered row points at t).  Several gathered rows may name
+// the same position (the reference pads masked_pos with 0, Base.py mask_random): their gradients add, so the rows of
+// a position form a chain rowmap[t] -> nextj[..] built in a fixed order.
 template <typename T>
-__device__ __forceinline__ bool load_dy(const LnP& p, const int* rowmap, int b, int t, int c0, float d[ElemTraits<T>::VEC]) {
+__device__ __forceinline__ bool load_dy(const LnP& p, const int* rowmap, const int* nextj, int b, int t, int c0,
+                                        float d[ElemTraits<T>::VEC]) {
     constexpr int VEC = ElemTraits<T>::VEC;
-    long row;
-    if (p.gpos) {
-        const int j = rowmap[t];
-        if (j < 0) {
+    if (!p.gpos) {
+        Vec16<T> v = ld16<T>(reinterpret_cast<const T*>(p.dy) + ((long)b * p.T + t) * p.C + c0);
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) d[q] = 0.f;
-            return false;
-        }
-        row = (long)b * p.Mg + j;
-    } else {
-        row = (long)b * p.T + t;
+        for (int q = 0; q < VEC; ++q) d[q] = to_f32(v.v[q]);
+        return true;
     }
-    Vec16<T> v = ld16<T>(reinterpret_cast<const T*>(p.dy) + row * p.C + c0);
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) d[q] = to_f32(v.v[q]);
-    return true;
+    for (int q = 0; q < VEC; ++q) d[q] = 0.f;
+    bool any = false;
+    for (int j = rowmap[t]; j >= 0; j = nextj[j]) {
+        long row = (long)b * p.Mg + j;
+        if (p.dy_rowmap) row = p.dy_rowmap[row];
+        if (row < 0) continue;
+        Vec16<T> v = ld16<T>(reinterpret_cast<const T*>(p.dy) + row * p.C + c0);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) d[q] += to_f32(v.v[q]);
+        any = true;
+    }
+    return any;
 }
 
 template <typename T>
@@ -125,6 +132,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
     const int b = blockIdx.x, cpv = p.C / VEC;
     const int rows_par = LN_THREADS / cpv, active = rows_par * cpv;
     int* rowmap = reinterpret_cast<int*>(cred + (size_t)rows_par * 2 * p.C);  // [T]
+    int* nextj = rowmap + p.T;                                                  // [Mg]
     const int tid = threadIdx.x;
     const bool on = tid < active;
     const int cv = tid % cpv, tr = tid / cpv, c0 = cv * VEC;
@@ -135,7 +143,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
     if (p.gpos) {
         for (int t = tid; t < p.T; t += LN_THREADS) rowmap[t] = -1;
         __syncthreads();
-        for (int j = tid; j < p.Mg; j += LN_THREADS) rowmap[(int)p.gpos[(long)b * p.Mg + j]] = j;
+        if (tid == 0)
+            for (int j = p.Mg - 1; j >= 0; --j) {     // chains in ascending j
+                const int t = (int)p.gpos[(long)b * p.Mg + j];
+                nextj[j] = rowmap[t];
+                rowmap[t] = j;
+            }
         __syncthreads();
     }
     float g[VEC];
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
     if (on)
         for (int t = tr; t < p.T; t += rows_par) {
             float d[VEC];
-            if (!load_dy<T>(p, rowmap, b, t, c0, d)) continue;
+            if (!load_dy<T>(p, rowmap, nextj, b, t, c0, d)) continue;
             float s[VEC];
             load_sum<T>(p, dk, b, t, c0, s);
 #pragma unroll
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
     T* dxd = reinterpret_cast<T*>(p.dx_drop);
     for (int t = tr; t < p.T; t += rows_par) {
         float d[VEC], s[VEC];
-        load_dy<T>(p, rowmap, b, t, c0, d);
+        load_dy<T>(p, rowmap, nextj, b, t, c0, d);
         load_sum<T>(p, dk, b, t, c0, s);
         const long row = (long)b * p.T + t;
         Vec16<T> o, od;
@@ -227,8 +240,8 @@ extern "C" int edgl_add_layernorm_fwd(const void* x, const void* resid, int ld_r
 extern "C" int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_res, const float* gamma,
                                       const float* stats, const void* dy, int B, int T, int C, float drop_rate,
                                       const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
-                                      int Mg, void* dsum, void* dx_drop, float* dgamma, float* dbeta,
-                                      float* workspace, int dtype, void* stream) {
+                                      int Mg, const int32_t* dy_rowmap, void* dsum, void* dx_drop, float* dgamma,
+                                      float* dbeta, float* workspace, int dtype, void* stream) {
     EDGL_REQUIRE(x && gamma && stats && dy && dgamma && dbeta && workspace, EDGL_ERR_NULL,
                  "edgl_add_layernorm_bwd: null pointer");
     int rc = check_ln_shape(B, T, C, dtype, "edgl_add_layernorm_bwd");
@@ -237,9 +250,10 @@ extern "C" int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_r
     p.x = x; p.resid = resid; p.ld_res = ld_res; p.gamma = gamma; p.B = B; p.T = T; p.C = C;
     p.rate = drop_rate; p.rng = rng_state; p.stream_id = stream_id; p.gpos = gather_pos; p.Mg = Mg;
     p.stats = const_cast<float*>(stats); p.dy = dy; p.dsum = dsum; p.dx_drop = dx_drop; p.part = workspace;
+    p.dy_rowmap = dy_rowmap;
     const int vec = dtype == EDGL_BF16 ? 8 : 4;
     const int rows_par = LN_THREADS / (C / vec);
-    const size_t smem = (8 + (size_t)rows_par * 2 * C) * sizeof(float) + (size_t)T * sizeof(int);
+    const size_t smem = (8 + (size_t)rows_par * 2 * C) * sizeof(float) + (size_t)(T + (gather_pos ? Mg : 0)) * sizeof(int);
     EDGL_REQUIRE(smem <= 150 * 1024, EDGL_ERR_SHAPE, "edgl_add_layernorm_bwd: LDS need %zu too large", smem);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EDGL_F32) hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3(B), dim3(LN_THREADS), smem, st, p);

@@ -47,6 +47,7 @@ struct ScoreP {
     const void* table; const void* tableT; int ldt;    // table [I][C], tableT [C][ldt]
     const float* out_bias; const int64_t* labels;
     int R, C, I, i0, i1;
+    const int32_t* nvalid;                              // optional device count: only rows < *nvalid carry weight
     float* row_lse; float* part; float* logits;         // fwd
     int zchunk, nchunk;                                 // z vectors per block (multiple of ZB), #chunks
     const float* coef; const float* gscale;             // bwd
@@ -147,6 +148,24 @@ __device__ __forceinline__ void logit_half(const T* Zs, int jz0, const Vec16<T> 
     }
 }
 
+// The number of weighted rows is only known on the device (edgl_compact_rows), so the x-block / item-chunk split of
+// a launch of G workgroups is derived there: nx x-blocks cover the valid rows, the G/nx chunks share the z range.
+struct DevPlan { int nx, nchunk, zchunk; };
+__host__ __device__ __forceinline__ DevPlan dev_plan(int x_eff, int xb, int G, int ztotal) {
+    DevPlan d;
+    d.nx = (x_eff + xb - 1) / xb;
+    if (d.nx < 1) d.nx = 1;
+    int ntiles = (ztotal + ZB - 1) / ZB;
+    if (ntiles < 1) ntiles = 1;
+    int nchunk = G / d.nx;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > ntiles) nchunk = ntiles;
+    const int per = (ntiles + nchunk - 1) / nchunk;
+    d.nchunk = (ntiles + per - 1) / per;
+    d.zchunk = per * ZB;
+    return d;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: online log-sum-exp per row over this block's item chunk (+ optional logits)
 // ---------------------------------------------------------------------------------------------
@@ -156,13 +175,17 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr size_t BUF = S::Z_BYTES + ZB * sizeof(float);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
-    const int m0 = blockIdx.x * XB + wave * 32;
-    const int c_lo = p.i0 + blockIdx.y * p.zchunk, c_hi = min(p.i1, c_lo + p.zchunk);
+    const int Reff = p.nvalid ? min(p.R, p.nvalid[0]) : p.R;
+    const DevPlan dp = dev_plan(Reff, XB, gridDim.x, p.i1 - p.i0);
+    if ((int)blockIdx.x >= dp.nx * dp.nchunk || Reff <= 0) return;
+    const int bx = blockIdx.x % dp.nx, by = blockIdx.x / dp.nx;
+    const int m0 = bx * XB + wave * 32;
+    const int c_lo = p.i0 + by * dp.zchunk, c_hi = min(p.i1, c_lo + dp.zchunk);
     const T* rows = reinterpret_cast<const T*>(p.rows);
     const T* table = reinterpret_cast<const T*>(p.table);
 
     Vec16<T> xf[2][S::NKB];
-    load_xfrags<T, CT>(rows, m0, p.R, false, lane, xf);
+    load_xfrags<T, CT>(rows, m0, Reff, false, lane, xf);
     ZStream<T, CT, false> zs;
     const int ntile = (c_hi - c_lo + ZB - 1) / ZB;
     zs.load(table, nullptr, 0, c_lo, c_hi, true);
@@ -208,7 +231,7 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
                         tmax = fmaxf(tmax, x);
                     }
                 }
-                if (p.logits && m < p.R) {
+                if (p.logits && m < Reff) {
                     float* dst = p.logits + (long)m * (p.i1 - p.i0) + (n0 - p.i0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -246,16 +269,19 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
         float s = (rmax[ix] > -INFINITY) ? rsum[ix] * __expf(rmax[ix] - mx) : 0.f;
         s = group_sum4(s);
         const int m = m0 + ix * 16 + l15;
-        if (lane < 16 && m < p.R) {
-            p.part[((long)m * p.nchunk + blockIdx.y) * 2] = mx;
-            p.part[((long)m * p.nchunk + blockIdx.y) * 2 + 1] = s;
+        if (lane < 16 && m < Reff) {
+            p.part[((long)m * dp.nchunk + by) * 2] = mx;
+            p.part[((long)m * dp.nchunk + by) * 2 + 1] = s;
         }
     }
 }
 
-__global__ void lse_combine_kernel(const float* part, int R, int nchunk, float* row_lse) {
+__global__ void lse_combine_kernel(const float* part, int R, const int32_t* nvalid, int G, int ztotal, float* row_lse) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= R) return;
+    const int Reff = nvalid ? min(R, nvalid[0]) : R;
+    if (m >= Reff) { row_lse[m] = 0.f; return; }
+    const int nchunk = dev_plan(Reff, XB, G, ztotal).nchunk;
     float mx = -INFINITY;
     for (int c = 0; c < nchunk; ++c) mx = fmaxf(mx, part[((long)m * nchunk + c) * 2]);
     float s = 0.f;
@@ -302,9 +328,25 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     const T* rowsT = reinterpret_cast<const T*>(p.rowsT);
     const T* table = reinterpret_cast<const T*>(p.table);
     const T* tableT = reinterpret_cast<const T*>(p.tableT);
+    const int Reff = p.nvalid ? min(p.R, p.nvalid[0]) : p.R;
+    // ROLE_Y: 1-D launch, (x-block, item chunk) derived from the valid row count; ROLE_W: x = items (blockIdx.x),
+    // the valid rows are split evenly over gridDim.y chunks
+    int bx, by, zchunk;
+    long slab_stride;
+    if (ROLE == ROLE_Y) {
+        const DevPlan dp = dev_plan(Reff, XBW, gridDim.x, p.i1 - p.i0);
+        if ((int)blockIdx.x >= dp.nx * dp.nchunk || Reff <= 0) return;
+        bx = blockIdx.x % dp.nx; by = blockIdx.x / dp.nx; zchunk = dp.zchunk;
+        slab_stride = (long)dp.nx * XBW * S::C;
+    } else {
+        bx = blockIdx.x; by = blockIdx.y;
+        const int ntiles = (Reff + ZB - 1) / ZB;
+        zchunk = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y * ZB;
+        slab_stride = (long)p.I * S::C;
+    }
     // x side
-    const int xbase = (ROLE == ROLE_Y ? 0 : p.i0) + blockIdx.x * XBW + wave * 32;
-    const int xend = ROLE == ROLE_Y ? p.R : p.i1;
+    const int xbase = (ROLE == ROLE_Y ? 0 : p.i0) + bx * XBW + wave * 32;
+    const int xend = ROLE == ROLE_Y ? Reff : p.i1;
     Vec16<T> xf[2][S::NKB];
     load_xfrags<T, CT>(ROLE == ROLE_Y ? rows : table, xbase, xend, ROLE == ROLE_W, lane, xf);
     float x_lse[2], x_cf[2], x_bias[2];
@@ -325,8 +367,8 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         }
     }
     // z side
-    const int z_lo = (ROLE == ROLE_Y ? p.i0 : 0) + blockIdx.y * p.zchunk;
-    const int z_hi = min(ROLE == ROLE_Y ? p.i1 : p.R, z_lo + p.zchunk);
+    const int z_lo = (ROLE == ROLE_Y ? p.i0 : 0) + by * zchunk;
+    const int z_hi = min(ROLE == ROLE_Y ? p.i1 : Reff, z_lo + zchunk);
     const T* zsrc = ROLE == ROLE_Y ? table : rows;
     const T* zsrcT = ROLE == ROLE_Y ? tableT : rowsT;
     const int ldT = ROLE == ROLE_Y ? p.ldt : p.ldr;
@@ -355,7 +397,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     float dbias[2] = {0.f, 0.f};
 
     ZStream<T, CT, true, NTHR> zs;
-    const int ntile = (z_hi - z_lo + ZB - 1) / ZB;
+    const int ntile = z_hi > z_lo ? (z_hi - z_lo + ZB - 1) / ZB : 0;
     if (ntile > 0) {
         zs.load(zsrc, zsrcT, ldT, z_lo, z_hi, ROLE == ROLE_Y);
         zs.store(reinterpret_cast<T*>(smem), reinterpret_cast<T*>(smem + S::Z_BYTES));
@@ -464,8 +506,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         __syncthreads();
     }
     // ---- write the slab: out regs r <-> x = ix*16 + g4 + r, lane l15 <-> c = ct*16 + l15 ----------------
-    const long nx = ROLE == ROLE_Y ? p.R : p.I;
-    float* slab = p.slabs + (long)blockIdx.y * nx * S::C;
+    float* slab = p.slabs + (long)by * slab_stride;
 #pragma unroll
     for (int ix = 0; ix < 2; ++ix)
 #pragma unroll
@@ -481,7 +522,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         for (int ix = 0; ix < 2; ++ix) {
             const float v = group_sum4(dbias[ix]);
             const int gx = xbase + ix * 16 + l15;
-            if (lane < 16 && gx < xend && gx > 0) p.bias_slabs[(long)blockIdx.y * (p.I - 1) + gx - 1] = v;
+            if (lane < 16 && gx < xend && gx > 0) p.bias_slabs[(long)by * (p.I - 1) + gx - 1] = v;
         }
     }
 }
@@ -495,6 +536,71 @@ __global__ void slab_reduce_kernel(const float* slabs, int nslab, long n, long l
         float a = 0.f;
         for (int s = 0; s < nslab; ++s) a += slabs[(long)s * n + i];
         out[i] = from_f32<TO>(i < zero_first ? 0.f : a * gs);
+    }
+}
+
+// d_rows[r] = (T) gs * sum over the item chunks' slabs; the slab geometry follows dev_plan of the producing launch.
+template <typename TO>
+__global__ void slab_reduce_rows_kernel(const float* slabs, const int32_t* nvalid, int R, int C, int xb, int G, int ztotal,
+                                        const float* gscale, TO* out) {
+    const float gs = gscale ? gscale[0] : 1.0f;
+    const int Reff = nvalid ? min(R, nvalid[0]) : R;
+    const DevPlan dp = dev_plan(Reff, xb, G, ztotal);
+    const long stride = (long)dp.nx * xb * C, nval = (long)Reff * C, n = (long)R * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        if (i < nval)
+            for (int s = 0; s < dp.nchunk; ++s) a += slabs[(long)s * stride + i];
+        out[i] = from_f32<TO>(a * gs);
+    }
+}
+
+// Rows whose label is 0 (a masked position that fell on padding) have weight 0 in the loss (EasyDGL.py:180): they
+// contribute nothing to the loss or to any gradient.  compact_scan orders the weighted rows first
+// (perm[j] = original row of compact row j, inv[r] = compact index of row r or -1, nvalid = #weighted rows), so the
+// scoring kernels can skip the rest exactly.
+__global__ __launch_bounds__(1024) void compact_scan_kernel(const int64_t* labels, int R, int32_t* perm, int32_t* inv,
+                                                            int32_t* nvalid) {
+    __shared__ int cnt[1024];
+    const int t = threadIdx.x, per = (R + 1023) / 1024;
+    const int r0 = t * per, r1 = min(R, r0 + per);
+    int c = 0;
+    for (int r = r0; r < r1; ++r) c += labels[r] != 0;
+    cnt[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // inclusive Hillis-Steele scan
+        const int v = t >= off ? cnt[t - off] : 0;
+        __syncthreads();
+        cnt[t] += v;
+        __syncthreads();
+    }
+    int pos = cnt[t] - c;
+    const int total = cnt[1023];
+    for (int r = r0; r < r1; ++r) {
+        if (labels[r] != 0) { perm[pos] = r; inv[r] = pos; ++pos; }
+        else inv[r] = -1;
+    }
+    for (int j = total + t; j < R; j += 1024) perm[j] = -1;
+    if (t == 0) nvalid[0] = total;
+}
+template <typename T>
+__global__ void compact_gather_kernel(const T* rows, const int64_t* labels, const int32_t* perm, int R, int C, T* rows_c,
+                                      int64_t* labels_c) {
+    const int vpr = C / ElemTraits<T>::VEC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)R * vpr; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i / vpr), cv = (int)(i % vpr);
+        const int r = perm[j];
+        st16<T>(rows_c + (long)j * C + cv * ElemTraits<T>::VEC, r >= 0 ? ld16<T>(rows + (long)r * C + cv * ElemTraits<T>::VEC) : zero16<T>());
+        if (cv == 0) labels_c[j] = r >= 0 ? labels[r] : 0;
+    }
+}
+template <typename T>
+__global__ void scatter_rows_kernel(const T* rows_c, const int32_t* inv, int R, int C, T* rows) {
+    const int vpr = C / ElemTraits<T>::VEC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)R * vpr; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / vpr), cv = (int)(i % vpr);
+        const int j = inv[r];
+        st16<T>(rows + (long)r * C + cv * ElemTraits<T>::VEC, j >= 0 ? ld16<T>(rows_c + (long)j * C + cv * ElemTraits<T>::VEC) : zero16<T>());
     }
 }
 
@@ -523,19 +629,22 @@ __global__ void ce_loss_kernel(const float* row_lse, const float* label_logit, c
     __shared__ float red[8];
     float num = 0.f, den = 0.f;
     for (int m = threadIdx.x; m < R; m += blockDim.x) {
-        const float w = labels[m] != 0 ? 1.f : 0.f;
+        if (labels[m] == 0) continue;            // weight 0 (EasyDGL.py:180): lse may be undefined for such rows
         const float py = __expf(label_logit[m] - row_lse[m]);
-        num += w * (-__logf(py + 1e-5f));
-        den += w;
+        num += -__logf(py + 1e-5f);
+        den += 1.f;
     }
     num = block_sum(num, red);
     den = block_sum(den, red);
     const float W = den + 1e-5f;
     if (threadIdx.x == 0) loss_out[0] = num / W;
     for (int m = threadIdx.x; m < R; m += blockDim.x) {
-        const float w = labels[m] != 0 ? 1.f : 0.f;
-        const float py = __expf(label_logit[m] - row_lse[m]);
-        coef[m] = (w / W) * (py / (py + 1e-5f));
+        float cf = 0.f;
+        if (labels[m] != 0) {
+            const float py = __expf(label_logit[m] - row_lse[m]);
+            cf = (1.f / W) * (py / (py + 1e-5f));
+        }
+        coef[m] = cf;
     }
 }
 
@@ -734,7 +843,7 @@ inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize) {
     auto take = [&](long floats) { const long at = o; o += (floats + 63) / 64 * 64; return at; };
     b.off_rowsT = take(((long)C * up8(R) * (long)esize + 3) / 4);
     b.off_tableT = take(((long)C * up8(I) * (long)esize + 3) / 4);
-    b.off_slabY = take((long)b.y.nchunk * R * C);
+    b.off_slabY = take((long)b.y.nchunk * xblocks_of(R, xb) * xb * C);   // G workgroups x one [xb, C] tile each
     b.off_slabW = take((long)b.w.nchunk * I * C);
     b.off_slabB = take((long)b.w.nchunk * (I - 1));
     b.total = o;
@@ -747,7 +856,7 @@ int run_fwd(ScoreP p, hipStream_t st) {
     const size_t smem = 2 * (S::Z_BYTES + ZB * sizeof(float));
     auto k = score_fwd_kernel<T, CT>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, dim3(xblocks_of(p.R), p.nchunk), dim3(SNT), smem, st, p);
+    hipLaunchKernelGGL(k, dim3(xblocks_of(p.R) * p.nchunk), dim3(SNT), smem, st, p);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
@@ -779,17 +888,19 @@ int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_tab
         if (nw == 8) {
             auto k = score_bwd_kernel<T, CT, ROLE_Y, 8>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 256), q.nchunk), dim3(512), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 256) * q.nchunk), dim3(512), smem_nw, st, q);
         } else {
             auto k = score_bwd_kernel<T, CT, ROLE_Y, 4>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 128), q.nchunk), dim3(256), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 128) * q.nchunk), dim3(256), smem_nw, st, q);
         }
         edgl_prof_end(EDGL_KERNEL_SCORE_BWD_ROWS, st);
         EDGL_LAUNCH_CHECK();
         const long n = (long)p.R * p.C;
-        hipLaunchKernelGGL((slab_reduce_kernel<T>), dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st,
-                           q.slabs, q.nchunk, n, 0L, n, 0L, p.gscale, reinterpret_cast<T*>(d_rows));
+        const int xb = 32 * nw;
+        hipLaunchKernelGGL((slab_reduce_rows_kernel<T>), dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st,
+                           q.slabs, p.nvalid, p.R, p.C, xb, xblocks_of(p.R, xb) * q.nchunk, p.i1 - p.i0, p.gscale,
+                           reinterpret_cast<T*>(d_rows));
         EDGL_LAUNCH_CHECK();
     }
     // d_table, d_bias
@@ -859,23 +970,57 @@ int bwd_dispatch(ScoreP p, int C, const BwdPlan& plan, float* ws, void* d_rows, 
 
 }  // namespace
 
-extern "C" int edgl_score_chunks(int R, int n_items) { return pick_chunks(xblocks_of(R), n_items, score_ftarget()).nchunk; }
+// workspace rule of the forward: 2 * R * edgl_score_chunks floats >= 2 * XB * (#workgroups), the most (row, chunk)
+// partial pairs any device-side split of the launch can produce
+extern "C" int edgl_score_chunks(int R, int n_items) {
+    const long g = (long)xblocks_of(R) * pick_chunks(xblocks_of(R), n_items, score_ftarget()).nchunk;
+    return (int)((g * XB + R - 1) / R);
+}
+
+extern "C" int edgl_compact_rows(const void* rows, const int64_t* labels, int R, int C, int32_t* perm, int32_t* inv,
+                                 int32_t* nvalid, void* rows_c, int64_t* labels_c, int dtype, void* stream) {
+    EDGL_REQUIRE(rows && labels && perm && inv && nvalid && rows_c && labels_c, EDGL_ERR_NULL, "edgl_compact_rows: null pointer");
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_compact_rows: bad dtype %d", dtype);
+    EDGL_REQUIRE(R > 0 && C % (dtype == EDGL_BF16 ? 8 : 4) == 0, EDGL_ERR_SHAPE, "edgl_compact_rows: bad shape R=%d C=%d", R, C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, labels, R, perm, inv, nvalid);
+    EDGL_LAUNCH_CHECK();
+    const long nv = (long)R * C / (dtype == EDGL_BF16 ? 8 : 4);
+    const unsigned nb = (unsigned)std::min<long>((nv + 255) / 256, 2048);
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((compact_gather_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)rows, labels, perm, R, C, (float*)rows_c, labels_c);
+    else hipLaunchKernelGGL((compact_gather_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)rows, labels, perm, R, C, (bf16*)rows_c, labels_c);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_scatter_rows(const void* rows_c, const int32_t* inv, int R, int C, void* rows, int dtype, void* stream) {
+    EDGL_REQUIRE(rows_c && inv && rows, EDGL_ERR_NULL, "edgl_scatter_rows: null pointer");
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_scatter_rows: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const long nv = (long)R * C / (dtype == EDGL_BF16 ? 8 : 4);
+    const unsigned nb = (unsigned)std::min<long>((nv + 255) / 256, 2048);
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((scatter_rows_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)rows_c, inv, R, C, (float*)rows);
+    else hipLaunchKernelGGL((scatter_rows_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)rows_c, inv, R, C, (bf16*)rows);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
 
 extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
-                                  int R, int C, int I, int i0, int i1, float* row_lse, float* label_logit,
-                                  float* logits, float* workspace, int dtype, void* stream) {
+                                  int R, int C, int I, int i0, int i1, const int32_t* nvalid, float* row_lse,
+                                  float* label_logit, float* logits, float* workspace, int dtype, void* stream) {
     int rc = check_score(rows, table, out_bias, R, C, I, i0, i1, dtype, "edgl_score_lse_fwd");
     if (rc) return rc;
     EDGL_REQUIRE(row_lse && workspace && (!labels || label_logit), EDGL_ERR_NULL, "edgl_score_lse_fwd: null output");
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
-    p.i1 = i1; p.row_lse = row_lse; p.part = workspace; p.logits = logits;
+    p.i1 = i1; p.nvalid = nvalid; p.row_lse = row_lse; p.part = workspace; p.logits = logits;
     const Chunking ch = pick_chunks(xblocks_of(R), i1 - i0, score_ftarget());
     p.nchunk = ch.nchunk; p.zchunk = ch.zchunk;
     hipStream_t st = (hipStream_t)stream;
     rc = dtype == EDGL_F32 ? fwd_dispatch<float>(p, C, st) : fwd_dispatch<bf16>(p, C, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(lse_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, st, workspace, R, p.nchunk, row_lse);
+    hipLaunchKernelGGL(lse_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, st, workspace, R, nvalid,
+                       xblocks_of(R) * p.nchunk, i1 - i0, row_lse);
     EDGL_LAUNCH_CHECK();
     if (labels) {
         if (dtype == EDGL_F32)
@@ -901,15 +1046,15 @@ extern "C" long edgl_score_bwd_workspace(int R, int C, int I, int n_items, int d
 
 extern "C" int edgl_score_ce_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                                  const float* row_lse, const float* coef, const float* gscale, int R, int C, int I,
-                                 int i0, int i1, void* d_rows, float* d_table, float* d_bias, float* workspace,
-                                 int dtype, void* stream) {
+                                 int i0, int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias,
+                                 float* workspace, int dtype, void* stream) {
     int rc = check_score(rows, table, out_bias, R, C, I, i0, i1, dtype, "edgl_score_ce_bwd");
     if (rc) return rc;
     EDGL_REQUIRE(labels && row_lse && coef && d_rows && d_table && d_bias && workspace, EDGL_ERR_NULL,
                  "edgl_score_ce_bwd: null pointer");
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
-    p.i1 = i1; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
+    p.i1 = i1; p.nvalid = nvalid; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
     const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
     static const int dbg = getenv("EDGL_DBG") ? atoi(getenv("EDGL_DBG")) : 0;
     p.dbg = dbg;

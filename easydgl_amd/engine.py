@@ -61,7 +61,10 @@ class TrainEngine:
                      dlam=e(H * B, T, E, dtype=f32), tpp=e(lib.edgl_tpp_workspace(), dtype=f32))
             self.blk.append(d)
         self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
-        self.hrows = e(self.R, C)
+        self.hrows, self.hrows_c = e(self.R, C), e(self.R, C)
+        self.labels_c = torch.zeros(self.R, device=dev, dtype=torch.int64)
+        self.perm, self.inv = e(self.R, dtype=torch.int32), e(self.R, dtype=torch.int32)
+        self.nvalid = torch.zeros(1, device=dev, dtype=torch.int32)
         self.lse, self.lab_logit, self.coef = e(self.R, dtype=f32), e(self.R, dtype=f32), e(self.R, dtype=f32)
         self.loss = e(1, dtype=f32)
         # ---- backward temporaries -------------------------------------------------------------------------------
@@ -107,12 +110,12 @@ class TrainEngine:
                                          _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(y), _ptr(stats),
                                          self.code, _stream()), "edgl_add_layernorm_fwd")
 
-    def _ln_bwd(self, x, resid, ld_res, ln, stats, dy, drop, dsum, dx_drop, gpos=None):
+    def _ln_bwd(self, x, resid, ld_res, ln, stats, dy, drop, dsum, dx_drop, gpos=None, rowmap=None):
         B, T, C = self.B, self.T, self.C
         check(lib.edgl_add_layernorm_bwd(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
                                          _ptr(stats), _ptr(dy), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
-                                         _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(dsum), _ptr(dx_drop),
-                                         _ptr(ln.gamma.grad), _ptr(ln.beta.grad), _ptr(self.ws), self.code, _stream()),
+                                         _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(rowmap), _ptr(dsum),
+                                         _ptr(dx_drop), _ptr(ln.gamma.grad), _ptr(ln.beta.grad), _ptr(self.ws), self.code, _stream()),
               "edgl_add_layernorm_bwd")
 
     # ---- one optimizer step, as a fixed launch sequence ----------------------------------------------------------------
@@ -149,9 +152,13 @@ class TrainEngine:
             x, cin = b["y"], C
         self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, C, C, gelu=True, pre=self.pre_t)
         self._ln_fwd(self.so, None, 0, m.transform_ln, ops.NO_DROP, self.hrows, self.st3, gpos=self.mpos)
-        lab = self.labels.view(-1)
-        check(lib.edgl_score_lse_fwd(_ptr(self.hrows), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
-                                     _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st), "edgl_score_lse_fwd")
+        # rows whose label is 0 have weight 0 (EasyDGL.py:180): score only the weighted ones
+        check(lib.edgl_compact_rows(_ptr(self.hrows), _ptr(self.labels), R, C, _ptr(self.perm), _ptr(self.inv),
+                                    _ptr(self.nvalid), _ptr(self.hrows_c), _ptr(self.labels_c), code, st), "edgl_compact_rows")
+        lab = self.labels_c
+        check(lib.edgl_score_lse_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
+                                     _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
+              "edgl_score_lse_fwd")
         check(lib.edgl_ce_loss_fwd(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef), st),
               "edgl_ce_loss_fwd")
         if m.l2_reg != 0.0:
@@ -167,11 +174,12 @@ class TrainEngine:
                                        _ptr(m.mark_lookup_table), B, T, H, E, M, float(coef), _ptr(b["tpp"]), None,
                                        _ptr(b["dlam"]), st), "edgl_tpp_bwd")
         # ================= backward =================
-        check(lib.edgl_score_ce_bwd(_ptr(self.hrows), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
-                                    _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.d_rows), _ptr(tab.grad),
+        check(lib.edgl_score_ce_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
+                                    _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows), _ptr(tab.grad),
                                     _ptr(m.output_bias.grad), _ptr(self.ws), code, st), "edgl_score_ce_bwd")
         # head: LN (gathered rows) -> gelu' -> dense
-        self._ln_bwd(self.so, None, 0, m.transform_ln, self.st3, self.d_rows, ops.NO_DROP, self.G1, None, gpos=self.mpos)
+        self._ln_bwd(self.so, None, 0, m.transform_ln, self.st3, self.d_rows, ops.NO_DROP, self.G1, None, gpos=self.mpos,
+                     rowmap=self.inv)
         n = self.rows * C
         check(lib.edgl_gelu_bwd(_ptr(self.G1), _ptr(self.pre_t), _ptr(self.G1), n, code, st), "edgl_gelu_bwd")
         y_last = self.blk[-1]["y"] if self.blk else self.x0

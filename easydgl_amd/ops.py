@@ -264,7 +264,7 @@ class AddLayerNormFn(torch.autograd.Function):
         ws = torch.empty(B * 2 * C, device=x.device, dtype=torch.float32)
         rptr, ld = (None, 0) if resid is None else (resid.data_ptr(), resid.stride(1))
         check(lib.edgl_add_layernorm_bwd(_ptr(x), rptr, ld, _ptr(gamma), _ptr(stats), _ptr(dy), B, T, C,
-                                         float(drop.rate), drop.ptr(), drop.stream_id, _ptr(gather_pos), Mg,
+                                         float(drop.rate), drop.ptr(), drop.stream_id, _ptr(gather_pos), Mg, None,
                                          _ptr(dsum), _ptr(dxd), _ptr(dg), _ptr(db), _ptr(ws), code, _stream()),
               "edgl_add_layernorm_bwd")
         dx = dxd if drop.active else dsum
@@ -274,7 +274,21 @@ class AddLayerNormFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # K5 scoring + CE
 # ------------------------------------------------------------------------------------------------
-def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False):
+def compact_rows(rows, labels):
+    """Weighted rows (label != 0) first: returns rows_c, labels_c, perm, inv, nvalid (all on device)."""
+    R, C = rows.shape
+    dev = rows.device
+    perm = torch.empty(R, device=dev, dtype=torch.int32)
+    inv = torch.empty(R, device=dev, dtype=torch.int32)
+    nvalid = torch.empty(1, device=dev, dtype=torch.int32)
+    rows_c = torch.empty_like(rows)
+    labels_c = torch.empty_like(labels)
+    check(lib.edgl_compact_rows(_ptr(rows), _ptr(labels), R, C, _ptr(perm), _ptr(inv), _ptr(nvalid), _ptr(rows_c),
+                                _ptr(labels_c), _code(rows), _stream()), "edgl_compact_rows")
+    return rows_c, labels_c, perm, inv, nvalid
+
+
+def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False, nvalid=None):
     R, C = rows.shape
     I = table_c.shape[0]
     dev = rows.device
@@ -282,40 +296,46 @@ def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False):
     lab_logit = torch.zeros(R, device=dev, dtype=torch.float32)
     logits = torch.empty((R, i1 - i0), device=dev, dtype=torch.float32) if want_logits else None
     ws = torch.empty(2 * R * lib.edgl_score_chunks(R, i1 - i0), device=dev, dtype=torch.float32)
-    check(lib.edgl_score_lse_fwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), R, C, I, i0, i1, _ptr(lse),
-                                 _ptr(lab_logit), _ptr(logits), _ptr(ws), _code(rows), _stream()), "edgl_score_lse_fwd")
+    check(lib.edgl_score_lse_fwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), R, C, I, i0, i1, _ptr(nvalid),
+                                 _ptr(lse), _ptr(lab_logit), _ptr(logits), _ptr(ws), _code(rows), _stream()),
+          "edgl_score_lse_fwd")
     return lse, lab_logit, logits
 
 
 class ScoreCEFn(torch.autograd.Function):
-    """EasyDGL.py:149-155,177-185 without the [R, I] logits tensor."""
+    """EasyDGL.py:149-155,177-185 without the [R, I] logits tensor.  Rows with label 0 carry weight 0
+    (EasyDGL.py:180); they are compacted away before scoring, which changes neither loss nor gradients."""
 
     @staticmethod
     def forward(ctx, rows, table_master, out_bias, table_c, labels):
+        rows, labels, _perm, inv, nvalid = compact_rows(rows.contiguous(), labels.reshape(-1).contiguous())
         R, C = rows.shape
         I = table_c.shape[0]
-        lse, lab_logit, _ = score_lse(rows, table_c, out_bias, labels, 0, I)
+        lse, lab_logit, _ = score_lse(rows, table_c, out_bias, labels, 0, I, nvalid=nvalid)
         loss = torch.empty(1, device=rows.device, dtype=torch.float32)
         coef = torch.empty(R, device=rows.device, dtype=torch.float32)
         check(lib.edgl_ce_loss_fwd(_ptr(lse), _ptr(lab_logit), _ptr(labels), R, _ptr(loss), _ptr(coef), _stream()),
               "edgl_ce_loss_fwd")
-        ctx.save_for_backward(rows, table_c, out_bias, labels, lse, coef)
+        ctx.save_for_backward(rows, table_c, out_bias, labels, lse, coef, inv, nvalid)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        rows, table_c, out_bias, labels, lse, coef = ctx.saved_tensors
+        rows, table_c, out_bias, labels, lse, coef, inv, nvalid = ctx.saved_tensors
         R, C = rows.shape
         I = table_c.shape[0]
         dev = rows.device
         g = g.reshape(1).to(torch.float32).contiguous()
+        d_rows_c = torch.empty_like(rows)
         d_rows = torch.empty_like(rows)
         d_table = torch.empty((I, C), device=dev, dtype=torch.float32)
         d_bias = torch.empty(I - 1, device=dev, dtype=torch.float32)
         ws = torch.empty(lib.edgl_score_bwd_workspace(R, C, I, I, _code(rows)), device=dev, dtype=torch.float32)
         check(lib.edgl_score_ce_bwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), _ptr(lse), _ptr(coef),
-                                    _ptr(g), R, C, I, 0, I, _ptr(d_rows), _ptr(d_table), _ptr(d_bias), _ptr(ws),
-                                    _code(rows), _stream()), "edgl_score_ce_bwd")
+                                    _ptr(g), R, C, I, 0, I, _ptr(nvalid), _ptr(d_rows_c), _ptr(d_table), _ptr(d_bias),
+                                    _ptr(ws), _code(rows), _stream()), "edgl_score_ce_bwd")
+        check(lib.edgl_scatter_rows(_ptr(d_rows_c), _ptr(inv), R, C, _ptr(d_rows), _code(rows), _stream()),
+              "edgl_scatter_rows")
         return d_rows, d_table, d_bias, None, None
 
 

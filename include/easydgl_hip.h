@@ -146,12 +146,15 @@ int edgl_add_layernorm_fwd(const void* x, const void* resid, int ld_res, const f
 /* Backward: given dy (dense [B,T,C], or gathered [B*Mg,C] when gather_pos != NULL), recomputes
  * xhat from (x, resid, stats) and writes dx (gradient w.r.t. dropout(x)+resid input sum, i.e. the
  * caller uses it for the residual; d_x_pre = dx * dropmask is written to dx_drop) and per-sample
- * partials of dgamma/dbeta into workspace [B,2,C] reduced into dgamma/dbeta (overwritten). */
+ * partials of dgamma/dbeta into workspace [B,2,C] reduced into dgamma/dbeta (overwritten).
+ * Gathered rows naming the same position add up.  dy_rowmap (int32 [B*Mg], may be NULL) redirects
+ * gathered row r to row dy_rowmap[r] of dy (-1: the row carries no gradient) — the `inv` map of
+ * edgl_compact_rows. */
 int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_res, const float* gamma,
                            const float* stats, const void* dy, int B, int T, int C, float drop_rate,
                            const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
-                           int Mg, void* dsum, void* dx_drop, float* dgamma, float* dbeta,
-                           float* workspace, int dtype, void* stream);
+                           int Mg, const int32_t* dy_rowmap, void* dsum, void* dx_drop, float* dgamma,
+                           float* dbeta, float* workspace, int dtype, void* stream);
 
 /* ---- K5: tied-embedding scoring + cross-entropy — EasyDGL.py:149-155,177-185, Base.py:106-110 --
  * rows [R,C] `dtype`; table [I,C] `dtype` (row 0 acts as zeros, column 0 logit == -1000); out_bias
@@ -162,9 +165,20 @@ int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_res, const f
  * workspace >= 2*R*edgl_score_chunks(R, i1-i0) floats.  C: power of two, 32..256 (bf16) / 32..128 (f32);
  * i0 must be a multiple of 8. */
 int edgl_score_chunks(int R, int n_items);
+/* Rows with label 0 have weight 0 in the loss (EasyDGL.py:180) and therefore no effect on the loss
+ * or on any gradient.  edgl_compact_rows orders the weighted rows first: perm int32 [R] (original
+ * row of compact row j, -1 past the end), inv int32 [R] (compact index of row r, or -1), nvalid
+ * int32 [1] (device), rows_c [R,C] / labels_c [R] the gathered copies (zero past nvalid).  The
+ * scoring entry points take `nvalid` (device pointer or NULL): rows >= *nvalid are skipped (their
+ * row_lse is 0, their d_rows undefined).  edgl_scatter_rows undoes the compaction:
+ * rows[r] = inv[r] >= 0 ? rows_c[inv[r]] : 0. */
+int edgl_compact_rows(const void* rows, const int64_t* labels, int R, int C, int32_t* perm, int32_t* inv,
+                      int32_t* nvalid, void* rows_c, int64_t* labels_c, int dtype, void* stream);
+int edgl_scatter_rows(const void* rows_c, const int32_t* inv, int R, int C, void* rows, int dtype,
+                      void* stream);
 int edgl_score_lse_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
-                       int R, int C, int I, int i0, int i1, float* row_lse, float* label_logit,
-                       float* logits, float* workspace, int dtype, void* stream);
+                       int R, int C, int I, int i0, int i1, const int32_t* nvalid, float* row_lse,
+                       float* label_logit, float* logits, float* workspace, int dtype, void* stream);
 /* loss = sum_r w_r * (-log(p_y + 1e-5)) / (sum w + 1e-5), w_r = [label != 0]; also writes the
  * per-row coefficient coef[r] = (w_r/W) * p_y/(p_y+1e-5) used by the backward.  loss_out f32[1]. */
 int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
@@ -177,8 +191,8 @@ int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64
 long edgl_score_bwd_workspace(int R, int C, int I, int n_items, int dtype);
 int edgl_score_ce_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                       const float* row_lse, const float* coef, const float* gscale, int R, int C, int I,
-                      int i0, int i1, void* d_rows, float* d_table, float* d_bias, float* workspace,
-                      int dtype, void* stream);
+                      int i0, int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias,
+                      float* workspace, int dtype, void* stream);
 
 /* ---- K6: evaluation — Base.py:150-207 ----------------------------------------------------------
  * logits f32 [R, n] for the item range starting at i0; seen [R,T] int64 item ids to mask with -inf

@@ -248,6 +248,7 @@ def test_score_ce_fwd_bwd(name, dt, tol, R_, C, I):
     bias = torch.tensor(_rand((I - 1,), rng, 0.2), dtype=torch.float32).cuda().requires_grad_()
     labels = rng.integers(0, I, size=R_)
     labels[:3] = 0
+    labels[rng.random(R_) < 0.4] = 0          # weight-0 rows (masked positions on padding) are compacted away
     lab = torch.tensor(labels, dtype=torch.int64).cuda()
     loss = o.ScoreCEFn.apply(rows, tab, bias, tab_c, lab)
     (loss * 1.7).backward()
@@ -269,6 +270,69 @@ def test_score_ce_fwd_bwd(name, dt, tol, R_, C, I):
     lg = o.ScoreLogitsFn.apply(rows.detach(), tab.detach(), bias.detach(), tab_c)
     assert_close(lg.cpu().numpy(), logits.detach().numpy(), 1e-5 if name == "f32" else 1e-5, "logits")
     assert float((lg[:, 0] + 1000.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("R_,frac", [(1, 0.0), (7, 1.0), (1000, 0.5), (5000, 0.0), (10240, 0.47)])
+def test_compact_rows_is_a_stable_partition(R_, frac):
+    o = ops()
+    rng = np.random.default_rng(R_)
+    C = 32
+    rows = torch.tensor(_rand((R_, C), rng), dtype=torch.bfloat16).cuda()
+    labels = rng.integers(1, 900, size=R_)
+    labels[rng.random(R_) < frac] = 0
+    lab = torch.tensor(labels, dtype=torch.int64).cuda()
+    rows_c, lab_c, perm, inv, nvalid = o.compact_rows(rows, lab)
+    keep = np.nonzero(labels)[0]
+    n = len(keep)
+    assert int(nvalid.item()) == n
+    np.testing.assert_array_equal(perm.cpu().numpy()[:n], keep)
+    assert (perm.cpu().numpy()[n:] == -1).all()
+    want_inv = np.full(R_, -1)
+    want_inv[keep] = np.arange(n)
+    np.testing.assert_array_equal(inv.cpu().numpy(), want_inv)
+    np.testing.assert_array_equal(lab_c.cpu().numpy()[:n], labels[keep])
+    assert (lab_c.cpu().numpy()[n:] == 0).all()
+    assert torch.equal(rows_c[:n], rows[torch.tensor(keep, dtype=torch.int64).cuda()])
+    assert float(rows_c[n:].float().abs().sum()) == 0.0
+
+
+def test_score_ce_all_rows_unweighted_gives_zero_loss_and_grads():
+    o = ops()
+    rng = np.random.default_rng(3)
+    rows = torch.tensor(_rand((40, 32), rng), dtype=torch.float32).cuda().requires_grad_()
+    tab = torch.tensor(_rand((200, 32), rng), dtype=torch.float32).cuda().requires_grad_()
+    bias = torch.zeros(199).cuda().requires_grad_()
+    lab = torch.zeros(40, dtype=torch.int64).cuda()
+    loss = o.ScoreCEFn.apply(rows, tab, bias, tab.detach(), lab)
+    loss.backward()
+    assert loss.item() == 0.0
+    assert float(rows.grad.abs().max()) == 0.0 and float(tab.grad.abs().max()) == 0.0 and float(bias.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+def test_layernorm_gather_with_repeated_positions(name, dt, tol):
+    """Base.py mask_random pads masked_positions with 0: several gathered rows may name one position; grads add."""
+    o = ops()
+    rng = np.random.default_rng(11)
+    B, T, C, M = 4, 13, 32, 6
+    x = torch.tensor(_rand((B, T, C), rng), dtype=dt).cuda().requires_grad_()
+    g = torch.tensor(1 + 0.1 * _rand((C,), rng), dtype=torch.float32).cuda().requires_grad_()
+    be = torch.tensor(0.1 * _rand((C,), rng), dtype=torch.float32).cuda().requires_grad_()
+    gp_np = rng.integers(0, T, size=(B, M))
+    gp_np[:, 3:] = 0
+    gp_np[1, 0] = 0
+    gp = torch.tensor(gp_np, dtype=torch.int64).cuda()
+    y = o.AddLayerNormFn.apply(x, None, g, be, o.NO_DROP, gp)
+    dy = torch.tensor(_rand(tuple(y.shape), rng), dtype=dt).cuda()
+    y.backward(dy)
+    xr = x.detach().double().cpu().requires_grad_()
+    gr, ber = g.detach().double().cpu().requires_grad_(), be.detach().double().cpu().requires_grad_()
+    yr = R.layernorm(xr, gr, ber)[torch.arange(B)[:, None], gp.cpu()].reshape(-1, C)
+    yr.backward(dy.double().cpu())
+    assert_close(y.detach().float().cpu().numpy(), yr.detach().numpy(), tol, "ln y")
+    assert_close(x.grad.float().cpu().numpy(), xr.grad.numpy(), tol * 3, "ln dx")
+    assert_close(g.grad.cpu().numpy(), gr.grad.numpy(), tol * 3, "ln dgamma")
+    assert_close(be.grad.cpu().numpy(), ber.grad.numpy(), tol * 3, "ln dbeta")
 
 
 def test_topk_ties_masking_merge_and_metrics():

@@ -24,7 +24,7 @@ ws = torch.empty(lib.edgl_score_bwd_workspace(R, C, I, I, 1), device="cuda")
 t_f = timeit(lambda: ops.score_lse(rows, tab, bias, lab, 0, I))
 _lib.profiler.start()
 def bwd():
-    check(lib.edgl_score_ce_bwd(_ptr(rows), _ptr(tab), _ptr(bias), _ptr(lab), _ptr(lse), _ptr(coef), None, R, C, I, 0, I,
+    check(lib.edgl_score_ce_bwd(_ptr(rows), _ptr(tab), _ptr(bias), _ptr(lab), _ptr(lse), _ptr(coef), None, R, C, I, 0, I, None,
                                 _ptr(d_rows), _ptr(d_tab), _ptr(d_bias), _ptr(ws), 1, _stream()))
 t_b = timeit(bwd)
 gf = 2.0 * R * C * I / 1e9
