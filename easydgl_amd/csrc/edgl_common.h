@@ -121,8 +121,14 @@ __device__ __forceinline__ f32x4 mma16(const Frag4<bf16>& a, const Frag4<bf16>& 
 }
 template <typename T> __device__ __forceinline__ Frag4<T> frag_from_acc(const f32x4& c) {
     Frag4<T> f;
+    if constexpr (sizeof(T) == 2) {   // one v_cvt_pk_bf16_f32 per pair (RNE, same as the scalar cast)
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+        const bf16x4_t v = __builtin_convertvector(c, bf16x4_t);
+        *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<const uint2*>(&v);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) f.v[r] = from_f32<T>(c[r]);
+        for (int r = 0; r < 4; ++r) f.v[r] = from_f32<T>(c[r]);
+    }
     return f;
 }
 template <typename T> __device__ __forceinline__ Frag4<T> frag_ld(const T* p) {  // 4 contiguous elements

@@ -30,11 +30,12 @@ __device__ __forceinline__ void st_frag(T* dst, const f32x4& a) {
     else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&f);
 }
 
-template <typename T, int DT, int NT>
+template <typename T, int DT, int NT, int EC>
 __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const PackDims pd = pack_dims<T>(dh, p.E);
+    const int E = EC ? EC : p.E;   // EC = 16: LDS offsets are immediates, the mark loops are straight-line code
+    const PackDims pd = pack_dims<T>(dh, E);
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.pack);
         uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
     stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, TR ? nullptr : KTs, LDT, lane);
     stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, Ts, TR ? nullptr : TTs, LDT, lane);
     stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, Vs, nullptr, LDT, lane);
-    stage_marks<T>(p.marks + (long)b * p.T * p.E, p.E, p.T, Tp, Ms, TR ? nullptr : MTs, LDT, lane);
+    stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, TR ? nullptr : MTs, LDT, lane);
     const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            if (e < p.E) {
+            if (EC == 16 || e < E) {
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
                     const int jt = e * DT + d;
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
                     zp[e] += zz[0] * wv.x + zz[1] * wv.y + zz[2] * wv.z + zz[3] * wv.w;
                 }
             }
+            if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // at most two marks' operand loads in flight
         }
         float z4[4], lam4[4], sg4[4];
         reduce_scatter16(zp, z4, lane);
@@ -224,9 +226,9 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float dl = dlamT[i];
-            if (p.d_lam_ext && qok && (g4 + i) < p.E) dl += p.d_lam_ext[(bp * p.T + q) * p.E + g4 + i];
+            if (p.d_lam_ext && qok && (g4 + i) < E) dl += p.d_lam_ext[(bp * p.T + q) * E + g4 + i];
             dz4[i] = dl * sg4[i];
-            if (qok && (g4 + i) < p.E) dsc_acc[i] += dl * (lam4[i] - z4[i] * sg4[i]);
+            if (qok && (g4 + i) < E) dsc_acc[i] += dl * (lam4[i] - z4[i] * sg4[i]);
         }
         if (qok) *reinterpret_cast<float4*>(p.dz_ws + (bp * p.T + q) * EP + g4) = make_float4(dz4[0], dz4[1], dz4[2], dz4[3]);
         float dz16[16];
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
         for (int ut = 0; ut < DT; ++ut) dH[ut] = zero4;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            if (e < p.E) {
+            if (EC == 16 || e < E) {
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
                     const int jt = e * DT + d;
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
                         dH[ut] = mma16(frag_ld<T>(W1R + (ut * 16 + l15) * pd.LDR + jt * 16 + g4), duf, dH[ut]);
                 }
             }
+            if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- dP2 = dH.T_^T ; dS = P*(dP - rowsum(dP*P)) * c --------------------------------------------
         Frag4<T> dhf[DT];
@@ -499,7 +502,7 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     const size_t smem = pd.bytes + waves * wave_bytes;
     EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: needs %zu B of LDS", smem);
     p.waves = waves;
-    auto kern = bimau_bwd_kernel<T, DT, NT>;
+    auto kern = p.E == 16 ? bimau_bwd_kernel<T, DT, NT, 16> : bimau_bwd_kernel<T, DT, NT, 0>;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const long jobs = (long)p.B * p.H;
     edgl_prof_begin(EDGL_KERNEL_BIMAU_BWD, st);

@@ -15,12 +15,14 @@ struct FwdP {
     int waves;
 };
 
-// DT = dh/16, NT = ceil(T/16)
-template <typename T, int DT, int NT>
+// DT = dh/16, NT = ceil(T/16); EC = compile-time mark count (16: all LDS offsets are immediates and the mark loop is
+// one straight-line block) or 0 (runtime p.E)
+template <typename T, int DT, int NT, int EC>
 __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const PackDims pd = pack_dims<T>(dh, p.E);
+    const int E = EC ? EC : p.E;
+    const PackDims pd = pack_dims<T>(dh, E);
     // ---- workgroup-shared intensity weights -------------------------------------------------
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.pack);
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, nullptr, LDT, lane);           // K  (split order Q,K,V,T: temporal.py:410)
     stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Ts : nullptr, TR ? nullptr : Ts, LDT, lane);   // T_
     stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Vs : nullptr, TR ? nullptr : Vs, LDT, lane);   // V
-    stage_marks<T>(p.marks + (long)b * p.T * p.E, p.E, p.T, Tp, Ms, nullptr, LDT, lane);
+    stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, nullptr, LDT, lane);
     const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
         for (int e = 0; e < 16; ++e) zp[e] = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            if (e < p.E) {
+            if (EC == 16 || e < E) {
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
                     const int jt = e * DT + d;
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                              sigmoid_pre(a[2] + fmaf(span, ws.z, bs.z)) * wv.z + sigmoid_pre(a[3] + fmaf(span, ws.w, bs.w)) * wv.w;
                 }
             }
+            if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // keep the operand loads of at most two marks in flight
         }
         float z4[4];
         reduce_scatter16(zp, z4, lane);  // lane group g now owns e = 4g + i
@@ -127,10 +130,14 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
             lf.v[i] = from_f32<T>(lam4[i]);
         }
         if (qok) {
-            float* dst = p.lam + (bp * p.T + q) * p.E + g4;
+            float* dst = p.lam + (bp * p.T + q) * E + g4;
+            if constexpr (EC == 16) {
+                *reinterpret_cast<float4*>(dst) = make_float4(lam4[0], lam4[1], lam4[2], lam4[3]);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (g4 + i < p.E) dst[i] = lam4[i];
+                for (int i = 0; i < 4; ++i)
+                    if (g4 + i < E) dst[i] = lam4[i];
+            }
         }
         // ---- G^T[k][q] = sum_e marks[k][e] lam[q][e]; diag := 1; A' = dropout(G * P) ------------
         const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);   // element index of (b', q, k=0); < 2^32 (host-checked)
@@ -173,23 +180,28 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     }
 }
 
-template <typename T, int DT, int NT>
-int launch_fwd(FwdP p, hipStream_t st) {
+template <typename T, int DT, int NT, int EC>
+int launch_fwd_e(FwdP p, hipStream_t st) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     const PackDims pd = pack_dims<T>(dh, p.E);
     const size_t wave_bytes = ((size_t)Tp * dh + 2 * (sizeof(T) == 2 ? (size_t)Tp * dh : (size_t)dh * LDT) + (size_t)Tp * EP) * sizeof(T);
     int waves = 4;
-    while (waves > 1 && pd.bytes + waves * wave_bytes > 64 * 1024) waves >>= 1;
+    while (waves > 1 && pd.bytes + waves * wave_bytes > 80 * 1024) waves >>= 1;
     const size_t smem = pd.bytes + waves * wave_bytes;
     EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_fwd: needs %zu B of LDS (dh=%d E=%d T=%d)", smem, dh,
                  p.E, p.T);
     p.waves = waves;
-    auto kern = bimau_fwd_kernel<T, DT, NT>;
+    auto kern = bimau_fwd_kernel<T, DT, NT, EC>;
     if (smem > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const long jobs = (long)p.B * p.H;
     hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
+}
+
+template <typename T, int DT, int NT>
+int launch_fwd(FwdP p, hipStream_t st) {
+    return p.E == 16 ? launch_fwd_e<T, DT, NT, 16>(p, st) : launch_fwd_e<T, DT, NT, 0>(p, st);
 }
 
 template <typename T, int DT>
