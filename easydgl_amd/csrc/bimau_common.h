@@ -83,38 +83,43 @@ __global__ void pack_kernel(const float* W1, const float* b1, const float* w, co
 //   -inf        k >= T (tile padding: excluded from the softmax)
 // `pad` keeps the padded-key bits for the backward (no gradient flows into a padded score).
 template <int NT>
-struct KeyMask { f32x4 madd[NT]; uint32_t pad; };
+struct KeyMask { const float* madd; uint32_t pad; };   // madd: wave-private LDS array [16*NT]
 template <int NT>
-__device__ __forceinline__ KeyMask<NT> load_keymask(const int64_t* ids_row, int T, int lane) {
+__device__ __forceinline__ KeyMask<NT> load_keymask(const int64_t* ids_row, int T, int lane, float* lds_madd) {
     KeyMask<NT> km;
     km.pad = 0u;
+    km.madd = lds_madd;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = kt * 16 + (lane >> 4) * 4 + r;
-            float v = -INFINITY;
-            if (k < T) {
-                v = 0.f;
-                if (ids_row[k] == 0) { v = -4294967296.0f; km.pad |= 1u << (kt * 4 + r); }
-            }
-            km.madd[kt][r] = v;
+            if (k < T && ids_row[k] == 0) km.pad |= 1u << (kt * 4 + r);
         }
+    for (int k = lane; k < 16 * NT; k += 64) {
+        float v = -INFINITY;
+        if (k < T) v = ids_row[k] == 0 ? -4294967296.0f : 0.f;
+        lds_madd[k] = v;
+    }
     return km;
 }
 
 // S^T tiles -> normalised P^T tiles (temporal.py:422-429).  s[kt][r] in: raw Q.K; out: softmax.
 template <int NT>
-__device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale) {
+__device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale, int lane) {
     float mx = -INFINITY;
+    const float* mrow = km.madd + (lane >> 4) * 4;
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NT; ++kt) {
+        const float4 m4 = *reinterpret_cast<const float4*>(mrow + kt * 16);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = fmaf(s[kt][r], cscale, km.madd[kt][r]);
+            const float v = fmaf(s[kt][r], cscale, mm[r]);
             s[kt][r] = v;
             mx = fmaxf(mx, v);
         }
+    }
     mx = group_max4(mx);
     float sum = 0.f;
 #pragma unroll

@@ -108,7 +108,8 @@ __device__ __forceinline__ f32x4 mma_kblock(const Vec16<bf16>& a, const Vec16<bf
 // 4-element (K=16) fragments used by the attention kernels: lane holds k=(l>>4)*4+j, j=0..3.
 template <typename T> struct Frag4;
 template <> struct Frag4<float> { float v[4]; };
-template <> struct Frag4<bf16> { bf16 v[4]; };
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+template <> struct Frag4<bf16> { bf16x4 v; };   // one 64-bit register pair; v[i] indexes the packed vector
 
 __device__ __forceinline__ f32x4 mma16(const Frag4<float>& a, const Frag4<float>& b, f32x4 acc) {
 #pragma unroll
@@ -116,15 +117,21 @@ __device__ __forceinline__ f32x4 mma16(const Frag4<float>& a, const Frag4<float>
     return acc;
 }
 __device__ __forceinline__ f32x4 mma16(const Frag4<bf16>& a, const Frag4<bf16>& b, f32x4 acc) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*reinterpret_cast<const s16x4*>(&a),
-                                                     *reinterpret_cast<const s16x4*>(&b), acc, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a.v), __builtin_bit_cast(s16x4, b.v), acc, 0, 0, 0);
 }
 template <typename T> __device__ __forceinline__ Frag4<T> frag_from_acc(const f32x4& c) {
     Frag4<T> f;
     if constexpr (sizeof(T) == 2) {   // one v_cvt_pk_bf16_f32 per pair (RNE, same as the scalar cast)
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-        const bf16x4_t v = __builtin_convertvector(c, bf16x4_t);
-        *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<const uint2*>(&v);
+        // two <2 x float> -> <2 x bfloat> truncations, each moved through a 32-bit integer: this is the form that
+        // selects one v_cvt_pk_bf16_f32 per pair (a <4 x bfloat> value feeding an MFMA is scalarised: 4 cvt + 2 perm)
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        const bf16x2_t lo = __builtin_convertvector((f32x2_t){c[0], c[1]}, bf16x2_t);
+        const bf16x2_t hi = __builtin_convertvector((f32x2_t){c[2], c[3]}, bf16x2_t);
+        uint2 u;
+        u.x = __builtin_bit_cast(uint32_t, lo);
+        u.y = __builtin_bit_cast(uint32_t, hi);
+        f.v = __builtin_bit_cast(bf16x4, u);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) f.v[r] = from_f32<T>(c[r]);

@@ -8,6 +8,10 @@
 //      dW1 / db1 / dw partials per workgroup, reduced deterministically by a third tiny kernel.
 #include "bimau_common.h"
 
+#ifndef EDGL_BWD_OCC
+#define EDGL_BWD_OCC
+#endif
+
 namespace {
 using namespace bimau;
 
@@ -31,7 +35,7 @@ __device__ __forceinline__ void st_frag(T* dst, const f32x4& a) {
 }
 
 template <typename T, int DT, int NT, int EC>
-__global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
+__global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = EC ? EC : p.E;   // EC = 16: LDS offsets are immediates, the mark loops are straight-line code
@@ -58,7 +62,8 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
     // operand with transpose reads (kfrag).  f32: additionally K^T, T_^T, marks^T images (no 32-bit transpose read).
     constexpr bool TR = sizeof(T) == 2;
     constexpr size_t EXTRA = TR ? 0 : 2 * (size_t)dh * LDT + (size_t)EP * LDT;
-    constexpr size_t WAVE_ELEMS = 3 * (size_t)Tp * dh + (size_t)Tp * EP + EXTRA;
+    constexpr size_t MASK_ELEMS = (size_t)Tp * sizeof(float) / sizeof(T);   // additive key mask, f32 [Tp]
+    constexpr size_t WAVE_ELEMS = 3 * (size_t)Tp * dh + (size_t)Tp * EP + EXTRA + MASK_ELEMS;
     T* Ks = reinterpret_cast<T*>(smem + pd.bytes) + (size_t)wave * WAVE_ELEMS;  // K  [Tp][dh]
     T* Ts = Ks + Tp * dh;                                                       // T_ [Tp][dh]
     T* Vs = Ts + Tp * dh;                                                       // V  [Tp][dh]
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
     stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, Ts, TR ? nullptr : TTs, LDT, lane);
     stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, Vs, nullptr, LDT, lane);
     stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, TR ? nullptr : MTs, LDT, lane);
-    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane);
+    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ks + WAVE_ELEMS - MASK_ELEMS));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -92,6 +97,9 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
     float dsc_acc[4] = {0.f, 0.f, 0.f, 0.f};
 
     for (int qt = 0; qt < NT; ++qt) {
+        // compiler-level memory barrier: without it every loop-invariant LDS operand (intensity weights, key mask) is
+        // hoisted out of the query loop and parked in ~190 extra registers
+        asm volatile("" ::: "memory");
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
         Frag4<T> qf[DT], dof[DT];
@@ -110,19 +118,24 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, km, cscale);  // s = P^T, L(first=k, second=q)
+        masked_softmax<NT>(s, km, cscale, lane);  // s = P^T, L(first=k, second=q)
+        // From here on P lives in the activation dtype only (bf16: 2 registers per key tile instead of 4).  That is
+        // the precision the forward pass used for P.T_ and A'.V anyway.
+        Frag4<T> pf[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) pf[kt] = frag_from_acc<T>(s[kt]);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- H^T and the intensity MLP ----------------------------------------------------------
         Frag4<T> hf[DT];
+        f32x4 hacc[DT];   // H^T in f32, L(first=u, second=q): used again by the softmax row-dot
         {
-            Frag4<T> pf[NT];
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt) pf[kt] = frag_from_acc<T>(s[kt]);
 #pragma unroll
             for (int ut = 0; ut < DT; ++ut) {
                 f32x4 a = zero4;
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
                     a = mma16(kfrag<T>(Ts, dh, TTs, LDT, kt * 16, ut * 16, lane), pf[kt], a);
+                hacc[ut] = a;
                 hf[ut] = frag_from_acc<T>(a);
                 if (qok) {  // Hin rows for kernel B (T-rounded, identical to what Z is computed from)
                     T* dst = reinterpret_cast<T*>(p.hin_ws) + (bp * p.T + q) * dh + ut * 16 + g4;
@@ -132,13 +145,17 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
             }
         }
         const float span = qok ? p.spans[(long)b * p.T + q] : 0.f;
-        f32x4 zt[16][DT];  // sigmoid outputs Z^T[j][q], j = e*dh + d*16 + g4 + r
+        // zq[e][d] = wv[j] * z (1 - z) for channel j = e*dh + d*16 + g4 + r (z = sigmoid output): all the du step needs.
+        // Kept in the activation dtype (bf16: 2 registers per tile instead of 4).
+        Frag4<T> zq[16][DT];
         float zp[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             zp[e] = 0.f;
+            if constexpr (EC != 16) {
 #pragma unroll
-            for (int d = 0; d < DT; ++d) zt[e][d] = zero4;
+                for (int d = 0; d < DT; ++d) zq[e][d] = frag_zero<T>();
+            }
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -153,13 +170,16 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
                     const float4 ws = *reinterpret_cast<const float4*>(w1s + jt * 16 + g4);
                     const float4 bs = *reinterpret_cast<const float4*>(b1s + jt * 16 + g4);
                     const float4 wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
-                    f32x4 zz;
+                    f32x4 zz, zw;
                     zz[0] = sigmoid_pre(a[0] + fmaf(span, ws.x, bs.x));
                     zz[1] = sigmoid_pre(a[1] + fmaf(span, ws.y, bs.y));
                     zz[2] = sigmoid_pre(a[2] + fmaf(span, ws.z, bs.z));
                     zz[3] = sigmoid_pre(a[3] + fmaf(span, ws.w, bs.w));
-                    zt[e][d] = zz;
-                    zp[e] += zz[0] * wv.x + zz[1] * wv.y + zz[2] * wv.z + zz[3] * wv.w;
+                    zw[0] = zz[0] * wv.x; zw[1] = zz[1] * wv.y; zw[2] = zz[2] * wv.z; zw[3] = zz[3] * wv.w;
+                    zp[e] += (zw[0] + zw[1]) + (zw[2] + zw[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) zw[r] = zw[r] - zw[r] * zz[r];   // wv z (1 - z)
+                    zq[e][d] = frag_from_acc<T>(zw);
                 }
             }
             if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // at most two marks' operand loads in flight
@@ -175,11 +195,13 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
             sg4[i] = sigmoid_f(x);
             lf.v[i] = from_f32<T>(lam4[i]);
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- G, dA, dG -> dlambda, dP1, and dV accumulation ----------------------------------------
         Frag4<T> dOT[DT];  // L(first=q, second=v): A operand contracting over q
 #pragma unroll
         for (int vt = 0; vt < DT; ++vt) dOT[vt] = frag_from_acc<T>(mma16(dof[vt], ident, zero4));
-        f32x4 dp[NT];
+        Frag4<T> d1f[NT];     // dP through A' (dA * D * G'), activation dtype
+        float rowdot = 0.f;   // sum_k dP[q][k] P[q][k]: this lane's part of  sum_k d1 * P
         f32x4 dlamT = zero4;  // L(first=e, second=q)
         const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);   // dropout element index of (b', q, k=0)
 #pragma unroll
@@ -204,23 +226,26 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = s[kt][r];
+                const float pv = to_f32(pf[kt].v[r]);
                 const float fac = facs[r];
                 ap[r] = fac * gv[r] * pv;                 // A' = D*G'*P
                 const float dad = da[r] * fac;
                 dg[r] = dad * pv;
                 d1[r] = dad * gv[r];                      // dP through A'
+                rowdot = fmaf(d1[r], pv, rowdot);
             }
             if (kt == qt) {   // set_diag blocks the gradient into lambda
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dg[r] = (g4 + r == l15) ? 0.f : dg[r];
             }
-            dp[kt] = d1;
+            d1f[kt] = frag_from_acc<T>(d1);
             dlamT = mma16(kfrag<T>(Ms, EP, MTs, LDT, kt * 16, 0, lane), frag_from_acc<T>(dg), dlamT);
             const Frag4<T> apT = frag_from_acc<T>(transpose_tile<T>(ap, ident));  // L(first=q, second=k)
 #pragma unroll
             for (int vt = 0; vt < DT; ++vt) dVa[vt][kt] = mma16(dOT[vt], apT, dVa[vt][kt]);
+            if (kt & 1) __builtin_amdgcn_sched_barrier(0);   // bound the live ranges: at most two key tiles interleaved
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dlambda -> dz, dscaling ---------------------------------------------------------------
         float dz4[4];
 #pragma unroll
@@ -233,6 +258,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
         if (qok) *reinterpret_cast<float4*>(p.dz_ws + (bp * p.T + q) * EP + g4) = make_float4(dz4[0], dz4[1], dz4[2], dz4[3]);
         float dz16[16];
         all_gather16(dz4, dz16, lane);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- du -> dH^T[u][q] = sum_j W1[u][j] du[q][j] -----------------------------------------------
         f32x4 dH[DT];
 #pragma unroll
@@ -243,13 +269,10 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
                     const int jt = e * DT + d;
-                    const float4 wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
-                    const f32x4 zz = zt[e][d];
+                    const Frag4<T> zf = zq[e][d];
                     f32x4 du;
-                    du[0] = dz16[e] * wv.x * zz[0] * (1.0f - zz[0]);
-                    du[1] = dz16[e] * wv.y * zz[1] * (1.0f - zz[1]);
-                    du[2] = dz16[e] * wv.z * zz[2] * (1.0f - zz[2]);
-                    du[3] = dz16[e] * wv.w * zz[3] * (1.0f - zz[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) du[r] = dz16[e] * to_f32(zf.v[r]);
                     const Frag4<T> duf = frag_from_acc<T>(du);
 #pragma unroll
                     for (int ut = 0; ut < DT; ++ut)
@@ -258,20 +281,16 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
             }
             if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- dP2 = dH.T_^T ; dS = P*(dP - rowsum(dP*P)) * c --------------------------------------------
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dP = d1 + dH.T_^T ; dS = P*(dP - rowsum(dP*P)) * c -----------------------------------------
+        // rowsum(dP*P) = sum_k d1*P + sum_k P[q][k] (dH[q].T_[k]) = sum_k d1*P + dH[q].H[q]   (H = P.T_), so the row
+        // term is known before the key sweep and dP never has to be kept for all key tiles.
         Frag4<T> dhf[DT];
 #pragma unroll
-        for (int ut = 0; ut < DT; ++ut) dhf[ut] = frag_from_acc<T>(dH[ut]);
-        float rowdot = 0.f;
+        for (int ut = 0; ut < DT; ++ut) {
+            dhf[ut] = frag_from_acc<T>(dH[ut]);
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4 a = dp[kt];
-#pragma unroll
-            for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ts + (kt * 16 + l15) * dh + ub * 16 + g4), dhf[ub], a);
-            dp[kt] = a;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rowdot += a[r] * s[kt][r];
+            for (int r = 0; r < 4; ++r) rowdot = fmaf(dH[ut][r], hacc[ut][r], rowdot);
         }
         rowdot = group_sum4(rowdot);
         // transposed operands for the query-contracting products
@@ -286,25 +305,32 @@ __global__ __launch_bounds__(256) void bimau_bwd_kernel(BwdP p) {
         for (int ut = 0; ut < DT; ++ut) dQ[ut] = zero4;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
+            f32x4 a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = to_f32(d1f[kt].v[r]);
+#pragma unroll
+            for (int ub = 0; ub < DT; ++ub)
+                a = mma16(frag_ld<T>(Ts + (kt * 16 + l15) * dh + ub * 16 + g4), dhf[ub], a);
             f32x4 ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // tf.where(mask==0, paddings, S) (temporal.py:425-426) passes no gradient to a padded key's
                 // score; P is non-zero there only for fully padded rows (uniform softmax)
                 const bool padded = (km.pad >> (kt * 4 + r)) & 1u;
-                ds[r] = padded ? 0.f : s[kt][r] * (dp[kt][r] - rowdot) * cscale;
+                ds[r] = padded ? 0.f : to_f32(pf[kt].v[r]) * (a[r] - rowdot) * cscale;
             }
             const Frag4<T> dsf = frag_from_acc<T>(ds);
 #pragma unroll
             for (int ut = 0; ut < DT; ++ut)
                 dQ[ut] = mma16(kfrag<T>(Ks, dh, KTs, LDT, kt * 16, ut * 16, lane), dsf, dQ[ut]);
             const Frag4<T> dsT = frag_from_acc<T>(transpose_tile<T>(ds, ident));
-            const Frag4<T> pT = frag_from_acc<T>(transpose_tile<T>(s[kt], ident));
+            const Frag4<T> pT = frag_from_acc<T>(mma16(pf[kt], ident, zero4));   // P^T tile: L(first=q, second=k)
 #pragma unroll
             for (int ut = 0; ut < DT; ++ut) {
                 dKa[ut][kt] = mma16(QT[ut], dsT, dKa[ut][kt]);
                 dTa[ut][kt] = mma16(dHT[ut], pT, dTa[ut][kt]);
             }
+            if (kt & 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (qok) {
 #pragma unroll
@@ -496,7 +522,8 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     const WsLayout wl = ws_layout<T>(p.B, p.T, p.C, p.H, p.E);
     p.hin_ws = ws + wl.hin; p.dz_ws = reinterpret_cast<float*>(ws + wl.dz);
     p.dsc_part = reinterpret_cast<float*>(ws + wl.dsc); p.wpart = reinterpret_cast<float*>(ws + wl.wpart);
-    const size_t wave_bytes = (3 * (size_t)Tp * dh + (size_t)Tp * EP + (sizeof(T) == 2 ? 0 : 2 * (size_t)dh * LDT + (size_t)EP * LDT)) * sizeof(T);
+    const size_t wave_bytes = (3 * (size_t)Tp * dh + (size_t)Tp * EP + (sizeof(T) == 2 ? 0 : 2 * (size_t)dh * LDT + (size_t)EP * LDT)) * sizeof(T) +
+                              (size_t)Tp * sizeof(float);
     int waves = 4;
     while (waves > 1 && pd.bytes + waves * wave_bytes > 80 * 1024) waves >>= 1;
     const size_t smem = pd.bytes + waves * wave_bytes;

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     //      KEY index fetch their operand with transpose reads (kfrag).  f32: T_ and V are staged transposed instead.
     constexpr bool TR = sizeof(T) == 2;
     constexpr size_t KV_ELEMS = TR ? (size_t)Tp * dh : (size_t)dh * LDT;
-    constexpr size_t WAVE_ELEMS = (size_t)Tp * dh + 2 * KV_ELEMS + (size_t)Tp * EP;
+    constexpr size_t MASK_ELEMS = (size_t)Tp * sizeof(float) / sizeof(T);   // additive key mask, f32 [Tp]
+    constexpr size_t WAVE_ELEMS = (size_t)Tp * dh + 2 * KV_ELEMS + (size_t)Tp * EP + MASK_ELEMS;
     T* Ks = reinterpret_cast<T*>(smem + pd.bytes) + (size_t)wave * WAVE_ELEMS;
     T* Ts = Ks + Tp * dh;       // T_ : row-major (bf16) or transposed [dh][LDT] (f32)
     T* Vs = Ts + KV_ELEMS;      // V  : same
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Ts : nullptr, TR ? nullptr : Ts, LDT, lane);   // T_
     stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Vs : nullptr, TR ? nullptr : Vs, LDT, lane);   // V
     stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, nullptr, LDT, lane);
-    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane);
+    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ms + Tp * EP));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, km, cscale);  // s := P^T
+        masked_softmax<NT>(s, km, cscale, lane);  // s := P^T
         // ---- H^T[u][q] = sum_k T_[k][u] P[q][k] -----------------------------------------------
         Frag4<T> pf[NT];
 #pragma unroll
@@ -184,7 +185,8 @@ template <typename T, int DT, int NT, int EC>
 int launch_fwd_e(FwdP p, hipStream_t st) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     const PackDims pd = pack_dims<T>(dh, p.E);
-    const size_t wave_bytes = ((size_t)Tp * dh + 2 * (sizeof(T) == 2 ? (size_t)Tp * dh : (size_t)dh * LDT) + (size_t)Tp * EP) * sizeof(T);
+    const size_t wave_bytes = ((size_t)Tp * dh + 2 * (sizeof(T) == 2 ? (size_t)Tp * dh : (size_t)dh * LDT) + (size_t)Tp * EP) * sizeof(T) +
+                              (size_t)Tp * sizeof(float);
     int waves = 4;
     while (waves > 1 && pd.bytes + waves * wave_bytes > 80 * 1024) waves >>= 1;
     const size_t smem = pd.bytes + waves * wave_bytes;
