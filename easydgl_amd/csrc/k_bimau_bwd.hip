@@ -15,7 +15,7 @@
 namespace {
 using namespace bimau;
 
-constexpr int KB_BLOCKS = 256;  // workgroups of kernel B (each 4 waves)
+constexpr int KB_BLOCKS = 192;  // workgroups of kernel B per mark group (x4 groups = 768 = 3 resident per CU: one full wave of WGs)
 
 struct BwdP {
     const void* qkvt; const int64_t* ids; const float* spans; const uint8_t* marks; const char* pack;
@@ -369,7 +369,7 @@ struct WgP {
 template <typename T, int DT>
 __global__ __launch_bounds__(256) void intensity_wgrad_kernel(WgP p) {
     constexpr int dh = 16 * DT;
-    constexpr int ECH = 16 / (DT * DT);  // marks per workgroup row (gridDim.y = 16/ECH)
+    constexpr int ECH = 4;  // marks per workgroup row (gridDim.y = 16/ECH): 4*DT*DT accumulator tiles per wave
     const int e0 = blockIdx.y * ECH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PackDims pd = pack_dims<T>(dh, p.E);
@@ -389,7 +389,10 @@ __global__ __launch_bounds__(256) void intensity_wgrad_kernel(WgP p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const Frag4<T> ident = identity_frag<T>(lane);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const long ntile = (p.R + 15) / 16;
+    // row tiles follow kernel A's (b', query tile) split: 16 consecutive queries of ONE b' = head*B + b, so the
+    // interval of a row needs no per-row division
+    const int ntq = (p.T + 15) / 16;
+    const int ntile = (int)(p.R / p.T) * ntq;
     const T* hin = reinterpret_cast<const T*>(p.hin_ws);
 
     f32x4 dW[ECH][DT][DT];  // [e-e0][d][ub]: tile (j-tile = e*DT+d, u-tile = ub), L(first=j, second=u)
@@ -403,26 +406,24 @@ __global__ __launch_bounds__(256) void intensity_wgrad_kernel(WgP p) {
             for (int ub = 0; ub < DT; ++ub) dW[e][d][ub] = zero4;
         }
 
-    for (long rt = (long)blockIdx.x * 4 + wave; rt < ntile; rt += (long)gridDim.x * 4) {
-        const long rowA = rt * 16 + l15;  // row on the lane axis (A operand)
+    for (int t = (int)blockIdx.x * 4 + wave; t < ntile; t += (int)gridDim.x * 4) {
+        const int bpq = t / ntq, qt = t - bpq * ntq, bb = bpq % p.B;
+        const long row0 = (long)bpq * p.T + qt * 16;
+        const bool okA = qt * 16 + l15 < p.T;   // row on the lane axis (A operand)
         Frag4<T> hA[DT], hB[DT];
 #pragma unroll
         for (int ub = 0; ub < DT; ++ub) {
-            hA[ub] = rowA < p.R ? frag_ld<T>(hin + rowA * dh + ub * 16 + g4) : frag_zero<T>();
+            hA[ub] = okA ? frag_ld<T>(hin + (row0 + l15) * dh + ub * 16 + g4) : frag_zero<T>();
             hB[ub] = frag_from_acc<T>(mma16(hA[ub], ident, zero4));  // L(first=row, second=u)
         }
         float spn[4];
-        long rr[4];
+        float4 dz4[4];   // dz[row g4+r][e0 .. e0+3]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            rr[r] = rt * 16 + g4 + r;
-            if (rr[r] < p.R) {
-                const long bpq = rr[r] / p.T;      // b' = head*B + b
-                const int q = (int)(rr[r] % p.T), bb = (int)(bpq % p.B);
-                spn[r] = p.spans[(long)bb * p.T + q];
-            } else {
-                spn[r] = 0.f;
-            }
+            const int qq = qt * 16 + g4 + r;
+            const bool ok = qq < p.T;
+            spn[r] = ok ? p.spans[(long)bb * p.T + qq] : 0.f;
+            dz4[r] = ok ? *reinterpret_cast<const float4*>(p.dz_ws + (row0 + g4 + r) * EP + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int ee = 0; ee < ECH; ++ee) {
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(256) void intensity_wgrad_kernel(WgP p) {
             if (e < p.E) {
                 float dzr[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dzr[r] = rr[r] < p.R ? p.dz_ws[rr[r] * EP + e] : 0.f;
+                for (int r = 0; r < 4; ++r) dzr[r] = ee == 0 ? dz4[r].x : ee == 1 ? dz4[r].y : ee == 2 ? dz4[r].z : dz4[r].w;
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
                     const int jt = e * DT + d, j = jt * 16 + l15;
@@ -543,7 +544,7 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     EDGL_REQUIRE(smem_b <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: weight-grad kernel needs %zu B of LDS", smem_b);
     auto kb = intensity_wgrad_kernel<T, DT>;
     hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
-    hipLaunchKernelGGL(kb, dim3(KB_BLOCKS, DT * DT), dim3(256), smem_b, st, wp);
+    hipLaunchKernelGGL(kb, dim3(KB_BLOCKS, 4), dim3(256), smem_b, st, wp);   // gridDim.y = 16 marks / ECH
     EDGL_LAUNCH_CHECK();
     if (db1 == dW1 + (dh + 1) * JE && dw == db1 + JE && dscaling == dw + JE) {   // flat-arena layout: one reduction
         return edgl_reduce_rows(p.wpart, KB_BLOCKS, NPAR + p.E, NPARX, dW1, 0, st);
