@@ -142,36 +142,34 @@ __device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>
 // reduce-scatter of 16 per-lane partials over the 4 lane groups: on return lane group g holds the
 // complete sums for e = 4g + i (i = 0..3) — exactly the MFMA B-operand layout lambda^T[e][q].
 __device__ __forceinline__ void reduce_scatter16(const float (&z)[16], float (&out)[4], int lane) {
-    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0;
+    (void)lane;
     float y[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float send = b5 ? z[i] : z[i + 8];
-        const float keep = b5 ? z[i + 8] : z[i];
-        y[i] = keep + __shfl_xor(send, 32, 64);
+    for (int i = 0; i < 8; ++i) {   // lanes < 32 end with index i, lanes >= 32 with index i + 8
+        const FPair p = swap32(z[i], z[i + 8]);
+        y[i] = p.first + p.second;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float send = b4 ? y[i] : y[i + 4];
-        const float keep = b4 ? y[i + 4] : y[i];
-        out[i] = keep + __shfl_xor(send, 16, 64);
+    for (int i = 0; i < 4; ++i) {   // even rows end with index i, odd rows with index i + 4 (of their half)
+        const FPair p = swap16(y[i], y[i + 4]);
+        out[i] = p.first + p.second;
     }
 }
 // inverse: every lane ends with all 16 values (value for e = 4g+i lives in lane group g)
 __device__ __forceinline__ void all_gather16(const float (&in)[4], float (&out)[16], int lane) {
-    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0;
+    (void)lane;
     float y[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float other = __shfl_xor(in[i], 16, 64);
-        y[i] = b4 ? other : in[i];
-        y[i + 4] = b4 ? in[i] : other;
+        const FPair p = swap16(in[i], in[i]);
+        y[i] = p.first;        // the even row's value (e = 8*half + i)
+        y[i + 4] = p.second;   // the odd row's value  (e = 8*half + 4 + i)
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float other = __shfl_xor(y[i], 32, 64);
-        out[i] = b5 ? other : y[i];
-        out[i + 8] = b5 ? y[i] : other;
+        const FPair p = swap32(y[i], y[i]);
+        out[i] = p.first;      // lower half's value
+        out[i + 8] = p.second; // upper half's value
     }
 }
 

@@ -105,6 +105,10 @@ __device__ __forceinline__ f32x4 mma_kblock(const Vec16<bf16>& a, const Vec16<bf
                                                    *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
 }
 
+// Scheduling fence: memory operations stay on their side at the IR level (asm memory clobber) and the machine scheduler
+// moves nothing across (sched_barrier).  Used to keep hand-placed operand prefetches where they were written.
+#define EDGL_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
 // 4-element (K=16) fragments used by the attention kernels: lane holds k=(l>>4)*4+j, j=0..3.
 template <typename T> struct Frag4;
 template <> struct Frag4<float> { float v[4]; };
@@ -156,15 +160,33 @@ template <typename T> __device__ __forceinline__ Frag4<T> frag_zero() {
 
 
 // ---- helpers on the MFMA register layout L(first,second): reg r of lane l = X[(l>>4)*4+r][l&15] ----
+// Row exchanges of a wave (rows = 16 lanes) without LDS traffic: gfx950's v_permlane16_swap / v_permlane32_swap
+// (semantics measured by tools/probe_swap.hip).  With rows r0..r3 of a and b:
+//   swap16(a, b): first = {a.r0, b.r0, a.r2, b.r2}, second = {a.r1, b.r1, a.r3, b.r3}
+//   swap32(a, b): first = {a.r0, a.r1, b.r0, b.r1}, second = {a.r2, a.r3, b.r2, b.r3}
+// Written as inline asm: hipcc 7.2 mis-selects the second result of __builtin_amdgcn_permlane*_swap when both results
+// feed one expression (it emits first + first).  The leading s_nop covers the VALU-write -> permlane-read wait states
+// the compiler would otherwise insert.
+struct FPair { float first, second; };
+__device__ __forceinline__ FPair swap16(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return FPair{a, b};
+}
+__device__ __forceinline__ FPair swap32(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return FPair{a, b};
+}
 __device__ __forceinline__ float group_sum4(float v) {  // sum over the 4 lane groups (same lane&15)
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    const FPair p = swap16(v, v);        // {r0,r0,r2,r2} , {r1,r1,r3,r3}
+    const float t = p.first + p.second;  // pair sums, in both rows of the pair
+    const FPair q = swap32(t, t);
+    return q.first + q.second;
 }
 __device__ __forceinline__ float group_max4(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    const FPair p = swap16(v, v);
+    const float t = fmaxf(p.first, p.second);
+    const FPair q = swap32(t, t);
+    return fmaxf(q.first, q.second);
 }
 template <typename T>
 __device__ __forceinline__ Frag4<T> identity_frag(int lane) {

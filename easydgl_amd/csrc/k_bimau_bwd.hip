@@ -11,6 +11,18 @@
 #ifndef EDGL_BWD_OCC
 #define EDGL_BWD_OCC
 #endif
+// -DEDGL_PHASE_TIMING builds a diagnostic variant: every wave accumulates s_memtime deltas per phase of the query loop
+// and lane 0 adds them to g_phase_cycles (read back with edgl_debug_phase_cycles).  Not part of the product build.
+#ifdef EDGL_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[16];
+#define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PH_FLUSH() do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phase_cycles[i_], ph_acc[i_]); } while (0)
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_FLUSH()
+#endif
 
 namespace {
 using namespace bimau;
@@ -95,19 +107,38 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) { dKa[u][kt] = zero4; dVa[u][kt] = zero4; dTa[u][kt] = zero4; }
     float dsc_acc[4] = {0.f, 0.f, 0.f, 0.f};
+    PH_DECL
+    PH_MARK(0);   // staging
 
+    // per-query-tile global operands (Q rows, dO rows, interval, upstream d lambda) are fetched one tile ahead so that
+    // their HBM/L2 latency overlaps the previous tile's work
+    struct QOps { Frag4<T> qf[DT], dof[DT]; float span, dlx[4]; };
+    auto load_q = [&](int qt) {
+        QOps o;
+        const int q = qt * 16 + l15;
+        const bool ok = q < p.T;
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) {
+            o.qf[ub] = ok ? frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4) : frag_zero<T>();
+            o.dof[ub] = ok ? frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4) : frag_zero<T>();
+        }
+        o.span = ok ? p.spans[(long)b * p.T + q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o.dlx[i] = (p.d_lam_ext && ok && (g4 + i) < E) ? p.d_lam_ext[(bp * p.T + q) * E + g4 + i] : 0.f;
+        return o;
+    };
+    QOps qcur = load_q(0);
     for (int qt = 0; qt < NT; ++qt) {
         // compiler-level memory barrier: without it every loop-invariant LDS operand (intensity weights, key mask) is
         // hoisted out of the query loop and parked in ~190 extra registers
         asm volatile("" ::: "memory");
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
+        const QOps qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
         Frag4<T> qf[DT], dof[DT];
 #pragma unroll
-        for (int ub = 0; ub < DT; ++ub) {
-            qf[ub] = qok ? frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4) : frag_zero<T>();
-            dof[ub] = qok ? frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4) : frag_zero<T>();
-        }
+        for (int ub = 0; ub < DT; ++ub) { qf[ub] = qcur.qf[ub]; dof[ub] = qcur.dof[ub]; }
         // ---- recompute S, P ---------------------------------------------------------------------
         f32x4 s[NT];
 #pragma unroll
@@ -119,6 +150,7 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
             s[kt] = a;
         }
         masked_softmax<NT>(s, km, cscale, lane);  // s = P^T, L(first=k, second=q)
+        PH_MARK(1);   // q loads + S + softmax
         // From here on P lives in the activation dtype only (bf16: 2 registers per key tile instead of 4).  That is
         // the precision the forward pass used for P.T_ and A'.V anyway.
         Frag4<T> pf[NT];
@@ -144,7 +176,8 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
                 }
             }
         }
-        const float span = qok ? p.spans[(long)b * p.T + q] : 0.f;
+        PH_MARK(2);   // H
+        const float span = qcur.span;
         // zq[e][d] = wv[j] * z (1 - z) for channel j = e*dh + d*16 + g4 + r (z = sigmoid output): all the du step needs.
         // Kept in the activation dtype (bf16: 2 registers per tile instead of 4).
         Frag4<T> zq[16][DT];
@@ -182,8 +215,9 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
                     zq[e][d] = frag_from_acc<T>(zw);
                 }
             }
-            if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // at most two marks' operand loads in flight
+            if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most four marks' operand loads in flight
         }
+        PH_MARK(3);   // intensity MLP
         float z4[4], lam4[4], sg4[4];
         reduce_scatter16(zp, z4, lane);
         Frag4<T> lf;
@@ -200,6 +234,7 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
         Frag4<T> dOT[DT];  // L(first=q, second=v): A operand contracting over q
 #pragma unroll
         for (int vt = 0; vt < DT; ++vt) dOT[vt] = frag_from_acc<T>(mma16(dof[vt], ident, zero4));
+        PH_MARK(4);   // lambda, dOT
         Frag4<T> d1f[NT];     // dP through A' (dA * D * G'), activation dtype
         float rowdot = 0.f;   // sum_k dP[q][k] P[q][k]: this lane's part of  sum_k d1 * P
         f32x4 dlamT = zero4;  // L(first=e, second=q)
@@ -243,15 +278,16 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
             const Frag4<T> apT = frag_from_acc<T>(transpose_tile<T>(ap, ident));  // L(first=q, second=k)
 #pragma unroll
             for (int vt = 0; vt < DT; ++vt) dVa[vt][kt] = mma16(dOT[vt], apT, dVa[vt][kt]);
-            if (kt & 1) __builtin_amdgcn_sched_barrier(0);   // bound the live ranges: at most two key tiles interleaved
+            if (kt == 3) __builtin_amdgcn_sched_barrier(0);   // bound the live ranges: at most four key tiles interleaved
         }
         __builtin_amdgcn_sched_barrier(0);
+        PH_MARK(5);   // G / dA / dV sweep
         // ---- dlambda -> dz, dscaling ---------------------------------------------------------------
         float dz4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float dl = dlamT[i];
-            if (p.d_lam_ext && qok && (g4 + i) < E) dl += p.d_lam_ext[(bp * p.T + q) * E + g4 + i];
+            dl += qcur.dlx[i];   // upstream d lambda (0 when absent / padded)
             dz4[i] = dl * sg4[i];
             if (qok && (g4 + i) < E) dsc_acc[i] += dl * (lam4[i] - z4[i] * sg4[i]);
         }
@@ -259,6 +295,7 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
         float dz16[16];
         all_gather16(dz4, dz16, lane);
         __builtin_amdgcn_sched_barrier(0);
+        PH_MARK(6);   // dz
         // ---- du -> dH^T[u][q] = sum_j W1[u][j] du[q][j] -----------------------------------------------
         f32x4 dH[DT];
 #pragma unroll
@@ -279,9 +316,10 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
                         dH[ut] = mma16(frag_ld<T>(W1R + (ut * 16 + l15) * pd.LDR + jt * 16 + g4), duf, dH[ut]);
                 }
             }
-            if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            if ((e & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        PH_MARK(7);   // du / dH
         // ---- dP = d1 + dH.T_^T ; dS = P*(dP - rowsum(dP*P)) * c -----------------------------------------
         // rowsum(dP*P) = sum_k d1*P + sum_k P[q][k] (dH[q].T_[k]) = sum_k d1*P + dH[q].H[q]   (H = P.T_), so the row
         // term is known before the key sweep and dP never has to be kept for all key tiles.
@@ -330,12 +368,14 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
                 dKa[ut][kt] = mma16(QT[ut], dsT, dKa[ut][kt]);
                 dTa[ut][kt] = mma16(dHT[ut], pT, dTa[ut][kt]);
             }
-            if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+            if (kt == 3) __builtin_amdgcn_sched_barrier(0);
         }
         if (qok) {
 #pragma unroll
             for (int ut = 0; ut < DT; ++ut) st_frag<T>(dqkvt + (long)q * ldq + head * dh + ut * 16 + g4, dQ[ut]);
         }
+        PH_MARK(8);   // dS sweep, dQ, dK, dT
+        qcur = qnext;
     }
     // ---- write dK / dV / dT_ (L(first=u, second=k): 4 consecutive channels of key row k) ----------
 #pragma unroll
@@ -351,6 +391,8 @@ __global__ __launch_bounds__(256) EDGL_BWD_OCC void bimau_bwd_kernel(BwdP p) {
             }
         }
     }
+    PH_MARK(9);   // epilogue stores
+    PH_FLUSH();
     // ---- dscaling partial: sum over the 16 query lanes -----------------------------------------
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -614,3 +656,14 @@ extern "C" int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float*
     edgl_set_error("edgl_bimau_bwd: head dim %d not supported (16 or 32)", dh);
     return EDGL_ERR_SHAPE;
 }
+
+#ifdef EDGL_PHASE_TIMING
+extern "C" int edgl_debug_phase_cycles(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

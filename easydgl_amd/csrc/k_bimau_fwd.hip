@@ -65,14 +65,31 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
 
+    // per-query-tile global operands (Q rows, interval, residual rows) are fetched one tile ahead: their HBM/L2 latency
+    // overlaps the previous tile's compute instead of opening every iteration with a stall
+    struct QOps { Frag4<T> qf[DT], rf[DT]; float span; };
+    auto load_q = [&](int qt) {
+        QOps o;
+        const int q = qt * 16 + l15;
+        const bool ok = q < p.T;
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) {
+            o.qf[ub] = ok ? frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4) : frag_zero<T>();
+            o.rf[ub] = ok ? frag_ld<T>(reinterpret_cast<const T*>(p.resid) + ((long)b * p.T + q) * p.ld_res + head * dh + ub * 16 + g4)
+                          : frag_zero<T>();
+        }
+        o.span = ok ? p.spans[(long)b * p.T + q] : 0.f;
+        return o;
+    };
+    QOps qcur = load_q(0);
     for (int qt = 0; qt < NT; ++qt) {
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
+        const QOps qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
         // ---- S^T[k][q] = sum_u K[k][u] Q[q][u] ------------------------------------------------
         Frag4<T> qf[DT];
 #pragma unroll
-        for (int ub = 0; ub < DT; ++ub)
-            qf[ub] = qok ? frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4) : frag_zero<T>();
+        for (int ub = 0; ub < DT; ++ub) qf[ub] = qcur.qf[ub];
         f32x4 s[NT];
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
@@ -97,28 +114,43 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
             hf[ut] = frag_from_acc<T>(a);
         }
         // ---- intensity MLP (temporal.py:287-306): Zpre^T[j][q], channel j = e*dh + u' ------------
-        const float span = qok ? p.spans[(long)b * p.T + q] : 0.f;
+        const float span = qcur.span;
         float zp[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) zp[e] = 0.f;
+        // operands of channel tile jt: W1T rows (A operand), interval weight, bias, output weight.  The tile after the
+        // one being computed is always in flight (explicit double buffer: the LDS latency hides behind one tile of
+        // MFMA + sigmoid work instead of stalling every tile).
+        struct MlpOps { Frag4<T> w[DT]; float4 ws, bs, wv; };
+        auto load_ops = [&](int jt) {
+            MlpOps o;
+#pragma unroll
+            for (int ub = 0; ub < DT; ++ub) o.w[ub] = frag_ld<T>(W1T + (jt * 16 + l15) * pd.LDW + ub * 16 + g4);
+            o.ws = *reinterpret_cast<const float4*>(w1s + jt * 16 + g4);
+            o.bs = *reinterpret_cast<const float4*>(b1s + jt * 16 + g4);
+            o.wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
+            return o;
+        };
+        MlpOps cur = load_ops(0);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             if (EC == 16 || e < E) {
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
                     const int jt = e * DT + d;
+                    const MlpOps nxt = load_ops(jt + 1 < E * DT ? jt + 1 : jt);
+                    EDGL_PIN();   // keep the prefetch at the top of this tile's work
                     f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ub = 0; ub < DT; ++ub)
-                        a = mma16(frag_ld<T>(W1T + (jt * 16 + l15) * pd.LDW + ub * 16 + g4), hf[ub], a);
-                    const float4 ws = *reinterpret_cast<const float4*>(w1s + jt * 16 + g4);
-                    const float4 bs = *reinterpret_cast<const float4*>(b1s + jt * 16 + g4);
-                    const float4 wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
-                    zp[e] += sigmoid_pre(a[0] + fmaf(span, ws.x, bs.x)) * wv.x + sigmoid_pre(a[1] + fmaf(span, ws.y, bs.y)) * wv.y +
-                             sigmoid_pre(a[2] + fmaf(span, ws.z, bs.z)) * wv.z + sigmoid_pre(a[3] + fmaf(span, ws.w, bs.w)) * wv.w;
+                    for (int ub = 0; ub < DT; ++ub) a = mma16(cur.w[ub], hf[ub], a);
+                    // (span*ws + a) + bs: chained on the MFMA result so that nothing of this tile can be hoisted into the
+                    // prefetch slot above (which would wait on the loads just issued)
+                    zp[e] += sigmoid_pre(fmaf(span, cur.ws.x, a[0]) + cur.bs.x) * cur.wv.x + sigmoid_pre(fmaf(span, cur.ws.y, a[1]) + cur.bs.y) * cur.wv.y +
+                             sigmoid_pre(fmaf(span, cur.ws.z, a[2]) + cur.bs.z) * cur.wv.z + sigmoid_pre(fmaf(span, cur.ws.w, a[3]) + cur.bs.w) * cur.wv.w;
+                    cur = nxt;
+                    EDGL_PIN();
                 }
             }
-            if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // keep the operand loads of at most two marks in flight
         }
         float z4[4];
         reduce_scatter16(zp, z4, lane);  // lane group g now owns e = 4g + i
@@ -169,7 +201,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                 a = mma16(kfrag<T>(Vs, dh, Vs, LDT, kt * 16, vt * 16, lane), pf[kt], a);
             if (qok) {
                 const int col = head * dh + vt * 16 + g4;
-                const Frag4<T> rf = frag_ld<T>(reinterpret_cast<const T*>(p.resid) + ((long)b * p.T + q) * p.ld_res + col);
+                const Frag4<T> rf = qcur.rf[vt];
                 Frag4<T> of;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) of.v[r] = from_f32<T>(a[r] + to_f32(rf.v[r]));
@@ -178,6 +210,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                 else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&of);
             }
         }
+        qcur = qnext;
     }
 }
 

@@ -1,0 +1,45 @@
+"""Diagnostic: per-phase wave cycles of the BiMAU backward kernel (needs a library built with -DEDGL_PHASE_TIMING, see
+k_bimau_bwd.hip).  python tools/phase_probe.py path/to/lib_phase.so"""
+import ctypes
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1:
+    shutil.copy(sys.argv[1], os.path.join(ROOT, "easydgl_amd", "libeasydgl_hip.so"))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from easydgl_amd import _lib  # noqa: E402
+from easydgl_amd.engine import TrainEngine  # noqa: E402
+
+NAMES = ["staging", "q loads+S+softmax", "H", "intensity MLP", "lambda,dOT", "G/dA/dV sweep", "dz", "du/dH",
+         "dS sweep,dQ,dK,dT", "epilogue"]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    cfg = dict(bench.HEADLINE)
+    model, feats, labels = bench.make_model_and_batch(cfg, "bf16", dev, seed=1)
+    eng = TrainEngine(model, cfg["batch"], use_graph=False)
+    eng.load_batch(feats, labels)
+    for _ in range(3):
+        eng.step()
+    torch.cuda.synchronize()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    buf = (ctypes.c_ulonglong * 16)()
+    raw.edgl_debug_phase_cycles(buf, 1)
+    n = 5
+    for _ in range(n):
+        eng.step()
+    torch.cuda.synchronize()
+    raw.edgl_debug_phase_cycles(buf, 0)
+    jobs = cfg["batch"] * cfg["num_heads"]
+    tot = sum(buf[:10])
+    for i, nm in enumerate(NAMES):
+        print(f"{nm:22s} {buf[i] / n / jobs:12.0f} cyc/job  {100.0 * buf[i] / tot:5.1f}%")
+    print(f"total {tot / n / jobs:.0f} cycles per (b, head) job")
+
+
+main()
