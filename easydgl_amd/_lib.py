@@ -31,9 +31,10 @@ SIGNATURES = {
     "edgl_gemm_dw": (I, [P, P, P, P, I, I, I, I, I, I, P, I, P]),
     "edgl_bimau_pack_bytes": (L, [I, I, I, I]),
     "edgl_bimau_pack": (I, [P, P, P, P, I, I, I, P, I, P]),
-    "edgl_bimau_fwd": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, I, P]),
+    "edgl_bimau_saved_bytes": (L, [I, I, I, I, I]),
+    "edgl_bimau_fwd": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, I, P]),
     "edgl_bimau_bwd_workspace": (L, [I, I, I, I, I, I]),
-    "edgl_bimau_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, I, P]),
+    "edgl_bimau_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, I, P]),
     "edgl_add_layernorm_fwd": (I, [P, P, I, P, P, I, I, I, F, P, U32, P, I, P, P, I, P]),
     "edgl_add_layernorm_bwd": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, P, I, P]),
     "edgl_score_chunks": (I, [I, I]),

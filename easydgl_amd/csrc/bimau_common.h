@@ -48,6 +48,18 @@ __host__ __device__ inline PackDims pack_dims(int dh, int E) {
     return d;
 }
 
+// Activations the forward keeps for the backward (one buffer): H rows [H*B*T, dh] in the activation dtype (input of the
+// intensity MLP) followed by z [H*B*T, 16] f32 (MLP output before scaling/softplus).
+struct SavedLayout { size_t off_hin, off_z, bytes; };
+inline SavedLayout saved_layout(int B, int T, int C, int H, size_t esize) {
+    const size_t R = (size_t)B * H * T, dh = (size_t)(C / H);
+    SavedLayout s;
+    s.off_hin = 0;
+    s.off_z = (R * dh * esize + 255) & ~(size_t)255;
+    s.bytes = s.off_z + R * EP * sizeof(float);
+    return s;
+}
+
 template <typename T>
 __global__ void pack_kernel(const float* W1, const float* b1, const float* w, const float* scaling, int dh, int E,
                             char* pack) {

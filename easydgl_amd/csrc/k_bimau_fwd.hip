@@ -12,6 +12,7 @@ struct FwdP {
     int B, T, C, H, E;
     float rate; const uint64_t* rng; uint32_t stream_id;
     void* out; float* lam;
+    void* hin_out; float* z_out;   // saved for the backward (NULL: inference)
     int waves;
 };
 
@@ -112,6 +113,11 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
             for (int kt = 0; kt < NT; ++kt)
                 a = mma16(kfrag<T>(Ts, dh, Ts, LDT, kt * 16, ut * 16, lane), pf[kt], a);
             hf[ut] = frag_from_acc<T>(a);
+            if (p.hin_out && qok) {   // H rows in the activation dtype: exactly what the intensity MLP consumed
+                T* dst = reinterpret_cast<T*>(p.hin_out) + (bp * p.T + q) * dh + ut * 16 + g4;
+                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&hf[ut]);
+                else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&hf[ut]);
+            }
         }
         // ---- intensity MLP (temporal.py:287-306): Zpre^T[j][q], channel j = e*dh + u' ------------
         const float span = qcur.span;
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
         }
         float z4[4];
         reduce_scatter16(zp, z4, lane);  // lane group g now owns e = 4g + i
+        if (p.z_out && qok) *reinterpret_cast<float4*>(p.z_out + (bp * p.T + q) * EP + g4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
         Frag4<T> lf;
         float lam4[4];
 #pragma unroll
@@ -272,6 +279,11 @@ extern "C" long edgl_bimau_pack_bytes(int C, int H, int E, int dtype) {
     return (long)(dtype == EDGL_BF16 ? bimau::pack_dims<bf16>(dh, E).bytes : bimau::pack_dims<float>(dh, E).bytes);
 }
 
+extern "C" long edgl_bimau_saved_bytes(int B, int T, int C, int H, int dtype) {
+    if (H <= 0 || C % H) return -1;
+    return (long)bimau::saved_layout(B, T, C, H, dtype == EDGL_BF16 ? 2 : 4).bytes;
+}
+
 extern "C" int edgl_bimau_pack(const float* W1, const float* b1, const float* w, const float* scaling, int C, int H,
                                int E, void* pack, int dtype, void* stream) {
     EDGL_REQUIRE(W1 && b1 && w && scaling && pack, EDGL_ERR_NULL, "edgl_bimau_pack: null pointer");
@@ -288,7 +300,7 @@ extern "C" int edgl_bimau_pack(const float* W1, const float* b1, const float* w,
 extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
                               const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
                               float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* out,
-                              float* lam_out, int dtype, void* stream) {
+                              float* lam_out, void* saved, int dtype, void* stream) {
     EDGL_REQUIRE(qkvt && resid && ids && spans && marks && pack && out && lam_out, EDGL_ERR_NULL,
                  "edgl_bimau_fwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
@@ -297,7 +309,12 @@ extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, c
     EDGL_REQUIRE(ld_res % 4 == 0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: ld_res must be a multiple of 4");
     EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: H*B*T*T must be < 2^32");
     FwdP p{qkvt, resid, ld_res, ids, spans, marks, (const char*)pack, B, T, C, H, E, drop_rate, rng_state, stream_id,
-           out, lam_out, 4};
+           out, lam_out, nullptr, nullptr, 4};
+    if (saved) {   // [H*B*T, dh] activation dtype | [H*B*T, 16] f32 (pre-softplus z)
+        const bimau::SavedLayout sl = bimau::saved_layout(B, T, C, H, dtype == EDGL_BF16 ? 2 : 4);
+        p.hin_out = (char*)saved + sl.off_hin;
+        p.z_out = reinterpret_cast<float*>((char*)saved + sl.off_z);
+    }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EDGL_F32) return dispatch_dt<float>(p, st);
     if (dtype == EDGL_BF16) return dispatch_dt<bf16>(p, st);

@@ -58,6 +58,7 @@ class TrainEngine:
                      st1=e(B, 2, dtype=f32), pre_f=e(B, T, 2 * C), f=e(B, T, 2 * C), o=e(B, T, C), y=e(B, T, C),
                      st2=e(B, 2, dtype=f32),
                      pack=e(lib.edgl_bimau_pack_bytes(C, H, E, self.code), dtype=torch.uint8),
+                     saved=e(lib.edgl_bimau_saved_bytes(B, T, C, H, self.code), dtype=torch.uint8),
                      dlam=e(H * B, T, E, dtype=f32), tpp=e(lib.edgl_tpp_workspace(), dtype=f32))
             self.blk.append(d)
         self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
@@ -143,7 +144,7 @@ class TrainEngine:
             da = drop(ad, 10 + 4 * i)
             check(lib.edgl_bimau_fwd(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
                                      _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
-                                     _ptr(b["lam"]), code, st), "edgl_bimau_fwd")
+                                     _ptr(b["lam"]), _ptr(b["saved"]), code, st), "edgl_bimau_fwd")
             self._dense_fwd(b["att"], blk.att_out.kernel, blk.att_out.bias, b["ao"], C, C)
             self._ln_fwd(b["ao"], x, cin, blk.att_ln, drop(hd, 11 + 4 * i), b["a1"], b["st1"])
             self._dense_fwd(b["a1"], blk.inter.kernel, blk.inter.bias, b["f"], C, 2 * C, gelu=True, pre=b["pre_f"])
@@ -209,7 +210,8 @@ class TrainEngine:
             att = blk.attention
             da = drop(ad, 10 + 4 * i)
             check(lib.edgl_bimau_bwd(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
-                                     _ptr(self.G2), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, B, T, C, H, E,
+                                     _ptr(self.G2), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, _ptr(b["lam"]),
+                                     _ptr(b["saved"]), B, T, C, H, E,
                                      float(da.rate), da.ptr(), da.stream_id, _ptr(self.G4c), _ptr(att.st_kernel.grad),
                                      _ptr(att.st_bias.grad), _ptr(att.weight.grad), _ptr(att.scaling.grad),
                                      _ptr(self.ws_bimau), code, st), "edgl_bimau_bwd")

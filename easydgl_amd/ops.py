@@ -200,16 +200,19 @@ class BiMAUFn(torch.autograd.Function):
         lam = torch.empty((H * B, T, E), device=qkvt.device, dtype=torch.float32)
         if resid.stride(-1) != 1 or resid.stride(0) != T * resid.stride(1):
             raise _lib.EdglError("BiMAU residual must be a row-strided view of a contiguous [B,T,*] tensor")
+        need_grad = any(ctx.needs_input_grad)
+        saved = torch.empty(lib.edgl_bimau_saved_bytes(B, T, C, H, code), device=qkvt.device, dtype=torch.uint8) if need_grad else None
         check(lib.edgl_bimau_fwd(_ptr(qkvt), resid.data_ptr(), resid.stride(1), _ptr(ids), _ptr(spans), _ptr(marks),
                                  _ptr(pack), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(out),
-                                 _ptr(lam), code, _stream()), "edgl_bimau_fwd")
-        ctx.save_for_backward(qkvt, ids, spans, marks, pack)
+                                 _ptr(lam), _ptr(saved), code, _stream()), "edgl_bimau_fwd")
+        if need_grad:
+            ctx.save_for_backward(qkvt, ids, spans, marks, pack, lam, saved)
         ctx.meta = (B, T, C, H, E, drop, code, W1.shape, b1.shape, w.shape, scaling.shape)
         return out, lam
 
     @staticmethod
     def backward(ctx, d_out, d_lam):
-        qkvt, ids, spans, marks, pack = ctx.saved_tensors
+        qkvt, ids, spans, marks, pack, lam, saved = ctx.saved_tensors
         B, T, C, H, E, drop, code, s1, s2, s3, s4 = ctx.meta
         d_out = d_out.contiguous()
         dev = d_out.device
@@ -221,7 +224,7 @@ class BiMAUFn(torch.autograd.Function):
         ws = torch.empty(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), device=dev, dtype=torch.uint8)
         dl = d_lam.contiguous() if d_lam is not None else None
         check(lib.edgl_bimau_bwd(_ptr(qkvt), _ptr(ids), _ptr(spans), _ptr(marks), _ptr(pack), _ptr(d_out), _ptr(dl),
-                                 B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(d_qkvt), _ptr(dW1),
+                                 _ptr(lam), _ptr(saved), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(d_qkvt), _ptr(dW1),
                                  _ptr(db1), _ptr(dw), _ptr(dsc), _ptr(ws), code, _stream()), "edgl_bimau_bwd")
         return d_qkvt, d_out, dW1, db1, dw, dsc, None, None, None, None, None
 
