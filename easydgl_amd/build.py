@@ -14,6 +14,11 @@ SOURCES = ["k_misc.hip", "k_encode.hip", "k_gemm.hip", "k_gemm2.hip", "k_layerno
            "k_score.hip"]
 HEADERS = ["edgl_common.h", "gemm_tile.h", "bimau_common.h", os.path.join("..", "..", "include", "easydgl_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read/write traffic around every VALU consumer);
+# gfx950's register file is unified, so nothing is lost by not using AGPRs.  Per file: hipcc 7.2 crashes on k_score.hip
+# with it, and the GEMM kernels (pure accumulate-then-store) gain nothing.
+EXTRA_FLAGS = {"k_bimau_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "k_bimau_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -44,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def run(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr[-4000:]))

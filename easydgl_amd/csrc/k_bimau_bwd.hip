@@ -113,35 +113,64 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
         for (int kt = 0; kt < NT; ++kt) dVa[u][kt] = zero4;
     float dsc_acc[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // per-query-tile global operands are fetched one tile ahead
-    struct QOps { Frag4<T> qf[DT], dof[DT]; float lam[4], z[4], dlx[4]; };
+    // Per-query-tile global operands are fetched one tile ahead.  The loads are unconditional (row / mark index clamped)
+    // so that the prefetch is straight-line code: with per-lane branches around them the wait-count insertion falls
+    // back to near-zero counts and every iteration would stall on the loads it has just issued.  Lanes past the end of
+    // the sequence (or marks >= E) are zeroed when the values are consumed.
+    struct QOps { Frag4<T> qf[DT], dof[DT]; float4 z; float lam[4], dlx[4]; };
+    const float* dlx_src = p.d_lam_ext ? p.d_lam_ext : p.lam;   // always a readable [rows, E] array
+    const float dlx_on = p.d_lam_ext ? 1.0f : 0.0f;
     auto load_q = [&](int qt) {
         QOps o;
-        const int q = qt * 16 + l15;
-        const bool ok = q < p.T;
+        const int q = min(qt * 16 + l15, p.T - 1);
         const long row = bp * p.T + q;
 #pragma unroll
         for (int ub = 0; ub < DT; ++ub) {
-            o.qf[ub] = ok ? frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4) : frag_zero<T>();
-            o.dof[ub] = ok ? frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4) : frag_zero<T>();
+            o.qf[ub] = frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4);
+            o.dof[ub] = frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4);
         }
-        const float4 z4 = ok ? *reinterpret_cast<const float4*>(p.z + row * EP + g4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        o.z[0] = z4.x; o.z[1] = z4.y; o.z[2] = z4.z; o.z[3] = z4.w;
+        o.z = *reinterpret_cast<const float4*>(p.z + row * EP + g4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool oke = ok && (EC == 16 || (g4 + i) < E);
-            o.lam[i] = oke ? p.lam[row * E + g4 + i] : 0.f;
-            o.dlx[i] = (p.d_lam_ext && oke) ? p.d_lam_ext[row * E + g4 + i] : 0.f;
+            const int e = EC == 16 ? g4 + i : min(g4 + i, E - 1);
+            o.lam[i] = p.lam[row * E + e];
+            o.dlx[i] = dlx_src[row * E + e];
         }
         return o;
     };
+    // zero what a lane past the sequence end (or a mark >= E) must not contribute
+    auto mask_q = [&](QOps& o, bool ok) {
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub)
+            if (!ok) o.dof[ub] = frag_zero<T>();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool oke = ok && (EC == 16 || (g4 + i) < E);
+            o.lam[i] = oke ? o.lam[i] : 0.f;
+            o.dlx[i] = oke ? o.dlx[i] * dlx_on : 0.f;
+        }
+    };
     PH_DECL
     QOps qcur = load_q(0);
+    // Results of a query tile are stored at the TOP of the next iteration: the loop-carried prefetch makes the compiler
+    // drain vmcnt to 0 on the back edge, and a store issued just before it would expose its full write latency there.
+    float pend_dz[4] = {0.f, 0.f, 0.f, 0.f}, pend_rowdot = 0.f;
+    int pend_q = p.T;   // >= T: nothing pending
+    auto flush_pending = [&]() {
+        if (pend_q < p.T) {
+            *reinterpret_cast<float4*>(p.dz_ws + (bp * p.T + pend_q) * EP + g4) = make_float4(pend_dz[0], pend_dz[1], pend_dz[2], pend_dz[3]);
+            if (lane < 16) p.rowdot_ws[bp * p.T + pend_q] = pend_rowdot;
+        }
+    };
     for (int qt = 0; qt < NT; ++qt) {
         asm volatile("" ::: "memory");   // keep loop-invariant LDS operands from being hoisted into registers
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
+        flush_pending();
         const QOps qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
+        asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
+        mask_q(qcur, qok);
+        const float zq4[4] = {qcur.z.x, qcur.z.y, qcur.z.z, qcur.z.w};
         // ---- recompute S, P --------------------------------------------------------------------------------------
         f32x4 s[NT];
 #pragma unroll
@@ -201,18 +230,18 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float dl = dlamT[i] + qcur.dlx[i];
-            const float sg = sigmoid_f(qcur.z[i] * isc[i]);   // softplus'
+            const float sg = sigmoid_f(zq4[i] * isc[i]);   // softplus'
             dz4[i] = dl * sg;
-            if (qok && (EC == 16 || (g4 + i) < E)) dsc_acc[i] += dl * (qcur.lam[i] - qcur.z[i] * sg);
+            if (qok && (EC == 16 || (g4 + i) < E)) dsc_acc[i] += dl * (qcur.lam[i] - zq4[i] * sg);
         }
-        rowdot = group_sum4(rowdot);
-        if (qok) {
-            *reinterpret_cast<float4*>(p.dz_ws + (bp * p.T + q) * EP + g4) = make_float4(dz4[0], dz4[1], dz4[2], dz4[3]);
-            if (lane < 16) p.rowdot_ws[bp * p.T + q] = rowdot;
-        }
+        pend_rowdot = group_sum4(rowdot);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pend_dz[i] = dz4[i];
+        pend_q = q;
         qcur = qnext;
         PH_MARK(2);
     }
+    flush_pending();
     // ---- write dV (L(first=v, second=k): 4 consecutive channels of key row k) -----------------------------------------
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
@@ -283,39 +312,65 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) { dKa[u][kt] = zero4; dTa[u][kt] = zero4; }
 
-    struct QOps { Frag4<T> qf[DT], dof[DT], hf[DT]; f32x4 dH[DT]; float lam[4], rowdot; };
+    // branch-free one-tile-ahead prefetch (see kernel X); kernel Y's dH partials are summed when consumed
+    struct QOps { Frag4<T> qf[DT], dof[DT], hf[DT]; float4 dHp[DT][KY_NY]; float lam[4], rowdot; };
     auto load_q = [&](int qt) {
         QOps o;
-        const int q = qt * 16 + l15;
-        const bool ok = q < p.T;
+        const int q = min(qt * 16 + l15, p.T - 1);
         const long row = bp * p.T + q;
 #pragma unroll
         for (int ub = 0; ub < DT; ++ub) {
-            o.qf[ub] = ok ? frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4) : frag_zero<T>();
-            o.dof[ub] = ok ? frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4) : frag_zero<T>();
-            o.hf[ub] = ok ? frag_ld<T>(hin + row * dh + ub * 16 + g4) : frag_zero<T>();
-            f32x4 a = zero4;   // dH^T[u][q], L(first=u, second=q): sum of kernel Y's mark-group partials (fixed order)
-            if (ok) {
+            o.qf[ub] = frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4);
+            o.dof[ub] = frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4);
+            o.hf[ub] = frag_ld<T>(hin + row * dh + ub * 16 + g4);
 #pragma unroll
-                for (int y = 0; y < KY_NY; ++y) {
-                    const float4 v = *reinterpret_cast<const float4*>(p.dh_ws + ((long)y * R + row) * dh + ub * 16 + g4);
-                    a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
-                }
-            }
-            o.dH[ub] = a;
+            for (int y = 0; y < KY_NY; ++y)
+                o.dHp[ub][y] = *reinterpret_cast<const float4*>(p.dh_ws + ((long)y * R + row) * dh + ub * 16 + g4);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o.lam[i] = (ok && (EC == 16 || (g4 + i) < E)) ? p.lam[row * E + g4 + i] : 0.f;
-        o.rowdot = ok ? p.rowdot_ws[row] : 0.f;
+        for (int i = 0; i < 4; ++i) o.lam[i] = p.lam[row * E + (EC == 16 ? g4 + i : min(g4 + i, E - 1))];
+        o.rowdot = p.rowdot_ws[row];
         return o;
     };
     PH_DECL
     QOps qcur = load_q(0);
+    // dQ of a query tile is stored at the top of the next iteration (see kernel X: the back edge drains vmcnt)
+    Frag4<T> pend_dq[DT];
+    int pend_q = p.T;
+    auto flush_pending = [&]() {
+        if (pend_q < p.T) {
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) {
+                T* dst = dqkvt + (long)pend_q * ldq + head * dh + ut * 16 + g4;
+                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&pend_dq[ut]);
+                else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&pend_dq[ut]);
+            }
+        }
+    };
+#pragma unroll
+    for (int ut = 0; ut < DT; ++ut) pend_dq[ut] = frag_zero<T>();
     for (int qt = 0; qt < NT; ++qt) {
         asm volatile("" ::: "memory");
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
+        (void)qok;
+        flush_pending();
         const QOps qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
+        asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
+        // consume the tile fetched one iteration ago; rows past the sequence end contribute nothing to dK / dT_
+        f32x4 dHq[DT];   // dH^T[u][q], L(first=u, second=q): sum of the mark-group partials in a fixed order
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) {
+            f32x4 a = zero4;
+#pragma unroll
+            for (int y = 0; y < KY_NY; ++y) {
+                a[0] += qcur.dHp[ub][y].x; a[1] += qcur.dHp[ub][y].y; a[2] += qcur.dHp[ub][y].z; a[3] += qcur.dHp[ub][y].w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dHq[ub][r] = qok ? a[r] : 0.f;
+            if (!qok) qcur.dof[ub] = frag_zero<T>();
+        }
+        const float rowdot1 = qok ? qcur.rowdot : 0.f;
         // ---- recompute S, P --------------------------------------------------------------------------------------
         f32x4 s[NT];
 #pragma unroll
@@ -330,19 +385,19 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         PH_MARK(0);
         Frag4<T> lf;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lf.v[i] = from_f32<T>(qcur.lam[i]);
+        for (int i = 0; i < 4; ++i) lf.v[i] = from_f32<T>((EC == 16 || (g4 + i) < E) ? qcur.lam[i] : 0.f);
         // rowsum(dP*P) = sum_k dP1*P (kernel X) + sum_k P[q][k] (dH[q].T_[k]) = ... + dH[q].H[q]   (H = P.T_, saved)
         float rowdot = 0.f;
         Frag4<T> dhf[DT], QT[DT], dHT[DT];
 #pragma unroll
         for (int ut = 0; ut < DT; ++ut) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rowdot = fmaf(qcur.dH[ut][r], to_f32(qcur.hf[ut].v[r]), rowdot);
-            dhf[ut] = frag_from_acc<T>(qcur.dH[ut]);
+            for (int r = 0; r < 4; ++r) rowdot = fmaf(dHq[ut][r], to_f32(qcur.hf[ut].v[r]), rowdot);
+            dhf[ut] = frag_from_acc<T>(dHq[ut]);
             QT[ut] = frag_from_acc<T>(mma16(qcur.qf[ut], ident, zero4));            // L(first=q, second=u)
-            dHT[ut] = frag_from_acc<T>(transpose_tile<T>(qcur.dH[ut], ident));
+            dHT[ut] = frag_from_acc<T>(transpose_tile<T>(dHq[ut], ident));
         }
-        rowdot = group_sum4(rowdot) + qcur.rowdot;
+        rowdot = group_sum4(rowdot) + rowdot1;
         // ---- dP = dP1 + dH.T_^T ; dS = P*(dP - rowsum(dP*P)) * c ; dQ, dK, dT_ -------------------------------------
         f32x4 dQ[DT];
 #pragma unroll
@@ -388,13 +443,13 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
                 dTa[ut][kt] = mma16(dHT[ut], pT, dTa[ut][kt]);
             }
         }
-        if (qok) {
 #pragma unroll
-            for (int ut = 0; ut < DT; ++ut) st_frag<T>(dqkvt + (long)q * ldq + head * dh + ut * 16 + g4, dQ[ut]);
-        }
+        for (int ut = 0; ut < DT; ++ut) pend_dq[ut] = frag_from_acc<T>(dQ[ut]);
+        pend_q = q;
         qcur = qnext;
         PH_MARK(1);
     }
+    flush_pending();
     // ---- write dK / dT_ (L(first=u, second=k): 4 consecutive channels of key row k) ----------------------------------
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {

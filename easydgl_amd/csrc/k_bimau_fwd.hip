@@ -69,17 +69,15 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     // per-query-tile global operands (Q rows, interval, residual rows) are fetched one tile ahead: their HBM/L2 latency
     // overlaps the previous tile's compute instead of opening every iteration with a stall
     struct QOps { Frag4<T> qf[DT], rf[DT]; float span; };
-    auto load_q = [&](int qt) {
+    auto load_q = [&](int qt) {   // unconditional (row clamped): branch-free, so the wait counts around it stay exact
         QOps o;
-        const int q = qt * 16 + l15;
-        const bool ok = q < p.T;
+        const int q = min(qt * 16 + l15, p.T - 1);
 #pragma unroll
         for (int ub = 0; ub < DT; ++ub) {
-            o.qf[ub] = ok ? frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4) : frag_zero<T>();
-            o.rf[ub] = ok ? frag_ld<T>(reinterpret_cast<const T*>(p.resid) + ((long)b * p.T + q) * p.ld_res + head * dh + ub * 16 + g4)
-                          : frag_zero<T>();
+            o.qf[ub] = frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4);
+            o.rf[ub] = frag_ld<T>(reinterpret_cast<const T*>(p.resid) + ((long)b * p.T + q) * p.ld_res + head * dh + ub * 16 + g4);
         }
-        o.span = ok ? p.spans[(long)b * p.T + q] : 0.f;
+        o.span = p.spans[(long)b * p.T + q];
         return o;
     };
     QOps qcur = load_q(0);
@@ -87,6 +85,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
         const QOps qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
+        asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
         // ---- S^T[k][q] = sum_u K[k][u] Q[q][u] ------------------------------------------------
         Frag4<T> qf[DT];
 #pragma unroll

@@ -1,5 +1,5 @@
 """Diagnostic: per-phase wave cycles of the BiMAU backward kernel (needs a library built with -DEDGL_PHASE_TIMING, see
-k_bimau_bwd.hip).  python tools/phase_probe.py path/to/lib_phase.so"""
+k_bimau_bwd.hip; cycles are per wave with the other resident waves of the SIMD competing).  python tools/phase_probe.py path/to/lib_phase.so"""
 import ctypes
 import os
 import shutil
@@ -14,8 +14,8 @@ import bench  # noqa: E402
 from easydgl_amd import _lib  # noqa: E402
 from easydgl_amd.engine import TrainEngine  # noqa: E402
 
-NAMES = ["staging", "q loads+S+softmax", "H", "intensity MLP", "lambda,dOT", "G/dA/dV sweep", "dz", "du/dH",
-         "dS sweep,dQ,dK,dT", "epilogue"]
+NAMES = ["X: S + softmax", "X: G/dA/dlam/dV sweep", "X: dz, row term", "X: epilogue", "-", "-", "-", "-",
+         "Z: S + softmax", "Z: dP/dS/dQ/dK/dT sweep", "Z: epilogue", "-", "-", "-", "-", "-"]
 
 
 def main():
@@ -36,9 +36,10 @@ def main():
     torch.cuda.synchronize()
     raw.edgl_debug_phase_cycles(buf, 0)
     jobs = cfg["batch"] * cfg["num_heads"]
-    tot = sum(buf[:10])
+    tot = sum(buf[:16])
     for i, nm in enumerate(NAMES):
-        print(f"{nm:22s} {buf[i] / n / jobs:12.0f} cyc/job  {100.0 * buf[i] / tot:5.1f}%")
+        if nm != "-":
+            print(f"{nm:28s} {buf[i] / n / jobs:12.0f} cyc/job  {100.0 * buf[i] / tot:5.1f}%")
     print(f"total {tot / n / jobs:.0f} cycles per (b, head) job")
 
 
