@@ -61,36 +61,34 @@ struct ZStream {
     using S = SC<T, CT, NTHR>;
     Vec16<T> rz[S::PER_Z];
     Vec16<T> rt[WITH_T ? S::PER_ZT : 1];
-    // Z image rows [z0, z0+ZB) of src [*, C]; rows >= zend (or global row 0 when zero_row0) read as zeros
+    int z0_, zend_;      // tile start / chunk end of the rows in flight
+    bool zero0_;
+    // Z image rows [z0, z0+ZB) of src [*, C]; rows >= zend (or global row 0 when zero_row0) read as zeros.
+    // The loads are UNCONDITIONAL (addresses clamped into the valid range) and the zeroing happens in store(): a
+    // per-lane branch around a load makes the compiler wait for that load inside the branch, which serialises the
+    // whole prefetch (one full memory latency per slot).
     __device__ __forceinline__ void load(const T* src, const T* srcT, int ldT, int z0, int zend, bool zero_row0) {
         load_z(src, z0, zend, zero_row0);
         load_t(srcT, ldT, z0, zend, zero_row0);
     }
     __device__ __forceinline__ void load_z(const T* src, int z0, int zend, bool zero_row0) {
+        z0_ = z0; zend_ = zend; zero0_ = zero_row0;
 #pragma unroll
         for (int i = 0; i < S::PER_Z; ++i) {
             const int v = threadIdx.x + i * NTHR;
-            const int row = v / S::CV, cv = v % S::CV, gz = z0 + row;
-            rz[i] = (gz < zend && !(zero_row0 && gz == 0)) ? ld16<T>(src + (long)gz * S::C + cv * S::VEC) : zero16<T>();
+            const int row = v / S::CV, cv = v % S::CV, gz = min(z0 + row, zend - 1);
+            rz[i] = ld16<T>(src + (long)gz * S::C + cv * S::VEC);
         }
     }
     __device__ __forceinline__ void load_t(const T* srcT, int ldT, int z0, int zend, bool zero_row0) {
         if constexpr (WITH_T) {
+            z0_ = z0; zend_ = zend; zero0_ = zero_row0;
             constexpr int ZV = ZB / S::VEC;
 #pragma unroll
             for (int i = 0; i < S::PER_ZT; ++i) {
                 const int v = threadIdx.x + i * NTHR;
-                const int c = v / ZV, zv = v % ZV, gz = z0 + zv * S::VEC;
-                const T* p = srcT + (long)c * ldT + gz;
-                if (gz + S::VEC <= zend && !(zero_row0 && gz == 0)) {
-                    rt[i] = ld16<T>(p);
-                } else {
-                    Vec16<T> t = zero16<T>();
-#pragma unroll
-                    for (int j = 0; j < S::VEC; ++j)
-                        if (gz + j < zend && !(zero_row0 && gz + j == 0)) t.v[j] = p[j];
-                    rt[i] = t;
-                }
+                const int c = v / ZV, zv = v % ZV, gz = min(z0 + zv * S::VEC, ldT - S::VEC);   // ldT is a multiple of VEC
+                rt[i] = ld16<T>(srcT + (long)c * ldT + gz);
             }
         }
     }
@@ -98,14 +96,23 @@ struct ZStream {
 #pragma unroll
         for (int i = 0; i < S::PER_Z; ++i) {
             const int v = threadIdx.x + i * NTHR;
-            st16<T>(Zs + (v / S::CV) * S::LDC + (v % S::CV) * S::VEC, rz[i]);
+            const int gz = z0_ + v / S::CV;
+            const bool ok = gz < zend_ && !(zero0_ && gz == 0);
+            st16<T>(Zs + (v / S::CV) * S::LDC + (v % S::CV) * S::VEC, ok ? rz[i] : zero16<T>());
         }
         if constexpr (WITH_T) {
             constexpr int ZV = ZB / S::VEC;
 #pragma unroll
             for (int i = 0; i < S::PER_ZT; ++i) {
                 const int v = threadIdx.x + i * NTHR;
-                st16<T>(ZTs + (v / ZV) * S::LDZ + (v % ZV) * S::VEC, rt[i]);
+                const int gz = z0_ + (v % ZV) * S::VEC;
+                Vec16<T> t = rt[i];
+                if (gz + S::VEC > zend_ || (zero0_ && gz == 0)) {   // only the last tile of a chunk / the tile holding row 0
+#pragma unroll
+                    for (int j = 0; j < S::VEC; ++j)
+                        if (gz + j >= zend_ || (zero0_ && gz + j == 0)) t.v[j] = from_f32<T>(0.f);
+                }
+                st16<T>(ZTs + (v / ZV) * S::LDZ + (v % ZV) * S::VEC, t);
             }
         }
     }
