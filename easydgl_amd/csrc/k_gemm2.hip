@@ -109,20 +109,34 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
     bf16* const Ostage = Ws + WELEMS + wave * 16 * LDO;
     const int nbase = blockIdx.y * NP;
     const int ncols = min(NP, p.N - nbase);          // multiple of 64
-    // ---- weights slice -> LDS (once) ----------------------------------------------------------------------------
-    if constexpr (B_KC) {
-        for (int v = tid; v < NP * (K / 8); v += W_NT) {
-            const int row = v / (K / 8), kv = v % (K / 8);
-            uint4 d = make_uint4(0, 0, 0, 0);
-            if (row < ncols) d = *reinterpret_cast<const uint4*>(p.B + (long)(nbase + row) * p.ldb + kv * 8);
-            *reinterpret_cast<uint4*>(Ws + row * LDW_KC + kv * 8) = d;
-        }
-    } else {
-        for (int v = tid; v < K * (NP / 8); v += W_NT) {
-            const int row = v / (NP / 8), nv = v % (NP / 8);
-            uint4 d = make_uint4(0, 0, 0, 0);
-            if (nv * 8 < ncols) d = *reinterpret_cast<const uint4*>(p.B + (long)row * p.ldb + nbase + nv * 8);
-            *reinterpret_cast<uint4*>(Ws + row * LDW_TR + nv * 8) = d;
+    // ---- weights slice -> LDS (once).  Unconditional loads (row / column clamped into the slice: the clamped copies land
+    //      in rows / columns >= ncols that no strip reads) issued in batches of 4, so the slice arrives in a few memory
+    //      round trips instead of one per 16-byte piece. ------------------------------------------------------------
+    {
+        constexpr int TOTAL = B_KC ? NP * (K / 8) : K * (NP / 8);
+        constexpr int ITER = (TOTAL + W_NT - 1) / W_NT;
+#pragma unroll
+        for (int i0 = 0; i0 < ITER; i0 += 4) {
+            uint4 d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = min(tid + (i0 + j) * W_NT, TOTAL - 1);
+                if constexpr (B_KC) {
+                    const int row = min(v / (K / 8), ncols - 1), kv = v % (K / 8);
+                    d[j] = *reinterpret_cast<const uint4*>(p.B + (long)(nbase + row) * p.ldb + kv * 8);
+                } else {
+                    const int row = v / (NP / 8), nv = min(v % (NP / 8), ncols / 8 - 1);
+                    d[j] = *reinterpret_cast<const uint4*>(p.B + (long)row * p.ldb + nbase + nv * 8);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int v = tid + (i0 + j) * W_NT;
+                if (i0 + j < ITER && v < TOTAL) {
+                    if constexpr (B_KC) *reinterpret_cast<uint4*>(Ws + (v / (K / 8)) * LDW_KC + (v % (K / 8)) * 8) = d[j];
+                    else *reinterpret_cast<uint4*>(Ws + (v / (NP / 8)) * LDW_TR + (v % (NP / 8)) * 8) = d[j];
+                }
+            }
         }
     }
     __syncthreads();
@@ -134,20 +148,18 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
         bf16x8 xf[2][NKB];
 #pragma unroll
         for (int ix = 0; ix < 2; ++ix) {
-            const int m = m0 + ix * 16 + l15;
+            // rows past M are clamped, not branched around: their results are never stored, and a per-lane branch
+            // around a load makes the compiler wait for it inside the branch (one memory round trip per fragment)
+            const int m = min(m0 + ix * 16 + l15, p.M - 1);
             const bf16* row = p.A + (long)m * p.lda;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 bf16x8 f;
-                if (m < p.M) {
-                    if constexpr (B_KC) {
-                        *reinterpret_cast<uint4*>(&f) = *reinterpret_cast<const uint4*>(row + kb * 32 + G * 8);
-                    } else {
-                        *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<const uint2*>(row + kb * 32 + g4);
-                        *(reinterpret_cast<uint2*>(&f) + 1) = *reinterpret_cast<const uint2*>(row + kb * 32 + 16 + g4);
-                    }
+                if constexpr (B_KC) {
+                    *reinterpret_cast<uint4*>(&f) = *reinterpret_cast<const uint4*>(row + kb * 32 + G * 8);
                 } else {
-                    *reinterpret_cast<uint4*>(&f) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<const uint2*>(row + kb * 32 + g4);
+                    *(reinterpret_cast<uint2*>(&f) + 1) = *reinterpret_cast<const uint2*>(row + kb * 32 + 16 + g4);
                 }
                 xf[ix][kb] = f;
             }
@@ -253,21 +265,26 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float csum = 0.f;   // thread t < 128: column n0 + t of Y
     uint4 px[4], py[4];
+    int r0_cur = 0;
+    // unconditional loads (row clamped into the split, column offset into the matrix); rows past the split are zeroed
+    // when the tile is written to LDS — a branch around a load would serialise the prefetch on memory latency
     auto load = [&](int r0) {
+        r0_cur = r0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int v = tid + i * T_NT, row = v >> 4, cv = v & 15, gr = r0 + row;
-            const bool okx = gr < r_hi && kf0 + cv * 8 < p.Kf, oky = gr < r_hi && n0 + cv * 8 < p.N;
-            px[i] = okx ? *reinterpret_cast<const uint4*>(p.X + (long)gr * p.ldx + kf0 + cv * 8) : make_uint4(0, 0, 0, 0);
-            py[i] = oky ? *reinterpret_cast<const uint4*>(p.Y + (long)gr * p.ldy + n0 + cv * 8) : make_uint4(0, 0, 0, 0);
+            const int v = tid + i * T_NT, row = v >> 4, cv = v & 15, gr = min(r0 + row, r_hi - 1);
+            const int cx = min(kf0 + cv * 8, p.Kf - 8), cy = min(n0 + cv * 8, p.N - 8);
+            px[i] = *reinterpret_cast<const uint4*>(p.X + (long)gr * p.ldx + cx);
+            py[i] = *reinterpret_cast<const uint4*>(p.Y + (long)gr * p.ldy + cy);
         }
     };
     auto store = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int v = tid + i * T_NT, row = v >> 4, cv = v & 15;
-            *reinterpret_cast<uint4*>(Xs + row * T_LD + cv * 8) = px[i];
-            *reinterpret_cast<uint4*>(Ys + row * T_LD + cv * 8) = py[i];
+            const bool ok = r0_cur + row < r_hi;
+            *reinterpret_cast<uint4*>(Xs + row * T_LD + cv * 8) = ok ? px[i] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Ys + row * T_LD + cv * 8) = ok ? py[i] : make_uint4(0, 0, 0, 0);
         }
     };
     const int nstep = (r_hi - r_lo + T_BR - 1) / T_BR;
