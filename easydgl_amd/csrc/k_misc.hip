@@ -218,11 +218,89 @@ inline int grid_for(long n) { return (int)std::min<long>((n + 255) / 256, 4096);
 
 }  // namespace
 
+// ---- deferred reductions ------------------------------------------------------------------------------------------
+// Every backward kernel that produces per-workgroup partials ends with one of these reductions; each is a few
+// microseconds of work behind a full kernel launch.  In deferred mode (edgl_reduce_defer(1)) the calls are collected on
+// the host and edgl_reduce_flush() runs all of them in ONE launch.  The caller must then keep every partial buffer
+// alive (distinct workspaces) until the flush.  Jobs that accumulate into `out` flush first and run immediately, so the
+// order of read-modify-write updates is preserved.
+constexpr int RED_MAX_JOBS = 24;
+struct RedJob { const float* part; float* out; long ld; int P, N, blk0; };
+struct RedBatch { RedJob j[RED_MAX_JOBS]; int n, blocks; };
+thread_local bool g_red_defer = false;
+thread_local RedBatch g_red_batch = {};
+
+__global__ __launch_bounds__(256) void reduce_rows_multi_kernel(RedBatch b) {
+    __shared__ float sm[8][33];
+    int ji = 0;
+    for (int i = 1; i < b.n; ++i)
+        if ((int)blockIdx.x >= b.j[i].blk0) ji = i;
+    const RedJob& jb = b.j[ji];
+    const float* part = jb.part;
+    const int P = jb.P, N = jb.N;
+    const long ld = jb.ld;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = ((int)blockIdx.x - jb.blk0) * 32 + tx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (n < N) {
+        int p = ty;
+        for (; p + 24 < P; p += 32) {
+            a0 += part[(long)p * ld + n];
+            a1 += part[(long)(p + 8) * ld + n];
+            a2 += part[(long)(p + 16) * ld + n];
+            a3 += part[(long)(p + 24) * ld + n];
+        }
+        for (; p < P; p += 8) a0 += part[(long)p * ld + n];
+    }
+    sm[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += sm[i][tx];
+        jb.out[n] = s;
+    }
+}
+
+int edgl_reduce_flush_impl(hipStream_t st) {
+    if (g_red_batch.n == 0) return EDGL_OK;
+    hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3(g_red_batch.blocks), dim3(256), 0, st, g_red_batch);
+    g_red_batch.n = 0;
+    g_red_batch.blocks = 0;
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
 int edgl_reduce_rows(const float* part, int P, int N, long ld, float* out, int accumulate, hipStream_t st) {
+    if (g_red_defer && !accumulate) {
+        if (g_red_batch.n == RED_MAX_JOBS) {
+            const int rc = edgl_reduce_flush_impl(st);
+            if (rc) return rc;
+        }
+        RedJob& j = g_red_batch.j[g_red_batch.n++];
+        j.part = part; j.out = out; j.ld = ld; j.P = P; j.N = N; j.blk0 = g_red_batch.blocks;
+        g_red_batch.blocks += (N + 31) / 32;
+        return EDGL_OK;
+    }
+    if (g_red_defer) {   // read-modify-write job: everything queued before it must have landed
+        const int rc = edgl_reduce_flush_impl(st);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 31) / 32), dim3(256), 0, st, part, P, N, ld, out, accumulate);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
+
+extern "C" int edgl_reduce_defer(int on, void* stream) {
+    if (!on && g_red_defer) {
+        const int rc = edgl_reduce_flush_impl((hipStream_t)stream);
+        if (rc) return rc;
+    }
+    g_red_defer = on != 0;
+    return EDGL_OK;
+}
+
+extern "C" int edgl_reduce_flush(void* stream) { return edgl_reduce_flush_impl((hipStream_t)stream); }
 
 extern "C" int edgl_rng_advance(uint64_t* rng_state, void* stream) {
     EDGL_REQUIRE(rng_state, EDGL_ERR_NULL, "edgl_rng_advance: null state");

@@ -79,7 +79,9 @@ class TrainEngine:
         for (kf, n) in ((3 * C, 4 * C), (C, 4 * C), (C, C), (C, 2 * C), (2 * C, C)):
             wsz.append(lib.edgl_gemm_dw_workspace(self.rows, kf, n, self.code))
         self.ws = e(max(wsz), dtype=f32)
-        self.ws_bimau = e(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, self.code), dtype=torch.uint8)
+        # The backward runs with deferred partial reductions (edgl_reduce_defer): every call that leaves partials behind
+        # gets its own workspace, handed out in call order (the launch sequence is fixed, so the addresses are too).
+        self._ws_list, self._ws_i = [], 0
         segs = []
         params = dict(m.named_parameters())
         for n in m.l2_param_names():
@@ -100,9 +102,21 @@ class TrainEngine:
         """out[rows, K_in] (=|+=) dz[rows, N] . kernel[K_in, N]^T"""
         self._gemm(dz, self.m.compute(kernel), out, self.rows, K_in, N, N, N, K_in, True, aux=aux, flags=flags)
 
+    def _ws(self, n, dtype=torch.float32):
+        """Private workspace of the next partial-producing call of the fixed backward sequence."""
+        i = self._ws_i
+        self._ws_i += 1
+        if i == len(self._ws_list):
+            self._ws_list.append(torch.empty(max(int(n), 1), device=self.m._arena.device, dtype=dtype))
+        w = self._ws_list[i]
+        if w.numel() < n or w.dtype != dtype:
+            raise _lib.EdglError("TrainEngine: backward launch sequence changed between steps")
+        return w
+
     def _dense_dw(self, x, dz, kernel, bias, K_in, N):
+        ws = self._ws(lib.edgl_gemm_dw_workspace(self.rows, K_in, N, self.code))
         check(lib.edgl_gemm_dw(_ptr(x), _ptr(dz), _ptr(kernel.grad), _ptr(bias.grad), self.rows, K_in, N, K_in, N, 0,
-                               _ptr(self.ws), self.code, _stream()), "edgl_gemm_dw")
+                               _ptr(ws), self.code, _stream()), "edgl_gemm_dw")
 
     def _ln_fwd(self, x, resid, ld_res, ln, drop, y, stats, gpos=None):
         B, T, C = self.B, self.T, self.C
@@ -116,7 +130,8 @@ class TrainEngine:
         check(lib.edgl_add_layernorm_bwd(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
                                          _ptr(stats), _ptr(dy), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
                                          _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(rowmap), _ptr(dsum),
-                                         _ptr(dx_drop), _ptr(ln.gamma.grad), _ptr(ln.beta.grad), _ptr(self.ws), self.code, _stream()),
+                                         _ptr(dx_drop), _ptr(ln.gamma.grad), _ptr(ln.beta.grad), _ptr(self._ws(B * 2 * C)),
+                                         self.code, _stream()),
               "edgl_add_layernorm_bwd")
 
     # ---- one optimizer step, as a fixed launch sequence ----------------------------------------------------------------
@@ -175,6 +190,8 @@ class TrainEngine:
                                        _ptr(m.mark_lookup_table), B, T, H, E, M, float(coef), _ptr(b["tpp"]), None,
                                        _ptr(b["dlam"]), st), "edgl_tpp_bwd")
         # ================= backward =================
+        self._ws_i = 0
+        check(lib.edgl_reduce_defer(1, st), "edgl_reduce_defer")
         check(lib.edgl_score_ce_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
                                     _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows), _ptr(tab.grad),
                                     _ptr(m.output_bias.grad), _ptr(self.ws), code, st), "edgl_score_ce_bwd")
@@ -214,7 +231,8 @@ class TrainEngine:
                                      _ptr(b["saved"]), B, T, C, H, E,
                                      float(da.rate), da.ptr(), da.stream_id, _ptr(self.G4c), _ptr(att.st_kernel.grad),
                                      _ptr(att.st_bias.grad), _ptr(att.weight.grad), _ptr(att.scaling.grad),
-                                     _ptr(self.ws_bimau), code, st), "edgl_bimau_bwd")
+                                     _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), code, st),
+                  "edgl_bimau_bwd")
             self._dense_dw(x_in, self.G4c, att.dense_kernel, att.dense_bias, cin, 4 * C)
             d_in = self.G3c if i == 0 else self.G3
             self._dense_dx(self.G4c, att.dense_kernel, d_in, cin, 4 * C)
@@ -229,7 +247,9 @@ class TrainEngine:
         d0 = drop(hd, 1)
         check(lib.edgl_encode_bwd(_ptr(self.ids), _ptr(self.marks), _ptr(dY), B, T, C, E, I, float(d0.rate), d0.ptr(),
                                   d0.stream_id, _ptr(tab.grad), _ptr(m.pcoding.pembs.lookup_table.grad),
-                                  _ptr(m.mark_embs.lookup_table.grad), _ptr(self.ws), code, st), "edgl_encode_bwd")
+                                  _ptr(m.mark_embs.lookup_table.grad), _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))),
+                                  code, st), "edgl_encode_bwd")
+        check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")   # runs every queued reduction in one launch
 
     def _optimizer(self):
         m = self.m

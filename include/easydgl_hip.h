@@ -212,6 +212,16 @@ int edgl_topk_merge(const float* cand_val, const int32_t* cand_idx, int S, int R
 int edgl_rank_metrics(const int32_t* topk_idx, int R, int K, const int64_t* label, float* metrics,
                       void* stream);
 
+/* ---- deferred partial reductions ------------------------------------------------------------------
+ * The weight-gradient entry points (edgl_gemm_dw, edgl_add_layernorm_bwd, edgl_encode_bwd,
+ * edgl_bimau_bwd, edgl_colsum) finish with a small fixed-order reduction of per-workgroup partials.
+ * After edgl_reduce_defer(1, stream) those reductions are queued on the calling host thread instead
+ * of launched, and edgl_reduce_flush(stream) (or edgl_reduce_defer(0, stream)) runs all of them in
+ * one launch.  While deferred, every call must be given its OWN workspace, kept until the flush,
+ * and the gradient outputs are not valid before it.  Accumulating calls flush and run immediately. */
+int edgl_reduce_defer(int on, void* stream);
+int edgl_reduce_flush(void* stream);
+
 /* ---- K8: TPP likelihood regulariser — temporal.py:317-333 + EasyDGL.py:157-175 -----------------
  * lam f32 [H*B,T,E]; masked_pos int64 [B,M]; labels int64 [B,M]; ts_raw f32 [B,T] (raw seconds);
  * mark_table uint8 [NI,E].  reg_out f32[1] (+)= coef * biased_mle with coef = ct_reg/H;
