@@ -105,6 +105,15 @@ __device__ __forceinline__ f32x4 mma_kblock(const Vec16<bf16>& a, const Vec16<bf
                                                    *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for every global
+// load a thread has in flight — which turns a register prefetch issued before the barrier into a stall on full memory
+// latency.  Use this one when only LDS contents are exchanged across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Scheduling fence: memory operations stay on their side at the IR level (asm memory clobber) and the machine scheduler
 // moves nothing across (sched_barrier).  Used to keep hand-placed operand prefetches where they were written.
 #define EDGL_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)

@@ -309,9 +309,9 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
 #pragma unroll 8
             for (int r = 0; r < T_BR; ++r) csum += to_f32(Ys[r * T_LD + tid]);
         }
-        __syncthreads();
+        lds_barrier();       // all reads of this tile done; the next tile's global loads stay in flight across it
         if (more) store();
-        __syncthreads();
+        lds_barrier();
     }
     float* out = p.partial + (long)blockIdx.z * (p.Kf + 1) * p.N;
 #pragma unroll

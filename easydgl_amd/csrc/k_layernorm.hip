@@ -9,6 +9,7 @@
 namespace {
 
 constexpr int LN_THREADS = 512;
+constexpr int LN_NR = 4;   // rows a thread can keep in registers between the passes
 
 struct LnP {
     const void* x; const void* resid; int ld_res;
@@ -48,23 +49,53 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(LnP p) {
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const float n = (float)p.T * (float)p.C;
 
+    // A thread owns rows tr, tr + rows_par, ...: when there are at most LN_NR of them (T <= LN_NR * rows_par, the usual
+    // case) the dropped-out sums are read ONCE into registers and all three passes (mean, variance, output) run from
+    // there; otherwise every pass re-reads its rows.
+    const bool cached = p.T <= LN_NR * rows_par;
+    float sc[LN_NR][VEC];
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < LN_NR; ++i) {
+            const int t = tr + i * rows_par;
+            load_sum<T>(p, dk, b, min(t, p.T - 1), c0, sc[i]);   // clamped, unconditional: the loads overlap
+            if (!(on && t < p.T)) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) sc[i][j] = 0.f;
+            }
+        }
+    }
     float acc = 0.f;
-    if (on)
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < LN_NR; ++i)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc += sc[i][j];
+    } else if (on) {
         for (int t = tr; t < p.T; t += rows_par) {
             float s[VEC];
             load_sum<T>(p, dk, b, t, c0, s);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc += s[j];
         }
+    }
     const float mean = block_sum(acc, red) / n;
     acc = 0.f;
-    if (on)
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < LN_NR; ++i)
+            if (on && tr + i * rows_par < p.T) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { const float d = sc[i][j] - mean; acc += d * d; }
+            }
+    } else if (on) {
         for (int t = tr; t < p.T; t += rows_par) {
             float s[VEC];
             load_sum<T>(p, dk, b, t, c0, s);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { const float d = s[j] - mean; acc += d * d; }
         }
+    }
     const float var = block_sum(acc, red) / n;
     const float rstd = rsqrtf(var + 1e-12f);
     if (tid == 0) { p.stats[2 * b] = mean; p.stats[2 * b + 1] = rstd; }
@@ -82,6 +113,17 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(LnP p) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) o.v[j] = from_f32<T>((s[j] - mean) * rstd * g[j] + be[j]);
             st16<T>(y + ((long)b * p.Mg + jrow) * p.C + c0, o);
+        }
+    } else if (cached) {
+#pragma unroll
+        for (int i = 0; i < LN_NR; ++i) {
+            const int t = tr + i * rows_par;
+            if (t < p.T) {
+                Vec16<T> o;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o.v[j] = from_f32<T>((sc[i][j] - mean) * rstd * g[j] + be[j]);
+                st16<T>(y + ((long)b * p.T + t) * p.C + c0, o);
+            }
         }
     } else {
         for (int t = tr; t < p.T; t += rows_par) {
@@ -159,7 +201,30 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
     float s1 = 0.f, s2 = 0.f, dga[VEC], dbe[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { dga[j] = 0.f; dbe[j] = 0.f; }
-    if (on)
+    // rows owned by this thread are read once (dy and the dropped-out sum) and kept for the second pass when they fit
+    const bool cached = p.T <= LN_NR * rows_par;
+    float dc[LN_NR][VEC], sc[LN_NR][VEC];
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < LN_NR; ++i) {
+            const int t = tr + i * rows_par;
+            const bool ok = on && t < p.T;
+            const int tc = min(t, p.T - 1);
+            load_sum<T>(p, dk, b, tc, c0, sc[i]);
+            const bool hasd = load_dy<T>(p, rowmap, nextj, b, tc, c0, dc[i]) && ok;
+            if (!hasd) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) dc[i][j] = 0.f;
+            }
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float xh = (sc[i][j] - mean) * rstd, gg = dc[i][j] * g[j];
+                    s1 += gg; s2 += gg * xh; dga[j] += dc[i][j] * xh; dbe[j] += dc[i][j];
+                }
+            }
+        }
+    } else if (on) {
         for (int t = tr; t < p.T; t += rows_par) {
             float d[VEC];
             if (!load_dy<T>(p, rowmap, nextj, b, t, c0, d)) continue;
@@ -171,6 +236,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
                 s1 += gg; s2 += gg * xh; dga[j] += d[j] * xh; dbe[j] += d[j];
             }
         }
+    }
     const float m1 = block_sum(s1, red) / n;
     const float m2 = block_sum(s2, red) / n;
     if (on) {
@@ -189,10 +255,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
     if (!on) return;
     T* dsum = reinterpret_cast<T*>(p.dsum);
     T* dxd = reinterpret_cast<T*>(p.dx_drop);
-    for (int t = tr; t < p.T; t += rows_par) {
-        float d[VEC], s[VEC];
-        load_dy<T>(p, rowmap, nextj, b, t, c0, d);
-        load_sum<T>(p, dk, b, t, c0, s);
+    auto emit = [&](int t, const float (&d)[VEC], const float (&s)[VEC]) {
         const long row = (long)b * p.T + t;
         Vec16<T> o, od;
 #pragma unroll
@@ -204,6 +267,20 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
         }
         if (dsum) st16<T>(dsum + row * p.C + c0, o);
         if (dxd) st16<T>(dxd + row * p.C + c0, od);
+    };
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < LN_NR; ++i) {
+            const int t = tr + i * rows_par;
+            if (t < p.T) emit(t, dc[i], sc[i]);
+        }
+    } else {
+        for (int t = tr; t < p.T; t += rows_par) {
+            float d[VEC], s[VEC];
+            load_dy<T>(p, rowmap, nextj, b, t, c0, d);
+            load_sum<T>(p, dk, b, t, c0, s);
+            emit(t, d, s);
+        }
     }
 }
 
