@@ -8,6 +8,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_long, c_uint32, c_void_p
 
+# PyTorch-ROCm bundles its own libamdhip64; it must be in the process BEFORE our library is loaded so that both bind to
+# ONE HIP runtime (same device context, streams and allocations).  Loading libeasydgl_hip.so first pulls in /opt/rocm's
+# copy and every launch on torch memory then fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeasydgl_hip.so")
 
