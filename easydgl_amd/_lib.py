@@ -62,7 +62,7 @@ SIGNATURES = {
     "edgl_cast": (I, [P, P, L, I, P]),
     "edgl_cast_back": (I, [P, P, L, I, I, P]),
     "edgl_add": (I, [P, P, P, L, I, P]),
-    "edgl_add_cols": (I, [P, I, P, I, L, I, I, P]),
+    "edgl_add_cols": (I, [P, I, P, P, I, L, I, I, P]),
     "edgl_gelu_bwd": (I, [P, P, P, L, I, P]),
 }
 

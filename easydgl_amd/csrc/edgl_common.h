@@ -105,6 +105,19 @@ __device__ __forceinline__ f32x4 mma_kblock(const Vec16<bf16>& a, const Vec16<bf
                                                    *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
 }
 
+// -DEDGL_PHASE_TIMING builds a diagnostic variant of a kernel file: every wave accumulates s_memtime deltas per phase and
+// lane 0 adds them to g_phase_cycles (16 slots per translation unit, read back with the file's edgl_debug_phase_cycles*).
+// Not part of the product build.
+#ifdef EDGL_PHASE_TIMING
+#define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PH_FLUSH(base) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_cycles[(base) + i_], ph_acc[i_]); } while (0)
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_FLUSH(base)
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for every global
 // load a thread has in flight — which turns a register prefetch issued before the barrier into a stall on full memory
 // latency.  Use this one when only LDS contents are exchanged across the barrier.

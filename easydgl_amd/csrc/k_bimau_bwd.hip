@@ -11,17 +11,8 @@
 // Products that contract over the QUERY index use operands transposed by one MFMA against the identity.
 #include "bimau_common.h"
 
-// -DEDGL_PHASE_TIMING builds a diagnostic variant: every wave of the sweep kernels accumulates s_memtime deltas per phase
-// and lane 0 adds them to g_phase_cycles (read back with edgl_debug_phase_cycles).  Not part of the product build.
 #ifdef EDGL_PHASE_TIMING
-__device__ unsigned long long g_phase_cycles[16];
-#define PH_DECL unsigned long long ph_t0 = __builtin_readcyclecounter(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define PH_MARK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t0; ph_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PH_FLUSH(base) do { if ((threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_phase_cycles[(base) + i_], ph_acc[i_]); } while (0)
-#else
-#define PH_DECL
-#define PH_MARK(i)
-#define PH_FLUSH(base)
+__device__ unsigned long long g_phase_cycles[16];   // see edgl_common.h (PH_MARK): X uses slots 0-7, Z slots 8-15
 #endif
 
 namespace {

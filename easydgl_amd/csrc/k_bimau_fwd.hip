@@ -81,9 +81,27 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
         return o;
     };
     QOps qcur = load_q(0);
+    // The output rows of a query tile (computed last) are stored at the TOP of the next iteration: the loop-carried
+    // prefetch makes the compiler drain vmcnt to 0 on the back edge, and a store issued just before it would expose its
+    // full write latency there.  (H rows, z and lambda are stored mid-iteration and have landed by then.)
+    Frag4<T> pend_o[DT];
+#pragma unroll
+    for (int ut = 0; ut < DT; ++ut) pend_o[ut] = frag_zero<T>();
+    int pend_q = p.T;   // >= T: nothing pending
+    auto flush_pending = [&]() {
+        if (pend_q < p.T) {
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) {
+                T* dst = reinterpret_cast<T*>(p.out) + ((long)b * p.T + pend_q) * p.C + head * dh + ut * 16 + g4;
+                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&pend_o[ut]);
+                else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&pend_o[ut]);
+            }
+        }
+    };
     for (int qt = 0; qt < NT; ++qt) {
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
+        flush_pending();
         const QOps qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
         asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
         // ---- S^T[k][q] = sum_u K[k][u] Q[q][u] ------------------------------------------------
@@ -205,19 +223,16 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
                 a = mma16(kfrag<T>(Vs, dh, Vs, LDT, kt * 16, vt * 16, lane), pf[kt], a);
-            if (qok) {
-                const int col = head * dh + vt * 16 + g4;
-                const Frag4<T> rf = qcur.rf[vt];
-                Frag4<T> of;
+            const Frag4<T> rf = qcur.rf[vt];
+            f32x4 o4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) of.v[r] = from_f32<T>(a[r] + to_f32(rf.v[r]));
-                T* dst = reinterpret_cast<T*>(p.out) + ((long)b * p.T + q) * p.C + col;
-                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&of);
-                else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&of);
-            }
+            for (int r = 0; r < 4; ++r) o4[r] = a[r] + to_f32(rf.v[r]);
+            pend_o[vt] = frag_from_acc<T>(o4);
         }
+        pend_q = q;
         qcur = qnext;
     }
+    flush_pending();
 }
 
 template <typename T, int DT, int NT, int EC>

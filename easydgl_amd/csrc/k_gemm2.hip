@@ -95,6 +95,9 @@ struct StripP {
 // workgroups that run side by side on the same rows.
 // NKB = K/32 ; B_KC: B stored [N][ldb] (k contiguous) else [K][ldb] (n contiguous, read with transpose reads)
 constexpr int W_NT = 512;
+#ifdef EDGL_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[16];
+#endif
 template <int NKB, bool B_KC>
 __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
     constexpr int K = 32 * NKB;
@@ -103,12 +106,19 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
     constexpr int LDW_TR = NP + 16;         // [K][NP+16]   rows k
     constexpr int WELEMS = B_KC ? NP * LDW_KC : K * LDW_TR;
     constexpr int LDO = 64 + 8;             // per-wave output staging [16][64+8] (one 16-row tile at a time)
+    constexpr int LDOF = 64 + 4;            // f32 staging [16][64+4] for the epilogues that combine with another tensor
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    PH_DECL
     bf16* const Ws = reinterpret_cast<bf16*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, g4 = G * 4, l15 = lane & 15;
-    bf16* const Ostage = Ws + WELEMS + wave * 16 * LDO;
+    const bool fstage = (p.epi.flags & (EDGL_EPI_ACCUM | EDGL_EPI_MUL_DGELU)) && !(p.epi.flags & EDGL_EPI_OUT_F32);
+    float* const biasS = reinterpret_cast<float*>(Ws + WELEMS);                   // this slice's bias (zeros if none)
+    bf16* const Ostage = Ws + WELEMS + 256 + wave * 16 * LDO;                     // (256 bf16 = the 128 bias floats)
+    float* const OstageF = reinterpret_cast<float*>(Ws + WELEMS + 256) + wave * 16 * LDOF;
     const int nbase = blockIdx.y * NP;
     const int ncols = min(NP, p.N - nbase);          // multiple of 64
+    if (p.dbg & 16) { if (tid < NP) biasS[tid] = 0.f; __syncthreads(); goto main_loop; }   // ablation: no weight staging
+    if (tid < NP) biasS[tid] = ((p.epi.flags & EDGL_EPI_BIAS) && nbase + tid < p.N) ? p.epi.bias[nbase + tid] : 0.f;
     // ---- weights slice -> LDS (once).  Unconditional loads (row / column clamped into the slice: the clamped copies land
     //      in rows / columns >= ncols that no strip reads) issued in batches of 4, so the slice arrives in a few memory
     //      round trips instead of one per 16-byte piece. ------------------------------------------------------------
@@ -140,7 +150,9 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
         }
     }
     __syncthreads();
-    const bool staged = !(p.epi.flags & (EDGL_EPI_OUT_F32 | EDGL_EPI_ACCUM | EDGL_EPI_MUL_DGELU));
+main_loop:
+    PH_MARK(0);   // weight slice staged
+    const bool staged = !(p.epi.flags & EDGL_EPI_OUT_F32) && !fstage;
     const int nstrip = (p.M + 31) / 32;
     for (int strip = blockIdx.x * 8 + wave; strip < nstrip; strip += gridDim.x * 8) {
         const int m0 = strip * 32;
@@ -155,6 +167,7 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 bf16x8 f;
+                if (p.dbg & 8) { *reinterpret_cast<uint4*>(&f) = make_uint4(lane, kb, 0, 0); xf[ix][kb] = f; continue; }   // ablation: no A loads
                 if constexpr (B_KC) {
                     *reinterpret_cast<uint4*>(&f) = *reinterpret_cast<const uint4*>(row + kb * 32 + G * 8);
                 } else {
@@ -164,10 +177,25 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
                 xf[ix][kb] = f;
             }
         }
+        PH_MARK(1);   // strip loads issued (+ waited where the first MFMA needs them: counted in phase 2)
         for (int nc = 0; nc < ncols; nc += 64) {
             f32x4 acc[4][2];
 #pragma unroll
             for (int jz = 0; jz < 4; ++jz) { acc[jz][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[jz][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            // ·GELU'(aux) / += C epilogues: the 16-byte pieces this lane will combine with are fetched now (whole 128-byte
+            // row segments) and used after the MFMA loop
+            uint4 pre_aux[2][2], pre_c[2][2];
+            if (fstage) {
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int m = min(m0 + ix * 16 + q * 8 + (lane >> 3), p.M - 1);
+                        const long idx = (long)m * p.ldc + nbase + nc + (lane & 7) * 8;
+                        if (p.epi.flags & EDGL_EPI_MUL_DGELU) pre_aux[ix][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.epi.aux) + idx);
+                        if (p.epi.flags & EDGL_EPI_ACCUM) pre_c[ix][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.C) + idx);
+                    }
+            }
             if (!(p.dbg & 2))
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
@@ -180,6 +208,7 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
                     acc[jz][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[1][kb], acc[jz][1], 0, 0, 0);
                 }
             }
+            PH_MARK(2);   // MFMA loop (incl. the wait for the strip)
             const int n0 = nbase + nc;
             // ---- epilogue.  acc[jz][ix] = L(first = n, second = m): a lane holds 4 consecutive n of one row, which
             //      would make every global store a 16-row x 32-byte scatter.  Simple epilogues (bias / GELU / cast)
@@ -192,8 +221,9 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
                     for (int jz = 0; jz < 4; ++jz) {
                         const int n = n0 + jz * 16 + g4;
                         float x[4] = {acc[jz][ix][0], acc[jz][ix][1], acc[jz][ix][2], acc[jz][ix][3]};
-                        if (p.epi.flags & EDGL_EPI_BIAS) {
-                            const float4 bb = *reinterpret_cast<const float4*>(p.epi.bias + n);
+                        {   // bias from the LDS copy: a global load here would put one memory round trip per tile on the
+                            // critical path of the epilogue
+                            const float4 bb = *reinterpret_cast<const float4*>(biasS + nc + jz * 16 + g4);
                             x[0] += bb.x; x[1] += bb.y; x[2] += bb.z; x[3] += bb.w;
                         }
                         if (p.epi.flags & EDGL_EPI_SAVE_PRE) {   // pre-activation image (2 GEMMs per step)
@@ -221,6 +251,42 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
+            } else if (fstage) {
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+#pragma unroll
+                    for (int jz = 0; jz < 4; ++jz) {
+                        const float4 bb = *reinterpret_cast<const float4*>(biasS + nc + jz * 16 + g4);
+                        *reinterpret_cast<float4*>(OstageF + l15 * LDOF + jz * 16 + g4) =
+                            make_float4(acc[jz][ix][0] + bb.x, acc[jz][ix][1] + bb.y, acc[jz][ix][2] + bb.z, acc[jz][ix][3] + bb.w);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int lrow = q * 8 + (lane >> 3), cv = lane & 7, m = m0 + ix * 16 + lrow;
+                        const float4 lo = *reinterpret_cast<const float4*>(OstageF + lrow * LDOF + cv * 8);
+                        const float4 hi = *reinterpret_cast<const float4*>(OstageF + lrow * LDOF + cv * 8 + 4);
+                        float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        if (p.epi.flags & EDGL_EPI_MUL_DGELU) {
+                            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&pre_aux[ix][q]);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) x[r] *= dgelu_f(to_f32(a[r]));
+                        }
+                        if (p.epi.flags & EDGL_EPI_ACCUM) {
+                            const bf16x8 o = *reinterpret_cast<const bf16x8*>(&pre_c[ix][q]);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) x[r] += to_f32(o[r]);
+                        }
+                        const Frag4<bf16> f0 = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
+                        const Frag4<bf16> f1 = frag_from_acc<bf16>(f32x4{x[4], x[5], x[6], x[7]});
+                        uint4 d;
+                        *reinterpret_cast<uint2*>(&d) = *reinterpret_cast<const uint2*>(&f0);
+                        *(reinterpret_cast<uint2*>(&d) + 1) = *reinterpret_cast<const uint2*>(&f1);
+                        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n0 + cv * 8) = d;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
             } else {
 #pragma unroll
                 for (int ix = 0; ix < 2; ++ix) {
@@ -235,8 +301,10 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
                     }
                 }
             }
+            PH_MARK(3);   // epilogue
         }
     }
+    PH_FLUSH(0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -341,7 +409,9 @@ template <int NKB, bool B_KC>
 static int launch_strip(const StripP& p, hipStream_t st) {
     constexpr int K = 32 * NKB;
     constexpr size_t wel = B_KC ? (size_t)128 * (K + 16) : (size_t)K * (128 + 16);
-    const size_t smem = (wel + (size_t)8 * 16 * (64 + 8)) * sizeof(bf16);
+    const bool fstage = (p.epi.flags & (EDGL_EPI_ACCUM | EDGL_EPI_MUL_DGELU)) && !(p.epi.flags & EDGL_EPI_OUT_F32);
+    const size_t smem = wel * sizeof(bf16) + 128 * sizeof(float) +
+                        (fstage ? (size_t)8 * 16 * (64 + 4) * sizeof(float) : (size_t)8 * 16 * (64 + 8) * sizeof(bf16));
     if (smem > 160 * 1024) return 0;
     auto k = strip_gemm_kernel<NKB, B_KC>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -406,3 +476,14 @@ int edgl_gemm2_try_tn(const void* X, const void* Y, float* C, int R, int Kf, int
     }
     return 1;
 }
+
+#ifdef EDGL_PHASE_TIMING
+extern "C" int edgl_debug_phase_cycles_gemm(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(gemm2::g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(gemm2::g_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

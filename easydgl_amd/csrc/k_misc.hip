@@ -174,11 +174,34 @@ __global__ void add_kernel(const T* a, const T* b, T* out, long n) {
 }
 // dst[r, :ncols] += src[r, :ncols] with independent row strides (residual gradients into the first C channels)
 template <typename T>
-__global__ void add_cols_kernel(T* dst, int ld_dst, const T* src, int ld_src, long rows, int ncols) {
+__global__ void add_cols_kernel(T* dst, int ld_dst, const T* src, const T* src2, int ld_src, long rows, int ncols) {
     const long total = rows * ncols;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / ncols; const int c = (int)(i % ncols);
-        dst[r * ld_dst + c] = from_f32<T>(to_f32(dst[r * ld_dst + c]) + to_f32(src[r * ld_src + c]));
+        float v = to_f32(dst[r * ld_dst + c]) + to_f32(src[r * ld_src + c]);
+        if (src2) v += to_f32(src2[r * ld_src + c]);
+        dst[r * ld_dst + c] = from_f32<T>(v);
+    }
+}
+// 16-byte vectors along the row (ncols, ld_dst, ld_src multiples of the vector width, 16-byte aligned bases)
+template <typename T>
+__global__ void add_cols_vec_kernel(T* dst, int ld_dst, const T* src, const T* src2, int ld_src, long rows, int ncols) {
+    constexpr int VEC = ElemTraits<T>::VEC;
+    const int vpr = ncols / VEC;
+    const long total = rows * vpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / vpr; const int c = (int)(i % vpr) * VEC;
+        Vec16<T> d = ld16<T>(dst + r * ld_dst + c);
+        const Vec16<T> a = ld16<T>(src + r * ld_src + c);
+        Vec16<T> b = a;
+        if (src2) b = ld16<T>(src2 + r * ld_src + c);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float v = to_f32(d.v[j]) + to_f32(a.v[j]);
+            if (src2) v += to_f32(b.v[j]);
+            d.v[j] = from_f32<T>(v);
+        }
+        st16<T>(dst + r * ld_dst + c, d);
     }
 }
 
@@ -400,14 +423,22 @@ extern "C" int edgl_add(const void* a, const void* b, void* out, long n, int dty
     return EDGL_OK;
 }
 
-extern "C" int edgl_add_cols(void* dst, int ld_dst, const void* src, int ld_src, long rows, int ncols, int dtype,
-                             void* stream) {
+extern "C" int edgl_add_cols(void* dst, int ld_dst, const void* src, const void* src2, int ld_src, long rows, int ncols,
+                             int dtype, void* stream) {
     EDGL_REQUIRE(dst && src, EDGL_ERR_NULL, "edgl_add_cols: null pointer");
+    EDGL_REQUIRE(dtype == EDGL_BF16 || dtype == EDGL_F32, EDGL_ERR_DTYPE, "edgl_add_cols: bad dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
-    const long n = rows * ncols;
-    if (dtype == EDGL_BF16) hipLaunchKernelGGL((add_cols_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (bf16*)dst, ld_dst, (const bf16*)src, ld_src, rows, ncols);
-    else if (dtype == EDGL_F32) hipLaunchKernelGGL((add_cols_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (float*)dst, ld_dst, (const float*)src, ld_src, rows, ncols);
-    else { edgl_set_error("edgl_add_cols: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    const int vec = dtype == EDGL_BF16 ? 8 : 4;
+    const bool vok = ncols % vec == 0 && ld_dst % vec == 0 && ld_src % vec == 0 &&
+                     (((uintptr_t)dst | (uintptr_t)src | (uintptr_t)src2) & 15) == 0;
+    const long n = vok ? rows * (ncols / vec) : rows * ncols;
+    if (dtype == EDGL_BF16) {
+        if (vok) hipLaunchKernelGGL((add_cols_vec_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (bf16*)dst, ld_dst, (const bf16*)src, (const bf16*)src2, ld_src, rows, ncols);
+        else hipLaunchKernelGGL((add_cols_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (bf16*)dst, ld_dst, (const bf16*)src, (const bf16*)src2, ld_src, rows, ncols);
+    } else {
+        if (vok) hipLaunchKernelGGL((add_cols_vec_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (float*)dst, ld_dst, (const float*)src, (const float*)src2, ld_src, rows, ncols);
+        else hipLaunchKernelGGL((add_cols_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (float*)dst, ld_dst, (const float*)src, (const float*)src2, ld_src, rows, ncols);
+    }
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

@@ -237,8 +237,7 @@ class TrainEngine:
             d_in = self.G3c if i == 0 else self.G3
             self._dense_dx(self.G4c, att.dense_kernel, d_in, cin, 4 * C)
             # both residual branches feed the first C channels of the block input (temporal.py:447, EasyDGL.py:116)
-            check(lib.edgl_add_cols(_ptr(d_in), cin, _ptr(self.G1), C, self.rows, C, code, st), "edgl_add_cols")
-            check(lib.edgl_add_cols(_ptr(d_in), cin, _ptr(self.G2), C, self.rows, C, code, st), "edgl_add_cols")
+            check(lib.edgl_add_cols(_ptr(d_in), cin, _ptr(self.G1), _ptr(self.G2), C, self.rows, C, code, st), "edgl_add_cols")
             if i > 0:  # next (earlier) block consumes d_in as its dY; keep it out of the scratch set it will overwrite
                 self.G2.copy_(self.G3)
                 dY = self.G2

@@ -252,8 +252,8 @@ int edgl_cast(const float* src, void* dst, long n, int dtype, void* stream);    
 int edgl_cast_back(const void* src, float* dst, long n, int accumulate, int dtype, void* stream); /* dst (+)= (f32)src */
 int edgl_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);      /* out = a + b           */
 int edgl_gelu_bwd(const void* dy, const void* pre, void* dz, long n, int dtype, void* stream); /* dz = dy*gelu'(pre), EasyDGL.py:19-32 */
-int edgl_add_cols(void* dst, int ld_dst, const void* src, int ld_src, long rows, int ncols, int dtype,
-                  void* stream);                                                             /* dst[:, :n] += src[:, :n] */
+int edgl_add_cols(void* dst, int ld_dst, const void* src, const void* src2, int ld_src, long rows, int ncols,
+                  int dtype, void* stream);                                                             /* dst[:, :n] += src[:, :n] (+ src2[:, :n] if not NULL; same ld_src) */
 
 #ifdef __cplusplus
 }
