@@ -88,6 +88,124 @@ struct StripP {
     int dbg;   // EDGL_DBG ablation bits (profiling only): 1 skip epilogue stores, 2 skip MFMA loop, 4 skip B streaming
 };
 
+// Epilogue of one [32 rows x 64 columns] accumulator block of a wave.  acc[jz][ix] = L(first = n, second = m): a lane holds 4
+// consecutive n of one row, which would make every global store a 16-row x 32-byte scatter; the values therefore go
+// through a wave-private LDS image and leave as whole 128-byte row segments.  bias64: LDS, the 64 bias values of the block.
+struct StripEpi {
+    bf16* Ostage; float* OstageF; const float* bias64;
+    bool staged, fstage;
+    uint4 pre_aux[2][2], pre_c[2][2];
+};
+__device__ __forceinline__ void strip_prefetch_combine(const StripP& p, StripEpi& e, int m0, int n0, int lane) {
+    // ·GELU'(aux) / += C epilogues: the 16-byte pieces this lane will combine with are fetched before the MFMA loop
+    // (whole 128-byte row segments) and used after it
+    if (e.fstage) {
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = min(m0 + ix * 16 + q * 8 + (lane >> 3), p.M - 1);
+                const long idx = (long)m * p.ldc + n0 + (lane & 7) * 8;
+                if (p.epi.flags & EDGL_EPI_MUL_DGELU) e.pre_aux[ix][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.epi.aux) + idx);
+                if (p.epi.flags & EDGL_EPI_ACCUM) e.pre_c[ix][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.C) + idx);
+            }
+    }
+}
+__device__ __forceinline__ void strip_epilogue(const StripP& p, StripEpi& e, f32x4 (&acc)[4][2], int m0, int n0, int lane) {
+    constexpr int LDO = 64 + 8, LDOF = 64 + 4;
+    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+    bf16* const Ostage = e.Ostage;
+    float* const OstageF = e.OstageF;
+    if (p.dbg & 1) return;
+    if (e.staged) {
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix) {
+#pragma unroll
+            for (int jz = 0; jz < 4; ++jz) {
+                const int n = n0 + jz * 16 + g4;
+                float x[4] = {acc[jz][ix][0], acc[jz][ix][1], acc[jz][ix][2], acc[jz][ix][3]};
+                {   // bias from the LDS copy: a global load here would put one memory round trip per tile on the
+                    // critical path of the epilogue
+                    const float4 bb = *reinterpret_cast<const float4*>(e.bias64 + jz * 16 + g4);
+                    x[0] += bb.x; x[1] += bb.y; x[2] += bb.z; x[3] += bb.w;
+                }
+                if (p.epi.flags & EDGL_EPI_SAVE_PRE) {   // pre-activation image (2 GEMMs per step)
+                    const int m = m0 + ix * 16 + l15;
+                    if (m < p.M) {
+                        Frag4<bf16> f = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.epi.aux) + (long)m * p.ldc + n) = *reinterpret_cast<uint2*>(&f);
+                    }
+                }
+                if (p.epi.flags & EDGL_EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+                }
+                Frag4<bf16> f = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
+                *reinterpret_cast<uint2*>(Ostage + l15 * LDO + jz * 16 + g4) = *reinterpret_cast<uint2*>(&f);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // 16 rows x 128 B: 8 lanes per row, 8 rows per instruction, 2 instructions
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int lrow = q * 8 + (lane >> 3), cv = lane & 7, m = m0 + ix * 16 + lrow;
+                const uint4 d = *reinterpret_cast<const uint4*>(Ostage + lrow * LDO + cv * 8);
+                if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n0 + cv * 8) = d;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else if (e.fstage) {
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix) {
+#pragma unroll
+            for (int jz = 0; jz < 4; ++jz) {
+                const float4 bb = *reinterpret_cast<const float4*>(e.bias64 + jz * 16 + g4);
+                *reinterpret_cast<float4*>(OstageF + l15 * LDOF + jz * 16 + g4) =
+                    make_float4(acc[jz][ix][0] + bb.x, acc[jz][ix][1] + bb.y, acc[jz][ix][2] + bb.z, acc[jz][ix][3] + bb.w);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int lrow = q * 8 + (lane >> 3), cv = lane & 7, m = m0 + ix * 16 + lrow;
+                const float4 lo = *reinterpret_cast<const float4*>(OstageF + lrow * LDOF + cv * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(OstageF + lrow * LDOF + cv * 8 + 4);
+                float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (p.epi.flags & EDGL_EPI_MUL_DGELU) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(&e.pre_aux[ix][q]);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) x[r] *= dgelu_f(to_f32(a[r]));
+                }
+                if (p.epi.flags & EDGL_EPI_ACCUM) {
+                    const bf16x8 o = *reinterpret_cast<const bf16x8*>(&e.pre_c[ix][q]);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) x[r] += to_f32(o[r]);
+                }
+                const Frag4<bf16> f0 = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
+                const Frag4<bf16> f1 = frag_from_acc<bf16>(f32x4{x[4], x[5], x[6], x[7]});
+                uint4 d;
+                *reinterpret_cast<uint2*>(&d) = *reinterpret_cast<const uint2*>(&f0);
+                *(reinterpret_cast<uint2*>(&d) + 1) = *reinterpret_cast<const uint2*>(&f1);
+                if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n0 + cv * 8) = d;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+#pragma unroll
+        for (int ix = 0; ix < 2; ++ix) {
+            const int m = m0 + ix * 16 + l15;
+            if (m < p.M) {
+#pragma unroll
+                for (int jz = 0; jz < 4; ++jz) {
+                    const int n = n0 + jz * 16 + g4;
+                    float x[4] = {acc[jz][ix][0], acc[jz][ix][1], acc[jz][ix][2], acc[jz][ix][3]};
+                    epi_store4(p.epi, reinterpret_cast<bf16*>(p.C), p.C, (long)m * p.ldc + n, n, x);
+                }
+            }
+        }
+    }
+}
+
 // Weights-resident strip GEMM.  A workgroup (8 waves) loads ONE column slice of B (<= 128 output columns, all K)
 // into LDS once, then its waves independently walk 32-row strips of A: strip fragments -> registers, MFMA against
 // the LDS-resident weights, epilogue, next strip.  There is no barrier and no shared traffic in the main loop, so
@@ -153,6 +271,8 @@ __global__ __launch_bounds__(W_NT) void strip_gemm_kernel(StripP p) {
 main_loop:
     PH_MARK(0);   // weight slice staged
     const bool staged = !(p.epi.flags & EDGL_EPI_OUT_F32) && !fstage;
+    StripEpi se;
+    se.Ostage = Ostage; se.OstageF = OstageF; se.staged = staged; se.fstage = fstage;
     const int nstrip = (p.M + 31) / 32;
     for (int strip = blockIdx.x * 8 + wave; strip < nstrip; strip += gridDim.x * 8) {
         const int m0 = strip * 32;
@@ -182,20 +302,7 @@ main_loop:
             f32x4 acc[4][2];
 #pragma unroll
             for (int jz = 0; jz < 4; ++jz) { acc[jz][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[jz][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            // ·GELU'(aux) / += C epilogues: the 16-byte pieces this lane will combine with are fetched now (whole 128-byte
-            // row segments) and used after the MFMA loop
-            uint4 pre_aux[2][2], pre_c[2][2];
-            if (fstage) {
-#pragma unroll
-                for (int ix = 0; ix < 2; ++ix)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int m = min(m0 + ix * 16 + q * 8 + (lane >> 3), p.M - 1);
-                        const long idx = (long)m * p.ldc + nbase + nc + (lane & 7) * 8;
-                        if (p.epi.flags & EDGL_EPI_MUL_DGELU) pre_aux[ix][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.epi.aux) + idx);
-                        if (p.epi.flags & EDGL_EPI_ACCUM) pre_c[ix][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16*>(p.C) + idx);
-                    }
-            }
+            strip_prefetch_combine(p, se, m0, nbase + nc, lane);
             if (!(p.dbg & 2))
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
@@ -209,100 +316,115 @@ main_loop:
                 }
             }
             PH_MARK(2);   // MFMA loop (incl. the wait for the strip)
-            const int n0 = nbase + nc;
-            // ---- epilogue.  acc[jz][ix] = L(first = n, second = m): a lane holds 4 consecutive n of one row, which
-            //      would make every global store a 16-row x 32-byte scatter.  Simple epilogues (bias / GELU / cast)
-            //      therefore go through a wave-private LDS image and leave as whole 128-byte row segments.
-            if (p.dbg & 1) continue;
-            if (staged) {
-#pragma unroll
-                for (int ix = 0; ix < 2; ++ix) {
-#pragma unroll
-                    for (int jz = 0; jz < 4; ++jz) {
-                        const int n = n0 + jz * 16 + g4;
-                        float x[4] = {acc[jz][ix][0], acc[jz][ix][1], acc[jz][ix][2], acc[jz][ix][3]};
-                        {   // bias from the LDS copy: a global load here would put one memory round trip per tile on the
-                            // critical path of the epilogue
-                            const float4 bb = *reinterpret_cast<const float4*>(biasS + nc + jz * 16 + g4);
-                            x[0] += bb.x; x[1] += bb.y; x[2] += bb.z; x[3] += bb.w;
-                        }
-                        if (p.epi.flags & EDGL_EPI_SAVE_PRE) {   // pre-activation image (2 GEMMs per step)
-                            const int m = m0 + ix * 16 + l15;
-                            if (m < p.M) {
-                                Frag4<bf16> f = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
-                                *reinterpret_cast<uint2*>(reinterpret_cast<bf16*>(p.epi.aux) + (long)m * p.ldc + n) = *reinterpret_cast<uint2*>(&f);
-                            }
-                        }
-                        if (p.epi.flags & EDGL_EPI_GELU) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
-                        }
-                        Frag4<bf16> f = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
-                        *reinterpret_cast<uint2*>(Ostage + l15 * LDO + jz * 16 + g4) = *reinterpret_cast<uint2*>(&f);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    // 16 rows x 128 B: 8 lanes per row, 8 rows per instruction, 2 instructions
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int lrow = q * 8 + (lane >> 3), cv = lane & 7, m = m0 + ix * 16 + lrow;
-                        const uint4 d = *reinterpret_cast<const uint4*>(Ostage + lrow * LDO + cv * 8);
-                        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n0 + cv * 8) = d;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            } else if (fstage) {
-#pragma unroll
-                for (int ix = 0; ix < 2; ++ix) {
-#pragma unroll
-                    for (int jz = 0; jz < 4; ++jz) {
-                        const float4 bb = *reinterpret_cast<const float4*>(biasS + nc + jz * 16 + g4);
-                        *reinterpret_cast<float4*>(OstageF + l15 * LDOF + jz * 16 + g4) =
-                            make_float4(acc[jz][ix][0] + bb.x, acc[jz][ix][1] + bb.y, acc[jz][ix][2] + bb.z, acc[jz][ix][3] + bb.w);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int lrow = q * 8 + (lane >> 3), cv = lane & 7, m = m0 + ix * 16 + lrow;
-                        const float4 lo = *reinterpret_cast<const float4*>(OstageF + lrow * LDOF + cv * 8);
-                        const float4 hi = *reinterpret_cast<const float4*>(OstageF + lrow * LDOF + cv * 8 + 4);
-                        float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                        if (p.epi.flags & EDGL_EPI_MUL_DGELU) {
-                            const bf16x8 a = *reinterpret_cast<const bf16x8*>(&pre_aux[ix][q]);
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) x[r] *= dgelu_f(to_f32(a[r]));
-                        }
-                        if (p.epi.flags & EDGL_EPI_ACCUM) {
-                            const bf16x8 o = *reinterpret_cast<const bf16x8*>(&pre_c[ix][q]);
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) x[r] += to_f32(o[r]);
-                        }
-                        const Frag4<bf16> f0 = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
-                        const Frag4<bf16> f1 = frag_from_acc<bf16>(f32x4{x[4], x[5], x[6], x[7]});
-                        uint4 d;
-                        *reinterpret_cast<uint2*>(&d) = *reinterpret_cast<const uint2*>(&f0);
-                        *(reinterpret_cast<uint2*>(&d) + 1) = *reinterpret_cast<const uint2*>(&f1);
-                        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n0 + cv * 8) = d;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            } else {
-#pragma unroll
-                for (int ix = 0; ix < 2; ++ix) {
-                    const int m = m0 + ix * 16 + l15;
-                    if (m < p.M) {
-#pragma unroll
-                        for (int jz = 0; jz < 4; ++jz) {
-                            const int n = n0 + jz * 16 + g4;
-                            float x[4] = {acc[jz][ix][0], acc[jz][ix][1], acc[jz][ix][2], acc[jz][ix][3]};
-                            epi_store4(p.epi, reinterpret_cast<bf16*>(p.C), p.C, (long)m * p.ldc + n, n, x);
-                        }
-                    }
-                }
-            }
+            se.bias64 = biasS + nc;
+            strip_epilogue(p, se, acc, m0, nbase + nc, lane);
             PH_MARK(3);   // epilogue
         }
+    }
+    PH_FLUSH(0);
+}
+
+// Activations-in-registers, weights-streamed variant for wide outputs (N >= 3 column slices).  The weights-resident
+// kernel above makes every column slice re-read all of A (the dominant cost once A no longer fits the L2 working set:
+// 4 x 40 MB for the QKVT projection); here a workgroup owns 256 rows — 8 waves x one 32-row strip held in registers for
+// the whole kernel — and walks ALL output columns in 64-column chunks of the weights, double-buffered through LDS (the
+// weights are small and L2-resident, so re-reading THEM per workgroup is cheap).  One LDS-scoped barrier per chunk.
+template <int NKB, bool B_KC>
+__global__ __launch_bounds__(W_NT) void strip_stream_kernel(StripP p) {
+    constexpr int K = 32 * NKB;
+    constexpr int NCH = 64;                 // output columns per chunk
+    constexpr int LDW_KC = K + 16;          // [NCH][K+16]
+    constexpr int LDW_TR = NCH + 16;        // [K][NCH+16]
+    constexpr int CELEMS = B_KC ? NCH * LDW_KC : K * LDW_TR;
+    constexpr int LDO = 64 + 8, LDOF = 64 + 4;
+    constexpr int TOTAL = B_KC ? NCH * (K / 8) : K * (NCH / 8);   // 16-byte pieces per chunk
+    constexpr int ITER = (TOTAL + W_NT - 1) / W_NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    PH_DECL
+    bf16* const Wbuf = reinterpret_cast<bf16*>(smem);              // [2][CELEMS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, g4 = G * 4, l15 = lane & 15;
+    float* const biasS = reinterpret_cast<float*>(Wbuf + 2 * CELEMS);   // [N] (zeros if none)
+    const int nb4 = (p.N + 3) / 4 * 4;
+    bf16* const stage0 = reinterpret_cast<bf16*>(biasS + nb4);
+    const bool fstage = (p.epi.flags & (EDGL_EPI_ACCUM | EDGL_EPI_MUL_DGELU)) && !(p.epi.flags & EDGL_EPI_OUT_F32);
+    StripEpi se;
+    se.Ostage = stage0 + wave * 16 * LDO;
+    se.OstageF = reinterpret_cast<float*>(stage0) + wave * 16 * LDOF;
+    se.fstage = fstage;
+    se.staged = !(p.epi.flags & EDGL_EPI_OUT_F32) && !fstage;
+    for (int i = tid; i < p.N; i += W_NT) biasS[i] = (p.epi.flags & EDGL_EPI_BIAS) ? p.epi.bias[i] : 0.f;
+
+    // chunk loader: global -> registers (unconditional, coalesced 16-byte pieces) ... -> LDS
+    uint4 wreg[ITER];
+    auto load_chunk = [&](int nc) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int v = min(tid + i * W_NT, TOTAL - 1);
+            if constexpr (B_KC) wreg[i] = *reinterpret_cast<const uint4*>(p.B + (long)(nc + v / (K / 8)) * p.ldb + (v % (K / 8)) * 8);
+            else wreg[i] = *reinterpret_cast<const uint4*>(p.B + (long)(v / (NCH / 8)) * p.ldb + nc + (v % (NCH / 8)) * 8);
+        }
+    };
+    auto store_chunk = [&](bf16* W) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int v = tid + i * W_NT;
+            if (v < TOTAL) {
+                if constexpr (B_KC) *reinterpret_cast<uint4*>(W + (v / (K / 8)) * LDW_KC + (v % (K / 8)) * 8) = wreg[i];
+                else *reinterpret_cast<uint4*>(W + (v / (NCH / 8)) * LDW_TR + (v % (NCH / 8)) * 8) = wreg[i];
+            }
+        }
+    };
+    load_chunk(0);
+    // ---- this wave's strip of A: registers, for the whole kernel -------------------------------------------------------
+    const int m0 = (blockIdx.x * 8 + wave) * 32;
+    bf16x8 xf[2][NKB];
+#pragma unroll
+    for (int ix = 0; ix < 2; ++ix) {
+        const int m = min(m0 + ix * 16 + l15, p.M - 1);   // clamped: rows past M are never stored
+        const bf16* row = p.A + (long)m * p.lda;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            bf16x8 f;
+            if constexpr (B_KC) {
+                *reinterpret_cast<uint4*>(&f) = *reinterpret_cast<const uint4*>(row + kb * 32 + G * 8);
+            } else {
+                *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<const uint2*>(row + kb * 32 + g4);
+                *(reinterpret_cast<uint2*>(&f) + 1) = *reinterpret_cast<const uint2*>(row + kb * 32 + 16 + g4);
+            }
+            xf[ix][kb] = f;
+        }
+    }
+    store_chunk(Wbuf);
+    lds_barrier();
+    PH_MARK(4);   // prologue: strip + first chunk
+    const int nchunks = p.N / NCH;
+    for (int c = 0; c < nchunks; ++c) {
+        const int nc = c * NCH;
+        const bf16* Ws = Wbuf + (c & 1) * CELEMS;
+        strip_prefetch_combine(p, se, m0, nc, lane);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int jz = 0; jz < 4; ++jz) { acc[jz][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[jz][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int jz = 0; jz < 4; ++jz) {
+                bf16x8 zf;
+                if constexpr (B_KC) zf = *reinterpret_cast<const bf16x8*>(Ws + (jz * 16 + l15) * LDW_KC + kb * 32 + G * 8);
+                else zf = tr_frag32(Ws, LDW_TR, kb * 32, jz * 16, lane);
+                acc[jz][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[0][kb], acc[jz][0], 0, 0, 0);
+                acc[jz][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zf, xf[1][kb], acc[jz][1], 0, 0, 0);
+            }
+        }
+        PH_MARK(5);   // MFMA loop issue
+        if (c + 1 < nchunks) load_chunk(nc + NCH);          // next chunk's pieces fly during the epilogue (issuing them
+                                                            // before the MFMA loop costs 24-32 more live registers)
+        se.bias64 = biasS + nc;
+        strip_epilogue(p, se, acc, m0, nc, lane);
+        PH_MARK(6);   // MFMA drain + epilogue
+        if (c + 1 < nchunks) store_chunk(Wbuf + ((c + 1) & 1) * CELEMS);   // that buffer was last read in iteration c - 1
+        lds_barrier();
+        PH_MARK(7);   // next chunk -> LDS, barrier
     }
     PH_FLUSH(0);
 }
@@ -406,6 +528,21 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
 using namespace gemm2;
 
 template <int NKB, bool B_KC>
+static int launch_stream(const StripP& p, hipStream_t st) {
+    constexpr int K = 32 * NKB;
+    constexpr size_t cel = B_KC ? (size_t)64 * (K + 16) : (size_t)K * (64 + 16);
+    const bool fstage = (p.epi.flags & (EDGL_EPI_ACCUM | EDGL_EPI_MUL_DGELU)) && !(p.epi.flags & EDGL_EPI_OUT_F32);
+    const size_t smem = 2 * cel * sizeof(bf16) + (size_t)((p.N + 3) / 4 * 4) * sizeof(float) +
+                        (fstage ? (size_t)8 * 16 * (64 + 4) * sizeof(float) : (size_t)8 * 16 * (64 + 8) * sizeof(bf16));
+    if (smem > 160 * 1024) return 0;
+    auto k = strip_stream_kernel<NKB, B_KC>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k, dim3((p.M + 255) / 256), dim3(W_NT), smem, st, p);
+    EDGL_LAUNCH_CHECK();
+    return 1;
+}
+
+template <int NKB, bool B_KC>
 static int launch_strip(const StripP& p, hipStream_t st) {
     constexpr int K = 32 * NKB;
     constexpr size_t wel = B_KC ? (size_t)128 * (K + 16) : (size_t)K * (128 + 16);
@@ -434,6 +571,13 @@ int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, in
     static const int dbg = getenv("EDGL_DBG") ? atoi(getenv("EDGL_DBG")) : 0;
     StripP p{(const bf16*)A, (const bf16*)B, C, M, N, K, lda, ldb, ldc, EpiP{bias, aux, flags}, dbg};
     int rc;
+    static const int stream_min_n = getenv("EDGL_GEMM_STREAM_N") ? atoi(getenv("EDGL_GEMM_STREAM_N")) : 384;
+    if (N >= stream_min_n && (K == 384 || K == 512) && M >= 4096) {   // A would be re-read by >= 3 column slices
+        rc = 0;
+        if (K == 384) rc = b_kc ? launch_stream<12, true>(p, st) : launch_stream<12, false>(p, st);
+        else rc = b_kc ? launch_stream<16, true>(p, st) : launch_stream<16, false>(p, st);
+        if (rc) return rc;
+    }
 #define STRIP_CASE(NKB)                                                             \
     case NKB: rc = b_kc ? launch_strip<NKB, true>(p, st) : launch_strip<NKB, false>(p, st); break;
     switch (K / 32) {

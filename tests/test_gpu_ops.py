@@ -41,6 +41,47 @@ def test_gemm_layouts(name, dt, tol, a_kc, b_kc, M, N, K):
     assert_close(got.cpu().numpy(), want, 2e-6 if name == "f32" else 1e-5, f"gemm {name} {a_kc}{b_kc}")
 
 
+@pytest.mark.parametrize("b_kc", [0, 1])
+@pytest.mark.parametrize("M,N,K,flags", [(4100, 512, 384, "bias"), (4352, 384, 512, "plain"), (4100, 384, 384, "gelu"),
+                                         (4100, 512, 512, "accum"), (300, 128, 128, "dgelu"), (5000, 256, 128, "accum")])
+def test_gemm_bf16_activation_kernels(b_kc, M, N, K, flags):
+    """bf16 dense fast paths at sizes that reach them: weights-resident strips, the weights-streamed kernel for wide
+    outputs (M >= 4096, K in {384, 512}, N >= 384), and the fused epilogues (bias, GELU + saved pre-activation,
+    x GELU'(aux), += C)."""
+    o = ops()
+    rng = np.random.default_rng(M + N + K + b_kc)
+    dt = torch.bfloat16
+    A = torch.tensor(_rand((M, K), rng), dtype=dt).cuda()
+    W = torch.tensor(_rand((K, N), rng, 0.05), dtype=dt).cuda()
+    Wt = W.t().contiguous() if b_kc else W
+    bias = torch.tensor(_rand((N,), rng), dtype=torch.float32).cuda()
+    ref = A.double().cpu() @ W.double().cpu()
+    from easydgl_amd import _lib as L
+    if flags == "bias":
+        got = o.gemm(A, Wt, M, N, K, K, Wt.stride(0), True, bool(b_kc), dt, bias=bias, flags=L.EPI_BIAS)
+        want = ref + bias.double().cpu()
+    elif flags == "plain":
+        got = o.gemm(A, Wt, M, N, K, K, Wt.stride(0), True, bool(b_kc), dt)
+        want = ref
+    elif flags == "gelu":
+        pre = torch.empty((M, N), dtype=dt, device="cuda")
+        got = o.gemm(A, Wt, M, N, K, K, Wt.stride(0), True, bool(b_kc), dt, bias=bias, aux=pre, flags=L.EPI_BIAS | L.EPI_GELU | L.EPI_SAVE_PRE)
+        z = ref + bias.double().cpu()
+        want = R.gelu(z)
+        assert_close(pre.float().cpu().numpy(), z.numpy(), 1e-2, "saved pre-activation")
+    elif flags == "dgelu":
+        aux = torch.tensor(_rand((M, N), rng), dtype=dt).cuda()
+        got = o.gemm(A, Wt, M, N, K, K, Wt.stride(0), True, bool(b_kc), dt, aux=aux, flags=L.EPI_MUL_DGELU)
+        a64 = aux.double().cpu().requires_grad_()
+        R.gelu(a64).sum().backward()
+        want = ref * a64.grad
+    else:
+        c0 = torch.tensor(_rand((M, N), rng), dtype=dt).cuda()
+        got = o.gemm(A, Wt, M, N, K, K, Wt.stride(0), True, bool(b_kc), dt, flags=L.EPI_ACCUM, out=c0.clone())
+        want = ref + c0.double().cpu()
+    assert_close(got.float().cpu().numpy(), want.detach().numpy(), 1.2e-2, f"bf16 gemm {flags} b_kc={b_kc}")
+
+
 @pytest.mark.parametrize("name,dt,tol", DTYPES)
 def test_gemm_epilogues_and_splitk(name, dt, tol):
     o = ops()

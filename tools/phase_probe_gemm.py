@@ -30,8 +30,10 @@ for _ in range(n):
 e1.record()
 torch.cuda.synchronize()
 raw.edgl_debug_phase_cycles_gemm(buf, 0)
-names = ["weight slice -> LDS", "strip loads issued", "MFMA loop (+ strip wait)", "epilogue"]
-tot = sum(buf[:4])
+names = ["resident: weight slice -> LDS", "resident: strip loads issued", "resident: MFMA loop (+ strip wait)", "resident: epilogue",
+         "stream: prologue (strip + chunk 0)", "stream: MFMA loop issue", "stream: MFMA drain + epilogue", "stream: chunk -> LDS + barrier"]
+tot = sum(buf[:8]) or 1
 for i, nm in enumerate(names):
-    print(f"{nm:28s} {buf[i] / n:16.0f} wave-cycles/launch  {100.0 * buf[i] / tot:5.1f}%")
+    if buf[i]:
+        print(f"{nm:36s} {buf[i] / n:16.0f} wave-cycles/launch  {100.0 * buf[i] / tot:5.1f}%")
 print(f"launch time {e0.elapsed_time(e1) / n * 1e3:.1f} us (instrumented)")
