@@ -27,6 +27,8 @@ SIGNATURES = {
     "edgl_version": (I, []),
     "edgl_profile_next": (I, [I, P, P]),
     "edgl_rng_advance": (I, [P, P]),
+    "edgl_mask_random": (I, [P, I, I, I, I64, P, U32, P, P, P, P]),
+    "edgl_mask_last": (I, [P, I, I, I64, P, P]),
     "edgl_encode_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I64, F, F, P, U32, P, P, P, I, P]),
     "edgl_encode_bwd_workspace": (L, [I, I, I]),
     "edgl_encode_bwd": (I, [P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libeasydgl_hip.so")
-SOURCES = ["k_misc.hip", "k_encode.hip", "k_gemm.hip", "k_gemm2.hip", "k_layernorm.hip", "k_bimau_fwd.hip", "k_bimau_bwd.hip",
+SOURCES = ["k_misc.hip", "k_data.hip", "k_encode.hip", "k_gemm.hip", "k_gemm2.hip", "k_layernorm.hip", "k_bimau_fwd.hip", "k_bimau_bwd.hip",
            "k_score.hip"]
 HEADERS = ["edgl_common.h", "gemm_tile.h", "bimau_common.h", os.path.join("..", "..", "include", "easydgl_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]

@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
             const Frag4<T> apT = frag_from_acc<T>(transpose_tile<T>(ap, ident));  // L(first=q, second=k)
 #pragma unroll
             for (int vt = 0; vt < DT; ++vt) dVa[vt][kt] = mma16(dOT[vt], apT, dVa[vt][kt]);
+            if (kt & 1) __builtin_amdgcn_sched_barrier(0);   // at most two key tiles' temporaries interleaved
         }
         PH_MARK(1);
         // ---- dlambda -> dz, dscaling; row term --------------------------------------------------------------------

@@ -33,6 +33,34 @@ def mask_random(tokens: torch.Tensor, timestamps: torch.Tensor, mask_id: int, ma
     return {"seqs_i": masked, "seqs_t": timestamps, "masked_positions": masked_positions}, labels
 
 
+def device_mask_random(tokens: torch.Tensor, timestamps: torch.Tensor, mask_id: int, masklen: int, rng_state: torch.Tensor,
+                       stream_id: int = 0x4d41534b):
+    """MAUPostProcessor.mask_random for a whole device batch in ONE kernel (edgl_mask_random): draws `masklen`
+    distinct positions in [1, T) per row from the counter-based generator keyed on `rng_state` (uint64[2] = seed,
+    step — advance the step between batches), replaces the tokens by MASK and gathers the labels."""
+    from . import ops
+    from ._lib import check, lib
+    tokens = tokens.contiguous()
+    B, T = tokens.shape
+    masked = torch.empty_like(tokens)
+    mpos = torch.empty((B, masklen), device=tokens.device, dtype=torch.int64)
+    labels = torch.empty((B, masklen), device=tokens.device, dtype=torch.int64)
+    check(lib.edgl_mask_random(ops._ptr(tokens), B, T, masklen, int(mask_id), ops._ptr(rng_state), stream_id,
+                               ops._ptr(masked), ops._ptr(mpos), ops._ptr(labels), ops._stream()), "edgl_mask_random")
+    return {"seqs_i": masked, "seqs_t": timestamps, "masked_positions": mpos}, labels
+
+
+def device_mask_last(tokens: torch.Tensor, timestamps: torch.Tensor, mask_id: int):
+    """MAUPostProcessor.mask_last on the device (edgl_mask_last)."""
+    from . import ops
+    from ._lib import check, lib
+    tokens = tokens.contiguous()
+    B, T = tokens.shape
+    masked = torch.empty_like(tokens)
+    check(lib.edgl_mask_last(ops._ptr(tokens), B, T, int(mask_id), ops._ptr(masked), ops._stream()), "edgl_mask_last")
+    return {"seqs_i": masked, "seqs_t": timestamps}, tokens
+
+
 def synthetic_batch(num_items: int, seqslen: int, batch: int, seed: int = 9876, min_len: int = 5):
     """SURVEY.md §8d synthetic sequences: row length ~ U{min_len..T}, left zero padding, Zipf(1.1) item ids
     clipped to [1, num_items-1], float32 timestamps 9.5e8 + cumsum(Exp(mean 3 days)).  T = seqslen + 1."""

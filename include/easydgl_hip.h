@@ -61,6 +61,17 @@ int edgl_profile_next(int kernel_id, void* ev_start, void* ev_stop);
 /* rng_state[1] += 1 on the device (one launch per training step, graph-capturable). */
 int edgl_rng_advance(uint64_t* rng_state, void* stream);
 
+/* ---- K0: batch construction — MAUPostProcessor, dataloader.py:159-206 (choice: :34-36) -----------
+ * tokens int64 [B,T] (T = seqslen + 1).  edgl_mask_random: per row `masklen` = M DISTINCT positions
+ * drawn uniformly from [1, T) (ignore_head = 1, dataloader.py:183-186) by a counter-based generator
+ * keyed on (rng_state, stream_id, row); masked_tokens = tokens with MASK = mask_id at those positions
+ * (:188-193), masked_pos int64 [B,M], labels int64 [B,M] = the original tokens there (:194-201).
+ * edgl_mask_last: evaluation batches — position T-1 := MASK (:166-179); labels are the input tokens. */
+int edgl_mask_random(const int64_t* tokens, int B, int T, int M, int64_t mask_id, const uint64_t* rng_state,
+                     uint32_t stream_id, int64_t* masked_tokens, int64_t* masked_pos, int64_t* labels,
+                     void* stream);
+int edgl_mask_last(const int64_t* tokens, int B, int T, int64_t mask_id, int64_t* masked_tokens, void* stream);
+
 /* ---- K1: input encoding — EasyDGL.py:70-95, coding.py:60-64,76-79,137-149 ---------------------
  * x0[b,t,:]   = [ item_tab[id]*sqrt(C) + sincos(ts/time_scale) | pos_tab[t] | nmarks*mark_emb[1] ]
  *               followed by hidden dropout (EasyDGL.py:92);

@@ -124,3 +124,40 @@ def test_sharded_eval_matches_unsharded(shards):
     v1, i1 = m.eval_topk_sharded(ef, mask_seen=True, world=shards)
     assert torch.equal(i0, i1)
     assert torch.allclose(v0, v1, rtol=0, atol=0)
+
+
+def test_device_masker_matches_reference_semantics():
+    """edgl_mask_random / edgl_mask_last against MAUPostProcessor's contract (dataloader.py:159-206): M distinct
+    positions in [1, T), token := MASK there, labels = original tokens, everything else untouched; the oracle's
+    mask_random reproduces the batch given the drawn positions; draws differ between steps and rows."""
+    from easydgl_amd import data as D
+    rng = np.random.default_rng(5)
+    B, T, M, mask_id = 64, 31, 6, 1000
+    tok = torch.tensor(rng.integers(0, 1000, size=(B, T)), dtype=torch.int64).cuda()
+    ts = torch.tensor(rng.random((B, T)), dtype=torch.float32).cuda()
+    state = torch.tensor([1234, 0], dtype=torch.int64).cuda()
+    feats, labels = D.device_mask_random(tok, ts, mask_id, M, state)
+    mp = feats["masked_positions"].cpu().numpy()
+    assert mp.shape == (B, M) and mp.min() >= 1 and mp.max() <= T - 1
+    assert all(len(set(r)) == M for r in mp)
+    cfg = O.Config(num_items=mask_id, num_units=8, num_heads=2, num_blocks=1, seqslen=T - 1, masklen=M, num_events=2)
+    want_f, want_l = O.mask_random(cfg, tok.cpu().numpy(), ts.cpu().numpy(), mp)
+    np.testing.assert_array_equal(feats["seqs_i"].cpu().numpy(), want_f["seqs_i"])
+    np.testing.assert_array_equal(labels.cpu().numpy(), want_l)
+    # same state -> same draw; next step -> a different one; positions are spread over [1, T)
+    f2, _ = D.device_mask_random(tok, ts, mask_id, M, state)
+    assert torch.equal(f2["masked_positions"], feats["masked_positions"])
+    state2 = torch.tensor([1234, 1], dtype=torch.int64).cuda()
+    f3, _ = D.device_mask_random(tok, ts, mask_id, M, state2)
+    assert not torch.equal(f3["masked_positions"], feats["masked_positions"])
+    big, _ = D.device_mask_random(tok.repeat(64, 1), ts.repeat(64, 1), mask_id, M, state)
+    hist = np.bincount(big["masked_positions"].cpu().numpy().ravel(), minlength=T)[1:]
+    expect = 64 * B * M / (T - 1)
+    assert hist.min() > 0.85 * expect and hist.max() < 1.15 * expect and hist.sum() == 64 * B * M
+    # full-length mask: every position in [1, T)
+    full, _ = D.device_mask_random(tok, ts, mask_id, T - 1, state)
+    assert (np.sort(full["masked_positions"].cpu().numpy(), axis=1) == np.arange(1, T)).all()
+    fe, le = D.device_mask_last(tok, ts, mask_id)
+    we, wl = O.mask_last(cfg, tok.cpu().numpy(), ts.cpu().numpy())
+    np.testing.assert_array_equal(fe["seqs_i"].cpu().numpy(), we["seqs_i"])
+    np.testing.assert_array_equal(le.cpu().numpy(), wl)
