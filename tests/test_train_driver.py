@@ -1,0 +1,65 @@
+"""Train/eval driver (easydgl_amd/train.py): EarlyStopping restates util.py:14-58 decision for decision (CPU); one
+tiny end-to-end run on the GPU from TFRecord files + a pickled csr mark table."""
+import math
+import pickle
+
+import numpy as np
+import pytest
+
+from easydgl_amd import formats as F
+from easydgl_amd.train import EarlyStopping
+
+
+def _m(h):
+    return {"H10": h / 2, "H50": h * 0.8, "H100": h, "N10": h / 4, "N50": h / 3, "N100": h / 2.5}
+
+
+def test_early_stopping_follows_reference_decisions():
+    saved = []
+    st = EarlyStopping("EasyDGL", patience=3, saver=lambda: saved.append(1))
+    # first evaluation: reference point, nothing saved (util.py:31-35)
+    assert not st.step(1.0, 0.10, _m(0.10), _m(0.20))
+    assert st.res == _m(0.20) and not saved
+    # better acc: counter reset, checkpoint saved, test metrics refreshed where valid >= FIRST valid (util.py:41-49)
+    assert not st.step(0.9, 0.12, _m(0.12), _m(0.25))
+    assert st.res == _m(0.25) and len(saved) == 1 and st.best_loss == 0.9
+    # equal acc counts as "not worse" (acc < best_acc is the only counting branch)
+    assert not st.step(0.95, 0.12, _m(0.12), _m(0.26))
+    assert st.counter == 0 and st.res == _m(0.26)
+    # worse acc x3 -> stop at patience (util.py:36-40); results untouched
+    assert not st.step(0.8, 0.11, _m(0.11), _m(0.9))
+    assert not st.step(0.8, 0.11, _m(0.11), _m(0.9))
+    assert st.step(0.8, 0.11, _m(0.11), _m(0.9))
+    assert st.early_stop and st.res == _m(0.26)
+    # best_valid is never refreshed: a metric that beats the FIRST validation value still
+    # refreshes even when it is below the best seen so far
+    st2 = EarlyStopping("EasyDGL", patience=3)
+    st2.step(1.0, 0.10, {"H100": 0.10, "N100": 0.05}, {"H100": 1.0, "N100": 1.0})
+    st2.step(1.0, 0.30, {"H100": 0.30, "N100": 0.30}, {"H100": 2.0, "N100": 2.0})
+    st2.step(1.0, 0.30, {"H100": 0.30, "N100": 0.06}, {"H100": 3.0, "N100": 3.0})
+    assert st2.res == {"H100": 3.0, "N100": 3.0}
+    # NaN loss stops immediately (util.py:29-30)
+    st3 = EarlyStopping("EasyDGL")
+    assert st3.step(float("nan"), 0.5, _m(0.5), _m(0.5)) and st3.res is None
+
+
+@pytest.mark.gpu
+def test_driver_end_to_end_from_tfrecords(tmp_path):
+    sp = pytest.importorskip("scipy.sparse")
+    from easydgl_amd import data as D
+    from easydgl_amd import train as TR
+    num_items, seqslen, E = 300, 20, 4
+    ids, ts = D.synthetic_batch(num_items, seqslen, 200, seed=3)
+    def dump(name, lo, hi):
+        F.write_tfrecord(str(tmp_path / name), [F.encode_example({"seqs_i": ids[i], "seqs_t": ts[i]}) for i in range(lo, hi)])
+    dump("train000.tfrec", 0, 70); dump("train001.tfrec", 70, 140); dump("validation.tfrec", 140, 170); dump("test.tfrec", 170, 200)
+    with open(tmp_path / "mark.pkl", "wb") as f:
+        pickle.dump(sp.csr_matrix(D.synthetic_mark_table(num_items, E).astype(np.int64)), f)
+    res = TR.main(["--model", "EasyDGL", "--train", str(tmp_path / "train*.tfrec"), "--valid", str(tmp_path / "validation.tfrec"),
+                   "--test", str(tmp_path / "test.tfrec"), "--num_items", str(num_items), "--num_units", "32", "--num_heads", "2",
+                   "--num_blocks", "1", "--seqslen", str(seqslen), "--masklen", "4", "--time_scale", "86400", "--mark",
+                   str(tmp_path / "mark.pkl"), "--ct_reg", "1e-7", "--batch_size", "64", "--num_epochs", "3", "--learning_rate",
+                   "1e-3", "--l2_reg", "1e-4", "--mask_seen", "--dtype", "f32", "--ckpt_dir", str(tmp_path / "ckpt")])
+    assert set(res) == {"H10", "H50", "H100", "N10", "N50", "N100"}
+    assert all(0.0 <= v <= 1.0 and math.isfinite(v) for v in res.values())
+    assert res["H10"] <= res["H50"] <= res["H100"]
