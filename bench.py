@@ -105,6 +105,71 @@ def cpu_baseline(c, budget_s=15.0):
                       f"oracle/torch_ref.py restatement of the TensorFlow graph (TF not installable offline)"}
 
 
+def encode_bench(args):
+    """K1 (EasyDGL.py:70-95) forward and backward alone at config 3: num_items 1M, seqslen 200 (T = 201), C = 256,
+    B = 512, E = 16, bf16.  Algorithmic bytes per SURVEY §8d: ids+ts in, gathered item rows, X0 out, spans+marks out,
+    position / mark tables.  One JSON line; `value` = forward GB/s."""
+    from easydgl_amd import data as D
+    from easydgl_amd import ops
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B, T, C, E, num_items = 512, 201, 256, 16, 1_000_000
+    I = num_items + 1
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    s = 2 if args.dtype == "bf16" else 4
+    ids_np, ts_np = D.synthetic_batch(num_items, T - 1, B, seed=9876)
+    ids, ts = torch.tensor(ids_np, device=dev), torch.tensor(ts_np, device=dev)
+    g = torch.Generator().manual_seed(1)
+    item = (torch.randn((I, C), generator=g) * 0.02).to(dev).requires_grad_()
+    pos = (torch.randn((T, C), generator=g) * 0.02).to(dev).requires_grad_()
+    mk = (torch.randn((E, C), generator=g) * 0.02).to(dev).requires_grad_()
+    item_c = item.detach().to(dt)
+    mtab = torch.tensor(D.synthetic_mark_table(num_items, E), device=dev)
+    tscale = ops.time_scales(C, dev) if hasattr(ops, "time_scales") else torch.pow(
+        torch.tensor(10000.0), 2.0 * torch.arange(C // 2, dtype=torch.float32) / C).to(dev)
+    drop = ops.NO_DROP
+
+    def fwd():
+        return ops.EncodeFn.apply(item, pos, mk, item_c, ids, ts, mtab, tscale, num_items, 86400.0, drop, dt)
+    x0, _, _ = fwd()
+    dx0 = torch.randn_like(x0)
+
+    def timed(fn, n):
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e-3
+
+    t_f = timed(lambda: fwd(), args.steps)
+
+    def bwd():
+        x, _, _ = fwd()
+        x.backward(dx0)
+    t_fb = timed(bwd, args.steps)
+    t_b = max(t_fb - t_f, 1e-9)
+    bytes_f = B * T * (8 + 4) + B * T * C * s + B * T * 3 * C * s + B * T * (4 + E) + T * C * 4 + E * C * 4
+    rows_touched = int((ids != 0).sum().item())
+    bytes_b = B * T * 3 * C * s + B * T * (8 + E) + rows_touched * C * 4 * 2 + T * C * 4 + E * C * 4
+    out = {"metric": "GB/s (K1 input encoding forward, |items|=1M L=200 d=256 B=512)", "value": round(bytes_f / t_f / 1e9, 1),
+           "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_f * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "K1 encode (item gather x sqrt(C) + sinusoidal time code + position + mark embeddings), "
+                                  "config 3: num_items 1000000, seqslen 200 (T=201), num_units 256, batch 512, 16 marks",
+                      "algorithmic_bytes_fwd": bytes_f, "algorithmic_bytes_bwd": bytes_b},
+           "roofline": {"bound": "hbm", "kernel": "encode_fwd_kernel", "achieved": round(bytes_f / t_f / 1e9, 1), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(bytes_f / t_f / 8e12, 4), "traffic": None},
+           "backward": {"ms": round(t_b * 1e3, 4), "achieved_GBps": round(bytes_b / t_b / 1e9, 1),
+                        "note": "encode_bwd + scatter into the touched rows of the [I, C] f32 table gradient (memset of the "
+                                "full table gradient excluded from the byte count, included in the time)"}}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,7 +181,13 @@ def main():
                     help="engine: static launch sequence issued eagerly (dominant kernel bracketed with HIP events); "
                          "graph: the same sequence replayed as one HIP graph; autograd: torch.autograd over the ops")
     ap.add_argument("--op-table", action="store_true", help="after the timed region, print a per-C-call time table to stderr")
+    ap.add_argument("--workload", default="step", choices=["step", "encode"],
+                    help="step: the headline optimizer step (default, the bench contract); encode: K1 input encoding "
+                         "(embedding gather + time code) alone at SURVEY §8d config 3 (|items| = 1M, L = 200, d = 256) — the "
+                         "HBM-bound regime, reported as GB/s against the HBM roofline")
     args = ap.parse_args()
+    if args.workload == "encode":
+        return encode_bench(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -16,11 +16,13 @@ struct EncP {
 
 template <typename T>
 __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
-    const int half = p.C >> 1;
+    // thread = 8 consecutive channels (4 sin/cos pairs) of one (b,t) row in all three C-wide sections: 16-byte item-row
+    // load, 16-byte (bf16) / 2 x 16-byte (f32) stores per section; C/8 threads share the row's id / timestamp / marks.
+    const int cpr = p.C >> 3;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long row = gid / half;
+    const long row = gid / cpr;
     if (row >= (long)p.B * p.T) return;
-    const int j = (int)(gid % half), c = 2 * j;
+    const int cv = (int)(gid % cpr), c0 = cv * 8, j0 = c0 >> 1;
     const int t = (int)(row % p.T);
     const int64_t id = p.ids[row];
     // EasyDGL.py:71 — float32 division (quantisation point shared with the oracle)
@@ -29,9 +31,19 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
     const int64_t mid = (id == p.mask_id) ? 0 : id;
     const uint8_t* mrow = p.mark_table + mid * p.E;
     int nm = 0;
-    for (int e = 0; e < p.E; ++e) nm += mrow[e];
-
-    if (j == 0) {
+    if (p.E == 16) {   // one 16-byte row: four v_sad_u8 instead of 16 dependent byte loads
+        const uint4 mv = *reinterpret_cast<const uint4*>(mrow);
+        nm = (int)__builtin_amdgcn_sad_u8(mv.x, 0u, 0u);
+        nm = (int)__builtin_amdgcn_sad_u8(mv.y, 0u, (uint32_t)nm);
+        nm = (int)__builtin_amdgcn_sad_u8(mv.z, 0u, (uint32_t)nm);
+        nm = (int)__builtin_amdgcn_sad_u8(mv.w, 0u, (uint32_t)nm);
+        if (cv == 0) *reinterpret_cast<uint4*>(p.marks + row * 16) = mv;
+    } else {
+        for (int e = 0; e < p.E; ++e) nm += mrow[e];
+        if (cv == 0)
+            for (int e = 0; e < p.E; ++e) p.marks[row * p.E + e] = mrow[e];
+    }
+    if (cv == 0) {
         // EasyDGL.py:73-74 — span[t] = clip(ts[t]-ts[t-1], 0, 100); span[0] := span[1]
         const int t1 = (t == 0) ? 1 : t;
         float sp = 0.f;
@@ -42,34 +54,68 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
         }
         p.spans[row] = sp;
     }
-    if (j < p.E) p.marks[row * p.E + j] = mrow[j];
-    if (j == 0 && half < p.E)
-        for (int e = half; e < p.E; ++e) p.marks[row * p.E + e] = mrow[e];
-
+    float v[3][8];
     // coding.py:141-145 — x / scale (float32 division), sin on even / cos on odd channels
-    const float arg = tsx / p.tscale[j];
-    float sn, cs;
-    sincosf(arg, &sn, &cs);
-    float e0 = 0.f, e1 = 0.f;
-    if (id != 0) {  // coding.py:56-57 zero-padded row 0
-        const T* it = reinterpret_cast<const T*>(p.item_tab) + id * p.C + c;
-        e0 = to_f32(it[0]); e1 = to_f32(it[1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float arg = tsx / p.tscale[j0 + q];
+        float sn, cs;
+        if constexpr (sizeof(T) == 4) {
+            sincosf(arg, &sn, &cs);   // parity mode: full-precision sin/cos of the float32 argument
+        } else {
+            // bf16 activations: the argument (up to ~1e4 rad for day-scaled Unix times) is reduced to [-1/2, 1/2]
+            // revolutions in double precision (exact to ~1e-12), then the hardware sin/cos (input in revolutions,
+            // ~1e-6 absolute) — two transcendental instructions instead of the ~100-instruction libm path; the result
+            // is rounded to bf16 anyway.
+            const double rev = (double)arg * 0.15915494309189533577;   // 1 / (2 pi)
+            const float fr = (float)(rev - __builtin_rint(rev));
+            sn = __builtin_amdgcn_sinf(fr);
+            cs = __builtin_amdgcn_cosf(fr);
+        }
+        v[0][2 * q] = sn; v[0][2 * q + 1] = cs;
     }
     const float sq = sqrtf((float)p.C);  // coding.py:62-63
-    float v[6];
-    v[0] = e0 * sq + sn; v[1] = e1 * sq + cs;
-    v[2] = p.pos_tab[t * p.C + c]; v[3] = p.pos_tab[t * p.C + c + 1];
-    // EasyDGL.py:87-88 — 0/1 mark values index the zero-padded mark-embedding table
-    const float fn = (float)nm;
-    v[4] = (p.E > 1) ? fn * p.mark_emb[p.C + c] : 0.f;
-    v[5] = (p.E > 1) ? fn * p.mark_emb[p.C + c + 1] : 0.f;
+    if (id != 0) {  // coding.py:56-57 zero-padded row 0
+        const T* it = reinterpret_cast<const T*>(p.item_tab) + id * p.C + c0;
+        if constexpr (sizeof(T) == 2) {
+            const Vec16<T> iv = ld16<T>(it);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[0][q] += to_f32(iv.v[q]) * sq;
+        } else {
+            const Vec16<T> i0 = ld16<T>(it), i1 = ld16<T>(it + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[0][q] += to_f32(i0.v[q]) * sq; v[0][4 + q] += to_f32(i1.v[q]) * sq; }
+        }
+    }
+    {
+        const float4 p0 = *reinterpret_cast<const float4*>(p.pos_tab + t * p.C + c0), p1 = *reinterpret_cast<const float4*>(p.pos_tab + t * p.C + c0 + 4);
+        v[1][0] = p0.x; v[1][1] = p0.y; v[1][2] = p0.z; v[1][3] = p0.w; v[1][4] = p1.x; v[1][5] = p1.y; v[1][6] = p1.z; v[1][7] = p1.w;
+        // EasyDGL.py:87-88 — 0/1 mark values index the zero-padded mark-embedding table
+        const float fn = (p.E > 1) ? (float)nm : 0.f;
+        const float4 m0 = *reinterpret_cast<const float4*>(p.mark_emb + p.C + c0), m1 = *reinterpret_cast<const float4*>(p.mark_emb + p.C + c0 + 4);
+        v[2][0] = fn * m0.x; v[2][1] = fn * m0.y; v[2][2] = fn * m0.z; v[2][3] = fn * m0.w;
+        v[2][4] = fn * m1.x; v[2][5] = fn * m1.y; v[2][6] = fn * m1.z; v[2][7] = fn * m1.w;
+    }
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     T* out = reinterpret_cast<T*>(p.x0) + row * 3 * p.C;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const uint64_t idx = (uint64_t)row * 3 * p.C + s * p.C + c;
-        out[s * p.C + c] = from_f32<T>(drop_apply(dk, idx, v[2 * s]));
-        out[s * p.C + c + 1] = from_f32<T>(drop_apply(dk, idx + 1, v[2 * s + 1]));
+        const uint64_t idx = (uint64_t)row * 3 * p.C + s * p.C + c0;
+        if constexpr (sizeof(T) == 2) {
+            Vec16<T> o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o.v[q] = from_f32<T>(drop_apply(dk, idx + q, v[s][q]));
+            st16<T>(out + s * p.C + c0, o);
+        } else {
+            Vec16<T> o0, o1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                o0.v[q] = from_f32<T>(drop_apply(dk, idx + q, v[s][q]));
+                o1.v[q] = from_f32<T>(drop_apply(dk, idx + 4 + q, v[s][4 + q]));
+            }
+            st16<T>(out + s * p.C + c0, o0);
+            st16<T>(out + s * p.C + c0 + 4, o1);
+        }
     }
 }
 
@@ -195,12 +241,12 @@ extern "C" int edgl_encode_fwd(const int64_t* ids, const float* ts, const void* 
                                uint8_t* marks, int dtype, void* stream) {
     EDGL_REQUIRE(ids && ts && item_tab && pos_tab && mark_emb && mark_table && tscale && x0 && spans && marks,
                  EDGL_ERR_NULL, "edgl_encode_fwd: null pointer");
-    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && (C % 2) == 0 && E >= 1 && I > 1, EDGL_ERR_SHAPE,
-                 "edgl_encode_fwd: bad shape B=%d T=%d C=%d E=%d I=%d", B, T, C, E, I);
+    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && (C % 8) == 0 && E >= 1 && I > 1, EDGL_ERR_SHAPE,
+                 "edgl_encode_fwd: bad shape B=%d T=%d C=%d E=%d I=%d (C must be a multiple of 8)", B, T, C, E, I);
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_encode_fwd: dropout without rng_state");
     EncP p{ids, ts, item_tab, pos_tab, mark_emb, mark_table, tscale, B, T, C, E, I, mask_id, time_scale,
            drop_rate, rng_state, stream_id, x0, spans, marks};
-    const long total = (long)B * T * (C / 2);
+    const long total = (long)B * T * (C / 8);
     dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EDGL_F32) hipLaunchKernelGGL((encode_fwd_kernel<float>), grid, dim3(256), 0, st, p);
