@@ -117,8 +117,13 @@ __device__ __forceinline__ KeyMask<NT> load_keymask(const int64_t* ids_row, int 
 }
 
 // S^T tiles -> normalised P^T tiles (temporal.py:422-429).  s[kt][r] in: raw Q.K; out: softmax.
+// `causal` (MAU.__call__ with causality=True, temporal.py:370-375): keys k > q get the same -2^32+1 score as padded keys
+// (tf.where(tril == 0, paddings, outputs)); q = this lane's query index.
+constexpr int MAU_CAUSAL = 1;    // future blinding (temporal.py:370-375)
+constexpr int MAU_NO_DIAG = 2;   // MAU keeps the modulation on the diagonal; BiMAU sets it to 1 (temporal.py:438-439)
 template <int NT>
-__device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale, int lane) {
+__device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale, int lane, int q = 0,
+                                               bool causal = false) {
     float mx = -INFINITY;
     const float* mrow = km.madd + (lane >> 4) * 4;
 #pragma unroll
@@ -127,7 +132,8 @@ __device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>
         const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = fmaf(s[kt][r], cscale, mm[r]);
+            float v = fmaf(s[kt][r], cscale, mm[r]);
+            if (causal && kt * 16 + (lane >> 4) * 4 + r > q && mm[r] != -INFINITY) v = -4294967296.0f;
             s[kt][r] = v;
             mx = fmaxf(mx, v);
         }

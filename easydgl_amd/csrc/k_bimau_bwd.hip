@@ -30,6 +30,7 @@ struct BwdP {
     void* d_qkvt;
     float* dz_ws; float* dh_ws; float* rowdot_ws; float* dsc_part; float* wpart;
     int waves;
+    int flags;   // MAU_CAUSAL | MAU_NO_DIAG
 };
 
 template <typename T>
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, km, cscale, lane);  // s = P^T, L(first=k, second=q)
+        masked_softmax<NT>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
         PH_MARK(0);
         Frag4<T> lf;
 #pragma unroll
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
             for (int vb = 0; vb < DT; ++vb)
                 da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
             f32x4 ap, dg, gv = gacc;
-            if (kt == qt) {   // only this key tile can hold k == q: G' diag := 1 (temporal.py:438-439)
+            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {   // only this key tile can hold k == q: G' diag := 1 (temporal.py:438-439)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
             }
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
                 dg[r] = da[r] * fp;                         // dG' = dA' * D * P
                 rowdot = fmaf(da[r] * facs[r] * gv[r], pv, rowdot);   // dP1 * P, dP1 = dA' * D * G'
             }
-            if (kt == qt) {   // set_diag blocks the gradient into lambda
+            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {   // set_diag blocks the gradient into lambda
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dg[r] = (g4 + r == l15) ? 0.f : dg[r];
             }
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, km, cscale, lane);  // s = P^T, L(first=k, second=q)
+        masked_softmax<NT>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
         PH_MARK(0);
         Frag4<T> lf;
 #pragma unroll
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             for (int vb = 0; vb < DT; ++vb)
                 da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
             f32x4 gv = gacc;
-            if (kt == qt) {
+            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
             }
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             for (int r = 0; r < 4; ++r) {
                 // tf.where(mask==0, paddings, S) (temporal.py:425-426) passes no gradient to a padded key's
                 // score; P is non-zero there only for fully padded rows (uniform softmax)
-                const bool padded = (km.pad >> (kt * 4 + r)) & 1u;
+                const bool padded = ((km.pad >> (kt * 4 + r)) & 1u) || ((p.flags & MAU_CAUSAL) && kt * 16 + g4 + r > q);
                 ds[r] = padded ? 0.f : s[kt][r] * (a[r] - rowdot) * cscale;
             }
             const Frag4<T> dsf = frag_from_acc<T>(ds);
@@ -731,7 +732,7 @@ extern "C" int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float*
                               const void* pack, const void* d_out, const float* d_lam_ext, const float* lam,
                               const void* saved, int B, int T, int C, int H, int E, float drop_rate,
                               const uint64_t* rng_state, uint32_t stream_id, void* d_qkvt, float* dW1, float* db1,
-                              float* dw, float* dscaling, void* workspace, int dtype, void* stream) {
+                              float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream) {
     EDGL_REQUIRE(qkvt && ids && spans && marks && pack && d_out && lam && saved && d_qkvt && dW1 && db1 && dw && dscaling && workspace,
                  EDGL_ERR_NULL, "edgl_bimau_bwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
@@ -746,7 +747,7 @@ extern "C" int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float*
     p.hin = (const char*)saved + sl.off_hin;
     p.z = reinterpret_cast<const float*>((const char*)saved + sl.off_z);
     p.B = B; p.T = T; p.C = C; p.H = H; p.E = E; p.rate = drop_rate; p.rng = rng_state;
-    p.stream_id = stream_id; p.d_qkvt = d_qkvt;
+    p.stream_id = stream_id; p.d_qkvt = d_qkvt; p.flags = flags;
     hipStream_t st = (hipStream_t)stream;
     const int dh = C / H;
     char* ws = (char*)workspace;

@@ -14,6 +14,7 @@ struct FwdP {
     void* out; float* lam;
     void* hin_out; float* z_out;   // saved for the backward (NULL: inference)
     int waves;
+    int flags;   // MAU_CAUSAL | MAU_NO_DIAG
 };
 
 // DT = dh/16, NT = ceil(T/16); EC = compile-time mark count (16: all LDS offsets are immediates and the mark loop is
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, km, cscale, lane);  // s := P^T
+        masked_softmax<NT>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s := P^T
         // ---- H^T[u][q] = sum_k T_[k][u] P[q][k] -----------------------------------------------
         Frag4<T> pf[NT];
 #pragma unroll
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, f32x4{0.f, 0.f, 0.f, 0.f});
-            if (kt == qt) {   // only this key tile can contain k == q (temporal.py:438-439)
+            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {   // only this key tile can contain k == q (temporal.py:438-439)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gacc[r] = (g4 + r == l15) ? 1.0f : gacc[r];
             }
@@ -314,7 +315,7 @@ extern "C" int edgl_bimau_pack(const float* W1, const float* b1, const float* w,
 extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
                               const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
                               float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* out,
-                              float* lam_out, void* saved, int dtype, void* stream) {
+                              float* lam_out, void* saved, int flags, int dtype, void* stream) {
     EDGL_REQUIRE(qkvt && resid && ids && spans && marks && pack && out && lam_out, EDGL_ERR_NULL,
                  "edgl_bimau_fwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
@@ -323,7 +324,7 @@ extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, c
     EDGL_REQUIRE(ld_res % 4 == 0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: ld_res must be a multiple of 4");
     EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: H*B*T*T must be < 2^32");
     FwdP p{qkvt, resid, ld_res, ids, spans, marks, (const char*)pack, B, T, C, H, E, drop_rate, rng_state, stream_id,
-           out, lam_out, nullptr, nullptr, 4};
+           out, lam_out, nullptr, nullptr, 4, flags};
     if (saved) {   // [H*B*T, dh] activation dtype | [H*B*T, 16] f32 (pre-softplus z)
         const bimau::SavedLayout sl = bimau::saved_layout(B, T, C, H, dtype == EDGL_BF16 ? 2 : 4);
         p.hin_out = (char*)saved + sl.off_hin;

@@ -159,7 +159,7 @@ class TrainEngine:
             da = drop(ad, 10 + 4 * i)
             check(lib.edgl_bimau_fwd(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
                                      _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
-                                     _ptr(b["lam"]), _ptr(b["saved"]), code, st), "edgl_bimau_fwd")
+                                     _ptr(b["lam"]), _ptr(b["saved"]), 0, code, st), "edgl_bimau_fwd")
             self._dense_fwd(b["att"], blk.att_out.kernel, blk.att_out.bias, b["ao"], C, C)
             self._ln_fwd(b["ao"], x, cin, blk.att_ln, drop(hd, 11 + 4 * i), b["a1"], b["st1"])
             self._dense_fwd(b["a1"], blk.inter.kernel, blk.inter.bias, b["f"], C, 2 * C, gelu=True, pre=b["pre_f"])
@@ -231,7 +231,7 @@ class TrainEngine:
                                      _ptr(b["saved"]), B, T, C, H, E,
                                      float(da.rate), da.ptr(), da.stream_id, _ptr(self.G4c), _ptr(att.st_kernel.grad),
                                      _ptr(att.st_bias.grad), _ptr(att.weight.grad), _ptr(att.scaling.grad),
-                                     _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), code, st),
+                                     _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), 0, code, st),
                   "edgl_bimau_bwd")
             self._dense_dw(x_in, self.G4c, att.dense_kernel, att.dense_bias, cin, 4 * C)
             d_in = self.G3c if i == 0 else self.G3

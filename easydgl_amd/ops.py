@@ -188,7 +188,7 @@ class BiMAUFn(torch.autograd.Function):
     """Fused attention of BiMAU.__call__ (temporal.py:413-447) given qkvt = dense(x)."""
 
     @staticmethod
-    def forward(ctx, qkvt, resid, W1, b1, w, scaling, ids, spans, marks, H, drop: Drop):
+    def forward(ctx, qkvt, resid, W1, b1, w, scaling, ids, spans, marks, H, drop: Drop, flags: int = 0):
         B, T, C4 = qkvt.shape
         C = C4 // 4
         E = w.shape[0]
@@ -204,16 +204,16 @@ class BiMAUFn(torch.autograd.Function):
         saved = torch.empty(lib.edgl_bimau_saved_bytes(B, T, C, H, code), device=qkvt.device, dtype=torch.uint8) if need_grad else None
         check(lib.edgl_bimau_fwd(_ptr(qkvt), resid.data_ptr(), resid.stride(1), _ptr(ids), _ptr(spans), _ptr(marks),
                                  _ptr(pack), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(out),
-                                 _ptr(lam), _ptr(saved), code, _stream()), "edgl_bimau_fwd")
+                                 _ptr(lam), _ptr(saved), int(flags), code, _stream()), "edgl_bimau_fwd")
         if need_grad:
             ctx.save_for_backward(qkvt, ids, spans, marks, pack, lam, saved)
-        ctx.meta = (B, T, C, H, E, drop, code, W1.shape, b1.shape, w.shape, scaling.shape)
+        ctx.meta = (B, T, C, H, E, drop, code, W1.shape, b1.shape, w.shape, scaling.shape, int(flags))
         return out, lam
 
     @staticmethod
     def backward(ctx, d_out, d_lam):
         qkvt, ids, spans, marks, pack, lam, saved = ctx.saved_tensors
-        B, T, C, H, E, drop, code, s1, s2, s3, s4 = ctx.meta
+        B, T, C, H, E, drop, code, s1, s2, s3, s4, flags = ctx.meta
         d_out = d_out.contiguous()
         dev = d_out.device
         d_qkvt = torch.empty_like(qkvt)
@@ -225,8 +225,8 @@ class BiMAUFn(torch.autograd.Function):
         dl = d_lam.contiguous() if d_lam is not None else None
         check(lib.edgl_bimau_bwd(_ptr(qkvt), _ptr(ids), _ptr(spans), _ptr(marks), _ptr(pack), _ptr(d_out), _ptr(dl),
                                  _ptr(lam), _ptr(saved), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(d_qkvt), _ptr(dW1),
-                                 _ptr(db1), _ptr(dw), _ptr(dsc), _ptr(ws), code, _stream()), "edgl_bimau_bwd")
-        return d_qkvt, d_out, dW1, db1, dw, dsc, None, None, None, None, None
+                                 _ptr(db1), _ptr(dw), _ptr(dsc), _ptr(ws), flags, code, _stream()), "edgl_bimau_bwd")
+        return d_qkvt, d_out, dW1, db1, dw, dsc, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

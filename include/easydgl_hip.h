@@ -126,7 +126,13 @@ int edgl_colsum(const void* X, int M, int N, int ld, float* out, int accumulate,
  * are first packed by edgl_bimau_pack into `pack` (edgl_bimau_pack_bytes bytes, reusable by fwd and
  * bwd until the weights change).  lam_out f32 [H*B,T,E].  `saved` (edgl_bimau_saved_bytes bytes, or
  * NULL for inference) receives what the backward re-uses: the H rows fed to the intensity MLP and its
- * pre-softplus output z.  Supported: dh in {16,32}, E<=16, T<=128. */
+ * pre-softplus output z.  `flags`: 0 = BiMAU as above; EDGL_MAU_CAUSAL adds the future-blinding mask of
+ * MAU.__call__(causality=True) (temporal.py:370-375: keys k > q scored -2^32+1 like padded keys, no gradient
+ * through them); EDGL_MAU_NO_DIAG keeps the modulation on the diagonal (MAU, temporal.py:383; BiMAU overwrites
+ * it with 1, :438-439).  The caller may fill the Q and K|V|T_ column blocks of qkvt from different inputs
+ * (MAU: Q = dense(LN(x)), K,V,T_ = dense(x), temporal.py:352-355).  Supported: dh in {16,32}, E<=16, T<=128. */
+#define EDGL_MAU_CAUSAL 1
+#define EDGL_MAU_NO_DIAG 2
 long edgl_bimau_pack_bytes(int C, int H, int E, int dtype);
 long edgl_bimau_saved_bytes(int B, int T, int C, int H, int dtype);
 int edgl_bimau_pack(const float* W1, const float* b1, const float* w, const float* scaling, int C, int H, int E,
@@ -134,7 +140,7 @@ int edgl_bimau_pack(const float* W1, const float* b1, const float* w, const floa
 int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
                    const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E, float drop_rate,
                    const uint64_t* rng_state, uint32_t stream_id, void* out, float* lam_out, void* saved,
-                   int dtype, void* stream);
+                   int flags, int dtype, void* stream);
 
 /* Backward.  d_out [B,T,C] `dtype`; d_lam_ext f32 [H*B,T,E] or NULL (gradient
  * from the TPP regulariser); lam / saved: the forward's lam_out and `saved` buffer.  Writes d_qkvt [B,T,4C] `dtype` and the f32 weight gradients dW1
@@ -146,7 +152,7 @@ int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float* spans, con
                    const void* pack, const void* d_out, const float* d_lam_ext, const float* lam,
                    const void* saved, int B, int T, int C, int H, int E, float drop_rate,
                    const uint64_t* rng_state, uint32_t stream_id, void* d_qkvt, float* dW1, float* db1,
-                   float* dw, float* dscaling, void* workspace, int dtype, void* stream);
+                   float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream);
 
 /* ---- K4-LN: y = layernorm_joint(dropout(x) + resid) — Base.py:12-67 (moments over (T,C) per
  * sample, eps 1e-12), EasyDGL.py:114-116,126-128,139.  resid may be NULL (ld_res ignored).

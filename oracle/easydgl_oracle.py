@@ -278,28 +278,37 @@ def intensity(H, intervals, marks, W1, b1, w, scaling, num_heads):
     return Mint, lam
 
 
-def bimau(cfg: Config, x, keymask, spans, marks, Wqkvt, bqkvt, W1, b1, w, scaling):
+def bimau(cfg: Config, x, keymask, spans, marks, Wqkvt, bqkvt, W1, b1, w, scaling, causal=False, set_diag=True,
+          qkvt=None, resid=None):
     """BiMAU.__call__, temporal.py:404-452 (dropout = identity; no causal mask).
-    x [B,T,Cin] -> (out [B,T,C], lam [hB,T,E])."""
+    x [B,T,Cin] -> (out [B,T,C], lam [hB,T,E]).  causal=True / set_diag=False restate MAU.__call__
+    (temporal.py:335-390): future blinding (:370-375), modulation kept on the diagonal; qkvt / resid let the caller
+    supply the projections (MAU: Q from LN(x), K,V,T_ from x, :352-355) and the residual (:383 adds the queries)."""
     C, h = cfg.num_units, cfg.num_heads
-    B, T, _ = x.shape
-    qkvt = dense(x, Wqkvt, bqkvt)  # :409
+    B, T = x.shape[0], x.shape[1]
+    if qkvt is None:
+        qkvt = dense(x, Wqkvt, bqkvt)  # :409
+    if resid is None:
+        resid = x[:, :, :C]
     Q, K, V, T_ = np.split(qkvt, 4, axis=-1)  # :410
     Q_, K_, V_, T__ = (split_heads(a, h) for a in (Q, K, V, T_))  # :413-416
     S = Q_ @ np.transpose(K_, (0, 2, 1))  # :419
     S = S / (K_.shape[-1] ** 0.5)  # :422
     km = np.tile(keymask[:, None, :], (h, T, 1))  # EasyDGL.py:94-95
     S = np.where(km == 0, PAD_SCORE, S)  # :425-426
+    if causal:  # :370-375 — tf.where(tril == 0, paddings, outputs)
+        S = np.where(np.tril(np.ones((T, T)))[None] == 0, PAD_SCORE, S)
     P = softmax(S)  # :429
     H = P @ T__  # :434
     Mint, lam = intensity(H, spans, marks, W1, b1, w, scaling, h)  # :435
-    idx = np.arange(T)
-    Mint = Mint.copy()
-    Mint[:, idx, idx] = 1.0  # :438-439 set_diag
+    if set_diag:
+        idx = np.arange(T)
+        Mint = Mint.copy()
+        Mint[:, idx, idx] = 1.0  # :438-439 set_diag
     A = Mint * P  # :441
     O = A @ V_  # :443
     out = merge_heads(O, h)  # :444
-    out = out + x[:, :, :C]  # :447
+    out = out + resid  # :447
     return out, lam
 
 

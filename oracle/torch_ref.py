@@ -71,24 +71,35 @@ def intensity(H, intervals, marks_f, W1, b1, w, scaling, h):  # temporal.py:281-
     return Mint, lam
 
 
-def bimau(C, h, x, keymask3, spans, marks_f, p, pre, att_drop, training):  # temporal.py:404-452
+def bimau(C, h, x, keymask3, spans, marks_f, p, pre, att_drop, training, causal=False, set_diag=True, qkvt=None,
+          resid=None):
+    """BiMAU.__call__ (temporal.py:404-452).  causal / set_diag=False give MAU.__call__ (temporal.py:335-390: future
+    blinding :370-375, no set_diag); qkvt / resid let the caller supply the four projections and the residual (MAU
+    projects Q from LN(x) and K, V, T_ from x, and adds the queries back)."""
     st = pre + "sequential_temporal_combined/"
-    qkvt = x @ p[pre + "dense/kernel"] + p[pre + "dense/bias"]
+    if qkvt is None:
+        qkvt = x @ p[pre + "dense/kernel"] + p[pre + "dense/bias"]
+    if resid is None:
+        resid = x[:, :, :C]
     Q, K, V, T_ = torch.split(qkvt, C, dim=-1)
     Q_, K_, V_, T__ = (split_heads(a, h) for a in (Q, K, V, T_))
     S = torch.matmul(Q_, K_.transpose(1, 2))
     S = S / (K_.shape[-1] ** 0.5)
     S = torch.where(keymask3 == 0, torch.full_like(S, PAD_SCORE), S)
+    T = S.shape[1]
+    if causal:  # temporal.py:370-375
+        tril = torch.tril(torch.ones(T, T, dtype=torch.bool))
+        S = torch.where(tril, S, torch.full_like(S, PAD_SCORE))
     P = torch.softmax(S, dim=-1)
     H = torch.matmul(P, T__)
     Mint, lam = intensity(H, spans, marks_f, p[st + "dense/kernel"], p[st + "dense/bias"],
                           p[st + "weight"], p[st + "scaling"], h)
-    T = S.shape[1]
-    eye = torch.eye(T, dtype=torch.bool)
-    Mint = torch.where(eye, torch.ones_like(Mint), Mint)  # set_diag :438-439
+    if set_diag:
+        eye = torch.eye(T, dtype=torch.bool)
+        Mint = torch.where(eye, torch.ones_like(Mint), Mint)  # set_diag :438-439
     A = dropout(Mint * P, att_drop, training)
     Ovals = torch.matmul(A, V_)
-    out = merge_heads(Ovals, h) + x[:, :, :C]
+    out = merge_heads(Ovals, h) + resid
     return out, lam
 
 

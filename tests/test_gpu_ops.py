@@ -257,6 +257,56 @@ def test_bimau_fwd_bwd(name, dt, tol, B, T, C, H, E):
     assert_close(sc.grad.cpu().numpy(), pr["sequential_temporal_combined/scaling"].grad.numpy(), gtol, "dscaling")
 
 
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+@pytest.mark.parametrize("flags", [1, 2, 3])
+def test_mau_causal_and_diag_flags(name, dt, tol, flags):
+    """EDGL_MAU_CAUSAL / EDGL_MAU_NO_DIAG (MAU.__call__, temporal.py:335-390) with separately projected Q and K|V|T_
+    and the queries as residual, forward and every gradient against the fp64 restatement."""
+    o = ops()
+    B, T, C, H, E = 3, 21, 32, 2, 5
+    cfg, x, ids, marks, spans, W = _bimau_case(B, T, C, H, E, seed=17, cin_mult=1)
+    rng = np.random.default_rng(4)
+    qkvt = torch.tensor(_rand((B, T, 4 * C), rng, 0.7), dtype=dt).cuda().requires_grad_()
+    resid = torch.tensor(_rand((B, T, C), rng), dtype=dt).cuda().requires_grad_()
+    W1 = torch.tensor(W["W1"], dtype=torch.float32).cuda().requires_grad_()
+    b1 = torch.tensor(W["b1"], dtype=torch.float32).cuda().requires_grad_()
+    w = torch.tensor(W["w"], dtype=torch.float32).cuda().requires_grad_()
+    sc = torch.tensor(W["sc"], dtype=torch.float32).cuda().requires_grad_()
+    out, lam = o.BiMAUFn.apply(qkvt, resid, W1, b1, w, sc, torch.tensor(ids).cuda(), torch.tensor(spans, dtype=torch.float32).cuda(),
+                               torch.tensor(marks.astype(np.uint8)).cuda(), H, o.NO_DROP, flags)
+    G1 = torch.tensor(_rand((B, T, C), rng), dtype=dt).cuda()
+    G2 = torch.tensor(_rand((H * B, T, E), rng, 0.3), dtype=torch.float32).cuda()
+    ((out.float() * G1.float()).sum() + (lam * G2).sum()).backward()
+    qr = qkvt.detach().double().cpu().requires_grad_()
+    rr = resid.detach().double().cpu().requires_grad_()
+    pr = {"sequential_temporal_combined/dense/kernel": W1.detach().double().cpu().requires_grad_(),
+          "sequential_temporal_combined/dense/bias": b1.detach().double().cpu().requires_grad_(),
+          "sequential_temporal_combined/weight": w.detach().double().cpu().requires_grad_(),
+          "sequential_temporal_combined/scaling": sc.detach().double().cpu().requires_grad_()}
+    km3 = torch.tensor((ids != 0).astype(np.float64)).unsqueeze(1).repeat(H, T, 1)
+    out_r, lam_r = R.bimau(C, H, None, km3, torch.tensor(spans), torch.tensor(marks, dtype=torch.float64), pr, "", 0.0, False,
+                           causal=bool(flags & 1), set_diag=not (flags & 2), qkvt=qr, resid=rr)
+    ((out_r * G1.double().cpu()).sum() + (lam_r * G2.double().cpu()).sum()).backward()
+    ftol = 3e-5 if name == "f32" else 3e-2
+    assert_close(lam.detach().cpu().numpy(), lam_r.detach().numpy(), ftol, "lambda")
+    assert_close(out.float().detach().cpu().numpy(), out_r.detach().numpy(), ftol, "out")
+    gtol = 2e-4 if name == "f32" else 6e-2
+    assert_close(qkvt.grad.float().cpu().numpy(), qr.grad.numpy(), gtol, "dqkvt")
+    assert_close(resid.grad.float().cpu().numpy(), rr.grad.numpy(), gtol, "dresid")
+    assert_close(W1.grad.cpu().numpy(), pr["sequential_temporal_combined/dense/kernel"].grad.numpy(), gtol, "dW1")
+    assert_close(w.grad.cpu().numpy(), pr["sequential_temporal_combined/weight"].grad.numpy(), gtol, "dw")
+    assert_close(sc.grad.cpu().numpy(), pr["sequential_temporal_combined/scaling"].grad.numpy(), gtol, "dscaling")
+    if flags & 1:   # a causal row never looks ahead: perturbing a future key leaves earlier outputs unchanged
+        q2 = qkvt.detach().clone()
+        q2[:, T - 1, C:] += 1.0
+        out2, _ = o.BiMAUFn.apply(q2, resid.detach(), W1.detach(), b1.detach(), w.detach(), sc.detach(), torch.tensor(ids).cuda(),
+                                  torch.tensor(spans, dtype=torch.float32).cuda(), torch.tensor(marks.astype(np.uint8)).cuda(), H,
+                                  o.NO_DROP, flags)
+        rows = [(b, t) for b in range(B) for t in range(T - 1) if ids[b, :t + 1].any()]
+        for b, t in rows:
+            assert torch.equal(out2[b, t], out.detach()[b, t])
+
+
 def test_bimau_fully_masked_row_is_uniform():
     """KAT temporal.py:425-429 through the kernel: all keys padded -> P = 1/T -> out = mean_k(G*V) + resid."""
     o = ops()
