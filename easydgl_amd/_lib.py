@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeasydgl_hip.so")
 
 F32, BF16 = 0, 1
-EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 8, 16, 32, 64
 MAU_CAUSAL, MAU_NO_DIAG = 1, 2
 
 P, I, F, L, U32, I64 = c_void_p, c_int, c_float, c_long, c_uint32, c_int64
@@ -33,6 +33,8 @@ SIGNATURES = {
     "edgl_encode_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I64, F, F, P, U32, P, P, P, I, P]),
     "edgl_encode_bwd_workspace": (L, [I, I, I]),
     "edgl_encode_bwd": (I, [P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
+    "edgl_embed_pos_fwd": (I, [P, P, P, P, P, I, I, I, I, F, F, P, U32, P, P, P, I, P]),
+    "edgl_embed_pos_bwd": (I, [P, P, I, I, I, I, F, P, U32, P, P, I, P]),
     "edgl_gemm": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, I, P]),
     "edgl_colsum": (I, [P, I, I, I, P, I, P, I, I, P]),
     "edgl_gemm_dw_workspace": (L, [I, I, I, I]),
@@ -66,6 +68,8 @@ SIGNATURES = {
     "edgl_cast_back": (I, [P, P, L, I, I, P]),
     "edgl_add": (I, [P, P, P, L, I, P]),
     "edgl_add_cols": (I, [P, I, P, P, I, L, I, I, P]),
+    "edgl_dropout": (I, [P, P, L, F, P, U32, I, P]),
+    "edgl_relu_bwd": (I, [P, P, P, L, I, P]),
     "edgl_gelu_bwd": (I, [P, P, P, L, I, P]),
 }
 

@@ -47,6 +47,10 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float v[4], int 
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
         }
+        if (p.flags & EDGL_EPI_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+        }
         if (p.flags & EDGL_EPI_MUL_DGELU) {
             const Frag4<T> a = frag_ld<T>(reinterpret_cast<const T*>(p.aux) + idx0);
 #pragma unroll
@@ -78,6 +82,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float v[4], int 
         const long idx = idx0 + r;
         if (p.flags & EDGL_EPI_SAVE_PRE) reinterpret_cast<T*>(p.aux)[idx] = from_f32<T>(x);
         if (p.flags & EDGL_EPI_GELU) x = gelu_f(x);
+        if (p.flags & EDGL_EPI_RELU) x = fmaxf(x, 0.f);
         if (p.flags & EDGL_EPI_MUL_DGELU) x *= dgelu_f(to_f32(reinterpret_cast<const T*>(p.aux)[idx]));
         if (p.flags & EDGL_EPI_OUT_F32) {
             float* c = reinterpret_cast<float*>(p.C);

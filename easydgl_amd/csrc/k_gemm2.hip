@@ -52,6 +52,10 @@ __device__ __forceinline__ void epi_store4(const EpiP& e, bf16* C, void* Cany, l
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
     }
+    if (e.flags & EDGL_EPI_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+    }
     if (e.flags & EDGL_EPI_MUL_DGELU) {
         const Frag4<bf16> a = frag_ld<bf16>(reinterpret_cast<const bf16*>(e.aux) + idx);
 #pragma unroll
@@ -139,6 +143,10 @@ __device__ __forceinline__ void strip_epilogue(const StripP& p, StripEpi& e, f32
                 if (p.epi.flags & EDGL_EPI_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+                }
+                if (p.epi.flags & EDGL_EPI_RELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
                 }
                 Frag4<bf16> f = frag_from_acc<bf16>(f32x4{x[0], x[1], x[2], x[3]});
                 *reinterpret_cast<uint2*>(Ostage + l15 * LDO + jz * 16 + g4) = *reinterpret_cast<uint2*>(&f);

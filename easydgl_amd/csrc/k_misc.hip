@@ -61,7 +61,9 @@ __device__ __forceinline__ void tpp_row(const TppP& p, long j, float& ev_ll, flo
                                         float* span_out, float* g_out, int* b_out, int* pos_out, int64_t* lab_out) {
     const long bp = j / p.M;
     const int m = (int)(j % p.M), b = (int)(bp % p.B);
-    const int pos = (int)p.mpos[(long)b * p.M + m];
+    // masked-position mode (EasyDGL.py:157-175) or, with mpos == NULL, every position of the sequence (CTSMA.py:95-108:
+    // M == T, ts holds T+1 raw timestamps per row and the interval is the plain forward difference)
+    const int pos = p.mpos ? (int)p.mpos[(long)b * p.M + m] : m;
     const int64_t lab = p.labels[(long)b * p.M + m];
     const uint8_t* nm = p.mtab + lab * p.E;
     const float* lm = p.lam + (bp * p.T + pos) * p.E;
@@ -69,7 +71,8 @@ __device__ __forceinline__ void tpp_row(const TppP& p, long j, float& ev_ll, flo
     for (int e = 0; e < p.E; ++e) { const float f = (float)nm[e]; cnt += f; ev += lm[e] * f; ent += lm[e]; }
     const float g = cnt > 0.f ? 1.f : 0.f;  // sign(sum nm), temporal.py:321
     ev *= g; ent *= g;
-    const float sp = raw_span(p.ts + (long)b * p.T, pos, p.T);
+    const float sp = p.mpos ? raw_span(p.ts + (long)b * p.T, pos, p.T)
+                            : p.ts[(long)b * (p.T + 1) + pos + 1] - p.ts[(long)b * (p.T + 1) + pos];
     ev_ll = __logf(ev == 0.f ? 1.f : ev);  // :324
     non_ev = ent * sp * 0.5f;              // :327-328
     nmk = cnt;
@@ -237,6 +240,12 @@ __global__ void gelu_bwd_kernel(const T* dy, const T* pre, T* dz, long n) {
         dz[i] = from_f32<T>(to_f32(dy[i]) * dgelu_f(to_f32(pre[i])));
 }
 
+template <typename T>
+__global__ void relu_bwd_kernel(const T* dy, const T* y, T* dz, long n) {   // dz = dy * [y > 0]
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dz[i] = to_f32(y[i]) > 0.f ? dy[i] : from_f32<T>(0.f);
+}
+
 inline int grid_for(long n) { return (int)std::min<long>((n + 255) / 256, 4096); }
 
 }  // namespace
@@ -337,8 +346,8 @@ extern "C" int edgl_tpp_workspace(void) { return RED_BLOCKS * 3 + 4; }
 extern "C" int edgl_tpp_fwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                             const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
                             float* reg_out, int accumulate, void* stream) {
-    EDGL_REQUIRE(lam && masked_pos && labels && ts_raw && mark_table && sums && reg_out, EDGL_ERR_NULL,
-                 "edgl_tpp_fwd: null pointer");
+    EDGL_REQUIRE(lam && labels && ts_raw && mark_table && sums && reg_out, EDGL_ERR_NULL, "edgl_tpp_fwd: null pointer");
+    EDGL_REQUIRE(masked_pos || M == T, EDGL_ERR_SHAPE, "edgl_tpp_fwd: all-position mode needs M == T");
     TppP p{lam, masked_pos, labels, ts_raw, mark_table, B, T, H, E, M, coef};
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(tpp_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, p, sums + 4);
@@ -351,8 +360,8 @@ extern "C" int edgl_tpp_fwd(const float* lam, const int64_t* masked_pos, const i
 extern "C" int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                             const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef,
                             const float* sums, const float* gscale, float* d_lam, void* stream) {
-    EDGL_REQUIRE(lam && masked_pos && labels && ts_raw && mark_table && sums && d_lam, EDGL_ERR_NULL,
-                 "edgl_tpp_bwd: null pointer");
+    EDGL_REQUIRE(lam && labels && ts_raw && mark_table && sums && d_lam, EDGL_ERR_NULL, "edgl_tpp_bwd: null pointer");
+    EDGL_REQUIRE(masked_pos || M == T, EDGL_ERR_SHAPE, "edgl_tpp_bwd: all-position mode needs M == T");
     TppP p{lam, masked_pos, labels, ts_raw, mark_table, B, T, H, E, M, coef};
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(d_lam, 0, (size_t)H * B * T * E * sizeof(float), st) != hipSuccess) {
@@ -439,6 +448,34 @@ extern "C" int edgl_add_cols(void* dst, int ld_dst, const void* src, const void*
         if (vok) hipLaunchKernelGGL((add_cols_vec_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (float*)dst, ld_dst, (const float*)src, (const float*)src2, ld_src, rows, ncols);
         else hipLaunchKernelGGL((add_cols_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (float*)dst, ld_dst, (const float*)src, (const float*)src2, ld_src, rows, ncols);
     }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+template <typename T>
+__global__ void dropout_state_kernel(const T* x, T* y, long n, const uint64_t* rng, uint32_t stream_id, float rate) {
+    const DropKey dk = make_dropkey(rng, stream_id, rate);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = from_f32<T>(drop_apply(dk, (uint64_t)i, to_f32(x[i])));
+}
+
+extern "C" int edgl_dropout(const void* x, void* y, long n, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                            int dtype, void* stream) {
+    EDGL_REQUIRE(x && y && (drop_rate == 0.f || rng_state), EDGL_ERR_NULL, "edgl_dropout: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_BF16) hipLaunchKernelGGL((dropout_state_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n, rng_state, stream_id, drop_rate);
+    else if (dtype == EDGL_F32) hipLaunchKernelGGL((dropout_state_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y, n, rng_state, stream_id, drop_rate);
+    else { edgl_set_error("edgl_dropout: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_relu_bwd(const void* dy, const void* y, void* dz, long n, int dtype, void* stream) {
+    EDGL_REQUIRE(dy && y && dz, EDGL_ERR_NULL, "edgl_relu_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_BF16) hipLaunchKernelGGL((relu_bwd_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, (bf16*)dz, n);
+    else if (dtype == EDGL_F32) hipLaunchKernelGGL((relu_bwd_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)dz, n);
+    else { edgl_set_error("edgl_relu_bwd: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

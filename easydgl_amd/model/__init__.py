@@ -1,2 +1,3 @@
 from .base import Sequential  # noqa: F401
 from .easydgl import EasyDGL  # noqa: F401
+from .ctsma import CTSMA  # noqa: F401

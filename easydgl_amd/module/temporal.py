@@ -1,4 +1,5 @@
-"""Mirror of src/module/temporal.py:BiMAU (the Bi-level Modulating Attention Unit used by EasyDGL)."""
+"""Mirror of src/module/temporal.py: BiMAU (the Bi-level Modulating Attention Unit used by EasyDGL) and MAU (the causal
+unit of CTSMA), both on the fused HIP attention kernels."""
 from __future__ import annotations
 
 import torch
@@ -36,3 +37,34 @@ class BiMAU(nn.Module):
         resid = queries[:, :, :C]
         return ops.BiMAUFn.apply(qkvt, resid, self.st_kernel, self.st_bias, self.weight, self.scaling, masks, intervals,
                                  marks, self.num_heads, drop if is_training else ops.NO_DROP)
+
+
+class MAU(nn.Module):
+    """temporal.py:335-390 (``T.MAU``, ICML'21 CTSMA): four separate projections — Q from ``queries``, K, V, T_ from ``keys``
+    (tf.layers.dense x4, glorot kernels; K|V|T_ are stored as one [Cin, 3C] matrix whose column blocks are the three TF
+    variables) — then the same fused kernel as BiMAU with ``causality`` (future blinding, :370-375) and the modulation
+    kept on the diagonal; the residual adds the queries' first C channels (:383)."""
+
+    def __init__(self, in_units, num_units, num_heads, num_events, dropout_rate, gen=None):
+        super().__init__()
+        self.num_units, self.num_heads, self.num_events, self.dropout_rate = num_units, num_heads, num_events, dropout_rate
+        dh = num_units // num_heads
+        self.q_kernel = nn.Parameter(glorot_uniform_(torch.empty(in_units, num_units), gen))        # dense
+        self.q_bias = nn.Parameter(torch.zeros(num_units))
+        kvt = torch.cat([glorot_uniform_(torch.empty(in_units, num_units), gen) for _ in range(3)], dim=1)
+        self.kvt_kernel = nn.Parameter(kvt)                                                           # dense_1 | dense_2 | dense_3
+        self.kvt_bias = nn.Parameter(torch.zeros(3 * num_units))
+        self.st_kernel = nn.Parameter(glorot_uniform_(torch.empty(dh + 1, dh * num_events), gen))
+        self.st_bias = nn.Parameter(torch.zeros(dh * num_events))
+        self.weight = nn.Parameter(glorot_uniform_(torch.empty(num_events, dh), gen))
+        self.scaling = nn.Parameter(torch.zeros(num_events))
+        self.compute = lambda p: p
+
+    def forward(self, queries, keys, masks, intervals, marks, is_training, causality=True, drop: ops.Drop = ops.NO_DROP):
+        C = self.num_units
+        q = ops.LinearFn.apply(queries, self.q_kernel, self.q_bias, self.compute(self.q_kernel), False)
+        kvt = ops.LinearFn.apply(keys, self.kvt_kernel, self.kvt_bias, self.compute(self.kvt_kernel), False)
+        qkvt = torch.cat([q, kvt], dim=-1)   # column blocks Q | K | V | T_ of the kernel's operand (a device-side copy)
+        flags = ops.MAU_NO_DIAG | (ops.MAU_CAUSAL if causality else 0)
+        return ops.BiMAUFn.apply(qkvt, queries[:, :, :C], self.st_kernel, self.st_bias, self.weight, self.scaling, masks,
+                                 intervals, marks, self.num_heads, drop if is_training else ops.NO_DROP, flags)

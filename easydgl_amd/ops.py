@@ -53,6 +53,7 @@ class Drop:
 
 
 NO_DROP = Drop()
+MAU_CAUSAL, MAU_NO_DIAG = _lib.MAU_CAUSAL, _lib.MAU_NO_DIAG
 
 
 def rng_advance(state: torch.Tensor) -> None:
@@ -147,6 +148,37 @@ class EncodeFn(torch.autograd.Function):
         return (d_item, d_pos, d_mark) + (None,) * 9
 
 
+class EmbedPosFn(torch.autograd.Function):
+    """CTSMA.py:48-58: X0 = dropout(concat(item[ids]*sqrt(C), pos[0..T))), spans, marks (edgl_embed_pos_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, item_master, pos_tab, item_c, ids, ts, mark_table, time_scale, drop: Drop, act_dtype):
+        B, T = ids.shape
+        I, C = item_c.shape
+        E = mark_table.shape[1]
+        x0 = torch.empty((B, T, 2 * C), device=ids.device, dtype=act_dtype)
+        spans = torch.empty((B, T), device=ids.device, dtype=torch.float32)
+        marks = torch.empty((B, T, E), device=ids.device, dtype=torch.uint8)
+        check(lib.edgl_embed_pos_fwd(_ptr(ids), _ptr(ts), _ptr(item_c), _ptr(pos_tab), _ptr(mark_table), B, T, C, E,
+                                     float(time_scale), float(drop.rate), drop.ptr(), drop.stream_id, _ptr(x0), _ptr(spans),
+                                     _ptr(marks), _DT[act_dtype], _stream()), "edgl_embed_pos_fwd")
+        ctx.save_for_backward(ids)
+        ctx.meta = (B, T, C, I, drop, item_master.shape, pos_tab.shape)
+        ctx.mark_non_differentiable(spans, marks)
+        return x0, spans, marks
+
+    @staticmethod
+    def backward(ctx, dx0, _ds, _dm):
+        (ids,) = ctx.saved_tensors
+        B, T, C, I, drop, ishape, pshape = ctx.meta
+        dx0 = dx0.contiguous()
+        d_item = torch.empty(ishape, device=dx0.device, dtype=torch.float32)
+        d_pos = torch.zeros(pshape, device=dx0.device, dtype=torch.float32)
+        check(lib.edgl_embed_pos_bwd(_ptr(ids), _ptr(dx0), B, T, C, I, float(drop.rate), drop.ptr(), drop.stream_id,
+                                     _ptr(d_item), _ptr(d_pos), _code(dx0), _stream()), "edgl_embed_pos_bwd")
+        return (d_item, d_pos) + (None,) * 7
+
+
 # ------------------------------------------------------------------------------------------------
 # K2/K4 dense
 # ------------------------------------------------------------------------------------------------
@@ -154,15 +186,18 @@ class LinearFn(torch.autograd.Function):
     """tf.layers.dense: y = act(x @ W + b), W [in, out] (Appendix A).  w_c is W in the activation dtype."""
 
     @staticmethod
-    def forward(ctx, x, w_master, bias, w_c, gelu: bool):
+    def forward(ctx, x, w_master, bias, w_c, gelu):
+        """`gelu`: False / True (erf-GELU, EasyDGL.py:19-32) / "relu" (FeedForward inner layer, Base.py:73)."""
         K, N = w_c.shape
-        x2 = x.reshape(-1, K)
+        x2 = x.reshape(-1, K).contiguous()
         M = x2.shape[0]
-        flags = _lib.EPI_BIAS | (_lib.EPI_GELU | _lib.EPI_SAVE_PRE if gelu else 0)
+        relu = gelu == "relu"
+        gelu = gelu is True
+        flags = _lib.EPI_BIAS | (_lib.EPI_GELU | _lib.EPI_SAVE_PRE if gelu else 0) | (_lib.EPI_RELU if relu else 0)
         pre = torch.empty((M, N), device=x.device, dtype=x.dtype) if gelu else None
         y = gemm(x2, w_c, M, N, K, K, N, True, False, x.dtype, bias=bias, aux=pre, flags=flags)
-        ctx.save_for_backward(x2, w_c, pre)
-        ctx.meta = (M, N, K, gelu, x.shape)
+        ctx.save_for_backward(x2, w_c, y if relu else pre)
+        ctx.meta = (M, N, K, "relu" if relu else gelu, x.shape)
         return y.reshape(x.shape[:-1] + (N,))
 
     @staticmethod
@@ -170,7 +205,11 @@ class LinearFn(torch.autograd.Function):
         x2, w_c, pre = ctx.saved_tensors
         M, N, K, gelu, xshape = ctx.meta
         dz = dy.reshape(M, N).contiguous()
-        if gelu:
+        if gelu == "relu":
+            out = torch.empty_like(dz)
+            check(lib.edgl_relu_bwd(_ptr(dz), _ptr(pre), _ptr(out), dz.numel(), _code(dz), _stream()), "edgl_relu_bwd")
+            dz = out
+        elif gelu:
             out = torch.empty_like(dz)
             check(lib.edgl_gelu_bwd(_ptr(dz), _ptr(pre), _ptr(out), dz.numel(), _code(dz), _stream()), "edgl_gelu_bwd")
             dz = out
@@ -378,7 +417,7 @@ class TppFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, lam, masked_pos, labels, ts_raw, mark_table, H, coef):
         HB, T, E = lam.shape
-        B, M = masked_pos.shape
+        B, M = labels.shape if masked_pos is None else masked_pos.shape
         sums = torch.empty(lib.edgl_tpp_workspace(), device=lam.device, dtype=torch.float32)
         reg = torch.empty(1, device=lam.device, dtype=torch.float32)
         check(lib.edgl_tpp_fwd(_ptr(lam), _ptr(masked_pos), _ptr(labels), _ptr(ts_raw), _ptr(mark_table), B, T, H, E, M,
@@ -446,3 +485,48 @@ def adam_step(param, grad, m, v, lr, state, l2, seg, shadow, beta1=0.9, beta2=0.
     check(lib.edgl_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), float(lr), beta1, beta2, eps,
                              _ptr(state), float(l2), _ptr(seg), 0 if seg is None else seg.numel() // 2, _ptr(shadow),
                              _stream()), "edgl_adam_step")
+
+
+class DropoutFn(torch.autograd.Function):
+    """tf.layers.dropout as a standalone op (FeedForward, Base.py:80,83): counter-based mask, regenerated in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, drop: Drop):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.edgl_dropout(_ptr(x), _ptr(y), x.numel(), float(drop.rate), drop.ptr(), drop.stream_id, _code(x), _stream()),
+              "edgl_dropout")
+        ctx.drop = drop
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        d = ctx.drop
+        check(lib.edgl_dropout(_ptr(dy), _ptr(dx), dy.numel(), float(d.rate), d.ptr(), d.stream_id, _code(dy), _stream()),
+              "edgl_dropout")
+        return dx, None
+
+
+def dropout(x, drop: Drop):
+    return x if not drop.active else DropoutFn.apply(x, drop)
+
+
+class AddFn(torch.autograd.Function):
+    """out = a + b (edgl_add); the gradient passes to both."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        check(lib.edgl_add(_ptr(a), _ptr(b), _ptr(out), a.numel(), _code(a), _stream()), "edgl_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return AddFn.apply(a, b)

@@ -6,4 +6,7 @@ def ranking(FLAGS):
     if FLAGS.model == "EasyDGL":
         from .model import EasyDGL
         return EasyDGL(FLAGS.num_items, FLAGS)
+    if FLAGS.model == "CTSMA":
+        from .model import CTSMA
+        return CTSMA(FLAGS.num_items, FLAGS)
     raise NotImplementedError("The ranking model: {0} not implemented".format(FLAGS.model))

@@ -46,7 +46,8 @@ enum {
     EDGL_EPI_SAVE_PRE = 4,    /* aux[m,n] = pre-activation (dtype)           */
     EDGL_EPI_MUL_DGELU = 8,   /* *= gelu'(aux[m,n])                          */
     EDGL_EPI_ACCUM = 16,      /* C += result                                 */
-    EDGL_EPI_OUT_F32 = 32     /* C is f32 regardless of dtype                */
+    EDGL_EPI_OUT_F32 = 32,    /* C is f32 regardless of dtype                */
+    EDGL_EPI_RELU = 64        /* max(x, 0) (FeedForward inner layer, Base.py:73) */
 };
 
 const char* edgl_last_error(void);
@@ -95,6 +96,19 @@ long edgl_encode_bwd_workspace(int B, int T, int C);
 int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const void* dx0, int B, int T, int C, int E,
                     int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, float* d_item,
                     float* d_pos, float* d_mark_emb, float* workspace, int dtype, void* stream);
+
+/* ---- K1b: CTSMA input encoding — CTSMA.py:48-58, coding.py:60-79 ----------------------------------
+ * ids int64 [B,T] (tokens[:-1]), ts f32 [B,T+1] raw seconds.  x0 [B,T,2C] `dtype` =
+ * dropout(concat(item_tab[ids] * sqrt(C) (row 0 reads as zeros), pos_tab[0..T))) (PositionCoding.__call__
+ * concatenates); spans f32 [B,T] = ts[t+1]/time_scale - ts[t]/time_scale (no clipping); marks u8 [B,T,E] =
+ * mark_table[ids].  bwd: d_item f32 [I,C] and d_pos f32 [T,C] are overwritten. */
+int edgl_embed_pos_fwd(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
+                       const uint8_t* mark_table, int B, int T, int C, int E, float time_scale, float drop_rate,
+                       const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans, uint8_t* marks,
+                       int dtype, void* stream);
+int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, int T, int C, int I, float drop_rate,
+                       const uint64_t* rng_state, uint32_t stream_id, float* d_item, float* d_pos, int dtype,
+                       void* stream);
 
 /* ---- K2/K4: dense layers — tf.layers.dense (temporal.py:409, EasyDGL.py:113,120,125,138) ------
  * C[M,N] = epilogue( sum_k A(m,k) * B(k,n) ).
@@ -244,7 +258,9 @@ int edgl_reduce_flush(void* stream);
  * mark_table uint8 [NI,E].  reg_out f32[1] (+)= coef * biased_mle with coef = ct_reg/H;
  * sums f32[edgl_tpp_workspace()] scratch (sums[0..2] = event-ll, non-event, #marks are reused by
  * the backward).  bwd zero-fills and writes d_lam f32 [H*B,T,E] (zero except at masked positions), scaled by
- * the device scalar gscale (NULL = 1). */
+ * the device scalar gscale (NULL = 1).
+ * masked_pos == NULL selects the all-position form of CTSMA.train (CTSMA.py:95-108): M == T, labels [B,T] (next
+ * items), ts_raw f32 [B,T+1] and the interval of position t is ts[t+1]-ts[t] (raw, unclipped). */
 int edgl_tpp_workspace(void);
 int edgl_tpp_fwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                  const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
@@ -268,6 +284,11 @@ int edgl_l2_loss(const float* param, const int64_t* seg, int nseg, float l2, flo
 int edgl_cast(const float* src, void* dst, long n, int dtype, void* stream);                 /* dst = (dtype)src      */
 int edgl_cast_back(const void* src, float* dst, long n, int accumulate, int dtype, void* stream); /* dst (+)= (f32)src */
 int edgl_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);      /* out = a + b           */
+/* y = x * keep / (1 - rate) with the counter-based keep mask of (rng_state, stream_id, element index): tf.layers.dropout
+ * (Base.py:80,83); calling it on dy with the same arguments is the backward. */
+int edgl_dropout(const void* x, void* y, long n, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, int dtype,
+                 void* stream);
+int edgl_relu_bwd(const void* dy, const void* y, void* dz, long n, int dtype, void* stream);   /* dz = dy*[y>0] (Base.py:73) */
 int edgl_gelu_bwd(const void* dy, const void* pre, void* dz, long n, int dtype, void* stream); /* dz = dy*gelu'(pre), EasyDGL.py:19-32 */
 int edgl_add_cols(void* dst, int ld_dst, const void* src, const void* src2, int ld_src, long rows, int ncols,
                   int dtype, void* stream);                                                             /* dst[:, :n] += src[:, :n] (+ src2[:, :n] if not NULL; same ld_src) */
