@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libeasydgl_hip.so")
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 8, 16, 32, 64
 MAU_CAUSAL, MAU_NO_DIAG = 1, 2
+TATTN_CAUSAL = 1
 
 P, I, F, L, U32, I64 = c_void_p, c_int, c_float, c_long, c_uint32, c_int64
 
@@ -71,6 +72,13 @@ SIGNATURES = {
     "edgl_dropout": (I, [P, P, L, F, P, U32, I, P]),
     "edgl_relu_bwd": (I, [P, P, P, L, I, P]),
     "edgl_gelu_bwd": (I, [P, P, P, L, I, P]),
+    "edgl_tattn_saved_bytes": (L, [I, I, I, I]),
+    "edgl_tattn_fwd": (I, [P, I, P, I, P, I, P, I, P, I, I, I, I, I, F, F, P, U32, P, I, P, I, I, P]),
+    "edgl_tattn_bwd": (I, [P, I, P, I, P, I, P, P, I, P, I, I, I, I, I, F, F, P, U32, P, I, P, I, P, I, I, I, P]),
+    "edgl_timefn_fwd": (I, [P, I, P, I, P, P, P, P, P, I, I, I, I, F, P, P, P, I, P]),
+    "edgl_timefn_bwd_workspace": (L, [I]),
+    "edgl_timefn_bwd": (I, [P, I, P, P, P, P, P, I, I, I, I, F, P, I, P, I, P, P, P, I, P]),
+    "edgl_mask_rows": (I, [P, P, P, L, I, I, P]),
 }
 
 

@@ -63,11 +63,13 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(EmbP p) {
     const int cv = (int)(gid % cpr), c0 = cv * 4, t = (int)(row % p.T);
     const long b = row / p.T;
     const int64_t id = p.ids[row];
-    if (cv == 0) {
+    if (cv == 0 && p.spans) {
         const float* tr = p.ts + b * (p.T + 1) + t;
         p.spans[row] = tr[1] / p.time_scale - tr[0] / p.time_scale;   // CTSMA.py:50-51
         for (int e = 0; e < p.E; ++e) p.marks[row * p.E + e] = p.mark_table[id * p.E + e];   // :54
     }
+    const int nseg = p.pos_tab ? 2 : 1;   // item | position (CTSMA) or the item embedding alone (TGAT.py:49, TiSASREC.py:52)
+    const long ldo = (long)nseg * p.C;
     const float sq = sqrtf((float)p.C);   // coding.py:62-63
     float v[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (id != 0) {   // coding.py:56-57 zero-padded row 0
@@ -75,15 +77,16 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(EmbP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[0][j] = to_f32(it.v[j]) * sq;
     }
-    const float4 pp = *reinterpret_cast<const float4*>(p.pos_tab + (long)t * p.C + c0);
-    v[1][0] = pp.x; v[1][1] = pp.y; v[1][2] = pp.z; v[1][3] = pp.w;
+    if (p.pos_tab) {
+        const float4 pp = *reinterpret_cast<const float4*>(p.pos_tab + (long)t * p.C + c0);
+        v[1][0] = pp.x; v[1][1] = pp.y; v[1][2] = pp.z; v[1][3] = pp.w;
+    }
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
-    T* out = reinterpret_cast<T*>(p.x0) + row * 2 * p.C;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    T* out = reinterpret_cast<T*>(p.x0) + row * ldo;
+    for (int s2 = 0; s2 < nseg; ++s2) {
         Frag4<T> o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o.v[j] = from_f32<T>(drop_apply(dk, (uint64_t)row * 2 * p.C + s2 * p.C + c0 + j, v[s2][j]));
+        for (int j = 0; j < 4; ++j) o.v[j] = from_f32<T>(drop_apply(dk, (uint64_t)row * ldo + s2 * p.C + c0 + j, v[s2][j]));
         if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(out + s2 * p.C + c0) = *reinterpret_cast<uint4*>(&o);
         else *reinterpret_cast<uint2*>(out + s2 * p.C + c0) = *reinterpret_cast<uint2*>(&o);
     }
@@ -99,13 +102,14 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(EmbP p) {
     const int cv = (int)(gid % cpr), c0 = cv * 4, t = (int)(row % p.T);
     const int64_t id = p.ids[row];
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
-    const T* d = reinterpret_cast<const T*>(p.dx0) + row * 2 * p.C;
-    const Frag4<T> g0 = frag_ld<T>(d + c0), g1 = frag_ld<T>(d + p.C + c0);
+    const long ldo = p.d_pos ? 2L * p.C : (long)p.C;
+    const T* d = reinterpret_cast<const T*>(p.dx0) + row * ldo;
+    const Frag4<T> g0 = frag_ld<T>(d + c0), g1 = p.d_pos ? frag_ld<T>(d + p.C + c0) : frag_zero<T>();
     const float sq = sqrtf((float)p.C);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (id != 0) atomicAdd(p.d_item + id * p.C + c0 + j, sq * drop_apply(dk, (uint64_t)row * 2 * p.C + c0 + j, to_f32(g0.v[j])));
-        atomicAdd(p.d_pos + (long)t * p.C + c0 + j, drop_apply(dk, (uint64_t)row * 2 * p.C + p.C + c0 + j, to_f32(g1.v[j])));
+        if (id != 0) atomicAdd(p.d_item + id * p.C + c0 + j, sq * drop_apply(dk, (uint64_t)row * ldo + c0 + j, to_f32(g0.v[j])));
+        if (p.d_pos) atomicAdd(p.d_pos + (long)t * p.C + c0 + j, drop_apply(dk, (uint64_t)row * ldo + p.C + c0 + j, to_f32(g1.v[j])));
     }
 }
 
@@ -115,8 +119,10 @@ extern "C" int edgl_embed_pos_fwd(const int64_t* ids, const float* ts, const voi
                                   const uint8_t* mark_table, int B, int T, int C, int E, float time_scale, float drop_rate,
                                   const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans, uint8_t* marks,
                                   int dtype, void* stream) {
-    EDGL_REQUIRE(ids && ts && item_tab && pos_tab && mark_table && x0 && spans && marks, EDGL_ERR_NULL, "edgl_embed_pos_fwd: null pointer");
-    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && E >= 1, EDGL_ERR_SHAPE, "edgl_embed_pos_fwd: bad shape B=%d T=%d C=%d E=%d", B, T, C, E);
+    EDGL_REQUIRE(ids && item_tab && x0, EDGL_ERR_NULL, "edgl_embed_pos_fwd: null pointer");
+    EDGL_REQUIRE((spans != nullptr) == (marks != nullptr) && (!spans || (ts && mark_table)), EDGL_ERR_NULL,
+                 "edgl_embed_pos_fwd: spans and marks go together and need ts and mark_table");
+    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && (E >= 1 || !spans), EDGL_ERR_SHAPE, "edgl_embed_pos_fwd: bad shape B=%d T=%d C=%d E=%d", B, T, C, E);
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_embed_pos_fwd: bad dtype %d", dtype);
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_embed_pos_fwd: dropout without rng_state");
     EmbP p{ids, ts, item_tab, pos_tab, mark_table, B, T, C, E, time_scale, drop_rate, rng_state, stream_id, x0, spans, marks,
@@ -132,12 +138,12 @@ extern "C" int edgl_embed_pos_fwd(const int64_t* ids, const float* ts, const voi
 extern "C" int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, int T, int C, int I, float drop_rate,
                                   const uint64_t* rng_state, uint32_t stream_id, float* d_item, float* d_pos, int dtype,
                                   void* stream) {
-    EDGL_REQUIRE(ids && dx0 && d_item && d_pos, EDGL_ERR_NULL, "edgl_embed_pos_bwd: null pointer");
+    EDGL_REQUIRE(ids && dx0 && d_item, EDGL_ERR_NULL, "edgl_embed_pos_bwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && I > 1, EDGL_ERR_SHAPE, "edgl_embed_pos_bwd: bad shape");
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_embed_pos_bwd: bad dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(d_item, 0, (size_t)I * C * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(d_pos, 0, (size_t)T * C * sizeof(float), st) != hipSuccess) {
+        (d_pos && hipMemsetAsync(d_pos, 0, (size_t)T * C * sizeof(float), st) != hipSuccess)) {
         edgl_set_error("edgl_embed_pos_bwd: memset failed");
         return EDGL_ERR_LAUNCH;
     }

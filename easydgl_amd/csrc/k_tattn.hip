@@ -1,0 +1,547 @@
+// K11: causal multi-head attention with a time feature map — TfMultiHeadAttention.__call__ (temporal.py:126-184, TGAT)
+// with TimeFunctionCoding.code (coding.py:104-122) folded into the operands.
+//
+// The reference scores a (query q, key k) pair with
+//     S[q,k] = sum_d Q[q,d] * ( K[k,d] + Pos[k,d] + cos(dt[q,k]*w_d + phi_d) ) / sqrt(dh),   dt[q,k] = max(t[q+1] - t[k], 0)
+// and materialises the cosine as a [B,T,T,C] tensor.  For every pair the causal + key masks keep (k <= q, key not padding)
+// the clamp is inactive when timestamps do not decrease, and cos(a-b) = cos a cos b + sin a sin b turns the time term
+// into two more inner products:
+//     q~[q] = [ Q | Q*cos(a_q w + phi) | Q*sin(a_q w + phi) ],  k~[k] = [ K + Pos | cos(b_k w) | sin(b_k w) ],  S = q~ . k~^T
+// with a_q = t[q+1] - base, b_k = t[k] - base (base = the sequence's last timestamp, so the arguments stay as small as the
+// reference's).  T*C transcendentals per sequence instead of T*T*C, and the T*T*C contraction runs on the matrix cores.
+// timefn_fwd counts sequences whose timestamps decrease at an unmasked position (the host checks the counter).
+//
+// The attention itself is generic in (Dq, Dv): one wave per (sample, head, 16-row tile); operands are read straight from
+// L2 as 4-element row chunks (A/B fragments of the 16x16 MFMA); a tile that has to be contracted along its rows is turned
+// with one MFMA against the identity (edgl_common.h transpose_tile) instead of an LDS round trip.
+//   fwd   : per query tile, online softmax over the key tiles, O^T += V^T . P^T; saves (max, sum) per row and O in f32
+//   bwd_q : per query tile, D = dO.O, dS = P*(dP - D), dQ~^T += K~^T . dS^T
+//   bwd_k : per key tile, loops the query tiles, dV^T += dO^T . A, dK~^T += Q~^T . dS
+// Fully masked query rows (left padding) are uniform over ALL keys in the reference (every score is replaced by the same
+// constant, temporal.py:158,166) and the joint LayerNorm that follows reads them, so no tile is skipped.
+#include <algorithm>
+
+#include "edgl_common.h"
+
+namespace {
+
+constexpr int TA_CAUSAL = 1;
+constexpr float PADV = -4294967296.0f;   // float32(-2**32 + 1)
+
+struct TaP {
+    const void *qx, *kx, *v, *resid;
+    int ldq, ldk, ldv, ldr;
+    const int64_t* ids;
+    int B, T, H, Dq, Dv;
+    float cscale, rate;
+    const uint64_t* rng; uint32_t stream_id;
+    void* out; int ldo;
+    float *st_m, *st_l, *st_d, *oatt;     // [H*B*T] each, oatt [B,T,H*Dv] f32
+    const void* d_out; int ld_do;
+    void *d_qx, *d_kx, *d_v; int ld_dq, ld_dk, ld_dv;
+    int flags, NT;
+};
+
+template <typename T> __device__ __forceinline__ void frag_st(T* dst, const Frag4<T>& f) {
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&f);
+    else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(&f);
+}
+// registers of a row-chunk load (lane = row l&15, 4 columns at (l>>4)*4) -> the same tile with rows on (l>>4)*4+r
+template <typename T> __device__ __forceinline__ Frag4<T> turn(const Frag4<T>& f, const Frag4<T>& ident) {
+    return frag_from_acc<T>(mma16(f, ident, f32x4{0.f, 0.f, 0.f, 0.f}));
+}
+
+struct Job { int b, head, tile; long bp; };
+__device__ __forceinline__ bool get_job(const TaP& p, Job& j) {
+    const long job = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (job >= (long)p.B * p.H * p.NT) return false;
+    j.tile = (int)(job % p.NT);
+    const long bh = job / p.NT;
+    j.head = (int)(bh % p.H);
+    j.b = (int)(bh / p.H);
+    j.bp = (long)j.head * p.B + j.b;   // head-major b' (temporal.py:139-141)
+    return true;
+}
+
+// ---- forward -----------------------------------------------------------------------------------------------------------
+template <typename T, int DVT>
+__global__ __launch_bounds__(256) void tattn_fwd_kernel(TaP p) {
+    Job j;
+    if (!get_job(p, j)) return;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
+    const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
+    const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * p.Dq;
+    const T* Kb = reinterpret_cast<const T*>(p.kx) + (long)j.b * p.T * p.ldk + j.head * p.Dq;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + (long)j.b * p.T * p.ldv + j.head * p.Dv;
+    const int64_t* idr = p.ids + (long)j.b * p.T;
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc[DVT];
+#pragma unroll
+    for (int ut = 0; ut < DVT; ++ut) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < p.NT; ++kt) {
+        const int kr = min(kt * 16 + l15, p.T - 1);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < p.Dq; d += 16) s = mma16(frag_ld<T>(Kb + (long)kr * p.ldk + d + g4), frag_ld<T>(Qr + d + g4), s);
+        float x[4], tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kt * 16 + g4 + r;
+            const float madd = k >= p.T ? -INFINITY : (idr[min(k, p.T - 1)] == 0 ? PADV : 0.f);   // temporal.py:153-158
+            float v = fmaf(s[r], p.cscale, madd);
+            if (causal && k > q && k < p.T) v = PADV;                                            // :161-166
+            x[r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+        tmax = group_max4(tmax);
+        const float m_new = fmaxf(m_run, tmax), corr = __expf(m_run - m_new);
+        f32x4 e;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = __expf(x[r] - m_new); psum += e[r]; }
+        l_run = l_run * corr + group_sum4(psum);
+        m_run = m_new;
+        if (dk.thresh != 0u) {   // :172 — the keep mask; the 1/(1-rate) factor is applied once in the epilogue
+            const uint32_t h0 = drop_hash_pair(dk, dbase + kt * 16 + g4), h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2);
+            e[0] = (h0 & 0xffffu) >= dk.t16 ? e[0] : 0.f;
+            e[1] = (h0 >> 16) >= dk.t16 ? e[1] : 0.f;
+            e[2] = (h1 & 0xffffu) >= dk.t16 ? e[2] : 0.f;
+            e[3] = (h1 >> 16) >= dk.t16 ? e[3] : 0.f;
+        }
+        const Frag4<T> pf = frag_from_acc<T>(e);
+#pragma unroll
+        for (int ut = 0; ut < DVT; ++ut) {
+            const Frag4<T> vt = turn<T>(frag_ld<T>(Vb + (long)kr * p.ldv + ut * 16 + g4), ident);   // V[k][u] with k on the registers
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ut][r] *= corr;
+            acc[ut] = mma16(vt, pf, acc[ut]);                                                          // :175
+        }
+    }
+    const float inv = dk.scale / l_run;
+    if (p.st_m && qok && g4 == 0) { p.st_m[j.bp * p.T + q] = m_run; p.st_l[j.bp * p.T + q] = l_run; }
+    if (!qok) return;
+    const long orow = (long)j.b * p.T + q;
+#pragma unroll
+    for (int ut = 0; ut < DVT; ++ut) {
+        const int col = j.head * p.Dv + ut * 16 + g4;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = acc[ut][r] * inv;
+        if (p.oatt) *reinterpret_cast<float4*>(p.oatt + orow * ((long)p.H * p.Dv) + col) = make_float4(o[0], o[1], o[2], o[3]);
+        const Frag4<T> rf = frag_ld<T>(reinterpret_cast<const T*>(p.resid) + orow * p.ldr + col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += to_f32(rf.v[r]);                                           // :181 residual
+        frag_st<T>(reinterpret_cast<T*>(p.out) + orow * p.ldo + col, frag_from_acc<T>(o));
+    }
+}
+
+// ---- backward, query side ---------------------------------------------------------------------------------------------
+template <typename T, int DQT>
+__global__ __launch_bounds__(256) void tattn_bwd_q_kernel(TaP p) {
+    Job j;
+    if (!get_job(p, j)) return;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
+    const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
+    const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * p.Dq;
+    const T* Kb = reinterpret_cast<const T*>(p.kx) + (long)j.b * p.T * p.ldk + j.head * p.Dq;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + (long)j.b * p.T * p.ldv + j.head * p.Dv;
+    const T* dOr = reinterpret_cast<const T*>(p.d_out) + ((long)j.b * p.T + qc) * p.ld_do + j.head * p.Dv;
+    const int64_t* idr = p.ids + (long)j.b * p.T;
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
+    // D[q] = sum_k dA[q,k] A[q,k] = dO[q] . O_att[q]
+    float dsum = 0.f;
+    {
+        const float* oa = p.oatt + ((long)j.b * p.T + qc) * ((long)p.H * p.Dv) + j.head * p.Dv;
+        for (int u = 0; u < p.Dv; u += 16) {
+            const Frag4<T> g = frag_ld<T>(dOr + u + g4);
+            const float4 o = *reinterpret_cast<const float4*>(oa + u + g4);
+            dsum += to_f32(g.v[0]) * o.x + to_f32(g.v[1]) * o.y + to_f32(g.v[2]) * o.z + to_f32(g.v[3]) * o.w;
+        }
+        dsum = group_sum4(dsum);
+        if (qok && g4 == 0) p.st_d[j.bp * p.T + q] = dsum;
+    }
+    const float m = p.st_m[j.bp * p.T + qc], invl = 1.0f / p.st_l[j.bp * p.T + qc];
+    f32x4 acc[DQT];
+#pragma unroll
+    for (int dt = 0; dt < DQT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < p.NT; ++kt) {
+        const int kr = min(kt * 16 + l15, p.T - 1);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < p.Dq; d += 16) s = mma16(frag_ld<T>(Kb + (long)kr * p.ldk + d + g4), frag_ld<T>(Qr + d + g4), s);
+        for (int u = 0; u < p.Dv; u += 16) da = mma16(frag_ld<T>(Vb + (long)kr * p.ldv + u + g4), frag_ld<T>(dOr + u + g4), da);
+        uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
+        if (dk.thresh != 0u) { h0 = drop_hash_pair(dk, dbase + kt * 16 + g4); h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2); }
+        const uint32_t hb[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kt * 16 + g4 + r;
+            const bool pad = k >= p.T || idr[min(k, p.T - 1)] == 0, fut = causal && k > q;
+            float v = fmaf(s[r], p.cscale, k >= p.T ? -INFINITY : (pad ? PADV : 0.f));
+            if (fut && k < p.T) v = PADV;
+            const float P = __expf(v - m) * invl;
+            const float dP = (dk.thresh == 0u || hb[r] >= dk.t16) ? da[r] * dk.scale : 0.f;
+            // a replaced score is a constant (tf.where): no gradient, also in a fully masked (uniform) row
+            ds[r] = (pad || fut || !qok) ? 0.f : P * (dP - dsum) * p.cscale;
+        }
+        const Frag4<T> dsf = frag_from_acc<T>(ds);
+#pragma unroll
+        for (int dt = 0; dt < DQT; ++dt)
+            acc[dt] = mma16(turn<T>(frag_ld<T>(Kb + (long)kr * p.ldk + dt * 16 + g4), ident), dsf, acc[dt]);
+    }
+    if (!qok) return;
+    T* dst = reinterpret_cast<T*>(p.d_qx) + ((long)j.b * p.T + q) * p.ld_dq + j.head * p.Dq;
+#pragma unroll
+    for (int dt = 0; dt < DQT; ++dt) frag_st<T>(dst + dt * 16 + g4, frag_from_acc<T>(acc[dt]));
+}
+
+// ---- backward, key side -----------------------------------------------------------------------------------------------
+template <typename T, int DQT, int DVT>
+__global__ __launch_bounds__(256) void tattn_bwd_k_kernel(TaP p) {
+    Job j;
+    if (!get_job(p, j)) return;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int k = j.tile * 16 + l15, kc = min(k, p.T - 1);
+    const bool kok = k < p.T, causal = (p.flags & TA_CAUSAL) != 0;
+    const T* Qb = reinterpret_cast<const T*>(p.qx) + (long)j.b * p.T * p.ldq + j.head * p.Dq;
+    const T* Kr = reinterpret_cast<const T*>(p.kx) + ((long)j.b * p.T + kc) * p.ldk + j.head * p.Dq;
+    const T* Vr = reinterpret_cast<const T*>(p.v) + ((long)j.b * p.T + kc) * p.ldv + j.head * p.Dv;
+    const T* dOb = reinterpret_cast<const T*>(p.d_out) + (long)j.b * p.T * p.ld_do + j.head * p.Dv;
+    const bool pad = !kok || p.ids[(long)j.b * p.T + kc] == 0;
+    const float madd = !kok ? -INFINITY : (pad ? PADV : 0.f);
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    f32x4 accK[DQT], accV[DVT];
+#pragma unroll
+    for (int dt = 0; dt < DQT; ++dt) accK[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ut = 0; ut < DVT; ++ut) accV[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < p.NT; ++qt) {
+        const int ql = min(qt * 16 + l15, p.T - 1);   // this lane's row when it loads an operand chunk
+        const T* Qrow = Qb + (long)ql * p.ldq;
+        const T* dOrow = dOb + (long)ql * p.ld_do;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};   // [q = g4+r][k = l15]
+        for (int d = 0; d < p.Dq; d += 16) s = mma16(frag_ld<T>(Qrow + d + g4), frag_ld<T>(Kr + d + g4), s);
+        for (int u = 0; u < p.Dv; u += 16) da = mma16(frag_ld<T>(dOrow + u + g4), frag_ld<T>(Vr + u + g4), da);
+        f32x4 a4, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + g4 + r, qc = min(q, p.T - 1);
+            const long si = j.bp * p.T + qc;
+            const bool fut = causal && k > q;
+            float v = fmaf(s[r], p.cscale, madd);
+            if (fut && kok) v = PADV;
+            const float P = (q < p.T) ? __expf(v - p.st_m[si]) / p.st_l[si] : 0.f;
+            bool keep = true;
+            if (dk.thresh != 0u) {
+                // same pairing as the forward: one hash per (k even, k + 1) of a row
+                const uint32_t h = drop_hash_pair(dk, (uint32_t)(si * p.T) + (uint32_t)(k & ~1));
+                keep = ((k & 1) ? (h >> 16) : (h & 0xffffu)) >= dk.t16;
+            }
+            a4[r] = keep ? P * dk.scale : 0.f;
+            const float dP = keep ? da[r] * dk.scale : 0.f;
+            ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - p.st_d[si]) * p.cscale;
+        }
+        const Frag4<T> af = frag_from_acc<T>(a4), dsf = frag_from_acc<T>(ds);
+#pragma unroll
+        for (int ut = 0; ut < DVT; ++ut)
+            accV[ut] = mma16(turn<T>(frag_ld<T>(dOrow + ut * 16 + g4), ident), af, accV[ut]);    // dV^T[u][k] += dO^T[u][q] A[q][k]
+#pragma unroll
+        for (int dt = 0; dt < DQT; ++dt)
+            accK[dt] = mma16(turn<T>(frag_ld<T>(Qrow + dt * 16 + g4), ident), dsf, accK[dt]);     // dK~^T[d][k] += Q~^T[d][q] dS[q][k]
+    }
+    if (!kok) return;
+    T* dK = reinterpret_cast<T*>(p.d_kx) + ((long)j.b * p.T + k) * p.ld_dk + j.head * p.Dq;
+    T* dV = reinterpret_cast<T*>(p.d_v) + ((long)j.b * p.T + k) * p.ld_dv + j.head * p.Dv;
+#pragma unroll
+    for (int dt = 0; dt < DQT; ++dt) frag_st<T>(dK + dt * 16 + g4, frag_from_acc<T>(accK[dt]));
+#pragma unroll
+    for (int ut = 0; ut < DVT; ++ut) frag_st<T>(dV + ut * 16 + g4, frag_from_acc<T>(accV[ut]));
+}
+
+template <typename K>
+int launch_jobs(K kern, const TaP& p, hipStream_t st) {
+    const long jobs = (long)p.B * p.H * p.NT;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, st, p);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+template <typename T>
+int launch_fwd(const TaP& p, hipStream_t st) {
+    switch (p.Dv / 16) {
+        case 1: return launch_jobs(tattn_fwd_kernel<T, 1>, p, st);
+        case 2: return launch_jobs(tattn_fwd_kernel<T, 2>, p, st);
+        case 4: return launch_jobs(tattn_fwd_kernel<T, 4>, p, st);
+        case 8: return launch_jobs(tattn_fwd_kernel<T, 8>, p, st);
+    }
+    edgl_set_error("edgl_tattn_fwd: value head dim %d not supported (16, 32, 64, 128)", p.Dv);
+    return EDGL_ERR_SHAPE;
+}
+template <typename T>
+int launch_bwd(const TaP& p, hipStream_t st) {
+    const int dqt = p.Dq / 16, dvt = p.Dv / 16;
+    int rc = EDGL_ERR_SHAPE;
+#define EDGL_TA_CASE(DQ, DV)                                                     \
+    if (dqt == DQ && dvt == DV) {                                                \
+        rc = launch_jobs(tattn_bwd_q_kernel<T, DQ>, p, st);                      \
+        if (rc == EDGL_OK) rc = launch_jobs(tattn_bwd_k_kernel<T, DQ, DV>, p, st); \
+        return rc;                                                               \
+    }
+    EDGL_TA_CASE(1, 1) EDGL_TA_CASE(2, 2) EDGL_TA_CASE(4, 4) EDGL_TA_CASE(8, 8)        // plain heads (Dq == Dv)
+    EDGL_TA_CASE(3, 1) EDGL_TA_CASE(6, 2) EDGL_TA_CASE(12, 4) EDGL_TA_CASE(24, 8)      // time feature map (Dq == 3 Dv)
+#undef EDGL_TA_CASE
+    edgl_set_error("edgl_tattn_bwd: head dims Dq=%d Dv=%d not supported (Dv in {16,32,64,128}, Dq in {Dv, 3 Dv})", p.Dq, p.Dv);
+    return rc;
+}
+
+// ---- time feature map (coding.py:104-122 through the angle-difference identity) ------------------------------------------
+struct TfP {
+    const void *q, *k; int ldq, ldk;
+    const float *pos, *ts, *omega, *phi;
+    const int64_t* ids;
+    int B, T, C, H;
+    float time_scale;
+    void *qx, *kx;
+    int* viol;
+    const void *d_qx, *d_kx;
+    void *d_q, *d_k; int ld_dq, ld_dk;
+    float* part;   // [blocks][2C]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void timefn_fwd_kernel(TfP p) {
+    const int cpr = p.C >> 2, dh = p.C / p.H;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = gid / cpr;
+    if (row >= (long)p.B * p.T) return;
+    const int c0 = (int)(gid % cpr) * 4, t = (int)(row % p.T);
+    const long b = row / p.T;
+    const float* tr = p.ts + b * (p.T + 1);
+    const float base = tr[p.T] / p.time_scale;                       // TGAT.py:46 (seqs_ts = seqs_t / time_scale)
+    const float xt = tr[t] / p.time_scale, xn = tr[t + 1] / p.time_scale;
+    const float a = xn - base, bk = xt - base;
+    if (c0 == 0 && xn < xt && p.ids[row] != 0) atomicAdd(p.viol, 1);  // max(.,0) of TGAT.py:54 would be active here
+    const Frag4<T> qv = frag_ld<T>(reinterpret_cast<const T*>(p.q) + row * p.ldq + c0);
+    const Frag4<T> kv = frag_ld<T>(reinterpret_cast<const T*>(p.k) + row * p.ldk + c0);
+    const float4 w = *reinterpret_cast<const float4*>(p.omega + c0), ph = *reinterpret_cast<const float4*>(p.phi + c0);
+    const float4 pp = *reinterpret_cast<const float4*>(p.pos + (long)t * p.C + c0);
+    const float ww[4] = {w.x, w.y, w.z, w.w}, pv[4] = {ph.x, ph.y, ph.z, ph.w}, ps[4] = {pp.x, pp.y, pp.z, pp.w};
+    Frag4<T> q0, qc, qs, k0, kc, ks;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float sq, cq, sk, ck;
+        sincosf(a * ww[i] + pv[i], &sq, &cq);
+        sincosf(bk * ww[i], &sk, &ck);
+        const float qf = to_f32(qv.v[i]);
+        q0.v[i] = qv.v[i];
+        qc.v[i] = from_f32<T>(qf * cq);
+        qs.v[i] = from_f32<T>(qf * sq);
+        k0.v[i] = from_f32<T>(to_f32(kv.v[i]) + ps[i]);              // temporal.py:143,148: Q . (K + pos)^T
+        kc.v[i] = from_f32<T>(ck);
+        ks.v[i] = from_f32<T>(sk);
+    }
+    const int head = c0 / dh, u = c0 % dh;
+    T* qo = reinterpret_cast<T*>(p.qx) + (row * p.H + head) * 3 * dh + u;
+    T* ko = reinterpret_cast<T*>(p.kx) + (row * p.H + head) * 3 * dh + u;
+    frag_st<T>(qo, q0); frag_st<T>(qo + dh, qc); frag_st<T>(qo + 2 * dh, qs);
+    frag_st<T>(ko, k0); frag_st<T>(ko + dh, kc); frag_st<T>(ko + 2 * dh, ks);
+}
+
+// dQ = dq0 + dqc*cos + dqs*sin; dK = dk0 (also the position-table gradient, summed over the batch by the caller);
+// dtheta = Q*(dqs*cos - dqc*sin) -> dphi += dtheta, domega += dtheta * a;  dpsi = dks*cos_k - dkc*sin_k -> domega += dpsi * b
+template <typename T>
+__global__ __launch_bounds__(256) void timefn_bwd_kernel(TfP p) {
+    __shared__ float red[256][8];
+    const int cpr = p.C >> 2, dh = p.C / p.H, rpb = 256 / cpr;     // rows per pass of a block
+    const int cv = threadIdx.x % cpr, rl = threadIdx.x / cpr, c0 = cv * 4;
+    const float4 w = *reinterpret_cast<const float4*>(p.omega + c0), ph = *reinterpret_cast<const float4*>(p.phi + c0);
+    const float ww[4] = {w.x, w.y, w.z, w.w}, pv[4] = {ph.x, ph.y, ph.z, ph.w};
+    float dw[4] = {0.f, 0.f, 0.f, 0.f}, dph[4] = {0.f, 0.f, 0.f, 0.f};
+    const long R = (long)p.B * p.T;
+    const int head = c0 / dh, u = c0 % dh;
+    for (long row = (long)blockIdx.x * rpb + rl; row < R; row += (long)gridDim.x * rpb) {
+        const int t = (int)(row % p.T);
+        const long b = row / p.T;
+        const float* tr = p.ts + b * (p.T + 1);
+        const float base = tr[p.T] / p.time_scale;
+        const float a = tr[t + 1] / p.time_scale - base, bk = tr[t] / p.time_scale - base;
+        const Frag4<T> qv = frag_ld<T>(reinterpret_cast<const T*>(p.q) + row * p.ldq + c0);
+        const T* gq = reinterpret_cast<const T*>(p.d_qx) + (row * p.H + head) * 3 * dh + u;
+        const T* gk = reinterpret_cast<const T*>(p.d_kx) + (row * p.H + head) * 3 * dh + u;
+        const Frag4<T> g0 = frag_ld<T>(gq), gc = frag_ld<T>(gq + dh), gs = frag_ld<T>(gq + 2 * dh);
+        const Frag4<T> h0 = frag_ld<T>(gk), hc = frag_ld<T>(gk + dh), hs = frag_ld<T>(gk + 2 * dh);
+        Frag4<T> dq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float sq, cq, sk, ck;
+            sincosf(a * ww[i] + pv[i], &sq, &cq);
+            sincosf(bk * ww[i], &sk, &ck);
+            const float gcf = to_f32(gc.v[i]), gsf = to_f32(gs.v[i]);
+            dq.v[i] = from_f32<T>(to_f32(g0.v[i]) + gcf * cq + gsf * sq);
+            const float dth = to_f32(qv.v[i]) * (gsf * cq - gcf * sq);
+            const float dps = to_f32(hs.v[i]) * ck - to_f32(hc.v[i]) * sk;
+            dph[i] += dth;
+            dw[i] += dth * a + dps * bk;
+        }
+        frag_st<T>(reinterpret_cast<T*>(p.d_q) + row * p.ld_dq + c0, dq);
+        frag_st<T>(reinterpret_cast<T*>(p.d_k) + row * p.ld_dk + c0, h0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x][i] = dw[i]; red[threadIdx.x][4 + i] = dph[i]; }
+    __syncthreads();
+    if (rl == 0) {
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rpb; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += red[r * cpr + cv][i];
+        float* dst = p.part + (long)blockIdx.x * 2 * p.C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dst[c0 + i] = o[i]; dst[p.C + c0 + i] = o[4 + i]; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mask_rows_kernel(const T* x, const int64_t* ids, T* y, long rows, int C) {
+    const int cpr = C >> 2;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = gid / cpr;
+    if (row >= rows) return;
+    const int c0 = (int)(gid % cpr) * 4;
+    const Frag4<T> v = ids[row] != 0 ? frag_ld<T>(x + row * C + c0) : frag_zero<T>();
+    frag_st<T>(y + row * C + c0, v);
+}
+
+constexpr int TF_BLOCKS = 256;
+
+struct SavedTa { size_t off_m, off_l, off_d, off_o, bytes; };
+SavedTa saved_ta(int B, int T, int H, int Dv) {
+    const size_t R = ((size_t)B * H * T + 63) & ~(size_t)63;
+    SavedTa s;
+    s.off_m = 0; s.off_l = R * 4; s.off_d = 2 * R * 4; s.off_o = 3 * R * 4;
+    s.bytes = s.off_o + (size_t)B * T * H * Dv * 4;
+    return s;
+}
+
+int check_common(const char* who, int B, int T, int H, int Dq, int Dv, int ldq, int ldk, int ldv, int dtype) {
+    EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && Dq > 0 && Dv > 0 && Dq % 16 == 0 && Dv % 16 == 0, EDGL_ERR_SHAPE,
+                 "%s: bad shape B=%d T=%d H=%d Dq=%d Dv=%d (head dims must be multiples of 16)", who, B, T, H, Dq, Dv);
+    EDGL_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, EDGL_ERR_SHAPE, "%s: row strides must be multiples of 4", who);
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
+    EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "%s: H*B*T*T must be < 2^32", who);
+    return EDGL_OK;
+}
+
+}  // namespace
+
+extern "C" long edgl_tattn_saved_bytes(int B, int T, int H, int Dv) {
+    if (B <= 0 || T <= 0 || H <= 0 || Dv <= 0) return -1;
+    return (long)saved_ta(B, T, H, Dv).bytes;
+}
+
+extern "C" int edgl_tattn_fwd(const void* qx, int ldq, const void* kx, int ldk, const void* v, int ldv, const void* resid,
+                              int ldr, const int64_t* ids, int B, int T, int H, int Dq, int Dv, float scale, float drop_rate,
+                              const uint64_t* rng_state, uint32_t stream_id, void* out, int ldo, void* saved, int flags,
+                              int dtype, void* stream) {
+    EDGL_REQUIRE(qx && kx && v && resid && ids && out, EDGL_ERR_NULL, "edgl_tattn_fwd: null pointer");
+    if (int rc = check_common("edgl_tattn_fwd", B, T, H, Dq, Dv, ldq, ldk, ldv, dtype)) return rc;
+    EDGL_REQUIRE(ldr % 4 == 0 && ldo % 4 == 0, EDGL_ERR_SHAPE, "edgl_tattn_fwd: row strides must be multiples of 4");
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_tattn_fwd: dropout without rng_state");
+    TaP p{};
+    p.qx = qx; p.kx = kx; p.v = v; p.resid = resid; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldr = ldr;
+    p.ids = ids; p.B = B; p.T = T; p.H = H; p.Dq = Dq; p.Dv = Dv; p.cscale = scale; p.rate = drop_rate;
+    p.rng = rng_state; p.stream_id = stream_id; p.out = out; p.ldo = ldo; p.flags = flags; p.NT = (T + 15) / 16;
+    if (saved) {
+        const SavedTa s = saved_ta(B, T, H, Dv);
+        p.st_m = reinterpret_cast<float*>((char*)saved + s.off_m);
+        p.st_l = reinterpret_cast<float*>((char*)saved + s.off_l);
+        p.st_d = reinterpret_cast<float*>((char*)saved + s.off_d);
+        p.oatt = reinterpret_cast<float*>((char*)saved + s.off_o);
+    }
+    return dtype == EDGL_F32 ? launch_fwd<float>(p, (hipStream_t)stream) : launch_fwd<bf16>(p, (hipStream_t)stream);
+}
+
+extern "C" int edgl_tattn_bwd(const void* qx, int ldq, const void* kx, int ldk, const void* v, int ldv, const int64_t* ids,
+                              const void* d_out, int ld_do, void* saved, int B, int T, int H, int Dq, int Dv, float scale,
+                              float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* d_qx, int ld_dq,
+                              void* d_kx, int ld_dk, void* d_v, int ld_dv, int flags, int dtype, void* stream) {
+    EDGL_REQUIRE(qx && kx && v && ids && d_out && saved && d_qx && d_kx && d_v, EDGL_ERR_NULL, "edgl_tattn_bwd: null pointer");
+    if (int rc = check_common("edgl_tattn_bwd", B, T, H, Dq, Dv, ldq, ldk, ldv, dtype)) return rc;
+    EDGL_REQUIRE(ld_do % 4 == 0 && ld_dq % 4 == 0 && ld_dk % 4 == 0 && ld_dv % 4 == 0, EDGL_ERR_SHAPE,
+                 "edgl_tattn_bwd: row strides must be multiples of 4");
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_tattn_bwd: dropout without rng_state");
+    TaP p{};
+    p.qx = qx; p.kx = kx; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+    p.ids = ids; p.B = B; p.T = T; p.H = H; p.Dq = Dq; p.Dv = Dv; p.cscale = scale; p.rate = drop_rate;
+    p.rng = rng_state; p.stream_id = stream_id; p.flags = flags; p.NT = (T + 15) / 16;
+    p.d_out = d_out; p.ld_do = ld_do; p.d_qx = d_qx; p.d_kx = d_kx; p.d_v = d_v; p.ld_dq = ld_dq; p.ld_dk = ld_dk; p.ld_dv = ld_dv;
+    const SavedTa s = saved_ta(B, T, H, Dv);
+    p.st_m = reinterpret_cast<float*>((char*)saved + s.off_m);
+    p.st_l = reinterpret_cast<float*>((char*)saved + s.off_l);
+    p.st_d = reinterpret_cast<float*>((char*)saved + s.off_d);
+    p.oatt = reinterpret_cast<float*>((char*)saved + s.off_o);
+    return dtype == EDGL_F32 ? launch_bwd<float>(p, (hipStream_t)stream) : launch_bwd<bf16>(p, (hipStream_t)stream);
+}
+
+extern "C" int edgl_timefn_fwd(const void* q, int ldq, const void* k, int ldk, const float* pos_tab, const float* ts,
+                               const int64_t* ids, const float* omega, const float* phi, int B, int T, int C, int H,
+                               float time_scale, void* qx, void* kx, int* violations, int dtype, void* stream) {
+    EDGL_REQUIRE(q && k && pos_tab && ts && ids && omega && phi && qx && kx && violations, EDGL_ERR_NULL, "edgl_timefn_fwd: null pointer");
+    EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && (C / H) % 16 == 0 && ldq % 4 == 0 && ldk % 4 == 0, EDGL_ERR_SHAPE,
+                 "edgl_timefn_fwd: bad shape B=%d T=%d C=%d H=%d (head dim must be a multiple of 16)", B, T, C, H);
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_timefn_fwd: bad dtype %d", dtype);
+    TfP p{};
+    p.q = q; p.k = k; p.ldq = ldq; p.ldk = ldk; p.pos = pos_tab; p.ts = ts; p.ids = ids; p.omega = omega; p.phi = phi;
+    p.B = B; p.T = T; p.C = C; p.H = H; p.time_scale = time_scale; p.qx = qx; p.kx = kx; p.viol = violations;
+    const long total = (long)B * T * (C / 4);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((timefn_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((timefn_fwd_kernel<bf16>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" long edgl_timefn_bwd_workspace(int C) { return (long)TF_BLOCKS * 2 * C; }
+
+extern "C" int edgl_timefn_bwd(const void* q, int ldq, const float* ts, const float* omega, const float* phi, const void* d_qx,
+                               const void* d_kx, int B, int T, int C, int H, float time_scale, void* d_q, int ld_dq, void* d_k,
+                               int ld_dk, float* d_omega, float* d_phi, float* workspace, int dtype, void* stream) {
+    EDGL_REQUIRE(q && ts && omega && phi && d_qx && d_kx && d_q && d_k && d_omega && d_phi && workspace, EDGL_ERR_NULL,
+                 "edgl_timefn_bwd: null pointer");
+    EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && (C / H) % 16 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0 &&
+                     ldq % 4 == 0 && ld_dq % 4 == 0 && ld_dk % 4 == 0, EDGL_ERR_SHAPE,
+                 "edgl_timefn_bwd: bad shape B=%d T=%d C=%d H=%d (C/4 must divide 256)", B, T, C, H);
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_timefn_bwd: bad dtype %d", dtype);
+    TfP p{};
+    p.q = q; p.ldq = ldq; p.ts = ts; p.omega = omega; p.phi = phi; p.B = B; p.T = T; p.C = C; p.H = H;
+    p.time_scale = time_scale; p.d_qx = d_qx; p.d_kx = d_kx; p.d_q = d_q; p.d_k = d_k; p.ld_dq = ld_dq; p.ld_dk = ld_dk;
+    p.part = workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int rpb = 256 / (C / 4);
+    const int blocks = (int)std::min<long>(TF_BLOCKS, ((long)B * T + rpb - 1) / rpb);
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((timefn_bwd_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((timefn_bwd_kernel<bf16>), dim3(blocks), dim3(256), 0, st, p);
+    EDGL_LAUNCH_CHECK();
+    // partial rows are [d_omega | d_phi]: one fixed-order reduction each
+    if (int rc = edgl_reduce_rows(workspace, blocks, C, 2L * C, d_omega, 0, st)) return rc;
+    return edgl_reduce_rows(workspace + C, blocks, C, 2L * C, d_phi, 0, st);
+}
+
+extern "C" int edgl_mask_rows(const void* x, const int64_t* ids, void* y, long rows, int C, int dtype, void* stream) {
+    EDGL_REQUIRE(x && ids && y, EDGL_ERR_NULL, "edgl_mask_rows: null pointer");
+    EDGL_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, EDGL_ERR_SHAPE, "edgl_mask_rows: bad shape rows=%ld C=%d", rows, C);
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_mask_rows: bad dtype %d", dtype);
+    const long total = rows * (C / 4);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((mask_rows_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream,
+                                              (const float*)x, ids, (float*)y, rows, C);
+    else hipLaunchKernelGGL((mask_rows_kernel<bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ids, (bf16*)y, rows, C);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}

@@ -152,7 +152,7 @@ class CTSMA(Sequential):
             with torch.no_grad():
                 param.copy_(torch.as_tensor(np.asarray(arr), dtype=param.dtype).reshape(param.shape))
         put(self.item_embs.lookup_table, values["CSTMA/item_embs/lookup_table"])
-        put(self.pcoding.pembs.lookup_table, values["CSTMA/spatial_embs/lookup_table"])
+        put(self.pcoding.pembs.lookup_table, values["CSTMA/spatial_embs/embedding/lookup_table"])
         put(self.output_bias, values["CSTMA/output_bias"])
         for i, blk in enumerate(self.layers):
             pre = f"num_blocks_{i}/"
@@ -182,7 +182,7 @@ class CTSMA(Sequential):
         """Gradients of the last backward under the TF variable names (K|V|T_ split back into dense_1..3)."""
         g = lambda q: q.grad.detach().float().cpu().numpy()
         out = {"CSTMA/item_embs/lookup_table": g(self.item_embs.lookup_table),
-               "CSTMA/spatial_embs/lookup_table": g(self.pcoding.pembs.lookup_table), "CSTMA/output_bias": g(self.output_bias)}
+               "CSTMA/spatial_embs/embedding/lookup_table": g(self.pcoding.pembs.lookup_table), "CSTMA/output_bias": g(self.output_bias)}
         C_ = self.num_units
         for i, blk in enumerate(self.layers):
             pre = f"num_blocks_{i}/"

@@ -48,3 +48,22 @@ class TimeSinusoidCoding(nn.Module):
         self.num_units = num_units
         scale = np.power(10000, np.arange(0, num_units, 2) * 1.0 / num_units).astype(np.float32)
         self.register_buffer("scale", torch.from_numpy(scale), persistent=False)
+
+
+class TimeFunctionCoding(nn.Module):
+    """coding.py:104-122 (TGAT): ``basis_freq`` [C] = linspace(0, 9, C), ``phase`` [C] zeros; code(dt) = cos(dt * basis_freq +
+    phase).  On the attention path the [B,T,T,C] code tensor is never built (csrc/k_tattn.hip folds it into the operands)."""
+
+    def __init__(self, num_units):
+        super().__init__()
+        self.num_units = num_units
+        self.basis_freq = nn.Parameter(torch.from_numpy(np.linspace(0, 9, num_units).astype(np.float32)))
+        self.phase = nn.Parameter(torch.zeros(num_units))
+
+
+class TimeIntervalCoding(nn.Module):
+    """coding.py:82-94 (TiSASRec): an embedding table indexed by the clipped integer interval."""
+
+    def __init__(self, vocab_size, num_units, l2_reg=0.0, gen=None):
+        super().__init__()
+        self.pembs = Embedding(vocab_size, num_units, l2_reg, zero_pad=False, scale=False, gen=gen)

@@ -1,5 +1,6 @@
 """Mirror of src/module/temporal.py: BiMAU (the Bi-level Modulating Attention Unit used by EasyDGL) and MAU (the causal
-unit of CTSMA), both on the fused HIP attention kernels."""
+unit of CTSMA), both on the fused HIP attention kernels, and TfMultiHeadAttention (TGAT) on the generic masked attention
+kernel with the time feature map."""
 from __future__ import annotations
 
 import torch
@@ -68,3 +69,35 @@ class MAU(nn.Module):
         flags = ops.MAU_NO_DIAG | (ops.MAU_CAUSAL if causality else 0)
         return ops.BiMAUFn.apply(qkvt, queries[:, :, :C], self.st_kernel, self.st_bias, self.weight, self.scaling, masks,
                                  intervals, marks, self.num_heads, drop if is_training else ops.NO_DROP, flags)
+
+
+class TfMultiHeadAttention(nn.Module):
+    """temporal.py:108-184 (TGAT, ICLR'20).  ``q_kernel`` [C,C] (dense), ``kv_kernel`` [C,2C] (dense_1 | dense_2 as column
+    blocks: K and V read the same input, one GEMM); the position table and the time-function parameters are the model's shared
+    ``pcoding_K`` / ``tcoding_K`` (TGAT.py:29-30).  ``__call__(queries, keys, intervals, is_training, causality)`` as in the
+    reference, except that ``intervals`` is the pair (ids [B,T], seqs_t [B,T+1]) the [B,T,T] interval tensor is a function of —
+    it is never materialised — and the key mask is ``ids != 0`` (a key row of the reference is all-zero exactly there)."""
+
+    def __init__(self, num_units, num_heads, dropout_rate, l2_reg, pcoding_K, tcoding_K, gen=None):
+        super().__init__()
+        self.num_units, self.num_heads, self.dropout_rate, self.l2_reg = num_units, num_heads, dropout_rate, l2_reg
+        self.q_kernel = nn.Parameter(glorot_uniform_(torch.empty(num_units, num_units), gen))
+        self.q_bias = nn.Parameter(torch.zeros(num_units))
+        kv = torch.cat([glorot_uniform_(torch.empty(num_units, num_units), gen) for _ in range(2)], dim=1)
+        self.kv_kernel = nn.Parameter(kv)
+        self.kv_bias = nn.Parameter(torch.zeros(2 * num_units))
+        object.__setattr__(self, "pcoding_K", pcoding_K)   # shared with the model: not registered twice
+        object.__setattr__(self, "tcoding_K", tcoding_K)
+        self.compute = lambda p: p
+        self.time_scale = 1.0
+        self.violations = None
+
+    def forward(self, queries, keys, intervals, is_training, causality=True, drop: ops.Drop = ops.NO_DROP):
+        if not causality:
+            raise NotImplementedError("the HIP time-function attention implements the causal form TGAT uses (TGAT.py:66)")
+        ids, ts = intervals
+        q = ops.LinearFn.apply(queries, self.q_kernel, self.q_bias, self.compute(self.q_kernel), False)
+        kv = ops.LinearFn.apply(keys, self.kv_kernel, self.kv_bias, self.compute(self.kv_kernel), False)
+        return ops.TfAttnFn.apply(q, kv, queries, self.pcoding_K.pembs.lookup_table, self.tcoding_K.basis_freq,
+                                  self.tcoding_K.phase, ids, ts, self.num_heads, self.time_scale,
+                                  drop if is_training else ops.NO_DROP, self.violations)

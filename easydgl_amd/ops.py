@@ -26,6 +26,15 @@ def _ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+def _vptr(t: torch.Tensor):
+    """Pointer of a strided VIEW (a column block of a wider activation buffer); the row stride is passed separately."""
+    if not t.is_cuda:
+        raise _lib.EdglError("easydgl_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+    if t.stride(-1) != 1:
+        raise _lib.EdglError("easydgl_amd ops need unit stride along the last axis")
+    return t.data_ptr()
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -530,3 +539,109 @@ class AddFn(torch.autograd.Function):
 
 def add(a, b):
     return AddFn.apply(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# config 5 baselines: item embedding alone, row mask, K11 attention with the time feature map
+# ------------------------------------------------------------------------------------------------
+class EmbedFn(torch.autograd.Function):
+    """x = dropout(item[ids] * sqrt(C)) with the zero-padded row 0 (TGAT.py:49-56, TiSASREC.py:52-65): edgl_embed_pos_* with
+    no position table."""
+
+    @staticmethod
+    def forward(ctx, item_master, item_c, ids, drop: Drop, act_dtype):
+        B, T = ids.shape
+        I, C = item_c.shape
+        x0 = torch.empty((B, T, C), device=ids.device, dtype=act_dtype)
+        check(lib.edgl_embed_pos_fwd(_ptr(ids), None, _ptr(item_c), None, None, B, T, C, 0, 1.0, float(drop.rate), drop.ptr(),
+                                     drop.stream_id, _ptr(x0), None, None, _DT[act_dtype], _stream()), "edgl_embed_pos_fwd")
+        ctx.save_for_backward(ids)
+        ctx.meta = (B, T, C, I, drop, item_master.shape)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        (ids,) = ctx.saved_tensors
+        B, T, C, I, drop, ishape = ctx.meta
+        dx0 = dx0.contiguous()
+        d_item = torch.empty(ishape, device=dx0.device, dtype=torch.float32)
+        check(lib.edgl_embed_pos_bwd(_ptr(ids), _ptr(dx0), B, T, C, I, float(drop.rate), drop.ptr(), drop.stream_id,
+                                     _ptr(d_item), None, _code(dx0), _stream()), "edgl_embed_pos_bwd")
+        return d_item, None, None, None, None
+
+
+class MaskRowsFn(torch.autograd.Function):
+    """y = x * (ids != 0)[..., None]  (`seqs_outs *= seqs_masks`, TGAT.py:70)."""
+
+    @staticmethod
+    def forward(ctx, x, ids):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.edgl_mask_rows(_ptr(x), _ptr(ids), _ptr(y), ids.numel(), x.shape[-1], _code(x), _stream()), "edgl_mask_rows")
+        ctx.save_for_backward(ids)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib.edgl_mask_rows(_ptr(dy), _ptr(ids), _ptr(dx), ids.numel(), dy.shape[-1], _code(dy), _stream()), "edgl_mask_rows")
+        return dx, None
+
+
+def mask_rows(x, ids):
+    return MaskRowsFn.apply(x, ids)
+
+
+class TfAttnFn(torch.autograd.Function):
+    """TfMultiHeadAttention after its dense layers (temporal.py:139-184): q [B,T,C], kv [B,T,2C] (K | V column blocks),
+    resid = the queries; time feature map (edgl_timefn_*) + masked causal attention (edgl_tattn_*).  `violations`: device
+    int32 counter of positions whose timestamps decrease (see include/easydgl_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, resid, pos_tab, omega, phi, ids, ts, H, time_scale, drop: Drop, violations):
+        B, T, C = q.shape
+        dh = C // H
+        q, kv, resid = q.contiguous(), kv.contiguous(), resid.contiguous()
+        code = _code(q)
+        qx = torch.empty((B, T, 3 * C), device=q.device, dtype=q.dtype)
+        kx = torch.empty_like(qx)
+        check(lib.edgl_timefn_fwd(_ptr(q), C, _ptr(kv), 2 * C, _ptr(pos_tab), _ptr(ts), _ptr(ids), _ptr(omega), _ptr(phi), B, T, C,
+                                  H, float(time_scale), _ptr(qx), _ptr(kx), _ptr(violations), code, _stream()), "edgl_timefn_fwd")
+        out = torch.empty((B, T, C), device=q.device, dtype=q.dtype)
+        need = any(ctx.needs_input_grad)
+        saved = torch.empty(int(lib.edgl_tattn_saved_bytes(B, T, H, dh)), device=q.device, dtype=torch.uint8) if need else None
+        scale = 1.0 / float(dh) ** 0.5                                                   # temporal.py:153
+        check(lib.edgl_tattn_fwd(_ptr(qx), 3 * C, _ptr(kx), 3 * C, _vptr(kv[:, :, C:]), 2 * C, _ptr(resid), C, _ptr(ids), B, T, H,
+                                 3 * dh, dh, scale, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(out), C, _ptr(saved),
+                                 _lib.TATTN_CAUSAL, code, _stream()), "edgl_tattn_fwd")
+        ctx.save_for_backward(q, kv, qx, kx, omega, phi, ids, ts, saved)
+        ctx.meta = (B, T, C, H, dh, scale, float(time_scale), drop, pos_tab.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q, kv, qx, kx, omega, phi, ids, ts, saved = ctx.saved_tensors
+        B, T, C, H, dh, scale, time_scale, drop, pshape = ctx.meta
+        d_out = d_out.contiguous()
+        code = _code(q)
+        d_qx, d_kx = torch.empty_like(qx), torch.empty_like(kx)
+        d_kv = torch.empty_like(kv)
+        check(lib.edgl_tattn_bwd(_ptr(qx), 3 * C, _ptr(kx), 3 * C, _vptr(kv[:, :, C:]), 2 * C, _ptr(ids), _ptr(d_out), C, _ptr(saved),
+                                 B, T, H, 3 * dh, dh, scale, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(d_qx), 3 * C,
+                                 _ptr(d_kx), 3 * C, _vptr(d_kv[:, :, C:]), 2 * C, _lib.TATTN_CAUSAL, code, _stream()), "edgl_tattn_bwd")
+        d_q = torch.empty_like(q)
+        d_omega = torch.empty(C, device=q.device, dtype=torch.float32)
+        d_phi = torch.empty_like(d_omega)
+        ws = torch.empty(int(lib.edgl_timefn_bwd_workspace(C)), device=q.device, dtype=torch.float32)
+        check(lib.edgl_timefn_bwd(_ptr(q), C, _ptr(ts), _ptr(omega), _ptr(phi), _ptr(d_qx), _ptr(d_kx), B, T, C, H, time_scale,
+                                  _ptr(d_q), C, _ptr(d_kv), 2 * C, _ptr(d_omega), _ptr(d_phi), _ptr(ws), code, _stream()),
+              "edgl_timefn_bwd")
+        # d(pos_tab)[t] = sum_b dK[b,t]  (K + pos enters the score, temporal.py:143,148): column sums of d_kv seen as [B, T*2C]
+        d_pos = colsum(d_kv.view(B, T * 2 * C), B, T * 2 * C).view(T, 2 * C)[:, :C].contiguous()
+        if pshape[0] != T:
+            full = torch.zeros(pshape, device=q.device, dtype=torch.float32)
+            full[:T] = d_pos
+            d_pos = full
+        return d_q, d_kv, d_out, d_pos, d_omega, d_phi, None, None, None, None, None, None

@@ -101,7 +101,9 @@ int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const void* dx0, i
  * ids int64 [B,T] (tokens[:-1]), ts f32 [B,T+1] raw seconds.  x0 [B,T,2C] `dtype` =
  * dropout(concat(item_tab[ids] * sqrt(C) (row 0 reads as zeros), pos_tab[0..T))) (PositionCoding.__call__
  * concatenates); spans f32 [B,T] = ts[t+1]/time_scale - ts[t]/time_scale (no clipping); marks u8 [B,T,E] =
- * mark_table[ids].  bwd: d_item f32 [I,C] and d_pos f32 [T,C] are overwritten. */
+ * mark_table[ids].  bwd: d_item f32 [I,C] and d_pos f32 [T,C] are overwritten.
+ * pos_tab == NULL (d_pos == NULL in the backward): x0 is [B,T,C], the item embedding alone (TGAT.py:49-56,
+ * TiSASREC.py:52-65); spans and marks may be NULL together (then ts and mark_table are not read). */
 int edgl_embed_pos_fwd(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
                        const uint8_t* mark_table, int B, int T, int C, int E, float time_scale, float drop_rate,
                        const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans, uint8_t* marks,
@@ -292,6 +294,48 @@ int edgl_relu_bwd(const void* dy, const void* y, void* dz, long n, int dtype, vo
 int edgl_gelu_bwd(const void* dy, const void* pre, void* dz, long n, int dtype, void* stream); /* dz = dy*gelu'(pre), EasyDGL.py:19-32 */
 int edgl_add_cols(void* dst, int ld_dst, const void* src, const void* src2, int ld_src, long rows, int ncols,
                   int dtype, void* stream);                                                             /* dst[:, :n] += src[:, :n] (+ src2[:, :n] if not NULL; same ld_src) */
+
+/* ---- K11: causal attention with a time feature map (config 5: TGAT) ---------------------------------
+ * Replaces TfMultiHeadAttention.__call__ (src/module/temporal.py:126-184) after its three dense layers, with
+ * TimeFunctionCoding.code (src/module/coding.py:104-122) folded into the operands.
+ *
+ * edgl_timefn_fwd: q [B,T,C] (row stride ldq), k [B,T,C] (ldk), pos_tab f32 [T,C] (pcoding_K), ts f32 [B,T+1] raw seconds
+ * (RegressivePostProcessor layout, dataloader.py:95-108), omega/phi f32 [C] (basis_freq, phase) ->
+ *   qx [B,T,H,3*dh] = [ Q | Q*cos(a w + phi) | Q*sin(a w + phi) ],  kx [B,T,H,3*dh] = [ K + pos | cos(b w) | sin(b w) ]
+ * with a[t] = ts[t+1]/time_scale - base, b[t] = ts[t]/time_scale - base, base = ts[T]/time_scale, so that
+ *   qx[q] . kx[k] = sum_d Q[q,d] (K[k,d] + pos[k,d] + cos((ts'[q+1]-ts'[k]) w_d + phi_d))       (temporal.py:143-148)
+ * which is the reference's score wherever its max(.,0) clamp (TGAT.py:54) is inactive: every unmasked (k <= q) pair of a
+ * sequence with non-decreasing timestamps.  *violations (int32, device) += number of unpadded positions t with
+ * ts[t+1] < ts[t]; the caller must treat a non-zero count as an input error.
+ * edgl_timefn_bwd: d_qx, d_kx -> d_q (ld_dq), d_k (ld_dk; this is also d(pos_tab) before the sum over the batch),
+ * d_omega, d_phi f32 [C] (overwritten).  workspace >= edgl_timefn_bwd_workspace(C) floats.
+ *
+ * edgl_tattn_fwd: generic masked attention per (sample, head): S = scale * qx_h . kx_h^T with head slices
+ * qx[:, :, h*Dq:(h+1)*Dq] (same for kx; v and out use Dv); scores of padded keys (ids == 0) and, with EDGL_TATTN_CAUSAL,
+ * of keys k > q are REPLACED by float32(-2^32+1) (temporal.py:153-166: a fully masked row is uniform over all T keys);
+ * P = softmax(S); out = dropout(P) . v_h + resid (temporal.py:169-181).  Dq, Dv multiples of 16; Dv in {16,32,64,128}.
+ * saved (NULL for inference): edgl_tattn_saved_bytes bytes = row max / sum / dO.O [H*B*T] f32 each + O before the
+ * residual [B,T,H*Dv] f32.  edgl_tattn_bwd (Dq in {Dv, 3*Dv}): d_out -> d_qx, d_kx, d_v (the residual gradient is d_out
+ * itself); no gradient flows into a replaced score. */
+#define EDGL_TATTN_CAUSAL 1
+long edgl_tattn_saved_bytes(int B, int T, int H, int Dv);
+int edgl_tattn_fwd(const void* qx, int ldq, const void* kx, int ldk, const void* v, int ldv, const void* resid, int ldr,
+                   const int64_t* ids, int B, int T, int H, int Dq, int Dv, float scale, float drop_rate,
+                   const uint64_t* rng_state, uint32_t stream_id, void* out, int ldo, void* saved, int flags, int dtype,
+                   void* stream);
+int edgl_tattn_bwd(const void* qx, int ldq, const void* kx, int ldk, const void* v, int ldv, const int64_t* ids,
+                   const void* d_out, int ld_do, void* saved, int B, int T, int H, int Dq, int Dv, float scale,
+                   float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* d_qx, int ld_dq, void* d_kx,
+                   int ld_dk, void* d_v, int ld_dv, int flags, int dtype, void* stream);
+int edgl_timefn_fwd(const void* q, int ldq, const void* k, int ldk, const float* pos_tab, const float* ts,
+                    const int64_t* ids, const float* omega, const float* phi, int B, int T, int C, int H,
+                    float time_scale, void* qx, void* kx, int* violations, int dtype, void* stream);
+long edgl_timefn_bwd_workspace(int C);
+int edgl_timefn_bwd(const void* q, int ldq, const float* ts, const float* omega, const float* phi, const void* d_qx,
+                    const void* d_kx, int B, int T, int C, int H, float time_scale, void* d_q, int ld_dq, void* d_k,
+                    int ld_dk, float* d_omega, float* d_phi, float* workspace, int dtype, void* stream);
+/* y = x * (ids != 0) per row: `seqs_outs *= seqs_masks` (TGAT.py:58,70; TiSASREC.py:73); its own backward. */
+int edgl_mask_rows(const void* x, const int64_t* ids, void* y, long rows, int C, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ def init_params(num_items: int, T: int, C: int, h: int, E: int, num_blocks: int,
     dh = C // h
     g = O.glorot_uniform
     p = {"CSTMA/item_embs/lookup_table": g(rng, (num_items, C)),
-         "CSTMA/spatial_embs/lookup_table": g(rng, (T, C)),
+         "CSTMA/spatial_embs/embedding/lookup_table": g(rng, (T, C)),
          "CSTMA/output_bias": np.zeros(num_items - 1)}
     for i in range(num_blocks):
         cin = 2 * C if i == 0 else C
@@ -59,7 +59,7 @@ def encoder(p, mark_table, seqs_i, seqs_t, C: int, h: int, num_blocks: int, time
     spans = ts[:, 1:] - ts[:, :-1]                                                  # :51
     marks = torch.tensor(np.asarray(mark_table)[np.asarray(seqs_i)], dtype=dtype)   # :54
     x = R.zero_padded(p["CSTMA/item_embs/lookup_table"])[ids] * (C ** 0.5)          # :55, coding.py:60-64
-    pos = p["CSTMA/spatial_embs/lookup_table"][:T].unsqueeze(0).expand(B, T, C)
+    pos = p["CSTMA/spatial_embs/embedding/lookup_table"][:T].unsqueeze(0).expand(B, T, C)
     x = torch.cat([x, pos], dim=-1)                                                 # :56, PositionCoding.__call__ coding.py:72-74
     keymask3 = (ids != 0).to(dtype).unsqueeze(1).repeat(h, T, 1)                    # :61-62
     lams: List[torch.Tensor] = []
@@ -100,7 +100,7 @@ def train_loss(p, mark_table, features, labels, C: int, h: int, num_blocks: int,
     lp = torch.log(torch.softmax(logits, -1) + 1e-5)                                 # :97
     reg = torch.zeros((), dtype=dtype)
     if l2_reg != 0.0:                                                               # coding.py:34-40 on both tables
-        for k in ("CSTMA/item_embs/lookup_table", "CSTMA/spatial_embs/lookup_table"):
+        for k in ("CSTMA/item_embs/lookup_table", "CSTMA/spatial_embs/embedding/lookup_table"):
             reg = reg + l2_reg * 0.5 * (p[k] ** 2).sum()
     if ct_reg != 0.0:                                                               # :101-112
         raw = torch.tensor(np.asarray(features["seqs_t"], dtype=np.float32).astype(np.float64), dtype=dtype)
