@@ -79,6 +79,11 @@ SIGNATURES = {
     "edgl_timefn_bwd_workspace": (L, [I]),
     "edgl_timefn_bwd": (I, [P, I, P, P, P, P, P, I, I, I, I, F, P, I, P, I, P, P, P, I, P]),
     "edgl_mask_rows": (I, [P, P, P, L, I, I, P]),
+    "edgl_tiattn_bucket_elems": (L, [I, I, I, I]),
+    "edgl_tiattn_fwd": (I, [P, I, P, I, P, I, P, I, P, P, P, P, I, I, I, I, I, F, F, I, F, P, U32, P, I, P, P, I, I, P]),
+    "edgl_tiattn_bwd": (I, [P, I, P, I, P, I, P, P, P, P, I, P, I, P, P, I, I, I, I, F, F, I, F, P, U32, P, I, P, I, P, I, P, P, P,
+                            I, I, P]),
+    "edgl_add_pos2": (I, [P, P, P, I, I, I, P, I, P]),
 }
 
 

@@ -265,6 +265,376 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_kernel(TaP p) {
     for (int ut = 0; ut < DVT; ++ut) frag_st<T>(dV + ut * 16 + g4, frag_from_acc<T>(accV[ut]));
 }
 
+// =========================================================================================================================
+// Interval-bucket form — TiMultiHeadAttention.__call__ (temporal.py:36-105, TiSASRec): the score adds Q[q].Ktime[dt(q,k)]
+// and the value adds Vtime[dt(q,k)], dt = int(clip(t[q+1] - t[k], 0, timelen)) (TiSASREC.py:58-62).  Per 16-row query tile
+// the wave projects its rows onto the whole interval table once (G[q][d] = Q[q].Ktime[d], 17 MFMA tiles into LDS) and the
+// [T,T] pair loop gathers from it; on the value side the probabilities are binned per interval (W[q][d] += A[q,k], LDS
+// atomics) and one more MFMA chain applies Vtime.  The reference builds two [B,T,T,C] gathers instead.
+// =========================================================================================================================
+struct TiP {
+    const float* ts; float time_scale; int timelen;
+    const void *ktime, *vtime; int ldt, tab_rows;     // [tab_rows, H*dh] activation dtype; bucket >= tab_rows reads as zeros
+    void *wbuf, *dgbuf; int NBp;                      // [H*B*T][NBp] activation dtype: binned probabilities / score gradients
+};
+
+__device__ __forceinline__ int bucket_of(float xq1, float xk, int timelen) {
+    return (int)fminf(fmaxf(xq1 - xk, 0.f), (float)timelen);                       // clip then tf.to_int64 (truncation)
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Gs[row l&15][d] = sum_u X[row][u] * tab[d][u] for every bucket d < NBp (tab rows >= tab_rows read as zero)
+template <typename T, int DT>
+__device__ __forceinline__ void bucket_project(const T* xrow, const T* tab, int ldt, int tab_rows, int NBp, float* Gs, int LDG, int lane) {
+    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+    Frag4<T> xf[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) xf[dt] = frag_ld<T>(xrow + dt * 16 + g4);
+    for (int d0 = 0; d0 < NBp; d0 += 16) {
+        const int dl = d0 + l15;
+        const T* trow = tab + (long)min(dl, tab_rows - 1) * ldt;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            Frag4<T> tf = frag_ld<T>(trow + dt * 16 + g4);
+            if (dl >= tab_rows) tf = frag_zero<T>();
+            a = mma16(tf, xf[dt], a);
+        }
+        *reinterpret_cast<float4*>(Gs + l15 * LDG + d0 + g4) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+template <typename T> __device__ __forceinline__ Frag4<T> frag_from_f4(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return frag_from_acc<T>(f32x4{v.x, v.y, v.z, v.w});
+}
+// acc[dt] += sum_d tab[d][dt*16 + .]^T . Ws[row][d]   (the bucket contraction on the matrix cores)
+template <typename T, int DT>
+__device__ __forceinline__ void bucket_apply(const float* Ws, int LDG, const T* tab, int ldt, int tab_rows, int NBp,
+                                             const Frag4<T>& ident, f32x4 (&acc)[DT], int lane) {
+    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+    for (int d0 = 0; d0 < NBp; d0 += 16) {
+        const Frag4<T> bf = frag_from_f4<T>(Ws + l15 * LDG + d0 + g4);
+        const int dl = d0 + l15;
+        const T* trow = tab + (long)min(dl, tab_rows - 1) * ldt;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            Frag4<T> tf = frag_ld<T>(trow + dt * 16 + g4);
+            if (dl >= tab_rows) tf = frag_zero<T>();
+            acc[dt] = mma16(turn<T>(tf, ident), bf, acc[dt]);
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void bucket_store(const float* Ws, int LDG, int NBp, T* dst_row, int lane) {
+    const int l15 = lane & 15;
+    for (int c = (lane >> 4) * 4; c < NBp; c += 16) frag_st<T>(dst_row + c, frag_from_f4<T>(Ws + l15 * LDG + c));
+}
+
+template <typename T, int DT>
+__global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    Job j;
+    if (!get_job(p, j)) return;
+    constexpr int dh = 16 * DT;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4;
+    float* Gs = lds_f + (size_t)(threadIdx.x >> 6) * 2 * 16 * LDG;
+    float* Ws = Gs + 16 * LDG;
+    const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
+    const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
+    const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * dh;
+    const T* Kb = reinterpret_cast<const T*>(p.kx) + (long)j.b * p.T * p.ldk + j.head * dh;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + (long)j.b * p.T * p.ldv + j.head * dh;
+    const T* Kt = reinterpret_cast<const T*>(t.ktime) + j.head * dh;
+    const T* Vt = reinterpret_cast<const T*>(t.vtime) + j.head * dh;
+    const int64_t* idr = p.ids + (long)j.b * p.T;
+    const float* tsr = t.ts + (long)j.b * (p.T + 1);
+    const float xq1 = tsr[qc + 1] / t.time_scale;                                         // TiSASREC.py:49
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
+    bucket_project<T, DT>(Qr, Kt, t.ldt, t.tab_rows, t.NBp, Gs, LDG, lane);               // temporal.py:58
+    for (int i = lane; i < 16 * LDG; i += 64) Ws[i] = 0.f;
+    wave_lds_sync();
+    Frag4<T> qf[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) qf[dt] = frag_ld<T>(Qr + dt * 16 + g4);
+    auto scores = [&](int kt, float (&x)[4], int (&bk)[4]) {
+        const int kr = min(kt * 16 + l15, p.T - 1);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) s = mma16(frag_ld<T>(Kb + (long)kr * p.ldk + dt * 16 + g4), qf[dt], s);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kt * 16 + g4 + r, kcl = min(k, p.T - 1);
+            bk[r] = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
+            const float madd = k >= p.T ? -INFINITY : (idr[kcl] == 0 ? PADV : 0.f);
+            float v = fmaf(s[r] + Gs[l15 * LDG + bk[r]], p.cscale, madd);                 // temporal.py:56-62
+            if (causal && k > q && k < p.T) v = PADV;
+            x[r] = v;
+        }
+    };
+    float m = -INFINITY, l = 0.f;
+    for (int kt = 0; kt < p.NT; ++kt) {
+        float x[4]; int bk[4];
+        scores(kt, x, bk);
+        const float tmax = group_max4(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+        const float m_new = fmaxf(m, tmax);
+        const float ps = __expf(x[0] - m_new) + __expf(x[1] - m_new) + __expf(x[2] - m_new) + __expf(x[3] - m_new);
+        l = l * __expf(m - m_new) + group_sum4(ps);
+        m = m_new;
+    }
+    const float invl = 1.0f / l;
+    f32x4 acc[DT];
+#pragma unroll
+    for (int ut = 0; ut < DT; ++ut) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < p.NT; ++kt) {
+        float x[4]; int bk[4];
+        scores(kt, x, bk);
+        const int kr = min(kt * 16 + l15, p.T - 1);
+        uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
+        if (dk.thresh != 0u) { h0 = drop_hash_pair(dk, dbase + kt * 16 + g4); h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2); }
+        const uint32_t hb[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+        f32x4 a4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float P = __expf(x[r] - m) * invl;
+            a4[r] = (dk.thresh == 0u || hb[r] >= dk.t16) ? P * dk.scale : 0.f;            // temporal.py:90
+            atomicAdd(&Ws[l15 * LDG + bk[r]], a4[r]);
+        }
+        const Frag4<T> pf = frag_from_acc<T>(a4);
+#pragma unroll
+        for (int ut = 0; ut < DT; ++ut)
+            acc[ut] = mma16(turn<T>(frag_ld<T>(Vb + (long)kr * p.ldv + ut * 16 + g4), ident), pf, acc[ut]);   // :93-94
+    }
+    wave_lds_sync();
+    bucket_apply<T, DT>(Ws, LDG, Vt, t.ldt, t.tab_rows, t.NBp, ident, acc, lane);                               // :95
+    if (t.wbuf && qok) bucket_store<T>(Ws, LDG, t.NBp, reinterpret_cast<T*>(t.wbuf) + (j.bp * p.T + q) * (long)t.NBp, lane);
+    if (p.st_m && qok && g4 == 0) { p.st_m[j.bp * p.T + q] = m; p.st_l[j.bp * p.T + q] = l; }
+    if (!qok) return;
+    const long orow = (long)j.b * p.T + q;
+#pragma unroll
+    for (int ut = 0; ut < DT; ++ut) {
+        const int col = j.head * dh + ut * 16 + g4;
+        f32x4 o = acc[ut];
+        if (p.oatt) *reinterpret_cast<float4*>(p.oatt + orow * ((long)p.H * dh) + col) = make_float4(o[0], o[1], o[2], o[3]);
+        const Frag4<T> rf = frag_ld<T>(reinterpret_cast<const T*>(p.resid) + orow * p.ldr + col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += to_f32(rf.v[r]);                                                    // :102-104
+        frag_st<T>(reinterpret_cast<T*>(p.out) + orow * p.ldo + col, frag_from_acc<T>(o));
+    }
+}
+
+template <typename T, int DT>
+__global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    Job j;
+    if (!get_job(p, j)) return;
+    constexpr int dh = 16 * DT;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4;
+    float* Gs = lds_f + (size_t)(threadIdx.x >> 6) * 3 * 16 * LDG;
+    float* dWs = Gs + 16 * LDG;
+    float* dGs = dWs + 16 * LDG;
+    const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
+    const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
+    const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * dh;
+    const T* Kb = reinterpret_cast<const T*>(p.kx) + (long)j.b * p.T * p.ldk + j.head * dh;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + (long)j.b * p.T * p.ldv + j.head * dh;
+    const T* dOr = reinterpret_cast<const T*>(p.d_out) + ((long)j.b * p.T + qc) * p.ld_do + j.head * dh;
+    const T* Kt = reinterpret_cast<const T*>(t.ktime) + j.head * dh;
+    const T* Vt = reinterpret_cast<const T*>(t.vtime) + j.head * dh;
+    const int64_t* idr = p.ids + (long)j.b * p.T;
+    const float* tsr = t.ts + (long)j.b * (p.T + 1);
+    const float xq1 = tsr[qc + 1] / t.time_scale;
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
+    bucket_project<T, DT>(Qr, Kt, t.ldt, t.tab_rows, t.NBp, Gs, LDG, lane);
+    bucket_project<T, DT>(dOr, Vt, t.ldt, t.tab_rows, t.NBp, dWs, LDG, lane);     // dA[q,k] gets dO[q].Vtime[dt(q,k)]
+    for (int i = lane; i < 16 * LDG; i += 64) dGs[i] = 0.f;
+    float dsum = 0.f;
+    Frag4<T> qf[DT], gf[DT];
+    {
+        const float* oa = p.oatt + ((long)j.b * p.T + qc) * ((long)p.H * dh) + j.head * dh;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            qf[dt] = frag_ld<T>(Qr + dt * 16 + g4);
+            gf[dt] = frag_ld<T>(dOr + dt * 16 + g4);
+            const float4 o = *reinterpret_cast<const float4*>(oa + dt * 16 + g4);
+            dsum += to_f32(gf[dt].v[0]) * o.x + to_f32(gf[dt].v[1]) * o.y + to_f32(gf[dt].v[2]) * o.z + to_f32(gf[dt].v[3]) * o.w;
+        }
+        dsum = group_sum4(dsum);
+        if (qok && g4 == 0) p.st_d[j.bp * p.T + q] = dsum;
+    }
+    const float m = p.st_m[j.bp * p.T + qc], invl = 1.0f / p.st_l[j.bp * p.T + qc];
+    wave_lds_sync();
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < p.NT; ++kt) {
+        const int kr = min(kt * 16 + l15, p.T - 1);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            s = mma16(frag_ld<T>(Kb + (long)kr * p.ldk + dt * 16 + g4), qf[dt], s);
+            da = mma16(frag_ld<T>(Vb + (long)kr * p.ldv + dt * 16 + g4), gf[dt], da);
+        }
+        uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
+        if (dk.thresh != 0u) { h0 = drop_hash_pair(dk, dbase + kt * 16 + g4); h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2); }
+        const uint32_t hb[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kt * 16 + g4 + r, kcl = min(k, p.T - 1);
+            const int bk = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
+            const bool pad = k >= p.T || idr[kcl] == 0, fut = causal && k > q;
+            float v = fmaf(s[r] + Gs[l15 * LDG + bk], p.cscale, k >= p.T ? -INFINITY : (pad ? PADV : 0.f));
+            if (fut && k < p.T) v = PADV;
+            const float P = __expf(v - m) * invl;
+            const float dP = (dk.thresh == 0u || hb[r] >= dk.t16) ? (da[r] + dWs[l15 * LDG + bk]) * dk.scale : 0.f;
+            ds[r] = (pad || fut || !qok) ? 0.f : P * (dP - dsum) * p.cscale;
+            atomicAdd(&dGs[l15 * LDG + bk], ds[r]);
+        }
+        const Frag4<T> dsf = frag_from_acc<T>(ds);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+            acc[dt] = mma16(turn<T>(frag_ld<T>(Kb + (long)kr * p.ldk + dt * 16 + g4), ident), dsf, acc[dt]);
+    }
+    wave_lds_sync();
+    bucket_apply<T, DT>(dGs, LDG, Kt, t.ldt, t.tab_rows, t.NBp, ident, acc, lane);   // dQ[q] += sum_d dG[q][d] Ktime[d]
+    if (qok) bucket_store<T>(dGs, LDG, t.NBp, reinterpret_cast<T*>(t.dgbuf) + (j.bp * p.T + q) * (long)t.NBp, lane);
+    if (!qok) return;
+    T* dst = reinterpret_cast<T*>(p.d_qx) + ((long)j.b * p.T + q) * p.ld_dq + j.head * dh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) frag_st<T>(dst + dt * 16 + g4, frag_from_acc<T>(acc[dt]));
+}
+
+template <typename T, int DT>
+__global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    Job j;
+    if (!get_job(p, j)) return;
+    constexpr int dh = 16 * DT;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4;
+    float* Gs = lds_f + (size_t)(threadIdx.x >> 6) * 2 * 16 * LDG;
+    float* dWs = Gs + 16 * LDG;
+    const int k = j.tile * 16 + l15, kc = min(k, p.T - 1);
+    const bool kok = k < p.T, causal = (p.flags & TA_CAUSAL) != 0;
+    const T* Qb = reinterpret_cast<const T*>(p.qx) + (long)j.b * p.T * p.ldq + j.head * dh;
+    const T* Kr = reinterpret_cast<const T*>(p.kx) + ((long)j.b * p.T + kc) * p.ldk + j.head * dh;
+    const T* Vr = reinterpret_cast<const T*>(p.v) + ((long)j.b * p.T + kc) * p.ldv + j.head * dh;
+    const T* dOb = reinterpret_cast<const T*>(p.d_out) + (long)j.b * p.T * p.ld_do + j.head * dh;
+    const T* Kt = reinterpret_cast<const T*>(t.ktime) + j.head * dh;
+    const T* Vt = reinterpret_cast<const T*>(t.vtime) + j.head * dh;
+    const float* tsr = t.ts + (long)j.b * (p.T + 1);
+    const float xk = tsr[kc] / t.time_scale;
+    const bool pad = !kok || p.ids[(long)j.b * p.T + kc] == 0;
+    const float madd = !kok ? -INFINITY : (pad ? PADV : 0.f);
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    Frag4<T> kf[DT], vf[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { kf[dt] = frag_ld<T>(Kr + dt * 16 + g4); vf[dt] = frag_ld<T>(Vr + dt * 16 + g4); }
+    f32x4 accK[DT], accV[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { accK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int qt = 0; qt < p.NT; ++qt) {
+        const int ql = min(qt * 16 + l15, p.T - 1);
+        const T* Qrow = Qb + (long)ql * p.ldq;
+        const T* dOrow = dOb + (long)ql * p.ld_do;
+        wave_lds_sync();                                                             // the previous tile's gathers are done
+        bucket_project<T, DT>(Qrow, Kt, t.ldt, t.tab_rows, t.NBp, Gs, LDG, lane);
+        bucket_project<T, DT>(dOrow, Vt, t.ldt, t.tab_rows, t.NBp, dWs, LDG, lane);
+        wave_lds_sync();
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+        Frag4<T> qf[DT], gf[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            qf[dt] = frag_ld<T>(Qrow + dt * 16 + g4);
+            gf[dt] = frag_ld<T>(dOrow + dt * 16 + g4);
+            s = mma16(qf[dt], kf[dt], s);
+            da = mma16(gf[dt], vf[dt], da);
+        }
+        f32x4 a4, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + g4 + r, qc = min(q, p.T - 1);
+            const long si = j.bp * p.T + qc;
+            const int bk = bucket_of(tsr[qc + 1] / t.time_scale, xk, t.timelen);
+            const bool fut = causal && k > q;
+            float v = fmaf(s[r] + Gs[(g4 + r) * LDG + bk], p.cscale, madd);
+            if (fut && kok) v = PADV;
+            const float P = (q < p.T) ? __expf(v - p.st_m[si]) / p.st_l[si] : 0.f;
+            bool keep = true;
+            if (dk.thresh != 0u) {
+                const uint32_t h = drop_hash_pair(dk, (uint32_t)(si * p.T) + (uint32_t)(k & ~1));
+                keep = ((k & 1) ? (h >> 16) : (h & 0xffffu)) >= dk.t16;
+            }
+            a4[r] = keep ? P * dk.scale : 0.f;
+            const float dP = keep ? (da[r] + dWs[(g4 + r) * LDG + bk]) * dk.scale : 0.f;
+            ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - p.st_d[si]) * p.cscale;
+        }
+        const Frag4<T> af = frag_from_acc<T>(a4), dsf = frag_from_acc<T>(ds);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            accV[dt] = mma16(turn<T>(gf[dt], ident), af, accV[dt]);
+            accK[dt] = mma16(turn<T>(qf[dt], ident), dsf, accK[dt]);
+        }
+    }
+    if (!kok) return;
+    T* dK = reinterpret_cast<T*>(p.d_kx) + ((long)j.b * p.T + k) * p.ld_dk + j.head * dh;
+    T* dV = reinterpret_cast<T*>(p.d_v) + ((long)j.b * p.T + k) * p.ld_dv + j.head * dh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { frag_st<T>(dK + dt * 16 + g4, frag_from_acc<T>(accK[dt])); frag_st<T>(dV + dt * 16 + g4, frag_from_acc<T>(accV[dt])); }
+}
+
+// d_tab[d][head*dh + u] += sum_r Wb[head*BT + r][d] * X[r][head*dh + u]: the interval-table gradients
+//   d(Ktime) = dG^T . Q,  d(Vtime) = W^T . dO   (contraction over all B*T rows; f32 atomics of per-split partial tiles)
+template <typename T>
+__global__ __launch_bounds__(256) void bucket_dtable_kernel(const T* Wb, int NBp, const T* X, int ldx, long BT, int H, int dh,
+                                                            int tab_rows, float* d_tab, int ldt, int splits) {
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int ndt = NBp / 16, nut = dh / 16;
+    long job = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (job >= (long)H * ndt * nut * splits) return;
+    const int sp = (int)(job % splits); job /= splits;
+    const int ut = (int)(job % nut); job /= nut;
+    const int dti = (int)(job % ndt);
+    const int head = (int)(job / ndt);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const long ntile = (BT + 15) / 16, per = (ntile + splits - 1) / splits;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long rt = sp * per; rt < min(ntile, (sp + 1) * per); ++rt) {
+        const long r = rt * 16 + l15, rc = min(r, BT - 1);
+        Frag4<T> wf = frag_ld<T>(Wb + ((long)head * BT + rc) * NBp + dti * 16 + g4);
+        if (r >= BT) wf = frag_zero<T>();
+        const Frag4<T> xf = frag_ld<T>(X + rc * ldx + head * dh + ut * 16 + g4);
+        acc = mma16(turn<T>(wf, ident), turn<T>(xf, ident), acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int d = dti * 16 + g4 + r;
+        if (d < tab_rows) atomicAdd(d_tab + (long)d * ldt + head * dh + ut * 16 + l15, acc[r]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_pos2_kernel(const T* kv, const float* posK, const float* posV, T* out, long rows, int T_, int C) {
+    const int cpr = (2 * C) >> 2;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = gid / cpr;
+    if (row >= rows) return;
+    const int c0 = (int)(gid % cpr) * 4, tpos = (int)(row % T_);
+    const Frag4<T> v = frag_ld<T>(kv + row * 2 * C + c0);
+    const float4 pp = *reinterpret_cast<const float4*>((c0 < C ? posK + (long)tpos * C + c0 : posV + (long)tpos * C + c0 - C));
+    Frag4<T> o;
+    o.v[0] = from_f32<T>(to_f32(v.v[0]) + pp.x); o.v[1] = from_f32<T>(to_f32(v.v[1]) + pp.y);
+    o.v[2] = from_f32<T>(to_f32(v.v[2]) + pp.z); o.v[3] = from_f32<T>(to_f32(v.v[3]) + pp.w);
+    frag_st<T>(out + row * 2 * C + c0, o);
+}
+
 template <typename K>
 int launch_jobs(K kern, const TaP& p, hipStream_t st) {
     const long jobs = (long)p.B * p.H * p.NT;
@@ -487,6 +857,143 @@ extern "C" int edgl_tattn_bwd(const void* qx, int ldq, const void* kx, int ldk, 
     p.st_d = reinterpret_cast<float*>((char*)saved + s.off_d);
     p.oatt = reinterpret_cast<float*>((char*)saved + s.off_o);
     return dtype == EDGL_F32 ? launch_bwd<float>(p, (hipStream_t)stream) : launch_bwd<bf16>(p, (hipStream_t)stream);
+}
+
+// ---- interval-bucket attention (TiSASRec) ---------------------------------------------------------------------------------
+namespace {
+template <typename K>
+int launch_ti(K kern, const TaP& p, const TiP& t, int waves, int tiles, hipStream_t st) {
+    const size_t smem = (size_t)waves * tiles * 16 * (t.NBp + 4) * sizeof(float);
+    EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_tiattn: timelen %d needs %zu B of LDS", t.timelen, smem);
+    if (smem > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const long jobs = (long)p.B * p.H * p.NT;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p, t);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+template <typename T, int DT>
+int ti_fwd(const TaP& p, const TiP& t, hipStream_t st) { return launch_ti(tiattn_fwd_kernel<T, DT>, p, t, 4, 2, st); }
+template <typename T, int DT>
+int ti_bwd(const TaP& p, const TiP& t, float* d_ktime, float* d_vtime, hipStream_t st) {
+    if (int rc = launch_ti(tiattn_bwd_q_kernel<T, DT>, p, t, 2, 3, st)) return rc;
+    if (int rc = launch_ti(tiattn_bwd_k_kernel<T, DT>, p, t, 4, 2, st)) return rc;
+    const int C = p.H * 16 * DT, splits = 32;
+    if (hipMemsetAsync(d_ktime, 0, (size_t)t.tab_rows * C * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(d_vtime, 0, (size_t)t.tab_rows * C * sizeof(float), st) != hipSuccess) {
+        edgl_set_error("edgl_tiattn_bwd: memset failed");
+        return EDGL_ERR_LAUNCH;
+    }
+    const long jobs = (long)p.H * (t.NBp / 16) * DT * splits;
+    const dim3 grid((unsigned)((jobs + 3) / 4));
+    const long BT = (long)p.B * p.T;
+    hipLaunchKernelGGL((bucket_dtable_kernel<T>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(t.dgbuf), t.NBp,
+                       reinterpret_cast<const T*>(p.qx), p.ldq, BT, p.H, 16 * DT, t.tab_rows, d_ktime, C, splits);
+    hipLaunchKernelGGL((bucket_dtable_kernel<T>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(t.wbuf), t.NBp,
+                       reinterpret_cast<const T*>(p.d_out), p.ld_do, BT, p.H, 16 * DT, t.tab_rows, d_vtime, C, splits);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+int ti_check(const char* who, int B, int T, int H, int dh, int timelen, int tab_rows, int dtype) {
+    EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && (dh == 16 || dh == 32 || dh == 64 || dh == 128), EDGL_ERR_SHAPE,
+                 "%s: bad shape B=%d T=%d H=%d head dim %d (16, 32, 64 or 128)", who, B, T, H, dh);
+    EDGL_REQUIRE(timelen >= 1 && timelen <= 256 && tab_rows >= 1 && tab_rows <= timelen + 1, EDGL_ERR_SHAPE,
+                 "%s: timelen %d (1..256) / table rows %d not supported", who, timelen, tab_rows);
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
+    EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "%s: H*B*T*T must be < 2^32", who);
+    return EDGL_OK;
+}
+}  // namespace
+
+extern "C" long edgl_tiattn_bucket_elems(int B, int T, int H, int timelen) {
+    if (B <= 0 || T <= 0 || H <= 0 || timelen < 1) return -1;
+    return (long)B * T * H * ((timelen + 1 + 15) / 16 * 16);
+}
+
+extern "C" int edgl_tiattn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* resid, int ldr,
+                               const int64_t* ids, const float* ts, const void* ktime, const void* vtime, int tab_rows, int B,
+                               int T, int H, int dh, float scale, float time_scale, int timelen, float drop_rate,
+                               const uint64_t* rng_state, uint32_t stream_id, void* out, int ldo, void* saved, void* wbuf,
+                               int flags, int dtype, void* stream) {
+    EDGL_REQUIRE(q && k && v && resid && ids && ts && ktime && vtime && out, EDGL_ERR_NULL, "edgl_tiattn_fwd: null pointer");
+    if (int rc = ti_check("edgl_tiattn_fwd", B, T, H, dh, timelen, tab_rows, dtype)) return rc;
+    EDGL_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldr % 4 == 0 && ldo % 4 == 0, EDGL_ERR_SHAPE,
+                 "edgl_tiattn_fwd: row strides must be multiples of 4");
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_tiattn_fwd: dropout without rng_state");
+    EDGL_REQUIRE((saved != nullptr) == (wbuf != nullptr), EDGL_ERR_NULL, "edgl_tiattn_fwd: saved and wbuf go together");
+    TaP p{};
+    p.qx = q; p.kx = k; p.v = v; p.resid = resid; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldr = ldr;
+    p.ids = ids; p.B = B; p.T = T; p.H = H; p.Dq = dh; p.Dv = dh; p.cscale = scale; p.rate = drop_rate;
+    p.rng = rng_state; p.stream_id = stream_id; p.out = out; p.ldo = ldo; p.flags = flags; p.NT = (T + 15) / 16;
+    if (saved) {
+        const SavedTa s = saved_ta(B, T, H, dh);
+        p.st_m = reinterpret_cast<float*>((char*)saved + s.off_m);
+        p.st_l = reinterpret_cast<float*>((char*)saved + s.off_l);
+        p.st_d = reinterpret_cast<float*>((char*)saved + s.off_d);
+        p.oatt = reinterpret_cast<float*>((char*)saved + s.off_o);
+    }
+    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, nullptr, (timelen + 1 + 15) / 16 * 16};
+    hipStream_t st = (hipStream_t)stream;
+#define EDGL_TI_FWD(TT)                                        \
+    switch (dh / 16) {                                         \
+        case 1: return ti_fwd<TT, 1>(p, t, st);                \
+        case 2: return ti_fwd<TT, 2>(p, t, st);                \
+        case 4: return ti_fwd<TT, 4>(p, t, st);                \
+        default: return ti_fwd<TT, 8>(p, t, st);               \
+    }
+    if (dtype == EDGL_F32) { EDGL_TI_FWD(float) }
+    EDGL_TI_FWD(bf16)
+#undef EDGL_TI_FWD
+}
+
+extern "C" int edgl_tiattn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const int64_t* ids,
+                               const float* ts, const void* ktime, const void* vtime, int tab_rows, const void* d_out, int ld_do,
+                               void* saved, void* wbuf, int B, int T, int H, int dh, float scale, float time_scale, int timelen,
+                               float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* d_q, int ld_dq, void* d_k,
+                               int ld_dk, void* d_v, int ld_dv, void* dgbuf, float* d_ktime, float* d_vtime, int flags, int dtype,
+                               void* stream) {
+    EDGL_REQUIRE(q && k && v && ids && ts && ktime && vtime && d_out && saved && wbuf && d_q && d_k && d_v && dgbuf && d_ktime &&
+                     d_vtime, EDGL_ERR_NULL, "edgl_tiattn_bwd: null pointer");
+    if (int rc = ti_check("edgl_tiattn_bwd", B, T, H, dh, timelen, tab_rows, dtype)) return rc;
+    EDGL_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ld_do % 4 == 0 && ld_dq % 4 == 0 && ld_dk % 4 == 0 && ld_dv % 4 == 0,
+                 EDGL_ERR_SHAPE, "edgl_tiattn_bwd: row strides must be multiples of 4");
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_tiattn_bwd: dropout without rng_state");
+    TaP p{};
+    p.qx = q; p.kx = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv;
+    p.ids = ids; p.B = B; p.T = T; p.H = H; p.Dq = dh; p.Dv = dh; p.cscale = scale; p.rate = drop_rate;
+    p.rng = rng_state; p.stream_id = stream_id; p.flags = flags; p.NT = (T + 15) / 16;
+    p.d_out = d_out; p.ld_do = ld_do; p.d_qx = d_q; p.d_kx = d_k; p.d_v = d_v; p.ld_dq = ld_dq; p.ld_dk = ld_dk; p.ld_dv = ld_dv;
+    const SavedTa s = saved_ta(B, T, H, dh);
+    p.st_m = reinterpret_cast<float*>((char*)saved + s.off_m);
+    p.st_l = reinterpret_cast<float*>((char*)saved + s.off_l);
+    p.st_d = reinterpret_cast<float*>((char*)saved + s.off_d);
+    p.oatt = reinterpret_cast<float*>((char*)saved + s.off_o);
+    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, dgbuf, (timelen + 1 + 15) / 16 * 16};
+    hipStream_t st = (hipStream_t)stream;
+#define EDGL_TI_BWD(TT)                                                        \
+    switch (dh / 16) {                                                         \
+        case 1: return ti_bwd<TT, 1>(p, t, d_ktime, d_vtime, st);              \
+        case 2: return ti_bwd<TT, 2>(p, t, d_ktime, d_vtime, st);              \
+        case 4: return ti_bwd<TT, 4>(p, t, d_ktime, d_vtime, st);              \
+        default: return ti_bwd<TT, 8>(p, t, d_ktime, d_vtime, st);             \
+    }
+    if (dtype == EDGL_F32) { EDGL_TI_BWD(float) }
+    EDGL_TI_BWD(bf16)
+#undef EDGL_TI_BWD
+}
+
+extern "C" int edgl_add_pos2(const void* kv, const float* posK, const float* posV, int B, int T, int C, void* out, int dtype,
+                             void* stream) {
+    EDGL_REQUIRE(kv && posK && posV && out, EDGL_ERR_NULL, "edgl_add_pos2: null pointer");
+    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0, EDGL_ERR_SHAPE, "edgl_add_pos2: bad shape B=%d T=%d C=%d", B, T, C);
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_add_pos2: bad dtype %d", dtype);
+    const long rows = (long)B * T, total = rows * (2 * C / 4);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((add_pos2_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)kv, posK,
+                                              posV, (float*)out, rows, T, C);
+    else hipLaunchKernelGGL((add_pos2_kernel<bf16>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)kv, posK, posV, (bf16*)out,
+                            rows, T, C);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
 }
 
 extern "C" int edgl_timefn_fwd(const void* q, int ldq, const void* k, int ldk, const float* pos_tab, const float* ts,

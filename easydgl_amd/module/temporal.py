@@ -101,3 +101,33 @@ class TfMultiHeadAttention(nn.Module):
         return ops.TfAttnFn.apply(q, kv, queries, self.pcoding_K.pembs.lookup_table, self.tcoding_K.basis_freq,
                                   self.tcoding_K.phase, ids, ts, self.num_heads, self.time_scale,
                                   drop if is_training else ops.NO_DROP, self.violations)
+
+
+class TiMultiHeadAttention(nn.Module):
+    """temporal.py:15-105 (TiSASRec, WSDM'20).  ``q_kernel`` [C,C], ``kv_kernel`` [C,2C] (dense_1 | dense_2); the position and
+    interval tables are the model's shared ``pcoding_K/V`` and ``tcoding_K/V`` (TiSASREC.py:30-33).  ``intervals`` is the pair
+    (ids, seqs_t): the integer [B,T,T] interval tensor is computed inside the kernel."""
+
+    def __init__(self, num_units, num_heads, dropout_rate, l2_reg, pcoding_K, pcoding_V, tcoding_K, tcoding_V, gen=None):
+        super().__init__()
+        self.num_units, self.num_heads, self.dropout_rate, self.l2_reg = num_units, num_heads, dropout_rate, l2_reg
+        self.q_kernel = nn.Parameter(glorot_uniform_(torch.empty(num_units, num_units), gen))
+        self.q_bias = nn.Parameter(torch.zeros(num_units))
+        kv = torch.cat([glorot_uniform_(torch.empty(num_units, num_units), gen) for _ in range(2)], dim=1)
+        self.kv_kernel = nn.Parameter(kv)
+        self.kv_bias = nn.Parameter(torch.zeros(2 * num_units))
+        for n, m in (("pcoding_K", pcoding_K), ("pcoding_V", pcoding_V), ("tcoding_K", tcoding_K), ("tcoding_V", tcoding_V)):
+            object.__setattr__(self, n, m)   # shared with the model: not registered twice
+        self.compute = lambda p: p
+        self.time_scale, self.timelen = 1.0, 256
+
+    def forward(self, queries, keys, intervals, is_training, causality=True, drop: ops.Drop = ops.NO_DROP):
+        if not causality:
+            raise NotImplementedError("the HIP interval attention implements the causal form TiSASRec uses (TiSASREC.py:70-71)")
+        ids, ts = intervals
+        q = ops.LinearFn.apply(queries, self.q_kernel, self.q_bias, self.compute(self.q_kernel), False)
+        kv = ops.LinearFn.apply(keys, self.kv_kernel, self.kv_bias, self.compute(self.kv_kernel), False)
+        kt, vt = self.tcoding_K.pembs.lookup_table, self.tcoding_V.pembs.lookup_table
+        return ops.TiAttnFn.apply(q, kv, queries, self.pcoding_K.pembs.lookup_table, self.pcoding_V.pembs.lookup_table, kt, vt,
+                                  self.compute(kt), self.compute(vt), ids, ts, self.num_heads, self.time_scale, self.timelen,
+                                  drop if is_training else ops.NO_DROP)

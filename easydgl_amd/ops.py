@@ -645,3 +645,54 @@ class TfAttnFn(torch.autograd.Function):
             full[:T] = d_pos
             d_pos = full
         return d_q, d_kv, d_out, d_pos, d_omega, d_phi, None, None, None, None, None, None
+
+
+class TiAttnFn(torch.autograd.Function):
+    """TiMultiHeadAttention after its dense layers (temporal.py:45-104): q [B,T,C], kv [B,T,2C] (K | V), resid = the queries,
+    position tables posK/posV f32 [>=T, C], interval tables (masters f32 + compute-dtype copies) [timelen, C]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, resid, posK, posV, ktime, vtime, ktime_c, vtime_c, ids, ts, H, time_scale, timelen, drop: Drop):
+        B, T, C = q.shape
+        dh = C // H
+        q, kv, resid = q.contiguous(), kv.contiguous(), resid.contiguous()
+        code = _code(q)
+        kvp = torch.empty_like(kv)
+        check(lib.edgl_add_pos2(_ptr(kv), _ptr(posK), _ptr(posV), B, T, C, _ptr(kvp), code, _stream()), "edgl_add_pos2")
+        out = torch.empty((B, T, C), device=q.device, dtype=q.dtype)
+        need = any(ctx.needs_input_grad)
+        saved = wbuf = None
+        if need:
+            saved = torch.empty(int(lib.edgl_tattn_saved_bytes(B, T, H, dh)), device=q.device, dtype=torch.uint8)
+            wbuf = torch.empty(int(lib.edgl_tiattn_bucket_elems(B, T, H, timelen)), device=q.device, dtype=q.dtype)
+        scale = 1.0 / float(dh) ** 0.5
+        rows = ktime_c.shape[0]
+        check(lib.edgl_tiattn_fwd(_ptr(q), C, _ptr(kvp), 2 * C, _vptr(kvp[:, :, C:]), 2 * C, _ptr(resid), C, _ptr(ids), _ptr(ts),
+                                  _ptr(ktime_c), _ptr(vtime_c), rows, B, T, H, dh, scale, float(time_scale), int(timelen),
+                                  float(drop.rate), drop.ptr(), drop.stream_id, _ptr(out), C, _ptr(saved), _ptr(wbuf),
+                                  _lib.TATTN_CAUSAL, code, _stream()), "edgl_tiattn_fwd")
+        ctx.save_for_backward(q, kvp, ktime_c, vtime_c, ids, ts, saved, wbuf)
+        ctx.meta = (B, T, C, H, dh, scale, float(time_scale), int(timelen), drop, posK.shape, posV.shape, rows)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        q, kvp, ktime_c, vtime_c, ids, ts, saved, wbuf = ctx.saved_tensors
+        B, T, C, H, dh, scale, time_scale, timelen, drop, pk_shape, pv_shape, rows = ctx.meta
+        d_out = d_out.contiguous()
+        code = _code(q)
+        d_q, d_kv = torch.empty_like(q), torch.empty_like(kvp)
+        dgbuf = torch.empty_like(wbuf)
+        d_kt = torch.empty((rows, C), device=q.device, dtype=torch.float32)
+        d_vt = torch.empty_like(d_kt)
+        check(lib.edgl_tiattn_bwd(_ptr(q), C, _ptr(kvp), 2 * C, _vptr(kvp[:, :, C:]), 2 * C, _ptr(ids), _ptr(ts), _ptr(ktime_c),
+                                  _ptr(vtime_c), rows, _ptr(d_out), C, _ptr(saved), _ptr(wbuf), B, T, H, dh, scale, time_scale,
+                                  timelen, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(d_q), C, _ptr(d_kv), 2 * C,
+                                  _vptr(d_kv[:, :, C:]), 2 * C, _ptr(dgbuf), _ptr(d_kt), _ptr(d_vt), _lib.TATTN_CAUSAL, code,
+                                  _stream()), "edgl_tiattn_bwd")
+        d_pos = colsum(d_kv.view(B, T * 2 * C), B, T * 2 * C).view(T, 2 * C)     # the tables enter K and V additively
+        d_pk = torch.zeros(pk_shape, device=q.device, dtype=torch.float32)
+        d_pv = torch.zeros(pv_shape, device=q.device, dtype=torch.float32)
+        d_pk[:T] = d_pos[:, :C]
+        d_pv[:T] = d_pos[:, C:]
+        return d_q, d_kv, d_out, d_pk, d_pv, d_kt, d_vt, None, None, None, None, None, None, None, None

@@ -9,6 +9,9 @@ def ranking(FLAGS):
     if FLAGS.model == "TGAT":
         from .model import TGAT
         return TGAT(FLAGS.num_items, FLAGS)
+    if FLAGS.model == "TiSASREC":
+        from .model import TiSASRec
+        return TiSASRec(FLAGS.num_items, FLAGS)
     if FLAGS.model == "CTSMA":
         from .model import CTSMA
         return CTSMA(FLAGS.num_items, FLAGS)

@@ -337,6 +337,32 @@ int edgl_timefn_bwd(const void* q, int ldq, const float* ts, const float* omega,
 /* y = x * (ids != 0) per row: `seqs_outs *= seqs_masks` (TGAT.py:58,70; TiSASREC.py:73); its own backward. */
 int edgl_mask_rows(const void* x, const int64_t* ids, void* y, long rows, int C, int dtype, void* stream);
 
+/* ---- K11b: causal attention with interval buckets (config 5: TiSASRec) ------------------------------
+ * Replaces TiMultiHeadAttention.__call__ (src/module/temporal.py:36-105) after its three dense layers.
+ * q [B,T,H*dh] (ldq); k, v = K + pcoding_K[t], V + pcoding_V[t] (edgl_add_pos2; temporal.py:50-51,57,94), strides ldk, ldv;
+ * ts f32 [B,T+1] raw seconds; ktime, vtime [tab_rows, H*dh] in `dtype` (tcoding_K / tcoding_V tables, head slice
+ * h*dh..); bucket(q,k) = int(clip(ts[q+1]/time_scale - ts[k]/time_scale, 0, timelen)) (TiSASREC.py:58-62), a bucket
+ * >= tab_rows reads a zero row (the GPU embedding lookup of the reference for the index `timelen` of a [timelen, C]
+ * table).  S[q,k] = scale * (q.k + q.ktime[bucket]); masks and softmax as edgl_tattn_fwd; out = dropout(P) . (v +
+ * vtime[bucket]) + resid.  The query mask of temporal.py:84-88 is the identity for LayerNorm-ed queries and is not
+ * applied.  saved: edgl_tattn_saved_bytes(B,T,H,dh) bytes; wbuf: edgl_tiattn_bucket_elems elements of `dtype` (binned
+ * probabilities, read by the backward); both NULL for inference.  timelen <= 256.
+ * edgl_tiattn_bwd: d_q, d_k, d_v; d_ktime, d_vtime f32 [tab_rows, H*dh] (overwritten); dgbuf: workspace like wbuf. */
+long edgl_tiattn_bucket_elems(int B, int T, int H, int timelen);
+int edgl_tiattn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* resid, int ldr,
+                    const int64_t* ids, const float* ts, const void* ktime, const void* vtime, int tab_rows, int B, int T,
+                    int H, int dh, float scale, float time_scale, int timelen, float drop_rate, const uint64_t* rng_state,
+                    uint32_t stream_id, void* out, int ldo, void* saved, void* wbuf, int flags, int dtype, void* stream);
+int edgl_tiattn_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const int64_t* ids,
+                    const float* ts, const void* ktime, const void* vtime, int tab_rows, const void* d_out, int ld_do,
+                    void* saved, void* wbuf, int B, int T, int H, int dh, float scale, float time_scale, int timelen,
+                    float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* d_q, int ld_dq, void* d_k,
+                    int ld_dk, void* d_v, int ld_dv, void* dgbuf, float* d_ktime, float* d_vtime, int flags, int dtype,
+                    void* stream);
+/* out[b,t,:] = kv[b,t,:] + concat(posK[t], posV[t]); kv, out [B,T,2C] `dtype`, posK/posV f32 [>=T, C]. */
+int edgl_add_pos2(const void* kv, const float* posK, const float* posV, int B, int T, int C, void* out, int dtype,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,167 @@
+"""SURVEY §8 row a-15 (config 5): the interval-bucket attention kernels (edgl_tiattn_*) and the TiSASRec model class, through
+the C ABI, against oracle/baselines_ref.py (float64).  Tolerances: f32 path 1e-4 / 1e-3 (gradients); bf16 path 3e-2 / 1e-1."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import baselines_ref as BR
+from oracle import easydgl_oracle as O
+from tests._util import assert_close, rel_err, to_dev
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    dict(B=24, T=12, C=32, h=2, I=60, nb=2, timelen=16),
+    dict(B=8, T=30, C=64, h=2, I=300, nb=1, timelen=50),        # dh = 32
+    dict(B=4, T=100, C=128, h=8, I=2000, nb=2, timelen=256),     # runme.sh:88-96 shape (8 heads, 2 blocks, timelen 256)
+]
+
+
+def _problem(seed, B, T, C, h, I, nb, timelen, time_scale=3600.0 * 24):
+    rng = np.random.default_rng(seed)
+    params = {}
+    for k, v in BR.tisasrec_init_params(I, timelen, C, nb, rng).items():
+        if v.ndim == 1:
+            v = v + 0.05 * rng.standard_normal(v.shape)
+        params[k] = v.astype(np.float32).astype(np.float64)
+    tokens = rng.integers(1, I, size=(B, T + 1))
+    tokens[0, :T // 3] = 0
+    tokens[1, :1] = 0
+    # mean gap of a few buckets; the tail of each sequence reaches past `timelen` buckets so the clip (and the zero row) is hit
+    ts = (9.5e8 + np.cumsum(rng.exponential(timelen / T * 1.5 * time_scale, size=(B, T + 1)), axis=1)).astype(np.float32)
+    ts[tokens == 0] = 0.0
+    feats = {"seqs_i": tokens[:, :-1].copy(), "seqs_t": ts}
+    return dict(params=params, feats=feats, tokens=tokens, kw=dict(C=C, h=h, nb=nb, time_scale=time_scale, timelen=timelen),
+                dims=dict(B=B, T=T, C=C, h=h, I=I, nb=nb, timelen=timelen))
+
+
+def _model(prob, mode, l2_reg=1e-3, hidden_drop=0.0, att_drop=0.0, lr=1e-3):
+    import easydgl_amd
+    d = prob["dims"]
+    F = SimpleNamespace(model="TiSASREC", num_items=d["I"], num_units=d["C"], num_heads=d["h"], num_blocks=d["nb"], seqslen=d["T"],
+                        timelen=d["timelen"], time_scale=prob["kw"]["time_scale"], learning_rate=lr, l2_reg=l2_reg,
+                        hidden_dropout_rate=hidden_drop, attention_probs_dropout_rate=att_drop, compute_dtype=mode,
+                        num_train_steps=None, num_warmup_steps=None)
+    m = easydgl_amd.ranking(F).finalize("cuda")
+    m.load_tf_variables(prob["params"])
+    return m
+
+
+def _p64(prob):
+    return {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in prob["params"].items()}
+
+
+@pytest.mark.parametrize("mode,ltol,gtol", [("f32", 1e-4, 1e-3), ("bf16", 3e-2, 1e-1)])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_tisasrec_forward_loss_and_gradients(mode, ltol, gtol, case):
+    prob = _problem(80 + case, **CASES[case])
+    m = _model(prob, mode)
+    feats = to_dev(prob["feats"])
+    labels_np = prob["tokens"][:, 1:].copy()
+    labels = torch.as_tensor(labels_np).cuda()
+    p64 = _p64(prob)
+    logits = m(feats, True)
+    ref_loss, aux = BR.tisasrec_train_loss(p64, prob["feats"], labels_np, l2_reg=1e-3, **prob["kw"])
+    assert logits.shape == aux["logits"].shape
+    assert_close(logits.detach().float().cpu().numpy(), aux["logits"].detach().numpy(), ltol, "train logits")
+    assert float((logits.detach()[:, 0] + 1000).abs().max()) == 0.0
+    m.zero_grad_arena()
+    loss = m.train_loss(feats, labels)
+    loss.backward()
+    ref_loss.backward()
+    assert_close(loss.item(), ref_loss.item(), ltol, "train loss")
+    got = m.tf_gradients()
+    assert set(got) == set(p64)
+    bad = {}
+    for name, g in got.items():
+        ref = p64[name].grad.numpy()
+        if name.endswith("timeinterval/dense_1/bias"):   # a bias on K shifts a whole score row: its true gradient is zero
+            ref_k = p64[name.replace("bias", "kernel")].grad.numpy()
+            assert np.abs(ref).max() < 1e-12 * max(np.abs(ref_k).max(), 1e-30)
+            e = float(np.abs(g).max() / np.abs(ref_k).max())
+        else:
+            e = rel_err(g, ref)
+        tol = 2 * gtol if (mode == "bf16" and "/Inner/" in name) else gtol   # ReLU mask flips, see test_gpu_ctsma.py
+        if e > tol:
+            bad[name] = e
+    assert not bad, f"gradient mismatch (rel to max |ref|): {bad}"
+    elog = m(feats, False)
+    want = BR.tisasrec_eval_logits(_p64(prob), prob["feats"], **prob["kw"])
+    assert_close(elog.detach().float().cpu().numpy(), want.detach().numpy(), ltol, "eval logits")
+
+
+def test_tisasrec_buckets_cover_the_clip_and_the_zero_row():
+    """The synthetic timestamps must exercise bucket 0, interior buckets and the clipped bucket `timelen` (zero row)."""
+    prob = _problem(80, **CASES[0])
+    ts32 = prob["feats"]["seqs_t"] / np.float32(prob["kw"]["time_scale"])
+    d = np.clip(ts32[:, 1:, None] - ts32[:, None, :-1], 0, prob["kw"]["timelen"]).astype(np.int64)
+    tril = np.tril(np.ones(d.shape[1:], dtype=bool))
+    seen = set(np.unique(d[:, tril]))
+    assert 0 in seen and prob["kw"]["timelen"] in seen and len(seen) > 5
+
+
+def test_tisasrec_adam_steps_dropout_training_and_metrics():
+    from oracle import torch_ref as R
+    prob = _problem(11, B=5, T=12, C=32, h=2, I=60, nb=2, timelen=16)
+    m = _model(prob, "f32")
+    p64 = _p64(prob)
+    opt = R.TFAdam(p64, 1e-3)
+    feats = to_dev(prob["feats"])
+    labels_np = prob["tokens"][:, 1:].copy()
+    labels = torch.as_tensor(labels_np).cuda()
+    for step in range(3):
+        got = float(m.train_step(feats, labels))
+        ref, _ = BR.tisasrec_train_loss(p64, prob["feats"], labels_np, l2_reg=1e-3, **prob["kw"])
+        ref.backward()
+        opt.step()
+        assert abs(got - float(ref.detach())) <= 2e-4 * abs(float(ref.detach())), (step, got)
+    prob = _problem(5, B=32, T=20, C=64, h=4, I=400, nb=2, timelen=32)
+    m = _model(prob, "bf16", hidden_drop=0.1, att_drop=0.1, lr=2e-3)
+    feats = to_dev(prob["feats"])
+    labels = torch.as_tensor(prob["tokens"][:, 1:].copy()).cuda()
+    losses = [float(m.train_step(feats, labels)) for _ in range(30)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.3, losses
+    _, idx = m.eval_topk(feats, mask_seen=True)
+    got = idx.cpu().numpy()
+    m.reset_metrics()
+    m.eval_step(feats, torch.as_tensor(prob["tokens"]).cuda())
+    per = O.ranking_metrics(got, prob["tokens"][:, -1])
+    for k, v in m.metrics().items():
+        assert abs(v - per[k].mean()) < 1e-5
+
+
+def test_tiattn_dropout_gradients_match_central_differences():
+    """Same counter-based mask in the forward and both backward kernels: directional derivatives of sum(out * w) wrt q, kv and
+    the interval tables against central differences (f32)."""
+    from easydgl_amd import ops
+    B, T, C, H, timelen = 2, 24, 32, 2, 16
+    g = torch.Generator(device="cuda").manual_seed(1)
+    mk = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    q, kv, resid, w = mk(B, T, C), mk(B, T, 2 * C), mk(B, T, C), mk(B, T, C)
+    posK, posV, kt, vt = mk(T, C) * 0.3, mk(T, C) * 0.3, mk(timelen, C) * 0.3, mk(timelen, C) * 0.3
+    ids = torch.randint(1, 9, (B, T), device="cuda")
+    ids[0, :5] = 0
+    ts = torch.cumsum(torch.rand(B, T + 1, device="cuda", generator=g) * 2.0, dim=1).float()
+    rng = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
+    drop = ops.Drop(0.25, rng, 5)
+
+    def run(q_, kv_, kt_, vt_):
+        return ops.TiAttnFn.apply(q_, kv_, resid, posK, posV, kt_, vt_, kt_, vt_, ids, ts, H, 1.0, timelen, drop)
+
+    leaves = [t.clone().requires_grad_(True) for t in (q, kv, kt, vt)]
+    out = run(*leaves)
+    (out * w).sum().backward()
+    base = [q, kv, kt, vt]
+    for i, name in enumerate(("q", "kv", "ktime", "vtime")):
+        d = torch.randn(base[i].shape, device="cuda", generator=g)
+        eps = 1e-2
+        args_p = [t.clone() for t in base]
+        args_m = [t.clone() for t in base]
+        args_p[i] += eps * d
+        args_m[i] -= eps * d
+        with torch.no_grad():
+            fd = float(((run(*args_p).double() - run(*args_m).double()) * w.double()).sum()) / (2 * eps)
+        an = float((leaves[i].grad.double() * d.double()).sum())
+        assert abs(fd - an) <= 2e-2 * max(1.0, abs(an)), (name, fd, an)
