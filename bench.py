@@ -170,6 +170,61 @@ def encode_bench(args):
     print(json.dumps(out))
 
 
+def baseline_model_bench(args):
+    """Config 5 (and the CTSMA row f-4): one optimizer step (forward, backward, Adam) of TGAT / TiSASREC / CTSMA through the HIP
+    attention kernels at the headline sizes B=512, seqslen 100, d=128, |items|=20K with the reference recipes' head / block
+    counts (runme.sh:60-96).  A parity-case throughput, not the bench contract's headline line."""
+    from types import SimpleNamespace
+    import easydgl_amd
+    from easydgl_amd import data as D
+    from easydgl_amd._lib import profiler
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    name = {"tgat": "TGAT", "tisasrec": "TiSASREC", "ctsma": "CTSMA"}[args.workload]
+    B, L, C, I = 512, 100, 128, 20000
+    heads, blocks = {"TGAT": (1, 3), "TiSASREC": (8, 2), "CTSMA": (8, 2)}[name]
+    F = SimpleNamespace(model=name, num_items=I, num_units=C, num_heads=heads, num_blocks=blocks, seqslen=L, timelen=256,
+                        time_scale=86400.0, learning_rate=5e-4, l2_reg=1e-4, ct_reg=1e-7, hidden_dropout_rate=0.1,
+                        attention_probs_dropout_rate=0.1, compute_dtype=args.dtype, num_train_steps=None, num_warmup_steps=None,
+                        mark_table=D.synthetic_mark_table(I, 16))
+    m = easydgl_amd.ranking(F).finalize(dev)
+    ids_np, ts_np = D.synthetic_batch(I, L, B, seed=9876)           # records of L+1 tokens
+    tok, tim = torch.tensor(ids_np, device=dev), torch.tensor(ts_np, device=dev)
+    feats, labels = {"seqs_i": tok[:, :-1].contiguous(), "seqs_t": tim}, tok[:, 1:].contiguous()
+
+    def step():
+        return m.train_step(feats, labels)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(args.steps):
+        loss = step()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / args.steps
+    if hasattr(m, "check_inputs"):
+        m.check_inputs()
+    table = None
+    if args.op_table:
+        profiler.start()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        profiler.stop()
+        table = {k: round(v[1] / 5, 4) for k, v in sorted(profiler.summary().items(), key=lambda kv: -kv[1][1])[:12]}
+    out = {"metric": f"sequences/sec ({name} fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K", "value": round(B / ms * 1e3, 1),
+           "unit": "sequences/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"{name} optimizer step (autograd path), batch 512, seqslen 100, num_units 128, {heads} heads, "
+                                  f"{blocks} blocks, num_items 20000, all-position loss, dropout 0.1/0.1, l2 1e-4"},
+           "loss": round(float(loss), 5)}
+    if table:
+        out["ms_per_c_call"] = table
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,13 +236,15 @@ def main():
                     help="engine: static launch sequence issued eagerly (dominant kernel bracketed with HIP events); "
                          "graph: the same sequence replayed as one HIP graph; autograd: torch.autograd over the ops")
     ap.add_argument("--op-table", action="store_true", help="after the timed region, print a per-C-call time table to stderr")
-    ap.add_argument("--workload", default="step", choices=["step", "encode"],
+    ap.add_argument("--workload", default="step", choices=["step", "encode", "tgat", "tisasrec", "ctsma"],
                     help="step: the headline optimizer step (default, the bench contract); encode: K1 input encoding "
                          "(embedding gather + time code) alone at SURVEY §8d config 3 (|items| = 1M, L = 200, d = 256) — the "
                          "HBM-bound regime, reported as GB/s against the HBM roofline")
     args = ap.parse_args()
     if args.workload == "encode":
         return encode_bench(args)
+    if args.workload in ("tgat", "tisasrec", "ctsma"):
+        return baseline_model_bench(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -91,25 +91,57 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(EmbP p) {
         else *reinterpret_cast<uint2*>(out + s2 * p.C + c0) = *reinterpret_cast<uint2*>(&o);
     }
 }
-// d_item[id] += sqrt(C) * dropmask * dx[:, :C] (rows with id != 0), d_pos[t] += dropmask * dx[:, C:2C]; f32 atomics into
-// zero-filled tables (a baseline model: simplicity over a deterministic order)
+// d_item[id] += sqrt(C) * dropmask * dx[:, :C] (rows with id != 0), d_pos[t] += dropmask * dx[:, C:2C] into zero-filled tables.
+// Item popularity is heavy-tailed, so raw global atomics serialise on the hot rows: a block takes ESROWS consecutive (b,t)
+// rows, finds for every row the first row of the block with the same id (its leader), accumulates per leader in LDS and
+// issues ONE global atomic per distinct id and channel (the scheme of k_encode.hip's encode_scatter_kernel).
+constexpr int ESROWS = 128;
 template <typename T>
 __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(EmbP p) {
-    const int cpr = p.C >> 2;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long row = gid / cpr;
-    if (row >= (long)p.B * p.T) return;
-    const int cv = (int)(gid % cpr), c0 = cv * 4, t = (int)(row % p.T);
-    const int64_t id = p.ids[row];
+    extern __shared__ float acc[];  // [ESROWS][C]
+    __shared__ int s_id[ESROWS];
+    __shared__ int s_lead[ESROWS];
+    const long rows = (long)p.B * p.T, r0 = (long)blockIdx.x * ESROWS;
+    const int tid = threadIdx.x;
+    if (tid < ESROWS) s_id[tid] = (r0 + tid < rows) ? (int)p.ids[r0 + tid] : -1;
+    for (int i = tid; i < ESROWS * p.C; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    if (tid < ESROWS) {
+        const int id = s_id[tid];
+        int lead = tid;
+        for (int j = 0; j < tid; ++j)
+            if (s_id[j] == id) { lead = j; break; }
+        s_lead[tid] = lead;
+    }
+    __syncthreads();
+    const int cpr = p.C >> 2, rows_par = 256 / cpr;
+    const int cv = tid % cpr, rl = tid / cpr, c0 = cv * 4;
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
-    const long ldo = p.d_pos ? 2L * p.C : (long)p.C;
-    const T* d = reinterpret_cast<const T*>(p.dx0) + row * ldo;
-    const Frag4<T> g0 = frag_ld<T>(d + c0), g1 = p.d_pos ? frag_ld<T>(d + p.C + c0) : frag_zero<T>();
     const float sq = sqrtf((float)p.C);
+    const long ldo = p.d_pos ? 2L * p.C : (long)p.C;
+    if (tid < rows_par * cpr)
+        for (int r = rl; r < ESROWS; r += rows_par) {
+            if (s_id[r] < 0) continue;   // past the end
+            const long row = r0 + r;
+            const T* d = reinterpret_cast<const T*>(p.dx0) + row * ldo;
+            if (s_id[r] != 0) {          // coding.py:56-57: row 0 is a constant
+                const Frag4<T> g0 = frag_ld<T>(d + c0);
+                float* dst = acc + s_lead[r] * p.C + c0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (id != 0) atomicAdd(p.d_item + id * p.C + c0 + j, sq * drop_apply(dk, (uint64_t)row * ldo + c0 + j, to_f32(g0.v[j])));
-        if (p.d_pos) atomicAdd(p.d_pos + (long)t * p.C + c0 + j, drop_apply(dk, (uint64_t)row * ldo + p.C + c0 + j, to_f32(g1.v[j])));
+                for (int j = 0; j < 4; ++j) atomicAdd(dst + j, sq * drop_apply(dk, (uint64_t)row * ldo + c0 + j, to_f32(g0.v[j])));
+            }
+            if (p.d_pos) {
+                const Frag4<T> g1 = frag_ld<T>(d + p.C + c0);
+                const int t = (int)(row % p.T);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    atomicAdd(p.d_pos + (long)t * p.C + c0 + j, drop_apply(dk, (uint64_t)row * ldo + p.C + c0 + j, to_f32(g1.v[j])));
+            }
+        }
+    __syncthreads();
+    for (int i = tid; i < ESROWS * p.C; i += 256) {
+        const int r = i / p.C, c = i % p.C;
+        if (s_lead[r] == r && s_id[r] > 0) atomicAdd(p.d_item + (long)s_id[r] * p.C + c, acc[i]);
     }
 }
 
@@ -139,7 +171,8 @@ extern "C" int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, in
                                   const uint64_t* rng_state, uint32_t stream_id, float* d_item, float* d_pos, int dtype,
                                   void* stream) {
     EDGL_REQUIRE(ids && dx0 && d_item, EDGL_ERR_NULL, "edgl_embed_pos_bwd: null pointer");
-    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && I > 1, EDGL_ERR_SHAPE, "edgl_embed_pos_bwd: bad shape");
+    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256 && (size_t)ESROWS * C * sizeof(float) <= 150 * 1024 && I > 1,
+                 EDGL_ERR_SHAPE, "edgl_embed_pos_bwd: bad shape B=%d T=%d C=%d", B, T, C);
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_embed_pos_bwd: bad dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(d_item, 0, (size_t)I * C * sizeof(float), st) != hipSuccess ||
@@ -149,10 +182,15 @@ extern "C" int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, in
     }
     EmbP p{ids, nullptr, nullptr, nullptr, nullptr, B, T, C, 0, 1.f, drop_rate, rng_state, stream_id, nullptr, nullptr, nullptr,
            dx0, d_item, d_pos};
-    const long total = (long)B * T * (C / 4);
-    dim3 grid((unsigned)((total + 255) / 256));
-    if (dtype == EDGL_F32) hipLaunchKernelGGL((embed_pos_bwd_kernel<float>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((embed_pos_bwd_kernel<bf16>), grid, dim3(256), 0, st, p);
+    const size_t smem = (size_t)ESROWS * C * sizeof(float);
+    dim3 grid((unsigned)(((long)B * T + ESROWS - 1) / ESROWS));
+    if (dtype == EDGL_F32) {
+        hipFuncSetAttribute((const void*)embed_pos_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((embed_pos_bwd_kernel<float>), grid, dim3(256), smem, st, p);
+    } else {
+        hipFuncSetAttribute((const void*)embed_pos_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((embed_pos_bwd_kernel<bf16>), grid, dim3(256), smem, st, p);
+    }
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

@@ -1,7 +1,9 @@
 """Train / evaluate driver — the role of the reference's ``src/main.py:78-151`` with ``util.EarlyStopping``
 (``src/util.py:14-58``), on the HIP model.
 
-Same flags as ``main.py:22-75`` for everything the EasyDGL path reads (``--train/--valid/--test`` file patterns,
+Models: EasyDGL (masked batches, ``MAUPostProcessor``) and CTSMA / TGAT / TiSASREC (regressive batches,
+``RegressivePostProcessor``), chosen as ``util.reader`` does (``util.py:99-129``).
+Same flags as ``main.py:22-75`` for everything these paths read (``--train/--valid/--test`` file patterns,
 ``--num_items --num_units --num_heads --num_blocks --seqslen --time_scale --masklen --mark --ct_reg --batch_size
 --num_epochs --learning_rate --l2_reg --hidden_dropout_rate --attention_probs_dropout_rate --eval_per_steps
 --mask_seen``).  Epoch structure as in the reference: one pass over the training records (masked on the device, one
@@ -30,7 +32,7 @@ def args(argv=None):
     p.add_argument("--train", required=True, help="training data file patterns (.tfrec or .npz)")
     p.add_argument("--valid", required=True)
     p.add_argument("--test", required=True)
-    p.add_argument("--model", required=True, help="algorithm name (EasyDGL)")
+    p.add_argument("--model", required=True, help="algorithm name: EasyDGL, CTSMA, TGAT or TiSASREC (util.ranking keys)")
     p.add_argument("--num_items", type=int, required=True)
     p.add_argument("--num_units", type=int, default=50)
     p.add_argument("--num_heads", type=int, default=1)
@@ -124,16 +126,24 @@ def load_checkpoint(model, path: str) -> None:
     model.sync_shadow()
 
 
+def regressive_batch(tok, tim, is_training: bool):
+    """RegressivePostProcessor (dataloader.py:88-108; util.reader's choice for CTSMA / TGAT / TiSASREC, util.py:116-129):
+    features see tokens[:-1] and every timestamp; labels = tokens[1:] (training) / the whole record (evaluation)."""
+    return {"seqs_i": tok[:, :-1].contiguous(), "seqs_t": tim}, (tok[:, 1:].contiguous() if is_training else tok)
+
+
 def evaluate(model, ids, ts, batch_size: int, mask_seen: bool) -> Dict[str, float]:
-    """One pass of ``Sequential.eval`` (Base.py:150-207) over a split: last position masked, streaming means."""
+    """One pass of ``Sequential.eval`` (Base.py:150-207) over a split: last position masked (EasyDGL) or predicted from the
+    prefix (regressive models), streaming means."""
     import torch
     from . import data as D
     model.reset_metrics()
     n = ids.shape[0]
+    masked = hasattr(model, "mask")
     for lo in range(0, n, batch_size):
         tok = torch.as_tensor(ids[lo:lo + batch_size]).cuda()
         tim = torch.as_tensor(ts[lo:lo + batch_size]).cuda()
-        feats, labels = D.device_mask_last(tok, tim, model.mask)
+        feats, labels = D.device_mask_last(tok, tim, model.mask) if masked else regressive_batch(tok, tim, False)
         model.eval_step(feats, labels, mask_seen=mask_seen)
     return model.metrics()
 
@@ -160,7 +170,12 @@ def run(FLAGS) -> Dict[str, float]:
     model = ranking(FLAGS)
     model.finalize(torch.device("cuda", torch.cuda.current_device()))
     bs = FLAGS.batch_size
-    engine = TrainEngine(model, bs, use_graph=False) if len(tr_i) >= bs else None
+    masked = FLAGS.model == "EasyDGL"          # MAUPostProcessor; every other model is fed regressively (util.py:99-129)
+    if FLAGS.model == "TGAT":                  # the time feature map needs time-sorted sequences (model/tgat.py)
+        for name, (ii, tt) in (("train", (tr_i, tr_t)), ("valid", (vl_i, vl_t)), ("test", (te_i, te_t))):
+            if np.any((np.diff(tt, axis=1) < 0) & (ii[:, :-1] != 0)):
+                raise ValueError(f"{name}: timestamps decrease inside a sequence; TGAT needs time-sorted records")
+    engine = TrainEngine(model, bs, use_graph=False) if (masked and len(tr_i) >= bs) else None
     ckpt = os.path.join(FLAGS.ckpt_dir, f"{FLAGS.model}.pt")
     stopper = EarlyStopping(FLAGS.model, patience=FLAGS.patience, saver=lambda: save_checkpoint(model, ckpt))
     mask_state = torch.tensor([FLAGS.seed, 0], dtype=torch.int64, device="cuda")   # (seed, batch counter) of the masker
@@ -173,8 +188,11 @@ def run(FLAGS) -> Dict[str, float]:
             idx = order[lo:lo + bs]
             tok = torch.as_tensor(tr_i[idx]).cuda()
             tim = torch.as_tensor(tr_t[idx]).cuda()
-            feats, labels = D.device_mask_random(tok, tim, model.mask, FLAGS.masklen, mask_state)
-            mask_state[1] += 1
+            if masked:
+                feats, labels = D.device_mask_random(tok, tim, model.mask, FLAGS.masklen, mask_state)
+                mask_state[1] += 1
+            else:
+                feats, labels = regressive_batch(tok, tim, True)
             if engine is not None and len(idx) == bs:
                 loss = engine.step(feats, labels)
             else:
@@ -185,6 +203,8 @@ def run(FLAGS) -> Dict[str, float]:
                 if math.isnan(running_loss):
                     break
         logging.info("%03d: Loss=%.4f", epoch, running_loss)
+        if hasattr(model, "check_inputs"):
+            model.check_inputs()
         if epoch % FLAGS.eval_per_steps:
             continue
         vl = evaluate(model, vl_i, vl_t, bs, FLAGS.mask_seen)

@@ -44,7 +44,8 @@ def test_early_stopping_follows_reference_decisions():
 
 
 @pytest.mark.gpu
-def test_driver_end_to_end_from_tfrecords(tmp_path):
+@pytest.mark.parametrize("model_name", ["EasyDGL", "CTSMA", "TGAT", "TiSASREC"])
+def test_driver_end_to_end_from_tfrecords(tmp_path, model_name):
     sp = pytest.importorskip("scipy.sparse")
     from easydgl_amd import data as D
     from easydgl_amd import train as TR
@@ -55,7 +56,7 @@ def test_driver_end_to_end_from_tfrecords(tmp_path):
     dump("train000.tfrec", 0, 70); dump("train001.tfrec", 70, 140); dump("validation.tfrec", 140, 170); dump("test.tfrec", 170, 200)
     with open(tmp_path / "mark.pkl", "wb") as f:
         pickle.dump(sp.csr_matrix(D.synthetic_mark_table(num_items, E).astype(np.int64)), f)
-    res = TR.main(["--model", "EasyDGL", "--train", str(tmp_path / "train*.tfrec"), "--valid", str(tmp_path / "validation.tfrec"),
+    res = TR.main(["--model", model_name, "--timelen", "32", "--train", str(tmp_path / "train*.tfrec"), "--valid", str(tmp_path / "validation.tfrec"),
                    "--test", str(tmp_path / "test.tfrec"), "--num_items", str(num_items), "--num_units", "32", "--num_heads", "2",
                    "--num_blocks", "1", "--seqslen", str(seqslen), "--masklen", "4", "--time_scale", "86400", "--mark",
                    str(tmp_path / "mark.pkl"), "--ct_reg", "1e-7", "--batch_size", "64", "--num_epochs", "3", "--learning_rate",
