@@ -63,8 +63,21 @@ __device__ __forceinline__ bool get_job(const TaP& p, Job& j) {
     return true;
 }
 
+// First position of the sequence with ids != 0 (T if none).  Rows before it are fully masked: every score is the same
+// replaced constant and the softmax is uniform over ALL keys, so their tiles must be computed.  Every later row has an
+// unmasked key, its replaced scores underflow to exactly 0 after the softmax, and key tiles above the diagonal contribute
+// exactly nothing — they are skipped (half of the causal work).
+__device__ __forceinline__ int first_unpadded(const int64_t* idr, int T, int lane) {
+    int f = T;
+    for (int k = lane; k < T; k += 64)
+        if (idr[k] != 0) f = min(f, k);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) f = min(f, __shfl_xor(f, o, 64));
+    return f;
+}
+
 // ---- forward -----------------------------------------------------------------------------------------------------------
-template <typename T, int DVT>
+template <typename T, int DQT, int DVT>
 __global__ __launch_bounds__(256) void tattn_fwd_kernel(TaP p) {
     Job j;
     if (!get_job(p, j)) return;
@@ -82,10 +95,22 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TaP p) {
     f32x4 acc[DVT];
 #pragma unroll
     for (int ut = 0; ut < DVT; ++ut) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < p.NT; ++kt) {
+    const int kt_end = (causal && j.tile * 16 >= first_unpadded(idr, p.T, lane)) ? j.tile + 1 : p.NT;
+    // compile-time contraction length: the operand loads of a tile are issued together instead of one per dependent MFMA
+    Frag4<T> qf[DQT];
+#pragma unroll
+    for (int dt = 0; dt < DQT; ++dt) qf[dt] = frag_ld<T>(Qr + dt * 16 + g4);
+    for (int kt = 0; kt < kt_end; ++kt) {
         const int kr = min(kt * 16 + l15, p.T - 1);
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int d = 0; d < p.Dq; d += 16) s = mma16(frag_ld<T>(Kb + (long)kr * p.ldk + d + g4), frag_ld<T>(Qr + d + g4), s);
+        Frag4<T> kf[DQT];
+#pragma unroll
+        for (int dt = 0; dt < DQT; ++dt) kf[dt] = frag_ld<T>(Kb + (long)kr * p.ldk + dt * 16 + g4);
+        Frag4<T> vraw[DVT];
+#pragma unroll
+        for (int ut = 0; ut < DVT; ++ut) vraw[ut] = frag_ld<T>(Vb + (long)kr * p.ldv + ut * 16 + g4);
+#pragma unroll
+        for (int dt = 0; dt < DQT; ++dt) s = mma16(kf[dt], qf[dt], s);
         float x[4], tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -114,7 +139,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TaP p) {
         const Frag4<T> pf = frag_from_acc<T>(e);
 #pragma unroll
         for (int ut = 0; ut < DVT; ++ut) {
-            const Frag4<T> vt = turn<T>(frag_ld<T>(Vb + (long)kr * p.ldv + ut * 16 + g4), ident);   // V[k][u] with k on the registers
+            const Frag4<T> vt = turn<T>(vraw[ut], ident);   // V[k][u] with k on the registers
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[ut][r] *= corr;
             acc[ut] = mma16(vt, pf, acc[ut]);                                                          // :175
@@ -139,7 +164,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TaP p) {
 }
 
 // ---- backward, query side ---------------------------------------------------------------------------------------------
-template <typename T, int DQT>
+template <typename T, int DQT, int DVT>
 __global__ __launch_bounds__(256) void tattn_bwd_q_kernel(TaP p) {
     Job j;
     if (!get_job(p, j)) return;
@@ -170,11 +195,24 @@ __global__ __launch_bounds__(256) void tattn_bwd_q_kernel(TaP p) {
     f32x4 acc[DQT];
 #pragma unroll
     for (int dt = 0; dt < DQT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < p.NT; ++kt) {
+    const int kt_end = (causal && j.tile * 16 >= first_unpadded(idr, p.T, lane)) ? j.tile + 1 : p.NT;
+    Frag4<T> qf[DQT], gf[DVT];
+#pragma unroll
+    for (int dt = 0; dt < DQT; ++dt) qf[dt] = frag_ld<T>(Qr + dt * 16 + g4);
+#pragma unroll
+    for (int ut = 0; ut < DVT; ++ut) gf[ut] = frag_ld<T>(dOr + ut * 16 + g4);
+    for (int kt = 0; kt < kt_end; ++kt) {
         const int kr = min(kt * 16 + l15, p.T - 1);
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
-        for (int d = 0; d < p.Dq; d += 16) s = mma16(frag_ld<T>(Kb + (long)kr * p.ldk + d + g4), frag_ld<T>(Qr + d + g4), s);
-        for (int u = 0; u < p.Dv; u += 16) da = mma16(frag_ld<T>(Vb + (long)kr * p.ldv + u + g4), frag_ld<T>(dOr + u + g4), da);
+        Frag4<T> kf[DQT], vf[DVT];
+#pragma unroll
+        for (int dt = 0; dt < DQT; ++dt) kf[dt] = frag_ld<T>(Kb + (long)kr * p.ldk + dt * 16 + g4);
+#pragma unroll
+        for (int ut = 0; ut < DVT; ++ut) vf[ut] = frag_ld<T>(Vb + (long)kr * p.ldv + ut * 16 + g4);
+#pragma unroll
+        for (int dt = 0; dt < DQT; ++dt) s = mma16(kf[dt], qf[dt], s);
+#pragma unroll
+        for (int ut = 0; ut < DVT; ++ut) da = mma16(vf[ut], gf[ut], da);
         uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
         if (dk.thresh != 0u) { h0 = drop_hash_pair(dk, dbase + kt * 16 + g4); h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2); }
         const uint32_t hb[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
@@ -192,8 +230,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_q_kernel(TaP p) {
         }
         const Frag4<T> dsf = frag_from_acc<T>(ds);
 #pragma unroll
-        for (int dt = 0; dt < DQT; ++dt)
-            acc[dt] = mma16(turn<T>(frag_ld<T>(Kb + (long)kr * p.ldk + dt * 16 + g4), ident), dsf, acc[dt]);
+        for (int dt = 0; dt < DQT; ++dt) acc[dt] = mma16(turn<T>(kf[dt], ident), dsf, acc[dt]);
     }
     if (!qok) return;
     T* dst = reinterpret_cast<T*>(p.d_qx) + ((long)j.b * p.T + q) * p.ld_dq + j.head * p.Dq;
@@ -217,18 +254,32 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_kernel(TaP p) {
     const float madd = !kok ? -INFINITY : (pad ? PADV : 0.f);
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const Frag4<T> ident = identity_frag<T>(lane);
+    Frag4<T> kf[DQT], vf[DVT];
+#pragma unroll
+    for (int dt = 0; dt < DQT; ++dt) kf[dt] = frag_ld<T>(Kr + dt * 16 + g4);
+#pragma unroll
+    for (int ut = 0; ut < DVT; ++ut) vf[ut] = frag_ld<T>(Vr + ut * 16 + g4);
     f32x4 accK[DQT], accV[DVT];
 #pragma unroll
     for (int dt = 0; dt < DQT; ++dt) accK[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ut = 0; ut < DVT; ++ut) accV[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fnp = first_unpadded(p.ids + (long)j.b * p.T, p.T, lane);
     for (int qt = 0; qt < p.NT; ++qt) {
+        if (causal && qt < j.tile && qt * 16 >= fnp) continue;   // all 16 queries see this key tile as future: exact zeros
         const int ql = min(qt * 16 + l15, p.T - 1);   // this lane's row when it loads an operand chunk
         const T* Qrow = Qb + (long)ql * p.ldq;
         const T* dOrow = dOb + (long)ql * p.ld_do;
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};   // [q = g4+r][k = l15]
-        for (int d = 0; d < p.Dq; d += 16) s = mma16(frag_ld<T>(Qrow + d + g4), frag_ld<T>(Kr + d + g4), s);
-        for (int u = 0; u < p.Dv; u += 16) da = mma16(frag_ld<T>(dOrow + u + g4), frag_ld<T>(Vr + u + g4), da);
+        Frag4<T> qf[DQT], gf[DVT];
+#pragma unroll
+        for (int dt = 0; dt < DQT; ++dt) qf[dt] = frag_ld<T>(Qrow + dt * 16 + g4);
+#pragma unroll
+        for (int ut = 0; ut < DVT; ++ut) gf[ut] = frag_ld<T>(dOrow + ut * 16 + g4);
+#pragma unroll
+        for (int dt = 0; dt < DQT; ++dt) s = mma16(qf[dt], kf[dt], s);
+#pragma unroll
+        for (int ut = 0; ut < DVT; ++ut) da = mma16(gf[ut], vf[ut], da);
         f32x4 a4, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -250,11 +301,9 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_kernel(TaP p) {
         }
         const Frag4<T> af = frag_from_acc<T>(a4), dsf = frag_from_acc<T>(ds);
 #pragma unroll
-        for (int ut = 0; ut < DVT; ++ut)
-            accV[ut] = mma16(turn<T>(frag_ld<T>(dOrow + ut * 16 + g4), ident), af, accV[ut]);    // dV^T[u][k] += dO^T[u][q] A[q][k]
+        for (int ut = 0; ut < DVT; ++ut) accV[ut] = mma16(turn<T>(gf[ut], ident), af, accV[ut]);    // dV^T[u][k] += dO^T[u][q] A[q][k]
 #pragma unroll
-        for (int dt = 0; dt < DQT; ++dt)
-            accK[dt] = mma16(turn<T>(frag_ld<T>(Qrow + dt * 16 + g4), ident), dsf, accK[dt]);     // dK~^T[d][k] += Q~^T[d][q] dS[q][k]
+        for (int dt = 0; dt < DQT; ++dt) accK[dt] = mma16(turn<T>(qf[dt], ident), dsf, accK[dt]);   // dK~^T[d][k] += Q~^T[d][q] dS[q][k]
     }
     if (!kok) return;
     T* dK = reinterpret_cast<T*>(p.d_kx) + ((long)j.b * p.T + k) * p.ld_dk + j.head * p.Dq;
@@ -276,6 +325,7 @@ struct TiP {
     const float* ts; float time_scale; int timelen;
     const void *ktime, *vtime; int ldt, tab_rows;     // [tab_rows, H*dh] activation dtype; bucket >= tab_rows reads as zeros
     void *wbuf, *dgbuf; int NBp;                      // [H*B*T][NBp] activation dtype: binned probabilities / score gradients
+    void *gbuf, *dwbuf;                               // same shape: Q.Ktime^T and dO.Vtime^T rows, written by bwd_q for bwd_k
 };
 
 __device__ __forceinline__ int bucket_of(float xq1, float xk, int timelen) {
@@ -286,10 +336,15 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// Gs[row l&15][d] = sum_u X[row][u] * tab[d][u] for every bucket d < NBp (tab rows >= tab_rows read as zero)
+// LDS tiles of one wave: projections [16][NBp + 8] in the activation dtype, bins [16][NBp + 4] f32
+__host__ __device__ constexpr size_t ti_tile_t(int NBp, size_t es) { return (size_t)16 * (NBp + 8) * es; }
+__host__ __device__ constexpr size_t ti_tile_f(int NBp) { return (size_t)16 * (NBp + 4) * sizeof(float); }
+
+// Gs[row l&15][d] = sum_u X[row][u] * tab[d][u] for every bucket d < NBp (tab rows >= tab_rows read as zero), rounded to
+// the activation dtype once — the forward and both backward kernels see the same values
 template <typename T, int DT>
-__device__ __forceinline__ void bucket_project(const T* xrow, const T* tab, int ldt, int tab_rows, int NBp, float* Gs, int LDG, int lane) {
-    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+__device__ __forceinline__ void bucket_project(const T* xrow, const T* tab, int ldt, int tab_rows, int NBp, T* Gs, int lane) {
+    const int g4 = (lane >> 4) * 4, l15 = lane & 15, LDT_ = NBp + 8;
     Frag4<T> xf[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) xf[dt] = frag_ld<T>(xrow + dt * 16 + g4);
@@ -303,7 +358,7 @@ __device__ __forceinline__ void bucket_project(const T* xrow, const T* tab, int 
             if (dl >= tab_rows) tf = frag_zero<T>();
             a = mma16(tf, xf[dt], a);
         }
-        *reinterpret_cast<float4*>(Gs + l15 * LDG + d0 + g4) = make_float4(a[0], a[1], a[2], a[3]);
+        frag_st<T>(Gs + l15 * LDT_ + d0 + g4, frag_from_acc<T>(a));
     }
 }
 template <typename T> __device__ __forceinline__ Frag4<T> frag_from_f4(const float* p) {
@@ -332,16 +387,22 @@ __device__ __forceinline__ void bucket_store(const float* Ws, int LDG, int NBp, 
     const int l15 = lane & 15;
     for (int c = (lane >> 4) * 4; c < NBp; c += 16) frag_st<T>(dst_row + c, frag_from_f4<T>(Ws + l15 * LDG + c));
 }
+template <typename T>
+__device__ __forceinline__ void bucket_copy(const T* Gs, int NBp, T* dst_row, int lane) {
+    const int l15 = lane & 15;
+    for (int c = (lane >> 4) * 4; c < NBp; c += 16) frag_st<T>(dst_row + c, frag_ld<T>(Gs + l15 * (NBp + 8) + c));
+}
 
 template <typename T, int DT>
-__global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
-    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+__global__ __launch_bounds__(128) void tiattn_fwd_kernel(TaP p, TiP t) {
+    extern __shared__ __attribute__((aligned(16))) char lds_c[];
     Job j;
     if (!get_job(p, j)) return;
     constexpr int dh = 16 * DT;
-    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4;
-    float* Gs = lds_f + (size_t)(threadIdx.x >> 6) * 2 * 16 * LDG;
-    float* Ws = Gs + 16 * LDG;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4, LDT_ = t.NBp + 8;
+    char* base = lds_c + (size_t)(threadIdx.x >> 6) * (ti_tile_t(t.NBp, sizeof(T)) + ti_tile_f(t.NBp));
+    float* Ws = reinterpret_cast<float*>(base);
+    T* Gs = reinterpret_cast<T*>(base + ti_tile_f(t.NBp));
     const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
     const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
     const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * dh;
@@ -355,7 +416,8 @@ __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const Frag4<T> ident = identity_frag<T>(lane);
     const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
-    bucket_project<T, DT>(Qr, Kt, t.ldt, t.tab_rows, t.NBp, Gs, LDG, lane);               // temporal.py:58
+    const int kt_end = (causal && j.tile * 16 >= first_unpadded(idr, p.T, lane)) ? j.tile + 1 : p.NT;
+    bucket_project<T, DT>(Qr, Kt, t.ldt, t.tab_rows, t.NBp, Gs, lane);                    // temporal.py:58
     for (int i = lane; i < 16 * LDG; i += 64) Ws[i] = 0.f;
     wave_lds_sync();
     Frag4<T> qf[DT];
@@ -371,13 +433,13 @@ __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
             const int k = kt * 16 + g4 + r, kcl = min(k, p.T - 1);
             bk[r] = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
             const float madd = k >= p.T ? -INFINITY : (idr[kcl] == 0 ? PADV : 0.f);
-            float v = fmaf(s[r] + Gs[l15 * LDG + bk[r]], p.cscale, madd);                 // temporal.py:56-62
+            float v = fmaf(s[r] + to_f32(Gs[l15 * LDT_ + bk[r]]), p.cscale, madd);        // temporal.py:56-62
             if (causal && k > q && k < p.T) v = PADV;
             x[r] = v;
         }
     };
     float m = -INFINITY, l = 0.f;
-    for (int kt = 0; kt < p.NT; ++kt) {
+    for (int kt = 0; kt < kt_end; ++kt) {
         float x[4]; int bk[4];
         scores(kt, x, bk);
         const float tmax = group_max4(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
@@ -390,7 +452,7 @@ __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
     f32x4 acc[DT];
 #pragma unroll
     for (int ut = 0; ut < DT; ++ut) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < p.NT; ++kt) {
+    for (int kt = 0; kt < kt_end; ++kt) {
         float x[4]; int bk[4];
         scores(kt, x, bk);
         const int kr = min(kt * 16 + l15, p.T - 1);
@@ -429,14 +491,15 @@ __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
 
 template <typename T, int DT>
 __global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
-    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    extern __shared__ __attribute__((aligned(16))) char lds_c[];
     Job j;
     if (!get_job(p, j)) return;
     constexpr int dh = 16 * DT;
-    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4;
-    float* Gs = lds_f + (size_t)(threadIdx.x >> 6) * 3 * 16 * LDG;
-    float* dWs = Gs + 16 * LDG;
-    float* dGs = dWs + 16 * LDG;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4, LDT_ = t.NBp + 8;
+    char* base = lds_c + (size_t)(threadIdx.x >> 6) * (2 * ti_tile_t(t.NBp, sizeof(T)) + ti_tile_f(t.NBp));
+    float* dGs = reinterpret_cast<float*>(base);
+    T* Gs = reinterpret_cast<T*>(base + ti_tile_f(t.NBp));
+    T* dWs = Gs + 16 * LDT_;
     const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
     const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
     const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * dh;
@@ -451,8 +514,9 @@ __global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const Frag4<T> ident = identity_frag<T>(lane);
     const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
-    bucket_project<T, DT>(Qr, Kt, t.ldt, t.tab_rows, t.NBp, Gs, LDG, lane);
-    bucket_project<T, DT>(dOr, Vt, t.ldt, t.tab_rows, t.NBp, dWs, LDG, lane);     // dA[q,k] gets dO[q].Vtime[dt(q,k)]
+    const int kt_end = (causal && j.tile * 16 >= first_unpadded(idr, p.T, lane)) ? j.tile + 1 : p.NT;
+    bucket_project<T, DT>(Qr, Kt, t.ldt, t.tab_rows, t.NBp, Gs, lane);
+    bucket_project<T, DT>(dOr, Vt, t.ldt, t.tab_rows, t.NBp, dWs, lane);          // dA[q,k] gets dO[q].Vtime[dt(q,k)]
     for (int i = lane; i < 16 * LDG; i += 64) dGs[i] = 0.f;
     float dsum = 0.f;
     Frag4<T> qf[DT], gf[DT];
@@ -470,10 +534,14 @@ __global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
     }
     const float m = p.st_m[j.bp * p.T + qc], invl = 1.0f / p.st_l[j.bp * p.T + qc];
     wave_lds_sync();
+    if (qok) {   // the key-side kernel gathers these rows from HBM instead of projecting every query tile again
+        bucket_copy<T>(Gs, t.NBp, reinterpret_cast<T*>(t.gbuf) + (j.bp * p.T + q) * (long)t.NBp, lane);
+        bucket_copy<T>(dWs, t.NBp, reinterpret_cast<T*>(t.dwbuf) + (j.bp * p.T + q) * (long)t.NBp, lane);
+    }
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < p.NT; ++kt) {
+    for (int kt = 0; kt < kt_end; ++kt) {
         const int kr = min(kt * 16 + l15, p.T - 1);
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -490,10 +558,10 @@ __global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
             const int k = kt * 16 + g4 + r, kcl = min(k, p.T - 1);
             const int bk = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
             const bool pad = k >= p.T || idr[kcl] == 0, fut = causal && k > q;
-            float v = fmaf(s[r] + Gs[l15 * LDG + bk], p.cscale, k >= p.T ? -INFINITY : (pad ? PADV : 0.f));
+            float v = fmaf(s[r] + to_f32(Gs[l15 * LDT_ + bk]), p.cscale, k >= p.T ? -INFINITY : (pad ? PADV : 0.f));
             if (fut && k < p.T) v = PADV;
             const float P = __expf(v - m) * invl;
-            const float dP = (dk.thresh == 0u || hb[r] >= dk.t16) ? (da[r] + dWs[l15 * LDG + bk]) * dk.scale : 0.f;
+            const float dP = (dk.thresh == 0u || hb[r] >= dk.t16) ? (da[r] + to_f32(dWs[l15 * LDT_ + bk])) * dk.scale : 0.f;
             ds[r] = (pad || fut || !qok) ? 0.f : P * (dP - dsum) * p.cscale;
             atomicAdd(&dGs[l15 * LDG + bk], ds[r]);
         }
@@ -513,27 +581,25 @@ __global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
 
 template <typename T, int DT>
 __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
-    extern __shared__ __attribute__((aligned(16))) float lds_f[];
     Job j;
     if (!get_job(p, j)) return;
     constexpr int dh = 16 * DT;
-    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4;
-    float* Gs = lds_f + (size_t)(threadIdx.x >> 6) * 2 * 16 * LDG;
-    float* dWs = Gs + 16 * LDG;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const int k = j.tile * 16 + l15, kc = min(k, p.T - 1);
     const bool kok = k < p.T, causal = (p.flags & TA_CAUSAL) != 0;
     const T* Qb = reinterpret_cast<const T*>(p.qx) + (long)j.b * p.T * p.ldq + j.head * dh;
     const T* Kr = reinterpret_cast<const T*>(p.kx) + ((long)j.b * p.T + kc) * p.ldk + j.head * dh;
     const T* Vr = reinterpret_cast<const T*>(p.v) + ((long)j.b * p.T + kc) * p.ldv + j.head * dh;
     const T* dOb = reinterpret_cast<const T*>(p.d_out) + (long)j.b * p.T * p.ld_do + j.head * dh;
-    const T* Kt = reinterpret_cast<const T*>(t.ktime) + j.head * dh;
-    const T* Vt = reinterpret_cast<const T*>(t.vtime) + j.head * dh;
+    const T* Gb = reinterpret_cast<const T*>(t.gbuf) + j.bp * p.T * (long)t.NBp;
+    const T* dWb = reinterpret_cast<const T*>(t.dwbuf) + j.bp * p.T * (long)t.NBp;
     const float* tsr = t.ts + (long)j.b * (p.T + 1);
     const float xk = tsr[kc] / t.time_scale;
     const bool pad = !kok || p.ids[(long)j.b * p.T + kc] == 0;
     const float madd = !kok ? -INFINITY : (pad ? PADV : 0.f);
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const Frag4<T> ident = identity_frag<T>(lane);
+    const int fnp = first_unpadded(p.ids + (long)j.b * p.T, p.T, lane);
     Frag4<T> kf[DT], vf[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { kf[dt] = frag_ld<T>(Kr + dt * 16 + g4); vf[dt] = frag_ld<T>(Vr + dt * 16 + g4); }
@@ -541,13 +607,10 @@ __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { accK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int qt = 0; qt < p.NT; ++qt) {
+        if (causal && qt < j.tile && qt * 16 >= fnp) continue;
         const int ql = min(qt * 16 + l15, p.T - 1);
         const T* Qrow = Qb + (long)ql * p.ldq;
         const T* dOrow = dOb + (long)ql * p.ld_do;
-        wave_lds_sync();                                                             // the previous tile's gathers are done
-        bucket_project<T, DT>(Qrow, Kt, t.ldt, t.tab_rows, t.NBp, Gs, LDG, lane);
-        bucket_project<T, DT>(dOrow, Vt, t.ldt, t.tab_rows, t.NBp, dWs, LDG, lane);
-        wave_lds_sync();
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
         Frag4<T> qf[DT], gf[DT];
 #pragma unroll
@@ -557,14 +620,23 @@ __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
             s = mma16(qf[dt], kf[dt], s);
             da = mma16(gf[dt], vf[dt], da);
         }
+        // unconditional gathers first (clamped rows), consumed below
+        float gq[4], dwq[4];
+        int qcs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            qcs[r] = min(qt * 16 + g4 + r, p.T - 1);
+            const int bk = bucket_of(tsr[qcs[r] + 1] / t.time_scale, xk, t.timelen);
+            gq[r] = to_f32(Gb[(long)qcs[r] * t.NBp + bk]);
+            dwq[r] = to_f32(dWb[(long)qcs[r] * t.NBp + bk]);
+        }
         f32x4 a4, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int q = qt * 16 + g4 + r, qc = min(q, p.T - 1);
-            const long si = j.bp * p.T + qc;
-            const int bk = bucket_of(tsr[qc + 1] / t.time_scale, xk, t.timelen);
+            const int q = qt * 16 + g4 + r;
+            const long si = j.bp * p.T + qcs[r];
             const bool fut = causal && k > q;
-            float v = fmaf(s[r] + Gs[(g4 + r) * LDG + bk], p.cscale, madd);
+            float v = fmaf(s[r] + gq[r], p.cscale, madd);
             if (fut && kok) v = PADV;
             const float P = (q < p.T) ? __expf(v - p.st_m[si]) / p.st_l[si] : 0.f;
             bool keep = true;
@@ -573,7 +645,7 @@ __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
                 keep = ((k & 1) ? (h >> 16) : (h & 0xffffu)) >= dk.t16;
             }
             a4[r] = keep ? P * dk.scale : 0.f;
-            const float dP = keep ? (da[r] + dWs[(g4 + r) * LDG + bk]) * dk.scale : 0.f;
+            const float dP = keep ? (da[r] + dwq[r]) * dk.scale : 0.f;
             ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - p.st_d[si]) * p.cscale;
         }
         const Frag4<T> af = frag_from_acc<T>(a4), dsf = frag_from_acc<T>(ds);
@@ -645,13 +717,12 @@ int launch_jobs(K kern, const TaP& p, hipStream_t st) {
 
 template <typename T>
 int launch_fwd(const TaP& p, hipStream_t st) {
-    switch (p.Dv / 16) {
-        case 1: return launch_jobs(tattn_fwd_kernel<T, 1>, p, st);
-        case 2: return launch_jobs(tattn_fwd_kernel<T, 2>, p, st);
-        case 4: return launch_jobs(tattn_fwd_kernel<T, 4>, p, st);
-        case 8: return launch_jobs(tattn_fwd_kernel<T, 8>, p, st);
-    }
-    edgl_set_error("edgl_tattn_fwd: value head dim %d not supported (16, 32, 64, 128)", p.Dv);
+    const int dqt = p.Dq / 16, dvt = p.Dv / 16;
+#define EDGL_TA_CASE(DQ, DV) if (dqt == DQ && dvt == DV) return launch_jobs(tattn_fwd_kernel<T, DQ, DV>, p, st);
+    EDGL_TA_CASE(1, 1) EDGL_TA_CASE(2, 2) EDGL_TA_CASE(4, 4) EDGL_TA_CASE(8, 8)
+    EDGL_TA_CASE(3, 1) EDGL_TA_CASE(6, 2) EDGL_TA_CASE(12, 4) EDGL_TA_CASE(24, 8)
+#undef EDGL_TA_CASE
+    edgl_set_error("edgl_tattn_fwd: head dims Dq=%d Dv=%d not supported (Dv in {16,32,64,128}, Dq in {Dv, 3 Dv})", p.Dq, p.Dv);
     return EDGL_ERR_SHAPE;
 }
 template <typename T>
@@ -660,7 +731,7 @@ int launch_bwd(const TaP& p, hipStream_t st) {
     int rc = EDGL_ERR_SHAPE;
 #define EDGL_TA_CASE(DQ, DV)                                                     \
     if (dqt == DQ && dvt == DV) {                                                \
-        rc = launch_jobs(tattn_bwd_q_kernel<T, DQ>, p, st);                      \
+        rc = launch_jobs(tattn_bwd_q_kernel<T, DQ, DV>, p, st);                      \
         if (rc == EDGL_OK) rc = launch_jobs(tattn_bwd_k_kernel<T, DQ, DV>, p, st); \
         return rc;                                                               \
     }
@@ -862,8 +933,8 @@ extern "C" int edgl_tattn_bwd(const void* qx, int ldq, const void* kx, int ldk, 
 // ---- interval-bucket attention (TiSASRec) ---------------------------------------------------------------------------------
 namespace {
 template <typename K>
-int launch_ti(K kern, const TaP& p, const TiP& t, int waves, int tiles, hipStream_t st) {
-    const size_t smem = (size_t)waves * tiles * 16 * (t.NBp + 4) * sizeof(float);
+int launch_ti(K kern, const TaP& p, const TiP& t, int waves, size_t wave_bytes, hipStream_t st) {
+    const size_t smem = (size_t)waves * wave_bytes;
     EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_tiattn: timelen %d needs %zu B of LDS", t.timelen, smem);
     if (smem > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const long jobs = (long)p.B * p.H * p.NT;
@@ -872,11 +943,13 @@ int launch_ti(K kern, const TaP& p, const TiP& t, int waves, int tiles, hipStrea
     return EDGL_OK;
 }
 template <typename T, int DT>
-int ti_fwd(const TaP& p, const TiP& t, hipStream_t st) { return launch_ti(tiattn_fwd_kernel<T, DT>, p, t, 4, 2, st); }
+int ti_fwd(const TaP& p, const TiP& t, hipStream_t st) {
+    return launch_ti(tiattn_fwd_kernel<T, DT>, p, t, 2, ti_tile_t(t.NBp, sizeof(T)) + ti_tile_f(t.NBp), st);
+}
 template <typename T, int DT>
 int ti_bwd(const TaP& p, const TiP& t, float* d_ktime, float* d_vtime, hipStream_t st) {
-    if (int rc = launch_ti(tiattn_bwd_q_kernel<T, DT>, p, t, 2, 3, st)) return rc;
-    if (int rc = launch_ti(tiattn_bwd_k_kernel<T, DT>, p, t, 4, 2, st)) return rc;
+    if (int rc = launch_ti(tiattn_bwd_q_kernel<T, DT>, p, t, 2, 2 * ti_tile_t(t.NBp, sizeof(T)) + ti_tile_f(t.NBp), st)) return rc;
+    if (int rc = launch_ti(tiattn_bwd_k_kernel<T, DT>, p, t, 4, 0, st)) return rc;
     const int C = p.H * 16 * DT, splits = 32;
     if (hipMemsetAsync(d_ktime, 0, (size_t)t.tab_rows * C * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(d_vtime, 0, (size_t)t.tab_rows * C * sizeof(float), st) != hipSuccess) {
@@ -931,7 +1004,7 @@ extern "C" int edgl_tiattn_fwd(const void* q, int ldq, const void* k, int ldk, c
         p.st_d = reinterpret_cast<float*>((char*)saved + s.off_d);
         p.oatt = reinterpret_cast<float*>((char*)saved + s.off_o);
     }
-    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, nullptr, (timelen + 1 + 15) / 16 * 16};
+    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, nullptr, (timelen + 1 + 15) / 16 * 16, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
 #define EDGL_TI_FWD(TT)                                        \
     switch (dh / 16) {                                         \
@@ -967,7 +1040,10 @@ extern "C" int edgl_tiattn_bwd(const void* q, int ldq, const void* k, int ldk, c
     p.st_l = reinterpret_cast<float*>((char*)saved + s.off_l);
     p.st_d = reinterpret_cast<float*>((char*)saved + s.off_d);
     p.oatt = reinterpret_cast<float*>((char*)saved + s.off_o);
-    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, dgbuf, (timelen + 1 + 15) / 16 * 16};
+    const int NBp = (timelen + 1 + 15) / 16 * 16;
+    const size_t bucket_bytes = (size_t)B * T * H * NBp * (dtype == EDGL_BF16 ? 2 : 4);   // dgbuf = [dG | G | dO.Vtime^T]
+    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, dgbuf, NBp, (char*)dgbuf + bucket_bytes,
+          (char*)dgbuf + 2 * bucket_bytes};
     hipStream_t st = (hipStream_t)stream;
 #define EDGL_TI_BWD(TT)                                                        \
     switch (dh / 16) {                                                         \

@@ -313,7 +313,7 @@ int edgl_add_cols(void* dst, int ld_dst, const void* src, const void* src2, int 
  * edgl_tattn_fwd: generic masked attention per (sample, head): S = scale * qx_h . kx_h^T with head slices
  * qx[:, :, h*Dq:(h+1)*Dq] (same for kx; v and out use Dv); scores of padded keys (ids == 0) and, with EDGL_TATTN_CAUSAL,
  * of keys k > q are REPLACED by float32(-2^32+1) (temporal.py:153-166: a fully masked row is uniform over all T keys);
- * P = softmax(S); out = dropout(P) . v_h + resid (temporal.py:169-181).  Dq, Dv multiples of 16; Dv in {16,32,64,128}.
+ * P = softmax(S); out = dropout(P) . v_h + resid (temporal.py:169-181).  Dv in {16,32,64,128}, Dq in {Dv, 3*Dv}.
  * saved (NULL for inference): edgl_tattn_saved_bytes bytes = row max / sum / dO.O [H*B*T] f32 each + O before the
  * residual [B,T,H*Dv] f32.  edgl_tattn_bwd (Dq in {Dv, 3*Dv}): d_out -> d_qx, d_kx, d_v (the residual gradient is d_out
  * itself); no gradient flows into a replaced score. */
@@ -347,7 +347,8 @@ int edgl_mask_rows(const void* x, const int64_t* ids, void* y, long rows, int C,
  * vtime[bucket]) + resid.  The query mask of temporal.py:84-88 is the identity for LayerNorm-ed queries and is not
  * applied.  saved: edgl_tattn_saved_bytes(B,T,H,dh) bytes; wbuf: edgl_tiattn_bucket_elems elements of `dtype` (binned
  * probabilities, read by the backward); both NULL for inference.  timelen <= 256.
- * edgl_tiattn_bwd: d_q, d_k, d_v; d_ktime, d_vtime f32 [tab_rows, H*dh] (overwritten); dgbuf: workspace like wbuf. */
+ * edgl_tiattn_bwd: d_q, d_k, d_v; d_ktime, d_vtime f32 [tab_rows, H*dh] (overwritten); dgbuf: workspace of 3 x
+ * edgl_tiattn_bucket_elems elements of `dtype` (binned score gradients and the two row projections the key-side kernel reads). */
 long edgl_tiattn_bucket_elems(int B, int T, int H, int timelen);
 int edgl_tiattn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* resid, int ldr,
                     const int64_t* ids, const float* ts, const void* ktime, const void* vtime, int tab_rows, int B, int T,
