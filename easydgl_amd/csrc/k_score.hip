@@ -568,25 +568,30 @@ __global__ void slab_reduce_rows_kernel(const float* slabs, const int32_t* nvali
 // scoring kernels can skip the rest exactly.
 __global__ __launch_bounds__(1024) void compact_scan_kernel(const int64_t* labels, int R, int32_t* perm, int32_t* inv,
                                                             int32_t* nvalid) {
-    __shared__ int cnt[1024];
-    const int t = threadIdx.x, per = (R + 1023) / 1024;
-    const int r0 = t * per, r1 = min(R, r0 + per);
-    int c = 0;
-    for (int r = r0; r < r1; ++r) c += labels[r] != 0;
-    cnt[t] = c;
+    // chunks of 1024 consecutive rows: one coalesced label per thread, wave ballots + a 16-entry scan of the wave counts
+    __shared__ int wcnt[16];
+    __shared__ int s_base;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) s_base = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // inclusive Hillis-Steele scan
-        const int v = t >= off ? cnt[t - off] : 0;
+    for (int r0 = 0; r0 < R; r0 += 1024) {
+        const int r = r0 + t;
+        const bool on = r < R && labels[r] != 0;
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) wcnt[w] = __popcll(bal);
         __syncthreads();
-        cnt[t] += v;
+        int before = s_base, tot = 0;
+        for (int i = 0; i < 16; ++i) { const int c = wcnt[i]; before += i < w ? c : 0; tot += c; }
+        const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+        if (r < R) {
+            if (on) { perm[pos] = r; inv[r] = pos; }
+            else inv[r] = -1;
+        }
         __syncthreads();
+        if (t == 0) s_base += tot;
     }
-    int pos = cnt[t] - c;
-    const int total = cnt[1023];
-    for (int r = r0; r < r1; ++r) {
-        if (labels[r] != 0) { perm[pos] = r; inv[r] = pos; ++pos; }
-        else inv[r] = -1;
-    }
+    __syncthreads();
+    const int total = s_base;
     for (int j = total + t; j < R; j += 1024) perm[j] = -1;
     if (t == 0) nvalid[0] = total;
 }

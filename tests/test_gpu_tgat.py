@@ -66,6 +66,8 @@ def _operands(seed, B, T, H, Dq, Dv, dtype):
     ids[0, :max(1, T // 3)] = 0          # left padding: fully masked query rows
     if T > 5:
         ids[-1, T - 3] = 0               # a padded key away from the left edge
+    if B >= 3:
+        ids[2, :] = 0                    # an all-padding sequence: every row uniform over all T keys
     return qx, kx, v, resid, d_out, ids
 
 
