@@ -95,18 +95,18 @@ __global__ void pack_kernel(const float* W1, const float* b1, const float* w, co
 //   -inf        k >= T (tile padding: excluded from the softmax)
 // `pad` keeps the padded-key bits for the backward (no gradient flows into a padded score).
 template <int NT>
-struct KeyMask { const float* madd; uint32_t pad; };   // madd: wave-private LDS array [16*NT]
+struct KeyMask { const float* madd; uint64_t pad; };   // pad: one bit per (key tile, register), NT <= 16   // madd: wave-private LDS array [16*NT]
 template <int NT>
 __device__ __forceinline__ KeyMask<NT> load_keymask(const int64_t* ids_row, int T, int lane, float* lds_madd) {
     KeyMask<NT> km;
-    km.pad = 0u;
+    km.pad = 0ull;
     km.madd = lds_madd;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = kt * 16 + (lane >> 4) * 4 + r;
-            if (k < T && ids_row[k] == 0) km.pad |= 1u << (kt * 4 + r);
+            if (k < T && ids_row[k] == 0) km.pad |= 1ull << (kt * 4 + r);
         }
     for (int k = lane; k < 16 * NT; k += 64) {
         float v = -INFINITY;

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             for (int r = 0; r < 4; ++r) {
                 // tf.where(mask==0, paddings, S) (temporal.py:425-426) passes no gradient to a padded key's
                 // score; P is non-zero there only for fully padded rows (uniform softmax)
-                const bool padded = ((km.pad >> (kt * 4 + r)) & 1u) || ((p.flags & MAU_CAUSAL) && kt * 16 + g4 + r > q);
+                const bool padded = ((km.pad >> (kt * 4 + r)) & 1ull) || ((p.flags & MAU_CAUSAL) && kt * 16 + g4 + r > q);
                 ds[r] = padded ? 0.f : s[kt][r] * (a[r] - rowdot) * cscale;
             }
             const Frag4<T> dsf = frag_from_acc<T>(ds);
@@ -715,8 +715,13 @@ int dispatch_nt(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dsc,
         case 6: return launch_bwd<T, DT, 6>(p, ws, dW1, db1, dw, dsc, st);
         case 7: return launch_bwd<T, DT, 7>(p, ws, dW1, db1, dw, dsc, st);
         case 8: return launch_bwd<T, DT, 8>(p, ws, dW1, db1, dw, dsc, st);
+        case 9: return launch_bwd<T, DT, 9>(p, ws, dW1, db1, dw, dsc, st);
+        case 10: return launch_bwd<T, DT, 10>(p, ws, dW1, db1, dw, dsc, st);
+        case 11: return launch_bwd<T, DT, 11>(p, ws, dW1, db1, dw, dsc, st);
+        case 12: return launch_bwd<T, DT, 12>(p, ws, dW1, db1, dw, dsc, st);
+        case 13: return launch_bwd<T, DT, 13>(p, ws, dW1, db1, dw, dsc, st);
     }
-    edgl_set_error("edgl_bimau_bwd: T=%d not supported (T <= 128)", p.T);
+    edgl_set_error("edgl_bimau_bwd: T=%d not supported (T <= 208)", p.T);
     return EDGL_ERR_SHAPE;
 }
 

@@ -273,8 +273,13 @@ int dispatch_nt(FwdP p, hipStream_t st) {
         case 6: return launch_fwd<T, DT, 6>(p, st);
         case 7: return launch_fwd<T, DT, 7>(p, st);
         case 8: return launch_fwd<T, DT, 8>(p, st);
+        case 9: return launch_fwd<T, DT, 9>(p, st);
+        case 10: return launch_fwd<T, DT, 10>(p, st);
+        case 11: return launch_fwd<T, DT, 11>(p, st);
+        case 12: return launch_fwd<T, DT, 12>(p, st);
+        case 13: return launch_fwd<T, DT, 13>(p, st);
     }
-    edgl_set_error("edgl_bimau_fwd: T=%d not supported (T <= 128)", p.T);
+    edgl_set_error("edgl_bimau_fwd: T=%d not supported (T <= 208)", p.T);
     return EDGL_ERR_SHAPE;
 }
 

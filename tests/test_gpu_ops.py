@@ -217,9 +217,12 @@ def _bimau_case(B, T, C, H, E, seed, cin_mult=3):
 
 
 @pytest.mark.parametrize("name,dt,tol", DTYPES)
-@pytest.mark.parametrize("B,T,C,H,E", [(3, 11, 32, 2, 4), (2, 31, 64, 2, 7), (2, 101, 128, 8, 16), (1, 128, 32, 2, 2)])
+@pytest.mark.parametrize("B,T,C,H,E", [(3, 11, 32, 2, 4), (2, 31, 64, 2, 7), (2, 101, 128, 8, 16), (1, 128, 32, 2, 2),
+                                       (2, 201, 256, 8, 16), (1, 150, 32, 2, 3)])
 def test_bimau_fwd_bwd(name, dt, tol, B, T, C, H, E):
     o = ops()
+    if name == "f32" and T > 128 and C // H == 32:
+        pytest.skip("f32 staging of 13 key tiles at head dim 32 needs 241 KB of LDS: T > 128 at dh = 32 is a bf16-only shape")
     cfg, x, ids, marks, spans, W = _bimau_case(B, T, C, H, E, seed=T + C)
     xt = torch.tensor(x, dtype=dt).cuda().requires_grad_()
     Wq = torch.tensor(W["Wq"], dtype=torch.float32).cuda().requires_grad_()
@@ -244,7 +247,7 @@ def test_bimau_fwd_bwd(name, dt, tol, B, T, C, H, E):
     km3 = torch.tensor((ids != 0).astype(np.float64)).unsqueeze(1).repeat(H, T, 1)
     out_r, lam_r = R.bimau(C, H, xr, km3, torch.tensor(spans), torch.tensor(marks, dtype=torch.float64), pr, "", 0.0, False)
     ((out_r * G1.double().cpu()).sum() + (lam_r * G2.double().cpu()).sum()).backward()
-    ftol = 3e-5 if name == "f32" else 3e-2
+    ftol = 3e-5 if name == "f32" else (3e-2 if T <= 128 else 5e-2)   # 201 bf16 probabilities per row at the config-3 shape
     assert_close(lam.detach().cpu().numpy(), lam_r.detach().numpy(), ftol, "lambda")
     assert_close(out.float().detach().cpu().numpy(), out_r.detach().numpy(), ftol, "out")
     gtol = 2e-4 if name == "f32" else 6e-2
@@ -287,7 +290,7 @@ def test_mau_causal_and_diag_flags(name, dt, tol, flags):
     out_r, lam_r = R.bimau(C, H, None, km3, torch.tensor(spans), torch.tensor(marks, dtype=torch.float64), pr, "", 0.0, False,
                            causal=bool(flags & 1), set_diag=not (flags & 2), qkvt=qr, resid=rr)
     ((out_r * G1.double().cpu()).sum() + (lam_r * G2.double().cpu()).sum()).backward()
-    ftol = 3e-5 if name == "f32" else 3e-2
+    ftol = 3e-5 if name == "f32" else (3e-2 if T <= 128 else 5e-2)   # 201 bf16 probabilities per row at the config-3 shape
     assert_close(lam.detach().cpu().numpy(), lam_r.detach().numpy(), ftol, "lambda")
     assert_close(out.float().detach().cpu().numpy(), out_r.detach().numpy(), ftol, "out")
     gtol = 2e-4 if name == "f32" else 6e-2
