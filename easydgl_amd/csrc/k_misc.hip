@@ -8,7 +8,7 @@
 
 namespace {
 thread_local char g_err[512] = "";
-constexpr int RED_BLOCKS = 64;
+constexpr int RED_BLOCKS = 256;   // per-block partials of the scalar reductions (one row per thread at the headline size)
 constexpr int SUMSQ_BLOCKS = 1024;
 }  // namespace
 
@@ -92,9 +92,11 @@ __global__ __launch_bounds__(256) void tpp_partial_kernel(TppP p, float* part) {
     if (threadIdx.x == 0) { part[blockIdx.x * 3] = a; part[blockIdx.x * 3 + 1] = bsum; part[blockIdx.x * 3 + 2] = c; }
 }
 __global__ void tpp_final_kernel(const float* part, int nblk, float coef, float* sums, float* reg_out, int accumulate) {
-    if (threadIdx.x != 0) return;
+    // one wave: lane i adds partials i, i+64, ... in index order, then a fixed xor tree — deterministic
     float a = 0.f, b = 0.f, c = 0.f;
-    for (int i = 0; i < nblk; ++i) { a += part[i * 3]; b += part[i * 3 + 1]; c += part[i * 3 + 2]; }
+    for (int i = threadIdx.x; i < nblk; i += 64) { a += part[i * 3]; b += part[i * 3 + 1]; c += part[i * 3 + 2]; }
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    if (threadIdx.x != 0) return;
     sums[0] = a; sums[1] = b; sums[2] = c;
     const float reg = coef * (-(a - b) / c);  // temporal.py:331-332, EasyDGL.py:175
     reg_out[0] = accumulate ? reg_out[0] + reg : reg;

@@ -636,25 +636,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* src, long rows,
 // ---------------------------------------------------------------------------------------------
 // CE loss from (lse, label logit) — EasyDGL.py:155,177-185
 // ---------------------------------------------------------------------------------------------
-__global__ void ce_loss_kernel(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
-                               float* loss_out, float* coef) {
-    __shared__ float red[8];
+__global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
+                                                       float* loss_out, float* coef) {
+    // one workgroup; a thread keeps up to CE_KEEP of its rows' probabilities in registers between the two passes (the loads of
+    // a pass are independent, so they overlap instead of paying one memory round trip per row)
+    constexpr int CE_KEEP = 16;
+    __shared__ float red[16];
+    float py[CE_KEEP];
     float num = 0.f, den = 0.f;
-    for (int m = threadIdx.x; m < R; m += blockDim.x) {
-        if (labels[m] == 0) continue;            // weight 0 (EasyDGL.py:180): lse may be undefined for such rows
-        const float py = __expf(label_logit[m] - row_lse[m]);
-        num += -__logf(py + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < CE_KEEP; ++i) {
+        const int m = threadIdx.x + i * 1024;
+        const int mc = min(m, R - 1);
+        const bool on = m < R && labels[mc] != 0;   // weight 0 (EasyDGL.py:180): lse may be undefined for such rows
+        const float v = __expf(label_logit[mc] - row_lse[mc]);
+        py[i] = on ? v : -1.f;
+        if (on) { num += -__logf(v + 1e-5f); den += 1.f; }
+    }
+    for (int m = threadIdx.x + CE_KEEP * 1024; m < R; m += 1024) {
+        if (labels[m] == 0) continue;
+        num += -__logf(__expf(label_logit[m] - row_lse[m]) + 1e-5f);
         den += 1.f;
     }
     num = block_sum(num, red);
     den = block_sum(den, red);
     const float W = den + 1e-5f;
     if (threadIdx.x == 0) loss_out[0] = num / W;
-    for (int m = threadIdx.x; m < R; m += blockDim.x) {
+#pragma unroll
+    for (int i = 0; i < CE_KEEP; ++i) {
+        const int m = threadIdx.x + i * 1024;
+        if (m < R) coef[m] = py[i] >= 0.f ? (1.f / W) * (py[i] / (py[i] + 1e-5f)) : 0.f;
+    }
+    for (int m = threadIdx.x + CE_KEEP * 1024; m < R; m += 1024) {
         float cf = 0.f;
         if (labels[m] != 0) {
-            const float py = __expf(label_logit[m] - row_lse[m]);
-            cf = (1.f / W) * (py / (py + 1e-5f));
+            const float v = __expf(label_logit[m] - row_lse[m]);
+            cf = (1.f / W) * (v / (v + 1e-5f));
         }
         coef[m] = cf;
     }
@@ -1047,7 +1064,7 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
 extern "C" int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
                                 float* loss_out, float* coef, void* stream) {
     EDGL_REQUIRE(row_lse && label_logit && labels && loss_out && coef, EDGL_ERR_NULL, "edgl_ce_loss_fwd: null pointer");
-    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, row_lse, label_logit, labels, R, loss_out, coef);
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_lse, label_logit, labels, R, loss_out, coef);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
