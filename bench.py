@@ -250,13 +250,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # one rank per GPU; EDGL_BENCH_BACKEND=gloo lets the multi-process path be exercised on a single-GPU box (ranks then share
+    # device 0 and the collective goes through the host) — a functional check only, never a measurement
+    backend = os.environ.get("EDGL_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     c = dict(HEADLINE)
     from easydgl_amd import _lib, parallel
     model, feats, labels = make_model_and_batch(c, args.dtype, dev, seed=9876 + rank)
