@@ -322,9 +322,12 @@ enum { ROLE_Y = 0, ROLE_W = 1 };
 // NW = 8: one workgroup per CU, double-buffered LDS, register prefetch across the compute phase.
 // NW = 4: two independent 4-wave workgroups per CU, single LDS buffer, next tile fetched at the tile boundary —
 //         the two workgroups drift apart, so one's MFMA phase overlaps the other's exp/VALU and load phases.
-template <typename T, int CT, int ROLE, int NW>
+// CO = output channel tiles accumulated per workgroup: CT (one pass) or CT/2 (C = 256: two passes over the channel halves —
+// the logits are recomputed per pass, but [2][16] accumulator tiles + operands do not fit 256 registers and spill ~300)
+template <typename T, int CT, int ROLE, int NW, int CO = CT>
 __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     constexpr int NTHR = 64 * NW, XBW = 32 * NW;
+    const int ct0 = (CO == CT) ? 0 : (ROLE == ROLE_Y ? (int)blockIdx.y : (int)blockIdx.z) * CO;
     using S = SC<T, CT, NTHR>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr size_t BUF = S::Z_BYTES + S::ZT_BYTES + S::INFO_BYTES;
@@ -396,11 +399,11 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         }
     };
 
-    f32x4 out[2][CT];
+    f32x4 out[2][CO];
 #pragma unroll
     for (int ix = 0; ix < 2; ++ix)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) out[ix][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ct = 0; ct < CO; ++ct) out[ix][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbias[2] = {0.f, 0.f};
 
     ZStream<T, CT, true, NTHR> zs;
@@ -481,8 +484,8 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                             af[ix][4 + r] = (bf16)acc[2 * jp + 1][ix][r];
                         }
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        const T* zt = ZTs + (ct * 16 + l15) * S::LDZ + (half * 2 + jp) * 32 + g4;
+                    for (int ct = 0; ct < CO; ++ct) {
+                        const T* zt = ZTs + ((ct0 + ct) * 16 + l15) * S::LDZ + (half * 2 + jp) * 32 + g4;
                         bf16x8 bfr;
                         *reinterpret_cast<uint2*>(&bfr) = *reinterpret_cast<const uint2*>(zt);
                         *(reinterpret_cast<uint2*>(&bfr) + 1) = *reinterpret_cast<const uint2*>(zt + 16);
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                 for (int j = 0; j < 4; ++j) {
                     const Frag4<T> a0 = frag_from_acc<T>(acc[j][0]), a1 = frag_from_acc<T>(acc[j][1]);
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        const Frag4<T> bfr = frag_ld<T>(ZTs + (ct * 16 + l15) * S::LDZ + (half * 4 + j) * 16 + g4);
+                    for (int ct = 0; ct < CO; ++ct) {
+                        const Frag4<T> bfr = frag_ld<T>(ZTs + ((ct0 + ct) * 16 + l15) * S::LDZ + (half * 4 + j) * 16 + g4);
                         out[0][ct] = mma16(a0, bfr, out[0][ct]);
                         out[1][ct] = mma16(a1, bfr, out[1][ct]);
                     }
@@ -521,10 +524,10 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
             const int gx = xbase + ix * 16 + g4 + r;
             if (gx < xend) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) slab[(long)gx * S::C + ct * 16 + l15] = out[ix][ct][r];
+                for (int ct = 0; ct < CO; ++ct) slab[(long)gx * S::C + (ct0 + ct) * 16 + l15] = out[ix][ct][r];
             }
         }
-    if (ROLE == ROLE_W) {
+    if (ROLE == ROLE_W && ct0 == 0) {
 #pragma unroll
         for (int ix = 0; ix < 2; ++ix) {
             const float v = group_sum4(dbias[ix]);
@@ -915,9 +918,10 @@ int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_tab
         q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY;
         edgl_prof_begin(EDGL_KERNEL_SCORE_BWD_ROWS, st);
         if (nw == 8) {
-            auto k = score_bwd_kernel<T, CT, ROLE_Y, 8>;
+            constexpr int CO = (CT == 16 && sizeof(T) == 2) ? 8 : CT;
+            auto k = score_bwd_kernel<T, CT, ROLE_Y, 8, CO>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 256) * q.nchunk), dim3(512), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 256) * q.nchunk, CT / CO), dim3(512), smem_nw, st, q);
         } else {
             auto k = score_bwd_kernel<T, CT, ROLE_Y, 4>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
@@ -937,9 +941,10 @@ int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_tab
         ScoreP q = p;
         q.zchunk = plan.w.zchunk; q.nchunk = plan.w.nchunk; q.slabs = ws + plan.off_slabW; q.bias_slabs = ws + plan.off_slabB;
         if (nw == 8) {
-            auto k = score_bwd_kernel<T, CT, ROLE_W, 8>;
+            constexpr int CO = (CT == 16 && sizeof(T) == 2) ? 8 : CT;
+            auto k = score_bwd_kernel<T, CT, ROLE_W, 8, CO>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, 256), q.nchunk), dim3(512), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, 256), q.nchunk, CT / CO), dim3(512), smem_nw, st, q);
         } else {
             auto k = score_bwd_kernel<T, CT, ROLE_W, 4>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
