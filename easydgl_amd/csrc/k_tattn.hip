@@ -316,16 +316,16 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_kernel(TaP p) {
 
 // =========================================================================================================================
 // Interval-bucket form — TiMultiHeadAttention.__call__ (temporal.py:36-105, TiSASRec): the score adds Q[q].Ktime[dt(q,k)]
-// and the value adds Vtime[dt(q,k)], dt = int(clip(t[q+1] - t[k], 0, timelen)) (TiSASREC.py:58-62).  Per 16-row query tile
-// the wave projects its rows onto the whole interval table once (G[q][d] = Q[q].Ktime[d], 17 MFMA tiles into LDS) and the
-// [T,T] pair loop gathers from it; on the value side the probabilities are binned per interval (W[q][d] += A[q,k], LDS
-// atomics) and one more MFMA chain applies Vtime.  The reference builds two [B,T,T,C] gathers instead.
+// and the value adds Vtime[dt(q,k)], dt = int(clip(t[q+1] - t[k], 0, timelen)) (TiSASREC.py:58-62).  The score term of a
+// pair is a dh-long dot product against the gathered table row (packed bf16 dot instructions; the tables are L2-resident);
+// on the value side the probabilities are binned per interval (W[q][d] += A[q,k], LDS atomics) and one MFMA chain applies
+// Vtime to the bins — likewise dQ += dG . Ktime backward, and the table gradients are dG^T . Q and W^T . dO over all rows.
+// The reference builds two [B,T,T,C] gathers instead.
 // =========================================================================================================================
 struct TiP {
     const float* ts; float time_scale; int timelen;
     const void *ktime, *vtime; int ldt, tab_rows;     // [tab_rows, H*dh] activation dtype; bucket >= tab_rows reads as zeros
     void *wbuf, *dgbuf; int NBp;                      // [H*B*T][NBp] activation dtype: binned probabilities / score gradients
-    void *gbuf, *dwbuf;                               // same shape: Q.Ktime^T and dO.Vtime^T rows, written by bwd_q for bwd_k
 };
 
 __device__ __forceinline__ int bucket_of(float xq1, float xk, int timelen) {
@@ -336,30 +336,37 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// LDS tiles of one wave: projections [16][NBp + 8] in the activation dtype, bins [16][NBp + 4] f32
-__host__ __device__ constexpr size_t ti_tile_t(int NBp, size_t es) { return (size_t)16 * (NBp + 8) * es; }
+// LDS tile of one wave: bins [16][NBp + 4] f32 (binned probabilities in the forward, binned score gradients backward)
 __host__ __device__ constexpr size_t ti_tile_f(int NBp) { return (size_t)16 * (NBp + 4) * sizeof(float); }
 
-// Gs[row l&15][d] = sum_u X[row][u] * tab[d][u] for every bucket d < NBp (tab rows >= tab_rows read as zero), rounded to
-// the activation dtype once — the forward and both backward kernels see the same values
+// <a, b> over one head slice (16*DT channels), both rows read from global / L1: the interval term of a (query, key) pair,
+// Q[q] . Ktime[bucket] or dO[q] . Vtime[bucket].  bf16: packed v_dot2c_f32_bf16 (2 MACs per instruction), f32 accumulate.
 template <typename T, int DT>
-__device__ __forceinline__ void bucket_project(const T* xrow, const T* tab, int ldt, int tab_rows, int NBp, T* Gs, int lane) {
-    const int g4 = (lane >> 4) * 4, l15 = lane & 15, LDT_ = NBp + 8;
-    Frag4<T> xf[DT];
+__device__ __forceinline__ float dot_rows(const T* a, const T* b) {
+    float acc = 0.f;
+    if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) xf[dt] = frag_ld<T>(xrow + dt * 16 + g4);
-    for (int d0 = 0; d0 < NBp; d0 += 16) {
-        const int dl = d0 + l15;
-        const T* trow = tab + (long)min(dl, tab_rows - 1) * ldt;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            Frag4<T> tf = frag_ld<T>(trow + dt * 16 + g4);
-            if (dl >= tab_rows) tf = frag_zero<T>();
-            a = mma16(tf, xf[dt], a);
+        for (int c = 0; c < 2 * DT; ++c) {
+            const uint4 x = *reinterpret_cast<const uint4*>(a + c * 8), y = *reinterpret_cast<const uint4*>(b + c * 8);
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x.x), __builtin_bit_cast(bf2, y.x), acc, false);
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x.y), __builtin_bit_cast(bf2, y.y), acc, false);
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x.z), __builtin_bit_cast(bf2, y.z), acc, false);
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x.w), __builtin_bit_cast(bf2, y.w), acc, false);
         }
-        frag_st<T>(Gs + l15 * LDT_ + d0 + g4, frag_from_acc<T>(a));
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4 * DT; ++c) {
+            const float4 x = *reinterpret_cast<const float4*>(a + c * 4), y = *reinterpret_cast<const float4*>(b + c * 4);
+            acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+        }
     }
+    return acc;
+}
+// row of an interval table for `bucket` (clamped address; the caller zeroes the result for bucket >= tab_rows)
+template <typename T>
+__device__ __forceinline__ const T* tab_row(const T* tab, int ldt, int tab_rows, int bucket) {
+    return tab + (long)min(bucket, tab_rows - 1) * ldt;
 }
 template <typename T> __device__ __forceinline__ Frag4<T> frag_from_f4(const float* p) {
     const float4 v = *reinterpret_cast<const float4*>(p);
@@ -370,6 +377,7 @@ template <typename T, int DT>
 __device__ __forceinline__ void bucket_apply(const float* Ws, int LDG, const T* tab, int ldt, int tab_rows, int NBp,
                                              const Frag4<T>& ident, f32x4 (&acc)[DT], int lane) {
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+#pragma unroll 4
     for (int d0 = 0; d0 < NBp; d0 += 16) {
         const Frag4<T> bf = frag_from_f4<T>(Ws + l15 * LDG + d0 + g4);
         const int dl = d0 + l15;
@@ -385,24 +393,17 @@ __device__ __forceinline__ void bucket_apply(const float* Ws, int LDG, const T* 
 template <typename T>
 __device__ __forceinline__ void bucket_store(const float* Ws, int LDG, int NBp, T* dst_row, int lane) {
     const int l15 = lane & 15;
+#pragma unroll 4
     for (int c = (lane >> 4) * 4; c < NBp; c += 16) frag_st<T>(dst_row + c, frag_from_f4<T>(Ws + l15 * LDG + c));
 }
-template <typename T>
-__device__ __forceinline__ void bucket_copy(const T* Gs, int NBp, T* dst_row, int lane) {
-    const int l15 = lane & 15;
-    for (int c = (lane >> 4) * 4; c < NBp; c += 16) frag_st<T>(dst_row + c, frag_ld<T>(Gs + l15 * (NBp + 8) + c));
-}
-
 template <typename T, int DT>
-__global__ __launch_bounds__(128) void tiattn_fwd_kernel(TaP p, TiP t) {
+__global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
     extern __shared__ __attribute__((aligned(16))) char lds_c[];
     Job j;
     if (!get_job(p, j)) return;
     constexpr int dh = 16 * DT;
-    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4, LDT_ = t.NBp + 8;
-    char* base = lds_c + (size_t)(threadIdx.x >> 6) * (ti_tile_t(t.NBp, sizeof(T)) + ti_tile_f(t.NBp));
-    float* Ws = reinterpret_cast<float*>(base);
-    T* Gs = reinterpret_cast<T*>(base + ti_tile_f(t.NBp));
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4;
+    float* Ws = reinterpret_cast<float*>(lds_c + (size_t)(threadIdx.x >> 6) * ti_tile_f(t.NBp));
     const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
     const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
     const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * dh;
@@ -417,8 +418,7 @@ __global__ __launch_bounds__(128) void tiattn_fwd_kernel(TaP p, TiP t) {
     const Frag4<T> ident = identity_frag<T>(lane);
     const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
     const int kt_end = (causal && j.tile * 16 >= first_unpadded(idr, p.T, lane)) ? j.tile + 1 : p.NT;
-    bucket_project<T, DT>(Qr, Kt, t.ldt, t.tab_rows, t.NBp, Gs, lane);                    // temporal.py:58
-    for (int i = lane; i < 16 * LDG; i += 64) Ws[i] = 0.f;
+    for (int i = lane * 4; i < 16 * LDG; i += 256) *reinterpret_cast<float4*>(Ws + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     wave_lds_sync();
     Frag4<T> qf[DT];
 #pragma unroll
@@ -433,12 +433,14 @@ __global__ __launch_bounds__(128) void tiattn_fwd_kernel(TaP p, TiP t) {
             const int k = kt * 16 + g4 + r, kcl = min(k, p.T - 1);
             bk[r] = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
             const float madd = k >= p.T ? -INFINITY : (idr[kcl] == 0 ? PADV : 0.f);
-            float v = fmaf(s[r] + to_f32(Gs[l15 * LDT_ + bk[r]]), p.cscale, madd);        // temporal.py:56-62
+            const float g = bk[r] < t.tab_rows ? dot_rows<T, DT>(Qr, tab_row<T>(Kt, t.ldt, t.tab_rows, bk[r])) : 0.f;   // temporal.py:58
+            float v = fmaf(s[r] + g, p.cscale, madd);                                     // temporal.py:56-62
             if (causal && k > q && k < p.T) v = PADV;
             x[r] = v;
         }
     };
     float m = -INFINITY, l = 0.f;
+#pragma unroll 2
     for (int kt = 0; kt < kt_end; ++kt) {
         float x[4]; int bk[4];
         scores(kt, x, bk);
@@ -452,6 +454,7 @@ __global__ __launch_bounds__(128) void tiattn_fwd_kernel(TaP p, TiP t) {
     f32x4 acc[DT];
 #pragma unroll
     for (int ut = 0; ut < DT; ++ut) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
     for (int kt = 0; kt < kt_end; ++kt) {
         float x[4]; int bk[4];
         scores(kt, x, bk);
@@ -490,16 +493,13 @@ __global__ __launch_bounds__(128) void tiattn_fwd_kernel(TaP p, TiP t) {
 }
 
 template <typename T, int DT>
-__global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
+__global__ __launch_bounds__(256) void tiattn_bwd_q_kernel(TaP p, TiP t) {
     extern __shared__ __attribute__((aligned(16))) char lds_c[];
     Job j;
     if (!get_job(p, j)) return;
     constexpr int dh = 16 * DT;
-    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4, LDT_ = t.NBp + 8;
-    char* base = lds_c + (size_t)(threadIdx.x >> 6) * (2 * ti_tile_t(t.NBp, sizeof(T)) + ti_tile_f(t.NBp));
-    float* dGs = reinterpret_cast<float*>(base);
-    T* Gs = reinterpret_cast<T*>(base + ti_tile_f(t.NBp));
-    T* dWs = Gs + 16 * LDT_;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15, LDG = t.NBp + 4;
+    float* dGs = reinterpret_cast<float*>(lds_c + (size_t)(threadIdx.x >> 6) * ti_tile_f(t.NBp));
     const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
     const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
     const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * dh;
@@ -515,9 +515,7 @@ __global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
     const Frag4<T> ident = identity_frag<T>(lane);
     const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
     const int kt_end = (causal && j.tile * 16 >= first_unpadded(idr, p.T, lane)) ? j.tile + 1 : p.NT;
-    bucket_project<T, DT>(Qr, Kt, t.ldt, t.tab_rows, t.NBp, Gs, lane);
-    bucket_project<T, DT>(dOr, Vt, t.ldt, t.tab_rows, t.NBp, dWs, lane);          // dA[q,k] gets dO[q].Vtime[dt(q,k)]
-    for (int i = lane; i < 16 * LDG; i += 64) dGs[i] = 0.f;
+    for (int i = lane * 4; i < 16 * LDG; i += 256) *reinterpret_cast<float4*>(dGs + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     float dsum = 0.f;
     Frag4<T> qf[DT], gf[DT];
     {
@@ -534,13 +532,10 @@ __global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
     }
     const float m = p.st_m[j.bp * p.T + qc], invl = 1.0f / p.st_l[j.bp * p.T + qc];
     wave_lds_sync();
-    if (qok) {   // the key-side kernel gathers these rows from HBM instead of projecting every query tile again
-        bucket_copy<T>(Gs, t.NBp, reinterpret_cast<T*>(t.gbuf) + (j.bp * p.T + q) * (long)t.NBp, lane);
-        bucket_copy<T>(dWs, t.NBp, reinterpret_cast<T*>(t.dwbuf) + (j.bp * p.T + q) * (long)t.NBp, lane);
-    }
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
     for (int kt = 0; kt < kt_end; ++kt) {
         const int kr = min(kt * 16 + l15, p.T - 1);
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
@@ -558,10 +553,13 @@ __global__ __launch_bounds__(128) void tiattn_bwd_q_kernel(TaP p, TiP t) {
             const int k = kt * 16 + g4 + r, kcl = min(k, p.T - 1);
             const int bk = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
             const bool pad = k >= p.T || idr[kcl] == 0, fut = causal && k > q;
-            float v = fmaf(s[r] + to_f32(Gs[l15 * LDT_ + bk]), p.cscale, k >= p.T ? -INFINITY : (pad ? PADV : 0.f));
+            const bool inb = bk < t.tab_rows;
+            const float g = inb ? dot_rows<T, DT>(Qr, tab_row<T>(Kt, t.ldt, t.tab_rows, bk)) : 0.f;
+            const float dw = inb ? dot_rows<T, DT>(dOr, tab_row<T>(Vt, t.ldt, t.tab_rows, bk)) : 0.f;   // dA[q,k] gets dO[q].Vtime[dt(q,k)]
+            float v = fmaf(s[r] + g, p.cscale, k >= p.T ? -INFINITY : (pad ? PADV : 0.f));
             if (fut && k < p.T) v = PADV;
             const float P = __expf(v - m) * invl;
-            const float dP = (dk.thresh == 0u || hb[r] >= dk.t16) ? (da[r] + to_f32(dWs[l15 * LDT_ + bk])) * dk.scale : 0.f;
+            const float dP = (dk.thresh == 0u || hb[r] >= dk.t16) ? (da[r] + dw) * dk.scale : 0.f;
             ds[r] = (pad || fut || !qok) ? 0.f : P * (dP - dsum) * p.cscale;
             atomicAdd(&dGs[l15 * LDG + bk], ds[r]);
         }
@@ -591,8 +589,8 @@ __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
     const T* Kr = reinterpret_cast<const T*>(p.kx) + ((long)j.b * p.T + kc) * p.ldk + j.head * dh;
     const T* Vr = reinterpret_cast<const T*>(p.v) + ((long)j.b * p.T + kc) * p.ldv + j.head * dh;
     const T* dOb = reinterpret_cast<const T*>(p.d_out) + (long)j.b * p.T * p.ld_do + j.head * dh;
-    const T* Gb = reinterpret_cast<const T*>(t.gbuf) + j.bp * p.T * (long)t.NBp;
-    const T* dWb = reinterpret_cast<const T*>(t.dwbuf) + j.bp * p.T * (long)t.NBp;
+    const T* Kt = reinterpret_cast<const T*>(t.ktime) + j.head * dh;
+    const T* Vt = reinterpret_cast<const T*>(t.vtime) + j.head * dh;
     const float* tsr = t.ts + (long)j.b * (p.T + 1);
     const float xk = tsr[kc] / t.time_scale;
     const bool pad = !kok || p.ids[(long)j.b * p.T + kc] == 0;
@@ -606,6 +604,7 @@ __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
     f32x4 accK[DT], accV[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { accK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 2
     for (int qt = 0; qt < p.NT; ++qt) {
         if (causal && qt < j.tile && qt * 16 >= fnp) continue;
         const int ql = min(qt * 16 + l15, p.T - 1);
@@ -620,15 +619,16 @@ __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
             s = mma16(qf[dt], kf[dt], s);
             da = mma16(gf[dt], vf[dt], da);
         }
-        // unconditional gathers first (clamped rows), consumed below
+        // interval terms of the 4 (q, k) pairs of this lane
         float gq[4], dwq[4];
         int qcs[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             qcs[r] = min(qt * 16 + g4 + r, p.T - 1);
             const int bk = bucket_of(tsr[qcs[r] + 1] / t.time_scale, xk, t.timelen);
-            gq[r] = to_f32(Gb[(long)qcs[r] * t.NBp + bk]);
-            dwq[r] = to_f32(dWb[(long)qcs[r] * t.NBp + bk]);
+            const bool inb = bk < t.tab_rows;
+            gq[r] = inb ? dot_rows<T, DT>(Qb + (long)qcs[r] * p.ldq, tab_row<T>(Kt, t.ldt, t.tab_rows, bk)) : 0.f;
+            dwq[r] = inb ? dot_rows<T, DT>(dOb + (long)qcs[r] * p.ld_do, tab_row<T>(Vt, t.ldt, t.tab_rows, bk)) : 0.f;
         }
         f32x4 a4, ds;
 #pragma unroll
@@ -944,11 +944,11 @@ int launch_ti(K kern, const TaP& p, const TiP& t, int waves, size_t wave_bytes, 
 }
 template <typename T, int DT>
 int ti_fwd(const TaP& p, const TiP& t, hipStream_t st) {
-    return launch_ti(tiattn_fwd_kernel<T, DT>, p, t, 2, ti_tile_t(t.NBp, sizeof(T)) + ti_tile_f(t.NBp), st);
+    return launch_ti(tiattn_fwd_kernel<T, DT>, p, t, 4, ti_tile_f(t.NBp), st);
 }
 template <typename T, int DT>
 int ti_bwd(const TaP& p, const TiP& t, float* d_ktime, float* d_vtime, hipStream_t st) {
-    if (int rc = launch_ti(tiattn_bwd_q_kernel<T, DT>, p, t, 2, 2 * ti_tile_t(t.NBp, sizeof(T)) + ti_tile_f(t.NBp), st)) return rc;
+    if (int rc = launch_ti(tiattn_bwd_q_kernel<T, DT>, p, t, 4, ti_tile_f(t.NBp), st)) return rc;
     if (int rc = launch_ti(tiattn_bwd_k_kernel<T, DT>, p, t, 4, 0, st)) return rc;
     const int C = p.H * 16 * DT, splits = 32;
     if (hipMemsetAsync(d_ktime, 0, (size_t)t.tab_rows * C * sizeof(float), st) != hipSuccess ||
@@ -1004,7 +1004,7 @@ extern "C" int edgl_tiattn_fwd(const void* q, int ldq, const void* k, int ldk, c
         p.st_d = reinterpret_cast<float*>((char*)saved + s.off_d);
         p.oatt = reinterpret_cast<float*>((char*)saved + s.off_o);
     }
-    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, nullptr, (timelen + 1 + 15) / 16 * 16, nullptr, nullptr};
+    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, nullptr, (timelen + 1 + 15) / 16 * 16};
     hipStream_t st = (hipStream_t)stream;
 #define EDGL_TI_FWD(TT)                                        \
     switch (dh / 16) {                                         \
@@ -1040,10 +1040,7 @@ extern "C" int edgl_tiattn_bwd(const void* q, int ldq, const void* k, int ldk, c
     p.st_l = reinterpret_cast<float*>((char*)saved + s.off_l);
     p.st_d = reinterpret_cast<float*>((char*)saved + s.off_d);
     p.oatt = reinterpret_cast<float*>((char*)saved + s.off_o);
-    const int NBp = (timelen + 1 + 15) / 16 * 16;
-    const size_t bucket_bytes = (size_t)B * T * H * NBp * (dtype == EDGL_BF16 ? 2 : 4);   // dgbuf = [dG | G | dO.Vtime^T]
-    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, dgbuf, NBp, (char*)dgbuf + bucket_bytes,
-          (char*)dgbuf + 2 * bucket_bytes};
+    TiP t{ts, time_scale, timelen, ktime, vtime, H * dh, tab_rows, wbuf, dgbuf, (timelen + 1 + 15) / 16 * 16};
     hipStream_t st = (hipStream_t)stream;
 #define EDGL_TI_BWD(TT)                                                        \
     switch (dh / 16) {                                                         \

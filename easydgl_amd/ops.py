@@ -682,7 +682,7 @@ class TiAttnFn(torch.autograd.Function):
         d_out = d_out.contiguous()
         code = _code(q)
         d_q, d_kv = torch.empty_like(q), torch.empty_like(kvp)
-        dgbuf = torch.empty(3 * wbuf.numel(), device=q.device, dtype=q.dtype)   # dG | Q.Ktime^T | dO.Vtime^T rows
+        dgbuf = torch.empty_like(wbuf)   # binned score gradients
         d_kt = torch.empty((rows, C), device=q.device, dtype=torch.float32)
         d_vt = torch.empty_like(d_kt)
         check(lib.edgl_tiattn_bwd(_ptr(q), C, _ptr(kvp), 2 * C, _vptr(kvp[:, :, C:]), 2 * C, _ptr(ids), _ptr(ts), _ptr(ktime_c),

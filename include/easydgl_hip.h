@@ -347,8 +347,8 @@ int edgl_mask_rows(const void* x, const int64_t* ids, void* y, long rows, int C,
  * vtime[bucket]) + resid.  The query mask of temporal.py:84-88 is the identity for LayerNorm-ed queries and is not
  * applied.  saved: edgl_tattn_saved_bytes(B,T,H,dh) bytes; wbuf: edgl_tiattn_bucket_elems elements of `dtype` (binned
  * probabilities, read by the backward); both NULL for inference.  timelen <= 256.
- * edgl_tiattn_bwd: d_q, d_k, d_v; d_ktime, d_vtime f32 [tab_rows, H*dh] (overwritten); dgbuf: workspace of 3 x
- * edgl_tiattn_bucket_elems elements of `dtype` (binned score gradients and the two row projections the key-side kernel reads). */
+ * edgl_tiattn_bwd: d_q, d_k, d_v; d_ktime, d_vtime f32 [tab_rows, H*dh] (overwritten); dgbuf: workspace like wbuf
+ * (binned score gradients). */
 long edgl_tiattn_bucket_elems(int B, int T, int H, int timelen);
 int edgl_tiattn_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* resid, int ldr,
                     const int64_t* ids, const float* ts, const void* ktime, const void* vtime, int tab_rows, int B, int T,
