@@ -70,6 +70,7 @@ SIGNATURES = {
     "edgl_add": (I, [P, P, P, L, I, P]),
     "edgl_add_cols": (I, [P, I, P, P, I, L, I, I, P]),
     "edgl_dropout": (I, [P, P, L, F, P, U32, I, P]),
+    "edgl_ff_tail": (I, [P, P, P, L, I, F, P, U32, P, I, P]),
     "edgl_relu_bwd": (I, [P, P, P, L, I, P]),
     "edgl_gelu_bwd": (I, [P, P, P, L, I, P]),
     "edgl_tattn_saved_bytes": (L, [I, I, I, I]),

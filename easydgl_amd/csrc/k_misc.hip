@@ -472,6 +472,40 @@ extern "C" int edgl_dropout(const void* x, void* y, long n, float drop_rate, con
     return EDGL_OK;
 }
 
+// FeedForward tail (Base.py:83-86 followed by `*= seqs_masks`, TGAT.py:70): out = (dropout(a) + b) * (ids != 0), 4 elements
+// per thread; b and ids optional.  With b == NULL it is also the backward of the `a` branch (mask and dropout commute).
+template <typename T>
+__global__ __launch_bounds__(256) void ff_tail_kernel(const T* a, const T* b, const int64_t* ids, long rows, int C, T* out,
+                                                      const uint64_t* rng, uint32_t stream_id, float rate) {
+    const DropKey dk = make_dropkey(rng, stream_id, rate);
+    const int cpr = C >> 2;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < rows * cpr; g += (long)gridDim.x * blockDim.x) {
+        const long row = g / cpr;
+        const long e0 = g * 4;
+        const Frag4<T> av = frag_ld<T>(a + e0);
+        const Frag4<T> bv = b ? frag_ld<T>(b + e0) : frag_zero<T>();
+        const float m = (!ids || ids[row] != 0) ? 1.f : 0.f;
+        Frag4<T> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.v[j] = from_f32<T>((drop_apply(dk, (uint64_t)(e0 + j), to_f32(av.v[j])) + to_f32(bv.v[j])) * m);
+        if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(out + e0) = *reinterpret_cast<uint4*>(&o);
+        else *reinterpret_cast<uint2*>(out + e0) = *reinterpret_cast<uint2*>(&o);
+    }
+}
+
+extern "C" int edgl_ff_tail(const void* a, const void* b, const int64_t* ids, long rows, int C, float drop_rate,
+                            const uint64_t* rng_state, uint32_t stream_id, void* out, int dtype, void* stream) {
+    EDGL_REQUIRE(a && out && (drop_rate == 0.f || rng_state), EDGL_ERR_NULL, "edgl_ff_tail: null pointer");
+    EDGL_REQUIRE(rows > 0 && C > 0 && C % 4 == 0, EDGL_ERR_SHAPE, "edgl_ff_tail: bad shape rows=%ld C=%d", rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(rows * (C / 4)));
+    if (dtype == EDGL_BF16) hipLaunchKernelGGL((ff_tail_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)a, (const bf16*)b, ids, rows, C, (bf16*)out, rng_state, stream_id, drop_rate);
+    else if (dtype == EDGL_F32) hipLaunchKernelGGL((ff_tail_kernel<float>), grid, dim3(256), 0, st, (const float*)a, (const float*)b, ids, rows, C, (float*)out, rng_state, stream_id, drop_rate);
+    else { edgl_set_error("edgl_ff_tail: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
 extern "C" int edgl_relu_bwd(const void* dy, const void* y, void* dz, long n, int dtype, void* stream) {
     EDGL_REQUIRE(dy && y && dz, EDGL_ERR_NULL, "edgl_relu_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;

@@ -105,9 +105,7 @@ class CTSMA(Sequential):
             if is_training and hd > 0.0:   # Base.py:80: dropout(inner) — an identity LayerNorm-free path: a scaled copy
                 inner = ops.dropout(inner, self._drop(hd, 11 + 4 * i, True))
             out = self._linear(inner, blk.ff.readout)                                                            # Base.py:82
-            if is_training and hd > 0.0:
-                out = ops.dropout(out, self._drop(hd, 12 + 4 * i, True))                                         # Base.py:83
-            x = ops.add(out, y)                                                                                  # Base.py:86
+            x = ops.ff_tail(out, y, None, self._drop(hd, 12 + 4 * i, is_training))                               # Base.py:83-86
             lams.append(lam)
         rows = ops.AddLayerNormFn.apply(x, None, self.out_ln.gamma, self.out_ln.beta, ops.NO_DROP, gather_pos)   # :82-83
         return rows, lams

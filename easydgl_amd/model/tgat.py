@@ -98,9 +98,7 @@ class TGAT(Sequential):
             if is_training and hd > 0.0:
                 inner = ops.dropout(inner, self._drop(hd, 11 + 4 * i, True))                                      # Base.py:80
             out = self._linear(inner, blk.ff.readout)                                                             # Base.py:82
-            if is_training and hd > 0.0:
-                out = ops.dropout(out, self._drop(hd, 12 + 4 * i, True))                                          # Base.py:83
-            x = ops.mask_rows(ops.add(out, y), ids)                                                               # Base.py:86, TGAT.py:70
+            x = ops.ff_tail(out, y, ids, self._drop(hd, 12 + 4 * i, is_training))                                 # Base.py:83-86, TGAT.py:70
         return ops.AddLayerNormFn.apply(x, None, self.out_ln.gamma, self.out_ln.beta, ops.NO_DROP, gather_pos)    # :72-73
 
     def forward(self, features: Dict[str, torch.Tensor], is_training: bool):

@@ -696,3 +696,38 @@ class TiAttnFn(torch.autograd.Function):
         d_pk[:T] = d_pos[:, :C]
         d_pv[:T] = d_pos[:, C:]
         return d_q, d_kv, d_out, d_pk, d_pv, d_kt, d_vt, None, None, None, None, None, None, None, None
+
+
+
+class FFTailFn(torch.autograd.Function):
+    """FeedForward tail: (dropout(a) + b) * (ids != 0) in one kernel (edgl_ff_tail); ids None = no row mask."""
+
+    @staticmethod
+    def forward(ctx, a, b, ids, drop: Drop):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        C = a.shape[-1]
+        rows = a.numel() // C
+        check(lib.edgl_ff_tail(_ptr(a), _ptr(b), _ptr(ids), rows, C, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(out),
+                               _code(a), _stream()), "edgl_ff_tail")
+        ctx.ids, ctx.drop, ctx.meta = ids, drop, (rows, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        rows, C = ctx.meta
+        d, ids = ctx.drop, ctx.ids
+        da = torch.empty_like(g)
+        check(lib.edgl_ff_tail(_ptr(g), None, _ptr(ids), rows, C, float(d.rate), d.ptr(), d.stream_id, _ptr(da), _code(g),
+                               _stream()), "edgl_ff_tail")
+        if ids is None:
+            db = g
+        else:
+            db = torch.empty_like(g)
+            check(lib.edgl_mask_rows(_ptr(g), _ptr(ids), _ptr(db), rows, C, _code(g), _stream()), "edgl_mask_rows")
+        return da, db, None, None
+
+
+def ff_tail(a, b, ids, drop: Drop):
+    return FFTailFn.apply(a, b, ids, drop)

@@ -290,6 +290,12 @@ int edgl_add(const void* a, const void* b, void* out, long n, int dtype, void* s
  * (Base.py:80,83); calling it on dy with the same arguments is the backward. */
 int edgl_dropout(const void* x, void* y, long n, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, int dtype,
                  void* stream);
+/* FeedForward tail in one pass (Base.py:83-86, then `seqs_outs *= seqs_masks`, TGAT.py:70 / TiSASREC.py:73):
+ * out[r,:] = (dropout(a[r,:]) + b[r,:]) * (ids[r] != 0); b and ids may be NULL (no residual / no row mask).  The dropout
+ * mask is the one edgl_dropout draws for the same (rng_state, stream_id, element index).  Backward of the `a` branch:
+ * the same call on the upstream gradient with b == NULL; of the `b` branch: edgl_mask_rows. */
+int edgl_ff_tail(const void* a, const void* b, const int64_t* ids, long rows, int C, float drop_rate,
+                 const uint64_t* rng_state, uint32_t stream_id, void* out, int dtype, void* stream);
 int edgl_relu_bwd(const void* dy, const void* y, void* dz, long n, int dtype, void* stream);   /* dz = dy*[y>0] (Base.py:73) */
 int edgl_gelu_bwd(const void* dy, const void* pre, void* dz, long n, int dtype, void* stream); /* dz = dy*gelu'(pre), EasyDGL.py:19-32 */
 int edgl_add_cols(void* dst, int ld_dst, const void* src, const void* src2, int ld_src, long rows, int ncols,

@@ -525,3 +525,36 @@ def test_dropout_is_consistent_between_forward_and_backward():
     # gradient w.r.t. x is exactly zero where the element was dropped; keep-rate ~ 0.75
     zero_frac = float((x.grad == 0).float().mean())
     assert abs(zero_frac - 0.25) < 0.02
+
+
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+@pytest.mark.parametrize("masked", [False, True])
+def test_ff_tail_equals_dropout_add_mask(name, dt, tol, masked):
+    """edgl_ff_tail == edgl_dropout -> edgl_add -> edgl_mask_rows with the same counter-based mask, forward and backward."""
+    o = ops()
+    rng = np.random.default_rng(3)
+    B, T, C = 5, 13, 32
+    a0, b0 = torch.tensor(_rand((B, T, C), rng), dtype=dt).cuda(), torch.tensor(_rand((B, T, C), rng), dtype=dt).cuda()
+    ids = torch.tensor(rng.integers(0, 3, size=(B, T))).cuda() if masked else None
+    state = torch.tensor([11, 4], dtype=torch.int64, device="cuda")
+    drop = o.Drop(0.3, state, 9)
+    g = torch.tensor(_rand((B, T, C), rng), dtype=dt).cuda()
+    outs = []
+    for fused in (True, False):
+        a, b = a0.clone().requires_grad_(), b0.clone().requires_grad_()
+        if fused:
+            y = o.ff_tail(a, b, ids, drop)
+        else:
+            y = o.add(o.dropout(a, drop), b)
+            if masked:
+                y = o.mask_rows(y, ids)
+        y.backward(g)
+        outs.append((y.detach(), a.grad, b.grad))
+    for u, v in zip(*outs):
+        # same mask (zero pattern); values agree to one rounding: the fused kernel contracts x*scale + b into one fma and, in
+        # bf16, rounds once where the unfused chain rounds after the dropout and again after the add
+        assert torch.equal(u == 0, v == 0)
+        assert_close(u.float().cpu().numpy(), v.float().cpu().numpy(), 1e-6 if name == "f32" else 1e-2, "fused vs unfused")
+    if masked:
+        assert float((outs[0][0] == 0).float().mean()) > 0.3      # a third of the rows carries id 0
+    assert float((outs[0][1] == 0).float().mean()) > 0.2          # the dropout zeroes ~30 % of d_a
