@@ -457,7 +457,16 @@ extern "C" int edgl_add_cols(void* dst, int ld_dst, const void* src, const void*
 template <typename T>
 __global__ void dropout_state_kernel(const T* x, T* y, long n, const uint64_t* rng, uint32_t stream_id, float rate) {
     const DropKey dk = make_dropkey(rng, stream_id, rate);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    const long n4 = n >> 2;   // 4 elements per thread; the mask depends on the element index only
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (long)gridDim.x * blockDim.x) {
+        const Frag4<T> v = frag_ld<T>(x + g * 4);
+        Frag4<T> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.v[j] = from_f32<T>(drop_apply(dk, (uint64_t)(g * 4 + j), to_f32(v.v[j])));
+        if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(y + g * 4) = *reinterpret_cast<uint4*>(&o);
+        else *reinterpret_cast<uint2*>(y + g * 4) = *reinterpret_cast<uint2*>(&o);
+    }
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         y[i] = from_f32<T>(drop_apply(dk, (uint64_t)i, to_f32(x[i])));
 }
 
@@ -465,8 +474,10 @@ extern "C" int edgl_dropout(const void* x, void* y, long n, float drop_rate, con
                             int dtype, void* stream) {
     EDGL_REQUIRE(x && y && (drop_rate == 0.f || rng_state), EDGL_ERR_NULL, "edgl_dropout: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == EDGL_BF16) hipLaunchKernelGGL((dropout_state_kernel<bf16>), dim3(grid_for(n)), dim3(256), 0, st, (const bf16*)x, (bf16*)y, n, rng_state, stream_id, drop_rate);
-    else if (dtype == EDGL_F32) hipLaunchKernelGGL((dropout_state_kernel<float>), dim3(grid_for(n)), dim3(256), 0, st, (const float*)x, (float*)y, n, rng_state, stream_id, drop_rate);
+    EDGL_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, EDGL_ERR_SHAPE, "edgl_dropout: buffers must be 16-byte aligned");
+    const dim3 grid(grid_for((n + 3) / 4));
+    if (dtype == EDGL_BF16) hipLaunchKernelGGL((dropout_state_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)x, (bf16*)y, n, rng_state, stream_id, drop_rate);
+    else if (dtype == EDGL_F32) hipLaunchKernelGGL((dropout_state_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (float*)y, n, rng_state, stream_id, drop_rate);
     else { edgl_set_error("edgl_dropout: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
