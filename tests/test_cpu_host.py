@@ -101,3 +101,16 @@ def test_graft_entry_build():
     import __graft_entry__ as g
     g.build()
     assert os.path.exists(os.path.join(ROOT, "easydgl_amd", "libeasydgl_hip.so"))
+
+
+def test_bench_flop_model_matches_the_survey_numbers():
+    """179.9 MFLOP per sequence forward at the headline configuration (M = 20), 108.2 at M = 6; x3 for fwd+bwd."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f20 = bench.flops_per_seq(bench.HEADLINE)
+    f6 = bench.flops_per_seq(dict(bench.HEADLINE, masklen=6))
+    assert abs(f20 / 1e6 - 179.9) < 0.2 and abs(f6 / 1e6 - 108.2) < 0.2
+    assert abs(3 * f20 * 512 / 1e9 - 276.3) < 0.5
