@@ -1108,7 +1108,8 @@ extern "C" int edgl_timefn_bwd(const void* q, int ldq, const float* ts, const fl
     if (dtype == EDGL_F32) hipLaunchKernelGGL((timefn_bwd_kernel<float>), dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((timefn_bwd_kernel<bf16>), dim3(blocks), dim3(256), 0, st, p);
     EDGL_LAUNCH_CHECK();
-    // partial rows are [d_omega | d_phi]: one fixed-order reduction each
+    // partial rows are [d_omega | d_phi]: one fixed-order reduction (adjacent outputs) or one each
+    if (d_phi == d_omega + C) return edgl_reduce_rows(workspace, blocks, 2 * C, 2L * C, d_omega, 0, st);
     if (int rc = edgl_reduce_rows(workspace, blocks, C, 2L * C, d_omega, 0, st)) return rc;
     return edgl_reduce_rows(workspace + C, blocks, C, 2L * C, d_phi, 0, st);
 }

@@ -8,6 +8,7 @@ import math
 from dataclasses import dataclass
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -104,8 +105,9 @@ def cast_to(src_f32: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tenso
 
 def dense_grads(x2, dz, M, K, N):
     code = _code(x2)
-    dw = torch.empty((K, N), device=x2.device, dtype=torch.float32)
-    db = torch.empty(N, device=x2.device, dtype=torch.float32)
+    # (dW, db) in one buffer, as they sit in the flat gradient arena: the library then reduces both with one launch
+    both = torch.empty((K + 1) * N, device=x2.device, dtype=torch.float32)
+    dw, db = both[:K * N].view(K, N), both[K * N:]
     ws = torch.empty(lib.edgl_gemm_dw_workspace(M, K, N, code), device=x2.device, dtype=torch.float32)
     check(lib.edgl_gemm_dw(_ptr(x2), _ptr(dz), _ptr(dw), _ptr(db), M, K, N, x2.stride(0), dz.stride(0), 0, _ptr(ws), code,
                            _stream()), "edgl_gemm_dw")
@@ -265,10 +267,11 @@ class BiMAUFn(torch.autograd.Function):
         d_out = d_out.contiguous()
         dev = d_out.device
         d_qkvt = torch.empty_like(qkvt)
-        dW1 = torch.empty(s1, device=dev, dtype=torch.float32)
-        db1 = torch.empty(s2, device=dev, dtype=torch.float32)
-        dw = torch.empty(s3, device=dev, dtype=torch.float32)
-        dsc = torch.empty(s4, device=dev, dtype=torch.float32)
+        # dW1 | db1 | dw | dscaling in one buffer (the flat-arena order): the library reduces all four with one launch
+        n1, n2, n3, n4 = (int(np.prod(sh)) for sh in (s1, s2, s3, s4))
+        both = torch.empty(n1 + n2 + n3 + n4, device=dev, dtype=torch.float32)
+        dW1, db1 = both[:n1].view(s1), both[n1:n1 + n2].view(s2)
+        dw, dsc = both[n1 + n2:n1 + n2 + n3].view(s3), both[n1 + n2 + n3:].view(s4)
         ws = torch.empty(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), device=dev, dtype=torch.uint8)
         dl = d_lam.contiguous() if d_lam is not None else None
         check(lib.edgl_bimau_bwd(_ptr(qkvt), _ptr(ids), _ptr(spans), _ptr(marks), _ptr(pack), _ptr(d_out), _ptr(dl),
@@ -310,8 +313,8 @@ class AddLayerNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         dsum = torch.empty_like(x)
         dxd = torch.empty_like(x) if drop.active else None
-        dg = torch.empty(C, device=x.device, dtype=torch.float32)
-        db = torch.empty(C, device=x.device, dtype=torch.float32)
+        both = torch.empty(2 * C, device=x.device, dtype=torch.float32)   # dbeta | dgamma adjacent: one reduction launch
+        db, dg = both[:C], both[C:]
         ws = torch.empty(B * 2 * C, device=x.device, dtype=torch.float32)
         rptr, ld = (None, 0) if resid is None else (resid.data_ptr(), resid.stride(1))
         check(lib.edgl_add_layernorm_bwd(_ptr(x), rptr, ld, _ptr(gamma), _ptr(stats), _ptr(dy), B, T, C,
@@ -632,8 +635,8 @@ class TfAttnFn(torch.autograd.Function):
                                  B, T, H, 3 * dh, dh, scale, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(d_qx), 3 * C,
                                  _ptr(d_kx), 3 * C, _vptr(d_kv[:, :, C:]), 2 * C, _lib.TATTN_CAUSAL, code, _stream()), "edgl_tattn_bwd")
         d_q = torch.empty_like(q)
-        d_omega = torch.empty(C, device=q.device, dtype=torch.float32)
-        d_phi = torch.empty_like(d_omega)
+        both = torch.empty(2 * C, device=q.device, dtype=torch.float32)   # d_omega | d_phi adjacent: one reduction launch
+        d_omega, d_phi = both[:C], both[C:]
         ws = torch.empty(int(lib.edgl_timefn_bwd_workspace(C)), device=q.device, dtype=torch.float32)
         check(lib.edgl_timefn_bwd(_ptr(q), C, _ptr(ts), _ptr(omega), _ptr(phi), _ptr(d_qx), _ptr(d_kx), B, T, C, H, time_scale,
                                   _ptr(d_q), C, _ptr(d_kv), 2 * C, _ptr(d_omega), _ptr(d_phi), _ptr(ws), code, _stream()),
