@@ -156,6 +156,10 @@ def encode_bench(args):
     bytes_f = B * T * (8 + 4) + B * T * C * s + B * T * 3 * C * s + B * T * (4 + E) + T * C * 4 + E * C * 4
     rows_touched = int((ids != 0).sum().item())
     bytes_b = B * T * 3 * C * s + B * T * (8 + E) + rows_touched * C * 4 * 2 + T * C * 4 + E * C * 4
+    enc_traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/profile_encode.sh), read side x1
+    tpath = os.path.join(ROOT, "profiles", "r01_encode_hbm.json")
+    if args.dtype == "bf16" and os.path.exists(tpath):
+        enc_traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_1x_read")
     out = {"metric": "GB/s (K1 input encoding forward, |items|=1M L=200 d=256 B=512)", "value": round(bytes_f / t_f / 1e9, 1),
            "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_f * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -163,7 +167,7 @@ def encode_bench(args):
                                   "config 3: num_items 1000000, seqslen 200 (T=201), num_units 256, batch 512, 16 marks",
                       "algorithmic_bytes_fwd": bytes_f, "algorithmic_bytes_bwd": bytes_b},
            "roofline": {"bound": "hbm", "kernel": "encode_fwd_kernel", "achieved": round(bytes_f / t_f / 1e9, 1), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(bytes_f / t_f / 8e12, 4), "traffic": None},
+                        "unit": "GB/s", "frac": round(bytes_f / t_f / 8e12, 4), "traffic": enc_traffic},
            "backward": {"ms": round(t_b * 1e3, 4), "achieved_GBps": round(bytes_b / t_b / 1e9, 1),
                         "note": "encode_bwd + scatter into the touched rows of the [I, C] f32 table gradient (memset of the "
                                 "full table gradient excluded from the byte count, included in the time)"}}
