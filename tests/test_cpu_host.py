@@ -34,6 +34,21 @@ def test_abi_argument_validation_without_gpu():
     rc = _lib.lib.edgl_bimau_pack(None, None, None, None, 128, 8, 16, None, 0, None)
     assert rc == -4
     assert _lib.lib.edgl_bimau_bwd_workspace(4, 11, 32, 3, 4, 0) == -1   # C % H != 0
+    # the attention entry points of the TGAT / TiSASRec path: nulls, head dims, interval table limits
+    L, one = _lib.lib, 1   # `one`: any non-null address — the checks below fail before a pointer is dereferenced
+    rc = L.edgl_tattn_fwd(None, 48, None, 48, None, 16, None, 16, None, 2, 8, 1, 48, 16, 0.25, 0.0, None, 0, None, 16, None, 1, 0, None)
+    assert rc == -4 and b"null" in L.edgl_last_error()
+    rc = L.edgl_tattn_fwd(one, 40, one, 40, one, 16, one, 16, one, 2, 8, 1, 40, 16, 0.25, 0.0, None, 0, one, 16, None, 1, 0, None)
+    assert rc == -1 and b"multiples of 16" in L.edgl_last_error()                      # Dq = 40
+    rc = L.edgl_tattn_fwd(one, 48, one, 48, one, 16, one, 16, one, 2, 8, 1, 48, 16, 0.25, 0.5, None, 0, one, 16, None, 1, 0, None)
+    assert rc == -4 and b"rng_state" in L.edgl_last_error()                            # dropout without a generator state
+    rc = L.edgl_tattn_fwd(one, 48, one, 48, one, 16, one, 16, one, 2, 8, 1, 48, 16, 0.25, 0.0, None, 0, one, 16, None, 1, 7, None)
+    assert rc == -2                                                                    # dtype code 7
+    rc = L.edgl_tiattn_fwd(one, 32, one, 64, one, 64, one, 32, one, one, one, one, 300, 2, 8, 2, 16, 0.25, 1.0, 300, 0.0, None, 0,
+                           one, 32, None, None, 1, 0, None)
+    assert rc == -1 and b"timelen" in L.edgl_last_error()                              # timelen > 256
+    assert L.edgl_tattn_saved_bytes(2, 8, 1, 16) > 0 and L.edgl_tattn_saved_bytes(0, 8, 1, 16) == -1
+    assert L.edgl_tiattn_bucket_elems(2, 8, 2, 256) == 2 * 8 * 2 * 272
 
 
 def test_ops_refuse_cpu_tensors():
