@@ -73,7 +73,8 @@ def _operands(seed, B, T, H, Dq, Dv, dtype):
 
 @pytest.mark.parametrize("dtype,ftol,gtol", [(torch.float32, 1e-4, 1e-3), (torch.bfloat16, 3e-2, 1e-1)])
 @pytest.mark.parametrize("B,T,H,Dq,Dv", [(3, 12, 2, 16, 16), (2, 37, 2, 48, 16), (2, 100, 1, 384, 128), (2, 50, 8, 48, 16),
-                                         (2, 33, 2, 96, 32), (1, 201, 2, 64, 64)])
+                                         (2, 33, 2, 96, 32), (1, 201, 2, 64, 64),
+                                         (1, 1, 1, 16, 16), (2, 16, 2, 32, 32), (2, 17, 1, 192, 64)])   # edges: one key, tile-exact, tile + 1
 def test_tattn_forward_and_backward_match_float64(dtype, ftol, gtol, B, T, H, Dq, Dv):
     qx, kx, v, resid, d_out, ids = _operands(B * T + Dq, B, T, H, Dq, Dv, dtype)
     scale = 1.0 / np.sqrt(Dv)
