@@ -439,40 +439,50 @@ __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
             x[r] = v;
         }
     };
+    // pass 1: scores of every key tile, kept in registers for pass 2 (LDS, not registers, bounds the occupancy here, and the
+    // second pass would otherwise repeat the S MFMA and the dependent timestamp -> bucket -> table-row loads of each pair)
+    constexpr int NTM = 16;                   // T <= 256 (host-checked)
+    float xs[NTM][4];
     float m = -INFINITY, l = 0.f;
-#pragma unroll 2
-    for (int kt = 0; kt < kt_end; ++kt) {
-        float x[4]; int bk[4];
-        scores(kt, x, bk);
-        const float tmax = group_max4(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
-        const float m_new = fmaxf(m, tmax);
-        const float ps = __expf(x[0] - m_new) + __expf(x[1] - m_new) + __expf(x[2] - m_new) + __expf(x[3] - m_new);
-        l = l * __expf(m - m_new) + group_sum4(ps);
-        m = m_new;
+#pragma unroll
+    for (int kt = 0; kt < NTM; ++kt) {
+        if (kt < kt_end) {
+            float x[4]; int bk[4];
+            scores(kt, x, bk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xs[kt][r] = x[r];
+            const float tmax = group_max4(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+            const float m_new = fmaxf(m, tmax);
+            const float ps = __expf(x[0] - m_new) + __expf(x[1] - m_new) + __expf(x[2] - m_new) + __expf(x[3] - m_new);
+            l = l * __expf(m - m_new) + group_sum4(ps);
+            m = m_new;
+        }
     }
     const float invl = 1.0f / l;
     f32x4 acc[DT];
 #pragma unroll
     for (int ut = 0; ut < DT; ++ut) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int kt = 0; kt < kt_end; ++kt) {
-        float x[4]; int bk[4];
-        scores(kt, x, bk);
-        const int kr = min(kt * 16 + l15, p.T - 1);
-        uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
-        if (dk.thresh != 0u) { h0 = drop_hash_pair(dk, dbase + kt * 16 + g4); h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2); }
-        const uint32_t hb[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
-        f32x4 a4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float P = __expf(x[r] - m) * invl;
-            a4[r] = (dk.thresh == 0u || hb[r] >= dk.t16) ? P * dk.scale : 0.f;            // temporal.py:90
-            atomicAdd(&Ws[l15 * LDG + bk[r]], a4[r]);
+    for (int kt = 0; kt < NTM; ++kt) {
+        if (kt < kt_end) {
+            const int kr = min(kt * 16 + l15, p.T - 1);
+            uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
+            if (dk.thresh != 0u) { h0 = drop_hash_pair(dk, dbase + kt * 16 + g4); h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2); }
+            const uint32_t hb[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+            f32x4 a4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kcl = min(kt * 16 + g4 + r, p.T - 1);
+                const int bk = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
+                const float P = __expf(xs[kt][r] - m) * invl;
+                a4[r] = (dk.thresh == 0u || hb[r] >= dk.t16) ? P * dk.scale : 0.f;            // temporal.py:90
+                atomicAdd(&Ws[l15 * LDG + bk], a4[r]);
+            }
+            const Frag4<T> pf = frag_from_acc<T>(a4);
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut)
+                acc[ut] = mma16(turn<T>(frag_ld<T>(Vb + (long)kr * p.ldv + ut * 16 + g4), ident), pf, acc[ut]);   // :93-94
         }
-        const Frag4<T> pf = frag_from_acc<T>(a4);
-#pragma unroll
-        for (int ut = 0; ut < DT; ++ut)
-            acc[ut] = mma16(turn<T>(frag_ld<T>(Vb + (long)kr * p.ldv + ut * 16 + g4), ident), pf, acc[ut]);   // :93-94
     }
     wave_lds_sync();
     bucket_apply<T, DT>(Ws, LDG, Vt, t.ldt, t.tab_rows, t.NBp, ident, acc, lane);                               // :95
@@ -971,6 +981,7 @@ int ti_check(const char* who, int B, int T, int H, int dh, int timelen, int tab_
                  "%s: bad shape B=%d T=%d H=%d head dim %d (16, 32, 64 or 128)", who, B, T, H, dh);
     EDGL_REQUIRE(timelen >= 1 && timelen <= 256 && tab_rows >= 1 && tab_rows <= timelen + 1, EDGL_ERR_SHAPE,
                  "%s: timelen %d (1..256) / table rows %d not supported", who, timelen, tab_rows);
+    EDGL_REQUIRE(T <= 256, EDGL_ERR_SHAPE, "%s: T=%d not supported (T <= 256: 16 key tiles are kept in registers)", who, T);
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
     EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "%s: H*B*T*T must be < 2^32", who);
     return EDGL_OK;

@@ -351,7 +351,7 @@ int edgl_mask_rows(const void* x, const int64_t* ids, void* y, long rows, int C,
  * >= tab_rows reads a zero row (the GPU embedding lookup of the reference for the index `timelen` of a [timelen, C]
  * table).  S[q,k] = scale * (q.k + q.ktime[bucket]); masks and softmax as edgl_tattn_fwd; out = dropout(P) . (v +
  * vtime[bucket]) + resid.  The query mask of temporal.py:84-88 is the identity for LayerNorm-ed queries and is not
- * applied.  saved: edgl_tattn_saved_bytes(B,T,H,dh) bytes; wbuf: edgl_tiattn_bucket_elems elements of `dtype` (binned
+ * applied.  T <= 256.  saved: edgl_tattn_saved_bytes(B,T,H,dh) bytes; wbuf: edgl_tiattn_bucket_elems elements of `dtype` (binned
  * probabilities, read by the backward); both NULL for inference.  timelen <= 256.
  * edgl_tiattn_bwd: d_q, d_k, d_v; d_ktime, d_vtime f32 [tab_rows, H*dh] (overwritten); dgbuf: workspace like wbuf
  * (binned score gradients). */
