@@ -64,3 +64,27 @@ def test_driver_end_to_end_from_tfrecords(tmp_path, model_name):
     assert set(res) == {"H10", "H50", "H100", "N10", "N50", "N100"}
     assert all(0.0 <= v <= 1.0 and math.isfinite(v) for v in res.values())
     assert res["H10"] <= res["H50"] <= res["H100"]
+
+
+@pytest.mark.gpu
+def test_checkpoint_round_trip_resumes_the_same_trajectory(tmp_path):
+    """save_checkpoint / load_checkpoint: parameters, Adam moments, step count and the dropout generator state — a restored
+    model takes exactly the next step the original takes."""
+    import torch
+    from easydgl_amd import train as TR
+    from tests._util import build_model, make_problem, to_dev
+    prob = make_problem(seed=4, batch=8)
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    m1 = build_model(prob, "bf16", hidden_drop=0.1, att_drop=0.1)
+    for _ in range(3):
+        m1.train_step(feats, labels)
+    path = str(tmp_path / "ck" / "m.pt")
+    TR.save_checkpoint(m1, path)
+    m2 = build_model(prob, "bf16", hidden_drop=0.1, att_drop=0.1)     # fresh weights, then restored
+    TR.load_checkpoint(m2, path)
+    assert torch.equal(m1._arena, m2._arena) and torch.equal(m1._adam_state, m2._adam_state)
+    l1, l2 = float(m1.train_step(feats, labels)), float(m2.train_step(feats, labels))
+    assert l1 == l2 and torch.equal(m1._arena, m2._arena)
+    bad = make_problem(seed=4, batch=8, num_units=64)
+    with pytest.raises(ValueError):
+        TR.load_checkpoint(build_model(bad, "bf16"), path)            # a different parameter layout is refused
