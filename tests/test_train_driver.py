@@ -84,7 +84,8 @@ def test_checkpoint_round_trip_resumes_the_same_trajectory(tmp_path):
     TR.load_checkpoint(m2, path)
     assert torch.equal(m1._arena, m2._arena) and torch.equal(m1._adam_state, m2._adam_state)
     l1, l2 = float(m1.train_step(feats, labels)), float(m2.train_step(feats, labels))
-    assert l1 == l2 and torch.equal(m1._arena, m2._arena)
+    # same dropout masks and moments; only the order of the f32 atomics of the embedding scatter may differ between the two runs
+    assert abs(l1 - l2) <= 1e-6 * abs(l1) and float((m1._arena - m2._arena).abs().max()) <= 1e-6
     bad = make_problem(seed=4, batch=8, num_units=64)
     with pytest.raises(ValueError):
         TR.load_checkpoint(build_model(bad, "bf16"), path)            # a different parameter layout is refused
