@@ -54,6 +54,7 @@ class Sequential(nn.Module):
             p.data = view
             p.grad = grad[offs[n]:offs[n] + p.numel()].view(p.shape)
         self._arena, self._grad_arena, self._offsets, self._order = arena, grad, offs, order
+        self._plist = [(params[n], params[n].grad) for n in order]   # (parameter, its view of the gradient arena)
         self._adam_m = torch.zeros_like(arena)
         self._adam_v = torch.zeros_like(arena)
         self._adam_state = torch.zeros(2, device=device, dtype=torch.int64)
@@ -87,6 +88,26 @@ class Sequential(nn.Module):
 
     def zero_grad_arena(self) -> None:
         self._grad_arena.zero_()
+
+    def detach_grads(self) -> None:
+        """Before an autograd backward of a training step: with `.grad` unset autograd hands every parameter the gradient tensor
+        an op produced instead of launching one `+=` kernel per parameter into the arena views."""
+        for p, _ in self._plist:
+            p.grad = None
+
+    def collect_grads(self) -> None:
+        """After that backward: copy the gradients into the flat arena with ONE multi-tensor launch and restore the views."""
+        src, dst = [], []
+        for p, view in self._plist:
+            g = p.grad
+            if g is None:
+                view.zero_()
+            else:
+                src.append(g)
+                dst.append(view)
+            p.grad = view
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def optimizer_step(self) -> None:
         """tf.train.AdamOptimizer(lr).minimize (Base.py:142-144) fused over the arena.  The l2 gradient is

@@ -176,9 +176,10 @@ class EasyDGL(Sequential):
     def train_step(self, features, labels):
         """One optimizer step: forward, backward, TF-Adam.  Returns the loss tensor (device scalar)."""
         ops.rng_advance(self._rng_state)
-        self.zero_grad_arena()
+        self.detach_grads()
         loss = self.train_loss(features, labels)
         loss.backward()
+        self.collect_grads()
         self.optimizer_step()
         return loss.detach()
 
