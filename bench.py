@@ -196,8 +196,14 @@ def baseline_model_bench(args):
     tok, tim = torch.tensor(ids_np, device=dev), torch.tensor(ts_np, device=dev)
     feats, labels = {"seqs_i": tok[:, :-1].contiguous(), "seqs_t": tim}, tok[:, 1:].contiguous()
 
-    def step():
-        return m.train_step(feats, labels)
+    if args.path == "graph":   # the whole autograd step replayed as one HIP graph
+        gstep = m.graphed_train_step(feats, labels)
+
+        def step():
+            return gstep(feats, labels)
+    else:
+        def step():
+            return m.train_step(feats, labels)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -221,7 +227,7 @@ def baseline_model_bench(args):
     out = {"metric": f"sequences/sec ({name} fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K", "value": round(B / ms * 1e3, 1),
            "unit": "sequences/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": f"{name} optimizer step (autograd path), batch 512, seqslen 100, num_units 128, {heads} heads, "
+           "config": {"workload": f"{name} optimizer step ({'autograd step replayed as a HIP graph' if args.path == 'graph' else 'autograd path'}), batch 512, seqslen 100, num_units 128, {heads} heads, "
                                   f"{blocks} blocks, num_items 20000, all-position loss, dropout 0.1/0.1, l2 1e-4"},
            "loss": round(float(loss), 5)}
     if table:

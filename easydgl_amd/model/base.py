@@ -109,6 +109,33 @@ class Sequential(nn.Module):
         if dst:
             torch._foreach_copy_(dst, src)
 
+    def graphed_train_step(self, features: Dict[str, torch.Tensor], labels: torch.Tensor, warmup: int = 2):
+        """One `train_step` captured into a HIP graph on static copies of the batch: returns step(features, labels) -> loss
+        (device scalar) that copies the new batch in and replays ~170 kernel launches as one submission.  Everything a step
+        needs lives on the device (dropout step counter, Adam step count), so replays advance like eager steps.  The `warmup`
+        eager steps that precede the capture are real optimizer steps."""
+        static_f = {k: v.clone() for k, v in features.items()}
+        static_l = labels.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.train_step(static_f, static_l)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self.train_step(static_f, static_l)
+
+        def step(f, l):
+            for k, buf in static_f.items():
+                buf.copy_(f[k])
+            static_l.copy_(l)
+            graph.replay()
+            return loss
+        step.graph = graph
+        return step
+
     def optimizer_step(self) -> None:
         """tf.train.AdamOptimizer(lr).minimize (Base.py:142-144) fused over the arena.  The l2 gradient is
         produced by autograd (ops.L2Fn), so no l2 is folded in here."""

@@ -449,12 +449,23 @@ class TppFn(torch.autograd.Function):
         return d_lam, None, None, None, None, None, None
 
 
+_SEG_CACHE = {}
+
+
+def _whole_segment(n: int, device) -> torch.Tensor:
+    """[0, n] on the device, built once per (n, device): no host-to-device copy inside a step (HIP graph capture forbids it)."""
+    key = (n, str(device))
+    if key not in _SEG_CACHE:
+        _SEG_CACHE[key] = torch.tensor([0, n], device=device, dtype=torch.int64)
+    return _SEG_CACHE[key]
+
+
 class L2Fn(torch.autograd.Function):
     """l2_reg * sum(w^2)/2 over one raw embedding table (coding.py:34-40)."""
 
     @staticmethod
     def forward(ctx, w, l2):
-        seg = torch.tensor([0, w.numel()], device=w.device, dtype=torch.int64)
+        seg = _whole_segment(w.numel(), w.device)
         out = torch.empty(1, device=w.device, dtype=torch.float32)
         ws = torch.empty(1024, device=w.device, dtype=torch.float32)
         check(lib.edgl_l2_loss(_ptr(w), _ptr(seg), 1, float(l2), _ptr(out), 0, _ptr(ws), _stream()), "edgl_l2_loss")

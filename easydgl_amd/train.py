@@ -56,6 +56,8 @@ def args(argv=None):
     p.add_argument("--ckpt_dir", default="ckpt")
     p.add_argument("--seed", type=int, default=9876)   # main.py:156-159
     p.add_argument("--patience", type=int, default=10)
+    p.add_argument("--graph", action="store_true",
+                   help="regressive models: replay the training step of full batches as one HIP graph (Sequential.graphed_train_step)")
     return p.parse_args(argv)
 
 
@@ -179,6 +181,7 @@ def run(FLAGS) -> Dict[str, float]:
     ckpt = os.path.join(FLAGS.ckpt_dir, f"{FLAGS.model}.pt")
     stopper = EarlyStopping(FLAGS.model, patience=FLAGS.patience, saver=lambda: save_checkpoint(model, ckpt))
     mask_state = torch.tensor([FLAGS.seed, 0], dtype=torch.int64, device="cuda")   # (seed, batch counter) of the masker
+    gstep = None
 
     logging.info("3. train and evaluate model")
     for epoch in range(FLAGS.num_epochs):
@@ -195,6 +198,10 @@ def run(FLAGS) -> Dict[str, float]:
                 feats, labels = regressive_batch(tok, tim, True)
             if engine is not None and len(idx) == bs:
                 loss = engine.step(feats, labels)
+            elif not masked and getattr(FLAGS, "graph", False) and len(idx) == bs:
+                if gstep is None:
+                    gstep = model.graphed_train_step(feats, labels, warmup=1)
+                loss = gstep(feats, labels)
             else:
                 loss = model.train_step(feats, labels)
             nb += 1

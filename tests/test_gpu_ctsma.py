@@ -148,3 +148,38 @@ def test_training_with_dropout_reduces_the_loss_bf16():
     losses = [float(m.train_step(feats, labels)) for _ in range(30)]
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0] - 0.3, losses
+
+
+@pytest.mark.parametrize("name", ["CTSMA", "TGAT", "TiSASREC"])
+def test_graphed_train_step_follows_the_eager_trajectory(name):
+    """Sequential.graphed_train_step: the autograd step captured into one HIP graph (2 eager warm-up steps, then replays) gives the
+    losses of eager train_step calls — dropout counter and Adam step count advance on the device inside the graph."""
+    import easydgl_amd
+    rng = np.random.default_rng(3)
+    B, T, C, I = 6, 14, 32, 50
+    tokens = rng.integers(1, I, size=(B, T + 1))
+    tokens[0, :4] = 0
+    ts = (9.5e8 + np.cumsum(rng.exponential(30000.0, size=(B, T + 1)), axis=1)).astype(np.float32)
+    ts[tokens == 0] = 0.0
+
+    def make():
+        F = SimpleNamespace(model=name, num_items=I, num_units=C, num_heads=2, num_blocks=2, seqslen=T, timelen=16, time_scale=86400.0,
+                            learning_rate=1e-3, l2_reg=1e-3, ct_reg=1e-4, hidden_dropout_rate=0.1, attention_probs_dropout_rate=0.1,
+                            mark_table=O.synthetic_mark_table(I, 4, multi_hot=True), compute_dtype="f32", num_train_steps=None,
+                            num_warmup_steps=None)
+        return easydgl_amd.ranking(F).finalize("cuda")
+
+    feats = to_dev({"seqs_i": tokens[:, :-1].copy(), "seqs_t": ts})
+    labels = torch.as_tensor(tokens[:, 1:].copy()).cuda()
+    eager, graphed = make(), make()
+    want = [float(eager.train_step(feats, labels)) for _ in range(6)]
+    step = graphed.graphed_train_step(feats, labels, warmup=2)          # two real steps happen here
+    got = [float(step(feats, labels)) for _ in range(4)]
+    for a, b in zip(got, want[2:]):
+        assert abs(a - b) <= 1e-4 * abs(b), (got, want)
+    # a different batch through the same graph
+    f2 = {k: v.clone() for k, v in feats.items()}
+    f2["seqs_i"][1, 5:8] = 7
+    l_g = float(step(f2, labels))
+    l_e = float(eager.train_step(f2, labels))
+    assert abs(l_g - l_e) <= 1e-4 * abs(l_e)

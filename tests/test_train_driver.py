@@ -44,8 +44,10 @@ def test_early_stopping_follows_reference_decisions():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model_name", ["EasyDGL", "CTSMA", "TGAT", "TiSASREC"])
+@pytest.mark.parametrize("model_name", ["EasyDGL", "CTSMA", "TGAT", "TiSASREC", "TGAT+graph"])
 def test_driver_end_to_end_from_tfrecords(tmp_path, model_name):
+    extra = ["--graph"] if model_name.endswith("+graph") else []
+    model_name = model_name.split("+")[0]
     sp = pytest.importorskip("scipy.sparse")
     from easydgl_amd import data as D
     from easydgl_amd import train as TR
@@ -60,7 +62,7 @@ def test_driver_end_to_end_from_tfrecords(tmp_path, model_name):
                    "--test", str(tmp_path / "test.tfrec"), "--num_items", str(num_items), "--num_units", "32", "--num_heads", "2",
                    "--num_blocks", "1", "--seqslen", str(seqslen), "--masklen", "4", "--time_scale", "86400", "--mark",
                    str(tmp_path / "mark.pkl"), "--ct_reg", "1e-7", "--batch_size", "64", "--num_epochs", "3", "--learning_rate",
-                   "1e-3", "--l2_reg", "1e-4", "--mask_seen", "--dtype", "f32", "--ckpt_dir", str(tmp_path / "ckpt")])
+                   "1e-3", "--l2_reg", "1e-4", "--mask_seen", "--dtype", "f32", "--ckpt_dir", str(tmp_path / "ckpt")] + extra)
     assert set(res) == {"H10", "H50", "H100", "N10", "N50", "N100"}
     assert all(0.0 <= v <= 1.0 and math.isfinite(v) for v in res.values())
     assert res["H10"] <= res["H50"] <= res["H100"]
