@@ -78,7 +78,16 @@ __device__ __forceinline__ int first_unpadded(const int64_t* idr, int T, int lan
 
 // ---- forward -----------------------------------------------------------------------------------------------------------
 template <typename T, int DQT, int DVT>
-__global__ __launch_bounds__(256) void tattn_fwd_kernel(TaP p) {
+__device__ __forceinline__ void tattn_fwd_body(const TaP& p);
+template <typename T, int DQT, int DVT>
+__global__ __launch_bounds__(256) void tattn_fwd_kernel(TaP p) { tattn_fwd_body<T, DQT, DVT>(p); }
+// same body under a 128-register budget (4 waves per SIMD): with one head of 128 channels (TGAT, h = 1) a launch has only
+// B * T/16 waves — 3584 at the headline sizes — and 3 waves per SIMD leave a second, nearly empty round
+template <typename T, int DQT, int DVT>
+__global__ __launch_bounds__(256, 4) void tattn_fwd_kernel_w4(TaP p) { tattn_fwd_body<T, DQT, DVT>(p); }
+
+template <typename T, int DQT, int DVT>
+__device__ __forceinline__ void tattn_fwd_body(const TaP& p) {
     Job j;
     if (!get_job(p, j)) return;
     const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15;
@@ -729,6 +738,9 @@ template <typename T>
 int launch_fwd(const TaP& p, hipStream_t st) {
     const int dqt = p.Dq / 16, dvt = p.Dv / 16;
 #define EDGL_TA_CASE(DQ, DV) if (dqt == DQ && dvt == DV) return launch_jobs(tattn_fwd_kernel<T, DQ, DV>, p, st);
+    if constexpr (sizeof(T) == 2) {
+        if (dqt == 24 && dvt == 8) return launch_jobs(tattn_fwd_kernel_w4<T, 24, 8>, p, st);
+    }
     EDGL_TA_CASE(1, 1) EDGL_TA_CASE(2, 2) EDGL_TA_CASE(4, 4) EDGL_TA_CASE(8, 8)
     EDGL_TA_CASE(3, 1) EDGL_TA_CASE(6, 2) EDGL_TA_CASE(12, 4) EDGL_TA_CASE(24, 8)
 #undef EDGL_TA_CASE
