@@ -7,10 +7,19 @@ with f32 accumulation / master weights.  Synthetic data, random
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `value` = N * 512 * K / (max-over-ranks wall time of the K timed steps).
-`roofline` is the dominant kernel's achieved MFMA rate (algorithmic FLOPs per launch / mean launch time,
-HIP events on the launch stream inside the timed region).  `cpu_baseline` times the restated reference
-graph (oracle/torch_ref.py, float32, reference op order) on this host's cores on a bounded sample.
+(`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks; a launcher whose
+WORLD_SIZE differs from --gpus is an error.)
+
+Rank 0 prints ONE JSON line.  `value` = N * 512 * K / (max-over-ranks wall time of the K timed steps); `step_ms_hipevents`
+= median / p10 / p90 of the per-step HIP-event times of the same region.  `roofline` is the dominant kernel's achieved MFMA
+rate: `frac` on ALGORITHMIC FLOPs per launch (one product), `hw_util` on the FLOPs the kernel executes (it also
+recomputes the logits), both over the mean launch time measured with HIP events on the launch stream inside the timed
+region.  `cpu_baseline` / `cpu_baseline_1thread` time the restated reference graph (oracle/torch_ref.py, float32, reference op
+order) on this host's cores (all cores up to 16 / the reference's own single-thread setting) on a bounded sample.  At N = 1
+`extras` adds the secondary rows of SURVEY §8(d): masklen 6, all rows weighted, dropout off, multi-hot marks, the config-3 K1
+encode line (algorithmic and counter-side GB/s) and the sharded-eval step.
+
+    python bench.py --workload eval --gpus N     # row-sharded full-catalogue scoring + RCCL top-K all-gather (|I| = 20K, 1M)
 """
 import argparse
 import json
@@ -35,8 +44,9 @@ DOMINANT_KERNEL_ID = 0   # EDGL_KERNEL_SCORE_BWD_ROWS
 DOMINANT_KERNEL = "score_bwd_kernel<bf16, C/16=8, ROLE_Y> (d_rows = dl . table, logits recomputed)"
 
 
-def flops_per_seq(c):
-    """SURVEY.md §8d algorithmic FLOPs per sequence, forward; fwd+bwd = 3x."""
+def flops_per_seq(c, rows_scored=None):
+    """SURVEY.md §8d algorithmic FLOPs per sequence, forward; fwd+bwd = 3x.  `rows_scored`: weighted masked slots per
+    sequence actually scored (default: all M — what the reference computes; label-0 slots have weight 0 and are skipped here)."""
     T, C, h, E, M, I, nb = c["seqslen"] + 1, c["num_units"], c["num_heads"], c["num_events"], c["masklen"], c["num_items"] + 1, c["num_blocks"]
     dh = C // h
     f = 0.0
@@ -49,11 +59,11 @@ def flops_per_seq(c):
     f += nb * 2 * T * C * C                        # F_proj
     f += nb * 8 * T * C * C                        # F_ffn
     f += 2 * T * C * C                             # F_head
-    f += 2 * M * C * I                             # F_score (train)
+    f += 2 * (M if rows_scored is None else rows_scored) * C * I     # F_score (train)
     return f
 
 
-def make_model_and_batch(c, dtype, device, seed):
+def make_model_and_batch(c, dtype, device, seed, full_rows=False):
     from types import SimpleNamespace
     import easydgl_amd
     from easydgl_amd import data as D
@@ -62,10 +72,12 @@ def make_model_and_batch(c, dtype, device, seed):
                         learning_rate=c["learning_rate"], l2_reg=c["l2_reg"], ct_reg=c["ct_reg"],
                         hidden_dropout_rate=c["hidden_dropout_rate"],
                         attention_probs_dropout_rate=c["attention_probs_dropout_rate"],
-                        mark_table=D.synthetic_mark_table(c["num_items"], c["num_events"]), compute_dtype=dtype,
+                        mark_table=D.synthetic_mark_table(c["num_items"], c["num_events"], multi_hot=bool(c.get("multi_hot", False))),
+                        compute_dtype=dtype,
                         num_train_steps=None, num_warmup_steps=None, seed=9876)
     model = easydgl_amd.ranking(F).finalize(device)
-    ids, ts = D.synthetic_batch(c["num_items"], c["seqslen"], c["batch"], seed=seed)
+    # full_rows: every sequence has all T tokens, so no masked slot falls on padding and every one of the B*M rows is scored
+    ids, ts = D.synthetic_batch(c["num_items"], c["seqslen"], c["batch"], seed=seed, min_len=(c["seqslen"] + 1) if full_rows else 5)
     g = torch.Generator().manual_seed(seed)
     mp = D.draw_masked_positions(c["batch"], c["seqslen"] + 1, c["masklen"], generator=g)
     feats, labels = D.mask_random(torch.tensor(ids), torch.tensor(ts), c["num_items"], mp)
@@ -73,14 +85,15 @@ def make_model_and_batch(c, dtype, device, seed):
     return model, feats, labels.to(device).contiguous()
 
 
-def cpu_baseline(c, budget_s=15.0):
+def cpu_baseline(c, budget_s=15.0, nthreads=None):
     """Restated reference graph on the host (TensorFlow is not installable offline): float32, reference op
     order incl. the materialised [hB,T,T(,E)] and [B*M,I] tensors, all host cores; bounded sample."""
     from oracle import easydgl_oracle as O
     from oracle import torch_ref as R
     # the reference pins intra/inter-op parallelism to 1 (src/main.py:167-168); on a many-core host the small
     # per-op tensors of this model do not scale past a few threads, so the baseline uses min(cores, 16) threads
-    nthreads = min(os.cpu_count() or 1, 16)
+    if nthreads is None:
+        nthreads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(nthreads)
     bs = 16
     cfg = O.Config(num_items=c["num_items"], seqslen=c["seqslen"], num_units=c["num_units"], num_heads=c["num_heads"],
@@ -171,7 +184,7 @@ def encode_bench(args):
            "backward": {"ms": round(t_b * 1e3, 4), "achieved_GBps": round(bytes_b / t_b / 1e9, 1),
                         "note": "encode_bwd + scatter into the touched rows of the [I, C] f32 table gradient (memset of the "
                                 "full table gradient excluded from the byte count, included in the time)"}}
-    print(json.dumps(out))
+    return out
 
 
 def baseline_model_bench(args):
@@ -238,28 +251,42 @@ def baseline_model_bench(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)    # >= 20 warm-up + >= 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", default="engine", choices=["engine", "graph", "autograd"],
                     help="engine: static launch sequence issued eagerly (dominant kernel bracketed with HIP events); "
                          "graph: the same sequence replayed as one HIP graph; autograd: torch.autograd over the ops")
     ap.add_argument("--op-table", action="store_true", help="after the timed region, print a per-C-call time table to stderr")
-    ap.add_argument("--workload", default="step", choices=["step", "encode", "tgat", "tisasrec", "ctsma"],
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary rows (M=6, all rows weighted, dropout off, "
+                                                             "config-3 encode, sharded eval) the default N=1 run appends")
+    ap.add_argument("--workload", default="step", choices=["step", "encode", "eval", "tgat", "tisasrec", "ctsma"],
                     help="step: the headline optimizer step (default, the bench contract); encode: K1 input encoding "
                          "(embedding gather + time code) alone at SURVEY §8d config 3 (|items| = 1M, L = 200, d = 256) — the "
                          "HBM-bound regime, reported as GB/s against the HBM roofline")
     args = ap.parse_args()
     if args.workload == "encode":
-        return encode_bench(args)
+        return print(json.dumps(encode_bench(args)))
     if args.workload in ("tgat", "tisasrec", "ctsma"):
         return baseline_model_bench(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become N ranks (one per GPU) under torch.distributed.run
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.workload == "eval":
+        return eval_bench(args, world, rank, local)
     # one rank per GPU; EDGL_BENCH_BACKEND=gloo lets the multi-process path be exercised on a single-GPU box (ranks then share
     # device 0 and the collective goes through the host) — a functional check only, never a measurement
     backend = os.environ.get("EDGL_BENCH_BACKEND", "nccl")
@@ -276,9 +303,84 @@ def main():
         else:
             dist.init_process_group(backend)
     c = dict(HEADLINE)
-    from easydgl_amd import _lib, parallel
-    model, feats, labels = make_model_and_batch(c, args.dtype, dev, seed=9876 + rank)
+    from easydgl_amd import _lib
+    res = run_step_workload(c, args, dev, rank, world, dist, args.steps, args.warmup, bracket=(args.path != "graph"))
+    dt, loss, labels, dom = res["dt"], res["loss"], res["labels"], res["dom"]
 
+    if rank == 0:
+        T, C, I, M = c["seqslen"] + 1, c["num_units"], c["num_items"] + 1, c["masklen"]
+        R = c["batch"] * M
+        # rows with label 0 (masked slots that fell on padding) have weight 0 in the loss (EasyDGL.py:180) and are not
+        # scored; only the weighted rows count as algorithmic work
+        R_w = int((labels != 0).sum().item())
+        # ALGORITHMIC work of the dominant kernel: ONE product d_rows = dl . table = 2*R_w*C*I.  The kernel also
+        # recomputes the [R_w, I] logits tile-wise (another 2*R_w*C*I that never leaves registers): that is executed work, it
+        # counts for `hw_util` (what the MFMA pipe did), not for `frac` (what the algorithm needed).
+        dom_flops = 2.0 * R_w * C * I
+        dom_ms = dom[1] / max(1, dom[0])
+        peak = 2500.0 if args.dtype == "bf16" else 157.3
+        traffic = None   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        for tp in ("r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tp)
+            if args.dtype == "bf16" and os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                break
+        ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        flops_done = 3 * flops_per_seq(c, rows_scored=R_w / c["batch"]) * c["batch"]
+        ms = res["step_ms"]
+        out = {
+            "metric": "sequences/sec (fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K",
+            "value": round(world * c["batch"] * args.steps / dt, 2),
+            "unit": "sequences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "EasyDGL optimizer step, per-GPU batch 512, seqslen 100 (T=101), num_units 128, 8 heads, "
+                                   "1 block, num_items 20000 (I=20001), masklen 20, 16 marks, dropout 0.1/0.1, ct_reg 1e-7, l2 1e-4",
+                       "global_batch": world * c["batch"], "parallelism": f"dp{world}",
+                       "algorithmic_gflop_per_step_all_rows": round(3 * flops_per_seq(c) * c["batch"] / 1e9, 1),
+                       "algorithmic_gflop_per_step_rows_scored": round(flops_done / 1e9, 1)},
+            "loss": round(float(loss), 5), "path": args.path,
+            "step_ms_hipevents": {"median": round(float(np.median(ms)), 4), "p10": round(float(np.percentile(ms, 10)), 4),
+                                  "p90": round(float(np.percentile(ms, 90)), 4), "n": len(ms)},
+            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL,
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "hw_util": round(2 * ach / peak, 4),
+                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "executed_flop": 2 * dom_flops,
+                         "rows_scored": R_w, "rows_total": R, "traffic": traffic},
+            # whole-step MFMA fraction on the work actually done (weight-0 rows are skipped exactly, so they are not counted)
+            "whole_step_mfma_frac": round(flops_done / (dt / args.steps) / 1e12 / peak, 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(c, budget_s=12.0)
+            # the reference's own thread setting (src/main.py:167-168: intra/inter-op parallelism = 1)
+            out["cpu_baseline_1thread"] = cpu_baseline(c, budget_s=8.0, nthreads=1)
+        if world == 1 and not args.no_extras and args.path == "engine":
+            out["extras"] = extras(c, args, dev)
+        if args.op_table:
+            step = res["step"]
+            _lib.profiler.start()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            _lib.profiler.stop()
+            rows = sorted(_lib.profiler.summary().items(), key=lambda kv: -kv[1][1])
+            tot = sum(v[1] for _, v in rows)
+            print("per-call GPU time over 5 steps (HIP events):", file=sys.stderr)
+            for k, (n, ms_) in rows:
+                print(f"  {k:28s} calls {n:4d}  {ms_ / 5:9.3f} ms/step  {100 * ms_ / tot:5.1f}%", file=sys.stderr)
+            print(f"  total {tot / 5:.3f} ms/step", file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=False, full_rows=False):
+    """W warm-up steps, then EXACTLY `steps` optimizer steps between barrier + synchronize on both sides; the time is the max
+    over ranks.  Every step is also bracketed by HIP events on the launch stream (median / p10 / p90)."""
+    from easydgl_amd import _lib, parallel
+    model, feats, labels = make_model_and_batch(c, args.dtype, dev, seed=9876 + rank, full_rows=full_rows)
     if args.path == "autograd":
         def step():
             from easydgl_amd import ops
@@ -298,86 +400,166 @@ def main():
         def step():
             return eng.step()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     evs = []
-    for _ in range(args.steps):          # pre-created HIP event pairs (handles exist after a first record)
+    for _ in range(steps):          # pre-created HIP event pairs (handles exist after a first record)
         a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); b_.record()
         evs.append((a, b_))
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    for e in marks:
+        e.record()
     torch.cuda.synchronize()
-    bracket = args.path != "graph"       # a captured graph cannot carry per-launch timing events
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
+        marks[i].record()
         if bracket:
             _lib.lib.edgl_profile_next(DOMINANT_KERNEL_ID, evs[i][0].cuda_event, evs[i][1].cuda_event)
         loss = step()
+    marks[steps].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dom = (len(evs), sum(a.elapsed_time(b_) for a, b_ in evs)) if bracket else (0, 0.0)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if not np.isfinite(float(loss)):
         raise RuntimeError("loss is not finite")
+    return {"dt": dt, "loss": loss, "labels": labels, "dom": dom, "step_ms": step_ms, "step": step, "model": model, "feats": feats}
 
-    if rank == 0:
-        T, C, I, M = c["seqslen"] + 1, c["num_units"], c["num_items"] + 1, c["masklen"]
-        R = c["batch"] * M
-        # rows with label 0 (masked slots that fell on padding) have weight 0 in the loss (EasyDGL.py:180) and are not
-        # scored; only the weighted rows count as algorithmic work
-        R_w = int((labels != 0).sum().item())
-        # per launch: recompute the [R_w, I] logits (2*R_w*C*I) + d_rows = dl . table (2*R_w*C*I)
-        dom_flops = 2 * 2.0 * R_w * C * I
-        dom_ms = dom[1] / max(1, dom[0])
-        peak = 2500.0 if args.dtype == "bf16" else 157.3
-        traffic = None   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        tpath = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
-        if args.dtype == "bf16" and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        out = {
-            "metric": "sequences/sec (fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K",
-            "value": round(world * c["batch"] * args.steps / dt, 2),
-            "unit": "sequences/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "EasyDGL optimizer step, per-GPU batch 512, seqslen 100 (T=101), num_units 128, 8 heads, "
-                                   "1 block, num_items 20000 (I=20001), masklen 20, 16 marks, dropout 0.1/0.1, ct_reg 1e-7, l2 1e-4",
-                       "global_batch": world * c["batch"], "parallelism": f"dp{world}",
-                       "algorithmic_gflop_per_step": round(3 * flops_per_seq(c) * c["batch"] / 1e9, 1)},
-            "loss": round(float(loss), 5), "path": args.path,
-            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL,
-                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "rows_scored": R_w,
-                         "rows_total": R, "traffic": traffic},
-            "whole_step_mfma_frac": round(3 * flops_per_seq(c) * c["batch"] / (dt / args.steps) / 1e12 / peak, 4),
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(c)
-        if args.op_table:
-            _lib.profiler.start()
+
+def extras(c, args, dev):
+    """Secondary rows of SURVEY §8(d), measured after the headline line on the same GPU (N = 1 only): the reference's default
+    masklen 6, a batch whose masked slots all carry weight, dropout off, the multi-hot mark table, the config-3 K1 line and the
+    sharded-eval step.  Short runs (30 timed steps each); none of them is `value`."""
+    import copy
+    out = {}
+    a2 = copy.copy(args)
+
+    def row(cc, full_rows=False, multi_hot=False):
+        cc = dict(cc, multi_hot=multi_hot)
+        r = run_step_workload(cc, a2, dev, 0, 1, None, 30, 10, bracket=False, full_rows=full_rows)
+        rw = int((r["labels"] != 0).sum().item())
+        fl = 3 * flops_per_seq(cc, rows_scored=rw / cc["batch"]) * cc["batch"]
+        ms = float(np.median(r["step_ms"]))
+        return {"ms_per_step": round(r["dt"] / 30 * 1e3, 4), "ms_median": round(ms, 4),
+                "sequences_per_s": round(cc["batch"] * 30 / r["dt"], 1), "rows_scored": rw, "rows_total": cc["batch"] * cc["masklen"],
+                "whole_step_mfma_frac": round(fl / (r["dt"] / 30) / 1e12 / (2500.0 if args.dtype == "bf16" else 157.3), 4)}
+    out["masklen_6"] = row(dict(c, masklen=6))
+    out["all_rows_weighted"] = row(c, full_rows=True)
+    out["dropout_off"] = row(dict(c, hidden_dropout_rate=0.0, attention_probs_dropout_rate=0.0))
+    out["multi_hot_marks"] = row(c, multi_hot=True)
+    torch.cuda.empty_cache()
+    a3 = copy.copy(args)
+    a3.steps, a3.warmup = 50, 10
+    enc = encode_bench(a3)
+    out["encode_config3"] = {"algorithmic_GBps": enc["value"], "ms": enc["ms_per_step"], "frac_of_8TBps_algorithmic": enc["roofline"]["frac"],
+                             "hbm_side_bytes_per_launch_pmc": enc["roofline"]["traffic"],
+                             "hbm_side_GBps_pmc": (round(enc["roofline"]["traffic"] / (enc["ms_per_step"] * 1e-3) / 1e9, 1)
+                                                   if enc["roofline"]["traffic"] else None),
+                             "workload": enc["config"]["workload"]}
+    torch.cuda.empty_cache()
+    out["eval_sharded"] = eval_rows(args, dev, 1, 0, None, steps=20, warmup=5, sizes=((20000, 128),))
+    return out
+
+
+def eval_rows(args, dev, world, rank, dist, steps, warmup, sizes):
+    """Sequential.eval's scoring step (Base.py:150-181) with the item table row-sharded over the ranks: every
+    rank holds the SAME evaluation batch of 512 sequences (the encoder is replicated), scores it against its table shard,
+    masks the seen ids that fall in the shard, keeps a local top-100 with global ids, and ONE packed all-gather + the merge
+    kernel give the global top-100.  The batch is shared, so the job does not grow with N: strong scaling."""
+    from types import SimpleNamespace
+    import easydgl_amd
+    from easydgl_amd import data as D
+    rows = []
+    for num_items, C in sizes:
+        cfgd = dict(HEADLINE, num_items=num_items, num_units=C, seqslen=100 if C == 128 else 200, masklen=20 if C == 128 else 40)
+        F = SimpleNamespace(model="EasyDGL", num_items=num_items, num_units=C, num_heads=8, num_blocks=1, seqslen=cfgd["seqslen"],
+                            masklen=cfgd["masklen"], time_scale=86400.0, learning_rate=5e-4, l2_reg=1e-4, ct_reg=1e-7,
+                            hidden_dropout_rate=0.1, attention_probs_dropout_rate=0.1,
+                            mark_table=D.synthetic_mark_table(num_items, 16), compute_dtype=args.dtype, num_train_steps=None,
+                            num_warmup_steps=None, seed=9876)
+        model = easydgl_amd.ranking(F).finalize(dev)
+        ids, ts = D.synthetic_batch(num_items, cfgd["seqslen"], 512, seed=9876)     # the same batch on every rank
+        feats, _ = D.device_mask_last(torch.tensor(ids, device=dev), torch.tensor(ts, device=dev), model.mask)
+        K = 100
+
+        def step():
+            return model.eval_topk_sharded(feats, mask_seen=True, K=K)
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            val, idx = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ag_ms = None
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            # the collective alone: one packed [512, 2K] 32-bit buffer per rank
+            packed = torch.zeros((512, 2 * K), device=dev, dtype=torch.int32)
+            flat = torch.empty((world * 512, 2 * K), device=dev, dtype=torch.int32)
             for _ in range(5):
-                step()
+                dist.all_gather_into_tensor(flat, packed)
             torch.cuda.synchronize()
-            _lib.profiler.stop()
-            rows = sorted(_lib.profiler.summary().items(), key=lambda kv: -kv[1][1])
-            tot = sum(v[1] for _, v in rows)
-            print("per-call GPU time over 5 steps (HIP events):", file=sys.stderr)
-            for k, (n, ms) in rows:
-                print(f"  {k:28s} calls {n:4d}  {ms / 5:9.3f} ms/step  {100 * ms / tot:5.1f}%", file=sys.stderr)
-            print(f"  total {tot / 5:.3f} ms/step", file=sys.stderr)
-        print(json.dumps(out))
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(20):
+                dist.all_gather_into_tensor(flat, packed)
+            b_.record()
+            torch.cuda.synchronize()
+            ag_ms = a.elapsed_time(b_) / 20
+        assert idx.shape == (512, K) and int(idx.min()) >= 0
+        rows.append({"num_items": num_items, "num_units": C, "T": cfgd["seqslen"] + 1, "batch": 512, "K": K, "shards": world,
+                     "ms_per_eval_step": round(dt / steps * 1e3, 4), "sequences_per_s": round(512 * steps / dt, 1),
+                     "allgather_bytes_per_rank": 512 * 2 * K * 4, "allgather_bytes_gathered": world * 512 * 2 * K * 4,
+                     "allgather_ms": None if ag_ms is None else round(ag_ms, 4)})
+        del model
+        torch.cuda.empty_cache()
+    return rows
+
+
+def eval_bench(args, world, rank, local):
+    """--workload eval: the row-sharded full-catalogue scoring step at |I| = 20K (headline) and |I| = 1M (config 3 sizes)."""
+    backend = os.environ.get("EDGL_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    rows = eval_rows(args, dev, world, rank, dist, args.steps, args.warmup, sizes=((20000, 128), (1_000_000, 256)))
+    if rank == 0:
+        head = rows[0]
+        print(json.dumps({"metric": "sequences/sec (evaluation: encode + sharded full-catalogue scoring + seen mask + top-100) B=512 L=100 d=128 |I|=20K",
+                          "value": head["sequences_per_s"], "unit": "sequences/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": head["ms_per_eval_step"], "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": "Sequential.eval scoring step, item table row-sharded over the ranks, one packed "
+                                                 "RCCL all-gather of the local top-100 + merge kernel", "parallelism": f"shard{world}"},
+                          "rows": rows}))
     if world > 1:
         dist.destroy_process_group()
 

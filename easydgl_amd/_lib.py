@@ -85,6 +85,12 @@ SIGNATURES = {
     "edgl_tiattn_bwd": (I, [P, I, P, I, P, I, P, P, P, P, I, P, I, P, P, I, I, I, I, F, F, I, F, P, U32, P, I, P, I, P, I, P, P, P,
                             I, I, P]),
     "edgl_add_pos2": (I, [P, P, P, I, I, I, P, I, P]),
+    "edgl_embedding_fwd": (I, [P, L, P, I, I, I, F, P, I, P]),
+    "edgl_embedding_bwd": (I, [P, L, P, I, I, I, F, P, I, P]),
+    "edgl_time_sinusoid": (I, [P, L, P, I, P, I, P]),
+    "edgl_time_function_fwd": (I, [P, L, P, P, I, P, I, P]),
+    "edgl_time_function_bwd_workspace": (L, [I]),
+    "edgl_time_function_bwd": (I, [P, L, P, P, I, P, P, P, P, I, P]),
 }
 
 

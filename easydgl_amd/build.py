@@ -2,6 +2,7 @@
 C-ABI shared object (include/easydgl_hip.h)."""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -11,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libeasydgl_hip.so")
 SOURCES = ["k_misc.hip", "k_data.hip", "k_encode.hip", "k_gemm.hip", "k_gemm2.hip", "k_layernorm.hip", "k_bimau_fwd.hip", "k_bimau_bwd.hip",
-           "k_score.hip", "k_tattn.hip"]
+           "k_score.hip", "k_tattn.hip", "k_coding.hip"]
 HEADERS = ["edgl_common.h", "gemm_tile.h", "bimau_common.h", os.path.join("..", "..", "include", "easydgl_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read/write traffic around every VALU consumer);
@@ -29,11 +30,26 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=()) -> str:
+    """sha256 over the CONTENT of the inputs (sources, headers, flags): a prebuilt object with a fresh mtime but other
+    sources is rebuilt, an untouched tree is not."""
+    h = hashlib.sha256()
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def _stamp_ok(target: str, digest: str) -> bool:
+    stamp = target + ".sha256"
+    return os.path.exists(target) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+
+
+def _write_stamp(target: str, digest: str) -> None:
+    with open(target + ".sha256", "w") as f:
+        f.write(digest + "\n")
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -42,10 +58,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
+    digests = {}
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + hdrs):
+        digests[o] = _digest([s] + hdrs, FLAGS + EXTRA_FLAGS.get(src, []))
+        if force or not _stamp_ok(o, digests[o]):
             jobs.append((s, o))
 
     def run(job):
@@ -54,6 +72,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr[-4000:]))
+        _write_stamp(o, digests[o])
         if verbose:
             print("compiled", os.path.basename(s))
         return o
@@ -62,11 +81,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(OUT, objs):
+    link_digest = _digest([], [digests[o] for o in objs])   # the library is current iff it was linked from THESE objects
+    if force or jobs or not _stamp_ok(OUT, link_digest):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        _write_stamp(OUT, link_digest)
     return OUT
 
 

@@ -326,6 +326,12 @@ int edgl_reduce_rows(const float* part, int P, int N, long ld, float* out, int a
 }
 
 extern "C" int edgl_reduce_defer(int on, void* stream) {
+    if (on < 0) {   // abort: forget the queued jobs (their partial buffers may be gone) and leave deferred mode
+        g_red_batch.n = 0;
+        g_red_batch.blocks = 0;
+        g_red_defer = false;
+        return EDGL_OK;
+    }
     if (!on && g_red_defer) {
         const int rc = edgl_reduce_flush_impl((hipStream_t)stream);
         if (rc) return rc;

@@ -192,6 +192,19 @@ class TrainEngine:
         # ================= backward =================
         self._ws_i = 0
         check(lib.edgl_reduce_defer(1, st), "edgl_reduce_defer")
+        try:
+            self._issue_backward(st, drop, tab, tab_c, lab)
+        except BaseException:
+            # never leave the thread in deferred mode: later ops would queue reductions that nobody flushes
+            lib.edgl_reduce_defer(-1, st)
+            raise
+        check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")   # runs every queued reduction in one launch
+
+    def _issue_backward(self, st, drop, tab, tab_c, lab):
+        m = self.m
+        B, T, C, H, E, M, I, R = self.B, self.T, self.C, self.H, self.E, self.M, self.I, self.R
+        code = self.code
+        hd, ad = m.hidden_dropout_rate, m.attention_probs_dropout_rate
         check(lib.edgl_score_ce_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
                                     _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows), _ptr(tab.grad),
                                     _ptr(m.output_bias.grad), _ptr(self.ws), code, st), "edgl_score_ce_bwd")
@@ -248,7 +261,6 @@ class TrainEngine:
                                   d0.stream_id, _ptr(tab.grad), _ptr(m.pcoding.pembs.lookup_table.grad),
                                   _ptr(m.mark_embs.lookup_table.grad), _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))),
                                   code, st), "edgl_encode_bwd")
-        check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")   # runs every queued reduction in one launch
 
     def _optimizer(self):
         m = self.m

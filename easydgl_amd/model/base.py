@@ -67,6 +67,14 @@ class Sequential(nn.Module):
         if self.act_dtype != torch.float32:
             self._shadow = torch.empty(total, device=device, dtype=self.act_dtype)
             self.sync_shadow()
+        # operator modules (module/coding.py, module/temporal.py) read parameters through the owning model's compute copy
+        for mod in self.modules():
+            if mod is self:
+                continue
+            if "compute" in mod.__dict__:
+                mod.compute = self.compute
+            if "act_dtype" in mod.__dict__:
+                mod.act_dtype = self.act_dtype
         return self
 
     def l2_param_names(self) -> List[str]:
@@ -118,9 +126,10 @@ class Sequential(nn.Module):
         static_l = labels.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        warm_loss = None
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.train_step(static_f, static_l)
+                warm_loss = self.train_step(static_f, static_l).clone()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -134,6 +143,7 @@ class Sequential(nn.Module):
             graph.replay()
             return loss
         step.graph = graph
+        step.warmup_loss = warm_loss   # loss of the last eager warm-up step (a real optimizer step on the capture batch)
         return step
 
     def optimizer_step(self) -> None:

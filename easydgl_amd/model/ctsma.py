@@ -38,7 +38,7 @@ class _Block(nn.Module):
     def __init__(self, cin, C_, heads, events, att_drop, gen):
         super().__init__()
         self.att_ln = _LayerNorm(cin)                                    # num_blocks_i/attention/LayerNorm
-        self.attention = T.MAU(cin, C_, heads, events, att_drop, gen)    # num_blocks_i/attention/modulating_attention
+        self.attention = T.MAU(C_, heads, events, att_drop, in_units=cin, gen=gen)    # num_blocks_i/attention/modulating_attention
         self.ff_ln = _LayerNorm(C_)                                      # num_blocks_i/feed-forward/LayerNorm
         self.ff = _FeedForward(C_, gen)
 

@@ -46,7 +46,7 @@ class _LayerNorm(nn.Module):
 class _Block(nn.Module):
     def __init__(self, cin, C_, heads, events, att_drop, gen):
         super().__init__()
-        self.attention = T.BiMAU(cin, C_, heads, events, att_drop, gen)   # layer_i/attention/self/TMAU
+        self.attention = T.BiMAU(C_, heads, events, att_drop, in_units=cin, gen=gen)   # layer_i/attention/self/TMAU
         self.att_out = _Dense(C_, C_, gen)                                 # layer_i/attention/output/dense
         self.att_ln = _LayerNorm(C_)                                       # layer_i/attention/output/LayerNorm
         self.inter = _Dense(C_, 2 * C_, gen)                               # layer_i/intermediate/dense

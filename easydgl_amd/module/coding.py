@@ -1,9 +1,11 @@
 """Mirror of the reference's src/module/coding.py operator classes (the ones on the EasyDGL path).
 
-These are parameter containers + thin callables; the arithmetic of Embedding / PositionCoding /
-TimeSinusoidCoding on the model's hot path is fused into ONE kernel (edgl_encode_fwd, see
-easydgl_amd/model/easydgl.py), so the per-class ``__call__``/``code`` methods below exist for API
-parity and run the same kernel on a degenerate input."""
+Same class names, constructor arguments and ``__call__`` / ``code`` methods as the reference.  On the model's hot path
+the arithmetic of Embedding / PositionCoding / TimeSinusoidCoding is fused into ONE kernel (``edgl_encode_fwd``, see
+``easydgl_amd/model/easydgl.py``) and the time-function / interval codings are folded into the attention kernels
+(``csrc/k_tattn.hip``); called on their own, the methods below run the stand-alone HIP entry points of
+``csrc/k_coding.hip`` (``edgl_embedding_fwd/bwd``, ``edgl_time_sinusoid``, ``edgl_time_function_fwd/bwd``).  ``compute`` is
+the hook the owning model installs to hand out the bf16 shadow of a parameter (identity in f32 mode)."""
 from __future__ import annotations
 
 import math
@@ -11,6 +13,8 @@ import math
 import numpy as np
 import torch
 from torch import nn
+
+from .. import ops
 
 
 def glorot_uniform_(t: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
@@ -30,6 +34,13 @@ class Embedding(nn.Module):
         super().__init__()
         self.num_units, self.l2_reg, self.zero_pad, self.scale = num_units, l2_reg, zero_pad, scale
         self.lookup_table = nn.Parameter(glorot_uniform_(torch.empty(vocab_size, num_units), gen))
+        self.compute = lambda p: p
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        """coding.py:60-64: ``lookup(table, inputs) * sqrt(num_units)`` (integer ``inputs`` of any shape)."""
+        tab = self.lookup_table
+        scale = float(self.num_units) ** 0.5 if self.scale else 1.0
+        return ops.EmbeddingFn.apply(tab, self.compute(tab), inputs.to(torch.int64), self.zero_pad, scale)
 
 
 class PositionCoding(nn.Module):
@@ -38,6 +49,17 @@ class PositionCoding(nn.Module):
     def __init__(self, vocab_size, num_units, l2_reg=0.0, gen=None):
         super().__init__()
         self.pembs = Embedding(vocab_size, num_units, l2_reg, zero_pad=False, scale=False, gen=gen)
+
+    def code(self, inputs: torch.Tensor) -> torch.Tensor:
+        """coding.py:76-79: the first ``inputs.shape[1]`` table rows, one copy per batch row -> [B, T, C]."""
+        B, T = inputs.shape[0], inputs.shape[1]
+        pos = torch.arange(T, device=inputs.device, dtype=torch.int64).unsqueeze(0).expand(B, T)
+        return self.pembs(pos)
+
+    def forward(self, inputs: torch.Tensor, **kwargs) -> torch.Tensor:
+        """coding.py:71-73: ``concat([inputs, code(inputs)], -1)``."""
+        code = self.code(inputs)
+        return torch.cat([inputs.to(code.dtype), code], dim=-1)
 
 
 class TimeSinusoidCoding(nn.Module):
@@ -48,6 +70,12 @@ class TimeSinusoidCoding(nn.Module):
         self.num_units = num_units
         scale = np.power(10000, np.arange(0, num_units, 2) * 1.0 / num_units).astype(np.float32)
         self.register_buffer("scale", torch.from_numpy(scale), persistent=False)
+        self.act_dtype = torch.float32
+
+    def code(self, inputs: torch.Tensor) -> torch.Tensor:
+        """coding.py:137-149: ``inputs`` [B, T] -> [B, T, C] with sin on the even and cos on the odd channels."""
+        assert inputs.dim() == 2, "the tensor rank should be 2."           # coding.py:139
+        return ops.time_sinusoid(inputs, self.scale, self.num_units, self.act_dtype)
 
 
 class TimeFunctionCoding(nn.Module):
@@ -59,6 +87,14 @@ class TimeFunctionCoding(nn.Module):
         self.num_units = num_units
         self.basis_freq = nn.Parameter(torch.from_numpy(np.linspace(0, 9, num_units).astype(np.float32)))
         self.phase = nn.Parameter(torch.zeros(num_units))
+        self.act_dtype = torch.float32
+
+    def code(self, inputs: torch.Tensor) -> torch.Tensor:
+        """coding.py:113-122: ``inputs`` [B, T, ...] -> [B, T, K, C] = cos(inputs * basis_freq + phase), K = the flattened
+        trailing axes (1 for a rank-2 input)."""
+        B, T = inputs.shape[0], inputs.shape[1]
+        x = inputs.reshape(B, T, -1)
+        return ops.TimeFunctionFn.apply(x, self.basis_freq, self.phase, self.act_dtype)
 
 
 class TimeIntervalCoding(nn.Module):
@@ -67,3 +103,8 @@ class TimeIntervalCoding(nn.Module):
     def __init__(self, vocab_size, num_units, l2_reg=0.0, gen=None):
         super().__init__()
         self.pembs = Embedding(vocab_size, num_units, l2_reg, zero_pad=False, scale=False, gen=gen)
+
+    def code(self, inputs: torch.Tensor) -> torch.Tensor:
+        """coding.py:93-94: the table row of every integer interval (an index past the table reads zeros, as the
+        reference's GPU lookup does for ``timelen``, TiSASREC.py:59)."""
+        return self.pembs(inputs)

@@ -10,6 +10,23 @@ from .. import ops
 from .coding import glorot_uniform_
 
 
+SUPPORTED_HEAD_DIMS = (16, 32, 64, 128)
+MAX_EVENTS = 16
+
+
+def _check_head_dim(num_units, num_heads, num_events, who):
+    """The fused attention kernels tile the head dim in 16-wide MFMA blocks (csrc/k_bimau_*.hip): fail here, with the
+    flag names, instead of at the first step with a low-level shape error."""
+    if num_heads <= 0 or num_units % num_heads:
+        raise ValueError(f"{who}: num_units={num_units} must be a multiple of num_heads={num_heads}")
+    dh = num_units // num_heads
+    if dh not in SUPPORTED_HEAD_DIMS:
+        raise ValueError(f"{who}: head dim num_units/num_heads = {dh} unsupported; the HIP kernels take {SUPPORTED_HEAD_DIMS} "
+                         f"(e.g. --num_units=512 --num_heads=8 as in runme.sh:15-23)")
+    if not (1 <= num_events <= MAX_EVENTS):
+        raise ValueError(f"{who}: num_events={num_events} unsupported (1..{MAX_EVENTS} mark types)")
+
+
 class BiMAU(nn.Module):
     """temporal.py:393-452 + MAU.intensity (temporal.py:281-315).
 
@@ -20,19 +37,43 @@ class BiMAU(nn.Module):
     keys are ignored exactly as in the reference (BiMAU projects Q,K,V,T from ``queries``), ``masks`` is the
     [B,T] item-id tensor (a key is masked where id == 0)."""
 
-    def __init__(self, in_units, num_units, num_heads, num_events, dropout_rate, gen=None):
+    def __init__(self, num_units, num_heads, num_events, dropout_rate, scope="TMAU", in_units=None, gen=None):
+        """Reference signature (temporal.py:401): ``BiMAU(num_units, num_heads, num_events, dropout_rate, scope)``.
+        ``in_units`` (width of ``queries``; 3C for EasyDGL's first block) is what tf.layers.dense infers at graph build:
+        give it to create the projection eagerly (the models do, so that it lands in the flat arena), or leave it None and
+        the projection is created on the first call."""
         super().__init__()
+        _check_head_dim(num_units, num_heads, num_events, "BiMAU")
         self.num_units, self.num_heads, self.num_events, self.dropout_rate = num_units, num_heads, num_events, dropout_rate
+        self.scope = scope
+        self._gen = gen
         dh = num_units // num_heads
-        self.dense_kernel = nn.Parameter(torch.randn(in_units, 4 * num_units, generator=gen) * 0.02)
-        self.dense_bias = nn.Parameter(torch.zeros(4 * num_units))
+        self.dense_kernel = None
+        self.dense_bias = None
+        if in_units is not None:
+            self._make_projection(in_units)
         self.st_kernel = nn.Parameter(glorot_uniform_(torch.empty(dh + 1, dh * num_events), gen))
         self.st_bias = nn.Parameter(torch.zeros(dh * num_events))
         self.weight = nn.Parameter(glorot_uniform_(torch.empty(num_events, dh), gen))
         self.scaling = nn.Parameter(torch.zeros(num_events))
         self.compute = lambda p: p  # replaced by the owning model (bf16 shadow lookup)
 
-    def forward(self, queries, keys, masks, intervals, marks, is_training, drop: ops.Drop = ops.NO_DROP):
+    def _make_projection(self, in_units, device=None):
+        k = torch.randn(in_units, 4 * self.num_units, generator=self._gen) * 0.02          # temporal.py:393,409
+        self.dense_kernel = nn.Parameter(k if device is None else k.to(device))
+        self.dense_bias = nn.Parameter(torch.zeros(4 * self.num_units, device=device))
+
+    def forward(self, queries, keys, masks, intervals, marks, is_training, causality=None, drop: ops.Drop = None):
+        """temporal.py:404: ``(queries, keys, masks, intervals, marks, is_training, causality=None)`` -> (outputs [B,T,C],
+        mark_intensity [h*B,T,E]).  ``causality`` is ignored exactly as in the reference (BiMAU is bidirectional);
+        ``drop`` names the dropout stream (the owning model passes its device RNG state; on its own the unit has none and
+        runs dropout-free unless one is given)."""
+        if isinstance(causality, ops.Drop):       # positional call of the models: (..., is_training, drop)
+            causality, drop = None, causality
+        if drop is None:
+            drop = ops.NO_DROP
+        if self.dense_kernel is None:
+            self._make_projection(queries.shape[-1], queries.device)
         C = self.num_units
         qkvt = ops.LinearFn.apply(queries, self.dense_kernel, self.dense_bias, self.compute(self.dense_kernel), False)
         resid = queries[:, :, :C]
@@ -46,9 +87,13 @@ class MAU(nn.Module):
     variables) — then the same fused kernel as BiMAU with ``causality`` (future blinding, :370-375) and the modulation
     kept on the diagonal; the residual adds the queries' first C channels (:383)."""
 
-    def __init__(self, in_units, num_units, num_heads, num_events, dropout_rate, gen=None):
+    def __init__(self, num_units, num_heads, num_events, dropout_rate, scope="modulating_attention", in_units=None, gen=None):
+        """Reference signature (temporal.py:274); ``in_units`` = width of queries / keys (default ``num_units``)."""
         super().__init__()
+        _check_head_dim(num_units, num_heads, num_events, "MAU")
         self.num_units, self.num_heads, self.num_events, self.dropout_rate = num_units, num_heads, num_events, dropout_rate
+        self.scope = scope
+        in_units = num_units if in_units is None else in_units
         dh = num_units // num_heads
         self.q_kernel = nn.Parameter(glorot_uniform_(torch.empty(in_units, num_units), gen))        # dense
         self.q_bias = nn.Parameter(torch.zeros(num_units))

@@ -745,3 +745,66 @@ class FFTailFn(torch.autograd.Function):
 
 def ff_tail(a, b, ids, drop: Drop):
     return FFTailFn.apply(a, b, ids, drop)
+
+
+# ------------------------------------------------------------------------------------------------
+# operator-level forms of src/module/coding.py (called on their own, outside the fused model kernels)
+# ------------------------------------------------------------------------------------------------
+class EmbeddingFn(torch.autograd.Function):
+    """Embedding.__call__ (coding.py:60-64): scale * table[ids] with the zero-padded row 0 (edgl_embedding_fwd/bwd).
+    table_c is the compute copy of the table (the f32 master, or its bf16 shadow); the gradient goes to the master."""
+
+    @staticmethod
+    def forward(ctx, table_master, table_c, ids, zero_pad, scale):
+        ids = ids.contiguous()
+        rows, C = table_c.shape
+        out = torch.empty(tuple(ids.shape) + (C,), device=ids.device, dtype=table_c.dtype)
+        check(lib.edgl_embedding_fwd(_ptr(ids), ids.numel(), _ptr(table_c), rows, C, int(bool(zero_pad)), float(scale), _ptr(out),
+                                     _code(table_c), _stream()), "edgl_embedding_fwd")
+        ctx.save_for_backward(ids)
+        ctx.meta = (rows, C, int(bool(zero_pad)), float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (ids,) = ctx.saved_tensors
+        rows, C, zero_pad, scale = ctx.meta
+        d_out = d_out.contiguous()
+        d_table = torch.empty((rows, C), device=d_out.device, dtype=torch.float32)
+        check(lib.edgl_embedding_bwd(_ptr(ids), ids.numel(), _ptr(d_out), rows, C, zero_pad, scale, _ptr(d_table), _code(d_out),
+                                     _stream()), "edgl_embedding_bwd")
+        return d_table, None, None, None, None
+
+
+def time_sinusoid(x: torch.Tensor, tscale: torch.Tensor, num_units: int, dtype=torch.float32) -> torch.Tensor:
+    """TimeSinusoidCoding.code (coding.py:137-149): x [B,T] -> [B,T,C], sin on even / cos on odd channels."""
+    x = x.to(torch.float32).contiguous()
+    out = torch.empty(tuple(x.shape) + (num_units,), device=x.device, dtype=dtype)
+    check(lib.edgl_time_sinusoid(_ptr(x), x.numel(), _ptr(tscale), num_units, _ptr(out), _DT[dtype], _stream()),
+          "edgl_time_sinusoid")
+    return out
+
+
+class TimeFunctionFn(torch.autograd.Function):
+    """TimeFunctionCoding.code (coding.py:113-122): cos(x[..., None] * basis_freq + phase)."""
+
+    @staticmethod
+    def forward(ctx, x, freq, phase, dtype):
+        x = x.to(torch.float32).contiguous()
+        C = freq.shape[0]
+        out = torch.empty(tuple(x.shape) + (C,), device=x.device, dtype=dtype)
+        check(lib.edgl_time_function_fwd(_ptr(x), x.numel(), _ptr(freq), _ptr(phase), C, _ptr(out), _DT[dtype], _stream()),
+              "edgl_time_function_fwd")
+        ctx.save_for_backward(x, freq, phase)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, freq, phase = ctx.saved_tensors
+        C = freq.shape[0]
+        d_out = d_out.contiguous()
+        both = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(int(lib.edgl_time_function_bwd_workspace(C)), device=x.device, dtype=torch.float32)
+        check(lib.edgl_time_function_bwd(_ptr(x), x.numel(), _ptr(freq), _ptr(phase), C, _ptr(d_out), _ptr(both[:C]),
+                                         _ptr(both[C:]), _ptr(ws), _code(d_out), _stream()), "edgl_time_function_bwd")
+        return None, both[:C], both[C:], None

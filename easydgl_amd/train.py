@@ -34,7 +34,9 @@ def args(argv=None):
     p.add_argument("--test", required=True)
     p.add_argument("--model", required=True, help="algorithm name: EasyDGL, CTSMA, TGAT or TiSASREC (util.ranking keys)")
     p.add_argument("--num_items", type=int, required=True)
-    p.add_argument("--num_units", type=int, default=50)
+    # reference default: 50 (main.py:30); the MFMA kernels need num_units / num_heads to be a multiple of 16, so the default
+    # here is the nearest supported width (every published recipe passes --num_units=512 explicitly, runme.sh:15-115)
+    p.add_argument("--num_units", type=int, default=64)
     p.add_argument("--num_heads", type=int, default=1)
     p.add_argument("--num_blocks", type=int, default=3)
     p.add_argument("--seqslen", type=int, default=30)
@@ -186,6 +188,9 @@ def run(FLAGS) -> Dict[str, float]:
     logging.info("3. train and evaluate model")
     for epoch in range(FLAGS.num_epochs):
         order = rng.permutation(len(tr_i))
+        # streaming epoch mean of the step losses, as tf.metrics.mean feeds EarlyStopping in the reference (Base.py:133-134,
+        # main.py:119-122); accumulated on the device, read back every 10 batches for the NaN test and once per epoch
+        loss_sum = torch.zeros((), device="cuda", dtype=torch.float64)
         running_loss, nb = float("nan"), 0
         for lo in range(0, len(order), bs):
             idx = order[lo:lo + bs]
@@ -200,18 +205,25 @@ def run(FLAGS) -> Dict[str, float]:
                 loss = engine.step(feats, labels)
             elif not masked and getattr(FLAGS, "graph", False) and len(idx) == bs:
                 if gstep is None:
+                    # the warm-up step that precedes the capture IS this batch's optimizer step: no replay for it
                     gstep = model.graphed_train_step(feats, labels, warmup=1)
-                loss = gstep(feats, labels)
+                    loss = gstep.warmup_loss
+                else:
+                    loss = gstep(feats, labels)
             else:
                 loss = model.train_step(feats, labels)
             nb += 1
+            loss_sum += loss.reshape(()).double()
             if nb % 10 == 0 or lo + bs >= len(order):
-                running_loss = float(loss)
+                running_loss = float(loss_sum) / nb
                 if math.isnan(running_loss):
                     break
         logging.info("%03d: Loss=%.4f", epoch, running_loss)
         if hasattr(model, "check_inputs"):
             model.check_inputs()
+        if math.isnan(running_loss):      # util.py:29-30: a NaN loss stops the run, whatever eval_per_steps says
+            stopper.step(running_loss, 0.0, {}, {})
+            break
         if epoch % FLAGS.eval_per_steps:
             continue
         vl = evaluate(model, vl_i, vl_t, bs, FLAGS.mask_seen)

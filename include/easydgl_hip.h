@@ -251,7 +251,9 @@ int edgl_rank_metrics(const int32_t* topk_idx, int R, int K, const int64_t* labe
  * After edgl_reduce_defer(1, stream) those reductions are queued on the calling host thread instead
  * of launched, and edgl_reduce_flush(stream) (or edgl_reduce_defer(0, stream)) runs all of them in
  * one launch.  While deferred, every call must be given its OWN workspace, kept until the flush,
- * and the gradient outputs are not valid before it.  Accumulating calls flush and run immediately. */
+ * and the gradient outputs are not valid before it.  Accumulating calls flush and run immediately.
+ * edgl_reduce_defer(-1, stream) is the error exit: it drops the queued jobs WITHOUT launching them and
+ * leaves deferred mode (a caller whose launch sequence failed half-way must not leave the thread deferred). */
 int edgl_reduce_defer(int on, void* stream);
 int edgl_reduce_flush(void* stream);
 
@@ -369,6 +371,31 @@ int edgl_tiattn_bwd(const void* q, int ldq, const void* k, int ldk, const void* 
 /* out[b,t,:] = kv[b,t,:] + concat(posK[t], posV[t]); kv, out [B,T,2C] `dtype`, posK/posV f32 [>=T, C]. */
 int edgl_add_pos2(const void* kv, const float* posK, const float* posV, int B, int T, int C, void* out, int dtype,
                   void* stream);
+
+/* ---- operator-level forms of src/module/coding.py (the classes' own __call__ / code methods) ------
+ * The model kernels fuse these (edgl_encode_fwd, edgl_embed_pos_fwd, edgl_timefn_fwd, edgl_tiattn_fwd); the entry
+ * points below are what `C.Embedding(...)(ids)`, `C.PositionCoding(...).code(x)`, `C.TimeIntervalCoding(...).code(x)`,
+ * `C.TimeSinusoidCoding(C).code(x)` and `C.TimeFunctionCoding(C).code(x)` bind to when called on their own.
+ * edgl_embedding_fwd — Embedding.__call__, coding.py:60-64: out[r,:] = scale * table[ids[r],:] over n flat indices;
+ *   table [rows, C] in `dtype`; zero_pad != 0: row 0 acts as a zero constant (coding.py:56-57); an index outside
+ *   [0, rows) reads zeros (tf.nn.embedding_lookup on the GPU).  scale = sqrt(num_units) or 1 (coding.py:62-63).
+ *   PositionCoding.code (coding.py:76-79) is this gather on ids = tile(range(T)); TimeIntervalCoding.code
+ *   (coding.py:93-94) on the integer intervals.
+ * edgl_embedding_bwd: d_table f32 [rows, C] (overwritten) += scale * d_out at the gathered rows.
+ * edgl_time_sinusoid — TimeSinusoidCoding.code, coding.py:137-149: x f32 [n]; out[r, 2j] = sin(x[r] / tscale[j]),
+ *   out[r, 2j+1] = cos(same); tscale f32 [C/2] = 10000^(2j/C) (coding.py:134).
+ * edgl_time_function_fwd — TimeFunctionCoding.code, coding.py:113-122: out[r, c] = cos(x[r] * freq[c] + phase[c]).
+ * edgl_time_function_bwd: d_freq, d_phase f32 [C] (overwritten); workspace: edgl_time_function_bwd_workspace(C) floats. */
+int edgl_embedding_fwd(const int64_t* ids, long n, const void* table, int rows, int C, int zero_pad, float scale, void* out,
+                       int dtype, void* stream);
+int edgl_embedding_bwd(const int64_t* ids, long n, const void* d_out, int rows, int C, int zero_pad, float scale,
+                       float* d_table, int dtype, void* stream);
+int edgl_time_sinusoid(const float* x, long n, const float* tscale, int C, void* out, int dtype, void* stream);
+int edgl_time_function_fwd(const float* x, long n, const float* freq, const float* phase, int C, void* out, int dtype,
+                           void* stream);
+long edgl_time_function_bwd_workspace(int C);
+int edgl_time_function_bwd(const float* x, long n, const float* freq, const float* phase, int C, const void* d_out,
+                           float* d_freq, float* d_phase, float* workspace, int dtype, void* stream);
 
 #ifdef __cplusplus
 }
