@@ -1,0 +1,463 @@
+// K3 backward sweep kernels (X and Z of k_bimau_bwd.hip's three passes), shared by k_bimau_bwd.hip (head dims 16 / 32) and
+// k_bimau_big.hip (head dims 64 / 128, where the intensity MLP backward runs as two GEMM-shaped kernels in between).
+#pragma once
+#include "bimau_common.h"
+
+#ifdef EDGL_PHASE_TIMING
+extern __device__ unsigned long long g_phase_cycles[16];
+#endif
+
+namespace bimau {
+
+
+constexpr int KY_ECH = 8;        // marks per workgroup row of kernel Y (gridDim.y = 16 / KY_ECH dH partials)
+constexpr int KY_NY = EP / KY_ECH;
+constexpr int KY_BLOCKS = 256;   // workgroups of kernel Y per mark group (x KY_NY = one resident round at 2 WGs/CU)
+
+struct BwdP {
+    const void* qkvt; const int64_t* ids; const float* spans; const uint8_t* marks; const char* pack;
+    const void* d_out; const float* d_lam_ext; const float* lam; const float* z; const void* hin;
+    int B, T, C, H, E;
+    float rate; const uint64_t* rng; uint32_t stream_id;
+    void* d_qkvt;
+    float* dz_ws; float* dh_ws; float* rowdot_ws; float* dsc_part; float* wpart;
+    int waves;
+    int flags;   // MAU_CAUSAL | MAU_NO_DIAG
+};
+
+template <typename T>
+__device__ __forceinline__ void st_frag(T* dst, const f32x4& a) {
+    Frag4<T> f = frag_from_acc<T>(a);
+    if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&f);
+    else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&f);
+}
+
+// dropout keep-factors of the 4 elements (k = kt*16 + g4 + r) of one key tile: the paired hash of the forward kernel
+__device__ __forceinline__ void drop_factors(const DropKey& dk, uint32_t base, float (&facs)[4]) {
+    facs[0] = facs[1] = facs[2] = facs[3] = 1.0f;
+    if (dk.thresh != 0u) {
+        const uint32_t h0 = drop_hash_pair(dk, base), h1 = drop_hash_pair(dk, base + 2);
+        facs[0] = (h0 & 0xffffu) >= dk.t16 ? dk.scale : 0.f;
+        facs[1] = (h0 >> 16) >= dk.t16 ? dk.scale : 0.f;
+        facs[2] = (h1 & 0xffffu) >= dk.t16 ? dk.scale : 0.f;
+        facs[3] = (h1 >> 16) >= dk.t16 ? dk.scale : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// X) sweep 1
+// ------------------------------------------------------------------------------------------------------------------
+// PREF: fetch the next query tile's operands one iteration ahead (head dims <= 32); at head dims 64 / 128 the doubled
+// operand set would not fit the register file, so the next tile is fetched at the end of the iteration instead.
+template <typename T, int DT, int NT, int EC, bool PREF = true>
+__global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
+    constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int E = EC ? EC : p.E;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long job = (long)blockIdx.x * p.waves + wave;
+    if (job >= (long)p.B * p.H) return;
+    const int b = (int)(job / p.H), head = (int)(job % p.H);
+    const long bp = (long)head * p.B + b;
+    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+
+    // wave-private LDS: K, V row-major [Tp][dh], marks [Tp][16] (+ transposed marks for f32), additive key mask
+    constexpr bool TR = sizeof(T) == 2;
+    constexpr size_t EXTRA = TR ? 0 : (size_t)EP * LDT;
+    constexpr size_t MASK_ELEMS = (size_t)Tp * sizeof(float) / sizeof(T);
+    constexpr size_t WAVE_ELEMS = 2 * (size_t)Tp * dh + (size_t)Tp * EP + EXTRA + MASK_ELEMS;
+    T* Ks = reinterpret_cast<T*>(smem) + (size_t)wave * WAVE_ELEMS;
+    T* Vs = Ks + Tp * dh;
+    T* Ms = Vs + Tp * dh;
+    T* MTs = Ms + Tp * EP;   // f32 only
+    const T* qkvt = reinterpret_cast<const T*>(p.qkvt) + (long)b * p.T * 4 * p.C;
+    const T* dout = reinterpret_cast<const T*>(p.d_out) + (long)b * p.T * p.C;
+    T* dqkvt = reinterpret_cast<T*>(p.d_qkvt) + (long)b * p.T * 4 * p.C;
+    const int ldq = 4 * p.C;
+    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, nullptr, LDT, lane);
+    stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, Vs, nullptr, LDT, lane);
+    stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, TR ? nullptr : MTs, LDT, lane);
+    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ks + WAVE_ELEMS - MASK_ELEMS));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const PackDims pd = pack_dims<T>(dh, E);
+    const float* iscs_g = reinterpret_cast<const float*>(p.pack + pd.off_f32) + 3 * pd.JE + EP;   // 1 / exp(scaling)
+    float isc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) isc[i] = iscs_g[g4 + i];
+
+    const float cscale = rsqrtf((float)dh);
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 dVa[DT][NT];  // L(first=v, second=k)
+#pragma unroll
+    for (int u = 0; u < DT; ++u)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) dVa[u][kt] = zero4;
+    float dsc_acc[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // Per-query-tile global operands are fetched one tile ahead.  The loads are unconditional (row / mark index clamped)
+    // so that the prefetch is straight-line code: with per-lane branches around them the wait-count insertion falls
+    // back to near-zero counts and every iteration would stall on the loads it has just issued.  Lanes past the end of
+    // the sequence (or marks >= E) are zeroed when the values are consumed.
+    struct QOps { Frag4<T> qf[DT], dof[DT]; float4 z; float lam[4], dlx[4]; };
+    const float* dlx_src = p.d_lam_ext ? p.d_lam_ext : p.lam;   // always a readable [rows, E] array
+    const float dlx_on = p.d_lam_ext ? 1.0f : 0.0f;
+    auto load_q = [&](int qt) {
+        QOps o;
+        const int q = min(qt * 16 + l15, p.T - 1);
+        const long row = bp * p.T + q;
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) {
+            o.qf[ub] = frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4);
+            o.dof[ub] = frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4);
+        }
+        o.z = *reinterpret_cast<const float4*>(p.z + row * EP + g4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = EC == 16 ? g4 + i : min(g4 + i, E - 1);
+            o.lam[i] = p.lam[row * E + e];
+            o.dlx[i] = dlx_src[row * E + e];
+        }
+        return o;
+    };
+    // zero what a lane past the sequence end (or a mark >= E) must not contribute
+    auto mask_q = [&](QOps& o, bool ok) {
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub)
+            if (!ok) o.dof[ub] = frag_zero<T>();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool oke = ok && (EC == 16 || (g4 + i) < E);
+            o.lam[i] = oke ? o.lam[i] : 0.f;
+            o.dlx[i] = oke ? o.dlx[i] * dlx_on : 0.f;
+        }
+    };
+    PH_DECL
+    QOps qcur = load_q(0);
+    // Results of a query tile are stored at the TOP of the next iteration: the loop-carried prefetch makes the compiler
+    // drain vmcnt to 0 on the back edge, and a store issued just before it would expose its full write latency there.
+    float pend_dz[4] = {0.f, 0.f, 0.f, 0.f}, pend_rowdot = 0.f;
+    int pend_q = p.T;   // >= T: nothing pending
+    auto flush_pending = [&]() {
+        if (pend_q < p.T) {
+            *reinterpret_cast<float4*>(p.dz_ws + (bp * p.T + pend_q) * EP + g4) = make_float4(pend_dz[0], pend_dz[1], pend_dz[2], pend_dz[3]);
+            if (lane < 16) p.rowdot_ws[bp * p.T + pend_q] = pend_rowdot;
+        }
+    };
+    for (int qt = 0; qt < NT; ++qt) {
+        asm volatile("" ::: "memory");   // keep loop-invariant LDS operands from being hoisted into registers
+        const int q = qt * 16 + l15;
+        const bool qok = q < p.T;
+        flush_pending();
+        QOps qnext;
+        if constexpr (PREF) qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
+        asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
+        mask_q(qcur, qok);
+        const float zq4[4] = {qcur.z.x, qcur.z.y, qcur.z.z, qcur.z.w};
+        // ---- recompute S, P --------------------------------------------------------------------------------------
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 a = zero4;
+#pragma unroll
+            for (int ub = 0; ub < DT; ++ub)
+                a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
+            s[kt] = a;
+        }
+        masked_softmax<NT>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        PH_MARK(0);
+        Frag4<T> lf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lf.v[i] = from_f32<T>(qcur.lam[i]);
+        Frag4<T> dOT[DT];  // L(first=q, second=v): A operand contracting over q
+#pragma unroll
+        for (int vt = 0; vt < DT; ++vt) dOT[vt] = frag_from_acc<T>(mma16(qcur.dof[vt], ident, zero4));
+        // ---- G', dA, dG -> dlambda, row term, dV ------------------------------------------------------------------
+        float rowdot = 0.f;   // this lane's part of  sum_k dP1[q][k] P[q][k]
+        f32x4 dlamT = zero4;  // L(first=e, second=q)
+        const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);   // dropout element index of (b', q, k=0)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, zero4);
+            f32x4 da = zero4;
+#pragma unroll
+            for (int vb = 0; vb < DT; ++vb)
+                da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
+            f32x4 ap, dg, gv = gacc;
+            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {   // only this key tile can hold k == q: G' diag := 1 (temporal.py:438-439)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
+            }
+            float facs[4];
+            drop_factors(dk, dbase + kt * 16 + g4, facs);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = s[kt][r];
+                const float fp = facs[r] * pv;
+                ap[r] = gv[r] * fp;                         // A' = D*G'*P
+                dg[r] = da[r] * fp;                         // dG' = dA' * D * P
+                rowdot = fmaf(da[r] * facs[r] * gv[r], pv, rowdot);   // dP1 * P, dP1 = dA' * D * G'
+            }
+            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {   // set_diag blocks the gradient into lambda
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dg[r] = (g4 + r == l15) ? 0.f : dg[r];
+            }
+            dlamT = mma16(kfrag<T>(Ms, EP, MTs, LDT, kt * 16, 0, lane), frag_from_acc<T>(dg), dlamT);
+            const Frag4<T> apT = frag_from_acc<T>(transpose_tile<T>(ap, ident));  // L(first=q, second=k)
+#pragma unroll
+            for (int vt = 0; vt < DT; ++vt) dVa[vt][kt] = mma16(dOT[vt], apT, dVa[vt][kt]);
+            if (kt & 1) __builtin_amdgcn_sched_barrier(0);   // at most two key tiles' temporaries interleaved
+        }
+        PH_MARK(1);
+        // ---- dlambda -> dz, dscaling; row term --------------------------------------------------------------------
+        float dz4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float dl = dlamT[i] + qcur.dlx[i];
+            const float sg = sigmoid_f(zq4[i] * isc[i]);   // softplus'
+            dz4[i] = dl * sg;
+            if (qok && (EC == 16 || (g4 + i) < E)) dsc_acc[i] += dl * (qcur.lam[i] - zq4[i] * sg);
+        }
+        pend_rowdot = group_sum4(rowdot);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pend_dz[i] = dz4[i];
+        pend_q = q;
+        if constexpr (PREF) qcur = qnext;
+        else if (qt + 1 < NT) qcur = load_q(qt + 1);
+        PH_MARK(2);
+    }
+    flush_pending();
+    // ---- write dV (L(first=v, second=k): 4 consecutive channels of key row k) -----------------------------------------
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const int k = kt * 16 + l15;
+        if (k < p.T) {
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) st_frag<T>(dqkvt + (long)k * ldq + 2 * p.C + head * dh + ut * 16 + g4, dVa[ut][kt]);
+        }
+    }
+    // ---- dscaling partial: sum over the 16 query lanes ---------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = dsc_acc[i];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (l15 == 0) p.dsc_part[job * EP + g4 + i] = v;
+    }
+    PH_MARK(3);
+    PH_FLUSH(0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Z) sweep 2
+// ------------------------------------------------------------------------------------------------------------------
+// NYP: number of dH partial slabs the intensity backward left in dh_ws (KY_NY mark groups at head dims <= 32, 1 above)
+template <typename T, int DT, int NT, int EC, int NYP = KY_NY, bool PREF = true>
+__global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
+    constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int E = EC ? EC : p.E;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long job = (long)blockIdx.x * p.waves + wave;
+    if (job >= (long)p.B * p.H) return;
+    const int b = (int)(job / p.H), head = (int)(job % p.H);
+    const long bp = (long)head * p.B + b;
+    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+
+    // wave-private LDS: K, T_, V row-major [Tp][dh], marks [Tp][16]; f32 additionally K^T (no 32-bit transpose read)
+    constexpr bool TR = sizeof(T) == 2;
+    constexpr size_t EXTRA = TR ? 0 : (size_t)dh * LDT;
+    constexpr size_t MASK_ELEMS = (size_t)Tp * sizeof(float) / sizeof(T);
+    constexpr size_t WAVE_ELEMS = 3 * (size_t)Tp * dh + (size_t)Tp * EP + EXTRA + MASK_ELEMS;
+    T* Ks = reinterpret_cast<T*>(smem) + (size_t)wave * WAVE_ELEMS;
+    T* Ts = Ks + Tp * dh;
+    T* Vs = Ts + Tp * dh;
+    T* Ms = Vs + Tp * dh;
+    T* KTs = Ms + Tp * EP;   // f32 only
+    const T* qkvt = reinterpret_cast<const T*>(p.qkvt) + (long)b * p.T * 4 * p.C;
+    const T* dout = reinterpret_cast<const T*>(p.d_out) + (long)b * p.T * p.C;
+    const T* hin = reinterpret_cast<const T*>(p.hin);
+    T* dqkvt = reinterpret_cast<T*>(p.d_qkvt) + (long)b * p.T * 4 * p.C;
+    const int ldq = 4 * p.C;
+    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, TR ? nullptr : KTs, LDT, lane);
+    stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, Ts, nullptr, LDT, lane);
+    stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, Vs, nullptr, LDT, lane);
+    stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, nullptr, LDT, lane);
+    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ks + WAVE_ELEMS - MASK_ELEMS));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const float cscale = rsqrtf((float)dh);
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long R = (long)p.B * p.H * p.T;
+
+    f32x4 dKa[DT][NT], dTa[DT][NT];  // L(first=u, second=k)
+#pragma unroll
+    for (int u = 0; u < DT; ++u)
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) { dKa[u][kt] = zero4; dTa[u][kt] = zero4; }
+
+    // branch-free one-tile-ahead prefetch (see kernel X); kernel Y's dH partials are summed when consumed
+    struct QOps { Frag4<T> qf[DT], dof[DT], hf[DT]; float4 dHp[DT][NYP]; float lam[4], rowdot; };
+    auto load_q = [&](int qt) {
+        QOps o;
+        const int q = min(qt * 16 + l15, p.T - 1);
+        const long row = bp * p.T + q;
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) {
+            o.qf[ub] = frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4);
+            o.dof[ub] = frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4);
+            o.hf[ub] = frag_ld<T>(hin + row * dh + ub * 16 + g4);
+#pragma unroll
+            for (int y = 0; y < NYP; ++y)
+                o.dHp[ub][y] = *reinterpret_cast<const float4*>(p.dh_ws + ((long)y * R + row) * dh + ub * 16 + g4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.lam[i] = p.lam[row * E + (EC == 16 ? g4 + i : min(g4 + i, E - 1))];
+        o.rowdot = p.rowdot_ws[row];
+        return o;
+    };
+    PH_DECL
+    QOps qcur = load_q(0);
+    // dQ of a query tile is stored at the top of the next iteration (see kernel X: the back edge drains vmcnt)
+    Frag4<T> pend_dq[DT];
+    int pend_q = p.T;
+    auto flush_pending = [&]() {
+        if (pend_q < p.T) {
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) {
+                T* dst = dqkvt + (long)pend_q * ldq + head * dh + ut * 16 + g4;
+                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&pend_dq[ut]);
+                else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&pend_dq[ut]);
+            }
+        }
+    };
+#pragma unroll
+    for (int ut = 0; ut < DT; ++ut) pend_dq[ut] = frag_zero<T>();
+    for (int qt = 0; qt < NT; ++qt) {
+        asm volatile("" ::: "memory");
+        const int q = qt * 16 + l15;
+        const bool qok = q < p.T;
+        (void)qok;
+        flush_pending();
+        QOps qnext;
+        if constexpr (PREF) qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
+        asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
+        // consume the tile fetched one iteration ago; rows past the sequence end contribute nothing to dK / dT_
+        f32x4 dHq[DT];   // dH^T[u][q], L(first=u, second=q): sum of the mark-group partials in a fixed order
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) {
+            f32x4 a = zero4;
+#pragma unroll
+            for (int y = 0; y < NYP; ++y) {
+                a[0] += qcur.dHp[ub][y].x; a[1] += qcur.dHp[ub][y].y; a[2] += qcur.dHp[ub][y].z; a[3] += qcur.dHp[ub][y].w;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dHq[ub][r] = qok ? a[r] : 0.f;
+            if (!qok) qcur.dof[ub] = frag_zero<T>();
+        }
+        const float rowdot1 = qok ? qcur.rowdot : 0.f;
+        // ---- recompute S, P --------------------------------------------------------------------------------------
+        f32x4 s[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x4 a = zero4;
+#pragma unroll
+            for (int ub = 0; ub < DT; ++ub)
+                a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
+            s[kt] = a;
+        }
+        masked_softmax<NT>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        PH_MARK(0);
+        Frag4<T> lf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lf.v[i] = from_f32<T>((EC == 16 || (g4 + i) < E) ? qcur.lam[i] : 0.f);
+        // rowsum(dP*P) = sum_k dP1*P (kernel X) + sum_k P[q][k] (dH[q].T_[k]) = ... + dH[q].H[q]   (H = P.T_, saved)
+        float rowdot = 0.f;
+        Frag4<T> dhf[DT], QT[DT], dHT[DT];
+#pragma unroll
+        for (int ut = 0; ut < DT; ++ut) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rowdot = fmaf(dHq[ut][r], to_f32(qcur.hf[ut].v[r]), rowdot);
+            dhf[ut] = frag_from_acc<T>(dHq[ut]);
+            QT[ut] = frag_from_acc<T>(mma16(qcur.qf[ut], ident, zero4));            // L(first=q, second=u)
+            dHT[ut] = frag_from_acc<T>(transpose_tile<T>(dHq[ut], ident));
+        }
+        rowdot = group_sum4(rowdot) + rowdot1;
+        // ---- dP = dP1 + dH.T_^T ; dS = P*(dP - rowsum(dP*P)) * c ; dQ, dK, dT_ -------------------------------------
+        f32x4 dQ[DT];
+#pragma unroll
+        for (int ut = 0; ut < DT; ++ut) dQ[ut] = zero4;
+        const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, zero4);
+            f32x4 da = zero4;
+#pragma unroll
+            for (int vb = 0; vb < DT; ++vb)
+                da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
+            f32x4 gv = gacc;
+            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
+            }
+            float facs[4];
+            drop_factors(dk, dbase + kt * 16 + g4, facs);
+            f32x4 a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = da[r] * facs[r] * gv[r];   // dP1 (same expression as kernel X)
+#pragma unroll
+            for (int ub = 0; ub < DT; ++ub)
+                a = mma16(frag_ld<T>(Ts + (kt * 16 + l15) * dh + ub * 16 + g4), dhf[ub], a);
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // tf.where(mask==0, paddings, S) (temporal.py:425-426) passes no gradient to a padded key's
+                // score; P is non-zero there only for fully padded rows (uniform softmax)
+                const bool padded = ((km.pad >> (kt * 4 + r)) & 1ull) || ((p.flags & MAU_CAUSAL) && kt * 16 + g4 + r > q);
+                ds[r] = padded ? 0.f : s[kt][r] * (a[r] - rowdot) * cscale;
+            }
+            const Frag4<T> dsf = frag_from_acc<T>(ds);
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut)
+                dQ[ut] = mma16(kfrag<T>(Ks, dh, KTs, LDT, kt * 16, ut * 16, lane), dsf, dQ[ut]);
+            const Frag4<T> dsT = frag_from_acc<T>(transpose_tile<T>(ds, ident));
+            const Frag4<T> pT = frag_from_acc<T>(transpose_tile<T>(s[kt], ident));
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) {
+                dKa[ut][kt] = mma16(QT[ut], dsT, dKa[ut][kt]);
+                dTa[ut][kt] = mma16(dHT[ut], pT, dTa[ut][kt]);
+            }
+        }
+#pragma unroll
+        for (int ut = 0; ut < DT; ++ut) pend_dq[ut] = frag_from_acc<T>(dQ[ut]);
+        pend_q = q;
+        if constexpr (PREF) qcur = qnext;
+        else if (qt + 1 < NT) qcur = load_q(qt + 1);
+        PH_MARK(1);
+    }
+    flush_pending();
+    // ---- write dK / dT_ (L(first=u, second=k): 4 consecutive channels of key row k) ----------------------------------
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const int k = kt * 16 + l15;
+        if (k < p.T) {
+#pragma unroll
+            for (int ut = 0; ut < DT; ++ut) {
+                T* row = dqkvt + (long)k * ldq + head * dh + ut * 16 + g4;
+                st_frag<T>(row + p.C, dKa[ut][kt]);
+                st_frag<T>(row + 3 * p.C, dTa[ut][kt]);
+            }
+        }
+    }
+    PH_MARK(2);
+    PH_FLUSH(8);
+}
+
+
+}  // namespace bimau

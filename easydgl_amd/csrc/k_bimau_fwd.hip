@@ -1,287 +1,9 @@
 // K3 forward: fused BiMAU attention — BiMAU.__call__ (temporal.py:404-452) with MAU.intensity
 // (temporal.py:281-315) inlined.  See bimau_common.h for the register-layout scheme.
-#include "bimau_common.h"
+#include "bimau_fwd_impl.h"
 
 namespace {
 using namespace bimau;
-
-struct FwdP {
-    const void* qkvt; const void* resid; int ld_res;
-    const int64_t* ids; const float* spans; const uint8_t* marks;
-    const char* pack;
-    int B, T, C, H, E;
-    float rate; const uint64_t* rng; uint32_t stream_id;
-    void* out; float* lam;
-    void* hin_out; float* z_out;   // saved for the backward (NULL: inference)
-    int waves;
-    int flags;   // MAU_CAUSAL | MAU_NO_DIAG
-};
-
-// DT = dh/16, NT = ceil(T/16); EC = compile-time mark count (16: all LDS offsets are immediates and the mark loop is
-// one straight-line block) or 0 (runtime p.E)
-template <typename T, int DT, int NT, int EC>
-__global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
-    constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int E = EC ? EC : p.E;
-    const PackDims pd = pack_dims<T>(dh, E);
-    // ---- workgroup-shared intensity weights -------------------------------------------------
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(p.pack);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int i = threadIdx.x; i < (int)(pd.bytes / 16); i += blockDim.x) dst[i] = src[i];
-    }
-    const T* W1T = reinterpret_cast<const T*>(smem);
-    const float* fW = reinterpret_cast<const float*>(smem + pd.off_f32);
-    const float* w1s = fW; const float* b1s = fW + pd.JE; const float* wvs = fW + 2 * pd.JE;
-    const float* scs = fW + 3 * pd.JE; const float* iscs = scs + EP;
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long job = (long)blockIdx.x * p.waves + wave;
-    if (job >= (long)p.B * p.H) return;
-    const int b = (int)(job / p.H), head = (int)(job % p.H);
-    const long bp = (long)head * p.B + b;  // head-major index b' (temporal.py:413-416)
-
-    // ---- wave-private LDS.  bf16: K, T_, V row-major [Tp][dh] + marks [Tp][16]; products that contract over the
-    //      KEY index fetch their operand with transpose reads (kfrag).  f32: T_ and V are staged transposed instead.
-    constexpr bool TR = sizeof(T) == 2;
-    constexpr size_t KV_ELEMS = TR ? (size_t)Tp * dh : (size_t)dh * LDT;
-    constexpr size_t MASK_ELEMS = (size_t)Tp * sizeof(float) / sizeof(T);   // additive key mask, f32 [Tp]
-    constexpr size_t WAVE_ELEMS = (size_t)Tp * dh + 2 * KV_ELEMS + (size_t)Tp * EP + MASK_ELEMS;
-    T* Ks = reinterpret_cast<T*>(smem + pd.bytes) + (size_t)wave * WAVE_ELEMS;
-    T* Ts = Ks + Tp * dh;       // T_ : row-major (bf16) or transposed [dh][LDT] (f32)
-    T* Vs = Ts + KV_ELEMS;      // V  : same
-    T* Ms = Vs + KV_ELEMS;
-    const T* qkvt = reinterpret_cast<const T*>(p.qkvt) + (long)b * p.T * 4 * p.C;
-    const int ldq = 4 * p.C;
-    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, nullptr, LDT, lane);           // K  (split order Q,K,V,T: temporal.py:410)
-    stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Ts : nullptr, TR ? nullptr : Ts, LDT, lane);   // T_
-    stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Vs : nullptr, TR ? nullptr : Vs, LDT, lane);   // V
-    stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, nullptr, LDT, lane);
-    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ms + Tp * EP));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    const float cscale = rsqrtf((float)dh);
-    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
-    const int g4 = (lane >> 4) * 4, l15 = lane & 15;
-
-    // per-query-tile global operands (Q rows, interval, residual rows) are fetched one tile ahead: their HBM/L2 latency
-    // overlaps the previous tile's compute instead of opening every iteration with a stall
-    struct QOps { Frag4<T> qf[DT], rf[DT]; float span; };
-    auto load_q = [&](int qt) {   // unconditional (row clamped): branch-free, so the wait counts around it stay exact
-        QOps o;
-        const int q = min(qt * 16 + l15, p.T - 1);
-#pragma unroll
-        for (int ub = 0; ub < DT; ++ub) {
-            o.qf[ub] = frag_ld<T>(qkvt + (long)q * ldq + head * dh + ub * 16 + g4);
-            o.rf[ub] = frag_ld<T>(reinterpret_cast<const T*>(p.resid) + ((long)b * p.T + q) * p.ld_res + head * dh + ub * 16 + g4);
-        }
-        o.span = p.spans[(long)b * p.T + q];
-        return o;
-    };
-    QOps qcur = load_q(0);
-    // The output rows of a query tile (computed last) are stored at the TOP of the next iteration: the loop-carried
-    // prefetch makes the compiler drain vmcnt to 0 on the back edge, and a store issued just before it would expose its
-    // full write latency there.  (H rows, z and lambda are stored mid-iteration and have landed by then.)
-    Frag4<T> pend_o[DT];
-#pragma unroll
-    for (int ut = 0; ut < DT; ++ut) pend_o[ut] = frag_zero<T>();
-    int pend_q = p.T;   // >= T: nothing pending
-    auto flush_pending = [&]() {
-        if (pend_q < p.T) {
-#pragma unroll
-            for (int ut = 0; ut < DT; ++ut) {
-                T* dst = reinterpret_cast<T*>(p.out) + ((long)b * p.T + pend_q) * p.C + head * dh + ut * 16 + g4;
-                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&pend_o[ut]);
-                else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&pend_o[ut]);
-            }
-        }
-    };
-    for (int qt = 0; qt < NT; ++qt) {
-        const int q = qt * 16 + l15;
-        const bool qok = q < p.T;
-        flush_pending();
-        const QOps qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
-        asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
-        // ---- S^T[k][q] = sum_u K[k][u] Q[q][u] ------------------------------------------------
-        Frag4<T> qf[DT];
-#pragma unroll
-        for (int ub = 0; ub < DT; ++ub) qf[ub] = qcur.qf[ub];
-        f32x4 s[NT];
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
-            s[kt] = a;
-        }
-        masked_softmax<NT>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s := P^T
-        // ---- H^T[u][q] = sum_k T_[k][u] P[q][k] -----------------------------------------------
-        Frag4<T> pf[NT];
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) pf[kt] = frag_from_acc<T>(s[kt]);
-        Frag4<T> hf[DT];
-#pragma unroll
-        for (int ut = 0; ut < DT; ++ut) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
-                a = mma16(kfrag<T>(Ts, dh, Ts, LDT, kt * 16, ut * 16, lane), pf[kt], a);
-            hf[ut] = frag_from_acc<T>(a);
-            if (p.hin_out && qok) {   // H rows in the activation dtype: exactly what the intensity MLP consumed
-                T* dst = reinterpret_cast<T*>(p.hin_out) + (bp * p.T + q) * dh + ut * 16 + g4;
-                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&hf[ut]);
-                else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&hf[ut]);
-            }
-        }
-        // ---- intensity MLP (temporal.py:287-306): Zpre^T[j][q], channel j = e*dh + u' ------------
-        const float span = qcur.span;
-        float zp[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) zp[e] = 0.f;
-        // operands of channel tile jt: W1T rows (A operand), interval weight, bias, output weight.  The tile after the
-        // one being computed is always in flight (explicit double buffer: the LDS latency hides behind one tile of
-        // MFMA + sigmoid work instead of stalling every tile).
-        struct MlpOps { Frag4<T> w[DT]; float4 ws, bs, wv; };
-        auto load_ops = [&](int jt) {
-            MlpOps o;
-#pragma unroll
-            for (int ub = 0; ub < DT; ++ub) o.w[ub] = frag_ld<T>(W1T + (jt * 16 + l15) * pd.LDW + ub * 16 + g4);
-            o.ws = *reinterpret_cast<const float4*>(w1s + jt * 16 + g4);
-            o.bs = *reinterpret_cast<const float4*>(b1s + jt * 16 + g4);
-            o.wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
-            return o;
-        };
-        MlpOps cur = load_ops(0);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (EC == 16 || e < E) {
-#pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    const int jt = e * DT + d;
-                    const MlpOps nxt = load_ops(jt + 1 < E * DT ? jt + 1 : jt);
-                    EDGL_PIN();   // keep the prefetch at the top of this tile's work
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ub = 0; ub < DT; ++ub) a = mma16(cur.w[ub], hf[ub], a);
-                    // (span*ws + a) + bs: chained on the MFMA result so that nothing of this tile can be hoisted into the
-                    // prefetch slot above (which would wait on the loads just issued)
-                    zp[e] += sigmoid_pre(fmaf(span, cur.ws.x, a[0]) + cur.bs.x) * cur.wv.x + sigmoid_pre(fmaf(span, cur.ws.y, a[1]) + cur.bs.y) * cur.wv.y +
-                             sigmoid_pre(fmaf(span, cur.ws.z, a[2]) + cur.bs.z) * cur.wv.z + sigmoid_pre(fmaf(span, cur.ws.w, a[3]) + cur.bs.w) * cur.wv.w;
-                    cur = nxt;
-                    EDGL_PIN();
-                }
-            }
-        }
-        float z4[4];
-        reduce_scatter16(zp, z4, lane);  // lane group g now owns e = 4g + i
-        if (p.z_out && qok) *reinterpret_cast<float4*>(p.z_out + (bp * p.T + q) * EP + g4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
-        Frag4<T> lf;
-        float lam4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float sc = scs[g4 + i], isc = iscs[g4 + i];
-            lam4[i] = sc * __logf(1.0f + __expf(z4[i] * isc));  // temporal.py:305-306
-            lf.v[i] = from_f32<T>(lam4[i]);
-        }
-        if (qok) {
-            float* dst = p.lam + (bp * p.T + q) * E + g4;
-            if constexpr (EC == 16) {
-                *reinterpret_cast<float4*>(dst) = make_float4(lam4[0], lam4[1], lam4[2], lam4[3]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (g4 + i < E) dst[i] = lam4[i];
-            }
-        }
-        // ---- G^T[k][q] = sum_e marks[k][e] lam[q][e]; diag := 1; A' = dropout(G * P) ------------
-        const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);   // element index of (b', q, k=0); < 2^32 (host-checked)
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, f32x4{0.f, 0.f, 0.f, 0.f});
-            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {   // only this key tile can contain k == q (temporal.py:438-439)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gacc[r] = (g4 + r == l15) ? 1.0f : gacc[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[kt][r] = gacc[r] * s[kt][r];     // temporal.py:441
-            if (dk.thresh != 0u) {                                          // temporal.py:442
-                const uint32_t h0 = drop_hash_pair(dk, dbase + kt * 16 + g4), h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2);
-                s[kt][0] = (h0 & 0xffffu) >= dk.t16 ? s[kt][0] * dk.scale : 0.f;
-                s[kt][1] = (h0 >> 16) >= dk.t16 ? s[kt][1] * dk.scale : 0.f;
-                s[kt][2] = (h1 & 0xffffu) >= dk.t16 ? s[kt][2] * dk.scale : 0.f;
-                s[kt][3] = (h1 >> 16) >= dk.t16 ? s[kt][3] * dk.scale : 0.f;
-            }
-            pf[kt] = frag_from_acc<T>(s[kt]);
-        }
-        // ---- O^T[v][q] = sum_k V[k][v] A'[q][k]; + residual (temporal.py:443-447) ----------------
-#pragma unroll
-        for (int vt = 0; vt < DT; ++vt) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
-                a = mma16(kfrag<T>(Vs, dh, Vs, LDT, kt * 16, vt * 16, lane), pf[kt], a);
-            const Frag4<T> rf = qcur.rf[vt];
-            f32x4 o4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o4[r] = a[r] + to_f32(rf.v[r]);
-            pend_o[vt] = frag_from_acc<T>(o4);
-        }
-        pend_q = q;
-        qcur = qnext;
-    }
-    flush_pending();
-}
-
-template <typename T, int DT, int NT, int EC>
-int launch_fwd_e(FwdP p, hipStream_t st) {
-    constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
-    const PackDims pd = pack_dims<T>(dh, p.E);
-    const size_t wave_bytes = ((size_t)Tp * dh + 2 * (sizeof(T) == 2 ? (size_t)Tp * dh : (size_t)dh * LDT) + (size_t)Tp * EP) * sizeof(T) +
-                              (size_t)Tp * sizeof(float);
-    int waves = 4;
-    while (waves > 1 && pd.bytes + waves * wave_bytes > 80 * 1024) waves >>= 1;
-    const size_t smem = pd.bytes + waves * wave_bytes;
-    EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_fwd: needs %zu B of LDS (dh=%d E=%d T=%d)", smem, dh,
-                 p.E, p.T);
-    p.waves = waves;
-    auto kern = bimau_fwd_kernel<T, DT, NT, EC>;
-    if (smem > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    const long jobs = (long)p.B * p.H;
-    hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
-    EDGL_LAUNCH_CHECK();
-    return EDGL_OK;
-}
-
-template <typename T, int DT, int NT>
-int launch_fwd(FwdP p, hipStream_t st) {
-    return p.E == 16 ? launch_fwd_e<T, DT, NT, 16>(p, st) : launch_fwd_e<T, DT, NT, 0>(p, st);
-}
-
-template <typename T, int DT>
-int dispatch_nt(FwdP p, hipStream_t st) {
-    const int nt = (p.T + 15) / 16;
-    switch (nt) {
-        case 1: return launch_fwd<T, DT, 1>(p, st);
-        case 2: return launch_fwd<T, DT, 2>(p, st);
-        case 3: return launch_fwd<T, DT, 3>(p, st);
-        case 4: return launch_fwd<T, DT, 4>(p, st);
-        case 5: return launch_fwd<T, DT, 5>(p, st);
-        case 6: return launch_fwd<T, DT, 6>(p, st);
-        case 7: return launch_fwd<T, DT, 7>(p, st);
-        case 8: return launch_fwd<T, DT, 8>(p, st);
-        case 9: return launch_fwd<T, DT, 9>(p, st);
-        case 10: return launch_fwd<T, DT, 10>(p, st);
-        case 11: return launch_fwd<T, DT, 11>(p, st);
-        case 12: return launch_fwd<T, DT, 12>(p, st);
-        case 13: return launch_fwd<T, DT, 13>(p, st);
-    }
-    edgl_set_error("edgl_bimau_fwd: T=%d not supported (T <= 208)", p.T);
-    return EDGL_ERR_SHAPE;
-}
 
 template <typename T>
 int dispatch_dt(FwdP p, hipStream_t st) {

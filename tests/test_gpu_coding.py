@@ -1,0 +1,165 @@
+"""Operator-level API of SURVEY §8(b): the classes of src/module/coding.py and T.BiMAU called on their own, with the
+reference's constructor signatures and methods, against the oracle's functions (coding.py:45-149, temporal.py:401-452)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import easydgl_oracle as O
+from oracle import torch_ref as R
+from tests._util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-6), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("zero_pad,scale", [(True, True), (False, False), (True, False)])
+def test_embedding_call_and_gradient(dt, tol, zero_pad, scale):
+    """C.Embedding(vocab, units, l2, zero_pad, scale)(ids) — coding.py:45-64."""
+    from easydgl_amd.module import coding as C
+    V, U = 37, 64
+    emb = C.Embedding(V, U, 0.0, zero_pad=zero_pad, scale=scale, gen=_gen(1)).cuda()
+    if dt != torch.float32:
+        shadow = emb.lookup_table.detach().to(dt)
+        emb.compute = lambda p: shadow
+    rng = np.random.default_rng(0)
+    ids = rng.integers(0, V, size=(5, 9))
+    ids[0, :3] = 0
+    out = emb(torch.tensor(ids).cuda())
+    tab = emb.compute(emb.lookup_table).detach().double().cpu().numpy()
+    want = (O.zero_padded(tab) if zero_pad else tab)[ids] * (U ** 0.5 if scale else 1.0)
+    assert out.shape == (5, 9, U) and out.dtype == dt
+    assert_close(out.detach().float().cpu().numpy(), want, tol, "embedding")
+    G = torch.randn(out.shape, generator=_gen(2)).to(dt).cuda()
+    out.backward(G)
+    d = np.zeros((V, U))
+    np.add.at(d, ids.reshape(-1), G.double().cpu().numpy().reshape(-1, U) * (U ** 0.5 if scale else 1.0))
+    if zero_pad:
+        d[0] = 0
+    assert_close(emb.lookup_table.grad.cpu().numpy(), d, 1e-5, "d_table")
+    # an index past the table reads zeros (the reference's GPU lookup; TiSASREC.py:59 relies on it)
+    far = emb(torch.tensor([[V, V + 3]]).cuda())
+    assert float(far.detach().float().abs().max()) == 0.0
+
+
+def test_position_coding_code_and_call():
+    """C.PositionCoding(vocab, units).code(x) / (x) — coding.py:67-79."""
+    from easydgl_amd.module import coding as C
+    pc = C.PositionCoding(21, 32, 0.0, gen=_gen(3)).cuda()
+    x = torch.randn((4, 13, 32), generator=_gen(4)).cuda()
+    code = pc.code(x)
+    tab = pc.pembs.lookup_table.detach().cpu().numpy()
+    want = np.broadcast_to(tab[:13][None], (4, 13, 32))
+    np.testing.assert_array_equal(code.detach().cpu().numpy(), want)
+    both = pc(x)
+    assert both.shape == (4, 13, 64)
+    np.testing.assert_array_equal(both[..., :32].detach().cpu().numpy(), x.cpu().numpy())
+    np.testing.assert_array_equal(both[..., 32:].detach().cpu().numpy(), want)
+    code.sum().backward()
+    g = pc.pembs.lookup_table.grad.cpu().numpy()
+    assert np.allclose(g[:13], 4.0) and np.allclose(g[13:], 0.0)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 5e-7), (torch.bfloat16, 5e-3)])
+def test_time_sinusoid_code(dt, tol):
+    """C.TimeSinusoidCoding(units).code(x[B,T]) — coding.py:125-149, at Netflix-scale arguments and at 0."""
+    from easydgl_amd.module import coding as C
+    tc = C.TimeSinusoidCoding(128).cuda()
+    tc.act_dtype = dt
+    cfg = O.Config(num_items=10, seqslen=40, num_units=128, num_heads=8, time_scale=86400.0, num_events=2)
+    _, ts = O.synthetic_sequences(cfg, 3, np.random.default_rng(2), min_len=30)
+    x32 = O.scaled_times(ts, cfg.time_scale)
+    got = tc.code(torch.tensor(x32).cuda())
+    want = O.time_sinusoid_code(x32, 128)
+    assert got.shape == (3, 41, 128)
+    assert np.abs(got.float().cpu().numpy() - want).max() < tol
+    z = tc.code(torch.zeros((1, 2)).cuda()).float().cpu().numpy()
+    np.testing.assert_array_equal(z[0, 0], np.tile([0.0, 1.0], 64))      # coding.py:144-148 at 0
+    with pytest.raises(AssertionError):
+        tc.code(torch.zeros((1, 2, 3)).cuda())                            # coding.py:139
+
+
+# f32: the argument x*f + phi reaches ~110 rad, so its float32 rounding alone moves the cosine by up to ~7e-6
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 8e-3)])
+def test_time_function_code_and_gradients(dt, tol):
+    """C.TimeFunctionCoding(units).code(x) — coding.py:97-122 — on [B,T] and [B,T,T] inputs."""
+    from easydgl_amd.module import coding as C
+    tf_ = C.TimeFunctionCoding(64).cuda()
+    tf_.act_dtype = dt
+    with torch.no_grad():
+        tf_.phase.copy_(torch.randn(64, generator=_gen(5)) * 0.3)
+    rng = np.random.default_rng(1)
+    for shape in [(3, 7), (2, 6, 6)]:
+        tf_.basis_freq.grad = tf_.phase.grad = None
+        x = rng.uniform(0, 12, size=shape).astype(np.float32)
+        got = tf_.code(torch.tensor(x).cuda())
+        f64 = tf_.basis_freq.detach().double().cpu().requires_grad_()
+        p64 = tf_.phase.detach().double().cpu().requires_grad_()
+        xr = torch.tensor(x, dtype=torch.float64).reshape(shape[0], shape[1], -1)
+        want = torch.cos(xr.unsqueeze(-1) * f64 + p64)                     # coding.py:113-121
+        assert got.shape == want.shape
+        assert_close(got.detach().float().cpu().numpy(), want.detach().numpy(), tol, "time function code")
+        G = torch.randn(want.shape, generator=_gen(6)).to(dt)
+        got.backward(G.cuda())
+        (want * G.double()).sum().backward()
+        assert_close(tf_.basis_freq.grad.cpu().numpy(), f64.grad.numpy(), 1e-4 if dt == torch.float32 else 2e-2, "d_freq")
+        assert_close(tf_.phase.grad.cpu().numpy(), p64.grad.numpy(), 1e-4 if dt == torch.float32 else 2e-2, "d_phase")
+
+
+def test_time_interval_code():
+    """C.TimeIntervalCoding(vocab, units).code(int intervals) — coding.py:82-94."""
+    from easydgl_amd.module import coding as C
+    ti = C.TimeIntervalCoding(16, 32, 0.0, gen=_gen(7)).cuda()
+    iv = torch.tensor(np.random.default_rng(3).integers(0, 17, size=(2, 5, 5))).cuda()   # 16 = one past the table
+    got = ti.code(iv)
+    tab = np.concatenate([ti.pembs.lookup_table.detach().cpu().numpy(), np.zeros((1, 32), np.float32)])
+    np.testing.assert_array_equal(got.detach().cpu().numpy(), tab[iv.cpu().numpy()])
+
+
+@pytest.mark.parametrize("dt,ftol,gtol", [(torch.float32, 3e-5, 2e-4), (torch.bfloat16, 3e-2, 6e-2)])
+def test_bimau_operator_with_the_reference_signature(dt, ftol, gtol):
+    """T.BiMAU(num_units, num_heads, num_events, dropout_rate)(queries, keys, masks, intervals, marks, is_training) ->
+    (outputs [B,T,C], mark_intensity [hB,T,E]) — temporal.py:401-452; the QKVT projection is created on the first call."""
+    from easydgl_amd.module import temporal as T
+    B, Tn, C, H, E = 3, 19, 64, 4, 5
+    att = T.BiMAU(C, H, E, 0.1).cuda()
+    assert att.dense_kernel is None
+    rng = np.random.default_rng(8)
+    x = torch.tensor(rng.standard_normal((B, Tn, 3 * C)), dtype=dt).cuda().requires_grad_()
+    ids = rng.integers(1, 30, size=(B, Tn)); ids[0, :5] = 0
+    mt = O.synthetic_mark_table(30, E, multi_hot=True)
+    marks = mt[ids]
+    spans = rng.uniform(0, 5, size=(B, Tn))
+    if dt != torch.float32:
+        att(x.detach(), x.detach(), torch.tensor(ids).cuda(), torch.tensor(spans, dtype=torch.float32).cuda(),
+            torch.tensor(marks.astype(np.uint8)).cuda(), False)                      # creates the projection
+        shadow = {id(p): p.detach().to(dt) for p in att.parameters()}
+        att.compute = lambda p: shadow[id(p)]
+    out, lam = att(x, x, torch.tensor(ids).cuda(), torch.tensor(spans, dtype=torch.float32).cuda(),
+                   torch.tensor(marks.astype(np.uint8)).cuda(), False)
+    assert tuple(att.dense_kernel.shape) == (3 * C, 4 * C) and abs(float(att.dense_kernel.detach().std()) - 0.02) < 0.002
+    assert out.shape == (B, Tn, C) and lam.shape == (H * B, Tn, E)
+    (out.float().sum() + lam.sum()).backward()
+    xr = x.detach().double().cpu().requires_grad_()
+    pr = {"dense/kernel": att.compute(att.dense_kernel).detach().double().cpu(), "dense/bias": att.dense_bias.detach().double().cpu(),
+          "sequential_temporal_combined/dense/kernel": att.st_kernel.detach().double().cpu(),
+          "sequential_temporal_combined/dense/bias": att.st_bias.detach().double().cpu(),
+          "sequential_temporal_combined/weight": att.weight.detach().double().cpu(),
+          "sequential_temporal_combined/scaling": att.scaling.detach().double().cpu()}
+    km3 = torch.tensor((ids != 0).astype(np.float64)).unsqueeze(1).repeat(H, Tn, 1)
+    out_r, lam_r = R.bimau(C, H, xr, km3, torch.tensor(spans), torch.tensor(marks, dtype=torch.float64), pr, "", 0.0, False)
+    (out_r.sum() + lam_r.sum()).backward()
+    assert_close(out.detach().float().cpu().numpy(), out_r.detach().numpy(), ftol, "outputs")
+    assert_close(lam.detach().cpu().numpy(), lam_r.detach().numpy(), ftol, "mark_intensity")
+    assert_close(x.grad.float().cpu().numpy(), xr.grad.numpy(), gtol, "d_queries")
+
+
+def test_unsupported_head_dim_fails_in_the_constructor():
+    from easydgl_amd.module import temporal as T
+    with pytest.raises(ValueError, match="head dim"):
+        T.BiMAU(50, 1, 4, 0.0)
+    with pytest.raises(ValueError, match="num_events"):
+        T.MAU(64, 2, 40, 0.0)
