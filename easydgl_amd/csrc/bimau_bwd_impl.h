@@ -1,6 +1,8 @@
 // K3 backward sweep kernels (X and Z of k_bimau_bwd.hip's three passes), shared by k_bimau_bwd.hip (head dims 16 / 32) and
 // k_bimau_big.hip (head dims 64 / 128, where the intensity MLP backward runs as two GEMM-shaped kernels in between).
 #pragma once
+#include <algorithm>
+
 #include "bimau_common.h"
 
 #ifdef EDGL_PHASE_TIMING
@@ -13,6 +15,32 @@ namespace bimau {
 constexpr int KY_ECH = 8;        // marks per workgroup row of kernel Y (gridDim.y = 16 / KY_ECH dH partials)
 constexpr int KY_NY = EP / KY_ECH;
 constexpr int KY_BLOCKS = 256;   // workgroups of kernel Y per mark group (x KY_NY = one resident round at 2 WGs/CU)
+
+// head dims >= 64 (k_bimau_big.hip): the weight-gradient kernel runs on a (row splits, channel groups) grid; a group is
+// 32 / (dh/16) channel tiles of 16.  Enough row splits for ~512 workgroups, at least 16.
+inline int big_row_splits(int dh, int E) {
+    const int nc = (32 / (dh / 16)) * 16;
+    const int groups = std::max(1, (dh * E + nc - 1) / nc);
+    return std::max(16, 512 / groups);
+}
+
+// workspace of edgl_bimau_bwd: dz [R,16] | dH partial slabs | row term [R] | dscaling partials | weight-gradient partials
+struct WsLayout { size_t dz, dh, rowdot, dsc, wpart, total; };
+inline WsLayout ws_layout(int B, int T_, int C, int H, int E) {
+    const int dh = C / H;
+    const bool big = dh >= 64;
+    const size_t R = (size_t)B * H * T_;
+    WsLayout w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    w.dz = take(R * EP * sizeof(float));
+    w.dh = take((size_t)(big ? 1 : KY_NY) * R * dh * sizeof(float));
+    w.rowdot = take(R * sizeof(float));
+    w.dsc = take((size_t)B * H * EP * sizeof(float));
+    w.wpart = take((size_t)(big ? big_row_splits(dh, E) : KY_BLOCKS) * ((size_t)(dh + 3) * dh * E + EP) * sizeof(float));
+    w.total = o;
+    return w;
+}
 
 struct BwdP {
     const void* qkvt; const int64_t* ids; const float* spans; const uint8_t* marks; const char* pack;
@@ -459,5 +487,8 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     PH_FLUSH(8);
 }
 
+
+// head dims 64 / 128 (k_bimau_big.hip)
+int big_bwd(const BwdP& p, char* ws, float* dW1, float* db1, float* dw, float* dsc, int dtype, hipStream_t st);
 
 }  // namespace bimau

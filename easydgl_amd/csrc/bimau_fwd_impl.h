@@ -315,4 +315,7 @@ int dispatch_nt(FwdP p, hipStream_t st) {
 }
 
 
+// head dims 64 / 128 (k_bimau_big.hip): scores phase -> intensity kernel -> values phase
+int big_fwd(const FwdP& p, int dtype, hipStream_t st);
+
 }  // namespace bimau

@@ -183,22 +183,6 @@ __global__ __launch_bounds__(256) void intensity_bwd_kernel(MlpP p) {
     }
 }
 
-struct WsLayout { size_t dz, dh, rowdot, dsc, wpart, total; };
-inline WsLayout ws_layout(int B, int T_, int C, int H, int E) {
-    const int dh = C / H;
-    const size_t R = (size_t)B * H * T_;
-    WsLayout w;
-    size_t o = 0;
-    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-    w.dz = take(R * EP * sizeof(float));
-    w.dh = take((size_t)KY_NY * R * dh * sizeof(float));
-    w.rowdot = take(R * sizeof(float));
-    w.dsc = take((size_t)B * H * EP * sizeof(float));
-    w.wpart = take((size_t)KY_BLOCKS * ((dh + 3) * dh * E + EP) * sizeof(float));
-    w.total = o;
-    return w;
-}
-
 template <typename T, int DT, int NT>
 int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscaling, hipStream_t st) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
@@ -321,7 +305,8 @@ extern "C" int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float*
         if (dh == 16) return dispatch_nt<bf16, 1>(p, ws, dW1, db1, dw, dscaling, st);
         if (dh == 32) return dispatch_nt<bf16, 2>(p, ws, dW1, db1, dw, dscaling, st);
     }
-    edgl_set_error("edgl_bimau_bwd: head dim %d not supported (16 or 32)", dh);
+    if (dh == 64 || dh == 128) return bimau::big_bwd(p, ws, dW1, db1, dw, dscaling, dtype, st);
+    edgl_set_error("edgl_bimau_bwd: head dim %d not supported (16, 32, 64 or 128)", dh);
     return EDGL_ERR_SHAPE;
 }
 

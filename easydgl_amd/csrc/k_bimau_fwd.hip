@@ -10,7 +10,7 @@ int dispatch_dt(FwdP p, hipStream_t st) {
     const int dh = p.C / p.H;
     if (dh == 16) return dispatch_nt<T, 1>(p, st);
     if (dh == 32) return dispatch_nt<T, 2>(p, st);
-    edgl_set_error("edgl_bimau_fwd: head dim %d not supported (16 or 32)", dh);
+    edgl_set_error("edgl_bimau_fwd: head dim %d not supported (16, 32, 64 or 128)", dh);
     return EDGL_ERR_SHAPE;
 }
 
@@ -58,6 +58,8 @@ extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, c
         p.z_out = reinterpret_cast<float*>((char*)saved + sl.off_z);
     }
     hipStream_t st = (hipStream_t)stream;
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_bimau_fwd: bad dtype %d", dtype);
+    if (C / H == 64 || C / H == 128) return bimau::big_fwd(p, dtype, st);
     if (dtype == EDGL_F32) return dispatch_dt<float>(p, st);
     if (dtype == EDGL_BF16) return dispatch_dt<bf16>(p, st);
     edgl_set_error("edgl_bimau_fwd: bad dtype %d", dtype);

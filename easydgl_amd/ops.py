@@ -251,7 +251,9 @@ class BiMAUFn(torch.autograd.Function):
         if resid.stride(-1) != 1 or resid.stride(0) != T * resid.stride(1):
             raise _lib.EdglError("BiMAU residual must be a row-strided view of a contiguous [B,T,*] tensor")
         need_grad = any(ctx.needs_input_grad)
-        saved = torch.empty(lib.edgl_bimau_saved_bytes(B, T, C, H, code), device=qkvt.device, dtype=torch.uint8) if need_grad else None
+        # head dims >= 64 run as scores phase -> intensity kernel -> values phase and hand H rows / z through `saved`
+        need_saved = need_grad or (C // H) >= 64
+        saved = torch.empty(lib.edgl_bimau_saved_bytes(B, T, C, H, code), device=qkvt.device, dtype=torch.uint8) if need_saved else None
         check(lib.edgl_bimau_fwd(_ptr(qkvt), resid.data_ptr(), resid.stride(1), _ptr(ids), _ptr(spans), _ptr(marks),
                                  _ptr(pack), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(out),
                                  _ptr(lam), _ptr(saved), int(flags), code, _stream()), "edgl_bimau_fwd")
