@@ -22,12 +22,33 @@
 
 namespace {
 
-constexpr int SNT = 512;   // threads per workgroup
-constexpr int XB = 256;    // x vectors per workgroup (32 per wave)
-constexpr int ZB = 128;    // z vectors per streamed tile
+constexpr int SNT = 512;   // threads per workgroup of the forward kernel
 
-template <typename T, int CT, int NTHR = SNT>
+// Tile shape per (dtype, C).  C <= 128 (and bf16 C = 256): a wave keeps TWO 16-x tiles in registers and 128-z tiles stream
+// through LDS.  Wider rows (bf16 C = 512 — every published recipe, runme.sh:15-115; f32 C = 256 / 512 for parity runs) keep
+// ONE x tile per wave (its fragments alone are 64-128 registers) and stream narrower z tiles so that the Z / Z^T images of
+// a tile still fit the 160 KB of LDS.
+template <typename T, int CT>
+struct ScoreCfg {
+    static constexpr bool BF = sizeof(T) == 2;
+    static constexpr bool STD = CT <= 8 || (BF && CT == 16);
+    static constexpr int IX = STD ? 2 : 1;                                   // 16-x tiles per wave
+    static constexpr int ZB = STD ? 128 : ((BF || CT == 16) ? 64 : 32);      // z vectors per streamed tile
+    static constexpr int NWB = (!BF && CT == 32) ? 4 : 8;                    // waves per workgroup, backward kernels
+    // output channel tiles per backward pass: bf16 C = 256 / 512 accumulate half the channels per pass (the logits are
+    // recomputed per pass) — all [IX][CT] accumulator tiles next to the x fragments spill ~100-300 registers
+    static constexpr int CO = (BF && CT >= 16) ? CT / 2 : CT;
+};
+struct RtCfg { int ix, zb, nwb; };
+inline RtCfg rt_cfg(int C, size_t esize) {   // the same table for the host-side planners
+    const int ct = C / 16;
+    const bool bf = esize == 2, stdc = ct <= 8 || (bf && ct == 16);
+    return RtCfg{stdc ? 2 : 1, stdc ? 128 : ((bf || ct == 16) ? 64 : 32), (!bf && ct == 32) ? 4 : 8};
+}
+
+template <typename T, int CT, int NTHR = SNT, int ZBT = ScoreCfg<T, CT>::ZB>
 struct SC {
+    static constexpr int ZB = ZBT;
     static constexpr int VEC = ElemTraits<T>::VEC;
     static constexpr int KB = ElemTraits<T>::KB;
     static constexpr int C = 16 * CT;
@@ -40,6 +61,9 @@ struct SC {
     static constexpr size_t Z_BYTES = (size_t)ZB * LDC * sizeof(T);
     static constexpr size_t ZT_BYTES = (size_t)C * LDZ * sizeof(T);
     static constexpr size_t INFO_BYTES = 3 * ZB * sizeof(float);
+    static constexpr int JH = ZB >= 64 ? 4 : ZB / 16;     // 16-z tiles per "half" (the unit whose logits are live at once)
+    static constexpr int NH = ZB / 16 / JH;               // halves per streamed tile
+    static_assert(PER_Z >= 1 && PER_ZT >= 1 && ZB % 16 == 0, "tile does not divide over the workgroup");
 };
 
 struct ScoreP {
@@ -83,7 +107,7 @@ struct ZStream {
     __device__ __forceinline__ void load_t(const T* srcT, int ldT, int z0, int zend, bool zero_row0) {
         if constexpr (WITH_T) {
             z0_ = z0; zend_ = zend; zero0_ = zero_row0;
-            constexpr int ZV = ZB / S::VEC;
+            constexpr int ZV = S::ZB / S::VEC;
 #pragma unroll
             for (int i = 0; i < S::PER_ZT; ++i) {
                 const int v = threadIdx.x + i * NTHR;
@@ -101,7 +125,7 @@ struct ZStream {
             st16<T>(Zs + (v / S::CV) * S::LDC + (v % S::CV) * S::VEC, ok ? rz[i] : zero16<T>());
         }
         if constexpr (WITH_T) {
-            constexpr int ZV = ZB / S::VEC;
+            constexpr int ZV = S::ZB / S::VEC;
 #pragma unroll
             for (int i = 0; i < S::PER_ZT; ++i) {
                 const int v = threadIdx.x + i * NTHR;
@@ -119,12 +143,12 @@ struct ZStream {
 };
 
 // x fragments of this wave's 32-x strip, kept in registers
-template <typename T, int CT>
+template <typename T, int CT, int IX>
 __device__ __forceinline__ void load_xfrags(const T* X, int x0, int xend, bool zero_row0, int lane,
-                                            Vec16<T> (&xf)[2][SC<T, CT>::NKB]) {
+                                            Vec16<T> (&xf)[IX][SC<T, CT>::NKB]) {
     using S = SC<T, CT>;
 #pragma unroll
-    for (int ix = 0; ix < 2; ++ix) {
+    for (int ix = 0; ix < IX; ++ix) {
         const int gx = x0 + ix * 16 + (lane & 15);
         const bool ok = gx < xend && !(zero_row0 && gx == 0);
 #pragma unroll
@@ -135,22 +159,21 @@ __device__ __forceinline__ void load_xfrags(const T* X, int x0, int xend, bool z
 
 // D[z][x] half tile of the wave (64 z = 4 jz tiles starting at jz0): acc[j][ix], L(first = z, second = x).
 // The 128-z tile is processed in two halves so that only 32 accumulator registers are live at a time.
-template <typename T, int CT>
-__device__ __forceinline__ void logit_half(const T* Zs, int jz0, const Vec16<T> (&xf)[2][SC<T, CT>::NKB], int lane,
-                                           f32x4 (&acc)[4][2]) {
+template <typename T, int CT, int IX>
+__device__ __forceinline__ void logit_half(const T* Zs, int jz0, const Vec16<T> (&xf)[IX][SC<T, CT>::NKB], int lane,
+                                           f32x4 (&acc)[SC<T, CT>::JH][IX]) {
     using S = SC<T, CT>;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        acc[j][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int j = 0; j < S::JH; ++j)
+#pragma unroll
+        for (int ix = 0; ix < IX; ++ix) acc[j][ix] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < S::NKB; ++kb) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < S::JH; ++j) {
             const Vec16<T> zf = ld16<T>(Zs + ((jz0 + j) * 16 + (lane & 15)) * S::LDC + kb * S::KB + (lane >> 4) * S::VEC);
-            acc[j][0] = mma_kblock(zf, xf[0][kb], acc[j][0]);
-            acc[j][1] = mma_kblock(zf, xf[1][kb], acc[j][1]);
+#pragma unroll
+            for (int ix = 0; ix < IX; ++ix) acc[j][ix] = mma_kblock(zf, xf[ix][kb], acc[j][ix]);
         }
     }
 }
@@ -158,7 +181,7 @@ __device__ __forceinline__ void logit_half(const T* Zs, int jz0, const Vec16<T> 
 // The number of weighted rows is only known on the device (edgl_compact_rows), so the x-block / item-chunk split of
 // a launch of G workgroups is derived there: nx x-blocks cover the valid rows, the G/nx chunks share the z range.
 struct DevPlan { int nx, nchunk, zchunk; };
-__host__ __device__ __forceinline__ DevPlan dev_plan(int x_eff, int xb, int G, int ztotal) {
+__host__ __device__ __forceinline__ DevPlan dev_plan(int x_eff, int xb, int G, int ztotal, int ZB) {
     DevPlan d;
     d.nx = (x_eff + xb - 1) / xb;
     if (d.nx < 1) d.nx = 1;
@@ -179,20 +202,21 @@ __host__ __device__ __forceinline__ DevPlan dev_plan(int x_eff, int xb, int G, i
 template <typename T, int CT>
 __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
     using S = SC<T, CT>;
+    constexpr int IX = ScoreCfg<T, CT>::IX, ZB = S::ZB, XB = 16 * IX * (SNT / 64), JH = S::JH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr size_t BUF = S::Z_BYTES + ZB * sizeof(float);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const int Reff = p.nvalid ? min(p.R, p.nvalid[0]) : p.R;
-    const DevPlan dp = dev_plan(Reff, XB, gridDim.x, p.i1 - p.i0);
+    const DevPlan dp = dev_plan(Reff, XB, gridDim.x, p.i1 - p.i0, ZB);
     if ((int)blockIdx.x >= dp.nx * dp.nchunk || Reff <= 0) return;
     const int bx = blockIdx.x % dp.nx, by = blockIdx.x / dp.nx;
-    const int m0 = bx * XB + wave * 32;
+    const int m0 = bx * XB + wave * 16 * IX;
     const int c_lo = p.i0 + by * dp.zchunk, c_hi = min(p.i1, c_lo + dp.zchunk);
     const T* rows = reinterpret_cast<const T*>(p.rows);
     const T* table = reinterpret_cast<const T*>(p.table);
 
-    Vec16<T> xf[2][S::NKB];
-    load_xfrags<T, CT>(rows, m0, Reff, false, lane, xf);
+    Vec16<T> xf[IX][S::NKB];
+    load_xfrags<T, CT, IX>(rows, m0, Reff, false, lane, xf);
     ZStream<T, CT, false> zs;
     const int ntile = (c_hi - c_lo + ZB - 1) / ZB;
     zs.load(table, nullptr, 0, c_lo, c_hi, true);
@@ -203,7 +227,9 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
         if (tid < ZB) { const int n = c_lo + tid; info[tid] = (n < c_hi && n > 0) ? p.out_bias[n - 1] : 0.f; }
     }
     __syncthreads();
-    float rmax[2] = {-INFINITY, -INFINITY}, rsum[2] = {0.f, 0.f};
+    float rmax[IX], rsum[IX];
+#pragma unroll
+    for (int ix = 0; ix < IX; ++ix) { rmax[ix] = -INFINITY; rsum[ix] = 0.f; }
     for (int it = 0; it < ntile; ++it) {
         const int n0 = c_lo + it * ZB;
         const bool more = it + 1 < ntile;
@@ -214,16 +240,16 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
         const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES);
         const bool edge = (n0 == 0) || (n0 + ZB > c_hi);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 acc[4][2];
-            logit_half<T, CT>(Zs, half * 4, xf, lane, acc);
+        for (int half = 0; half < S::NH; ++half) {
+            f32x4 acc[JH][IX];
+            logit_half<T, CT, IX>(Zs, half * JH, xf, lane, acc);
 #pragma unroll
-            for (int ix = 0; ix < 2; ++ix) {
+            for (int ix = 0; ix < IX; ++ix) {
                 const int m = m0 + ix * 16 + l15;
                 float tmax = -INFINITY;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int jz = half * 4 + j;
+                for (int j = 0; j < JH; ++j) {
+                    const int jz = half * JH + j;
                     const float4 bz = *reinterpret_cast<const float4*>(info + jz * 16 + g4);
                     const float bb[4] = {bz.x, bz.y, bz.z, bz.w};
 #pragma unroll
@@ -241,10 +267,10 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
                 if (p.logits && m < Reff) {
                     float* dst = p.logits + (long)m * (p.i1 - p.i0) + (n0 - p.i0);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < JH; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const int zz = (half * 4 + j) * 16 + g4 + r;
+                            const int zz = (half * JH + j) * 16 + g4 + r;
                             if (n0 + zz < c_hi) dst[zz] = acc[j][ix][r];
                         }
                 }
@@ -252,7 +278,7 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
                 if (nm > -INFINITY) {
                     float sacc = rsum[ix] * __expf(rmax[ix] - nm);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < JH; ++j)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) sacc += __expf(acc[j][ix][r] - nm);
                     rsum[ix] = sacc;
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
     }
     // the 4 lane groups of a wave hold disjoint z subsets of the same x: combine them
 #pragma unroll
-    for (int ix = 0; ix < 2; ++ix) {
+    for (int ix = 0; ix < IX; ++ix) {
         const float mx = group_max4(rmax[ix]);
         float s = (rmax[ix] > -INFINITY) ? rsum[ix] * __expf(rmax[ix] - mx) : 0.f;
         s = group_sum4(s);
@@ -283,12 +309,12 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
     }
 }
 
-__global__ void lse_combine_kernel(const float* part, int R, const int32_t* nvalid, int G, int ztotal, float* row_lse) {
+__global__ void lse_combine_kernel(const float* part, int R, const int32_t* nvalid, int xb, int zb, int G, int ztotal, float* row_lse) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= R) return;
     const int Reff = nvalid ? min(R, nvalid[0]) : R;
     if (m >= Reff) { row_lse[m] = 0.f; return; }
-    const int nchunk = dev_plan(Reff, XB, G, ztotal).nchunk;
+    const int nchunk = dev_plan(Reff, xb, G, ztotal, zb).nchunk;
     float mx = -INFINITY;
     for (int c = 0; c < nchunk; ++c) mx = fmaxf(mx, part[((long)m * nchunk + c) * 2]);
     float s = 0.f;
@@ -326,13 +352,15 @@ enum { ROLE_Y = 0, ROLE_W = 1 };
 // the logits are recomputed per pass, but [2][16] accumulator tiles + operands do not fit 256 registers and spill ~300)
 template <typename T, int CT, int ROLE, int NW, int CO = CT>
 __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
-    constexpr int NTHR = 64 * NW, XBW = 32 * NW;
+    constexpr int IX = ScoreCfg<T, CT>::IX;
+    constexpr int NTHR = 64 * NW, XBW = 16 * IX * NW;
     const int ct0 = (CO == CT) ? 0 : (ROLE == ROLE_Y ? (int)blockIdx.y : (int)blockIdx.z) * CO;
     using S = SC<T, CT, NTHR>;
+    constexpr int ZB = S::ZB, JH = S::JH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr size_t BUF = S::Z_BYTES + S::ZT_BYTES + S::INFO_BYTES;
     constexpr bool DOUBLE = (NW == 8) && (2 * BUF <= 160 * 1024);
-    constexpr bool PREFETCH = (NW == 8);
+    constexpr bool PREFETCH = (NW == 8) && ScoreCfg<T, CT>::STD;   // the wide shapes have no registers to spare for the next tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const T* rows = reinterpret_cast<const T*>(p.rows);
     const T* rowsT = reinterpret_cast<const T*>(p.rowsT);
@@ -344,7 +372,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     int bx, by, zchunk;
     long slab_stride;
     if (ROLE == ROLE_Y) {
-        const DevPlan dp = dev_plan(Reff, XBW, gridDim.x, p.i1 - p.i0);
+        const DevPlan dp = dev_plan(Reff, XBW, gridDim.x, p.i1 - p.i0, ZB);
         if ((int)blockIdx.x >= dp.nx * dp.nchunk || Reff <= 0) return;
         bx = blockIdx.x % dp.nx; by = blockIdx.x / dp.nx; zchunk = dp.zchunk;
         slab_stride = (long)dp.nx * XBW * S::C;
@@ -355,14 +383,14 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         slab_stride = (long)p.I * S::C;
     }
     // x side
-    const int xbase = (ROLE == ROLE_Y ? 0 : p.i0) + bx * XBW + wave * 32;
+    const int xbase = (ROLE == ROLE_Y ? 0 : p.i0) + bx * XBW + wave * 16 * IX;
     const int xend = ROLE == ROLE_Y ? Reff : p.i1;
-    Vec16<T> xf[2][S::NKB];
-    load_xfrags<T, CT>(ROLE == ROLE_Y ? rows : table, xbase, xend, ROLE == ROLE_W, lane, xf);
-    float x_lse[2], x_cf[2], x_bias[2];
-    int x_lab[2];
+    Vec16<T> xf[IX][S::NKB];
+    load_xfrags<T, CT, IX>(ROLE == ROLE_Y ? rows : table, xbase, xend, ROLE == ROLE_W, lane, xf);
+    float x_lse[IX], x_cf[IX], x_bias[IX];
+    int x_lab[IX];
 #pragma unroll
-    for (int ix = 0; ix < 2; ++ix) {
+    for (int ix = 0; ix < IX; ++ix) {
         const int gx = xbase + ix * 16 + l15;
         const bool ok = gx < xend;
         if (ROLE == ROLE_Y) {
@@ -399,12 +427,14 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         }
     };
 
-    f32x4 out[2][CO];
+    f32x4 out[IX][CO];
 #pragma unroll
-    for (int ix = 0; ix < 2; ++ix)
+    for (int ix = 0; ix < IX; ++ix)
 #pragma unroll
         for (int ct = 0; ct < CO; ++ct) out[ix][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dbias[2] = {0.f, 0.f};
+    float dbias[IX];
+#pragma unroll
+    for (int ix = 0; ix < IX; ++ix) dbias[ix] = 0.f;
 
     ZStream<T, CT, true, NTHR> zs;
     const int ntile = z_hi > z_lo ? (z_hi - z_lo + ZB - 1) / ZB : 0;
@@ -425,18 +455,20 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES + S::ZT_BYTES);
         const bool edge = (ROLE == ROLE_Y) && ((z0 == 0) || (z0 + ZB > z_hi));
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 acc[4][2];
-            if (!(p.dbg & 8)) logit_half<T, CT>(Zs, half * 4, xf, lane, acc);
+        for (int half = 0; half < S::NH; ++half) {
+            f32x4 acc[JH][IX];
+            if (!(p.dbg & 8)) logit_half<T, CT, IX>(Zs, half * JH, xf, lane, acc);
             else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { acc[j][0] = f32x4{0.1f, 0.2f, 0.3f, 0.4f}; acc[j][1] = acc[j][0]; }
+                for (int j = 0; j < JH; ++j)
+#pragma unroll
+                    for (int ix = 0; ix < IX; ++ix) acc[j][ix] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
             }
             // ---- dl[z][x] in place ------------------------------------------------------------------
             if (!(p.dbg & 1))
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int jz = half * 4 + j;
+            for (int j = 0; j < JH; ++j) {
+                const int jz = half * JH + j;
                 float zb[4];   // ROLE_Y: bias[z] ; ROLE_W: lse[z] - log coef[z]
                 int zlab[4];
                 {
@@ -448,7 +480,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                     zlab[0] = c4.x; zlab[1] = c4.y; zlab[2] = c4.z; zlab[3] = c4.w;
                 }
 #pragma unroll
-                for (int ix = 0; ix < 2; ++ix)
+                for (int ix = 0; ix < IX; ++ix)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int gz = z0 + jz * 16 + g4 + r;
@@ -471,13 +503,13 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                     }
             }
             // ---- out[x][c] += sum_z dl[x][z] Z[z][c] --------------------------------------------------
-            if (p.dbg & 2) { out[0][0] += acc[0][0]; out[1][0] += acc[3][1]; continue; }
+            if (p.dbg & 2) { out[0][0] += acc[0][0]; out[IX - 1][0] += acc[JH - 1][IX - 1]; continue; }
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    bf16x8 af[2];
+                for (int jp = 0; jp < JH / 2; ++jp) {
+                    bf16x8 af[IX];
 #pragma unroll
-                    for (int ix = 0; ix < 2; ++ix)
+                    for (int ix = 0; ix < IX; ++ix)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             af[ix][r] = (bf16)acc[2 * jp][ix][r];
@@ -485,23 +517,25 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                         }
 #pragma unroll
                     for (int ct = 0; ct < CO; ++ct) {
-                        const T* zt = ZTs + ((ct0 + ct) * 16 + l15) * S::LDZ + (half * 2 + jp) * 32 + g4;
+                        const T* zt = ZTs + ((ct0 + ct) * 16 + l15) * S::LDZ + (half * (JH / 2) + jp) * 32 + g4;
                         bf16x8 bfr;
                         *reinterpret_cast<uint2*>(&bfr) = *reinterpret_cast<const uint2*>(zt);
                         *(reinterpret_cast<uint2*>(&bfr) + 1) = *reinterpret_cast<const uint2*>(zt + 16);
-                        out[0][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr, out[0][ct], 0, 0, 0);
-                        out[1][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr, out[1][ct], 0, 0, 0);
+#pragma unroll
+                        for (int ix = 0; ix < IX; ++ix) out[ix][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ix], bfr, out[ix][ct], 0, 0, 0);
                     }
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const Frag4<T> a0 = frag_from_acc<T>(acc[j][0]), a1 = frag_from_acc<T>(acc[j][1]);
+                for (int j = 0; j < JH; ++j) {
+                    Frag4<T> a[IX];
+#pragma unroll
+                    for (int ix = 0; ix < IX; ++ix) a[ix] = frag_from_acc<T>(acc[j][ix]);
 #pragma unroll
                     for (int ct = 0; ct < CO; ++ct) {
-                        const Frag4<T> bfr = frag_ld<T>(ZTs + ((ct0 + ct) * 16 + l15) * S::LDZ + (half * 4 + j) * 16 + g4);
-                        out[0][ct] = mma16(a0, bfr, out[0][ct]);
-                        out[1][ct] = mma16(a1, bfr, out[1][ct]);
+                        const Frag4<T> bfr = frag_ld<T>(ZTs + ((ct0 + ct) * 16 + l15) * S::LDZ + (half * JH + j) * 16 + g4);
+#pragma unroll
+                        for (int ix = 0; ix < IX; ++ix) out[ix][ct] = mma16(a[ix], bfr, out[ix][ct]);
                     }
                 }
             }
@@ -518,7 +552,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     // ---- write the slab: out regs r <-> x = ix*16 + g4 + r, lane l15 <-> c = ct*16 + l15 ----------------
     float* slab = p.slabs + (long)by * slab_stride;
 #pragma unroll
-    for (int ix = 0; ix < 2; ++ix)
+    for (int ix = 0; ix < IX; ++ix)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gx = xbase + ix * 16 + g4 + r;
@@ -529,7 +563,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         }
     if (ROLE == ROLE_W && ct0 == 0) {
 #pragma unroll
-        for (int ix = 0; ix < 2; ++ix) {
+        for (int ix = 0; ix < IX; ++ix) {
             const float v = group_sum4(dbias[ix]);
             const int gx = xbase + ix * 16 + l15;
             if (lane < 16 && gx < xend && gx > 0) p.bias_slabs[(long)by * (p.I - 1) + gx - 1] = v;
@@ -551,11 +585,11 @@ __global__ void slab_reduce_kernel(const float* slabs, int nslab, long n, long l
 
 // d_rows[r] = (T) gs * sum over the item chunks' slabs; the slab geometry follows dev_plan of the producing launch.
 template <typename TO>
-__global__ void slab_reduce_rows_kernel(const float* slabs, const int32_t* nvalid, int R, int C, int xb, int G, int ztotal,
+__global__ void slab_reduce_rows_kernel(const float* slabs, const int32_t* nvalid, int R, int C, int xb, int zb, int G, int ztotal,
                                         const float* gscale, TO* out) {
     const float gs = gscale ? gscale[0] : 1.0f;
     const int Reff = nvalid ? min(R, nvalid[0]) : R;
-    const DevPlan dp = dev_plan(Reff, xb, G, ztotal);
+    const DevPlan dp = dev_plan(Reff, xb, G, ztotal, zb);
     const long stride = (long)dp.nx * xb * C, nval = (long)Reff * C, n = (long)R * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float a = 0.f;
@@ -852,7 +886,7 @@ struct Chunking { int nchunk, zchunk; };
 // `l2_tiles` (0 = no limit): most z tiles one chunk may span.  Every workgroup of a chunk streams the same z range; the
 // workgroups drift apart, and once that range no longer fits the 4 MB L2 of an XCD each of them re-reads it from HBM
 // (measured at R = 51200 rows: d_rows kernel 917 us with one chunk of 157 item tiles, 474 us with 5 chunks of 32).
-inline Chunking pick_chunks(int xblocks, int ztotal, int target_blocks, int l2_tiles = 0) {
+inline Chunking pick_chunks(int xblocks, int ztotal, int target_blocks, int ZB, int l2_tiles = 0) {
     const int ntiles = std::max(1, (ztotal + ZB - 1) / ZB);
     int nchunk = std::min(ntiles, std::max(1, target_blocks / std::max(1, xblocks)));
     if (l2_tiles > 0) nchunk = std::min(ntiles, std::max(nchunk, (ntiles + l2_tiles - 1) / l2_tiles));
@@ -860,7 +894,7 @@ inline Chunking pick_chunks(int xblocks, int ztotal, int target_blocks, int l2_t
     nchunk = (ntiles + per - 1) / per;
     return Chunking{nchunk, per * ZB};
 }
-inline int xblocks_of(int n, int xb = XB) { return (n + xb - 1) / xb; }
+inline int xblocks_of(int n, int xb) { return (n + xb - 1) / xb; }
 inline int score_nw() { static const int nw = getenv("EDGL_SCORE_NW") ? atoi(getenv("EDGL_SCORE_NW")) : 8; return nw == 4 ? 4 : 8; }
 inline int score_ftarget() { static const int t = getenv("EDGL_SCORE_FTARGET") ? atoi(getenv("EDGL_SCORE_FTARGET")) : 256; return t; }
 inline int score_target() { static const int t = getenv("EDGL_SCORE_TARGET") ? atoi(getenv("EDGL_SCORE_TARGET")) : 256; return t; }
@@ -868,23 +902,25 @@ inline long up8(long v) { return (v + 7) / 8 * 8; }
 
 // z tiles per chunk that keep a chunk's streamed range within ~2 MB (half an XCD's L2); `images` = 2 when the kernel reads the
 // tile and its transposed copy (d_rows), 1 for the forward
-inline int l2_tiles_for(int C, size_t esize, int images) { return std::max(8, (int)((2u << 20) / ((size_t)ZB * C * esize * images))); }
-constexpr int F_L2_TILES_MIN = 32;   // smallest value l2_tiles_for(C, esize, 1) takes over the supported (C, dtype): workspace bound
+inline int l2_tiles_for(int C, size_t esize, int images, int ZB) { return std::max(8, (int)((2u << 20) / ((size_t)ZB * C * esize * images))); }
+constexpr int F_L2_TILES_MIN = 32;   // smallest value l2_tiles_for(C, esize, 1, zb) takes over the supported (C, dtype): workspace bound
 struct BwdPlan {
     Chunking y, w;
     long off_rowsT, off_tableT, off_slabY, off_slabW, off_slabB, total;  // float offsets
 };
 inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize) {
     BwdPlan b;
-    const int xb = 32 * score_nw();
-    b.y = pick_chunks(xblocks_of(R, xb), n_items, score_target(), l2_tiles_for(C, esize, 2));
+    const RtCfg cf = rt_cfg(C, esize);
+    const int nw = cf.nwb == 8 ? score_nw() : cf.nwb, zb = cf.zb;
+    const int xb = 16 * cf.ix * nw;
+    b.y = pick_chunks(xblocks_of(R, xb), n_items, score_target(), zb, l2_tiles_for(C, esize, 2, zb));
     {   // every chunk writes an [R, C] f32 slab that a later kernel sums: keep that side traffic bounded (1M-item tables would
         // otherwise ask for hundreds of chunks)
         const long slab_bytes = (long)xblocks_of(R, xb) * xb * C * 4;
         const int cap = (int)std::max<long>(score_target() / std::max(1, xblocks_of(R, xb)), (256L << 20) / std::max(1L, slab_bytes));
-        if (b.y.nchunk > cap) b.y = pick_chunks(xblocks_of(R, xb), n_items, cap * xblocks_of(R, xb));
+        if (b.y.nchunk > cap) b.y = pick_chunks(xblocks_of(R, xb), n_items, cap * xblocks_of(R, xb), zb);
     }
-    b.w = pick_chunks(xblocks_of(n_items, xb), R, score_target());
+    b.w = pick_chunks(xblocks_of(n_items, xb), R, score_target(), zb);
     long o = 0;
     auto take = [&](long floats) { const long at = o; o += (floats + 63) / 64 * 64; return at; };
     b.off_rowsT = take(((long)C * up8(R) * (long)esize + 3) / 4);
@@ -899,10 +935,12 @@ inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize) {
 template <typename T, int CT>
 int run_fwd(ScoreP p, hipStream_t st) {
     using S = SC<T, CT>;
-    const size_t smem = 2 * (S::Z_BYTES + ZB * sizeof(float));
+    constexpr int XB = 16 * ScoreCfg<T, CT>::IX * (SNT / 64);
+    const size_t smem = 2 * (S::Z_BYTES + S::ZB * sizeof(float));
+    static_assert(2 * (S::Z_BYTES + S::ZB * sizeof(float)) <= 160 * 1024, "forward tile images exceed the LDS");
     auto k = score_fwd_kernel<T, CT>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(k, dim3(xblocks_of(p.R) * p.nchunk), dim3(SNT), smem, st, p);
+    hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, XB) * p.nchunk), dim3(SNT), smem, st, p);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
@@ -924,29 +962,30 @@ int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_tab
                        reinterpret_cast<const T*>(p.table), (long)p.I, p.C, tableT, (long)p.ldt);
     EDGL_LAUNCH_CHECK();
     p.rowsT = rowsT; p.tableT = tableT;
-    const int nw = score_nw();
+    using Cfg = ScoreCfg<T, CT>;
+    constexpr int CO = Cfg::CO, ZBK = S::ZB;
+    const int nw = Cfg::NWB == 8 ? score_nw() : Cfg::NWB;
     const size_t smem_nw = nw == 8 ? smem : BUF;
+    const int xb = 16 * Cfg::IX * nw;
     // d_rows
     {
         ScoreP q = p;
         q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY;
         edgl_prof_begin(EDGL_KERNEL_SCORE_BWD_ROWS, st);
         if (nw == 8) {
-            constexpr int CO = (CT == 16 && sizeof(T) == 2) ? 8 : CT;
             auto k = score_bwd_kernel<T, CT, ROLE_Y, 8, CO>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 256) * q.nchunk, CT / CO), dim3(512), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, xb) * q.nchunk, CT / CO), dim3(512), smem_nw, st, q);
         } else {
             auto k = score_bwd_kernel<T, CT, ROLE_Y, 4>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, 128) * q.nchunk), dim3(256), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, xb) * q.nchunk), dim3(256), smem_nw, st, q);
         }
         edgl_prof_end(EDGL_KERNEL_SCORE_BWD_ROWS, st);
         EDGL_LAUNCH_CHECK();
         const long n = (long)p.R * p.C;
-        const int xb = 32 * nw;
         hipLaunchKernelGGL((slab_reduce_rows_kernel<T>), dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st,
-                           q.slabs, p.nvalid, p.R, p.C, xb, xblocks_of(p.R, xb) * q.nchunk, p.i1 - p.i0, p.gscale,
+                           q.slabs, p.nvalid, p.R, p.C, xb, ZBK, xblocks_of(p.R, xb) * q.nchunk, p.i1 - p.i0, p.gscale,
                            reinterpret_cast<T*>(d_rows));
         EDGL_LAUNCH_CHECK();
     }
@@ -955,14 +994,13 @@ int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_tab
         ScoreP q = p;
         q.zchunk = plan.w.zchunk; q.nchunk = plan.w.nchunk; q.slabs = ws + plan.off_slabW; q.bias_slabs = ws + plan.off_slabB;
         if (nw == 8) {
-            constexpr int CO = (CT == 16 && sizeof(T) == 2) ? 8 : CT;
             auto k = score_bwd_kernel<T, CT, ROLE_W, 8, CO>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, 256), q.nchunk, CT / CO), dim3(512), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, xb), q.nchunk, CT / CO), dim3(512), smem_nw, st, q);
         } else {
             auto k = score_bwd_kernel<T, CT, ROLE_W, 4>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, 128), q.nchunk), dim3(256), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, xb), q.nchunk), dim3(256), smem_nw, st, q);
         }
         EDGL_LAUNCH_CHECK();
         const long n = (long)p.I * p.C, lo = (long)p.i0 * p.C, hi = (long)p.i1 * p.C;
@@ -987,9 +1025,8 @@ int check_score(const void* rows, const void* table, const float* out_bias, int 
                  "%s: bad shape R=%d I=%d [%d,%d) (i0 must be a multiple of 8)", who, R, I, i0, i1);
     EDGL_REQUIRE(((uintptr_t)rows & 15) == 0 && ((uintptr_t)table & 15) == 0, EDGL_ERR_SHAPE,
                  "%s: operands must be 16-byte aligned", who);
-    const int maxc = dtype == EDGL_F32 ? 128 : 256;
-    EDGL_REQUIRE(C >= 32 && C <= maxc && (C & (C - 1)) == 0, EDGL_ERR_SHAPE, "%s: C=%d unsupported (power of two in [32, %d])",
-                 who, C, maxc);
+    EDGL_REQUIRE(C >= 32 && C <= 512 && (C & (C - 1)) == 0, EDGL_ERR_SHAPE, "%s: C=%d unsupported (power of two in [32, 512])",
+                 who, C);
     return EDGL_OK;
 }
 
@@ -998,7 +1035,8 @@ int check_score(const void* rows, const void* table, const float* out_bias, int 
         case 2: return CALL(T, 2);                                   \
         case 4: return CALL(T, 4);                                   \
         case 8: return CALL(T, 8);                                   \
-        case 16: if constexpr (sizeof(T) == 2) return CALL(T, 16);   \
+        case 16: return CALL(T, 16);                                 \
+        case 32: return CALL(T, 32);                                 \
     }                                                                \
     edgl_set_error("edgl_score: C=%d unsupported", C);               \
     return EDGL_ERR_SHAPE;
@@ -1021,8 +1059,13 @@ int bwd_dispatch(ScoreP p, int C, const BwdPlan& plan, float* ws, void* d_rows, 
 // workspace rule of the forward: 2 * R * edgl_score_chunks floats >= 2 * XB * (#workgroups), the most (row, chunk)
 // partial pairs any device-side split of the launch can produce
 extern "C" int edgl_score_chunks(int R, int n_items) {
-    const long g = (long)xblocks_of(R) * pick_chunks(xblocks_of(R), n_items, score_ftarget(), F_L2_TILES_MIN).nchunk;
-    return (int)((g * XB + R - 1) / R);
+    long best = 1;   // C is not an argument: take the largest need over the tile shapes of ScoreCfg
+    for (int xb : {256, 128})
+        for (int zb : {128, 64, 32}) {
+            const long g = (long)xblocks_of(R, xb) * pick_chunks(xblocks_of(R, xb), n_items, score_ftarget(), zb, F_L2_TILES_MIN).nchunk;
+            best = std::max(best, (g * xb + R - 1) / R);
+        }
+    return (int)best;
 }
 
 extern "C" int edgl_compact_rows(const void* rows, const int64_t* labels, int R, int C, int32_t* perm, int32_t* inv,
@@ -1062,13 +1105,16 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = row_lse; p.part = workspace; p.logits = logits;
-    const Chunking ch = pick_chunks(xblocks_of(R), i1 - i0, score_ftarget(), l2_tiles_for(C, dtype == EDGL_BF16 ? 2 : 4, 1));
+    const size_t esize = dtype == EDGL_BF16 ? 2 : 4;
+    const RtCfg cf = rt_cfg(C, esize);
+    const int xbf = 16 * cf.ix * (SNT / 64);
+    const Chunking ch = pick_chunks(xblocks_of(R, xbf), i1 - i0, score_ftarget(), cf.zb, l2_tiles_for(C, esize, 1, cf.zb));
     p.nchunk = ch.nchunk; p.zchunk = ch.zchunk;
     hipStream_t st = (hipStream_t)stream;
     rc = dtype == EDGL_F32 ? fwd_dispatch<float>(p, C, st) : fwd_dispatch<bf16>(p, C, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(lse_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, st, workspace, R, nvalid,
-                       xblocks_of(R) * p.nchunk, i1 - i0, row_lse);
+    hipLaunchKernelGGL(lse_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, st, workspace, R, nvalid, xbf, cf.zb,
+                       xblocks_of(R, xbf) * p.nchunk, i1 - i0, row_lse);
     EDGL_LAUNCH_CHECK();
     if (labels) {
         if (dtype == EDGL_F32)

@@ -342,11 +342,11 @@ def test_bimau_fully_masked_row_is_uniform():
 
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,dt,tol", DTYPES)
-@pytest.mark.parametrize("R_,C,I", [(37, 32, 300), (260, 128, 2701), (130, 64, 5200), (300, 256, 1500)])
+@pytest.mark.parametrize("R_,C,I", [(37, 32, 300), (260, 128, 2701), (130, 64, 5200), (300, 256, 1500),
+                                    # num_units = 512: every published recipe (runme.sh:15-115); 17772 = Netflix's table rows
+                                    (300, 512, 1500), (3072, 512, 17772), (70, 256, 700)])
 def test_score_ce_fwd_bwd(name, dt, tol, R_, C, I):
     o = ops()
-    if name == "f32" and C > 128:
-        pytest.skip("the fused f32 scoring kernels cover C <= 128; C = 256 (config 3) is a bf16 shape")
     rng = np.random.default_rng(R_)
     rows = torch.tensor(_rand((R_, C), rng, 0.5), dtype=dt).cuda().requires_grad_()
     tab = torch.tensor(_rand((I, C), rng, 0.3), dtype=torch.float32).cuda().requires_grad_()

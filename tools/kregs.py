@@ -16,6 +16,6 @@ for b in txt.split("- .agpr_count:")[1:]:
     rows.append((nm, vg, ag, sp, sc))
 names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
 for (nm, vg, ag, sp, sc), d in zip(rows, names):
-    d = re.sub(r"^void ", "", re.sub(r"\(.*", "", d)).replace("(anonymous namespace)::", "")
+    d = re.sub(r"^void ", "", re.sub(r"\(.*", "", d.replace("(anonymous namespace)::", "")))
     if flt in d:
         print(f"{d[:100]:100s} vgpr {vg:4d} agpr {ag:3d} spill {sp:4d} scratch {sc}")
