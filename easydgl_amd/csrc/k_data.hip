@@ -53,6 +53,7 @@ struct EmbP {
     int B, T, C, E; float time_scale; float rate; const uint64_t* rng; uint32_t stream_id;
     void* x0; float* spans; uint8_t* marks;
     const void* dx0; float* d_item; float* d_pos;
+    int srows;   // rows per block of the backward (<= ESROWS; fewer when ESROWS*C floats exceed the LDS)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(EmbP p) {
@@ -101,12 +102,13 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(EmbP p) {
     extern __shared__ float acc[];  // [ESROWS][C]
     __shared__ int s_id[ESROWS];
     __shared__ int s_lead[ESROWS];
-    const long rows = (long)p.B * p.T, r0 = (long)blockIdx.x * ESROWS;
+    const int SR = p.srows;
+    const long rows = (long)p.B * p.T, r0 = (long)blockIdx.x * SR;
     const int tid = threadIdx.x;
-    if (tid < ESROWS) s_id[tid] = (r0 + tid < rows) ? (int)p.ids[r0 + tid] : -1;
-    for (int i = tid; i < ESROWS * p.C; i += 256) acc[i] = 0.f;
+    if (tid < SR) s_id[tid] = (r0 + tid < rows) ? (int)p.ids[r0 + tid] : -1;
+    for (int i = tid; i < SR * p.C; i += 256) acc[i] = 0.f;
     __syncthreads();
-    if (tid < ESROWS) {
+    if (tid < SR) {
         const int id = s_id[tid];
         int lead = tid;
         for (int j = 0; j < tid; ++j)
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(EmbP p) {
     const float sq = sqrtf((float)p.C);
     const long ldo = p.d_pos ? 2L * p.C : (long)p.C;
     if (tid < rows_par * cpr)
-        for (int r = rl; r < ESROWS; r += rows_par) {
+        for (int r = rl; r < SR; r += rows_par) {
             if (s_id[r] < 0) continue;   // past the end
             const long row = r0 + r;
             const T* d = reinterpret_cast<const T*>(p.dx0) + row * ldo;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(EmbP p) {
             }
         }
     __syncthreads();
-    for (int i = tid; i < ESROWS * p.C; i += 256) {
+    for (int i = tid; i < SR * p.C; i += 256) {
         const int r = i / p.C, c = i % p.C;
         if (s_lead[r] == r && s_id[r] > 0) atomicAdd(p.d_item + (long)s_id[r] * p.C + c, acc[i]);
     }
@@ -158,7 +160,7 @@ extern "C" int edgl_embed_pos_fwd(const int64_t* ids, const float* ts, const voi
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_embed_pos_fwd: bad dtype %d", dtype);
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_embed_pos_fwd: dropout without rng_state");
     EmbP p{ids, ts, item_tab, pos_tab, mark_table, B, T, C, E, time_scale, drop_rate, rng_state, stream_id, x0, spans, marks,
-           nullptr, nullptr, nullptr};
+           nullptr, nullptr, nullptr, 0};
     const long total = (long)B * T * (C / 4);
     dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == EDGL_F32) hipLaunchKernelGGL((embed_pos_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -171,8 +173,10 @@ extern "C" int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, in
                                   const uint64_t* rng_state, uint32_t stream_id, float* d_item, float* d_pos, int dtype,
                                   void* stream) {
     EDGL_REQUIRE(ids && dx0 && d_item, EDGL_ERR_NULL, "edgl_embed_pos_bwd: null pointer");
-    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256 && (size_t)ESROWS * C * sizeof(float) <= 150 * 1024 && I > 1,
+    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256 && I > 1,
                  EDGL_ERR_SHAPE, "edgl_embed_pos_bwd: bad shape B=%d T=%d C=%d", B, T, C);
+    int srows = ESROWS;
+    while (srows > 8 && (size_t)srows * C * sizeof(float) > 150 * 1024) srows >>= 1;   // C = 512: 64 rows per block
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_embed_pos_bwd: bad dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(d_item, 0, (size_t)I * C * sizeof(float), st) != hipSuccess ||
@@ -181,9 +185,9 @@ extern "C" int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, in
         return EDGL_ERR_LAUNCH;
     }
     EmbP p{ids, nullptr, nullptr, nullptr, nullptr, B, T, C, 0, 1.f, drop_rate, rng_state, stream_id, nullptr, nullptr, nullptr,
-           dx0, d_item, d_pos};
-    const size_t smem = (size_t)ESROWS * C * sizeof(float);
-    dim3 grid((unsigned)(((long)B * T + ESROWS - 1) / ESROWS));
+           dx0, d_item, d_pos, srows};
+    const size_t smem = (size_t)srows * C * sizeof(float);
+    dim3 grid((unsigned)(((long)B * T + srows - 1) / srows));
     if (dtype == EDGL_F32) {
         hipFuncSetAttribute((const void*)embed_pos_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL((embed_pos_bwd_kernel<float>), grid, dim3(256), smem, st, p);

@@ -123,6 +123,7 @@ struct EncBwdP {
     const int64_t* ids; const uint8_t* marks; const void* dx0;
     int B, T, C, E, I; float rate; const uint64_t* rng; uint32_t stream_id;
     float* d_item; float* part_pos; float* part_mk; int nchunk;
+    int srows;   // rows per block of the scatter stage (<= SROWS; fewer when SROWS*C floats exceed the LDS)
 };
 
 // d_pos / d_mark: grid (T, nchunk): the block owns position t for the b-range of its chunk.  Thread = 4
@@ -194,12 +195,13 @@ __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
     extern __shared__ float acc[];  // [SROWS][C]
     __shared__ int s_id[SROWS];
     __shared__ int s_lead[SROWS];
-    const long rows = (long)p.B * p.T, r0 = (long)blockIdx.x * SROWS;
+    const int SR = p.srows;
+    const long rows = (long)p.B * p.T, r0 = (long)blockIdx.x * SR;
     const int tid = threadIdx.x;
-    if (tid < SROWS) s_id[tid] = (r0 + tid < rows) ? (int)p.ids[r0 + tid] : 0;
-    for (int i = tid; i < SROWS * p.C; i += 256) acc[i] = 0.f;
+    if (tid < SR) s_id[tid] = (r0 + tid < rows) ? (int)p.ids[r0 + tid] : 0;
+    for (int i = tid; i < SR * p.C; i += 256) acc[i] = 0.f;
     __syncthreads();
-    if (tid < SROWS) {
+    if (tid < SR) {
         const int id = s_id[tid];
         int lead = tid;
         for (int j = 0; j < tid; ++j)
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const float sq = sqrtf((float)p.C);
     if (tid < rows_par * cpr)
-        for (int r = rl; r < SROWS; r += rows_par) {
+        for (int r = rl; r < SR; r += rows_par) {
             if (s_id[r] == 0) continue;  // padding rows and rows past the end
             const long row = r0 + r;
             const Frag4<T> g0 = frag_ld<T>(reinterpret_cast<const T*>(p.dx0) + row * 3 * p.C + c0);
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
                 atomicAdd(dst + j, sq * drop_apply(dk, (uint64_t)row * 3 * p.C + c0 + j, to_f32(g0.v[j])));
         }
     __syncthreads();
-    for (int i = tid; i < SROWS * p.C; i += 256) {
+    for (int i = tid; i < SR * p.C; i += 256) {
         const int r = i / p.C, c = i % p.C;
         if (s_lead[r] == r && s_id[r] != 0) atomicAdd(p.d_item + (long)s_id[r] * p.C + c, acc[i]);
     }
@@ -266,7 +268,9 @@ extern "C" int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const v
     EDGL_REQUIRE(C % 4 == 0 && C / 4 <= 256, EDGL_ERR_SHAPE, "edgl_encode_bwd: C=%d unsupported", C);
     float* part_pos = workspace;
     float* part_mk = workspace + (long)ENC_NCHUNK * T * C;
-    EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, part_pos, part_mk, ENC_NCHUNK};
+    int srows = SROWS;
+    while (srows > 8 && (size_t)srows * C * sizeof(float) > 150 * 1024) srows >>= 1;   // C = 512: 64 rows per block
+    EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, part_pos, part_mk, ENC_NCHUNK, srows};
     hipStream_t st = (hipStream_t)stream;
     const int rows_par = 256 / (C / 4);
     dim3 grid(T, ENC_NCHUNK);
@@ -275,9 +279,9 @@ extern "C" int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const v
     else hipLaunchKernelGGL((encode_bwd_kernel<bf16>), grid, dim3(256), smem, st, p);
     EDGL_LAUNCH_CHECK();
     {
-        const size_t smem_s = (size_t)SROWS * C * sizeof(float);
+        const size_t smem_s = (size_t)srows * C * sizeof(float);
         EDGL_REQUIRE(smem_s <= 150 * 1024, EDGL_ERR_SHAPE, "edgl_encode_bwd: C=%d too large for the scatter stage", C);
-        const unsigned nb = (unsigned)(((long)B * T + SROWS - 1) / SROWS);
+        const unsigned nb = (unsigned)(((long)B * T + srows - 1) / srows);
         if (dtype == EDGL_F32) {
             hipFuncSetAttribute((const void*)encode_scatter_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
             hipLaunchKernelGGL((encode_scatter_kernel<float>), dim3(nb), dim3(256), smem_s, st, p);

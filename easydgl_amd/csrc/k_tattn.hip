@@ -726,6 +726,269 @@ __global__ __launch_bounds__(256) void add_pos2_kernel(const T* kv, const float*
     frag_st<T>(out + row * 2 * C + c0, o);
 }
 
+// =========================================================================================================================
+// Wide heads (Dv > 128): TGAT's published recipe is ONE head of 512 channels (runme.sh:80-87: num_units 512, num_heads 1), so
+// Dq = 1536, Dv = 512 — 128 operand fragments per row, far beyond a wave's registers.  The head is cut into SLICES of 128
+// channels: a wave owns (sample, head, 16-row tile, slice); the score of a (q, k) tile needs the FULL contraction and is
+// recomputed by every slice (operands re-read per 128-channel chunk from L1/L2 — at T = 30 a sequence has two key tiles),
+// while the wide accumulators (O, dQ~, dK~, dV) are split over the slices.  Same arithmetic and the same saved statistics as
+// the narrow kernels above.
+// =========================================================================================================================
+constexpr int SL = 8;   // 16-channel tiles per slice
+
+struct SJob { int b, head, tile, slice; long bp; };
+__device__ __forceinline__ bool get_sjob(const TaP& p, int nslice, SJob& j) {
+    const long job = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (job >= (long)p.B * p.H * p.NT * nslice) return false;
+    j.slice = (int)(job % nslice);
+    const long r = job / nslice;
+    j.tile = (int)(r % p.NT);
+    const long bh = r / p.NT;
+    j.head = (int)(bh % p.H);
+    j.b = (int)(bh / p.H);
+    j.bp = (long)j.head * p.B + j.b;
+    return true;
+}
+
+// s[k][q] += sum over ALL Dq channels of K~[k] . Q~[q]  (row pointers of this lane's key row / query row)
+template <typename T>
+__device__ __forceinline__ f32x4 full_score(const T* Krow, const T* Qrow, int Dq, int g4, bool k_is_a) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < Dq; c += 16 * SL) {
+        Frag4<T> kf[SL], qf[SL];
+#pragma unroll
+        for (int dt = 0; dt < SL; ++dt) { kf[dt] = frag_ld<T>(Krow + c + dt * 16 + g4); qf[dt] = frag_ld<T>(Qrow + c + dt * 16 + g4); }
+#pragma unroll
+        for (int dt = 0; dt < SL; ++dt) s = k_is_a ? mma16(kf[dt], qf[dt], s) : mma16(qf[dt], kf[dt], s);
+    }
+    return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tattn_fwd_sliced_kernel(TaP p) {
+    SJob j;
+    const int nslice = p.Dv / (16 * SL);
+    if (!get_sjob(p, nslice, j)) return;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
+    const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
+    const int v0 = j.slice * 16 * SL;
+    const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * p.Dq;
+    const T* Kb = reinterpret_cast<const T*>(p.kx) + (long)j.b * p.T * p.ldk + j.head * p.Dq;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + (long)j.b * p.T * p.ldv + j.head * p.Dv + v0;
+    const int64_t* idr = p.ids + (long)j.b * p.T;
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 acc[SL];
+#pragma unroll
+    for (int ut = 0; ut < SL; ++ut) acc[ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kt_end = (causal && j.tile * 16 >= first_unpadded(idr, p.T, lane)) ? j.tile + 1 : p.NT;
+    for (int kt = 0; kt < kt_end; ++kt) {
+        const int kr = min(kt * 16 + l15, p.T - 1);
+        const f32x4 s = full_score<T>(Kb + (long)kr * p.ldk, Qr, p.Dq, g4, true);
+        Frag4<T> vraw[SL];
+#pragma unroll
+        for (int ut = 0; ut < SL; ++ut) vraw[ut] = frag_ld<T>(Vb + (long)kr * p.ldv + ut * 16 + g4);
+        float x[4], tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kt * 16 + g4 + r;
+            const float madd = k >= p.T ? -INFINITY : (idr[min(k, p.T - 1)] == 0 ? PADV : 0.f);   // temporal.py:153-158
+            float v = fmaf(s[r], p.cscale, madd);
+            if (causal && k > q && k < p.T) v = PADV;                                            // :161-166
+            x[r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+        tmax = group_max4(tmax);
+        const float m_new = fmaxf(m_run, tmax), corr = __expf(m_run - m_new);
+        f32x4 e;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[r] = __expf(x[r] - m_new); psum += e[r]; }
+        l_run = l_run * corr + group_sum4(psum);
+        m_run = m_new;
+        if (dk.thresh != 0u) {
+            const uint32_t h0 = drop_hash_pair(dk, dbase + kt * 16 + g4), h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2);
+            e[0] = (h0 & 0xffffu) >= dk.t16 ? e[0] : 0.f;
+            e[1] = (h0 >> 16) >= dk.t16 ? e[1] : 0.f;
+            e[2] = (h1 & 0xffffu) >= dk.t16 ? e[2] : 0.f;
+            e[3] = (h1 >> 16) >= dk.t16 ? e[3] : 0.f;
+        }
+        const Frag4<T> pf = frag_from_acc<T>(e);
+#pragma unroll
+        for (int ut = 0; ut < SL; ++ut) {
+            const Frag4<T> vt = turn<T>(vraw[ut], ident);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ut][r] *= corr;
+            acc[ut] = mma16(vt, pf, acc[ut]);
+        }
+    }
+    const float inv = dk.scale / l_run;
+    if (p.st_m && qok && g4 == 0 && j.slice == 0) { p.st_m[j.bp * p.T + q] = m_run; p.st_l[j.bp * p.T + q] = l_run; }
+    if (!qok) return;
+    const long orow = (long)j.b * p.T + q;
+#pragma unroll
+    for (int ut = 0; ut < SL; ++ut) {
+        const int col = j.head * p.Dv + v0 + ut * 16 + g4;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = acc[ut][r] * inv;
+        if (p.oatt) *reinterpret_cast<float4*>(p.oatt + orow * ((long)p.H * p.Dv) + col) = make_float4(o[0], o[1], o[2], o[3]);
+        const Frag4<T> rf = frag_ld<T>(reinterpret_cast<const T*>(p.resid) + orow * p.ldr + col);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] += to_f32(rf.v[r]);
+        frag_st<T>(reinterpret_cast<T*>(p.out) + orow * p.ldo + col, frag_from_acc<T>(o));
+    }
+}
+
+// da[k][q] (or [q][k]) = sum over ALL Dv channels of V[k] . dO[q]
+template <typename T>
+__device__ __forceinline__ f32x4 full_da(const T* Vrow, const T* dOrow, int Dv, int g4, bool v_is_a) {
+    f32x4 da = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < Dv; c += 16 * SL) {
+        Frag4<T> vf[SL], gf[SL];
+#pragma unroll
+        for (int ut = 0; ut < SL; ++ut) { vf[ut] = frag_ld<T>(Vrow + c + ut * 16 + g4); gf[ut] = frag_ld<T>(dOrow + c + ut * 16 + g4); }
+#pragma unroll
+        for (int ut = 0; ut < SL; ++ut) da = v_is_a ? mma16(vf[ut], gf[ut], da) : mma16(gf[ut], vf[ut], da);
+    }
+    return da;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tattn_bwd_q_sliced_kernel(TaP p) {
+    SJob j;
+    const int nslice = p.Dq / (16 * SL);
+    if (!get_sjob(p, nslice, j)) return;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int q = j.tile * 16 + l15, qc = min(q, p.T - 1);
+    const bool qok = q < p.T, causal = (p.flags & TA_CAUSAL) != 0;
+    const int d0 = j.slice * 16 * SL;
+    const T* Qr = reinterpret_cast<const T*>(p.qx) + ((long)j.b * p.T + qc) * p.ldq + j.head * p.Dq;
+    const T* Kb = reinterpret_cast<const T*>(p.kx) + (long)j.b * p.T * p.ldk + j.head * p.Dq;
+    const T* Vb = reinterpret_cast<const T*>(p.v) + (long)j.b * p.T * p.ldv + j.head * p.Dv;
+    const T* dOr = reinterpret_cast<const T*>(p.d_out) + ((long)j.b * p.T + qc) * p.ld_do + j.head * p.Dv;
+    const int64_t* idr = p.ids + (long)j.b * p.T;
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    const uint32_t dbase = (uint32_t)((j.bp * p.T + qc) * p.T);
+    float dsum = 0.f;   // D[q] = dO[q] . O_att[q]
+    {
+        const float* oa = p.oatt + ((long)j.b * p.T + qc) * ((long)p.H * p.Dv) + j.head * p.Dv;
+        for (int u = 0; u < p.Dv; u += 16) {
+            const Frag4<T> g = frag_ld<T>(dOr + u + g4);
+            const float4 o = *reinterpret_cast<const float4*>(oa + u + g4);
+            dsum += to_f32(g.v[0]) * o.x + to_f32(g.v[1]) * o.y + to_f32(g.v[2]) * o.z + to_f32(g.v[3]) * o.w;
+        }
+        dsum = group_sum4(dsum);
+        if (qok && g4 == 0 && j.slice == 0) p.st_d[j.bp * p.T + q] = dsum;
+    }
+    const float m = p.st_m[j.bp * p.T + qc], invl = 1.0f / p.st_l[j.bp * p.T + qc];
+    f32x4 acc[SL];
+#pragma unroll
+    for (int dt = 0; dt < SL; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kt_end = (causal && j.tile * 16 >= first_unpadded(idr, p.T, lane)) ? j.tile + 1 : p.NT;
+    for (int kt = 0; kt < kt_end; ++kt) {
+        const int kr = min(kt * 16 + l15, p.T - 1);
+        const f32x4 s = full_score<T>(Kb + (long)kr * p.ldk, Qr, p.Dq, g4, true);
+        const f32x4 da = full_da<T>(Vb + (long)kr * p.ldv, dOr, p.Dv, g4, true);
+        uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu;
+        if (dk.thresh != 0u) { h0 = drop_hash_pair(dk, dbase + kt * 16 + g4); h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2); }
+        const uint32_t hb[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kt * 16 + g4 + r;
+            const bool pad = k >= p.T || idr[min(k, p.T - 1)] == 0, fut = causal && k > q;
+            float v = fmaf(s[r], p.cscale, k >= p.T ? -INFINITY : (pad ? PADV : 0.f));
+            if (fut && k < p.T) v = PADV;
+            const float P = __expf(v - m) * invl;
+            const float dP = (dk.thresh == 0u || hb[r] >= dk.t16) ? da[r] * dk.scale : 0.f;
+            ds[r] = (pad || fut || !qok) ? 0.f : P * (dP - dsum) * p.cscale;
+        }
+        const Frag4<T> dsf = frag_from_acc<T>(ds);
+#pragma unroll
+        for (int dt = 0; dt < SL; ++dt)
+            acc[dt] = mma16(turn<T>(frag_ld<T>(Kb + (long)kr * p.ldk + d0 + dt * 16 + g4), ident), dsf, acc[dt]);
+    }
+    if (!qok) return;
+    T* dst = reinterpret_cast<T*>(p.d_qx) + ((long)j.b * p.T + q) * p.ld_dq + j.head * p.Dq + d0;
+#pragma unroll
+    for (int dt = 0; dt < SL; ++dt) frag_st<T>(dst + dt * 16 + g4, frag_from_acc<T>(acc[dt]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tattn_bwd_k_sliced_kernel(TaP p) {
+    SJob j;
+    const int nq = p.Dq / (16 * SL), nslice = nq + p.Dv / (16 * SL);   // slices [0, nq): dK~ channels; the rest: dV channels
+    if (!get_sjob(p, nslice, j)) return;
+    const int lane = threadIdx.x & 63, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int k = j.tile * 16 + l15, kc = min(k, p.T - 1);
+    const bool kok = k < p.T, causal = (p.flags & TA_CAUSAL) != 0;
+    const bool for_k = j.slice < nq;
+    const int c0 = (for_k ? j.slice : j.slice - nq) * 16 * SL;
+    const T* Qb = reinterpret_cast<const T*>(p.qx) + (long)j.b * p.T * p.ldq + j.head * p.Dq;
+    const T* Kr = reinterpret_cast<const T*>(p.kx) + ((long)j.b * p.T + kc) * p.ldk + j.head * p.Dq;
+    const T* Vr = reinterpret_cast<const T*>(p.v) + ((long)j.b * p.T + kc) * p.ldv + j.head * p.Dv;
+    const T* dOb = reinterpret_cast<const T*>(p.d_out) + (long)j.b * p.T * p.ld_do + j.head * p.Dv;
+    const bool pad = !kok || p.ids[(long)j.b * p.T + kc] == 0;
+    const float madd = !kok ? -INFINITY : (pad ? PADV : 0.f);
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    const Frag4<T> ident = identity_frag<T>(lane);
+    f32x4 acc[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fnp = first_unpadded(p.ids + (long)j.b * p.T, p.T, lane);
+    for (int qt = 0; qt < p.NT; ++qt) {
+        if (causal && qt < j.tile && qt * 16 >= fnp) continue;
+        const int ql = min(qt * 16 + l15, p.T - 1);
+        const T* Qrow = Qb + (long)ql * p.ldq;
+        const T* dOrow = dOb + (long)ql * p.ld_do;
+        const f32x4 s = full_score<T>(Kr, Qrow, p.Dq, g4, false);     // [q = g4+r][k = l15]
+        const f32x4 da = full_da<T>(Vr, dOrow, p.Dv, g4, false);
+        f32x4 a4, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + g4 + r, qc = min(q, p.T - 1);
+            const long si = j.bp * p.T + qc;
+            const bool fut = causal && k > q;
+            float v = fmaf(s[r], p.cscale, madd);
+            if (fut && kok) v = PADV;
+            const float P = (q < p.T) ? __expf(v - p.st_m[si]) / p.st_l[si] : 0.f;
+            bool keep = true;
+            if (dk.thresh != 0u) {
+                const uint32_t h = drop_hash_pair(dk, (uint32_t)(si * p.T) + (uint32_t)(k & ~1));
+                keep = ((k & 1) ? (h >> 16) : (h & 0xffffu)) >= dk.t16;
+            }
+            a4[r] = keep ? P * dk.scale : 0.f;
+            const float dP = keep ? da[r] * dk.scale : 0.f;
+            ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - p.st_d[si]) * p.cscale;
+        }
+        const Frag4<T> rhs = frag_from_acc<T>(for_k ? ds : a4);
+        const T* src = for_k ? Qrow + c0 : dOrow + c0;     // dK~^T += Q~^T . dS ; dV^T += dO^T . A
+#pragma unroll
+        for (int t = 0; t < SL; ++t) acc[t] = mma16(turn<T>(frag_ld<T>(src + t * 16 + g4), ident), rhs, acc[t]);
+    }
+    if (!kok) return;
+    T* dst = for_k ? reinterpret_cast<T*>(p.d_kx) + ((long)j.b * p.T + k) * p.ld_dk + j.head * p.Dq + c0
+                   : reinterpret_cast<T*>(p.d_v) + ((long)j.b * p.T + k) * p.ld_dv + j.head * p.Dv + c0;
+#pragma unroll
+    for (int t = 0; t < SL; ++t) frag_st<T>(dst + t * 16 + g4, frag_from_acc<T>(acc[t]));
+}
+
+template <typename K>
+int launch_sliced(K kern, const TaP& p, int nslice, hipStream_t st) {
+    const long jobs = (long)p.B * p.H * p.NT * nslice;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, st, p);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+inline bool wide_head(const TaP& p) { return p.Dv > 128 && p.Dv % (16 * SL) == 0 && p.Dq % (16 * SL) == 0; }
+
 template <typename K>
 int launch_jobs(K kern, const TaP& p, hipStream_t st) {
     const long jobs = (long)p.B * p.H * p.NT;
@@ -737,6 +1000,7 @@ int launch_jobs(K kern, const TaP& p, hipStream_t st) {
 template <typename T>
 int launch_fwd(const TaP& p, hipStream_t st) {
     const int dqt = p.Dq / 16, dvt = p.Dv / 16;
+    if (wide_head(p)) return launch_sliced(tattn_fwd_sliced_kernel<T>, p, p.Dv / (16 * SL), st);
 #define EDGL_TA_CASE(DQ, DV) if (dqt == DQ && dvt == DV) return launch_jobs(tattn_fwd_kernel<T, DQ, DV>, p, st);
     if constexpr (sizeof(T) == 2) {
         if (dqt == 24 && dvt == 8) return launch_jobs(tattn_fwd_kernel_w4<T, 24, 8>, p, st);
@@ -744,13 +1008,18 @@ int launch_fwd(const TaP& p, hipStream_t st) {
     EDGL_TA_CASE(1, 1) EDGL_TA_CASE(2, 2) EDGL_TA_CASE(4, 4) EDGL_TA_CASE(8, 8)
     EDGL_TA_CASE(3, 1) EDGL_TA_CASE(6, 2) EDGL_TA_CASE(12, 4) EDGL_TA_CASE(24, 8)
 #undef EDGL_TA_CASE
-    edgl_set_error("edgl_tattn_fwd: head dims Dq=%d Dv=%d not supported (Dv in {16,32,64,128}, Dq in {Dv, 3 Dv})", p.Dq, p.Dv);
+    edgl_set_error("edgl_tattn_fwd: head dims Dq=%d Dv=%d not supported (Dv in {16,32,64,128} with Dq in {Dv, 3 Dv}, or multiples of 128 above)", p.Dq, p.Dv);
     return EDGL_ERR_SHAPE;
 }
 template <typename T>
 int launch_bwd(const TaP& p, hipStream_t st) {
     const int dqt = p.Dq / 16, dvt = p.Dv / 16;
     int rc = EDGL_ERR_SHAPE;
+    if (wide_head(p)) {
+        rc = launch_sliced(tattn_bwd_q_sliced_kernel<T>, p, p.Dq / (16 * SL), st);
+        if (rc == EDGL_OK) rc = launch_sliced(tattn_bwd_k_sliced_kernel<T>, p, (p.Dq + p.Dv) / (16 * SL), st);
+        return rc;
+    }
 #define EDGL_TA_CASE(DQ, DV)                                                     \
     if (dqt == DQ && dvt == DV) {                                                \
         rc = launch_jobs(tattn_bwd_q_kernel<T, DQ, DV>, p, st);                      \
@@ -760,7 +1029,7 @@ int launch_bwd(const TaP& p, hipStream_t st) {
     EDGL_TA_CASE(1, 1) EDGL_TA_CASE(2, 2) EDGL_TA_CASE(4, 4) EDGL_TA_CASE(8, 8)        // plain heads (Dq == Dv)
     EDGL_TA_CASE(3, 1) EDGL_TA_CASE(6, 2) EDGL_TA_CASE(12, 4) EDGL_TA_CASE(24, 8)      // time feature map (Dq == 3 Dv)
 #undef EDGL_TA_CASE
-    edgl_set_error("edgl_tattn_bwd: head dims Dq=%d Dv=%d not supported (Dv in {16,32,64,128}, Dq in {Dv, 3 Dv})", p.Dq, p.Dv);
+    edgl_set_error("edgl_tattn_bwd: head dims Dq=%d Dv=%d not supported (Dv in {16,32,64,128} with Dq in {Dv, 3 Dv}, or multiples of 128 above)", p.Dq, p.Dv);
     return rc;
 }
 

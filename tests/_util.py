@@ -57,3 +57,22 @@ def rel_err(a, b):
 def assert_close(a, b, tol, what=""):
     e = rel_err(a, b)
     assert e <= tol, f"{what}: max-abs-err / max-abs-ref = {e:.3e} > {tol:.1e}"
+
+
+def relu_flip_err(got, ref, tol):
+    """Error measure for the gradients behind a ReLU (FeedForward's Inner kernel / bias) on the bf16 path.  A
+    pre-activation within bf16 rounding of 0 flips its ReLU mask against the fp64 reference, which moves ONE whole term of
+    the row sum of that hidden unit: the error sits in a few columns (hidden units), at ~1/sqrt(rows) of the column's
+    size, and is not a rounding effect the max-norm tolerance can bound (measured with the kernels checked exact on their
+    own operands: 5 of 512 columns above 0.1, max 0.42, at 120 rows).  Returns the max error over the columns that are NOT
+    flipped, after checking that (a) at most 5 % of the columns exceed `tol` and (b) the rms error stays below tol / 2."""
+    got = np.asarray(got, dtype=np.float64).reshape(-1, np.asarray(ref).shape[-1])
+    ref = np.asarray(ref, dtype=np.float64).reshape(got.shape)
+    mx = np.abs(ref).max() + 1e-30
+    err = np.abs(got - ref) / mx
+    col = err.max(axis=0)
+    flipped = col > tol
+    assert flipped.mean() <= 0.05, f"{flipped.sum()} of {len(col)} columns exceed {tol}: not ReLU flips"
+    rms = float(np.sqrt((err ** 2).mean()))
+    assert rms <= tol / 2, f"rms error {rms:.3e} > {tol / 2:.1e}"
+    return float(col[~flipped].max()) if (~flipped).any() else 0.0

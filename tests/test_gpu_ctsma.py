@@ -9,7 +9,7 @@ import torch
 
 from oracle import ctsma_ref as CR
 from oracle import easydgl_oracle as O
-from tests._util import assert_close, rel_err, to_dev
+from tests._util import assert_close, rel_err, relu_flip_err, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -17,6 +17,7 @@ CASES = [
     dict(B=3, T=12, C=32, h=2, E=4, I=60, nb=2),
     dict(B=32, T=30, C=64, h=2, E=7, I=300, nb=1),         # dh = 32
     dict(B=4, T=100, C=128, h=8, E=16, I=2000, nb=2),      # headline widths
+    dict(B=4, T=30, C=512, h=4, E=16, I=700, nb=2),        # the published recipe runme.sh:107-115 (dh = 128, 2 blocks, seqslen 30)
 ]
 
 
@@ -92,8 +93,9 @@ def test_forward_loss_and_gradients(mode, ltol, gtol, case):
         # bf16 only: a pre-activation within bf16 rounding of 0 flips its ReLU mask, which moves one whole term of the
         # row sums behind Inner/kernel and Inner/bias (measured: error ~ 1/sqrt(rows), 0.13 at 120 rows, 0.05 at 3840);
         # every other gradient is continuous in the activations.  f32 keeps the plain tolerance.
-        tol = 2 * gtol if (mode == "bf16" and "/Inner/" in name) else gtol
-        if e > tol:
+        if mode == "bf16" and "/Inner/" in name:
+            e = relu_flip_err(g, ref, gtol)       # tests/_util.py: flipped hidden units are counted, the rest is held to gtol
+        if e > gtol:
             bad[name] = e
     assert not bad, f"gradient mismatch (rel to max |ref|): {bad}"
     # ---- evaluation: logits of the last position

@@ -10,7 +10,8 @@ from tests._util import build_model, make_problem, rel_err, to_dev
 pytestmark = pytest.mark.gpu
 
 CASES = [dict(), dict(num_units=64, num_heads=2, num_blocks=1, seqslen=30, masklen=6, num_events=7, num_items=300),
-         dict(num_units=128, num_heads=8, num_blocks=1, seqslen=100, masklen=20, num_events=16, num_items=2000)]
+         dict(num_units=128, num_heads=8, num_blocks=1, seqslen=100, masklen=20, num_events=16, num_items=2000),
+         dict(num_units=512, num_heads=8, num_blocks=1, seqslen=30, masklen=6, num_events=16, num_items=700)]   # runme.sh:15-23
 
 
 @pytest.mark.parametrize("mode,ltol,gtol", [("f32", 1e-4, 1e-3), ("bf16", 3e-2, 1e-1)])

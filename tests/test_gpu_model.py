@@ -17,6 +17,8 @@ CASES = [
     dict(num_units=64, num_heads=2, num_blocks=1, seqslen=30, masklen=6, num_events=7, num_items=300),   # dh=32, T=31
     dict(num_units=128, num_heads=8, num_blocks=1, seqslen=100, masklen=20, num_events=16, num_items=2000),  # headline shape
     dict(num_units=64, num_heads=4, num_blocks=1, seqslen=200, masklen=40, num_events=7, num_items=500),     # config-3 length (T=201)
+    # the published EasyDGL recipe (runme.sh:15-23 + the defaults main.py:38,44): C=512, h=8 (dh=64), 1 block, T=31, M=6
+    dict(num_units=512, num_heads=8, num_blocks=1, seqslen=30, masklen=6, num_events=16, num_items=700),
 ]
 
 

@@ -91,3 +91,42 @@ def test_checkpoint_round_trip_resumes_the_same_trajectory(tmp_path):
     bad = make_problem(seed=4, batch=8, num_units=64)
     with pytest.raises(ValueError):
         TR.load_checkpoint(build_model(bad, "bf16"), path)            # a different parameter layout is refused
+
+
+# The published recipes, flag for flag (runme.sh:15-23 EasyDGL, :80-87 TGAT, :89-96 TiSASREC, :107-115 CTSMA; --seqslen /
+# --masklen are left at the reference defaults 30 / 6, main.py:38,44).  Only the data paths, the epoch count and the checkpoint
+# directory differ: synthetic TFRecords with Netflix's catalogue size stand in for the (external) Netflix files.
+RECIPES = {
+    "EasyDGL": "--num_units=512 --hidden_dropout_rate=0.1 --attention_probs_dropout_rate=0.1 --learning_rate=5e-4 --batch_size=512 "
+               "--l2_reg=1e-4 --ct_reg=1e-7 --num_items=17771 --model=EasyDGL --num_blocks=1 --num_heads=8 --mask_seen --time_scale=86400",
+    "TGAT": "--num_units=512 --hidden_dropout_rate=0.1 --attention_probs_dropout_rate=0.1 --learning_rate=5e-5 --batch_size=512 "
+            "--l2_reg=1e-4 --num_items=17771 --model=TGAT --num_blocks=3 --num_heads=1 --mask_seen --time_scale=86400",
+    "TiSASREC": "--num_units=512 --hidden_dropout_rate=0.1 --attention_probs_dropout_rate=0.1 --learning_rate=5e-4 --batch_size=512 "
+                "--l2_reg=1e-4 --num_items=17771 --model=TiSASREC --timelen=256 --num_blocks=2 --num_heads=8 --mask_seen --time_scale=86400",
+    "CTSMA": "--num_units=512 --hidden_dropout_rate=0.1 --attention_probs_dropout_rate=0.2 --learning_rate=5e-4 --batch_size=512 "
+             "--l2_reg=1e-4 --ct_reg=1e-7 --num_items=17771 --model=CTSMA --num_blocks=2 --num_heads=4 --mask_seen --time_scale=86400",
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(RECIPES))
+def test_published_recipe_flags_run_verbatim(tmp_path, name):
+    sp = pytest.importorskip("scipy.sparse")
+    from easydgl_amd import data as D
+    from easydgl_amd import train as TR
+    num_items, seqslen, E = 17771, 30, 16
+    ids, ts = D.synthetic_batch(num_items, seqslen, 1300, seed=5)          # two full batches of 512 + a remainder
+
+    def dump(fname, lo, hi):
+        F.write_tfrecord(str(tmp_path / fname), [F.encode_example({"seqs_i": ids[i], "seqs_t": ts[i]}) for i in range(lo, hi)])
+    dump("train000.tfrec", 0, 600); dump("train001.tfrec", 600, 1100); dump("validation.tfrec", 1100, 1200); dump("test.tfrec", 1200, 1300)
+    with open(tmp_path / "mark.pkl", "wb") as f:
+        pickle.dump(sp.csr_matrix(D.synthetic_mark_table(num_items, E).astype(np.int64)), f)
+    argv = RECIPES[name].split() + ["--train", str(tmp_path / "train???.tfrec"), "--valid", str(tmp_path / "validation.tfrec"),
+                                    "--test", str(tmp_path / "test.tfrec"), "--num_epochs", "2", "--ckpt_dir", str(tmp_path / "ckpt")]
+    if name in ("EasyDGL", "CTSMA"):
+        argv += ["--mark", str(tmp_path / "mark.pkl")]
+    res = TR.main(argv)
+    assert set(res) == {"H10", "H50", "H100", "N10", "N50", "N100"}
+    assert all(0.0 <= v <= 1.0 and math.isfinite(v) for v in res.values())
+    assert res["H10"] <= res["H50"] <= res["H100"]
