@@ -188,8 +188,8 @@ class EasyDGL(Sequential):
     def eval_topk(self, features, mask_seen=True, K=100):
         rows, _ = self.encoder(features, False, self._gather_pos(features, False))
         tab = self.item_embs.lookup_table
-        _, _, logits = ops.score_lse(rows, self.compute(tab), self.output_bias, None, 0, self.num_items, want_logits=True)
-        return ops.mask_topk(logits, 0, features["seqs_i"] if mask_seen else None, K)
+        return ops.score_topk(rows, self.compute(tab), self.output_bias, features["seqs_i"] if mask_seen else None, K, 0,
+                              self.num_items)
 
     @torch.no_grad()
     def eval_topk_sharded(self, features, mask_seen=True, K=100, group=None, world=None, rank=None):
@@ -207,8 +207,7 @@ class EasyDGL(Sequential):
                 R = rows.shape[0]
                 return (torch.full((R, K), float("-inf"), device=rows.device),
                         torch.full((R, K), -1, device=rows.device, dtype=torch.int32))
-            _, _, logits = ops.score_lse(rows, tab_c, self.output_bias, None, i0, i1, want_logits=True)
-            return ops.mask_topk(logits, i0, seen, K)
+            return ops.score_topk(rows, tab_c, self.output_bias, seen, K, i0, i1)
 
         if world is not None:   # in-process emulation of `world` shards
             vals, idxs = zip(*(local_topk(*parallel.shard_bounds(self.num_items, world, r)) for r in range(world)))

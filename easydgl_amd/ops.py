@@ -501,6 +501,36 @@ def topk_merge(cand_val: torch.Tensor, cand_idx: torch.Tensor):
     return val, idx
 
 
+EVAL_TILE_BYTES = 64 << 20   # logits staging tile of score_topk: [R, chunk] f32, sized to stay L2 / MALL resident
+
+
+def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
+    """Sequential.eval's scoring + seen-mask + top-K (Base.py:150-181) over the item range [i0, i1) WITHOUT the [R, I]
+    logits tensor of the reference: the range is walked in chunks whose [R, chunk] f32 logits tile is bounded by
+    EVAL_TILE_BYTES (2 GB per batch at |items| = 1M otherwise); every chunk gives a local top-K with global ids and the
+    merge kernel orders the candidates by (value desc, id asc) — the tie rule of tf.nn.top_k.  Returns (val, idx) [R, K]."""
+    R = rows.shape[0]
+    n = i1 - i0
+    chunk = max(1024, (EVAL_TILE_BYTES // (4 * R)) // 8 * 8)
+    if n <= chunk:
+        _, _, logits = score_lse(rows, table_c, out_bias, None, i0, i1, want_logits=True)
+        return mask_topk(logits, i0, seen, K)
+    cands = []
+    for lo in range(i0, i1, chunk):                      # chunk starts stay multiples of 8 (i0 is one)
+        hi = min(i1, lo + chunk)
+        _, _, logits = score_lse(rows, table_c, out_bias, None, lo, hi, want_logits=True)
+        cands.append(mask_topk(logits, lo, seen, K))
+        del logits
+    fan = max(2, 1024 // K)                              # the merge kernel orders up to 1024 candidates per row
+    while len(cands) > 1:
+        nxt = []
+        for g in range(0, len(cands), fan):
+            grp = cands[g:g + fan]
+            nxt.append(grp[0] if len(grp) == 1 else topk_merge(torch.stack([c[0] for c in grp]), torch.stack([c[1] for c in grp])))
+        cands = nxt
+    return cands[0]
+
+
 def rank_metrics(topk_idx: torch.Tensor, label: torch.Tensor, metrics: torch.Tensor) -> None:
     R, K = topk_idx.shape
     check(lib.edgl_rank_metrics(_ptr(topk_idx), R, K, _ptr(label), _ptr(metrics), _stream()), "edgl_rank_metrics")

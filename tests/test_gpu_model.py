@@ -164,3 +164,19 @@ def test_device_masker_matches_reference_semantics():
     we, wl = O.mask_last(cfg, tok.cpu().numpy(), ts.cpu().numpy())
     np.testing.assert_array_equal(fe["seqs_i"].cpu().numpy(), we["seqs_i"])
     np.testing.assert_array_equal(le.cpu().numpy(), wl)
+
+
+def test_chunked_eval_scoring_matches_the_single_pass(monkeypatch):
+    """ops.score_topk walks the catalogue in bounded logits tiles (no [B, I] tensor): with a tile of 1024 items a 5000-item
+    catalogue takes five chunks and two merge levels; values and ids must equal the single-pass result exactly."""
+    from easydgl_amd import ops
+    prob = make_problem(seed=12, batch=12, num_items=5000, seqslen=20, num_units=32, num_heads=2, num_blocks=1)
+    m = build_model(prob, "f32")
+    ef = to_dev(prob["efeats"])
+    v0, i0 = m.eval_topk(ef, mask_seen=True)
+    monkeypatch.setattr(ops, "EVAL_TILE_BYTES", 4 * 12 * 1024)
+    v1, i1 = m.eval_topk(ef, mask_seen=True)
+    assert torch.equal(i0, i1) and torch.equal(v0, v1)
+    monkeypatch.setattr(ops, "EVAL_TILE_BYTES", 4 * 12 * 1024 * 3)     # chunks of 3072: the last one is partial
+    v2, i2 = m.eval_topk(ef, mask_seen=True, K=100)
+    assert torch.equal(i0, i2) and torch.equal(v0, v2)
