@@ -48,6 +48,7 @@ SIGNATURES = {
     "edgl_bimau_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, I, I, P]),
     "edgl_add_layernorm_fwd": (I, [P, P, I, P, P, I, I, I, F, P, U32, P, I, P, P, I, P]),
     "edgl_add_layernorm_bwd": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, P, I, P]),
+    "edgl_add_layernorm_bwd_act": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, P, P, I, P]),
     "edgl_score_chunks": (I, [I, I]),
     "edgl_compact_rows": (I, [P, P, I, I, P, P, P, P, P, I, P]),
     "edgl_scatter_rows": (I, [P, P, I, I, P, I, P]),
@@ -85,6 +86,11 @@ SIGNATURES = {
     "edgl_tiattn_bwd": (I, [P, I, P, I, P, I, P, P, P, P, I, P, I, P, P, I, I, I, I, F, F, I, F, P, U32, P, I, P, I, P, I, P, P, P,
                             I, I, P]),
     "edgl_add_pos2": (I, [P, P, P, I, I, I, P, I, P]),
+    "edgl_tail_pack_elems": (L, [I]),
+    "edgl_tail_supported": (I, [I, I, I]),
+    "edgl_tail_pack": (I, [P, P, P, P, I, P, P]),
+    "edgl_tail_fwd": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, P, I, I, P, P, P, P, P, P, P, P, P, P, P,
+                          P, I, P]),
     "edgl_embedding_fwd": (I, [P, L, P, I, I, I, F, P, I, P]),
     "edgl_embedding_bwd": (I, [P, L, P, I, I, I, F, P, I, P]),
     "edgl_time_sinusoid": (I, [P, L, P, I, P, I, P]),

@@ -305,6 +305,28 @@ __device__ __forceinline__ float dgelu_f(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26): one v_rcp, one v_exp and five FMAs instead of libm's ~70
+// instructions.  Used by the bf16 kernels only (a bf16 GELU output carries 4e-3 of rounding); the f32 parity path keeps
+// erff.  `e_out` = exp(-u*u), which the GELU derivative needs as well.
+__device__ __forceinline__ float erf_as(float u, float& e_out) {
+    const float a = fabsf(u);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+    const float e = __expf(-a * a);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    e_out = e;
+    return copysignf(1.0f - poly * e, u);
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) {     // gelu_f for activation dtype T
+    if constexpr (sizeof(T) == 4) return gelu_f(x);
+    float e;
+    return x * (0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, e)));
+}
+template <typename T> __device__ __forceinline__ float dgelu_t(float x) {    // dgelu_f for activation dtype T
+    if constexpr (sizeof(T) == 4) return dgelu_f(x);
+    float e;
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f, e));
+    return cdf + x * (0.39894228040143267794f * e);
+}
 // v_rcp_f32 (1 ulp) instead of an IEEE division sequence: sigmoid sits in the inner loop of the intensity MLP
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }

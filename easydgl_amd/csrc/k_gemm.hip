@@ -45,7 +45,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float v[4], int 
         if (p.flags & EDGL_EPI_SAVE_PRE) store4<T>(reinterpret_cast<T*>(p.aux) + idx0, x);
         if (p.flags & EDGL_EPI_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+            for (int r = 0; r < 4; ++r) x[r] = gelu_t<T>(x[r]);
         }
         if (p.flags & EDGL_EPI_RELU) {
 #pragma unroll
@@ -54,7 +54,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float v[4], int 
         if (p.flags & EDGL_EPI_MUL_DGELU) {
             const Frag4<T> a = frag_ld<T>(reinterpret_cast<const T*>(p.aux) + idx0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] *= dgelu_f(to_f32(a.v[r]));
+            for (int r = 0; r < 4; ++r) x[r] *= dgelu_t<T>(to_f32(a.v[r]));
         }
         if (p.flags & EDGL_EPI_OUT_F32) {
             float* c = reinterpret_cast<float*>(p.C) + idx0;
@@ -81,9 +81,9 @@ __device__ __forceinline__ void epilogue_store4(const GemmP& p, float v[4], int 
         if (p.flags & EDGL_EPI_BIAS) x += p.bias[n + r];
         const long idx = idx0 + r;
         if (p.flags & EDGL_EPI_SAVE_PRE) reinterpret_cast<T*>(p.aux)[idx] = from_f32<T>(x);
-        if (p.flags & EDGL_EPI_GELU) x = gelu_f(x);
+        if (p.flags & EDGL_EPI_GELU) x = gelu_t<T>(x);
         if (p.flags & EDGL_EPI_RELU) x = fmaxf(x, 0.f);
-        if (p.flags & EDGL_EPI_MUL_DGELU) x *= dgelu_f(to_f32(reinterpret_cast<const T*>(p.aux)[idx]));
+        if (p.flags & EDGL_EPI_MUL_DGELU) x *= dgelu_t<T>(to_f32(reinterpret_cast<const T*>(p.aux)[idx]));
         if (p.flags & EDGL_EPI_OUT_F32) {
             float* c = reinterpret_cast<float*>(p.C);
             c[idx] = (p.flags & EDGL_EPI_ACCUM) ? c[idx] + x : x;

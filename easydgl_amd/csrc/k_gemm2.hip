@@ -50,7 +50,7 @@ __device__ __forceinline__ void epi_store4(const EpiP& e, bf16* C, void* Cany, l
     }
     if (e.flags & EDGL_EPI_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+        for (int r = 0; r < 4; ++r) x[r] = gelu_t<bf16>(x[r]);
     }
     if (e.flags & EDGL_EPI_RELU) {
 #pragma unroll
@@ -59,7 +59,7 @@ __device__ __forceinline__ void epi_store4(const EpiP& e, bf16* C, void* Cany, l
     if (e.flags & EDGL_EPI_MUL_DGELU) {
         const Frag4<bf16> a = frag_ld<bf16>(reinterpret_cast<const bf16*>(e.aux) + idx);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] *= dgelu_f(to_f32(a.v[r]));
+        for (int r = 0; r < 4; ++r) x[r] *= dgelu_t<bf16>(to_f32(a.v[r]));
     }
     if (e.flags & EDGL_EPI_OUT_F32) {
         float* c = reinterpret_cast<float*>(Cany) + idx;
@@ -142,7 +142,7 @@ __device__ __forceinline__ void strip_epilogue(const StripP& p, StripEpi& e, f32
                 }
                 if (p.epi.flags & EDGL_EPI_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+                    for (int r = 0; r < 4; ++r) x[r] = gelu_t<bf16>(x[r]);
                 }
                 if (p.epi.flags & EDGL_EPI_RELU) {
 #pragma unroll
@@ -182,7 +182,7 @@ __device__ __forceinline__ void strip_epilogue(const StripP& p, StripEpi& e, f32
                 if (p.epi.flags & EDGL_EPI_MUL_DGELU) {
                     const bf16x8 a = *reinterpret_cast<const bf16x8*>(&e.pre_aux[ix][q]);
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) x[r] *= dgelu_f(to_f32(a[r]));
+                    for (int r = 0; r < 8; ++r) x[r] *= dgelu_t<bf16>(to_f32(a[r]));
                 }
                 if (p.epi.flags & EDGL_EPI_ACCUM) {
                     const bf16x8 o = *reinterpret_cast<const bf16x8*>(&e.pre_c[ix][q]);
@@ -600,7 +600,10 @@ int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, in
 // workspace floats: edgl_gemm2_tn_workspace(R, Kf, N).
 static int tn_splits(int R, int Kf, int N) {
     const int tiles = ((Kf + 127) / 128) * ((N + 127) / 128);
-    int splits = std::max(1, std::min(384 / tiles, R / 128));
+    // row splits: enough workgroups to fill the chip, but every split leaves a [Kf+1, N] f32 slab behind that a second
+    // kernel sums — 384 workgroups over a 128x128 output meant 25 MB of partials for a 64 KB result
+    static const int target = getenv("EDGL_TN_TARGET") ? atoi(getenv("EDGL_TN_TARGET")) : 384;
+    int splits = std::max(1, std::min(target / tiles, R / 128));
     return splits;
 }
 long edgl_gemm2_tn_workspace(int R, int Kf, int N) { return (long)tn_splits(R, Kf, N) * (Kf + 1) * N; }

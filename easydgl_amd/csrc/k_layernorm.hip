@@ -21,6 +21,7 @@ struct LnP {
     // backward
     const void* dy; void* dsum; void* dx_drop; float* part;
     const int32_t* dy_rowmap;   // gathered mode: compact row of (b, j), or -1 (row carries no gradient)
+    const void* act_pre;        // backward: x = gelu(act_pre); the emitted gradients are multiplied by gelu'(act_pre)
 };
 
 template <typename T>
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float xh = (s[j] - mean) * rstd;
-            const float v = rstd * (d[j] * g[j] - m1 - xh * m2);
+            float v = rstd * (d[j] * g[j] - m1 - xh * m2);
+            if (p.act_pre) v *= dgelu_t<T>(to_f32(reinterpret_cast<const T*>(p.act_pre)[row * p.C + c0 + j]));
             o.v[j] = from_f32<T>(v);
             od.v[j] = from_f32<T>(drop_apply(dk, (uint64_t)(row * p.C + c0 + j), v));
         }
@@ -319,6 +321,15 @@ extern "C" int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_r
                                       const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
                                       int Mg, const int32_t* dy_rowmap, void* dsum, void* dx_drop, float* dgamma,
                                       float* dbeta, float* workspace, int dtype, void* stream) {
+    return edgl_add_layernorm_bwd_act(x, resid, ld_res, gamma, stats, dy, B, T, C, drop_rate, rng_state, stream_id, gather_pos, Mg,
+                                      dy_rowmap, nullptr, dsum, dx_drop, dgamma, dbeta, workspace, dtype, stream);
+}
+
+extern "C" int edgl_add_layernorm_bwd_act(const void* x, const void* resid, int ld_res, const float* gamma,
+                                          const float* stats, const void* dy, int B, int T, int C, float drop_rate,
+                                          const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                                          int Mg, const int32_t* dy_rowmap, const void* act_pre, void* dsum, void* dx_drop,
+                                          float* dgamma, float* dbeta, float* workspace, int dtype, void* stream) {
     EDGL_REQUIRE(x && gamma && stats && dy && dgamma && dbeta && workspace, EDGL_ERR_NULL,
                  "edgl_add_layernorm_bwd: null pointer");
     int rc = check_ln_shape(B, T, C, dtype, "edgl_add_layernorm_bwd");
@@ -327,7 +338,7 @@ extern "C" int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_r
     p.x = x; p.resid = resid; p.ld_res = ld_res; p.gamma = gamma; p.B = B; p.T = T; p.C = C;
     p.rate = drop_rate; p.rng = rng_state; p.stream_id = stream_id; p.gpos = gather_pos; p.Mg = Mg;
     p.stats = const_cast<float*>(stats); p.dy = dy; p.dsum = dsum; p.dx_drop = dx_drop; p.part = workspace;
-    p.dy_rowmap = dy_rowmap;
+    p.dy_rowmap = dy_rowmap; p.act_pre = act_pre;
     const int vec = dtype == EDGL_BF16 ? 8 : 4;
     const int rows_par = LN_THREADS / (C / vec);
     const size_t smem = (8 + (size_t)rows_par * 2 * C) * sizeof(float) + (size_t)(T + (gather_pos ? Mg : 0)) * sizeof(int);

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* part, int
 template <typename T>
 __global__ void gelu_bwd_kernel(const T* dy, const T* pre, T* dz, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dz[i] = from_f32<T>(to_f32(dy[i]) * dgelu_f(to_f32(pre[i])));
+        dz[i] = from_f32<T>(to_f32(dy[i]) * dgelu_t<T>(to_f32(pre[i])));
 }
 
 template <typename T>

@@ -1,0 +1,362 @@
+// Fused per-sample block tail (EasyDGL.py:110-139): the reference's LayerNorm normalises jointly over (T, C) PER SAMPLE
+// (Base.py:12-67), so one workgroup that owns a sample can run
+//     ao = att.Wo + bo ; a1 = LN1(drop(ao) + x_in) ; f = gelu(a1.Wi + bi) ; o = f.Wout + bout ; y = LN2(drop(o) + a1)
+//     [head]  so = gelu(y.Wt + bt) ; rows = LN3(so)[masked positions]
+// with the [T, C] activations held in LDS between the steps (T = 101, C = 128: 28 KB per tensor) and the weights streamed
+// from L2 as MFMA operands: no HBM round trip between the four dense layers and three LayerNorms — each intermediate is
+// written once (the backward needs it) and never read back by this kernel.  The unfused path is seven launches.
+//   MFMA orientation: D[n][row] = sum_k W^T[n][k] X[row][k]; a wave owns one 16-wide tile of output channels for ALL rows
+//   (A operand = 16 rows of the packed W^T, read from global/L2; B operand = activation rows from LDS), so a lane ends up
+//   with 4 consecutive channels of one row: bias, dropout, residual, GELU and the LayerNorm moments all run on registers;
+//   results go to the next LDS buffer and leave for HBM as whole 256-byte rows.
+// Arithmetic is that of the unfused kernels step for step (GEMM outputs rounded to the activation dtype before the
+// LayerNorm reads them, two-pass moments, the same dropout element indices), so both paths produce the same tensors.
+// bf16, C in {64, 128}, T <= 112.
+#include "edgl_common.h"
+
+namespace {
+
+constexpr int MAXRT = 7;   // 16-row tiles per sample (T <= 112)
+#ifndef GELU_TAIL
+#define GELU_TAIL gelu_f
+#endif
+
+struct TailP {
+    const bf16* att; const bf16* xin; int ld_x;
+    const bf16 *WoT, *WiT, *WoutT, *WtT;            // packed [N][K] images (k contiguous)
+    const float *bo, *bi, *bout, *bt, *g1, *b1, *g2, *b2, *g3, *b3;
+    int B, T, C;
+    float rate; const uint64_t* rng; uint32_t sid1, sid2;
+    const int64_t* mpos; int M; int head;
+    bf16 *ao, *a1, *pre_f, *f, *o, *y, *pre_t, *so, *hrows;
+    float *st1, *st2, *st3;
+};
+
+template <int CT>
+struct TailGeom {
+    static constexpr int C = 16 * CT, NW = CT, NTHR = 64 * CT, LD = C + 8, CV = C / 8;
+    static constexpr size_t BUF = (size_t)MAXRT * 16 * LD * sizeof(bf16);
+    static constexpr size_t SMEM = 4 * BUF + 64 * sizeof(float);
+};
+
+// rows [0, T) of a [T, C] global tensor (row stride ld) -> LDS image [112][LD]; rows >= T are zero
+template <int CT>
+__device__ __forceinline__ void copy_in(bf16* dst, const bf16* src, long ld, int T) {
+    using G = TailGeom<CT>;
+    for (int v = threadIdx.x; v < MAXRT * 16 * G::CV; v += G::NTHR) {
+        const int row = v / G::CV, cv = v % G::CV;
+        uint4 d = make_uint4(0, 0, 0, 0);
+        if (row < T) d = *reinterpret_cast<const uint4*>(src + (long)row * ld + cv * 8);
+        *reinterpret_cast<uint4*>(dst + row * G::LD + cv * 8) = d;
+    }
+}
+template <int CT>
+__device__ __forceinline__ void copy_out(bf16* dst, long ld, const bf16* src, int T) {
+    using G = TailGeom<CT>;
+    for (int v = threadIdx.x; v < T * G::CV; v += G::NTHR) {
+        const int row = v / G::CV, cv = v % G::CV;
+        *reinterpret_cast<uint4*>(dst + (long)row * ld + cv * 8) = *reinterpret_cast<const uint4*>(src + row * G::LD + cv * 8);
+    }
+}
+
+// acc[rt] += W^T[n-tile rows][k0 .. k0 + 32*NKB) . X[rows of tile rt][same k]   (WT row stride ldw, X image stride LD)
+template <int CT, int NKB>
+__device__ __forceinline__ void tile_gemm(const bf16* WTrows, int ldw, const bf16* Xs, int nrt, int lane, f32x4 (&acc)[MAXRT]) {
+    using G = TailGeom<CT>;
+    const int l15 = lane & 15, kg = (lane >> 4) * 8;
+    Vec16<bf16> wf[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) wf[kb] = ld16<bf16>(WTrows + (long)l15 * ldw + kb * 32 + kg);
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) {
+        if (rt < nrt) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+                acc[rt] = mma_kblock(wf[kb], ld16<bf16>(Xs + (rt * 16 + l15) * G::LD + kb * 32 + kg), acc[rt]);
+        }
+        // at most two row tiles' operand reads in flight: unbounded, the scheduler hoists all 7 x NKB LDS reads (112+
+        // registers) above the first MFMA
+        if (rt & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void st_bf4(bf16* dst, const float (&v)[4]) {
+    const Frag4<bf16> f = frag_from_acc<bf16>(f32x4{v[0], v[1], v[2], v[3]});
+    *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(&f);
+}
+__device__ __forceinline__ void ld_bf4(const bf16* src, float (&v)[4]) {
+    const Frag4<bf16> f = frag_ld<bf16>(src);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = to_f32(f.v[r]);
+}
+__device__ __forceinline__ float rbf(float x) { return to_f32(from_f32<bf16>(x)); }   // round through the activation dtype
+
+// Workgroup sum through LDS with LDS-scoped barriers only: __syncthreads() also drains vmcnt, i.e. it would wait for the
+// copy_out stores still in flight (a full HBM write latency at every step of the chain).
+__device__ __forceinline__ float block_sum_lds(float v, float* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    lds_barrier();
+    if (lane == 0) red[w] = v;
+    lds_barrier();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// joint (T, C) moments of the values z[rt][r] held by the workgroup (rows >= T excluded): two passes, as tf.nn.moments
+template <int CT>
+__device__ __forceinline__ void joint_moments(const float (&z)[MAXRT][4], int nrt, int T, int lane, float* red, float& mean, float& rstd) {
+    const int l15 = lane & 15;
+    const float n = (float)T * (float)(16 * CT);
+    float a = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt)
+        if (rt < nrt && rt * 16 + l15 < T) a += (z[rt][0] + z[rt][1]) + (z[rt][2] + z[rt][3]);
+    mean = block_sum_lds(a, red) / n;
+    a = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt)
+        if (rt < nrt && rt * 16 + l15 < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = z[rt][r] - mean; a += d * d; }
+        }
+    rstd = rsqrtf(block_sum_lds(a, red) / n + 1e-12f);
+}
+
+// Four LDS images per workgroup: A (att -> y), B (x_in -> a1 -> LN3 rows), C (f halves, so), S (staging of the tensors
+// that only pass through: ao, pre_f, o, pre_t).  Everything leaves for HBM as whole 256-byte rows (copy_out); storing
+// the pass-through tensors straight from the accumulator registers (8 bytes per lane) measured slower (88 vs 83 us).
+template <int CT>
+__global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
+    using G = TailGeom<CT>;
+    constexpr int C = G::C, LD = G::LD, NKB = C / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* bufA = reinterpret_cast<bf16*>(smem);
+    bf16* bufB = reinterpret_cast<bf16*>(smem + G::BUF);
+    bf16* bufC = reinterpret_cast<bf16*>(smem + 2 * G::BUF);
+    bf16* bufS = reinterpret_cast<bf16*>(smem + 3 * G::BUF);
+    float* red = reinterpret_cast<float*>(smem + 4 * G::BUF);
+    const int b = blockIdx.x, T = p.T, nrt = (T + 15) / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int n0 = wave * 16, nl = n0 + g4;                 // this lane's 4 output channels: nl .. nl + 3
+    const long row0 = (long)b * T;
+    const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
+
+    copy_in<CT>(bufA, p.att + row0 * C, C, T);
+    copy_in<CT>(bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
+    lds_barrier();
+    float z[MAXRT][4];
+    // ---- ao = att.Wo + bo ; z1 = drop(ao) + x_in (EasyDGL.py:113-115) -------------------------------------------------
+    {
+        f32x4 acc[MAXRT];
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tile_gemm<CT, NKB>(p.WoT + (long)n0 * C, C, bufA, nrt, lane, acc);
+        const float4 bb = *reinterpret_cast<const float4*>(p.bo + nl);
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+            if (rt < nrt) {
+                const int row = rt * 16 + l15;
+                float v[4], xr[4];
+                ld_bf4(bufB + row * LD + nl, xr);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = rbf(acc[rt][r] + bv[r]);
+                    z[rt][r] = drop_apply(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), v[r]) + xr[r];
+                }
+                st_bf4(bufS + row * LD + nl, v);
+            }
+    }
+    lds_barrier();
+    copy_out<CT>(p.ao + row0 * C, C, bufS, T);
+    // ---- a1 = LN1(z1) (EasyDGL.py:116) -> B, in place of the residual it consumed -----------------------------------------
+    {
+        float mean, rstd;
+        joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
+        if (threadIdx.x == 0) { p.st1[2 * b] = mean; p.st1[2 * b + 1] = rstd; }
+        const float4 gg = *reinterpret_cast<const float4*>(p.g1 + nl), be = *reinterpret_cast<const float4*>(p.b1 + nl);
+        const float gv[4] = {gg.x, gg.y, gg.z, gg.w}, ev[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+            if (rt < nrt) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (z[rt][r] - mean) * rstd * gv[r] + ev[r];
+                st_bf4(bufB + (rt * 16 + l15) * LD + nl, v);
+            }
+    }
+    lds_barrier();
+    copy_out<CT>(p.a1 + row0 * C, C, bufB, T);
+    // ---- f = gelu(a1.Wi + bi) in two halves of C columns; o accumulates f.Wout half by half (EasyDGL.py:120-125) ----------
+    f32x4 acc3[MAXRT];
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) acc3[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < 2; ++h) {
+        {
+            f32x4 acc[MAXRT];
+#pragma unroll
+            for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            tile_gemm<CT, NKB>(p.WiT + (long)(h * C + n0) * C, C, bufB, nrt, lane, acc);
+            const float4 bb = *reinterpret_cast<const float4*>(p.bi + h * C + nl);
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int rt = 0; rt < MAXRT; ++rt)
+                if (rt < nrt) {
+                    const int row = rt * 16 + l15;
+                    float pre[4], fv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pre[r] = acc[rt][r] + bv[r]; fv[r] = GELU_TAIL(pre[r]); }
+                    st_bf4(bufS + row * LD + nl, pre);
+                    st_bf4(bufC + row * LD + nl, fv);
+                }
+        }
+        lds_barrier();
+        copy_out<CT>(p.pre_f + row0 * 2 * C + h * C, 2 * C, bufS, T);
+        copy_out<CT>(p.f + row0 * 2 * C + h * C, 2 * C, bufC, T);
+        tile_gemm<CT, NKB>(p.WoutT + (long)n0 * 2 * C + h * C, 2 * C, bufC, nrt, lane, acc3);
+        lds_barrier();
+    }
+    // ---- o = . + bout ; z2 = drop(o) + a1 ; y = LN2(z2) (EasyDGL.py:126-128) -> A ---------------------------------------------
+    {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bout + nl);
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+            if (rt < nrt) {
+                const int row = rt * 16 + l15;
+                float v[4], xr[4];
+                ld_bf4(bufB + row * LD + nl, xr);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = rbf(acc3[rt][r] + bv[r]);
+                    z[rt][r] = drop_apply(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), v[r]) + xr[r];
+                }
+                st_bf4(bufS + row * LD + nl, v);
+            }
+    }
+    lds_barrier();
+    copy_out<CT>(p.o + row0 * C, C, bufS, T);
+    {
+        float mean, rstd;
+        joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
+        if (threadIdx.x == 0) { p.st2[2 * b] = mean; p.st2[2 * b + 1] = rstd; }
+        const float4 gg = *reinterpret_cast<const float4*>(p.g2 + nl), be = *reinterpret_cast<const float4*>(p.b2 + nl);
+        const float gv[4] = {gg.x, gg.y, gg.z, gg.w}, ev[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+            if (rt < nrt) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (z[rt][r] - mean) * rstd * gv[r] + ev[r];
+                st_bf4(bufA + (rt * 16 + l15) * LD + nl, v);
+            }
+    }
+    lds_barrier();
+    copy_out<CT>(p.y + row0 * C, C, bufA, T);
+    if (!p.head) return;
+    // ---- head: so = gelu(y.Wt + bt) ; rows = LN3(so)[masked positions] (EasyDGL.py:136-146) --------------------------------
+    {
+        f32x4 acc[MAXRT];
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tile_gemm<CT, NKB>(p.WtT + (long)n0 * C, C, bufA, nrt, lane, acc);
+        const float4 bb = *reinterpret_cast<const float4*>(p.bt + nl);
+        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+            if (rt < nrt) {
+                const int row = rt * 16 + l15;
+                float pre[4], sv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pre[r] = acc[rt][r] + bv[r]; sv[r] = GELU_TAIL(pre[r]); z[rt][r] = rbf(sv[r]); }
+                st_bf4(bufS + row * LD + nl, pre);
+                st_bf4(bufC + row * LD + nl, sv);
+            }
+    }
+    lds_barrier();
+    copy_out<CT>(p.pre_t + row0 * C, C, bufS, T);
+    copy_out<CT>(p.so + row0 * C, C, bufC, T);
+    {
+        float mean, rstd;
+        joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
+        if (threadIdx.x == 0) { p.st3[2 * b] = mean; p.st3[2 * b + 1] = rstd; }
+        const float4 gg = *reinterpret_cast<const float4*>(p.g3 + nl), be = *reinterpret_cast<const float4*>(p.b3 + nl);
+        const float gv[4] = {gg.x, gg.y, gg.z, gg.w}, ev[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+            if (rt < nrt) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (z[rt][r] - mean) * rstd * gv[r] + ev[r];
+                st_bf4(bufB + (rt * 16 + l15) * LD + nl, v);
+            }
+    }
+    lds_barrier();
+    for (int v = threadIdx.x; v < p.M * G::CV; v += G::NTHR) {      // batch_gather of the masked positions (EasyDGL.py:142-143)
+        const int j = v / G::CV, cv = v % G::CV;
+        const int t = (int)p.mpos[(long)b * p.M + j];
+        *reinterpret_cast<uint4*>(p.hrows + ((long)b * p.M + j) * C + cv * 8) = *reinterpret_cast<const uint4*>(bufB + t * LD + cv * 8);
+    }
+}
+
+// dst[n][k] = src[k][n]  (tf.layers.dense kernels are [in, out]; the MFMA A operand wants k contiguous)
+__global__ void tail_pack_kernel(const bf16* Wo, const bf16* Wi, const bf16* Wout, const bf16* Wt, int C, bf16* pack) {
+    const long cc = (long)C * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 6 * cc; i += (long)gridDim.x * blockDim.x) {
+        const bf16* src; long off; int K, N;
+        if (i < cc) { src = Wo; off = 0; K = C; N = C; }
+        else if (i < 3 * cc) { src = Wi; off = cc; K = C; N = 2 * C; }
+        else if (i < 5 * cc) { src = Wout; off = 3 * cc; K = 2 * C; N = C; }
+        else { src = Wt; off = 5 * cc; K = C; N = C; }
+        const long j = i - off;
+        const int n = (int)(j / K), k = (int)(j % K);
+        pack[i] = src[(long)k * N + n];
+    }
+}
+
+}  // namespace
+
+extern "C" long edgl_tail_pack_elems(int C) { return 6L * C * C; }
+
+extern "C" int edgl_tail_supported(int T, int C, int dtype) { return dtype == EDGL_BF16 && (C == 64 || C == 128) && T >= 1 && T <= 16 * MAXRT; }
+
+extern "C" int edgl_tail_pack(const void* Wo, const void* Wi, const void* Wout, const void* Wt, int C, void* pack, void* stream) {
+    EDGL_REQUIRE(Wo && Wi && Wout && Wt && pack, EDGL_ERR_NULL, "edgl_tail_pack: null pointer");
+    EDGL_REQUIRE(C == 64 || C == 128, EDGL_ERR_SHAPE, "edgl_tail_pack: C=%d unsupported (64 or 128)", C);
+    hipLaunchKernelGGL(tail_pack_kernel, dim3(96), dim3(256), 0, (hipStream_t)stream, (const bf16*)Wo, (const bf16*)Wi,
+                       (const bf16*)Wout, (const bf16*)Wt, C, (bf16*)pack);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const void* pack, const float* bo, const float* bi,
+                             const float* bout, const float* bt, const float* g1, const float* b1, const float* g2,
+                             const float* b2, const float* g3, const float* b3, int B, int T, int C, float drop_rate,
+                             const uint64_t* rng_state, uint32_t sid1, uint32_t sid2, const int64_t* masked_pos, int M, int head,
+                             void* ao, void* a1, float* st1, void* pre_f, void* f, void* o, void* y, float* st2, void* pre_t,
+                             void* so, float* st3, void* hrows, int dtype, void* stream) {
+    EDGL_REQUIRE(att && xin && pack && bo && bi && bout && g1 && b1 && g2 && b2 && ao && a1 && st1 && pre_f && f && o && y && st2,
+                 EDGL_ERR_NULL, "edgl_tail_fwd: null pointer");
+    EDGL_REQUIRE(!head || (bt && g3 && b3 && masked_pos && pre_t && so && st3 && hrows && M >= 1), EDGL_ERR_NULL,
+                 "edgl_tail_fwd: the head needs its weights, positions and outputs");
+    EDGL_REQUIRE(B > 0 && edgl_tail_supported(T, C, dtype) && ld_x % 8 == 0, EDGL_ERR_SHAPE,
+                 "edgl_tail_fwd: unsupported shape B=%d T=%d C=%d dtype=%d (bf16, C in {64,128}, T <= 112)", B, T, C, dtype);
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_tail_fwd: dropout without rng_state");
+    const bf16* pk = (const bf16*)pack;
+    const long cc = (long)C * C;
+    TailP p{(const bf16*)att, (const bf16*)xin, ld_x, pk, pk + cc, pk + 3 * cc, pk + 5 * cc, bo, bi, bout, bt, g1, b1, g2, b2, g3, b3,
+            B, T, C, drop_rate, rng_state, sid1, sid2, masked_pos, M, head, (bf16*)ao, (bf16*)a1, (bf16*)pre_f, (bf16*)f, (bf16*)o,
+            (bf16*)y, (bf16*)pre_t, (bf16*)so, (bf16*)hrows, st1, st2, st3};
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 128) {
+        hipFuncSetAttribute((const void*)tail_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailGeom<8>::SMEM);
+        hipLaunchKernelGGL((tail_fwd_kernel<8>), dim3(B), dim3(512), TailGeom<8>::SMEM, st, p);
+    } else {
+        hipFuncSetAttribute((const void*)tail_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailGeom<4>::SMEM);
+        hipLaunchKernelGGL((tail_fwd_kernel<4>), dim3(B), dim3(256), TailGeom<4>::SMEM, st, p);
+    }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}

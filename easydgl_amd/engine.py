@@ -13,6 +13,7 @@ weights against the autograd path and the fp64 oracle.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -25,7 +26,7 @@ EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 
 
 
 class TrainEngine:
-    def __init__(self, model, batch: int, use_graph: bool = True, process_group=None):
+    def __init__(self, model, batch: int, use_graph: bool = True, process_group=None, fused_tail=None):
         self.m = model
         self.B = batch
         self.use_graph = use_graph
@@ -62,6 +63,10 @@ class TrainEngine:
                      dlam=e(H * B, T, E, dtype=f32), tpp=e(lib.edgl_tpp_workspace(), dtype=f32))
             self.blk.append(d)
         self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
+        # fused per-sample block tail (csrc/k_tail.hip): one launch for dense -> LN -> GELU-dense -> dense -> LN (-> head)
+        ok = bool(lib.edgl_tail_supported(T, C, self.code)) and os.environ.get("EDGL_FUSED_TAIL", "1") != "0"
+        self.fused_tail = ok if fused_tail is None else (bool(fused_tail) and ok)
+        self.tail_pack = [e(int(lib.edgl_tail_pack_elems(C))) for _ in range(nb)] if self.fused_tail else []
         self.hrows, self.hrows_c = e(self.R, C), e(self.R, C)
         self.labels_c = torch.zeros(self.R, device=dev, dtype=torch.int64)
         self.perm, self.inv = e(self.R, dtype=torch.int32), e(self.R, dtype=torch.int32)
@@ -125,14 +130,14 @@ class TrainEngine:
                                          _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(y), _ptr(stats),
                                          self.code, _stream()), "edgl_add_layernorm_fwd")
 
-    def _ln_bwd(self, x, resid, ld_res, ln, stats, dy, drop, dsum, dx_drop, gpos=None, rowmap=None):
+    def _ln_bwd(self, x, resid, ld_res, ln, stats, dy, drop, dsum, dx_drop, gpos=None, rowmap=None, act_pre=None):
         B, T, C = self.B, self.T, self.C
-        check(lib.edgl_add_layernorm_bwd(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
-                                         _ptr(stats), _ptr(dy), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
-                                         _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(rowmap), _ptr(dsum),
-                                         _ptr(dx_drop), _ptr(ln.gamma.grad), _ptr(ln.beta.grad), _ptr(self._ws(B * 2 * C)),
-                                         self.code, _stream()),
-              "edgl_add_layernorm_bwd")
+        check(lib.edgl_add_layernorm_bwd_act(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
+                                             _ptr(stats), _ptr(dy), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
+                                             _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(rowmap), _ptr(act_pre),
+                                             _ptr(dsum), _ptr(dx_drop), _ptr(ln.gamma.grad), _ptr(ln.beta.grad),
+                                             _ptr(self._ws(B * 2 * C)), self.code, _stream()),
+              "edgl_add_layernorm_bwd_act")
 
     # ---- one optimizer step, as a fixed launch sequence ----------------------------------------------------------------
     def _issue(self):
@@ -160,14 +165,30 @@ class TrainEngine:
             check(lib.edgl_bimau_fwd(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
                                      _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
                                      _ptr(b["lam"]), _ptr(b["saved"]), 0, code, st), "edgl_bimau_fwd")
-            self._dense_fwd(b["att"], blk.att_out.kernel, blk.att_out.bias, b["ao"], C, C)
-            self._ln_fwd(b["ao"], x, cin, blk.att_ln, drop(hd, 11 + 4 * i), b["a1"], b["st1"])
-            self._dense_fwd(b["a1"], blk.inter.kernel, blk.inter.bias, b["f"], C, 2 * C, gelu=True, pre=b["pre_f"])
-            self._dense_fwd(b["f"], blk.out.kernel, blk.out.bias, b["o"], 2 * C, C)
-            self._ln_fwd(b["o"], b["a1"], C, blk.out_ln, drop(hd, 12 + 4 * i), b["y"], b["st2"])
+            if self.fused_tail:
+                last = i == len(self.blk) - 1
+                pk = self.tail_pack[i]
+                check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
+                                         _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C, _ptr(pk), st),
+                      "edgl_tail_pack")
+                dh1 = drop(hd, 11 + 4 * i)
+                check(lib.edgl_tail_fwd(_ptr(b["att"]), x.data_ptr(), cin, _ptr(pk), _ptr(blk.att_out.bias), _ptr(blk.inter.bias),
+                                        _ptr(blk.out.bias), _ptr(m.transform.bias), _ptr(blk.att_ln.gamma), _ptr(blk.att_ln.beta),
+                                        _ptr(blk.out_ln.gamma), _ptr(blk.out_ln.beta), _ptr(m.transform_ln.gamma),
+                                        _ptr(m.transform_ln.beta), B, T, C, float(dh1.rate), dh1.ptr(), 11 + 4 * i, 12 + 4 * i,
+                                        _ptr(self.mpos), M, int(last), _ptr(b["ao"]), _ptr(b["a1"]), _ptr(b["st1"]), _ptr(b["pre_f"]),
+                                        _ptr(b["f"]), _ptr(b["o"]), _ptr(b["y"]), _ptr(b["st2"]), _ptr(self.pre_t), _ptr(self.so),
+                                        _ptr(self.st3), _ptr(self.hrows), code, st), "edgl_tail_fwd")
+            else:
+                self._dense_fwd(b["att"], blk.att_out.kernel, blk.att_out.bias, b["ao"], C, C)
+                self._ln_fwd(b["ao"], x, cin, blk.att_ln, drop(hd, 11 + 4 * i), b["a1"], b["st1"])
+                self._dense_fwd(b["a1"], blk.inter.kernel, blk.inter.bias, b["f"], C, 2 * C, gelu=True, pre=b["pre_f"])
+                self._dense_fwd(b["f"], blk.out.kernel, blk.out.bias, b["o"], 2 * C, C)
+                self._ln_fwd(b["o"], b["a1"], C, blk.out_ln, drop(hd, 12 + 4 * i), b["y"], b["st2"])
             x, cin = b["y"], C
-        self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, C, C, gelu=True, pre=self.pre_t)
-        self._ln_fwd(self.so, None, 0, m.transform_ln, ops.NO_DROP, self.hrows, self.st3, gpos=self.mpos)
+        if not (self.fused_tail and self.blk):
+            self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, C, C, gelu=True, pre=self.pre_t)
+            self._ln_fwd(self.so, None, 0, m.transform_ln, ops.NO_DROP, self.hrows, self.st3, gpos=self.mpos)
         # rows whose label is 0 have weight 0 (EasyDGL.py:180): score only the weighted ones
         check(lib.edgl_compact_rows(_ptr(self.hrows), _ptr(self.labels), R, C, _ptr(self.perm), _ptr(self.inv),
                                     _ptr(self.nvalid), _ptr(self.hrows_c), _ptr(self.labels_c), code, st), "edgl_compact_rows")
@@ -209,10 +230,9 @@ class TrainEngine:
                                     _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows), _ptr(tab.grad),
                                     _ptr(m.output_bias.grad), _ptr(self.ws), code, st), "edgl_score_ce_bwd")
         # head: LN (gathered rows) -> gelu' -> dense
+        # the GELU' of the head transform rides in the LayerNorm backward (G1 = gradient w.r.t. the dense pre-activation)
         self._ln_bwd(self.so, None, 0, m.transform_ln, self.st3, self.d_rows, ops.NO_DROP, self.G1, None, gpos=self.mpos,
-                     rowmap=self.inv)
-        n = self.rows * C
-        check(lib.edgl_gelu_bwd(_ptr(self.G1), _ptr(self.pre_t), _ptr(self.G1), n, code, st), "edgl_gelu_bwd")
+                     rowmap=self.inv, act_pre=self.pre_t)
         y_last = self.blk[-1]["y"] if self.blk else self.x0
         self._dense_dw(y_last, self.G1, m.transform.kernel, m.transform.bias, C, C)
         self._dense_dx(self.G1, m.transform.kernel, self.G2, C, C)

@@ -191,6 +191,13 @@ int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_res, const f
                            const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
                            int Mg, const int32_t* dy_rowmap, void* dsum, void* dx_drop, float* dgamma,
                            float* dbeta, float* workspace, int dtype, void* stream);
+/* The same with a fused activation backward: x is gelu(act_pre) (the head transform, EasyDGL.py:136-139); the emitted
+ * gradients (dsum, dx_drop) are multiplied by gelu'(act_pre) — the gradient w.r.t. the dense layer's pre-activation. */
+int edgl_add_layernorm_bwd_act(const void* x, const void* resid, int ld_res, const float* gamma,
+                               const float* stats, const void* dy, int B, int T, int C, float drop_rate,
+                               const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                               int Mg, const int32_t* dy_rowmap, const void* act_pre, void* dsum, void* dx_drop,
+                               float* dgamma, float* dbeta, float* workspace, int dtype, void* stream);
 
 /* ---- K5: tied-embedding scoring + cross-entropy — EasyDGL.py:149-155,177-185, Base.py:106-110 --
  * rows [R,C] `dtype`; table [I,C] `dtype` (row 0 acts as zeros, column 0 logit == -1000); out_bias
@@ -396,6 +403,27 @@ int edgl_time_function_fwd(const float* x, long n, const float* freq, const floa
 long edgl_time_function_bwd_workspace(int C);
 int edgl_time_function_bwd(const float* x, long n, const float* freq, const float* phase, int C, const void* d_out,
                            float* d_freq, float* d_phase, float* workspace, int dtype, void* stream);
+
+/* ---- fused per-sample block tail — EasyDGL.py:110-139 in ONE launch (csrc/k_tail.hip) ----------------
+ * The reference's LayerNorm is joint over (T, C) per sample (Base.py:12-67), so a workgroup owning a sample runs
+ *   ao = att.Wo + bo ; a1 = LN1(dropout(ao) + x_in) ; f = gelu(a1.Wi + bi) ; o = f.Wout + bout ; y = LN2(dropout(o) + a1)
+ *   head != 0:  so = gelu(y.Wt + bt) ; hrows[b*M + j] = LN3(so)[masked_pos[b, j]]                     (EasyDGL.py:136-146)
+ * with the activations in LDS between the steps; every intermediate the backward reads is written once:
+ * ao, a1, o, y, pre_t, so [B,T,C]; pre_f, f [B,T,2C]; st1/st2/st3 f32 [B,2] = (mean, rstd).  Same arithmetic, the same
+ * dropout element indices (streams sid1 / sid2) and the same saved tensors as edgl_gemm + edgl_add_layernorm_fwd, which
+ * remain the path for every other shape: edgl_tail_supported(T, C, dtype) != 0 iff dtype is EDGL_BF16, C in {64, 128},
+ * T <= 112.  att [B,T,C]; xin = the block input's first C channels, row stride ld_x.
+ * pack: edgl_tail_pack_elems(C) elements of `dtype` written by edgl_tail_pack from the four [in, out] kernels (compute
+ * copies) — their [out][in] images, the MFMA operand layout. */
+long edgl_tail_pack_elems(int C);
+int edgl_tail_supported(int T, int C, int dtype);
+int edgl_tail_pack(const void* Wo, const void* Wi, const void* Wout, const void* Wt, int C, void* pack, void* stream);
+int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const void* pack, const float* bo, const float* bi,
+                  const float* bout, const float* bt, const float* g1, const float* b1, const float* g2,
+                  const float* b2, const float* g3, const float* b3, int B, int T, int C, float drop_rate,
+                  const uint64_t* rng_state, uint32_t sid1, uint32_t sid2, const int64_t* masked_pos, int M, int head,
+                  void* ao, void* a1, float* st1, void* pre_f, void* f, void* o, void* y, float* st2, void* pre_t,
+                  void* so, float* st3, void* hrows, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -7,9 +7,9 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d "$OUT/ktrace" -o k -- $BENCH > "$OUT/ktrace.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o f -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o w -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o f -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o w -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/write.log" 2>&1
 grep -h '"metric"' "$OUT/ktrace.log" | tail -1 > "$OUT/bench_line.json"
 ls "$OUT"/*/ 
