@@ -449,28 +449,31 @@ struct TnP {
     int with_colsum;
 };
 
+// TM = output tile edge of a workgroup (4 waves in a 2 x 2 arrangement): 128 (default) or 64 (see tn_tile)
+template <int TM>
 __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
-    __shared__ __attribute__((aligned(16))) bf16 Xs[T_BR * T_LD];
-    __shared__ __attribute__((aligned(16))) bf16 Ys[T_BR * T_LD];
+    constexpr int NI = TM / 32, LDT = TM + 16, PCS = TM / 8, NLD = T_BR * PCS / T_NT;   // 16-byte pieces per row / per thread
+    __shared__ __attribute__((aligned(16))) bf16 Xs[T_BR * LDT];
+    __shared__ __attribute__((aligned(16))) bf16 Ys[T_BR * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
-    const int kf0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int kf0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
     const int r_lo = blockIdx.z * p.rows_per_split, r_hi = min(p.R, r_lo + p.rows_per_split);
-    f32x4 acc[4][4];   // [i: kf tile][j: n tile], L(first = kf, second = n)
+    f32x4 acc[NI][NI];   // [i: kf tile][j: n tile], L(first = kf, second = n)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float csum = 0.f;   // thread t < 128: column n0 + t of Y
-    uint4 px[4], py[4];
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum = 0.f;   // thread t < TM: column n0 + t of Y
+    uint4 px[NLD], py[NLD];
     int r0_cur = 0;
     // unconditional loads (row clamped into the split, column offset into the matrix); rows past the split are zeroed
     // when the tile is written to LDS — a branch around a load would serialise the prefetch on memory latency
     auto load = [&](int r0) {
         r0_cur = r0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = tid + i * T_NT, row = v >> 4, cv = v & 15, gr = min(r0 + row, r_hi - 1);
+        for (int i = 0; i < NLD; ++i) {
+            const int v = tid + i * T_NT, row = v / PCS, cv = v % PCS, gr = min(r0 + row, r_hi - 1);
             const int cx = min(kf0 + cv * 8, p.Kf - 8), cy = min(n0 + cv * 8, p.N - 8);
             px[i] = *reinterpret_cast<const uint4*>(p.X + (long)gr * p.ldx + cx);
             py[i] = *reinterpret_cast<const uint4*>(p.Y + (long)gr * p.ldy + cy);
@@ -478,11 +481,11 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
     };
     auto store = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = tid + i * T_NT, row = v >> 4, cv = v & 15;
+        for (int i = 0; i < NLD; ++i) {
+            const int v = tid + i * T_NT, row = v / PCS, cv = v % PCS;
             const bool ok = r0_cur + row < r_hi;
-            *reinterpret_cast<uint4*>(Xs + row * T_LD + cv * 8) = ok ? px[i] : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(Ys + row * T_LD + cv * 8) = ok ? py[i] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Xs + row * LDT + cv * 8) = ok ? px[i] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Ys + row * LDT + cv * 8) = ok ? py[i] : make_uint4(0, 0, 0, 0);
         }
     };
     const int nstep = (r_hi - r_lo + T_BR - 1) / T_BR;
@@ -493,19 +496,19 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
         if (more) load(r_lo + (st + 1) * T_BR);
 #pragma unroll
         for (int rb = 0; rb < T_BR / 32; ++rb) {
-            bf16x8 af[4], bf_[4];
+            bf16x8 af[NI], bf_[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = tr_frag32(Xs, T_LD, rb * 32, wm * 64 + i * 16, lane);
+            for (int i = 0; i < NI; ++i) af[i] = tr_frag32(Xs, LDT, rb * 32, wm * (TM / 2) + i * 16, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf_[j] = tr_frag32(Ys, T_LD, rb * 32, wn * 64 + j * 16, lane);
+            for (int j = 0; j < NI; ++j) bf_[j] = tr_frag32(Ys, LDT, rb * 32, wn * (TM / 2) + j * 16, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
         }
-        if (p.with_colsum && blockIdx.y == 0 && tid < 128) {
+        if (p.with_colsum && blockIdx.y == 0 && tid < TM) {
 #pragma unroll 8
-            for (int r = 0; r < T_BR; ++r) csum += to_f32(Ys[r * T_LD + tid]);
+            for (int r = 0; r < T_BR; ++r) csum += to_f32(Ys[r * LDT + tid]);
         }
         lds_barrier();       // all reads of this tile done; the next tile's global loads stay in flight across it
         if (more) store();
@@ -513,19 +516,19 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
     }
     float* out = p.partial + (long)blockIdx.z * (p.Kf + 1) * p.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int kf = kf0 + wm * 64 + i * 16 + g4 + r;
+            const int kf = kf0 + wm * (TM / 2) + i * 16 + g4 + r;
             if (kf < p.Kf) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wn * 64 + j * 16 + l15;
+                for (int j = 0; j < NI; ++j) {
+                    const int n = n0 + wn * (TM / 2) + j * 16 + l15;
                     if (n < p.N) out[(long)kf * p.N + n] = acc[i][j][r];
                 }
             }
         }
-    if (p.with_colsum && blockIdx.y == 0 && tid < 128 && n0 + tid < p.N) out[(long)p.Kf * p.N + n0 + tid] = csum;
+    if (p.with_colsum && blockIdx.y == 0 && tid < TM && n0 + tid < p.N) out[(long)p.Kf * p.N + n0 + tid] = csum;
 }
 
 }  // namespace gemm2
@@ -598,8 +601,17 @@ int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, in
 
 // C[Kf,N] = X^T . Y (f32, overwritten or accumulated); if dbias != nullptr also dbias[N] = colsum(Y).
 // workspace floats: edgl_gemm2_tn_workspace(R, Kf, N).
+static int tn_tile(int Kf, int N) {
+    // 128-tiles by default.  64-tiles (EDGL_TN_TILE=64, experiment) quarter the partial slabs of the 128 x 128 layers but
+    // every operand column block is then read by twice as many workgroups: measured +18 us in the GEMMs for -12 us in
+    // the slab reduction.
+    (void)Kf; (void)N;
+    static const int force = getenv("EDGL_TN_TILE") ? atoi(getenv("EDGL_TN_TILE")) : 0;
+    return force == 64 ? 64 : 128;
+}
 static int tn_splits(int R, int Kf, int N) {
-    const int tiles = ((Kf + 127) / 128) * ((N + 127) / 128);
+    const int tm = tn_tile(Kf, N);
+    const int tiles = ((Kf + tm - 1) / tm) * ((N + tm - 1) / tm);
     // row splits: enough workgroups to fill the chip, but every split leaves a [Kf+1, N] f32 slab behind that a second
     // kernel sums — 384 workgroups over a 128x128 output meant 25 MB of partials for a 64 KB result
     static const int target = getenv("EDGL_TN_TARGET") ? atoi(getenv("EDGL_TN_TARGET")) : 384;
@@ -617,7 +629,8 @@ int edgl_gemm2_try_tn(const void* X, const void* Y, float* C, int R, int Kf, int
     int rps = ((R + splits - 1) / splits + T_BR - 1) / T_BR * T_BR;
     splits = (R + rps - 1) / rps;
     TnP p{(const bf16*)X, (const bf16*)Y, R, Kf, N, ldx, ldy, rps, workspace, dbias ? 1 : 0};
-    hipLaunchKernelGGL(tn_gemm_kernel, dim3((N + 127) / 128, (Kf + 127) / 128, splits), dim3(T_NT), 0, st, p);
+    if (tn_tile(Kf, N) == 64) hipLaunchKernelGGL(tn_gemm_kernel<64>, dim3((N + 63) / 64, (Kf + 63) / 64, splits), dim3(T_NT), 0, st, p);
+    else hipLaunchKernelGGL(tn_gemm_kernel<128>, dim3((N + 127) / 128, (Kf + 127) / 128, splits), dim3(T_NT), 0, st, p);
     EDGL_LAUNCH_CHECK();
     if (dbias && dbias == C + (long)Kf * N) {   // (dW, db) contiguous, as in the flat gradient arena: one reduction
         const int rc = edgl_reduce_rows(workspace, splits, (Kf + 1) * N, (long)(Kf + 1) * N, C, accumulate, st);
