@@ -38,10 +38,13 @@ HEADLINE = dict(num_items=20000, seqslen=100, num_units=128, num_heads=8, num_bl
                 hidden_dropout_rate=0.1, attention_probs_dropout_rate=0.1)
 
 # the ONE kernel whose every launch in the timed region is bracketed with HIP events on its launch stream
-# (library hook edgl_profile_next): score_bwd_kernel<ROLE_Y> — d_rows of the fused scoring/CE backward, the
-# kernel family that carries 76 % of the step's algorithmic FLOPs.
+# (library hook edgl_profile_next): score_bwd_kernel<ROLE_YF> — the row-side pass of the fused scoring / cross-entropy: ONE
+# sweep over the item table computes the [R_w, I] logits, their row log-sum-exp AND the row gradients dl . table
+# (flash-style running maxima; edgl_score_flash_fwd).  The scoring family carries 76 % of the step's algorithmic FLOPs
+# (DESIGN.md §5).  With EDGL_FLASH_CE=0 the same slot times the round-1 kernel (ROLE_Y: d_rows only, logits recomputed).
 DOMINANT_KERNEL_ID = 0   # EDGL_KERNEL_SCORE_BWD_ROWS
-DOMINANT_KERNEL = "score_bwd_kernel<bf16, C/16=8, ROLE_Y> (d_rows = dl . table, logits recomputed)"
+DOMINANT_KERNEL = "score_bwd_kernel<bf16, C/16=8, ROLE_YF> (forward logits + row LSE + d_rows = dl . table in one pass)"
+DOMINANT_KERNEL_R1 = "score_bwd_kernel<bf16, C/16=8, ROLE_Y> (d_rows = dl . table, logits recomputed)"
 
 
 def flops_per_seq(c, rows_scored=None):
@@ -313,10 +316,13 @@ def main():
         # rows with label 0 (masked slots that fell on padding) have weight 0 in the loss (EasyDGL.py:180) and are not
         # scored; only the weighted rows count as algorithmic work
         R_w = int((labels != 0).sum().item())
-        # ALGORITHMIC work of the dominant kernel: ONE product d_rows = dl . table = 2*R_w*C*I.  The kernel also
-        # recomputes the [R_w, I] logits tile-wise (another 2*R_w*C*I that never leaves registers): that is executed work, it
-        # counts for `hw_util` (what the MFMA pipe did), not for `frac` (what the algorithm needed).
-        dom_flops = 2.0 * R_w * C * I
+        # ALGORITHMIC work of the dominant kernel.  Flash form: the kernel IS the forward scoring (logits
+        # 2*R_w*C*I — F_score of the forward pass) and the row-gradient product d_rows = dl . table (2*R_w*C*I): both are
+        # algorithmic, nothing is recomputed.  Round-1 form (EDGL_FLASH_CE=0): only the d_rows product is algorithmic, its
+        # logits are a recomputation and count for `hw_util` (what the MFMA pipe did) alone.
+        flash = bool(getattr(res.get("engine"), "flash_ce", False))
+        dom_exec = 4.0 * R_w * C * I
+        dom_flops = dom_exec if flash else 2.0 * R_w * C * I
         dom_ms = dom[1] / max(1, dom[0])
         peak = 2500.0 if args.dtype == "bf16" else 157.3
         traffic = None   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
@@ -344,10 +350,10 @@ def main():
             "loss": round(float(loss), 5), "path": args.path,
             "step_ms_hipevents": {"median": round(float(np.median(ms)), 4), "p10": round(float(np.percentile(ms, 10)), 4),
                                   "p90": round(float(np.percentile(ms, 90)), 4), "n": len(ms)},
-            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL,
+            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL if flash else DOMINANT_KERNEL_R1,
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                         "hw_util": round(2 * ach / peak, 4),
-                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "executed_flop": 2 * dom_flops,
+                         "hw_util": round(dom_exec / (dom_ms * 1e-3) / 1e12 / peak, 4) if dom_ms > 0 else 0.0,
+                         "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "executed_flop": dom_exec,
                          "rows_scored": R_w, "rows_total": R, "traffic": traffic},
             # whole-step MFMA fraction on the work actually done (weight-0 rows are skipped exactly, so they are not counted)
             "whole_step_mfma_frac": round(flops_done / (dt / args.steps) / 1e12 / peak, 4),
@@ -435,7 +441,8 @@ def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=Fa
         dt = float(t.item())
     if not np.isfinite(float(loss)):
         raise RuntimeError("loss is not finite")
-    return {"dt": dt, "loss": loss, "labels": labels, "dom": dom, "step_ms": step_ms, "step": step, "model": model, "feats": feats}
+    return {"dt": dt, "loss": loss, "labels": labels, "dom": dom, "step_ms": step_ms, "step": step, "model": model, "feats": feats,
+            "engine": None if args.path == "autograd" else eng}
 
 
 def extras(c, args, dev):

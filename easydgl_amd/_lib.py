@@ -56,6 +56,9 @@ SIGNATURES = {
     "edgl_ce_loss_fwd": (I, [P, P, P, I, P, P, P]),
     "edgl_score_bwd_workspace": (L, [I, I, I, I, I]),
     "edgl_score_ce_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
+    "edgl_score_flash_workspace": (L, [I, I, I, I, I]),
+    "edgl_score_flash_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, P]),
+    "edgl_score_flash_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_reduce_defer": (I, [I, P]),
     "edgl_reduce_flush": (I, [P]),
     "edgl_mask_topk": (I, [P, I, I, I, P, I, I, P, P, P]),

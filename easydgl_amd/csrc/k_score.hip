@@ -343,7 +343,11 @@ __global__ __launch_bounds__(256) void label_logit_kernel(const T* rows, const T
 // ---------------------------------------------------------------------------------------------
 // backward: ROLE_Y (x = rows, z = items) -> d_rows ; ROLE_W (x = items, z = rows) -> d_table, d_bias
 // ---------------------------------------------------------------------------------------------
-enum { ROLE_Y = 0, ROLE_W = 1 };
+// ROLE_YF ("flash" form of ROLE_Y, used by edgl_score_flash_*): the SAME pass also produces the row log-sum-exp, so the separate
+// forward LSE kernel disappears — dl is exp(logit - running row max) and the accumulators are rescaled whenever the running
+// max of a row moves (rare after the first tiles); the finish kernel divides by the row sum, applies the loss coefficient
+// and subtracts the label row.
+enum { ROLE_Y = 0, ROLE_W = 1, ROLE_YF = 2 };
 
 // NW = 8: one workgroup per CU, double-buffered LDS, register prefetch across the compute phase.
 // NW = 4: two independent 4-wave workgroups per CU, single LDS buffer, next tile fetched at the tile boundary —
@@ -354,7 +358,8 @@ template <typename T, int CT, int ROLE, int NW, int CO = CT>
 __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     constexpr int IX = ScoreCfg<T, CT>::IX;
     constexpr int NTHR = 64 * NW, XBW = 16 * IX * NW;
-    const int ct0 = (CO == CT) ? 0 : (ROLE == ROLE_Y ? (int)blockIdx.y : (int)blockIdx.z) * CO;
+    constexpr bool YS = ROLE != ROLE_W, FLASH = ROLE == ROLE_YF;   // YS: x = rows, z = items
+    const int ct0 = (CO == CT) ? 0 : (YS ? (int)blockIdx.y : (int)blockIdx.z) * CO;
     using S = SC<T, CT, NTHR>;
     constexpr int ZB = S::ZB, JH = S::JH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -369,12 +374,12 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     const int Reff = p.nvalid ? min(p.R, p.nvalid[0]) : p.R;
     // ROLE_Y: 1-D launch, (x-block, item chunk) derived from the valid row count; ROLE_W: x = items (blockIdx.x),
     // the valid rows are split evenly over gridDim.y chunks
-    int bx, by, zchunk;
+    int bx, by, zchunk, nchunk_dev = 1;
     long slab_stride;
-    if (ROLE == ROLE_Y) {
+    if (YS) {
         const DevPlan dp = dev_plan(Reff, XBW, gridDim.x, p.i1 - p.i0, ZB);
         if ((int)blockIdx.x >= dp.nx * dp.nchunk || Reff <= 0) return;
-        bx = blockIdx.x % dp.nx; by = blockIdx.x / dp.nx; zchunk = dp.zchunk;
+        bx = blockIdx.x % dp.nx; by = blockIdx.x / dp.nx; zchunk = dp.zchunk; nchunk_dev = dp.nchunk;
         slab_stride = (long)dp.nx * XBW * S::C;
     } else {
         bx = blockIdx.x; by = blockIdx.y;
@@ -383,17 +388,21 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         slab_stride = (long)p.I * S::C;
     }
     // x side
-    const int xbase = (ROLE == ROLE_Y ? 0 : p.i0) + bx * XBW + wave * 16 * IX;
-    const int xend = ROLE == ROLE_Y ? Reff : p.i1;
+    const int xbase = (YS ? 0 : p.i0) + bx * XBW + wave * 16 * IX;
+    const int xend = YS ? Reff : p.i1;
     Vec16<T> xf[IX][S::NKB];
-    load_xfrags<T, CT, IX>(ROLE == ROLE_Y ? rows : table, xbase, xend, ROLE == ROLE_W, lane, xf);
+    load_xfrags<T, CT, IX>(YS ? rows : table, xbase, xend, ROLE == ROLE_W, lane, xf);
     float x_lse[IX], x_cf[IX], x_bias[IX];
     int x_lab[IX];
+    float m_run[IX], s_run[IX];   // ROLE_YF: running row max (uniform over the 4 lane groups) and this lane's part of the row sum
 #pragma unroll
     for (int ix = 0; ix < IX; ++ix) {
         const int gx = xbase + ix * 16 + l15;
         const bool ok = gx < xend;
-        if (ROLE == ROLE_Y) {
+        m_run[ix] = -INFINITY; s_run[ix] = 0.f;
+        if (FLASH) {
+            x_lse[ix] = 0.f; x_cf[ix] = 0.f; x_lab[ix] = -1; x_bias[ix] = 0.f;
+        } else if (ROLE == ROLE_Y) {
             x_cf[ix] = ok ? p.coef[gx] : 0.f;
             // coef*exp(x - lse) = exp(x - (lse - log coef)); coef == 0 (label 0 / row past the end) -> +inf -> 0
             x_lse[ix] = x_cf[ix] > 0.f ? p.row_lse[gx] - __logf(x_cf[ix]) : INFINITY;
@@ -405,18 +414,18 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         }
     }
     // z side
-    const int z_lo = (ROLE == ROLE_Y ? p.i0 : 0) + by * zchunk;
-    const int z_hi = min(ROLE == ROLE_Y ? p.i1 : Reff, z_lo + zchunk);
-    const T* zsrc = ROLE == ROLE_Y ? table : rows;
-    const T* zsrcT = ROLE == ROLE_Y ? tableT : rowsT;
-    const int ldT = ROLE == ROLE_Y ? p.ldt : p.ldr;
+    const int z_lo = (YS ? p.i0 : 0) + by * zchunk;
+    const int z_hi = min(YS ? p.i1 : Reff, z_lo + zchunk);
+    const T* zsrc = YS ? table : rows;
+    const T* zsrcT = YS ? tableT : rowsT;
+    const int ldT = YS ? p.ldt : p.ldr;
 
     auto fill_info = [&](char* buf, int z0) {
         float* info = reinterpret_cast<float*>(buf + S::Z_BYTES + S::ZT_BYTES);
         if (tid < ZB) {
             const int gz = z0 + tid;
             const bool ok = gz < z_hi;
-            if (ROLE == ROLE_Y) {
+            if (YS) {
                 info[tid] = (ok && gz > 0) ? p.out_bias[gz - 1] : 0.f;
             } else {
                 const float cf = ok ? p.coef[gz] : 0.f;
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     ZStream<T, CT, true, NTHR> zs;
     const int ntile = z_hi > z_lo ? (z_hi - z_lo + ZB - 1) / ZB : 0;
     if (ntile > 0) {
-        zs.load(zsrc, zsrcT, ldT, z_lo, z_hi, ROLE == ROLE_Y);
+        zs.load(zsrc, zsrcT, ldT, z_lo, z_hi, YS);
         zs.store(reinterpret_cast<T*>(smem), reinterpret_cast<T*>(smem + S::Z_BYTES));
         fill_info(smem, z_lo);
     }
@@ -449,11 +458,11 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         const bool more = it + 1 < ntile;
         char* cur = smem + (DOUBLE ? (size_t)(it & 1) * BUF : 0);
         char* nxt = smem + (DOUBLE ? (size_t)((it + 1) & 1) * BUF : 0);
-        if (PREFETCH && more && !(p.dbg & 4)) zs.load_z(zsrc, z0 + ZB, z_hi, ROLE == ROLE_Y);
+        if (PREFETCH && more && !(p.dbg & 4)) zs.load_z(zsrc, z0 + ZB, z_hi, YS);
         const T* Zs = reinterpret_cast<const T*>(cur);
         const T* ZTs = reinterpret_cast<const T*>(cur + S::Z_BYTES);
         const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES + S::ZT_BYTES);
-        const bool edge = (ROLE == ROLE_Y) && ((z0 == 0) || (z0 + ZB > z_hi));
+        const bool edge = YS && ((z0 == 0) || (z0 + ZB > z_hi));
 #pragma unroll
         for (int half = 0; half < S::NH; ++half) {
             f32x4 acc[JH][IX];
@@ -465,7 +474,61 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                     for (int ix = 0; ix < IX; ++ix) acc[j][ix] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
             }
             // ---- dl[z][x] in place ------------------------------------------------------------------
-            if (!(p.dbg & 1))
+            if constexpr (FLASH) {
+                float tmax[IX];
+#pragma unroll
+                for (int ix = 0; ix < IX; ++ix) tmax[ix] = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < JH; ++j) {
+                    const int jz = half * JH + j;
+                    const float4 t4 = *reinterpret_cast<const float4*>(info + jz * 16 + g4);
+                    const float zb[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                    for (int ix = 0; ix < IX; ++ix)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = acc[j][ix][r] + zb[r];
+                            if (edge) {
+                                const int gz = z0 + jz * 16 + g4 + r;
+                                x = (gz == 0) ? -1000.0f : x;          // zero-padded row . y + (-1000)  (Base.py:110)
+                                x = (gz < z_hi) ? x : -INFINITY;
+                            }
+                            acc[j][ix][r] = x;
+                            tmax[ix] = fmaxf(tmax[ix], x);
+                        }
+                }
+                bool moved = false;
+                float corr[IX];
+#pragma unroll
+                for (int ix = 0; ix < IX; ++ix) {
+                    const float m_new = fmaxf(m_run[ix], group_max4(tmax[ix]));
+                    corr[ix] = (m_run[ix] > -INFINITY) ? __expf(m_run[ix] - m_new) : 0.f;
+                    moved = moved || (m_new > m_run[ix]);
+                    m_run[ix] = m_new;
+                }
+                if (__any(moved)) {     // rescale what was accumulated against the old maxima (wave-uniform branch)
+#pragma unroll
+                    for (int ix = 0; ix < IX; ++ix) {
+                        s_run[ix] *= corr[ix];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float f = __shfl(corr[ix], g4 + r, 64);   // the factor of row x = ix*16 + g4 + r sits in lane g4 + r
+#pragma unroll
+                            for (int ct = 0; ct < CO; ++ct) out[ix][ct][r] *= f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < JH; ++j)
+#pragma unroll
+                    for (int ix = 0; ix < IX; ++ix)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float d = __expf(acc[j][ix][r] - m_run[ix]);
+                            s_run[ix] += d;
+                            acc[j][ix][r] = d;
+                        }
+            } else if (!(p.dbg & 1))
 #pragma unroll
             for (int j = 0; j < JH; ++j) {
                 const int jz = half * JH + j;
@@ -542,8 +605,8 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         }
         if (!DOUBLE) __syncthreads();
         if (more && !(p.dbg & 4)) {
-            if (!PREFETCH) zs.load_z(zsrc, z0 + ZB, z_hi, ROLE == ROLE_Y);
-            zs.load_t(zsrcT, ldT, z0 + ZB, z_hi, ROLE == ROLE_Y);   // short-lived: the other wave of the SIMD covers it
+            if (!PREFETCH) zs.load_z(zsrc, z0 + ZB, z_hi, YS);
+            zs.load_t(zsrcT, ldT, z0 + ZB, z_hi, YS);   // short-lived: the other wave of the SIMD covers it
             zs.store(reinterpret_cast<T*>(nxt), reinterpret_cast<T*>(nxt + S::Z_BYTES));
             fill_info(nxt, z0 + ZB);
         }
@@ -561,6 +624,17 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                 for (int ct = 0; ct < CO; ++ct) slab[(long)gx * S::C + (ct0 + ct) * 16 + l15] = out[ix][ct][r];
             }
         }
+    if (FLASH && ct0 == 0) {   // (row max, row sum) of this item chunk: lse_combine_kernel / flash_finish_kernel merge the chunks
+#pragma unroll
+        for (int ix = 0; ix < IX; ++ix) {
+            const float sm = group_sum4(s_run[ix]);
+            const int gx = xbase + ix * 16 + l15;
+            if (lane < 16 && gx < xend) {
+                p.part[((long)gx * nchunk_dev + by) * 2] = m_run[ix];
+                p.part[((long)gx * nchunk_dev + by) * 2 + 1] = sm;
+            }
+        }
+    }
     if (ROLE == ROLE_W && ct0 == 0) {
 #pragma unroll
         for (int ix = 0; ix < IX; ++ix) {
@@ -596,6 +670,33 @@ __global__ void slab_reduce_rows_kernel(const float* slabs, const int32_t* nvali
         if (i < nval)
             for (int s = 0; s < dp.nchunk; ++s) a += slabs[(long)s * stride + i];
         out[i] = from_f32<TO>(a * gs);
+    }
+}
+
+// ROLE_YF finish: d_rows[r] = gs * coef[r] * ( sum_chunks slab_c[r] * exp(m_c - lse[r])  -  table[label[r]] )
+//   = gs * coef * (sum_z p_z T_z - T_label)   (Appendix C: dy_rows = dl . table, dl = coef (p - onehot))
+template <typename TO>
+__global__ void flash_finish_kernel(const float* slabs, const float* part, const float* row_lse, const float* coef,
+                                    const int64_t* labels, const TO* table, const int32_t* nvalid, int R, int C, int xb, int zb,
+                                    int G, int ztotal, const float* gscale, TO* out) {
+    const float gs = gscale ? gscale[0] : 1.0f;
+    const int Reff = nvalid ? min(R, nvalid[0]) : R;
+    const DevPlan dp = dev_plan(Reff, xb, G, ztotal, zb);
+    const long stride = (long)dp.nx * xb * C, nval = (long)Reff * C, n = (long)R * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < nval) {
+            const int r = (int)(i / C), c = (int)(i % C);
+            const float cf = coef[r];
+            if (cf != 0.f) {
+                const float lse = row_lse[r];
+                float a = 0.f;
+                for (int s = 0; s < dp.nchunk; ++s) a += slabs[(long)s * stride + i] * __expf(part[((long)r * dp.nchunk + s) * 2] - lse);
+                const int64_t lab = labels[r];
+                v = gs * cf * (a - (lab > 0 ? to_f32(table[lab * C + c]) : 0.f));
+            }
+        }
+        out[i] = from_f32<TO>(v);
     }
 }
 
@@ -906,7 +1007,7 @@ inline int l2_tiles_for(int C, size_t esize, int images, int ZB) { return std::m
 constexpr int F_L2_TILES_MIN = 32;   // smallest value l2_tiles_for(C, esize, 1, zb) takes over the supported (C, dtype): workspace bound
 struct BwdPlan {
     Chunking y, w;
-    long off_rowsT, off_tableT, off_slabY, off_slabW, off_slabB, total;  // float offsets
+    long off_rowsT, off_tableT, off_slabY, off_slabW, off_slabB, off_part, total;  // float offsets
 };
 inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize) {
     BwdPlan b;
@@ -928,6 +1029,7 @@ inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize) {
     b.off_slabY = take((long)b.y.nchunk * xblocks_of(R, xb) * xb * C);   // G workgroups x one [xb, C] tile each
     b.off_slabW = take((long)b.w.nchunk * I * C);
     b.off_slabB = take((long)b.w.nchunk * (I - 1));
+    b.off_part = take(2L * b.y.nchunk * xblocks_of(R, xb) * xb);   // (max, sum) per (row, item chunk) of the ROLE_YF pass
     b.total = o;
     return b;
 }
@@ -945,8 +1047,11 @@ int run_fwd(ScoreP p, hipStream_t st) {
     return EDGL_OK;
 }
 
-template <typename T, int CT>
-int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_table, float* d_bias, hipStream_t st) {
+// MODE 0: edgl_score_ce_bwd (transposes, d_rows with the known lse, d_table / d_bias)
+// MODE 1: edgl_score_flash_fwd (transposes, ROLE_YF pass: unnormalised d_rows slabs + per-chunk (max, sum) -> row lse)
+// MODE 2: edgl_score_flash_bwd (finish d_rows from the slabs of MODE 1, then d_table / d_bias)
+template <typename T, int CT, int MODE>
+int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_table, float* d_bias, hipStream_t st) {
     using S = SC<T, CT>;
     constexpr size_t BUF = S::Z_BYTES + S::ZT_BYTES + S::INFO_BYTES;
     const size_t smem = (2 * BUF <= 160 * 1024) ? 2 * BUF : BUF;
@@ -955,38 +1060,53 @@ int run_bwd(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_tab
     T* rowsT = reinterpret_cast<T*>(ws + plan.off_rowsT);
     T* tableT = reinterpret_cast<T*>(ws + plan.off_tableT);
     p.ldr = (int)up8(p.R); p.ldt = (int)up8(p.I);
-    hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)((p.ldr + 63) / 64), (p.C + 63) / 64), dim3(256), 0, st,
-                       reinterpret_cast<const T*>(p.rows), (long)p.R, p.C, rowsT, (long)p.ldr);
-    EDGL_LAUNCH_CHECK();
-    hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)((p.ldt + 63) / 64), (p.C + 63) / 64), dim3(256), 0, st,
-                       reinterpret_cast<const T*>(p.table), (long)p.I, p.C, tableT, (long)p.ldt);
-    EDGL_LAUNCH_CHECK();
+    if (MODE != 2) {
+        hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)((p.ldr + 63) / 64), (p.C + 63) / 64), dim3(256), 0, st,
+                           reinterpret_cast<const T*>(p.rows), (long)p.R, p.C, rowsT, (long)p.ldr);
+        EDGL_LAUNCH_CHECK();
+        hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)((p.ldt + 63) / 64), (p.C + 63) / 64), dim3(256), 0, st,
+                           reinterpret_cast<const T*>(p.table), (long)p.I, p.C, tableT, (long)p.ldt);
+        EDGL_LAUNCH_CHECK();
+    }
     p.rowsT = rowsT; p.tableT = tableT;
     using Cfg = ScoreCfg<T, CT>;
     constexpr int CO = Cfg::CO, ZBK = S::ZB;
     const int nw = Cfg::NWB == 8 ? score_nw() : Cfg::NWB;
     const size_t smem_nw = nw == 8 ? smem : BUF;
     const int xb = 16 * Cfg::IX * nw;
-    // d_rows
-    {
+    const int G = xblocks_of(p.R, xb) * plan.y.nchunk;
+    float* part = ws + plan.off_part;
+    if (MODE != 2) {   // the row-side pass
+        constexpr int RY = MODE == 1 ? ROLE_YF : ROLE_Y;
         ScoreP q = p;
-        q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY;
+        q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY; q.part = part;
         edgl_prof_begin(EDGL_KERNEL_SCORE_BWD_ROWS, st);
         if (nw == 8) {
-            auto k = score_bwd_kernel<T, CT, ROLE_Y, 8, CO>;
+            auto k = score_bwd_kernel<T, CT, RY, 8, CO>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, xb) * q.nchunk, CT / CO), dim3(512), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(G, CT / CO), dim3(512), smem_nw, st, q);
         } else {
-            auto k = score_bwd_kernel<T, CT, ROLE_Y, 4>;
+            auto k = score_bwd_kernel<T, CT, RY, 4>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
-            hipLaunchKernelGGL(k, dim3(xblocks_of(p.R, xb) * q.nchunk), dim3(256), smem_nw, st, q);
+            hipLaunchKernelGGL(k, dim3(G), dim3(256), smem_nw, st, q);
         }
         edgl_prof_end(EDGL_KERNEL_SCORE_BWD_ROWS, st);
         EDGL_LAUNCH_CHECK();
-        const long n = (long)p.R * p.C;
-        hipLaunchKernelGGL((slab_reduce_rows_kernel<T>), dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st,
-                           q.slabs, p.nvalid, p.R, p.C, xb, ZBK, xblocks_of(p.R, xb) * q.nchunk, p.i1 - p.i0, p.gscale,
-                           reinterpret_cast<T*>(d_rows));
+    }
+    const long nrc = (long)p.R * p.C;
+    if (MODE == 0) {
+        hipLaunchKernelGGL((slab_reduce_rows_kernel<T>), dim3((unsigned)std::min<long>((nrc + 255) / 256, 2048)), dim3(256), 0, st,
+                           ws + plan.off_slabY, p.nvalid, p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
+        EDGL_LAUNCH_CHECK();
+    } else if (MODE == 1) {
+        hipLaunchKernelGGL(lse_combine_kernel, dim3((p.R + 255) / 256), dim3(256), 0, st, part, p.R, p.nvalid, xb, ZBK, G,
+                           p.i1 - p.i0, p.row_lse);
+        EDGL_LAUNCH_CHECK();
+        return EDGL_OK;
+    } else {
+        hipLaunchKernelGGL((flash_finish_kernel<T>), dim3((unsigned)std::min<long>((nrc + 255) / 256, 2048)), dim3(256), 0, st,
+                           ws + plan.off_slabY, part, p.row_lse, p.coef, p.labels, reinterpret_cast<const T*>(p.table), p.nvalid,
+                           p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
         EDGL_LAUNCH_CHECK();
     }
     // d_table, d_bias
@@ -1047,9 +1167,9 @@ int fwd_dispatch(ScoreP p, int C, hipStream_t st) {
     SCORE_DISPATCH(T, CALL_FWD)
 #undef CALL_FWD
 }
-template <typename T>
+template <typename T, int MODE>
 int bwd_dispatch(ScoreP p, int C, const BwdPlan& plan, float* ws, void* d_rows, float* d_table, float* d_bias, hipStream_t st) {
-#define CALL_BWD(T, CT) run_bwd<T, CT>(p, plan, ws, d_rows, d_table, d_bias, st)
+#define CALL_BWD(T, CT) run_bwd_mode<T, CT, MODE>(p, plan, ws, d_rows, d_table, d_bias, st)
     SCORE_DISPATCH(T, CALL_BWD)
 #undef CALL_BWD
 }
@@ -1153,8 +1273,58 @@ extern "C" int edgl_score_ce_bwd(const void* rows, const void* table, const floa
     static const int dbg = getenv("EDGL_DBG") ? atoi(getenv("EDGL_DBG")) : 0;
     p.dbg = dbg;
     hipStream_t st = (hipStream_t)stream;
-    return dtype == EDGL_F32 ? bwd_dispatch<float>(p, C, plan, workspace, d_rows, d_table, d_bias, st)
-                             : bwd_dispatch<bf16>(p, C, plan, workspace, d_rows, d_table, d_bias, st);
+    return dtype == EDGL_F32 ? bwd_dispatch<float, 0>(p, C, plan, workspace, d_rows, d_table, d_bias, st)
+                             : bwd_dispatch<bf16, 0>(p, C, plan, workspace, d_rows, d_table, d_bias, st);
+}
+
+// ---- "flash" form: the forward scoring pass already accumulates the row gradients -------------------------------------------
+// edgl_score_flash_fwd: ONE pass over the item table computes, per weighted row, the log-sum-exp of its logits (as
+// edgl_score_lse_fwd) AND sum_z exp(logit_z - max) table[z] — the row gradient up to the loss coefficient — with flash-style
+// running maxima; the label logits come from the same small gather kernel.  edgl_score_flash_bwd then finishes d_rows
+// (divide by the row sum, apply coef, subtract the label row) and computes d_table / d_bias as edgl_score_ce_bwd does.
+// The logits are computed 2x per step (here and in the d_table pass) instead of 3x.  `workspace` (edgl_score_flash_workspace
+// floats) carries the slabs from the forward to the backward call and must not be touched in between.
+extern "C" long edgl_score_flash_workspace(int R, int C, int I, int n_items, int dtype) {
+    return bwd_plan(R, C, I, n_items, dtype == EDGL_BF16 ? 2 : 4).total;
+}
+
+extern "C" int edgl_score_flash_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
+                                    int C, int I, int i0, int i1, const int32_t* nvalid, float* row_lse, float* label_logit,
+                                    float* workspace, int dtype, void* stream) {
+    int rc = check_score(rows, table, out_bias, R, C, I, i0, i1, dtype, "edgl_score_flash_fwd");
+    if (rc) return rc;
+    EDGL_REQUIRE(labels && row_lse && label_logit && workspace, EDGL_ERR_NULL, "edgl_score_flash_fwd: null pointer");
+    ScoreP p{};
+    p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
+    p.i1 = i1; p.nvalid = nvalid; p.row_lse = row_lse;
+    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
+    hipStream_t st = (hipStream_t)stream;
+    rc = dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
+                           : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);
+    if (rc) return rc;
+    if (dtype == EDGL_F32)
+        hipLaunchKernelGGL((label_logit_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, st, (const float*)rows, (const float*)table, out_bias, labels, R, C, i0, i1, label_logit);
+    else
+        hipLaunchKernelGGL((label_logit_kernel<bf16>), dim3((R + 3) / 4), dim3(256), 0, st, (const bf16*)rows, (const bf16*)table, out_bias, labels, R, C, i0, i1, label_logit);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+extern "C" int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
+                                    const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
+                                    int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias,
+                                    float* workspace, int dtype, void* stream) {
+    int rc = check_score(rows, table, out_bias, R, C, I, i0, i1, dtype, "edgl_score_flash_bwd");
+    if (rc) return rc;
+    EDGL_REQUIRE(labels && row_lse && coef && d_rows && d_table && d_bias && workspace, EDGL_ERR_NULL,
+                 "edgl_score_flash_bwd: null pointer");
+    ScoreP p{};
+    p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
+    p.i1 = i1; p.nvalid = nvalid; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
+    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == EDGL_F32 ? bwd_dispatch<float, 2>(p, C, plan, workspace, d_rows, d_table, d_bias, st)
+                             : bwd_dispatch<bf16, 2>(p, C, plan, workspace, d_rows, d_table, d_bias, st);
 }
 
 extern "C" int edgl_mask_topk(float* logits, int R, int n, int i0, const int64_t* seen, int T, int K, float* out_val,

@@ -14,6 +14,10 @@
 // bf16, C in {64, 128}, T <= 112.
 #include "edgl_common.h"
 
+#ifdef EDGL_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[16];   // see edgl_common.h (PH_MARK); read back with edgl_debug_phase_cycles_tail
+#endif
+
 namespace {
 
 constexpr int MAXRT = 7;   // 16-row tiles per sample (T <= 112)
@@ -143,9 +147,11 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     const long row0 = (long)b * T;
     const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
 
+    PH_DECL
     copy_in<CT>(bufA, p.att + row0 * C, C, T);
     copy_in<CT>(bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
     lds_barrier();
+    PH_MARK(0);   // inputs in LDS
     float z[MAXRT][4];
     // ---- ao = att.Wo + bo ; z1 = drop(ao) + x_in (EasyDGL.py:113-115) -------------------------------------------------
     {
@@ -169,8 +175,10 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
                 st_bf4(bufS + row * LD + nl, v);
             }
     }
+    PH_MARK(1);   // G1 + epilogue
     lds_barrier();
     copy_out<CT>(p.ao + row0 * C, C, bufS, T);
+    PH_MARK(2);   // barrier + copy_out(ao)
     // ---- a1 = LN1(z1) (EasyDGL.py:116) -> B, in place of the residual it consumed -----------------------------------------
     {
         float mean, rstd;
@@ -187,8 +195,10 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
                 st_bf4(bufB + (rt * 16 + l15) * LD + nl, v);
             }
     }
+    PH_MARK(3);   // LN1
     lds_barrier();
     copy_out<CT>(p.a1 + row0 * C, C, bufB, T);
+    PH_MARK(4);   // barrier + copy_out(a1)
     // ---- f = gelu(a1.Wi + bi) in two halves of C columns; o accumulates f.Wout half by half (EasyDGL.py:120-125) ----------
     f32x4 acc3[MAXRT];
 #pragma unroll
@@ -212,11 +222,13 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
                     st_bf4(bufC + row * LD + nl, fv);
                 }
         }
+        PH_MARK(5);   // G2 half + GELU
         lds_barrier();
         copy_out<CT>(p.pre_f + row0 * 2 * C + h * C, 2 * C, bufS, T);
         copy_out<CT>(p.f + row0 * 2 * C + h * C, 2 * C, bufC, T);
         tile_gemm<CT, NKB>(p.WoutT + (long)n0 * 2 * C + h * C, 2 * C, bufC, nrt, lane, acc3);
         lds_barrier();
+        PH_MARK(6);   // barrier + copy_out(pre_f, f) + G3 half + barrier
     }
     // ---- o = . + bout ; z2 = drop(o) + a1 ; y = LN2(z2) (EasyDGL.py:126-128) -> A ---------------------------------------------
     {
@@ -255,6 +267,10 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     }
     lds_barrier();
     copy_out<CT>(p.y + row0 * C, C, bufA, T);
+    PH_MARK(7);   // o, LN2, y
+#ifdef EDGL_PHASE_TIMING
+    PH_FLUSH(0); ph_acc[0] = 0; ph_t0 = __builtin_readcyclecounter();
+#endif
     if (!p.head) return;
     // ---- head: so = gelu(y.Wt + bt) ; rows = LN3(so)[masked positions] (EasyDGL.py:136-146) --------------------------------
     {
@@ -299,6 +315,10 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
         const int t = (int)p.mpos[(long)b * p.M + j];
         *reinterpret_cast<uint4*>(p.hrows + ((long)b * p.M + j) * C + cv * 8) = *reinterpret_cast<const uint4*>(bufB + t * LD + cv * 8);
     }
+#ifdef EDGL_PHASE_TIMING
+    PH_MARK(0);   // head (slot 8)
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_phase_cycles[8], ph_acc[0]);
+#endif
 }
 
 // dst[n][k] = src[k][n]  (tf.layers.dense kernels are [in, out]; the MFMA A operand wants k contiguous)
@@ -360,3 +380,14 @@ extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const v
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
+
+#ifdef EDGL_PHASE_TIMING
+extern "C" int edgl_debug_phase_cycles_tail(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

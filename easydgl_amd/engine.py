@@ -26,7 +26,7 @@ EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32 = 1, 2, 
 
 
 class TrainEngine:
-    def __init__(self, model, batch: int, use_graph: bool = True, process_group=None, fused_tail=None):
+    def __init__(self, model, batch: int, use_graph: bool = True, process_group=None, fused_tail=None, flash_ce=None):
         self.m = model
         self.B = batch
         self.use_graph = use_graph
@@ -67,6 +67,10 @@ class TrainEngine:
         ok = bool(lib.edgl_tail_supported(T, C, self.code)) and os.environ.get("EDGL_FUSED_TAIL", "1") != "0"
         self.fused_tail = ok if fused_tail is None else (bool(fused_tail) and ok)
         self.tail_pack = [e(int(lib.edgl_tail_pack_elems(C))) for _ in range(nb)] if self.fused_tail else []
+        # "flash" scoring: the forward LSE pass also accumulates the row gradients (edgl_score_flash_fwd / _bwd); its
+        # workspace carries the slabs from the forward to the backward and is therefore private
+        self.flash_ce = (os.environ.get("EDGL_FLASH_CE", "1") != "0") if flash_ce is None else bool(flash_ce)
+        self.ws_flash = e(int(lib.edgl_score_flash_workspace(self.R, C, I, I, self.code)), dtype=f32) if self.flash_ce else None
         self.hrows, self.hrows_c = e(self.R, C), e(self.R, C)
         self.labels_c = torch.zeros(self.R, device=dev, dtype=torch.int64)
         self.perm, self.inv = e(self.R, dtype=torch.int32), e(self.R, dtype=torch.int32)
@@ -193,9 +197,14 @@ class TrainEngine:
         check(lib.edgl_compact_rows(_ptr(self.hrows), _ptr(self.labels), R, C, _ptr(self.perm), _ptr(self.inv),
                                     _ptr(self.nvalid), _ptr(self.hrows_c), _ptr(self.labels_c), code, st), "edgl_compact_rows")
         lab = self.labels_c
-        check(lib.edgl_score_lse_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
-                                     _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
-              "edgl_score_lse_fwd")
+        if self.flash_ce:
+            check(lib.edgl_score_flash_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
+                                           _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.ws_flash), code, st),
+                  "edgl_score_flash_fwd")
+        else:
+            check(lib.edgl_score_lse_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
+                                         _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
+                  "edgl_score_lse_fwd")
         check(lib.edgl_ce_loss_fwd(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef), st),
               "edgl_ce_loss_fwd")
         if m.l2_reg != 0.0:
@@ -226,9 +235,15 @@ class TrainEngine:
         B, T, C, H, E, M, I, R = self.B, self.T, self.C, self.H, self.E, self.M, self.I, self.R
         code = self.code
         hd, ad = m.hidden_dropout_rate, m.attention_probs_dropout_rate
-        check(lib.edgl_score_ce_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
-                                    _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows), _ptr(tab.grad),
-                                    _ptr(m.output_bias.grad), _ptr(self.ws), code, st), "edgl_score_ce_bwd")
+        if self.flash_ce:
+            check(lib.edgl_score_flash_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
+                                           _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows),
+                                           _ptr(tab.grad), _ptr(m.output_bias.grad), _ptr(self.ws_flash), code, st),
+                  "edgl_score_flash_bwd")
+        else:
+            check(lib.edgl_score_ce_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
+                                        _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows), _ptr(tab.grad),
+                                        _ptr(m.output_bias.grad), _ptr(self.ws), code, st), "edgl_score_ce_bwd")
         # head: LN (gathered rows) -> gelu' -> dense
         # the GELU' of the head transform rides in the LayerNorm backward (G1 = gradient w.r.t. the dense pre-activation)
         self._ln_bwd(self.so, None, 0, m.transform_ln, self.st3, self.d_rows, ops.NO_DROP, self.G1, None, gpos=self.mpos,

@@ -252,6 +252,23 @@ int edgl_topk_merge(const float* cand_val, const int32_t* cand_idx, int S, int R
 int edgl_rank_metrics(const int32_t* topk_idx, int R, int K, const int64_t* label, float* metrics,
                       void* stream);
 
+/* ---- K5, "flash" form (used by the static training engine): the forward scoring pass already accumulates the row
+ * gradients, so the [R, I] logits are computed twice per step instead of three times.
+ * edgl_score_flash_fwd: one pass over the item rows [i0, i1) gives row_lse (as edgl_score_lse_fwd), label_logit, and keeps
+ * sum_z exp(logit_z - max) table[z] per weighted row (flash-style running maxima) in `workspace`.
+ * edgl_score_flash_bwd: d_rows = gscale * coef * (that sum / row sum - table[label]) — i.e. dl . table with
+ * dl = coef (softmax - onehot), SURVEY Appendix C — then d_table / d_bias exactly as edgl_score_ce_bwd.  `workspace`:
+ * edgl_score_flash_workspace floats, untouched between the two calls.  Other arguments as edgl_score_lse_fwd /
+ * edgl_score_ce_bwd (EasyDGL.py:149-155,177-185). */
+long edgl_score_flash_workspace(int R, int C, int I, int n_items, int dtype);
+int edgl_score_flash_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
+                         int I, int i0, int i1, const int32_t* nvalid, float* row_lse, float* label_logit,
+                         float* workspace, int dtype, void* stream);
+int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
+                         const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
+                         int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias, float* workspace,
+                         int dtype, void* stream);
+
 /* ---- deferred partial reductions ------------------------------------------------------------------
  * The weight-gradient entry points (edgl_gemm_dw, edgl_add_layernorm_bwd, edgl_encode_bwd,
  * edgl_bimau_bwd, edgl_colsum) finish with a small fixed-order reduction of per-workgroup partials.

@@ -568,3 +568,45 @@ def test_ff_tail_equals_dropout_add_mask(name, dt, tol, masked):
     if masked:
         assert float((outs[0][0] == 0).float().mean()) > 0.3      # a third of the rows carries id 0
     assert float((outs[0][1] == 0).float().mean()) > 0.2          # the dropout zeroes ~30 % of d_a
+
+
+@pytest.mark.parametrize("name,dt,tol", DTYPES)
+@pytest.mark.parametrize("R_,C,I", [(300, 128, 2701), (700, 64, 20001), (130, 256, 1500), (260, 512, 3000)])
+def test_score_flash_matches_the_two_pass_kernels(name, dt, tol, R_, C, I):
+    """edgl_score_flash_fwd / _bwd (one pass gives the row log-sum-exp AND the unnormalised row gradients, flash-style running
+    maxima) against edgl_score_lse_fwd + edgl_score_ce_bwd on the same operands: lse, label logits, d_rows, d_table, d_bias."""
+    from easydgl_amd._lib import check, lib
+    o = ops()
+    rng = np.random.default_rng(R_ + C)
+    rows = torch.tensor(_rand((R_, C), rng, 0.6), dtype=dt).cuda()
+    tab_c = torch.tensor(_rand((I, C), rng, 0.4), dtype=dt).cuda()
+    bias = torch.tensor(_rand((I - 1,), rng, 0.3), dtype=torch.float32).cuda()
+    labels = rng.integers(0, I, size=R_)
+    labels[rng.random(R_) < 0.3] = 0
+    rows_c, lab_c, _perm, _inv, nvalid = o.compact_rows(rows, torch.tensor(labels, dtype=torch.int64).cuda())
+    code = o._code(rows)
+    p, st = o._ptr, o._stream()
+    # two-pass path
+    lse0, ll0, _ = o.score_lse(rows_c, tab_c, bias, lab_c, 0, I, nvalid=nvalid)
+    loss = torch.empty(1, device="cuda"); coef = torch.empty(R_, device="cuda")
+    check(lib.edgl_ce_loss_fwd(p(lse0), p(ll0), p(lab_c), R_, p(loss), p(coef), st))
+    d_rows0 = torch.empty_like(rows_c); d_tab0 = torch.empty((I, C), device="cuda"); d_b0 = torch.empty(I - 1, device="cuda")
+    ws = torch.empty(lib.edgl_score_bwd_workspace(R_, C, I, I, code), device="cuda")
+    check(lib.edgl_score_ce_bwd(p(rows_c), p(tab_c), p(bias), p(lab_c), p(lse0), p(coef), None, R_, C, I, 0, I, p(nvalid), p(d_rows0),
+                                p(d_tab0), p(d_b0), p(ws), code, st), "edgl_score_ce_bwd")
+    # flash path
+    wsf = torch.empty(lib.edgl_score_flash_workspace(R_, C, I, I, code), device="cuda")
+    lse1 = torch.empty(R_, device="cuda"); ll1 = torch.zeros(R_, device="cuda")
+    check(lib.edgl_score_flash_fwd(p(rows_c), p(tab_c), p(bias), p(lab_c), R_, C, I, 0, I, p(nvalid), p(lse1), p(ll1), p(wsf), code, st),
+          "edgl_score_flash_fwd")
+    d_rows1 = torch.empty_like(rows_c); d_tab1 = torch.empty((I, C), device="cuda"); d_b1 = torch.empty(I - 1, device="cuda")
+    check(lib.edgl_score_flash_bwd(p(rows_c), p(tab_c), p(bias), p(lab_c), p(lse1), p(coef), None, R_, C, I, 0, I, p(nvalid), p(d_rows1),
+                                   p(d_tab1), p(d_b1), p(wsf), code, st), "edgl_score_flash_bwd")
+    n = int(nvalid.item())
+    assert_close(lse1[:n].cpu().numpy(), lse0[:n].cpu().numpy(), 1e-6 if name == "f32" else 1e-5, "lse")
+    assert torch.equal(ll0, ll1)
+    # the flash form rounds exp(l - max) to the activation dtype and scales in f32 afterwards; the two-pass form rounds coef * p
+    gt = 2e-5 if name == "f32" else 2e-2
+    assert_close(d_rows1.float().cpu().numpy(), d_rows0.float().cpu().numpy(), gt, "d_rows")
+    assert_close(d_tab1.cpu().numpy(), d_tab0.cpu().numpy(), 1e-6, "d_table (same kernel, same lse up to rounding)") if name == "f32" else None
+    assert_close(d_b1.cpu().numpy(), d_b0.cpu().numpy(), 1e-5 if name == "f32" else 1e-3, "d_bias")
