@@ -360,24 +360,36 @@ def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False, nvalid
 
 class ScoreCEFn(torch.autograd.Function):
     """EasyDGL.py:149-155,177-185 without the [R, I] logits tensor.  Rows with label 0 carry weight 0
-    (EasyDGL.py:180); they are compacted away before scoring, which changes neither loss nor gradients."""
+    (EasyDGL.py:180); they are compacted away before scoring, which changes neither loss nor gradients.
+    When a gradient is wanted the forward is the flash form (edgl_score_flash_fwd): the same sweep over the item table that
+    gives the row log-sum-exp also accumulates the row gradients, and the backward only finishes them."""
 
     @staticmethod
     def forward(ctx, rows, table_master, out_bias, table_c, labels):
         rows, labels, _perm, inv, nvalid = compact_rows(rows.contiguous(), labels.reshape(-1).contiguous())
         R, C = rows.shape
         I = table_c.shape[0]
-        lse, lab_logit, _ = score_lse(rows, table_c, out_bias, labels, 0, I, nvalid=nvalid)
+        flash = any(ctx.needs_input_grad)
+        ws = None
+        if flash:
+            code = _code(rows)
+            ws = torch.empty(int(lib.edgl_score_flash_workspace(R, C, I, I, code)), device=rows.device, dtype=torch.float32)
+            lse = torch.empty(R, device=rows.device, dtype=torch.float32)
+            lab_logit = torch.zeros(R, device=rows.device, dtype=torch.float32)
+            check(lib.edgl_score_flash_fwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), R, C, I, 0, I, _ptr(nvalid),
+                                           _ptr(lse), _ptr(lab_logit), _ptr(ws), code, _stream()), "edgl_score_flash_fwd")
+        else:
+            lse, lab_logit, _ = score_lse(rows, table_c, out_bias, labels, 0, I, nvalid=nvalid)
         loss = torch.empty(1, device=rows.device, dtype=torch.float32)
         coef = torch.empty(R, device=rows.device, dtype=torch.float32)
         check(lib.edgl_ce_loss_fwd(_ptr(lse), _ptr(lab_logit), _ptr(labels), R, _ptr(loss), _ptr(coef), _stream()),
               "edgl_ce_loss_fwd")
-        ctx.save_for_backward(rows, table_c, out_bias, labels, lse, coef, inv, nvalid)
+        ctx.save_for_backward(rows, table_c, out_bias, labels, lse, coef, inv, nvalid, ws)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        rows, table_c, out_bias, labels, lse, coef, inv, nvalid = ctx.saved_tensors
+        rows, table_c, out_bias, labels, lse, coef, inv, nvalid, ws = ctx.saved_tensors
         R, C = rows.shape
         I = table_c.shape[0]
         dev = rows.device
@@ -386,10 +398,9 @@ class ScoreCEFn(torch.autograd.Function):
         d_rows = torch.empty_like(rows)
         d_table = torch.empty((I, C), device=dev, dtype=torch.float32)
         d_bias = torch.empty(I - 1, device=dev, dtype=torch.float32)
-        ws = torch.empty(lib.edgl_score_bwd_workspace(R, C, I, I, _code(rows)), device=dev, dtype=torch.float32)
-        check(lib.edgl_score_ce_bwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), _ptr(lse), _ptr(coef),
-                                    _ptr(g), R, C, I, 0, I, _ptr(nvalid), _ptr(d_rows_c), _ptr(d_table), _ptr(d_bias),
-                                    _ptr(ws), _code(rows), _stream()), "edgl_score_ce_bwd")
+        check(lib.edgl_score_flash_bwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), _ptr(lse), _ptr(coef),
+                                       _ptr(g), R, C, I, 0, I, _ptr(nvalid), _ptr(d_rows_c), _ptr(d_table), _ptr(d_bias),
+                                       _ptr(ws), _code(rows), _stream()), "edgl_score_flash_bwd")
         check(lib.edgl_scatter_rows(_ptr(d_rows_c), _ptr(inv), R, C, _ptr(d_rows), _code(rows), _stream()),
               "edgl_scatter_rows")
         return d_rows, d_table, d_bias, None, None
