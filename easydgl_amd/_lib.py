@@ -94,6 +94,9 @@ SIGNATURES = {
     "edgl_tail_pack": (I, [P, P, P, P, I, P, P]),
     "edgl_tail_fwd": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, P, I, I, P, P, P, P, P, P, P, P, P, P, P,
                           P, I, P]),
+    "edgl_tail_bwd_workspace": (L, [I, I]),
+    "edgl_tail_bwd": (I, [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, I, P, P, I, P, P, P, P, P, P, P, P,
+                          P, P, P, P, P, P, P, I, P]),
     "edgl_embedding_fwd": (I, [P, L, P, I, I, I, F, P, I, P]),
     "edgl_embedding_bwd": (I, [P, L, P, I, I, I, F, P, I, P]),
     "edgl_time_sinusoid": (I, [P, L, P, I, P, I, P]),

@@ -21,8 +21,13 @@ __device__ unsigned long long g_phase_cycles[16];   // see edgl_common.h (PH_MAR
 namespace {
 
 constexpr int MAXRT = 7;   // 16-row tiles per sample (T <= 112)
+// libm erf in this file: the inlined fast form (edgl_common.h gelu_t<bf16>) lets the scheduler interleave all 28 chains of a
+// phase and costs ~80 more registers (spills) than it saves in instructions
 #ifndef GELU_TAIL
 #define GELU_TAIL gelu_f
+#endif
+#ifndef DGELU_TAIL
+#define DGELU_TAIL dgelu_f
 #endif
 
 struct TailP {
@@ -41,6 +46,7 @@ struct TailGeom {
     static constexpr int C = 16 * CT, NW = CT, NTHR = 64 * CT, LD = C + 8, CV = C / 8;
     static constexpr size_t BUF = (size_t)MAXRT * 16 * LD * sizeof(bf16);
     static constexpr size_t SMEM = 4 * BUF + 64 * sizeof(float);
+    static constexpr size_t SMEM_BWD = SMEM + (size_t)(MAXRT * 16 + 256) * sizeof(int);   // + rowmap [112] + nextj [<= 256]
 };
 
 // rows [0, T) of a [T, C] global tensor (row stride ld) -> LDS image [112][LD]; rows >= T are zero
@@ -321,6 +327,274 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
 #endif
 }
 
+// =========================================================================================================================
+// Backward of the same chain in one launch per block: LN3' -> GELU' -> dX(Wt) -> LN2' -> dX(Wout) -> GELU' -> dX(Wi) -> LN1' ->
+// dX(Wo).  The dX products contract over the layer's OUTPUT index, so their weight operand is the [in, out] kernel itself
+// (a lane = one input channel k, 8 consecutive n) — no packed image.  What the weight-gradient GEMMs need (the gradients
+// w.r.t. the four dense outputs) is written once; the LayerNorm parameter gradients leave as per-sample partials.
+// Rounding points as in the unfused kernels (every tensor those write in the activation dtype is rounded here too).
+// =========================================================================================================================
+struct TailBwdP {
+    // saved by the forward
+    const bf16 *xin; int ld_x;
+    const bf16 *ao, *a1, *pre_f, *o, *pre_t, *so;
+    const float *st1, *st2, *st3;
+    const bf16 *Wo, *Wi, *Wout, *Wt;          // [in, out] compute copies
+    const float *g1, *g2, *g3;
+    int B, T, C;
+    float rate; const uint64_t* rng; uint32_t sid1, sid2;
+    int head;
+    const bf16* d_rows; const int64_t* mpos; int M; const int32_t* rowmap;   // head: compact row gradients, positions, inv map
+    const bf16* d_y_in;                                                       // head == 0: gradient w.r.t. y [B,T,C]
+    // outputs
+    bf16 *d_pre_t, *d_o, *d_pre_f, *d_ao, *d_res1, *d_att;
+    float *part1, *part2, *part3;             // [B][2C] (dbeta | dgamma) of LN1 / LN2 / LN3
+};
+
+// dX tile: acc[rt] += W[k-tile rows][n0 .. n0 + 32*NKB) . G[rows of tile rt][same n]   (W row stride ldw; G image stride LD)
+// — the same MFMA pattern as tile_gemm with the [in, out] kernel as the A operand
+template <int CT, int NKB>
+__device__ __forceinline__ void tile_dx(const bf16* Wrows, int ldw, const bf16* Gs, int nrt, int lane, f32x4 (&acc)[MAXRT]) {
+    tile_gemm<CT, NKB>(Wrows, ldw, Gs, nrt, lane, acc);
+}
+
+// LayerNorm backward on registers: z = LN input sum, dy = upstream gradient; returns d(sum) in dz and writes the
+// per-sample (dbeta | dgamma) partials of this wave's channels
+template <int CT>
+__device__ __forceinline__ void ln_bwd_regs(const float (&z)[MAXRT][4], const float (&dy)[MAXRT][4], float mean, float rstd,
+                                            const float (&gv)[4], int nrt, int T, int lane, int nl, float* red, float* part_b,
+                                            float (&dz)[MAXRT][4]) {
+    const int l15 = lane & 15;
+    const float n = (float)T * (float)(16 * CT);
+    float s1 = 0.f, s2 = 0.f, dga[4] = {0.f, 0.f, 0.f, 0.f}, dbe[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt)
+        if (rt < nrt && rt * 16 + l15 < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xh = (z[rt][r] - mean) * rstd, gg = dy[rt][r] * gv[r];
+                s1 += gg; s2 += gg * xh; dga[r] += dy[rt][r] * xh; dbe[r] += dy[rt][r];
+            }
+        }
+    const float m1 = block_sum_lds(s1, red) / n;
+    const float m2 = block_sum_lds(s2, red) / n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // sum over the 16 rows held by the lanes of this lane group
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { dga[r] += __shfl_xor(dga[r], o, 64); dbe[r] += __shfl_xor(dbe[r], o, 64); }
+    }
+    if (l15 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { part_b[nl + r] = dbe[r]; part_b[16 * CT + nl + r] = dga[r]; }
+    }
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xh = (z[rt][r] - mean) * rstd;
+            dz[rt][r] = rstd * (dy[rt][r] * gv[r] - m1 - xh * m2);
+        }
+}
+
+template <int CT>
+__global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
+    using G = TailGeom<CT>;
+    constexpr int C = G::C, LD = G::LD, NKB = C / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* bufA = reinterpret_cast<bf16*>(smem);
+    bf16* bufB = reinterpret_cast<bf16*>(smem + G::BUF);
+    bf16* bufC = reinterpret_cast<bf16*>(smem + 2 * G::BUF);
+    bf16* bufS = reinterpret_cast<bf16*>(smem + 3 * G::BUF);
+    float* red = reinterpret_cast<float*>(smem + 4 * G::BUF);
+    int* rowmap = reinterpret_cast<int*>(red + 64);          // [T] head of the chain of gathered rows naming position t
+    int* nextj = rowmap + MAXRT * 16;                        // [M]
+    const int b = blockIdx.x, T = p.T, nrt = (T + 15) / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
+    const int n0 = wave * 16, nl = n0 + g4;
+    const long row0 = (long)b * T;
+    const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
+    float z[MAXRT][4], dy[MAXRT][4], dz[MAXRT][4];
+
+    if (p.head) {
+        // ---- LN3' on the gathered rows, GELU' -> d_pre_t (EasyDGL.py:136-146 backward) ------------------------------------
+        copy_in<CT>(bufA, p.so + row0 * C, C, T);
+        copy_in<CT>(bufB, p.pre_t + row0 * C, C, T);
+        for (int t = threadIdx.x; t < MAXRT * 16; t += G::NTHR) rowmap[t] = -1;
+        lds_barrier();
+        if (threadIdx.x == 0)
+            for (int j = p.M - 1; j >= 0; --j) {     // chains in ascending j (the order the unfused kernel sums in)
+                const int t = (int)p.mpos[(long)b * p.M + j];
+                nextj[j] = rowmap[t];
+                rowmap[t] = j;
+            }
+        lds_barrier();
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt) {
+            const int row = rt * 16 + l15;
+            ld_bf4(bufA + row * LD + nl, z[rt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dy[rt][r] = 0.f;
+            if (rt < nrt && row < T)
+                for (int j = rowmap[row]; j >= 0; j = nextj[j]) {
+                    long src = (long)b * p.M + j;
+                    if (p.rowmap) src = p.rowmap[src];
+                    if (src < 0) continue;
+                    float v[4];
+                    ld_bf4(p.d_rows + src * C + nl, v);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dy[rt][r] += v[r];
+                }
+        }
+        {
+            const float4 gg = *reinterpret_cast<const float4*>(p.g3 + nl);
+            const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+            ln_bwd_regs<CT>(z, dy, p.st3[2 * b], p.st3[2 * b + 1], gv, nrt, T, lane, nl, red, p.part3 + (long)b * 2 * C, dz);
+        }
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+            if (rt < nrt) {
+                const int row = rt * 16 + l15;
+                float pre[4], v[4];
+                ld_bf4(bufB + row * LD + nl, pre);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = dz[rt][r] * DGELU_TAIL(pre[r]);
+                st_bf4(bufC + row * LD + nl, v);
+            }
+        lds_barrier();
+        copy_out<CT>(p.d_pre_t + row0 * C, C, bufC, T);
+        // ---- d_y = d_pre_t . Wt^T ----------------------------------------------------------------------------------------------
+        f32x4 acc[MAXRT];
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tile_dx<CT, NKB>(p.Wt + (long)n0 * C, C, bufC, nrt, lane, acc);
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dy[rt][r] = rbf(acc[rt][r]);
+        lds_barrier();     // bufA / bufB / bufC are rewritten below
+    } else {
+        copy_in<CT>(bufA, p.d_y_in + row0 * C, C, T);
+        lds_barrier();
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt) ld_bf4(bufA + (rt * 16 + l15) * LD + nl, dy[rt]);
+        lds_barrier();
+    }
+    // ---- LN2': z2 = drop(o) + a1 ; d_o = drop(d_z2) ; d_a1 (residual part) = d_z2 (EasyDGL.py:126-128 backward) -----------------
+    copy_in<CT>(bufA, p.o + row0 * C, C, T);
+    copy_in<CT>(bufB, p.a1 + row0 * C, C, T);
+    lds_barrier();
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) {
+        const int row = rt * 16 + l15;
+        float ov[4], av[4];
+        ld_bf4(bufA + row * LD + nl, ov);
+        ld_bf4(bufB + row * LD + nl, av);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[rt][r] = drop_apply(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), ov[r]) + av[r];
+    }
+    {
+        const float4 gg = *reinterpret_cast<const float4*>(p.g2 + nl);
+        const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+        ln_bwd_regs<CT>(z, dy, p.st2[2 * b], p.st2[2 * b + 1], gv, nrt, T, lane, nl, red, p.part2 + (long)b * 2 * C, dz);
+    }
+    float da1[MAXRT][4];   // gradient w.r.t. a1: the residual branch now, + d_pre_f . Wi^T below
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt)
+        if (rt < nrt) {
+            const int row = rt * 16 + l15;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                da1[rt][r] = rbf(dz[rt][r]);
+                v[r] = drop_apply(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), dz[rt][r]);
+            }
+            st_bf4(bufC + row * LD + nl, v);
+        }
+    lds_barrier();
+    copy_out<CT>(p.d_o + row0 * C, C, bufC, T);
+    // ---- d_pre_f = (d_o . Wout^T) * gelu'(pre_f), two halves of the 2C hidden channels; d_a1 += d_pre_f . Wi^T -------------------
+    f32x4 acc6[MAXRT];
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) acc6[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < 2; ++h) {
+        copy_in<CT>(bufA, p.pre_f + row0 * 2 * C + h * C, 2 * C, T);
+        {
+            f32x4 acc[MAXRT];
+#pragma unroll
+            for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            tile_dx<CT, NKB>(p.Wout + (long)(h * C + n0) * C, C, bufC, nrt, lane, acc);
+            lds_barrier();   // pre_f half in place (and, for h = 1, every wave past its reads of the previous d_pre_f half)
+#pragma unroll
+            for (int rt = 0; rt < MAXRT; ++rt)
+                if (rt < nrt) {
+                    const int row = rt * 16 + l15;
+                    float pre[4], v[4];
+                    ld_bf4(bufA + row * LD + nl, pre);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[rt][r] * DGELU_TAIL(pre[r]);
+                    st_bf4(bufB + row * LD + nl, v);
+                }
+        }
+        lds_barrier();
+        copy_out<CT>(p.d_pre_f + row0 * 2 * C + h * C, 2 * C, bufB, T);
+        tile_dx<CT, NKB>(p.Wi + (long)n0 * 2 * C + h * C, 2 * C, bufB, nrt, lane, acc6);
+        lds_barrier();
+    }
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dy[rt][r] = rbf(acc6[rt][r] + da1[rt][r]);
+    // ---- LN1': z1 = drop(ao) + x_in ; d_ao = drop(d_z1) ; d_res1 = d_z1 (EasyDGL.py:113-116 backward) ------------------------------
+    copy_in<CT>(bufA, p.ao + row0 * C, C, T);
+    copy_in<CT>(bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
+    lds_barrier();
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) {
+        const int row = rt * 16 + l15;
+        float ov[4], xv[4];
+        ld_bf4(bufA + row * LD + nl, ov);
+        ld_bf4(bufB + row * LD + nl, xv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[rt][r] = drop_apply(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), ov[r]) + xv[r];
+    }
+    {
+        const float4 gg = *reinterpret_cast<const float4*>(p.g1 + nl);
+        const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
+        ln_bwd_regs<CT>(z, dy, p.st1[2 * b], p.st1[2 * b + 1], gv, nrt, T, lane, nl, red, p.part1 + (long)b * 2 * C, dz);
+    }
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt)
+        if (rt < nrt) {
+            const int row = rt * 16 + l15;
+            float v[4], w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                w[r] = dz[rt][r];
+                v[r] = drop_apply(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), dz[rt][r]);
+            }
+            st_bf4(bufC + row * LD + nl, v);
+            st_bf4(bufS + row * LD + nl, w);
+        }
+    lds_barrier();
+    copy_out<CT>(p.d_ao + row0 * C, C, bufC, T);
+    copy_out<CT>(p.d_res1 + row0 * C, C, bufS, T);
+    // ---- d_att = d_ao . Wo^T ---------------------------------------------------------------------------------------------------------
+    {
+        f32x4 acc[MAXRT];
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tile_dx<CT, NKB>(p.Wo + (long)n0 * C, C, bufC, nrt, lane, acc);
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+            if (rt < nrt) {
+                const float v[4] = {acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]};
+                st_bf4(bufA + (rt * 16 + l15) * LD + nl, v);
+            }
+    }
+    lds_barrier();
+    copy_out<CT>(p.d_att + row0 * C, C, bufA, T);
+}
+
 // dst[n][k] = src[k][n]  (tf.layers.dense kernels are [in, out]; the MFMA A operand wants k contiguous)
 __global__ void tail_pack_kernel(const bf16* Wo, const bf16* Wi, const bf16* Wout, const bf16* Wt, int C, bf16* pack) {
     const long cc = (long)C * C;
@@ -380,6 +654,52 @@ extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const v
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
+
+extern "C" int edgl_tail_bwd(const void* xin, int ld_x, const void* ao, const void* a1, const void* pre_f, const void* o,
+                             const void* pre_t, const void* so, const float* st1, const float* st2, const float* st3,
+                             const void* Wo, const void* Wi, const void* Wout, const void* Wt, const float* g1, const float* g2,
+                             const float* g3, int B, int T, int C, float drop_rate, const uint64_t* rng_state, uint32_t sid1,
+                             uint32_t sid2, int head, const void* d_rows, const int64_t* masked_pos, int M,
+                             const int32_t* dy_rowmap, const void* d_y_in, void* d_pre_t, void* d_o, void* d_pre_f, void* d_ao,
+                             void* d_res1, void* d_att, float* dg1, float* db1, float* dg2, float* db2, float* dg3, float* db3,
+                             float* workspace, int dtype, void* stream) {
+    EDGL_REQUIRE(xin && ao && a1 && pre_f && o && st1 && st2 && Wo && Wi && Wout && g1 && g2 && d_o && d_pre_f && d_ao && d_res1 &&
+                 d_att && dg1 && db1 && dg2 && db2 && workspace, EDGL_ERR_NULL, "edgl_tail_bwd: null pointer");
+    EDGL_REQUIRE(head ? (pre_t && so && st3 && Wt && g3 && d_rows && masked_pos && d_pre_t && dg3 && db3 && M >= 1 && M <= 256) : (d_y_in != nullptr),
+                 EDGL_ERR_NULL, "edgl_tail_bwd: head needs its tensors (M <= 256); without it d_y_in is the upstream gradient");
+    EDGL_REQUIRE(B > 0 && edgl_tail_supported(T, C, dtype) && ld_x % 8 == 0, EDGL_ERR_SHAPE,
+                 "edgl_tail_bwd: unsupported shape B=%d T=%d C=%d dtype=%d", B, T, C, dtype);
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_tail_bwd: dropout without rng_state");
+    float* part1 = workspace; float* part2 = workspace + (long)B * 2 * C; float* part3 = workspace + (long)B * 4 * C;
+    TailBwdP p{(const bf16*)xin, ld_x, (const bf16*)ao, (const bf16*)a1, (const bf16*)pre_f, (const bf16*)o, (const bf16*)pre_t,
+               (const bf16*)so, st1, st2, st3, (const bf16*)Wo, (const bf16*)Wi, (const bf16*)Wout, (const bf16*)Wt, g1, g2, g3, B, T, C,
+               drop_rate, rng_state, sid1, sid2, head, (const bf16*)d_rows, masked_pos, M, dy_rowmap, (const bf16*)d_y_in,
+               (bf16*)d_pre_t, (bf16*)d_o, (bf16*)d_pre_f, (bf16*)d_ao, (bf16*)d_res1, (bf16*)d_att, part1, part2, part3};
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 128) {
+        hipFuncSetAttribute((const void*)tail_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailGeom<8>::SMEM_BWD);
+        hipLaunchKernelGGL((tail_bwd_kernel<8>), dim3(B), dim3(512), TailGeom<8>::SMEM_BWD, st, p);
+    } else {
+        hipFuncSetAttribute((const void*)tail_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailGeom<4>::SMEM_BWD);
+        hipLaunchKernelGGL((tail_bwd_kernel<4>), dim3(B), dim3(256), TailGeom<4>::SMEM_BWD, st, p);
+    }
+    EDGL_LAUNCH_CHECK();
+    // (dbeta | dgamma) per sample -> parameter gradients, fixed order (deferred-reduction aware)
+    auto red2 = [&](float* part, float* dg, float* db) -> int {
+        if (dg == db + C) return edgl_reduce_rows(part, B, 2 * C, 2L * C, db, 0, st);
+        int rc = edgl_reduce_rows(part, B, C, 2L * C, db, 0, st);
+        if (rc) return rc;
+        return edgl_reduce_rows(part + C, B, C, 2L * C, dg, 0, st);
+    };
+    int rc = red2(part1, dg1, db1);
+    if (rc) return rc;
+    rc = red2(part2, dg2, db2);
+    if (rc) return rc;
+    if (head) rc = red2(part3, dg3, db3);
+    return rc;
+}
+
+extern "C" long edgl_tail_bwd_workspace(int B, int C) { return 6L * B * C; }
 
 #ifdef EDGL_PHASE_TIMING
 extern "C" int edgl_debug_phase_cycles_tail(unsigned long long* out16, int reset) {

@@ -67,6 +67,8 @@ class TrainEngine:
         ok = bool(lib.edgl_tail_supported(T, C, self.code)) and os.environ.get("EDGL_FUSED_TAIL", "1") != "0"
         self.fused_tail = ok if fused_tail is None else (bool(fused_tail) and ok)
         self.tail_pack = [e(int(lib.edgl_tail_pack_elems(C))) for _ in range(nb)] if self.fused_tail else []
+        if self.fused_tail:   # outputs of the fused backward: the gradients w.r.t. the four dense outputs (operands of the dW GEMMs)
+            self.d_pre_t, self.d_o, self.d_pre_f, self.d_ao = e(B, T, C), e(B, T, C), e(B, T, 2 * C), e(B, T, C)
         # "flash" scoring: the forward LSE pass also accumulates the row gradients (edgl_score_flash_fwd / _bwd); its
         # workspace carries the slabs from the forward to the backward and is therefore private
         self.flash_ce = (os.environ.get("EDGL_FLASH_CE", "1") != "0") if flash_ce is None else bool(flash_ce)
@@ -244,34 +246,54 @@ class TrainEngine:
             check(lib.edgl_score_ce_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
                                         _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows), _ptr(tab.grad),
                                         _ptr(m.output_bias.grad), _ptr(self.ws), code, st), "edgl_score_ce_bwd")
-        # head: LN (gathered rows) -> gelu' -> dense
-        # the GELU' of the head transform rides in the LayerNorm backward (G1 = gradient w.r.t. the dense pre-activation)
-        self._ln_bwd(self.so, None, 0, m.transform_ln, self.st3, self.d_rows, ops.NO_DROP, self.G1, None, gpos=self.mpos,
-                     rowmap=self.inv, act_pre=self.pre_t)
         y_last = self.blk[-1]["y"] if self.blk else self.x0
-        self._dense_dw(y_last, self.G1, m.transform.kernel, m.transform.bias, C, C)
-        self._dense_dx(self.G1, m.transform.kernel, self.G2, C, C)
+        if not (self.fused_tail and self.blk):
+            # head: LN (gathered rows) -> gelu' -> dense
+            # the GELU' of the head transform rides in the LayerNorm backward (G1 = gradient w.r.t. the dense pre-activation)
+            self._ln_bwd(self.so, None, 0, m.transform_ln, self.st3, self.d_rows, ops.NO_DROP, self.G1, None, gpos=self.mpos,
+                         rowmap=self.inv, act_pre=self.pre_t)
+            self._dense_dw(y_last, self.G1, m.transform.kernel, m.transform.bias, C, C)
+            self._dense_dx(self.G1, m.transform.kernel, self.G2, C, C)
         dY = self.G2
         for i in reversed(range(len(self.blk))):
             blk, b = m.layers[i], self.blk[i]
             x_in, cin = (self.x0, 3 * C) if i == 0 else (self.blk[i - 1]["y"], C)
             dh2, dh1 = drop(hd, 12 + 4 * i), drop(hd, 11 + 4 * i)
-            # y = LN(drop(o) + a1)
-            self._ln_bwd(b["o"], b["a1"], C, blk.out_ln, b["st2"], dY, dh2, self.G3, self.G4 if dh2.active else None)
-            d_o = self.G4 if dh2.active else self.G3
-            self._dense_dw(b["f"], d_o, blk.out.kernel, blk.out.bias, 2 * C, C)
-            # d_pre_f = (d_o . Wout^T) * gelu'(pre_f)   — GELU' fused into the GEMM epilogue
-            self._dense_dx(d_o, blk.out.kernel, self.G2c, 2 * C, C, flags=EPI_MUL_DGELU, aux=b["pre_f"])
-            self._dense_dw(b["a1"], self.G2c, blk.inter.kernel, blk.inter.bias, C, 2 * C)
-            # d_a1 = dsum (in G3) + d_pre_f . Wi^T        — accumulated by the GEMM epilogue
-            if dh2.active:
-                pass  # G3 holds dsum already
-            self._dense_dx(self.G2c, blk.inter.kernel, self.G3, C, 2 * C, flags=EPI_ACCUM)
-            # a1 = LN(drop(ao) + x_in[:, :, :C])
-            self._ln_bwd(b["ao"], x_in, cin, blk.att_ln, b["st1"], self.G3, dh1, self.G1, self.G4 if dh1.active else None)
-            d_ao = self.G4 if dh1.active else self.G1
-            self._dense_dw(b["att"], d_ao, blk.att_out.kernel, blk.att_out.bias, C, C)
-            self._dense_dx(d_ao, blk.att_out.kernel, self.G2, C, C)          # G2 = d_att
+            if self.fused_tail:
+                # one launch: LN3' -> GELU' -> dX(Wt) -> LN2' -> dX(Wout) * GELU' -> dX(Wi) -> LN1' -> dX(Wo)  (csrc/k_tail.hip)
+                last = i == len(self.blk) - 1
+                tl = m.transform_ln
+                check(lib.edgl_tail_bwd(x_in.data_ptr(), cin, _ptr(b["ao"]), _ptr(b["a1"]), _ptr(b["pre_f"]), _ptr(b["o"]),
+                                        _ptr(self.pre_t), _ptr(self.so), _ptr(b["st1"]), _ptr(b["st2"]), _ptr(self.st3),
+                                        _ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
+                                        _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)),
+                                        _ptr(blk.att_ln.gamma), _ptr(blk.out_ln.gamma), _ptr(tl.gamma), B, T, C, float(dh1.rate),
+                                        dh1.ptr(), 11 + 4 * i, 12 + 4 * i, int(last), _ptr(self.d_rows), _ptr(self.mpos), M,
+                                        _ptr(self.inv), None if last else _ptr(dY), _ptr(self.d_pre_t), _ptr(self.d_o),
+                                        _ptr(self.d_pre_f), _ptr(self.d_ao), _ptr(self.G1), _ptr(self.G2),
+                                        _ptr(blk.att_ln.gamma.grad), _ptr(blk.att_ln.beta.grad), _ptr(blk.out_ln.gamma.grad),
+                                        _ptr(blk.out_ln.beta.grad), _ptr(tl.gamma.grad), _ptr(tl.beta.grad),
+                                        _ptr(self._ws(lib.edgl_tail_bwd_workspace(B, C))), code, st), "edgl_tail_bwd")
+                if last:
+                    self._dense_dw(y_last, self.d_pre_t, m.transform.kernel, m.transform.bias, C, C)
+                self._dense_dw(b["f"], self.d_o, blk.out.kernel, blk.out.bias, 2 * C, C)
+                self._dense_dw(b["a1"], self.d_pre_f, blk.inter.kernel, blk.inter.bias, C, 2 * C)
+                self._dense_dw(b["att"], self.d_ao, blk.att_out.kernel, blk.att_out.bias, C, C)
+            else:
+                # y = LN(drop(o) + a1)
+                self._ln_bwd(b["o"], b["a1"], C, blk.out_ln, b["st2"], dY, dh2, self.G3, self.G4 if dh2.active else None)
+                d_o = self.G4 if dh2.active else self.G3
+                self._dense_dw(b["f"], d_o, blk.out.kernel, blk.out.bias, 2 * C, C)
+                # d_pre_f = (d_o . Wout^T) * gelu'(pre_f)   — GELU' fused into the GEMM epilogue
+                self._dense_dx(d_o, blk.out.kernel, self.G2c, 2 * C, C, flags=EPI_MUL_DGELU, aux=b["pre_f"])
+                self._dense_dw(b["a1"], self.G2c, blk.inter.kernel, blk.inter.bias, C, 2 * C)
+                # d_a1 = dsum (in G3) + d_pre_f . Wi^T        — accumulated by the GEMM epilogue
+                self._dense_dx(self.G2c, blk.inter.kernel, self.G3, C, 2 * C, flags=EPI_ACCUM)
+                # a1 = LN(drop(ao) + x_in[:, :, :C])
+                self._ln_bwd(b["ao"], x_in, cin, blk.att_ln, b["st1"], self.G3, dh1, self.G1, self.G4 if dh1.active else None)
+                d_ao = self.G4 if dh1.active else self.G1
+                self._dense_dw(b["att"], d_ao, blk.att_out.kernel, blk.att_out.bias, C, C)
+                self._dense_dx(d_ao, blk.att_out.kernel, self.G2, C, C)          # G2 = d_att
             att = blk.attention
             da = drop(ad, 10 + 4 * i)
             check(lib.edgl_bimau_bwd(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),

@@ -442,6 +442,23 @@ int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const void* pack, 
                   void* ao, void* a1, float* st1, void* pre_f, void* f, void* o, void* y, float* st2, void* pre_t,
                   void* so, float* st3, void* hrows, int dtype, void* stream);
 
+/* Backward of the same chain, one launch per block: given the gradient of the gathered head rows (head != 0: d_rows [*, C]
+ * compact, masked_pos [B, M], dy_rowmap = the `inv` map of edgl_compact_rows or NULL) or of y (head == 0: d_y_in [B,T,C]),
+ * recomputes the three LayerNorm inputs from the saved tensors and writes what the weight-gradient GEMMs consume:
+ * d_pre_t, d_o, d_ao [B,T,C] and d_pre_f [B,T,2C] (gradients w.r.t. the four dense outputs), d_res1 (gradient into the LN1
+ * residual x_in[:, :, :C]) and d_att (gradient w.r.t. the block-tail input); LayerNorm parameter gradients dg*, db*
+ * (overwritten; reduced from per-sample partials in `workspace`, edgl_tail_bwd_workspace(B, C) floats).  Wo, Wi, Wout, Wt: the
+ * [in, out] kernels' compute copies (no packed image needed: dX contracts over the output index). */
+long edgl_tail_bwd_workspace(int B, int C);
+int edgl_tail_bwd(const void* xin, int ld_x, const void* ao, const void* a1, const void* pre_f, const void* o,
+                  const void* pre_t, const void* so, const float* st1, const float* st2, const float* st3,
+                  const void* Wo, const void* Wi, const void* Wout, const void* Wt, const float* g1, const float* g2,
+                  const float* g3, int B, int T, int C, float drop_rate, const uint64_t* rng_state, uint32_t sid1,
+                  uint32_t sid2, int head, const void* d_rows, const int64_t* masked_pos, int M,
+                  const int32_t* dy_rowmap, const void* d_y_in, void* d_pre_t, void* d_o, void* d_pre_f, void* d_ao,
+                  void* d_res1, void* d_att, float* dg1, float* db1, float* dg2, float* db2, float* dg3, float* db3,
+                  float* workspace, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
