@@ -102,9 +102,9 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
     const T* dout = reinterpret_cast<const T*>(p.d_out) + (long)b * p.T * p.C;
     T* dqkvt = reinterpret_cast<T*>(p.d_qkvt) + (long)b * p.T * 4 * p.C;
     const int ldq = 4 * p.C;
-    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, nullptr, LDT, lane);
-    stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, Vs, nullptr, LDT, lane);
-    stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, TR ? nullptr : MTs, LDT, lane);
+    stage_rows<T, DT, NT>(qkvt + p.C + head * dh, ldq, p.T, Ks, nullptr, LDT, lane);
+    stage_rows<T, DT, NT>(qkvt + 2 * p.C + head * dh, ldq, p.T, Vs, nullptr, LDT, lane);
+    stage_marks<T, NT, EC>(p.marks + (long)b * p.T * E, E, p.T, Ms, TR ? nullptr : MTs, LDT, lane);
     const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ks + WAVE_ELEMS - MASK_ELEMS));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
         PH_MARK(0);
         Frag4<T> lf;
 #pragma unroll
@@ -310,10 +310,10 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     const T* hin = reinterpret_cast<const T*>(p.hin);
     T* dqkvt = reinterpret_cast<T*>(p.d_qkvt) + (long)b * p.T * 4 * p.C;
     const int ldq = 4 * p.C;
-    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, TR ? nullptr : KTs, LDT, lane);
-    stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, Ts, nullptr, LDT, lane);
-    stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, Vs, nullptr, LDT, lane);
-    stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, nullptr, LDT, lane);
+    stage_rows<T, DT, NT>(qkvt + p.C + head * dh, ldq, p.T, Ks, TR ? nullptr : KTs, LDT, lane);
+    stage_rows<T, DT, NT>(qkvt + 3 * p.C + head * dh, ldq, p.T, Ts, nullptr, LDT, lane);
+    stage_rows<T, DT, NT>(qkvt + 2 * p.C + head * dh, ldq, p.T, Vs, nullptr, LDT, lane);
+    stage_marks<T, NT, EC>(p.marks + (long)b * p.T * E, E, p.T, Ms, nullptr, LDT, lane);
     const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ks + WAVE_ELEMS - MASK_ELEMS));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
         PH_MARK(0);
         Frag4<T> lf;
 #pragma unroll

@@ -25,13 +25,17 @@ __device__ __forceinline__ float sigmoid_pre(float xs) { return fast_rcp(1.0f + 
 
 // ---- intensity-weight pack (built once per launch by pack_kernel, copied to LDS by every WG) ---
 // T-typed: W1T [JE][LDW]  (W1T[j][u] = -log2e * W1[u][j], u < dh) -> A operand of Zpre'^T = W1T.H^T
-//          W1R [dh][LDR]  (W1R[u][j] = W1[u][j], unscaled)       -> A operand of dH^T = W1.du^T
+//          W1X [JE][8]    (bf16 only) interval weight and bias of channel j as bf16 split terms -> A operand of the
+//                         MFMA that adds  span * w1s[j] + b1[j]  to the pre-activation (see span_frag)
 // f32:     w1s [JE] = -log2e * W1[dh][j] (interval weight), b1 [JE] = -log2e * b1, wv [JE] = w.flatten(),
 //          sc[16] = exp(scaling), isc[16] = 1/sc.
+// T-typed: W1R [dh][LDR]  (W1R[u][j] = W1[u][j], unscaled)       -> A operand of dH^T = W1.du^T   (backward only: last,
+//                         so that the forward copies `fwd_bytes` and leaves it out)
 // The -log2(e) factor turns sigmoid(x) into rcp(1 + exp2(x')) — one v_exp_f32 and one v_rcp_f32, no multiply.
+constexpr int XW = 8;   // K slots of the interval / bias MFMA that carry data (lane groups 0 and 1)
 struct PackDims {
     int dh, E, JE, LDW, LDR;
-    size_t off_w1r, off_f32, bytes;  // byte offsets
+    size_t off_w1x, off_f32, off_w1r, fwd_bytes, bytes;  // byte offsets
 };
 template <typename T>
 __host__ __device__ inline PackDims pack_dims(int dh, int E) {
@@ -39,13 +43,44 @@ __host__ __device__ inline PackDims pack_dims(int dh, int E) {
     d.dh = dh; d.E = E; d.JE = dh * E; d.LDW = dh + 4; d.LDR = d.JE + 4;
     size_t w1t = (size_t)d.JE * d.LDW * sizeof(T);
     w1t = (w1t + 15) & ~(size_t)15;
+    const size_t w1x = sizeof(T) == 2 ? (size_t)d.JE * XW * sizeof(T) : 0;
+    size_t f32b = ((size_t)3 * d.JE + 2 * EP) * sizeof(float);
+    f32b = (f32b + 15) & ~(size_t)15;
     size_t w1r = (size_t)dh * d.LDR * sizeof(T);
     w1r = (w1r + 15) & ~(size_t)15;
-    d.off_w1r = w1t;
-    d.off_f32 = w1t + w1r;
-    d.bytes = d.off_f32 + ((size_t)3 * d.JE + 2 * EP) * sizeof(float);
-    d.bytes = (d.bytes + 15) & ~(size_t)15;
+    d.off_w1x = w1t;
+    d.off_f32 = w1t + w1x;
+    d.off_w1r = d.off_f32 + f32b;
+    d.fwd_bytes = d.off_w1r;
+    d.bytes = d.off_w1r + w1r;
     return d;
+}
+
+// bf16 split of an f32 value: x = t0 + t1 + t2 up to 2^-24 |x|
+struct Split3 { bf16 t0, t1, t2; };
+__device__ __forceinline__ Split3 split3(float x) {
+    Split3 s;
+    s.t0 = from_f32<bf16>(x);
+    const float r1 = x - to_f32(s.t0);
+    s.t1 = from_f32<bf16>(r1);
+    s.t2 = from_f32<bf16>(r1 - to_f32(s.t1));
+    return s;
+}
+// B operand of the interval / bias MFMA for this lane's query row (K slot = 4 * lane group + i):
+//   W1X row j : [w0 w1 w0 w2 | w1 w0 b0 b1]        (w = w0 + w1 + w2 interval weight, b = b0 + b1 bias)
+//   span_frag : [s0 s0 s1 s0 | s1 s2  1  1 | 0 ...]  (span = s0 + s1 + s2)
+// sum of the eight products = span * w + b with every cross term above 2^-24 kept (bf16 x bf16 is exact in the f32
+// accumulator).  Lane groups 2 and 3 hold zeros here, so whatever finite values the A operand has there do not matter.
+__device__ __forceinline__ Frag4<bf16> span_frag(float span, int lane) {
+    const Split3 s = split3(span);
+    const bf16 one = from_f32<bf16>(1.f), zero = from_f32<bf16>(0.f);
+    Frag4<bf16> f;
+    const int g = lane >> 4;
+    f.v[0] = g == 0 ? s.t0 : g == 1 ? s.t1 : zero;
+    f.v[1] = g == 0 ? s.t0 : g == 1 ? s.t2 : zero;
+    f.v[2] = g == 0 ? s.t1 : g == 1 ? one : zero;
+    f.v[3] = g == 0 ? s.t0 : g == 1 ? one : zero;
+    return f;
 }
 
 // Activations the forward keeps for the backward (one buffer): H rows [H*B*T, dh] in the activation dtype (input of the
@@ -68,6 +103,14 @@ __global__ void pack_kernel(const float* W1, const float* b1, const float* w, co
     T* w1r = reinterpret_cast<T*>(pack + d.off_w1r);
     float* f = reinterpret_cast<float*>(pack + d.off_f32);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if constexpr (sizeof(T) == 2) {
+        T* w1x = reinterpret_cast<T*>(pack + d.off_w1x);
+        for (int j = tid; j < d.JE; j += nth) {
+            const Split3 w = split3(NLOG2E * W1[(long)dh * d.JE + j]), b = split3(NLOG2E * b1[j]);
+            T* r = w1x + (long)j * XW;
+            r[0] = w.t0; r[1] = w.t1; r[2] = w.t0; r[3] = w.t2; r[4] = w.t1; r[5] = w.t0; r[6] = b.t0; r[7] = b.t1;
+        }
+    }
     for (int i = tid; i < d.JE * d.LDW; i += nth) {
         const int j = i / d.LDW, u = i % d.LDW;
         w1t[i] = from_f32<T>(u < dh ? NLOG2E * W1[(long)u * d.JE + j] : 0.f);
@@ -96,22 +139,28 @@ __global__ void pack_kernel(const float* W1, const float* b1, const float* w, co
 // `pad` keeps the padded-key bits for the backward (no gradient flows into a padded score).
 template <int NT>
 struct KeyMask { const float* madd; uint64_t pad; };   // pad: one bit per (key tile, register), NT <= 16   // madd: wave-private LDS array [16*NT]
+// One id per lane and round (keys lane, lane + 64, ...): the additive mask goes to LDS, the padded-key bits of this lane's
+// (key tile, register) slots are cut out of the wave ballots — no per-slot id loads.
 template <int NT>
 __device__ __forceinline__ KeyMask<NT> load_keymask(const int64_t* ids_row, int T, int lane, float* lds_madd) {
     KeyMask<NT> km;
     km.pad = 0ull;
     km.madd = lds_madd;
+    constexpr int NR = (16 * NT + 63) / 64;
+    uint64_t padded[NR];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+    for (int i = 0; i < NR; ++i) {
+        const int k = lane + 64 * i;
+        const int64_t id = ids_row[min(k, T - 1)];
+        const bool pd = k < T && id == 0;
+        padded[i] = __ballot(pd);
+        if (k < 16 * NT) lds_madd[k] = k >= T ? -INFINITY : (pd ? -4294967296.0f : 0.f);
+    }
+    const int g4 = (lane >> 4) * 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = kt * 16 + (lane >> 4) * 4 + r;
-            if (k < T && ids_row[k] == 0) km.pad |= 1ull << (kt * 4 + r);
-        }
-    for (int k = lane; k < 16 * NT; k += 64) {
-        float v = -INFINITY;
-        if (k < T) v = ids_row[k] == 0 ? -4294967296.0f : 0.f;
-        lds_madd[k] = v;
+    for (int kt = 0; kt < NT; ++kt) {
+        const uint64_t nib = (padded[kt / 4] >> ((kt % 4) * 16 + g4)) & 0xfull;   // keys kt*16 + g4 .. + 3
+        km.pad |= nib << (kt * 4);
     }
     return km;
 }
@@ -121,40 +170,117 @@ __device__ __forceinline__ KeyMask<NT> load_keymask(const int64_t* ids_row, int 
 // (tf.where(tril == 0, paddings, outputs)); q = this lane's query index.
 constexpr int MAU_CAUSAL = 1;    // future blinding (temporal.py:370-375)
 constexpr int MAU_NO_DIAG = 2;   // MAU keeps the modulation on the diagonal; BiMAU sets it to 1 (temporal.py:438-439)
-template <int NT>
-__device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale, int lane, int q = 0,
-                                               bool causal = false) {
+// The scale carries log2(e) so that the exponential is one v_exp_f32 (2^x) on (v - max): fma, sub, exp per element — all
+// in 2- / 4-wide vector form (v_pk_fma_f32 / v_pk_add_f32).  The additive mask keeps its magnitude: a padded score is
+// "-2^32 + something below the f32 resolution there", a fully padded row is uniform exactly as in the reference.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <int NT, bool CAUSAL, bool VEC>
+__device__ __forceinline__ void masked_softmax_impl(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale, int lane, int q) {
+    const float c2 = cscale * 1.4426950408889634f;
     float mx = -INFINITY;
     const float* mrow = km.madd + (lane >> 4) * 4;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-        const float4 m4 = *reinterpret_cast<const float4*>(mrow + kt * 16);
-        const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(mrow + kt * 16);
+        f32x4 v;
+        if constexpr (VEC) {
+            v = s[kt] * f32x4{c2, c2, c2, c2} + m4;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = fmaf(s[kt][r], cscale, mm[r]);
-            if (causal && kt * 16 + (lane >> 4) * 4 + r > q && mm[r] != -INFINITY) v = -4294967296.0f;
-            s[kt][r] = v;
-            mx = fmaxf(mx, v);
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(s[kt][r], c2, m4[r]);
         }
+        if constexpr (CAUSAL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (kt * 16 + (lane >> 4) * 4 + r > q && m4[r] != -INFINITY) v[r] = -4294967296.0f;
+        }
+        s[kt] = v;
+        mx = fmaxf(fmaxf(mx, v[0]), fmaxf(v[1], fmaxf(v[2], v[3])));
     }
     mx = group_max4(mx);
-    float sum = 0.f;
+    float sum;
+    // (v - mx) first: exact 0 for the row maximum even at the -2^32 padding magnitude
+    if constexpr (VEC) {
+        const f32x4 mx4 = {mx, mx, mx, mx};
+        f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+        for (int kt = 0; kt < NT; ++kt) {
+            const f32x4 d = s[kt] - mx4;
+            f32x4 e;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            // (s - mx) first: exact 0 for the row maximum even at the -2^32 padding magnitude
-            const float e = __expf(s[kt][r] - mx);
-            s[kt][r] = e;
-            sum += e;
+            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(d[r]);
+            s[kt] = e;
+            sum4 += e;
         }
+        sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+    } else {
+        sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+                s[kt][r] = e;
+                sum += e;
+            }
+    }
     sum = group_sum4(sum);
     const float inv = fast_rcp(sum);
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NT; ++kt) {
+        if constexpr (VEC) {
+            s[kt] *= f32x4{inv, inv, inv, inv};
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
+            for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
+        }
+    }
+}
+// MODE 2: causal / bidirectional code paths behind one wave-uniform branch (no per-element causal selects on the
+//         bidirectional path), 2-wide packed f32 arithmetic — the bf16 forward.
+// MODE 1: the same branch, scalar arithmetic — the bf16 backward sweeps (packed operands need aligned register pairs;
+//         at 7 key tiles that takes the sweeps past 256 registers, i.e. from two waves per SIMD to one).
+// MODE 0: one code path with a run-time causal flag — the f32 kernels: at their register pressure (T_ and V staged
+//         transposed, up to 13 key tiles) the other forms spill, and hipcc 7.2 crashes on that in its MFMA rewrite pass.
+template <int NT, int MODE = 0>
+__device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale, int lane, int q = 0,
+                                               bool causal = false) {
+    if constexpr (MODE != 0) {
+        if (causal) masked_softmax_impl<NT, true, false>(s, km, cscale, lane, q);
+        else masked_softmax_impl<NT, false, false>(s, km, cscale, lane, q);
+    } else {
+        const float c2 = cscale * 1.4426950408889634f;
+        float mx = -INFINITY;
+        const float* mrow = km.madd + (lane >> 4) * 4;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mrow + kt * 16);
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaf(s[kt][r], c2, mm[r]);
+                if (causal && kt * 16 + (lane >> 4) * 4 + r > q && mm[r] != -INFINITY) v = -4294967296.0f;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = group_max4(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+                s[kt][r] = e;
+                sum += e;
+            }
+        sum = group_sum4(sum);
+        const float inv = fast_rcp(sum);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
+    }
 }
 
 // reduce-scatter of 16 per-lane partials over the 4 lane groups: on return lane group g holds the
@@ -212,31 +338,76 @@ __device__ __forceinline__ Frag4<T> kfrag(const T* rm, int ld_rm, const T* tr, i
 // wave-private staging of one (b, head)'s K / T_ / V slices and marks into LDS.
 //   row-major [Tp][dh]  (A operand with the channel as contraction index)
 //   transposed [dh][LDT] (A operand with the key as contraction index)
-template <typename T>
-__device__ __forceinline__ void stage_rows(const T* src, int ld, int Tlen, int Tp, int dh, T* rowmajor, T* transposed,
-                                           int LDT, int lane) {
-    const int cpr = dh / 4, nchunk = Tp * cpr;
-    for (int c = lane; c < nchunk; c += 64) {
-        const int k = c / cpr, u4 = (c % cpr) * 4;
-        Frag4<T> f = (k < Tlen) ? frag_ld<T>(src + (long)k * ld + u4) : frag_zero<T>();
-        if (rowmajor) {
-            if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(rowmajor + k * dh + u4) = *reinterpret_cast<uint4*>(&f);
-            else *reinterpret_cast<uint2*>(rowmajor + k * dh + u4) = *reinterpret_cast<uint2*>(&f);
-        }
-        if (transposed) {
+// All global loads of a batch are issued before the first LDS store (rows clamped, so the loads are straight-line code):
+// the staging costs one memory latency per batch instead of one per 64 chunks — it was 42 of the forward kernel's 98 us.
+template <typename T, int DT, int NT>
+__device__ __forceinline__ void stage_rows(const T* src, int ld, int Tlen, T* rowmajor, T* transposed, int LDT, int lane) {
+    constexpr int cpr = 4 * DT, dh = 16 * DT, NI = NT * DT;   // chunks of 4 elements: 64 * NI of them
+    constexpr int BATCH = sizeof(T) == 2 ? 28 : 16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) transposed[(u4 + i) * LDT + k] = f.v[i];
-        }
+    for (int i0 = 0; i0 < NI; i0 += BATCH) {
+        Frag4<T> f[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+            if (i0 + j < NI) {
+                const int c = lane + 64 * (i0 + j), k = c / cpr, u4 = (c % cpr) * 4;
+                f[j] = frag_ld<T>(src + (long)min(k, Tlen - 1) * ld + u4);
+            }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j)
+            if (i0 + j < NI) {
+                const int c = lane + 64 * (i0 + j), k = c / cpr, u4 = (c % cpr) * 4;
+                if (k >= Tlen) f[j] = frag_zero<T>();
+                if (rowmajor) {
+                    if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(rowmajor + k * dh + u4) = *reinterpret_cast<uint4*>(&f[j]);
+                    else *reinterpret_cast<uint2*>(rowmajor + k * dh + u4) = *reinterpret_cast<uint2*>(&f[j]);
+                }
+                if (transposed) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) transposed[(u4 + r) * LDT + k] = f[j].v[r];
+                }
+            }
     }
 }
-template <typename T>
-__device__ __forceinline__ void stage_marks(const uint8_t* marks_row, int E, int Tlen, int Tp, T* rowmajor,
-                                            T* transposed, int LDT, int lane) {
-    for (int i = lane; i < Tp * EP; i += 64) {
-        const int k = i / EP, e = i % EP;
-        const float v = (k < Tlen && e < E) ? (float)marks_row[(long)k * E + e] : 0.f;
-        if (rowmajor) rowmajor[k * EP + e] = from_f32<T>(v);
-        if (transposed) transposed[e * LDT + k] = from_f32<T>(v);
+// marks [T][E] uint8 -> [Tp][16] in the activation dtype: one key row per lane and round, its E bytes loaded together
+// (one 16-byte load when E == 16)
+template <typename T, int NT, int EC>
+__device__ __forceinline__ void stage_marks(const uint8_t* marks_row, int E, int Tlen, T* rowmajor, T* transposed, int LDT, int lane) {
+    constexpr int Tp = 16 * NT, NR = (Tp + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int k = lane + 64 * i;
+        const uint8_t* row = marks_row + (long)min(k, Tlen - 1) * E;
+        uint32_t w[4];
+        if constexpr (EC == 16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            uint8_t by[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) by[e] = row[min(e, E - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w[j] = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[j] |= (4 * j + e < E ? (uint32_t)by[4 * j + e] : 0u) << (8 * e);
+            }
+        }
+        if (k < Tp) {
+            const bool ok = k < Tlen;
+            T vals[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vals[e] = from_f32<T>(ok ? (float)((w[e / 4] >> (8 * (e % 4))) & 0xffu) : 0.f);
+            if (rowmajor) {
+#pragma unroll
+                for (int j = 0; j < (int)(16 * sizeof(T) / 16); ++j)
+                    reinterpret_cast<uint4*>(rowmajor + k * EP)[j] = reinterpret_cast<const uint4*>(vals)[j];
+            }
+            if (transposed) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) transposed[e * LDT + k] = vals[e];
+            }
+        }
     }
 }
 

@@ -5,6 +5,8 @@
 //   PHASE 2  values:  S, softmax recomputed, lambda rows read back, G, diag := 1, dropout, O = A.V + residual
 // BiMAU.__call__ (temporal.py:404-452) with MAU.intensity (temporal.py:281-315); see bimau_common.h for the layout scheme.
 #pragma once
+#include <type_traits>
+
 #include "bimau_common.h"
 
 namespace bimau {
@@ -39,18 +41,19 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     const int E = EC ? EC : p.E;
     constexpr bool FUSED = PHASE == 0, HAS_T = PHASE != 2, HAS_V = PHASE != 1, HAS_M = PHASE != 1;
     const PackDims pd = pack_dims<T>(dh, E);
-    const size_t pack_bytes = FUSED ? pd.bytes : 0;
+    const size_t pack_bytes = FUSED ? pd.fwd_bytes : 0;   // the backward-only W1R image stays in HBM
     // ---- workgroup-shared intensity weights (fused form only) ---------------------------------
     if constexpr (FUSED) {
         const uint4* src = reinterpret_cast<const uint4*>(p.pack);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int i = threadIdx.x; i < (int)(pd.bytes / 16); i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(pd.fwd_bytes / 16); i += blockDim.x) dst[i] = src[i];
     }
     const T* W1T = reinterpret_cast<const T*>(smem);
+    const T* W1X = reinterpret_cast<const T*>(smem + pd.off_w1x);
     const float* fW = reinterpret_cast<const float*>(smem + pd.off_f32);
     const float* w1s = fW; const float* b1s = fW + pd.JE; const float* wvs = fW + 2 * pd.JE;
     const float* scs = fW + 3 * pd.JE; const float* iscs = scs + EP;
-    (void)W1T; (void)w1s; (void)b1s; (void)wvs; (void)scs; (void)iscs;
+    (void)W1T; (void)W1X; (void)w1s; (void)b1s; (void)wvs; (void)scs; (void)iscs;
     if constexpr (FUSED) __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -72,13 +75,16 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     T* Ms = Vs + (HAS_V ? KV_ELEMS : 0);
     const T* qkvt = reinterpret_cast<const T*>(p.qkvt) + (long)b * p.T * 4 * p.C;
     const int ldq = 4 * p.C;
-    stage_rows<T>(qkvt + p.C + head * dh, ldq, p.T, Tp, dh, Ks, nullptr, LDT, lane);           // K  (split order Q,K,V,T: temporal.py:410)
-    if constexpr (HAS_T) stage_rows<T>(qkvt + 3 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Ts : nullptr, TR ? nullptr : Ts, LDT, lane);   // T_
-    if constexpr (HAS_V) stage_rows<T>(qkvt + 2 * p.C + head * dh, ldq, p.T, Tp, dh, TR ? Vs : nullptr, TR ? nullptr : Vs, LDT, lane);   // V
-    if constexpr (HAS_M) stage_marks<T>(p.marks + (long)b * p.T * E, E, p.T, Tp, Ms, nullptr, LDT, lane);
+    stage_rows<T, DT, NT>(qkvt + p.C + head * dh, ldq, p.T, Ks, nullptr, LDT, lane);           // K  (split order Q,K,V,T: temporal.py:410)
+    if constexpr (HAS_T) stage_rows<T, DT, NT>(qkvt + 3 * p.C + head * dh, ldq, p.T, TR ? Ts : nullptr, TR ? nullptr : Ts, LDT, lane);   // T_
+    if constexpr (HAS_V) stage_rows<T, DT, NT>(qkvt + 2 * p.C + head * dh, ldq, p.T, TR ? Vs : nullptr, TR ? nullptr : Vs, LDT, lane);   // V
+    if constexpr (HAS_M) stage_marks<T, NT, EC>(p.marks + (long)b * p.T * E, E, p.T, Ms, nullptr, LDT, lane);
     const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ms + (HAS_M ? Tp * EP : 0)));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#ifdef EDGL_PROLOGUE_ONLY
+    if (p.B > 0) { if (km.pad == 0x1234567ull) reinterpret_cast<T*>(p.out)[0] = Ks[lane] + Ms[lane]; return; }
+#endif
 
     const float cscale = rsqrtf((float)dh);
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s := P^T
+        masked_softmax<NT, sizeof(T) == 2 ? 2 : 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s := P^T
         // ---- H^T[u][q] = sum_k T_[k][u] P[q][k] -----------------------------------------------
         Frag4<T> pf[NT];
 #pragma unroll
@@ -169,39 +175,90 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
         // ---- intensity MLP (temporal.py:287-306): Zpre^T[j][q], channel j = e*dh + u' ------------
         const float span = qcur.span;
         float zp[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) zp[e] = 0.f;
-        // operands of channel tile jt: W1T rows (A operand), interval weight, bias, output weight.  The tile after the
-        // one being computed is always in flight (explicit double buffer: the LDS latency hides behind one tile of
-        // MFMA + sigmoid work instead of stalling every tile).
-        struct MlpOps { Frag4<T> w[DT]; float4 ws, bs, wv; };
+        // operands of channel tile jt: W1T rows (A operand), output weight, and the interval weight / bias — as the A rows of
+        // a second MFMA (bf16: span * w1s + b1 comes out of the matrix pipe, see span_frag) or as f32 vectors (f32).  The tile
+        // after the one being computed is always in flight (explicit double buffer: the LDS latency hides behind one tile
+        // of MFMA + sigmoid work instead of stalling every tile).
+        struct MlpOps { Frag4<T> w[DT]; Frag4<T> wx; f32x4 ws, bs, wv; };
+        Frag4<T> sf;
+        if constexpr (TR) sf = span_frag(span, lane);
         auto load_ops = [&](int jt) {
             MlpOps o;
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub) o.w[ub] = frag_ld<T>(W1T + (jt * 16 + l15) * pd.LDW + ub * 16 + g4);
-            o.ws = *reinterpret_cast<const float4*>(w1s + jt * 16 + g4);
-            o.bs = *reinterpret_cast<const float4*>(b1s + jt * 16 + g4);
-            o.wv = *reinterpret_cast<const float4*>(wvs + jt * 16 + g4);
+            if constexpr (TR) {
+                o.wx = frag_ld<T>(W1X + (jt * 16 + l15) * XW + (g4 & 4));
+            } else {
+                o.ws = *reinterpret_cast<const f32x4*>(w1s + jt * 16 + g4);
+                o.bs = *reinterpret_cast<const f32x4*>(b1s + jt * 16 + g4);
+            }
+            o.wv = *reinterpret_cast<const f32x4*>(wvs + jt * 16 + g4);
             return o;
         };
-        MlpOps cur = load_ops(0);
+        // pre-activation of one channel tile (matrix pipe) and sigmoid . output weight (VALU); `acc` is the running pair sum
+        auto tile_pre = [&](const MlpOps& o) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (TR) a = mma16(o.wx, sf, a);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (EC == 16 || e < E) {
+            for (int ub = 0; ub < DT; ++ub) a = mma16(o.w[ub], hf[ub], a);
+            // f32: (span*ws + a) + bs, chained on the MFMA result so that nothing of this tile can be hoisted into the
+            // prefetch slot above (which would wait on the loads just issued)
+            if constexpr (!TR) {
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    const int jt = e * DT + d;
-                    const MlpOps nxt = load_ops(jt + 1 < E * DT ? jt + 1 : jt);
-                    EDGL_PIN();   // keep the prefetch at the top of this tile's work
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 4; ++r) a[r] = fmaf(span, o.ws[r], a[r]) + o.bs[r];
+            }
+            return a;
+        };
+        auto tile_post = [&](const f32x4& a, const MlpOps& o, float& acc, bool first) {
+            float sg[4];
 #pragma unroll
-                    for (int ub = 0; ub < DT; ++ub) a = mma16(cur.w[ub], hf[ub], a);
-                    // (span*ws + a) + bs: chained on the MFMA result so that nothing of this tile can be hoisted into the
-                    // prefetch slot above (which would wait on the loads just issued)
-                    zp[e] += sigmoid_pre(fmaf(span, cur.ws.x, a[0]) + cur.bs.x) * cur.wv.x + sigmoid_pre(fmaf(span, cur.ws.y, a[1]) + cur.bs.y) * cur.wv.y +
-                             sigmoid_pre(fmaf(span, cur.ws.z, a[2]) + cur.bs.z) * cur.wv.z + sigmoid_pre(fmaf(span, cur.ws.w, a[3]) + cur.bs.w) * cur.wv.w;
-                    cur = nxt;
-                    EDGL_PIN();
+            for (int r = 0; r < 4; ++r) sg[r] = fast_rcp(1.0f + __builtin_amdgcn_exp2f(a[r]));
+            acc = first ? sg[0] * o.wv[0] : fmaf(sg[0], o.wv[0], acc);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) acc = fmaf(sg[r], o.wv[r], acc);
+        };
+        if constexpr (EC == 16) {
+            // two channel tiles per step: the exp / rcp chains of one tile fill the MFMA and transcendental latencies of the
+            // other (a wave has only one partner on its SIMD); the pair after the one being computed is in flight
+            // ... and software-pipelined: the MFMAs of the next pair are issued before the sigmoids of the current one, the
+            // operands of the pair after that are in flight
+            MlpOps c0 = load_ops(0), c1 = load_ops(1);
+            MlpOps n0 = load_ops(2), n1 = load_ops(3);
+            f32x4 a0 = tile_pre(c0), a1 = tile_pre(c1);
+            float zacc;
+#pragma unroll
+            for (int jt = 0; jt < 16 * DT; jt += 2) {
+                const int jn = jt + 4 < 16 * DT ? jt + 4 : jt;
+                const MlpOps m0 = load_ops(jn), m1 = load_ops(jn + 1);
+                EDGL_PIN();   // keep the prefetch at the top of this pair's work
+                f32x4 b0 = a0, b1 = a1;
+                if (jt + 2 < 16 * DT) { b0 = tile_pre(n0); b1 = tile_pre(n1); }
+                const int e0 = jt / DT, e1 = (jt + 1) / DT;
+                tile_post(a0, c0, zacc, jt % DT == 0);
+                if (e1 != e0) zp[e0] = zacc;
+                tile_post(a1, c1, zacc, (jt + 1) % DT == 0);
+                if ((jt + 2) % DT == 0) zp[e1] = zacc;
+                c0 = n0; c1 = n1; n0 = m0; n1 = m1; a0 = b0; a1 = b1;
+                EDGL_PIN();
+            }
+        } else {
+            MlpOps cur = load_ops(0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                zp[e] = 0.f;
+                if (e < E) {
+                    float zacc;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        const int jt = e * DT + d;
+                        const MlpOps nxt = load_ops(jt + 1 < E * DT ? jt + 1 : jt);
+                        EDGL_PIN();   // keep the prefetch at the top of this tile's work
+                        const f32x4 a = tile_pre(cur);
+                        tile_post(a, cur, zacc, d == 0);
+                        cur = nxt;
+                        EDGL_PIN();
+                    }
+                    zp[e] = zacc;
                 }
             }
         }
@@ -231,24 +288,31 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
         }
         // ---- G^T[k][q] = sum_e marks[k][e] lam[q][e]; diag := 1; A' = dropout(G * P) ------------
         const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);   // element index of (b', q, k=0); < 2^32 (host-checked)
+        // One straight-line block for all key tiles (the dropout decision is taken once, outside; the diagonal is a select
+        // on a scalar-and-ed lane mask): the scheduler can issue the seven MFMAs ahead and run the hashes in their shadow.
+        const bool set_diag = !(p.flags & MAU_NO_DIAG);
+        auto modulate = [&](auto drop_on) {
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, f32x4{0.f, 0.f, 0.f, 0.f});
-            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {   // only this key tile can contain k == q (temporal.py:438-439)
+            for (int kt = 0; kt < NT; ++kt) {
+                f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, f32x4{0.f, 0.f, 0.f, 0.f});
+                const bool dtile = set_diag && kt == qt;   // only this key tile can contain k == q (temporal.py:438-439)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gacc[r] = (g4 + r == l15) ? 1.0f : gacc[r];
+                for (int r = 0; r < 4; ++r) {
+                    gacc[r] = (dtile && g4 + r == l15) ? 1.0f : gacc[r];
+                    s[kt][r] = gacc[r] * s[kt][r];     // temporal.py:441
+                }
+                if constexpr (decltype(drop_on)::value) {                       // temporal.py:442
+                    const uint32_t h0 = drop_hash_pair(dk, dbase + kt * 16 + g4), h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2);
+                    s[kt][0] = (h0 & 0xffffu) >= dk.t16 ? s[kt][0] * dk.scale : 0.f;
+                    s[kt][1] = (h0 >> 16) >= dk.t16 ? s[kt][1] * dk.scale : 0.f;
+                    s[kt][2] = (h1 & 0xffffu) >= dk.t16 ? s[kt][2] * dk.scale : 0.f;
+                    s[kt][3] = (h1 >> 16) >= dk.t16 ? s[kt][3] * dk.scale : 0.f;
+                }
+                pf[kt] = frag_from_acc<T>(s[kt]);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[kt][r] = gacc[r] * s[kt][r];     // temporal.py:441
-            if (dk.thresh != 0u) {                                          // temporal.py:442
-                const uint32_t h0 = drop_hash_pair(dk, dbase + kt * 16 + g4), h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2);
-                s[kt][0] = (h0 & 0xffffu) >= dk.t16 ? s[kt][0] * dk.scale : 0.f;
-                s[kt][1] = (h0 >> 16) >= dk.t16 ? s[kt][1] * dk.scale : 0.f;
-                s[kt][2] = (h1 & 0xffffu) >= dk.t16 ? s[kt][2] * dk.scale : 0.f;
-                s[kt][3] = (h1 >> 16) >= dk.t16 ? s[kt][3] * dk.scale : 0.f;
-            }
-            pf[kt] = frag_from_acc<T>(s[kt]);
-        }
+        };
+        if (dk.thresh != 0u) modulate(std::true_type{});
+        else modulate(std::false_type{});
         // ---- O^T[v][q] = sum_k V[k][v] A'[q][k]; + residual (temporal.py:443-447) ----------------
 #pragma unroll
         for (int vt = 0; vt < DT; ++vt) {
@@ -271,7 +335,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
 template <typename T, int DT, int NT, int EC, int PHASE = 0>
 int launch_fwd_e(FwdP p, hipStream_t st) {
     constexpr int dh = 16 * DT;
-    const size_t pack_bytes = PHASE == 0 ? pack_dims<T>(dh, p.E).bytes : 0;
+    const size_t pack_bytes = PHASE == 0 ? pack_dims<T>(dh, p.E).fwd_bytes : 0;
     constexpr size_t wave_bytes = fwd_wave_bytes<T, DT, NT, PHASE>();
     int waves = 4;
     while (waves > 1 && pack_bytes + waves * wave_bytes > 80 * 1024) waves >>= 1;
