@@ -14,7 +14,7 @@ namespace bimau {
 
 constexpr int KY_ECH = 8;        // marks per workgroup row of kernel Y (gridDim.y = 16 / KY_ECH dH partials)
 constexpr int KY_NY = EP / KY_ECH;
-constexpr int KY_BLOCKS = 256;   // workgroups of kernel Y per mark group (x KY_NY = one resident round at 2 WGs/CU)
+constexpr int KY_BLOCKS = 384;   // workgroups of kernel Y per mark group (x KY_NY = one resident round at 3 WGs/CU)
 
 // head dims >= 64 (k_bimau_big.hip): the weight-gradient kernel runs on a (row splits, channel groups) grid; a group is
 // 32 / (dh/16) channel tiles of 16.  Enough row splits for ~512 workgroups, at least 16.

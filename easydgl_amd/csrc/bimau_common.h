@@ -56,6 +56,22 @@ __host__ __device__ inline PackDims pack_dims(int dh, int E) {
     return d;
 }
 
+// Workgroup copy of the weight pack into LDS, eight 16-byte loads per thread in flight before the first store (a plain
+// copy loop pays one L2 round trip per 4 KB of a 256-thread workgroup).
+__device__ __forceinline__ void copy_pack_to_lds(char* smem, const char* pack, size_t bytes) {
+    const uint4* src = reinterpret_cast<const uint4*>(pack);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const int n = (int)(bytes / 16), nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * nt) {
+        uint4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[min(i0 + j * nt, n - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j * nt < n) dst[i0 + j * nt] = v[j];
+    }
+}
+
 // bf16 split of an f32 value: x = t0 + t1 + t2 up to 2^-24 |x|
 struct Split3 { bf16 t0, t1, t2; };
 __device__ __forceinline__ Split3 split3(float x) {

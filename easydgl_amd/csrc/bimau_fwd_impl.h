@@ -43,11 +43,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     const PackDims pd = pack_dims<T>(dh, E);
     const size_t pack_bytes = FUSED ? pd.fwd_bytes : 0;   // the backward-only W1R image stays in HBM
     // ---- workgroup-shared intensity weights (fused form only) ---------------------------------
-    if constexpr (FUSED) {
-        const uint4* src = reinterpret_cast<const uint4*>(p.pack);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int i = threadIdx.x; i < (int)(pd.fwd_bytes / 16); i += blockDim.x) dst[i] = src[i];
-    }
+    if constexpr (FUSED) copy_pack_to_lds(smem, p.pack, pd.fwd_bytes);
     const T* W1T = reinterpret_cast<const T*>(smem);
     const T* W1X = reinterpret_cast<const T*>(smem + pd.off_w1x);
     const float* fW = reinterpret_cast<const float*>(smem + pd.off_f32);

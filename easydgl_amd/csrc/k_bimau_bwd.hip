@@ -27,25 +27,31 @@ struct MlpP {
 };
 
 template <typename T, int DT>
-__global__ __launch_bounds__(256) void intensity_bwd_kernel(MlpP p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void intensity_bwd_kernel(MlpP p) {
     constexpr int dh = 16 * DT;
     constexpr int ECH = KY_ECH;
     const int e0 = blockIdx.y * ECH;
+    PH_DECL
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PackDims pd = pack_dims<T>(dh, p.E);
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(p.pack);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int i = threadIdx.x; i < (int)(pd.bytes / 16); i += blockDim.x) dst[i] = src[i];
-    }
+    copy_pack_to_lds(smem, p.pack, pd.bytes);
     const int JE = pd.JE, NPAR = (dh + 3) * JE, NPARX = NPAR + EP;
-    float* accs = reinterpret_cast<float*>(smem + pd.bytes);  // [NPAR + 16] block accumulator
-    for (int i = threadIdx.x; i < NPARX; i += blockDim.x) accs[i] = 0.f;
+    // block accumulator: dW1[u][j] at accs[j * (dh + 1) + u] (u on the lanes: conflict-free adds; the odd stride keeps the
+    // j-major read-out conflict-free too), then the interval row, db1 and dw [JE] each
+    const int NACC = JE * (dh + 4), WROW = JE * (dh + 1);
+    float* accs = reinterpret_cast<float*>(smem + pd.bytes);
+    for (int i = threadIdx.x; i < NACC; i += blockDim.x) accs[i] = 0.f;
+    // wave-private scratch behind it: dz [16 rows][ECH] and the intervals [16] of the current row tile
+    float* dzs = accs + ((NACC + 3) & ~3) + (threadIdx.x >> 6) * (16 * ECH + 16);
+    float* sps = dzs + 16 * ECH;
     const T* W1T = reinterpret_cast<const T*>(smem);
+    const T* W1X = reinterpret_cast<const T*>(smem + pd.off_w1x);
     const T* W1R = reinterpret_cast<const T*>(smem + pd.off_w1r);
     const float* fW = reinterpret_cast<const float*>(smem + pd.off_f32);
     const float* w1s = fW; const float* b1s = fW + JE; const float* wvs = fW + 2 * JE;
+    (void)W1X; (void)w1s; (void)b1s;
     __syncthreads();
+    PH_MARK(4);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const Frag4<T> ident = identity_frag<T>(lane);
@@ -67,53 +73,78 @@ __global__ __launch_bounds__(256) void intensity_bwd_kernel(MlpP p) {
             for (int ub = 0; ub < DT; ++ub) dW[e][d][ub] = zero4;
         }
 
-    for (int t = (int)blockIdx.x * 4 + wave; t < ntile; t += (int)gridDim.x * 4) {
+    // Operands of a row tile — H rows, intervals, dz — are three unconditional loads (rows clamped into the arrays), fetched
+    // one tile ahead; dz and the intervals go through the wave's LDS scratch, from where the mark loop reads the four rows
+    // of its lane group as broadcasts (instead of 8 + 4 conditional global loads per lane and tile, which cost 35 of the
+    // kernel's 100 us in round trips).
+    static_assert(ECH == 8, "a lane stages two dz values of its row");
+    struct TileOps { Frag4<T> hA[DT]; float span; float2 dz; };
+    auto load_tile = [&](int t) {
+        TileOps o;
         const int bpq = t / ntq, qt = t - bpq * ntq, bb = bpq % p.B;
+        const long row = min((long)bpq * p.T + qt * 16 + l15, p.R - 1);
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) o.hA[ub] = frag_ld<T>(hin + row * dh + ub * 16 + g4);
+        o.span = p.spans[(long)bb * p.T + min(qt * 16 + l15, p.T - 1)];
+        o.dz = *reinterpret_cast<const float2*>(p.dz_ws + row * EP + e0 + (g4 >> 1));   // lane group g: marks e0 + 2g, 2g + 1
+        return o;
+    };
+    const int tstep = (int)gridDim.x * 4, tfirst = (int)blockIdx.x * 4 + wave;
+    TileOps cur;
+    if (tfirst < ntile) cur = load_tile(tfirst);
+    for (int t = tfirst; t < ntile; t += tstep) {
+        const TileOps nxt = load_tile(t + tstep < ntile ? t + tstep : t);
+        asm volatile("" ::: "memory");   // the prefetch stays at the top of the tile
+        const int bpq = t / ntq, qt = t - bpq * ntq;
         const long row0 = (long)bpq * p.T + qt * 16;
         const bool okA = qt * 16 + l15 < p.T;   // row on the lane axis (A operand)
+        // rows past the end of their sequence contribute nothing: zero H and dz there
+        dzs[l15 * ECH + (g4 >> 1)] = okA ? cur.dz.x : 0.f;
+        dzs[l15 * ECH + (g4 >> 1) + 1] = okA ? cur.dz.y : 0.f;
+        if (lane < 16) sps[l15] = okA ? cur.span : 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         Frag4<T> hA[DT], hB[DT];
 #pragma unroll
         for (int ub = 0; ub < DT; ++ub) {
-            hA[ub] = okA ? frag_ld<T>(hin + (row0 + l15) * dh + ub * 16 + g4) : frag_zero<T>();
+            hA[ub] = okA ? cur.hA[ub] : frag_zero<T>();
             hB[ub] = frag_from_acc<T>(mma16(hA[ub], ident, zero4));  // L(first=row, second=u)
         }
-        float spn[4];
-        float4 dz4[4][ECH / 4];   // dz[row g4+r][e0 .. e0+ECH-1]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qq = qt * 16 + g4 + r;
-            const bool ok = qq < p.T;
-            spn[r] = ok ? p.spans[(long)bb * p.T + qq] : 0.f;
-#pragma unroll
-            for (int h = 0; h < ECH / 4; ++h)
-                dz4[r][h] = ok ? *reinterpret_cast<const float4*>(p.dz_ws + (row0 + g4 + r) * EP + e0 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        // bf16: span * w1s + b1 of every channel comes out of the matrix pipe (span_frag / W1X, bimau_common.h)
+        Frag4<T> sfA;
+        if constexpr (sizeof(T) == 2) sfA = span_frag(cur.span, lane);
+        const float4 sp4 = *reinterpret_cast<const float4*>(sps + g4);
+        const float spn[4] = {sp4.x, sp4.y, sp4.z, sp4.w};
         f32x4 dHt[DT];   // dH[row][u] of this mark group, L(first=row, second=u)
 #pragma unroll
         for (int ut = 0; ut < DT; ++ut) dHt[ut] = zero4;
+        PH_MARK(5);
 #pragma unroll
         for (int ee = 0; ee < ECH; ++ee) {
             const int e = e0 + ee;
             if (e < p.E) {
-                float dzr[4];
+                float dzr[4];   // dz[row g4 + r][e]: LDS broadcast
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 v = dz4[r][ee / 4];
-                    dzr[r] = (ee & 3) == 0 ? v.x : (ee & 3) == 1 ? v.y : (ee & 3) == 2 ? v.z : v.w;
-                }
+                for (int r = 0; r < 4; ++r) dzr[r] = dzs[(g4 + r) * ECH + ee];
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
                     const int jt = e * DT + d, j = jt * 16 + l15;
                     f32x4 a = zero4;  // Zpre[row][j], L(first=row, second=j)
+                    if constexpr (sizeof(T) == 2) a = mma16(sfA, frag_ld<T>(W1X + (jt * 16 + l15) * XW + (g4 & 4)), a);
 #pragma unroll
                     for (int ub = 0; ub < DT; ++ub)
                         a = mma16(hA[ub], frag_ld<T>(W1T + (jt * 16 + l15) * pd.LDW + ub * 16 + g4), a);
-                    const float ws = w1s[j], bs = b1s[j], wv = wvs[j];
+                    const float wv = wvs[j];
+                    if constexpr (sizeof(T) == 4) {
+                        const float ws = w1s[j], bs = b1s[j];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a[r] = fmaf(spn[r], ws, a[r]) + bs;
+                    }
                     f32x4 du;
                     float sdb = 0.f, sdws = 0.f, sdw = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float z = sigmoid_pre(fmaf(spn[r], ws, a[r]) + bs);
+                        const float z = sigmoid_pre(a[r]);
                         const float t2 = dzr[r] * z;
                         du[r] = t2 * wv * (1.0f - z);
                         sdb += du[r]; sdws += du[r] * spn[r]; sdw += t2;
@@ -138,6 +169,8 @@ __global__ __launch_bounds__(256) void intensity_bwd_kernel(MlpP p) {
 #pragma unroll
                 for (int ut = 0; ut < DT; ++ut) dst[(long)(g4 + r) * dh + ut * 16 + l15] = dHt[ut][r];
             }
+        cur = nxt;
+        PH_MARK(6);
     }
     // ---- block reduction: waves take turns adding into the LDS accumulator (deterministic) -----------
     for (int w = 0; w < 4; ++w) {
@@ -152,16 +185,16 @@ __global__ __launch_bounds__(256) void intensity_bwd_kernel(MlpP p) {
                         const float sb = group_sum4(adb[ee][d]), sws = group_sum4(adws[ee][d]), sw = group_sum4(adw[ee][d]);
                         if (lane < 16) {
                             const int j = jt * 16 + l15;
-                            accs[dh * JE + j] += sws;          // dW1[dh][j]   (interval row)
-                            accs[(dh + 1) * JE + j] += sb;     // db1[j]
-                            accs[(dh + 2) * JE + j] += sw;     // dw.flatten()[j]
+                            accs[WROW + j] += sws;          // dW1[dh][j]   (interval row)
+                            accs[WROW + JE + j] += sb;     // db1[j]
+                            accs[WROW + 2 * JE + j] += sw;     // dw.flatten()[j]
                         }
 #pragma unroll
                         for (int ub = 0; ub < DT; ++ub)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int j = jt * 16 + g4 + r, u = ub * 16 + l15;
-                                accs[u * JE + j] += dW[ee][d][ub][r];  // dW1[u][j]
+                                accs[j * (dh + 1) + u] += dW[ee][d][ub][r];  // dW1[u][j]
                             }
                     }
                 }
@@ -171,16 +204,29 @@ __global__ __launch_bounds__(256) void intensity_bwd_kernel(MlpP p) {
     }
     for (int i = threadIdx.x; i < NPAR; i += blockDim.x) {
         const int e = (i % JE) / dh;  // every entry belongs to exactly one mark e -> one blockIdx.y
-        if (e >= e0 && e < e0 + ECH) p.wpart[(long)blockIdx.x * NPARX + i] = accs[i];
+        const int row = i / JE, j = i - row * JE;
+        if (e >= e0 && e < e0 + ECH) p.wpart[(long)blockIdx.x * NPARX + i] = row < dh ? accs[j * (dh + 1) + row] : accs[WROW + (row - dh) * JE + j];
     }
-    // dscaling: fold this block's slice of kernel X's per-(b,head) partials into the same partial row
-    if (blockIdx.y == 0 && threadIdx.x < EP) {
+    // dscaling: fold this block's slice of kernel X's per-(b,head) partials into the same partial row.  All 256 threads
+    // load (16 jobs x 16 marks per round), the 16 job slices are summed through LDS in a fixed order.
+    if (blockIdx.y == 0) {
         const long per = (p.njobs + gridDim.x - 1) / gridDim.x;
         const long j0 = blockIdx.x * per, j1 = min(p.njobs, j0 + per);
+        const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
         float a = 0.f;
-        for (long j = j0; j < j1; ++j) a += p.dsc_part[j * EP + threadIdx.x];
-        p.wpart[(long)blockIdx.x * NPARX + NPAR + threadIdx.x] = a;
+        for (long j = j0 + sl; j < j1; j += 16) a += p.dsc_part[j * EP + e];
+        __syncthreads();   // accs has been written out
+        accs[sl * EP + e] = a;
+        __syncthreads();
+        if (threadIdx.x < EP) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += accs[k * EP + threadIdx.x];
+            p.wpart[(long)blockIdx.x * NPARX + NPAR + threadIdx.x] = v;
+        }
     }
+    PH_MARK(7);
+    PH_FLUSH(0);
 }
 
 template <typename T, int DT, int NT>
@@ -208,8 +254,8 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     // ---- Y ----
     {
         MlpP mp{p.hin, p.dz_ws, p.spans, p.pack, (long)p.B * p.H * p.T, p.B, p.T, p.E, p.dh_ws, p.wpart, p.dsc_part, jobs};
-        const int JE = dh * p.E, NPARX = (dh + 3) * JE + EP;
-        const size_t smem_b = pd.bytes + (size_t)NPARX * sizeof(float);
+        const int JE = dh * p.E, NACC = JE * (dh + 4);
+        const size_t smem_b = pd.bytes + ((size_t)((NACC + 3) & ~3) + 4 * (16 * KY_ECH + 16)) * sizeof(float);   // + per-wave tile scratch
         EDGL_REQUIRE(smem_b <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: intensity kernel needs %zu B of LDS", smem_b);
         auto kb = intensity_bwd_kernel<T, DT>;
         hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);

@@ -14,7 +14,7 @@ import bench  # noqa: E402
 from easydgl_amd import _lib  # noqa: E402
 from easydgl_amd.engine import TrainEngine  # noqa: E402
 
-NAMES = ["X: S + softmax", "X: G/dA/dlam/dV sweep", "X: dz, row term", "X: epilogue", "-", "-", "-", "-",
+NAMES = ["X: S + softmax", "X: G/dA/dlam/dV sweep", "X: dz, row term", "X: epilogue", "Y: pack -> LDS", "Y: tile operands", "Y: mark loop + dH store", "Y: reduction + partials",
          "Z: S + softmax", "Z: dP/dS/dQ/dK/dT sweep", "Z: epilogue", "-", "-", "-", "-", "-"]
 
 
