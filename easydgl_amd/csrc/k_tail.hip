@@ -21,14 +21,12 @@ __device__ unsigned long long g_phase_cycles[16];   // see edgl_common.h (PH_MAR
 namespace {
 
 constexpr int MAXRT = 7;   // 16-row tiles per sample (T <= 112)
-// libm erf in this file: the inlined fast form (edgl_common.h gelu_t<bf16>) lets the scheduler interleave all 28 chains of a
-// phase and costs ~80 more registers (spills) than it saves in instructions
-#ifndef GELU_TAIL
+// libm erf in this file.  The inlined fast form (edgl_common.h gelu_t<bf16>) was measured twice: unfenced, the scheduler
+// interleaves all 28 chains of a phase (~80 more registers, spills); with a scheduling fence per row tile the z / acc
+// state still spills around the GELU phases: forward 84 -> 88 us, backward 120 -> 138 us.
 #define GELU_TAIL gelu_f
-#endif
-#ifndef DGELU_TAIL
 #define DGELU_TAIL dgelu_f
-#endif
+#define TAIL_FENCE()
 
 struct TailP {
     const bf16* att; const bf16* xin; int ld_x;
@@ -53,11 +51,19 @@ struct TailGeom {
 template <int CT>
 __device__ __forceinline__ void copy_in(bf16* dst, const bf16* src, long ld, int T) {
     using G = TailGeom<CT>;
-    for (int v = threadIdx.x; v < MAXRT * 16 * G::CV; v += G::NTHR) {
-        const int row = v / G::CV, cv = v % G::CV;
-        uint4 d = make_uint4(0, 0, 0, 0);
-        if (row < T) d = *reinterpret_cast<const uint4*>(src + (long)row * ld + cv * 8);
-        *reinterpret_cast<uint4*>(dst + row * G::LD + cv * 8) = d;
+    // all loads of the image are issued before the first LDS store (rows clamped: straight-line code); a load / store
+    // loop pays one HBM round trip per 8 KB of a 512-thread workgroup
+    constexpr int NV = MAXRT * 16 * G::CV, NI = (NV + G::NTHR - 1) / G::NTHR;
+    uint4 d[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int v = threadIdx.x + i * G::NTHR, row = v / G::CV, cv = v % G::CV;
+        d[i] = *reinterpret_cast<const uint4*>(src + (long)min(row, T - 1) * ld + cv * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int v = threadIdx.x + i * G::NTHR, row = v / G::CV, cv = v % G::CV;
+        if (v < NV) *reinterpret_cast<uint4*>(dst + row * G::LD + cv * 8) = row < T ? d[i] : make_uint4(0, 0, 0, 0);
     }
 }
 template <int CT>
@@ -226,6 +232,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
                     for (int r = 0; r < 4; ++r) { pre[r] = acc[rt][r] + bv[r]; fv[r] = GELU_TAIL(pre[r]); }
                     st_bf4(bufS + row * LD + nl, pre);
                     st_bf4(bufC + row * LD + nl, fv);
+                    TAIL_FENCE();
                 }
         }
         PH_MARK(5);   // G2 half + GELU
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
                 for (int r = 0; r < 4; ++r) { pre[r] = acc[rt][r] + bv[r]; sv[r] = GELU_TAIL(pre[r]); z[rt][r] = rbf(sv[r]); }
                 st_bf4(bufS + row * LD + nl, pre);
                 st_bf4(bufC + row * LD + nl, sv);
+                TAIL_FENCE();
             }
     }
     lds_barrier();
@@ -459,6 +467,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = dz[rt][r] * DGELU_TAIL(pre[r]);
                 st_bf4(bufC + row * LD + nl, v);
+                TAIL_FENCE();
             }
         lds_barrier();
         copy_out<CT>(p.d_pre_t + row0 * C, C, bufC, T);
@@ -533,6 +542,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = acc[rt][r] * DGELU_TAIL(pre[r]);
                     st_bf4(bufB + row * LD + nl, v);
+                    TAIL_FENCE();
                 }
         }
         lds_barrier();
