@@ -40,6 +40,7 @@ SIGNATURES = {
     "edgl_colsum": (I, [P, I, I, I, P, I, P, I, I, P]),
     "edgl_gemm_dw_workspace": (L, [I, I, I, I]),
     "edgl_gemm_dw": (I, [P, P, P, P, I, I, I, I, I, I, P, I, P]),
+    "edgl_gemm_dw_defer": (I, [I, P]),
     "edgl_bimau_pack_bytes": (L, [I, I, I, I]),
     "edgl_bimau_pack": (I, [P, P, P, P, I, I, I, P, I, P]),
     "edgl_bimau_saved_bytes": (L, [I, I, I, I, I]),

@@ -321,6 +321,9 @@ extern "C" long edgl_gemm_dw_workspace(int R, int Kf, int N, int dtype) {
     return dtype == EDGL_BF16 ? std::max(tn, generic) : generic;
 }
 
+int edgl_gemm2_tn_defer(int on, hipStream_t st);
+extern "C" int edgl_gemm_dw_defer(int on, void* stream) { return edgl_gemm2_tn_defer(on, (hipStream_t)stream); }
+
 extern "C" int edgl_gemm_dw(const void* X, const void* dY, float* dW, float* dbias, int R, int Kf, int N, int ldx, int ldy,
                             int accumulate, float* workspace, int dtype, void* stream) {
     EDGL_REQUIRE(X && dY && dW && workspace, EDGL_ERR_NULL, "edgl_gemm_dw: null pointer");

@@ -451,14 +451,12 @@ struct TnP {
 
 // TM = output tile edge of a workgroup (4 waves in a 2 x 2 arrangement): 128 (default) or 64 (see tn_tile)
 template <int TM>
-__global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
+__device__ __forceinline__ void tn_body(const TnP& p, int bx, int by, int bz, bf16* Xs, bf16* Ys) {
     constexpr int NI = TM / 32, LDT = TM + 16, PCS = TM / 8, NLD = T_BR * PCS / T_NT;   // 16-byte pieces per row / per thread
-    __shared__ __attribute__((aligned(16))) bf16 Xs[T_BR * LDT];
-    __shared__ __attribute__((aligned(16))) bf16 Ys[T_BR * LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
-    const int kf0 = blockIdx.y * TM, n0 = blockIdx.x * TM;
-    const int r_lo = blockIdx.z * p.rows_per_split, r_hi = min(p.R, r_lo + p.rows_per_split);
+    const int kf0 = by * TM, n0 = bx * TM;
+    const int r_lo = bz * p.rows_per_split, r_hi = min(p.R, r_lo + p.rows_per_split);
     f32x4 acc[NI][NI];   // [i: kf tile][j: n tile], L(first = kf, second = n)
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -506,7 +504,7 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
         }
-        if (p.with_colsum && blockIdx.y == 0 && tid < TM) {
+        if (p.with_colsum && by == 0 && tid < TM) {
 #pragma unroll 8
             for (int r = 0; r < T_BR; ++r) csum += to_f32(Ys[r * LDT + tid]);
         }
@@ -514,7 +512,7 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
         if (more) store();
         lds_barrier();
     }
-    float* out = p.partial + (long)blockIdx.z * (p.Kf + 1) * p.N;
+    float* out = p.partial + (long)bz * (p.Kf + 1) * p.N;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -528,7 +526,30 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
                 }
             }
         }
-    if (p.with_colsum && blockIdx.y == 0 && tid < TM && n0 + tid < p.N) out[(long)p.Kf * p.N + n0 + tid] = csum;
+    if (p.with_colsum && by == 0 && tid < TM && n0 + tid < p.N) out[(long)p.Kf * p.N + n0 + tid] = csum;
+}
+
+template <int TM>
+__global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
+    __shared__ __attribute__((aligned(16))) bf16 Xs[T_BR * (TM + 16)];
+    __shared__ __attribute__((aligned(16))) bf16 Ys[T_BR * (TM + 16)];
+    tn_body<TM>(p, blockIdx.x, blockIdx.y, blockIdx.z, Xs, Ys);
+}
+
+// Several weight-gradient GEMMs in ONE launch (edgl_gemm_dw_defer): the dW products of a block are independent of each
+// other and individually too small for the chip — the 128 x 128 layers run two 64-row steps per workgroup and leave 25 MB of
+// partial slabs each.  Grouped, they share the launch with the wide QKVT product and get row splits of similar length.
+constexpr int TN_MAX_JOBS = 8;
+struct TnGroupP { TnP job[TN_MAX_JOBS]; int tiles_n[TN_MAX_JOBS], tiles_k[TN_MAX_JOBS], blk0[TN_MAX_JOBS + 1]; int n; };
+__global__ __launch_bounds__(T_NT) void tn_gemm_group_kernel(TnGroupP g) {
+    __shared__ __attribute__((aligned(16))) bf16 Xs[T_BR * (128 + 16)];
+    __shared__ __attribute__((aligned(16))) bf16 Ys[T_BR * (128 + 16)];
+    int j = 0;
+    for (int i = 1; i < g.n; ++i)
+        if ((int)blockIdx.x >= g.blk0[i]) j = i;
+    const int local = (int)blockIdx.x - g.blk0[j];
+    const int tn = g.tiles_n[j], tk = g.tiles_k[j];
+    tn_body<128>(g.job[j], local % tn, (local / tn) % tk, local / (tn * tk), Xs, Ys);
 }
 
 }  // namespace gemm2
@@ -620,6 +641,73 @@ static int tn_splits(int R, int Kf, int N) {
 }
 long edgl_gemm2_tn_workspace(int R, int Kf, int N) { return (long)tn_splits(R, Kf, N) * (Kf + 1) * N; }
 
+// reductions of one TN product's split slabs into (dW, db)
+static int tn_reduce(const float* workspace, int splits, float* C, int Kf, int N, float* dbias, int accumulate, hipStream_t st) {
+    if (dbias && dbias == C + (long)Kf * N)   // (dW, db) contiguous, as in the flat gradient arena: one reduction
+        return edgl_reduce_rows(workspace, splits, (Kf + 1) * N, (long)(Kf + 1) * N, C, accumulate, st);
+    int rc = edgl_reduce_rows(workspace, splits, Kf * N, (long)(Kf + 1) * N, C, accumulate, st);
+    if (rc) return rc;
+    if (dbias) rc = edgl_reduce_rows(workspace + (long)Kf * N, splits, N, (long)(Kf + 1) * N, dbias, accumulate, st);
+    return rc;
+}
+
+// ---- deferred / grouped mode -------------------------------------------------------------------------------------------
+struct TnQueued { TnP p; float* C; float* dbias; int accumulate, max_splits; };
+thread_local bool g_tn_defer = false;
+thread_local int g_tn_n = 0;
+thread_local TnQueued g_tn_q[TN_MAX_JOBS];
+
+static int tn_flush(hipStream_t st) {
+    const int n = g_tn_n;
+    g_tn_n = 0;
+    if (n == 0) return EDGL_OK;
+    TnGroupP g;
+    g.n = n;
+    int total_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        g.tiles_n[i] = (g_tn_q[i].p.N + 127) / 128;
+        g.tiles_k[i] = (g_tn_q[i].p.Kf + 127) / 128;
+        total_tiles += g.tiles_n[i] * g.tiles_k[i];
+    }
+    // one split count for the whole group (row ranges of similar length), capped by what each job's workspace was sized for
+    static const int target = getenv("EDGL_TN_GROUP_TARGET") ? atoi(getenv("EDGL_TN_GROUP_TARGET")) : 768;
+    const int group_splits = std::max(1, target / std::max(1, total_tiles));
+    int splits[TN_MAX_JOBS], blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        TnP& p = g_tn_q[i].p;
+        int sp = std::max(1, std::min(std::min(group_splits, g_tn_q[i].max_splits), p.R / 128));
+        const int rps = ((p.R + sp - 1) / sp + T_BR - 1) / T_BR * T_BR;
+        sp = (p.R + rps - 1) / rps;
+        p.rows_per_split = rps;
+        splits[i] = sp;
+        g.job[i] = p;
+        g.blk0[i] = blocks;
+        blocks += g.tiles_n[i] * g.tiles_k[i] * sp;
+    }
+    g.blk0[n] = blocks;
+    hipLaunchKernelGGL(tn_gemm_group_kernel, dim3(blocks), dim3(T_NT), 0, st, g);
+    EDGL_LAUNCH_CHECK();
+    for (int i = 0; i < n; ++i) {
+        const TnP& p = g_tn_q[i].p;
+        const int rc = tn_reduce(p.partial, splits[i], g_tn_q[i].C, p.Kf, p.N, g_tn_q[i].dbias, g_tn_q[i].accumulate, st);
+        if (rc) return rc;
+    }
+    return EDGL_OK;
+}
+
+// on = 1: the following edgl_gemm_dw calls (bf16, 128-tiles) are queued; on = 0: they run as one grouped launch on `stream`
+// followed by their slab reductions; on < 0: forget the queue.  The operands and workspaces of queued calls must stay
+// untouched until the flush; a full queue flushes itself.
+int edgl_gemm2_tn_defer(int on, hipStream_t st) {
+    if (on < 0) { g_tn_n = 0; g_tn_defer = false; return EDGL_OK; }
+    if (!on && g_tn_defer) {
+        g_tn_defer = false;
+        return tn_flush(st);
+    }
+    g_tn_defer = on != 0;
+    return EDGL_OK;
+}
+
 int edgl_gemm2_try_tn(const void* X, const void* Y, float* C, int R, int Kf, int N, int ldx, int ldy, int ldc, float* dbias,
                       int accumulate, float* workspace, hipStream_t st) {
     const bool ok = (Kf % 8 == 0) && (N % 8 == 0) && (ldx % 8 == 0) && (ldy % 8 == 0) && ldc == N &&
@@ -629,20 +717,19 @@ int edgl_gemm2_try_tn(const void* X, const void* Y, float* C, int R, int Kf, int
     int rps = ((R + splits - 1) / splits + T_BR - 1) / T_BR * T_BR;
     splits = (R + rps - 1) / rps;
     TnP p{(const bf16*)X, (const bf16*)Y, R, Kf, N, ldx, ldy, rps, workspace, dbias ? 1 : 0};
+    if (g_tn_defer && tn_tile(Kf, N) == 128) {
+        if (g_tn_n == TN_MAX_JOBS) {
+            const int rc = tn_flush(st);
+            if (rc) return rc;
+        }
+        g_tn_q[g_tn_n++] = TnQueued{p, C, dbias, accumulate, splits};
+        return 1;
+    }
     if (tn_tile(Kf, N) == 64) hipLaunchKernelGGL(tn_gemm_kernel<64>, dim3((N + 63) / 64, (Kf + 63) / 64, splits), dim3(T_NT), 0, st, p);
     else hipLaunchKernelGGL(tn_gemm_kernel<128>, dim3((N + 127) / 128, (Kf + 127) / 128, splits), dim3(T_NT), 0, st, p);
     EDGL_LAUNCH_CHECK();
-    if (dbias && dbias == C + (long)Kf * N) {   // (dW, db) contiguous, as in the flat gradient arena: one reduction
-        const int rc = edgl_reduce_rows(workspace, splits, (Kf + 1) * N, (long)(Kf + 1) * N, C, accumulate, st);
-        return rc ? rc : 1;
-    }
-    int rc = edgl_reduce_rows(workspace, splits, Kf * N, (long)(Kf + 1) * N, C, accumulate, st);
-    if (rc) return rc;
-    if (dbias) {
-        rc = edgl_reduce_rows(workspace + (long)Kf * N, splits, N, (long)(Kf + 1) * N, dbias, accumulate, st);
-        if (rc) return rc;
-    }
-    return 1;
+    const int rc = tn_reduce(workspace, splits, C, Kf, N, dbias, accumulate, st);
+    return rc ? rc : 1;
 }
 
 #ifdef EDGL_PHASE_TIMING

@@ -229,6 +229,7 @@ class TrainEngine:
         except BaseException:
             # never leave the thread in deferred mode: later ops would queue reductions that nobody flushes
             lib.edgl_reduce_defer(-1, st)
+            lib.edgl_gemm_dw_defer(-1, st)
             raise
         check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")   # runs every queued reduction in one launch
 
@@ -260,6 +261,8 @@ class TrainEngine:
             x_in, cin = (self.x0, 3 * C) if i == 0 else (self.blk[i - 1]["y"], C)
             dh2, dh1 = drop(hd, 12 + 4 * i), drop(hd, 11 + 4 * i)
             if self.fused_tail:
+                # the five weight-gradient products of the block run as one grouped launch after the BiMAU backward
+                check(lib.edgl_gemm_dw_defer(1, st), "edgl_gemm_dw_defer")
                 # one launch: LN3' -> GELU' -> dX(Wt) -> LN2' -> dX(Wout) * GELU' -> dX(Wi) -> LN1' -> dX(Wo)  (csrc/k_tail.hip)
                 last = i == len(self.blk) - 1
                 tl = m.transform_ln
@@ -304,6 +307,8 @@ class TrainEngine:
                                      _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), 0, code, st),
                   "edgl_bimau_bwd")
             self._dense_dw(x_in, self.G4c, att.dense_kernel, att.dense_bias, cin, 4 * C)
+            if self.fused_tail:
+                check(lib.edgl_gemm_dw_defer(0, st), "edgl_gemm_dw_defer")
             d_in = self.G3c if i == 0 else self.G3
             self._dense_dx(self.G4c, att.dense_kernel, d_in, cin, 4 * C)
             # both residual branches feed the first C channels of the block input (temporal.py:447, EasyDGL.py:116)

@@ -128,6 +128,11 @@ int edgl_gemm(const void* A, const void* Bm, void* Cm, int M, int N, int K, int 
 long edgl_gemm_dw_workspace(int R, int Kf, int N, int dtype);
 int edgl_gemm_dw(const void* X, const void* dY, float* dW, float* dbias, int R, int Kf, int N, int ldx, int ldy,
                  int accumulate, float* workspace, int dtype, void* stream);
+/* Grouped mode of edgl_gemm_dw (bf16): after edgl_gemm_dw_defer(1, stream) the calls are queued on the calling host thread;
+ * edgl_gemm_dw_defer(0, stream) runs all of them as ONE launch (up to 8 products, row splits of similar length) followed by
+ * their slab reductions.  Operands and workspaces of queued calls must stay untouched until then.  on < 0: drop the queue
+ * without launching (error exit). */
+int edgl_gemm_dw_defer(int on, void* stream);
 
 /* out[n] (+)= sum_m X[m, n]  — bias gradients.  X `dtype` (or f32 if x_f32) [M, ld]; out f32[N]. */
 int edgl_colsum(const void* X, int M, int N, int ld, float* out, int accumulate, float* workspace,
