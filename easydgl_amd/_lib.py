@@ -68,7 +68,10 @@ SIGNATURES = {
     "edgl_tpp_workspace": (I, []),
     "edgl_tpp_fwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P]),
     "edgl_tpp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, P, P]),
+    "edgl_tpp_fwd_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P, P]),
     "edgl_adam_step": (I, [P, P, P, P, L, F, F, F, F, P, F, P, I, P, P]),
+    "edgl_step_begin": (I, [P, P, F, F, F, P]),
+    "edgl_adam_apply": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P]),
     "edgl_l2_loss": (I, [P, P, I, F, P, I, P, P]),
     "edgl_cast": (I, [P, P, L, I, P]),
     "edgl_cast_back": (I, [P, P, L, I, I, P]),

@@ -123,7 +123,8 @@ struct EncBwdP {
     const int64_t* ids; const uint8_t* marks; const void* dx0;
     int B, T, C, E, I; float rate; const uint64_t* rng; uint32_t stream_id;
     float* d_item; float* part_pos; float* part_mk; int nchunk;
-    int srows;   // rows per block of the scatter stage (<= SROWS; fewer when SROWS*C floats exceed the LDS)
+    int srows;
+    float* d_mark_zero;   // [E*C]: cleared by block (0, 0) of the position / mark stage (only row 1 is ever written afterwards)   // rows per block of the scatter stage (<= SROWS; fewer when SROWS*C floats exceed the LDS)
 };
 
 // d_pos / d_mark: grid (T, nchunk): the block owns position t for the b-range of its chunk.  Thread = 4
@@ -134,6 +135,8 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(EncBwdP p) {
     extern __shared__ float sm[];  // [rows_par][2][C]
     __shared__ float s_nm[64];
     const int t = blockIdx.x, chunk = blockIdx.y;
+    if (t == 0 && chunk == 0 && p.d_mark_zero)
+        for (int i = threadIdx.x; i < p.E * p.C; i += blockDim.x) p.d_mark_zero[i] = 0.f;
     const int bper = (p.B + p.nchunk - 1) / p.nchunk;
     const int b0 = chunk * bper, b1 = min(p.B, b0 + bper);
     const int cpr = p.C / 4, rows_par = 256 / cpr;
@@ -270,7 +273,7 @@ extern "C" int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const v
     float* part_mk = workspace + (long)ENC_NCHUNK * T * C;
     int srows = SROWS;
     while (srows > 8 && (size_t)srows * C * sizeof(float) > 150 * 1024) srows >>= 1;   // C = 512: 64 rows per block
-    EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, part_pos, part_mk, ENC_NCHUNK, srows};
+    EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, part_pos, part_mk, ENC_NCHUNK, srows, d_mark_emb};
     hipStream_t st = (hipStream_t)stream;
     const int rows_par = 256 / (C / 4);
     dim3 grid(T, ENC_NCHUNK);
@@ -293,10 +296,6 @@ extern "C" int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const v
     }
     int rc = edgl_reduce_rows(part_pos, ENC_NCHUNK, T * C, (long)T * C, d_pos, 0, st);
     if (rc) return rc;
-    if (hipMemsetAsync(d_mark_emb, 0, (size_t)E * C * sizeof(float), st) != hipSuccess) {
-        edgl_set_error("edgl_encode_bwd: memset failed");
-        return EDGL_ERR_LAUNCH;
-    }
     if (E > 1) {  // only row 1 of the mark-embedding table is ever indexed (EasyDGL.py:87-88)
         rc = edgl_reduce_rows(part_mk, ENC_NCHUNK * T, C, C, d_mark_emb + C, 0, st);
         if (rc) return rc;

@@ -670,7 +670,7 @@ static int tn_flush(hipStream_t st) {
         total_tiles += g.tiles_n[i] * g.tiles_k[i];
     }
     // one split count for the whole group (row ranges of similar length), capped by what each job's workspace was sized for
-    static const int target = getenv("EDGL_TN_GROUP_TARGET") ? atoi(getenv("EDGL_TN_GROUP_TARGET")) : 768;
+    static const int target = getenv("EDGL_TN_GROUP_TARGET") ? atoi(getenv("EDGL_TN_GROUP_TARGET")) : 512;
     const int group_splits = std::max(1, target / std::max(1, total_tiles));
     int splits[TN_MAX_JOBS], blocks = 0;
     for (int i = 0; i < n; ++i) {

@@ -118,6 +118,146 @@ __global__ __launch_bounds__(256) void tpp_bwd_kernel(TppP p, const float* sums,
     }
 }
 
+// Regulariser and its gradient for the training engine (edgl_tpp_fwd_bwd): d lambda is written for EVERY (b', position) row —
+// zeros where the position is not masked, so the [H*B*T, E] gradient needs no memset, and the slots of a repeated masked
+// position are summed (the gradient of tf.gather).  The normaliser c = sum of mark counts depends on the labels only and is
+// computed first by one small workgroup (exact: integer counts), which removes the partial -> final -> gradient chain of
+// launches.  (No last-workgroup-done reduction for the scalar sums: on this multi-XCD part every __threadfence() is an L2
+// write-back — 2048 of them cost 50 us; a 64-thread final kernel costs 5.)
+// one label per thread; integer atomics: exact and order-independent, hence deterministic
+__global__ __launch_bounds__(256) void tpp_norm_kernel(TppP p, int* acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int cnt = 0;
+    if (i < p.B * p.M) {
+        const uint8_t* nm = p.mtab + p.labels[i] * p.E;
+        if (p.E == 16 && ((uintptr_t)p.mtab & 15) == 0) {
+            const uint4 w = *reinterpret_cast<const uint4*>(nm);
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cnt += (int)((ws[j] & 0xffu) + ((ws[j] >> 8) & 0xffu) + ((ws[j] >> 16) & 0xffu) + (ws[j] >> 24));
+        } else {
+            for (int e = 0; e < p.E; ++e) cnt += nm[e];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(acc, cnt);
+}
+constexpr int TPP_MAXM = 256, TPP_FUSED_BLOCKS = 2048;
+__global__ __launch_bounds__(128) void tpp_fused_kernel(TppP p, const float* sums, float* part, float* d_lam) {
+    __shared__ float red[8];
+    __shared__ int s_pos[TPP_MAXM];
+    __shared__ int s_lab[TPP_MAXM];
+    __shared__ __attribute__((aligned(16))) float s_out[2][64 * 16];   // per wave: 64 gradient rows, for coalesced stores
+    const float c = (float)reinterpret_cast<const int*>(sums)[4] * (float)p.H;   // tpp_norm_kernel
+    const float k = -p.coef / c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a = 0.f, bsum = 0.f;
+    for (int bp = blockIdx.x; bp < p.H * p.B; bp += gridDim.x) {
+        const int b = bp % p.B;
+        __syncthreads();
+        for (int m = threadIdx.x; m < p.M; m += blockDim.x) {
+            s_pos[m] = p.mpos ? (int)p.mpos[(long)b * p.M + m] : m;
+            s_lab[m] = (int)p.labels[(long)b * p.M + m];
+        }
+        __syncthreads();
+        for (int t0 = 0; t0 < p.T; t0 += blockDim.x) {
+            const int t = t0 + threadIdx.x;
+            const long row = (long)bp * p.T + min(t, p.T - 1);
+            float lam[16], gr[16];
+            bool loaded = false;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) gr[e] = 0.f;
+            // slots of this position: the search is a cheap LDS scan; the heavy part below runs once per FOUND slot, so the
+            // lanes of a wave do their first (usually only) slot together instead of one lane per loop iteration
+            const int m_hi = t >= p.T ? 0 : (p.mpos ? p.M : t + 1);
+            int m = p.mpos ? -1 : t - 1;
+            for (;;) {
+                int nxt = -1;
+                for (int q = m + 1; q < m_hi; ++q)
+                    if (s_pos[q] == t) { nxt = q; break; }
+                if (nxt < 0) break;
+                m = nxt;
+                if (!loaded) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { lam[e] = p.lam[row * p.E + min(e, p.E - 1)]; asm volatile("" : "+v"(lam[e])); }
+                    loaded = true;
+                }
+                const uint8_t* nm = p.mtab + (long)s_lab[m] * p.E;
+                // the E mark bytes of the label: one 16-byte load (E == 16), else E clamped byte loads — all unconditional
+                // (a select around a load becomes a branch: dependent round trips)
+                uint32_t mw[4];
+                if (p.E == 16 && ((uintptr_t)p.mtab & 15) == 0) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(nm);
+                    mw[0] = w.x; mw[1] = w.y; mw[2] = w.z; mw[3] = w.w;
+                } else {
+                    uint32_t by[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { by[e] = nm[min(e, p.E - 1)]; asm volatile("" : "+v"(by[e])); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mw[j] = by[4 * j] | (by[4 * j + 1] << 8) | (by[4 * j + 2] << 16) | (by[4 * j + 3] << 24);
+                }
+                float cnt = 0.f, ev = 0.f, ent = 0.f, f[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    f[e] = e < p.E ? (float)((mw[e >> 2] >> (8 * (e & 3))) & 0xffu) : 0.f;
+                    cnt += f[e]; ev += lam[e] * f[e]; ent += e < p.E ? lam[e] : 0.f;
+                }
+                const float g = cnt > 0.f ? 1.f : 0.f;  // sign(sum nm), temporal.py:321
+                ev *= g; ent *= g;
+                const float sp = p.mpos ? raw_span(p.ts + (long)b * p.T, t, p.T)
+                                        : p.ts[(long)b * (p.T + 1) + t + 1] - p.ts[(long)b * (p.T + 1) + t];
+                a += __logf(ev == 0.f ? 1.f : ev);      // :324
+                bsum += ent * sp * 0.5f;                // :327-328
+                const float iev = ev != 0.f ? 1.0f / ev : 0.f, kg = k * g, hs = sp * 0.5f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) gr[e] += kg * (f[e] * iev - hs);
+            }
+            if (d_lam) {
+                if (p.E == 16) {
+                    // 64 rows x 64 bytes of a wave are contiguous in d_lam: through LDS so that a store instruction
+                    // writes 1 KB of consecutive bytes (lane = one 16-byte piece) instead of 64 scattered pieces
+                    float* so = s_out[wave];
+#pragma unroll
+                    for (int e = 0; e < 16; e += 4)
+                        *reinterpret_cast<float4*>(so + lane * 16 + e) = make_float4(gr[e], gr[e + 1], gr[e + 2], gr[e + 3]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int row_w0 = t0 + wave * 64;                       // first position of this wave
+                    const int nrows = min(64, p.T - row_w0);                 // <= 0: nothing to store
+                    float* dst = d_lam + ((long)bp * p.T + row_w0) * 16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int piece = i * 64 + lane;                     // 16-byte piece index in the wave's 4 KB
+                        if (piece < nrows * 4) *reinterpret_cast<float4*>(dst + piece * 4) = *reinterpret_cast<const float4*>(so + piece * 4);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                } else if (t < p.T) {
+                    float* dst = d_lam + row * p.E;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (e < p.E) dst[e] = gr[e];
+                }
+            }
+        }
+    }
+    a = block_sum(a, red); bsum = block_sum(bsum, red);
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = a; part[blockIdx.x * 2 + 1] = bsum; }
+}
+__global__ __launch_bounds__(256) void tpp_final2_kernel(const float* part, int nblk, float coef, int H, float* sums, float* reg_out,
+                                                         int accumulate) {
+    // one workgroup: thread i adds partials i, i+256, ... in index order, then the fixed block_sum tree — deterministic
+    __shared__ float red[8];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) { a += part[i * 2]; b += part[i * 2 + 1]; }
+    a = block_sum(a, red); b = block_sum(b, red);
+    if (threadIdx.x != 0) return;
+    const float c = (float)reinterpret_cast<const int*>(sums)[4] * (float)H;
+    sums[0] = a; sums[1] = b; sums[2] = c;
+    const float reg = coef * (-(a - b) / c);  // temporal.py:331-332, EasyDGL.py:175
+    reg_out[0] = accumulate ? reg_out[0] + reg : reg;
+    reinterpret_cast<int*>(sums)[4] = 0;   // normaliser accumulator back to zero for the next call
+}
+
 // ---------------------------------------------------------------------------------------------
 // Adam (TF form) over the flat arena
 // ---------------------------------------------------------------------------------------------
@@ -349,7 +489,7 @@ extern "C" int edgl_rng_advance(uint64_t* rng_state, void* stream) {
     return EDGL_OK;
 }
 
-extern "C" int edgl_tpp_workspace(void) { return RED_BLOCKS * 3 + 4; }
+extern "C" int edgl_tpp_workspace(void) { return std::max(RED_BLOCKS * 3 + 4, 8 + 2 * 2048); }   // edgl_tpp_fwd_bwd: sums[8] + partial pairs
 
 extern "C" int edgl_tpp_fwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                             const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
@@ -381,6 +521,25 @@ extern "C" int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const i
     return EDGL_OK;
 }
 
+extern "C" int edgl_tpp_fwd_bwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                                const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
+                                float* reg_out, int accumulate, float* d_lam, void* stream) {
+    EDGL_REQUIRE(lam && labels && ts_raw && mark_table && sums && reg_out, EDGL_ERR_NULL, "edgl_tpp_fwd_bwd: null pointer");
+    EDGL_REQUIRE(masked_pos || M == T, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: all-position mode needs M == T");
+    EDGL_REQUIRE(E >= 1 && E <= 16, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: E=%d (1..16)", E);
+    EDGL_REQUIRE(M <= TPP_MAXM, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: M=%d > %d", M, TPP_MAXM);
+    TppP p{lam, masked_pos, labels, ts_raw, mark_table, B, T, H, E, M, coef};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tpp_norm_kernel, dim3((B * M + 255) / 256), dim3(256), 0, st, p, reinterpret_cast<int*>(sums) + 4);
+    EDGL_LAUNCH_CHECK();
+    const int nblk = std::min(TPP_FUSED_BLOCKS, H * B);
+    hipLaunchKernelGGL(tpp_fused_kernel, dim3(nblk), dim3(128), 0, st, p, sums, sums + 8, d_lam);
+    EDGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tpp_final2_kernel, dim3(1), dim3(256), 0, st, sums + 8, nblk, coef, H, sums, reg_out, accumulate);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
 extern "C" int edgl_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr, float beta1,
                               float beta2, float eps, uint64_t* step_state, float l2, const int64_t* seg, int nseg,
                               void* shadow, void* stream) {
@@ -389,6 +548,36 @@ extern "C" int edgl_adam_step(float* param, const float* grad, float* m, float* 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, step_state, lr, beta1, beta2);
     EDGL_LAUNCH_CHECK();
+    if (shadow)
+        hipLaunchKernelGGL((adam_kernel<true>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
+                           step_state, l2, seg, nseg, (bf16*)shadow);
+    else
+        hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
+                           step_state, l2, seg, nseg, (bf16*)nullptr);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+// The two single-thread state updates of a training step in one launch (a launch boundary costs ~4 us on this device
+// whatever the kernel does): dropout step counter += 1, Adam step += 1 and its bias-corrected learning rate.
+// edgl_adam_apply is then the parameter update alone.  edgl_adam_step == the Adam half of edgl_step_begin + edgl_adam_apply.
+__global__ void step_begin_kernel(uint64_t* rng, uint64_t* adam, float lr, float b1, float b2) {
+    rng[1] += 1ull;
+    adam[0] += 1ull;
+    const double t = (double)adam[0];
+    reinterpret_cast<float*>(adam + 1)[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+}
+extern "C" int edgl_step_begin(uint64_t* rng_state, uint64_t* adam_state, float lr, float beta1, float beta2, void* stream) {
+    EDGL_REQUIRE(rng_state && adam_state, EDGL_ERR_NULL, "edgl_step_begin: null state");
+    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state, adam_state, lr, beta1, beta2);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+extern "C" int edgl_adam_apply(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
+                               const uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, void* stream) {
+    EDGL_REQUIRE(param && grad && m && v && step_state, EDGL_ERR_NULL, "edgl_adam_apply: null pointer");
+    EDGL_REQUIRE(l2 == 0.f || nseg == 0 || seg, EDGL_ERR_NULL, "edgl_adam_apply: l2 without segments");
+    hipStream_t st = (hipStream_t)stream;
     if (shadow)
         hipLaunchKernelGGL((adam_kernel<true>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
                            step_state, l2, seg, nseg, (bf16*)shadow);

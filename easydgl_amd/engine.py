@@ -60,7 +60,8 @@ class TrainEngine:
                      st2=e(B, 2, dtype=f32),
                      pack=e(lib.edgl_bimau_pack_bytes(C, H, E, self.code), dtype=torch.uint8),
                      saved=e(lib.edgl_bimau_saved_bytes(B, T, C, H, self.code), dtype=torch.uint8),
-                     dlam=e(H * B, T, E, dtype=f32), tpp=e(lib.edgl_tpp_workspace(), dtype=f32))
+                     dlam=e(H * B, T, E, dtype=f32),
+                     tpp=torch.zeros(lib.edgl_tpp_workspace(), device=dev, dtype=f32))   # [3]: ticket of edgl_tpp_fwd_bwd
             self.blk.append(d)
         self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
         # fused per-sample block tail (csrc/k_tail.hip): one launch for dense -> LN -> GELU-dense -> dense -> LN (-> head)
@@ -79,6 +80,10 @@ class TrainEngine:
         self.nvalid = torch.zeros(1, device=dev, dtype=torch.int32)
         self.lse, self.lab_logit, self.coef = e(self.R, dtype=f32), e(self.R, dtype=f32), e(self.R, dtype=f32)
         self.loss = e(1, dtype=f32)
+        # cross-entropy term (main stream) and L2 + TPP terms (side stream); self.loss = their sum
+        self.loss_ce, self.loss_aux = e(1, dtype=f32), torch.zeros(1, device=dev, dtype=f32)
+        self.ws_l2 = e(1024, dtype=f32)
+        self.side = torch.cuda.Stream(device=dev)
         # ---- backward temporaries -------------------------------------------------------------------------------
         self.d_rows = e(self.R, C)
         self.G1, self.G2, self.G3, self.G4 = e(B, T, C), e(B, T, C), e(B, T, C), e(B, T, C)
@@ -154,7 +159,31 @@ class TrainEngine:
         drop = lambda rate, sid: ops.Drop(rate, m._rng_state, sid) if rate > 0 else ops.NO_DROP  # noqa: E731
         tab = m.item_embs.lookup_table
         tab_c = m.compute(tab)
-        ops.rng_advance(m._rng_state)
+        # ---- side stream: launches that depend on the weights only (weight packs, the L2 term) start with the step and
+        # run under the encoder / QKVT projection: few-microsecond kernels that would otherwise sit in the critical path,
+        # each behind a full launch.  (Small kernels next to the one-workgroup-per-CU kernels — block tail, scoring — is what
+        # NOT to do: the fat workgroups cannot be placed while small ones hold registers of a CU; measured 84 -> 247 us.)
+        main, side = torch.cuda.current_stream(), self.side
+        sst = side.cuda_stream
+        side.wait_stream(main)
+        aux_written, tpp_joined = False, False
+        with torch.cuda.stream(side):
+            for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
+                att = blk.attention
+                check(lib.edgl_bimau_pack(_ptr(att.st_kernel), _ptr(att.st_bias), _ptr(att.weight), _ptr(att.scaling), C, H, E,
+                                          _ptr(b["pack"]), code, sst), "edgl_bimau_pack")
+                if self.fused_tail:
+                    check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
+                                             _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
+                                             _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
+            ev_pack = side.record_event()
+            if m.l2_reg != 0.0:
+                check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss_aux), 0,
+                                       _ptr(self.ws_l2), sst), "edgl_l2_loss")
+                aux_written = True
+        # dropout step counter, Adam step counter and learning rate of this step: one single-thread launch
+        check(lib.edgl_step_begin(_ptr(m._rng_state), _ptr(m._adam_state), float(m.learning_rate), 0.9, 0.999, st),
+              "edgl_step_begin")
         # ================= forward (EasyDGL.py:70-151) =================
         d0 = drop(hd, 1)
         check(lib.edgl_encode_fwd(_ptr(self.ids), _ptr(self.ts), _ptr(tab_c), _ptr(m.pcoding.pembs.lookup_table),
@@ -165,18 +194,24 @@ class TrainEngine:
         for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
             att = blk.attention
             self._dense_fwd(x, att.dense_kernel, att.dense_bias, b["qkvt"], cin, 4 * C)
-            check(lib.edgl_bimau_pack(_ptr(att.st_kernel), _ptr(att.st_bias), _ptr(att.weight), _ptr(att.scaling), C, H, E,
-                                      _ptr(b["pack"]), code, st), "edgl_bimau_pack")
+            if i == 0:
+                main.wait_event(ev_pack)
             da = drop(ad, 10 + 4 * i)
             check(lib.edgl_bimau_fwd(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
                                      _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
                                      _ptr(b["lam"]), _ptr(b["saved"]), 0, code, st), "edgl_bimau_fwd")
+            if m.ct_reg != 0.0:   # TPP regulariser of this block: loss term and d lambda (one small launch pair)
+                if not tpp_joined:   # the L2 term of the side stream is accumulated into the same scalar
+                    main.wait_stream(side)
+                    tpp_joined = True
+                check(lib.edgl_tpp_fwd_bwd(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
+                                           _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
+                                           _ptr(self.loss_aux), 1 if aux_written else 0, _ptr(b["dlam"]), st),
+                      "edgl_tpp_fwd_bwd")
+                aux_written = True
             if self.fused_tail:
                 last = i == len(self.blk) - 1
                 pk = self.tail_pack[i]
-                check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
-                                         _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C, _ptr(pk), st),
-                      "edgl_tail_pack")
                 dh1 = drop(hd, 11 + 4 * i)
                 check(lib.edgl_tail_fwd(_ptr(b["att"]), x.data_ptr(), cin, _ptr(pk), _ptr(blk.att_out.bias), _ptr(blk.inter.bias),
                                         _ptr(blk.out.bias), _ptr(m.transform.bias), _ptr(blk.att_ln.gamma), _ptr(blk.att_ln.beta),
@@ -192,6 +227,8 @@ class TrainEngine:
                 self._dense_fwd(b["f"], blk.out.kernel, blk.out.bias, b["o"], 2 * C, C)
                 self._ln_fwd(b["o"], b["a1"], C, blk.out_ln, drop(hd, 12 + 4 * i), b["y"], b["st2"])
             x, cin = b["y"], C
+        if not self.blk:
+            main.wait_event(ev_pack)
         if not (self.fused_tail and self.blk):
             self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, C, C, gelu=True, pre=self.pre_t)
             self._ln_fwd(self.so, None, 0, m.transform_ln, ops.NO_DROP, self.hrows, self.st3, gpos=self.mpos)
@@ -207,20 +244,12 @@ class TrainEngine:
             check(lib.edgl_score_lse_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
                                          _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
                   "edgl_score_lse_fwd")
-        check(lib.edgl_ce_loss_fwd(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef), st),
-              "edgl_ce_loss_fwd")
-        if m.l2_reg != 0.0:
-            check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss), 1,
-                                   _ptr(self.ws), st), "edgl_l2_loss")
-        if m.ct_reg != 0.0:
-            coef = m.ct_reg / H
-            for b in self.blk:
-                check(lib.edgl_tpp_fwd(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
-                                       _ptr(m.mark_lookup_table), B, T, H, E, M, float(coef), _ptr(b["tpp"]), _ptr(self.loss),
-                                       1, st), "edgl_tpp_fwd")
-                check(lib.edgl_tpp_bwd(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
-                                       _ptr(m.mark_lookup_table), B, T, H, E, M, float(coef), _ptr(b["tpp"]), None,
-                                       _ptr(b["dlam"]), st), "edgl_tpp_bwd")
+        has_aux = m.l2_reg != 0.0 or (m.ct_reg != 0.0 and len(self.blk) > 0)
+        check(lib.edgl_ce_loss_fwd(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss_ce if has_aux else self.loss),
+                                   _ptr(self.coef), st), "edgl_ce_loss_fwd")
+        main.wait_stream(side)   # join: loss terms and d lambda of the side stream
+        if has_aux:
+            torch.add(self.loss_ce, self.loss_aux, out=self.loss)
         # ================= backward =================
         self._ws_i = 0
         check(lib.edgl_reduce_defer(1, st), "edgl_reduce_defer")
@@ -326,8 +355,10 @@ class TrainEngine:
 
     def _optimizer(self):
         m = self.m
-        ops.adam_step(m._arena, m._grad_arena, m._adam_m, m._adam_v, m.learning_rate, m._adam_state, m.l2_reg,
-                      self.l2_seg if m.l2_reg != 0.0 else None, m._shadow)
+        seg = self.l2_seg if m.l2_reg != 0.0 else None
+        check(lib.edgl_adam_apply(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,
+                                  0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg),
+                                  0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _stream()), "edgl_adam_apply")
 
     # ---- public API --------------------------------------------------------------------------------------------------------
     def load_batch(self, features: Dict[str, torch.Tensor], labels: torch.Tensor) -> None:

@@ -301,6 +301,13 @@ int edgl_tpp_fwd(const float* lam, const int64_t* masked_pos, const int64_t* lab
 int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                  const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef,
                  const float* sums, const float* gscale, float* d_lam, void* stream);
+/* edgl_tpp_fwd + edgl_tpp_bwd as one call (three small launches instead of four + a memset): reg_out (+)= regulariser, sums[0..2] as edgl_tpp_fwd, and (d_lam != NULL) the
+ * FULL gradient d_lam[H*B*T, E] — zero rows where the position is not masked (no memset needed), contributions of repeated
+ * masked positions summed.  sums: edgl_tpp_workspace() floats; sums[4] must be zero before the first call (integer normaliser
+ * accumulator; left zero). */
+int edgl_tpp_fwd_bwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                     const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
+                     float* reg_out, int accumulate, float* d_lam, void* stream);
 
 /* ---- optimizer — tf.train.AdamOptimizer (Base.py:142-144) over a flat f32 arena ----------------
  * step_state: device uint64[2]: [0] = step count (incremented by this call, so the first call is
@@ -310,6 +317,12 @@ int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const int64_t* lab
 int edgl_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr, float beta1,
                    float beta2, float eps, uint64_t* step_state, float l2, const int64_t* seg, int nseg,
                    void* shadow, void* stream);
+/* Training-step form of the two state updates: edgl_step_begin = edgl_rng_advance + the step / learning-rate half of
+ * edgl_adam_step in ONE single-thread launch at the start of the step; edgl_adam_apply = the parameter-update half (reads
+ * the learning rate edgl_step_begin left in step_state). */
+int edgl_step_begin(uint64_t* rng_state, uint64_t* adam_state, float lr, float beta1, float beta2, void* stream);
+int edgl_adam_apply(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
+                    const uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, void* stream);
 /* l2 part of the loss: out[0] (+)= 0.5*l2*sum(w[seg]^2)  (EasyDGL.py:158); workspace >= 1024 floats. */
 int edgl_l2_loss(const float* param, const int64_t* seg, int nseg, float l2, float* out, int accumulate,
                  float* workspace, void* stream);

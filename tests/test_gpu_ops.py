@@ -499,6 +499,44 @@ def test_tpp_regulariser_fwd_bwd():
     assert_close(lam.grad.cpu().numpy(), lr.grad.numpy(), 1e-5, "tpp dlam")
 
 
+@pytest.mark.parametrize("repeat", [False, True])
+def test_tpp_fused_launch_matches_the_reference(repeat):
+    """edgl_tpp_fwd_bwd (regulariser, its sums and the FULL d lambda in one launch, the engine's form) against the fp64 oracle:
+    rows of unmasked positions are zero without a memset, and a masked position that occurs twice in a sample (padding
+    slots repeat position 0) receives the SUM of its slots' gradients — the gradient of tf.gather (EasyDGL.py:157-175)."""
+    from easydgl_amd import _lib
+    lib = _lib.lib
+    rng = np.random.default_rng(12)
+    B, T, H, E, M, NI = 6, 21, 3, 5, 4, 40
+    lam = torch.tensor(rng.uniform(0.2, 2.0, size=(H * B, T, E)), dtype=torch.float32).cuda()
+    mpn = np.stack([rng.choice(T - 1, M, replace=False) + 1 for _ in range(B)])
+    labels = rng.integers(1, NI, size=(B, M)); labels[0, 0] = 0
+    if repeat:
+        mpn[1, 2] = mpn[1, 0]          # the same position twice, two different labels
+        mpn[2, 3] = mpn[2, 1]; labels[2, 3] = 0   # ... and once as a zero-weight padding slot
+    mp = torch.tensor(mpn).cuda()
+    ts = np.cumsum(rng.exponential(40.0, size=(B, T)), axis=1).astype(np.float32) + 9.5e8
+    mt = O.synthetic_mark_table(NI, E, multi_hot=True)
+    coef = 0.41
+    sums = torch.zeros(int(lib.edgl_tpp_workspace()), device="cuda")
+    reg = torch.full((1,), 3.0, device="cuda")
+    dlam = torch.full((H * B, T, E), float("nan"), device="cuda")
+    lab_t, ts_t, mt_t = torch.tensor(labels).cuda(), torch.tensor(ts).cuda(), torch.tensor(mt.astype(np.uint8)).cuda()
+    for _ in range(2):   # twice: the ticket of the last-workgroup reduction must come back to zero
+        reg.fill_(3.0)
+        _lib.check(lib.edgl_tpp_fwd_bwd(lam.data_ptr(), mp.data_ptr(), lab_t.data_ptr(), ts_t.data_ptr(), mt_t.data_ptr(), B, T, H, E,
+                                        M, coef, sums.data_ptr(), reg.data_ptr(), 1, dlam.data_ptr(), None), "edgl_tpp_fwd_bwd")
+    torch.cuda.synchronize()
+    lr = lam.double().cpu().requires_grad_()
+    sp = torch.tensor(O.spans_from_times(ts))[torch.arange(B)[:, None], mp.cpu()].repeat(H, 1)
+    nm = torch.tensor(mt[labels], dtype=torch.float64).repeat(H, 1, 1)
+    lg = lr[torch.arange(H * B)[:, None], mp.cpu().repeat(H, 1)]
+    ref = coef * R.biased_likelihood(lg, nm, sp)
+    ref.backward()
+    assert_close(reg.item() - 3.0, ref.item(), 1e-5, "tpp reg (accumulated)")
+    assert_close(dlam.cpu().numpy(), lr.grad.numpy(), 1e-5, "tpp dlam (dense)")
+
+
 def test_adam_matches_tf_form():
     o = ops()
     rng = np.random.default_rng(6)

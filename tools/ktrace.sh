@@ -7,4 +7,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT" -o k -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras "$@" > "$OUT/log.txt" 2>&1
 python $ROOT/tools/kstats.py "$OUT/k_results.db" 25 | cut -c1-150 | head -${KT_LINES:-28}
 grep -h '"metric"' "$OUT/log.txt" | cut -c1-260
+if [ -n "$KT_TIMELINE" ]; then python $ROOT/tools/ktimeline.py "$OUT/k_results.db" "$KT_TIMELINE"; fi
 rm -f "$OUT/k_results.db"
