@@ -76,19 +76,29 @@ __device__ __forceinline__ void copy_out(bf16* dst, long ld, const bf16* src, in
 }
 
 // acc[rt] += W^T[n-tile rows][k0 .. k0 + 32*NKB) . X[rows of tile rt][same k]   (WT row stride ldw, X image stride LD)
+// The weight fragments of a wave's 16 output channels (global, L2-resident) are fetched ahead of the product that uses
+// them — one product early, under the epilogue / LayerNorm / copy-out of the previous step — so that no product of the
+// chain opens with an L2 round trip (8 waves per CU: nothing else would hide it).
+template <int NKB>
+struct WFrags { Vec16<bf16> w[NKB]; };
+template <int NKB>
+__device__ __forceinline__ WFrags<NKB> load_wfrags(const bf16* WTrows, int ldw, int lane) {
+    const int l15 = lane & 15, kg = (lane >> 4) * 8;
+    WFrags<NKB> f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) f.w[kb] = ld16<bf16>(WTrows + (long)l15 * ldw + kb * 32 + kg);
+    return f;
+}
 template <int CT, int NKB>
-__device__ __forceinline__ void tile_gemm(const bf16* WTrows, int ldw, const bf16* Xs, int nrt, int lane, f32x4 (&acc)[MAXRT]) {
+__device__ __forceinline__ void tile_gemm(const WFrags<NKB>& wf, const bf16* Xs, int nrt, int lane, f32x4 (&acc)[MAXRT]) {
     using G = TailGeom<CT>;
     const int l15 = lane & 15, kg = (lane >> 4) * 8;
-    Vec16<bf16> wf[NKB];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) wf[kb] = ld16<bf16>(WTrows + (long)l15 * ldw + kb * 32 + kg);
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) {
         if (rt < nrt) {
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
-                acc[rt] = mma_kblock(wf[kb], ld16<bf16>(Xs + (rt * 16 + l15) * G::LD + kb * 32 + kg), acc[rt]);
+                acc[rt] = mma_kblock(wf.w[kb], ld16<bf16>(Xs + (rt * 16 + l15) * G::LD + kb * 32 + kg), acc[rt]);
         }
         // at most two row tiles' operand reads in flight: unbounded, the scheduler hoists all 7 x NKB LDS reads (112+
         // registers) above the first MFMA
@@ -160,6 +170,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
 
     PH_DECL
+    WFrags<NKB> wf = load_wfrags<NKB>(p.WoT + (long)n0 * C, C, lane);
     copy_in<CT>(bufA, p.att + row0 * C, C, T);
     copy_in<CT>(bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
     lds_barrier();
@@ -170,7 +181,9 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
         f32x4 acc[MAXRT];
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        tile_gemm<CT, NKB>(p.WoT + (long)n0 * C, C, bufA, nrt, lane, acc);
+        tile_gemm<CT, NKB>(wf, bufA, nrt, lane, acc);
+        wf = load_wfrags<NKB>(p.WiT + (long)n0 * C, C, lane);   // first half of the inner dense
+        EDGL_PIN();   // issued here, not sunk to their use
         const float4 bb = *reinterpret_cast<const float4*>(p.bo + nl);
         const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
@@ -220,7 +233,9 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
             f32x4 acc[MAXRT];
 #pragma unroll
             for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            tile_gemm<CT, NKB>(p.WiT + (long)(h * C + n0) * C, C, bufB, nrt, lane, acc);
+            tile_gemm<CT, NKB>(wf, bufB, nrt, lane, acc);
+            wf = load_wfrags<NKB>(p.WoutT + (long)n0 * 2 * C + h * C, 2 * C, lane);
+            EDGL_PIN();
             const float4 bb = *reinterpret_cast<const float4*>(p.bi + h * C + nl);
             const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
@@ -239,7 +254,10 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
         lds_barrier();
         copy_out<CT>(p.pre_f + row0 * 2 * C + h * C, 2 * C, bufS, T);
         copy_out<CT>(p.f + row0 * 2 * C + h * C, 2 * C, bufC, T);
-        tile_gemm<CT, NKB>(p.WoutT + (long)n0 * 2 * C + h * C, 2 * C, bufC, nrt, lane, acc3);
+        tile_gemm<CT, NKB>(wf, bufC, nrt, lane, acc3);
+        // next: second half of the inner dense, then the head transform (fetched even when this block has no head: cheap)
+        wf = h == 0 ? load_wfrags<NKB>(p.WiT + (long)(C + n0) * C, C, lane) : load_wfrags<NKB>(p.WtT + (long)n0 * C, C, lane);
+        EDGL_PIN();
         lds_barrier();
         PH_MARK(6);   // barrier + copy_out(pre_f, f) + G3 half + barrier
     }
@@ -290,7 +308,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
         f32x4 acc[MAXRT];
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        tile_gemm<CT, NKB>(p.WtT + (long)n0 * C, C, bufA, nrt, lane, acc);
+        tile_gemm<CT, NKB>(wf, bufA, nrt, lane, acc);
         const float4 bb = *reinterpret_cast<const float4*>(p.bt + nl);
         const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
@@ -362,8 +380,8 @@ struct TailBwdP {
 // dX tile: acc[rt] += W[k-tile rows][n0 .. n0 + 32*NKB) . G[rows of tile rt][same n]   (W row stride ldw; G image stride LD)
 // — the same MFMA pattern as tile_gemm with the [in, out] kernel as the A operand
 template <int CT, int NKB>
-__device__ __forceinline__ void tile_dx(const bf16* Wrows, int ldw, const bf16* Gs, int nrt, int lane, f32x4 (&acc)[MAXRT]) {
-    tile_gemm<CT, NKB>(Wrows, ldw, Gs, nrt, lane, acc);
+__device__ __forceinline__ void tile_dx(const WFrags<NKB>& wf, const bf16* Gs, int nrt, int lane, f32x4 (&acc)[MAXRT]) {
+    tile_gemm<CT, NKB>(wf, Gs, nrt, lane, acc);
 }
 
 // LayerNorm backward on registers: z = LN input sum, dy = upstream gradient; returns d(sum) in dz and writes the
@@ -422,6 +440,8 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     const long row0 = (long)b * T;
     const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
     float z[MAXRT][4], dy[MAXRT][4], dz[MAXRT][4];
+    // weight fragments of the next product, fetched one product ahead (see load_wfrags)
+    WFrags<NKB> wf = p.head ? load_wfrags<NKB>(p.Wt + (long)n0 * C, C, lane) : load_wfrags<NKB>(p.Wout + (long)n0 * C, C, lane);
 
     if (p.head) {
         // ---- LN3' on the gathered rows, GELU' -> d_pre_t (EasyDGL.py:136-146 backward) ------------------------------------
@@ -475,7 +495,8 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         f32x4 acc[MAXRT];
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        tile_dx<CT, NKB>(p.Wt + (long)n0 * C, C, bufC, nrt, lane, acc);
+        tile_dx<CT, NKB>(wf, bufC, nrt, lane, acc);
+        wf = load_wfrags<NKB>(p.Wout + (long)n0 * C, C, lane);
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
 #pragma unroll
@@ -531,7 +552,8 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
             f32x4 acc[MAXRT];
 #pragma unroll
             for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            tile_dx<CT, NKB>(p.Wout + (long)(h * C + n0) * C, C, bufC, nrt, lane, acc);
+            tile_dx<CT, NKB>(wf, bufC, nrt, lane, acc);
+            wf = load_wfrags<NKB>(p.Wi + (long)n0 * 2 * C + h * C, 2 * C, lane);
             lds_barrier();   // pre_f half in place (and, for h = 1, every wave past its reads of the previous d_pre_f half)
 #pragma unroll
             for (int rt = 0; rt < MAXRT; ++rt)
@@ -547,7 +569,8 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         }
         lds_barrier();
         copy_out<CT>(p.d_pre_f + row0 * 2 * C + h * C, 2 * C, bufB, T);
-        tile_dx<CT, NKB>(p.Wi + (long)n0 * 2 * C + h * C, 2 * C, bufB, nrt, lane, acc6);
+        tile_dx<CT, NKB>(wf, bufB, nrt, lane, acc6);
+        wf = h == 0 ? load_wfrags<NKB>(p.Wout + (long)(C + n0) * C, C, lane) : load_wfrags<NKB>(p.Wo + (long)n0 * C, C, lane);
         lds_barrier();
     }
 #pragma unroll
@@ -593,7 +616,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         f32x4 acc[MAXRT];
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        tile_dx<CT, NKB>(p.Wo + (long)n0 * C, C, bufC, nrt, lane, acc);
+        tile_dx<CT, NKB>(wf, bufC, nrt, lane, acc);
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
             if (rt < nrt) {

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
-DOMINANT = "score_bwd_kernelIDF16bLi8ELi0ELi8E"   # score_bwd_kernel<bf16, C/16 = 8, ROLE_Y, 8 waves>
+DOMINANT = "score_bwd_kernelIDF16bLi8ELi2ELi8E"   # score_bwd_kernel<bf16, C/16 = 8, ROLE_YF (flash), 8 waves>
 
 
 def kernel_stats(db_path, steps):
@@ -61,7 +61,7 @@ def main():
         f.write("\n".join(lines) + "\n")
     if dom:
         with open(os.path.join(prof, f"{tag}_dominant_kernel_traffic.json"), "w") as f:
-            json.dump({"kernel": "score_bwd_kernel<bf16,8,ROLE_Y>", "fetch_size_kib": round(dom[1], 1),
+            json.dump({"kernel": "score_bwd_kernel<bf16,8,ROLE_YF>", "fetch_size_kib": round(dom[1], 1),
                        "write_size_kib": round(dom[2], 1),
                        "hbm_bytes_per_launch": int(2 * dom[1] * 1024 + dom[2] * 1024),
                        "note": "separate --pmc passes; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE correction)"},
