@@ -196,29 +196,58 @@ constexpr int SROWS = 128;
 template <typename T>
 __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
     extern __shared__ float acc[];  // [SROWS][C]
-    __shared__ int s_id[SROWS];
+    __shared__ __attribute__((aligned(16))) int s_id[SROWS];
     __shared__ int s_lead[SROWS];
     const int SR = p.srows;
     const long rows = (long)p.B * p.T, r0 = (long)blockIdx.x * SR;
     const int tid = threadIdx.x;
     if (tid < SR) s_id[tid] = (r0 + tid < rows) ? (int)p.ids[r0 + tid] : 0;
+    if (tid >= SR && tid < SROWS) s_id[tid] = -1;   // the leader search reads whole int4 groups
+    const int cpr = p.C / 4, rows_par = 256 / cpr;
+    const int cv = tid % cpr, rl = tid / cpr, c0 = cv * 4;
+    // this thread's rows (rl, rl + rows_par, ...): all gradient fragments are fetched up front, rows clamped — a load
+    // inside the per-row loop costs one HBM round trip per row (16 of them at C = 128)
+    constexpr int MAXR = 16;
+    Frag4<T> g[MAXR];
+    const bool worker = tid < rows_par * cpr;
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+        const long row = min(r0 + rl + (long)k * rows_par, rows - 1);
+        g[k] = frag_ld<T>(reinterpret_cast<const T*>(p.dx0) + row * 3 * p.C + c0);
+    }
     for (int i = tid; i < SR * p.C; i += 256) acc[i] = 0.f;
     __syncthreads();
     if (tid < SR) {
+        // leader = first row of the block with the same id: branch-free scan over int4 groups (a per-element scan with an
+        // early exit is a chain of up to 127 dependent LDS reads)
         const int id = s_id[tid];
         int lead = tid;
-        for (int j = 0; j < tid; ++j)
-            if (s_id[j] == id) { lead = j; break; }
+        for (int j4 = (tid >> 2); j4 >= 0; --j4) {
+            const int4 v = *reinterpret_cast<const int4*>(s_id + 4 * j4);
+            const int j = 4 * j4;
+            if (v.w == id && j + 3 < tid) lead = j + 3;
+            if (v.z == id && j + 2 < tid) lead = j + 2;
+            if (v.y == id && j + 1 < tid) lead = j + 1;
+            if (v.x == id && j < tid) lead = j;
+        }
         s_lead[tid] = lead;
     }
     __syncthreads();
-    const int cpr = p.C / 4, rows_par = 256 / cpr;
-    const int cv = tid % cpr, rl = tid / cpr, c0 = cv * 4;
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const float sq = sqrtf((float)p.C);
-    if (tid < rows_par * cpr)
-        for (int r = rl; r < SR; r += rows_par) {
-            if (s_id[r] == 0) continue;  // padding rows and rows past the end
+    if (worker) {
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) {
+            const int r = rl + k * rows_par;
+            if (r >= SR || s_id[r] == 0) continue;  // padding rows and rows past the end
+            const long row = r0 + r;
+            float* dst = acc + s_lead[r] * p.C + c0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                atomicAdd(dst + j, sq * drop_apply(dk, (uint64_t)row * 3 * p.C + c0 + j, to_f32(g[k].v[j])));
+        }
+        for (int r = rl + MAXR * rows_par; r < SR; r += rows_par) {   // (C < 128: more than MAXR rows per thread)
+            if (s_id[r] == 0) continue;
             const long row = r0 + r;
             const Frag4<T> g0 = frag_ld<T>(reinterpret_cast<const T*>(p.dx0) + row * 3 * p.C + c0);
             float* dst = acc + s_lead[r] * p.C + c0;
@@ -226,6 +255,7 @@ __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
             for (int j = 0; j < 4; ++j)
                 atomicAdd(dst + j, sq * drop_apply(dk, (uint64_t)row * 3 * p.C + c0 + j, to_f32(g0.v[j])));
         }
+    }
     __syncthreads();
     for (int i = tid; i < SR * p.C; i += 256) {
         const int r = i / p.C, c = i % p.C;
