@@ -404,8 +404,10 @@ struct RedBatch { RedJob j[RED_MAX_JOBS]; int n, blocks; };
 thread_local bool g_red_defer = false;
 thread_local RedBatch g_red_batch = {};
 
-__global__ __launch_bounds__(256) void reduce_rows_multi_kernel(RedBatch b) {
-    __shared__ float sm[8][33];
+// 32 columns x 32 partial-row lanes per workgroup: the deepest jobs (1616 partial rows of the mark-embedding gradient) were a
+// chain of 50 dependent loads per thread with 8 row lanes; the job list is otherwise made of 24-64 row jobs
+__global__ __launch_bounds__(1024) void reduce_rows_multi_kernel(RedBatch b) {
+    __shared__ float sm[32][33];
     int ji = 0;
     for (int i = 1; i < b.n; ++i)
         if ((int)blockIdx.x >= b.j[i].blk0) ji = i;
@@ -418,27 +420,27 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_kernel(RedBatch b) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (n < N) {
         int p = ty;
-        for (; p + 24 < P; p += 32) {
+        for (; p + 96 < P; p += 128) {
             a0 += part[(long)p * ld + n];
-            a1 += part[(long)(p + 8) * ld + n];
-            a2 += part[(long)(p + 16) * ld + n];
-            a3 += part[(long)(p + 24) * ld + n];
+            a1 += part[(long)(p + 32) * ld + n];
+            a2 += part[(long)(p + 64) * ld + n];
+            a3 += part[(long)(p + 96) * ld + n];
         }
-        for (; p < P; p += 8) a0 += part[(long)p * ld + n];
+        for (; p < P; p += 32) a0 += part[(long)p * ld + n];
     }
     sm[ty][tx] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (ty == 0 && n < N) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += sm[i][tx];
+        for (int i = 0; i < 32; ++i) s += sm[i][tx];
         jb.out[n] = s;
     }
 }
 
 int edgl_reduce_flush_impl(hipStream_t st) {
     if (g_red_batch.n == 0) return EDGL_OK;
-    hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3(g_red_batch.blocks), dim3(256), 0, st, g_red_batch);
+    hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3(g_red_batch.blocks), dim3(1024), 0, st, g_red_batch);
     g_red_batch.n = 0;
     g_red_batch.blocks = 0;
     EDGL_LAUNCH_CHECK();

@@ -260,7 +260,8 @@ class TrainEngine:
             lib.edgl_reduce_defer(-1, st)
             lib.edgl_gemm_dw_defer(-1, st)
             raise
-        check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")   # runs every queued reduction in one launch
+        check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")   # runs the remaining queued reductions in one launch
+        torch.cuda.current_stream().wait_stream(self.side)
 
     def _issue_backward(self, st, drop, tab, tab_c, lab):
         m = self.m
@@ -340,6 +341,11 @@ class TrainEngine:
                 check(lib.edgl_gemm_dw_defer(0, st), "edgl_gemm_dw_defer")
             d_in = self.G3c if i == 0 else self.G3
             self._dense_dx(self.G4c, att.dense_kernel, d_in, cin, 4 * C)
+            if i == 0:
+                # every slab reduction queued so far (weight-gradient GEMMs, BiMAU / LayerNorm partials) runs on the side
+                # stream under the embedding backward, whose atomics leave the CUs mostly idle
+                self.side.wait_stream(torch.cuda.current_stream())
+                check(lib.edgl_reduce_flush(self.side.cuda_stream), "edgl_reduce_flush")
             # both residual branches feed the first C channels of the block input (temporal.py:447, EasyDGL.py:116)
             check(lib.edgl_add_cols(_ptr(d_in), cin, _ptr(self.G1), _ptr(self.G2), C, self.rows, C, code, st), "edgl_add_cols")
             if i > 0:  # next (earlier) block consumes d_in as its dY; keep it out of the scratch set it will overwrite
