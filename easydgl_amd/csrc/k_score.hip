@@ -76,6 +76,7 @@ struct ScoreP {
     int zchunk, nchunk;                                 // z vectors per block (multiple of ZB), #chunks
     const float* coef; const float* gscale;             // bwd
     float* slabs; float* bias_slabs;
+    float* lab_out;                                     // flash forward: label logits [R]
     int dbg;   // EDGL_DBG ablation bits (profiling only): 1 skip dl math, 2 skip second product, 4 skip z streaming, 8 skip logit MFMA
 };
 
@@ -323,6 +324,39 @@ __global__ void lse_combine_kernel(const float* part, int R, const int32_t* nval
         if (pm > -INFINITY) s += part[((long)m * nchunk + c) * 2 + 1] * __expf(pm - mx);
     }
     row_lse[m] = mx + __logf(s);
+}
+
+// lse_combine_kernel + label_logit_kernel in one launch (flash form): one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void lse_label_kernel(const float* part, int R, const int32_t* nvalid, int xb, int zb, int G, int ztotal,
+                                                        float* row_lse, const T* rows, const T* table, const float* out_bias,
+                                                        const int64_t* labels, int C, int i0, int i1, float* lab_out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const int Reff = nvalid ? min(R, nvalid[0]) : R;
+    const int64_t lab = labels[r];
+    float a = 0.f;
+    if (lab != 0 && lab >= i0 && lab < i1)
+        for (int c = lane; c < C; c += 64) a += to_f32(rows[(long)r * C + c]) * to_f32(table[lab * C + c]);
+    float lse = 0.f;
+    if (r < Reff) {
+        const int nchunk = dev_plan(Reff, xb, G, ztotal, zb).nchunk;
+        float mx = -INFINITY;
+        for (int c = lane; c < nchunk; c += 64) mx = fmaxf(mx, part[((long)r * nchunk + c) * 2]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float s = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            const float pm = part[((long)r * nchunk + c) * 2];
+            if (pm > -INFINITY) s += part[((long)r * nchunk + c) * 2 + 1] * __expf(pm - mx);
+        }
+        s = wave_sum(s);
+        lse = mx + __logf(s);
+    }
+    a = wave_sum(a);
+    if (lane == 0) {
+        row_lse[r] = lse;
+        if (lab >= i0 && lab < i1) lab_out[r] = (lab == 0) ? -1000.0f : a + out_bias[lab - 1];
+    }
 }
 
 // label logit: one wave per row (a [R] gather-dot; keeps the label test out of the MFMA epilogue)
@@ -645,15 +679,20 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     }
 }
 
-// out[i] = (T) sum_s slabs[s][i]; `zero_first` elements at the front are forced to 0 (table row 0)
+// out[i] = (T) sum_s slabs[s][i]; `zero_first` elements at the front are forced to 0 (table row 0).  A second job (the bias
+// gradient next to the table gradient) rides in the same launch: workgroups [nb0, gridDim.x) belong to it.
+struct SlabJob { const float* slabs; long n, lo, hi, zero_first; void* out; };
 template <typename TO>
-__global__ void slab_reduce_kernel(const float* slabs, int nslab, long n, long lo, long hi, long zero_first,
-                                   const float* gscale, TO* out) {
+__global__ void slab_reduce_kernel(SlabJob j0, SlabJob j1, int nb0, int nslab, const float* gscale) {
     const float gs = gscale ? gscale[0] : 1.0f;   // upstream d(loss) scalar
-    for (long i = lo + (long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long)gridDim.x * blockDim.x) {
+    const bool first = (int)blockIdx.x < nb0;
+    const SlabJob& j = first ? j0 : j1;
+    const long bid = first ? blockIdx.x : blockIdx.x - nb0, nblk = first ? nb0 : (long)gridDim.x - nb0;
+    TO* out = reinterpret_cast<TO*>(j.out);
+    for (long i = j.lo + bid * blockDim.x + threadIdx.x; i < j.hi; i += nblk * blockDim.x) {
         float a = 0.f;
-        for (int s = 0; s < nslab; ++s) a += slabs[(long)s * n + i];
-        out[i] = from_f32<TO>(i < zero_first ? 0.f : a * gs);
+        for (int s = 0; s < nslab; ++s) a += j.slabs[(long)s * j.n + i];
+        out[i] = from_f32<TO>(i < j.zero_first ? 0.f : a * gs);
     }
 }
 
@@ -754,11 +793,17 @@ __global__ void scatter_rows_kernel(const T* rows_c, const int32_t* inv, int R, 
     }
 }
 
-// [rows, C] -> [C, ld] transposed copy (operand images for the second MFMA product)
+// [rows, C] -> [C, ld] transposed copy (operand images for the second MFMA product).  Two matrices per launch (the compacted
+// rows and the item table): blocks [0, nbx0) of the x grid belong to the first.
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* src, long rows, int C, T* dst, long ld) {
+__global__ __launch_bounds__(256) void transpose_kernel(const T* src0, long rows0, T* dst0, long ld0, int nbx0, const T* src1, long rows1,
+                                                        T* dst1, long ld1, int C) {
     __shared__ T tile[64][65];
-    const long r0 = (long)blockIdx.x * 64;
+    const bool first = (int)blockIdx.x < nbx0;
+    const T* src = first ? src0 : src1;
+    T* dst = first ? dst0 : dst1;
+    const long rows = first ? rows0 : rows1, ld = first ? ld0 : ld1;
+    const long r0 = (long)((int)blockIdx.x - (first ? 0 : nbx0)) * 64;
     const int c0 = blockIdx.y * 64;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int r = i / 64, c = i % 64;
@@ -775,7 +820,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* src, long rows,
 // CE loss from (lse, label logit) — EasyDGL.py:155,177-185
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
-                                                       float* loss_out, float* coef) {
+                                                       float* loss_out, float* coef, const float* add_in) {
     // one workgroup; a thread keeps up to CE_KEEP of its rows' probabilities in registers between the two passes (the loads of
     // a pass are independent, so they overlap instead of paying one memory round trip per row)
     constexpr int CE_KEEP = 16;
@@ -799,7 +844,7 @@ __global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, con
     num = block_sum(num, red);
     den = block_sum(den, red);
     const float W = den + 1e-5f;
-    if (threadIdx.x == 0) loss_out[0] = num / W;
+    if (threadIdx.x == 0) loss_out[0] = num / W + (add_in ? add_in[0] : 0.f);   // + the regularisation terms of the step, if given
 #pragma unroll
     for (int i = 0; i < CE_KEEP; ++i) {
         const int m = threadIdx.x + i * 1024;
@@ -1061,11 +1106,10 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     T* tableT = reinterpret_cast<T*>(ws + plan.off_tableT);
     p.ldr = (int)up8(p.R); p.ldt = (int)up8(p.I);
     if (MODE != 2) {
-        hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)((p.ldr + 63) / 64), (p.C + 63) / 64), dim3(256), 0, st,
-                           reinterpret_cast<const T*>(p.rows), (long)p.R, p.C, rowsT, (long)p.ldr);
-        EDGL_LAUNCH_CHECK();
-        hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)((p.ldt + 63) / 64), (p.C + 63) / 64), dim3(256), 0, st,
-                           reinterpret_cast<const T*>(p.table), (long)p.I, p.C, tableT, (long)p.ldt);
+        const int nbx0 = (p.ldr + 63) / 64, nbx1 = (p.ldt + 63) / 64;
+        hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)(nbx0 + nbx1), (p.C + 63) / 64), dim3(256), 0, st,
+                           reinterpret_cast<const T*>(p.rows), (long)p.R, rowsT, (long)p.ldr, nbx0,
+                           reinterpret_cast<const T*>(p.table), (long)p.I, tableT, (long)p.ldt, p.C);
         EDGL_LAUNCH_CHECK();
     }
     p.rowsT = rowsT; p.tableT = tableT;
@@ -1099,8 +1143,9 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
                            ws + plan.off_slabY, p.nvalid, p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
         EDGL_LAUNCH_CHECK();
     } else if (MODE == 1) {
-        hipLaunchKernelGGL(lse_combine_kernel, dim3((p.R + 255) / 256), dim3(256), 0, st, part, p.R, p.nvalid, xb, ZBK, G,
-                           p.i1 - p.i0, p.row_lse);
+        hipLaunchKernelGGL((lse_label_kernel<T>), dim3((p.R + 3) / 4), dim3(256), 0, st, part, p.R, p.nvalid, xb, ZBK, G, p.i1 - p.i0,
+                           p.row_lse, reinterpret_cast<const T*>(p.rows), reinterpret_cast<const T*>(p.table), p.out_bias, p.labels,
+                           p.C, p.i0, p.i1, p.lab_out);
         EDGL_LAUNCH_CHECK();
         return EDGL_OK;
     } else {
@@ -1124,15 +1169,12 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
         }
         EDGL_LAUNCH_CHECK();
         const long n = (long)p.I * p.C, lo = (long)p.i0 * p.C, hi = (long)p.i1 * p.C;
-        hipLaunchKernelGGL((slab_reduce_kernel<float>), dim3((unsigned)std::min<long>((hi - lo + 255) / 256, 2048)), dim3(256), 0,
-                           st, q.slabs, q.nchunk, n, lo, hi, (long)p.C, p.gscale, d_table);
-        EDGL_LAUNCH_CHECK();
         const long nb = p.I - 1, blo = std::max(p.i0, 1) - 1, bhi = p.i1 - 1;
-        if (bhi > blo) {
-            hipLaunchKernelGGL((slab_reduce_kernel<float>), dim3((unsigned)std::min<long>((bhi - blo + 255) / 256, 2048)), dim3(256),
-                               0, st, q.bias_slabs, q.nchunk, nb, blo, bhi, 0L, p.gscale, d_bias);
-            EDGL_LAUNCH_CHECK();
-        }
+        const int nb0 = (int)std::min<long>((hi - lo + 255) / 256, 2048), nb1 = bhi > blo ? (int)std::min<long>((bhi - blo + 255) / 256, 256) : 0;
+        hipLaunchKernelGGL((slab_reduce_kernel<float>), dim3((unsigned)(nb0 + nb1)), dim3(256), 0, st,
+                           SlabJob{q.slabs, n, lo, hi, (long)p.C, d_table}, SlabJob{q.bias_slabs, nb, blo, bhi, 0L, d_bias}, nb0,
+                           q.nchunk, p.gscale);
+        EDGL_LAUNCH_CHECK();
     }
     return EDGL_OK;
 }
@@ -1246,12 +1288,17 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
     return EDGL_OK;
 }
 
-extern "C" int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
-                                float* loss_out, float* coef, void* stream) {
+extern "C" int edgl_ce_loss_fwd_add(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
+                                    float* coef, const float* add_in, void* stream) {
     EDGL_REQUIRE(row_lse && label_logit && labels && loss_out && coef, EDGL_ERR_NULL, "edgl_ce_loss_fwd: null pointer");
-    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_lse, label_logit, labels, R, loss_out, coef);
+    hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_lse, label_logit, labels, R, loss_out, coef,
+                       add_in);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
+}
+extern "C" int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
+                                float* loss_out, float* coef, void* stream) {
+    return edgl_ce_loss_fwd_add(row_lse, label_logit, labels, R, loss_out, coef, nullptr, stream);
 }
 
 extern "C" long edgl_score_bwd_workspace(int R, int C, int I, int n_items, int dtype) {
@@ -1299,15 +1346,9 @@ extern "C" int edgl_score_flash_fwd(const void* rows, const void* table, const f
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = row_lse;
     const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
     hipStream_t st = (hipStream_t)stream;
-    rc = dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
-                           : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);
-    if (rc) return rc;
-    if (dtype == EDGL_F32)
-        hipLaunchKernelGGL((label_logit_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, st, (const float*)rows, (const float*)table, out_bias, labels, R, C, i0, i1, label_logit);
-    else
-        hipLaunchKernelGGL((label_logit_kernel<bf16>), dim3((R + 3) / 4), dim3(256), 0, st, (const bf16*)rows, (const bf16*)table, out_bias, labels, R, C, i0, i1, label_logit);
-    EDGL_LAUNCH_CHECK();
-    return EDGL_OK;
+    p.lab_out = label_logit;   // row LSE and label logits come out of one small kernel behind the scoring pass
+    return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
+                             : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);
 }
 
 extern "C" int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,

@@ -80,8 +80,8 @@ class TrainEngine:
         self.nvalid = torch.zeros(1, device=dev, dtype=torch.int32)
         self.lse, self.lab_logit, self.coef = e(self.R, dtype=f32), e(self.R, dtype=f32), e(self.R, dtype=f32)
         self.loss = e(1, dtype=f32)
-        # cross-entropy term (main stream) and L2 + TPP terms (side stream); self.loss = their sum
-        self.loss_ce, self.loss_aux = e(1, dtype=f32), torch.zeros(1, device=dev, dtype=f32)
+        # L2 + TPP terms (accumulated before the cross-entropy kernel, which adds them to its own term)
+        self.loss_aux = torch.zeros(1, device=dev, dtype=f32)
         self.ws_l2 = e(1024, dtype=f32)
         self.side = torch.cuda.Stream(device=dev)
         # ---- backward temporaries -------------------------------------------------------------------------------
@@ -245,11 +245,9 @@ class TrainEngine:
                                          _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
                   "edgl_score_lse_fwd")
         has_aux = m.l2_reg != 0.0 or (m.ct_reg != 0.0 and len(self.blk) > 0)
-        check(lib.edgl_ce_loss_fwd(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss_ce if has_aux else self.loss),
-                                   _ptr(self.coef), st), "edgl_ce_loss_fwd")
-        main.wait_stream(side)   # join: loss terms and d lambda of the side stream
-        if has_aux:
-            torch.add(self.loss_ce, self.loss_aux, out=self.loss)
+        main.wait_stream(side)   # join: the L2 term of the side stream
+        check(lib.edgl_ce_loss_fwd_add(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef),
+                                       _ptr(self.loss_aux) if has_aux else None, st), "edgl_ce_loss_fwd_add")
         # ================= backward =================
         self._ws_i = 0
         check(lib.edgl_reduce_defer(1, st), "edgl_reduce_defer")
