@@ -34,6 +34,7 @@ SIGNATURES = {
     "edgl_encode_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I64, F, F, P, U32, P, P, P, I, P]),
     "edgl_encode_bwd_workspace": (L, [I, I, I]),
     "edgl_encode_bwd": (I, [P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
+    "edgl_encode_bwd_add": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
     "edgl_embed_pos_fwd": (I, [P, P, P, P, P, I, I, I, I, F, F, P, U32, P, P, P, I, P]),
     "edgl_embed_pos_bwd": (I, [P, P, I, I, I, I, F, P, U32, P, P, I, P]),
     "edgl_gemm": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, I, P]),

@@ -124,6 +124,7 @@ struct EncBwdP {
     int B, T, C, E, I; float rate; const uint64_t* rng; uint32_t stream_id;
     float* d_item; float* part_pos; float* part_mk; int nchunk;
     int srows;
+    const void* add1; const void* add2;   // optional [B*T, C] terms added to the item section of dX0 (residual branches)
     float* d_mark_zero;   // [E*C]: cleared by block (0, 0) of the position / mark stage (only row 1 is ever written afterwards)   // rows per block of the scatter stage (<= SROWS; fewer when SROWS*C floats exceed the LDS)
 };
 
@@ -210,11 +211,19 @@ __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
     constexpr int MAXR = 16;
     Frag4<T> g[MAXR];
     const bool worker = tid < rows_par * cpr;
+    // gradient of the item section: dX0[:, :C] (+ the two residual-branch terms of the first block, summed in f32)
+    auto item_grad = [&](long row) {
+        Frag4<T> v = frag_ld<T>(reinterpret_cast<const T*>(p.dx0) + row * 3 * p.C + c0);
+        if (p.add1) {
+            const Frag4<T> a = frag_ld<T>(reinterpret_cast<const T*>(p.add1) + row * p.C + c0);
+            const Frag4<T> b = frag_ld<T>(reinterpret_cast<const T*>(p.add2) + row * p.C + c0);
 #pragma unroll
-    for (int k = 0; k < MAXR; ++k) {
-        const long row = min(r0 + rl + (long)k * rows_par, rows - 1);
-        g[k] = frag_ld<T>(reinterpret_cast<const T*>(p.dx0) + row * 3 * p.C + c0);
-    }
+            for (int j = 0; j < 4; ++j) v.v[j] = from_f32<T>(to_f32(v.v[j]) + to_f32(a.v[j]) + to_f32(b.v[j]));
+        }
+        return v;
+    };
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) g[k] = item_grad(min(r0 + rl + (long)k * rows_par, rows - 1));
     for (int i = tid; i < SR * p.C; i += 256) acc[i] = 0.f;
     __syncthreads();
     if (tid < SR) {
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
         for (int r = rl + MAXR * rows_par; r < SR; r += rows_par) {   // (C < 128: more than MAXR rows per thread)
             if (s_id[r] == 0) continue;
             const long row = r0 + r;
-            const Frag4<T> g0 = frag_ld<T>(reinterpret_cast<const T*>(p.dx0) + row * 3 * p.C + c0);
+            const Frag4<T> g0 = item_grad(row);
             float* dst = acc + s_lead[r] * p.C + c0;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -291,10 +300,20 @@ extern "C" int edgl_encode_fwd(const int64_t* ids, const float* ts, const void* 
     return EDGL_OK;
 }
 
+extern "C" int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
+                                   int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                                   float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int dtype, void* stream);
 extern "C" int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const void* dx0, int B, int T, int C,
                                int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
                                float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int dtype,
                                void* stream) {
+    return edgl_encode_bwd_add(ids, marks, dx0, nullptr, nullptr, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, d_pos,
+                               d_mark_emb, workspace, dtype, stream);
+}
+extern "C" int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
+                                   int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                                   float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int dtype, void* stream) {
+    EDGL_REQUIRE((add1 == nullptr) == (add2 == nullptr), EDGL_ERR_NULL, "edgl_encode_bwd_add: add1 / add2 go together");
     EDGL_REQUIRE(ids && marks && dx0 && d_item && d_pos && d_mark_emb && workspace, EDGL_ERR_NULL,
                  "edgl_encode_bwd: null pointer");
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_encode_bwd: bad dtype %d", dtype);
@@ -303,7 +322,8 @@ extern "C" int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const v
     float* part_mk = workspace + (long)ENC_NCHUNK * T * C;
     int srows = SROWS;
     while (srows > 8 && (size_t)srows * C * sizeof(float) > 150 * 1024) srows >>= 1;   // C = 512: 64 rows per block
-    EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, part_pos, part_mk, ENC_NCHUNK, srows, d_mark_emb};
+    EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, part_pos, part_mk, ENC_NCHUNK, srows, add1, add2,
+              d_mark_emb};
     hipStream_t st = (hipStream_t)stream;
     const int rows_par = 256 / (C / 4);
     dim3 grid(T, ENC_NCHUNK);

@@ -345,17 +345,19 @@ class TrainEngine:
                 self.side.wait_stream(torch.cuda.current_stream())
                 check(lib.edgl_reduce_flush(self.side.cuda_stream), "edgl_reduce_flush")
             # both residual branches feed the first C channels of the block input (temporal.py:447, EasyDGL.py:116)
-            check(lib.edgl_add_cols(_ptr(d_in), cin, _ptr(self.G1), _ptr(self.G2), C, self.rows, C, code, st), "edgl_add_cols")
-            if i > 0:  # next (earlier) block consumes d_in as its dY; keep it out of the scratch set it will overwrite
+            if i > 0:
+                check(lib.edgl_add_cols(_ptr(d_in), cin, _ptr(self.G1), _ptr(self.G2), C, self.rows, C, code, st), "edgl_add_cols")
+                # next (earlier) block consumes d_in as its dY; keep it out of the scratch set it will overwrite
                 self.G2.copy_(self.G3)
                 dY = self.G2
             else:
-                dY = d_in
+                dY = d_in   # first block: the embedding backward adds the two branches itself (one pass less over dX0)
         d0 = drop(hd, 1)
-        check(lib.edgl_encode_bwd(_ptr(self.ids), _ptr(self.marks), _ptr(dY), B, T, C, E, I, float(d0.rate), d0.ptr(),
-                                  d0.stream_id, _ptr(tab.grad), _ptr(m.pcoding.pembs.lookup_table.grad),
-                                  _ptr(m.mark_embs.lookup_table.grad), _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))),
-                                  code, st), "edgl_encode_bwd")
+        add1, add2 = (self.G1, self.G2) if self.blk else (None, None)
+        check(lib.edgl_encode_bwd_add(_ptr(self.ids), _ptr(self.marks), _ptr(dY), _ptr(add1), _ptr(add2), B, T, C, E, I,
+                                      float(d0.rate), d0.ptr(), d0.stream_id, _ptr(tab.grad), _ptr(m.pcoding.pembs.lookup_table.grad),
+                                      _ptr(m.mark_embs.lookup_table.grad), _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))),
+                                      code, st), "edgl_encode_bwd_add")
 
     def _optimizer(self):
         m = self.m

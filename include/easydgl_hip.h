@@ -96,6 +96,12 @@ long edgl_encode_bwd_workspace(int B, int T, int C);
 int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const void* dx0, int B, int T, int C, int E,
                     int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, float* d_item,
                     float* d_pos, float* d_mark_emb, float* workspace, int dtype, void* stream);
+/* The same with two optional [B*T, C] terms (activation dtype; both or neither) added in f32 to the item section dX0[:, :C]
+ * before the scatter: the residual branches of the first block, which the training engine would otherwise add with a
+ * separate pass over dX0 (edgl_add_cols). */
+int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
+                        int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                        float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int dtype, void* stream);
 
 /* ---- K1b: CTSMA input encoding — CTSMA.py:48-58, coding.py:60-79 ----------------------------------
  * ids int64 [B,T] (tokens[:-1]), ts f32 [B,T+1] raw seconds.  x0 [B,T,2C] `dtype` =
