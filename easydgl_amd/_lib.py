@@ -56,7 +56,7 @@ SIGNATURES = {
     "edgl_scatter_rows": (I, [P, P, I, I, P, I, P]),
     "edgl_score_lse_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_ce_loss_fwd": (I, [P, P, P, I, P, P, P]),
-    "edgl_ce_loss_fwd_add": (I, [P, P, P, I, P, P, P, P]),
+    "edgl_ce_loss_fwd_add": (I, [P, P, P, I, P, P, P, P, P]),
     "edgl_score_bwd_workspace": (L, [I, I, I, I, I]),
     "edgl_score_ce_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_score_flash_workspace": (L, [I, I, I, I, I]),

@@ -751,21 +751,32 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(const int64_t* label
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (t == 0) s_base = 0;
     __syncthreads();
-    for (int r0 = 0; r0 < R; r0 += 1024) {
-        const int r = r0 + t;
-        const bool on = r < R && labels[r] != 0;
-        const unsigned long long bal = __ballot(on);
-        if (lane == 0) wcnt[w] = __popcll(bal);
-        __syncthreads();
-        int before = s_base, tot = 0;
-        for (int i = 0; i < 16; ++i) { const int c = wcnt[i]; before += i < w ? c : 0; tot += c; }
-        const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
-        if (r < R) {
-            if (on) { perm[pos] = r; inv[r] = pos; }
-            else inv[r] = -1;
+    // labels of 16 chunks are fetched together (clamped, unconditional): one memory round trip per 16 K rows, not per chunk
+    for (int g0 = 0; g0 < R; g0 += 16 * 1024) {
+        unsigned onbits = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int r = g0 + k * 1024 + t;
+            const int64_t lab = labels[min(r, R - 1)];
+            onbits |= (r < R && lab != 0) ? (1u << k) : 0u;
         }
-        __syncthreads();
-        if (t == 0) s_base += tot;
+#pragma unroll 1
+        for (int k = 0; k < 16 && g0 + k * 1024 < R; ++k) {
+            const int r = g0 + k * 1024 + t;
+            const bool on = (onbits >> k) & 1u;
+            const unsigned long long bal = __ballot(on);
+            if (lane == 0) wcnt[w] = __popcll(bal);
+            lds_barrier();   // LDS-scoped: __syncthreads() would also wait for the perm / inv stores of the previous chunk
+            int before = s_base, tot = 0;
+            for (int i = 0; i < 16; ++i) { const int c = wcnt[i]; before += i < w ? c : 0; tot += c; }
+            const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+            if (r < R) {
+                if (on) { perm[pos] = r; inv[r] = pos; }
+                else inv[r] = -1;
+            }
+            lds_barrier();
+            if (t == 0) s_base += tot;
+        }
     }
     __syncthreads();
     const int total = s_base;
@@ -820,7 +831,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* src0, long rows
 // CE loss from (lse, label logit) — EasyDGL.py:155,177-185
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
-                                                       float* loss_out, float* coef, const float* add_in) {
+                                                       float* loss_out, float* coef, const float* add_in, const float* add_in2) {
     // one workgroup; a thread keeps up to CE_KEEP of its rows' probabilities in registers between the two passes (the loads of
     // a pass are independent, so they overlap instead of paying one memory round trip per row)
     constexpr int CE_KEEP = 16;
@@ -844,7 +855,7 @@ __global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, con
     num = block_sum(num, red);
     den = block_sum(den, red);
     const float W = den + 1e-5f;
-    if (threadIdx.x == 0) loss_out[0] = num / W + (add_in ? add_in[0] : 0.f);   // + the regularisation terms of the step, if given
+    if (threadIdx.x == 0) loss_out[0] = num / W + (add_in ? add_in[0] : 0.f) + (add_in2 ? add_in2[0] : 0.f);   // + regularisation terms
 #pragma unroll
     for (int i = 0; i < CE_KEEP; ++i) {
         const int m = threadIdx.x + i * 1024;
@@ -1289,16 +1300,16 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
 }
 
 extern "C" int edgl_ce_loss_fwd_add(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
-                                    float* coef, const float* add_in, void* stream) {
+                                    float* coef, const float* add_in, const float* add_in2, void* stream) {
     EDGL_REQUIRE(row_lse && label_logit && labels && loss_out && coef, EDGL_ERR_NULL, "edgl_ce_loss_fwd: null pointer");
     hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_lse, label_logit, labels, R, loss_out, coef,
-                       add_in);
+                       add_in, add_in2);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
 extern "C" int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
                                 float* loss_out, float* coef, void* stream) {
-    return edgl_ce_loss_fwd_add(row_lse, label_logit, labels, R, loss_out, coef, nullptr, stream);
+    return edgl_ce_loss_fwd_add(row_lse, label_logit, labels, R, loss_out, coef, nullptr, nullptr, stream);
 }
 
 extern "C" long edgl_score_bwd_workspace(int R, int C, int I, int n_items, int dtype) {

@@ -81,7 +81,7 @@ class TrainEngine:
         self.lse, self.lab_logit, self.coef = e(self.R, dtype=f32), e(self.R, dtype=f32), e(self.R, dtype=f32)
         self.loss = e(1, dtype=f32)
         # L2 + TPP terms (accumulated before the cross-entropy kernel, which adds them to its own term)
-        self.loss_aux = torch.zeros(1, device=dev, dtype=f32)
+        self.loss_aux, self.loss_tpp = torch.zeros(1, device=dev, dtype=f32), torch.zeros(1, device=dev, dtype=f32)
         self.ws_l2 = e(1024, dtype=f32)
         self.side = torch.cuda.Stream(device=dev)
         # ---- backward temporaries -------------------------------------------------------------------------------
@@ -166,7 +166,6 @@ class TrainEngine:
         main, side = torch.cuda.current_stream(), self.side
         sst = side.cuda_stream
         side.wait_stream(main)
-        aux_written, tpp_joined = False, False
         with torch.cuda.stream(side):
             for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
                 att = blk.attention
@@ -180,7 +179,6 @@ class TrainEngine:
             if m.l2_reg != 0.0:
                 check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss_aux), 0,
                                        _ptr(self.ws_l2), sst), "edgl_l2_loss")
-                aux_written = True
         # dropout step counter, Adam step counter and learning rate of this step: one single-thread launch
         check(lib.edgl_step_begin(_ptr(m._rng_state), _ptr(m._adam_state), float(m.learning_rate), 0.9, 0.999, st),
               "edgl_step_begin")
@@ -200,15 +198,10 @@ class TrainEngine:
             check(lib.edgl_bimau_fwd(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
                                      _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
                                      _ptr(b["lam"]), _ptr(b["saved"]), 0, code, st), "edgl_bimau_fwd")
-            if m.ct_reg != 0.0:   # TPP regulariser of this block: loss term and d lambda (one small launch pair)
-                if not tpp_joined:   # the L2 term of the side stream is accumulated into the same scalar
-                    main.wait_stream(side)
-                    tpp_joined = True
+            if m.ct_reg != 0.0:   # TPP regulariser of this block: loss term and d lambda (three small launches)
                 check(lib.edgl_tpp_fwd_bwd(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
                                            _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
-                                           _ptr(self.loss_aux), 1 if aux_written else 0, _ptr(b["dlam"]), st),
-                      "edgl_tpp_fwd_bwd")
-                aux_written = True
+                                           _ptr(self.loss_tpp), 1 if i > 0 else 0, _ptr(b["dlam"]), st), "edgl_tpp_fwd_bwd")
             if self.fused_tail:
                 last = i == len(self.blk) - 1
                 pk = self.tail_pack[i]
@@ -244,10 +237,10 @@ class TrainEngine:
             check(lib.edgl_score_lse_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
                                          _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
                   "edgl_score_lse_fwd")
-        has_aux = m.l2_reg != 0.0 or (m.ct_reg != 0.0 and len(self.blk) > 0)
         main.wait_stream(side)   # join: the L2 term of the side stream
         check(lib.edgl_ce_loss_fwd_add(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef),
-                                       _ptr(self.loss_aux) if has_aux else None, st), "edgl_ce_loss_fwd_add")
+                                       _ptr(self.loss_aux) if m.l2_reg != 0.0 else None,
+                                       _ptr(self.loss_tpp) if (m.ct_reg != 0.0 and self.blk) else None, st), "edgl_ce_loss_fwd_add")
         # ================= backward =================
         self._ws_i = 0
         check(lib.edgl_reduce_defer(1, st), "edgl_reduce_defer")

@@ -237,10 +237,11 @@ int edgl_score_lse_fwd(const void* rows, const void* table, const float* out_bia
  * per-row coefficient coef[r] = (w_r/W) * p_y/(p_y+1e-5) used by the backward.  loss_out f32[1]. */
 int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
                      float* loss_out, float* coef, void* stream);
-/* The same with loss_out[0] = cross-entropy + add_in[0] (add_in: device scalar holding the regularisation terms of the
- * step, may be NULL): saves the training engine a separate one-element add launch. */
+/* The same with loss_out[0] = cross-entropy + add_in[0] + add_in2[0] (device scalars holding the regularisation terms of
+ * the step — two, so that terms produced on different streams need no common accumulator; either may be NULL): saves the
+ * training engine a separate one-element add launch. */
 int edgl_ce_loss_fwd_add(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
-                         float* coef, const float* add_in, void* stream);
+                         float* coef, const float* add_in, const float* add_in2, void* stream);
 /* backward of the CE: dl[r,j] = g * coef[r] * (p[r,j] - [j==label_r]) (g = d loss, device scalar or
  * NULL for 1), never materialised:  d_rows[R,C] (`dtype`) = dl . table ;  d_table[I,C] (f32,
  * overwritten for rows [i0,i1), row 0 := 0) = dl^T . rows ;  d_bias[I-1] f32 = colsum(dl)[1:].
