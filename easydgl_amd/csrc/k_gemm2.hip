@@ -438,6 +438,126 @@ __global__ __launch_bounds__(W_NT) void strip_stream_kernel(StripP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 128 x 128 tiled GEMM for the wide projections (QKVT forward: [M, 384] . [384, 512] + bias; its dX: [M, 512] . [512, 384])
+// ------------------------------------------------------------------------------------------------
+// The strip kernels give every wave 32 rows x ALL columns: 8 epilogues and 8 workgroup barriers per strip, the 8 waves of a
+// workgroup in lock-step, 202 workgroups for 256 CUs.  Here a 4-wave workgroup (2 x 2 waves, 64 x 64 outputs each = 16
+// accumulator tiles) owns one 128 x 128 output tile and walks K in 64-wide steps: both operand tiles double-buffered in LDS
+// (register prefetch of the next step, one LDS-scoped barrier per step), two independent workgroups per CU, 1616 workgroups
+// for the QKVT shape; the output tile leaves through LDS as whole 256-byte row segments.  Epilogue: optional bias.
+constexpr int G_BM = 128, G_BN = 128, G_BK = 64, G_NT = 256;
+constexpr int G_LDK = G_BK + 8;      // [rows][k] images (A; B when k-contiguous)
+constexpr int G_LDN = G_BN + 16;     // [k][n] image (B when n-contiguous: transpose reads)
+constexpr int G_LDO = G_BN + 8;      // output staging [128][128]
+template <bool B_KC>
+__global__ __launch_bounds__(G_NT, 2) void tile_nn_kernel(StripP p) {
+    constexpr int A_EL = G_BM * G_LDK, B_EL = B_KC ? G_BN * G_LDK : G_BK * G_LDN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][A_EL]
+    bf16* Bs = As + 2 * A_EL;                                  // [2][B_EL]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int G = lane >> 4, g4 = G * 4, l15 = lane & 15;
+    // consecutive workgroups share the row block (its A rows stay in L2 across the N / 128 column tiles)
+    const int nbn = p.N / G_BN;
+    const int m0 = ((int)blockIdx.x / nbn) * G_BM, n0 = ((int)blockIdx.x % nbn) * G_BN;
+    uint4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;   // named registers (arrays captured by a lambda end up in scratch here)
+    // piece v of an operand tile: A (and B when k-contiguous): row v >> 3, k offset (v & 7) * 8; B n-contiguous: k row v >> 4, n offset (v & 15) * 8
+#define G_LOAD_ONE(PA, PB, I)                                                                                                  \
+    {                                                                                                                          \
+        const int v = tid + (I) * G_NT, ar = v >> 3, ac = (v & 7) * 8;                                                         \
+        PA = *reinterpret_cast<const uint4*>(p.A + (long)min(m0 + ar, p.M - 1) * p.lda + k0_ + ac);                            \
+        if constexpr (B_KC) PB = *reinterpret_cast<const uint4*>(p.B + (long)(n0 + ar) * p.ldb + k0_ + ac);                    \
+        else PB = *reinterpret_cast<const uint4*>(p.B + (long)(k0_ + (v >> 4)) * p.ldb + n0 + (v & 15) * 8);                   \
+    }
+#define G_LOAD(K0) { const int k0_ = (K0); G_LOAD_ONE(pa0, pb0, 0) G_LOAD_ONE(pa1, pb1, 1) G_LOAD_ONE(pa2, pb2, 2) G_LOAD_ONE(pa3, pb3, 3) }
+#define G_STORE_ONE(PA, PB, I, BUF)                                                                                            \
+    {                                                                                                                          \
+        const int v = tid + (I) * G_NT, ar = v >> 3, ac = (v & 7) * 8;                                                         \
+        *reinterpret_cast<uint4*>(As + (BUF) * A_EL + ar * G_LDK + ac) = PA;                                                   \
+        if constexpr (B_KC) *reinterpret_cast<uint4*>(Bs + (BUF) * B_EL + ar * G_LDK + ac) = PB;                               \
+        else *reinterpret_cast<uint4*>(Bs + (BUF) * B_EL + (v >> 4) * G_LDN + (v & 15) * 8) = PB;                              \
+    }
+#define G_STORE(BUF) { G_STORE_ONE(pa0, pb0, 0, BUF) G_STORE_ONE(pa1, pb1, 1, BUF) G_STORE_ONE(pa2, pb2, 2, BUF) G_STORE_ONE(pa3, pb3, 3, BUF) }
+    f32x4 acc[4][4];   // [i: m tile][j: n tile], L(first = n, second = m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nstep = p.K / G_BK;
+    G_LOAD(0)
+    G_STORE(0)
+    lds_barrier();
+    for (int st = 0; st < nstep; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstep) G_LOAD((st + 1) * G_BK)
+        const bf16* Ab = As + buf * A_EL + (wm * 64) * G_LDK;
+        const bf16* Bb = Bs + buf * B_EL;
+#pragma unroll
+        for (int kb = 0; kb < G_BK / 32; ++kb) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16* ar = Ab + (i * 16 + l15) * G_LDK + kb * 32;
+                if constexpr (B_KC) {
+                    af[i] = *reinterpret_cast<const bf16x8*>(ar + G * 8);
+                } else {   // k-slot order of the transpose-read B fragment: slots 0-3 <-> 4G + j, slots 4-7 <-> 16 + 4G + j
+                    *reinterpret_cast<uint2*>(&af[i]) = *reinterpret_cast<const uint2*>(ar + g4);
+                    *(reinterpret_cast<uint2*>(&af[i]) + 1) = *reinterpret_cast<const uint2*>(ar + 16 + g4);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (B_KC) bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + (wn * 64 + j * 16 + l15) * G_LDK + kb * 32 + G * 8);
+                else bfr[j] = tr_frag32(Bb, G_LDN, kb * 32, wn * 64 + j * 16, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (st + 1 < nstep) G_STORE(buf ^ 1)   // that buffer was last read in step st - 1 (barrier below, one step back)
+        lds_barrier();
+    }
+    // ---- epilogue: bias, bf16, through LDS, whole 256-byte row segments -------------------------------------------------
+    bf16* Os = reinterpret_cast<bf16*>(smem);   // [128][G_LDO] over the operand buffers (all reads are behind the last barrier)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nl = wn * 64 + j * 16 + g4;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.epi.flags & EDGL_EPI_BIAS) b4 = *reinterpret_cast<const float4*>(p.epi.bias + n0 + nl);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = wm * 64 + i * 16 + l15;
+            const Frag4<bf16> f = frag_from_acc<bf16>(f32x4{acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w});
+            *reinterpret_cast<uint2*>(Os + ml * G_LDO + nl) = *reinterpret_cast<const uint2*>(&f);
+        }
+    }
+    lds_barrier();
+    bf16* C = reinterpret_cast<bf16*>(p.C);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int v = tid + i * G_NT, r = v >> 4, cpc = (v & 15) * 8;   // 128 rows x 16 pieces
+        if (m0 + r < p.M) *reinterpret_cast<uint4*>(C + (long)(m0 + r) * p.ldc + n0 + cpc) = *reinterpret_cast<const uint4*>(Os + r * G_LDO + cpc);
+    }
+#undef G_LOAD_ONE
+#undef G_LOAD
+#undef G_STORE_ONE
+#undef G_STORE
+}
+
+template <bool B_KC>
+static int launch_tile_nn(const StripP& p, hipStream_t st) {
+    constexpr size_t a_el = (size_t)G_BM * G_LDK, b_el = B_KC ? (size_t)G_BN * G_LDK : (size_t)G_BK * G_LDN;
+    const size_t smem = std::max(2 * (a_el + b_el) * sizeof(bf16), (size_t)G_BM * G_LDO * sizeof(bf16));
+    auto k = tile_nn_kernel<B_KC>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const int nbm = (p.M + G_BM - 1) / G_BM, nbn = p.N / G_BN;
+    hipLaunchKernelGGL(k, dim3((unsigned)(nbm * nbn)), dim3(G_NT), smem, st, p);
+    EDGL_LAUNCH_CHECK();
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // TN GEMM (dW / db)
 // ------------------------------------------------------------------------------------------------
 constexpr int T_NT = 256, T_BR = 64, T_LD = 128 + 16;
@@ -603,6 +723,11 @@ int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, in
     static const int dbg = getenv("EDGL_DBG") ? atoi(getenv("EDGL_DBG")) : 0;
     StripP p{(const bf16*)A, (const bf16*)B, C, M, N, K, lda, ldb, ldc, EpiP{bias, aux, flags}, dbg};
     int rc;
+    // wide projections with a plain (bias-only) epilogue: the 128 x 128 tiled kernel
+    static const int use_tile = getenv("EDGL_GEMM_TILE") ? atoi(getenv("EDGL_GEMM_TILE")) : 1;
+    if (use_tile && M >= 4096 && N >= 256 && (N % G_BN) == 0 && (K % G_BK) == 0 && K >= 128 && (flags & ~EDGL_EPI_BIAS) == 0 &&
+        (ldc % 8) == 0)
+        return b_kc ? launch_tile_nn<true>(p, st) : launch_tile_nn<false>(p, st);
     static const int stream_min_n = getenv("EDGL_GEMM_STREAM_N") ? atoi(getenv("EDGL_GEMM_STREAM_N")) : 384;
     if (N >= stream_min_n && (K == 384 || K == 512) && M >= 4096) {   // A would be re-read by >= 3 column slices
         rc = 0;
