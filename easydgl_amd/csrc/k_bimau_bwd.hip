@@ -56,10 +56,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const Frag4<T> ident = identity_frag<T>(lane);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // row tiles follow the sweep kernels' (b', query tile) split: 16 consecutive queries of ONE b' = head*B + b, so the
-    // interval of a row needs no per-row division
-    const int ntq = (p.T + 15) / 16;
-    const int ntile = (int)(p.R / p.T) * ntq;
+    // row tiles are 16 consecutive rows of the flat [H*B*T] row space (dz, H rows and the dH slabs are all indexed that
+    // way); a tile may straddle two sequences — only the interval lookup needs (b, q), one division per lane and tile.
+    // (Tiles per (b', query tile) as in the sweeps padded every sequence to a multiple of 16: 112 rows for T = 101.)
+    const int ntile = (int)((p.R + 15) / 16);
     const T* hin = reinterpret_cast<const T*>(p.hin);
 
     f32x4 dW[ECH][DT][DT];  // [e-e0][d][ub]: tile (j-tile = e*DT+d, u-tile = ub), L(first=j, second=u)
@@ -81,11 +81,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
     struct TileOps { Frag4<T> hA[DT]; float span; float2 dz; };
     auto load_tile = [&](int t) {
         TileOps o;
-        const int bpq = t / ntq, qt = t - bpq * ntq, bb = bpq % p.B;
-        const long row = min((long)bpq * p.T + qt * 16 + l15, p.R - 1);
+        const long row = min((long)t * 16 + l15, p.R - 1);
+        const int bp = (int)(row / p.T), q = (int)(row - (long)bp * p.T), bb = bp % p.B;
 #pragma unroll
         for (int ub = 0; ub < DT; ++ub) o.hA[ub] = frag_ld<T>(hin + row * dh + ub * 16 + g4);
-        o.span = p.spans[(long)bb * p.T + min(qt * 16 + l15, p.T - 1)];
+        o.span = p.spans[(long)bb * p.T + q];
         o.dz = *reinterpret_cast<const float2*>(p.dz_ws + row * EP + e0 + (g4 >> 1));   // lane group g: marks e0 + 2g, 2g + 1
         return o;
     };
@@ -95,10 +95,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
     for (int t = tfirst; t < ntile; t += tstep) {
         const TileOps nxt = load_tile(t + tstep < ntile ? t + tstep : t);
         asm volatile("" ::: "memory");   // the prefetch stays at the top of the tile
-        const int bpq = t / ntq, qt = t - bpq * ntq;
-        const long row0 = (long)bpq * p.T + qt * 16;
-        const bool okA = qt * 16 + l15 < p.T;   // row on the lane axis (A operand)
-        // rows past the end of their sequence contribute nothing: zero H and dz there
+        const long row0 = (long)t * 16;
+        const bool okA = row0 + l15 < p.R;   // row on the lane axis (A operand)
+        // rows past the end of the row space (last tile) contribute nothing: zero H and dz there
         dzs[l15 * ECH + (g4 >> 1)] = okA ? cur.dz.x : 0.f;
         dzs[l15 * ECH + (g4 >> 1) + 1] = okA ? cur.dz.y : 0.f;
         if (lane < 16) sps[l15] = okA ? cur.span : 0.f;
@@ -141,15 +140,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
                         for (int r = 0; r < 4; ++r) a[r] = fmaf(spn[r], ws, a[r]) + bs;
                     }
                     f32x4 du;
-                    float sdb = 0.f, sdws = 0.f, sdw = 0.f;
+                    // the kernel is VALU-issue bound (3 waves per SIMD): three instructions per element after the sigmoid
+                    // (dz*z, wv*(1-z) as one fma, their product) and the three sums straight into their accumulators
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float z = sigmoid_pre(a[r]);
                         const float t2 = dzr[r] * z;
-                        du[r] = t2 * wv * (1.0f - z);
-                        sdb += du[r]; sdws += du[r] * spn[r]; sdw += t2;
+                        du[r] = t2 * fmaf(-z, wv, wv);
+                        adb[ee][d] += du[r];
+                        adws[ee][d] = fmaf(du[r], spn[r], adws[ee][d]);
+                        adw[ee][d] += t2;
                     }
-                    adb[ee][d] += sdb; adws[ee][d] += sdws; adw[ee][d] += sdw;
                     const Frag4<T> duf = frag_from_acc<T>(du);  // as A operand: A[m=j][kk=row]
 #pragma unroll
                     for (int ub = 0; ub < DT; ++ub) dW[ee][d][ub] = mma16(duf, hB[ub], dW[ee][d][ub]);
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
         float* dst = p.dh_ws + ((long)blockIdx.y * p.R + row0) * dh;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (qt * 16 + g4 + r < p.T) {
+            if (row0 + g4 + r < p.R) {
 #pragma unroll
                 for (int ut = 0; ut < DT; ++ut) dst[(long)(g4 + r) * dh + ut * 16 + l15] = dHt[ut][r];
             }
