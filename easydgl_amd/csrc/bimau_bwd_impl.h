@@ -78,7 +78,7 @@ __device__ __forceinline__ void drop_factors(const DropKey& dk, uint32_t base, f
 // PREF: fetch the next query tile's operands one iteration ahead (head dims <= 32); at head dims 64 / 128 the doubled
 // operand set would not fit the register file, so the next tile is fetched at the end of the iteration instead.
 template <typename T, int DT, int NT, int EC, bool PREF = true>
-__global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {
+__global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (forcing 3 waves / SIMD: 83 spilled registers, 76 -> 239 us)
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = EC ? EC : p.E;
