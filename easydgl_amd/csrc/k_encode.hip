@@ -272,6 +272,117 @@ __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
     }
 }
 
+// bf16, C = 16 * CT <= 128: the same per-block aggregation as ONE matrix product on the MFMA pipe —
+//     acc[leader][c] = sum_row onehot[leader][row] * masked_g[row][c]
+// with the dropout mask applied as exact 0 / g in bf16 and the scalar sqrt(C) / (1 - rate) applied to the f32 sums.  It
+// replaces 64 KB of LDS zeroing, 64 LDS atomics per thread and a 64-trip read-out loop (the kernel took 65 us with the
+// global atomics compiled out: they were never the limit) by 64 MFMAs per wave; the block's sums are formed in one fixed
+// order.  Leaders then add their rows to the table gradient straight from the accumulator registers.
+typedef __attribute__((ext_vector_type(4))) short enc_s16x4;
+__device__ __forceinline__ uint2 enc_tr_read(const bf16* tile, int ld, int k0, int z0, int lane) {
+    const int G = lane >> 4, s = lane & 15;
+    const bf16* p = tile + (k0 + 4 * G + (s >> 2)) * ld + z0 + 4 * (s & 3);
+    enc_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) enc_s16x4*)p);
+    return *reinterpret_cast<uint2*>(&v);
+}
+template <int CT>
+__global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
+    constexpr int C = 16 * CT, LDG = C + 8, SR = SROWS;
+    __shared__ __attribute__((aligned(16))) bf16 Gs[SR * LDG];   // masked gradient rows of the block
+    __shared__ __attribute__((aligned(16))) int s_id[SR];
+    __shared__ __attribute__((aligned(16))) int s_lead[SR];       // first row with the same id; -1: padding / past the end
+    const long rows = (long)p.B * p.T, r0 = (long)blockIdx.x * SR;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, g4 = G * 4, l15 = lane & 15;
+    if (tid < SR) s_id[tid] = (r0 + tid < rows) ? (int)p.ids[r0 + tid] : 0;
+    // gradient fragments of this thread's rows, all in flight before anything else (rows clamped)
+    constexpr int cpr = C / 4, rows_par = 256 / cpr, NR = SR / rows_par;
+    const int cv = tid % cpr, rl = tid / cpr, c0 = cv * 4;
+    const bf16* dx0 = reinterpret_cast<const bf16*>(p.dx0);
+    Frag4<bf16> g[NR], ga[NR], gb[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const long row = min(r0 + rl + (long)k * rows_par, rows - 1);
+        g[k] = frag_ld<bf16>(dx0 + row * 3 * C + c0);
+        if (p.add1) {
+            ga[k] = frag_ld<bf16>(reinterpret_cast<const bf16*>(p.add1) + row * C + c0);
+            gb[k] = frag_ld<bf16>(reinterpret_cast<const bf16*>(p.add2) + row * C + c0);
+        }
+    }
+    __syncthreads();
+    if (tid < SR) {
+        const int id = s_id[tid];
+        int lead = tid;
+        for (int j4 = (tid >> 2); j4 >= 0; --j4) {
+            const int4 v = *reinterpret_cast<const int4*>(s_id + 4 * j4);
+            const int j = 4 * j4;
+            if (v.w == id && j + 3 < tid) lead = j + 3;
+            if (v.z == id && j + 2 < tid) lead = j + 2;
+            if (v.y == id && j + 1 < tid) lead = j + 1;
+            if (v.x == id && j < tid) lead = j;
+        }
+        s_lead[tid] = id == 0 ? -1 : lead;
+    }
+    const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = rl + k * rows_par;
+        const long row = r0 + r;
+        Frag4<bf16> v = g[k];
+        if (p.add1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v.v[j] = from_f32<bf16>(to_f32(v.v[j]) + to_f32(ga[k].v[j]) + to_f32(gb[k].v[j]));
+        }
+        if (dk.thresh != 0u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!drop_keep(dk, (uint64_t)row * 3 * C + c0 + j)) v.v[j] = from_f32<bf16>(0.f);
+        }
+        *reinterpret_cast<uint2*>(Gs + r * LDG + c0) = *reinterpret_cast<const uint2*>(&v);
+    }
+    __syncthreads();
+    // wave w: leaders [32 w, 32 w + 32) x all channels
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[mt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16 one = from_f32<bf16>(1.f), zero = from_f32<bf16>(0.f);
+#pragma unroll
+    for (int kb = 0; kb < SR / 32; ++kb) {
+        // k-slot order of the transpose-read fragments: slots 0-3 <-> row 32 kb + 4G + j, slots 4-7 <-> 32 kb + 16 + 4G + j
+        const int4 la = *reinterpret_cast<const int4*>(s_lead + kb * 32 + g4);
+        const int4 lb = *reinterpret_cast<const int4*>(s_lead + kb * 32 + 16 + g4);
+        const int lk[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+        bf16x8 af[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int lead = wave * 32 + mt * 16 + l15;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[mt][i] = lk[i] == lead ? one : zero;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            bf16x8 bfr;
+            *reinterpret_cast<uint2*>(&bfr) = enc_tr_read(Gs, LDG, kb * 32, ct * 16, lane);
+            *(reinterpret_cast<uint2*>(&bfr) + 1) = enc_tr_read(Gs, LDG, kb * 32 + 16, ct * 16, lane);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr, acc[mt][ct], 0, 0, 0);
+        }
+    }
+    // acc[mt][ct][r] = sum for leader 32 w + 16 mt + 4G + r, channel 16 ct + l15
+    const float sqs = sqrtf((float)C) * dk.scale;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lead = wave * 32 + mt * 16 + g4 + r;
+            if (s_lead[lead] != lead) continue;   // not a leader (or padding)
+            float* dst = p.d_item + (long)s_id[lead] * C + l15;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) atomicAdd(dst + ct * 16, sqs * acc[mt][ct][r]);
+        }
+}
+
 constexpr int ENC_NCHUNK = 16;
 
 }  // namespace
@@ -335,7 +446,11 @@ extern "C" int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, con
         const size_t smem_s = (size_t)srows * C * sizeof(float);
         EDGL_REQUIRE(smem_s <= 150 * 1024, EDGL_ERR_SHAPE, "edgl_encode_bwd: C=%d too large for the scatter stage", C);
         const unsigned nb = (unsigned)(((long)B * T + srows - 1) / srows);
-        if (dtype == EDGL_F32) {
+        if (dtype == EDGL_BF16 && (C == 128 || C == 64) && (((uintptr_t)dx0 | (uintptr_t)add1 | (uintptr_t)add2) & 7) == 0) {
+            const unsigned nbm = (unsigned)(((long)B * T + SROWS - 1) / SROWS);
+            if (C == 128) hipLaunchKernelGGL((encode_scatter_mfma_kernel<8>), dim3(nbm), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((encode_scatter_mfma_kernel<4>), dim3(nbm), dim3(256), 0, st, p);
+        } else if (dtype == EDGL_F32) {
             hipFuncSetAttribute((const void*)encode_scatter_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
             hipLaunchKernelGGL((encode_scatter_kernel<float>), dim3(nb), dim3(256), smem_s, st, p);
         } else {

@@ -404,10 +404,13 @@ struct RedBatch { RedJob j[RED_MAX_JOBS]; int n, blocks; };
 thread_local bool g_red_defer = false;
 thread_local RedBatch g_red_batch = {};
 
-// 32 columns x 32 partial-row lanes per workgroup: the deepest jobs (1616 partial rows of the mark-embedding gradient) were a
-// chain of 50 dependent loads per thread with 8 row lanes; the job list is otherwise made of 24-64 row jobs
-__global__ __launch_bounds__(1024) void reduce_rows_multi_kernel(RedBatch b) {
-    __shared__ float sm[32][33];
+// 32 columns x RL partial-row lanes per workgroup.  RL = 8 (256 threads) for the usual job lists (24-512 partial rows);
+// RL = 32 (1024 threads) when a list holds a deep job (the 1616 partial rows of the mark-embedding gradient were a chain of
+// 50 dependent loads per thread with 8 lanes) — 1024-thread workgroups are slow to place next to other kernels, so they are
+// used only then.
+template <int RL>
+__global__ __launch_bounds__(32 * RL) void reduce_rows_multi_kernel(RedBatch b) {
+    __shared__ float sm[RL][33];
     int ji = 0;
     for (int i = 1; i < b.n; ++i)
         if ((int)blockIdx.x >= b.j[i].blk0) ji = i;
@@ -420,27 +423,30 @@ __global__ __launch_bounds__(1024) void reduce_rows_multi_kernel(RedBatch b) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (n < N) {
         int p = ty;
-        for (; p + 96 < P; p += 128) {
+        for (; p + 3 * RL < P; p += 4 * RL) {
             a0 += part[(long)p * ld + n];
-            a1 += part[(long)(p + 32) * ld + n];
-            a2 += part[(long)(p + 64) * ld + n];
-            a3 += part[(long)(p + 96) * ld + n];
+            a1 += part[(long)(p + RL) * ld + n];
+            a2 += part[(long)(p + 2 * RL) * ld + n];
+            a3 += part[(long)(p + 3 * RL) * ld + n];
         }
-        for (; p < P; p += 32) a0 += part[(long)p * ld + n];
+        for (; p < P; p += RL) a0 += part[(long)p * ld + n];
     }
     sm[ty][tx] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (ty == 0 && n < N) {
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) s += sm[i][tx];
+        for (int i = 0; i < RL; ++i) s += sm[i][tx];
         jb.out[n] = s;
     }
 }
 
 int edgl_reduce_flush_impl(hipStream_t st) {
     if (g_red_batch.n == 0) return EDGL_OK;
-    hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3(g_red_batch.blocks), dim3(1024), 0, st, g_red_batch);
+    int maxp = 0;
+    for (int i = 0; i < g_red_batch.n; ++i) maxp = std::max(maxp, g_red_batch.j[i].P);
+    if (maxp > 1024) hipLaunchKernelGGL(reduce_rows_multi_kernel<32>, dim3(g_red_batch.blocks), dim3(1024), 0, st, g_red_batch);
+    else hipLaunchKernelGGL(reduce_rows_multi_kernel<8>, dim3(g_red_batch.blocks), dim3(256), 0, st, g_red_batch);
     g_red_batch.n = 0;
     g_red_batch.blocks = 0;
     EDGL_LAUNCH_CHECK();
