@@ -53,6 +53,8 @@ SIGNATURES = {
     "edgl_add_layernorm_bwd_act": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, P, P, I, P]),
     "edgl_score_chunks": (I, [I, I]),
     "edgl_compact_rows": (I, [P, P, I, I, P, P, P, P, P, I, P]),
+    "edgl_compact_scan": (I, [P, I, P, P, P, P]),
+    "edgl_compact_gather": (I, [P, P, P, I, I, P, P, I, P]),
     "edgl_scatter_rows": (I, [P, P, I, I, P, I, P]),
     "edgl_score_lse_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_ce_loss_fwd": (I, [P, P, P, I, P, P, P]),
@@ -61,6 +63,8 @@ SIGNATURES = {
     "edgl_score_ce_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_score_flash_workspace": (L, [I, I, I, I, I]),
     "edgl_score_flash_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, P]),
+    "edgl_score_prepare_table": (I, [P, I, I, I, I, I, P, I, P]),
+    "edgl_score_flash_fwd_pre": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, I, P]),
     "edgl_score_flash_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_reduce_defer": (I, [I, P]),
     "edgl_reduce_flush": (I, [P]),
@@ -71,6 +75,8 @@ SIGNATURES = {
     "edgl_tpp_fwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P]),
     "edgl_tpp_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, P, P]),
     "edgl_tpp_fwd_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P, P]),
+    "edgl_tpp_norm": (I, [P, P, I, I, I, P, P]),
+    "edgl_tpp_fwd_bwd_ex": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P, I, P]),
     "edgl_adam_step": (I, [P, P, P, P, L, F, F, F, F, P, F, P, I, P, P]),
     "edgl_step_begin": (I, [P, P, F, F, F, P]),
     "edgl_adam_apply": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P]),

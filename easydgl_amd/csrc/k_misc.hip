@@ -529,23 +529,41 @@ extern "C" int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const i
     return EDGL_OK;
 }
 
-extern "C" int edgl_tpp_fwd_bwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
-                                const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
-                                float* reg_out, int accumulate, float* d_lam, void* stream) {
+// normaliser of the regulariser: integer sum of the mark counts of the batch's labels into sums[4] (labels only: may run
+// ahead of the step's forward, e.g. on a side stream)
+extern "C" int edgl_tpp_norm(const int64_t* labels, const uint8_t* mark_table, int B, int M, int E, float* sums, void* stream) {
+    EDGL_REQUIRE(labels && mark_table && sums, EDGL_ERR_NULL, "edgl_tpp_norm: null pointer");
+    TppP p{nullptr, nullptr, labels, nullptr, mark_table, B, 0, 0, E, M, 0.f};
+    hipLaunchKernelGGL(tpp_norm_kernel, dim3((B * M + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, reinterpret_cast<int*>(sums) + 4);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+// with_norm = 0: edgl_tpp_norm has already run for this batch on the same `sums`
+extern "C" int edgl_tpp_fwd_bwd_ex(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                                   const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
+                                   float* reg_out, int accumulate, float* d_lam, int with_norm, void* stream) {
     EDGL_REQUIRE(lam && labels && ts_raw && mark_table && sums && reg_out, EDGL_ERR_NULL, "edgl_tpp_fwd_bwd: null pointer");
     EDGL_REQUIRE(masked_pos || M == T, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: all-position mode needs M == T");
     EDGL_REQUIRE(E >= 1 && E <= 16, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: E=%d (1..16)", E);
     EDGL_REQUIRE(M <= TPP_MAXM, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: M=%d > %d", M, TPP_MAXM);
+    if (with_norm) {
+        const int rc = edgl_tpp_norm(labels, mark_table, B, M, E, sums, stream);
+        if (rc) return rc;
+    }
     TppP p{lam, masked_pos, labels, ts_raw, mark_table, B, T, H, E, M, coef};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(tpp_norm_kernel, dim3((B * M + 255) / 256), dim3(256), 0, st, p, reinterpret_cast<int*>(sums) + 4);
-    EDGL_LAUNCH_CHECK();
     const int nblk = std::min(TPP_FUSED_BLOCKS, H * B);
     hipLaunchKernelGGL(tpp_fused_kernel, dim3(nblk), dim3(128), 0, st, p, sums, sums + 8, d_lam);
     EDGL_LAUNCH_CHECK();
     hipLaunchKernelGGL(tpp_final2_kernel, dim3(1), dim3(256), 0, st, sums + 8, nblk, coef, H, sums, reg_out, accumulate);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
+}
+extern "C" int edgl_tpp_fwd_bwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                                const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
+                                float* reg_out, int accumulate, float* d_lam, void* stream) {
+    return edgl_tpp_fwd_bwd_ex(lam, masked_pos, labels, ts_raw, mark_table, B, T, H, E, M, coef, sums, reg_out, accumulate, d_lam, 1,
+                               stream);
 }
 
 extern "C" int edgl_adam_step(float* param, const float* grad, float* m, float* v, long n, float lr, float beta1,

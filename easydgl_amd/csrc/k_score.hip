@@ -77,6 +77,7 @@ struct ScoreP {
     const float* coef; const float* gscale;             // bwd
     float* slabs; float* bias_slabs;
     float* lab_out;                                     // flash forward: label logits [R]
+    int table_ready;                                    // tableT already written by edgl_score_prepare_table
     int dbg;   // EDGL_DBG ablation bits (profiling only): 1 skip dl math, 2 skip second product, 4 skip z streaming, 8 skip logit MFMA
 };
 
@@ -1117,7 +1118,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     T* tableT = reinterpret_cast<T*>(ws + plan.off_tableT);
     p.ldr = (int)up8(p.R); p.ldt = (int)up8(p.I);
     if (MODE != 2) {
-        const int nbx0 = (p.ldr + 63) / 64, nbx1 = (p.ldt + 63) / 64;
+        const int nbx0 = (p.ldr + 63) / 64, nbx1 = p.table_ready ? 0 : (p.ldt + 63) / 64;
         hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)(nbx0 + nbx1), (p.C + 63) / 64), dim3(256), 0, st,
                            reinterpret_cast<const T*>(p.rows), (long)p.R, rowsT, (long)p.ldr, nbx0,
                            reinterpret_cast<const T*>(p.table), (long)p.I, tableT, (long)p.ldt, p.C);
@@ -1241,20 +1242,33 @@ extern "C" int edgl_score_chunks(int R, int n_items) {
     return (int)best;
 }
 
-extern "C" int edgl_compact_rows(const void* rows, const int64_t* labels, int R, int C, int32_t* perm, int32_t* inv,
-                                 int32_t* nvalid, void* rows_c, int64_t* labels_c, int dtype, void* stream) {
-    EDGL_REQUIRE(rows && labels && perm && inv && nvalid && rows_c && labels_c, EDGL_ERR_NULL, "edgl_compact_rows: null pointer");
-    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_compact_rows: bad dtype %d", dtype);
-    EDGL_REQUIRE(R > 0 && C % (dtype == EDGL_BF16 ? 8 : 4) == 0, EDGL_ERR_SHAPE, "edgl_compact_rows: bad shape R=%d C=%d", R, C);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, labels, R, perm, inv, nvalid);
+// edgl_compact_rows = edgl_compact_scan (labels only: may run as soon as the batch is known, e.g. on a side stream at the start
+// of the step) + edgl_compact_gather (needs the rows)
+extern "C" int edgl_compact_scan(const int64_t* labels, int R, int32_t* perm, int32_t* inv, int32_t* nvalid, void* stream) {
+    EDGL_REQUIRE(labels && perm && inv && nvalid, EDGL_ERR_NULL, "edgl_compact_scan: null pointer");
+    EDGL_REQUIRE(R > 0, EDGL_ERR_SHAPE, "edgl_compact_scan: bad shape R=%d", R);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, R, perm, inv, nvalid);
     EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+extern "C" int edgl_compact_gather(const void* rows, const int64_t* labels, const int32_t* perm, int R, int C, void* rows_c,
+                                   int64_t* labels_c, int dtype, void* stream) {
+    EDGL_REQUIRE(rows && labels && perm && rows_c && labels_c, EDGL_ERR_NULL, "edgl_compact_gather: null pointer");
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_compact_gather: bad dtype %d", dtype);
+    EDGL_REQUIRE(R > 0 && C % (dtype == EDGL_BF16 ? 8 : 4) == 0, EDGL_ERR_SHAPE, "edgl_compact_gather: bad shape R=%d C=%d", R, C);
+    hipStream_t st = (hipStream_t)stream;
     const long nv = (long)R * C / (dtype == EDGL_BF16 ? 8 : 4);
     const unsigned nb = (unsigned)std::min<long>((nv + 255) / 256, 2048);
     if (dtype == EDGL_F32) hipLaunchKernelGGL((compact_gather_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)rows, labels, perm, R, C, (float*)rows_c, labels_c);
     else hipLaunchKernelGGL((compact_gather_kernel<bf16>), dim3(nb), dim3(256), 0, st, (const bf16*)rows, labels, perm, R, C, (bf16*)rows_c, labels_c);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
+}
+extern "C" int edgl_compact_rows(const void* rows, const int64_t* labels, int R, int C, int32_t* perm, int32_t* inv,
+                                 int32_t* nvalid, void* rows_c, int64_t* labels_c, int dtype, void* stream) {
+    EDGL_REQUIRE(rows && labels && perm && inv && nvalid && rows_c && labels_c, EDGL_ERR_NULL, "edgl_compact_rows: null pointer");
+    const int rc = edgl_compact_scan(labels, R, perm, inv, nvalid, stream);
+    return rc ? rc : edgl_compact_gather(rows, labels, perm, R, C, rows_c, labels_c, dtype, stream);
 }
 
 extern "C" int edgl_scatter_rows(const void* rows_c, const int32_t* inv, int R, int C, void* rows, int dtype, void* stream) {
@@ -1358,6 +1372,41 @@ extern "C" int edgl_score_flash_fwd(const void* rows, const void* table, const f
     const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
     hipStream_t st = (hipStream_t)stream;
     p.lab_out = label_logit;   // row LSE and label logits come out of one small kernel behind the scoring pass
+    return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
+                             : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);
+}
+
+// The transposed image of the item table depends on the weights only: edgl_score_prepare_table writes it into the flash
+// workspace ahead of time (e.g. on a side stream at the start of the step) and edgl_score_flash_fwd_pre then transposes the
+// rows alone.  Same R, C, I, [i0, i1) and workspace as the forward call that follows.
+extern "C" int edgl_score_prepare_table(const void* table, int R, int C, int I, int i0, int i1, float* workspace, int dtype,
+                                        void* stream) {
+    EDGL_REQUIRE(table && workspace, EDGL_ERR_NULL, "edgl_score_prepare_table: null pointer");
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_score_prepare_table: bad dtype %d", dtype);
+    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
+    const long ldt = (long)up8(I);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((ldt + 63) / 64), (C + 63) / 64);
+    if (dtype == EDGL_F32)
+        hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, st, (const float*)table, (long)I, reinterpret_cast<float*>(workspace + plan.off_tableT), ldt,
+                           (int)grid.x, (const float*)nullptr, 0L, (float*)nullptr, 0L, C);
+    else
+        hipLaunchKernelGGL((transpose_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)table, (long)I, reinterpret_cast<bf16*>(workspace + plan.off_tableT), ldt,
+                           (int)grid.x, (const bf16*)nullptr, 0L, (bf16*)nullptr, 0L, C);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+extern "C" int edgl_score_flash_fwd_pre(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
+                                        int C, int I, int i0, int i1, const int32_t* nvalid, float* row_lse, float* label_logit,
+                                        float* workspace, int table_ready, int dtype, void* stream) {
+    int rc = check_score(rows, table, out_bias, R, C, I, i0, i1, dtype, "edgl_score_flash_fwd");
+    if (rc) return rc;
+    EDGL_REQUIRE(labels && row_lse && label_logit && workspace, EDGL_ERR_NULL, "edgl_score_flash_fwd: null pointer");
+    ScoreP p{};
+    p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
+    p.i1 = i1; p.nvalid = nvalid; p.row_lse = row_lse; p.lab_out = label_logit; p.table_ready = table_ready;
+    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
+    hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
                              : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);
 }

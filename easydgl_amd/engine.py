@@ -167,8 +167,12 @@ class TrainEngine:
         sst = side.cuda_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            # needed by the first BiMAU forward (first join): TPP normaliser (labels only), weight packs
             for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
                 att = blk.attention
+                if m.ct_reg != 0.0:
+                    check(lib.edgl_tpp_norm(_ptr(self.labels), _ptr(m.mark_lookup_table), B, M, E, _ptr(b["tpp"]), sst),
+                          "edgl_tpp_norm")
                 check(lib.edgl_bimau_pack(_ptr(att.st_kernel), _ptr(att.st_bias), _ptr(att.weight), _ptr(att.scaling), C, H, E,
                                           _ptr(b["pack"]), code, sst), "edgl_bimau_pack")
                 if self.fused_tail:
@@ -176,6 +180,11 @@ class TrainEngine:
                                              _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
                                              _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
             ev_pack = side.record_event()
+            # needed by the scoring (second join, before the row gather): row compaction map (labels only), L2 term
+            check(lib.edgl_compact_scan(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid), sst),
+                  "edgl_compact_scan")
+            # (the transposed table image is NOT prepared here, although it depends on the weights only: written 200 us before
+            # its use it has left the L2 by then and the scoring pass measured 109 -> 118 us — edgl_score_prepare_table)
             if m.l2_reg != 0.0:
                 check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss_aux), 0,
                                        _ptr(self.ws_l2), sst), "edgl_l2_loss")
@@ -199,9 +208,9 @@ class TrainEngine:
                                      _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
                                      _ptr(b["lam"]), _ptr(b["saved"]), 0, code, st), "edgl_bimau_fwd")
             if m.ct_reg != 0.0:   # TPP regulariser of this block: loss term and d lambda (three small launches)
-                check(lib.edgl_tpp_fwd_bwd(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
-                                           _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
-                                           _ptr(self.loss_tpp), 1 if i > 0 else 0, _ptr(b["dlam"]), st), "edgl_tpp_fwd_bwd")
+                check(lib.edgl_tpp_fwd_bwd_ex(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
+                                              _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
+                                              _ptr(self.loss_tpp), 1 if i > 0 else 0, _ptr(b["dlam"]), 0, st), "edgl_tpp_fwd_bwd_ex")
             if self.fused_tail:
                 last = i == len(self.blk) - 1
                 pk = self.tail_pack[i]
@@ -226,18 +235,18 @@ class TrainEngine:
             self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, C, C, gelu=True, pre=self.pre_t)
             self._ln_fwd(self.so, None, 0, m.transform_ln, ops.NO_DROP, self.hrows, self.st3, gpos=self.mpos)
         # rows whose label is 0 have weight 0 (EasyDGL.py:180): score only the weighted ones
-        check(lib.edgl_compact_rows(_ptr(self.hrows), _ptr(self.labels), R, C, _ptr(self.perm), _ptr(self.inv),
-                                    _ptr(self.nvalid), _ptr(self.hrows_c), _ptr(self.labels_c), code, st), "edgl_compact_rows")
+        main.wait_stream(side)   # join: compaction map, L2 term
+        check(lib.edgl_compact_gather(_ptr(self.hrows), _ptr(self.labels), _ptr(self.perm), R, C, _ptr(self.hrows_c),
+                                      _ptr(self.labels_c), code, st), "edgl_compact_gather")
         lab = self.labels_c
         if self.flash_ce:
-            check(lib.edgl_score_flash_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
-                                           _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.ws_flash), code, st),
-                  "edgl_score_flash_fwd")
+            check(lib.edgl_score_flash_fwd_pre(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
+                                               _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.ws_flash), 0, code,
+                                               st), "edgl_score_flash_fwd_pre")
         else:
             check(lib.edgl_score_lse_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
                                          _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
                   "edgl_score_lse_fwd")
-        main.wait_stream(side)   # join: the L2 term of the side stream
         check(lib.edgl_ce_loss_fwd_add(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef),
                                        _ptr(self.loss_aux) if m.l2_reg != 0.0 else None,
                                        _ptr(self.loss_tpp) if (m.ct_reg != 0.0 and self.blk) else None, st), "edgl_ce_loss_fwd_add")

@@ -228,6 +228,10 @@ int edgl_score_chunks(int R, int n_items);
  * rows[r] = inv[r] >= 0 ? rows_c[inv[r]] : 0. */
 int edgl_compact_rows(const void* rows, const int64_t* labels, int R, int C, int32_t* perm, int32_t* inv,
                       int32_t* nvalid, void* rows_c, int64_t* labels_c, int dtype, void* stream);
+/* The two halves of edgl_compact_rows: the scan needs the labels only (it may run before the rows exist), the gather the rows. */
+int edgl_compact_scan(const int64_t* labels, int R, int32_t* perm, int32_t* inv, int32_t* nvalid, void* stream);
+int edgl_compact_gather(const void* rows, const int64_t* labels, const int32_t* perm, int R, int C, void* rows_c,
+                        int64_t* labels_c, int dtype, void* stream);
 int edgl_scatter_rows(const void* rows_c, const int32_t* inv, int R, int C, void* rows, int dtype,
                       void* stream);
 int edgl_score_lse_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
@@ -280,6 +284,13 @@ long edgl_score_flash_workspace(int R, int C, int I, int n_items, int dtype);
 int edgl_score_flash_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
                          int I, int i0, int i1, const int32_t* nvalid, float* row_lse, float* label_logit,
                          float* workspace, int dtype, void* stream);
+/* The transposed operand image of the item table depends on the weights only: edgl_score_prepare_table writes it into the
+ * flash workspace ahead of the forward (same R, C, I, [i0, i1), workspace, dtype), and edgl_score_flash_fwd_pre with
+ * table_ready != 0 skips it (table_ready == 0: identical to edgl_score_flash_fwd). */
+int edgl_score_prepare_table(const void* table, int R, int C, int I, int i0, int i1, float* workspace, int dtype, void* stream);
+int edgl_score_flash_fwd_pre(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
+                             int I, int i0, int i1, const int32_t* nvalid, float* row_lse, float* label_logit,
+                             float* workspace, int table_ready, int dtype, void* stream);
 int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                          const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
                          int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias, float* workspace,
@@ -319,6 +330,12 @@ int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const int64_t* lab
 int edgl_tpp_fwd_bwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                      const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
                      float* reg_out, int accumulate, float* d_lam, void* stream);
+/* The normaliser alone (labels only; integer sum into sums[4]) and edgl_tpp_fwd_bwd with it optional (with_norm == 0: edgl_tpp_norm
+ * already ran for this batch on the same `sums`). */
+int edgl_tpp_norm(const int64_t* labels, const uint8_t* mark_table, int B, int M, int E, float* sums, void* stream);
+int edgl_tpp_fwd_bwd_ex(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                        const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
+                        float* reg_out, int accumulate, float* d_lam, int with_norm, void* stream);
 
 /* ---- optimizer — tf.train.AdamOptimizer (Base.py:142-144) over a flat f32 arena ----------------
  * step_state: device uint64[2]: [0] = step count (incremented by this call, so the first call is
