@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ms + (HAS_M ? Tp * EP : 0)));
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-#ifdef EDGL_PROLOGUE_ONLY
+#ifdef EDGL_PROLOGUE_ONLY   // diagnostic build (not the product): time of the LDS staging alone — rule 9 of DESIGN.md §4.2
     if (p.B > 0) { if (km.pad == 0x1234567ull) reinterpret_cast<T*>(p.out)[0] = Ks[lane] + Ms[lane]; return; }
 #endif
 
