@@ -142,11 +142,12 @@ __global__ __launch_bounds__(256) void tpp_norm_kernel(TppP p, int* acc) {
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(acc, cnt);
 }
-constexpr int TPP_MAXM = 256, TPP_FUSED_BLOCKS = 2048;
+constexpr int TPP_MAXM = 256, TPP_MAXT = 1024, TPP_FUSED_BLOCKS = 2048;   // (4096 one-sequence workgroups measured slower: 24 vs 19 us)
 __global__ __launch_bounds__(128) void tpp_fused_kernel(TppP p, const float* sums, float* part, float* d_lam) {
     __shared__ float red[8];
     __shared__ int s_pos[TPP_MAXM];
     __shared__ int s_lab[TPP_MAXM];
+    __shared__ int s_head[TPP_MAXT];
     __shared__ __attribute__((aligned(16))) float s_out[2][64 * 16];   // per wave: 64 gradient rows, for coalesced stores
     const float c = (float)reinterpret_cast<const int*>(sums)[4] * (float)p.H;   // tpp_norm_kernel
     const float k = -p.coef / c;
@@ -159,6 +160,14 @@ __global__ __launch_bounds__(128) void tpp_fused_kernel(TppP p, const float* sum
             s_pos[m] = p.mpos ? (int)p.mpos[(long)b * p.M + m] : m;
             s_lab[m] = (int)p.labels[(long)b * p.M + m];
         }
+        for (int t = threadIdx.x; t < p.T; t += blockDim.x) s_head[t] = 0x7fffffff;
+        __syncthreads();
+        // first slot of every position (integer atomicMin: order-independent); unmasked positions — two thirds of the rows —
+        // then skip the slot search altogether, and further slots of a repeated position are searched from the first one on
+        for (int m = threadIdx.x; m < p.M; m += blockDim.x) {
+            const int pos = s_pos[m];
+            if (pos >= 0 && pos < p.T) atomicMin(&s_head[pos], m);
+        }
         __syncthreads();
         for (int t0 = 0; t0 < p.T; t0 += blockDim.x) {
             const int t = t0 + threadIdx.x;
@@ -169,14 +178,15 @@ __global__ __launch_bounds__(128) void tpp_fused_kernel(TppP p, const float* sum
             for (int e = 0; e < 16; ++e) gr[e] = 0.f;
             // slots of this position: the search is a cheap LDS scan; the heavy part below runs once per FOUND slot, so the
             // lanes of a wave do their first (usually only) slot together instead of one lane per loop iteration
-            const int m_hi = t >= p.T ? 0 : (p.mpos ? p.M : t + 1);
-            int m = p.mpos ? -1 : t - 1;
+            const int m_hi = t >= p.T ? 0 : p.M;
+            int m = -1, nxt = t < p.T ? s_head[t] : 0x7fffffff;
             for (;;) {
-                int nxt = -1;
-                for (int q = m + 1; q < m_hi; ++q)
-                    if (s_pos[q] == t) { nxt = q; break; }
-                if (nxt < 0) break;
+                if (nxt >= m_hi) break;
                 m = nxt;
+                nxt = 0x7fffffff;
+                if (p.mpos)                              // another slot of the same position (rare; none in all-position mode)
+                    for (int q = m + 1; q < m_hi; ++q)
+                        if (s_pos[q] == t) { nxt = q; break; }
                 if (!loaded) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { lam[e] = p.lam[row * p.E + min(e, p.E - 1)]; asm volatile("" : "+v"(lam[e])); }
@@ -497,7 +507,7 @@ extern "C" int edgl_rng_advance(uint64_t* rng_state, void* stream) {
     return EDGL_OK;
 }
 
-extern "C" int edgl_tpp_workspace(void) { return std::max(RED_BLOCKS * 3 + 4, 8 + 2 * 2048); }   // edgl_tpp_fwd_bwd: sums[8] + partial pairs
+extern "C" int edgl_tpp_workspace(void) { return std::max(RED_BLOCKS * 3 + 4, 8 + 2 * 4096); }   // edgl_tpp_fwd_bwd: sums[8] + partial pairs
 
 extern "C" int edgl_tpp_fwd(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                             const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
@@ -545,7 +555,7 @@ extern "C" int edgl_tpp_fwd_bwd_ex(const float* lam, const int64_t* masked_pos, 
     EDGL_REQUIRE(lam && labels && ts_raw && mark_table && sums && reg_out, EDGL_ERR_NULL, "edgl_tpp_fwd_bwd: null pointer");
     EDGL_REQUIRE(masked_pos || M == T, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: all-position mode needs M == T");
     EDGL_REQUIRE(E >= 1 && E <= 16, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: E=%d (1..16)", E);
-    EDGL_REQUIRE(M <= TPP_MAXM, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: M=%d > %d", M, TPP_MAXM);
+    EDGL_REQUIRE(M <= TPP_MAXM && T <= TPP_MAXT, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd: M=%d > %d or T=%d > %d", M, TPP_MAXM, T, TPP_MAXT);
     if (with_norm) {
         const int rc = edgl_tpp_norm(labels, mark_table, B, M, E, sums, stream);
         if (rc) return rc;
