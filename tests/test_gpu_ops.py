@@ -537,6 +537,32 @@ def test_tpp_fused_launch_matches_the_reference(repeat):
     assert_close(dlam.cpu().numpy(), lr.grad.numpy(), 1e-5, "tpp dlam (dense)")
 
 
+def test_tpp_fused_launch_all_position_mode():
+    """edgl_tpp_fwd_bwd without masked positions (CTSMA's form: every position scored, T + 1 raw timestamps per row) against
+    the separate forward / backward kernels behind TppFn."""
+    from easydgl_amd import _lib
+    lib = _lib.lib
+    o = ops()
+    rng = np.random.default_rng(21)
+    B, T, H, E, NI = 5, 37, 2, 16, 50
+    lam = torch.tensor(rng.uniform(0.2, 2.0, size=(H * B, T, E)), dtype=torch.float32).cuda()
+    labels = torch.tensor(rng.integers(0, NI, size=(B, T))).cuda()
+    ts = torch.tensor(np.cumsum(rng.exponential(40.0, size=(B, T + 1)), axis=1).astype(np.float32) + 9.5e8).cuda()
+    mt = torch.tensor(O.synthetic_mark_table(NI, E, multi_hot=True).astype(np.uint8)).cuda()
+    coef = 0.23
+    lam_a = lam.clone().requires_grad_()
+    reg_ref = o.TppFn.apply(lam_a, None, labels, ts, mt, H, coef)
+    reg_ref.backward()
+    sums = torch.zeros(int(lib.edgl_tpp_workspace()), device="cuda")
+    reg = torch.zeros(1, device="cuda")
+    dlam = torch.full((H * B, T, E), float("nan"), device="cuda")
+    _lib.check(lib.edgl_tpp_fwd_bwd(lam.data_ptr(), None, labels.data_ptr(), ts.data_ptr(), mt.data_ptr(), B, T, H, E, T, coef,
+                                    sums.data_ptr(), reg.data_ptr(), 0, dlam.data_ptr(), None), "edgl_tpp_fwd_bwd")
+    torch.cuda.synchronize()
+    assert_close(reg.item(), reg_ref.item(), 1e-5, "tpp reg, all positions")
+    assert_close(dlam.cpu().numpy(), lam_a.grad.cpu().numpy(), 1e-5, "tpp dlam, all positions")
+
+
 def test_adam_matches_tf_form():
     o = ops()
     rng = np.random.default_rng(6)
