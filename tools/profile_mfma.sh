@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/mfma
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+CMD="python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --pmc MfmaUtil -d "$OUT/mfma" -o m -- $CMD > "$OUT/mfma.log" 2>&1
 rocprofv3 --kernel-trace --pmc VALUBusy -d "$OUT/valu" -o v -- $CMD > "$OUT/valu.log" 2>&1
 ls "$OUT"/*
