@@ -77,7 +77,9 @@ __device__ __forceinline__ void drop_factors(const DropKey& dk, uint32_t base, f
 // ------------------------------------------------------------------------------------------------------------------
 // PREF: fetch the next query tile's operands one iteration ahead (head dims <= 32); at head dims 64 / 128 the doubled
 // operand set would not fit the register file, so the next tile is fetched at the end of the iteration instead.
-template <typename T, int DT, int NT, int EC, bool PREF = true>
+// FL: -1 = MAU_CAUSAL / MAU_NO_DIAG read from p.flags at run time; 0 = the BiMAU configuration compiled in (bidirectional,
+// diagonal set): no per-element causal compares / selects in the softmax, the diagonal as one select on a scalar-and-ed mask
+template <typename T, int DT, int NT, int EC, bool PREF = true, int FL = -1>
 __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (forcing 3 waves / SIMD: 83 spilled registers, 76 -> 239 us)
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,7 +198,8 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        if constexpr (FL == 0) masked_softmax_impl<NT, false, false>(s, km, cscale, lane, q);
+        else masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
         PH_MARK(0);
         Frag4<T> lf;
 #pragma unroll
@@ -216,7 +219,11 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
             for (int vb = 0; vb < DT; ++vb)
                 da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
             f32x4 ap, dg, gv = gacc;
-            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {   // only this key tile can hold k == q: G' diag := 1 (temporal.py:438-439)
+            const bool dtile = kt == qt && (FL == 0 || !(p.flags & MAU_NO_DIAG));   // only this key tile can hold k == q
+            if constexpr (FL == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[r] = (dtile && g4 + r == l15) ? 1.0f : gacc[r];   // G' diag := 1 (temporal.py:438-439)
+            } else if (dtile) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
             }
@@ -230,7 +237,10 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
                 dg[r] = da[r] * fp;                         // dG' = dA' * D * P
                 rowdot = fmaf(da[r] * facs[r] * gv[r], pv, rowdot);   // dP1 * P, dP1 = dA' * D * G'
             }
-            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {   // set_diag blocks the gradient into lambda
+            if constexpr (FL == 0) {   // set_diag blocks the gradient into lambda
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dg[r] = (dtile && g4 + r == l15) ? 0.f : dg[r];
+            } else if (dtile) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dg[r] = (g4 + r == l15) ? 0.f : dg[r];
             }
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
 // Z) sweep 2
 // ------------------------------------------------------------------------------------------------------------------
 // NYP: number of dH partial slabs the intensity backward left in dh_ws (KY_NY mark groups at head dims <= 32, 1 above)
-template <typename T, int DT, int NT, int EC, int NYP = KY_NY, bool PREF = true>
+template <typename T, int DT, int NT, int EC, int NYP = KY_NY, bool PREF = true, int FL = -1>
 __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -400,7 +410,8 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        if constexpr (FL == 0) masked_softmax_impl<NT, false, false>(s, km, cscale, lane, q);
+        else masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
         PH_MARK(0);
         Frag4<T> lf;
 #pragma unroll
@@ -430,7 +441,11 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             for (int vb = 0; vb < DT; ++vb)
                 da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
             f32x4 gv = gacc;
-            if (kt == qt && !(p.flags & MAU_NO_DIAG)) {
+            if constexpr (FL == 0) {
+                const bool dtile = kt == qt;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gv[r] = (dtile && g4 + r == l15) ? 1.0f : gacc[r];
+            } else if (kt == qt && !(p.flags & MAU_NO_DIAG)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
             }
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             for (int r = 0; r < 4; ++r) {
                 // tf.where(mask==0, paddings, S) (temporal.py:425-426) passes no gradient to a padded key's
                 // score; P is non-zero there only for fully padded rows (uniform softmax)
-                const bool padded = ((km.pad >> (kt * 4 + r)) & 1ull) || ((p.flags & MAU_CAUSAL) && kt * 16 + g4 + r > q);
+                const bool padded = ((km.pad >> (kt * 4 + r)) & 1ull) || (FL != 0 && (p.flags & MAU_CAUSAL) && kt * 16 + g4 + r > q);
                 ds[r] = padded ? 0.f : s[kt][r] * (a[r] - rowdot) * cscale;
             }
             const Frag4<T> dsf = frag_from_acc<T>(ds);

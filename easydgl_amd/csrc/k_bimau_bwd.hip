@@ -247,7 +247,12 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
         while (waves > 1 && waves * wave_bytes > 64 * 1024) waves >>= 1;
         const size_t smem = waves * wave_bytes;
         p.waves = waves;
+        // bf16, head dim 16, BiMAU flags (the headline family): the variant with the flags compiled in
+        constexpr bool SPEC = sizeof(T) == 2 && DT == 1;
         auto kern = p.E == 16 ? bimau_bwd_sweep1_kernel<T, DT, NT, 16> : bimau_bwd_sweep1_kernel<T, DT, NT, 0>;
+        if constexpr (SPEC) {
+            if (p.flags == 0) kern = p.E == 16 ? bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0> : bimau_bwd_sweep1_kernel<T, DT, NT, 0, true, 0>;
+        }
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
         EDGL_LAUNCH_CHECK();
@@ -271,7 +276,11 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
         const size_t smem = waves * wave_bytes;
         EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: needs %zu B of LDS", smem);
         p.waves = waves;
+        constexpr bool SPEC = sizeof(T) == 2 && DT == 1;
         auto kern = p.E == 16 ? bimau_bwd_sweep2_kernel<T, DT, NT, 16> : bimau_bwd_sweep2_kernel<T, DT, NT, 0>;
+        if constexpr (SPEC) {
+            if (p.flags == 0) kern = p.E == 16 ? bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0> : bimau_bwd_sweep2_kernel<T, DT, NT, 0, KY_NY, true, 0>;
+        }
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         edgl_prof_begin(EDGL_KERNEL_BIMAU_BWD, st);
         hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
