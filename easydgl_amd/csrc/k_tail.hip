@@ -17,16 +17,28 @@
 #ifdef EDGL_PHASE_TIMING
 __device__ unsigned long long g_phase_cycles[16];   // see edgl_common.h (PH_MARK); read back with edgl_debug_phase_cycles_tail
 #endif
+// -DEDGL_PHASE_TIMING -DEDGL_PHASE_BWD: the slots count the phases of the backward kernel instead of the forward's
+#if defined(EDGL_PHASE_TIMING) && defined(EDGL_PHASE_BWD)
+#define PHB_DECL PH_DECL
+#define PHB_MARK(i) PH_MARK(i)
+#define PHB_FLUSH() PH_FLUSH(0)
+#else
+#define PHB_DECL
+#define PHB_MARK(i)
+#define PHB_FLUSH()
+#endif
 
 namespace {
 
 constexpr int MAXRT = 7;   // 16-row tiles per sample (T <= 112)
-// libm erf in this file.  The inlined fast form (edgl_common.h gelu_t<bf16>) was measured twice: unfenced, the scheduler
-// interleaves all 28 chains of a phase (~80 more registers, spills); with a scheduling fence per row tile the z / acc
-// state still spills around the GELU phases: forward 84 -> 88 us, backward 120 -> 138 us.
-#define GELU_TAIL gelu_f
-#define DGELU_TAIL dgelu_f
-#define TAIL_FENCE()
+// GELU runs as its own pass over an f32 LDS image (gelu_pass), eight elements per thread in a loop that is not unrolled,
+// with the one-rcp-one-exp erf of edgl_common.h, and the same pass writes gelu'(pre) — the only thing the backward needs the
+// pre-activations for — in place of the pre-activations themselves, so the backward multiplies by a loaded tensor.  Inside
+// the epilogues (on the accumulator registers) libm's erff cost ~400 issue cycles per element — 28 % of the forward, 40 %
+// of the backward — and the inlined fast form spilled there: the scheduler interleaves all 28 chains of a phase (~80 more
+// registers), and with a scheduling fence per row tile the z / acc state still went to scratch (forward 84 -> 88 us,
+// backward 120 -> 138 us).  Computing gelu' in the backward's input copy (fast form, 32 per thread and image) still cost
+// 7 k of the 60 k cycles of a block, three to five times per step.
 
 struct TailP {
     const bf16* att; const bf16* xin; int ld_x;
@@ -35,16 +47,18 @@ struct TailP {
     int B, T, C;
     float rate; const uint64_t* rng; uint32_t sid1, sid2;
     const int64_t* mpos; int M; int head;
-    bf16 *ao, *a1, *pre_f, *f, *o, *y, *pre_t, *so, *hrows;
+    bf16 *ao, *a1, *pre_f, *f, *o, *y, *pre_t, *so, *hrows;   // pre_f / pre_t receive gelu'(pre-activation)
     float *st1, *st2, *st3;
 };
 
 template <int CT>
 struct TailGeom {
     static constexpr int C = 16 * CT, NW = CT, NTHR = 64 * CT, LD = C + 8, CV = C / 8;
+    static constexpr int LDF = C + 4;                                  // f32 staging image [112][LDF] over buffers A + S
     static constexpr size_t BUF = (size_t)MAXRT * 16 * LD * sizeof(bf16);
+    static_assert((size_t)MAXRT * 16 * LDF * sizeof(float) <= 2 * BUF, "f32 staging image exceeds two buffers");
     static constexpr size_t SMEM = 4 * BUF + 64 * sizeof(float);
-    static constexpr size_t SMEM_BWD = SMEM + (size_t)(MAXRT * 16 + 256) * sizeof(int);   // + rowmap [112] + nextj [<= 256]
+    static constexpr size_t SMEM_BWD = SMEM + (size_t)(MAXRT * 16 + 512) * sizeof(int);   // + rowmap [112] + nextj, positions [<= 256 each]
 };
 
 // rows [0, T) of a [T, C] global tensor (row stride ld) -> LDS image [112][LD]; rows >= T are zero
@@ -72,6 +86,36 @@ __device__ __forceinline__ void copy_out(bf16* dst, long ld, const bf16* src, in
     for (int v = threadIdx.x; v < T * G::CV; v += G::NTHR) {
         const int row = v / G::CV, cv = v % G::CV;
         *reinterpret_cast<uint4*>(dst + (long)row * ld + cv * 8) = *reinterpret_cast<const uint4*>(src + row * G::LD + cv * 8);
+    }
+}
+
+// f32 image stg [112][LDF] of dense outputs (bias not yet added; `bias` = the C biases of these columns) -> with pre = . + bias:
+// dact = gelu'(pre) (bf16, global) and act = gelu(pre) (bf16, global + LDS image act_s).  A thread keeps its 8 columns
+// over all its rows.
+template <int CT>
+__device__ __forceinline__ void gelu_pass(const float* stg, const float* bias, bf16* dact_g, bf16* act_g, long ldg, bf16* act_s, int T) {
+    using G = TailGeom<CT>;
+    static_assert(G::NTHR % G::CV == 0, "a thread's column group must not change from row to row");
+    const int cv = threadIdx.x % G::CV;
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + cv * 8), b1 = *reinterpret_cast<const float4*>(bias + cv * 8 + 4);
+#pragma unroll 1
+    for (int row = threadIdx.x / G::CV; row < MAXRT * 16; row += G::NTHR / G::CV) {
+        const float4 x0 = *reinterpret_cast<const float4*>(stg + row * G::LDF + cv * 8);
+        const float4 x1 = *reinterpret_cast<const float4*>(stg + row * G::LDF + cv * 8 + 4);
+        const float x[8] = {x0.x + b0.x, x0.y + b0.y, x0.z + b0.z, x0.w + b0.w, x1.x + b1.x, x1.y + b1.y, x1.z + b1.z, x1.w + b1.w};
+        Vec16<bf16> dact, act;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {    // gelu_t / dgelu_t<bf16> of edgl_common.h with the erf shared
+            float e;
+            const float cdf = 0.5f * (1.0f + erf_as(x[j] * 0.70710678118654752440f, e));
+            act.v[j] = from_f32<bf16>(x[j] * cdf);
+            dact.v[j] = from_f32<bf16>(cdf + x[j] * (0.39894228040143267794f * e));
+        }
+        st16<bf16>(act_s + row * G::LD + cv * 8, act);
+        if (row < T) {
+            st16<bf16>(dact_g + (long)row * ldg + cv * 8, dact);
+            st16<bf16>(act_g + (long)row * ldg + cv * 8, act);
+        }
     }
 }
 
@@ -151,19 +195,22 @@ __device__ __forceinline__ void joint_moments(const float (&z)[MAXRT][4], int nr
 }
 
 // Four LDS images per workgroup: A (att -> y), B (x_in -> a1 -> LN3 rows), C (f halves, so), S (staging of the tensors
-// that only pass through: ao, pre_f, o, pre_t).  Everything leaves for HBM as whole 256-byte rows (copy_out); storing
+// that only pass through: ao, o); A + S together hold the f32 pre-activations of a GELU pass.  Everything leaves for HBM as whole 256-byte rows (copy_out); storing
 // the pass-through tensors straight from the accumulator registers (8 bytes per lane) measured slower (88 vs 83 us).
-template <int CT>
+// NRT = 7: the row-tile count as a constant (T in 97..112, the benchmark shape) — every `rt < nrt` guard folds away and the
+// seven accumulator tiles stay seven independent tuples; NRT = 0: run-time count (short sequences skip their empty tiles).
+template <int CT, int NRT>
 __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     using G = TailGeom<CT>;
     constexpr int C = G::C, LD = G::LD, NKB = C / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* bufA = reinterpret_cast<bf16*>(smem);
-    bf16* bufB = reinterpret_cast<bf16*>(smem + G::BUF);
-    bf16* bufC = reinterpret_cast<bf16*>(smem + 2 * G::BUF);
-    bf16* bufS = reinterpret_cast<bf16*>(smem + 3 * G::BUF);
+    bf16* bufS = reinterpret_cast<bf16*>(smem + G::BUF);
+    bf16* bufB = reinterpret_cast<bf16*>(smem + 2 * G::BUF);
+    bf16* bufC = reinterpret_cast<bf16*>(smem + 3 * G::BUF);
+    float* stg = reinterpret_cast<float*>(smem);             // f32 image over A + S while neither holds a tensor
     float* red = reinterpret_cast<float*>(smem + 4 * G::BUF);
-    const int b = blockIdx.x, T = p.T, nrt = (T + 15) / 16;
+    const int b = blockIdx.x, T = p.T, nrt = NRT ? NRT : (T + 15) / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const int n0 = wave * 16, nl = n0 + g4;                 // this lane's 4 output channels: nl .. nl + 3
     const long row0 = (long)b * T;
@@ -236,30 +283,19 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
             tile_gemm<CT, NKB>(wf, bufB, nrt, lane, acc);
             wf = load_wfrags<NKB>(p.WoutT + (long)n0 * 2 * C + h * C, 2 * C, lane);
             EDGL_PIN();
-            const float4 bb = *reinterpret_cast<const float4*>(p.bi + h * C + nl);
-            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-            for (int rt = 0; rt < MAXRT; ++rt)
-                if (rt < nrt) {
-                    const int row = rt * 16 + l15;
-                    float pre[4], fv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { pre[r] = acc[rt][r] + bv[r]; fv[r] = GELU_TAIL(pre[r]); }
-                    st_bf4(bufS + row * LD + nl, pre);
-                    st_bf4(bufC + row * LD + nl, fv);
-                    TAIL_FENCE();
-                }
+            for (int rt = 0; rt < MAXRT; ++rt)   // all 7 tiles, unconditionally (tiles >= nrt hold zeros)
+                *reinterpret_cast<float4*>(stg + (rt * 16 + l15) * G::LDF + nl) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
         }
+        lds_barrier();   // (every wave is also past its reads of the previous half's f image)
+        gelu_pass<CT>(stg, p.bi + h * C, p.pre_f + row0 * 2 * C + h * C, p.f + row0 * 2 * C + h * C, 2 * C, bufC, T);
         PH_MARK(5);   // G2 half + GELU
         lds_barrier();
-        copy_out<CT>(p.pre_f + row0 * 2 * C + h * C, 2 * C, bufS, T);
-        copy_out<CT>(p.f + row0 * 2 * C + h * C, 2 * C, bufC, T);
         tile_gemm<CT, NKB>(wf, bufC, nrt, lane, acc3);
         // next: second half of the inner dense, then the head transform (fetched even when this block has no head: cheap)
         wf = h == 0 ? load_wfrags<NKB>(p.WiT + (long)(C + n0) * C, C, lane) : load_wfrags<NKB>(p.WtT + (long)n0 * C, C, lane);
         EDGL_PIN();
-        lds_barrier();
-        PH_MARK(6);   // barrier + copy_out(pre_f, f) + G3 half + barrier
+        PH_MARK(6);   // G3 half
     }
     // ---- o = . + bout ; z2 = drop(o) + a1 ; y = LN2(z2) (EasyDGL.py:126-128) -> A ---------------------------------------------
     {
@@ -299,7 +335,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     lds_barrier();
     copy_out<CT>(p.y + row0 * C, C, bufA, T);
     PH_MARK(7);   // o, LN2, y
-#ifdef EDGL_PHASE_TIMING
+#if defined(EDGL_PHASE_TIMING) && !defined(EDGL_PHASE_BWD)
     PH_FLUSH(0); ph_acc[0] = 0; ph_t0 = __builtin_readcyclecounter();
 #endif
     if (!p.head) return;
@@ -309,23 +345,16 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
         tile_gemm<CT, NKB>(wf, bufA, nrt, lane, acc);
-        const float4 bb = *reinterpret_cast<const float4*>(p.bt + nl);
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+        lds_barrier();   // y (buffer A) is overwritten by the f32 image
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
-            if (rt < nrt) {
-                const int row = rt * 16 + l15;
-                float pre[4], sv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { pre[r] = acc[rt][r] + bv[r]; sv[r] = GELU_TAIL(pre[r]); z[rt][r] = rbf(sv[r]); }
-                st_bf4(bufS + row * LD + nl, pre);
-                st_bf4(bufC + row * LD + nl, sv);
-                TAIL_FENCE();
-            }
+            *reinterpret_cast<float4*>(stg + (rt * 16 + l15) * G::LDF + nl) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
     }
     lds_barrier();
-    copy_out<CT>(p.pre_t + row0 * C, C, bufS, T);
-    copy_out<CT>(p.so + row0 * C, C, bufC, T);
+    gelu_pass<CT>(stg, p.bt, p.pre_t + row0 * C, p.so + row0 * C, C, bufC, T);
+    lds_barrier();
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) ld_bf4(bufC + (rt * 16 + l15) * LD + nl, z[rt]);   // so, rounded through the activation dtype
     {
         float mean, rstd;
         joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
@@ -347,7 +376,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
         const int t = (int)p.mpos[(long)b * p.M + j];
         *reinterpret_cast<uint4*>(p.hrows + ((long)b * p.M + j) * C + cv * 8) = *reinterpret_cast<const uint4*>(bufB + t * LD + cv * 8);
     }
-#ifdef EDGL_PHASE_TIMING
+#if defined(EDGL_PHASE_TIMING) && !defined(EDGL_PHASE_BWD)
     PH_MARK(0);   // head (slot 8)
     if ((threadIdx.x & 63) == 0) atomicAdd(&g_phase_cycles[8], ph_acc[0]);
 #endif
@@ -363,7 +392,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
 struct TailBwdP {
     // saved by the forward
     const bf16 *xin; int ld_x;
-    const bf16 *ao, *a1, *pre_f, *o, *pre_t, *so;
+    const bf16 *ao, *a1, *pre_f, *o, *pre_t, *so;   // pre_f / pre_t: gelu'(pre-activation), as edgl_tail_fwd wrote them
     const float *st1, *st2, *st3;
     const bf16 *Wo, *Wi, *Wout, *Wt;          // [in, out] compute copies
     const float *g1, *g2, *g3;
@@ -422,19 +451,20 @@ __device__ __forceinline__ void ln_bwd_regs(const float (&z)[MAXRT][4], const fl
         }
 }
 
-template <int CT>
+template <int CT, int NRT>
 __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     using G = TailGeom<CT>;
     constexpr int C = G::C, LD = G::LD, NKB = C / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* bufA = reinterpret_cast<bf16*>(smem);
-    bf16* bufB = reinterpret_cast<bf16*>(smem + G::BUF);
-    bf16* bufC = reinterpret_cast<bf16*>(smem + 2 * G::BUF);
-    bf16* bufS = reinterpret_cast<bf16*>(smem + 3 * G::BUF);
+    bf16* bufS = reinterpret_cast<bf16*>(smem + G::BUF);
+    bf16* bufB = reinterpret_cast<bf16*>(smem + 2 * G::BUF);
+    bf16* bufC = reinterpret_cast<bf16*>(smem + 3 * G::BUF);
     float* red = reinterpret_cast<float*>(smem + 4 * G::BUF);
     int* rowmap = reinterpret_cast<int*>(red + 64);          // [T] head of the chain of gathered rows naming position t
     int* nextj = rowmap + MAXRT * 16;                        // [M]
-    const int b = blockIdx.x, T = p.T, nrt = (T + 15) / 16;
+    int* mpos_s = nextj + 256;                               // [M] masked positions of this sample
+    const int b = blockIdx.x, T = p.T, nrt = NRT ? NRT : (T + 15) / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const int n0 = wave * 16, nl = n0 + g4;
     const long row0 = (long)b * T;
@@ -442,37 +472,81 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     float z[MAXRT][4], dy[MAXRT][4], dz[MAXRT][4];
     // weight fragments of the next product, fetched one product ahead (see load_wfrags)
     WFrags<NKB> wf = p.head ? load_wfrags<NKB>(p.Wt + (long)n0 * C, C, lane) : load_wfrags<NKB>(p.Wout + (long)n0 * C, C, lane);
+    PHB_DECL
 
     if (p.head) {
         // ---- LN3' on the gathered rows, GELU' -> d_pre_t (EasyDGL.py:136-146 backward) ------------------------------------
-        copy_in<CT>(bufA, p.so + row0 * C, C, T);
-        copy_in<CT>(bufB, p.pre_t + row0 * C, C, T);
+        // the M gathered row gradients of this sample -> buffer C rows [0, M) (compacted-away rows as zeros): walking the
+        // chains below against global memory cost one round trip per link and row tile (50 of the head block's 117 k cycles).
+        // Their row indices are fetched first, so that the second hop travels with the two images.
+        const bool staged = p.M <= MAXRT * 16;
+        constexpr int NG = (MAXRT * 16 * G::CV + G::NTHR - 1) / G::NTHR;
+        long gsrc[NG];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int v = threadIdx.x + i * G::NTHR, j = min(v / G::CV, p.M - 1);
+            gsrc[i] = (long)b * p.M + j;
+            if (staged && p.rowmap) gsrc[i] = p.rowmap[gsrc[i]];
+        }
+        for (int j = threadIdx.x; j < p.M; j += G::NTHR) mpos_s[j] = (int)p.mpos[(long)b * p.M + j];
         for (int t = threadIdx.x; t < MAXRT * 16; t += G::NTHR) rowmap[t] = -1;
-        lds_barrier();
-        if (threadIdx.x == 0)
-            for (int j = p.M - 1; j >= 0; --j) {     // chains in ascending j (the order the unfused kernel sums in)
-                const int t = (int)p.mpos[(long)b * p.M + j];
-                nextj[j] = rowmap[t];
-                rowmap[t] = j;
+        if (staged) {
+            Vec16<bf16> g[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int cv = (threadIdx.x + i * G::NTHR) % G::CV;
+                g[i] = ld16<bf16>(p.d_rows + max(gsrc[i], 0L) * C + cv * 8);
             }
+            copy_in<CT>(bufB, p.so + row0 * C, C, T);
+            copy_in<CT>(bufA, p.pre_t + row0 * C, C, T);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const int v = threadIdx.x + i * G::NTHR, j = v / G::CV, cv = v % G::CV;
+                if (j < p.M) st16<bf16>(bufC + j * LD + cv * 8, gsrc[i] >= 0 ? g[i] : zero16<bf16>());
+            }
+        } else {
+            copy_in<CT>(bufB, p.so + row0 * C, C, T);
+            copy_in<CT>(bufA, p.pre_t + row0 * C, C, T);
+        }
+        lds_barrier();
+        // chains of the gathered rows naming one position, in ascending j (the order the unfused kernel sums in): row j links to
+        // the next larger j' with the same position; the smallest j of a position is its head
+        for (int j = threadIdx.x; j < p.M; j += G::NTHR) {
+            const int t = mpos_s[j];
+            int nxt = -1;
+            bool first = true;
+#pragma unroll 8
+            for (int k = 0; k < p.M; ++k) {          // uniform trip count: the LDS reads of an unrolled group travel together
+                const bool same = mpos_s[k] == t;
+                nxt = (same && k > j && nxt < 0) ? k : nxt;
+                first = first && !(same && k < j);
+            }
+            nextj[j] = nxt;
+            if (first) rowmap[t] = j;
+        }
         lds_barrier();
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt) {
             const int row = rt * 16 + l15;
-            ld_bf4(bufA + row * LD + nl, z[rt]);
+            ld_bf4(bufB + row * LD + nl, z[rt]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) dy[rt][r] = 0.f;
             if (rt < nrt && row < T)
                 for (int j = rowmap[row]; j >= 0; j = nextj[j]) {
-                    long src = (long)b * p.M + j;
-                    if (p.rowmap) src = p.rowmap[src];
-                    if (src < 0) continue;
                     float v[4];
-                    ld_bf4(p.d_rows + src * C + nl, v);
+                    if (staged) {
+                        ld_bf4(bufC + j * LD + nl, v);
+                    } else {
+                        long src = (long)b * p.M + j;
+                        if (p.rowmap) src = p.rowmap[src];
+                        if (src < 0) continue;
+                        ld_bf4(p.d_rows + src * C + nl, v);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dy[rt][r] += v[r];
                 }
         }
+        PHB_MARK(0);   // head inputs, gathered row gradients
         {
             const float4 gg = *reinterpret_cast<const float4*>(p.g3 + nl);
             const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
@@ -482,12 +556,10 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         for (int rt = 0; rt < MAXRT; ++rt)
             if (rt < nrt) {
                 const int row = rt * 16 + l15;
-                float pre[4], v[4];
-                ld_bf4(bufB + row * LD + nl, pre);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = dz[rt][r] * DGELU_TAIL(pre[r]);
+                float dg[4];
+                ld_bf4(bufA + row * LD + nl, dg);
+                const float v[4] = {dz[rt][0] * dg[0], dz[rt][1] * dg[1], dz[rt][2] * dg[2], dz[rt][3] * dg[3]};
                 st_bf4(bufC + row * LD + nl, v);
-                TAIL_FENCE();
             }
         lds_barrier();
         copy_out<CT>(p.d_pre_t + row0 * C, C, bufC, T);
@@ -502,6 +574,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dy[rt][r] = rbf(acc[rt][r]);
         lds_barrier();     // bufA / bufB / bufC are rewritten below
+        PHB_MARK(1);   // LN3', gelu', dX(Wt)
     } else {
         copy_in<CT>(bufA, p.d_y_in + row0 * C, C, T);
         lds_barrier();
@@ -522,6 +595,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[rt][r] = drop_apply(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), ov[r]) + av[r];
     }
+    PHB_MARK(2);   // o, a1 -> z2
     {
         const float4 gg = *reinterpret_cast<const float4*>(p.g2 + nl);
         const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
@@ -542,6 +616,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         }
     lds_barrier();
     copy_out<CT>(p.d_o + row0 * C, C, bufC, T);
+    PHB_MARK(3);   // LN2', d_o
     // ---- d_pre_f = (d_o . Wout^T) * gelu'(pre_f), two halves of the 2C hidden channels; d_a1 += d_pre_f . Wi^T -------------------
     f32x4 acc6[MAXRT];
 #pragma unroll
@@ -554,17 +629,15 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
             for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
             tile_dx<CT, NKB>(wf, bufC, nrt, lane, acc);
             wf = load_wfrags<NKB>(p.Wi + (long)n0 * 2 * C + h * C, 2 * C, lane);
-            lds_barrier();   // pre_f half in place (and, for h = 1, every wave past its reads of the previous d_pre_f half)
+            lds_barrier();   // gelu'(pre_f half) in place (and, for h = 1, every wave past its reads of the previous d_pre_f half)
 #pragma unroll
             for (int rt = 0; rt < MAXRT; ++rt)
                 if (rt < nrt) {
                     const int row = rt * 16 + l15;
-                    float pre[4], v[4];
-                    ld_bf4(bufA + row * LD + nl, pre);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[rt][r] * DGELU_TAIL(pre[r]);
+                    float dg[4];
+                    ld_bf4(bufA + row * LD + nl, dg);
+                    const float v[4] = {acc[rt][0] * dg[0], acc[rt][1] * dg[1], acc[rt][2] * dg[2], acc[rt][3] * dg[3]};
                     st_bf4(bufB + row * LD + nl, v);
-                    TAIL_FENCE();
                 }
         }
         lds_barrier();
@@ -577,6 +650,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     for (int rt = 0; rt < MAXRT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dy[rt][r] = rbf(acc6[rt][r] + da1[rt][r]);
+    PHB_MARK(4);   // the two halves of the hidden layer
     // ---- LN1': z1 = drop(ao) + x_in ; d_ao = drop(d_z1) ; d_res1 = d_z1 (EasyDGL.py:113-116 backward) ------------------------------
     copy_in<CT>(bufA, p.ao + row0 * C, C, T);
     copy_in<CT>(bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
@@ -590,6 +664,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[rt][r] = drop_apply(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), ov[r]) + xv[r];
     }
+    PHB_MARK(5);   // ao, x_in -> z1
     {
         const float4 gg = *reinterpret_cast<const float4*>(p.g1 + nl);
         const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
@@ -611,6 +686,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     lds_barrier();
     copy_out<CT>(p.d_ao + row0 * C, C, bufC, T);
     copy_out<CT>(p.d_res1 + row0 * C, C, bufS, T);
+    PHB_MARK(6);   // LN1', d_ao, d_res1
     // ---- d_att = d_ao . Wo^T ---------------------------------------------------------------------------------------------------------
     {
         f32x4 acc[MAXRT];
@@ -626,6 +702,8 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     }
     lds_barrier();
     copy_out<CT>(p.d_att + row0 * C, C, bufA, T);
+    PHB_MARK(7);   // dX(Wo), d_att
+    PHB_FLUSH();
 }
 
 // dst[n][k] = src[k][n]  (tf.layers.dense kernels are [in, out]; the MFMA A operand wants k contiguous)
@@ -677,13 +755,11 @@ extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const v
             B, T, C, drop_rate, rng_state, sid1, sid2, masked_pos, M, head, (bf16*)ao, (bf16*)a1, (bf16*)pre_f, (bf16*)f, (bf16*)o,
             (bf16*)y, (bf16*)pre_t, (bf16*)so, (bf16*)hrows, st1, st2, st3};
     hipStream_t st = (hipStream_t)stream;
-    if (C == 128) {
-        hipFuncSetAttribute((const void*)tail_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailGeom<8>::SMEM);
-        hipLaunchKernelGGL((tail_fwd_kernel<8>), dim3(B), dim3(512), TailGeom<8>::SMEM, st, p);
-    } else {
-        hipFuncSetAttribute((const void*)tail_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailGeom<4>::SMEM);
-        hipLaunchKernelGGL((tail_fwd_kernel<4>), dim3(B), dim3(256), TailGeom<4>::SMEM, st, p);
-    }
+    const bool full = (T + 15) / 16 == MAXRT;
+    auto k = C == 128 ? (full ? tail_fwd_kernel<8, MAXRT> : tail_fwd_kernel<8, 0>) : (full ? tail_fwd_kernel<4, MAXRT> : tail_fwd_kernel<4, 0>);
+    const size_t smem = C == 128 ? TailGeom<8>::SMEM : TailGeom<4>::SMEM;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k, dim3(B), dim3(C == 128 ? 512 : 256), smem, st, p);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
@@ -709,13 +785,11 @@ extern "C" int edgl_tail_bwd(const void* xin, int ld_x, const void* ao, const vo
                drop_rate, rng_state, sid1, sid2, head, (const bf16*)d_rows, masked_pos, M, dy_rowmap, (const bf16*)d_y_in,
                (bf16*)d_pre_t, (bf16*)d_o, (bf16*)d_pre_f, (bf16*)d_ao, (bf16*)d_res1, (bf16*)d_att, part1, part2, part3};
     hipStream_t st = (hipStream_t)stream;
-    if (C == 128) {
-        hipFuncSetAttribute((const void*)tail_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailGeom<8>::SMEM_BWD);
-        hipLaunchKernelGGL((tail_bwd_kernel<8>), dim3(B), dim3(512), TailGeom<8>::SMEM_BWD, st, p);
-    } else {
-        hipFuncSetAttribute((const void*)tail_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailGeom<4>::SMEM_BWD);
-        hipLaunchKernelGGL((tail_bwd_kernel<4>), dim3(B), dim3(256), TailGeom<4>::SMEM_BWD, st, p);
-    }
+    const bool full = (T + 15) / 16 == MAXRT;
+    auto k = C == 128 ? (full ? tail_bwd_kernel<8, MAXRT> : tail_bwd_kernel<8, 0>) : (full ? tail_bwd_kernel<4, MAXRT> : tail_bwd_kernel<4, 0>);
+    const size_t smem = C == 128 ? TailGeom<8>::SMEM_BWD : TailGeom<4>::SMEM_BWD;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(k, dim3(B), dim3(C == 128 ? 512 : 256), smem, st, p);
     EDGL_LAUNCH_CHECK();
     // (dbeta | dgamma) per sample -> parameter gradients, fixed order (deferred-reduction aware)
     auto red2 = [&](float* part, float* dg, float* db) -> int {

@@ -472,9 +472,11 @@ int edgl_time_function_bwd(const float* x, long n, const float* freq, const floa
  *   ao = att.Wo + bo ; a1 = LN1(dropout(ao) + x_in) ; f = gelu(a1.Wi + bi) ; o = f.Wout + bout ; y = LN2(dropout(o) + a1)
  *   head != 0:  so = gelu(y.Wt + bt) ; hrows[b*M + j] = LN3(so)[masked_pos[b, j]]                     (EasyDGL.py:136-146)
  * with the activations in LDS between the steps; every intermediate the backward reads is written once:
- * ao, a1, o, y, pre_t, so [B,T,C]; pre_f, f [B,T,2C]; st1/st2/st3 f32 [B,2] = (mean, rstd).  Same arithmetic, the same
- * dropout element indices (streams sid1 / sid2) and the same saved tensors as edgl_gemm + edgl_add_layernorm_fwd, which
- * remain the path for every other shape: edgl_tail_supported(T, C, dtype) != 0 iff dtype is EDGL_BF16, C in {64, 128},
+ * ao, a1, o, y, pre_t, so [B,T,C]; pre_f, f [B,T,2C]; st1/st2/st3 f32 [B,2] = (mean, rstd).  pre_f and pre_t receive
+ * gelu'(pre-activation), not the pre-activation: the derivative is all edgl_tail_bwd needs them for, and the forward has the
+ * erf at hand (the unfused kernels save the pre-activation itself — do not mix the two paths within a block).  Otherwise the
+ * same arithmetic, the same dropout element indices (streams sid1 / sid2) and the same saved tensors as edgl_gemm +
+ * edgl_add_layernorm_fwd, which remain the path for every other shape: edgl_tail_supported(T, C, dtype) != 0 iff dtype is EDGL_BF16, C in {64, 128},
  * T <= 112.  att [B,T,C]; xin = the block input's first C channels, row stride ld_x.
  * pack: edgl_tail_pack_elems(C) elements of `dtype` written by edgl_tail_pack from the four [in, out] kernels (compute
  * copies) — their [out][in] images, the MFMA operand layout. */
@@ -490,7 +492,8 @@ int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const void* pack, 
 
 /* Backward of the same chain, one launch per block: given the gradient of the gathered head rows (head != 0: d_rows [*, C]
  * compact, masked_pos [B, M], dy_rowmap = the `inv` map of edgl_compact_rows or NULL) or of y (head == 0: d_y_in [B,T,C]),
- * recomputes the three LayerNorm inputs from the saved tensors and writes what the weight-gradient GEMMs consume:
+ * recomputes the three LayerNorm inputs from the saved tensors (pre_f / pre_t as edgl_tail_fwd wrote them: gelu') and writes
+ * what the weight-gradient GEMMs consume:
  * d_pre_t, d_o, d_ao [B,T,C] and d_pre_f [B,T,2C] (gradients w.r.t. the four dense outputs), d_res1 (gradient into the LN1
  * residual x_in[:, :, :C]) and d_att (gradient w.r.t. the block-tail input); LayerNorm parameter gradients dg*, db*
  * (overwritten; reduced from per-sample partials in `workspace`, edgl_tail_bwd_workspace(B, C) floats).  Wo, Wi, Wout, Wt: the

@@ -138,10 +138,15 @@ def test_fused_block_tail_matches_the_unfused_kernels(case, drop):
                           **{k: b[k].float().clone() for k in ("ao", "a1", "pre_f", "f", "o", "y", "st1", "st2")},
                           pre_t=eng.pre_t.float().clone(), so=eng.so.float().clone(), st3=eng.st3.clone(), hrows=eng.hrows.float().clone())
     a, b = out[False], out[True]
+    for k in ("pre_f", "pre_t"):   # the fused forward saves gelu'(pre-activation) in these buffers (include/easydgl_hip.h),
+        x = a[k].double()          # rounded to bf16 once more
+        a[k] = (0.5 * (1.0 + torch.erf(x / 2.0 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2.0 * torch.pi) ** 0.5).float()
+        a[k], b[k] = a[k].bfloat16().float(), b[k].bfloat16().float()
     for k in ("ao", "a1", "pre_f", "f", "o", "y", "pre_t", "so", "hrows", "st1", "st2", "st3"):
         err = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-30))
         assert err < 1.6e-2, (k, err)           # one bf16 ulp (2^-7 relative) of the largest element
-        if not k.startswith("st"):   # ... and only on a few elements (the [B, 2] statistics differ in their last f32 digits)
+        if not k.startswith("st") and k not in ("pre_f", "pre_t"):   # ... and only on a few elements (the [B, 2] statistics differ
+            # in their last f32 digits; gelu' of the rounded vs the unrounded pre-activation differs by an ulp on many elements)
             assert float(((a[k] - b[k]).abs() > 1e-6 * a[k].abs().max()).float().mean()) < 0.05, k
     assert abs(a["loss"] - b["loss"]) <= 2e-3 * abs(a["loss"])
     assert rel_err(b["grads"].cpu().numpy(), a["grads"].cpu().numpy()) < 2e-2
