@@ -61,24 +61,49 @@ struct TailGeom {
     static constexpr size_t SMEM_BWD = SMEM + (size_t)(MAXRT * 16 + 512) * sizeof(int);   // + rowmap [112] + nextj, positions [<= 256 each]
 };
 
-// rows [0, T) of a [T, C] global tensor (row stride ld) -> LDS image [112][LD]; rows >= T are zero
+// rows [0, T) of a [T, C] global tensor (row stride ld) -> LDS image [112][LD]; rows >= T are zero.  load() issues every
+// 16-byte vector of the image, store() writes them to the LDS: all loads of a phase — of BOTH its images — go out before the
+// first store (a load / store loop pays one HBM round trip per 8 KB of a 512-thread workgroup, two copies one after the
+// other pay two).  Straight-line code: rows are clamped, and the threads that have no vector of their own in the last round
+// repeat one of the same round (same data to the same address) — a guard there puts the load and its wait inside a branch.
+template <int CT>
+struct RowImage {
+    using G = TailGeom<CT>;
+    static constexpr int NV = MAXRT * 16 * G::CV, NI = (NV + G::NTHR - 1) / G::NTHR;
+    static_assert(NI * G::NTHR - NV < G::NTHR && NV >= G::NTHR, "last round: at most one repeat per thread");
+    uint4 d[NI];
+    static __device__ __forceinline__ int vec(int i) {
+        const int v = threadIdx.x + i * G::NTHR;
+        return v < NV ? v : v - (NI * G::NTHR - NV);
+    }
+    __device__ __forceinline__ void load(const bf16* src, long ld, int T) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int v = vec(i), row = v / G::CV, cv = v % G::CV;
+            d[i] = *reinterpret_cast<const uint4*>(src + (long)min(row, T - 1) * ld + cv * 8);
+        }
+    }
+    __device__ __forceinline__ void store(bf16* dst, int T) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int v = vec(i), row = v / G::CV, cv = v % G::CV;
+            *reinterpret_cast<uint4*>(dst + row * G::LD + cv * 8) = row < T ? d[i] : make_uint4(0, 0, 0, 0);
+        }
+    }
+};
 template <int CT>
 __device__ __forceinline__ void copy_in(bf16* dst, const bf16* src, long ld, int T) {
-    using G = TailGeom<CT>;
-    // all loads of the image are issued before the first LDS store (rows clamped: straight-line code); a load / store
-    // loop pays one HBM round trip per 8 KB of a 512-thread workgroup
-    constexpr int NV = MAXRT * 16 * G::CV, NI = (NV + G::NTHR - 1) / G::NTHR;
-    uint4 d[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int v = threadIdx.x + i * G::NTHR, row = v / G::CV, cv = v % G::CV;
-        d[i] = *reinterpret_cast<const uint4*>(src + (long)min(row, T - 1) * ld + cv * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int v = threadIdx.x + i * G::NTHR, row = v / G::CV, cv = v % G::CV;
-        if (v < NV) *reinterpret_cast<uint4*>(dst + row * G::LD + cv * 8) = row < T ? d[i] : make_uint4(0, 0, 0, 0);
-    }
+    RowImage<CT> a;
+    a.load(src, ld, T);
+    a.store(dst, T);
+}
+template <int CT>
+__device__ __forceinline__ void copy_in2(bf16* dst0, const bf16* src0, long ld0, bf16* dst1, const bf16* src1, long ld1, int T) {
+    RowImage<CT> a, b;
+    a.load(src0, ld0, T);
+    b.load(src1, ld1, T);
+    a.store(dst0, T);
+    b.store(dst1, T);
 }
 template <int CT>
 __device__ __forceinline__ void copy_out(bf16* dst, long ld, const bf16* src, int T) {
@@ -218,8 +243,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
 
     PH_DECL
     WFrags<NKB> wf = load_wfrags<NKB>(p.WoT + (long)n0 * C, C, lane);
-    copy_in<CT>(bufA, p.att + row0 * C, C, T);
-    copy_in<CT>(bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
+    copy_in2<CT>(bufA, p.att + row0 * C, C, bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
     lds_barrier();
     PH_MARK(0);   // inputs in LDS
     float z[MAXRT][4];
@@ -468,7 +492,6 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const int n0 = wave * 16, nl = n0 + g4;
     const long row0 = (long)b * T;
-    const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
     float z[MAXRT][4], dy[MAXRT][4], dz[MAXRT][4];
     // weight fragments of the next product, fetched one product ahead (see load_wfrags)
     WFrags<NKB> wf = p.head ? load_wfrags<NKB>(p.Wt + (long)n0 * C, C, lane) : load_wfrags<NKB>(p.Wout + (long)n0 * C, C, lane);
@@ -480,34 +503,37 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         // chains below against global memory cost one round trip per link and row tile (50 of the head block's 117 k cycles).
         // Their row indices are fetched first, so that the second hop travels with the two images.
         const bool staged = p.M <= MAXRT * 16;
-        constexpr int NG = (MAXRT * 16 * G::CV + G::NTHR - 1) / G::NTHR;
-        long gsrc[NG];
+        constexpr int NG = RowImage<CT>::NI;
+        int gsrc[NG];
+        if (staged && p.rowmap) {      // (uniform branch; straight-line loads inside)
 #pragma unroll
-        for (int i = 0; i < NG; ++i) {
-            const int v = threadIdx.x + i * G::NTHR, j = min(v / G::CV, p.M - 1);
-            gsrc[i] = (long)b * p.M + j;
-            if (staged && p.rowmap) gsrc[i] = p.rowmap[gsrc[i]];
+            for (int i = 0; i < NG; ++i) gsrc[i] = p.rowmap[(long)b * p.M + min(RowImage<CT>::vec(i) / G::CV, p.M - 1)];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NG; ++i) gsrc[i] = b * p.M + min(RowImage<CT>::vec(i) / G::CV, p.M - 1);
         }
-        for (int j = threadIdx.x; j < p.M; j += G::NTHR) mpos_s[j] = (int)p.mpos[(long)b * p.M + j];
-        for (int t = threadIdx.x; t < MAXRT * 16; t += G::NTHR) rowmap[t] = -1;
+        const int my_pos = (int)p.mpos[(long)b * p.M + min((int)threadIdx.x, p.M - 1)];      // M <= 256 <= threads
+        RowImage<CT> im_so, im_dg;
+        im_so.load(p.so + row0 * C, C, T);
+        im_dg.load(p.pre_t + row0 * C, C, T);
         if (staged) {
-            Vec16<bf16> g[NG];
+            uint4 g[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+                g[i] = *reinterpret_cast<const uint4*>(p.d_rows + (long)max(gsrc[i], 0) * C + (RowImage<CT>::vec(i) % G::CV) * 8);
+            im_so.store(bufB, T);
+            im_dg.store(bufA, T);
 #pragma unroll
             for (int i = 0; i < NG; ++i) {
-                const int cv = (threadIdx.x + i * G::NTHR) % G::CV;
-                g[i] = ld16<bf16>(p.d_rows + max(gsrc[i], 0L) * C + cv * 8);
-            }
-            copy_in<CT>(bufB, p.so + row0 * C, C, T);
-            copy_in<CT>(bufA, p.pre_t + row0 * C, C, T);
-#pragma unroll
-            for (int i = 0; i < NG; ++i) {
-                const int v = threadIdx.x + i * G::NTHR, j = v / G::CV, cv = v % G::CV;
-                if (j < p.M) st16<bf16>(bufC + j * LD + cv * 8, gsrc[i] >= 0 ? g[i] : zero16<bf16>());
+                const int v = RowImage<CT>::vec(i), j = v / G::CV, cv = v % G::CV;
+                if (j < p.M) *reinterpret_cast<uint4*>(bufC + j * LD + cv * 8) = gsrc[i] >= 0 ? g[i] : make_uint4(0, 0, 0, 0);
             }
         } else {
-            copy_in<CT>(bufB, p.so + row0 * C, C, T);
-            copy_in<CT>(bufA, p.pre_t + row0 * C, C, T);
+            im_so.store(bufB, T);
+            im_dg.store(bufA, T);
         }
+        if ((int)threadIdx.x < p.M) mpos_s[threadIdx.x] = my_pos;
+        for (int t = threadIdx.x; t < MAXRT * 16; t += G::NTHR) rowmap[t] = -1;
         lds_barrier();
         // chains of the gathered rows naming one position, in ascending j (the order the unfused kernel sums in): row j links to
         // the next larger j' with the same position; the smallest j of a position is its head
@@ -525,27 +551,47 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
             if (first) rowmap[t] = j;
         }
         lds_barrier();
+        // first link of every row tile's chain as straight-line code (heads, rows, next links: three rounds of LDS reads for
+        // all seven tiles instead of three dependent reads per tile); longer chains — repeated positions — in the loop below
+        int jn[MAXRT];
+        {
+            int jh[MAXRT];
 #pragma unroll
-        for (int rt = 0; rt < MAXRT; ++rt) {
-            const int row = rt * 16 + l15;
-            ld_bf4(bufB + row * LD + nl, z[rt]);
+            for (int rt = 0; rt < MAXRT; ++rt) {
+                const int row = rt * 16 + l15;
+                ld_bf4(bufB + row * LD + nl, z[rt]);
+                jh[rt] = (rt < nrt && row < T) ? rowmap[row] : -1;
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dy[rt][r] = 0.f;
-            if (rt < nrt && row < T)
-                for (int j = rowmap[row]; j >= 0; j = nextj[j]) {
-                    float v[4];
-                    if (staged) {
-                        ld_bf4(bufC + j * LD + nl, v);
-                    } else {
-                        long src = (long)b * p.M + j;
-                        if (p.rowmap) src = p.rowmap[src];
-                        if (src < 0) continue;
-                        ld_bf4(p.d_rows + src * C + nl, v);
-                    }
+            for (int rt = 0; rt < MAXRT; ++rt) {
+                jn[rt] = nextj[max(jh[rt], 0)];
+                if (staged) {
+                    ld_bf4(bufC + max(jh[rt], 0) * LD + nl, dy[rt]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dy[rt][r] += v[r];
+                    for (int r = 0; r < 4; ++r) dy[rt][r] = jh[rt] >= 0 ? dy[rt][r] : 0.f;
+                    jn[rt] = jh[rt] >= 0 ? jn[rt] : -1;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dy[rt][r] = 0.f;
+                    jn[rt] = jh[rt];
                 }
+            }
         }
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)
+            for (int j = jn[rt]; j >= 0; j = nextj[j]) {
+                float v[4];
+                if (staged) {
+                    ld_bf4(bufC + j * LD + nl, v);
+                } else {
+                    long src = (long)b * p.M + j;
+                    if (p.rowmap) src = p.rowmap[src];
+                    if (src < 0) continue;
+                    ld_bf4(p.d_rows + src * C + nl, v);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dy[rt][r] += v[r];
+            }
         PHB_MARK(0);   // head inputs, gathered row gradients
         {
             const float4 gg = *reinterpret_cast<const float4*>(p.g3 + nl);
@@ -583,8 +629,9 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         lds_barrier();
     }
     // ---- LN2': z2 = drop(o) + a1 ; d_o = drop(d_z2) ; d_a1 (residual part) = d_z2 (EasyDGL.py:126-128 backward) -----------------
-    copy_in<CT>(bufA, p.o + row0 * C, C, T);
-    copy_in<CT>(bufB, p.a1 + row0 * C, C, T);
+    // (the dropout keys hang on a load of the generator state: created here, not ahead of the head's loads)
+    const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
+    copy_in2<CT>(bufA, p.o + row0 * C, C, bufB, p.a1 + row0 * C, C, T);
     lds_barrier();
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) {
@@ -652,8 +699,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         for (int r = 0; r < 4; ++r) dy[rt][r] = rbf(acc6[rt][r] + da1[rt][r]);
     PHB_MARK(4);   // the two halves of the hidden layer
     // ---- LN1': z1 = drop(ao) + x_in ; d_ao = drop(d_z1) ; d_res1 = d_z1 (EasyDGL.py:113-116 backward) ------------------------------
-    copy_in<CT>(bufA, p.ao + row0 * C, C, T);
-    copy_in<CT>(bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
+    copy_in2<CT>(bufA, p.ao + row0 * C, C, bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
     lds_barrier();
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) {
