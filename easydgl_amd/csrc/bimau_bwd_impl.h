@@ -104,10 +104,10 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
     const T* dout = reinterpret_cast<const T*>(p.d_out) + (long)b * p.T * p.C;
     T* dqkvt = reinterpret_cast<T*>(p.d_qkvt) + (long)b * p.T * 4 * p.C;
     const int ldq = 4 * p.C;
-    stage_rows<T, DT, NT>(qkvt + p.C + head * dh, ldq, p.T, Ks, nullptr, LDT, lane);
-    stage_rows<T, DT, NT>(qkvt + 2 * p.C + head * dh, ldq, p.T, Vs, nullptr, LDT, lane);
-    stage_marks<T, NT, EC>(p.marks + (long)b * p.T * E, E, p.T, Ms, TR ? nullptr : MTs, LDT, lane);
-    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ks + WAVE_ELEMS - MASK_ELEMS));
+    const KeyMask<NT> km = stage_wave<T, DT, NT, EC>(
+        qkvt + p.C + head * dh, Ks, nullptr, static_cast<const T*>(nullptr), static_cast<T*>(nullptr), static_cast<T*>(nullptr),
+        qkvt + 2 * p.C + head * dh, Vs, nullptr, ldq, p.marks + (long)b * p.T * E, E, Ms, TR ? nullptr : MTs,
+        p.ids + (long)b * p.T, reinterpret_cast<float*>(Ks + WAVE_ELEMS - MASK_ELEMS), p.T, LDT, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -320,11 +320,10 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     const T* hin = reinterpret_cast<const T*>(p.hin);
     T* dqkvt = reinterpret_cast<T*>(p.d_qkvt) + (long)b * p.T * 4 * p.C;
     const int ldq = 4 * p.C;
-    stage_rows<T, DT, NT>(qkvt + p.C + head * dh, ldq, p.T, Ks, TR ? nullptr : KTs, LDT, lane);
-    stage_rows<T, DT, NT>(qkvt + 3 * p.C + head * dh, ldq, p.T, Ts, nullptr, LDT, lane);
-    stage_rows<T, DT, NT>(qkvt + 2 * p.C + head * dh, ldq, p.T, Vs, nullptr, LDT, lane);
-    stage_marks<T, NT, EC>(p.marks + (long)b * p.T * E, E, p.T, Ms, nullptr, LDT, lane);
-    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ks + WAVE_ELEMS - MASK_ELEMS));
+    const KeyMask<NT> km = stage_wave<T, DT, NT, EC>(
+        qkvt + p.C + head * dh, Ks, TR ? nullptr : KTs, qkvt + 3 * p.C + head * dh, Ts, static_cast<T*>(nullptr),
+        qkvt + 2 * p.C + head * dh, Vs, static_cast<T*>(nullptr), ldq, p.marks + (long)b * p.T * E, E, Ms, static_cast<T*>(nullptr),
+        p.ids + (long)b * p.T, reinterpret_cast<float*>(Ks + WAVE_ELEMS - MASK_ELEMS), p.T, LDT, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 

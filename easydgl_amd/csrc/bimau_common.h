@@ -67,6 +67,9 @@ __device__ __forceinline__ void copy_pack_to_lds(char* smem, const char* pack, s
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = src[min(i0 + j * nt, n - 1)];
 #pragma unroll
+        for (int j = 0; j < 8; ++j)   // "used" here: otherwise each load sinks into the guard of its store and waits there (8 round trips)
+            asm volatile("" : "+v"(v[j].x), "+v"(v[j].y), "+v"(v[j].z), "+v"(v[j].w));
+#pragma unroll
         for (int j = 0; j < 8; ++j)
             if (i0 + j * nt < n) dst[i0 + j * nt] = v[j];
     }
@@ -424,6 +427,122 @@ __device__ __forceinline__ void stage_marks(const uint8_t* marks_row, int E, int
                 for (int e = 0; e < 16; ++e) transposed[e * LDT + k] = vals[e];
             }
         }
+    }
+}
+
+// ---- one round trip for a wave's whole staging -------------------------------------------------------------------------------
+// stage_rows / stage_marks / load_keymask one after the other are 4-5 dependent round trips at the head of every wave (each
+// waits for its own loads before its LDS stores).  At the small shapes (bf16, <= 8 fragments per lane and matrix, 16 marks)
+// everything fits in registers at once: all loads of K / T_ / V / marks / ids go out first, then the stores.
+template <typename T, int DT, int NT>
+struct RowStage {
+    static constexpr int cpr = 4 * DT, dh = 16 * DT, NI = NT * DT;
+    Frag4<T> f[NI];
+    __device__ __forceinline__ void load(const T* src, int ld, int Tlen, int lane) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int c = lane + 64 * j, k = c / cpr, u4 = (c % cpr) * 4;
+            f[j] = frag_ld<T>(src + (long)min(k, Tlen - 1) * ld + u4);
+        }
+    }
+    __device__ __forceinline__ void pin() {
+        static_assert(sizeof(Frag4<T>) == 8, "bf16 fragments");
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { uint2& u = *reinterpret_cast<uint2*>(&f[j]); asm volatile("" : "+v"(u.x), "+v"(u.y)); }
+    }
+    __device__ __forceinline__ void store(T* rowmajor, T* transposed, int LDT, int Tlen, int lane) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int c = lane + 64 * j, k = c / cpr, u4 = (c % cpr) * 4;
+            if (k >= Tlen) f[j] = frag_zero<T>();
+            if (rowmajor) *reinterpret_cast<uint2*>(rowmajor + k * dh + u4) = *reinterpret_cast<uint2*>(&f[j]);
+            if (transposed) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) transposed[(u4 + r) * LDT + k] = f[j].v[r];
+            }
+        }
+    }
+};
+template <typename T, int DT, int NT, int EC>
+constexpr bool stage_merged() { return sizeof(T) == 2 && NT * DT <= 8 && EC == 16; }
+
+// k / t / v: source (null = not staged), row-major image, transposed image (either may be null)
+template <typename T, int DT, int NT, int EC>
+__device__ __forceinline__ KeyMask<NT> stage_wave(const T* k_src, T* k_rm, T* k_tr, const T* t_src, T* t_rm, T* t_tr,
+                                                  const T* v_src, T* v_rm, T* v_tr, int ld, const uint8_t* marks_row, int E,
+                                                  T* m_rm, T* m_tr, const int64_t* ids_row, float* lds_madd, int Tlen, int LDT,
+                                                  int lane) {
+    if constexpr (stage_merged<T, DT, NT, EC>()) {
+        constexpr int Tp = 16 * NT, NR = (Tp + 63) / 64;
+        RowStage<T, DT, NT> sk, st, sv;
+        uint4 mk[NR];
+        int64_t id[NR];
+        sk.load(k_src, ld, Tlen, lane);
+        if (t_src) st.load(t_src, ld, Tlen, lane);
+        if (v_src) sv.load(v_src, ld, Tlen, lane);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int k = min(lane + 64 * i, Tlen - 1);
+            if (marks_row) mk[i] = *reinterpret_cast<const uint4*>(marks_row + (long)k * 16);
+            id[i] = ids_row[k];
+        }
+        sk.pin();
+        if (t_src) st.pin();
+        if (v_src) sv.pin();
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (marks_row) asm volatile("" : "+v"(mk[i].x), "+v"(mk[i].y), "+v"(mk[i].z), "+v"(mk[i].w));
+            asm volatile("" : "+v"(id[i]));
+        }
+        sk.store(k_rm, k_tr, LDT, Tlen, lane);
+        if (t_src) st.store(t_rm, t_tr, LDT, Tlen, lane);
+        if (v_src) sv.store(v_rm, v_tr, LDT, Tlen, lane);
+        if (marks_row) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int k = lane + 64 * i;
+                if (k < Tp) {
+                    const bool ok = k < Tlen;
+                    const uint32_t w[4] = {mk[i].x, mk[i].y, mk[i].z, mk[i].w};
+                    T vals[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) vals[e] = from_f32<T>(ok ? (float)((w[e / 4] >> (8 * (e % 4))) & 0xffu) : 0.f);
+                    if (m_rm) {
+#pragma unroll
+                        for (int j = 0; j < (int)(16 * sizeof(T) / 16); ++j)
+                            reinterpret_cast<uint4*>(m_rm + k * EP)[j] = reinterpret_cast<const uint4*>(vals)[j];
+                    }
+                    if (m_tr) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) m_tr[e * LDT + k] = vals[e];
+                    }
+                }
+            }
+        }
+        KeyMask<NT> km;
+        km.pad = 0ull;
+        km.madd = lds_madd;
+        uint64_t padded[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int k = lane + 64 * i;
+            const bool pd = k < Tlen && id[i] == 0;
+            padded[i] = __ballot(pd);
+            if (k < Tp) lds_madd[k] = k >= Tlen ? -INFINITY : (pd ? -4294967296.0f : 0.f);
+        }
+        const int g4 = (lane >> 4) * 4;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            const uint64_t nib = (padded[kt / 4] >> ((kt % 4) * 16 + g4)) & 0xfull;
+            km.pad |= nib << (kt * 4);
+        }
+        return km;
+    } else {
+        stage_rows<T, DT, NT>(k_src, ld, Tlen, k_rm, k_tr, LDT, lane);
+        if (t_src) stage_rows<T, DT, NT>(t_src, ld, Tlen, t_rm, t_tr, LDT, lane);
+        if (v_src) stage_rows<T, DT, NT>(v_src, ld, Tlen, v_rm, v_tr, LDT, lane);
+        if (marks_row) stage_marks<T, NT, EC>(marks_row, E, Tlen, m_rm, m_tr, LDT, lane);
+        return load_keymask<NT>(ids_row, Tlen, lane, lds_madd);
     }
 }
 

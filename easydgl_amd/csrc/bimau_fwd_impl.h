@@ -71,11 +71,13 @@ __global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
     T* Ms = Vs + (HAS_V ? KV_ELEMS : 0);
     const T* qkvt = reinterpret_cast<const T*>(p.qkvt) + (long)b * p.T * 4 * p.C;
     const int ldq = 4 * p.C;
-    stage_rows<T, DT, NT>(qkvt + p.C + head * dh, ldq, p.T, Ks, nullptr, LDT, lane);           // K  (split order Q,K,V,T: temporal.py:410)
-    if constexpr (HAS_T) stage_rows<T, DT, NT>(qkvt + 3 * p.C + head * dh, ldq, p.T, TR ? Ts : nullptr, TR ? nullptr : Ts, LDT, lane);   // T_
-    if constexpr (HAS_V) stage_rows<T, DT, NT>(qkvt + 2 * p.C + head * dh, ldq, p.T, TR ? Vs : nullptr, TR ? nullptr : Vs, LDT, lane);   // V
-    if constexpr (HAS_M) stage_marks<T, NT, EC>(p.marks + (long)b * p.T * E, E, p.T, Ms, nullptr, LDT, lane);
-    const KeyMask<NT> km = load_keymask<NT>(p.ids + (long)b * p.T, p.T, lane, reinterpret_cast<float*>(Ms + (HAS_M ? Tp * EP : 0)));
+    // K, T_, V (split order Q,K,V,T: temporal.py:410), marks, key mask — one round trip at the small shapes (stage_wave)
+    const KeyMask<NT> km = stage_wave<T, DT, NT, EC>(
+        qkvt + p.C + head * dh, Ks, nullptr,
+        HAS_T ? qkvt + 3 * p.C + head * dh : nullptr, TR ? Ts : nullptr, TR ? nullptr : Ts,
+        HAS_V ? qkvt + 2 * p.C + head * dh : nullptr, TR ? Vs : nullptr, TR ? nullptr : Vs, ldq,
+        HAS_M ? p.marks + (long)b * p.T * E : nullptr, E, Ms, nullptr, p.ids + (long)b * p.T,
+        reinterpret_cast<float*>(Ms + (HAS_M ? Tp * EP : 0)), p.T, LDT, lane);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #ifdef EDGL_PROLOGUE_ONLY   // diagnostic build (not the product): time of the LDS staging alone — rule 9 of DESIGN.md §4.2

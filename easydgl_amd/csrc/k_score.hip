@@ -144,18 +144,36 @@ struct ZStream {
     }
 };
 
-// x fragments of this wave's 32-x strip, kept in registers
+// x fragments of this wave's 32-x strip, kept in registers.  Two halves: issue_xfrags() sends every load (row clamped,
+// unconditional), finish_xfrags() — called after the first streamed tile's loads have been issued as well — zeroes the
+// fragments of rows past the end.  `ok ? load : zero` compiles to a branch around each load with its own wait: IX * NKB
+// dependent round trips at the head of the kernel (8 at C = 128).
 template <typename T, int CT, int IX>
-__device__ __forceinline__ void load_xfrags(const T* X, int x0, int xend, bool zero_row0, int lane,
-                                            Vec16<T> (&xf)[IX][SC<T, CT>::NKB]) {
+__device__ __forceinline__ void issue_xfrags(const T* X, int x0, int xend, int lane, Vec16<T> (&xf)[IX][SC<T, CT>::NKB]) {
     using S = SC<T, CT>;
+#pragma unroll
+    for (int ix = 0; ix < IX; ++ix) {
+        const int gx = max(min(x0 + ix * 16 + (lane & 15), xend - 1), 0);
+#pragma unroll
+        for (int kb = 0; kb < S::NKB; ++kb) xf[ix][kb] = ld16<T>(X + (long)gx * S::C + kb * S::KB + (lane >> 4) * S::VEC);
+    }
+}
+template <typename T, int CT, int IX>
+__device__ __forceinline__ void finish_xfrags(int x0, int xend, bool zero_row0, int lane, Vec16<T> (&xf)[IX][SC<T, CT>::NKB]) {
+    using S = SC<T, CT>;
+#pragma unroll
+    for (int ix = 0; ix < IX; ++ix)
+#pragma unroll
+        for (int kb = 0; kb < S::NKB; ++kb) {      // the loaded values are "used" here: the loads cannot sink into a branch
+            uint4& u = *reinterpret_cast<uint4*>(&xf[ix][kb]);
+            asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w));
+        }
 #pragma unroll
     for (int ix = 0; ix < IX; ++ix) {
         const int gx = x0 + ix * 16 + (lane & 15);
         const bool ok = gx < xend && !(zero_row0 && gx == 0);
 #pragma unroll
-        for (int kb = 0; kb < S::NKB; ++kb)
-            xf[ix][kb] = ok ? ld16<T>(X + (long)gx * S::C + kb * S::KB + (lane >> 4) * S::VEC) : zero16<T>();
+        for (int kb = 0; kb < S::NKB; ++kb) xf[ix][kb] = ok ? xf[ix][kb] : zero16<T>();
     }
 }
 
@@ -218,15 +236,20 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
     const T* table = reinterpret_cast<const T*>(p.table);
 
     Vec16<T> xf[IX][S::NKB];
-    load_xfrags<T, CT, IX>(rows, m0, Reff, false, lane, xf);
+    issue_xfrags<T, CT, IX>(rows, m0, Reff, lane, xf);
     ZStream<T, CT, false> zs;
     const int ntile = (c_hi - c_lo + ZB - 1) / ZB;
     zs.load(table, nullptr, 0, c_lo, c_hi, true);
+    finish_xfrags<T, CT, IX>(m0, Reff, false, lane, xf);
     {
         T* Zs = reinterpret_cast<T*>(smem);
         float* info = reinterpret_cast<float*>(smem + S::Z_BYTES);
         zs.store(Zs, nullptr);
-        if (tid < ZB) { const int n = c_lo + tid; info[tid] = (n < c_hi && n > 0) ? p.out_bias[n - 1] : 0.f; }
+        if (tid < ZB) {
+            const int n = c_lo + tid;
+            const float ob = p.out_bias[min(max(n, 1), p.I - 1) - 1];
+            info[tid] = (n < c_hi && n > 0) ? ob : 0.f;
+        }
     }
     __syncthreads();
     float rmax[IX], rsum[IX];
@@ -237,7 +260,11 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
         const bool more = it + 1 < ntile;
         const char* cur = smem + (size_t)(it & 1) * BUF;
         char* nxt = smem + (size_t)((it + 1) & 1) * BUF;
-        if (more) zs.load(table, nullptr, 0, n0 + ZB, c_hi, true);
+        float ob_next = 0.f;      // bias of the next tile's items: loaded with the tile, stored after it (no wait in between)
+        if (more) {
+            zs.load(table, nullptr, 0, n0 + ZB, c_hi, true);
+            if (tid < ZB) ob_next = p.out_bias[min(max(n0 + ZB + tid, 1), p.I - 1) - 1];
+        }
         const T* Zs = reinterpret_cast<const T*>(cur);
         const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES);
         const bool edge = (n0 == 0) || (n0 + ZB > c_hi);
@@ -292,7 +319,7 @@ __global__ __launch_bounds__(SNT) void score_fwd_kernel(ScoreP p) {
             zs.store(reinterpret_cast<T*>(nxt), nullptr);
             if (tid < ZB) {
                 const int n = n0 + ZB + tid;
-                reinterpret_cast<float*>(nxt + S::Z_BYTES)[tid] = (n < c_hi && n > 0) ? p.out_bias[n - 1] : 0.f;
+                reinterpret_cast<float*>(nxt + S::Z_BYTES)[tid] = (n < c_hi && n > 0) ? ob_next : 0.f;
             }
         }
         __syncthreads();
@@ -426,7 +453,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     const int xbase = (YS ? 0 : p.i0) + bx * XBW + wave * 16 * IX;
     const int xend = YS ? Reff : p.i1;
     Vec16<T> xf[IX][S::NKB];
-    load_xfrags<T, CT, IX>(YS ? rows : table, xbase, xend, ROLE == ROLE_W, lane, xf);
+    issue_xfrags<T, CT, IX>(YS ? rows : table, xbase, xend, lane, xf);
     float x_lse[IX], x_cf[IX], x_bias[IX];
     int x_lab[IX];
     float m_run[IX], s_run[IX];   // ROLE_YF: running row max (uniform over the 4 lane groups) and this lane's part of the row sum
@@ -438,13 +465,17 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         if (FLASH) {
             x_lse[ix] = 0.f; x_cf[ix] = 0.f; x_lab[ix] = -1; x_bias[ix] = 0.f;
         } else if (ROLE == ROLE_Y) {
-            x_cf[ix] = ok ? p.coef[gx] : 0.f;
+            const int gc = max(min(gx, xend - 1), 0);
+            const float cf = p.coef[gc], ls = p.row_lse[gc];
+            const int64_t lb = p.labels[gc];
+            x_cf[ix] = ok ? cf : 0.f;
             // coef*exp(x - lse) = exp(x - (lse - log coef)); coef == 0 (label 0 / row past the end) -> +inf -> 0
-            x_lse[ix] = x_cf[ix] > 0.f ? p.row_lse[gx] - __logf(x_cf[ix]) : INFINITY;
-            x_lab[ix] = ok ? (int)p.labels[gx] : -1;
+            x_lse[ix] = x_cf[ix] > 0.f ? ls - __logf(x_cf[ix]) : INFINITY;
+            x_lab[ix] = ok ? (int)lb : -1;
             x_bias[ix] = 0.f;
         } else {
-            x_bias[ix] = (ok && gx > 0) ? p.out_bias[gx - 1] : 0.f;
+            const float ob = p.out_bias[min(max(gx, 1), p.I - 1) - 1];     // unconditional load, then the select
+            x_bias[ix] = (ok && gx > 0) ? ob : 0.f;
             x_lse[ix] = 0.f; x_cf[ix] = 0.f; x_lab[ix] = ok ? gx : -2;   // x_lab = own item id
         }
     }
@@ -455,18 +486,34 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
     const T* zsrcT = YS ? tableT : rowsT;
     const int ldT = YS ? p.ldt : p.ldr;
 
-    auto fill_info = [&](char* buf, int z0) {
+    // per-z scalars of a streamed tile (ROLE_Y*: bias[z]; ROLE_W: lse[z] - log coef[z], coef[z], label[z]), threads < ZB: the
+    // loads are unconditional (index clamped) and issued with the tile's own loads, the LDS stores follow the tile's —
+    // a load inside `ok ? .. : 0` waits for its data on the spot, one exposed round trip per streamed tile
+    float zi_a = 0.f, zi_b = 0.f;
+    int64_t zi_c = 0;
+    auto load_info = [&](int z0) {
+        if (tid < ZB) {
+            const int gz = z0 + tid;
+            if (YS) {
+                zi_a = p.out_bias[min(max(gz, 1), p.I - 1) - 1];
+            } else {
+                const int gc = min(gz, Reff - 1);
+                zi_a = p.coef[gc]; zi_b = p.row_lse[gc]; zi_c = p.labels[gc];
+            }
+        }
+    };
+    auto store_info = [&](char* buf, int z0) {
         float* info = reinterpret_cast<float*>(buf + S::Z_BYTES + S::ZT_BYTES);
         if (tid < ZB) {
             const int gz = z0 + tid;
             const bool ok = gz < z_hi;
             if (YS) {
-                info[tid] = (ok && gz > 0) ? p.out_bias[gz - 1] : 0.f;
+                info[tid] = (ok && gz > 0) ? zi_a : 0.f;
             } else {
-                const float cf = ok ? p.coef[gz] : 0.f;
-                info[tid] = cf > 0.f ? p.row_lse[gz] - __logf(cf) : INFINITY;
+                const float cf = ok ? zi_a : 0.f;
+                info[tid] = cf > 0.f ? zi_b - __logf(cf) : INFINITY;
                 info[ZB + tid] = cf;
-                reinterpret_cast<int*>(info)[2 * ZB + tid] = ok ? (int)p.labels[gz] : -1;
+                reinterpret_cast<int*>(info)[2 * ZB + tid] = ok ? (int)zi_c : -1;
             }
         }
     };
@@ -482,10 +529,11 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
 
     ZStream<T, CT, true, NTHR> zs;
     const int ntile = z_hi > z_lo ? (z_hi - z_lo + ZB - 1) / ZB : 0;
+    if (ntile > 0) { zs.load(zsrc, zsrcT, ldT, z_lo, z_hi, YS); load_info(z_lo); }
+    finish_xfrags<T, CT, IX>(xbase, xend, ROLE == ROLE_W, lane, xf);
     if (ntile > 0) {
-        zs.load(zsrc, zsrcT, ldT, z_lo, z_hi, YS);
         zs.store(reinterpret_cast<T*>(smem), reinterpret_cast<T*>(smem + S::Z_BYTES));
-        fill_info(smem, z_lo);
+        store_info(smem, z_lo);
     }
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
@@ -493,7 +541,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         const bool more = it + 1 < ntile;
         char* cur = smem + (DOUBLE ? (size_t)(it & 1) * BUF : 0);
         char* nxt = smem + (DOUBLE ? (size_t)((it + 1) & 1) * BUF : 0);
-        if (PREFETCH && more && !(p.dbg & 4)) zs.load_z(zsrc, z0 + ZB, z_hi, YS);
+        if (PREFETCH && more && !(p.dbg & 4)) { zs.load_z(zsrc, z0 + ZB, z_hi, YS); load_info(z0 + ZB); }
         const T* Zs = reinterpret_cast<const T*>(cur);
         const T* ZTs = reinterpret_cast<const T*>(cur + S::Z_BYTES);
         const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES + S::ZT_BYTES);
@@ -640,10 +688,10 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         }
         if (!DOUBLE) __syncthreads();
         if (more && !(p.dbg & 4)) {
-            if (!PREFETCH) zs.load_z(zsrc, z0 + ZB, z_hi, YS);
+            if (!PREFETCH) { zs.load_z(zsrc, z0 + ZB, z_hi, YS); load_info(z0 + ZB); }
             zs.load_t(zsrcT, ldT, z0 + ZB, z_hi, YS);   // short-lived: the other wave of the SIMD covers it
             zs.store(reinterpret_cast<T*>(nxt), reinterpret_cast<T*>(nxt + S::Z_BYTES));
-            fill_info(nxt, z0 + ZB);
+            store_info(nxt, z0 + ZB);
         }
         __syncthreads();
     }
