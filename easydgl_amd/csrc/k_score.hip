@@ -10,9 +10,11 @@
 //   * the other operand ("z": item tiles, or row tiles) streams through LDS in 128-z tiles, double buffered,
 //     prefetched through registers, one barrier per tile;
 //   * logit tile in the swapped orientation  D[z][x]  (register layout L(first=z, second=x)), so that dl is
-//     directly the A operand of the second product  out[x][c] += sum_z dl[x][z] Z[z][c]; its B operand is
-//     read from a second LDS image of the same tile in [c][z] order, filled from a pre-transposed copy of the
-//     operand in HBM (tableT [C][ldt] / rowsT [C][ldr]) — no in-kernel transposes, full-rate 16x16x32 MFMA.
+//     directly the A operand of the second product  out[x][c] += sum_z dl[x][z] Z[z][c]; its B operand (z along
+//     the contraction) comes out of the SAME row-major LDS tile through gfx950's transpose read
+//     (ds_read_b64_tr_b16, bf16) — one image per tile, no transposed copies of the operands in HBM.  f32 has no
+//     32-bit transpose read: there a second LDS image in [c][z] order is filled from a pre-transposed copy
+//     (tableT [C][ldt] / rowsT [C][ldr]).
 //   score_fwd_kernel : x = rows,  z = items   -> per-chunk (max, sumexp) [+ optional logits]
 //   score_bwd<ROLE_Y>: x = rows,  z = items   -> d_rows slabs
 //   score_bwd<ROLE_W>: x = items, z = rows    -> d_table slabs, d_bias slabs
@@ -59,12 +61,30 @@ struct SC {
     static constexpr int PER_Z = ZB * CV / NTHR;          // 16-byte vectors per thread, Z image
     static constexpr int PER_ZT = C * (ZB / VEC) / NTHR;  // same count, ZT image
     static constexpr size_t Z_BYTES = (size_t)ZB * LDC * sizeof(T);
-    static constexpr size_t ZT_BYTES = (size_t)C * LDZ * sizeof(T);
+    // second image of the tile in [c][z] order: f32 only — bf16 fetches the z-contracting operand of the second product from
+    // the Z image itself with the LDS transpose read (ds_read_b64_tr_b16; row stride LDC * 2 B = 8 banks mod 64: conflict-free)
+    static constexpr bool WT = sizeof(T) == 4;
+    static constexpr size_t ZT_BYTES = WT ? (size_t)C * LDZ * sizeof(T) : 0;
     static constexpr size_t INFO_BYTES = 3 * ZB * sizeof(float);
     static constexpr int JH = ZB >= 64 ? 4 : ZB / 16;     // 16-z tiles per "half" (the unit whose logits are live at once)
     static constexpr int NH = ZB / 16 / JH;               // halves per streamed tile
     static_assert(PER_Z >= 1 && PER_ZT >= 1 && ZB % 16 == 0, "tile does not divide over the workgroup");
 };
+
+typedef __attribute__((ext_vector_type(4))) short sc_s16x4;
+// B operand of a 16x16x32 MFMA whose contraction index runs along the ROWS of a row-major bf16 LDS tile (rows k0 .. k0+31,
+// columns z0 .. z0+15): slots 0-3 <-> k0 + 4G + j, slots 4-7 <-> k0 + 16 + 4G + j (G = lane >> 4) — the order in which the
+// dl fragment is packed from the logit accumulators (see csrc/k_gemm2.hip for the measured lane map of the instruction)
+__device__ __forceinline__ bf16x8 sc_tr_frag32(const bf16* tile, int ld, int k0, int z0, int lane) {
+    const int G = lane >> 4, sl = lane & 15;
+    const bf16* p = tile + (k0 + 4 * G + (sl >> 2)) * ld + z0 + 4 * (sl & 3);
+    bf16x8 f;
+    sc_s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sc_s16x4*)p);
+    sc_s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sc_s16x4*)(p + 16 * ld));
+    *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<uint2*>(&v0);
+    *(reinterpret_cast<uint2*>(&f) + 1) = *reinterpret_cast<uint2*>(&v1);
+    return f;
+}
 
 struct ScoreP {
     const void* rows; const void* rowsT; int ldr;      // rows [R][C], rowsT [C][ldr]
@@ -527,7 +547,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
 #pragma unroll
     for (int ix = 0; ix < IX; ++ix) dbias[ix] = 0.f;
 
-    ZStream<T, CT, true, NTHR> zs;
+    ZStream<T, CT, S::WT, NTHR> zs;
     const int ntile = z_hi > z_lo ? (z_hi - z_lo + ZB - 1) / ZB : 0;
     if (ntile > 0) { zs.load(zsrc, zsrcT, ldT, z_lo, z_hi, YS); load_info(z_lo); }
     finish_xfrags<T, CT, IX>(xbase, xend, ROLE == ROLE_W, lane, xf);
@@ -663,10 +683,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                         }
 #pragma unroll
                     for (int ct = 0; ct < CO; ++ct) {
-                        const T* zt = ZTs + ((ct0 + ct) * 16 + l15) * S::LDZ + (half * (JH / 2) + jp) * 32 + g4;
-                        bf16x8 bfr;
-                        *reinterpret_cast<uint2*>(&bfr) = *reinterpret_cast<const uint2*>(zt);
-                        *(reinterpret_cast<uint2*>(&bfr) + 1) = *reinterpret_cast<const uint2*>(zt + 16);
+                        const bf16x8 bfr = sc_tr_frag32(Zs, S::LDC, (half * (JH / 2) + jp) * 32, (ct0 + ct) * 16, lane);
 #pragma unroll
                         for (int ix = 0; ix < IX; ++ix) out[ix][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ix], bfr, out[ix][ct], 0, 0, 0);
                     }
@@ -1165,7 +1182,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     T* rowsT = reinterpret_cast<T*>(ws + plan.off_rowsT);
     T* tableT = reinterpret_cast<T*>(ws + plan.off_tableT);
     p.ldr = (int)up8(p.R); p.ldt = (int)up8(p.I);
-    if (MODE != 2) {
+    if (MODE != 2 && S::WT) {   // bf16 reads the transposed operand out of the row-major LDS tile: no transposed copies
         const int nbx0 = (p.ldr + 63) / 64, nbx1 = p.table_ready ? 0 : (p.ldt + 63) / 64;
         hipLaunchKernelGGL((transpose_kernel<T>), dim3((unsigned)(nbx0 + nbx1), (p.C + 63) / 64), dim3(256), 0, st,
                            reinterpret_cast<const T*>(p.rows), (long)p.R, rowsT, (long)p.ldr, nbx0,
@@ -1435,12 +1452,9 @@ extern "C" int edgl_score_prepare_table(const void* table, int R, int C, int I, 
     const long ldt = (long)up8(I);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((ldt + 63) / 64), (C + 63) / 64);
-    if (dtype == EDGL_F32)
-        hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, st, (const float*)table, (long)I, reinterpret_cast<float*>(workspace + plan.off_tableT), ldt,
-                           (int)grid.x, (const float*)nullptr, 0L, (float*)nullptr, 0L, C);
-    else
-        hipLaunchKernelGGL((transpose_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)table, (long)I, reinterpret_cast<bf16*>(workspace + plan.off_tableT), ldt,
-                           (int)grid.x, (const bf16*)nullptr, 0L, (bf16*)nullptr, 0L, C);
+    if (dtype != EDGL_F32) return EDGL_OK;      // the bf16 kernels need no transposed image
+    hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, st, (const float*)table, (long)I, reinterpret_cast<float*>(workspace + plan.off_tableT), ldt,
+                       (int)grid.x, (const float*)nullptr, 0L, (float*)nullptr, 0L, C);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
