@@ -249,8 +249,9 @@ int edgl_ce_loss_fwd_add(const float* row_lse, const float* label_logit, const i
 /* backward of the CE: dl[r,j] = g * coef[r] * (p[r,j] - [j==label_r]) (g = d loss, device scalar or
  * NULL for 1), never materialised:  d_rows[R,C] (`dtype`) = dl . table ;  d_table[I,C] (f32,
  * overwritten for rows [i0,i1), row 0 := 0) = dl^T . rows ;  d_bias[I-1] f32 = colsum(dl)[1:].
- * workspace >= edgl_score_bwd_workspace(R, C, I, i1-i0, dtype) floats (holds the transposed operand
- * images rowsT/tableT and the per-chunk partial slabs, reduced in a fixed order). */
+ * workspace >= edgl_score_bwd_workspace(R, C, I, i1-i0, dtype) floats (holds the per-chunk partial slabs, reduced in a
+ * fixed order, and — f32 only — the transposed operand images rowsT/tableT; the bf16 kernels read the transposed
+ * operand out of their row-major LDS tiles). */
 long edgl_score_bwd_workspace(int R, int C, int I, int n_items, int dtype);
 int edgl_score_ce_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                       const float* row_lse, const float* coef, const float* gscale, int R, int C, int I,
@@ -284,9 +285,10 @@ long edgl_score_flash_workspace(int R, int C, int I, int n_items, int dtype);
 int edgl_score_flash_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
                          int I, int i0, int i1, const int32_t* nvalid, float* row_lse, float* label_logit,
                          float* workspace, int dtype, void* stream);
-/* The transposed operand image of the item table depends on the weights only: edgl_score_prepare_table writes it into the
- * flash workspace ahead of the forward (same R, C, I, [i0, i1), workspace, dtype), and edgl_score_flash_fwd_pre with
- * table_ready != 0 skips it (table_ready == 0: identical to edgl_score_flash_fwd). */
+/* f32: the transposed operand image of the item table depends on the weights only: edgl_score_prepare_table writes it into
+ * the flash workspace ahead of the forward (same R, C, I, [i0, i1), workspace, dtype), and edgl_score_flash_fwd_pre with
+ * table_ready != 0 skips it (table_ready == 0: identical to edgl_score_flash_fwd).  bf16 needs no such image:
+ * edgl_score_prepare_table returns at once and table_ready is ignored. */
 int edgl_score_prepare_table(const void* table, int R, int C, int I, int i0, int i1, float* workspace, int dtype, void* stream);
 int edgl_score_flash_fwd_pre(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
                              int I, int i0, int i1, const int32_t* nvalid, float* row_lse, float* label_logit,
