@@ -381,33 +381,49 @@ __global__ __launch_bounds__(256) void lse_label_kernel(const float* part, int R
                                                         const int64_t* labels, int C, int i0, int i1, float* lab_out) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;
+    // two round trips: {row count, label}, then everything that hangs on them — chunk partials, row, label row of the table, bias —
+    // as unconditional loads (indices clamped); guarded loads made this kernel six dependent round trips
     const int Reff = nvalid ? min(R, nvalid[0]) : R;
     const int64_t lab = labels[r];
+    const int nchunk = dev_plan(max(Reff, 1), xb, G, ztotal, zb).nchunk;
+    const bool own = lab >= i0 && lab < i1;
+    const int64_t labc = own ? lab : (int64_t)i0;
+    const long pidx = ((long)min(r, max(Reff - 1, 0)) * nchunk + min(lane, nchunk - 1)) * 2;
+    float pm = part[pidx], ps = part[pidx + 1];
+    float ob = out_bias[max(labc, (int64_t)1) - 1];
     float a = 0.f;
-    if (lab != 0 && lab >= i0 && lab < i1)
-        for (int c = lane; c < C; c += 64) a += to_f32(rows[(long)r * C + c]) * to_f32(table[lab * C + c]);
+    if (C <= 128) {
+        const int c0 = min(lane, C - 1), c1 = min(lane + 64, C - 1);
+        float x0 = to_f32(rows[(long)r * C + c0]), x1 = to_f32(rows[(long)r * C + c1]);
+        float t0 = to_f32(table[labc * C + c0]), t1 = to_f32(table[labc * C + c1]);
+        asm volatile("" : "+v"(pm), "+v"(ps), "+v"(ob), "+v"(x0), "+v"(x1), "+v"(t0), "+v"(t1));
+        a = lane < C ? x0 * t0 : 0.f;                       // the summation order of label_logit_kernel (bit-equal results)
+        a = lane + 64 < C ? fmaf(x1, t1, a) : a;
+    } else {
+        asm volatile("" : "+v"(pm), "+v"(ps), "+v"(ob));
+        for (int c = lane; c < C; c += 64) a += to_f32(rows[(long)r * C + c]) * to_f32(table[labc * C + c]);
+    }
+    a = (lab != 0 && own) ? a : 0.f;
     float lse = 0.f;
     if (r < Reff) {
-        const int nchunk = dev_plan(Reff, xb, G, ztotal, zb).nchunk;
-        float mx = -INFINITY;
-        for (int c = lane; c < nchunk; c += 64) mx = fmaxf(mx, part[((long)r * nchunk + c) * 2]);
+        float mx = lane < nchunk ? pm : -INFINITY;
+        for (int c = lane + 64; c < nchunk; c += 64) mx = fmaxf(mx, part[((long)r * nchunk + c) * 2]);
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float s = 0.f;
-        for (int c = lane; c < nchunk; c += 64) {
-            const float pm = part[((long)r * nchunk + c) * 2];
-            if (pm > -INFINITY) s += part[((long)r * nchunk + c) * 2 + 1] * __expf(pm - mx);
+        float sm = (lane < nchunk && pm > -INFINITY) ? ps * __expf(pm - mx) : 0.f;
+        for (int c = lane + 64; c < nchunk; c += 64) {
+            const float qm = part[((long)r * nchunk + c) * 2];
+            if (qm > -INFINITY) sm += part[((long)r * nchunk + c) * 2 + 1] * __expf(qm - mx);
         }
-        s = wave_sum(s);
-        lse = mx + __logf(s);
+        sm = wave_sum(sm);
+        lse = mx + __logf(sm);
     }
     a = wave_sum(a);
     if (lane == 0) {
         row_lse[r] = lse;
-        if (lab >= i0 && lab < i1) lab_out[r] = (lab == 0) ? -1000.0f : a + out_bias[lab - 1];
+        if (own) lab_out[r] = (lab == 0) ? -1000.0f : a + ob;
     }
 }
 
-// label logit: one wave per row (a [R] gather-dot; keeps the label test out of the MFMA epilogue)
 template <typename T>
 __global__ __launch_bounds__(256) void label_logit_kernel(const T* rows, const T* table, const float* out_bias,
                                                           const int64_t* labels, int R, int C, int i0, int i1, float* out) {
@@ -904,14 +920,26 @@ __global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, con
     __shared__ float red[16];
     float py[CE_KEEP];
     float num = 0.f, den = 0.f;
+    {   // all 3 * CE_KEEP loads issued before the first use (`m < R && labels[..]` is a guarded load: a branch and a wait per row
+        // — 16 dependent round trips, 10 us for this kernel)
+        int64_t lb[CE_KEEP];
+        float lg[CE_KEEP], ls[CE_KEEP];
 #pragma unroll
-    for (int i = 0; i < CE_KEEP; ++i) {
-        const int m = threadIdx.x + i * 1024;
-        const int mc = min(m, R - 1);
-        const bool on = m < R && labels[mc] != 0;   // weight 0 (EasyDGL.py:180): lse may be undefined for such rows
-        const float v = __expf(label_logit[mc] - row_lse[mc]);
-        py[i] = on ? v : -1.f;
-        if (on) { num += -__logf(v + 1e-5f); den += 1.f; }
+        for (int i = 0; i < CE_KEEP; ++i) {
+            const int mc = min((int)threadIdx.x + i * 1024, R - 1);
+            lb[i] = labels[mc]; lg[i] = label_logit[mc]; ls[i] = row_lse[mc];
+        }
+#pragma unroll
+        for (int i = 0; i < CE_KEEP; ++i) asm volatile("" : "+v"(lb[i]), "+v"(lg[i]), "+v"(ls[i]));
+#pragma unroll
+        for (int i = 0; i < CE_KEEP; ++i) {
+            const int m = threadIdx.x + i * 1024;
+            const bool on = (m < R) & (lb[i] != 0);   // weight 0 (EasyDGL.py:180): lse may be undefined for such rows
+            const float v = __expf(lg[i] - ls[i]);
+            py[i] = on ? v : -1.f;
+            num += on ? -__logf(v + 1e-5f) : 0.f;
+            den += on ? 1.f : 0.f;
+        }
     }
     for (int m = threadIdx.x + CE_KEEP * 1024; m < R; m += 1024) {
         if (labels[m] == 0) continue;
