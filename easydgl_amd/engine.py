@@ -167,7 +167,7 @@ class TrainEngine:
         sst = side.cuda_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            # needed by the first BiMAU forward (first join): TPP normaliser (labels only), weight packs
+            # needed by the first BiMAU forward (the one join of the forward): TPP normaliser (labels only), weight packs
             for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
                 att = blk.attention
                 if m.ct_reg != 0.0:
@@ -179,8 +179,8 @@ class TrainEngine:
                     check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
                                              _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
                                              _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
-            ev_pack = side.record_event()
-            # needed by the scoring (second join, before the row gather): row compaction map (labels only), L2 term
+            # needed by the scoring: row compaction map (labels only), L2 term — same join: every cross-stream edge costs the
+            # waiting stream ~6 us even when the other side finished long ago, and all of this ends under the QKVT projection
             check(lib.edgl_compact_scan(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid), sst),
                   "edgl_compact_scan")
             # (the transposed table image is NOT prepared here, although it depends on the weights only: written 200 us before
@@ -188,6 +188,7 @@ class TrainEngine:
             if m.l2_reg != 0.0:
                 check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss_aux), 0,
                                        _ptr(self.ws_l2), sst), "edgl_l2_loss")
+            ev_pack = side.record_event()
         # dropout step counter, Adam step counter and learning rate of this step: one single-thread launch
         check(lib.edgl_step_begin(_ptr(m._rng_state), _ptr(m._adam_state), float(m.learning_rate), 0.9, 0.999, st),
               "edgl_step_begin")
@@ -235,7 +236,6 @@ class TrainEngine:
             self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, C, C, gelu=True, pre=self.pre_t)
             self._ln_fwd(self.so, None, 0, m.transform_ln, ops.NO_DROP, self.hrows, self.st3, gpos=self.mpos)
         # rows whose label is 0 have weight 0 (EasyDGL.py:180): score only the weighted ones
-        main.wait_stream(side)   # join: compaction map, L2 term
         check(lib.edgl_compact_gather(_ptr(self.hrows), _ptr(self.labels), _ptr(self.perm), R, C, _ptr(self.hrows_c),
                                       _ptr(self.labels_c), code, st), "edgl_compact_gather")
         lab = self.labels_c
