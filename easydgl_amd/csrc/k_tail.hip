@@ -222,8 +222,10 @@ __device__ __forceinline__ void joint_moments(const float (&z)[MAXRT][4], int nr
 // Four LDS images per workgroup: A (att -> y), B (x_in -> a1 -> LN3 rows), C (f halves, so), S (staging of the tensors
 // that only pass through: ao, o); A + S together hold the f32 pre-activations of a GELU pass.  Everything leaves for HBM as whole 256-byte rows (copy_out); storing
 // the pass-through tensors straight from the accumulator registers (8 bytes per lane) measured slower (88 vs 83 us).
-// NRT = 7: the row-tile count as a constant (T in 97..112, the benchmark shape) — every `rt < nrt` guard folds away and the
-// seven accumulator tiles stay seven independent tuples; NRT = 0: run-time count (short sequences skip their empty tiles).
+// NRT: the row-tile count as a template constant (2, 4 or 7 tiles: T <= 32, 64, 112; tiles past the sequence are padding like
+// the rows past it) — every `rt < nrt` guard folds away and the accumulator tiles stay independent tuples.  With a run-time
+// count (NRT = 0, not instantiated) the compiler keeps whole 28-register copies of the tile arrays alive across the guards:
+// 47 / 129 spilled registers.
 template <int CT, int NRT>
 __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     using G = TailGeom<CT>;
@@ -801,8 +803,9 @@ extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const v
             B, T, C, drop_rate, rng_state, sid1, sid2, masked_pos, M, head, (bf16*)ao, (bf16*)a1, (bf16*)pre_f, (bf16*)f, (bf16*)o,
             (bf16*)y, (bf16*)pre_t, (bf16*)so, (bf16*)hrows, st1, st2, st3};
     hipStream_t st = (hipStream_t)stream;
-    const bool full = (T + 15) / 16 == MAXRT;
-    auto k = C == 128 ? (full ? tail_fwd_kernel<8, MAXRT> : tail_fwd_kernel<8, 0>) : (full ? tail_fwd_kernel<4, MAXRT> : tail_fwd_kernel<4, 0>);
+    const int nrt = (T + 15) / 16;
+    auto k = C == 128 ? (nrt <= 2 ? tail_fwd_kernel<8, 2> : nrt <= 4 ? tail_fwd_kernel<8, 4> : tail_fwd_kernel<8, MAXRT>)
+                      : (nrt <= 2 ? tail_fwd_kernel<4, 2> : nrt <= 4 ? tail_fwd_kernel<4, 4> : tail_fwd_kernel<4, MAXRT>);
     const size_t smem = C == 128 ? TailGeom<8>::SMEM : TailGeom<4>::SMEM;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, dim3(B), dim3(C == 128 ? 512 : 256), smem, st, p);
@@ -831,8 +834,9 @@ extern "C" int edgl_tail_bwd(const void* xin, int ld_x, const void* ao, const vo
                drop_rate, rng_state, sid1, sid2, head, (const bf16*)d_rows, masked_pos, M, dy_rowmap, (const bf16*)d_y_in,
                (bf16*)d_pre_t, (bf16*)d_o, (bf16*)d_pre_f, (bf16*)d_ao, (bf16*)d_res1, (bf16*)d_att, part1, part2, part3};
     hipStream_t st = (hipStream_t)stream;
-    const bool full = (T + 15) / 16 == MAXRT;
-    auto k = C == 128 ? (full ? tail_bwd_kernel<8, MAXRT> : tail_bwd_kernel<8, 0>) : (full ? tail_bwd_kernel<4, MAXRT> : tail_bwd_kernel<4, 0>);
+    const int nrt = (T + 15) / 16;
+    auto k = C == 128 ? (nrt <= 2 ? tail_bwd_kernel<8, 2> : nrt <= 4 ? tail_bwd_kernel<8, 4> : tail_bwd_kernel<8, MAXRT>)
+                      : (nrt <= 2 ? tail_bwd_kernel<4, 2> : nrt <= 4 ? tail_bwd_kernel<4, 4> : tail_bwd_kernel<4, MAXRT>);
     const size_t smem = C == 128 ? TailGeom<8>::SMEM_BWD : TailGeom<4>::SMEM_BWD;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, dim3(B), dim3(C == 128 ? 512 : 256), smem, st, p);
