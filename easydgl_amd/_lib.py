@@ -54,6 +54,7 @@ SIGNATURES = {
     "edgl_score_chunks": (I, [I, I]),
     "edgl_compact_rows": (I, [P, P, I, I, P, P, P, P, P, I, P]),
     "edgl_compact_scan": (I, [P, I, P, P, P, P]),
+    "edgl_compact_scan_labels": (I, [P, I, P, P, P, P, P]),
     "edgl_compact_gather": (I, [P, P, P, I, I, P, P, I, P]),
     "edgl_scatter_rows": (I, [P, P, I, I, P, I, P]),
     "edgl_score_lse_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
@@ -105,7 +106,7 @@ SIGNATURES = {
     "edgl_tail_supported": (I, [I, I, I]),
     "edgl_tail_pack": (I, [P, P, P, P, I, P, P]),
     "edgl_tail_fwd": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, P, I, I, P, P, P, P, P, P, P, P, P, P, P,
-                          P, I, P]),
+                          P, P, I, P]),
     "edgl_tail_bwd_workspace": (L, [I, I]),
     "edgl_tail_bwd": (I, [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, I, P, P, I, P, P, P, P, P, P, P, P,
                           P, P, P, P, P, P, P, I, P]),

@@ -826,7 +826,7 @@ __global__ void flash_finish_kernel(const float* slabs, const float* part, const
 // (perm[j] = original row of compact row j, inv[r] = compact index of row r or -1, nvalid = #weighted rows), so the
 // scoring kernels can skip the rest exactly.
 __global__ __launch_bounds__(1024) void compact_scan_kernel(const int64_t* labels, int R, int32_t* perm, int32_t* inv,
-                                                            int32_t* nvalid) {
+                                                            int32_t* nvalid, int64_t* labels_c) {
     // chunks of 1024 consecutive rows: one coalesced label per thread, wave ballots + a 16-entry scan of the wave counts
     __shared__ int wcnt[16];
     __shared__ int s_base;
@@ -835,17 +835,14 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(const int64_t* label
     __syncthreads();
     // labels of 16 chunks are fetched together (clamped, unconditional): one memory round trip per 16 K rows, not per chunk
     for (int g0 = 0; g0 < R; g0 += 16 * 1024) {
-        unsigned onbits = 0u;
+        int64_t labk[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) labk[k] = labels[min(g0 + k * 1024 + t, R - 1)];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
+            if (g0 + k * 1024 >= R) break;
             const int r = g0 + k * 1024 + t;
-            const int64_t lab = labels[min(r, R - 1)];
-            onbits |= (r < R && lab != 0) ? (1u << k) : 0u;
-        }
-#pragma unroll 1
-        for (int k = 0; k < 16 && g0 + k * 1024 < R; ++k) {
-            const int r = g0 + k * 1024 + t;
-            const bool on = (onbits >> k) & 1u;
+            const bool on = r < R && labk[k] != 0;
             const unsigned long long bal = __ballot(on);
             if (lane == 0) wcnt[w] = __popcll(bal);
             lds_barrier();   // LDS-scoped: __syncthreads() would also wait for the perm / inv stores of the previous chunk
@@ -853,7 +850,7 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(const int64_t* label
             for (int i = 0; i < 16; ++i) { const int c = wcnt[i]; before += i < w ? c : 0; tot += c; }
             const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
             if (r < R) {
-                if (on) { perm[pos] = r; inv[r] = pos; }
+                if (on) { perm[pos] = r; inv[r] = pos; if (labels_c) labels_c[pos] = labk[k]; }
                 else inv[r] = -1;
             }
             lds_barrier();
@@ -862,7 +859,7 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(const int64_t* label
     }
     __syncthreads();
     const int total = s_base;
-    for (int j = total + t; j < R; j += 1024) perm[j] = -1;
+    for (int j = total + t; j < R; j += 1024) { perm[j] = -1; if (labels_c) labels_c[j] = 0; }
     if (t == 0) nvalid[0] = total;
 }
 template <typename T>
@@ -1340,7 +1337,17 @@ extern "C" int edgl_score_chunks(int R, int n_items) {
 extern "C" int edgl_compact_scan(const int64_t* labels, int R, int32_t* perm, int32_t* inv, int32_t* nvalid, void* stream) {
     EDGL_REQUIRE(labels && perm && inv && nvalid, EDGL_ERR_NULL, "edgl_compact_scan: null pointer");
     EDGL_REQUIRE(R > 0, EDGL_ERR_SHAPE, "edgl_compact_scan: bad shape R=%d", R);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, R, perm, inv, nvalid);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, R, perm, inv, nvalid, (int64_t*)nullptr);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+// The scan that also writes the compacted labels (labels_c [R]: the labels of the weighted rows first, 0 behind them) — with
+// it and edgl_tail_fwd's row map the rows reach the scoring kernels without edgl_compact_gather.
+extern "C" int edgl_compact_scan_labels(const int64_t* labels, int R, int32_t* perm, int32_t* inv, int32_t* nvalid,
+                                        int64_t* labels_c, void* stream) {
+    EDGL_REQUIRE(labels && perm && inv && nvalid && labels_c, EDGL_ERR_NULL, "edgl_compact_scan_labels: null pointer");
+    EDGL_REQUIRE(R > 0, EDGL_ERR_SHAPE, "edgl_compact_scan_labels: bad shape R=%d", R);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, labels, R, perm, inv, nvalid, labels_c);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

@@ -46,7 +46,7 @@ struct TailP {
     const float *bo, *bi, *bout, *bt, *g1, *b1, *g2, *b2, *g3, *b3;
     int B, T, C;
     float rate; const uint64_t* rng; uint32_t sid1, sid2;
-    const int64_t* mpos; int M; int head;
+    const int64_t* mpos; int M; int head; const int32_t* hmap;   // hmap: optional destination row of head row b*M + j (< 0: dropped)
     bf16 *ao, *a1, *pre_f, *f, *o, *y, *pre_t, *so, *hrows;   // pre_f / pre_t receive gelu'(pre-activation)
     float *st1, *st2, *st3;
 };
@@ -399,8 +399,10 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     lds_barrier();
     for (int v = threadIdx.x; v < p.M * G::CV; v += G::NTHR) {      // batch_gather of the masked positions (EasyDGL.py:142-143)
         const int j = v / G::CV, cv = v % G::CV;
-        const int t = (int)p.mpos[(long)b * p.M + j];
-        *reinterpret_cast<uint4*>(p.hrows + ((long)b * p.M + j) * C + cv * 8) = *reinterpret_cast<const uint4*>(bufB + t * LD + cv * 8);
+        const long src = (long)b * p.M + j;
+        const int t = (int)p.mpos[src];
+        const long dst = p.hmap ? (long)p.hmap[src] : src;         // row compaction of the scoring (edgl_compact_scan's `inv`)
+        if (dst >= 0) *reinterpret_cast<uint4*>(p.hrows + dst * C + cv * 8) = *reinterpret_cast<const uint4*>(bufB + t * LD + cv * 8);
     }
 #if defined(EDGL_PHASE_TIMING) && !defined(EDGL_PHASE_BWD)
     PH_MARK(0);   // head (slot 8)
@@ -789,7 +791,7 @@ extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const v
                              const float* b2, const float* g3, const float* b3, int B, int T, int C, float drop_rate,
                              const uint64_t* rng_state, uint32_t sid1, uint32_t sid2, const int64_t* masked_pos, int M, int head,
                              void* ao, void* a1, float* st1, void* pre_f, void* f, void* o, void* y, float* st2, void* pre_t,
-                             void* so, float* st3, void* hrows, int dtype, void* stream) {
+                             void* so, float* st3, void* hrows, const int32_t* hrow_map, int dtype, void* stream) {
     EDGL_REQUIRE(att && xin && pack && bo && bi && bout && g1 && b1 && g2 && b2 && ao && a1 && st1 && pre_f && f && o && y && st2,
                  EDGL_ERR_NULL, "edgl_tail_fwd: null pointer");
     EDGL_REQUIRE(!head || (bt && g3 && b3 && masked_pos && pre_t && so && st3 && hrows && M >= 1), EDGL_ERR_NULL,
@@ -800,7 +802,7 @@ extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const v
     const bf16* pk = (const bf16*)pack;
     const long cc = (long)C * C;
     TailP p{(const bf16*)att, (const bf16*)xin, ld_x, pk, pk + cc, pk + 3 * cc, pk + 5 * cc, bo, bi, bout, bt, g1, b1, g2, b2, g3, b3,
-            B, T, C, drop_rate, rng_state, sid1, sid2, masked_pos, M, head, (bf16*)ao, (bf16*)a1, (bf16*)pre_f, (bf16*)f, (bf16*)o,
+            B, T, C, drop_rate, rng_state, sid1, sid2, masked_pos, M, head, hrow_map, (bf16*)ao, (bf16*)a1, (bf16*)pre_f, (bf16*)f, (bf16*)o,
             (bf16*)y, (bf16*)pre_t, (bf16*)so, (bf16*)hrows, st1, st2, st3};
     hipStream_t st = (hipStream_t)stream;
     const int nrt = (T + 15) / 16;

@@ -75,6 +75,7 @@ class TrainEngine:
         self.flash_ce = (os.environ.get("EDGL_FLASH_CE", "1") != "0") if flash_ce is None else bool(flash_ce)
         self.ws_flash = e(int(lib.edgl_score_flash_workspace(self.R, C, I, I, self.code)), dtype=f32) if self.flash_ce else None
         self.hrows, self.hrows_c = e(self.R, C), e(self.R, C)
+        self.hrows_c.zero_()   # rows behind the weighted ones are never written on the fused path (and never read as data)
         self.labels_c = torch.zeros(self.R, device=dev, dtype=torch.int64)
         self.perm, self.inv = e(self.R, dtype=torch.int32), e(self.R, dtype=torch.int32)
         self.nvalid = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -181,8 +182,8 @@ class TrainEngine:
                                              _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
             # needed by the scoring: row compaction map (labels only), L2 term — same join: every cross-stream edge costs the
             # waiting stream ~6 us even when the other side finished long ago, and all of this ends under the QKVT projection
-            check(lib.edgl_compact_scan(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid), sst),
-                  "edgl_compact_scan")
+            check(lib.edgl_compact_scan_labels(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid),
+                                               _ptr(self.labels_c), sst), "edgl_compact_scan_labels")
             # (the transposed table image is NOT prepared here, although it depends on the weights only: written 200 us before
             # its use it has left the L2 by then and the scoring pass measured 109 -> 118 us — edgl_score_prepare_table)
             if m.l2_reg != 0.0:
@@ -222,7 +223,7 @@ class TrainEngine:
                                         _ptr(m.transform_ln.beta), B, T, C, float(dh1.rate), dh1.ptr(), 11 + 4 * i, 12 + 4 * i,
                                         _ptr(self.mpos), M, int(last), _ptr(b["ao"]), _ptr(b["a1"]), _ptr(b["st1"]), _ptr(b["pre_f"]),
                                         _ptr(b["f"]), _ptr(b["o"]), _ptr(b["y"]), _ptr(b["st2"]), _ptr(self.pre_t), _ptr(self.so),
-                                        _ptr(self.st3), _ptr(self.hrows), code, st), "edgl_tail_fwd")
+                                        _ptr(self.st3), _ptr(self.hrows_c), _ptr(self.inv), code, st), "edgl_tail_fwd")
             else:
                 self._dense_fwd(b["att"], blk.att_out.kernel, blk.att_out.bias, b["ao"], C, C)
                 self._ln_fwd(b["ao"], x, cin, blk.att_ln, drop(hd, 11 + 4 * i), b["a1"], b["st1"])
@@ -236,8 +237,9 @@ class TrainEngine:
             self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, C, C, gelu=True, pre=self.pre_t)
             self._ln_fwd(self.so, None, 0, m.transform_ln, ops.NO_DROP, self.hrows, self.st3, gpos=self.mpos)
         # rows whose label is 0 have weight 0 (EasyDGL.py:180): score only the weighted ones
-        check(lib.edgl_compact_gather(_ptr(self.hrows), _ptr(self.labels), _ptr(self.perm), R, C, _ptr(self.hrows_c),
-                                      _ptr(self.labels_c), code, st), "edgl_compact_gather")
+        if not (self.fused_tail and self.blk):   # the fused tail writes its head rows compacted (row map = inv)
+            check(lib.edgl_compact_gather(_ptr(self.hrows), _ptr(self.labels), _ptr(self.perm), R, C, _ptr(self.hrows_c),
+                                          _ptr(self.labels_c), code, st), "edgl_compact_gather")
         lab = self.labels_c
         if self.flash_ce:
             check(lib.edgl_score_flash_fwd_pre(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,

@@ -230,6 +230,9 @@ int edgl_compact_rows(const void* rows, const int64_t* labels, int R, int C, int
                       int32_t* nvalid, void* rows_c, int64_t* labels_c, int dtype, void* stream);
 /* The two halves of edgl_compact_rows: the scan needs the labels only (it may run before the rows exist), the gather the rows. */
 int edgl_compact_scan(const int64_t* labels, int R, int32_t* perm, int32_t* inv, int32_t* nvalid, void* stream);
+/* ... the scan that also writes the compacted labels (labels_c int64 [R]: weighted rows first, 0 behind them) */
+int edgl_compact_scan_labels(const int64_t* labels, int R, int32_t* perm, int32_t* inv, int32_t* nvalid, int64_t* labels_c,
+                             void* stream);
 int edgl_compact_gather(const void* rows, const int64_t* labels, const int32_t* perm, int R, int C, void* rows_c,
                         int64_t* labels_c, int dtype, void* stream);
 int edgl_scatter_rows(const void* rows_c, const int32_t* inv, int R, int C, void* rows, int dtype,
@@ -473,6 +476,8 @@ int edgl_time_function_bwd(const float* x, long n, const float* freq, const floa
  * The reference's LayerNorm is joint over (T, C) per sample (Base.py:12-67), so a workgroup owning a sample runs
  *   ao = att.Wo + bo ; a1 = LN1(dropout(ao) + x_in) ; f = gelu(a1.Wi + bi) ; o = f.Wout + bout ; y = LN2(dropout(o) + a1)
  *   head != 0:  so = gelu(y.Wt + bt) ; hrows[b*M + j] = LN3(so)[masked_pos[b, j]]                     (EasyDGL.py:136-146)
+ *               hrow_map (optional, int32 [B*M]): the row goes to hrows[hrow_map[b*M + j]] instead, rows with a negative entry
+ *               are dropped — with edgl_compact_scan_labels' `inv` the weighted rows land compacted, no edgl_compact_gather
  * with the activations in LDS between the steps; every intermediate the backward reads is written once:
  * ao, a1, o, y, pre_t, so [B,T,C]; pre_f, f [B,T,2C]; st1/st2/st3 f32 [B,2] = (mean, rstd).  pre_f and pre_t receive
  * gelu'(pre-activation), not the pre-activation: the derivative is all edgl_tail_bwd needs them for, and the forward has the
@@ -490,7 +495,7 @@ int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const void* pack, 
                   const float* b2, const float* g3, const float* b3, int B, int T, int C, float drop_rate,
                   const uint64_t* rng_state, uint32_t sid1, uint32_t sid2, const int64_t* masked_pos, int M, int head,
                   void* ao, void* a1, float* st1, void* pre_f, void* f, void* o, void* y, float* st2, void* pre_t,
-                  void* so, float* st3, void* hrows, int dtype, void* stream);
+                  void* so, float* st3, void* hrows, const int32_t* hrow_map, int dtype, void* stream);
 
 /* Backward of the same chain, one launch per block: given the gradient of the gathered head rows (head != 0: d_rows [*, C]
  * compact, masked_pos [B, M], dy_rowmap = the `inv` map of edgl_compact_rows or NULL) or of y (head == 0: d_y_in [B,T,C]),

@@ -136,7 +136,8 @@ def test_fused_block_tail_matches_the_unfused_kernels(case, drop):
         b = eng.blk[-1]
         out[fused] = dict(loss=float(eng.loss), grads=m._grad_arena.clone(),
                           **{k: b[k].float().clone() for k in ("ao", "a1", "pre_f", "f", "o", "y", "st1", "st2")},
-                          pre_t=eng.pre_t.float().clone(), so=eng.so.float().clone(), st3=eng.st3.clone(), hrows=eng.hrows.float().clone())
+                          pre_t=eng.pre_t.float().clone(), so=eng.so.float().clone(), st3=eng.st3.clone(),
+                          hrows=eng.hrows_c[:int(eng.nvalid[0])].float().clone())   # the weighted rows, compacted
     a, b = out[False], out[True]
     for k in ("pre_f", "pre_t"):   # the fused forward saves gelu'(pre-activation) in these buffers (include/easydgl_hip.h),
         x = a[k].double()          # rounded to bf16 once more
