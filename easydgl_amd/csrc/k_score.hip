@@ -97,6 +97,7 @@ struct ScoreP {
     const float* coef; const float* gscale;             // bwd
     float* slabs; float* bias_slabs;
     float* lab_out;                                     // flash forward: label logits [R]
+    float* coef_out;                                    // flash forward, compacted rows, whole table: loss coefficients [R]
     int table_ready;                                    // tableT already written by edgl_score_prepare_table
     int dbg;   // EDGL_DBG ablation bits (profiling only): 1 skip dl math, 2 skip second product, 4 skip z streaming, 8 skip logit MFMA
 };
@@ -378,7 +379,7 @@ __global__ void lse_combine_kernel(const float* part, int R, const int32_t* nval
 template <typename T>
 __global__ __launch_bounds__(256) void lse_label_kernel(const float* part, int R, const int32_t* nvalid, int xb, int zb, int G, int ztotal,
                                                         float* row_lse, const T* rows, const T* table, const float* out_bias,
-                                                        const int64_t* labels, int C, int i0, int i1, float* lab_out) {
+                                                        const int64_t* labels, int C, int i0, int i1, float* lab_out, float* coef_out) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;
     // two round trips: {row count, label}, then everything that hangs on them — chunk partials, row, label row of the table, bias —
@@ -420,7 +421,12 @@ __global__ __launch_bounds__(256) void lse_label_kernel(const float* part, int R
     a = wave_sum(a);
     if (lane == 0) {
         row_lse[r] = lse;
-        if (own) lab_out[r] = (lab == 0) ? -1000.0f : a + ob;
+        const float ll = (lab == 0) ? -1000.0f : a + ob;
+        if (own) lab_out[r] = ll;
+        if (coef_out) {   // d loss / d logit scale of the row: ce_loss_kernel's coefficient, its row count known as *nvalid
+            const float v = __expf(ll - lse), W = (float)Reff + 1e-5f;
+            coef_out[r] = (r < Reff && lab != 0) ? (1.f / W) * (v / (v + 1e-5f)) : 0.f;
+        }
     }
 }
 
@@ -947,6 +953,7 @@ __global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, con
     den = block_sum(den, red);
     const float W = den + 1e-5f;
     if (threadIdx.x == 0) loss_out[0] = num / W + (add_in ? add_in[0] : 0.f) + (add_in2 ? add_in2[0] : 0.f);   // + regularisation terms
+    if (!coef) return;    // (the flash forward wrote the coefficients: edgl_score_flash_fwd_coef)
 #pragma unroll
     for (int i = 0; i < CE_KEEP; ++i) {
         const int m = threadIdx.x + i * 1024;
@@ -1247,7 +1254,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     } else if (MODE == 1) {
         hipLaunchKernelGGL((lse_label_kernel<T>), dim3((p.R + 3) / 4), dim3(256), 0, st, part, p.R, p.nvalid, xb, ZBK, G, p.i1 - p.i0,
                            p.row_lse, reinterpret_cast<const T*>(p.rows), reinterpret_cast<const T*>(p.table), p.out_bias, p.labels,
-                           p.C, p.i0, p.i1, p.lab_out);
+                           p.C, p.i0, p.i1, p.lab_out, p.coef_out);
         EDGL_LAUNCH_CHECK();
         return EDGL_OK;
     } else {
@@ -1415,7 +1422,7 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
 
 extern "C" int edgl_ce_loss_fwd_add(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
                                     float* coef, const float* add_in, const float* add_in2, void* stream) {
-    EDGL_REQUIRE(row_lse && label_logit && labels && loss_out && coef, EDGL_ERR_NULL, "edgl_ce_loss_fwd: null pointer");
+    EDGL_REQUIRE(row_lse && label_logit && labels && loss_out, EDGL_ERR_NULL, "edgl_ce_loss_fwd: null pointer");   // coef may be NULL
     hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_lse, label_logit, labels, R, loss_out, coef,
                        add_in, add_in2);
     EDGL_LAUNCH_CHECK();
@@ -1503,6 +1510,24 @@ extern "C" int edgl_score_flash_fwd_pre(const void* rows, const void* table, con
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = row_lse; p.lab_out = label_logit; p.table_ready = table_ready;
     const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
+                             : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);
+}
+// edgl_score_flash_fwd over the whole table for COMPACTED rows (edgl_compact_*: the *nvalid weighted rows first, labels 0 behind
+// them) that also writes the loss coefficients coef[r] = (1 / (n + 1e-5)) * p_y / (p_y + 1e-5), n = *nvalid — what edgl_ce_loss_fwd
+// computes after a reduction over the rows; with them the backward does not wait for the loss kernel (EasyDGL.py:177-185).
+extern "C" int edgl_score_flash_fwd_coef(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
+                                         int C, int I, const int32_t* nvalid, float* row_lse, float* label_logit, float* coef,
+                                         float* workspace, int dtype, void* stream) {
+    int rc = check_score(rows, table, out_bias, R, C, I, 0, I, dtype, "edgl_score_flash_fwd_coef");
+    if (rc) return rc;
+    EDGL_REQUIRE(labels && row_lse && label_logit && workspace && nvalid && coef, EDGL_ERR_NULL,
+                 "edgl_score_flash_fwd_coef: null pointer (the row count of the compaction is required)");
+    ScoreP p{};
+    p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = 0;
+    p.i1 = I; p.nvalid = nvalid; p.row_lse = row_lse; p.lab_out = label_logit; p.coef_out = coef;
+    const BwdPlan plan = bwd_plan(R, C, I, I, dtype == EDGL_BF16 ? 2 : 4);
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
                              : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);

@@ -85,6 +85,7 @@ class TrainEngine:
         self.loss_aux, self.loss_tpp = torch.zeros(1, device=dev, dtype=f32), torch.zeros(1, device=dev, dtype=f32)
         self.ws_l2 = e(1024, dtype=f32)
         self.side = torch.cuda.Stream(device=dev)
+        self._pending_loss = None
         # ---- backward temporaries -------------------------------------------------------------------------------
         self.d_rows = e(self.R, C)
         self.G1, self.G2, self.G3, self.G4 = e(B, T, C), e(B, T, C), e(B, T, C), e(B, T, C)
@@ -241,17 +242,24 @@ class TrainEngine:
             check(lib.edgl_compact_gather(_ptr(self.hrows), _ptr(self.labels), _ptr(self.perm), R, C, _ptr(self.hrows_c),
                                           _ptr(self.labels_c), code, st), "edgl_compact_gather")
         lab = self.labels_c
+        aux = _ptr(self.loss_aux) if m.l2_reg != 0.0 else None
+        tpp = _ptr(self.loss_tpp) if (m.ct_reg != 0.0 and self.blk) else None
         if self.flash_ce:
-            check(lib.edgl_score_flash_fwd_pre(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
-                                               _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.ws_flash), 0, code,
-                                               st), "edgl_score_flash_fwd_pre")
+            # the forward pass writes the loss coefficients itself (the row count of the loss is the compaction's): the backward
+            # starts behind it, and the loss kernel — a one-workgroup reduction over the rows — leaves the critical path
+            check(lib.edgl_score_flash_fwd_coef(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I,
+                                                _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.coef),
+                                                _ptr(self.ws_flash), code, st), "edgl_score_flash_fwd_coef")
+            # (launched on the side stream at the join the backward has anyway: an event record of its own costs the main
+            # stream as much as the kernel)
+            self._pending_loss = lambda s: check(lib.edgl_ce_loss_fwd_add(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R,
+                                                                          _ptr(self.loss), None, aux, tpp, s), "edgl_ce_loss_fwd_add")
         else:
             check(lib.edgl_score_lse_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
                                          _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
                   "edgl_score_lse_fwd")
-        check(lib.edgl_ce_loss_fwd_add(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef),
-                                       _ptr(self.loss_aux) if m.l2_reg != 0.0 else None,
-                                       _ptr(self.loss_tpp) if (m.ct_reg != 0.0 and self.blk) else None, st), "edgl_ce_loss_fwd_add")
+            check(lib.edgl_ce_loss_fwd_add(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef),
+                                           aux, tpp, st), "edgl_ce_loss_fwd_add")
         # ================= backward =================
         self._ws_i = 0
         check(lib.edgl_reduce_defer(1, st), "edgl_reduce_defer")
@@ -261,8 +269,12 @@ class TrainEngine:
             # never leave the thread in deferred mode: later ops would queue reductions that nobody flushes
             lib.edgl_reduce_defer(-1, st)
             lib.edgl_gemm_dw_defer(-1, st)
+            self._pending_loss = None
             raise
         check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")   # runs the remaining queued reductions in one launch
+        if self._pending_loss is not None:   # (no block: no side-stream join in the backward)
+            self._pending_loss(st)
+            self._pending_loss = None
         torch.cuda.current_stream().wait_stream(self.side)
 
     def _issue_backward(self, st, drop, tab, tab_c, lab):
@@ -347,6 +359,9 @@ class TrainEngine:
                 # every slab reduction queued so far (weight-gradient GEMMs, BiMAU / LayerNorm partials) runs on the side
                 # stream under the embedding backward, whose atomics leave the CUs mostly idle
                 self.side.wait_stream(torch.cuda.current_stream())
+                if self._pending_loss is not None:
+                    self._pending_loss(self.side.cuda_stream)
+                    self._pending_loss = None
                 check(lib.edgl_reduce_flush(self.side.cuda_stream), "edgl_reduce_flush")
             # both residual branches feed the first C channels of the block input (temporal.py:447, EasyDGL.py:116)
             if i > 0:

@@ -296,6 +296,13 @@ int edgl_score_prepare_table(const void* table, int R, int C, int I, int i0, int
 int edgl_score_flash_fwd_pre(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
                              int I, int i0, int i1, const int32_t* nvalid, float* row_lse, float* label_logit,
                              float* workspace, int table_ready, int dtype, void* stream);
+/* edgl_score_flash_fwd over the whole table for COMPACTED rows (edgl_compact_*: the *nvalid weighted rows first, labels 0 behind)
+ * that also writes the loss coefficients coef[r] = (1 / (n + 1e-5)) * p_y / (p_y + 1e-5), n = *nvalid — exactly what
+ * edgl_ce_loss_fwd computes after its reduction over the rows (EasyDGL.py:177-185); the backward then does not wait for the loss
+ * kernel, which may be given coef = NULL. */
+int edgl_score_flash_fwd_coef(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
+                              int I, const int32_t* nvalid, float* row_lse, float* label_logit, float* coef, float* workspace,
+                              int dtype, void* stream);
 int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                          const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
                          int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias, float* workspace,
