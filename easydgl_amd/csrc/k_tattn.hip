@@ -432,18 +432,67 @@ __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
     Frag4<T> qf[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) qf[dt] = frag_ld<T>(Qr + dt * 16 + g4);
+    uint4 qrow[(sizeof(T) == 2 && DT <= 2) ? 2 * DT : 1];   // bf16: this lane's query row (one head slice), kept for the interval dot products
+    if constexpr (sizeof(T) == 2 && DT <= 2) {
+#pragma unroll
+        for (int c = 0; c < 2 * DT; ++c) qrow[c] = *reinterpret_cast<const uint4*>(Qr + c * 8);
+    }
+    // The interval term of a pair hangs on two dependent loads (timestamp -> bucket -> table row).  Written per pair — with the
+    // table row behind `bucket < tab_rows ? .. : 0` — that is a branch and two waits per pair: 8 dependent round trips per key
+    // tile.  Here the four timestamps / ids of a tile travel together, then the four table rows (clamped, unconditional).
     auto scores = [&](int kt, float (&x)[4], int (&bk)[4]) {
         const int kr = min(kt * 16 + l15, p.T - 1);
+        float tsk[4];
+        int64_t idk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kcl = min(kt * 16 + g4 + r, p.T - 1);
+            tsk[r] = tsr[kcl]; idk[r] = idr[kcl];
+        }
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) s = mma16(frag_ld<T>(Kb + (long)kr * p.ldk + dt * 16 + g4), qf[dt], s);
+        const T* rowp[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int k = kt * 16 + g4 + r, kcl = min(k, p.T - 1);
-            bk[r] = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
-            const float madd = k >= p.T ? -INFINITY : (idr[kcl] == 0 ? PADV : 0.f);
-            const float g = bk[r] < t.tab_rows ? dot_rows<T, DT>(Qr, tab_row<T>(Kt, t.ldt, t.tab_rows, bk[r])) : 0.f;   // temporal.py:58
-            float v = fmaf(s[r] + g, p.cscale, madd);                                     // temporal.py:56-62
+            bk[r] = bucket_of(xq1, tsk[r] / t.time_scale, t.timelen);
+            rowp[r] = tab_row<T>(Kt, t.ldt, t.tab_rows, bk[r]);
+        }
+        float g[4];
+        if constexpr (sizeof(T) == 2 && DT <= 2) {     // (wider head slices: the four rows no longer fit in registers)
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+            uint4 y[4][2 * DT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 2 * DT; ++c) y[r][c] = *reinterpret_cast<const uint4*>(rowp[r] + c * 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 2 * DT; ++c) asm volatile("" : "+v"(y[r][c].x), "+v"(y[r][c].y), "+v"(y[r][c].z), "+v"(y[r][c].w));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2 * DT; ++c) {
+                    const uint4 xq = qrow[c];
+                    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, xq.x), __builtin_bit_cast(bf2, y[r][c].x), acc, false);
+                    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, xq.y), __builtin_bit_cast(bf2, y[r][c].y), acc, false);
+                    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, xq.z), __builtin_bit_cast(bf2, y[r][c].z), acc, false);
+                    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, xq.w), __builtin_bit_cast(bf2, y[r][c].w), acc, false);
+                }
+                g[r] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = bk[r] < t.tab_rows ? dot_rows<T, DT>(Qr, rowp[r]) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kt * 16 + g4 + r;
+            const float madd = k >= p.T ? -INFINITY : (idk[r] == 0 ? PADV : 0.f);
+            const float gi = bk[r] < t.tab_rows ? g[r] : 0.f;                            // temporal.py:58
+            float v = fmaf(s[r] + gi, p.cscale, madd);                                    // temporal.py:56-62
             if (causal && k > q && k < p.T) v = PADV;
             x[r] = v;
         }
