@@ -405,6 +405,84 @@ __device__ __forceinline__ void bucket_store(const float* Ws, int LDG, int NBp, 
 #pragma unroll 4
     for (int c = (lane >> 4) * 4; c < NBp; c += 16) frag_st<T>(dst_row + c, frag_from_f4<T>(Ws + l15 * LDG + c));
 }
+// Interval dot products of a key tile's four pairs for 16-wide head slices (bf16, DT = 1; at DT = 2 the batches cost a wave of occupancy): all table rows are fetched before the
+// first use (clamped addresses; the caller masks out-of-table buckets) — per pair, behind `bucket < tab_rows ? .. : 0`, they
+// were a branch and a wait each.  xa: this lane's row a (2*DT 16-byte vectors, loaded once); TWO: also <xb, tab2[bucket]>.
+template <int DT, bool TWO>
+__device__ __forceinline__ void interval_dots4(const uint4 (&xa)[2 * DT], const uint4 (&xb)[2 * DT], const bf16* tab1, const bf16* tab2,
+                                               int ldt, int tab_rows, const int (&bk)[4], float (&g1)[4], float (&g2)[4]) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    uint4 y1[4][2 * DT], y2[TWO ? 4 : 1][2 * DT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long off = (long)min(bk[r], tab_rows - 1) * ldt;
+#pragma unroll
+        for (int c = 0; c < 2 * DT; ++c) {
+            y1[r][c] = *reinterpret_cast<const uint4*>(tab1 + off + c * 8);
+            if constexpr (TWO) y2[r][c] = *reinterpret_cast<const uint4*>(tab2 + off + c * 8);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 2 * DT; ++c) {
+            asm volatile("" : "+v"(y1[r][c].x), "+v"(y1[r][c].y), "+v"(y1[r][c].z), "+v"(y1[r][c].w));
+            if constexpr (TWO) asm volatile("" : "+v"(y2[r][c].x), "+v"(y2[r][c].y), "+v"(y2[r][c].z), "+v"(y2[r][c].w));
+        }
+    auto dot = [](const uint4& a, const uint4& b, float acc) {
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.x), __builtin_bit_cast(bf2, b.x), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.y), __builtin_bit_cast(bf2, b.y), acc, false);
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.z), __builtin_bit_cast(bf2, b.z), acc, false);
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, a.w), __builtin_bit_cast(bf2, b.w), acc, false);
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2 * DT; ++c) {
+            a1 = dot(xa[c], y1[r][c], a1);
+            if constexpr (TWO) a2 = dot(xb[c], y2[r][c], a2);
+        }
+        g1[r] = a1; g2[r] = a2;
+    }
+}
+
+// ... the same with a different left row per pair (the key-side backward: rows of four queries against their buckets' rows)
+template <int DT>
+__device__ __forceinline__ void interval_dots4_rows(const bf16* a0, long lda, const int (&arow)[4], const bf16* tab, int ldt,
+                                                    int tab_rows, const int (&bk)[4], float (&g)[4]) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    uint4 x[4][2 * DT], y[4][2 * DT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long off = (long)min(bk[r], tab_rows - 1) * ldt;
+#pragma unroll
+        for (int c = 0; c < 2 * DT; ++c) {
+            x[r][c] = *reinterpret_cast<const uint4*>(a0 + (long)arow[r] * lda + c * 8);
+            y[r][c] = *reinterpret_cast<const uint4*>(tab + off + c * 8);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 2 * DT; ++c) {
+            asm volatile("" : "+v"(x[r][c].x), "+v"(x[r][c].y), "+v"(x[r][c].z), "+v"(x[r][c].w));
+            asm volatile("" : "+v"(y[r][c].x), "+v"(y[r][c].y), "+v"(y[r][c].z), "+v"(y[r][c].w));
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2 * DT; ++c) {
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x[r][c].x), __builtin_bit_cast(bf2, y[r][c].x), acc, false);
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x[r][c].y), __builtin_bit_cast(bf2, y[r][c].y), acc, false);
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x[r][c].z), __builtin_bit_cast(bf2, y[r][c].z), acc, false);
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, x[r][c].w), __builtin_bit_cast(bf2, y[r][c].w), acc, false);
+        }
+        g[r] = acc;
+    }
+}
+
 template <typename T, int DT>
 __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
     extern __shared__ __attribute__((aligned(16))) char lds_c[];
@@ -432,8 +510,8 @@ __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
     Frag4<T> qf[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) qf[dt] = frag_ld<T>(Qr + dt * 16 + g4);
-    uint4 qrow[(sizeof(T) == 2 && DT <= 2) ? 2 * DT : 1];   // bf16: this lane's query row (one head slice), kept for the interval dot products
-    if constexpr (sizeof(T) == 2 && DT <= 2) {
+    uint4 qrow[(sizeof(T) == 2 && DT == 1) ? 2 * DT : 1];   // bf16: this lane's query row (one head slice), kept for the interval dot products
+    if constexpr (sizeof(T) == 2 && DT == 1) {
 #pragma unroll
         for (int c = 0; c < 2 * DT; ++c) qrow[c] = *reinterpret_cast<const uint4*>(Qr + c * 8);
     }
@@ -442,6 +520,22 @@ __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
     // tile.  Here the four timestamps / ids of a tile travel together, then the four table rows (clamped, unconditional).
     auto scores = [&](int kt, float (&x)[4], int (&bk)[4]) {
         const int kr = min(kt * 16 + l15, p.T - 1);
+        if constexpr (!(sizeof(T) == 2 && DT == 1)) {       // wide head slices / f32: per pair (four rows do not fit in registers)
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) s = mma16(frag_ld<T>(Kb + (long)kr * p.ldk + dt * 16 + g4), qf[dt], s);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kt * 16 + g4 + r, kcl = min(k, p.T - 1);
+                bk[r] = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
+                const float madd = k >= p.T ? -INFINITY : (idr[kcl] == 0 ? PADV : 0.f);
+                const float g = bk[r] < t.tab_rows ? dot_rows<T, DT>(Qr, tab_row<T>(Kt, t.ldt, t.tab_rows, bk[r])) : 0.f;   // temporal.py:58
+                float v = fmaf(s[r] + g, p.cscale, madd);                                     // temporal.py:56-62
+                if (causal && k > q && k < p.T) v = PADV;
+                x[r] = v;
+            }
+            return;
+        }
         float tsk[4];
         int64_t idk[4];
 #pragma unroll
@@ -459,7 +553,7 @@ __global__ __launch_bounds__(256) void tiattn_fwd_kernel(TaP p, TiP t) {
             rowp[r] = tab_row<T>(Kt, t.ldt, t.tab_rows, bk[r]);
         }
         float g[4];
-        if constexpr (sizeof(T) == 2 && DT <= 2) {     // (wider head slices: the four rows no longer fit in registers)
+        if constexpr (sizeof(T) == 2 && DT == 1) {     // (wider head slices: the four rows no longer fit in registers)
             typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
             uint4 y[4][2 * DT];
 #pragma unroll
@@ -599,6 +693,12 @@ __global__ __launch_bounds__(256) void tiattn_bwd_q_kernel(TaP p, TiP t) {
         if (qok && g4 == 0) p.st_d[j.bp * p.T + q] = dsum;
     }
     const float m = p.st_m[j.bp * p.T + qc], invl = 1.0f / p.st_l[j.bp * p.T + qc];
+    constexpr bool NARROW = sizeof(T) == 2 && DT == 1;      // interval dots with batched table rows (interval_dots4)
+    uint4 qrow[NARROW ? 2 * DT : 1], dorow[NARROW ? 2 * DT : 1];
+    if constexpr (NARROW) {
+#pragma unroll
+        for (int c = 0; c < 2 * DT; ++c) { qrow[c] = *reinterpret_cast<const uint4*>(Qr + c * 8); dorow[c] = *reinterpret_cast<const uint4*>(dOr + c * 8); }
+    }
     wave_lds_sync();
     f32x4 acc[DT];
 #pragma unroll
@@ -616,14 +716,36 @@ __global__ __launch_bounds__(256) void tiattn_bwd_q_kernel(TaP p, TiP t) {
         if (dk.thresh != 0u) { h0 = drop_hash_pair(dk, dbase + kt * 16 + g4); h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2); }
         const uint32_t hb[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16};
         f32x4 ds;
+        float tsk[4];
+        int64_t idk[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int k = kt * 16 + g4 + r, kcl = min(k, p.T - 1);
-            const int bk = bucket_of(xq1, tsr[kcl] / t.time_scale, t.timelen);
-            const bool pad = k >= p.T || idr[kcl] == 0, fut = causal && k > q;
+            const int kcl = min(kt * 16 + g4 + r, p.T - 1);
+            tsk[r] = tsr[kcl]; idk[r] = idr[kcl];
+        }
+        int bks[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bks[r] = bucket_of(xq1, tsk[r] / t.time_scale, t.timelen);
+        float gq[4], gd[4];
+        if constexpr (NARROW) {
+            interval_dots4<DT, true>(qrow, dorow, reinterpret_cast<const bf16*>(Kt), reinterpret_cast<const bf16*>(Vt), t.ldt, t.tab_rows,
+                                     bks, gq, gd);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool inb = bks[r] < t.tab_rows;
+                gq[r] = inb ? dot_rows<T, DT>(Qr, tab_row<T>(Kt, t.ldt, t.tab_rows, bks[r])) : 0.f;
+                gd[r] = inb ? dot_rows<T, DT>(dOr, tab_row<T>(Vt, t.ldt, t.tab_rows, bks[r])) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kt * 16 + g4 + r;
+            const int bk = bks[r];
+            const bool pad = k >= p.T || idk[r] == 0, fut = causal && k > q;
             const bool inb = bk < t.tab_rows;
-            const float g = inb ? dot_rows<T, DT>(Qr, tab_row<T>(Kt, t.ldt, t.tab_rows, bk)) : 0.f;
-            const float dw = inb ? dot_rows<T, DT>(dOr, tab_row<T>(Vt, t.ldt, t.tab_rows, bk)) : 0.f;   // dA[q,k] gets dO[q].Vtime[dt(q,k)]
+            const float g = inb ? gq[r] : 0.f;
+            const float dw = inb ? gd[r] : 0.f;                                                          // dA[q,k] gets dO[q].Vtime[dt(q,k)]
             float v = fmaf(s[r] + g, p.cscale, k >= p.T ? -INFINITY : (pad ? PADV : 0.f));
             if (fut && k < p.T) v = PADV;
             const float P = __expf(v - m) * invl;
@@ -689,14 +811,28 @@ __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
         }
         // interval terms of the 4 (q, k) pairs of this lane
         float gq[4], dwq[4];
-        int qcs[4];
+        int qcs[4], bks[4];
+        float tsq[4], stm[4], stl[4], std_[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {      // per-query scalars of the tile: one batch (unconditional, clamped rows)
             qcs[r] = min(qt * 16 + g4 + r, p.T - 1);
-            const int bk = bucket_of(tsr[qcs[r] + 1] / t.time_scale, xk, t.timelen);
-            const bool inb = bk < t.tab_rows;
-            gq[r] = inb ? dot_rows<T, DT>(Qb + (long)qcs[r] * p.ldq, tab_row<T>(Kt, t.ldt, t.tab_rows, bk)) : 0.f;
-            dwq[r] = inb ? dot_rows<T, DT>(dOb + (long)qcs[r] * p.ld_do, tab_row<T>(Vt, t.ldt, t.tab_rows, bk)) : 0.f;
+            const long si = j.bp * p.T + qcs[r];
+            tsq[r] = tsr[qcs[r] + 1]; stm[r] = p.st_m[si]; stl[r] = p.st_l[si]; std_[r] = p.st_d[si];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bks[r] = bucket_of(tsq[r] / t.time_scale, xk, t.timelen);
+        if constexpr (sizeof(T) == 2 && DT == 1) {
+            interval_dots4_rows<DT>(reinterpret_cast<const bf16*>(Qb), p.ldq, qcs, reinterpret_cast<const bf16*>(Kt), t.ldt, t.tab_rows, bks, gq);
+            interval_dots4_rows<DT>(reinterpret_cast<const bf16*>(dOb), p.ld_do, qcs, reinterpret_cast<const bf16*>(Vt), t.ldt, t.tab_rows, bks, dwq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const bool inb = bks[r] < t.tab_rows; gq[r] = inb ? gq[r] : 0.f; dwq[r] = inb ? dwq[r] : 0.f; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool inb = bks[r] < t.tab_rows;
+                gq[r] = inb ? dot_rows<T, DT>(Qb + (long)qcs[r] * p.ldq, tab_row<T>(Kt, t.ldt, t.tab_rows, bks[r])) : 0.f;
+                dwq[r] = inb ? dot_rows<T, DT>(dOb + (long)qcs[r] * p.ld_do, tab_row<T>(Vt, t.ldt, t.tab_rows, bks[r])) : 0.f;
+            }
         }
         f32x4 a4, ds;
 #pragma unroll
@@ -706,7 +842,7 @@ __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
             const bool fut = causal && k > q;
             float v = fmaf(s[r] + gq[r], p.cscale, madd);
             if (fut && kok) v = PADV;
-            const float P = (q < p.T) ? __expf(v - p.st_m[si]) / p.st_l[si] : 0.f;
+            const float P = (q < p.T) ? __expf(v - stm[r]) / stl[r] : 0.f;
             bool keep = true;
             if (dk.thresh != 0u) {
                 const uint32_t h = drop_hash_pair(dk, (uint32_t)(si * p.T) + (uint32_t)(k & ~1));
@@ -714,7 +850,7 @@ __global__ __launch_bounds__(256) void tiattn_bwd_k_kernel(TaP p, TiP t) {
             }
             a4[r] = keep ? P * dk.scale : 0.f;
             const float dP = keep ? (da[r] + dwq[r]) * dk.scale : 0.f;
-            ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - p.st_d[si]) * p.cscale;
+            ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - std_[r]) * p.cscale;
         }
         const Frag4<T> af = frag_from_acc<T>(a4), dsf = frag_from_acc<T>(ds);
 #pragma unroll
