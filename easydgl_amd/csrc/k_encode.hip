@@ -24,12 +24,24 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
     if (row >= (long)p.B * p.T) return;
     const int cv = (int)(gid % cpr), c0 = cv * 8, j0 = c0 >> 1;
     const int t = (int)(row % p.T);
+    // Two rounds of loads: everything addressed by (row, t, channel) — id, timestamps, time scales, position row, mark embedding —
+    // then the two rows addressed by the id (mark-table row, item row; unconditional, id 0 / MASK handled by selects).  Written
+    // where first used, each was a load with its own wait: ~6 dependent round trips in a kernel that lives for 1.6 block rounds.
     const int64_t id = p.ids[row];
+    const int t1 = (t == 0) ? 1 : t;
+    const long r1 = p.T > 1 ? row - t + t1 : row + 1;     // (T == 1: ts has no neighbour; the span is 0 below)
+    const float ts0 = p.ts[row], tsa = p.ts[p.T > 1 ? r1 : row], tsb = p.ts[p.T > 1 ? r1 - 1 : row];
+    const float4 sc4 = *reinterpret_cast<const float4*>(p.tscale + j0);
+    const float4 p0 = *reinterpret_cast<const float4*>(p.pos_tab + t * p.C + c0), p1 = *reinterpret_cast<const float4*>(p.pos_tab + t * p.C + c0 + 4);
+    const float4 m0 = *reinterpret_cast<const float4*>(p.mark_emb + p.C + c0), m1 = *reinterpret_cast<const float4*>(p.mark_emb + p.C + c0 + 4);
     // EasyDGL.py:71 — float32 division (quantisation point shared with the oracle)
-    const float tsx = p.ts[row] / p.time_scale;
+    const float tsx = ts0 / p.time_scale;
     // EasyDGL.py:76-77 — MASK -> row 0 of the mark table
     const int64_t mid = (id == p.mask_id) ? 0 : id;
     const uint8_t* mrow = p.mark_table + mid * p.E;
+    const T* it = reinterpret_cast<const T*>(p.item_tab) + id * p.C + c0;      // id 0: row 0 is read and dropped
+    Vec16<T> iv0 = ld16<T>(it), iv1 = iv0;
+    if constexpr (sizeof(T) == 4) iv1 = ld16<T>(it + 4);
     int nm = 0;
     if (p.E == 16) {   // one 16-byte row: four v_sad_u8 instead of 16 dependent byte loads
         const uint4 mv = *reinterpret_cast<const uint4*>(mrow);
@@ -45,20 +57,14 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
     }
     if (cv == 0) {
         // EasyDGL.py:73-74 — span[t] = clip(ts[t]-ts[t-1], 0, 100); span[0] := span[1]
-        const int t1 = (t == 0) ? 1 : t;
-        float sp = 0.f;
-        if (p.T > 1) {
-            const long r1 = row - t + t1;
-            const float a = p.ts[r1] / p.time_scale, bq = p.ts[r1 - 1] / p.time_scale;
-            sp = fminf(fmaxf(a - bq, 0.f), 100.f);
-        }
-        p.spans[row] = sp;
+        const float a = tsa / p.time_scale, bq = tsb / p.time_scale;
+        p.spans[row] = p.T > 1 ? fminf(fmaxf(a - bq, 0.f), 100.f) : 0.f;
     }
     float v[3][8];
     // coding.py:141-145 — x / scale (float32 division), sin on even / cos on odd channels
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float arg = tsx / p.tscale[j0 + q];
+        const float arg = tsx / (q == 0 ? sc4.x : q == 1 ? sc4.y : q == 2 ? sc4.z : sc4.w);
         float sn, cs;
         if constexpr (sizeof(T) == 4) {
             sincosf(arg, &sn, &cs);   // parity mode: full-precision sin/cos of the float32 argument
@@ -75,24 +81,23 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
         v[0][2 * q] = sn; v[0][2 * q + 1] = cs;
     }
     const float sq = sqrtf((float)p.C);  // coding.py:62-63
-    if (id != 0) {  // coding.py:56-57 zero-padded row 0
-        const T* it = reinterpret_cast<const T*>(p.item_tab) + id * p.C + c0;
+    {   // coding.py:56-57 zero-padded row 0
+        const float on = id != 0 ? sq : 0.f;
         if constexpr (sizeof(T) == 2) {
-            const Vec16<T> iv = ld16<T>(it);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[0][q] += to_f32(iv.v[q]) * sq;
+            for (int q = 0; q < 8; ++q) v[0][q] = id != 0 ? v[0][q] + to_f32(iv0.v[q]) * on : v[0][q];
         } else {
-            const Vec16<T> i0 = ld16<T>(it), i1 = ld16<T>(it + 4);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { v[0][q] += to_f32(i0.v[q]) * sq; v[0][4 + q] += to_f32(i1.v[q]) * sq; }
+            for (int q = 0; q < 4; ++q) {
+                v[0][q] = id != 0 ? v[0][q] + to_f32(iv0.v[q]) * on : v[0][q];
+                v[0][4 + q] = id != 0 ? v[0][4 + q] + to_f32(iv1.v[q]) * on : v[0][4 + q];
+            }
         }
     }
     {
-        const float4 p0 = *reinterpret_cast<const float4*>(p.pos_tab + t * p.C + c0), p1 = *reinterpret_cast<const float4*>(p.pos_tab + t * p.C + c0 + 4);
         v[1][0] = p0.x; v[1][1] = p0.y; v[1][2] = p0.z; v[1][3] = p0.w; v[1][4] = p1.x; v[1][5] = p1.y; v[1][6] = p1.z; v[1][7] = p1.w;
         // EasyDGL.py:87-88 — 0/1 mark values index the zero-padded mark-embedding table
         const float fn = (p.E > 1) ? (float)nm : 0.f;
-        const float4 m0 = *reinterpret_cast<const float4*>(p.mark_emb + p.C + c0), m1 = *reinterpret_cast<const float4*>(p.mark_emb + p.C + c0 + 4);
         v[2][0] = fn * m0.x; v[2][1] = fn * m0.y; v[2][2] = fn * m0.z; v[2][3] = fn * m0.w;
         v[2][4] = fn * m1.x; v[2][5] = fn * m1.y; v[2][6] = fn * m1.z; v[2][7] = fn * m1.w;
     }
