@@ -777,6 +777,30 @@ __global__ void slab_reduce_kernel(SlabJob j0, SlabJob j1, int nb0, int nslab, c
     const SlabJob& j = first ? j0 : j1;
     const long bid = first ? blockIdx.x : blockIdx.x - nb0, nblk = first ? nb0 : (long)gridDim.x - nb0;
     TO* out = reinterpret_cast<TO*>(j.out);
+    if constexpr (sizeof(TO) == 4) {
+        // f32 output with everything a multiple of 4 (the table gradient): 16-byte vectors, the slabs of a group of four fetched
+        // together (slab index clamped, the surplus weighted 0) — one element per thread and slab was a round trip per slab
+        if (((j.lo | j.hi | j.n | j.zero_first) & 3) == 0 && ((uintptr_t)j.slabs & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+            for (long i = j.lo + (bid * blockDim.x + threadIdx.x) * 4; i < j.hi; i += nblk * blockDim.x * 4) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int s0 = 0; s0 < nslab; s0 += 4) {
+                    float4 x[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const float4*>(j.slabs + (long)min(s0 + k, nslab - 1) * j.n + i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float w = s0 + k < nslab ? 1.f : 0.f;
+                        a.x = s0 + k < nslab ? a.x + x[k].x : a.x; a.y = s0 + k < nslab ? a.y + x[k].y : a.y;
+                        a.z = s0 + k < nslab ? a.z + x[k].z : a.z; a.w = s0 + k < nslab ? a.w + x[k].w : a.w;
+                        (void)w;
+                    }
+                }
+                const bool z = i < j.zero_first;
+                *reinterpret_cast<float4*>(out + i) = z ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(a.x * gs, a.y * gs, a.z * gs, a.w * gs);
+            }
+            return;
+        }
+    }
     for (long i = j.lo + bid * blockDim.x + threadIdx.x; i < j.hi; i += nblk * blockDim.x) {
         float a = 0.f;
         for (int s = 0; s < nslab; ++s) a += j.slabs[(long)s * j.n + i];
@@ -808,22 +832,59 @@ __global__ void flash_finish_kernel(const float* slabs, const float* part, const
                                     int G, int ztotal, const float* gscale, TO* out) {
     const float gs = gscale ? gscale[0] : 1.0f;
     const int Reff = nvalid ? min(R, nvalid[0]) : R;
-    const DevPlan dp = dev_plan(Reff, xb, G, ztotal, zb);
-    const long stride = (long)dp.nx * xb * C, nval = (long)Reff * C, n = (long)R * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        if (i < nval) {
-            const int r = (int)(i / C), c = (int)(i % C);
+    const DevPlan dp = dev_plan(max(Reff, 1), xb, G, ztotal, zb);
+    const long stride = (long)dp.nx * xb * C;
+    const int nch = dp.nchunk, C4 = C >> 2;
+    constexpr int MAXCH = 16;
+    // a thread = 4 consecutive channels of a row; two rounds of loads: the row's scalars with every chunk's slab values and
+    // maxima (chunk index clamped, the surplus weighted 0), then the label row of the table.  One element per thread with the
+    // chunk loop rolled was a dependent round trip per chunk.
+    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < (long)R * C4; i4 += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i4 / C4), c = (int)(i4 % C4) * 4, rc = min(r, max(Reff - 1, 0));
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nch <= MAXCH && (((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)table) & 15) == 0 && (stride & 3) == 0) {
+            float cf = coef[rc], lse = row_lse[rc];
+            int64_t lab = labels[rc];
+            float4 sl[MAXCH];
+            float pm[MAXCH];
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) {
+                const int sc = min(s, nch - 1);
+                sl[s] = *reinterpret_cast<const float4*>(slabs + (long)sc * stride + (long)rc * C + c);
+                pm[s] = part[((long)rc * nch + sc) * 2];
+            }
+            asm volatile("" : "+v"(cf), "+v"(lse), "+v"(lab));
+            float tb[4];
+            {
+                const TO* trow = table + (lab > 0 ? lab : 0) * C + c;
+                if constexpr (sizeof(TO) == 2) { const Frag4<TO> f = frag_ld<TO>(trow); for (int q = 0; q < 4; ++q) tb[q] = to_f32(f.v[q]); }
+                else { const float4 f = *reinterpret_cast<const float4*>(trow); tb[0] = f.x; tb[1] = f.y; tb[2] = f.z; tb[3] = f.w; }
+            }
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) {
+                const float e = s < nch ? __expf(pm[s] - lse) : 0.f;
+                const float x[4] = {sl[s].x, sl[s].y, sl[s].z, sl[s].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = s < nch ? fmaf(x[q], e, a[q]) : a[q];
+            }
+            const bool on = r < Reff && cf != 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = on ? gs * cf * (a[q] - (lab > 0 ? tb[q] : 0.f)) : 0.f;
+        } else if (r < Reff) {
             const float cf = coef[r];
             if (cf != 0.f) {
                 const float lse = row_lse[r];
-                float a = 0.f;
-                for (int s = 0; s < dp.nchunk; ++s) a += slabs[(long)s * stride + i] * __expf(part[((long)r * dp.nchunk + s) * 2] - lse);
                 const int64_t lab = labels[r];
-                v = gs * cf * (a - (lab > 0 ? to_f32(table[lab * C + c]) : 0.f));
+                for (int q = 0; q < 4; ++q) {
+                    float a = 0.f;
+                    for (int s = 0; s < nch; ++s) a += slabs[(long)s * stride + (long)r * C + c + q] * __expf(part[((long)r * nch + s) * 2] - lse);
+                    v[q] = gs * cf * (a - (lab > 0 ? to_f32(table[lab * C + c + q]) : 0.f));
+                }
             }
         }
-        out[i] = from_f32<TO>(v);
+        if constexpr (sizeof(TO) == 2) { const Frag4<TO> f = frag_from_acc<TO>(f32x4{v[0], v[1], v[2], v[3]}); *reinterpret_cast<uint2*>(out + (long)r * C + c) = *reinterpret_cast<const uint2*>(&f); }
+        else *reinterpret_cast<float4*>(out + (long)r * C + c) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -1258,7 +1319,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
         EDGL_LAUNCH_CHECK();
         return EDGL_OK;
     } else {
-        hipLaunchKernelGGL((flash_finish_kernel<T>), dim3((unsigned)std::min<long>((nrc + 255) / 256, 2048)), dim3(256), 0, st,
+        hipLaunchKernelGGL((flash_finish_kernel<T>), dim3((unsigned)std::min<long>((nrc / 4 + 255) / 256, 2048)), dim3(256), 0, st,
                            ws + plan.off_slabY, part, p.row_lse, p.coef, p.labels, reinterpret_cast<const T*>(p.table), p.nvalid,
                            p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
         EDGL_LAUNCH_CHECK();
@@ -1279,7 +1340,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
         EDGL_LAUNCH_CHECK();
         const long n = (long)p.I * p.C, lo = (long)p.i0 * p.C, hi = (long)p.i1 * p.C;
         const long nb = p.I - 1, blo = std::max(p.i0, 1) - 1, bhi = p.i1 - 1;
-        const int nb0 = (int)std::min<long>((hi - lo + 255) / 256, 2048), nb1 = bhi > blo ? (int)std::min<long>((bhi - blo + 255) / 256, 256) : 0;
+        const int nb0 = (int)std::min<long>(((hi - lo) / 4 + 255) / 256 + 1, 2048), nb1 = bhi > blo ? (int)std::min<long>((bhi - blo + 255) / 256, 256) : 0;
         hipLaunchKernelGGL((slab_reduce_kernel<float>), dim3((unsigned)(nb0 + nb1)), dim3(256), 0, st,
                            SlabJob{q.slabs, n, lo, hi, (long)p.C, d_table}, SlabJob{q.bias_slabs, nb, blo, bhi, 0L, d_bias}, nb0,
                            q.nchunk, p.gscale);
