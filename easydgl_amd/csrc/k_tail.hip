@@ -500,6 +500,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     // weight fragments of the next product, fetched one product ahead (see load_wfrags)
     WFrags<NKB> wf = p.head ? load_wfrags<NKB>(p.Wt + (long)n0 * C, C, lane) : load_wfrags<NKB>(p.Wout + (long)n0 * C, C, lane);
     PHB_DECL
+    RowImage<CT> im_o, im_a;      // o, a1: loaded one phase ahead
 
     if (p.head) {
         // ---- LN3' on the gathered rows, GELU' -> d_pre_t (EasyDGL.py:136-146 backward) ------------------------------------
@@ -614,6 +615,10 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         lds_barrier();
         copy_out<CT>(p.d_pre_t + row0 * C, C, bufC, T);
         // ---- d_y = d_pre_t . Wt^T ----------------------------------------------------------------------------------------------
+        // (the next phase's two images are requested here: their round trip runs under this product and its barrier)
+        im_o.load(p.o + row0 * C, C, T);
+        im_a.load(p.a1 + row0 * C, C, T);
+        EDGL_PIN();
         f32x4 acc[MAXRT];
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -626,6 +631,9 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         lds_barrier();     // bufA / bufB / bufC are rewritten below
         PHB_MARK(1);   // LN3', gelu', dX(Wt)
     } else {
+        im_o.load(p.o + row0 * C, C, T);
+        im_a.load(p.a1 + row0 * C, C, T);
+        EDGL_PIN();
         copy_in<CT>(bufA, p.d_y_in + row0 * C, C, T);
         lds_barrier();
 #pragma unroll
@@ -635,7 +643,8 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     // ---- LN2': z2 = drop(o) + a1 ; d_o = drop(d_z2) ; d_a1 (residual part) = d_z2 (EasyDGL.py:126-128 backward) -----------------
     // (the dropout keys hang on a load of the generator state: created here, not ahead of the head's loads)
     const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
-    copy_in2<CT>(bufA, p.o + row0 * C, C, bufB, p.a1 + row0 * C, C, T);
+    im_o.store(bufA, T);
+    im_a.store(bufB, T);
     lds_barrier();
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) {
@@ -646,6 +655,9 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) z[rt][r] = drop_apply(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), ov[r]) + av[r];
     }
+    RowImage<CT> im_p;            // gelu'(pre_f) half: requested one phase ahead as well
+    im_p.load(p.pre_f + row0 * 2 * C, 2 * C, T);
+    EDGL_PIN();
     PHB_MARK(2);   // o, a1 -> z2
     {
         const float4 gg = *reinterpret_cast<const float4*>(p.g2 + nl);
@@ -673,7 +685,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) acc6[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < 2; ++h) {
-        copy_in<CT>(bufA, p.pre_f + row0 * 2 * C + h * C, 2 * C, T);
+        im_p.store(bufA, T);
         {
             f32x4 acc[MAXRT];
 #pragma unroll
@@ -692,6 +704,13 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
                 }
         }
         lds_barrier();
+        if (h == 0) {   // the other half's image / the two images of the LN1' phase travel under the rest of this half
+            im_p.load(p.pre_f + row0 * 2 * C + C, 2 * C, T);
+        } else {
+            im_o.load(p.ao + row0 * C, C, T);
+            im_a.load(p.xin + row0 * p.ld_x, p.ld_x, T);
+        }
+        EDGL_PIN();
         copy_out<CT>(p.d_pre_f + row0 * 2 * C + h * C, 2 * C, bufB, T);
         tile_dx<CT, NKB>(wf, bufB, nrt, lane, acc6);
         wf = h == 0 ? load_wfrags<NKB>(p.Wout + (long)(C + n0) * C, C, lane) : load_wfrags<NKB>(p.Wo + (long)n0 * C, C, lane);
@@ -703,7 +722,8 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         for (int r = 0; r < 4; ++r) dy[rt][r] = rbf(acc6[rt][r] + da1[rt][r]);
     PHB_MARK(4);   // the two halves of the hidden layer
     // ---- LN1': z1 = drop(ao) + x_in ; d_ao = drop(d_z1) ; d_res1 = d_z1 (EasyDGL.py:113-116 backward) ------------------------------
-    copy_in2<CT>(bufA, p.ao + row0 * C, C, bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
+    im_o.store(bufA, T);
+    im_a.store(bufB, T);
     lds_barrier();
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) {
