@@ -674,3 +674,15 @@ def test_score_flash_matches_the_two_pass_kernels(name, dt, tol, R_, C, I):
     assert_close(d_rows1.float().cpu().numpy(), d_rows0.float().cpu().numpy(), gt, "d_rows")
     assert_close(d_tab1.cpu().numpy(), d_tab0.cpu().numpy(), 1e-6, "d_table (same kernel, same lse up to rounding)") if name == "f32" else None
     assert_close(d_b1.cpu().numpy(), d_b0.cpu().numpy(), 1e-5 if name == "f32" else 1e-3, "d_bias")
+    # the forward that also writes the loss coefficients (row count = the compaction's): same lse / label logits, and the
+    # coefficients of edgl_ce_loss_fwd computed from them; the loss kernel then runs with coef = NULL
+    lse2 = torch.empty(R_, device="cuda"); ll2 = torch.zeros(R_, device="cuda"); coef2 = torch.full((R_,), 7.0, device="cuda")
+    check(lib.edgl_score_flash_fwd_coef(p(rows_c), p(tab_c), p(bias), p(lab_c), R_, C, I, p(nvalid), p(lse2), p(ll2), p(coef2), p(wsf),
+                                        code, st), "edgl_score_flash_fwd_coef")
+    assert torch.equal(lse2, lse1) and torch.equal(ll2, ll1)
+    coef1 = torch.empty(R_, device="cuda"); loss1 = torch.empty(1, device="cuda"); loss2 = torch.empty(1, device="cuda")
+    check(lib.edgl_ce_loss_fwd(p(lse1), p(ll1), p(lab_c), R_, p(loss1), p(coef1), st))
+    assert_close(coef2.cpu().numpy(), coef1.cpu().numpy(), 1e-6, "coef")
+    assert float(coef2[n:].abs().max()) == 0.0 if n < R_ else True
+    check(lib.edgl_ce_loss_fwd_add(p(lse1), p(ll1), p(lab_c), R_, p(loss2), None, None, None, st))
+    assert float(loss1) == float(loss2)
