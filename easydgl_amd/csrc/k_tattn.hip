@@ -290,6 +290,12 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_kernel(TaP p) {
 #pragma unroll
         for (int ut = 0; ut < DVT; ++ut) da = mma16(gf[ut], vf[ut], da);
         f32x4 a4, ds;
+        float stm[4], stl[4], std_[4];      // softmax statistics of the tile's four queries: one batch of unconditional loads
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long si = j.bp * p.T + min(qt * 16 + g4 + r, p.T - 1);
+            stm[r] = p.st_m[si]; stl[r] = p.st_l[si]; std_[r] = p.st_d[si];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qt * 16 + g4 + r, qc = min(q, p.T - 1);
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_kernel(TaP p) {
             const bool fut = causal && k > q;
             float v = fmaf(s[r], p.cscale, madd);
             if (fut && kok) v = PADV;
-            const float P = (q < p.T) ? __expf(v - p.st_m[si]) / p.st_l[si] : 0.f;
+            const float P = (q < p.T) ? __expf(v - stm[r]) / stl[r] : 0.f;
             bool keep = true;
             if (dk.thresh != 0u) {
                 // same pairing as the forward: one hash per (k even, k + 1) of a row
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_kernel(TaP p) {
             }
             a4[r] = keep ? P * dk.scale : 0.f;
             const float dP = keep ? da[r] * dk.scale : 0.f;
-            ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - p.st_d[si]) * p.cscale;
+            ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - std_[r]) * p.cscale;
         }
         const Frag4<T> af = frag_from_acc<T>(a4), dsf = frag_from_acc<T>(ds);
 #pragma unroll
@@ -1136,6 +1142,12 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_sliced_kernel(TaP p) {
         const f32x4 s = full_score<T>(Kr, Qrow, p.Dq, g4, false);     // [q = g4+r][k = l15]
         const f32x4 da = full_da<T>(Vr, dOrow, p.Dv, g4, false);
         f32x4 a4, ds;
+        float stm[4], stl[4], std_[4];      // softmax statistics of the tile's four queries: one batch of unconditional loads
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long si = j.bp * p.T + min(qt * 16 + g4 + r, p.T - 1);
+            stm[r] = p.st_m[si]; stl[r] = p.st_l[si]; std_[r] = p.st_d[si];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qt * 16 + g4 + r, qc = min(q, p.T - 1);
@@ -1143,7 +1155,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_sliced_kernel(TaP p) {
             const bool fut = causal && k > q;
             float v = fmaf(s[r], p.cscale, madd);
             if (fut && kok) v = PADV;
-            const float P = (q < p.T) ? __expf(v - p.st_m[si]) / p.st_l[si] : 0.f;
+            const float P = (q < p.T) ? __expf(v - stm[r]) / stl[r] : 0.f;
             bool keep = true;
             if (dk.thresh != 0u) {
                 const uint32_t h = drop_hash_pair(dk, (uint32_t)(si * p.T) + (uint32_t)(k & ~1));
@@ -1151,7 +1163,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_k_sliced_kernel(TaP p) {
             }
             a4[r] = keep ? P * dk.scale : 0.f;
             const float dP = keep ? da[r] * dk.scale : 0.f;
-            ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - p.st_d[si]) * p.cscale;
+            ds[r] = (pad || fut || q >= p.T) ? 0.f : P * (dP - std_[r]) * p.cscale;
         }
         const Frag4<T> rhs = frag_from_acc<T>(for_k ? ds : a4);
         const T* src = for_k ? Qrow + c0 : dOrow + c0;     // dK~^T += Q~^T . dS ; dV^T += dO^T . A
