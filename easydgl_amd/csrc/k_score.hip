@@ -21,6 +21,16 @@
 #include <cstdlib>
 
 #include "edgl_common.h"
+#include "score_plan.h"
+
+// csrc/k_score_strip.hip: one-wave-per-SIMD form of the two product passes (bf16, C = 128)
+bool edgl_strip_enabled();
+int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, int R, int I, int i0, int i1, const int32_t* nvalid,
+                    float* slabs, float* part, int G, hipStream_t st);
+int edgl_strip_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
+                     int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, hipStream_t st);
+int edgl_strip_label_scatter(const void* rows, const int64_t* labels, const float* coef, const int32_t* nvalid, int R, int i0, int i1,
+                             const float* gscale, float* d_table, float* d_bias, hipStream_t st);
 
 namespace {
 
@@ -217,24 +227,6 @@ __device__ __forceinline__ void logit_half(const T* Zs, int jz0, const Vec16<T> 
             for (int ix = 0; ix < IX; ++ix) acc[j][ix] = mma_kblock(zf, xf[ix][kb], acc[j][ix]);
         }
     }
-}
-
-// The number of weighted rows is only known on the device (edgl_compact_rows), so the x-block / item-chunk split of
-// a launch of G workgroups is derived there: nx x-blocks cover the valid rows, the G/nx chunks share the z range.
-struct DevPlan { int nx, nchunk, zchunk; };
-__host__ __device__ __forceinline__ DevPlan dev_plan(int x_eff, int xb, int G, int ztotal, int ZB) {
-    DevPlan d;
-    d.nx = (x_eff + xb - 1) / xb;
-    if (d.nx < 1) d.nx = 1;
-    int ntiles = (ztotal + ZB - 1) / ZB;
-    if (ntiles < 1) ntiles = 1;
-    int nchunk = G / d.nx;
-    if (nchunk < 1) nchunk = 1;
-    if (nchunk > ntiles) nchunk = ntiles;
-    const int per = (ntiles + nchunk - 1) / nchunk;
-    d.nchunk = (ntiles + per - 1) / per;
-    d.zchunk = per * ZB;
-    return d;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1224,11 +1216,14 @@ struct BwdPlan {
     Chunking y, w;
     long off_rowsT, off_tableT, off_slabY, off_slabW, off_slabB, off_part, total;  // float offsets
 };
-inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize) {
+// The flash form (edgl_score_flash_*) at bf16 / C = 128 runs the strip kernels (k_score_strip.hip): 256 x vectors per
+// workgroup as well, but 64-z tiles.
+inline bool use_strip(int C, size_t esize) { return esize == 2 && C == 128 && edgl_strip_enabled(); }
+inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize, bool strip = false) {
     BwdPlan b;
     const RtCfg cf = rt_cfg(C, esize);
-    const int nw = cf.nwb == 8 ? score_nw() : cf.nwb, zb = cf.zb;
-    const int xb = 16 * cf.ix * nw;
+    const int nw = strip ? 8 : (cf.nwb == 8 ? score_nw() : cf.nwb), zb = strip ? 64 : cf.zb;
+    const int xb = strip ? 256 : 16 * cf.ix * nw;
     b.y = pick_chunks(xblocks_of(R, xb), n_items, score_target(), zb, l2_tiles_for(C, esize, 2, zb));
     {   // every chunk writes an [R, C] f32 slab that a later kernel sums: keep that side traffic bounded (1M-item tables would
         // otherwise ask for hundreds of chunks)
@@ -1241,10 +1236,12 @@ inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize) {
     auto take = [&](long floats) { const long at = o; o += (floats + 63) / 64 * 64; return at; };
     b.off_rowsT = take(((long)C * up8(R) * (long)esize + 3) / 4);
     b.off_tableT = take(((long)C * up8(I) * (long)esize + 3) / 4);
-    b.off_slabY = take((long)b.y.nchunk * xblocks_of(R, xb) * xb * C);   // G workgroups x one [xb, C] tile each
+    // G workgroups x one [xb, C] tile each (strip: the grid is at least score_target() workgroups, split on the device)
+    const long gy = strip ? std::max<long>((long)b.y.nchunk * xblocks_of(R, xb), score_target()) : (long)b.y.nchunk * xblocks_of(R, xb);
+    b.off_slabY = take(gy * xb * C);
     b.off_slabW = take((long)b.w.nchunk * I * C);
     b.off_slabB = take((long)b.w.nchunk * (I - 1));
-    b.off_part = take(2L * b.y.nchunk * xblocks_of(R, xb) * xb);   // (max, sum) per (row, item chunk) of the ROLE_YF pass
+    b.off_part = take(2L * gy * xb);   // (max, sum) per (row, item chunk) of the ROLE_YF pass
     b.total = o;
     return b;
 }
@@ -1284,18 +1281,23 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     }
     p.rowsT = rowsT; p.tableT = tableT;
     using Cfg = ScoreCfg<T, CT>;
-    constexpr int CO = Cfg::CO, ZBK = S::ZB;
+    constexpr int CO = Cfg::CO;
+    const bool strip = MODE != 0 && use_strip(p.C, sizeof(T));     // plan built with the same flag by the callers
+    const int ZBK = strip ? 64 : S::ZB;
     const int nw = Cfg::NWB == 8 ? score_nw() : Cfg::NWB;
     const size_t smem_nw = nw == 8 ? smem : BUF;
-    const int xb = 16 * Cfg::IX * nw;
-    const int G = xblocks_of(p.R, xb) * plan.y.nchunk;
+    const int xb = strip ? 256 : 16 * Cfg::IX * nw;
+    const int G = strip ? std::max(xblocks_of(p.R, xb) * plan.y.nchunk, score_target()) : xblocks_of(p.R, xb) * plan.y.nchunk;
     float* part = ws + plan.off_part;
     if (MODE != 2) {   // the row-side pass
         constexpr int RY = MODE == 1 ? ROLE_YF : ROLE_Y;
         ScoreP q = p;
         q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY; q.part = part;
         edgl_prof_begin(EDGL_KERNEL_SCORE_BWD_ROWS, st);
-        if (nw == 8) {
+        if (strip) {
+            const int rc = edgl_strip_rows(p.rows, p.table, p.out_bias, p.R, p.I, p.i0, p.i1, p.nvalid, q.slabs, part, G, st);
+            if (rc) return rc;
+        } else if (nw == 8) {
             auto k = score_bwd_kernel<T, CT, RY, 8, CO>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
             hipLaunchKernelGGL(k, dim3(G, CT / CO), dim3(512), smem_nw, st, q);
@@ -1328,7 +1330,11 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     {
         ScoreP q = p;
         q.zchunk = plan.w.zchunk; q.nchunk = plan.w.nchunk; q.slabs = ws + plan.off_slabW; q.bias_slabs = ws + plan.off_slabB;
-        if (nw == 8) {
+        if (strip) {
+            const int rc = edgl_strip_table(p.rows, p.table, p.out_bias, p.coef, p.row_lse, p.R, p.I, p.i0, p.i1, p.nvalid, q.slabs,
+                                            q.bias_slabs, q.nchunk, st);
+            if (rc) return rc;
+        } else if (nw == 8) {
             auto k = score_bwd_kernel<T, CT, ROLE_W, 8, CO>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
             hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, xb), q.nchunk, CT / CO), dim3(512), smem_nw, st, q);
@@ -1345,6 +1351,10 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
                            SlabJob{q.slabs, n, lo, hi, (long)p.C, d_table}, SlabJob{q.bias_slabs, nb, blo, bhi, 0L, d_bias}, nb0,
                            q.nchunk, p.gscale);
         EDGL_LAUNCH_CHECK();
+        if (strip) {   // the one-hot part of dl, which the strip product pass leaves out
+            const int rc = edgl_strip_label_scatter(p.rows, p.labels, p.coef, p.nvalid, p.R, p.i0, p.i1, p.gscale, d_table, d_bias, st);
+            if (rc) return rc;
+        }
     }
     return EDGL_OK;
 }
@@ -1525,7 +1535,7 @@ extern "C" int edgl_score_ce_bwd(const void* rows, const void* table, const floa
 // The logits are computed 2x per step (here and in the d_table pass) instead of 3x.  `workspace` (edgl_score_flash_workspace
 // floats) carries the slabs from the forward to the backward call and must not be touched in between.
 extern "C" long edgl_score_flash_workspace(int R, int C, int I, int n_items, int dtype) {
-    return bwd_plan(R, C, I, n_items, dtype == EDGL_BF16 ? 2 : 4).total;
+    return bwd_plan(R, C, I, n_items, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4)).total;
 }
 
 extern "C" int edgl_score_flash_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
@@ -1537,7 +1547,7 @@ extern "C" int edgl_score_flash_fwd(const void* rows, const void* table, const f
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = row_lse;
-    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
+    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     p.lab_out = label_logit;   // row LSE and label logits come out of one small kernel behind the scoring pass
     return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
@@ -1570,7 +1580,7 @@ extern "C" int edgl_score_flash_fwd_pre(const void* rows, const void* table, con
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = row_lse; p.lab_out = label_logit; p.table_ready = table_ready;
-    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
+    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
                              : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);
@@ -1588,7 +1598,7 @@ extern "C" int edgl_score_flash_fwd_coef(const void* rows, const void* table, co
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = 0;
     p.i1 = I; p.nvalid = nvalid; p.row_lse = row_lse; p.lab_out = label_logit; p.coef_out = coef;
-    const BwdPlan plan = bwd_plan(R, C, I, I, dtype == EDGL_BF16 ? 2 : 4);
+    const BwdPlan plan = bwd_plan(R, C, I, I, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)
                              : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);
@@ -1605,7 +1615,7 @@ extern "C" int edgl_score_flash_bwd(const void* rows, const void* table, const f
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
-    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
+    const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 2>(p, C, plan, workspace, d_rows, d_table, d_bias, st)
                              : bwd_dispatch<bf16, 2>(p, C, plan, workspace, d_rows, d_table, d_bias, st);

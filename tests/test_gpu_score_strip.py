@@ -1,0 +1,132 @@
+"""K5 strip kernels (csrc/k_score_strip.hip: bf16, C = 128, one wave per SIMD) behind edgl_score_flash_fwd_coef / _bwd, against an
+fp64 restatement of EasyDGL.py:149-155,177-185 (Appendix C of SURVEY.md) computed by torch on the same bf16 operands — at sizes up
+to the benchmarked one (R_w ~ 5.4 K weighted rows x 20001 items = 12 item chunks x 21 row blocks), with the label pile-up of the
+Zipf recipe, and with logit spreads that force the exact-maximum fallback of the row reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from easydgl_amd import ops
+    return ops
+
+
+def _reference(rows, tab, bias, labels):
+    """fp64: lse, label logits, coef, d_rows, d_table, d_bias for the weighted rows (label != 0)."""
+    R, C = rows.shape
+    I = tab.shape[0]
+    x = rows.double()
+    t = tab.double().clone()
+    t[0] = 0.0                                                   # zero-padded table (coding.py:56-57)
+    b = torch.cat([torch.full((1,), -1000.0, dtype=torch.float64, device=rows.device), bias.double()])   # Base.py:106-110
+    logits = x @ t.T + b
+    lse = torch.logsumexp(logits, dim=1)
+    ll = logits.gather(1, labels.view(-1, 1)).squeeze(1)
+    w = (labels != 0).double()
+    n = w.sum()
+    py = torch.exp(ll - lse)
+    coef = w * (1.0 / (n + 1e-5)) * (py / (py + 1e-5))            # d loss / d logit scale (EasyDGL.py:155,177-185)
+    p = torch.exp(logits - lse.view(-1, 1))
+    dl = coef.view(-1, 1) * p
+    dl[torch.arange(R, device=rows.device), labels] -= coef
+    d_rows = dl @ t
+    d_tab = dl.T @ x
+    d_tab[0] = 0.0
+    d_bias = dl[:, 1:].sum(0)
+    return lse, ll, coef, d_rows, d_tab, d_bias
+
+
+def _rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def _rel_max(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+def _run_flash(rows, tab, bias, labels):
+    from easydgl_amd._lib import check, lib
+    o = _ops()
+    R, C = rows.shape
+    I = tab.shape[0]
+    rows_c, lab_c, perm, _inv, nvalid = o.compact_rows(rows, labels)
+    p, st, code = o._ptr, o._stream(), o._code(rows)
+    wsf = torch.empty(lib.edgl_score_flash_workspace(R, C, I, I, code), device="cuda")
+    lse = torch.empty(R, device="cuda"); ll = torch.zeros(R, device="cuda"); coef = torch.empty(R, device="cuda")
+    check(lib.edgl_score_flash_fwd_coef(p(rows_c), p(tab), p(bias), p(lab_c), R, C, I, p(nvalid), p(lse), p(ll), p(coef), p(wsf), code, st),
+          "edgl_score_flash_fwd_coef")
+    d_rows = torch.empty_like(rows_c); d_tab = torch.empty((I, C), device="cuda"); d_b = torch.empty(I - 1, device="cuda")
+    check(lib.edgl_score_flash_bwd(p(rows_c), p(tab), p(bias), p(lab_c), p(lse), p(coef), None, R, C, I, 0, I, p(nvalid), p(d_rows),
+                                   p(d_tab), p(d_b), p(wsf), code, st), "edgl_score_flash_bwd")
+    torch.cuda.synchronize()
+    n = int(nvalid.item())
+    return n, perm[:n].long(), lse[:n], ll[:n], coef[:n], d_rows[:n], d_tab, d_b
+
+
+def _check(rows, tab, bias, labels, tol_rows=1.2e-2, tol_tab=6e-3):
+    n, perm, lse, ll, coef, d_rows, d_tab, d_b = _run_flash(rows, tab, bias, labels)
+    assert n == int((labels != 0).sum())
+    r_lse, r_ll, r_coef, r_drows, r_dtab, r_db = _reference(rows[perm], tab, bias, labels[perm])
+    assert _rel_max(lse, r_lse) < 2e-5, _rel_max(lse, r_lse)
+    assert float((ll.double() - r_ll).abs().max()) < 1e-4 * (1.0 + float(r_ll.abs().max()))
+    assert _rel_max(coef, r_coef) < 2e-3, _rel_max(coef, r_coef)
+    # d_rows is stored in bf16 (half an ulp = 2e-3 relative per element) from P rounded to bf16; d_table / d_bias are f32 sums of
+    # bf16-rounded P: per-tensor relative L2 AND max-norm
+    e2, em = _rel_l2(d_rows.float(), r_drows), _rel_max(d_rows.float(), r_drows)
+    assert e2 < tol_rows and em < 2 * tol_rows, ("d_rows", e2, em)
+    e2, em = _rel_l2(d_tab, r_dtab), _rel_max(d_tab, r_dtab)
+    assert e2 < tol_tab and em < 2 * tol_tab, ("d_table", e2, em)
+    e2, em = _rel_l2(d_b, r_db), _rel_max(d_b, r_db)
+    assert e2 < tol_tab and em < 2 * tol_tab, ("d_bias", e2, em)
+    assert float(d_tab[0].abs().max()) == 0.0
+
+
+def _problem(R, I, seed, hot=0.0, zero=0.3, scale_rows=0.6, scale_tab=0.4):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rows = (torch.randn(R, 128, device="cuda", generator=g) * scale_rows).bfloat16()
+    tab = (torch.randn(I, 128, device="cuda", generator=g) * scale_tab).bfloat16()
+    bias = torch.randn(I - 1, device="cuda", generator=g) * 0.3
+    labels = torch.randint(1, I, (R,), device="cuda", generator=g)
+    u = torch.rand(R, device="cuda", generator=g)
+    labels[u < hot] = I - 2                                       # the clip pile-up of the Zipf recipe
+    labels[u > 1.0 - zero] = 0
+    return rows, tab, bias, labels
+
+
+@pytest.mark.parametrize("R,I,hot", [(70, 130, 0.0), (257, 2701, 0.2), (1000, 20001, 0.35), (640, 4099, 0.0)])
+def test_strip_against_fp64(R, I, hot):
+    _check(*_problem(R, I, seed=R + I, hot=hot))
+
+
+def test_strip_at_the_benchmarked_size():
+    """B = 512, M = 20 -> 10240 masked slots of which ~52 % are weighted: 21 row blocks x 12 item chunks of the 20001-item table."""
+    rows, tab, bias, labels = _problem(10240, 20001, seed=5, hot=0.35, zero=0.475)
+    _check(rows, tab, bias, labels)
+
+
+def test_strip_all_rows_weighted():
+    rows, tab, bias, labels = _problem(10240, 20001, seed=6, hot=0.0, zero=0.0)
+    _check(rows, tab, bias, labels)
+
+
+def test_strip_reference_fallback_on_a_wide_logit_spread():
+    """A few rows whose largest logit sits ~150 above the logits of the chunk's first unit: exp(logit - reference) overflows f32
+    in the first attempt, the workgroup must redo its chunk with the exact row maxima — results as accurate as everywhere else."""
+    rows, tab, bias, labels = _problem(600, 9001, seed=11, hot=0.0, zero=0.2)
+    rows = rows.float(); tab = tab.float()
+    for r, z in ((3, 4000), (200, 77), (599, 9000), (300, 8000)):
+        v = rows[r] / rows[r].norm()
+        tab[z] = v * (150.0 / float(rows[r].norm()))              # logit(r, z) ~ +150, the rest stay O(1)
+    rows = rows.bfloat16(); tab = tab.bfloat16()
+    labels[3] = 4000; labels[200] = 5; labels[599] = 0
+    _check(rows, tab, bias, labels, tol_rows=2e-2, tol_tab=1.5e-2)
+
+
+def test_strip_label_scatter_with_every_row_on_one_label():
+    rows, tab, bias, labels = _problem(900, 3001, seed=13, hot=1.0, zero=0.0)
+    _check(rows, tab, bias, labels)
