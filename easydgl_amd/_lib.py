@@ -14,7 +14,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_long, c_uint32, c_void_p
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeasydgl_hip.so")
+# (EDGL_LIB_PATH: development override — tools/ load instrumented builds of the same library through it)
+LIB_PATH = os.environ.get("EDGL_LIB_PATH") or os.path.join(_HERE, "libeasydgl_hip.so")
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 8, 16, 32, 64

@@ -23,7 +23,7 @@ EXTRA_FLAGS = {"k_bimau_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "k_bimau_big.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "k_tattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # hand-placed instruction stream: the SLP vectoriser packs the row sums into v_pk_add_f32 (slow beside MFMAs)
-               "k_score_strip.hip": ["-fno-slp-vectorize", "-Wno-unused-value"] + (["-DSTRIP_SAFE"] if os.environ.get("EDGL_STRIP_SAFE") else [])}
+               "k_score_strip.hip": ["-fno-slp-vectorize", "-Wno-unused-value"] + (["-DSTRIP_SAFE"] if os.environ.get("EDGL_STRIP_SAFE") else []) + os.environ.get("EDGL_STRIP_DEFS", "").split()}
 
 
 def _hipcc() -> str:

@@ -1217,12 +1217,12 @@ struct BwdPlan {
     long off_rowsT, off_tableT, off_slabY, off_slabW, off_slabB, off_part, total;  // float offsets
 };
 // The flash form (edgl_score_flash_*) at bf16 / C = 128 runs the strip kernels (k_score_strip.hip): 256 x vectors per
-// workgroup as well, but 64-z tiles.
+// workgroup as well, 64-z tiles handed out in pairs.
 inline bool use_strip(int C, size_t esize) { return esize == 2 && C == 128 && edgl_strip_enabled(); }
 inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize, bool strip = false) {
     BwdPlan b;
     const RtCfg cf = rt_cfg(C, esize);
-    const int nw = strip ? 8 : (cf.nwb == 8 ? score_nw() : cf.nwb), zb = strip ? 64 : cf.zb;
+    const int nw = strip ? 8 : (cf.nwb == 8 ? score_nw() : cf.nwb), zb = strip ? 128 : cf.zb;   // strip: pairs of its 64-z tiles
     const int xb = strip ? 256 : 16 * cf.ix * nw;
     b.y = pick_chunks(xblocks_of(R, xb), n_items, score_target(), zb, l2_tiles_for(C, esize, 2, zb));
     {   // every chunk writes an [R, C] f32 slab that a later kernel sums: keep that side traffic bounded (1M-item tables would
@@ -1283,7 +1283,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     using Cfg = ScoreCfg<T, CT>;
     constexpr int CO = Cfg::CO;
     const bool strip = MODE != 0 && use_strip(p.C, sizeof(T));     // plan built with the same flag by the callers
-    const int ZBK = strip ? 64 : S::ZB;
+    const int ZBK = strip ? 128 : S::ZB;
     const int nw = Cfg::NWB == 8 ? score_nw() : Cfg::NWB;
     const size_t smem_nw = nw == 8 ? smem : BUF;
     const int xb = strip ? 256 : 16 * Cfg::IX * nw;

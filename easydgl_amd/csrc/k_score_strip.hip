@@ -52,7 +52,16 @@ struct StripP {
     const int32_t* nvalid;
     const float* coef; const float* row_lse;     // ROLE_W
     float* slabs; float* bias_slabs; float* part;
+    unsigned long long* stamps;     // -DSTRIP_TIMING builds only: [workgroup][8] shader-clock stamps of wave 0
 };
+#ifdef STRIP_TIMING
+__device__ unsigned long long g_ph[48];
+#define PHT(i) do { SPIN(); const unsigned long long t_ = __builtin_readcyclecounter(); ph_acc[i] += t_ - ph_t; ph_t = t_; SPIN(); } while (0)
+#define STAMP(i) do { if (p.stamps && g.tid == 0) p.stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i)
+#define PHT(i)
+#endif
 
 __device__ __forceinline__ int rot16(int z) { return (((z & 3) << 2) | ((z >> 2) & 3)) * 16; }
 
@@ -93,49 +102,69 @@ __device__ __forceinline__ LaneOff lane_off(int lane) {
     return o;
 }
 
-// global -> registers -> LDS staging of one 64-row tile (+ its per-row C operand)
+// global -> registers -> LDS staging of one 64-row tile (+ its per-row C operand), in single-instruction pieces (load_piece /
+// store_piece) that the main loop places one per MFMA slot.  One wave per SIMD issues ~one instruction per 4-5 cycles, i.e.
+// about six besides each 32-cycle MFMA: the loop is ISSUE bound, and every instruction of the staging counts.  Hence
+//   * thread-constant offsets (row = tid/16 + 16 i keeps rot(row): the four pieces of a thread are 8 KB apart in LDS, 4 KB in
+//     global memory): a piece is one min + one address add + the access;
+//   * NO zero-filling of rows past the chunk / of table row 0: their C operand (-inf / -1000) makes every exponential of such a
+//     row exactly 0 (exp2 underflows below -1000 log2 e for any finite reference), so the row's DATA only has to be finite —
+//     the loads are clamped to the last valid row of the chunk.
 template <int ROLE>
 struct Stage {
-    uint4 g[4];
+    uint4 g0, g1, g2, g3;      // (named members, not an array: the array form ended up in scratch)
     float cinfo, cinfo2;
     int z0_, zend_;
-    __device__ __forceinline__ void load(const StripP& p, const bf16* Z, int z0, int zend, int Reff, int tid) {
-        z0_ = z0; zend_ = zend;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = tid + NTHR * i, row = v >> 4, cv = v & 15, gz = max(min(z0 + row, zend - 1), 0);
-            g[i] = *reinterpret_cast<const uint4*>(Z + (long)gz * C + cv * 8);
-        }
-        cinfo = 0.f; cinfo2 = 0.f;
-        if (tid < ZT) {
-            const int z = z0 + tid;
+    const bf16* Z_;
+    const float* bias_; const float* coef_; const float* lse_;     // (by value: a pointer to the kernel's parameter struct would
+    int I_, Reff_, tid_, row0_, goff_, loff_;                       //  put that struct — and every access to it — into scratch)
+    __device__ __forceinline__ void init(const StripP& p, const bf16* Z, int zend, int Reff, int tid) {
+        Z_ = Z; bias_ = p.out_bias; coef_ = p.coef; lse_ = p.row_lse; I_ = p.I; zend_ = zend; Reff_ = Reff; tid_ = tid;
+        cinfo = 0.f; cinfo2 = 0.f; z0_ = 0;
+        row0_ = tid >> 4;
+        goff_ = (tid & 15) * 8;                                      // elements
+        loff_ = row0_ * ROWB + rot16(row0_) + (tid & 15) * 16;       // bytes
+    }
+    __device__ __forceinline__ void begin(int z0) { z0_ = z0; }
+    __device__ __forceinline__ void load_piece(int i) {      // i = 0..3: 16 bytes of the tile;  i = 4: the per-row scalars
+        if (i < 4) {
+            const int gz = max(min(z0_ + row0_ + 16 * i, zend_ - 1), 0);
+            const uint4 v = *reinterpret_cast<const uint4*>(Z_ + (long)gz * C + goff_);
+            if (i == 0) g0 = v; else if (i == 1) g1 = v; else if (i == 2) g2 = v; else g3 = v;
+        } else {
+            const int z = z0_ + (tid_ & (ZT - 1));      // every wave loads them (no divergent branch); wave 0 stores them
             if (ROLE == ROLE_YF) {
-                cinfo = p.out_bias[min(max(z, 1), p.I - 1) - 1];
+                cinfo = bias_[min(max(z, 1), I_ - 1) - 1];
             } else {
-                const int gc = max(min(z, Reff - 1), 0);
-                cinfo = p.coef[gc]; cinfo2 = p.row_lse[gc];
+                const int gc = max(min(z, Reff_ - 1), 0);
+                cinfo = coef_[gc]; cinfo2 = lse_[gc];
             }
         }
     }
-    __device__ __forceinline__ void store(char* slot, int tid) {
+    __device__ __forceinline__ void load(int z0) {
+        begin(z0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int v = tid + NTHR * i, row = v >> 4, cv = v & 15, gz = z0_ + row;
-            const bool ok = gz < zend_ && !(ROLE == ROLE_YF && gz == 0);   // table row 0 acts as zeros (coding.py:56-57)
-            *reinterpret_cast<uint4*>(slot + row * ROWB + rot16(row) + cv * 16) = ok ? g[i] : make_uint4(0, 0, 0, 0);
-        }
-        if (tid < ZT) {
-            const int z = z0_ + tid;
+        for (int i = 0; i < 5; ++i) load_piece(i);
+    }
+    __device__ __forceinline__ void store_piece(char* slot, int i) {
+        if (i < 4) {
+            *reinterpret_cast<uint4*>(slot + loff_ + i * 16 * ROWB) = i == 0 ? g0 : (i == 1 ? g1 : (i == 2 ? g2 : g3));
+        } else {
+            const int z = z0_ + (tid_ & (ZT - 1));
             float c;
             if (ROLE == ROLE_YF) c = z >= zend_ ? -INFINITY : (z == 0 ? -1000.0f : cinfo);   // pad logit -1000 (Base.py:110)
             else c = (z < zend_ && cinfo > 0.f) ? __logf(cinfo) - cinfo2 : -INFINITY;        // -(lse - log coef)
-            reinterpret_cast<float*>(slot + TILEB)[tid] = c;
+            if (tid_ < ZT) reinterpret_cast<float*>(slot + TILEB)[tid_] = c;
         }
+    }
+    __device__ __forceinline__ void store(char* slot) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) store_piece(slot, i);
     }
 };
 
-struct Carry {            // operands fetched one iteration ahead: first two row fragments and the C rows of the next S unit
-    v4i zf0, zf1;
+struct Carry {            // operands fetched one iteration ahead: first three row fragments and the C rows of the next S unit
+    v4i zf0, zf1, zf2;
     f32x16 ci;
 };
 __device__ __forceinline__ void fetch_ci(f32x16& ci, const char* info, const LaneOff& lo) {
@@ -148,6 +177,7 @@ __device__ __forceinline__ void fetch_ci(f32x16& ci, const char* info, const Lan
 __device__ __forceinline__ void fetch_carry(Carry& cy, const char* unit, const char* info, const LaneOff& lo) {
     cy.zf0 = lds_b128(unit + lo.zf);
     cy.zf1 = lds_b128(unit + lo.zf + 32);
+    cy.zf2 = lds_b128(unit + lo.zf + 64);
     fetch_ci(cy.ci, info, lo);
 }
 
@@ -187,101 +217,156 @@ __device__ __forceinline__ void settle_o(f32x16 (&O)[2][4]) {
                  "+a"(O[1][2]), "+a"(O[1][3]));
 }
 
-// VALU work of MFMA slot e (0..15) of one half iteration on the 16 logits S of an x tile, ONE asm statement per slot (separate
-// statements draw a compiler s_nop between them):
-//   p_e = exp2(S_e * log2(e) + add)  in place;  row sum += p_(e-1);  after every odd logit the pair before it is packed — always
-//   one slot late, so that no instruction reads a v_exp result in the slot that produced it
-__device__ __forceinline__ void slot_valu(f32x16& S, int (&pk)[8], float& lsum, float add, int e) {
-    float cur = S[e];
-    if (e == 0) {
-        asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_exp_f32 %0, %0" : "+v"(cur) : "s"(L2E), "v"(add));
-    } else if (e & 1) {
-        asm volatile("v_fma_f32 %0, %0, %2, %3\n\tv_exp_f32 %0, %0\n\tv_add_f32 %1, %1, %4"
-                     : "+v"(cur), "+v"(lsum) : "s"(L2E), "v"(add), "v"(S[e - 1]));
+// One MFMA slot = ONE asm statement: the MFMA and the VALU work on logit e (0..15) of the x tile T being exponentiated; no
+// instruction depends on a result of the same slot (one wave per SIMD: a dependent pair costs the full VALU latency), and separate
+// statements would draw a compiler s_nop between them (an issue slot each).
+//   T[e]   <- exp2(T[e])                      T[e] already holds  logit * log2(e) + add  (written one slot earlier)
+//   T[e+1] <- T[e+1] * log2(e) + add          (e = 0 also scales itself first)
+//   row sum += T[e-1];  after every odd logit the pair before it is packed
+// slot_tail() finishes the tile (sum / pack of logits 14, 15).
+#define VALU_E0 "v_fma_f32 %[cur], %[cur], %[l2e], %[add]\n\tv_fma_f32 %[nxt], %[nxt], %[l2e], %[add]\n\tv_exp_f32 %[cur], %[cur]"
+#define VALU_ODD "v_exp_f32 %[cur], %[cur]\n\tv_fma_f32 %[nxt], %[nxt], %[l2e], %[add]\n\tv_add_f32 %[sum], %[sum], %[p1]"
+#define VALU_EVEN VALU_ODD "\n\tv_cvt_pk_bf16_f32 %[pk], %[p2], %[p1]"
+#define VALU_E15 "v_exp_f32 %[cur], %[cur]\n\tv_add_f32 %[sum], %[sum], %[p1]"
+#define MF_S0 "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[c]\n\t"
+#define MF_S "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]\n\t"
+// kind 0: S MFMA with C = ci (D early-clobber VGPR), 1: S MFMA accumulating (D VGPR, B AGPR), 2: O MFMA (D AGPR, B VGPR)
+template <int KIND>
+__device__ __forceinline__ void slot(f32x16& d, const v4i& a, const v4i& b, const f32x16& c, f32x16& T, int (&pk)[8], float& lsum,
+                                     float add, int e) {
+#ifdef STRIP_NOVALU
+    if (KIND == 0) mfma_s0(d, a, b, c); else if (KIND == 1) mfma_s(d, a, b); else mfma_o(d, a, b);
+    if (e & 1) pk[e >> 1] = __builtin_bit_cast(int, T[e]);
+    return;
+#else
+    float cur = T[e], nxt = T[e < 15 ? e + 1 : 15];
+    int r = 0;
+#define SLOT_ASM(MF, VA, DC, BC)                                                                                                  \
+    asm volatile(MF VA : [d] DC(d), [cur] "+v"(cur), [nxt] "+v"(nxt), [sum] "+v"(lsum), [pk] "=&v"(r)                          \
+                 : [a] "v"(a), [b] BC(b), [l2e] "s"(L2E), [add] "v"(add), [p1] "v"(T[e >= 1 ? e - 1 : 0]), [p2] "v"(T[e >= 2 ? e - 2 : 0]))
+#define SLOT_ASM_C(MF, VA, DC, BC)                                                                                                \
+    asm volatile(MF VA : [d] DC(d), [cur] "+v"(cur), [nxt] "+v"(nxt), [sum] "+v"(lsum), [pk] "=&v"(r)                          \
+                 : [a] "v"(a), [b] BC(b), [c] "v"(c), [l2e] "s"(L2E), [add] "v"(add), [p1] "v"(T[e >= 1 ? e - 1 : 0]),             \
+                   [p2] "v"(T[e >= 2 ? e - 2 : 0]))
+    if (KIND == 0) {
+        if (e == 0) SLOT_ASM_C(MF_S0, VALU_E0, "=&v", "a");
+        else SLOT_ASM_C(MF_S0, VALU_ODD, "=&v", "a");          // (kind 0 occupies slots 0 and 1 only)
+    } else if (KIND == 1) {
+        if (e == 15) SLOT_ASM(MF_S, VALU_E15, "+v", "a");
+        else if (e & 1) SLOT_ASM(MF_S, VALU_ODD, "+v", "a");
+        else SLOT_ASM(MF_S, VALU_EVEN, "+v", "a");
     } else {
-        int r;
-        asm volatile("v_fma_f32 %0, %0, %3, %4\n\tv_exp_f32 %0, %0\n\tv_add_f32 %1, %1, %5\n\tv_cvt_pk_bf16_f32 %2, %6, %5"
-                     : "+v"(cur), "+v"(lsum), "=&v"(r) : "s"(L2E), "v"(add), "v"(S[e - 1]), "v"(S[e - 2]));
-        pk[(e - 2) >> 1] = r;
+        if (e == 0) SLOT_ASM(MF_S, VALU_E0, "+a", "v");
+        else if (e == 15) SLOT_ASM(MF_S, VALU_E15, "+a", "v");
+        else if (e & 1) SLOT_ASM(MF_S, VALU_ODD, "+a", "v");
+        else SLOT_ASM(MF_S, VALU_EVEN, "+a", "v");
     }
-    S[e] = cur;
+#undef SLOT_ASM_C
+#undef SLOT_ASM
+    T[e] = cur;
+    if (e < 15) T[e + 1] = nxt;
+    if (e >= 2 && (e & 1) == 0) pk[(e - 2) >> 1] = r;
+#endif
 }
-__device__ __forceinline__ void slot_valu_tail(f32x16& S, int (&pk)[8], float& lsum) {   // after slot 15
+__device__ __forceinline__ void slot_tail(f32x16& T, int (&pk)[8], float& lsum) {
+#ifndef STRIP_NOVALU
     int r;
-    asm volatile("v_add_f32 %0, %0, %2\n\tv_cvt_pk_bf16_f32 %1, %3, %2" : "+v"(lsum), "=&v"(r) : "v"(S[15]), "v"(S[14]));
+    asm volatile("v_add_f32 %0, %0, %2\n\tv_cvt_pk_bf16_f32 %1, %3, %2" : "+v"(lsum), "=&v"(r) : "v"(T[15]), "v"(T[14]));
     pk[7] = r;
+#endif
 }
 
 // One pipeline iteration u: S(u+1) -> Sn, P(u) <- exp of Sc, O += P(u-1) . Z(u-1).
 //   s_unit / o_unit: LDS rows of unit u+1 / unit u-1;  nx_unit / nx_info: unit u+2 (operands of the next iteration's first MFMAs).
 //   STAGE: the staged tile is written to `st_slot` in the S half and the workgroup barrier sits between the halves.
-template <int ROLE, bool STAGE>
+//   LOAD : the loads of the tile after next are issued in the S half (stg.begin() called by the caller).
+template <int ROLE, bool STAGE, bool LOAD>
 __device__ __forceinline__ void unit_iter(f32x16 (&O)[2][4], const v4i (&XF)[2][8], f32x16 (&Sc)[2], f32x16 (&Sn)[2],
                                           v4i (&Pc)[2][2], const v4i (&Pp)[2][2], const float (&add)[2], float (&lsum)[2],
                                           Carry& cy, const char* s_unit, const char* o_unit, const char* nx_unit,
-                                          const char* nx_info, const LaneOff& lo, Stage<ROLE>& stg, char* st_slot, int tid) {
+                                          const char* nx_info, const LaneOff& lo, Stage<ROLE>& stg, char* st_slot, int tid
+#ifdef STRIP_TIMING
+                                          , unsigned long long (&ph_acc)[12], unsigned long long& ph_t
+#endif
+) {
+    PHT(11);
     // ---- S half: 16 MFMAs beside the 16 logits of x tile 0 --------------------------------------------------------------------
-    v4i zf[3];
-    zf[0] = cy.zf0; zf[1] = cy.zf1;
-    v4i tf[3];
+    // LDS operands are fetched THREE MFMA pairs ahead (rings of 4): with the four waves of the workgroup in lock step their reads
+    // queue up behind each other, and two pairs (~130 cycles) did not cover it.
+    v4i zf[4];
+    zf[0] = cy.zf0; zf[1] = cy.zf1; zf[2] = cy.zf2;
+    v4i tf[4];
     int pk[2][8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        if (ks + 2 < 8) zf[(ks + 2) % 3] = lds_b128(s_unit + lo.zf + (ks + 2) * 32);
-        if (!STAGE && ks == 6) tf[0] = lds_tr(o_unit + lo.tr);
-        if (!STAGE && ks == 7) tf[1] = lds_tr(o_unit + lo.tr + 64);
+#ifndef STRIP_T_NOZF
+        if (ks + 3 < 8) zf[(ks + 3) % 4] = lds_b128(s_unit + lo.zf + (ks + 3) * 32);
+#else
+        if (ks == 0) zf[3] = cy.zf0;
+#endif
+#ifndef STRIP_T_NOTF
+        if (ks >= 5) tf[ks - 5] = lds_tr(o_unit + lo.tr + (ks - 5) * 64);     // (tile u-1: resident long before this iteration)
+#else
+        if (ks == 6) { tf[0] = cy.zf0; tf[1] = cy.zf1; tf[2] = cy.zf0; tf[3] = cy.zf1; }
+#endif
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt) {
-            if (ks == 0) mfma_s0(Sn[xt], zf[0], XF[xt][0], cy.ci);
-            else mfma_s(Sn[xt], zf[ks % 3], XF[xt][ks]);
+            // (kind 0: slot 0 starts the x tile: VALU_E0; slot 1 is an odd slot)
+            if (ks == 0) slot<0>(Sn[xt], zf[0], XF[xt][0], cy.ci, Sc[0], pk[0], lsum[0], add[0], xt);
+            else slot<1>(Sn[xt], zf[ks % 4], XF[xt][ks], cy.ci, Sc[0], pk[0], lsum[0], add[0], 2 * ks + xt);
             // SrcC of the two ks = 0 MFMAs is read late in their passes: nothing may be allocated over `ci` until they are done
-            // (the first build loaded the next row fragment over it: the x tile 1 logits came out with errors of 1e-3..1e-1)
+            // (the first build loaded the next row fragment over it: the x tile 1 logits came out with errors of 1e-3..1e-1) —
+            // it stays an operand of an (empty) statement for two more MFMA pairs.
             if (ks == 1 || ks == 2) asm volatile("" ::"v"(cy.ci));
-            slot_valu(Sc[0], pk[0], lsum[0], add[0], 2 * ks + xt);
-            if (STAGE && ks >= 2 && ks < 4) {   // the staged tile: one 16-byte LDS store per slot, 4 slots
-                const int i = (ks - 2) * 2 + xt;
-                const int v = tid + NTHR * i, row = v >> 4, cvv = v & 15, gz = stg.z0_ + row;
-                const bool ok = gz < stg.zend_ && !(ROLE == ROLE_YF && gz == 0);
-                *reinterpret_cast<uint4*>(st_slot + row * ROWB + rot16(row) + cvv * 16) = ok ? stg.g[i] : make_uint4(0, 0, 0, 0);
-            }
+            const int sl = 2 * ks + xt;                          // one staging piece per slot
+#ifndef STRIP_T_NOSTORE
+            if (STAGE && sl >= 4 && sl <= 12 && (sl & 1) == 0) stg.store_piece(st_slot, (sl - 4) >> 1);
+#endif
+#ifndef STRIP_T_NOLOADS
+            if (LOAD && sl >= 2 && sl < 7) stg.load_piece(sl - 2);
+#endif
             SPIN();
+            if (sl == 3) PHT(STAGE ? 0 : 4);
+            if (sl == 12) PHT(STAGE ? 1 : 5);
         }
     }
-    slot_valu_tail(Sc[0], pk[0], lsum[0]);
-    if (STAGE) {
-        if (tid < ZT) {
-            const int z = stg.z0_ + tid;
-            float c;
-            if (ROLE == ROLE_YF) c = z >= stg.zend_ ? -INFINITY : (z == 0 ? -1000.0f : stg.cinfo);
-            else c = (z < stg.zend_ && stg.cinfo > 0.f) ? __logf(stg.cinfo) - stg.cinfo2 : -INFINITY;
-            reinterpret_cast<float*>(st_slot + TILEB)[tid] = c;
-        }
-        lds_barrier();
-        tf[0] = lds_tr(o_unit + lo.tr);
-        tf[1] = lds_tr(o_unit + lo.tr + 64);
-    }
+    slot_tail(Sc[0], pk[0], lsum[0]);
+    PHT(STAGE ? 2 : 6);
+#ifndef STRIP_T_NOBAR
+    // Workgroup barrier behind the staged stores.  Only the stores have to be complete: LDS operations retire in order, so
+    // lgkmcnt(2) lets the two youngest ones — the transpose reads of tf[2], issued at ks = 7 behind the last store piece (slot 12)
+    // — stay in flight; a full drain exposed their whole latency once per tile.  The count must never exceed the number of LDS
+    // operations issued after the last store piece: 2.
+    if (STAGE) asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
+#endif
     SPIN();
+    PHT(STAGE ? 3 : 7);
     // ---- O half: 16 MFMAs beside the 16 logits of x tile 1 --------------------------------------------------------------------
 #pragma unroll
     for (int f = 0; f < 8; ++f) {          // f = ks2 * 4 + ct
         const int ks2 = f >> 2, ct = f & 3;
-        if (f + 2 < 8) tf[(f + 2) % 3] = lds_tr(o_unit + lo.tr + ((f + 2) >> 2) * 16 * ROWB + ((f + 2) & 3) * 64);
-        if (f == 5) { cy.zf0 = lds_b128(nx_unit + lo.zf); cy.zf1 = lds_b128(nx_unit + lo.zf + 32); }
-        if (f == 6) fetch_ci(cy.ci, nx_info, lo);
+#ifndef STRIP_T_NOTF
+        if (f + 3 < 8) tf[(f + 3) % 4] = lds_tr(o_unit + lo.tr + ((f + 3) >> 2) * 16 * ROWB + ((f + 3) & 3) * 64);
+#endif
+#ifndef STRIP_T_NOCARRY
+        if (f == 4) cy.zf0 = lds_b128(nx_unit + lo.zf);
+        if (f == 5) { fetch_ci(cy.ci, nx_info, lo); cy.zf1 = lds_b128(nx_unit + lo.zf + 32); }
+        if (f == 6) cy.zf2 = lds_b128(nx_unit + lo.zf + 64);
+#endif
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt) {
-            mfma_o(O[xt][ct], Pp[xt][ks2], tf[f % 3]);
-            slot_valu(Sc[1], pk[1], lsum[1], add[1], 2 * f + xt);
+            slot<2>(O[xt][ct], Pp[xt][ks2], tf[f % 4], Sc[1], Sc[1], pk[1], lsum[1], add[1], 2 * f + xt);
             SPIN();
         }
     }
-    slot_valu_tail(Sc[1], pk[1], lsum[1]);
+    slot_tail(Sc[1], pk[1], lsum[1]);
 #pragma unroll
     for (int xt = 0; xt < 2; ++xt)
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
             Pc[xt][k2] = v4i{pk[xt][4 * k2], pk[xt][4 * k2 + 1], pk[xt][4 * k2 + 2], pk[xt][4 * k2 + 3]};
     SPIN();
+    PHT(STAGE ? 8 : 9);
 }
 
 // S-only sweep over the chunk (ROLE_YF fallback): the exact maximum of every row's logits, per lane (16 of the 32 rows of a unit)
@@ -322,10 +407,34 @@ struct Geo {     // per-wave geometry of a launch
     LaneOff lo;
 };
 
+// x fragments X[x = 32 xt + l31][16 ks + 8 hi ..+7] straight into AGPRs.  Rows past the end (and the pad item 0 of ROLE_W, whose
+// table row is not zero in memory) are NOT zeroed: their outputs are never stored and `add` = -inf / -1000 makes every exponential
+// of theirs 0, so no other row sees them.
+__device__ __forceinline__ void load_xfrags(v4i (&XF)[2][8], const bf16* X, const Geo& g) {
+    const bf16* x0 = X + (long)max(min(g.xbase + g.l31, g.xend - 1), 0) * C + g.hi * 8;
+    const bf16* x1 = X + (long)max(min(g.xbase + 32 + g.l31, g.xend - 1), 0) * C + g.hi * 8;
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\t"
+        "global_load_dwordx4 %2, %16, off offset:64\n\tglobal_load_dwordx4 %3, %16, off offset:96\n\t"
+        "global_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
+        "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"
+        "global_load_dwordx4 %8, %17, off\n\tglobal_load_dwordx4 %9, %17, off offset:32\n\t"
+        "global_load_dwordx4 %10, %17, off offset:64\n\tglobal_load_dwordx4 %11, %17, off offset:96\n\t"
+        "global_load_dwordx4 %12, %17, off offset:128\n\tglobal_load_dwordx4 %13, %17, off offset:160\n\t"
+        "global_load_dwordx4 %14, %17, off offset:192\n\tglobal_load_dwordx4 %15, %17, off offset:224\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&a"(XF[0][0]), "=&a"(XF[0][1]), "=&a"(XF[0][2]), "=&a"(XF[0][3]), "=&a"(XF[0][4]), "=&a"(XF[0][5]), "=&a"(XF[0][6]),
+          "=&a"(XF[0][7]), "=&a"(XF[1][0]), "=&a"(XF[1][1]), "=&a"(XF[1][2]), "=&a"(XF[1][3]), "=&a"(XF[1][4]), "=&a"(XF[1][5]),
+          "=&a"(XF[1][6]), "=&a"(XF[1][7])
+        : "v"(x0), "v"(x1)
+        : "memory");
+}
+
 // One sweep of the wave's 64 x vectors over the workgroup's z chunk: O, lsum (and, ROLE_YF with !EXACT, the reference m2 / add
 // from the chunk's first unit).
-template <int ROLE, bool EXACT>
-__device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* smem, const v4i (&XF)[2][8], f32x16 (&O)[2][4],
+// LOADX: the x fragments are fetched here, behind the first tile loads (one memory round trip for both instead of two).
+template <int ROLE, bool EXACT, bool LOADX>
+__device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* smem, const bf16* X, v4i (&XF)[2][8], f32x16 (&O)[2][4],
                                           float (&add)[2], float (&m2)[2], float (&lsum)[2]) {
     constexpr bool YS = ROLE == ROLE_YF;
     const int tid = g.tid;
@@ -341,12 +450,22 @@ __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* s
             asm volatile("" : "+a"(O[xt][ct]));
         }
     lsum[0] = 0.f; lsum[1] = 0.f;
-    if (g.ntile == 0) return;
-    Stage<ROLE> stg;
-    // ---- prologue: tile 0 (and tile 1 in flight), S(0) --------------------------------------------------------------------
-    stg.load(p, g.Z, g.z_lo, g.z_hi, g.Reff, tid);
-    stg.store(smem, tid);
-    stg.load(p, g.Z, g.z_lo + ZT, g.z_hi, g.Reff, tid);     // (rows past the chunk: clamped addresses, zero-filled in LDS)
+    if (g.ntile == 0) {
+        if (LOADX) load_xfrags(XF, X, g);
+        return;
+    }
+    STAMP(1);
+    // Two staging register sets: the loads of a tile are issued THREE iterations (~5 k cycles) before its LDS stores — with one set
+    // and one iteration of distance every tile waited ~400 cycles for its data (global-load latency under this load > 1 us).
+    Stage<ROLE> stg0, stg1;      // stg1: odd tiles, stg0: even tiles
+    stg0.init(p, g.Z, g.z_hi, g.Reff, tid);
+    stg1.init(p, g.Z, g.z_hi, g.Reff, tid);
+    // ---- prologue: tile 0 (tiles 1 and 2 in flight), S(0) -------------------------------------------------------------------
+    stg0.load(g.z_lo);
+    stg1.load(g.z_lo + ZT);         // (rows past the chunk: clamped to its last row; their C operand is -inf)
+    if (LOADX) load_xfrags(XF, X, g);     // waits for everything issued so far
+    stg0.store(smem);
+    stg0.load(g.z_lo + 2 * ZT);
     // iteration 0 multiplies P(-1) = 0 into "tile -1" = ring slot 3: its second unit must hold finite numbers
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(smem + 3 * SLOTB + UNITB + (tid + NTHR * i) * 16) = make_uint4(0, 0, 0, 0);
@@ -364,7 +483,7 @@ __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* s
     fetch_carry(cy, smem, smem + TILEB, lo);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const v4i zf = ks == 0 ? cy.zf0 : (ks == 1 ? cy.zf1 : lds_b128(smem + lo.zf + ks * 32));
+        const v4i zf = ks == 0 ? cy.zf0 : (ks == 1 ? cy.zf1 : (ks == 2 ? cy.zf2 : lds_b128(smem + lo.zf + ks * 32)));
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt) {
             if (ks == 0) mfma_s0(Sa[xt], zf, XF[xt][0], cy.ci);
@@ -384,26 +503,47 @@ __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* s
         }
     }
     fetch_carry(cy, smem + UNITB, smem + TILEB + ZU * 4, lo);   // unit 1
+    STAMP(2);
+#ifdef STRIP_TIMING
+    unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_readcyclecounter();
+#endif
     // ---- main loop: two iterations per tile -------------------------------------------------------------------------------
     // (no unrolling / peeling: a peeled first trip gets its own register assignment for the accumulators, i.e. 192 v_accvgpr_mov
     // next to MFMAs that the compiler cannot pad)
+#ifdef STRIP_TIMING
+#define PH_ARGS , ph_acc, ph_t
+#else
+#define PH_ARGS
+#endif
+    // Tiles are processed in pairs (static names for the two staging sets); an odd tile count runs one all-padding tile (rows
+    // past the chunk are zero-filled and carry C = -inf: their exponentials are 0).  edgl's planners hand out chunks of an even
+    // number of tiles, so only the last chunk of a launch can be odd.
+    const int ntile2 = (g.ntile + 1) & ~1;
 #pragma clang loop unroll(disable)
-    for (int t = 0; t < g.ntile; ++t) {
-        char* cur = smem + (t & 3) * SLOTB;
-        char* prv = smem + ((t + 3) & 3) * SLOTB;     // tile t-1 (t = 0: the zeroed unit of slot 3, P(-1) = 0)
-        char* nxt = smem + ((t + 1) & 3) * SLOTB;
+    for (int t = 0; t < ntile2; t += 2) {
+        char* s0 = smem + (t & 3) * SLOTB;            // tile t
+        char* sm = smem + ((t + 3) & 3) * SLOTB;      // tile t-1 (t = 0: the zeroed unit of slot 3, P(-1) = 0)
+        char* s1 = smem + ((t + 1) & 3) * SLOTB;      // tile t+1
+        char* s2 = smem + ((t + 2) & 3) * SLOTB;      // tile t+2
         // iteration A (u = 2t): S(2t+1) from the second unit of tile t, O(2t-1) from the second unit of tile t-1; writes the
         // staged tile t+1 (behind the last tile: a harmless rewrite of stale rows — ONE code path, so that the accumulators
         // keep their registers: an if / else over two instances made the allocator shuffle 128 AGPRs per trip)
-        unit_iter<ROLE, true>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, cur + UNITB, prv + UNITB, nxt, nxt + TILEB, lo, stg,
-                              nxt, tid);
-        stg.load(p, g.Z, g.z_lo + (t + 2) * ZT, g.z_hi, g.Reff, tid);
-        // iteration B (u = 2t+1): S(2t+2) from the first unit of tile t+1 (unused garbage past the end), O(2t) from tile t
-        unit_iter<ROLE, false>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, nxt, cur, nxt + UNITB, nxt + TILEB + ZU * 4, lo, stg, nxt, tid);
+        unit_iter<ROLE, true, false>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, s0 + UNITB, sm + UNITB, s1, s1 + TILEB, lo, stg1, s1, tid PH_ARGS);
+        // iteration B (u = 2t+1): S(2t+2) from the first unit of tile t+1, O(2t) from tile t; issues the loads of tile t+3
+        stg1.begin(g.z_lo + (t + 3) * ZT);
+        unit_iter<ROLE, false, true>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, s1, s0, s1 + UNITB, s1 + TILEB + ZU * 4, lo, stg1, s1, tid PH_ARGS);
+        // the same for tile t+1: A writes tile t+2, B loads tile t+4
+        unit_iter<ROLE, true, false>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, s1 + UNITB, s0 + UNITB, s2, s2 + TILEB, lo, stg0, s2, tid PH_ARGS);
+        stg0.begin(g.z_lo + (t + 4) * ZT);
+        unit_iter<ROLE, false, true>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, s2, s1, s2 + UNITB, s2 + TILEB + ZU * 4, lo, stg0, s2, tid PH_ARGS);
     }
+    STAMP(3);
+#ifdef STRIP_TIMING
+    if (g.lane == 0 && blockIdx.x == 3 && blockIdx.y == 0) for (int i = 0; i < 12; ++i) g_ph[g.wave * 12 + i] = ph_acc[i];
+#endif
     // ---- drain: O(2 ntile - 1) ----------------------------------------------------------------------------------------------
     {
-        const char* o_unit = smem + ((g.ntile - 1) & 3) * SLOTB + UNITB;
+        const char* o_unit = smem + ((ntile2 - 1) & 3) * SLOTB + UNITB;
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             const v4i tf = lds_tr(o_unit + lo.tr + (f >> 2) * 16 * ROWB + (f & 3) * 64);
@@ -412,6 +552,7 @@ __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* s
         }
     }
     settle_o(O);
+    STAMP(4);
 }
 
 // the wave's [64 x 128] accumulator -> LDS -> whole 512-byte rows of the slab; row sums / references
@@ -452,29 +593,6 @@ __device__ __forceinline__ void epilogue(const StripP& p, const Geo& g, char* sm
     }
 }
 
-// x fragments X[x = 32 xt + l31][16 ks + 8 hi ..+7] straight into AGPRs.  Rows past the end (and the pad item 0 of ROLE_W, whose
-// table row is not zero in memory) are NOT zeroed: their outputs are never stored and `add` = -inf / -1000 makes every exponential
-// of theirs 0, so no other row sees them.
-__device__ __forceinline__ void load_xfrags(v4i (&XF)[2][8], const bf16* X, const Geo& g) {
-    const bf16* x0 = X + (long)max(min(g.xbase + g.l31, g.xend - 1), 0) * C + g.hi * 8;
-    const bf16* x1 = X + (long)max(min(g.xbase + 32 + g.l31, g.xend - 1), 0) * C + g.hi * 8;
-    asm volatile(
-        "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\t"
-        "global_load_dwordx4 %2, %16, off offset:64\n\tglobal_load_dwordx4 %3, %16, off offset:96\n\t"
-        "global_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
-        "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"
-        "global_load_dwordx4 %8, %17, off\n\tglobal_load_dwordx4 %9, %17, off offset:32\n\t"
-        "global_load_dwordx4 %10, %17, off offset:64\n\tglobal_load_dwordx4 %11, %17, off offset:96\n\t"
-        "global_load_dwordx4 %12, %17, off offset:128\n\tglobal_load_dwordx4 %13, %17, off offset:160\n\t"
-        "global_load_dwordx4 %14, %17, off offset:192\n\tglobal_load_dwordx4 %15, %17, off offset:224\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&a"(XF[0][0]), "=&a"(XF[0][1]), "=&a"(XF[0][2]), "=&a"(XF[0][3]), "=&a"(XF[0][4]), "=&a"(XF[0][5]), "=&a"(XF[0][6]),
-          "=&a"(XF[0][7]), "=&a"(XF[1][0]), "=&a"(XF[1][1]), "=&a"(XF[1][2]), "=&a"(XF[1][3]), "=&a"(XF[1][4]), "=&a"(XF[1][5]),
-          "=&a"(XF[1][6]), "=&a"(XF[1][7])
-        : "v"(x0), "v"(x1)
-        : "memory");
-}
-
 // ROLE_YF, rare: a row sum left the f32-safe range.  Exact row maxima over the whole chunk (S-only sweep), then the sweep again with
 // them as references (exp <= 1).  NOT inlined: as part of the kernel body its live ranges cost the hot sweep 60 spilled registers
 // and a copy of the x fragments per MFMA; as a function it has its own allocation and reloads what it needs.
@@ -484,11 +602,12 @@ __device__ __attribute__((noinline)) void fallback_exact(const StripP* pp, const
     v4i XF[2][8];
     load_xfrags(XF, p.rows, g);
     Stage<ROLE_YF> stg;
+    stg.init(p, g.Z, g.z_hi, g.Reff, g.tid);
     float mx[2] = {-INFINITY, -INFINITY};
     for (int t = 0; t < g.ntile; ++t) {
         __syncthreads();
-        stg.load(p, g.Z, g.z_lo + t * ZT, g.z_hi, g.Reff, g.tid);
-        stg.store(smem, g.tid);
+        stg.load(g.z_lo + t * ZT);
+        stg.store(smem);
         __syncthreads();
         max_unit(mx, XF, smem, smem + TILEB, g.lo);
         max_unit(mx, XF, smem + UNITB, smem + TILEB + ZU * 4, g.lo);
@@ -501,7 +620,7 @@ __device__ __attribute__((noinline)) void fallback_exact(const StripP* pp, const
         add[xt] = -m2[xt];
     }
     f32x16 O[2][4];
-    main_pass<ROLE_YF, true>(p, g, smem, XF, O, add, m2, lsum);
+    main_pass<ROLE_YF, true, false>(p, g, smem, p.rows, XF, O, add, m2, lsum);
     epilogue<ROLE_YF>(p, g, smem, O, m2, lsum);
 }
 
@@ -515,14 +634,19 @@ __global__ __launch_bounds__(NTHR, 1) void strip_kernel(StripP p) {
     int bx, zchunk;
     g.nchunk_dev = 1;
     if (YS) {
-        const DevPlan dp = dev_plan(g.Reff, XB, gridDim.x, p.i1 - p.i0, ZT);
-        if ((int)blockIdx.x >= dp.nx * dp.nchunk || g.Reff <= 0) return;
-        bx = blockIdx.x % dp.nx; g.by = blockIdx.x / dp.nx; zchunk = dp.zchunk; g.nchunk_dev = dp.nchunk;
+        const DevPlan dp = dev_plan(g.Reff, XB, gridDim.x, p.i1 - p.i0, 2 * ZT);     // chunks of whole tile pairs
+        // XCD-aware order: workgroup b runs on XCD b % 8 (observed placement; speed only), and the nx workgroups of an item chunk
+        // stream the SAME table rows — chunk-major ids are dealt to the XCDs in contiguous runs, so that one XCD's L2 holds 2-3
+        // chunks (~1 MB) instead of seeing the whole table (5 MB > 4 MB: every tile came from the Infinity Cache)
+        int id = blockIdx.x;
+        if ((gridDim.x & 7) == 0) id = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+        if (id >= dp.nx * dp.nchunk || g.Reff <= 0) return;
+        bx = id % dp.nx; g.by = id / dp.nx; zchunk = dp.zchunk; g.nchunk_dev = dp.nchunk;
         g.slab_stride = (long)dp.nx * XB * C;
     } else {
         bx = blockIdx.x; g.by = blockIdx.y;
-        const int ntiles = (g.Reff + ZT - 1) / ZT;
-        zchunk = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y * ZT;
+        const int ntiles = (g.Reff + 2 * ZT - 1) / (2 * ZT);
+        zchunk = (ntiles + (int)gridDim.y - 1) / (int)gridDim.y * 2 * ZT;
         g.slab_stride = (long)p.I * C;
     }
     g.xbase = (YS ? 0 : p.i0) + bx * XB + g.wave * XW;
@@ -533,9 +657,8 @@ __global__ __launch_bounds__(NTHR, 1) void strip_kernel(StripP p) {
     g.z_hi = min(YS ? p.i1 : g.Reff, g.z_lo + zchunk);
     g.ntile = g.z_hi > g.z_lo ? (g.z_hi - g.z_lo + ZT - 1) / ZT : 0;
     g.lo = lane_off(g.lane);
-
+    STAMP(0);
     v4i XF[2][8];
-    load_xfrags(XF, X, g);
     float add[2], lsum[2], m2[2];
 #pragma unroll
     for (int xt = 0; xt < 2; ++xt) {
@@ -547,7 +670,7 @@ __global__ __launch_bounds__(NTHR, 1) void strip_kernel(StripP p) {
     }
     {
         f32x16 O[2][4];
-        main_pass<ROLE, false>(p, g, smem, XF, O, add, m2, lsum);
+        main_pass<ROLE, false, true>(p, g, smem, X, XF, O, add, m2, lsum);
         bool bad = false;
         if (YS) {
 #pragma unroll
@@ -558,6 +681,10 @@ __global__ __launch_bounds__(NTHR, 1) void strip_kernel(StripP p) {
         }
         if (!YS || !__syncthreads_or(bad ? 1 : 0)) {
             epilogue<ROLE>(p, g, smem, O, m2, lsum);
+            STAMP(5);
+#ifdef STRIP_TIMING
+            if (p.stamps && g.tid == 0) p.stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 6] = (unsigned long long)g.ntile;
+#endif
             return;
         }
     }
@@ -621,6 +748,11 @@ __global__ __launch_bounds__(128) void label_scatter_kernel(const bf16* rows, co
 }  // namespace strip
 
 // ---- host side (called from k_score.hip) --------------------------------------------------------------------------------------
+static unsigned long long* g_strip_stamps = nullptr;
+extern "C" void edgl_debug_strip_stamps(void* buf) { g_strip_stamps = (unsigned long long*)buf; }   // STRIP_TIMING builds (tools/)
+#ifdef STRIP_TIMING
+extern "C" void edgl_debug_strip_phases(unsigned long long* out4) { hipMemcpyFromSymbol(out4, HIP_SYMBOL(strip::g_ph), 384); }
+#endif
 bool edgl_strip_enabled() {
     static const int on = getenv("EDGL_SCORE_STRIP") ? atoi(getenv("EDGL_SCORE_STRIP")) : 1;
     return on != 0;
@@ -630,7 +762,7 @@ int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, 
                     float* slabs, float* part, int G, hipStream_t st) {
     strip::StripP p{};
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
-    p.nvalid = nvalid; p.slabs = slabs; p.part = part;
+    p.nvalid = nvalid; p.slabs = slabs; p.part = part; p.stamps = g_strip_stamps;
     auto k = strip::strip_kernel<strip::ROLE_YF>;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, strip::SMEM); attr = true; }
@@ -643,7 +775,7 @@ int edgl_strip_table(const void* rows, const void* table, const float* out_bias,
                      int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, hipStream_t st) {
     strip::StripP p{};
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
-    p.nvalid = nvalid; p.coef = coef; p.row_lse = row_lse; p.slabs = slabs; p.bias_slabs = bias_slabs;
+    p.nvalid = nvalid; p.coef = coef; p.row_lse = row_lse; p.slabs = slabs; p.bias_slabs = bias_slabs; p.stamps = g_strip_stamps;
     auto k = strip::strip_kernel<strip::ROLE_W>;
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, strip::SMEM); attr = true; }
