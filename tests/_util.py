@@ -76,3 +76,25 @@ def relu_flip_err(got, ref, tol):
     rms = float(np.sqrt((err ** 2).mean()))
     assert rms <= tol / 2, f"rms error {rms:.3e} > {tol / 2:.1e}"
     return float(col[~flipped].max()) if (~flipped).any() else 0.0
+
+
+# bf16 path, gradients: a max-norm bound alone lets every small entry of a tensor be wrong.  Every gradient
+# tensor is held to a relative L2 error AND to max-abs-error / max-abs-reference.  f32 path: 1e-3 on both.
+GRAD_TOL = {"f32": (1e-3, 1e-3), "bf16": (2e-2, 5e-2)}
+LOSS_TOL = {"f32": 1e-4, "bf16": 5e-3}
+
+
+def grad_errors(got, want):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    d = got - want
+    return float(np.linalg.norm(d) / (np.linalg.norm(want) + 1e-300)), float(np.abs(d).max() / (np.abs(want).max() + 1e-30))
+
+
+def grad_ok(got, want, mode):
+    """(ok, (rel_l2, rel_max)) under GRAD_TOL[mode]; a reference gradient that is exactly zero must be reproduced as (near) zero."""
+    l2, mx = grad_errors(got, want)
+    t2, tm = GRAD_TOL[mode]
+    if not np.any(np.asarray(want)):
+        return bool(np.abs(np.asarray(got, dtype=np.float64)).max() < 1e-12), (l2, mx)
+    return bool(l2 <= t2 and mx <= tm), (l2, mx)

@@ -1,14 +1,14 @@
 """Whole-model parity: the HIP EasyDGL (through the reference's model interface) vs the fp64 oracle on the
-same seeded inputs and weights.  Stated tolerances: f32 path rtol 1e-4 on logits / loss,
-1e-3 on gradients; bf16 path <= 2e-2 relative on logits (3e-2 used for the loss / 1e-1 for gradients, which
-go through bf16 activations end to end)."""
+same seeded inputs and weights.  Stated tolerances: f32 path rtol 1e-4 on logits / loss, 1e-3 on gradients;
+bf16 path <= 2e-2 relative on logits / lambda, 5e-3 on the loss, and every gradient tensor within 2e-2 relative L2 AND 5e-2 of its
+largest entry (tests/_util.py GRAD_TOL)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import easydgl_oracle as O
 from oracle import torch_ref as R
-from tests._util import assert_close, build_model, make_problem, rel_err, to_dev
+from tests._util import GRAD_TOL, LOSS_TOL, assert_close, build_model, grad_ok, make_problem, rel_err, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -22,9 +22,9 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode,ltol,gtol", [("f32", 1e-4, 1e-3), ("bf16", 3e-2, 1e-1)])
+@pytest.mark.parametrize("mode,ltol", [("f32", 1e-4), ("bf16", 2e-2)])
 @pytest.mark.parametrize("case", range(len(CASES)))
-def test_forward_loss_and_gradients(mode, ltol, gtol, case):
+def test_forward_loss_and_gradients(mode, ltol, case):
     prob = make_problem(seed=10 + case, batch=4, **CASES[case])
     cfg = prob["cfg"]
     m = build_model(prob, mode)
@@ -44,12 +44,13 @@ def test_forward_loss_and_gradients(mode, ltol, gtol, case):
     p64 = R.to_torch_params(prob["params"])
     ref_loss, _ = R.train_loss(cfg, p64, prob["mark_table"], prob["feats"], prob["labels"])
     ref_loss.backward()
-    assert_close(loss.item(), ref_loss.item(), ltol, "train loss")
-    worst = {}
+    assert_close(loss.item(), ref_loss.item(), LOSS_TOL[mode], "train loss")
+    bad = {}
     for name, p in m.tf_variable_map().items():
-        worst[name] = rel_err(p.grad.cpu().numpy(), p64[name].grad.numpy())
-    bad = {k: v for k, v in worst.items() if v > gtol}
-    assert not bad, f"gradient mismatch (rel to max |ref|): {bad}"
+        ok, e = grad_ok(p.grad.cpu().numpy(), p64[name].grad.numpy(), mode)
+        if not ok:
+            bad[name] = e
+    assert not bad, f"gradient mismatch (relative L2, max-abs / max-abs-ref) vs {GRAD_TOL[mode]}: {bad}"
     # ---- eval logits (last position)
     elog = m(to_dev(prob["efeats"]), False)
     want_e, _ = O.forward(cfg, prob["params"], prob["mark_table"], prob["efeats"], False)
