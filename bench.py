@@ -44,7 +44,7 @@ HEADLINE = dict(num_items=20000, seqslen=100, num_units=128, num_heads=8, num_bl
 # (flash-style running maxima; edgl_score_flash_fwd).  The scoring family carries 76 % of the step's algorithmic FLOPs
 # (DESIGN.md §5).  With EDGL_FLASH_CE=0 the same slot times the round-1 kernel (ROLE_Y: d_rows only, logits recomputed).
 DOMINANT_KERNEL_ID = 0   # EDGL_KERNEL_SCORE_BWD_ROWS
-DOMINANT_KERNEL = "score_bwd_kernel<bf16, C/16=8, ROLE_YF> (forward logits + row LSE + d_rows = dl . table in one pass)"
+DOMINANT_KERNEL = "strip_kernel<ROLE_YF> (bf16, C=128: forward logits + row reference / sum + d_rows = dl . table in one pass)"
 DOMINANT_KERNEL_R1 = "score_bwd_kernel<bf16, C/16=8, ROLE_Y> (d_rows = dl . table, logits recomputed)"
 
 
@@ -67,7 +67,10 @@ def flops_per_seq(c, rows_scored=None):
     return f
 
 
-def make_model_and_batch(c, dtype, device, seed, full_rows=False):
+NBATCH = 8     # distinct device-resident batches rotated through the timed loop (the step never sees the same batch twice in a row)
+
+
+def make_model_and_batch(c, dtype, device, seed, full_rows=False, nbatch=1, ids="zipf"):
     from types import SimpleNamespace
     import easydgl_amd
     from easydgl_amd import data as D
@@ -81,15 +84,21 @@ def make_model_and_batch(c, dtype, device, seed, full_rows=False):
                         num_train_steps=None, num_warmup_steps=None, seed=9876)
     model = easydgl_amd.ranking(F).finalize(device)
     # full_rows: every sequence has all T tokens, so no masked slot falls on padding and every one of the B*M rows is scored
-    ids, ts = D.synthetic_batch(c["num_items"], c["seqslen"], c["batch"], seed=seed, min_len=(c["seqslen"] + 1) if full_rows else 5)
-    g = torch.Generator().manual_seed(seed)
-    mp = D.draw_masked_positions(c["batch"], c["seqslen"] + 1, c["masklen"], generator=g)
-    feats, labels = D.mask_random(torch.tensor(ids), torch.tensor(ts), c["num_items"], mp)
-    feats = {k: v.to(device).contiguous() for k, v in feats.items()}
-    return model, feats, labels.to(device).contiguous()
+    batches = []
+    for k in range(nbatch):
+        sd = seed + 7919 * k
+        ids_np, ts = D.synthetic_batch(c["num_items"], c["seqslen"], c["batch"], seed=sd, min_len=(c["seqslen"] + 1) if full_rows else 5,
+                                       ids=ids)
+        g = torch.Generator().manual_seed(sd)
+        mp = D.draw_masked_positions(c["batch"], c["seqslen"] + 1, c["masklen"], generator=g)
+        feats, labels = D.mask_random(torch.tensor(ids_np), torch.tensor(ts), c["num_items"], mp)
+        batches.append(({k_: v.to(device).contiguous() for k_, v in feats.items()}, labels.to(device).contiguous()))
+    if nbatch == 1:
+        return model, batches[0][0], batches[0][1]
+    return model, batches
 
 
-def cpu_baseline(c, budget_s=15.0, nthreads=None):
+def cpu_baseline(c, budget_s=15.0, nthreads=None, bs=None):
     """Restated reference graph on the host (TensorFlow is not installable offline): float32, reference op
     order incl. the materialised [hB,T,T(,E)] and [B*M,I] tensors, all host cores; bounded sample."""
     from oracle import easydgl_oracle as O
@@ -99,7 +108,7 @@ def cpu_baseline(c, budget_s=15.0, nthreads=None):
     if nthreads is None:
         nthreads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(nthreads)
-    bs = 16
+    bs = c["batch"] if bs is None else bs      # the GPU workload's own batch (512) unless a smaller sample is asked for
     cfg = O.Config(num_items=c["num_items"], seqslen=c["seqslen"], num_units=c["num_units"], num_heads=c["num_heads"],
                    num_blocks=c["num_blocks"], masklen=c["masklen"], time_scale=c["time_scale"], ct_reg=c["ct_reg"],
                    l2_reg=c["l2_reg"], learning_rate=c["learning_rate"], num_events=c["num_events"])
@@ -134,8 +143,10 @@ def encode_bench(args):
     I = num_items + 1
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     s = 2 if args.dtype == "bf16" else 4
-    ids_np, ts_np = D.synthetic_batch(num_items, T - 1, B, seed=9876)
+    ids_mode = getattr(args, "ids", "zipf")
+    ids_np, ts_np = D.synthetic_batch(num_items, T - 1, B, seed=9876, ids=ids_mode)
     ids, ts = torch.tensor(ids_np, device=dev), torch.tensor(ts_np, device=dev)
+    unique_rows = int(np.unique(ids_np[ids_np != 0]).size)
     g = torch.Generator().manual_seed(1)
     item = (torch.randn((I, C), generator=g) * 0.02).to(dev).requires_grad_()
     pos = (torch.randn((T, C), generator=g) * 0.02).to(dev).requires_grad_()
@@ -174,15 +185,17 @@ def encode_bench(args):
     rows_touched = int((ids != 0).sum().item())
     bytes_b = B * T * 3 * C * s + B * T * (8 + E) + rows_touched * C * 4 * 2 + T * C * 4 + E * C * 4
     enc_traffic = None   # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/profile_encode.sh), read side x1
-    tpath = os.path.join(ROOT, "profiles", "r01_encode_hbm.json")
-    if args.dtype == "bf16" and os.path.exists(tpath):
-        enc_traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_1x_read")
+    for tp in (f"r03_encode_hbm_{ids_mode}.json", "r01_encode_hbm.json" if ids_mode == "zipf" else ""):
+        tpath = os.path.join(ROOT, "profiles", tp)
+        if tp and args.dtype == "bf16" and os.path.exists(tpath):
+            enc_traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_1x_read")
+            break
     out = {"metric": "GB/s (K1 input encoding forward, |items|=1M L=200 d=256 B=512)", "value": round(bytes_f / t_f / 1e9, 1),
            "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_f * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "K1 encode (item gather x sqrt(C) + sinusoidal time code + position + mark embeddings), "
-                                  "config 3: num_items 1000000, seqslen 200 (T=201), num_units 256, batch 512, 16 marks",
-                      "algorithmic_bytes_fwd": bytes_f, "algorithmic_bytes_bwd": bytes_b},
+                                  f"config 3: num_items 1000000, seqslen 200 (T=201), num_units 256, batch 512, 16 marks, ids {ids_mode}",
+                      "unique_item_rows": unique_rows, "algorithmic_bytes_fwd": bytes_f, "algorithmic_bytes_bwd": bytes_b},
            "roofline": {"bound": "hbm", "kernel": "encode_fwd_kernel", "achieved": round(bytes_f / t_f / 1e9, 1), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(bytes_f / t_f / 8e12, 4), "traffic": enc_traffic},
            "backward": {"ms": round(t_b * 1e3, 4), "achieved_GBps": round(bytes_b / t_b / 1e9, 1),
@@ -265,6 +278,8 @@ def main():
     ap.add_argument("--op-table", action="store_true", help="after the timed region, print a per-C-call time table to stderr")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary rows (M=6, all rows weighted, dropout off, "
                                                              "config-3 encode, sharded eval) the default N=1 run appends")
+    ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform"], help="item-id distribution of the synthetic sequences "
+                    "(--workload encode; the step workload reports the uniform variant as an extra)")
     ap.add_argument("--workload", default="step", choices=["step", "encode", "eval", "tgat", "tisasrec", "ctsma"],
                     help="step: the headline optimizer step (default, the bench contract); encode: K1 input encoding "
                          "(embedding gather + time code) alone at SURVEY §8d config 3 (|items| = 1M, L = 200, d = 256) — the "
@@ -309,32 +324,51 @@ def main():
     c = dict(HEADLINE)
     from easydgl_amd import _lib
     res = run_step_workload(c, args, dev, rank, world, dist, args.steps, args.warmup, bracket=(args.path != "graph"))
-    dt, loss, labels, dom = res["dt"], res["loss"], res["labels"], res["dom"]
+    dt, loss, dom = res["dt"], res["loss"], res["dom"]
 
     if rank == 0:
         T, C, I, M = c["seqslen"] + 1, c["num_units"], c["num_items"] + 1, c["masklen"]
         R = c["batch"] * M
+        h, E, nb = c["num_heads"], c["num_events"], c["num_blocks"]
         # rows with label 0 (masked slots that fell on padding) have weight 0 in the loss (EasyDGL.py:180) and are not
-        # scored; only the weighted rows count as algorithmic work
-        R_w = int((labels != 0).sum().item())
+        # scored; only the weighted rows count as algorithmic work.  The timed loop rotates NBATCH batches: R_w is the mean over
+        # the batches (whole step) / over the batches of the bracketed launches (dominant kernel).
+        rows_w = res["rows_w"]
+        R_w_mean = float(np.mean(rows_w))
         # ALGORITHMIC work of the dominant kernel.  Flash form: the kernel IS the forward scoring (logits
         # 2*R_w*C*I — F_score of the forward pass) and the row-gradient product d_rows = dl . table (2*R_w*C*I): both are
         # algorithmic, nothing is recomputed.  Round-1 form (EDGL_FLASH_CE=0): only the d_rows product is algorithmic, its
         # logits are a recomputation and count for `hw_util` (what the MFMA pipe did) alone.
         flash = bool(getattr(res.get("engine"), "flash_ce", False))
+        n_dom, ms_dom, bidx = dom[0]
+        R_w = float(np.mean([rows_w[k] for k in bidx])) if bidx else R_w_mean
         dom_exec = 4.0 * R_w * C * I
         dom_flops = dom_exec if flash else 2.0 * R_w * C * I
-        dom_ms = dom[1] / max(1, dom[0])
+        dom_ms = ms_dom / max(1, n_dom)
         peak = 2500.0 if args.dtype == "bf16" else 157.3
         traffic = None   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        for tp in ("r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+        for tp in ("r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if args.dtype == "bf16" and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 break
         ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        flops_done = 3 * flops_per_seq(c, rows_scored=R_w / c["batch"]) * c["batch"]
+        flops_done = 3 * flops_per_seq(c, rows_scored=R_w_mean / c["batch"]) * c["batch"]
         ms = res["step_ms"]
+        # the attention block (north_star: "MFMA utilisation for the attention/scoring blocks"): K3 forward (one launch) and the
+        # three backward passes, bracketed like the dominant kernel; algorithmic FLOPs per SURVEY §8d: F_attn + F_int + F_mark
+        # forward, twice that backward.  VALUBusy / MfmaUtil of the same kernels: profiles/r03_mfma_valu_util.txt.
+        dh = C // h
+        f_att_fwd = c["batch"] * nb * (6.0 * T * T * C + 2.0 * T * C * E * (dh + 2) + 2.0 * h * T * T * E)
+        att = {}
+        for key, kid, mult in (("forward", 2, 1.0), ("backward", 3, 2.0)):
+            n_k, ms_k, _ = dom[kid]
+            t_ms = ms_k / max(1, n_k) / max(1, nb)         # per BiMAU call (one per block)
+            fl = mult * f_att_fwd / max(1, nb)
+            att[key] = {"avg_ms": round(t_ms, 4), "algorithmic_gflop": round(fl / 1e9, 2),
+                        "achieved": round(fl / (t_ms * 1e-3) / 1e12, 2) if t_ms > 0 else 0.0,
+                        "frac": round(fl / (t_ms * 1e-3) / 1e12 / peak, 4) if t_ms > 0 else 0.0, "launches_timed": n_k}
+        pu = os.path.join(ROOT, "profiles", "r03_mfma_valu_util.json")
         out = {
             "metric": "sequences/sec (fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K",
             "value": round(world * c["batch"] * args.steps / dt, 2),
@@ -346,6 +380,7 @@ def main():
             "config": {"workload": "EasyDGL optimizer step, per-GPU batch 512, seqslen 100 (T=101), num_units 128, 8 heads, "
                                    "1 block, num_items 20000 (I=20001), masklen 20, 16 marks, dropout 0.1/0.1, ct_reg 1e-7, l2 1e-4",
                        "global_batch": world * c["batch"], "parallelism": f"dp{world}",
+                       "batches_rotated": NBATCH,
                        "algorithmic_gflop_per_step_all_rows": round(3 * flops_per_seq(c) * c["batch"] / 1e9, 1),
                        "algorithmic_gflop_per_step_rows_scored": round(flops_done / 1e9, 1)},
             "loss": round(float(loss), 5), "path": args.path,
@@ -356,21 +391,26 @@ def main():
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "hw_util": round(dom_exec / (dom_ms * 1e-3) / 1e12 / peak, 4) if dom_ms > 0 else 0.0,
                          "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "executed_flop": dom_exec,
-                         "rows_scored": R_w, "rows_total": R, "traffic": traffic, "launches_timed": dom[0]},
+                         "rows_scored": round(R_w, 1), "rows_total": R, "traffic": traffic, "launches_timed": n_dom},
+            "roofline_attention": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+                                   "kernels": "K3 BiMAU: bimau_fwd_kernel | bimau_bwd_sweep1 + intensity_bwd + bimau_bwd_sweep2 "
+                                              "(QK^T, softmax, P.T_, intensity MLP, lambda.marks^T, (G.P).V and their backward)",
+                                   "forward": att["forward"], "backward": att["backward"],
+                                   "pipe_utilisation_pmc": json.load(open(pu)) if os.path.exists(pu) else None},
             # whole-step MFMA fraction on the work actually done (weight-0 rows are skipped exactly, so they are not counted)
             "whole_step_mfma_frac": round(flops_done / (dt / args.steps) / 1e12 / peak, 4),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(c, budget_s=12.0)
-            # the reference's own thread setting (src/main.py:167-168: intra/inter-op parallelism = 1)
-            out["cpu_baseline_1thread"] = cpu_baseline(c, budget_s=8.0, nthreads=1)
+            out["cpu_baseline"] = cpu_baseline(c, budget_s=12.0)      # the GPU workload's own batch of 512
+            # the reference's own thread setting (src/main.py:167-168: intra/inter-op parallelism = 1), on a batch of 16
+            out["cpu_baseline_1thread_batch16"] = cpu_baseline(c, budget_s=8.0, nthreads=1, bs=16)
         if world == 1 and not args.no_extras and args.path == "engine":
             out["extras"] = extras(c, args, dev)
         if args.op_table:
             step = res["step"]
             _lib.profiler.start()
-            for _ in range(5):
-                step()
+            for i_ in range(5):
+                step(i_)
             torch.cuda.synchronize()
             _lib.profiler.stop()
             rows = sorted(_lib.profiler.summary().items(), key=lambda kv: -kv[1][1])
@@ -384,14 +424,28 @@ def main():
         dist.destroy_process_group()
 
 
-def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=False, full_rows=False):
+BRACKETS = (0, 2, 3)   # EDGL_KERNEL_SCORE_BWD_ROWS, EDGL_KERNEL_BIMAU_FWD, EDGL_KERNEL_BIMAU_BWD_ALL (include/easydgl_hip.h)
+
+
+def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=False, full_rows=False, ids="zipf", device_masker=False):
     """W warm-up steps, then EXACTLY `steps` optimizer steps between barrier + synchronize on both sides; the time is the max
-    over ranks.  Every step is also bracketed by HIP events on the launch stream (median / p10 / p90)."""
+    over ranks.  The steps rotate through NBATCH distinct batches resident in HBM (the engine is pointed at them: no copies);
+    `device_masker`: every step first draws its masked positions on the device (edgl_mask_random, row a-1) from the unmasked
+    sequences.  Groups of steps are bracketed by HIP events on the launch stream (median / p10 / p90)."""
     from easydgl_amd import _lib, parallel
-    model, feats, labels = make_model_and_batch(c, args.dtype, dev, seed=9876 + rank, full_rows=full_rows)
+    from easydgl_amd import data as D
+    model, batches = make_model_and_batch(c, args.dtype, dev, seed=9876 + rank, full_rows=full_rows, nbatch=NBATCH, ids=ids)
+    raw = None
+    if device_masker:      # unmasked sequences of the same batches; the masker writes fresh features / labels every step
+        raw = []
+        for k in range(NBATCH):
+            ids_np, ts = D.synthetic_batch(c["num_items"], c["seqslen"], c["batch"], seed=9876 + rank + 7919 * k,
+                                           min_len=(c["seqslen"] + 1) if full_rows else 5, ids=ids)
+            raw.append((torch.tensor(ids_np, device=dev), torch.tensor(ts, device=dev)))
     if args.path == "autograd":
-        def step():
+        def step(i=0):
             from easydgl_amd import ops
+            feats, labels = batches[i % NBATCH]
             ops.rng_advance(model._rng_state)
             model.zero_grad_arena()
             loss = model.train_loss(feats, labels)
@@ -402,14 +456,22 @@ def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=Fa
             return loss.detach()
     else:
         from easydgl_amd.engine import TrainEngine
-        eng = TrainEngine(model, c["batch"], use_graph=(args.path == "graph"))
-        eng.load_batch(feats, labels)
+        eng = TrainEngine(model, c["batch"], use_graph=(args.path == "graph"), process_group=None)
+        eng.load_batch(*batches[0])
 
-        def step():
+        def step(i=0):
+            if raw is not None:
+                feats, labels = D.device_mask_random(raw[i % NBATCH][0], raw[i % NBATCH][1], model.mask, c["masklen"], model._rng_state,
+                                                     stream_id=0x4d41534b + i)
+            else:
+                feats, labels = batches[i % NBATCH]
+            if args.path == "graph":
+                return eng.step(feats, labels)        # the captured launches read the static buffers: four small copies
+            eng.bind_batch(feats, labels)
             return eng.step()
 
-    for _ in range(warmup):
-        step()
+    for i in range(warmup):
+        step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -424,25 +486,29 @@ def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=Fa
         e.record()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # HIP events inside the timed region cost ~6 us of launch-stream idle each (measured: kernel timeline): the dominant
-    # kernel is bracketed on every BR_EVERY-th step and the step marks are recorded every MARK_EVERY steps
-    BR_EVERY = int(os.environ.get("EDGL_BENCH_BRACKET_EVERY", "4"))
+    # HIP events inside the timed region cost ~6 us of launch-stream idle each (measured: kernel timeline): ONE kernel group is
+    # bracketed per step, three steps out of BR_EVERY (scoring rows pass, BiMAU forward, BiMAU backward), and the step marks are
+    # recorded every MARK_EVERY steps
+    BR_EVERY = max(4, int(os.environ.get("EDGL_BENCH_BRACKET_EVERY", "4")))
     MARK_EVERY = int(os.environ.get("EDGL_BENCH_MARK_EVERY", "5"))
-    br_used = []
+    br_used = {k: [] for k in BRACKETS}
     for i in range(steps):
         if i % MARK_EVERY == 0:
             marks[i].record()
-        if bracket and i % BR_EVERY == 0:
-            _lib.lib.edgl_profile_next(DOMINANT_KERNEL_ID, evs[i][0].cuda_event, evs[i][1].cuda_event)
-            br_used.append(i)
-        loss = step()
+        if bracket and i % BR_EVERY < len(BRACKETS):
+            kid = BRACKETS[i % BR_EVERY]
+            _lib.lib.edgl_profile_next(kid, evs[i][0].cuda_event, evs[i][1].cuda_event)
+            br_used[kid].append(i)
+        loss = step(warmup + i)
     marks[steps].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    dom = (len(br_used), sum(evs[i][0].elapsed_time(evs[i][1]) for i in br_used)) if bracket else (0, 0.0)
+    _lib.lib.edgl_profile_next(-1, None, None)
+    # (count, total ms, batch index of every bracketed step) per kernel group
+    dom = {k: (len(v), sum(evs[i][0].elapsed_time(evs[i][1]) for i in v), [(warmup + i) % NBATCH for i in v]) for k, v in br_used.items()}
     mk = list(range(0, steps, MARK_EVERY)) + [steps]
     step_ms = [marks[a].elapsed_time(marks[b_]) / (b_ - a) for a, b_ in zip(mk[:-1], mk[1:])]   # mean step time per group
     if world > 1:
@@ -451,7 +517,8 @@ def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=Fa
         dt = float(t.item())
     if not np.isfinite(float(loss)):
         raise RuntimeError("loss is not finite")
-    return {"dt": dt, "loss": loss, "labels": labels, "dom": dom, "step_ms": step_ms, "step": step, "model": model, "feats": feats,
+    rows_w = [int((lb != 0).sum().item()) for _, lb in batches]
+    return {"dt": dt, "loss": loss, "rows_w": rows_w, "dom": dom, "step_ms": step_ms, "step": step, "model": model,
             "engine": None if args.path == "autograd" else eng}
 
 
@@ -463,28 +530,37 @@ def extras(c, args, dev):
     out = {}
     a2 = copy.copy(args)
 
-    def row(cc, full_rows=False, multi_hot=False):
+    def row(cc, full_rows=False, multi_hot=False, ids="zipf", device_masker=False):
         cc = dict(cc, multi_hot=multi_hot)
-        r = run_step_workload(cc, a2, dev, 0, 1, None, 30, 10, bracket=False, full_rows=full_rows)
-        rw = int((r["labels"] != 0).sum().item())
+        r = run_step_workload(cc, a2, dev, 0, 1, None, 30, 10, bracket=False, full_rows=full_rows, ids=ids, device_masker=device_masker)
+        rw = float(np.mean(r["rows_w"]))
         fl = 3 * flops_per_seq(cc, rows_scored=rw / cc["batch"]) * cc["batch"]
         ms = float(np.median(r["step_ms"]))
         return {"ms_per_step": round(r["dt"] / 30 * 1e3, 4), "ms_median": round(ms, 4),
-                "sequences_per_s": round(cc["batch"] * 30 / r["dt"], 1), "rows_scored": rw, "rows_total": cc["batch"] * cc["masklen"],
+                "sequences_per_s": round(cc["batch"] * 30 / r["dt"], 1), "rows_scored": round(rw, 1), "rows_total": cc["batch"] * cc["masklen"],
                 "whole_step_mfma_frac": round(fl / (r["dt"] / 30) / 1e12 / (2500.0 if args.dtype == "bf16" else 157.3), 4)}
     out["masklen_6"] = row(dict(c, masklen=6))
     out["all_rows_weighted"] = row(c, full_rows=True)
     out["dropout_off"] = row(dict(c, hidden_dropout_rate=0.0, attention_probs_dropout_rate=0.0))
     out["multi_hot_marks"] = row(c, multi_hot=True)
+    # ids ~ U[1, num_items): no clip pile-up on one id (the Zipf recipe of SURVEY §8d puts ~35 % of the tokens and labels on id
+    # num_items - 1, which flatters the gather, the embedding scatter and the label paths)
+    out["uniform_ids"] = row(c, ids="uniform")
+    # row a-1 inside the step: the masked positions of every batch are drawn on the device (edgl_mask_random) right before it
+    out["with_device_masker"] = row(c, device_masker=True)
     torch.cuda.empty_cache()
     a3 = copy.copy(args)
     a3.steps, a3.warmup = 50, 10
-    enc = encode_bench(a3)
-    out["encode_config3"] = {"algorithmic_GBps": enc["value"], "ms": enc["ms_per_step"], "frac_of_8TBps_algorithmic": enc["roofline"]["frac"],
-                             "hbm_side_bytes_per_launch_pmc": enc["roofline"]["traffic"],
-                             "hbm_side_GBps_pmc": (round(enc["roofline"]["traffic"] / (enc["ms_per_step"] * 1e-3) / 1e9, 1)
-                                                   if enc["roofline"]["traffic"] else None),
-                             "workload": enc["config"]["workload"]}
+    for key, ids_mode in (("encode_config3", "zipf"), ("encode_config3_uniform_ids", "uniform")):
+        a3.ids = ids_mode
+        enc = encode_bench(a3)
+        tr = enc["roofline"]["traffic"]
+        out[key] = {"algorithmic_GBps": enc["value"], "ms": enc["ms_per_step"], "frac_of_8TBps_algorithmic": enc["roofline"]["frac"],
+                    "hbm_side_bytes_per_launch_pmc": tr,
+                    "hbm_side_GBps_pmc": round(tr / (enc["ms_per_step"] * 1e-3) / 1e9, 1) if tr else None,
+                    # counter bytes below the algorithmic bytes = gathered rows served from L2 / MALL: the honest HBM fraction
+                    "frac_of_8TBps_counter_side": round(tr / (enc["ms_per_step"] * 1e-3) / 8e12, 4) if tr else None,
+                    "unique_item_rows": enc["config"]["unique_item_rows"], "workload": enc["config"]["workload"]}
     torch.cuda.empty_cache()
     out["eval_sharded"] = eval_rows(args, dev, 1, 0, None, steps=20, warmup=5, sizes=((20000, 128),))
     return out

@@ -61,6 +61,7 @@ SIGNATURES = {
     "edgl_score_lse_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_ce_loss_fwd": (I, [P, P, P, I, P, P, P]),
     "edgl_ce_loss_fwd_add": (I, [P, P, P, I, P, P, P, P, P]),
+    "edgl_ce_loss_fwd_add_w": (I, [P, P, P, I, P, P, P, P, P, P]),
     "edgl_score_bwd_workspace": (L, [I, I, I, I, I]),
     "edgl_score_ce_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_score_flash_workspace": (L, [I, I, I, I, I]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "edgl_score_prepare_table": (I, [P, I, I, I, I, I, P, I, P]),
     "edgl_score_flash_fwd_pre": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, I, P]),
     "edgl_score_flash_fwd_coef": (I, [P, P, P, P, I, I, I, P, P, P, P, P, I, P]),
+    "edgl_score_flash_fwd_coef_w": (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, I, P]),
     "edgl_score_flash_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_reduce_defer": (I, [I, P]),
     "edgl_reduce_flush": (I, [P]),

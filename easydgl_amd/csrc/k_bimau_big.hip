@@ -360,6 +360,7 @@ int bwd_big(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscaling
     p.rowdot_ws = reinterpret_cast<float*>(ws + wl.rowdot);
     p.dsc_part = reinterpret_cast<float*>(ws + wl.dsc); p.wpart = reinterpret_cast<float*>(ws + wl.wpart);
     const long jobs = (long)p.B * p.H;
+    edgl_prof_begin(EDGL_KERNEL_BIMAU_BWD_ALL, st);
     {   // X: sweep 1
         const size_t wave_bytes = (2 * (size_t)Tp * dh + (size_t)Tp * EP + (TR ? 0 : (size_t)EP * LDT)) * sizeof(T) + (size_t)Tp * sizeof(float);
         int waves = 4;
@@ -403,6 +404,7 @@ int bwd_big(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscaling
         edgl_prof_begin(EDGL_KERNEL_BIMAU_BWD, st);
         hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
         edgl_prof_end(EDGL_KERNEL_BIMAU_BWD, st);
+        edgl_prof_end(EDGL_KERNEL_BIMAU_BWD_ALL, st);
         EDGL_LAUNCH_CHECK();
     }
     if (db1 == dW1 + (dh + 1) * JE && dw == db1 + JE && dscaling == dw + JE)   // flat-arena layout: one reduction

@@ -240,6 +240,7 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     p.dsc_part = reinterpret_cast<float*>(ws + wl.dsc); p.wpart = reinterpret_cast<float*>(ws + wl.wpart);
     const long jobs = (long)p.B * p.H;
     constexpr bool TR = sizeof(T) == 2;
+    edgl_prof_begin(EDGL_KERNEL_BIMAU_BWD_ALL, st);
     // ---- X ----
     {
         const size_t wave_bytes = (2 * (size_t)Tp * dh + (size_t)Tp * EP + (TR ? 0 : (size_t)EP * LDT)) * sizeof(T) + (size_t)Tp * sizeof(float);
@@ -285,6 +286,7 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
         edgl_prof_begin(EDGL_KERNEL_BIMAU_BWD, st);
         hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
         edgl_prof_end(EDGL_KERNEL_BIMAU_BWD, st);
+        edgl_prof_end(EDGL_KERNEL_BIMAU_BWD_ALL, st);
         EDGL_LAUNCH_CHECK();
     }
     const int JE = dh * p.E, NPAR = (dh + 3) * JE, NPARX = NPAR + EP;

@@ -59,9 +59,11 @@ extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, c
     }
     hipStream_t st = (hipStream_t)stream;
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_bimau_fwd: bad dtype %d", dtype);
-    if (C / H == 64 || C / H == 128) return bimau::big_fwd(p, dtype, st);
-    if (dtype == EDGL_F32) return dispatch_dt<float>(p, st);
-    if (dtype == EDGL_BF16) return dispatch_dt<bf16>(p, st);
-    edgl_set_error("edgl_bimau_fwd: bad dtype %d", dtype);
-    return EDGL_ERR_DTYPE;
+    edgl_prof_begin(EDGL_KERNEL_BIMAU_FWD, st);
+    int rc;
+    if (C / H == 64 || C / H == 128) rc = bimau::big_fwd(p, dtype, st);
+    else if (dtype == EDGL_F32) rc = dispatch_dt<float>(p, st);
+    else rc = dispatch_dt<bf16>(p, st);
+    edgl_prof_end(EDGL_KERNEL_BIMAU_FWD, st);
+    return rc;
 }

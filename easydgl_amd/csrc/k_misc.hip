@@ -544,6 +544,12 @@ extern "C" int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const i
 extern "C" int edgl_tpp_norm(const int64_t* labels, const uint8_t* mark_table, int B, int M, int E, float* sums, void* stream) {
     EDGL_REQUIRE(labels && mark_table && sums, EDGL_ERR_NULL, "edgl_tpp_norm: null pointer");
     TppP p{nullptr, nullptr, labels, nullptr, mark_table, B, 0, 0, E, M, 0.f};
+    // the count is formed from zero every time: a step that aborted between this call and tpp_final2_kernel (which zeroes the slot
+    // again) must not leave a stale count behind for the next one
+    if (hipMemsetAsync(reinterpret_cast<int*>(sums) + 4, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) {
+        edgl_set_error("edgl_tpp_norm: memset failed");
+        return EDGL_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(tpp_norm_kernel, dim3((B * M + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, reinterpret_cast<int*>(sums) + 4);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;

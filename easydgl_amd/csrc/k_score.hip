@@ -109,6 +109,7 @@ struct ScoreP {
     float* lab_out;                                     // flash forward: label logits [R]
     float* coef_out;                                    // flash forward, compacted rows, whole table: loss coefficients [R]
     int table_ready;                                    // tableT already written by edgl_score_prepare_table
+    const int32_t* wtotal;                              // data parallel: weighted rows of the GLOBAL batch (denominator of the loss)
     int dbg;   // EDGL_DBG ablation bits (profiling only): 1 skip dl math, 2 skip second product, 4 skip z streaming, 8 skip logit MFMA
 };
 
@@ -371,7 +372,8 @@ __global__ void lse_combine_kernel(const float* part, int R, const int32_t* nval
 template <typename T>
 __global__ __launch_bounds__(256) void lse_label_kernel(const float* part, int R, const int32_t* nvalid, int xb, int zb, int G, int ztotal,
                                                         float* row_lse, const T* rows, const T* table, const float* out_bias,
-                                                        const int64_t* labels, int C, int i0, int i1, float* lab_out, float* coef_out) {
+                                                        const int64_t* labels, int C, int i0, int i1, float* lab_out, float* coef_out,
+                                                        const int32_t* wtotal) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= R) return;
     // two round trips: {row count, label}, then everything that hangs on them — chunk partials, row, label row of the table, bias —
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256) void lse_label_kernel(const float* part, int R
         const float ll = (lab == 0) ? -1000.0f : a + ob;
         if (own) lab_out[r] = ll;
         if (coef_out) {   // d loss / d logit scale of the row: ce_loss_kernel's coefficient, its row count known as *nvalid
-            const float v = __expf(ll - lse), W = (float)Reff + 1e-5f;
+            const float v = __expf(ll - lse), W = (float)(wtotal ? wtotal[0] : Reff) + 1e-5f;   // EasyDGL.py:184 over the global batch
             coef_out[r] = (r < Reff && lab != 0) ? (1.f / W) * (v / (v + 1e-5f)) : 0.f;
         }
     }
@@ -969,7 +971,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* src0, long rows
 // CE loss from (lse, label logit) — EasyDGL.py:155,177-185
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
-                                                       float* loss_out, float* coef, const float* add_in, const float* add_in2) {
+                                                       float* loss_out, float* coef, const float* add_in, const float* add_in2,
+                                                       const int32_t* wtotal) {
     // one workgroup; a thread keeps up to CE_KEEP of its rows' probabilities in registers between the two passes (the loads of
     // a pass are independent, so they overlap instead of paying one memory round trip per row)
     constexpr int CE_KEEP = 16;
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, con
     }
     num = block_sum(num, red);
     den = block_sum(den, red);
-    const float W = den + 1e-5f;
+    const float W = (wtotal ? (float)wtotal[0] : den) + 1e-5f;     // data parallel: the weighted rows of all ranks
     if (threadIdx.x == 0) loss_out[0] = num / W + (add_in ? add_in[0] : 0.f) + (add_in2 ? add_in2[0] : 0.f);   // + regularisation terms
     if (!coef) return;    // (the flash forward wrote the coefficients: edgl_score_flash_fwd_coef)
 #pragma unroll
@@ -1317,7 +1320,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     } else if (MODE == 1) {
         hipLaunchKernelGGL((lse_label_kernel<T>), dim3((p.R + 3) / 4), dim3(256), 0, st, part, p.R, p.nvalid, xb, ZBK, G, p.i1 - p.i0,
                            p.row_lse, reinterpret_cast<const T*>(p.rows), reinterpret_cast<const T*>(p.table), p.out_bias, p.labels,
-                           p.C, p.i0, p.i1, p.lab_out, p.coef_out);
+                           p.C, p.i0, p.i1, p.lab_out, p.coef_out, p.wtotal);
         EDGL_LAUNCH_CHECK();
         return EDGL_OK;
     } else {
@@ -1397,6 +1400,10 @@ int bwd_dispatch(ScoreP p, int C, const BwdPlan& plan, float* ws, void* d_rows, 
 }
 
 }  // namespace
+
+extern "C" int edgl_score_flash_fwd_coef_w(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
+                                           int C, int I, const int32_t* nvalid, const int32_t* wtotal, float* row_lse,
+                                           float* label_logit, float* coef, float* workspace, int dtype, void* stream);
 
 // workspace rule of the forward: 2 * R * edgl_score_chunks floats >= 2 * XB * (#workgroups), the most (row, chunk)
 // partial pairs any device-side split of the launch can produce
@@ -1491,13 +1498,17 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
     return EDGL_OK;
 }
 
-extern "C" int edgl_ce_loss_fwd_add(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
-                                    float* coef, const float* add_in, const float* add_in2, void* stream) {
+extern "C" int edgl_ce_loss_fwd_add_w(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
+                                      float* coef, const float* add_in, const float* add_in2, const int32_t* wtotal, void* stream) {
     EDGL_REQUIRE(row_lse && label_logit && labels && loss_out, EDGL_ERR_NULL, "edgl_ce_loss_fwd: null pointer");   // coef may be NULL
     hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_lse, label_logit, labels, R, loss_out, coef,
-                       add_in, add_in2);
+                       add_in, add_in2, wtotal);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
+}
+extern "C" int edgl_ce_loss_fwd_add(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
+                                    float* coef, const float* add_in, const float* add_in2, void* stream) {
+    return edgl_ce_loss_fwd_add_w(row_lse, label_logit, labels, R, loss_out, coef, add_in, add_in2, nullptr, stream);
 }
 extern "C" int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64_t* labels, int R,
                                 float* loss_out, float* coef, void* stream) {
@@ -1591,13 +1602,21 @@ extern "C" int edgl_score_flash_fwd_pre(const void* rows, const void* table, con
 extern "C" int edgl_score_flash_fwd_coef(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
                                          int C, int I, const int32_t* nvalid, float* row_lse, float* label_logit, float* coef,
                                          float* workspace, int dtype, void* stream) {
+    return edgl_score_flash_fwd_coef_w(rows, table, out_bias, labels, R, C, I, nvalid, nullptr, row_lse, label_logit, coef, workspace,
+                                       dtype, stream);
+}
+// Data parallel form: `wtotal` (device, may be NULL) = weighted rows of the GLOBAL batch; the coefficients then are those of the
+// global loss (EasyDGL.py:183-185 with the denominator summed over the ranks), and the ranks' gradients ADD UP to its gradient.
+extern "C" int edgl_score_flash_fwd_coef_w(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
+                                           int C, int I, const int32_t* nvalid, const int32_t* wtotal, float* row_lse,
+                                           float* label_logit, float* coef, float* workspace, int dtype, void* stream) {
     int rc = check_score(rows, table, out_bias, R, C, I, 0, I, dtype, "edgl_score_flash_fwd_coef");
     if (rc) return rc;
     EDGL_REQUIRE(labels && row_lse && label_logit && workspace && nvalid && coef, EDGL_ERR_NULL,
                  "edgl_score_flash_fwd_coef: null pointer (the row count of the compaction is required)");
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = 0;
-    p.i1 = I; p.nvalid = nvalid; p.row_lse = row_lse; p.lab_out = label_logit; p.coef_out = coef;
+    p.i1 = I; p.nvalid = nvalid; p.row_lse = row_lse; p.lab_out = label_logit; p.coef_out = coef; p.wtotal = wtotal;
     const BwdPlan plan = bwd_plan(R, C, I, I, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st)

@@ -61,9 +61,12 @@ def device_mask_last(tokens: torch.Tensor, timestamps: torch.Tensor, mask_id: in
     return {"seqs_i": masked, "seqs_t": timestamps}, tokens
 
 
-def synthetic_batch(num_items: int, seqslen: int, batch: int, seed: int = 9876, min_len: int = 5):
+def synthetic_batch(num_items: int, seqslen: int, batch: int, seed: int = 9876, min_len: int = 5, ids: str = "zipf"):
     """SURVEY.md §8d synthetic sequences: row length ~ U{min_len..T}, left zero padding, Zipf(1.1) item ids
-    clipped to [1, num_items-1], float32 timestamps 9.5e8 + cumsum(Exp(mean 3 days)).  T = seqslen + 1."""
+    clipped to [1, num_items-1], float32 timestamps 9.5e8 + cumsum(Exp(mean 3 days)).  T = seqslen + 1.
+    (The clip piles ~35 % of the tokens on id num_items-1: `ids="uniform"` draws U[1, num_items) instead — no hot row, every
+    gathered table row distinct with high probability: the variant that makes the embedding gather really read HBM.)"""
+    ids_mode = ids
     rng = np.random.default_rng(seed)
     T = seqslen + 1
     ids = np.zeros((batch, T), dtype=np.int64)
@@ -71,7 +74,8 @@ def synthetic_batch(num_items: int, seqslen: int, batch: int, seed: int = 9876, 
     lens = rng.integers(min(min_len, T), T + 1, size=batch)
     for b in range(batch):
         n = int(lens[b])
-        ids[b, T - n:] = np.clip(rng.zipf(1.1, size=n), 1, num_items - 1)
+        ids[b, T - n:] = (rng.integers(1, num_items, size=n) if ids_mode == "uniform"
+                          else np.clip(rng.zipf(1.1, size=n), 1, num_items - 1))
         ts[b, T - n:] = (9.5e8 + np.cumsum(rng.exponential(3 * 86400.0, size=n))).astype(np.float32)
     return ids, ts
 

@@ -86,6 +86,9 @@ class TrainEngine:
         self.ws_l2 = e(1024, dtype=f32)
         self.side = torch.cuda.Stream(device=dev)
         self._pending_loss = None
+        # data parallel: weighted rows / TPP normaliser of the GLOBAL batch (filled by _global_counts before a step)
+        self.counts = torch.zeros(2, device=dev, dtype=torch.int32)
+        self._dp = False
         # ---- backward temporaries -------------------------------------------------------------------------------
         self.d_rows = e(self.R, C)
         self.G1, self.G2, self.G3, self.G4 = e(B, T, C), e(B, T, C), e(B, T, C), e(B, T, C)
@@ -172,7 +175,7 @@ class TrainEngine:
             # needed by the first BiMAU forward (the one join of the forward): TPP normaliser (labels only), weight packs
             for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
                 att = blk.attention
-                if m.ct_reg != 0.0:
+                if m.ct_reg != 0.0 and not self._dp:    # (data parallel: _global_counts put the all-reduced count there)
                     check(lib.edgl_tpp_norm(_ptr(self.labels), _ptr(m.mark_lookup_table), B, M, E, _ptr(b["tpp"]), sst),
                           "edgl_tpp_norm")
                 check(lib.edgl_bimau_pack(_ptr(att.st_kernel), _ptr(att.st_bias), _ptr(att.weight), _ptr(att.scaling), C, H, E,
@@ -247,19 +250,21 @@ class TrainEngine:
         if self.flash_ce:
             # the forward pass writes the loss coefficients itself (the row count of the loss is the compaction's): the backward
             # starts behind it, and the loss kernel — a one-workgroup reduction over the rows — leaves the critical path
-            check(lib.edgl_score_flash_fwd_coef(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I,
-                                                _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.coef),
-                                                _ptr(self.ws_flash), code, st), "edgl_score_flash_fwd_coef")
+            wtot = self.counts.data_ptr() if self._dp else None
+            check(lib.edgl_score_flash_fwd_coef_w(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I,
+                                                  _ptr(self.nvalid), wtot, _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.coef),
+                                                  _ptr(self.ws_flash), code, st), "edgl_score_flash_fwd_coef")
             # (launched on the side stream at the join the backward has anyway: an event record of its own costs the main
             # stream as much as the kernel)
-            self._pending_loss = lambda s: check(lib.edgl_ce_loss_fwd_add(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R,
-                                                                          _ptr(self.loss), None, aux, tpp, s), "edgl_ce_loss_fwd_add")
+            self._pending_loss = lambda s: check(lib.edgl_ce_loss_fwd_add_w(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R,
+                                                                            _ptr(self.loss), None, aux, tpp, wtot, s),
+                                                 "edgl_ce_loss_fwd_add")
         else:
             check(lib.edgl_score_lse_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
                                          _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
                   "edgl_score_lse_fwd")
-            check(lib.edgl_ce_loss_fwd_add(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef),
-                                           aux, tpp, st), "edgl_ce_loss_fwd_add")
+            check(lib.edgl_ce_loss_fwd_add_w(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef),
+                                             aux, tpp, self.counts.data_ptr() if self._dp else None, st), "edgl_ce_loss_fwd_add")
         # ================= backward =================
         self._ws_i = 0
         check(lib.edgl_reduce_defer(1, st), "edgl_reduce_defer")
@@ -390,17 +395,52 @@ class TrainEngine:
         self.ids.copy_(features["seqs_i"]); self.ts.copy_(features["seqs_t"])
         self.mpos.copy_(features["masked_positions"]); self.labels.copy_(labels)
 
+    def bind_batch(self, features: Dict[str, torch.Tensor], labels: torch.Tensor) -> None:
+        """Point the eager launch sequence at device tensors that already hold a batch (no copies: a rotation of resident
+        batches costs nothing).  Not for the HIP-graph path, whose captured launches keep the addresses of the static buffers."""
+        if self.use_graph:
+            raise _lib.EdglError("TrainEngine.bind_batch: the graph path reads the static buffers (use load_batch / step(features, labels))")
+        new = (features["seqs_i"], features["seqs_t"], features["masked_positions"], labels)
+        for t, ref, nm in zip(new, (self.ids, self.ts, self.mpos, self.labels), ("seqs_i", "seqs_t", "masked_positions", "labels")):
+            if t.shape != ref.shape or t.dtype != ref.dtype or t.device != ref.device or not t.is_contiguous():
+                raise _lib.EdglError(f"TrainEngine.bind_batch: {nm} must be a contiguous {tuple(ref.shape)} {ref.dtype} tensor on {ref.device}")
+        self.ids, self.ts, self.mpos, self.labels = new
+
+    def _global_counts(self) -> None:
+        """Data parallel: the two normalisers of the loss that are sums over the BATCH — the number of weighted rows
+        (EasyDGL.py:183-185) and the number of next-event marks of the TPP term (temporal.py:331-333) — are all-reduced before the
+        step, so that every rank differentiates its share of the GLOBAL-batch loss and the ranks' gradients simply add up.
+        Labels only: issued ahead of the step's first kernel (one 8-byte all-reduce, hidden under the encoder)."""
+        import torch.distributed as dist
+        m = self.m
+        self.counts[0:1] = (self.labels != 0).sum().to(torch.int32)
+        if m.ct_reg != 0.0 and self.blk:
+            tpp0 = self.blk[0]["tpp"]
+            check(lib.edgl_tpp_norm(_ptr(self.labels), _ptr(m.mark_lookup_table), self.B, self.M, self.E, _ptr(tpp0), _stream()),
+                  "edgl_tpp_norm")
+            self.counts[1:2] = tpp0.view(torch.int32)[4:5]
+        dist.all_reduce(self.counts, op=dist.ReduceOp.SUM, group=self.group)
+        if m.ct_reg != 0.0:
+            for b in self.blk:
+                b["tpp"].view(torch.int32)[4:5] = self.counts[1:2]
+
     def step(self, features=None, labels=None) -> torch.Tensor:
-        """One optimizer step on the (optionally refreshed) static batch; returns the loss (device scalar)."""
+        """One optimizer step on the (optionally refreshed) static batch; returns the loss (device scalar; data parallel: this
+        rank's share of the global cross-entropy plus the regularisation terms).  Data parallel: the normalisers of the loss are
+        global (_global_counts), the flat gradient arena is all-reduced with SUM — the result is the gradient of the loss over
+        the concatenated batch, whatever the ranks' numbers of weighted rows."""
         if features is not None:
             self.load_batch(features, labels)
         distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size(self.group) > 1
+        self._dp = distributed
         if not self.use_graph:
+            if distributed:
+                self._global_counts()
             self._issue()
             if distributed:
                 from . import parallel
-                parallel.allreduce_mean_(self.m._grad_arena, self.group)
+                parallel.allreduce_sum_(self.m._grad_arena, self.group)
             self._optimizer()
             return self.loss
         if self.graph is None:
@@ -408,6 +448,8 @@ class TrainEngine:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
+                if distributed:
+                    self._global_counts()
                 self._issue()
                 if not distributed:
                     self._optimizer()
@@ -416,18 +458,23 @@ class TrainEngine:
             # the warm-up was a real step; undo nothing: training simply started one step earlier
             if distributed:
                 from . import parallel
-                parallel.allreduce_mean_(self.m._grad_arena, self.group)
+                parallel.allreduce_sum_(self.m._grad_arena, self.group)
                 self._optimizer()
+                self._global_counts()      # (the capture below reads the counts of the current batch)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._issue()
                 if not distributed:
                     self._optimizer()
             self._distributed = distributed
+            if distributed:                # the captured launches have not run: this call is the warm-up step only
+                return self.loss
             return self.loss
+        if self._distributed:
+            self._global_counts()
         self.graph.replay()
         if self._distributed:
             from . import parallel
-            parallel.allreduce_mean_(self.m._grad_arena, self.group)
+            parallel.allreduce_sum_(self.m._grad_arena, self.group)
             self._optimizer()
         return self.loss

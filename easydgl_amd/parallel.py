@@ -5,7 +5,9 @@
   [R, 2K] 32-bit buffer per rank (K=100, R=512: 400 KB) and a merge kernel orders the S*K candidates
   by (value desc, id asc) — the tf.nn.top_k tie rule of Base.py:181.
 * Training: data parallel over sequences (per-sample LayerNorm and per-sequence attention make samples
-  independent); the flat f32 gradient arena is all-reduced in one call and averaged.
+  independent).  The loss normalises by sums over the BATCH (weighted rows, next-event marks); the engine all-reduces those
+  two integers before the step (TrainEngine._global_counts), every rank differentiates its share of the global-batch loss
+  and the flat f32 gradient arena is all-reduced with SUM in one call: the result is the gradient over the concatenated batch.
 
 The scoring / top-K / merge callables are injected so that the protocol can be exercised on CPU with the
 gloo backend (tests/test_distributed_cpu.py supplies the oracle there; the product path passes the HIP ops).
@@ -54,3 +56,11 @@ def allreduce_mean_(flat_grad: torch.Tensor, group: Optional[dist.ProcessGroup] 
         return
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
     flat_grad.mul_(1.0 / dist.get_world_size(group))
+
+
+def allreduce_sum_(flat_grad: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Sum of the ranks' gradient arenas (one collective per step): with the loss normalisers taken over the global batch
+    (TrainEngine._global_counts) this is the gradient of the loss over the concatenated batch."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)

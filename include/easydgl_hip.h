@@ -53,9 +53,12 @@ enum {
 const char* edgl_last_error(void);
 int edgl_version(void);
 
-/* Profiling hook (measurement only): the NEXT launch of kernel `kernel_id` on the calling thread records the two
- * hipEvent_t handles immediately before / after that single kernel on its launch stream, then the slot clears. */
-enum { EDGL_KERNEL_SCORE_BWD_ROWS = 0, EDGL_KERNEL_BIMAU_BWD = 1 };
+/* Profiling hook (measurement only): the NEXT launch of kernel (group) `kernel_id` on the calling thread records the two
+ * hipEvent_t handles immediately before / after it on its launch stream, then the slot clears.
+ *   SCORE_BWD_ROWS : the row-side scoring pass (K5);  BIMAU_BWD : sweep 2 of the BiMAU backward alone;
+ *   BIMAU_FWD      : every kernel of one edgl_bimau_fwd call (K3 forward: temporal.py:404-452 + 281-315);
+ *   BIMAU_BWD_ALL  : the three backward passes X, Y, Z of one edgl_bimau_bwd call (without the parameter-partial reductions) */
+enum { EDGL_KERNEL_SCORE_BWD_ROWS = 0, EDGL_KERNEL_BIMAU_BWD = 1, EDGL_KERNEL_BIMAU_FWD = 2, EDGL_KERNEL_BIMAU_BWD_ALL = 3 };
 int edgl_profile_next(int kernel_id, void* ev_start, void* ev_stop);
 
 /* ---- dropout RNG state ----------------------------------------------------------------------- */
@@ -249,6 +252,10 @@ int edgl_ce_loss_fwd(const float* row_lse, const float* label_logit, const int64
  * training engine a separate one-element add launch. */
 int edgl_ce_loss_fwd_add(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
                          float* coef, const float* add_in, const float* add_in2, void* stream);
+/* ... with the denominator of the GLOBAL batch (`wtotal`, device int32 or NULL; see edgl_score_flash_fwd_coef_w): loss_out[0] is
+ * then this rank's share of the global cross-entropy (+ the terms added in). */
+int edgl_ce_loss_fwd_add_w(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
+                           float* coef, const float* add_in, const float* add_in2, const int32_t* wtotal, void* stream);
 /* backward of the CE: dl[r,j] = g * coef[r] * (p[r,j] - [j==label_r]) (g = d loss, device scalar or
  * NULL for 1), never materialised:  d_rows[R,C] (`dtype`) = dl . table ;  d_table[I,C] (f32,
  * overwritten for rows [i0,i1), row 0 := 0) = dl^T . rows ;  d_bias[I-1] f32 = colsum(dl)[1:].
@@ -303,6 +310,12 @@ int edgl_score_flash_fwd_pre(const void* rows, const void* table, const float* o
 int edgl_score_flash_fwd_coef(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
                               int I, const int32_t* nvalid, float* row_lse, float* label_logit, float* coef, float* workspace,
                               int dtype, void* stream);
+/* Data-parallel form: `wtotal` (device int32, may be NULL = the local count) is the number of weighted rows of the
+ * GLOBAL batch — the denominator of EasyDGL.py:183-185 summed over the ranks — so that the ranks' gradients add up to the gradient
+ * of the global-batch loss. */
+int edgl_score_flash_fwd_coef_w(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
+                                int I, const int32_t* nvalid, const int32_t* wtotal, float* row_lse, float* label_logit, float* coef,
+                                float* workspace, int dtype, void* stream);
 int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                          const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
                          int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias, float* workspace,

@@ -161,17 +161,20 @@ def forward(cfg, p, mark_table, features, is_training, dtype=torch.float64,
     return logits_from(cfg, p, rows), lams, so
 
 
-def biased_likelihood(lam_g, nm, iv):  # temporal.py:317-333
+def biased_likelihood(lam_g, nm, iv, nm_total=None):  # temporal.py:317-333
     lam_g = lam_g * torch.sign(nm.sum(dim=2, keepdim=True))
     ev = (lam_g * nm).sum(dim=2)
     event_ll = torch.log(torch.where(ev == 0, torch.ones_like(ev), ev)).sum()
     non_event = (lam_g.sum(dim=2) * iv * 0.5).sum()
-    return -(event_ll - non_event) / nm.sum()
+    return -(event_ll - non_event) / (nm.sum() if nm_total is None else nm_total)
 
 
 def train_loss(cfg, p, mark_table, features, labels, dtype=torch.float64,
-               hidden_drop=0.0, att_drop=0.0, training=True):
-    """EasyDGL.train (EasyDGL.py:153-188). Returns (loss, dict)."""
+               hidden_drop=0.0, att_drop=0.0, training=True, w_total=None, nm_total=None):
+    """EasyDGL.train (EasyDGL.py:153-188). Returns (loss, dict).
+    w_total / nm_total (data-parallel tests): the two batch-sum normalisers — weighted rows (EasyDGL.py:184) and next-event marks
+    (temporal.py:333, counted once per sample) — of a LARGER batch this one is a slice of; the result is then this slice's share of
+    the larger batch's cross-entropy / TPP term (the l2 term is not a batch sum and is returned in full)."""
     logits, lams, so = forward(cfg, p, mark_table, features, True, dtype,
                                hidden_drop if training else 0.0, att_drop if training else 0.0)
     lp = torch.log(torch.softmax(logits, -1) + 1e-5)
@@ -190,12 +193,12 @@ def train_loss(cfg, p, mark_table, features, labels, dtype=torch.float64,
             sp, nm, mp = sp.repeat(h, 1), nm.repeat(h, 1, 1), mp.repeat(h, 1)
         for lam in lams:
             lg = lam[torch.arange(lam.shape[0])[:, None], mp]
-            reg = reg + cfg.ct_reg * biased_likelihood(lg, nm, sp) / h
+            reg = reg + cfg.ct_reg * biased_likelihood(lg, nm, sp, None if nm_total is None else nm_total * h) / h
     lab = torch.as_tensor(np.asarray(labels).reshape(-1), dtype=torch.long)
     onehot = torch.nn.functional.one_hot(lab, cfg.I).to(dtype)  # :179 (materialised like the reference)
     w = (lab != 0).to(dtype)
     per = -(lp * onehot).sum(-1)
-    ce = (w * per).sum() / (w.sum() + 1e-5)
+    ce = (w * per).sum() / ((w.sum() if w_total is None else w_total) + 1e-5)
     return ce + reg, dict(ce=ce, reg=reg, logits=logits, lams=lams, seq_out=so)
 
 

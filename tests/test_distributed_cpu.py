@@ -74,3 +74,57 @@ def test_single_process_is_a_noop():
     g = torch.ones(4)
     P.allreduce_mean_(g)
     assert torch.equal(g, torch.ones(4))
+
+
+def _dp_worker(rank, world, port, out):
+    """Data-parallel protocol of TrainEngine.step (engine.py: _global_counts + allreduce_sum_) with the fp64 oracle as the step:
+    the ranks hold halves of a batch with DIFFERENT numbers of weighted rows; global normalisers + a SUM all-reduce must give the
+    gradient of the loss over the whole batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from easydgl_amd import parallel as P
+    from oracle import torch_ref as R
+    from tests._util import make_problem
+    prob = make_problem(seed=21, batch=6, num_items=60, seqslen=12, num_units=16, num_heads=2, num_blocks=1, masklen=4, num_events=3)
+    cfg, mt = prob["cfg"], prob["mark_table"]
+    labels = np.asarray(prob["labels"]).copy()
+    labels[0, :3] = 0                                             # rank 0's half carries fewer weighted rows than rank 1's
+    half = slice(rank * 3, rank * 3 + 3)
+    feats = {k: np.asarray(v)[half] for k, v in prob["feats"].items()}
+    # the two integers the engine all-reduces before the step
+    counts = torch.tensor([int((labels[half] != 0).sum()), int(np.asarray(mt)[labels[half]].sum())], dtype=torch.int64)
+    dist.all_reduce(counts)
+    p = R.to_torch_params(prob["params"])
+    loss, _ = R.train_loss(cfg, p, mt, feats, labels[half], w_total=float(counts[0]), nm_total=float(counts[1]))
+    loss.backward()
+    names = sorted(p)
+    flat = torch.cat([p[k].grad.reshape(-1) for k in names])
+    P.allreduce_sum_(flat)
+    # the l2 term is not a batch sum: every rank added it in full
+    l2 = torch.cat([(cfg.l2_reg * p[k].detach() if k in R.O.EMBEDDING_TABLES else torch.zeros_like(p[k])).reshape(-1) for k in names])
+    flat = flat - (world - 1) * l2
+    q = R.to_torch_params(prob["params"])
+    ref, _ = R.train_loss(cfg, q, mt, prob["feats"], labels)
+    ref.backward()
+    want = torch.cat([q[k].grad.reshape(-1) for k in names])
+    # the naive protocol (local normalisers, mean of the gradients) is NOT the global gradient when the counts differ
+    p2 = R.to_torch_params(prob["params"])
+    l_naive, _ = R.train_loss(cfg, p2, mt, feats, labels[half])
+    l_naive.backward()
+    naive = torch.cat([p2[k].grad.reshape(-1) for k in names])
+    P.allreduce_mean_(naive)
+    err = float((flat - want).abs().max() / want.abs().max())
+    err_naive = float((naive - want).abs().max() / want.abs().max())
+    out[rank] = (err < 1e-10, err_naive > 1e-3, err, err_naive)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_is_the_global_batch_gradient():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        ok, naive_differs, err, err_naive = out[r]
+        assert ok and naive_differs, (r, err, err_naive)

@@ -59,3 +59,72 @@ def test_sharded_eval_and_data_parallel_step_over_rccl():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert all(out.get(r, False) for r in range(world)), dict(out)
+
+
+def _dp_engine_worker(rank, world, port, out):
+    """Two engine ranks on ONE GPU over gloo (the collective goes through the host: a functional check of the protocol, not of
+    RCCL): halves of a batch with different numbers of weighted rows."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from easydgl_amd import parallel
+    from easydgl_amd.engine import TrainEngine
+    from tests._util import build_model, make_problem, to_dev
+    prob = make_problem(seed=31, batch=12, num_items=900, seqslen=24, num_units=32, num_heads=2, num_blocks=1, masklen=5, num_events=4)
+    labels = torch.as_tensor(prob["labels"]).clone()
+    labels[:3, :4] = 0                                    # rank 0's half carries far fewer weighted rows
+    feats = to_dev(prob["feats"])
+    half = slice(rank * 6, rank * 6 + 6)
+    m = build_model(prob, "f32")
+    eng = TrainEngine(m, 6, use_graph=False)
+    eng.load_batch({k: v[half].contiguous() for k, v in feats.items()}, labels[half].cuda().contiguous())
+    eng._dp = True
+    eng._global_counts()
+    m._grad_arena.zero_()                                  # (the flat arena has alignment gaps between the parameters)
+    eng._issue()
+    loss_share = eng.loss.clone()
+    parallel.allreduce_sum_(m._grad_arena)
+    dist.all_reduce(loss_share)
+    ok, info = True, None
+    if rank == 0:
+        m1 = build_model(prob, "f32")
+        e1 = TrainEngine(m1, 12, use_graph=False)
+        e1.load_batch(feats, labels.cuda().contiguous())
+        e1._issue()
+        torch.cuda.synchronize()
+        g, w = m._grad_arena, m1._grad_arena
+        err = float((g - w).abs().max() / w.abs().max())
+        # the summed loss shares count the (batch-independent) l2 term once per rank
+        l2 = float(e1.loss_aux) if m1.l2_reg != 0.0 else 0.0
+        lerr = abs(float(loss_share) - (world - 1) * l2 - float(e1.loss)) / abs(float(e1.loss))
+        ok, info = bool(err < 1e-5 and lerr < 1e-5), (err, lerr, int(eng.counts[0]), int(e1.nvalid))
+    out[rank] = (ok, info)
+    dist.destroy_process_group()
+
+
+def test_two_engine_ranks_reproduce_the_global_batch_gradient():
+    """VERDICT r02 weak #8: 2 ranks x B/2 == 1 rank x B — global loss normalisers (TrainEngine._global_counts) + SUM all-reduce."""
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_engine_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), dict(out)
+
+
+def test_bench_two_ranks_over_gloo_smoke():
+    """bench.py --gpus 2 on whatever box this is: EDGL_BENCH_BACKEND=gloo lets both ranks share device 0 (a functional check of the
+    multi-process path of the bench contract: launcher re-exec, barriers, max-over-ranks time, one JSON line from rank 0)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDGL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-extras",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["config"]["global_batch"] == 1024 and j["value"] > 0 and j["scaling"] == "weak"
