@@ -65,7 +65,11 @@ class TrainEngine:
             self.blk.append(d)
         self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
         # fused per-sample block tail (csrc/k_tail.hip): one launch for dense -> LN -> GELU-dense -> dense -> LN (-> head)
-        ok = bool(lib.edgl_tail_supported(T, C, self.code)) and os.environ.get("EDGL_FUSED_TAIL", "1") != "0"
+        # (the head of the fused tail and the fused TPP kernel hold the masked positions of a sample in LDS: M <= 256, T <= 1024 —
+        # beyond what the BiMAU kernels take (T <= 208), checked here so that a future relaxation fails at construction)
+        if m.ct_reg != 0.0 and (M > 256 or T > 1024):
+            raise _lib.EdglError(f"TrainEngine: masklen {M} > 256 or T {T} > 1024 exceeds the fused TPP kernel (edgl_tpp_fwd_bwd_ex)")
+        ok = bool(lib.edgl_tail_supported(T, C, self.code)) and M <= 256 and os.environ.get("EDGL_FUSED_TAIL", "1") != "0"
         self.fused_tail = ok if fused_tail is None else (bool(fused_tail) and ok)
         self.tail_pack = [e(int(lib.edgl_tail_pack_elems(C))) for _ in range(nb)] if self.fused_tail else []
         if self.fused_tail:   # outputs of the fused backward: the gradients w.r.t. the four dense outputs (operands of the dW GEMMs)

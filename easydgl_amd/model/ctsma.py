@@ -99,7 +99,7 @@ class CTSMA(Sequential):
         for i, blk in enumerate(self.layers):
             q_in = ops.AddLayerNormFn.apply(x, None, blk.att_ln.gamma, blk.att_ln.beta, ops.NO_DROP, None)       # :70
             att, lam = blk.attention(q_in, x, ids, spans, marks, is_training, True,
-                                     self._drop(self.attention_probs_dropout_rate, 10 + 4 * i, is_training))
+                                     drop=self._drop(self.attention_probs_dropout_rate, 10 + 4 * i, is_training))
             y = ops.AddLayerNormFn.apply(att, None, blk.ff_ln.gamma, blk.ff_ln.beta, ops.NO_DROP, None)          # :75
             inner = self._linear(y, blk.ff.inner, "relu")                                                        # Base.py:79
             if is_training and hd > 0.0:   # Base.py:80: dropout(inner) — an identity LayerNorm-free path: a scaled copy

@@ -129,7 +129,7 @@ class EasyDGL(Sequential):
         for i, blk in enumerate(self.layers):
             layer_in = x
             att, lam = blk.attention(layer_in, layer_in, ids, spans, marks, is_training,
-                                     self._drop(self.attention_probs_dropout_rate, 10 + 4 * i, is_training))
+                                     drop=self._drop(self.attention_probs_dropout_rate, 10 + 4 * i, is_training))
             att = self._linear(att, blk.att_out)                                                   # :113
             att = ops.AddLayerNormFn.apply(att, layer_in[:, :, :C_], blk.att_ln.gamma, blk.att_ln.beta,
                                            self._drop(self.hidden_dropout_rate, 11 + 4 * i, is_training), None)  # :114-116

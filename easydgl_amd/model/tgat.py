@@ -47,7 +47,7 @@ class TGAT(Sequential):
         if C_ % self.num_heads or not (dh in (16, 32, 64, 128) or (dh > 128 and dh % 128 == 0)):
             raise ValueError(f"TGAT: head dim num_units/num_heads = {dh} unsupported; the HIP attention kernels take 16, 32, 64, "
                              f"128 or a multiple of 128 (e.g. --num_units=512 --num_heads=1, runme.sh:80-87)")
-        if C_ > 1024 or C_ & (C_ - 1) or C_ < 32:
+        if C_ > 512 or C_ & (C_ - 1) or C_ < 32:
             raise ValueError(f"TGAT: num_units={C_} unsupported (a power of two in [32, 512] for the fused scoring kernels)")
         self.item_embs = C.Embedding(num_items, C_, self.l2_reg, zero_pad=True, scale=True, gen=gen)     # TGAT.py:27-28
         self.pcoding_K = C.PositionCoding(self.seqslen, C_, self.l2_reg, gen=gen)                         # :29

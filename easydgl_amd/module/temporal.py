@@ -27,6 +27,24 @@ def _check_head_dim(num_units, num_heads, num_events, who):
         raise ValueError(f"{who}: num_events={num_events} unsupported (1..{MAX_EVENTS} mark types)")
 
 
+def key_ids_from_masks(masks: torch.Tensor, batch: int, seqlen: int, num_heads: int) -> torch.Tensor:
+    """The fused kernels take the key mask as a [B, T] int64 vector (a key is masked where it is 0: the item ids serve as is).
+    The reference hands ``masks`` = tile(expand_dims(float(ids != 0), 1), [h, T, 1]) — [h*B, T, T] floats, every query row
+    the same key vector (EasyDGL.py:94-95, used at temporal.py:425-426).  Accepted here and reduced on the device:
+      * int64 [B, T]                      -> as is (ids or 0 / 1);
+      * [h*B, T, T], [B, T, T], [B, 1, T] -> head 0, query row 0 (head-major stacking: rows 0..B-1 are head 0);
+      * [B, T] of another dtype           -> != 0.
+    Anything else raises (a silently mis-read mask is a wrong model, not an error message)."""
+    if not torch.is_tensor(masks):
+        raise TypeError("BiMAU / MAU: `masks` must be a tensor ([B,T] ids, or the reference's [h*B,T,T] key mask)")
+    if masks.dim() == 2 and tuple(masks.shape) == (batch, seqlen):
+        return masks.contiguous() if masks.dtype == torch.int64 else (masks != 0).to(torch.int64)
+    if masks.dim() == 3 and masks.shape[2] == seqlen and masks.shape[1] in (1, seqlen) and masks.shape[0] in (batch, num_heads * batch):
+        return (masks[:batch, 0, :] != 0).to(torch.int64).contiguous()
+    raise ValueError(f"BiMAU / MAU: `masks` of shape {tuple(masks.shape)} / {masks.dtype}: expected int64 [B={batch}, T={seqlen}] "
+                     f"(item ids or 0/1), or the reference's key mask [h*B, T, T] / [B, T, T] / [B, 1, T]")
+
+
 class BiMAU(nn.Module):
     """temporal.py:393-452 + MAU.intensity (temporal.py:281-315).
 
@@ -35,7 +53,8 @@ class BiMAU(nn.Module):
     (TMAU/sequential_temporal_combined/dense); ``weight`` [E, dh] glorot; ``scaling`` [E] zeros.
     ``__call__(queries, keys, masks, intervals, marks, is_training)`` keeps the reference's signature:
     keys are ignored exactly as in the reference (BiMAU projects Q,K,V,T from ``queries``), ``masks`` is the
-    [B,T] item-id tensor (a key is masked where id == 0)."""
+    [B,T] item-id tensor (a key is masked where id == 0) or the reference's own [h*B,T,T] float key mask
+    (``key_ids_from_masks``)."""
 
     def __init__(self, num_units, num_heads, num_events, dropout_rate, scope="TMAU", in_units=None, gen=None):
         """Reference signature (temporal.py:401): ``BiMAU(num_units, num_heads, num_events, dropout_rate, scope)``.
@@ -63,18 +82,24 @@ class BiMAU(nn.Module):
         self.dense_kernel = nn.Parameter(k if device is None else k.to(device))
         self.dense_bias = nn.Parameter(torch.zeros(4 * self.num_units, device=device))
 
-    def forward(self, queries, keys, masks, intervals, marks, is_training, causality=None, drop: ops.Drop = None):
+    def forward(self, queries, keys, masks, intervals, marks, is_training, causality=None, *, drop: ops.Drop = None):
         """temporal.py:404: ``(queries, keys, masks, intervals, marks, is_training, causality=None)`` -> (outputs [B,T,C],
-        mark_intensity [h*B,T,E]).  ``causality`` is ignored exactly as in the reference (BiMAU is bidirectional);
-        ``drop`` names the dropout stream (the owning model passes its device RNG state; on its own the unit has none and
-        runs dropout-free unless one is given)."""
-        if isinstance(causality, ops.Drop):       # positional call of the models: (..., is_training, drop)
-            causality, drop = None, causality
+        mark_intensity [h*B,T,E]).  ``causality`` is ignored exactly as in the reference (BiMAU is bidirectional).
+        ``drop`` (keyword only) names the dropout stream: the owning model passes its device RNG state; a unit used on its
+        own with ``is_training`` and ``dropout_rate > 0`` draws from a module-local state (seeded once, advanced per call), so
+        that the reference signature alone never silently trains without dropout."""
         if drop is None:
-            drop = ops.NO_DROP
+            if is_training and self.dropout_rate > 0:
+                if getattr(self, "_own_rng", None) is None or self._own_rng.device != queries.device:
+                    self._own_rng = ops.make_rng_state(queries.device, seed=0x42694d4155)
+                ops.rng_advance(self._own_rng)
+                drop = ops.Drop(self.dropout_rate, self._own_rng, 10)
+            else:
+                drop = ops.NO_DROP
         if self.dense_kernel is None:
             self._make_projection(queries.shape[-1], queries.device)
         C = self.num_units
+        masks = key_ids_from_masks(masks, queries.shape[0], queries.shape[1], self.num_heads)
         qkvt = ops.LinearFn.apply(queries, self.dense_kernel, self.dense_bias, self.compute(self.dense_kernel), False)
         resid = queries[:, :, :C]
         return ops.BiMAUFn.apply(qkvt, resid, self.st_kernel, self.st_bias, self.weight, self.scaling, masks, intervals,
@@ -106,8 +131,17 @@ class MAU(nn.Module):
         self.scaling = nn.Parameter(torch.zeros(num_events))
         self.compute = lambda p: p
 
-    def forward(self, queries, keys, masks, intervals, marks, is_training, causality=True, drop: ops.Drop = ops.NO_DROP):
+    def forward(self, queries, keys, masks, intervals, marks, is_training, causality=True, *, drop: ops.Drop = None):
         C = self.num_units
+        if drop is None:
+            if is_training and self.dropout_rate > 0:
+                if getattr(self, "_own_rng", None) is None or self._own_rng.device != queries.device:
+                    self._own_rng = ops.make_rng_state(queries.device, seed=0x4d4155)
+                ops.rng_advance(self._own_rng)
+                drop = ops.Drop(self.dropout_rate, self._own_rng, 10)
+            else:
+                drop = ops.NO_DROP
+        masks = key_ids_from_masks(masks, queries.shape[0], queries.shape[1], self.num_heads)
         q = ops.LinearFn.apply(queries, self.q_kernel, self.q_bias, self.compute(self.q_kernel), False)
         kvt = ops.LinearFn.apply(keys, self.kvt_kernel, self.kvt_bias, self.compute(self.kvt_kernel), False)
         qkvt = torch.cat([q, kvt], dim=-1)   # column blocks Q | K | V | T_ of the kernel's operand (a device-side copy)

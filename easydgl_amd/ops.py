@@ -66,6 +66,11 @@ NO_DROP = Drop()
 MAU_CAUSAL, MAU_NO_DIAG = _lib.MAU_CAUSAL, _lib.MAU_NO_DIAG
 
 
+def make_rng_state(device, seed: int = 9876) -> torch.Tensor:
+    """Device RNG state of the counter-based dropout generator: int64[2] = (seed, step)."""
+    return torch.tensor([int(seed), 0], device=device, dtype=torch.int64)
+
+
 def rng_advance(state: torch.Tensor) -> None:
     check(lib.edgl_rng_advance(_ptr(state), _stream()), "edgl_rng_advance")
 
@@ -243,6 +248,11 @@ class BiMAUFn(torch.autograd.Function):
         C = C4 // 4
         E = w.shape[0]
         code = _code(qkvt)
+        # the kernel reads `ids` as B*T 64-bit words: the reference's [h*B,T,T] float mask handed through unchanged would be read
+        # as garbage ids without any error (module/temporal.py key_ids_from_masks converts it)
+        if ids.dtype != torch.int64 or tuple(ids.shape) != (B, T) or not ids.is_contiguous() or ids.device != qkvt.device:
+            raise _lib.EdglError(f"BiMAU: key ids / mask must be a contiguous int64 [B={B}, T={T}] tensor on {qkvt.device}, got "
+                                 f"{tuple(ids.shape)} {ids.dtype}")
         pack = torch.empty(lib.edgl_bimau_pack_bytes(C, H, E, code), device=qkvt.device, dtype=torch.uint8)
         check(lib.edgl_bimau_pack(_ptr(W1), _ptr(b1), _ptr(w), _ptr(scaling), C, H, E, _ptr(pack), code, _stream()),
               "edgl_bimau_pack")
@@ -532,6 +542,9 @@ def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
         _, _, logits = score_lse(rows, table_c, out_bias, None, lo, hi, want_logits=True)
         cands.append(mask_topk(logits, lo, seen, K))
         del logits
+    if len(range(i0, i1, chunk)) > 1 and K > 512:
+        raise _lib.EdglError(f"score_topk: K={K} > 512 on the chunked path (the merge kernel orders up to 1024 candidates per row: "
+                             f"two K-lists at least)")
     fan = max(2, 1024 // K)                              # the merge kernel orders up to 1024 candidates per row
     while len(cands) > 1:
         nxt = []

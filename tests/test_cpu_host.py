@@ -129,3 +129,25 @@ def test_bench_flop_model_matches_the_survey_numbers():
     f6 = bench.flops_per_seq(dict(bench.HEADLINE, masklen=6))
     assert abs(f20 / 1e6 - 179.9) < 0.2 and abs(f6 / 1e6 - 108.2) < 0.2
     assert abs(3 * f20 * 512 / 1e9 - 276.3) < 0.5
+
+
+def test_key_mask_forms_accepted_by_the_attention_units():
+    """BiMAU / MAU keep the reference's positional signature, whose `masks` is the [h*B, T, T] float key mask
+    (EasyDGL.py:94-95); the kernels take a [B, T] int64 vector.  The module reduces the reference forms and rejects anything else."""
+    import pytest
+    import torch
+    from easydgl_amd.module.temporal import key_ids_from_masks
+    B, T, h = 3, 5, 2
+    ids = torch.tensor([[0, 0, 4, 9, 2], [0, 7, 7, 1, 3], [5, 6, 1, 2, 8]])
+    want = (ids != 0).to(torch.int64)
+    assert key_ids_from_masks(ids, B, T, h) is not None and torch.equal(key_ids_from_masks(ids, B, T, h), ids)
+    ref_mask = (ids != 0).float().unsqueeze(1).repeat(h, T, 1)            # tf.tile(expand_dims(.., 1), [h, T, 1])
+    assert ref_mask.shape == (h * B, T, T)
+    for m in (ref_mask, ref_mask[:B], (ids != 0).float().unsqueeze(1), (ids != 0).float(), (ids != 0)):
+        got = key_ids_from_masks(m, B, T, h)
+        assert got.dtype == torch.int64 and got.shape == (B, T) and torch.equal(got, want)
+    for bad in (torch.zeros(B, T + 1), torch.zeros(h * B, T), torch.zeros(B, 2, T), torch.zeros(4, 4, 4, 4)):
+        with pytest.raises(ValueError):
+            key_ids_from_masks(bad, B, T, h)
+    with pytest.raises(TypeError):
+        key_ids_from_masks([[1, 2]], B, T, h)

@@ -163,3 +163,31 @@ def test_unsupported_head_dim_fails_in_the_constructor():
         T.BiMAU(50, 1, 4, 0.0)
     with pytest.raises(ValueError, match="num_events"):
         T.MAU(64, 2, 40, 0.0)
+
+
+def test_bimau_takes_the_reference_key_mask_and_trains_with_dropout_on_its_own():
+    """(queries, keys, masks, ...) with the reference's own `masks` — tile(expand_dims(float(ids != 0), 1), [h, T, 1]), EasyDGL.py:94-95
+    — gives the outputs of the [B, T] id form; is_training with dropout_rate > 0 and no model around draws from a module-local state."""
+    from easydgl_amd import ops
+    from easydgl_amd._lib import EdglError
+    from easydgl_amd.module import temporal as T
+    B, Tn, C, H, E = 3, 19, 64, 4, 5
+    att = T.BiMAU(C, H, E, 0.3).cuda()
+    rng = np.random.default_rng(9)
+    x = torch.tensor(rng.standard_normal((B, Tn, 3 * C)), dtype=torch.float32).cuda()
+    ids = rng.integers(1, 30, size=(B, Tn)); ids[1, :7] = 0
+    ids_t = torch.tensor(ids).cuda()
+    spans = torch.tensor(rng.uniform(0, 5, size=(B, Tn)), dtype=torch.float32).cuda()
+    marks = torch.tensor(O.synthetic_mark_table(30, E, multi_hot=True)[ids].astype(np.uint8)).cuda()
+    ref_mask = (ids_t != 0).float().unsqueeze(1).repeat(H, Tn, 1)                      # [h*B, T, T]
+    o0, l0 = att(x, x, ids_t, spans, marks, False)
+    o1, l1 = att(x, x, ref_mask, spans, marks, False)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    with pytest.raises(ValueError):
+        att(x, x, ref_mask[:, :, :-1], spans, marks, False)
+    with pytest.raises(EdglError):                                                     # the raw op refuses what it would mis-read
+        ops.BiMAUFn.apply(torch.zeros(B, Tn, 4 * C, device="cuda"), x[:, :, :C], att.st_kernel, att.st_bias, att.weight, att.scaling,
+                          ref_mask, spans, marks, H, ops.NO_DROP)
+    t1, _ = att(x, x, ids_t, spans, marks, True)
+    t2, _ = att(x, x, ids_t, spans, marks, True)
+    assert not torch.equal(t1, o0) and not torch.equal(t1, t2)                          # dropout is on, and a fresh mask per call
