@@ -1,2 +1,2 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -6
+cd $GRAFT_REPO_ROOT
+KT_LINES=45 bash tools/ktrace.sh 2>&1 | tail -50
