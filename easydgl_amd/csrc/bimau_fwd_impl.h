@@ -9,6 +9,10 @@
 
 #include "bimau_common.h"
 
+#ifndef EDGL_BIMAU_FWD_WAVES
+#define EDGL_BIMAU_FWD_WAVES 2   // waves per SIMD the headline instance (bf16, head dim 16, E = 16) is compiled for (3: 168 registers, 4 spilled — 79 -> 84 us)
+#endif
+
 namespace bimau {
 
 
@@ -35,7 +39,7 @@ __host__ __device__ constexpr size_t fwd_wave_bytes() {
 // DT = dh/16, NT = ceil(T/16); EC = compile-time mark count (16: all LDS offsets are immediates and the mark loop is
 // one straight-line block) or 0 (runtime p.E)
 template <typename T, int DT, int NT, int EC, int PHASE = 0>
-__global__ __launch_bounds__(256) void bimau_fwd_kernel(FwdP p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHASE == 0) ? EDGL_BIMAU_FWD_WAVES : 1) void bimau_fwd_kernel(FwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = EC ? EC : p.E;

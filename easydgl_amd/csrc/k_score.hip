@@ -110,7 +110,6 @@ struct ScoreP {
     float* coef_out;                                    // flash forward, compacted rows, whole table: loss coefficients [R]
     int table_ready;                                    // tableT already written by edgl_score_prepare_table
     const int32_t* wtotal;                              // data parallel: weighted rows of the GLOBAL batch (denominator of the loss)
-    int dbg;   // EDGL_DBG ablation bits (profiling only): 1 skip dl math, 2 skip second product, 4 skip z streaming, 8 skip logit MFMA
 };
 
 // ---- streamed tile: global -> registers -> LDS -------------------------------------------------
@@ -577,7 +576,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
         const bool more = it + 1 < ntile;
         char* cur = smem + (DOUBLE ? (size_t)(it & 1) * BUF : 0);
         char* nxt = smem + (DOUBLE ? (size_t)((it + 1) & 1) * BUF : 0);
-        if (PREFETCH && more && !(p.dbg & 4)) { zs.load_z(zsrc, z0 + ZB, z_hi, YS); load_info(z0 + ZB); }
+        if (PREFETCH && more) { zs.load_z(zsrc, z0 + ZB, z_hi, YS); load_info(z0 + ZB); }
         const T* Zs = reinterpret_cast<const T*>(cur);
         const T* ZTs = reinterpret_cast<const T*>(cur + S::Z_BYTES);
         const float* info = reinterpret_cast<const float*>(cur + S::Z_BYTES + S::ZT_BYTES);
@@ -585,13 +584,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
 #pragma unroll
         for (int half = 0; half < S::NH; ++half) {
             f32x4 acc[JH][IX];
-            if (!(p.dbg & 8)) logit_half<T, CT, IX>(Zs, half * JH, xf, lane, acc);
-            else {
-#pragma unroll
-                for (int j = 0; j < JH; ++j)
-#pragma unroll
-                    for (int ix = 0; ix < IX; ++ix) acc[j][ix] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
-            }
+            logit_half<T, CT, IX>(Zs, half * JH, xf, lane, acc);
             // ---- dl[z][x] in place ------------------------------------------------------------------
             if constexpr (FLASH) {
                 float tmax[IX];
@@ -647,7 +640,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                             s_run[ix] += d;
                             acc[j][ix][r] = d;
                         }
-            } else if (!(p.dbg & 1))
+            } else
 #pragma unroll
             for (int j = 0; j < JH; ++j) {
                 const int jz = half * JH + j;
@@ -685,7 +678,6 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
                     }
             }
             // ---- out[x][c] += sum_z dl[x][z] Z[z][c] --------------------------------------------------
-            if (p.dbg & 2) { out[0][0] += acc[0][0]; out[IX - 1][0] += acc[JH - 1][IX - 1]; continue; }
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
                 for (int jp = 0; jp < JH / 2; ++jp) {
@@ -720,7 +712,7 @@ __global__ __launch_bounds__(64 * NW) void score_bwd_kernel(ScoreP p) {
             }
         }
         if (!DOUBLE) __syncthreads();
-        if (more && !(p.dbg & 4)) {
+        if (more) {
             if (!PREFETCH) { zs.load_z(zsrc, z0 + ZB, z_hi, YS); load_info(z0 + ZB); }
             zs.load_t(zsrcT, ldT, z0 + ZB, z_hi, YS);   // short-lived: the other wave of the SIMD covers it
             zs.store(reinterpret_cast<T*>(nxt), reinterpret_cast<T*>(nxt + S::Z_BYTES));
@@ -1531,8 +1523,6 @@ extern "C" int edgl_score_ce_bwd(const void* rows, const void* table, const floa
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
     const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4);
-    static const int dbg = getenv("EDGL_DBG") ? atoi(getenv("EDGL_DBG")) : 0;
-    p.dbg = dbg;
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 0>(p, C, plan, workspace, d_rows, d_table, d_bias, st)
                              : bwd_dispatch<bf16, 0>(p, C, plan, workspace, d_rows, d_table, d_bias, st);

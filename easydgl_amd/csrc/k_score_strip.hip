@@ -688,11 +688,13 @@ __global__ __launch_bounds__(NTHR, 1) void strip_kernel(StripP p) {
             return;
         }
     }
+#ifndef STRIP_TEST_NOFALLBACK
     if (YS) {   // copies: the structs the hot path reads must not be address-taken (they would live in scratch)
         const StripP p2 = p;
         const Geo g2 = g;
         fallback_exact(&p2, &g2, smem);
     }
+#endif
 }
 
 // d_table[label[r]] -= coef[r] rows[r];  d_bias[label[r] - 1] -= coef[r]   over the weighted rows (label != 0): the one-hot part of

@@ -1,4 +1,4 @@
-"""Times the scoring kernels at the headline shape (R=10240, C=128, I=20001), optionally under EDGL_DBG."""
+"""Times the scoring kernels at the headline shape (R=10240, C=128, I=20001)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
