@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("EDGL_LIB_PATH") or os.path.join(_HERE, "libeasydgl_hi
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 8, 16, 32, 64
-MAU_CAUSAL, MAU_NO_DIAG = 1, 2
+MAU_CAUSAL, MAU_NO_DIAG, MAU_DIAG_ZERO = 1, 2, 4
 TATTN_CAUSAL = 1
 
 P, I, F, L, U32, I64 = c_void_p, c_int, c_float, c_long, c_uint32, c_int64
@@ -46,6 +46,7 @@ SIGNATURES = {
     "edgl_bimau_pack_bytes": (L, [I, I, I, I]),
     "edgl_bimau_pack": (I, [P, P, P, P, I, I, I, P, I, P]),
     "edgl_bimau_saved_bytes": (L, [I, I, I, I, I]),
+    "edgl_bimau_mark_group": (I, [I, I, I]),
     "edgl_bimau_fwd": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, I, I, P]),
     "edgl_bimau_bwd_workspace": (L, [I, I, I, I, I, I]),
     "edgl_bimau_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, I, I, P]),

@@ -50,7 +50,7 @@ struct BwdP {
     void* d_qkvt;
     float* dz_ws; float* dh_ws; float* rowdot_ws; float* dsc_part; float* wpart;
     int waves;
-    int flags;   // MAU_CAUSAL | MAU_NO_DIAG
+    int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
 };
 
 template <typename T>
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
                 for (int r = 0; r < 4; ++r) gv[r] = (dtile && g4 + r == l15) ? 1.0f : gacc[r];   // G' diag := 1 (temporal.py:438-439)
             } else if (dtile) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
+                for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? ((p.flags & MAU_DIAG_ZERO) ? 0.0f : 1.0f) : gacc[r];
             }
             float facs[4];
             drop_factors(dk, dbase + kt * 16 + g4, facs);
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
                 for (int r = 0; r < 4; ++r) gv[r] = (dtile && g4 + r == l15) ? 1.0f : gacc[r];
             } else if (kt == qt && !(p.flags & MAU_NO_DIAG)) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? 1.0f : gacc[r];
+                for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? ((p.flags & MAU_DIAG_ZERO) ? 0.0f : 1.0f) : gacc[r];
             }
             float facs[4];
             drop_factors(dk, dbase + kt * 16 + g4, facs);

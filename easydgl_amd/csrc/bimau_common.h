@@ -189,6 +189,9 @@ __device__ __forceinline__ KeyMask<NT> load_keymask(const int64_t* ids_row, int 
 // (tf.where(tril == 0, paddings, outputs)); q = this lane's query index.
 constexpr int MAU_CAUSAL = 1;    // future blinding (temporal.py:370-375)
 constexpr int MAU_NO_DIAG = 2;   // MAU keeps the modulation on the diagonal; BiMAU sets it to 1 (temporal.py:438-439)
+// More than 16 mark types run as groups of <= 16 marks, one launch each (module/temporal.py): G = sum_g G_g is linear in the
+// groups, so the first group writes the diagonal 1 and the later ones 0 — their outputs then add up to the ungrouped result.
+constexpr int MAU_DIAG_ZERO = 4;
 // The scale carries log2(e) so that the exponential is one v_exp_f32 (2^x) on (v - max): fma, sub, exp per element — all
 // in 2- / 4-wide vector form (v_pk_fma_f32 / v_pk_add_f32).  The additive mask keeps its magnitude: a padded score is
 // "-2^32 + something below the f32 resolution there", a fully padded row is uniform exactly as in the reference.

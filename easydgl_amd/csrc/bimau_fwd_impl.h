@@ -25,7 +25,7 @@ struct FwdP {
     void* out; float* lam;
     void* hin_out; float* z_out;   // saved for the backward (NULL: inference)
     int waves;
-    int flags;   // MAU_CAUSAL | MAU_NO_DIAG
+    int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
 };
 
 // wave-private LDS bytes of a phase (K always; T_ unless values phase; V and marks unless scores phase; the f32 key mask)
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         // One straight-line block for all key tiles (the dropout decision is taken once, outside; the diagonal is a select
         // on a scalar-and-ed lane mask): the scheduler can issue the seven MFMAs ahead and run the hashes in their shadow.
         const bool set_diag = !(p.flags & MAU_NO_DIAG);
+        const float dval = (p.flags & MAU_DIAG_ZERO) ? 0.0f : 1.0f;   // later mark groups of a split call (bimau_common.h)
         auto modulate = [&](auto drop_on) {
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
                 const bool dtile = set_diag && kt == qt;   // only this key tile can contain k == q (temporal.py:438-439)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    gacc[r] = (dtile && g4 + r == l15) ? 1.0f : gacc[r];
+                    gacc[r] = (dtile && g4 + r == l15) ? dval : gacc[r];
                     s[kt][r] = gacc[r] * s[kt][r];     // temporal.py:441
                 }
                 if constexpr (decltype(drop_on)::value) {                       // temporal.py:442

@@ -230,6 +230,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
     PH_FLUSH(0);
 }
 
+// LDS bytes of the intensity backward kernel: the weight images + the dW1 / db1 / dw accumulators + per-wave tile scratch
+template <typename T>
+size_t intensity_bwd_lds(int dh, int E) {
+    const int NACC = dh * E * (dh + 4);
+    return pack_dims<T>(dh, E).bytes + ((size_t)((NACC + 3) & ~3) + 4 * (16 * KY_ECH + 16)) * sizeof(float);
+}
+
 template <typename T, int DT, int NT>
 int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscaling, hipStream_t st) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
@@ -261,8 +268,7 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     // ---- Y ----
     {
         MlpP mp{p.hin, p.dz_ws, p.spans, p.pack, (long)p.B * p.H * p.T, p.B, p.T, p.E, p.dh_ws, p.wpart, p.dsc_part, jobs};
-        const int JE = dh * p.E, NACC = JE * (dh + 4);
-        const size_t smem_b = pd.bytes + ((size_t)((NACC + 3) & ~3) + 4 * (16 * KY_ECH + 16)) * sizeof(float);   // + per-wave tile scratch
+        const size_t smem_b = intensity_bwd_lds<T>(dh, p.E);
         EDGL_REQUIRE(smem_b <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: intensity kernel needs %zu B of LDS", smem_b);
         auto kb = intensity_bwd_kernel<T, DT>;
         hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
@@ -331,6 +337,20 @@ extern "C" long edgl_bimau_bwd_workspace(int B, int T, int C, int H, int E, int 
     (void)dtype;
     if (H <= 0 || C % H) return -1;
     return (long)ws_layout(B, T, C, H, E).total;
+}
+
+// Largest mark count (<= 16) one launch of the fused unit takes at this head dim and dtype — what a caller with more mark types
+// splits them by (EDGL_MAU_DIAG_ZERO).  Head dims 16 / 32 are bounded by the LDS of the intensity backward kernel (f32, dh = 32:
+// 11 marks); head dims 64 / 128 stream the weights (k_bimau_big.hip) and take the full 16.
+extern "C" int edgl_bimau_mark_group(int C, int H, int dtype) {
+    if (H <= 0 || C % H || (dtype != EDGL_F32 && dtype != EDGL_BF16)) return -1;
+    const int dh = C / H;
+    if (dh >= 64) return bimau::EP;
+    for (int E = bimau::EP; E >= 1; --E) {
+        const size_t b = dtype == EDGL_BF16 ? intensity_bwd_lds<bf16>(dh, E) : intensity_bwd_lds<float>(dh, E);
+        if (b <= 160 * 1024) return E;
+    }
+    return -1;
 }
 
 extern "C" int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks,

@@ -39,6 +39,10 @@ class TrainEngine:
         self.code = ops._DT[self.dt]
         B, T, C, H, E, M, I = batch, m.seqslen, m.num_units, m.num_heads, m.num_events, m.masklen, m.num_items
         self.T, self.C, self.H, self.E, self.M, self.I = T, C, H, E, M, I
+        if E > 16:
+            raise _lib.EdglError(f"TrainEngine: num_events={E}: the static engine issues one attention launch per block (<= 16 mark "
+                                 "types); models with more marks train through the autograd path (model.train_loss), which runs the "
+                                 "marks in groups of 16 (module/temporal.py modulated_attention)")
         self.R = B * M
         self.rows = B * T
         nb = len(m.layers)

@@ -55,8 +55,8 @@ class CTSMA(Sequential):
         if table.shape[0] < num_items or not np.isin(table, (0, 1)).all():
             raise ValueError("mark table must be a 0/1 multi-hot table with one row per item id")
         self.num_events = int(table.shape[-1])
-        if not (2 <= self.num_events <= 16):
-            raise ValueError("num_events must be in [2, 16] for the fused attention kernel")
+        if not (2 <= self.num_events <= T.MAX_EVENTS):
+            raise ValueError(f"num_events must be in [2, {T.MAX_EVENTS}] (more than 16 run as mark groups: temporal.modulated_attention)")
         self.register_buffer("mark_lookup_table", torch.from_numpy(table.astype(np.uint8)), persistent=False)
         self.ct_reg = float(getattr(FLAGS, "ct_reg", 0.0) or 0.0)
         gen = torch.Generator().manual_seed(self.seed)

@@ -73,8 +73,8 @@ class EasyDGL(Sequential):
         if not np.isin(table, (0, 1)).all():
             raise ValueError("mark table must be 0/1 multi-hot")
         self.num_events = int(table.shape[-1])                     # EasyDGL.py:46
-        if not (2 <= self.num_events <= 16):
-            raise ValueError("num_events must be in [2, 16] for the fused BiMAU kernel")
+        if not (2 <= self.num_events <= T.MAX_EVENTS):
+            raise ValueError(f"num_events must be in [2, {T.MAX_EVENTS}] (more than 16 run as mark groups: temporal.modulated_attention)")
         self.register_buffer("mark_lookup_table", torch.from_numpy(table.astype(np.uint8)), persistent=False)
         self.ct_reg = float(getattr(FLAGS, "ct_reg", 0.0) or 0.0)
 

@@ -11,7 +11,8 @@ from .coding import glorot_uniform_
 
 
 SUPPORTED_HEAD_DIMS = (16, 32, 64, 128)
-MAX_EVENTS = 16
+MARK_GROUP = 16      # mark types one kernel launch takes (one MFMA K-block, csrc/bimau_common.h EP)
+MAX_EVENTS = 256     # marks travel as uint8 one-hot columns; beyond 16 they run as groups (modulated_attention)
 
 
 def _check_head_dim(num_units, num_heads, num_events, who):
@@ -43,6 +44,32 @@ def key_ids_from_masks(masks: torch.Tensor, batch: int, seqlen: int, num_heads: 
         return (masks[:batch, 0, :] != 0).to(torch.int64).contiguous()
     raise ValueError(f"BiMAU / MAU: `masks` of shape {tuple(masks.shape)} / {masks.dtype}: expected int64 [B={batch}, T={seqlen}] "
                      f"(item ids or 0/1), or the reference's key mask [h*B, T, T] / [B, T, T] / [B, 1, T]")
+
+
+def modulated_attention(qkvt, resid, st_kernel, st_bias, weight, scaling, masks, intervals, marks, num_heads, drop, flags=0):
+    """The fused attention of BiMAU / MAU for any number of mark types.  Up to 16 marks: one launch (ops.BiMAUFn).  More: the
+    modulation G[q,k] = sum_e marks[k,e] lambda[q,e] (temporal.py:309-313) is a sum over marks and the output (G * P) V is linear
+    in G, and lambda_e only reads its own dh columns of the intensity MLP (temporal.py:291: split(Z, dh)), so the marks run as
+    groups of <= 16 (edgl_bimau_mark_group) — each launch with its column block of ``st_kernel`` / ``st_bias``, its rows of ``weight`` / ``scaling`` and
+    its mark columns, the SAME dropout stream (one mask for the whole of G) — and the outputs add up.  The first group carries
+    the residual and, for BiMAU, the diagonal 1 (set_diag, :438-439); the later groups a zero residual and the diagonal 0."""
+    E, dh = weight.shape
+    group = ops.lib.edgl_bimau_mark_group(dh * num_heads, num_heads, ops._code(qkvt))   # 16, or what the intensity backward's LDS holds
+    if group <= 0:
+        raise ValueError(f"BiMAU / MAU: head dim {dh} / {qkvt.dtype} unsupported")
+    if E <= group:
+        return ops.BiMAUFn.apply(qkvt, resid, st_kernel, st_bias, weight, scaling, masks, intervals, marks, num_heads, drop, flags)
+    out, lams = None, []
+    zero_resid = torch.zeros_like(resid)
+    for e0 in range(0, E, group):
+        e1 = min(E, e0 + group)
+        gflags = flags if e0 == 0 else (flags | (0 if flags & ops.MAU_NO_DIAG else ops.MAU_DIAG_ZERO))
+        o, lam = ops.BiMAUFn.apply(qkvt, resid if e0 == 0 else zero_resid, st_kernel[:, e0 * dh:e1 * dh].contiguous(),
+                                   st_bias[e0 * dh:e1 * dh].contiguous(), weight[e0:e1].contiguous(), scaling[e0:e1].contiguous(),
+                                   masks, intervals, marks[:, :, e0:e1].contiguous(), num_heads, drop, gflags)
+        out = o if out is None else out + o
+        lams.append(lam)
+    return out, torch.cat(lams, dim=-1)
 
 
 class BiMAU(nn.Module):
@@ -102,8 +129,8 @@ class BiMAU(nn.Module):
         masks = key_ids_from_masks(masks, queries.shape[0], queries.shape[1], self.num_heads)
         qkvt = ops.LinearFn.apply(queries, self.dense_kernel, self.dense_bias, self.compute(self.dense_kernel), False)
         resid = queries[:, :, :C]
-        return ops.BiMAUFn.apply(qkvt, resid, self.st_kernel, self.st_bias, self.weight, self.scaling, masks, intervals,
-                                 marks, self.num_heads, drop if is_training else ops.NO_DROP)
+        return modulated_attention(qkvt, resid, self.st_kernel, self.st_bias, self.weight, self.scaling, masks, intervals,
+                                   marks, self.num_heads, drop if is_training else ops.NO_DROP)
 
 
 class MAU(nn.Module):
@@ -146,8 +173,8 @@ class MAU(nn.Module):
         kvt = ops.LinearFn.apply(keys, self.kvt_kernel, self.kvt_bias, self.compute(self.kvt_kernel), False)
         qkvt = torch.cat([q, kvt], dim=-1)   # column blocks Q | K | V | T_ of the kernel's operand (a device-side copy)
         flags = ops.MAU_NO_DIAG | (ops.MAU_CAUSAL if causality else 0)
-        return ops.BiMAUFn.apply(qkvt, queries[:, :, :C], self.st_kernel, self.st_bias, self.weight, self.scaling, masks,
-                                 intervals, marks, self.num_heads, drop if is_training else ops.NO_DROP, flags)
+        return modulated_attention(qkvt, queries[:, :, :C], self.st_kernel, self.st_bias, self.weight, self.scaling, masks,
+                                   intervals, marks, self.num_heads, drop if is_training else ops.NO_DROP, flags)
 
 
 class TfMultiHeadAttention(nn.Module):

@@ -63,7 +63,7 @@ class Drop:
 
 
 NO_DROP = Drop()
-MAU_CAUSAL, MAU_NO_DIAG = _lib.MAU_CAUSAL, _lib.MAU_NO_DIAG
+MAU_CAUSAL, MAU_NO_DIAG, MAU_DIAG_ZERO = _lib.MAU_CAUSAL, _lib.MAU_NO_DIAG, _lib.MAU_DIAG_ZERO
 
 
 def make_rng_state(device, seed: int = 9876) -> torch.Tensor:

@@ -159,12 +159,17 @@ int edgl_colsum(const void* X, int M, int N, int ld, float* out, int accumulate,
  * pre-softplus output z.  `flags`: 0 = BiMAU as above; EDGL_MAU_CAUSAL adds the future-blinding mask of
  * MAU.__call__(causality=True) (temporal.py:370-375: keys k > q scored -2^32+1 like padded keys, no gradient
  * through them); EDGL_MAU_NO_DIAG keeps the modulation on the diagonal (MAU, temporal.py:383; BiMAU overwrites
- * it with 1, :438-439).  The caller may fill the Q and K|V|T_ column blocks of qkvt from different inputs
+ * it with 1, :438-439); EDGL_MAU_DIAG_ZERO writes 0 there instead of 1 — for a unit with more than 16 mark types, run as
+ * groups of <= 16 marks whose outputs are summed (G is linear in the marks: group 0 carries the diagonal 1 and the
+ * residual, the later groups 0 and a zero residual).  The caller may fill the Q and K|V|T_ column blocks of qkvt from different inputs
  * (MAU: Q = dense(LN(x)), K,V,T_ = dense(x), temporal.py:352-355).  Supported: dh in {16,32}, E<=16, T<=128. */
 #define EDGL_MAU_CAUSAL 1
 #define EDGL_MAU_NO_DIAG 2
+#define EDGL_MAU_DIAG_ZERO 4
 long edgl_bimau_pack_bytes(int C, int H, int E, int dtype);
 long edgl_bimau_saved_bytes(int B, int T, int C, int H, int dtype);
+/* largest mark count (<= 16) one launch takes at this head dim / dtype (LDS of the intensity backward); -1: bad arguments */
+int edgl_bimau_mark_group(int C, int H, int dtype);
 int edgl_bimau_pack(const float* W1, const float* b1, const float* w, const float* scaling, int C, int H, int E,
                     void* pack, int dtype, void* stream);
 int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,

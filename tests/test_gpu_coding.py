@@ -162,7 +162,7 @@ def test_unsupported_head_dim_fails_in_the_constructor():
     with pytest.raises(ValueError, match="head dim"):
         T.BiMAU(50, 1, 4, 0.0)
     with pytest.raises(ValueError, match="num_events"):
-        T.MAU(64, 2, 40, 0.0)
+        T.MAU(64, 2, 300, 0.0)
 
 
 def test_bimau_takes_the_reference_key_mask_and_trains_with_dropout_on_its_own():
@@ -191,3 +191,47 @@ def test_bimau_takes_the_reference_key_mask_and_trains_with_dropout_on_its_own()
     t1, _ = att(x, x, ids_t, spans, marks, True)
     t2, _ = att(x, x, ids_t, spans, marks, True)
     assert not torch.equal(t1, o0) and not torch.equal(t1, t2)                          # dropout is on, and a fresh mask per call
+
+
+@pytest.mark.parametrize("unit", ["BiMAU", "MAU"])
+def test_mark_groups_share_one_dropout_mask(unit):
+    """A unit with 32 mark types whose first 16 mark columns are empty computes what the 16-mark unit built from the second half
+    of its intensity weights computes — with attention dropout ON: the two launches of modulated_attention must drop the same
+    (query, key) pairs, the first one carries the residual and (BiMAU) the diagonal 1, the second the modulation."""
+    from easydgl_amd import ops
+    from easydgl_amd.module import temporal as T
+    B, Tn, C, H, E = 3, 21, 64, 4, 32
+    dh = C // H
+    gen = torch.Generator().manual_seed(4)
+    mk = (lambda e: T.BiMAU(C, H, e, 0.25, in_units=C, gen=gen)) if unit == "BiMAU" else (lambda e: T.MAU(C, H, e, 0.25, gen=gen))
+    big, small = mk(E).cuda(), mk(16).cuda()
+    with torch.no_grad():
+        for n, p in small.named_parameters():
+            q = dict(big.named_parameters())[n]
+            if n == "st_kernel": p.copy_(q[:, 16 * dh:])
+            elif n == "st_bias": p.copy_(q[16 * dh:])
+            elif n in ("weight", "scaling"): p.copy_(q[16:])
+            else: p.copy_(q)
+        big.scaling.add_(0.1 * torch.randn(E, generator=gen).cuda()); small.scaling.copy_(big.scaling[16:])
+    rng = np.random.default_rng(12)
+    x = torch.tensor(rng.standard_normal((B, Tn, C)), dtype=torch.float32).cuda()
+    ids = rng.integers(1, 40, size=(B, Tn)); ids[2, :6] = 0
+    ids_t = torch.tensor(ids).cuda()
+    spans = torch.tensor(rng.uniform(0, 5, size=(B, Tn)), dtype=torch.float32).cuda()
+    m16 = O.synthetic_mark_table(40, 16, multi_hot=True)[ids].astype(np.uint8)
+    marks16 = torch.tensor(m16).cuda()
+    marks32 = torch.cat([torch.zeros_like(marks16), marks16], dim=-1).contiguous()
+    rng_state = ops.make_rng_state("cuda", seed=77)
+    drop = ops.Drop(0.25, rng_state, 3)
+    xb, xs = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ob, lb = big(xb, xb, ids_t, spans, marks32, True, drop=drop)
+    os_, ls = small(xs, xs, ids_t, spans, marks16, True, drop=drop)
+    assert lb.shape == (H * B, Tn, E)
+    assert float((ob - os_).abs().max()) < 2e-5 * (1 + float(os_.abs().max()))
+    assert float((lb[:, :, 16:] - ls).abs().max()) < 1e-5
+    w = torch.tensor(rng.standard_normal((B, Tn, C)), dtype=torch.float32).cuda()
+    (ob * w).sum().backward(); (os_ * w).sum().backward()
+    assert float((xb.grad - xs.grad).abs().max()) < 5e-5 * (1 + float(xs.grad.abs().max()))
+    gb, gs = big.st_kernel.grad[:, 16 * dh:], small.st_kernel.grad
+    assert float((gb - gs).abs().max()) < 5e-5 * (1 + float(gs.abs().max()))
+    assert not torch.equal(ob, big(xb, xb, ids_t, spans, marks32, False)[0])       # dropout was on

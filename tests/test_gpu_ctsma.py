@@ -18,6 +18,7 @@ CASES = [
     dict(B=32, T=30, C=64, h=2, E=7, I=300, nb=1),         # dh = 32
     dict(B=4, T=100, C=128, h=8, E=16, I=2000, nb=2),      # headline widths
     dict(B=4, T=30, C=512, h=4, E=16, I=700, nb=2),        # the published recipe runme.sh:107-115 (dh = 128, 2 blocks, seqslen 30)
+    dict(B=3, T=14, C=64, h=2, E=24, I=90, nb=1),          # more than 16 mark types: two mark groups, MAU keeps the diagonal
 ]
 
 

@@ -19,6 +19,9 @@ CASES = [
     dict(num_units=64, num_heads=4, num_blocks=1, seqslen=200, masklen=40, num_events=7, num_items=500),     # config-3 length (T=201)
     # the published EasyDGL recipe (runme.sh:15-23 + the defaults main.py:38,44): C=512, h=8 (dh=64), 1 block, T=31, M=6
     dict(num_units=512, num_heads=8, num_blocks=1, seqslen=30, masklen=6, num_events=16, num_items=700),
+    # more than 16 mark types (EasyDGL.py:46 takes the count from the mark table): groups of 16 (temporal.modulated_attention)
+    dict(num_units=64, num_heads=4, num_blocks=2, seqslen=20, masklen=5, num_events=24, num_items=300),      # 16 + 8, dh = 16
+    dict(num_units=128, num_heads=2, num_blocks=1, seqslen=18, masklen=4, num_events=40, num_items=200),     # 16 + 16 + 8, dh = 64
 ]
 
 
