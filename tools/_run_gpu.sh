@@ -1,5 +1,18 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r3c
-for v in "" tools/variants/lib_nofb.so; do
-EDGL_LIB_PATH=$v rocprofv3 --kernel-trace --stats -d gpurun_out/r3c/p -o s -- python tools/strip_bench.py > gpurun_out/r3c/log.txt 2>&1
-python tools/kstats.py gpurun_out/r3c/p/s_results.db 4 | grep strip_kernel | cut -c1-120; rm -rf gpurun_out/r3c/p
-done
+#!/bin/bash
+# full profile refresh of the round: kernel trace + HBM PMC passes of the step, MFMA / VALU utilisation, K1 encode (zipf, uniform)
+cd $GRAFT_REPO_ROOT
+TAG=${1:-r03}
+bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
+bash tools/profile_mfma.sh > gpurun_out/mfma.log 2>&1
+bash tools/profile_encode.sh zipf > gpurun_out/encode_zipf.log 2>&1
+bash tools/profile_encode.sh uniform > gpurun_out/encode_uniform.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/make_profiles.py $TAG
+python tools/make_mfma_profile.py $TAG
+python tools/make_encode_profile.py $TAG zipf
+python tools/make_encode_profile.py $TAG uniform
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
+cp gpurun_out/refresh/bench_line.json gpurun_out/profiles_$TAG/${TAG}_bench_line_profiled.json
+# the databases are large: keep only the summaries
+rm -rf gpurun_out/refresh/ktrace gpurun_out/refresh/fetch gpurun_out/refresh/write gpurun_out/mfma/mfma gpurun_out/mfma/valu gpurun_out/encode_*/ktrace gpurun_out/encode_*/fetch gpurun_out/encode_*/write
+ls -la gpurun_out/profiles_$TAG

@@ -9,7 +9,8 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
-DOMINANT = "score_bwd_kernelIDF16bLi8ELi2ELi8E"   # score_bwd_kernel<bf16, C/16 = 8, ROLE_YF (flash), 8 waves>
+DOMINANT = ("strip_kernel<0>", "strip_kernelILi0E")   # strip::strip_kernel<ROLE_YF> (k_score_strip.hip), demangled / mangled spelling
+DOMINANT_W = ("strip_kernel<1>", "strip_kernelILi1E")  # strip::strip_kernel<ROLE_W>
 
 
 def kernel_stats(db_path, steps):
@@ -34,7 +35,7 @@ def counter_means(db_path, counter):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     prof = os.path.join(ROOT, "profiles")
     steps = 25
     head = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   ({steps} optimizer steps, engine path, round {tag})"]
@@ -49,23 +50,28 @@ def main():
              "# per-launch averages; units: KiB as reported (x1024 = bytes).  MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE counts 128-B requests",
              "# as 64 B for wide coalesced streams -> the corrected read bytes are 2 x FETCH_SIZE (upper bound; WRITE_SIZE uncalibrated).",
              "# kernel | FETCH_SIZE KiB | corrected read MB | WRITE_SIZE KiB | write MB"]
-    dom = None
+    dom = domw = None
     for name in sorted(fetch, key=lambda k: -(fetch[k] + write.get(k, 0.0))):
         fk, wk = fetch[name], write.get(name, 0.0)
         if fk + wk < 2000:
             continue
         lines.append(f"{name[:80]} | {fk:.0f} | {2 * fk * 1024 / 1e6:.1f} | {wk:.0f} | {wk * 1024 / 1e6:.1f}")
-        if DOMINANT in name:
+        if any(d in name for d in DOMINANT):
             dom = (name, fk, wk)
+        if any(d in name for d in DOMINANT_W):
+            domw = (name, fk, wk)
     with open(os.path.join(prof, f"{tag}_hbm_traffic_pmc.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     if dom:
         with open(os.path.join(prof, f"{tag}_dominant_kernel_traffic.json"), "w") as f:
-            json.dump({"kernel": "score_bwd_kernel<bf16,8,ROLE_YF>", "fetch_size_kib": round(dom[1], 1),
-                       "write_size_kib": round(dom[2], 1),
-                       "hbm_bytes_per_launch": int(2 * dom[1] * 1024 + dom[2] * 1024),
-                       "note": "separate --pmc passes; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE correction)"},
-                      f, indent=1)
+            d = {"kernel": "strip::strip_kernel<ROLE_YF>", "fetch_size_kib": round(dom[1], 1),
+                 "write_size_kib": round(dom[2], 1),
+                 "hbm_bytes_per_launch": int(2 * dom[1] * 1024 + dom[2] * 1024),
+                 "note": "separate --pmc passes; read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE correction)"}
+            if domw:
+                d["role_w"] = {"kernel": "strip::strip_kernel<ROLE_W>", "fetch_size_kib": round(domw[1], 1), "write_size_kib": round(domw[2], 1),
+                               "hbm_bytes_per_launch": int(2 * domw[1] * 1024 + domw[2] * 1024)}
+            json.dump(d, f, indent=1)
     print("profiles refreshed:", tag)
 
 
