@@ -48,6 +48,7 @@ SIGNATURES = {
     "edgl_bimau_saved_bytes": (L, [I, I, I, I, I]),
     "edgl_bimau_mark_group": (I, [I, I, I]),
     "edgl_bimau_fwd": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, I, I, P]),
+    "edgl_bimau_fwd_zr": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, I, P]),
     "edgl_bimau_bwd_workspace": (L, [I, I, I, I, I, I]),
     "edgl_bimau_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, I, I, P]),
     "edgl_add_layernorm_fwd": (I, [P, P, I, P, P, I, I, I, F, P, U32, P, I, P, P, I, P]),
@@ -83,6 +84,8 @@ SIGNATURES = {
     "edgl_tpp_fwd_bwd": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P, P]),
     "edgl_tpp_norm": (I, [P, P, I, I, I, P, P]),
     "edgl_tpp_fwd_bwd_ex": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P, I, P]),
+    "edgl_tpp_rows_workspace": (L, [I, I, I]),
+    "edgl_tpp_fwd_bwd_rows": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P, P]),
     "edgl_adam_step": (I, [P, P, P, P, L, F, F, F, F, P, F, P, I, P, P]),
     "edgl_step_begin": (I, [P, P, F, F, F, P]),
     "edgl_adam_apply": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P]),

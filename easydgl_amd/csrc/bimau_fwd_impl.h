@@ -24,6 +24,8 @@ struct FwdP {
     float rate; const uint64_t* rng; uint32_t stream_id;
     void* out; float* lam;
     void* hin_out; float* z_out;   // saved for the backward (NULL: inference)
+    float* zero_rows;              // optional [H*B, T, E] f32 array that this launch fills with zeros (the engine's d lambda buffer:
+                                   //  edgl_tpp_fwd_bwd_rows then writes the masked positions only); head dims 16 / 32 only
     int waves;
     int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
 };
@@ -278,10 +280,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
             float* dst = p.lam + (bp * p.T + q) * E + g4;
             if constexpr (EC == 16) {
                 *reinterpret_cast<float4*>(dst) = make_float4(lam4[0], lam4[1], lam4[2], lam4[3]);
+                if (p.zero_rows) *reinterpret_cast<float4*>(p.zero_rows + (bp * p.T + q) * E + g4) = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (g4 + i < E) dst[i] = lam4[i];
+                    if (g4 + i < E) { dst[i] = lam4[i]; if (p.zero_rows) p.zero_rows[(bp * p.T + q) * E + g4 + i] = 0.f; }
             }
         }
         } else {   // values phase: lambda of this query tile was prefetched with the Q rows

@@ -39,10 +39,23 @@ extern "C" int edgl_bimau_pack(const float* W1, const float* b1, const float* w,
     return EDGL_OK;
 }
 
+extern "C" int edgl_bimau_fwd_zr(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
+                                 const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
+                                 float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* out,
+                                 float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream);
 extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
                               const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
                               float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* out,
                               float* lam_out, void* saved, int flags, int dtype, void* stream) {
+    return edgl_bimau_fwd_zr(qkvt, resid, ld_res, ids, spans, marks, pack, B, T, C, H, E, drop_rate, rng_state, stream_id, out, lam_out,
+                             saved, nullptr, flags, dtype, stream);
+}
+// edgl_bimau_fwd that also fills `zero_rows` ([H*B, T, E] f32, may be NULL) with zeros: the forward is VALU bound and its stores are
+// free, a memset of the 26 MB d lambda buffer of the headline step is not.
+extern "C" int edgl_bimau_fwd_zr(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
+                                 const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
+                                 float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* out,
+                                 float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream) {
     EDGL_REQUIRE(qkvt && resid && ids && spans && marks && pack && out && lam_out, EDGL_ERR_NULL,
                  "edgl_bimau_fwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
@@ -51,13 +64,21 @@ extern "C" int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, c
     EDGL_REQUIRE(ld_res % 4 == 0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: ld_res must be a multiple of 4");
     EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: H*B*T*T must be < 2^32");
     FwdP p{qkvt, resid, ld_res, ids, spans, marks, (const char*)pack, B, T, C, H, E, drop_rate, rng_state, stream_id,
-           out, lam_out, nullptr, nullptr, 4, flags};
+           out, lam_out, nullptr, nullptr, nullptr, 4, flags};
+    hipStream_t st = (hipStream_t)stream;
+    if (C / H == 64 || C / H == 128) {   // three-launch form: lambda is written by the intensity kernel — plain memset there
+        if (zero_rows && hipMemsetAsync(zero_rows, 0, (size_t)H * B * T * E * sizeof(float), st) != hipSuccess) {
+            edgl_set_error("edgl_bimau_fwd: memset failed");
+            return EDGL_ERR_LAUNCH;
+        }
+    } else {
+        p.zero_rows = zero_rows;
+    }
     if (saved) {   // [H*B*T, dh] activation dtype | [H*B*T, 16] f32 (pre-softplus z)
         const bimau::SavedLayout sl = bimau::saved_layout(B, T, C, H, dtype == EDGL_BF16 ? 2 : 4);
         p.hin_out = (char*)saved + sl.off_hin;
         p.z_out = reinterpret_cast<float*>((char*)saved + sl.off_z);
     }
-    hipStream_t st = (hipStream_t)stream;
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_bimau_fwd: bad dtype %d", dtype);
     edgl_prof_begin(EDGL_KERNEL_BIMAU_FWD, st);
     int rc;

@@ -253,6 +253,112 @@ __global__ __launch_bounds__(128) void tpp_fused_kernel(TppP p, const float* sum
     a = block_sum(a, red); bsum = block_sum(bsum, red);
     if (threadIdx.x == 0) { part[blockIdx.x * 2] = a; part[blockIdx.x * 2 + 1] = bsum; }
 }
+// The same regulariser and gradient with ONE THREAD PER MASKED SLOT (b', m), for a d lambda array that already holds zeros
+// (edgl_bimau_fwd_zr fills it beside the lambda rows): only the rows of masked positions are written — 5 MB instead of the 26 MB
+// of the headline step — and no position of the sequence is visited that carries no slot.  A position drawn into several slots
+// (mask_random draws without replacement; padding rows can repeat position 0) is written once, by its FIRST slot, with the sum
+// over its slots — the gradient of tf.gather; every slot adds its own term to the two loss sums.
+__global__ __launch_bounds__(256) void tpp_rows_kernel(TppP p, const float* sums, float* part, float* d_lam) {
+    __shared__ float red[8];
+    __shared__ int s_pos[256], s_lab[256];
+    const float c = (float)reinterpret_cast<const int*>(sums)[4] * (float)p.H;   // tpp_norm_kernel
+    const float k = -p.coef / c;
+    // M <= 256: a workgroup takes 256 / M whole (b', .) slot lists, positions and labels staged in LDS (the searches for the other
+    // slots of a position are LDS reads; as global loads they were a chain of M dependent round trips: 17 us for 5 MB of work)
+    const int G = p.M <= 256 ? 256 / p.M : 0;
+    long bp; int m; bool active;
+    if (G) {
+        bp = (long)blockIdx.x * G + threadIdx.x / p.M; m = threadIdx.x % p.M;
+        active = (int)threadIdx.x < G * p.M && bp < (long)p.H * p.B;
+    } else {
+        const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        bp = j / p.M; m = (int)(j % p.M); active = j < (long)p.H * p.B * p.M;
+    }
+    const int b = (int)(bp % p.B);
+    const int64_t* mp = (p.mpos && active) ? p.mpos + (long)b * p.M : nullptr;
+    const int pos = !active ? 0 : (p.mpos ? (int)mp[m] : m);
+    const int lab = active ? (int)p.labels[(long)b * p.M + m] : 0;
+    if (G) {
+        s_pos[threadIdx.x] = active ? pos : -1 - (int)threadIdx.x;
+        s_lab[threadIdx.x] = lab;
+        __syncthreads();
+    }
+    float a = 0.f, bsum = 0.f;
+    if (active) {
+        const long row = bp * p.T + pos;
+        float lam[16];
+        if (p.E == 16) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(p.lam + row * 16 + e);
+                lam[e] = v.x; lam[e + 1] = v.y; lam[e + 2] = v.z; lam[e + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { lam[e] = p.lam[row * p.E + min(e, p.E - 1)]; asm volatile("" : "+v"(lam[e])); }
+        }
+        const float sp = p.mpos ? raw_span(p.ts + (long)b * p.T, pos, p.T)
+                                : p.ts[(long)b * (p.T + 1) + pos + 1] - p.ts[(long)b * (p.T + 1) + pos];
+        // other slots of this position: any earlier one (then this slot is not the writer), any later one (rare)
+        const int base = G ? (int)threadIdx.x - m : 0;
+        bool head = true, later = false;
+        if (p.mpos)
+            for (int q = 0; q < p.M; ++q) {
+                const bool same = (G ? s_pos[base + q] : (int)mp[q]) == pos;
+                head = head && !(same && q < m);
+                later = later || (same && q > m);
+            }
+        float gr[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gr[e] = 0.f;
+        // this slot, then (first slot of a repeated position only) the later slots of the same position
+        const int q_end = (head && later) ? p.M : m + 1;
+        for (int q = m; q < q_end; ++q) {
+            if (q != m && (G ? s_pos[base + q] : (int)mp[q]) != pos) continue;
+            const int lq = q == m ? lab : (G ? s_lab[base + q] : (int)p.labels[(long)b * p.M + q]);
+            const uint8_t* nm = p.mtab + (long)lq * p.E;
+            uint32_t mw[4];
+            if (p.E == 16 && ((uintptr_t)p.mtab & 15) == 0) {
+                const uint4 w = *reinterpret_cast<const uint4*>(nm);
+                mw[0] = w.x; mw[1] = w.y; mw[2] = w.z; mw[3] = w.w;
+            } else {
+                uint32_t by[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { by[e] = nm[min(e, p.E - 1)]; asm volatile("" : "+v"(by[e])); }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) mw[jj] = by[4 * jj] | (by[4 * jj + 1] << 8) | (by[4 * jj + 2] << 16) | (by[4 * jj + 3] << 24);
+            }
+            float cnt = 0.f, ev = 0.f, ent = 0.f, f[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                f[e] = e < p.E ? (float)((mw[e >> 2] >> (8 * (e & 3))) & 0xffu) : 0.f;
+                cnt += f[e]; ev += lam[e] * f[e]; ent += e < p.E ? lam[e] : 0.f;
+            }
+            const float g = cnt > 0.f ? 1.f : 0.f;  // sign(sum nm), temporal.py:321
+            ev *= g; ent *= g;
+            if (q == m) {
+                a = __logf(ev == 0.f ? 1.f : ev);       // :324
+                bsum = ent * sp * 0.5f;                 // :327-328
+            }
+            const float iev = ev != 0.f ? 1.0f / ev : 0.f, kg = k * g, hs = sp * 0.5f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) gr[e] += kg * (f[e] * iev - hs);
+        }
+        if (head && d_lam) {
+            float* dst = d_lam + row * p.E;
+            if (p.E == 16) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) *reinterpret_cast<float4*>(dst + e) = make_float4(gr[e], gr[e + 1], gr[e + 2], gr[e + 3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (e < p.E) dst[e] = gr[e];
+            }
+        }
+    }
+    a = block_sum(a, red); bsum = block_sum(bsum, red);
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = a; part[blockIdx.x * 2 + 1] = bsum; }
+}
 __global__ __launch_bounds__(256) void tpp_final2_kernel(const float* part, int nblk, float coef, int H, float* sums, float* reg_out,
                                                          int accumulate) {
     // one workgroup: thread i adds partials i, i+256, ... in index order, then the fixed block_sum tree — deterministic
@@ -414,10 +520,11 @@ struct RedBatch { RedJob j[RED_MAX_JOBS]; int n, blocks; };
 thread_local bool g_red_defer = false;
 thread_local RedBatch g_red_batch = {};
 
-// 32 columns x RL partial-row lanes per workgroup.  RL = 8 (256 threads) for the usual job lists (24-512 partial rows);
-// RL = 32 (1024 threads) when a list holds a deep job (the 1616 partial rows of the mark-embedding gradient were a chain of
-// 50 dependent loads per thread with 8 lanes) — 1024-thread workgroups are slow to place next to other kernels, so they are
-// used only then.
+// 32 columns per workgroup.  Scalar form: one column per thread x RL partial-row lanes (RL = 8, or 32 when a list holds a deep job:
+// the 1616 partial rows of the mark-embedding gradient were a chain of 50 dependent loads per thread with 8 lanes).
+// Vector form (every job of the list has N, ld and both pointers multiples of four floats — the layouts of all producers here):
+// 8 float4 column groups x 32 row lanes in 256 threads, eight loads in flight per thread: a 512-row job is two rounds of loads
+// instead of sixteen (the scalar list of the headline step took 26 us for ~12 MB: latency, not bandwidth).
 template <int RL>
 __global__ __launch_bounds__(32 * RL) void reduce_rows_multi_kernel(RedBatch b) {
     __shared__ float sm[RL][33];
@@ -451,11 +558,56 @@ __global__ __launch_bounds__(32 * RL) void reduce_rows_multi_kernel(RedBatch b) 
     }
 }
 
+__global__ __launch_bounds__(256) void reduce_rows_multi_vec_kernel(RedBatch b) {
+    __shared__ float4 sm[32][9];
+    int ji = 0;
+    for (int i = 1; i < b.n; ++i)
+        if ((int)blockIdx.x >= b.j[i].blk0) ji = i;
+    const RedJob& jb = b.j[ji];
+    const int P = jb.P, N = jb.N;
+    const long ld = jb.ld;
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;          // float4 column group, row lane
+    const int n = ((int)blockIdx.x - jb.blk0) * 32 + 4 * tx;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) {
+        const float* base = jb.part + n;
+        int p = ty;
+        for (; p + 7 * 32 < P; p += 8 * 32) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (long)(p + 32 * u) * ld);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; p < P; p += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)p * ld);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    sm[ty][tx] = acc;
+    __syncthreads();
+    if (ty < 4 && n < N) {       // 32 threads finish the 32 columns: thread (ty, tx) takes component ty of group tx
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float4 v = sm[i][tx];
+            s += ty == 0 ? v.x : (ty == 1 ? v.y : (ty == 2 ? v.z : v.w));
+        }
+        jb.out[n + ty] = s;
+    }
+}
+
 int edgl_reduce_flush_impl(hipStream_t st) {
     if (g_red_batch.n == 0) return EDGL_OK;
     int maxp = 0;
-    for (int i = 0; i < g_red_batch.n; ++i) maxp = std::max(maxp, g_red_batch.j[i].P);
-    if (maxp > 1024) hipLaunchKernelGGL(reduce_rows_multi_kernel<32>, dim3(g_red_batch.blocks), dim3(1024), 0, st, g_red_batch);
+    bool vec = true;
+    for (int i = 0; i < g_red_batch.n; ++i) {
+        const RedJob& j = g_red_batch.j[i];
+        maxp = std::max(maxp, j.P);
+        vec = vec && (j.N & 3) == 0 && (j.ld & 3) == 0 && (((uintptr_t)j.part | (uintptr_t)j.out) & 15) == 0;
+    }
+    if (vec) hipLaunchKernelGGL(reduce_rows_multi_vec_kernel, dim3(g_red_batch.blocks), dim3(256), 0, st, g_red_batch);
+    else if (maxp > 1024) hipLaunchKernelGGL(reduce_rows_multi_kernel<32>, dim3(g_red_batch.blocks), dim3(1024), 0, st, g_red_batch);
     else hipLaunchKernelGGL(reduce_rows_multi_kernel<8>, dim3(g_red_batch.blocks), dim3(256), 0, st, g_red_batch);
     g_red_batch.n = 0;
     g_red_batch.blocks = 0;
@@ -570,6 +722,27 @@ extern "C" int edgl_tpp_fwd_bwd_ex(const float* lam, const int64_t* masked_pos, 
     hipStream_t st = (hipStream_t)stream;
     const int nblk = std::min(TPP_FUSED_BLOCKS, H * B);
     hipLaunchKernelGGL(tpp_fused_kernel, dim3(nblk), dim3(128), 0, st, p, sums, sums + 8, d_lam);
+    EDGL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tpp_final2_kernel, dim3(1), dim3(256), 0, st, sums + 8, nblk, coef, H, sums, reg_out, accumulate);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+// edgl_tpp_fwd_bwd_ex (with_norm = 0) for a d_lam array that ALREADY HOLDS ZEROS (edgl_bimau_fwd_zr): one thread per masked
+// slot, only the rows of masked positions are written.  `sums` needs edgl_tpp_rows_workspace(B, H, M) floats.
+static long tpp_rows_blocks(int B, int H, int M) {
+    return M <= 256 ? ((long)H * B + 256 / M - 1) / (256 / M) : ((long)H * B * M + 255) / 256;
+}
+extern "C" long edgl_tpp_rows_workspace(int B, int H, int M) { return (B > 0 && H > 0 && M > 0) ? 8 + 2 * tpp_rows_blocks(B, H, M) : -1; }
+extern "C" int edgl_tpp_fwd_bwd_rows(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                                     const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
+                                     float* reg_out, int accumulate, float* d_lam, void* stream) {
+    EDGL_REQUIRE(lam && labels && ts_raw && mark_table && sums && reg_out, EDGL_ERR_NULL, "edgl_tpp_fwd_bwd_rows: null pointer");
+    EDGL_REQUIRE(masked_pos || M == T, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd_rows: all-position mode needs M == T");
+    EDGL_REQUIRE(E >= 1 && E <= 16 && B > 0 && H > 0 && M > 0, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd_rows: bad shape E=%d B=%d H=%d M=%d", E, B, H, M);
+    TppP p{lam, masked_pos, labels, ts_raw, mark_table, B, T, H, E, M, coef};
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)tpp_rows_blocks(B, H, M);
+    hipLaunchKernelGGL(tpp_rows_kernel, dim3(nblk), dim3(256), 0, st, p, sums, sums + 8, d_lam);
     EDGL_LAUNCH_CHECK();
     hipLaunchKernelGGL(tpp_final2_kernel, dim3(1), dim3(256), 0, st, sums + 8, nblk, coef, H, sums, reg_out, accumulate);
     EDGL_LAUNCH_CHECK();

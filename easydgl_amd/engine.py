@@ -65,7 +65,7 @@ class TrainEngine:
                      pack=e(lib.edgl_bimau_pack_bytes(C, H, E, self.code), dtype=torch.uint8),
                      saved=e(lib.edgl_bimau_saved_bytes(B, T, C, H, self.code), dtype=torch.uint8),
                      dlam=e(H * B, T, E, dtype=f32),
-                     tpp=torch.zeros(lib.edgl_tpp_workspace(), device=dev, dtype=f32))   # [3]: ticket of edgl_tpp_fwd_bwd
+                     tpp=torch.zeros(max(lib.edgl_tpp_workspace(), lib.edgl_tpp_rows_workspace(B, H, M)), device=dev, dtype=f32))
             self.blk.append(d)
         self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
         # fused per-sample block tail (csrc/k_tail.hip): one launch for dense -> LN -> GELU-dense -> dense -> LN (-> head)
@@ -218,13 +218,16 @@ class TrainEngine:
             if i == 0:
                 main.wait_event(ev_pack)
             da = drop(ad, 10 + 4 * i)
-            check(lib.edgl_bimau_fwd(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
-                                     _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
-                                     _ptr(b["lam"]), _ptr(b["saved"]), 0, code, st), "edgl_bimau_fwd")
-            if m.ct_reg != 0.0:   # TPP regulariser of this block: loss term and d lambda (three small launches)
-                check(lib.edgl_tpp_fwd_bwd_ex(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
-                                              _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
-                                              _ptr(self.loss_tpp), 1 if i > 0 else 0, _ptr(b["dlam"]), 0, st), "edgl_tpp_fwd_bwd_ex")
+            # the forward also zero-fills this block's d lambda buffer (free beside its VALU work): the TPP launch then writes
+            # the rows of the masked positions only — 5 MB instead of 26 MB at the headline shape
+            check(lib.edgl_bimau_fwd_zr(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
+                                        _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
+                                        _ptr(b["lam"]), _ptr(b["saved"]), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, 0, code, st),
+                  "edgl_bimau_fwd_zr")
+            if m.ct_reg != 0.0:   # TPP regulariser of this block: loss term and d lambda (two small launches)
+                check(lib.edgl_tpp_fwd_bwd_rows(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
+                                                _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
+                                                _ptr(self.loss_tpp), 1 if i > 0 else 0, _ptr(b["dlam"]), st), "edgl_tpp_fwd_bwd_rows")
             if self.fused_tail:
                 last = i == len(self.blk) - 1
                 pk = self.tail_pack[i]

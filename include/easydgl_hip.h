@@ -176,6 +176,12 @@ int edgl_bimau_fwd(const void* qkvt, const void* resid, int ld_res, const int64_
                    const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E, float drop_rate,
                    const uint64_t* rng_state, uint32_t stream_id, void* out, float* lam_out, void* saved,
                    int flags, int dtype, void* stream);
+/* edgl_bimau_fwd that also fills `zero_rows` (f32 [H*B,T,E], may be NULL) with zeros — the training engine's d lambda buffer, of
+ * which edgl_tpp_fwd_bwd_rows then writes the masked positions only (the forward is VALU bound: the extra stores are free). */
+int edgl_bimau_fwd_zr(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
+                      const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E, float drop_rate,
+                      const uint64_t* rng_state, uint32_t stream_id, void* out, float* lam_out, void* saved,
+                      float* zero_rows, int flags, int dtype, void* stream);
 
 /* Backward.  d_out [B,T,C] `dtype`; d_lam_ext f32 [H*B,T,E] or NULL (gradient
  * from the TPP regulariser); lam / saved: the forward's lam_out and `saved` buffer.  Writes d_qkvt [B,T,4C] `dtype` and the f32 weight gradients dW1
@@ -366,6 +372,13 @@ int edgl_tpp_norm(const int64_t* labels, const uint8_t* mark_table, int B, int M
 int edgl_tpp_fwd_bwd_ex(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                         const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
                         float* reg_out, int accumulate, float* d_lam, int with_norm, void* stream);
+/* edgl_tpp_fwd_bwd_ex(with_norm = 0) for a d_lam array that ALREADY HOLDS ZEROS (edgl_bimau_fwd_zr): one thread per masked slot,
+ * only the rows of masked positions are written (repeated positions: once, summed).  sums: max(edgl_tpp_workspace(),
+ * edgl_tpp_rows_workspace(B, H, M)) floats; edgl_tpp_norm must have run on the same `sums`. */
+long edgl_tpp_rows_workspace(int B, int H, int M);
+int edgl_tpp_fwd_bwd_rows(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
+                          const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
+                          float* reg_out, int accumulate, float* d_lam, void* stream);
 
 /* ---- optimizer — tf.train.AdamOptimizer (Base.py:142-144) over a flat f32 arena ----------------
  * step_state: device uint64[2]: [0] = step count (incremented by this call, so the first call is

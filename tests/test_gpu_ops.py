@@ -537,6 +537,87 @@ def test_tpp_fused_launch_matches_the_reference(repeat):
     assert_close(dlam.cpu().numpy(), lr.grad.numpy(), 1e-5, "tpp dlam (dense)")
 
 
+@pytest.mark.parametrize("E,M,repeat", [(5, 4, False), (5, 4, True), (16, 20, True), (16, 300, False)])
+def test_tpp_rows_launch_matches_the_reference(E, M, repeat):
+    """edgl_tpp_norm + edgl_tpp_fwd_bwd_rows (the engine's form: one thread per masked slot, d lambda pre-zeroed by
+    edgl_bimau_fwd_zr — here by the test) against the fp64 oracle: rows of unmasked positions stay zero, a position drawn into two
+    slots gets the sum of its slots' gradients exactly once (EasyDGL.py:157-175), M = 300 slots per sample crosses workgroups."""
+    from easydgl_amd import _lib
+    lib = _lib.lib
+    rng = np.random.default_rng(12 + E + M)
+    B, T, H, NI = 6, max(21, M + 5), 3, 40
+    lam = torch.tensor(rng.uniform(0.2, 2.0, size=(H * B, T, E)), dtype=torch.float32).cuda()
+    mpn = np.stack([rng.choice(T - 1, M, replace=False) + 1 for _ in range(B)])
+    labels = rng.integers(1, NI, size=(B, M)); labels[0, 0] = 0
+    if repeat:
+        mpn[1, 2] = mpn[1, 0]          # the same position twice, two different labels
+        mpn[2, 3] = mpn[2, 1]; labels[2, 3] = 0   # ... and once as a zero-weight padding slot
+        mpn[3, :3] = 0; labels[3, :3] = 0          # padding slots all on position 0
+    mp = torch.tensor(mpn).cuda()
+    ts = np.cumsum(rng.exponential(40.0, size=(B, T)), axis=1).astype(np.float32) + 9.5e8
+    mt = O.synthetic_mark_table(NI, E, multi_hot=True)
+    coef = 0.41
+    sums = torch.zeros(int(max(lib.edgl_tpp_workspace(), lib.edgl_tpp_rows_workspace(B, H, M))), device="cuda")
+    reg = torch.full((1,), 3.0, device="cuda")
+    dlam = torch.zeros((H * B, T, E), device="cuda")
+    lab_t, ts_t, mt_t = torch.tensor(labels).cuda(), torch.tensor(ts).cuda(), torch.tensor(mt.astype(np.uint8)).cuda()
+    for _ in range(2):   # twice: the normaliser accumulator must come back to zero
+        reg.fill_(3.0); dlam.zero_()
+        _lib.check(lib.edgl_tpp_norm(lab_t.data_ptr(), mt_t.data_ptr(), B, M, E, sums.data_ptr(), None), "edgl_tpp_norm")
+        _lib.check(lib.edgl_tpp_fwd_bwd_rows(lam.data_ptr(), mp.data_ptr(), lab_t.data_ptr(), ts_t.data_ptr(), mt_t.data_ptr(), B, T, H,
+                                             E, M, coef, sums.data_ptr(), reg.data_ptr(), 1, dlam.data_ptr(), None), "edgl_tpp_fwd_bwd_rows")
+    torch.cuda.synchronize()
+    lr = lam.double().cpu().requires_grad_()
+    sp = torch.tensor(O.spans_from_times(ts))[torch.arange(B)[:, None], mp.cpu()].repeat(H, 1)
+    nm = torch.tensor(mt[labels], dtype=torch.float64).repeat(H, 1, 1)
+    lg = lr[torch.arange(H * B)[:, None], mp.cpu().repeat(H, 1)]
+    ref = coef * R.biased_likelihood(lg, nm, sp)
+    ref.backward()
+    assert_close(reg.item() - 3.0, ref.item(), 1e-5, "tpp reg (accumulated)")
+    assert_close(dlam.cpu().numpy(), lr.grad.numpy(), 1e-5, "tpp dlam (rows form)")
+
+
+def test_bimau_forward_zero_fills_the_d_lambda_buffer():
+    """edgl_bimau_fwd_zr: same outputs as edgl_bimau_fwd, and the extra [H*B, T, E] array comes back all zero (head dims 16 and 64:
+    fused kernel / memset in front of the three-launch form)."""
+    from easydgl_amd import _lib
+    lib = _lib.lib
+    o = ops()
+    rng = np.random.default_rng(3)
+    for C, H, E, T in ((32, 2, 16, 19), (32, 2, 5, 19), (128, 2, 16, 23)):
+        B = 3
+        qkvt = torch.tensor(rng.standard_normal((B, T, 4 * C)) * 0.3, dtype=torch.bfloat16).cuda()
+        resid = torch.tensor(rng.standard_normal((B, T, C)), dtype=torch.bfloat16).cuda()
+        ids = torch.tensor(rng.integers(1, 30, size=(B, T))).cuda()
+        spans = torch.tensor(rng.uniform(0, 5, size=(B, T)), dtype=torch.float32).cuda()
+        marks = torch.tensor(O.synthetic_mark_table(30, E, multi_hot=True)[ids.cpu().numpy()].astype(np.uint8)).cuda()
+        dh = C // H
+        W1 = torch.tensor(rng.standard_normal((dh + 1, dh * E)) * 0.2, dtype=torch.float32).cuda()
+        b1 = torch.zeros(dh * E, device="cuda"); w = torch.tensor(rng.standard_normal((E, dh)) * 0.3, dtype=torch.float32).cuda()
+        sc = torch.zeros(E, device="cuda")
+        code = o._code(qkvt)
+        pack = torch.empty(lib.edgl_bimau_pack_bytes(C, H, E, code), device="cuda", dtype=torch.uint8)
+        _lib.check(lib.edgl_bimau_pack(W1.data_ptr(), b1.data_ptr(), w.data_ptr(), sc.data_ptr(), C, H, E, pack.data_ptr(), code, None), "pack")
+        saved = torch.empty(lib.edgl_bimau_saved_bytes(B, T, C, H, code), device="cuda", dtype=torch.uint8)
+        outs = []
+        for zr in (False, True):
+            out = torch.empty((B, T, C), device="cuda", dtype=torch.bfloat16)
+            lam = torch.empty((H * B, T, E), device="cuda")
+            z = torch.full((H * B, T, E), float("nan"), device="cuda")
+            if zr:
+                _lib.check(lib.edgl_bimau_fwd_zr(qkvt.data_ptr(), resid.data_ptr(), C, ids.data_ptr(), spans.data_ptr(), marks.data_ptr(),
+                                                 pack.data_ptr(), B, T, C, H, E, 0.0, None, 0, out.data_ptr(), lam.data_ptr(),
+                                                 saved.data_ptr(), z.data_ptr(), 0, code, None), "edgl_bimau_fwd_zr")
+            else:
+                _lib.check(lib.edgl_bimau_fwd(qkvt.data_ptr(), resid.data_ptr(), C, ids.data_ptr(), spans.data_ptr(), marks.data_ptr(),
+                                              pack.data_ptr(), B, T, C, H, E, 0.0, None, 0, out.data_ptr(), lam.data_ptr(),
+                                              saved.data_ptr(), 0, code, None), "edgl_bimau_fwd")
+            torch.cuda.synchronize()
+            outs.append((out, lam, z))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert float(outs[1][2].abs().max()) == 0.0, (C, H, E)
+
+
 def test_tpp_fused_launch_all_position_mode():
     """edgl_tpp_fwd_bwd without masked positions (CTSMA's form: every position scored, T + 1 raw timestamps per row) against
     the separate forward / backward kernels behind TppFn."""

@@ -1,18 +1,6 @@
 #!/bin/bash
-# full profile refresh of the round: kernel trace + HBM PMC passes of the step, MFMA / VALU utilisation, K1 encode (zipf, uniform)
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
-bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
-bash tools/profile_mfma.sh > gpurun_out/mfma.log 2>&1
-bash tools/profile_encode.sh zipf > gpurun_out/encode_zipf.log 2>&1
-bash tools/profile_encode.sh uniform > gpurun_out/encode_uniform.log 2>&1
-cd $GRAFT_REPO_ROOT
-python tools/make_profiles.py $TAG
-python tools/make_mfma_profile.py $TAG
-python tools/make_encode_profile.py $TAG zipf
-python tools/make_encode_profile.py $TAG uniform
-mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
-cp gpurun_out/refresh/bench_line.json gpurun_out/profiles_$TAG/${TAG}_bench_line_profiled.json
-# the databases are large: keep only the summaries
-rm -rf gpurun_out/refresh/ktrace gpurun_out/refresh/fetch gpurun_out/refresh/write gpurun_out/mfma/mfma gpurun_out/mfma/valu gpurun_out/encode_*/ktrace gpurun_out/encode_*/fetch gpurun_out/encode_*/write
-ls -la gpurun_out/profiles_$TAG
+python -m pytest tests/test_gpu_ops.py -x -q -k "tpp or zero_fills" 2>&1 | tail -3
+python -m pytest tests/test_gpu_engine.py -x -q 2>&1 | tail -2
+python bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | cut -c1-330
+KT_LINES=1 KT_TIMELINE=step_begin bash tools/ktrace.sh | grep -E "tpp|bimau_fwd|span" | cut -c1-120
