@@ -10,15 +10,22 @@ with f32 accumulation / master weights.  Synthetic data, random
 (`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks; a launcher whose
 WORLD_SIZE differs from --gpus is an error.)
 
-Rank 0 prints ONE JSON line.  `value` = N * 512 * K / (max-over-ranks wall time of the K timed steps); `step_ms_hipevents`
-= median / p10 / p90 of the per-step HIP-event times of the same region.  `roofline` is the dominant kernel's achieved MFMA
-rate: `frac` on ALGORITHMIC FLOPs per launch (one product), `hw_util` on the FLOPs the kernel executes (it also
-recomputes the logits), both over the mean launch time measured with HIP events on the launch stream inside the timed
-region.  `cpu_baseline` / `cpu_baseline_1thread` time the restated reference graph (oracle/torch_ref.py, float32, reference op
-order) on this host's cores (all cores up to 16 / the reference's own single-thread setting) on a bounded sample.  At N = 1
-`extras` adds the secondary rows of SURVEY §8(d): masklen 6, all rows weighted, dropout off, multi-hot marks, the config-3 K1
-encode line (algorithmic and counter-side GB/s) and the sharded-eval step.
+Rank 0 prints ONE JSON line.  The timed steps rotate through 8 distinct synthetic batches resident in HBM (the engine is pointed
+at them: no copies).  `value` = N * 512 * K / (max-over-ranks wall time of the K timed steps); `step_ms_hipevents` = median /
+p10 / p90 of HIP-event times of groups of 5 steps of the same region.  `roofline` is the dominant kernel's achieved MFMA rate —
+strip_kernel<ROLE_YF>, the row-side pass of the fused scoring / cross-entropy: ALGORITHMIC FLOPs per launch (both of its products,
+at the mean weighted-row count of the bracketed batches) over the mean launch time measured with HIP events on the launch stream
+inside the timed region; `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/).
+`roofline_attention` does the same for the K3 BiMAU forward launch and its three backward passes (the brackets rotate: one
+kernel id per step), with the PMC pipe utilisation of those kernels beside it.  `cpu_baseline` times the restated reference graph
+(oracle/torch_ref.py, float32, reference op order) on this host's cores at the same batch of 512 on a bounded sample;
+`cpu_baseline_1thread_batch16` is the reference's own single-thread setting.  At N = 1 `extras` adds the secondary rows of SURVEY
+§8(d): masklen 6, all rows weighted, dropout off, multi-hot marks, uniform item ids, the device masker inside the step, the
+published recipe's shape, the config-3 K1 encode line with Zipf and uniform ids (algorithmic and counter-side GB/s) and the
+sharded-eval step.
 
+    python bench.py --workload recipe            # the published recipe's shape (runme.sh:15-23: 512 units, 8 heads, L = 30, M = 6)
+    python bench.py --workload encode [--ids uniform]    # K1 alone at config 3 (HBM roofline)
     python bench.py --workload eval --gpus N     # row-sharded full-catalogue scoring + RCCL top-K all-gather (|I| = 20K, 1M)
 """
 import argparse
@@ -36,15 +43,20 @@ sys.path.insert(0, ROOT)
 HEADLINE = dict(num_items=20000, seqslen=100, num_units=128, num_heads=8, num_blocks=1, masklen=20,
                 num_events=16, batch=512, time_scale=86400.0, learning_rate=5e-4, l2_reg=1e-4, ct_reg=1e-7,
                 hidden_dropout_rate=0.1, attention_probs_dropout_rate=0.1)
+# the published EasyDGL recipe (runme.sh:15-23 + the defaults of main.py:38,44): 512 units, 8 heads (head dim 64), 1 block,
+# seqslen 30 (T = 31), masklen 6, batch 512, num_items 17771 — `--workload recipe`: the static engine with the unfused block tail
+# (the fused one takes C in {64, 128}), the three-launch BiMAU of k_bimau_big.hip and the 16x16-tile scoring kernels at C = 512
+RECIPE = dict(HEADLINE, num_items=17771, seqslen=30, num_units=512, masklen=6)
 
-# the ONE kernel whose launches in the timed region are bracketed with HIP events on its launch stream — every 4th step:
-# an event record costs ~6 us of stream idle, 13 us per step if every launch were bracketed — (library hook
-# edgl_profile_next): score_bwd_kernel<ROLE_YF> — the row-side pass of the fused scoring / cross-entropy: ONE
-# sweep over the item table computes the [R_w, I] logits, their row log-sum-exp AND the row gradients dl . table
-# (flash-style running maxima; edgl_score_flash_fwd).  The scoring family carries 76 % of the step's algorithmic FLOPs
-# (DESIGN.md §5).  With EDGL_FLASH_CE=0 the same slot times the round-1 kernel (ROLE_Y: d_rows only, logits recomputed).
+# the kernels whose launches in the timed region are bracketed with HIP events on their launch stream (library hook
+# edgl_profile_next) — ONE kernel id per step, rotating through BRACKETS: an event record costs ~6 us of stream idle.  Id 0 is the
+# dominant kernel: strip_kernel<ROLE_YF> — the row-side pass of the fused scoring / cross-entropy: ONE sweep over the item table
+# computes the [R_w, I] logits, their row reference / sum AND the row gradients dl . table (edgl_score_flash_fwd_coef).  The
+# scoring family carries 76 % of the step's algorithmic FLOPs.  With EDGL_SCORE_STRIP=0 the same slot times the
+# round-2 kernel, with EDGL_FLASH_CE=0 the round-1 kernel (ROLE_Y: d_rows only, logits recomputed).
 DOMINANT_KERNEL_ID = 0   # EDGL_KERNEL_SCORE_BWD_ROWS
 DOMINANT_KERNEL = "strip_kernel<ROLE_YF> (bf16, C=128: forward logits + row reference / sum + d_rows = dl . table in one pass)"
+DOMINANT_KERNEL_R2 = "score_bwd_kernel<ROLE_YF> (16x16 MFMA tiles, running row maxima: other widths / dtypes, EDGL_SCORE_STRIP=0)"
 DOMINANT_KERNEL_R1 = "score_bwd_kernel<bf16, C/16=8, ROLE_Y> (d_rows = dl . table, logits recomputed)"
 
 
@@ -280,7 +292,7 @@ def main():
                                                              "config-3 encode, sharded eval) the default N=1 run appends")
     ap.add_argument("--ids", default="zipf", choices=["zipf", "uniform"], help="item-id distribution of the synthetic sequences "
                     "(--workload encode; the step workload reports the uniform variant as an extra)")
-    ap.add_argument("--workload", default="step", choices=["step", "encode", "eval", "tgat", "tisasrec", "ctsma"],
+    ap.add_argument("--workload", default="step", choices=["step", "recipe", "encode", "eval", "tgat", "tisasrec", "ctsma"],
                     help="step: the headline optimizer step (default, the bench contract); encode: K1 input encoding "
                          "(embedding gather + time code) alone at SURVEY §8d config 3 (|items| = 1M, L = 200, d = 256) — the "
                          "HBM-bound regime, reported as GB/s against the HBM roofline")
@@ -321,7 +333,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
-    c = dict(HEADLINE)
+    c = dict(RECIPE if args.workload == "recipe" else HEADLINE)
     from easydgl_amd import _lib
     res = run_step_workload(c, args, dev, rank, world, dist, args.steps, args.warmup, bracket=(args.path != "graph"))
     dt, loss, dom = res["dt"], res["loss"], res["dom"]
@@ -349,7 +361,7 @@ def main():
         traffic = None   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         for tp in ("r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
-            if args.dtype == "bf16" and os.path.exists(tpath):
+            if args.dtype == "bf16" and args.workload == "step" and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 break
         ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -370,15 +382,16 @@ def main():
                         "frac": round(fl / (t_ms * 1e-3) / 1e12 / peak, 4) if t_ms > 0 else 0.0, "launches_timed": n_k}
         pu = os.path.join(ROOT, "profiles", "r03_mfma_valu_util.json")
         out = {
-            "metric": "sequences/sec (fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K",
+            "metric": "sequences/sec (fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K" if args.workload != "recipe" else
+                      "sequences/sec (fwd+bwd+Adam) published recipe runme.sh:15-23: B=512 L=30 d=512 h=8 M=6 |I|=17.8K",
             "value": round(world * c["batch"] * args.steps / dt, 2),
             "unit": "sequences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "EasyDGL optimizer step, per-GPU batch 512, seqslen 100 (T=101), num_units 128, 8 heads, "
-                                   "1 block, num_items 20000 (I=20001), masklen 20, 16 marks, dropout 0.1/0.1, ct_reg 1e-7, l2 1e-4",
+            "config": {"workload": f"EasyDGL optimizer step, per-GPU batch {c['batch']}, seqslen {c['seqslen']} (T={T}), num_units {C}, {h} heads, "
+                                   f"{nb} block, num_items {c['num_items']} (I={I}), masklen {M}, {E} marks, dropout 0.1/0.1, ct_reg 1e-7, l2 1e-4",
                        "global_batch": world * c["batch"], "parallelism": f"dp{world}",
                        "batches_rotated": NBATCH,
                        "algorithmic_gflop_per_step_all_rows": round(3 * flops_per_seq(c) * c["batch"] / 1e9, 1),
@@ -387,7 +400,8 @@ def main():
             "step_ms_hipevents": {"median": round(float(np.median(ms)), 4), "p10": round(float(np.percentile(ms, 10)), 4),
                                   "p90": round(float(np.percentile(ms, 90)), 4), "n": len(ms),
                                   "note": "mean step time of groups of 5 consecutive steps (one event record per group)"},
-            "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL if flash else DOMINANT_KERNEL_R1,
+            "roofline": {"bound": "mfma", "kernel": (DOMINANT_KERNEL if C == 128 and args.dtype == "bf16" and os.environ.get("EDGL_SCORE_STRIP", "1") != "0"
+                                                      else DOMINANT_KERNEL_R2) if flash else DOMINANT_KERNEL_R1,
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "hw_util": round(dom_exec / (dom_ms * 1e-3) / 1e12 / peak, 4) if dom_ms > 0 else 0.0,
                          "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "executed_flop": dom_exec,
@@ -548,6 +562,8 @@ def extras(c, args, dev):
     out["uniform_ids"] = row(c, ids="uniform")
     # row a-1 inside the step: the masked positions of every batch are drawn on the device (edgl_mask_random) right before it
     out["with_device_masker"] = row(c, device_masker=True)
+    # the published recipe's shape (runme.sh:15-23) through the same engine: `python bench.py --workload recipe` prints it as a line
+    out["recipe_runme_sh"] = dict(row(dict(RECIPE)), workload="num_units 512, 8 heads, seqslen 30, masklen 6, batch 512, num_items 17771")
     torch.cuda.empty_cache()
     a3 = copy.copy(args)
     a3.steps, a3.warmup = 50, 10

@@ -449,7 +449,10 @@ constexpr int G_BM = 128, G_BN = 128, G_BK = 64, G_NT = 256;
 constexpr int G_LDK = G_BK + 8;      // [rows][k] images (A; B when k-contiguous)
 constexpr int G_LDN = G_BN + 16;     // [k][n] image (B when n-contiguous: transpose reads)
 constexpr int G_LDO = G_BN + 8;      // output staging [128][128]
-template <bool B_KC>
+// EPI = false: bias-only epilogue, bf16 output staged through LDS.  EPI = true: every epilogue of epi_store4 (GELU / ReLU with
+// the saved pre-activation, x GELU', accumulate, f32 output) written straight from the accumulator fragments (8 / 16 bytes per
+// lane) — the wide layers of the 512-unit recipes (K = 1024 / 1536 / 2048), which the register-strip kernels (K <= 512) do not take.
+template <bool B_KC, bool EPI = false>
 __global__ __launch_bounds__(G_NT, 2) void tile_nn_kernel(StripP p) {
     constexpr int A_EL = G_BM * G_LDK, B_EL = B_KC ? G_BN * G_LDK : G_BK * G_LDN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -518,6 +521,19 @@ __global__ __launch_bounds__(G_NT, 2) void tile_nn_kernel(StripP p) {
         if (st + 1 < nstep) G_STORE(buf ^ 1)   // that buffer was last read in step st - 1 (barrier below, one step back)
         lds_barrier();
     }
+    if constexpr (EPI) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + g4;
+                float x[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (m < p.M) epi_store4(p.epi, reinterpret_cast<bf16*>(p.C), p.C, (long)m * p.ldc + n, n, x);
+            }
+        }
+        return;
+    }
     // ---- epilogue: bias, bf16, through LDS, whole 256-byte row segments -------------------------------------------------
     bf16* Os = reinterpret_cast<bf16*>(smem);   // [128][G_LDO] over the operand buffers (all reads are behind the last barrier)
 #pragma unroll
@@ -545,11 +561,11 @@ __global__ __launch_bounds__(G_NT, 2) void tile_nn_kernel(StripP p) {
 #undef G_STORE
 }
 
-template <bool B_KC>
+template <bool B_KC, bool EPI = false>
 static int launch_tile_nn(const StripP& p, hipStream_t st) {
     constexpr size_t a_el = (size_t)G_BM * G_LDK, b_el = B_KC ? (size_t)G_BN * G_LDK : (size_t)G_BK * G_LDN;
     const size_t smem = std::max(2 * (a_el + b_el) * sizeof(bf16), (size_t)G_BM * G_LDO * sizeof(bf16));
-    auto k = tile_nn_kernel<B_KC>;
+    auto k = tile_nn_kernel<B_KC, EPI>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const int nbm = (p.M + G_BM - 1) / G_BM, nbn = p.N / G_BN;
     hipLaunchKernelGGL(k, dim3((unsigned)(nbm * nbn)), dim3(G_NT), smem, st, p);
@@ -718,7 +734,7 @@ static int launch_strip(const StripP& p, hipStream_t st) {
 // returns 1 if the fast path was taken, 0 if the shape does not qualify, <0 on error
 int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int b_kc,
                          const float* bias, void* aux, int flags, hipStream_t st) {
-    const bool ok = (K % 32 == 0) && K >= 32 && K <= 512 && (N % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
+    const bool ok = (K % 32 == 0) && K >= 32 && (N % 64 == 0) && (lda % 8 == 0) && (ldb % 8 == 0) &&
                     (ldc % 4 == 0) && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 &&
                     (!aux || ((uintptr_t)aux & 7) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
     if (!ok) return 0;
@@ -730,6 +746,12 @@ int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, in
     if (use_tile && M >= 4096 && N >= 256 && (N % G_BN) == 0 && (K % G_BK) == 0 && K >= 128 && (flags & ~EDGL_EPI_BIAS) == 0 &&
         (ldc % 8) == 0)
         return b_kc ? launch_tile_nn<true>(p, st) : launch_tile_nn<false>(p, st);
+    // beyond the register strips (K <= 512): the tiled kernel with the general epilogue
+    if (K > 512) {
+        if (use_tile && M >= 1024 && (N % G_BN) == 0 && (K % G_BK) == 0)
+            return b_kc ? launch_tile_nn<true, true>(p, st) : launch_tile_nn<false, true>(p, st);
+        return 0;
+    }
     static const int stream_min_n = getenv("EDGL_GEMM_STREAM_N") ? atoi(getenv("EDGL_GEMM_STREAM_N")) : 384;
     if (N >= stream_min_n && (K == 384 || K == 512) && M >= 4096) {   // A would be re-read by >= 3 column slices
         rc = 0;
@@ -741,9 +763,12 @@ int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, in
     case NKB: rc = b_kc ? launch_strip<NKB, true>(p, st) : launch_strip<NKB, false>(p, st); break;
     switch (K / 32) {
         STRIP_CASE(1) STRIP_CASE(2) STRIP_CASE(4) STRIP_CASE(8) STRIP_CASE(12) STRIP_CASE(16)
-        default: return 0;
+        default: rc = 0;
     }
 #undef STRIP_CASE
+    // shapes the strips decline (their weight slice + staging exceed the LDS, e.g. K = 512 with N = 1024 and an epilogue)
+    if (rc == 0 && use_tile && M >= 1024 && (N % G_BN) == 0 && (K % G_BK) == 0 && K >= 128)
+        return b_kc ? launch_tile_nn<true, true>(p, st) : launch_tile_nn<false, true>(p, st);
     return rc;
 }
 

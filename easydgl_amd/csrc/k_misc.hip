@@ -515,8 +515,11 @@ inline int grid_for(long n) { return (int)std::min<long>((n + 255) / 256, 4096);
 // alive (distinct workspaces) until the flush.  Jobs that accumulate into `out` flush first and run immediately, so the
 // order of read-modify-write updates is preserved.
 constexpr int RED_MAX_JOBS = 24;
+constexpr int RED_COL_P = 32;      // jobs with at most this many partial rows run in the column form of the vector kernel
 struct RedJob { const float* part; float* out; long ld; int P, N, blk0; };
 struct RedBatch { RedJob j[RED_MAX_JOBS]; int n, blocks; };
+static inline int red_blocks_scalar(const RedJob& j) { return (j.N + 31) / 32; }
+static inline int red_blocks_vec(const RedJob& j) { return j.P <= RED_COL_P ? (j.N + 1023) / 1024 : (j.N + 31) / 32; }
 thread_local bool g_red_defer = false;
 thread_local RedBatch g_red_batch = {};
 
@@ -566,6 +569,29 @@ __global__ __launch_bounds__(256) void reduce_rows_multi_vec_kernel(RedBatch b) 
     const RedJob& jb = b.j[ji];
     const int P = jb.P, N = jb.N;
     const long ld = jb.ld;
+    if (P <= RED_COL_P) {
+        // few partial rows (the row splits of a weight-gradient GEMM: 2-24 slabs of up to 3 M elements): a thread owns one
+        // float4 column and adds its P values — 4 KB of consecutive bytes per row and workgroup, 32x fewer workgroups than the
+        // row-lane form, whose 32 lanes per column would mostly idle (the 512-unit recipe's lists took 213 us for 143 MB)
+        const int n = (((int)blockIdx.x - jb.blk0) * 256 + (int)threadIdx.x) * 4;
+        if (n >= N) return;
+        const float* base = jb.part + n;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int p0 = 0;
+        for (; p0 + 8 <= P; p0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (long)(p0 + u) * ld);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; p0 < P; ++p0) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)p0 * ld);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(jb.out + n) = acc;
+        return;
+    }
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;          // float4 column group, row lane
     const int n = ((int)blockIdx.x - jb.blk0) * 32 + 4 * tx;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -606,6 +632,13 @@ int edgl_reduce_flush_impl(hipStream_t st) {
         maxp = std::max(maxp, j.P);
         vec = vec && (j.N & 3) == 0 && (j.ld & 3) == 0 && (((uintptr_t)j.part | (uintptr_t)j.out) & 15) == 0;
     }
+    int blocks = 0;      // first-block index of every job for the kernel form chosen
+    for (int i = 0; i < g_red_batch.n; ++i) {
+        RedJob& j = g_red_batch.j[i];
+        j.blk0 = blocks;
+        blocks += vec ? red_blocks_vec(j) : red_blocks_scalar(j);
+    }
+    g_red_batch.blocks = blocks;
     if (vec) hipLaunchKernelGGL(reduce_rows_multi_vec_kernel, dim3(g_red_batch.blocks), dim3(256), 0, st, g_red_batch);
     else if (maxp > 1024) hipLaunchKernelGGL(reduce_rows_multi_kernel<32>, dim3(g_red_batch.blocks), dim3(1024), 0, st, g_red_batch);
     else hipLaunchKernelGGL(reduce_rows_multi_kernel<8>, dim3(g_red_batch.blocks), dim3(256), 0, st, g_red_batch);

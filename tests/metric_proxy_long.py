@@ -125,13 +125,23 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["oracle", "hip"])
     ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--seeds", type=int, nargs="+", default=[101, 202, 303])
+    ap.add_argument("--seeds", type=int, nargs="+", default=None, help="dropout seeds (default: oracle 101 202 303; hip: the fixture's)")
+    ap.add_argument("--merge", default=None, help="oracle: a second result file whose runs are appended to the fixture")
     ap.add_argument("--modes", nargs="+", default=["bf16", "f32"])
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
+    if a.what == "oracle" and a.merge:
+        res, more = json.load(open(a.out or FIXTURE)), json.load(open(a.merge))
+        assert res["config"] == more["config"]
+        res["runs"] += [r for r in more["runs"] if r["seed"] not in {x["seed"] for x in res["runs"]}]
+        res["summary"] = summarise(res["runs"])
+        with open(a.out or FIXTURE, "w") as f:
+            f.write(json.dumps(res, indent=1) + "\n")
+        print(json.dumps(res["summary"], indent=1))
+        return
     if a.what == "oracle":
         prob = problem(a.steps)
-        runs = [run_oracle(prob, s) for s in a.seeds]
+        runs = [run_oracle(prob, s) for s in (a.seeds or [101, 202, 303])]
         res = {"config": dict(**SHAPE, **RECIPE, batch=BATCH, steps=a.steps, n_eval=N_EVAL, data_seed=DATA_SEED),
                "generated_by": "python tests/metric_proxy_long.py oracle", "runs": runs, "summary": summarise(runs)}
         with open(a.out or FIXTURE, "w") as f:
@@ -141,8 +151,9 @@ def main():
     ref = json.load(open(FIXTURE))
     prob = problem(ref["config"]["steps"])
     res = {"config": ref["config"], "ref": {"runs": ref["runs"], "summary": ref["summary"]}}
+    seeds = a.seeds or [r["seed"] for r in ref["runs"]]
     for mode in a.modes:
-        runs = [run_hip(prob, mode, s) for s in a.seeds]
+        runs = [run_hip(prob, mode, s) for s in seeds]
         res[mode] = {"runs": runs, "summary": summarise(runs)}
     res["comparison"] = compare(res)
     txt = json.dumps(res, indent=1)

@@ -43,7 +43,10 @@ def test_gemm_layouts(name, dt, tol, a_kc, b_kc, M, N, K):
 
 @pytest.mark.parametrize("b_kc", [0, 1])
 @pytest.mark.parametrize("M,N,K,flags", [(4100, 512, 384, "bias"), (4352, 384, 512, "plain"), (4100, 384, 384, "gelu"),
-                                         (4100, 512, 512, "accum"), (300, 128, 128, "dgelu"), (5000, 256, 128, "accum")])
+                                         (4100, 512, 512, "accum"), (300, 128, 128, "dgelu"), (5000, 256, 128, "accum"),
+                                         # the wide layers of the 512-unit recipes (K > 512: tiled kernel, general epilogue)
+                                         (2100, 2048, 1536, "bias"), (1500, 512, 1024, "plain"), (1100, 1024, 1024, "gelu"),
+                                         (1300, 512, 1024, "accum"), (1030, 1536, 2048, "dgelu")])
 def test_gemm_bf16_activation_kernels(b_kc, M, N, K, flags):
     """bf16 dense fast paths at sizes that reach them: weights-resident strips, the weights-streamed kernel for wide
     outputs (M >= 4096, K in {384, 512}, N >= 384), and the fused epilogues (bias, GELU + saved pre-activation,
@@ -767,3 +770,42 @@ def test_score_flash_matches_the_two_pass_kernels(name, dt, tol, R_, C, I):
     assert float(coef2[n:].abs().max()) == 0.0 if n < R_ else True
     check(lib.edgl_ce_loss_fwd_add(p(lse1), p(ll1), p(lab_c), R_, p(loss2), None, None, None, st))
     assert float(loss1) == float(loss2)
+
+
+def test_deferred_reductions_match_the_immediate_ones():
+    """edgl_reduce_defer(1) ... edgl_reduce_flush: one launch for every queued slab reduction — the column form for the few row
+    splits of a weight-gradient GEMM (2-24 slabs), the row-lane form for deep lists (one partial row per sample of a LayerNorm
+    backward) — against the same calls reduced immediately."""
+    from easydgl_amd import _lib as L
+    lib = L.lib
+    o = ops()
+    shapes = [(4096, 512, 512), (2048, 1536, 2048), (640, 128, 256), (16384, 128, 128)]
+    res = {}
+    for mode in ("now", "deferred"):
+        outs = []
+        if mode == "deferred":
+            L.check(lib.edgl_reduce_defer(1, None), "defer")
+        keep = []
+        for R_, Kf, N in shapes:
+            g = np.random.default_rng(R_ + Kf + N)
+            X = torch.tensor(_rand((R_, Kf), g), dtype=torch.bfloat16).cuda()
+            dY = torch.tensor(_rand((R_, N), g, 0.1), dtype=torch.bfloat16).cuda()
+            both = torch.full((Kf * N + N,), float("nan"), device="cuda")
+            ws = torch.empty(lib.edgl_gemm_dw_workspace(R_, Kf, N, L.BF16), device="cuda")
+            L.check(lib.edgl_gemm_dw(X.data_ptr(), dY.data_ptr(), both.data_ptr(), both.data_ptr() + 4 * Kf * N, R_, Kf, N, Kf, N, 0,
+                                     ws.data_ptr(), L.BF16, None), "edgl_gemm_dw")
+            keep.append((X, dY, ws))
+            outs.append(both)
+        # a deep job next to them: LayerNorm backward partials, one row per sample
+        B, T, C = 300, 9, 64
+        x = torch.tensor(_rand((B, T, C), np.random.default_rng(5)), dtype=torch.float32).cuda().requires_grad_()
+        gam = torch.ones(C, device="cuda", requires_grad=True); bet = torch.zeros(C, device="cuda", requires_grad=True)
+        y = o.AddLayerNormFn.apply(x, None, gam, bet, o.NO_DROP, None)
+        (y * y).sum().backward()
+        if mode == "deferred":
+            L.check(lib.edgl_reduce_defer(0, None), "flush")
+        torch.cuda.synchronize()
+        res[mode] = [t.clone() for t in outs] + [gam.grad.clone(), bet.grad.clone()]
+    for a, b in zip(res["now"], res["deferred"]):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 1e-5 * (1.0 + float(a.abs().max()))

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_ops.py -x -q -k "tpp or zero_fills" 2>&1 | tail -3
-python -m pytest tests/test_gpu_engine.py -x -q 2>&1 | tail -2
-python bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | cut -c1-330
-KT_LINES=1 KT_TIMELINE=step_begin bash tools/ktrace.sh | grep -E "tpp|bimau_fwd|span" | cut -c1-120
+python -m pytest tests/test_gpu_ops.py -x -q -k "deferred or gemm" 2>&1 | tail -3
+python -m pytest tests/test_gpu_model.py tests/test_gpu_engine.py tests/test_gpu_headline_parity.py -x -q 2>&1 | tail -2
+KT_LINES=8 bash tools/ktrace.sh --workload recipe | cut -c1-170
+KT_LINES=1 KT_TIMELINE=step_begin bash tools/ktrace.sh | grep -E "reduce|span|metric" | cut -c1-200
