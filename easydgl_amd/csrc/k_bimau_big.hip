@@ -251,14 +251,38 @@ __global__ __launch_bounds__(256) void intensity_bwd_weights_big_kernel(IntP p) 
 #pragma unroll
         for (int ub = 0; ub < DT; ++ub) dW[jj][ub] = zero4;
     }
-    for (long t = (long)blockIdx.x * 4 + wave; t < ntile; t += (long)gridDim.x * 4) {
+    // Operands of a row tile — the H rows, the intervals, dz of the (at most two) marks this channel group spans — are fetched ONE
+    // TILE AHEAD with unconditional, clamped loads and masked when consumed: with `ok ? load : 0` per value every tile paid three
+    // dependent round trips (32 tiles per wave: 235 us at the 512-unit recipe shape, ~6 us per tile for ~2 us of arithmetic).
+    struct Pre { Frag4<T> hA[DT]; float spn[4]; float dz0[4], dz1[4]; };
+    const int e_lo = min(j0 / dh, EP - 1), e_hi = min(e_lo + 1, EP - 1);
+    auto load_tile = [&](long t) {
+        Pre o;
+        t = min(t, ntile - 1);
         const long bpq = t / ntq; const int qt = (int)(t - bpq * ntq), bb = (int)(bpq % p.B);
-        const long row0 = bpq * p.T + qt * 16;
+        const long rowq = bpq * p.T;
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) o.hA[ub] = frag_ld<T>(hin + (rowq + min(qt * 16 + l15, p.T - 1)) * dh + ub * 16 + g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = min(qt * 16 + g4 + r, p.T - 1);
+            o.spn[r] = p.spans[(long)bb * p.T + q];
+            o.dz0[r] = p.dz[(rowq + q) * EP + e_lo];
+            o.dz1[r] = p.dz[(rowq + q) * EP + e_hi];
+        }
+        return o;
+    };
+    const long tstep = (long)gridDim.x * 4;
+    long t = (long)blockIdx.x * 4 + wave;
+    Pre cur = load_tile(t);
+    for (; t < ntile; t += tstep) {
+        const Pre nxt = load_tile(t + tstep);
+        const long bpq = t / ntq; const int qt = (int)(t - bpq * ntq);
         const bool okA = qt * 16 + l15 < p.T;
         Frag4<T> hA[DT], hB[DT];
 #pragma unroll
         for (int ub = 0; ub < DT; ++ub) {
-            hA[ub] = okA ? frag_ld<T>(hin + (row0 + l15) * dh + ub * 16 + g4) : frag_zero<T>();
+            hA[ub] = okA ? cur.hA[ub] : frag_zero<T>();
             hB[ub] = frag_from_acc<T>(mma16(hA[ub], ident, zero4));   // L(first = row, second = u)
         }
         float spn[4];
@@ -266,11 +290,11 @@ __global__ __launch_bounds__(256) void intensity_bwd_weights_big_kernel(IntP p) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             rok[r] = qt * 16 + g4 + r < p.T;
-            spn[r] = rok[r] ? p.spans[(long)bb * p.T + qt * 16 + g4 + r] : 0.f;
+            spn[r] = rok[r] ? cur.spn[r] : 0.f;
         }
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
-            const int e = min((j0 + jj * 16) / dh, EP - 1);
+            const bool hi_mark = (j0 + jj * 16) / dh > e_lo;      // uniform
             f32x4 a = zero4;
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub) a = mma16(hA[ub], frag_ld<T>(Wc + (jj * 16 + l15) * LDW + ub * 16 + g4), a);
@@ -279,7 +303,7 @@ __global__ __launch_bounds__(256) void intensity_bwd_weights_big_kernel(IntP p) 
             float sdb = 0.f, sdws = 0.f, sdw = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float dz = rok[r] ? p.dz[(row0 + g4 + r) * EP + e] : 0.f;
+                const float dz = rok[r] ? (hi_mark ? cur.dz1[r] : cur.dz0[r]) : 0.f;
                 const float z = sigmoid_pre(fmaf(spn[r], ws, a[r]) + bs);
                 const float t2 = dz * z;
                 du[r] = t2 * wv * (1.0f - z);
@@ -290,6 +314,7 @@ __global__ __launch_bounds__(256) void intensity_bwd_weights_big_kernel(IntP p) 
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub) dW[jj][ub] = mma16(duf, hB[ub], dW[jj][ub]);
         }
+        cur = nxt;
     }
     // block reduction in LDS, waves in turn (fixed order)
     for (int w = 0; w < 4; ++w) {

@@ -290,9 +290,12 @@ __device__ __forceinline__ uint2 enc_tr_read(const bf16* tile, int ld, int k0, i
     enc_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) enc_s16x4*)p);
     return *reinterpret_cast<uint2*>(&v);
 }
+// CT = channel tiles of one workgroup's slice (C = 16 CT channels starting at blockIdx.y * C of the p.C-wide rows: the 256 / 512-unit
+// recipes run as 2 / 4 slices of 128)
 template <int CT>
 __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
     constexpr int C = 16 * CT, LDG = C + 8, SR = SROWS;
+    const int CF = p.C, coff = (int)blockIdx.y * C;      // full row width, first channel of this slice
     __shared__ __attribute__((aligned(16))) bf16 Gs[SR * LDG];   // masked gradient rows of the block
     __shared__ __attribute__((aligned(16))) int s_id[SR];
     __shared__ __attribute__((aligned(16))) int s_lead[SR];       // first row with the same id; -1: padding / past the end
@@ -307,10 +310,10 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const long row = min(r0 + rl + (long)k * rows_par, rows - 1);
-        g[k] = frag_ld<bf16>(dx0 + row * 3 * C + c0);
+        g[k] = frag_ld<bf16>(dx0 + row * 3 * CF + coff + c0);
         if (p.add1) {
-            ga[k] = frag_ld<bf16>(reinterpret_cast<const bf16*>(p.add1) + row * C + c0);
-            gb[k] = frag_ld<bf16>(reinterpret_cast<const bf16*>(p.add2) + row * C + c0);
+            ga[k] = frag_ld<bf16>(reinterpret_cast<const bf16*>(p.add1) + row * CF + coff + c0);
+            gb[k] = frag_ld<bf16>(reinterpret_cast<const bf16*>(p.add2) + row * CF + coff + c0);
         }
     }
     __syncthreads();
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
         if (dk.thresh != 0u) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (!drop_keep(dk, (uint64_t)row * 3 * C + c0 + j)) v.v[j] = from_f32<bf16>(0.f);
+                if (!drop_keep(dk, (uint64_t)row * 3 * CF + coff + c0 + j)) v.v[j] = from_f32<bf16>(0.f);
         }
         *reinterpret_cast<uint2*>(Gs + r * LDG + c0) = *reinterpret_cast<const uint2*>(&v);
     }
@@ -375,14 +378,14 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
         }
     }
     // acc[mt][ct][r] = sum for leader 32 w + 16 mt + 4G + r, channel 16 ct + l15
-    const float sqs = sqrtf((float)C) * dk.scale;
+    const float sqs = sqrtf((float)CF) * dk.scale;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int lead = wave * 32 + mt * 16 + g4 + r;
             if (s_lead[lead] != lead) continue;   // not a leader (or padding)
-            float* dst = p.d_item + (long)s_id[lead] * C + l15;
+            float* dst = p.d_item + (long)s_id[lead] * CF + coff + l15;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) atomicAdd(dst + ct * 16, sqs * acc[mt][ct][r]);
         }
@@ -451,9 +454,9 @@ extern "C" int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, con
         const size_t smem_s = (size_t)srows * C * sizeof(float);
         EDGL_REQUIRE(smem_s <= 150 * 1024, EDGL_ERR_SHAPE, "edgl_encode_bwd: C=%d too large for the scatter stage", C);
         const unsigned nb = (unsigned)(((long)B * T + srows - 1) / srows);
-        if (dtype == EDGL_BF16 && (C == 128 || C == 64) && (((uintptr_t)dx0 | (uintptr_t)add1 | (uintptr_t)add2) & 7) == 0) {
+        if (dtype == EDGL_BF16 && (C % 128 == 0 || C == 64) && (((uintptr_t)dx0 | (uintptr_t)add1 | (uintptr_t)add2) & 7) == 0) {
             const unsigned nbm = (unsigned)(((long)B * T + SROWS - 1) / SROWS);
-            if (C == 128) hipLaunchKernelGGL((encode_scatter_mfma_kernel<8>), dim3(nbm), dim3(256), 0, st, p);
+            if (C % 128 == 0) hipLaunchKernelGGL((encode_scatter_mfma_kernel<8>), dim3(nbm, C / 128), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((encode_scatter_mfma_kernel<4>), dim3(nbm), dim3(256), 0, st, p);
         } else if (dtype == EDGL_F32) {
             hipFuncSetAttribute((const void*)encode_scatter_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);

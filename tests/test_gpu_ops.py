@@ -143,14 +143,15 @@ def test_layernorm_fwd_bwd(name, dt, tol, B, T, C, gather, resid):
 
 
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("width", [32, 128, 512])     # 128 / 512: the one-hot MFMA scatter (bf16), one / four channel slices
 @pytest.mark.parametrize("name,dt,tol", DTYPES)
-def test_encode_fwd_bwd(name, dt, tol):
+def test_encode_fwd_bwd(name, dt, tol, width):
     o = ops()
-    cfg = O.Config(num_items=40, seqslen=12, num_units=32, num_heads=2, time_scale=86400.0, num_events=5)
+    cfg = O.Config(num_items=40, seqslen=12 if width == 32 else 37, num_units=width, num_heads=2, time_scale=86400.0, num_events=5)
     rng = np.random.default_rng(3)
     p = O.init_params(cfg, rng)
     mt = O.synthetic_mark_table(cfg.num_items, cfg.num_events, multi_hot=True)
-    ids, ts = O.synthetic_sequences(cfg, 6, rng, min_len=2)
+    ids, ts = O.synthetic_sequences(cfg, 6 if width == 32 else 9, rng, min_len=2)
     ids[0, -1] = cfg.mask_id
     item = torch.tensor(p["CSTMA/item_embs/lookup_table"], dtype=torch.float32).cuda().requires_grad_()
     pos = torch.tensor(p["CSTMA/spatial_embs/embedding/lookup_table"], dtype=torch.float32).cuda().requires_grad_()
