@@ -180,6 +180,11 @@ class TrainEngine:
         sst = side.cuda_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            # needed by the scoring: row compaction map (labels only).  FIRST on the side stream: its one 1024-thread workgroup
+            # needs a whole CU's worth of free wave slots, which it gets beside the small encoder kernel but not once the QKVT
+            # projection fills the chip (512-unit recipe: 5 .. 516 us, the main stream waiting for it at the join)
+            check(lib.edgl_compact_scan_labels(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid),
+                                               _ptr(self.labels_c), sst), "edgl_compact_scan_labels")
             # needed by the first BiMAU forward (the one join of the forward): TPP normaliser (labels only), weight packs
             for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
                 att = blk.attention
@@ -192,10 +197,8 @@ class TrainEngine:
                     check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
                                              _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
                                              _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
-            # needed by the scoring: row compaction map (labels only), L2 term — same join: every cross-stream edge costs the
-            # waiting stream ~6 us even when the other side finished long ago, and all of this ends under the QKVT projection
-            check(lib.edgl_compact_scan_labels(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid),
-                                               _ptr(self.labels_c), sst), "edgl_compact_scan_labels")
+            # L2 term — same join: every cross-stream edge costs the waiting stream ~6 us even when the other side finished long
+            # ago, and all of this ends under the QKVT projection
             # (the transposed table image is NOT prepared here, although it depends on the weights only: written 200 us before
             # its use it has left the L2 by then and the scoring pass measured 109 -> 118 us — edgl_score_prepare_table)
             if m.l2_reg != 0.0:
