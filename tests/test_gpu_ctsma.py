@@ -1,6 +1,6 @@
 """the HIP CTSMA (easydgl_amd/model/ctsma.py, through the reference's model interface) vs the fp64
 restatement oracle/ctsma_ref.py on the same seeded inputs and weights.  Tolerances as for EasyDGL: f32 path 1e-4 on
-logits / loss and 1e-3 on gradients; bf16 path 3e-2 and 1e-1."""
+logits / loss and 1e-3 on gradients; bf16 path 3e-2 and, per gradient tensor, max-norm 1e-1 AND relative L2 8e-2 (BF16_GRAD_L2)."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -9,7 +9,13 @@ import torch
 
 from oracle import ctsma_ref as CR
 from oracle import easydgl_oracle as O
-from tests._util import assert_close, rel_err, relu_flip_err, to_dev
+from tests._util import assert_close, grad_errors, rel_err, relu_flip_err, to_dev
+
+# per-tensor relative L2 bound of the bf16 path beside the max-norm bound `gtol`.  These models gate their feed-forward with a
+# ReLU: a pre-activation within bf16 rounding of 0 flips its mask against the fp64 reference, and the flipped unit's whole
+# contribution then travels to every gradient upstream of it (measured: up to 0.058 in the first block of the two-block
+# cases, 0.02-0.03 elsewhere; the GELU-gated EasyDGL path holds 2e-2: tests/_util.py GRAD_TOL)
+BF16_GRAD_L2 = 8e-2
 
 pytestmark = pytest.mark.gpu
 
@@ -91,6 +97,10 @@ def test_forward_loss_and_gradients(mode, ltol, gtol, case):
             e = float(np.abs(g).max() / np.abs(ref_k).max())
         else:
             e = rel_err(g, ref)
+            # bf16: the max-norm bound alone lets every small entry of a tensor be wrong — a relative-L2 bound beside it
+            # (the ReLU-gated Inner tensors are held by relu_flip_err's own rms bound instead)
+            if mode == "bf16" and "/Inner/" not in name and grad_errors(g, ref)[0] > BF16_GRAD_L2:
+                bad[name + " (rel-L2)"] = grad_errors(g, ref)[0]
         # bf16 only: a pre-activation within bf16 rounding of 0 flips its ReLU mask, which moves one whole term of the
         # row sums behind Inner/kernel and Inner/bias (measured: error ~ 1/sqrt(rows), 0.13 at 120 rows, 0.05 at 3840);
         # every other gradient is continuous in the activations.  f32 keeps the plain tolerance.

@@ -10,7 +10,7 @@ import torch
 
 from oracle import easydgl_oracle as O
 from oracle import torch_ref as R
-from tests._util import assert_close, build_model, make_problem, rel_err, to_dev
+from tests._util import LOSS_TOL, assert_close, build_model, grad_ok, make_problem, rel_err, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -114,8 +114,8 @@ def test_encode_against_a_million_row_table(name, dt, C):
 HEADLINE_ITEMS = dict(num_units=128, num_heads=8, num_blocks=1, seqslen=100, masklen=20, num_events=16, num_items=20000)
 
 
-@pytest.mark.parametrize("mode,ltol,gtol", [("f32", 1e-4, 1e-3), ("bf16", 3e-2, 1e-1)])
-def test_model_and_engine_at_the_headline_catalogue(mode, ltol, gtol):
+@pytest.mark.parametrize("mode,ltol", [("f32", 1e-4), ("bf16", 2e-2)])
+def test_model_and_engine_at_the_headline_catalogue(mode, ltol):
     """EasyDGL at the BASELINE.json shape (T = 101, C = 128, h = 8, M = 20, E = 16, I = 20 001; batch 4 keeps the fp64
     [80, 20001] logits small): logits, loss, every gradient through the autograd path, then the static engine."""
     from easydgl_amd.engine import TrainEngine
@@ -133,21 +133,26 @@ def test_model_and_engine_at_the_headline_catalogue(mode, ltol, gtol):
     p64 = R.to_torch_params(prob["params"])
     ref_loss, _ = R.train_loss(cfg, p64, prob["mark_table"], prob["feats"], prob["labels"])
     ref_loss.backward()
-    assert_close(loss.item(), ref_loss.item(), ltol, "train loss")
-    bad = {n: e for n, p in m.tf_variable_map().items() if (e := rel_err(p.grad.cpu().numpy(), p64[n].grad.numpy())) > gtol}
+    assert_close(loss.item(), ref_loss.item(), LOSS_TOL[mode], "train loss")
+    # every gradient tensor: relative L2 AND max-norm (tests/_util.py GRAD_TOL)
+    bad = {}
+    for n, p in m.tf_variable_map().items():
+        ok, e = grad_ok(p.grad.cpu().numpy(), p64[n].grad.numpy(), mode)
+        if not ok:
+            bad[n] = e
     assert not bad, f"autograd path: {bad}"
     eng = TrainEngine(m, 4, use_graph=False)
     eng.load_batch(feats, labels)
     m._grad_arena.fill_(float("nan"))
     eng._issue()
-    assert abs(float(eng.loss) - float(ref_loss)) <= ltol * abs(float(ref_loss))
+    assert abs(float(eng.loss) - float(ref_loss)) <= LOSS_TOL[mode] * abs(float(ref_loss))
     bad = {}
     for name, p in m.tf_variable_map().items():
         want = p64[name].grad.numpy().copy()
         if name in O.EMBEDDING_TABLES:
             want -= cfg.l2_reg * prob["params"][name]      # the engine folds the l2 gradient into the Adam kernel
-        e = rel_err(p.grad.cpu().numpy(), want)
-        if not e <= gtol:
+        ok, e = grad_ok(p.grad.cpu().numpy(), want, mode)
+        if not ok:
             bad[name] = e
     assert not bad, f"engine path: {bad}"
     # evaluation at the same catalogue: top-100 vs the oracle's ranking
@@ -177,12 +182,16 @@ def test_config3_workload_end_to_end():
     p64 = R.to_torch_params(prob["params"])
     ref_loss, _ = R.train_loss(cfg, p64, prob["mark_table"], prob["feats"], prob["labels"])
     ref_loss.backward()
-    assert_close(loss.item(), ref_loss.item(), 3e-2, "train loss")
-    bad = {n: e for n, p in m.tf_variable_map().items() if (e := rel_err(p.grad.cpu().numpy(), p64[n].grad.numpy())) > 1e-1}
+    assert_close(loss.item(), ref_loss.item(), LOSS_TOL["bf16"], "train loss")
+    bad = {}
+    for n, p in m.tf_variable_map().items():
+        ok, e = grad_ok(p.grad.cpu().numpy(), p64[n].grad.numpy(), "bf16")
+        if not ok:
+            bad[n] = e
     assert not bad, bad
     eng = TrainEngine(m, 2, use_graph=False)
     l_eng = float(eng.step(feats, labels))
-    assert abs(l_eng - float(ref_loss)) <= 3e-2 * abs(float(ref_loss))
+    assert abs(l_eng - float(ref_loss)) <= LOSS_TOL["bf16"] * abs(float(ref_loss))
     ef = to_dev(prob["efeats"])
     val, idx = m.eval_topk(ef, mask_seen=True)
     assert idx.shape == (2, 100) and int(idx.min()) >= 1 and int(idx.max()) <= 1_000_000

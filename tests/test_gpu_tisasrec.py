@@ -1,5 +1,5 @@
 """SURVEY §8 row a-15 (config 5): the interval-bucket attention kernels (edgl_tiattn_*) and the TiSASRec model class, through
-the C ABI, against oracle/baselines_ref.py (float64).  Tolerances: f32 path 1e-4 / 1e-3 (gradients); bf16 path 3e-2 / 1e-1."""
+the C ABI, against oracle/baselines_ref.py (float64).  Tolerances: f32 path 1e-4 / 1e-3 (gradients); bf16 path 3e-2 / max-norm 1e-1 AND relative L2 8e-2 per gradient tensor."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -8,7 +8,13 @@ import torch
 
 from oracle import baselines_ref as BR
 from oracle import easydgl_oracle as O
-from tests._util import assert_close, rel_err, relu_flip_err, to_dev
+from tests._util import assert_close, grad_errors, rel_err, relu_flip_err, to_dev
+
+# per-tensor relative L2 bound of the bf16 path beside the max-norm bound `gtol`.  These models gate their feed-forward with a
+# ReLU: a pre-activation within bf16 rounding of 0 flips its mask against the fp64 reference, and the flipped unit's whole
+# contribution then travels to every gradient upstream of it (measured: up to 0.058 in the first block of the two-block
+# cases, 0.02-0.03 elsewhere; the GELU-gated EasyDGL path holds 2e-2: tests/_util.py GRAD_TOL)
+BF16_GRAD_L2 = 8e-2
 
 pytestmark = pytest.mark.gpu
 
@@ -84,6 +90,10 @@ def test_tisasrec_forward_loss_and_gradients(mode, ltol, gtol, case):
             e = float(np.abs(g).max() / np.abs(ref_k).max())
         else:
             e = rel_err(g, ref)
+            # bf16: the max-norm bound alone lets every small entry of a tensor be wrong — a relative-L2 bound beside it
+            # (the ReLU-gated Inner tensors are held by relu_flip_err's own rms bound instead)
+            if mode == "bf16" and "/Inner/" not in name and grad_errors(g, ref)[0] > BF16_GRAD_L2:
+                bad[name + " (rel-L2)"] = grad_errors(g, ref)[0]
         if mode == "bf16" and "/Inner/" in name:   # ReLU mask flips, see tests/_util.py:relu_flip_err
             e = relu_flip_err(g, ref, gtol)
         if e > gtol:
