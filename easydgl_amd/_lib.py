@@ -72,6 +72,7 @@ SIGNATURES = {
     "edgl_score_flash_fwd_pre": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, I, I, P]),
     "edgl_score_flash_fwd_coef": (I, [P, P, P, P, I, I, I, P, P, P, P, P, I, P]),
     "edgl_score_flash_fwd_coef_w": (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, I, P]),
+    "edgl_score_flash_fwd_rows_w": (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, I, P]),
     "edgl_score_flash_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_reduce_defer": (I, [I, P]),
     "edgl_reduce_flush": (I, [P]),

@@ -810,6 +810,108 @@ __global__ void slab_reduce_rows_kernel(const float* slabs, const int32_t* nvali
     }
 }
 
+// lse_label_kernel + flash_finish_kernel in ONE launch (the training engine: both run back to back between the two product passes,
+// each a few microseconds of work behind a kernel boundary).  LPR = C / 4 lanes own a row (4 consecutive channels each): every lane
+// forms the row's log-sum-exp from the chunk partials itself (<= 16 exponentials), the label logit is the LPR-lane sum of the
+// lanes' 4-channel dot products with the label row of the table — the row this kernel loads anyway for the -table[label] term —
+// then coefficient and d_rows as in the two kernels.  Chunk counts above MAXCH take the rolled loops.
+template <typename TO, int LPR>
+__global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slabs, const float* part, const TO* rows, const TO* table,
+                                                               const float* out_bias, const int64_t* labels, const int32_t* nvalid,
+                                                               const int32_t* wtotal, int R, int xb, int zb, int G, int ztotal,
+                                                               const float* gscale, float* row_lse, float* lab_out, float* coef_out,
+                                                               TO* out) {
+    constexpr int C = 4 * LPR, MAXCH = 16;
+    const float gs = gscale ? gscale[0] : 1.0f;
+    const int Reff = nvalid ? min(R, nvalid[0]) : R;
+    const float W = (float)(wtotal ? wtotal[0] : Reff) + 1e-5f;       // EasyDGL.py:184 over the global batch
+    const DevPlan dp = dev_plan(max(Reff, 1), xb, G, ztotal, zb);
+    const long stride = (long)dp.nx * xb * C;
+    const int nch = dp.nchunk;
+    const int nrow_blk = 256 / LPR;
+    for (long r0 = (long)blockIdx.x * nrow_blk; r0 < R; r0 += (long)gridDim.x * nrow_blk) {
+        const int r = (int)min(r0 + threadIdx.x / LPR, (long)R - 1), c = (threadIdx.x % LPR) * 4, rc = min(r, max(Reff - 1, 0));
+        const bool live = r0 + threadIdx.x / LPR < R;
+        int64_t lab = labels[r];
+        asm volatile("" : "+v"(lab));
+        const int64_t labc = lab > 0 ? lab : 0;
+        float4 sl[MAXCH];
+        float pm[MAXCH], ps[MAXCH];
+        if (nch <= MAXCH) {
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) {
+                const int sc = min(s, nch - 1);
+                sl[s] = *reinterpret_cast<const float4*>(slabs + (long)sc * stride + (long)rc * C + c);
+                pm[s] = part[((long)rc * nch + sc) * 2];
+                ps[s] = part[((long)rc * nch + sc) * 2 + 1];
+            }
+        }
+        float ob = out_bias[max(labc, (int64_t)1) - 1];
+        float xr[4], tb[4];
+        if constexpr (sizeof(TO) == 2) {
+            const Frag4<TO> fx = frag_ld<TO>(rows + (long)r * C + c), ft = frag_ld<TO>(table + labc * C + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xr[q] = to_f32(fx.v[q]); tb[q] = to_f32(ft.v[q]); }
+        } else {
+            const float4 fx = *reinterpret_cast<const float4*>(rows + (long)r * C + c), ft = *reinterpret_cast<const float4*>(table + labc * C + c);
+            xr[0] = fx.x; xr[1] = fx.y; xr[2] = fx.z; xr[3] = fx.w; tb[0] = ft.x; tb[1] = ft.y; tb[2] = ft.z; tb[3] = ft.w;
+        }
+        asm volatile("" : "+v"(ob));
+        // ---- row log-sum-exp over the chunks
+        float lse = 0.f;
+        if (r < Reff) {
+            float mx = -INFINITY, sm = 0.f;
+            if (nch <= MAXCH) {
+#pragma unroll
+                for (int s = 0; s < MAXCH; ++s) mx = s < nch ? fmaxf(mx, pm[s]) : mx;
+#pragma unroll
+                for (int s = 0; s < MAXCH; ++s) sm += (s < nch && pm[s] > -INFINITY) ? ps[s] * __expf(pm[s] - mx) : 0.f;
+            } else {
+                for (int s = 0; s < nch; ++s) mx = fmaxf(mx, part[((long)r * nch + s) * 2]);
+                for (int s = 0; s < nch; ++s) {
+                    const float qm = part[((long)r * nch + s) * 2];
+                    if (qm > -INFINITY) sm += part[((long)r * nch + s) * 2 + 1] * __expf(qm - mx);
+                }
+            }
+            lse = mx + __logf(sm);
+        }
+        // ---- label logit: LPR-lane sum (a row's lanes are LPR consecutive lanes of one wave)
+        float a = (xr[0] * tb[0] + xr[1] * tb[1]) + (xr[2] * tb[2] + xr[3] * tb[3]);
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        const float ll = lab == 0 ? -1000.0f : a + ob;
+        const float v = __expf(ll - lse);
+        const float cf = (r < Reff && lab != 0) ? (1.f / W) * (v / (v + 1e-5f)) : 0.f;
+        if (live && c == 0) { row_lse[r] = lse; lab_out[r] = ll; coef_out[r] = cf; }
+        // ---- d_rows = gs * coef * ( sum_chunks slab_c * exp(m_c - lse)  -  table[label] )
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cf != 0.f) {
+            if (nch <= MAXCH) {
+#pragma unroll
+                for (int s = 0; s < MAXCH; ++s) {
+                    const float e = s < nch ? __expf(pm[s] - lse) : 0.f;
+                    const float x[4] = {sl[s].x, sl[s].y, sl[s].z, sl[s].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = s < nch ? fmaf(x[q], e, acc[q]) : acc[q];
+                }
+            } else {
+                for (int s = 0; s < nch; ++s) {
+                    const float e = __expf(part[((long)r * nch + s) * 2] - lse);
+                    const float4 x = *reinterpret_cast<const float4*>(slabs + (long)s * stride + (long)r * C + c);
+                    acc[0] = fmaf(x.x, e, acc[0]); acc[1] = fmaf(x.y, e, acc[1]); acc[2] = fmaf(x.z, e, acc[2]); acc[3] = fmaf(x.w, e, acc[3]);
+                }
+            }
+        }
+        float o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o4[q] = cf != 0.f ? gs * cf * (acc[q] - tb[q]) : 0.f;
+        if (live) {
+            if constexpr (sizeof(TO) == 2) { const Frag4<TO> f = frag_from_acc<TO>(f32x4{o4[0], o4[1], o4[2], o4[3]}); *reinterpret_cast<uint2*>(out + (long)r * C + c) = *reinterpret_cast<const uint2*>(&f); }
+            else *reinterpret_cast<float4*>(out + (long)r * C + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        }
+    }
+}
+
 // ROLE_YF finish: d_rows[r] = gs * coef[r] * ( sum_chunks slab_c[r] * exp(m_c - lse[r])  -  table[label[r]] )
 //   = gs * coef * (sum_z p_z T_z - T_label)   (Appendix C: dy_rows = dl . table, dl = coef (p - onehot))
 template <typename TO>
@@ -1310,12 +1412,33 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
                            ws + plan.off_slabY, p.nvalid, p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
         EDGL_LAUNCH_CHECK();
     } else if (MODE == 1) {
+        if (d_rows && (p.C == 128 || p.C == 64 || p.C == 256) && p.i0 == 0 && p.i1 == p.I) {
+            // rows finished in one launch: log-sum-exp, label logit, coefficient and d_rows (edgl_score_flash_fwd_rows_w)
+            const T* rows_t = reinterpret_cast<const T*>(p.rows);
+            const T* tab_t = reinterpret_cast<const T*>(p.table);
+            const float* slabY = ws + plan.off_slabY;
+            T* out_t = reinterpret_cast<T*>(d_rows);
+#define EDGL_FFL(LPR)                                                                                                          \
+    hipLaunchKernelGGL((flash_finish_lse_kernel<T, LPR>), dim3((unsigned)std::min<long>(((long)p.R * LPR + 255) / 256, 4096)),  \
+                       dim3(256), 0, st, slabY, part, rows_t, tab_t, p.out_bias, p.labels, p.nvalid, p.wtotal, p.R, xb, ZBK, G, \
+                       p.i1 - p.i0, p.gscale, p.row_lse, p.lab_out, p.coef_out, out_t)
+            if (p.C == 128) EDGL_FFL(32); else if (p.C == 64) EDGL_FFL(16); else EDGL_FFL(64);
+#undef EDGL_FFL
+            EDGL_LAUNCH_CHECK();
+            return EDGL_OK;
+        }
         hipLaunchKernelGGL((lse_label_kernel<T>), dim3((p.R + 3) / 4), dim3(256), 0, st, part, p.R, p.nvalid, xb, ZBK, G, p.i1 - p.i0,
                            p.row_lse, reinterpret_cast<const T*>(p.rows), reinterpret_cast<const T*>(p.table), p.out_bias, p.labels,
                            p.C, p.i0, p.i1, p.lab_out, p.coef_out, p.wtotal);
         EDGL_LAUNCH_CHECK();
+        if (d_rows) {   // other widths: the two kernels, one after the other
+            hipLaunchKernelGGL((flash_finish_kernel<T>), dim3((unsigned)std::min<long>((nrc / 4 + 255) / 256, 2048)), dim3(256), 0, st,
+                               ws + plan.off_slabY, part, p.row_lse, p.coef_out, p.labels, reinterpret_cast<const T*>(p.table), p.nvalid,
+                               p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
+            EDGL_LAUNCH_CHECK();
+        }
         return EDGL_OK;
-    } else {
+    } else if (d_rows) {
         hipLaunchKernelGGL((flash_finish_kernel<T>), dim3((unsigned)std::min<long>((nrc / 4 + 255) / 256, 2048)), dim3(256), 0, st,
                            ws + plan.off_slabY, part, p.row_lse, p.coef, p.labels, reinterpret_cast<const T*>(p.table), p.nvalid,
                            p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
@@ -1613,13 +1736,34 @@ extern "C" int edgl_score_flash_fwd_coef_w(const void* rows, const void* table, 
                              : bwd_dispatch<bf16, 1>(p, C, plan, workspace, nullptr, nullptr, nullptr, st);
 }
 
+// edgl_score_flash_fwd_coef_w that also finishes the rows: d_rows (= gscale * d loss / d rows, what edgl_score_flash_bwd would write)
+// comes out of the same launch as lse / label logits / coefficients; edgl_score_flash_bwd is then called with d_rows = NULL and
+// only runs the table side.
+extern "C" int edgl_score_flash_fwd_rows_w(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
+                                           int C, int I, const int32_t* nvalid, const int32_t* wtotal, const float* gscale,
+                                           float* row_lse, float* label_logit, float* coef, void* d_rows, float* workspace,
+                                           int dtype, void* stream) {
+    int rc = check_score(rows, table, out_bias, R, C, I, 0, I, dtype, "edgl_score_flash_fwd_rows");
+    if (rc) return rc;
+    EDGL_REQUIRE(labels && row_lse && label_logit && workspace && nvalid && coef && d_rows, EDGL_ERR_NULL,
+                 "edgl_score_flash_fwd_rows: null pointer (the row count of the compaction is required)");
+    ScoreP p{};
+    p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = 0;
+    p.i1 = I; p.nvalid = nvalid; p.row_lse = row_lse; p.lab_out = label_logit; p.coef_out = coef; p.wtotal = wtotal; p.gscale = gscale;
+    const BwdPlan plan = bwd_plan(R, C, I, I, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
+    hipStream_t st = (hipStream_t)stream;
+    return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, d_rows, nullptr, nullptr, st)
+                             : bwd_dispatch<bf16, 1>(p, C, plan, workspace, d_rows, nullptr, nullptr, st);
+}
+
 extern "C" int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                                     const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
                                     int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias,
                                     float* workspace, int dtype, void* stream) {
     int rc = check_score(rows, table, out_bias, R, C, I, i0, i1, dtype, "edgl_score_flash_bwd");
     if (rc) return rc;
-    EDGL_REQUIRE(labels && row_lse && coef && d_rows && d_table && d_bias && workspace, EDGL_ERR_NULL,
+    // d_rows == NULL: the rows were finished by edgl_score_flash_fwd_rows_w; only d_table / d_bias are computed
+    EDGL_REQUIRE(labels && row_lse && coef && d_table && d_bias && workspace, EDGL_ERR_NULL,
                  "edgl_score_flash_bwd: null pointer");
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;

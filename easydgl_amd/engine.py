@@ -265,9 +265,10 @@ class TrainEngine:
             # the forward pass writes the loss coefficients itself (the row count of the loss is the compaction's): the backward
             # starts behind it, and the loss kernel — a one-workgroup reduction over the rows — leaves the critical path
             wtot = self.counts.data_ptr() if self._dp else None
-            check(lib.edgl_score_flash_fwd_coef_w(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I,
-                                                  _ptr(self.nvalid), wtot, _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.coef),
-                                                  _ptr(self.ws_flash), code, st), "edgl_score_flash_fwd_coef")
+            # (... and d_rows: log-sum-exp, label logits, coefficients and the row gradients leave ONE finishing launch)
+            check(lib.edgl_score_flash_fwd_rows_w(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I,
+                                                  _ptr(self.nvalid), wtot, None, _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.coef),
+                                                  _ptr(self.d_rows), _ptr(self.ws_flash), code, st), "edgl_score_flash_fwd_rows")
             # (launched on the side stream at the join the backward has anyway: an event record of its own costs the main
             # stream as much as the kernel)
             self._pending_loss = lambda s: check(lib.edgl_ce_loss_fwd_add_w(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R,
@@ -303,7 +304,7 @@ class TrainEngine:
         hd, ad = m.hidden_dropout_rate, m.attention_probs_dropout_rate
         if self.flash_ce:
             check(lib.edgl_score_flash_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
-                                           _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows),
+                                           _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), None,   # d_rows: written by the forward call
                                            _ptr(tab.grad), _ptr(m.output_bias.grad), _ptr(self.ws_flash), code, st),
                   "edgl_score_flash_bwd")
         else:

@@ -327,6 +327,12 @@ int edgl_score_flash_fwd_coef(const void* rows, const void* table, const float* 
 int edgl_score_flash_fwd_coef_w(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
                                 int I, const int32_t* nvalid, const int32_t* wtotal, float* row_lse, float* label_logit, float* coef,
                                 float* workspace, int dtype, void* stream);
+/* ... that also finishes the rows: d_rows [R, C] `dtype` (= gscale * d loss / d rows; gscale device scalar or NULL = 1) is written by
+ * the launch that forms lse / label logits / coefficients (one kernel instead of two between the two product passes);
+ * edgl_score_flash_bwd is then called with d_rows = NULL and computes d_table / d_bias only. */
+int edgl_score_flash_fwd_rows_w(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
+                                int I, const int32_t* nvalid, const int32_t* wtotal, const float* gscale, float* row_lse,
+                                float* label_logit, float* coef, void* d_rows, float* workspace, int dtype, void* stream);
 int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                          const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
                          int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias, float* workspace,

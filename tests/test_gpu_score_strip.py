@@ -130,3 +130,44 @@ def test_strip_reference_fallback_on_a_wide_logit_spread():
 def test_strip_label_scatter_with_every_row_on_one_label():
     rows, tab, bias, labels = _problem(900, 3001, seed=13, hot=1.0, zero=0.0)
     _check(rows, tab, bias, labels)
+
+
+@pytest.mark.parametrize("dt,C", [(torch.bfloat16, 128), (torch.bfloat16, 64), (torch.float32, 128), (torch.bfloat16, 256), (torch.bfloat16, 512)])
+def test_rows_finished_in_the_forward_call_match_the_two_call_sequence(dt, C):
+    """edgl_score_flash_fwd_rows_w (lse, label logits, coefficients AND d_rows from one finishing launch) + edgl_score_flash_bwd with
+    d_rows = NULL  ==  edgl_score_flash_fwd_coef + edgl_score_flash_bwd: same numbers (chunk sums and label logits are summed in another order:
+    2e-6), widths with the fused kernel (64 / 128 / 256) and without (512: the two kernels behind the same entry point)."""
+    from easydgl_amd._lib import check, lib
+    o = _ops()
+    R, I = 777, 3001
+    g = torch.Generator(device="cuda").manual_seed(C + 1)
+    rows = (torch.randn(R, C, device="cuda", generator=g) * 0.6 * (128 / C) ** 0.5).to(dt)
+    tab = (torch.randn(I, C, device="cuda", generator=g) * 0.4).to(dt)
+    bias = torch.randn(I - 1, device="cuda", generator=g) * 0.3
+    labels = torch.randint(1, I, (R,), device="cuda", generator=g)
+    labels[torch.rand(R, device="cuda", generator=g) > 0.6] = 0
+    rows_c, lab_c, perm, _inv, nvalid = o.compact_rows(rows, labels)
+    p, st, code = o._ptr, o._stream(), o._code(rows)
+    ws = torch.empty(lib.edgl_score_flash_workspace(R, C, I, I, code), device="cuda")
+    wtot = torch.tensor([1234], device="cuda", dtype=torch.int32)
+    gs = torch.tensor([0.7], device="cuda")
+
+    def outs():
+        return (torch.empty(R, device="cuda"), torch.zeros(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty_like(rows_c),
+                torch.empty((I, C), device="cuda"), torch.empty(I - 1, device="cuda"))
+    lse0, ll0, cf0, dr0, dt0, db0 = outs()
+    check(lib.edgl_score_flash_fwd_coef_w(p(rows_c), p(tab), p(bias), p(lab_c), R, C, I, p(nvalid), p(wtot), p(lse0), p(ll0), p(cf0), p(ws),
+                                          code, st), "fwd_coef_w")
+    check(lib.edgl_score_flash_bwd(p(rows_c), p(tab), p(bias), p(lab_c), p(lse0), p(cf0), p(gs), R, C, I, 0, I, p(nvalid), p(dr0), p(dt0),
+                                   p(db0), p(ws), code, st), "bwd")
+    lse1, ll1, cf1, dr1, dt1, db1 = outs()
+    check(lib.edgl_score_flash_fwd_rows_w(p(rows_c), p(tab), p(bias), p(lab_c), R, C, I, p(nvalid), p(wtot), p(gs), p(lse1), p(ll1), p(cf1),
+                                          p(dr1), p(ws), code, st), "fwd_rows_w")
+    check(lib.edgl_score_flash_bwd(p(rows_c), p(tab), p(bias), p(lab_c), p(lse1), p(cf1), p(gs), R, C, I, 0, I, p(nvalid), None, p(dt1),
+                                   p(db1), p(ws), code, st), "bwd (table side only)")
+    torch.cuda.synchronize()
+    assert float((lse0 - lse1).abs().max()) <= 2e-6 * (1 + float(lse0.abs().max()))      # chunk sums in another order
+    assert float((ll0 - ll1).abs().max()) <= 2e-6 * (1 + float(ll0.abs().max()))
+    assert _rel_max(cf1, cf0) < 1e-5
+    assert _rel_max(dr1.float(), dr0.float()) < (1e-5 if dt == torch.float32 else 1e-2)     # bf16 outputs: an ulp where the coefficient moved
+    assert _rel_max(dt1, dt0) < 1e-4 and _rel_max(db1, db0) < 1e-4
