@@ -74,6 +74,8 @@ SIGNATURES = {
     "edgl_score_flash_fwd_coef_w": (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, I, P]),
     "edgl_score_flash_fwd_rows_w": (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, I, P]),
     "edgl_score_flash_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
+    "edgl_score_flash_bwd_ex": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, I, P]),
+    "edgl_score_flash_label_term": (I, [P, P, P, P, I, I, I, I, I, P, P, P, I, P]),
     "edgl_reduce_defer": (I, [I, P]),
     "edgl_reduce_flush": (I, [P]),
     "edgl_mask_topk": (I, [P, I, I, I, P, I, I, P, P, P]),

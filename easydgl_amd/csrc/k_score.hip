@@ -110,6 +110,7 @@ struct ScoreP {
     float* coef_out;                                    // flash forward, compacted rows, whole table: loss coefficients [R]
     int table_ready;                                    // tableT already written by edgl_score_prepare_table
     const int32_t* wtotal;                              // data parallel: weighted rows of the GLOBAL batch (denominator of the loss)
+    bool defer_label;                                   // strip path: the caller applies the one-hot term (edgl_score_flash_label_term)
 };
 
 // ---- streamed tile: global -> registers -> LDS -------------------------------------------------
@@ -1469,7 +1470,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
                            SlabJob{q.slabs, n, lo, hi, (long)p.C, d_table}, SlabJob{q.bias_slabs, nb, blo, bhi, 0L, d_bias}, nb0,
                            q.nchunk, p.gscale);
         EDGL_LAUNCH_CHECK();
-        if (strip) {   // the one-hot part of dl, which the strip product pass leaves out
+        if (strip && !p.defer_label) {   // the one-hot part of dl, which the strip product pass leaves out
             const int rc = edgl_strip_label_scatter(p.rows, p.labels, p.coef, p.nvalid, p.R, p.i0, p.i1, p.gscale, d_table, d_bias, st);
             if (rc) return rc;
         }
@@ -1756,10 +1757,34 @@ extern "C" int edgl_score_flash_fwd_rows_w(const void* rows, const void* table, 
                              : bwd_dispatch<bf16, 1>(p, C, plan, workspace, d_rows, nullptr, nullptr, st);
 }
 
+extern "C" int edgl_score_flash_bwd_ex(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
+                                       const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
+                                       int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias,
+                                       float* workspace, int defer_label_term, int dtype, void* stream);
 extern "C" int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                                     const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
                                     int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias,
                                     float* workspace, int dtype, void* stream) {
+    return edgl_score_flash_bwd_ex(rows, table, out_bias, labels, row_lse, coef, gscale, R, C, I, i0, i1, nvalid, d_rows, d_table, d_bias,
+                                   workspace, 0, dtype, stream);
+}
+// The one-hot part of dl = coef (p - onehot(label)) as its own call:  d_table[label[r]] -= gscale coef[r] rows[r],
+// d_bias[label[r] - 1] -= gscale coef[r]  over the weighted rows (f32 atomics, commutes with every other accumulation into the two
+// arrays).  edgl_score_flash_bwd_ex(defer_label_term = 1) leaves exactly this out WHERE ITS PRODUCT PASS DOES NOT CONTAIN IT (bf16,
+// C = 128: the strip kernels) — edgl_score_flash_label_term is then a launch, and a no-op (return 0) for every other configuration,
+// whose product kernels subtract the one-hot in place.  The training engine runs it on its side stream under the embedding backward.
+extern "C" int edgl_score_flash_label_term(const void* rows, const int64_t* labels, const float* coef, const float* gscale, int R, int C,
+                                           int I, int i0, int i1, const int32_t* nvalid, float* d_table, float* d_bias, int dtype,
+                                           void* stream) {
+    EDGL_REQUIRE(rows && labels && coef && d_table && d_bias, EDGL_ERR_NULL, "edgl_score_flash_label_term: null pointer");
+    EDGL_REQUIRE(R > 0 && I > 1 && i0 >= 0 && i1 <= I && i0 < i1, EDGL_ERR_SHAPE, "edgl_score_flash_label_term: bad shape");
+    if (!use_strip(C, dtype == EDGL_BF16 ? 2 : 4)) return EDGL_OK;
+    return edgl_strip_label_scatter(rows, labels, coef, nvalid, R, i0, i1, gscale, d_table, d_bias, (hipStream_t)stream);
+}
+extern "C" int edgl_score_flash_bwd_ex(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
+                                       const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
+                                       int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias,
+                                       float* workspace, int defer_label_term, int dtype, void* stream) {
     int rc = check_score(rows, table, out_bias, R, C, I, i0, i1, dtype, "edgl_score_flash_bwd");
     if (rc) return rc;
     // d_rows == NULL: the rows were finished by edgl_score_flash_fwd_rows_w; only d_table / d_bias are computed
@@ -1768,6 +1793,7 @@ extern "C" int edgl_score_flash_bwd(const void* rows, const void* table, const f
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
+    p.defer_label = defer_label_term != 0;
     const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 2>(p, C, plan, workspace, d_rows, d_table, d_bias, st)

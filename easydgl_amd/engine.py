@@ -94,6 +94,7 @@ class TrainEngine:
         self.ws_l2 = e(1024, dtype=f32)
         self.side = torch.cuda.Stream(device=dev)
         self._pending_loss = None
+        self._pending_label = None
         # data parallel: weighted rows / TPP normaliser of the GLOBAL batch (filled by _global_counts before a step)
         self.counts = torch.zeros(2, device=dev, dtype=torch.int32)
         self._dp = False
@@ -290,6 +291,7 @@ class TrainEngine:
             lib.edgl_reduce_defer(-1, st)
             lib.edgl_gemm_dw_defer(-1, st)
             self._pending_loss = None
+            self._pending_label = None
             raise
         check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")   # runs the remaining queued reductions in one launch
         if self._pending_loss is not None:   # (no block: no side-stream join in the backward)
@@ -303,10 +305,24 @@ class TrainEngine:
         code = self.code
         hd, ad = m.hidden_dropout_rate, m.attention_probs_dropout_rate
         if self.flash_ce:
-            check(lib.edgl_score_flash_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
-                                           _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), None,   # d_rows: written by the forward call
-                                           _ptr(tab.grad), _ptr(m.output_bias.grad), _ptr(self.ws_flash), code, st),
+            # d_rows: written by the forward call.  The one-hot term of the table / bias gradient (a scatter of the weighted rows:
+            # f32 atomics that commute with the embedding scatter's) is deferred to the side stream at the end of the backward
+            defer = 1 if self.blk else 0
+            check(lib.edgl_score_flash_bwd_ex(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
+                                              _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), None,
+                                              _ptr(tab.grad), _ptr(m.output_bias.grad), _ptr(self.ws_flash), defer, code, st),
                   "edgl_score_flash_bwd")
+            if defer:
+                self._pending_label = lambda s: check(lib.edgl_score_flash_label_term(
+                    _ptr(self.hrows_c), _ptr(lab), _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(tab.grad),
+                    _ptr(m.output_bias.grad), code, s), "edgl_score_flash_label_term")
+                # ... started right here on the side stream, beside the block-tail backward (measured on one box, 3 x 300 steps each:
+                # 0.8895 ms against 0.8946 with the launch at the end of the backward, where it sat in front of the slab reductions
+                # of the final join; the tail kernel itself takes 88 instead of 82 us next to it).  EDGL_LABEL_EARLY=0: at the end.
+                if os.environ.get("EDGL_LABEL_EARLY", "1") != "0":
+                    self.side.wait_stream(torch.cuda.current_stream())
+                    self._pending_label(self.side.cuda_stream)
+                    self._pending_label = None
         else:
             check(lib.edgl_score_ce_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
                                         _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows), _ptr(tab.grad),
@@ -382,6 +398,9 @@ class TrainEngine:
                 if self._pending_loss is not None:
                     self._pending_loss(self.side.cuda_stream)
                     self._pending_loss = None
+                if self._pending_label is not None:
+                    self._pending_label(self.side.cuda_stream)
+                    self._pending_label = None
                 check(lib.edgl_reduce_flush(self.side.cuda_stream), "edgl_reduce_flush")
             # both residual branches feed the first C channels of the block input (temporal.py:447, EasyDGL.py:116)
             if i > 0:

@@ -337,6 +337,17 @@ int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_b
                          const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
                          int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias, float* workspace,
                          int dtype, void* stream);
+/* The one-hot part of dl = coef (p - onehot(label)) as a call of its own: d_table[label[r]] -= gscale coef[r] rows[r], d_bias[label[r]-1]
+ * -= gscale coef[r] over the weighted rows (f32 atomics: commutes with every other accumulation into the two arrays).
+ * edgl_score_flash_bwd_ex(defer_label_term = 1) leaves exactly this out where its product pass does not contain it (bf16, C = 128);
+ * edgl_score_flash_label_term then applies it — and is a no-op for every other configuration.  A training loop may run it off the
+ * critical path (any time after the table-side reduction of edgl_score_flash_bwd_ex wrote d_table / d_bias). */
+int edgl_score_flash_bwd_ex(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
+                            const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
+                            int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias, float* workspace,
+                            int defer_label_term, int dtype, void* stream);
+int edgl_score_flash_label_term(const void* rows, const int64_t* labels, const float* coef, const float* gscale, int R, int C, int I,
+                                int i0, int i1, const int32_t* nvalid, float* d_table, float* d_bias, int dtype, void* stream);
 
 /* ---- deferred partial reductions ------------------------------------------------------------------
  * The weight-gradient entry points (edgl_gemm_dw, edgl_add_layernorm_bwd, edgl_encode_bwd,

@@ -1,4 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python tests/metric_proxy_long.py hip --out gpurun_out/r03_metric_proxy_long.json 2>&1 | tail -3
-python -m pytest tests/test_gpu_metric_proxy_long.py -x -q -s 2>&1 | tail -4
+for i in 1 2 3; do
+for E in 0 1; do
+echo -n "EARLY=$E "; EDGL_LABEL_EARLY=$E python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['step_ms_hipevents']['median'])"
+done; done
