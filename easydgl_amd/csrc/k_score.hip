@@ -836,17 +836,6 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
         int64_t lab = labels[r];
         asm volatile("" : "+v"(lab));
         const int64_t labc = lab > 0 ? lab : 0;
-        float4 sl[MAXCH];
-        float pm[MAXCH], ps[MAXCH];
-        if (nch <= MAXCH) {
-#pragma unroll
-            for (int s = 0; s < MAXCH; ++s) {
-                const int sc = min(s, nch - 1);
-                sl[s] = *reinterpret_cast<const float4*>(slabs + (long)sc * stride + (long)rc * C + c);
-                pm[s] = part[((long)rc * nch + sc) * 2];
-                ps[s] = part[((long)rc * nch + sc) * 2 + 1];
-            }
-        }
         float ob = out_bias[max(labc, (int64_t)1) - 1];
         float xr[4], tb[4];
         if constexpr (sizeof(TO) == 2) {
@@ -857,25 +846,57 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
             const float4 fx = *reinterpret_cast<const float4*>(rows + (long)r * C + c), ft = *reinterpret_cast<const float4*>(table + labc * C + c);
             xr[0] = fx.x; xr[1] = fx.y; xr[2] = fx.z; xr[3] = fx.w; tb[0] = ft.x; tb[1] = ft.y; tb[2] = ft.z; tb[3] = ft.w;
         }
-        asm volatile("" : "+v"(ob));
-        // ---- row log-sum-exp over the chunks
-        float lse = 0.f;
-        if (r < Reff) {
-            float mx = -INFINITY, sm = 0.f;
-            if (nch <= MAXCH) {
+        // ---- chunk partials in batches of MAXCH (all loads of a batch in flight together; index clamped, the surplus weighted 0):
+        //      the row maximum first, then  sm = sum_c l_c e_c,  a = sum_c slab_c e_c  with e_c = exp(m_c - max);
+        //      lse = max + log sm,  sum_c slab_c exp(m_c - lse) = a / sm
+        float mx = -INFINITY;
+        float4 sl0[MAXCH];                      // the first batch stays in registers (the benchmark has 11-12 chunks): ONE round trip
+        float pm0[MAXCH], ps0[MAXCH];
 #pragma unroll
-                for (int s = 0; s < MAXCH; ++s) mx = s < nch ? fmaxf(mx, pm[s]) : mx;
-#pragma unroll
-                for (int s = 0; s < MAXCH; ++s) sm += (s < nch && pm[s] > -INFINITY) ? ps[s] * __expf(pm[s] - mx) : 0.f;
-            } else {
-                for (int s = 0; s < nch; ++s) mx = fmaxf(mx, part[((long)r * nch + s) * 2]);
-                for (int s = 0; s < nch; ++s) {
-                    const float qm = part[((long)r * nch + s) * 2];
-                    if (qm > -INFINITY) sm += part[((long)r * nch + s) * 2 + 1] * __expf(qm - mx);
-                }
-            }
-            lse = mx + __logf(sm);
+        for (int s = 0; s < MAXCH; ++s) {
+            const int sc = min(s, nch - 1);
+            sl0[s] = *reinterpret_cast<const float4*>(slabs + (long)sc * stride + (long)rc * C + c);
+            pm0[s] = part[((long)rc * nch + sc) * 2];
+            ps0[s] = part[((long)rc * nch + sc) * 2 + 1];
         }
+#pragma unroll
+        for (int s = 0; s < MAXCH; ++s) mx = s < nch ? fmaxf(mx, pm0[s]) : mx;
+        for (int s0 = MAXCH; s0 < nch; s0 += MAXCH) {
+            float pm[MAXCH];
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) pm[s] = part[((long)rc * nch + min(s0 + s, nch - 1)) * 2];
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) mx = s0 + s < nch ? fmaxf(mx, pm[s]) : mx;
+        }
+        float sm = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < MAXCH; ++s) {
+            const float e = (s < nch && pm0[s] > -INFINITY) ? __expf(pm0[s] - mx) : 0.f;
+            sm = fmaf(ps0[s], e, sm);
+            acc[0] = fmaf(sl0[s].x, e, acc[0]); acc[1] = fmaf(sl0[s].y, e, acc[1]);
+            acc[2] = fmaf(sl0[s].z, e, acc[2]); acc[3] = fmaf(sl0[s].w, e, acc[3]);
+        }
+        for (int s0 = MAXCH; s0 < nch; s0 += MAXCH) {
+            float4 sl[MAXCH];
+            float pm[MAXCH], ps[MAXCH];
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) {
+                const int sc = min(s0 + s, nch - 1);
+                sl[s] = *reinterpret_cast<const float4*>(slabs + (long)sc * stride + (long)rc * C + c);
+                pm[s] = part[((long)rc * nch + sc) * 2];
+                ps[s] = part[((long)rc * nch + sc) * 2 + 1];
+            }
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) {
+                const float e = (s0 + s < nch && pm[s] > -INFINITY) ? __expf(pm[s] - mx) : 0.f;
+                sm = fmaf(ps[s], e, sm);
+                acc[0] = fmaf(sl[s].x, e, acc[0]); acc[1] = fmaf(sl[s].y, e, acc[1]);
+                acc[2] = fmaf(sl[s].z, e, acc[2]); acc[3] = fmaf(sl[s].w, e, acc[3]);
+            }
+        }
+        asm volatile("" : "+v"(ob));
+        const float lse = r < Reff ? mx + __logf(sm) : 0.f;
+        const float inv_sm = (r < Reff && sm > 0.f) ? 1.0f / sm : 0.f;
         // ---- label logit: LPR-lane sum (a row's lanes are LPR consecutive lanes of one wave)
         float a = (xr[0] * tb[0] + xr[1] * tb[1]) + (xr[2] * tb[2] + xr[3] * tb[3]);
 #pragma unroll
@@ -885,24 +906,8 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
         const float cf = (r < Reff && lab != 0) ? (1.f / W) * (v / (v + 1e-5f)) : 0.f;
         if (live && c == 0) { row_lse[r] = lse; lab_out[r] = ll; coef_out[r] = cf; }
         // ---- d_rows = gs * coef * ( sum_chunks slab_c * exp(m_c - lse)  -  table[label] )
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cf != 0.f) {
-            if (nch <= MAXCH) {
 #pragma unroll
-                for (int s = 0; s < MAXCH; ++s) {
-                    const float e = s < nch ? __expf(pm[s] - lse) : 0.f;
-                    const float x[4] = {sl[s].x, sl[s].y, sl[s].z, sl[s].w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = s < nch ? fmaf(x[q], e, acc[q]) : acc[q];
-                }
-            } else {
-                for (int s = 0; s < nch; ++s) {
-                    const float e = __expf(part[((long)r * nch + s) * 2] - lse);
-                    const float4 x = *reinterpret_cast<const float4*>(slabs + (long)s * stride + (long)r * C + c);
-                    acc[0] = fmaf(x.x, e, acc[0]); acc[1] = fmaf(x.y, e, acc[1]); acc[2] = fmaf(x.z, e, acc[2]); acc[3] = fmaf(x.w, e, acc[3]);
-                }
-            }
-        }
+        for (int q = 0; q < 4; ++q) acc[q] *= inv_sm;
         float o4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) o4[q] = cf != 0.f ? gs * cf * (acc[q] - tb[q]) : 0.f;
@@ -925,23 +930,16 @@ __global__ void flash_finish_kernel(const float* slabs, const float* part, const
     const long stride = (long)dp.nx * xb * C;
     const int nch = dp.nchunk, C4 = C >> 2;
     constexpr int MAXCH = 16;
-    // a thread = 4 consecutive channels of a row; two rounds of loads: the row's scalars with every chunk's slab values and
-    // maxima (chunk index clamped, the surplus weighted 0), then the label row of the table.  One element per thread with the
-    // chunk loop rolled was a dependent round trip per chunk.
+    const bool vec = (((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)table) & 15) == 0 && (stride & 3) == 0;
+    // a thread = 4 consecutive channels of a row; rounds of loads: the row's scalars with the slab values and maxima of up to
+    // MAXCH chunks at a time (chunk index clamped, the surplus weighted 0), then the label row of the table.  One element per
+    // thread with the chunk loop rolled was a dependent round trip per chunk (the 512-unit recipe has > 16 chunks: 60 us).
     for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < (long)R * C4; i4 += (long)gridDim.x * blockDim.x) {
         const int r = (int)(i4 / C4), c = (int)(i4 % C4) * 4, rc = min(r, max(Reff - 1, 0));
         float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (nch <= MAXCH && (((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)table) & 15) == 0 && (stride & 3) == 0) {
+        if (vec) {
             float cf = coef[rc], lse = row_lse[rc];
             int64_t lab = labels[rc];
-            float4 sl[MAXCH];
-            float pm[MAXCH];
-#pragma unroll
-            for (int s = 0; s < MAXCH; ++s) {
-                const int sc = min(s, nch - 1);
-                sl[s] = *reinterpret_cast<const float4*>(slabs + (long)sc * stride + (long)rc * C + c);
-                pm[s] = part[((long)rc * nch + sc) * 2];
-            }
             asm volatile("" : "+v"(cf), "+v"(lse), "+v"(lab));
             float tb[4];
             {
@@ -950,12 +948,22 @@ __global__ void flash_finish_kernel(const float* slabs, const float* part, const
                 else { const float4 f = *reinterpret_cast<const float4*>(trow); tb[0] = f.x; tb[1] = f.y; tb[2] = f.z; tb[3] = f.w; }
             }
             float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < nch; s0 += MAXCH) {
+                float4 sl[MAXCH];
+                float pm[MAXCH];
 #pragma unroll
-            for (int s = 0; s < MAXCH; ++s) {
-                const float e = s < nch ? __expf(pm[s] - lse) : 0.f;
-                const float x[4] = {sl[s].x, sl[s].y, sl[s].z, sl[s].w};
+                for (int s = 0; s < MAXCH; ++s) {
+                    const int sc = min(s0 + s, nch - 1);
+                    sl[s] = *reinterpret_cast<const float4*>(slabs + (long)sc * stride + (long)rc * C + c);
+                    pm[s] = part[((long)rc * nch + sc) * 2];
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] = s < nch ? fmaf(x[q], e, a[q]) : a[q];
+                for (int s = 0; s < MAXCH; ++s) {
+                    const float e = s0 + s < nch ? __expf(pm[s] - lse) : 0.f;
+                    const float x[4] = {sl[s].x, sl[s].y, sl[s].z, sl[s].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] = s0 + s < nch ? fmaf(x[q], e, a[q]) : a[q];
+                }
             }
             const bool on = r < Reff && cf != 0.f;
 #pragma unroll
