@@ -833,6 +833,14 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
     for (long r0 = (long)blockIdx.x * nrow_blk; r0 < R; r0 += (long)gridDim.x * nrow_blk) {
         const int r = (int)min(r0 + threadIdx.x / LPR, (long)R - 1), c = (threadIdx.x % LPR) * 4, rc = min(r, max(Reff - 1, 0));
         const bool live = r0 + threadIdx.x / LPR < R;
+        if (r0 >= Reff) {      // (uniform) rows behind the weighted ones — label 0 by construction of the compaction: nothing to load
+            if (live) {
+                if (c == 0) { row_lse[r] = 0.f; lab_out[r] = labels[r] == 0 ? -1000.0f : 0.f; coef_out[r] = 0.f; }
+                if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint2*>(out + (long)r * C + c) = make_uint2(0u, 0u);
+                else *reinterpret_cast<float4*>(out + (long)r * C + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            continue;
+        }
         int64_t lab = labels[r];
         asm volatile("" : "+v"(lab));
         const int64_t labc = lab > 0 ? lab : 0;
