@@ -44,6 +44,14 @@ def main():
         head.append("# bench line of the same run: " + open(bl).read().strip())
     with open(os.path.join(prof, f"{tag}_kernel_stats.txt"), "w") as f:
         f.write("\n".join(head + kernel_stats(os.path.join(SRC, "ktrace", "k_results.db"), steps)) + "\n")
+    rdb = os.path.join(SRC, "recipe", "k_results.db")
+    if os.path.exists(rdb):
+        rhead = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload recipe --steps 20 --warmup 5 --no-cpu-baseline   ({steps} optimizer steps, engine path, round {tag})"]
+        rbl = os.path.join(SRC, "recipe_bench_line.json")
+        if os.path.exists(rbl):
+            rhead.append("# bench line of the same run: " + open(rbl).read().strip())
+        with open(os.path.join(prof, f"{tag}_recipe_kernel_stats.txt"), "w") as f:
+            f.write("\n".join(rhead + kernel_stats(rdb, steps)) + "\n")
     fetch = counter_means(os.path.join(SRC, "fetch", "f_results.db"), "FETCH_SIZE")
     write = counter_means(os.path.join(SRC, "write", "w_results.db"), "WRITE_SIZE")
     lines = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and (separate pass)  --pmc WRITE_SIZE  -- python bench.py --steps 3 --warmup 2",

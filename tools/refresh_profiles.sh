@@ -12,4 +12,7 @@ rocprofv3 --kernel-trace --stats -d "$OUT/ktrace" -o k -- $BENCH > "$OUT/ktrace.
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o f -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o w -- python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/write.log" 2>&1
 grep -h '"metric"' "$OUT/ktrace.log" | tail -1 > "$OUT/bench_line.json"
+# the published recipe's shape (bench.py --workload recipe): kernel trace only
+rocprofv3 --kernel-trace --stats -d "$OUT/recipe" -o k -- python $ROOT/bench.py --workload recipe --steps 20 --warmup 5 --no-cpu-baseline --no-extras > "$OUT/recipe.log" 2>&1
+grep -h '"metric"' "$OUT/recipe.log" | tail -1 > "$OUT/recipe_bench_line.json"
 ls "$OUT"/*/ 
