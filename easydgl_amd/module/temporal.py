@@ -169,9 +169,9 @@ class MAU(nn.Module):
             else:
                 drop = ops.NO_DROP
         masks = key_ids_from_masks(masks, queries.shape[0], queries.shape[1], self.num_heads)
-        q = ops.LinearFn.apply(queries, self.q_kernel, self.q_bias, self.compute(self.q_kernel), False)
-        kvt = ops.LinearFn.apply(keys, self.kvt_kernel, self.kvt_bias, self.compute(self.kvt_kernel), False)
-        qkvt = torch.cat([q, kvt], dim=-1)   # column blocks Q | K | V | T_ of the kernel's operand (a device-side copy)
+        # column blocks Q | K | V | T_ of the kernel's operand, written in place by the two projections (no concatenation copy)
+        qkvt = ops.DualLinearFn.apply(queries, keys, self.q_kernel, self.q_bias, self.compute(self.q_kernel), self.kvt_kernel,
+                                      self.kvt_bias, self.compute(self.kvt_kernel))
         flags = ops.MAU_NO_DIAG | (ops.MAU_CAUSAL if causality else 0)
         return modulated_attention(qkvt, queries[:, :, :C], self.st_kernel, self.st_bias, self.weight, self.scaling, masks,
                                    intervals, marks, self.num_heads, drop if is_training else ops.NO_DROP, flags)

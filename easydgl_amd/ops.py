@@ -236,6 +236,47 @@ class LinearFn(torch.autograd.Function):
         return dx.reshape(xshape), dw, db, None, None
 
 
+class DualLinearFn(torch.autograd.Function):
+    """Q = dense(xq, C) and K | V | T_ = dense(xk, 3C) written as the column blocks of ONE [.., 4C] operand — MAU.__call__'s four
+    projections (temporal.py:352-355) in the layout the fused attention kernel reads, without a concatenation copy (forward) or
+    slice copies (backward): the GEMMs take the row stride 4C of the shared buffer."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, wq_master, bq, wq_c, wk_master, bk, wk_c):
+        Kq, C = wq_c.shape
+        Kk, C3 = wk_c.shape
+        xq2, xk2 = xq.reshape(-1, Kq).contiguous(), xk.reshape(-1, Kk).contiguous()
+        M = xq2.shape[0]
+        out = torch.empty((M, C + C3), device=xq.device, dtype=xq.dtype)
+        code, st = _code(xq2), _stream()
+        for x2, w, b, K, N, col in ((xq2, wq_c, bq, Kq, C, 0), (xk2, wk_c, bk, Kk, C3, C)):
+            check(lib.edgl_gemm(_ptr(x2), _ptr(w), _vptr(out[:, col:]), M, N, K, K, N, out.stride(0), 1, 0, _ptr(b), None, _lib.EPI_BIAS, 1,
+                                None, code, st), "edgl_gemm")
+        ctx.save_for_backward(xq2, xk2, wq_c, wk_c)
+        ctx.meta = (M, C, C3, Kq, Kk, xq.shape, xk.shape)
+        return out.reshape(xq.shape[:-1] + (C + C3,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        xq2, xk2, wq_c, wk_c = ctx.saved_tensors
+        M, C, C3, Kq, Kk, qshape, kshape = ctx.meta
+        dz = dy.reshape(M, C + C3).contiguous()
+        code, st = _code(dz), _stream()
+        res = []
+        for x2, w, K, N, col in ((xq2, wq_c, Kq, C, 0), (xk2, wk_c, Kk, C3, C)):
+            dzv = dz[:, col:col + N]                                   # column block, row stride 4C
+            dx = torch.empty((M, K), device=dz.device, dtype=dz.dtype)
+            check(lib.edgl_gemm(_vptr(dzv), _ptr(w), _ptr(dx), M, K, N, dz.stride(0), N, K, 1, 1, None, None, 0, 1, None, code, st),
+                  "edgl_gemm")
+            both = torch.empty((K + 1) * N, device=dz.device, dtype=torch.float32)
+            ws = torch.empty(lib.edgl_gemm_dw_workspace(M, K, N, code), device=dz.device, dtype=torch.float32)
+            check(lib.edgl_gemm_dw(_ptr(x2), _vptr(dzv), _ptr(both), both.data_ptr() + 4 * K * N, M, K, N, K, dz.stride(0), 0, _ptr(ws), code,
+                                   st), "edgl_gemm_dw")
+            res.append((dx, both[:K * N].view(K, N), both[K * N:]))
+        (dxq, dwq, dbq), (dxk, dwk, dbk) = res
+        return dxq.reshape(qshape), dxk.reshape(kshape), dwq, dbq, None, dwk, dbk, None
+
+
 # ------------------------------------------------------------------------------------------------
 # K3 BiMAU
 # ------------------------------------------------------------------------------------------------
