@@ -39,6 +39,22 @@ __device__ __forceinline__ bf16x8 tr_frag32(const bf16* tile, int ld, int k0, in
 struct EpiP {
     const float* bias; void* aux; int flags;
 };
+
+// XCD-aware workgroup order.  The hardware deals workgroup b of a launch to XCD b % 8 (observed; speed only), and each XCD has its
+// own 4 MB L2: consecutive ids — which these kernels give to the tiles that stream the SAME operand rows — would land on eight
+// different L2s and every one of them would fetch those rows again (QKVT projection: 162 MB fetched for 40 MB of activations, its
+// dX 167 for 53, the grouped dW 434 for ~110).  With a grid padded to a multiple of 8 the virtual id  v = (b % 8) * (G / 8) + b / 8
+// hands every XCD one contiguous run of virtual ids; ids >= n_real are padding.  Returns -1 for padding workgroups.
+__device__ __forceinline__ int xcd_virtual_id(int b, int grid, int n_real, int on) {
+    if (!on || (grid & 7)) return b < n_real ? b : -1;
+    const int v = (b & 7) * (grid >> 3) + (b >> 3);
+    return v < n_real ? v : -1;
+}
+static inline int xcd_grid(int n_real) { return (n_real + 7) / 8 * 8; }
+static inline int xcd_on() {
+    static const int on = getenv("EDGL_XCD_ORDER") ? atoi(getenv("EDGL_XCD_ORDER")) : 1;
+    return on;
+}
 __device__ __forceinline__ void epi_store4(const EpiP& e, bf16* C, void* Cany, long idx, int n, float x[4]) {
     if (e.flags & EDGL_EPI_BIAS) {
         const float4 b = *reinterpret_cast<const float4*>(e.bias + n);
@@ -90,6 +106,7 @@ struct StripP {
     int M, N, K, lda, ldb, ldc;
     EpiP epi;
     int dbg;   // EDGL_DBG ablation bits (profiling only): 1 skip epilogue stores, 2 skip MFMA loop, 4 skip B streaming
+    int xcd;   // tile_nn_kernel: XCD-aware workgroup order (xcd_virtual_id)
 };
 
 // Epilogue of one [32 rows x 64 columns] accumulator block of a wave.  acc[jz][ix] = L(first = n, second = m): a lane holds 4
@@ -462,7 +479,9 @@ __global__ __launch_bounds__(G_NT, 2) void tile_nn_kernel(StripP p) {
     const int G = lane >> 4, g4 = G * 4, l15 = lane & 15;
     // consecutive workgroups share the row block (its A rows stay in L2 across the N / 128 column tiles)
     const int nbn = p.N / G_BN;
-    const int m0 = ((int)blockIdx.x / nbn) * G_BM, n0 = ((int)blockIdx.x % nbn) * G_BN;
+    const int vid = xcd_virtual_id((int)blockIdx.x, (int)gridDim.x, ((p.M + G_BM - 1) / G_BM) * nbn, p.xcd);
+    if (vid < 0) return;
+    const int m0 = (vid / nbn) * G_BM, n0 = (vid % nbn) * G_BN;
     uint4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;   // named registers (arrays captured by a lambda end up in scratch here)
     // piece v of an operand tile: A (and B when k-contiguous): row v >> 3, k offset (v & 7) * 8; B n-contiguous: k row v >> 4, n offset (v & 15) * 8
 #define G_LOAD_ONE(PA, PB, I)                                                                                                  \
@@ -568,7 +587,9 @@ static int launch_tile_nn(const StripP& p, hipStream_t st) {
     auto k = tile_nn_kernel<B_KC, EPI>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const int nbm = (p.M + G_BM - 1) / G_BM, nbn = p.N / G_BN;
-    hipLaunchKernelGGL(k, dim3((unsigned)(nbm * nbn)), dim3(G_NT), smem, st, p);
+    StripP q = p;
+    q.xcd = xcd_on();
+    hipLaunchKernelGGL(k, dim3((unsigned)(q.xcd ? xcd_grid(nbm * nbn) : nbm * nbn)), dim3(G_NT), smem, st, q);
     EDGL_LAUNCH_CHECK();
     return 1;
 }
@@ -677,15 +698,18 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
 // other and individually too small for the chip — the 128 x 128 layers run two 64-row steps per workgroup and leave 25 MB of
 // partial slabs each.  Grouped, they share the launch with the wide QKVT product and get row splits of similar length.
 constexpr int TN_MAX_JOBS = 8;
-struct TnGroupP { TnP job[TN_MAX_JOBS]; int tiles_n[TN_MAX_JOBS], tiles_k[TN_MAX_JOBS], blk0[TN_MAX_JOBS + 1]; int n; };
+struct TnGroupP { TnP job[TN_MAX_JOBS]; int tiles_n[TN_MAX_JOBS], tiles_k[TN_MAX_JOBS], blk0[TN_MAX_JOBS + 1]; int n, xcd; };
 __global__ __launch_bounds__(T_NT) void tn_gemm_group_kernel(TnGroupP g) {
     extern __shared__ __attribute__((aligned(16))) char tn_smem[];
     bf16* Xs = reinterpret_cast<bf16*>(tn_smem);
     bf16* Ys = Xs + T_BR * (128 + 16);
+    // (the tiles of one row split are consecutive ids: with the XCD-aware order they share one L2)
+    const int vid = xcd_virtual_id((int)blockIdx.x, (int)gridDim.x, g.blk0[g.n], g.xcd);
+    if (vid < 0) return;
     int j = 0;
     for (int i = 1; i < g.n; ++i)
-        if ((int)blockIdx.x >= g.blk0[i]) j = i;
-    const int local = (int)blockIdx.x - g.blk0[j];
+        if (vid >= g.blk0[i]) j = i;
+    const int local = vid - g.blk0[j];
     const int tn = g.tiles_n[j], tk = g.tiles_k[j];
     tn_body<128>(g.job[j], local % tn, (local / tn) % tk, local / (tn * tk), Xs, Ys);
 }
@@ -739,7 +763,7 @@ int edgl_gemm2_try_strip(const void* A, const void* B, void* C, int M, int N, in
                     (!aux || ((uintptr_t)aux & 7) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
     if (!ok) return 0;
     static const int dbg = getenv("EDGL_DBG") ? atoi(getenv("EDGL_DBG")) : 0;
-    StripP p{(const bf16*)A, (const bf16*)B, C, M, N, K, lda, ldb, ldc, EpiP{bias, aux, flags}, dbg};
+    StripP p{(const bf16*)A, (const bf16*)B, C, M, N, K, lda, ldb, ldc, EpiP{bias, aux, flags}, dbg, 0};
     int rc;
     // wide projections with a plain (bias-only) epilogue: the 128 x 128 tiled kernel
     static const int use_tile = getenv("EDGL_GEMM_TILE") ? atoi(getenv("EDGL_GEMM_TILE")) : 1;
@@ -837,9 +861,10 @@ static int tn_flush(hipStream_t st) {
         blocks += g.tiles_n[i] * g.tiles_k[i] * sp;
     }
     g.blk0[n] = blocks;
+    g.xcd = xcd_on();
     const size_t tn_lds = (size_t)2 * T_BR * (128 + 16) * sizeof(bf16);
     hipFuncSetAttribute((const void*)tn_gemm_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tn_lds);
-    hipLaunchKernelGGL(tn_gemm_group_kernel, dim3(blocks), dim3(T_NT), tn_lds, st, g);
+    hipLaunchKernelGGL(tn_gemm_group_kernel, dim3(g.xcd ? xcd_grid(blocks) : blocks), dim3(T_NT), tn_lds, st, g);
     EDGL_LAUNCH_CHECK();
     for (int i = 0; i < n; ++i) {
         const TnP& p = g_tn_q[i].p;

@@ -1,18 +1,8 @@
 #!/bin/bash
-# full profile refresh of the round: kernel trace + HBM PMC passes of the step, MFMA / VALU utilisation, K1 encode (zipf, uniform)
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
-bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
-bash tools/profile_mfma.sh > gpurun_out/mfma.log 2>&1
-bash tools/profile_encode.sh zipf > gpurun_out/encode_zipf.log 2>&1
-bash tools/profile_encode.sh uniform > gpurun_out/encode_uniform.log 2>&1
-cd $GRAFT_REPO_ROOT
-python tools/make_profiles.py $TAG
-python tools/make_mfma_profile.py $TAG
-python tools/make_encode_profile.py $TAG zipf
-python tools/make_encode_profile.py $TAG uniform
-mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
-rm -rf gpurun_out/refresh/ktrace gpurun_out/refresh/recipe gpurun_out/refresh/fetch gpurun_out/refresh/write gpurun_out/mfma/mfma gpurun_out/mfma/valu gpurun_out/encode_*/ktrace gpurun_out/encode_*/fetch gpurun_out/encode_*/write
-python bench.py > gpurun_out/profiles_$TAG/${TAG}_bench_line.json 2> gpurun_out/bench_final.err
-tail -c 300 gpurun_out/bench_final.err
-ls -la gpurun_out/profiles_$TAG
+python -m pytest tests/test_gpu_ops.py -x -q -k "gemm or deferred" 2>&1 | tail -2
+python -m pytest tests/test_gpu_engine.py tests/test_gpu_headline_parity.py -x -q 2>&1 | tail -2
+for i in 1 2 3; do for X in 0 1; do
+echo -n "XCD=$X "; EDGL_XCD_ORDER=$X python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['step_ms_hipevents']['median'])"
+done; done
+for X in 0 1; do EDGL_XCD_ORDER=$X KT_LINES=16 bash tools/ktrace.sh | grep -E "tile_nn|tn_gemm" | cut -c1-150; done
