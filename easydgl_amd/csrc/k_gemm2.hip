@@ -604,6 +604,7 @@ struct TnP {
     int rows_per_split;
     float* partial;   // [splits][Kf + 1][N]  (row Kf = column sums of Y)
     int with_colsum;
+    int tiles_n, tiles_k, nblocks, xcd;   // tn_gemm_kernel: 1-D grid (padded to a multiple of 8 with the XCD-aware order)
 };
 
 // TM = output tile edge of a workgroup (4 waves in a 2 x 2 arrangement): 128 (default) or 64 (see tn_tile)
@@ -691,7 +692,10 @@ __global__ __launch_bounds__(T_NT) void tn_gemm_kernel(TnP p) {
     extern __shared__ __attribute__((aligned(16))) char tn_smem[];
     bf16* Xs = reinterpret_cast<bf16*>(tn_smem);
     bf16* Ys = Xs + T_BR * (TM + 16);
-    tn_body<TM>(p, blockIdx.x, blockIdx.y, blockIdx.z, Xs, Ys);
+    // tiles of one row split are consecutive virtual ids: they stream the same rows of X and Y and share one XCD's L2
+    const int vid = xcd_virtual_id((int)blockIdx.x, (int)gridDim.x, p.nblocks, p.xcd);
+    if (vid < 0) return;
+    tn_body<TM>(p, vid % p.tiles_n, (vid / p.tiles_n) % p.tiles_k, vid / (p.tiles_n * p.tiles_k), Xs, Ys);
 }
 
 // Several weight-gradient GEMMs in ONE launch (edgl_gemm_dw_defer): the dW products of a block are independent of each
@@ -895,7 +899,7 @@ int edgl_gemm2_try_tn(const void* X, const void* Y, float* C, int R, int Kf, int
     int splits = tn_splits(R, Kf, N);
     int rps = ((R + splits - 1) / splits + T_BR - 1) / T_BR * T_BR;
     splits = (R + rps - 1) / rps;
-    TnP p{(const bf16*)X, (const bf16*)Y, R, Kf, N, ldx, ldy, rps, workspace, dbias ? 1 : 0};
+    TnP p{(const bf16*)X, (const bf16*)Y, R, Kf, N, ldx, ldy, rps, workspace, dbias ? 1 : 0, 0, 0, 0, 0};
     if (g_tn_defer && tn_tile(Kf, N) == 128) {
         if (g_tn_n == TN_MAX_JOBS) {
             const int rc = tn_flush(st);
@@ -907,11 +911,13 @@ int edgl_gemm2_try_tn(const void* X, const void* Y, float* C, int R, int Kf, int
     if (tn_tile(Kf, N) == 64) {
         const size_t lds = (size_t)2 * T_BR * (64 + 16) * sizeof(bf16);
         hipFuncSetAttribute((const void*)tn_gemm_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(tn_gemm_kernel<64>, dim3((N + 63) / 64, (Kf + 63) / 64, splits), dim3(T_NT), lds, st, p);
+        p.tiles_n = (N + 63) / 64; p.tiles_k = (Kf + 63) / 64; p.nblocks = p.tiles_n * p.tiles_k * splits; p.xcd = xcd_on();
+        hipLaunchKernelGGL(tn_gemm_kernel<64>, dim3(p.xcd ? xcd_grid(p.nblocks) : p.nblocks), dim3(T_NT), lds, st, p);
     } else {
         const size_t lds = (size_t)2 * T_BR * (128 + 16) * sizeof(bf16);
         hipFuncSetAttribute((const void*)tn_gemm_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(tn_gemm_kernel<128>, dim3((N + 127) / 128, (Kf + 127) / 128, splits), dim3(T_NT), lds, st, p);
+        p.tiles_n = (N + 127) / 128; p.tiles_k = (Kf + 127) / 128; p.nblocks = p.tiles_n * p.tiles_k * splits; p.xcd = xcd_on();
+        hipLaunchKernelGGL(tn_gemm_kernel<128>, dim3(p.xcd ? xcd_grid(p.nblocks) : p.nblocks), dim3(T_NT), lds, st, p);
     }
     EDGL_LAUNCH_CHECK();
     const int rc = tn_reduce(workspace, splits, C, Kf, N, dbias, accumulate, st);
