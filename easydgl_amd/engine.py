@@ -319,7 +319,9 @@ class TrainEngine:
                 # ... started right here on the side stream, beside the block-tail backward (measured on one box, 3 x 300 steps each:
                 # 0.8895 ms against 0.8946 with the launch at the end of the backward, where it sat in front of the slab reductions
                 # of the final join; the tail kernel itself takes 88 instead of 82 us next to it).  EDGL_LABEL_EARLY=0: at the end.
-                if os.environ.get("EDGL_LABEL_EARLY", "1") != "0":
+                # Default (2): behind the tail backward, beside the BiMAU sweeps (2 waves per SIMD at 256 registers, no LDS
+                # pressure from the scatter): 0.868 ms against 0.876 (1) and 0.879 (0), 3 x 300 steps each on one box.
+                if os.environ.get("EDGL_LABEL_EARLY", "2") == "1":
                     self.side.wait_stream(torch.cuda.current_stream())
                     self._pending_label(self.side.cuda_stream)
                     self._pending_label = None
@@ -357,6 +359,10 @@ class TrainEngine:
                                         _ptr(blk.att_ln.gamma.grad), _ptr(blk.att_ln.beta.grad), _ptr(blk.out_ln.gamma.grad),
                                         _ptr(blk.out_ln.beta.grad), _ptr(tl.gamma.grad), _ptr(tl.beta.grad),
                                         _ptr(self._ws(lib.edgl_tail_bwd_workspace(B, C))), code, st), "edgl_tail_bwd")
+                if self._pending_label is not None and os.environ.get("EDGL_LABEL_EARLY", "2") == "2":   # beside the BiMAU sweeps
+                    self.side.wait_stream(torch.cuda.current_stream())
+                    self._pending_label(self.side.cuda_stream)
+                    self._pending_label = None
                 if last:
                     self._dense_dw(y_last, self.d_pre_t, m.transform.kernel, m.transform.bias, C, C)
                 self._dense_dw(b["f"], self.d_o, blk.out.kernel, blk.out.bias, 2 * C, C)

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_ops.py -x -q -k "gemm or deferred or linear" 2>&1 | tail -2
-python -m pytest tests/test_gpu_model.py tests/test_gpu_ctsma.py -x -q 2>&1 | tail -2
-for X in 0 1; do echo "XCD=$X"; EDGL_XCD_ORDER=$X KT_LINES=9 bash tools/ktrace.sh --workload recipe | grep -E "tn_gemm|tile_nn|metric" | cut -c1-250; done
+for i in 1 2 3; do for E in 0 1 2; do
+echo -n "EARLY=$E "; EDGL_LABEL_EARLY=$E python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['step_ms_hipevents']['median'])"
+done; done
