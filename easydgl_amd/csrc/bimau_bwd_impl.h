@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
     };
     PH_DECL
     QOps qcur = load_q(0);
+    touch_regs(qcur);   // complete before the loop (edgl_common.h)
     // Results of a query tile are stored at the TOP of the next iteration: the loop-carried prefetch makes the compiler
     // drain vmcnt to 0 on the back edge, and a store issued just before it would expose its full write latency there.
     float pend_dz[4] = {0.f, 0.f, 0.f, 0.f}, pend_rowdot = 0.f;
@@ -182,7 +183,6 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         asm volatile("" ::: "memory");   // keep loop-invariant LDS operands from being hoisted into registers
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
-        flush_pending();
         QOps qnext;
         if constexpr (PREF) qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
         asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
@@ -200,6 +200,12 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         }
         if constexpr (FL == 0) masked_softmax_impl<NT, false, false>(s, km, cscale, lane, q);
         else masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        // The previous tile's results leave HERE, behind the first use of this tile's operands: stores count in vmcnt like loads, and
+        // stores issued at the top of the iteration (in front of the prefetch) sat between the loads of the previous iteration and
+        // the wait for them — that wait then also waited for the store to be acknowledged (~2 us per query tile in the stamps).
+        asm volatile("" ::: "memory");
+        flush_pending();
+        asm volatile("" ::: "memory");
         PH_MARK(0);
         Frag4<T> lf;
 #pragma unroll
@@ -268,7 +274,15 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         else if (qt + 1 < NT) qcur = load_q(qt + 1);
         PH_MARK(2);
     }
+    // ---- dscaling partial: sum over the 16 query lanes (before the stores: nothing behind them waits on vmcnt) ------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = dsc_acc[i];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        dsc_acc[i] = v;
+    }
     flush_pending();
+    if (l15 == 0) *reinterpret_cast<float4*>(p.dsc_part + job * EP + g4) = make_float4(dsc_acc[0], dsc_acc[1], dsc_acc[2], dsc_acc[3]);
     // ---- write dV (L(first=v, second=k): 4 consecutive channels of key row k) -----------------------------------------
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
@@ -277,13 +291,6 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
 #pragma unroll
             for (int ut = 0; ut < DT; ++ut) st_frag<T>(dqkvt + (long)k * ldq + 2 * p.C + head * dh + ut * 16 + g4, dVa[ut][kt]);
         }
-    }
-    // ---- dscaling partial: sum over the 16 query lanes ---------------------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float v = dsc_acc[i];
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-        if (l15 == 0) p.dsc_part[job * EP + g4 + i] = v;
     }
     PH_MARK(3);
     PH_FLUSH(0);
@@ -361,6 +368,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     };
     PH_DECL
     QOps qcur = load_q(0);
+    touch_regs(qcur);   // complete before the loop (edgl_common.h)
     // dQ of a query tile is stored at the top of the next iteration (see kernel X: the back edge drains vmcnt)
     Frag4<T> pend_dq[DT];
     int pend_q = p.T;
@@ -381,10 +389,10 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
         (void)qok;
-        flush_pending();
         QOps qnext;
         if constexpr (PREF) qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
         asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
+        PH_MARK(3);
         // consume the tile fetched one iteration ago; rows past the sequence end contribute nothing to dK / dT_
         f32x4 dHq[DT];   // dH^T[u][q], L(first=u, second=q): sum of the mark-group partials in a fixed order
 #pragma unroll
@@ -399,6 +407,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             if (!qok) qcur.dof[ub] = frag_zero<T>();
         }
         const float rowdot1 = qok ? qcur.rowdot : 0.f;
+        PH_MARK(4);
         // ---- recompute S, P --------------------------------------------------------------------------------------
         f32x4 s[NT];
 #pragma unroll
@@ -409,8 +418,12 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
+        PH_MARK(5);
         if constexpr (FL == 0) masked_softmax_impl<NT, false, false>(s, km, cscale, lane, q);
         else masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        asm volatile("" ::: "memory");
+        flush_pending();   // behind the first use of this tile's operands (see kernel X)
+        asm volatile("" ::: "memory");
         PH_MARK(0);
         Frag4<T> lf;
 #pragma unroll

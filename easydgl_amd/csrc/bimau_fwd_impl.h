@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         return o;
     };
     QOps qcur = load_q(0);
+    touch_regs(qcur);   // complete before the loop (edgl_common.h)
     // The output rows of a query tile (computed last) are stored at the TOP of the next iteration: the loop-carried
     // prefetch makes the compiler drain vmcnt to 0 on the back edge, and a store issued just before it would expose its
     // full write latency there.  (H rows, z and lambda are stored mid-iteration and have landed by then.)
@@ -133,7 +134,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
     for (int qt = 0; qt < NT; ++qt) {
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
-        flush_pending();
         const QOps qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
         asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
         // ---- S^T[k][q] = sum_u K[k][u] Q[q][u] ------------------------------------------------
@@ -150,6 +150,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
             s[kt] = a;
         }
         masked_softmax<NT, sizeof(T) == 2 ? 2 : 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s := P^T
+        // the previous tile's output rows leave here, behind the first use of this tile's operands: a store in front of the prefetch
+        // sits between the previous iteration's loads and the wait for them, and that wait then waits for the store's acknowledge
+        asm volatile("" ::: "memory");
+        flush_pending();
+        asm volatile("" ::: "memory");
         // ---- H^T[u][q] = sum_k T_[k][u] P[q][k] -----------------------------------------------
         Frag4<T> pf[NT];
 #pragma unroll

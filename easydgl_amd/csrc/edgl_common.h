@@ -118,6 +118,17 @@ __device__ __forceinline__ f32x4 mma_kblock(const Vec16<bf16>& a, const Vec16<bf
 #define PH_FLUSH(base)
 #endif
 
+// "Use" of every 32-bit word of a register-resident POD (prefetched operands): pins the s_waitcnt for its loads to this point.
+// A prefetch that is still pending when a loop is entered makes every wait inside the loop conservative (the entry state is merged
+// into the loop header): the waits then also count the stores of the previous iteration, i.e. stall on their acknowledges.
+template <typename S>
+__device__ __forceinline__ void touch_regs(S& s) {
+    static_assert(sizeof(S) % 4 == 0, "32-bit words");
+    uint32_t* w = reinterpret_cast<uint32_t*>(&s);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(S) / 4); ++i) asm volatile("" : "+v"(w[i]));
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for every global
 // load a thread has in flight — which turns a register prefetch issued before the barrier into a stall on full memory
 // latency.  Use this one when only LDS contents are exchanged across the barrier.

@@ -9,6 +9,9 @@
 //      dW1 / db1 / dw, reduced deterministically by edgl_reduce_rows.
 //   Z) sweep 2, one wave per (b, head): recomputes S, P, G', dA and finishes dP = dP1 + dH.T_^T, dS, dQ, dK, dT_.
 // Products that contract over the QUERY index use operands transposed by one MFMA against the identity.
+#include <algorithm>
+#include <cstdlib>
+
 #include "bimau_bwd_impl.h"
 
 #ifdef EDGL_PHASE_TIMING
@@ -21,19 +24,33 @@ using namespace bimau;
 // ------------------------------------------------------------------------------------------------------------------
 // Y) intensity MLP backward: dH partials + weight-gradient partials
 // ------------------------------------------------------------------------------------------------------------------
+// registers a wave parks in its slab of the block reduction: dW tiles, the extra tiles (bf16) or db1 / interval sums (f32), dw sums
+template <typename T>
+constexpr int intensity_bwd_nreg(int DT) {
+    return KY_ECH * DT * DT * 4 + (sizeof(T) == 2 ? (KY_ECH / 4) * DT * 4 : 2 * KY_ECH * DT) + KY_ECH * DT;
+}
+
 struct MlpP {
     const void* hin; const float* dz_ws; const float* spans; const char* pack;
     long R; int B, T, E; float* dh_ws; float* wpart; const float* dsc_part; long njobs;
+    int slab_epi;   // block reduction through four register slabs (they fit the LDS) instead of wave turns on one accumulator
 };
 
-template <typename T, int DT>
+// EC: compile-time mark count (16: no guards around the mark blocks, so the scheduler may run the LDS operand reads of a block
+// ahead of the previous block's arithmetic) or 0 (run-time p.E).
+// bf16: the row sums of du for db1 and for the interval row of dW1 (du * span) come out of ONE more MFMA per channel tile against
+// the operand hX = [1 | span_hi | span_lo | 0 ...] (span as two bf16 terms) instead of two VALU instructions per element: the
+// kernel is VALU-issue bound, the matrix pipe is idle.
+template <typename T, int DT, int EC>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void intensity_bwd_kernel(MlpP p) {
     constexpr int dh = 16 * DT;
     constexpr int ECH = KY_ECH;
+    constexpr bool MX = sizeof(T) == 2;
+    const int E = EC ? EC : p.E;
     const int e0 = blockIdx.y * ECH;
     PH_DECL
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const PackDims pd = pack_dims<T>(dh, p.E);
+    const PackDims pd = pack_dims<T>(dh, E);
     copy_pack_to_lds(smem, p.pack, pd.bytes);
     const int JE = pd.JE, NPAR = (dh + 3) * JE, NPARX = NPAR + EP;
     // block accumulator: dW1[u][j] at accs[j * (dh + 1) + u] (u on the lanes: conflict-free adds; the odd stride keeps the
@@ -57,21 +74,30 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
     const Frag4<T> ident = identity_frag<T>(lane);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // row tiles are 16 consecutive rows of the flat [H*B*T] row space (dz, H rows and the dH slabs are all indexed that
-    // way); a tile may straddle two sequences — only the interval lookup needs (b, q), one division per lane and tile.
-    // (Tiles per (b', query tile) as in the sweeps padded every sequence to a multiple of 16: 112 rows for T = 101.)
-    const int ntile = (int)((p.R + 15) / 16);
+    // way); a tile may straddle two sequences — only the interval lookup needs (b, q) = row mod (B*T).  32-bit row arithmetic
+    // (R < 2^31, host-checked): the head comes from a float product and one correction step instead of a 64-bit division
+    // (which was ~125 instructions of every row tile).
+    const int R = (int)p.R, ntile = (R + 15) / 16, BT = p.B * p.T;
+    const float inv_bt = 1.0f / (float)BT;
+    const float cx0 = l15 == 0 ? 1.0f : 0.0f, cx1 = l15 == 1 ? 1.0f : 0.0f, cx2 = l15 == 2 ? 1.0f : 0.0f;   // column selectors of hX
+    (void)cx0; (void)cx1; (void)cx2;
     const T* hin = reinterpret_cast<const T*>(p.hin);
 
     f32x4 dW[ECH][DT][DT];  // [e-e0][d][ub]: tile (j-tile = e*DT+d, u-tile = ub), L(first=j, second=u)
+    // bf16: L(first=j_local, second=c): mark ee of a group of four owns the columns c = 3 * (ee % 4) + {0: db1[j], 1 and 2: interval
+    // row (hi, lo span terms)} of the group's tile — the B operand of mark ee is hX shifted by 3 * (ee % 4) lanes (one DPP move)
+    f32x4 dWx[MX ? ECH / 4 : 1][DT];
     float adb[ECH][DT], adws[ECH][DT], adw[ECH][DT];
 #pragma unroll
     for (int e = 0; e < ECH; ++e)
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
             adb[e][d] = 0.f; adws[e][d] = 0.f; adw[e][d] = 0.f;
+            if constexpr (MX) dWx[e / 4][d] = zero4;
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub) dW[e][d][ub] = zero4;
         }
+    if constexpr (!MX) dWx[0][0] = zero4;
 
     // Operands of a row tile — H rows, intervals, dz — are three unconditional loads (rows clamped into the arrays), fetched
     // one tile ahead; dz and the intervals go through the wave's LDS scratch, from where the mark loop reads the four rows
@@ -81,22 +107,35 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
     struct TileOps { Frag4<T> hA[DT]; float span; float2 dz; };
     auto load_tile = [&](int t) {
         TileOps o;
-        const long row = min((long)t * 16 + l15, p.R - 1);
-        const int bp = (int)(row / p.T), q = (int)(row - (long)bp * p.T), bb = bp % p.B;
+        const int row = min(t * 16 + l15, R - 1);
+        int sidx = row - (int)((float)row * inv_bt) * BT;   // row mod (B*T): the estimate of the head is off by at most one
+        sidx = sidx < 0 ? sidx + BT : sidx;
+        sidx = sidx >= BT ? sidx - BT : sidx;
 #pragma unroll
-        for (int ub = 0; ub < DT; ++ub) o.hA[ub] = frag_ld<T>(hin + row * dh + ub * 16 + g4);
-        o.span = p.spans[(long)bb * p.T + q];
-        o.dz = *reinterpret_cast<const float2*>(p.dz_ws + row * EP + e0 + (g4 >> 1));   // lane group g: marks e0 + 2g, 2g + 1
+        for (int ub = 0; ub < DT; ++ub) o.hA[ub] = frag_ld<T>(hin + (long)row * dh + ub * 16 + g4);
+        o.span = p.spans[sidx];
+        o.dz = *reinterpret_cast<const float2*>(p.dz_ws + (long)row * EP + e0 + (g4 >> 1));   // lane group g: marks e0 + 2g, 2g + 1
         return o;
+    };
+    // "use" of a fetched tile: pins the wait for its loads to this point of the program
+    auto touch_tile = [&](TileOps& o) {
+#pragma unroll
+        for (int ub = 0; ub < DT; ++ub) {
+            if constexpr (sizeof(T) == 2) { uint2& h = *reinterpret_cast<uint2*>(&o.hA[ub]); asm volatile("" : "+v"(h.x), "+v"(h.y)); }
+            else { uint4& h = *reinterpret_cast<uint4*>(&o.hA[ub]); asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w)); }
+        }
+        asm volatile("" : "+v"(o.span), "+v"(o.dz.x), "+v"(o.dz.y));
     };
     const int tstep = (int)gridDim.x * 4, tfirst = (int)blockIdx.x * 4 + wave;
     TileOps cur;
-    if (tfirst < ntile) cur = load_tile(tfirst);
+    cur = load_tile(min(tfirst, ntile - 1));
+    touch_tile(cur);   // complete before the loop: a tile pending at the loop entry makes every in-loop wait conservative (it would
+                       // count the stores of the previous tile, i.e. wait for their acknowledges)
     for (int t = tfirst; t < ntile; t += tstep) {
-        const TileOps nxt = load_tile(t + tstep < ntile ? t + tstep : t);
+        TileOps nxt = load_tile(t + tstep < ntile ? t + tstep : t);
         asm volatile("" ::: "memory");   // the prefetch stays at the top of the tile
-        const long row0 = (long)t * 16;
-        const bool okA = row0 + l15 < p.R;   // row on the lane axis (A operand)
+        const int row0 = t * 16;
+        const bool okA = row0 + l15 < R;   // row on the lane axis (A operand)
         // rows past the end of the row space (last tile) contribute nothing: zero H and dz there
         dzs[l15 * ECH + (g4 >> 1)] = okA ? cur.dz.x : 0.f;
         dzs[l15 * ECH + (g4 >> 1) + 1] = okA ? cur.dz.y : 0.f;
@@ -111,9 +150,30 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
         }
         // bf16: span * w1s + b1 of every channel comes out of the matrix pipe (span_frag / W1X, bimau_common.h)
         Frag4<T> sfA;
-        if constexpr (sizeof(T) == 2) sfA = span_frag(cur.span, lane);
+        if constexpr (MX) sfA = span_frag(cur.span, lane);
         const float4 sp4 = *reinterpret_cast<const float4*>(sps + g4);
         const float spn[4] = {sp4.x, sp4.y, sp4.z, sp4.w};
+        Frag4<T> hX;   // L(first=row, second=c): branch-free — hi = the span truncated to bf16 (exact), lo = span - hi (rounded by the pack)
+        if constexpr (MX) {
+            f32x4 hx;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float hi = __uint_as_float(__float_as_uint(spn[r]) & 0xffff0000u);
+                hx[r] = fmaf(cx1, hi, fmaf(cx2, spn[r] - hi, cx0));
+            }
+            hX = frag_from_acc<T>(hx);
+        }
+        Frag4<T> hXv[4];
+        if constexpr (MX) {
+            hXv[0] = hX;
+            const uint2 h0 = *reinterpret_cast<const uint2*>(&hX);
+#define EDGL_ROW_SHR(x, n) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x110 + (n), 0xf, 0xf, true)
+            uint2 h;
+            h.x = EDGL_ROW_SHR(h0.x, 3); h.y = EDGL_ROW_SHR(h0.y, 3); *reinterpret_cast<uint2*>(&hXv[1]) = h;
+            h.x = EDGL_ROW_SHR(h0.x, 6); h.y = EDGL_ROW_SHR(h0.y, 6); *reinterpret_cast<uint2*>(&hXv[2]) = h;
+            h.x = EDGL_ROW_SHR(h0.x, 9); h.y = EDGL_ROW_SHR(h0.y, 9); *reinterpret_cast<uint2*>(&hXv[3]) = h;
+#undef EDGL_ROW_SHR
+        }
         f32x4 dHt[DT];   // dH[row][u] of this mark group, L(first=row, second=u)
 #pragma unroll
         for (int ut = 0; ut < DT; ++ut) dHt[ut] = zero4;
@@ -121,7 +181,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
 #pragma unroll
         for (int ee = 0; ee < ECH; ++ee) {
             const int e = e0 + ee;
-            if (e < p.E) {
+            if (EC == 16 || e < E) {
                 float dzr[4];   // dz[row g4 + r][e]: LDS broadcast
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dzr[r] = dzs[(g4 + r) * ECH + ee];
@@ -129,31 +189,34 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
                 for (int d = 0; d < DT; ++d) {
                     const int jt = e * DT + d, j = jt * 16 + l15;
                     f32x4 a = zero4;  // Zpre[row][j], L(first=row, second=j)
-                    if constexpr (sizeof(T) == 2) a = mma16(sfA, frag_ld<T>(W1X + (jt * 16 + l15) * XW + (g4 & 4)), a);
+                    if constexpr (MX) a = mma16(sfA, frag_ld<T>(W1X + (jt * 16 + l15) * XW + (g4 & 4)), a);
 #pragma unroll
                     for (int ub = 0; ub < DT; ++ub)
                         a = mma16(hA[ub], frag_ld<T>(W1T + (jt * 16 + l15) * pd.LDW + ub * 16 + g4), a);
                     const float wv = wvs[j];
-                    if constexpr (sizeof(T) == 4) {
+                    if constexpr (!MX) {
                         const float ws = w1s[j], bs = b1s[j];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) a[r] = fmaf(spn[r], ws, a[r]) + bs;
                     }
                     f32x4 du;
                     // the kernel is VALU-issue bound (3 waves per SIMD): three instructions per element after the sigmoid
-                    // (dz*z, wv*(1-z) as one fma, their product) and the three sums straight into their accumulators
+                    // (dz*z, wv*(1-z) as one fma, their product) and the sums straight into their accumulators
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float z = sigmoid_pre(a[r]);
                         const float t2 = dzr[r] * z;
                         du[r] = t2 * fmaf(-z, wv, wv);
-                        adb[ee][d] += du[r];
-                        adws[ee][d] = fmaf(du[r], spn[r], adws[ee][d]);
+                        if constexpr (!MX) {
+                            adb[ee][d] += du[r];
+                            adws[ee][d] = fmaf(du[r], spn[r], adws[ee][d]);
+                        }
                         adw[ee][d] += t2;
                     }
                     const Frag4<T> duf = frag_from_acc<T>(du);  // as A operand: A[m=j][kk=row]
 #pragma unroll
                     for (int ub = 0; ub < DT; ++ub) dW[ee][d][ub] = mma16(duf, hB[ub], dW[ee][d][ub]);
+                    if constexpr (MX) dWx[ee / 4][d] = mma16(duf, hXv[ee % 4], dWx[ee / 4][d]);
                     // dH[row][u] += sum_j du[row][j] W1[u][j]: du^T as A (contracting over j), W1 rows as B
                     const Frag4<T> duT = frag_from_acc<T>(mma16(duf, ident, zero4));   // L(first=j, second=row)
 #pragma unroll
@@ -161,34 +224,108 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
                         dHt[ut] = mma16(duT, frag_ld<T>(W1R + (ut * 16 + l15) * pd.LDR + jt * 16 + g4), dHt[ut]);
                 }
             }
+            if (MX && DT == 1 && (ee & 1)) __builtin_amdgcn_sched_barrier(0);   // at most two marks' operands and temporaries in flight (168 registers)
         }
+        // The next tile's operands are "used" here, in front of the stores: vmcnt counts loads and stores in issue order, and with the
+        // (conditional) stores between the prefetch and its first use the wait for the prefetch also waited for the stores' acknowledges.
+        touch_tile(nxt);
         // dH partial of this mark group: lane holds rows g4+r, channel u = ut*16 + l15
-        float* dst = p.dh_ws + ((long)blockIdx.y * p.R + row0) * dh;
+        float* dst = p.dh_ws + ((long)blockIdx.y * R + row0) * dh;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (row0 + g4 + r < p.R) {
+            if (row0 + g4 + r < R) {
 #pragma unroll
                 for (int ut = 0; ut < DT; ++ut) dst[(long)(g4 + r) * dh + ut * 16 + l15] = dHt[ut][r];
             }
         cur = nxt;
         PH_MARK(6);
     }
-    // ---- block reduction: waves take turns adding into the LDS accumulator (deterministic) -----------
+    // ---- block reduction ----------------------------------------------------------------------------------------------------------
+    // Slab form: once every wave is past the mark loop the whole LDS (weight images + accumulator) is free, and the four waves park
+    // their accumulator REGISTERS there as four [register][lane] slabs — independent, conflict-free stores.  The read-out then sums
+    // the four slabs in a fixed order straight into the partial row of this workgroup.  (Wave turns on one LDS accumulator were ~80
+    // dependent LDS round trips per wave, four turns in series: 40 % of the kernel in the phase stamps; LDS float atomics instead of
+    // the read-modify-writes were slower still: 73 -> 94 us.)
+    constexpr int RX = ECH * DT * DT * 4, RW = RX + (MX ? (ECH / 4) * DT * 4 : 2 * ECH * DT), NREG = RW + ECH * DT;
+    static_assert(NREG == intensity_bwd_nreg<T>(DT), "host / device slab layouts differ");
+    if (p.slab_epi) {
+        __syncthreads();
+        float* slab = reinterpret_cast<float*>(smem) + (size_t)wave * NREG * 64 + lane;
+#pragma unroll
+        for (int ee = 0; ee < ECH; ++ee)
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+#pragma unroll
+                for (int ub = 0; ub < DT; ++ub)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[((((ee * DT + d) * DT + ub) * 4) + r) * 64] = dW[ee][d][ub][r];
+                if constexpr (MX) {
+                    if (ee % 4 == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) slab[(RX + ((ee / 4) * DT + d) * 4 + r) * 64] = dWx[ee / 4][d][r];
+                    }
+                } else {
+                    slab[(RX + (ee * DT + d) * 2) * 64] = adb[ee][d];
+                    slab[(RX + (ee * DT + d) * 2 + 1) * 64] = adws[ee][d];
+                }
+                slab[(RW + ee * DT + d) * 64] = adw[ee][d];
+            }
+        __syncthreads();
+        const float* sl = reinterpret_cast<const float*>(smem);
+        auto sum4 = [&](int reg, int ln) {   // the four waves' values of (register, lane), fixed order
+            const float* q = sl + reg * 64 + ln;
+            return (q[0] + q[NREG * 64]) + (q[2 * NREG * 64] + q[3 * NREG * 64]);
+        };
+        for (int i = threadIdx.x; i < NPAR; i += blockDim.x) {
+            const int row = i / JE, j = i - row * JE;   // row < dh: dW1[row][j]; dh: interval row; dh + 1: db1; dh + 2: dw
+            const int jt = j >> 4, jl = j & 15, e = jt / DT, d = jt - e * DT, ee = e - e0;
+            if (ee < 0 || ee >= ECH) continue;     // every entry belongs to exactly one mark e -> one blockIdx.y
+            float v;
+            if (row < dh) {
+                v = sum4((((ee * DT + d) * DT + (row >> 4)) * 4) + (jl & 3), (jl >> 2) * 16 + (row & 15));
+            } else if (row == dh + 2) {
+                const int reg = RW + ee * DT + d;
+                v = (sum4(reg, jl) + sum4(reg, 16 + jl)) + (sum4(reg, 32 + jl) + sum4(reg, 48 + jl));
+            } else if constexpr (MX) {
+                const int reg = RX + ((ee / 4) * DT + d) * 4 + (jl & 3), ln = (jl >> 2) * 16 + 3 * (ee % 4);
+                v = row == dh + 1 ? sum4(reg, ln) : sum4(reg, ln + 1) + sum4(reg, ln + 2);
+            } else {
+                const int reg = RX + (ee * DT + d) * 2 + (row == dh ? 1 : 0);
+                v = (sum4(reg, jl) + sum4(reg, 16 + jl)) + (sum4(reg, 32 + jl) + sum4(reg, 48 + jl));
+            }
+            p.wpart[(long)blockIdx.x * NPARX + i] = v;
+        }
+    } else {
+    // turn form (the slabs do not fit): waves take turns adding into the LDS accumulator (deterministic)
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int ee = 0; ee < ECH; ++ee) {
                 const int e = e0 + ee;
-                if (e < p.E) {
+                if (EC == 16 || e < E) {
 #pragma unroll
                     for (int d = 0; d < DT; ++d) {
                         const int jt = e * DT + d;
-                        const float sb = group_sum4(adb[ee][d]), sws = group_sum4(adws[ee][d]), sw = group_sum4(adw[ee][d]);
-                        if (lane < 16) {
-                            const int j = jt * 16 + l15;
-                            accs[WROW + j] += sws;          // dW1[dh][j]   (interval row)
-                            accs[WROW + JE + j] += sb;     // db1[j]
-                            accs[WROW + 2 * JE + j] += sw;     // dw.flatten()[j]
+                        const float sw = group_sum4(adw[ee][d]);
+                        if (lane < 16) accs[WROW + 2 * JE + jt * 16 + l15] += sw;     // dw.flatten()[j]
+                        if constexpr (MX) {
+                            // columns 3 * (ee % 4) + {0: db1, 1: interval row hi, 2: lo} of the group's extra tile; register r is
+                            // channel j = jt*16 + g4 + r.  Lane c0 + 1 takes the lo term from its neighbour (DPP row_shl:1).
+                            const int c0 = 3 * (ee % 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float x = dWx[ee / 4][d][r];
+                                const float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x101, 0xf, 0xf, true));
+                                const int j = jt * 16 + g4 + r;
+                                if (l15 == c0 || l15 == c0 + 1) accs[l15 == c0 ? WROW + JE + j : WROW + j] += l15 == c0 ? x : x + nb;   // db1[j] | dW1[dh][j]
+                            }
+                        } else {
+                            const float sb = group_sum4(adb[ee][d]), sws = group_sum4(adws[ee][d]);
+                            if (lane < 16) {
+                                const int j = jt * 16 + l15;
+                                accs[WROW + j] += sws;          // dW1[dh][j]   (interval row)
+                                accs[WROW + JE + j] += sb;     // db1[j]
+                            }
                         }
 #pragma unroll
                         for (int ub = 0; ub < DT; ++ub)
@@ -207,6 +344,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1) ? 3 : 1) void inte
         const int e = (i % JE) / dh;  // every entry belongs to exactly one mark e -> one blockIdx.y
         const int row = i / JE, j = i - row * JE;
         if (e >= e0 && e < e0 + ECH) p.wpart[(long)blockIdx.x * NPARX + i] = row < dh ? accs[j * (dh + 1) + row] : accs[WROW + (row - dh) * JE + j];
+    }
     }
     // dscaling: fold this block's slice of kernel X's per-(b,head) partials into the same partial row.  All 256 threads
     // load (16 jobs x 16 marks per round), the 16 job slices are summed through LDS in a fixed order.
@@ -267,10 +405,16 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
     }
     // ---- Y ----
     {
-        MlpP mp{p.hin, p.dz_ws, p.spans, p.pack, (long)p.B * p.H * p.T, p.B, p.T, p.E, p.dh_ws, p.wpart, p.dsc_part, jobs};
-        const size_t smem_b = intensity_bwd_lds<T>(dh, p.E);
+        MlpP mp{p.hin, p.dz_ws, p.spans, p.pack, (long)p.B * p.H * p.T, p.B, p.T, p.E, p.dh_ws, p.wpart, p.dsc_part, jobs, 0};
+        size_t smem_b = intensity_bwd_lds<T>(dh, p.E);
+        const size_t slab_b = (size_t)4 * intensity_bwd_nreg<T>(DT) * 64 * sizeof(float);
+        mp.slab_epi = slab_b <= std::max(smem_b, (size_t)52 * 1024);   // (three workgroups per CU stay resident up to 53 KB)
+        if (mp.slab_epi) smem_b = std::max(smem_b, slab_b);
         EDGL_REQUIRE(smem_b <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: intensity kernel needs %zu B of LDS", smem_b);
-        auto kb = intensity_bwd_kernel<T, DT>;
+        EDGL_REQUIRE((long)p.B * p.H * p.T < (1l << 31) - 16, EDGL_ERR_SHAPE, "edgl_bimau_bwd: B*H*T = %ld rows exceed the 32-bit row index", (long)p.B * p.H * p.T);
+        // (a compile-time mark count — no guards around the mark blocks — lets the scheduler hoist the LDS operand reads of all eight
+        //  blocks: 168 registers no longer hold them, 25-37 spilled inside the tile loop, 81 -> 180 us.  Run-time E it is.)
+        auto kb = intensity_bwd_kernel<T, DT, 0>;
         hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
         hipLaunchKernelGGL(kb, dim3(KY_BLOCKS, KY_NY), dim3(256), smem_b, st, mp);
         EDGL_LAUNCH_CHECK();

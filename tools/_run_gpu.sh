@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do for E in 0 1 2; do
-echo -n "EARLY=$E "; EDGL_LABEL_EARLY=$E python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['step_ms_hipevents']['median'])"
-done; done
+python -m pytest tests/test_gpu_ops.py -x -q -k "bimau or mau" 2>&1 | tail -2
+python -m pytest tests/test_gpu_engine.py tests/test_gpu_sizes.py tests/test_gpu_ctsma.py tests/test_gpu_coding.py -x -q 2>&1 | tail -2
+EDGL_LABEL_EARLY=1 KT_LINES=9 bash tools/ktrace.sh | cut -c1-150 | grep -i "intens\|bimau\|metric"

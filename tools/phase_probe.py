@@ -15,7 +15,7 @@ from easydgl_amd import _lib  # noqa: E402
 from easydgl_amd.engine import TrainEngine  # noqa: E402
 
 NAMES = ["X: S + softmax", "X: G/dA/dlam/dV sweep", "X: dz, row term", "X: epilogue", "Y: pack -> LDS", "Y: tile operands", "Y: mark loop + dH store", "Y: reduction + partials",
-         "Z: S + softmax", "Z: dP/dS/dQ/dK/dT sweep", "Z: epilogue", "-", "-", "-", "-", "-"]
+         "Z: softmax", "Z: dP/dS/dQ/dK/dT sweep", "Z: epilogue", "Z: prefetch issue", "Z: first use of operands", "Z: S products", "-", "-"]
 
 
 def main():
