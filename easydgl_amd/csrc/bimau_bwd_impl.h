@@ -60,18 +60,6 @@ __device__ __forceinline__ void st_frag(T* dst, const f32x4& a) {
     else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&f);
 }
 
-// dropout keep-factors of the 4 elements (k = kt*16 + g4 + r) of one key tile: the paired hash of the forward kernel
-__device__ __forceinline__ void drop_factors(const DropKey& dk, uint32_t base, float (&facs)[4]) {
-    facs[0] = facs[1] = facs[2] = facs[3] = 1.0f;
-    if (dk.thresh != 0u) {
-        const uint32_t h0 = drop_hash_pair(dk, base), h1 = drop_hash_pair(dk, base + 2);
-        facs[0] = (h0 & 0xffffu) >= dk.t16 ? dk.scale : 0.f;
-        facs[1] = (h0 >> 16) >= dk.t16 ? dk.scale : 0.f;
-        facs[2] = (h1 & 0xffffu) >= dk.t16 ? dk.scale : 0.f;
-        facs[3] = (h1 >> 16) >= dk.t16 ? dk.scale : 0.f;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // X) sweep 1
 // ------------------------------------------------------------------------------------------------------------------
@@ -184,7 +172,11 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
         QOps qnext;
+#ifdef EDGL_NO_PREFETCH   // timing experiment only (wrong results)
+        qnext = qcur;
+#else
         if constexpr (PREF) qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
+#endif
         asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
         mask_q(qcur, qok);
         const float zq4[4] = {qcur.z.x, qcur.z.y, qcur.z.z, qcur.z.w};
@@ -198,8 +190,16 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
-        if constexpr (FL == 0) masked_softmax_impl<NT, false, false>(s, km, cscale, lane, q);
-        else masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        // s = P^T * (dropout scale), L(first=k, second=q): every use of P in this sweep carries the scale, so it rides on the softmax
+        // normalisation (no multiply of its own)
+        if constexpr (FL == 0) masked_softmax_impl<NT, false, false>(s, km, cscale, lane, q, dk.scale);
+        else {
+            masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] *= dk.scale;
+        }
         // The previous tile's results leave HERE, behind the first use of this tile's operands: stores count in vmcnt like loads, and
         // stores issued at the top of the iteration (in front of the prefetch) sat between the loads of the previous iteration and
         // the wait for them — that wait then also waited for the store to be acknowledged (~2 us per query tile in the stamps).
@@ -233,15 +233,15 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? ((p.flags & MAU_DIAG_ZERO) ? 0.0f : 1.0f) : gacc[r];
             }
-            float facs[4];
-            drop_factors(dk, dbase + kt * 16 + g4, facs);
+            // dropout: one hash per four neighbouring elements (drop_hash_quad; rate 0: threshold 0, everything kept, scale 1)
+            const uint64_t hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+            const bool keep[4] = {drop_quad_keep<0>(dk, hw), drop_quad_keep<1>(dk, hw), drop_quad_keep<2>(dk, hw), drop_quad_keep<3>(dk, hw)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = s[kt][r];
-                const float fp = facs[r] * pv;
+                const float fp = keep[r] ? s[kt][r] : 0.f;  // D*P (with the scale)
                 ap[r] = gv[r] * fp;                         // A' = D*G'*P
                 dg[r] = da[r] * fp;                         // dG' = dA' * D * P
-                rowdot = fmaf(da[r] * facs[r] * gv[r], pv, rowdot);   // dP1 * P, dP1 = dA' * D * G'
+                rowdot = fmaf(dg[r], gv[r], rowdot);        // dP1 * P, dP1 = dA' * D * G'  (before the diagonal of dG' is blocked)
             }
             if constexpr (FL == 0) {   // set_diag blocks the gradient into lambda
 #pragma unroll
@@ -336,6 +336,14 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
 
     const float cscale = rsqrtf((float)dh);
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
+    // 1/sqrt(dh) of dS, or 0 when every key of the sequence is padded (uniform softmax: no score takes a gradient, temporal.py:425-426)
+    float cz = cscale;
+    if constexpr (FL == 0) {
+        bool real = false;
+        for (int k = lane; k < Tp; k += 64) real |= km.madd[k] == 0.f;
+        cz = __any(real) ? cscale : 0.f;
+    }
+    (void)cz;
     const Frag4<T> ident = identity_frag<T>(lane);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const long R = (long)p.B * p.H * p.T;
@@ -390,7 +398,11 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         const bool qok = q < p.T;
         (void)qok;
         QOps qnext;
+#ifdef EDGL_NO_PREFETCH   // timing experiment only (wrong results)
+        qnext = qcur;
+#else
         if constexpr (PREF) qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
+#endif
         asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
         PH_MARK(3);
         // consume the tile fetched one iteration ago; rows past the sequence end contribute nothing to dK / dT_
@@ -425,9 +437,10 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         flush_pending();   // behind the first use of this tile's operands (see kernel X)
         asm volatile("" ::: "memory");
         PH_MARK(0);
+        // G' carries the dropout scale here (lambda * scale, diagonal := scale): dP1 = D * dA' * G' is then one multiply and one select
         Frag4<T> lf;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lf.v[i] = from_f32<T>((EC == 16 || (g4 + i) < E) ? qcur.lam[i] : 0.f);
+        for (int i = 0; i < 4; ++i) lf.v[i] = from_f32<T>((EC == 16 || (g4 + i) < E) ? qcur.lam[i] * dk.scale : 0.f);
         // rowsum(dP*P) = sum_k dP1*P (kernel X) + sum_k P[q][k] (dH[q].T_[k]) = ... + dH[q].H[q]   (H = P.T_, saved)
         float rowdot = 0.f;
         Frag4<T> dhf[DT], QT[DT], dHT[DT];
@@ -456,16 +469,16 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             if constexpr (FL == 0) {
                 const bool dtile = kt == qt;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gv[r] = (dtile && g4 + r == l15) ? 1.0f : gacc[r];
+                for (int r = 0; r < 4; ++r) gv[r] = (dtile && g4 + r == l15) ? dk.scale : gacc[r];
             } else if (kt == qt && !(p.flags & MAU_NO_DIAG)) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? ((p.flags & MAU_DIAG_ZERO) ? 0.0f : 1.0f) : gacc[r];
+                for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? ((p.flags & MAU_DIAG_ZERO) ? 0.0f : dk.scale) : gacc[r];
             }
-            float facs[4];
-            drop_factors(dk, dbase + kt * 16 + g4, facs);
+            const uint64_t hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+            const bool keep[4] = {drop_quad_keep<0>(dk, hw), drop_quad_keep<1>(dk, hw), drop_quad_keep<2>(dk, hw), drop_quad_keep<3>(dk, hw)};
             f32x4 a;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = da[r] * facs[r] * gv[r];   // dP1 (same expression as kernel X)
+            for (int r = 0; r < 4; ++r) a[r] = keep[r] ? da[r] * gv[r] : 0.f;   // dP1 = D * dA' * G'  (kernel X's dP1)
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
                 a = mma16(frag_ld<T>(Ts + (kt * 16 + l15) * dh + ub * 16 + g4), dhf[ub], a);
@@ -474,8 +487,14 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             for (int r = 0; r < 4; ++r) {
                 // tf.where(mask==0, paddings, S) (temporal.py:425-426) passes no gradient to a padded key's
                 // score; P is non-zero there only for fully padded rows (uniform softmax)
-                const bool padded = ((km.pad >> (kt * 4 + r)) & 1ull) || (FL != 0 && (p.flags & MAU_CAUSAL) && kt * 16 + g4 + r > q);
-                ds[r] = padded ? 0.f : s[kt][r] * (a[r] - rowdot) * cscale;
+                // BiMAU (FL == 0): the masked keys are the same for every query row, and P is EXACTLY 0 on them unless all keys of the
+                // sequence are padded — the select and the 1/sqrt(dh) factor are one per-wave factor `cz` on dQ and dK instead.
+                if constexpr (FL == 0) {
+                    ds[r] = s[kt][r] * (a[r] - rowdot);
+                } else {
+                    const bool padded = ((km.pad >> (kt * 4 + r)) & 1ull) || ((p.flags & MAU_CAUSAL) && kt * 16 + g4 + r > q);
+                    ds[r] = padded ? 0.f : s[kt][r] * (a[r] - rowdot) * cscale;
+                }
             }
             const Frag4<T> dsf = frag_from_acc<T>(ds);
 #pragma unroll
@@ -490,7 +509,13 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             }
         }
 #pragma unroll
-        for (int ut = 0; ut < DT; ++ut) pend_dq[ut] = frag_from_acc<T>(dQ[ut]);
+        for (int ut = 0; ut < DT; ++ut) {
+            if constexpr (FL == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dQ[ut][r] *= cz;
+            }
+            pend_dq[ut] = frag_from_acc<T>(dQ[ut]);
+        }
         pend_q = q;
         if constexpr (PREF) qcur = qnext;
         else if (qt + 1 < NT) qcur = load_q(qt + 1);
@@ -505,6 +530,10 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
 #pragma unroll
             for (int ut = 0; ut < DT; ++ut) {
                 T* row = dqkvt + (long)k * ldq + head * dh + ut * 16 + g4;
+                if constexpr (FL == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dKa[ut][kt][r] *= cz;
+                }
                 st_frag<T>(row + p.C, dKa[ut][kt]);
                 st_frag<T>(row + 3 * p.C, dTa[ut][kt]);
             }

@@ -196,8 +196,10 @@ constexpr int MAU_DIAG_ZERO = 4;
 // in 2- / 4-wide vector form (v_pk_fma_f32 / v_pk_add_f32).  The additive mask keeps its magnitude: a padded score is
 // "-2^32 + something below the f32 resolution there", a fully padded row is uniform exactly as in the reference.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-template <int NT, bool CAUSAL, bool VEC>
-__device__ __forceinline__ void masked_softmax_impl(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale, int lane, int q) {
+// NORM: s := softmax * post (the factor rides on the normalisation: the dropout scale of sweep 1, whose every use of P carries it);
+// !NORM: s := exp(v - max) unnormalised, the return value is 1 / sum (the forward folds it into lambda and the H rows).
+template <int NT, bool CAUSAL, bool VEC, bool NORM = true>
+__device__ __forceinline__ float masked_softmax_impl(f32x4 (&s)[NT], const KeyMask<NT>& km, float cscale, int lane, int q, float post = 1.0f) {
     const float c2 = cscale * 1.4426950408889634f;
     float mx = -INFINITY;
     const float* mrow = km.madd + (lane >> 4) * 4;
@@ -248,15 +250,18 @@ __device__ __forceinline__ void masked_softmax_impl(f32x4 (&s)[NT], const KeyMas
     }
     sum = group_sum4(sum);
     const float inv = fast_rcp(sum);
+    if constexpr (!NORM) return inv;
+    const float f = inv * post;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
         if constexpr (VEC) {
-            s[kt] *= f32x4{inv, inv, inv, inv};
+            s[kt] *= f32x4{f, f, f, f};
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[kt][r] *= inv;
+            for (int r = 0; r < 4; ++r) s[kt][r] *= f;
         }
     }
+    return inv;
 }
 // MODE 2: causal / bidirectional code paths behind one wave-uniform branch (no per-element causal selects on the
 //         bidirectional path), 2-wide packed f32 arithmetic — the bf16 forward.

@@ -149,7 +149,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
                 a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
             s[kt] = a;
         }
-        masked_softmax<NT, sizeof(T) == 2 ? 2 : 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s := P^T
+        // bf16: s := exp(v - max), UNNORMALISED; 1 / sum (`pinv`) rides on the H rows (4 values) and, together with the dropout scale,
+        // on lambda (G = lambda . marks^T is linear in it) — 2 x 28 multiplies per query tile that the tile itself never sees.
+        // f32: s := P^T (pinv = 1).
+        float pinv = 1.0f;
+        if constexpr (TR) {
+            if (p.flags & MAU_CAUSAL) pinv = masked_softmax_impl<NT, true, false, false>(s, km, cscale, lane, q);
+            else pinv = masked_softmax_impl<NT, false, false, false>(s, km, cscale, lane, q);
+        } else {
+            masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);
+        }
+        const float gfac = pinv * dk.scale;   // factor of G (and of its diagonal)
         // the previous tile's output rows leave here, behind the first use of this tile's operands: a store in front of the prefetch
         // sits between the previous iteration's loads and the wait for them, and that wait then waits for the store's acknowledge
         asm volatile("" ::: "memory");
@@ -167,6 +177,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
 #pragma unroll
                 for (int kt = 0; kt < NT; ++kt)
                     a = mma16(kfrag<T>(Ts, dh, Ts, LDT, kt * 16, ut * 16, lane), pf[kt], a);
+                if constexpr (TR) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] *= pinv;
+                }
                 hf[ut] = frag_from_acc<T>(a);
                 if (p.hin_out && qok) {   // H rows in the activation dtype: exactly what the intensity MLP consumed
                     T* dst = reinterpret_cast<T*>(p.hin_out) + (bp * p.T + q) * dh + ut * 16 + g4;
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         for (int i = 0; i < 4; ++i) {
             const float sc = scs[g4 + i], isc = iscs[g4 + i];
             lam4[i] = sc * __logf(1.0f + __expf(z4[i] * isc));  // temporal.py:305-306
-            lf.v[i] = from_f32<T>(lam4[i]);
+            lf.v[i] = from_f32<T>(lam4[i] * gfac);
         }
         if (qok) {
             float* dst = p.lam + (bp * p.T + q) * E + g4;
@@ -294,14 +308,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         }
         } else {   // values phase: lambda of this query tile was prefetched with the Q rows
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lf.v[i] = from_f32<T>(qcur.lam[i]);
+            for (int i = 0; i < 4; ++i) lf.v[i] = from_f32<T>(qcur.lam[i] * gfac);
         }
         // ---- G^T[k][q] = sum_e marks[k][e] lam[q][e]; diag := 1; A' = dropout(G * P) ------------
         const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);   // element index of (b', q, k=0); < 2^32 (host-checked)
         // One straight-line block for all key tiles (the dropout decision is taken once, outside; the diagonal is a select
         // on a scalar-and-ed lane mask): the scheduler can issue the seven MFMAs ahead and run the hashes in their shadow.
         const bool set_diag = !(p.flags & MAU_NO_DIAG);
-        const float dval = (p.flags & MAU_DIAG_ZERO) ? 0.0f : 1.0f;   // later mark groups of a split call (bimau_common.h)
+        const float dval = (p.flags & MAU_DIAG_ZERO) ? 0.0f : gfac;   // later mark groups of a split call (bimau_common.h): 0
         auto modulate = [&](auto drop_on) {
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt) {
@@ -312,12 +326,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
                     gacc[r] = (dtile && g4 + r == l15) ? dval : gacc[r];
                     s[kt][r] = gacc[r] * s[kt][r];     // temporal.py:441
                 }
-                if constexpr (decltype(drop_on)::value) {                       // temporal.py:442
-                    const uint32_t h0 = drop_hash_pair(dk, dbase + kt * 16 + g4), h1 = drop_hash_pair(dk, dbase + kt * 16 + g4 + 2);
-                    s[kt][0] = (h0 & 0xffffu) >= dk.t16 ? s[kt][0] * dk.scale : 0.f;
-                    s[kt][1] = (h0 >> 16) >= dk.t16 ? s[kt][1] * dk.scale : 0.f;
-                    s[kt][2] = (h1 & 0xffffu) >= dk.t16 ? s[kt][2] * dk.scale : 0.f;
-                    s[kt][3] = (h1 >> 16) >= dk.t16 ? s[kt][3] * dk.scale : 0.f;
+                if constexpr (decltype(drop_on)::value) {                       // temporal.py:442 (the scale is in G already)
+                    const uint64_t hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+                    s[kt][0] = drop_quad_keep<0>(dk, hw) ? s[kt][0] : 0.f;
+                    s[kt][1] = drop_quad_keep<1>(dk, hw) ? s[kt][1] : 0.f;
+                    s[kt][2] = drop_quad_keep<2>(dk, hw) ? s[kt][2] : 0.f;
+                    s[kt][3] = drop_quad_keep<3>(dk, hw) ? s[kt][3] : 0.f;
                 }
                 pf[kt] = frag_from_acc<T>(s[kt]);
             }

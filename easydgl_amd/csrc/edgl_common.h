@@ -301,6 +301,21 @@ __device__ __forceinline__ uint32_t drop_hash_pair(const DropKey& k, uint32_t id
     h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
     return h;
 }
+// Quad form (BiMAU kernels): ONE 32-bit hash of the index of the first of four neighbouring elements, widened to 64 bits by one
+// 32 x 32 -> 64 multiply (v_mad_u64_u32): element r of the quad owns the 16-bit field [16r, 16r + 16) and is kept iff its field is
+// >= t16.  The top field ranges over [0, 0xFFF1] only: |p_eff - p| <= 2.3e-4 p there, 8e-6 on the others (tools/ hash statistics in
+// rates, field / lag / step correlations at the noise level of 2^18 samples).  Half the VALU work of two paired hashes.
+__device__ __forceinline__ uint64_t drop_hash_quad(const DropKey& k, uint32_t idx0) {
+    uint32_t h = (idx0 ^ k.k0) * 0x9E3779B1u + k.k1;
+    h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
+    return (uint64_t)h * 0xFFF1AFD7u;
+}
+// keep-decision of element r (compile-time) of a quad
+template <int R>
+__device__ __forceinline__ bool drop_quad_keep(const DropKey& k, uint64_t w) {
+    const uint32_t half = R < 2 ? (uint32_t)w : (uint32_t)(w >> 32);
+    return ((R & 1) ? (half >> 16) : (half & 0xffffu)) >= k.t16;
+}
 __device__ __forceinline__ float drop_apply(const DropKey& k, uint64_t idx, float x) {
     return k.thresh == 0u ? x : (drop_keep(k, idx) ? x * k.scale : 0.f);
 }
