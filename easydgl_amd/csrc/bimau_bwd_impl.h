@@ -172,11 +172,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
         QOps qnext;
-#ifdef EDGL_NO_PREFETCH   // timing experiment only (wrong results)
-        qnext = qcur;
-#else
         if constexpr (PREF) qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
-#endif
         asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
         mask_q(qcur, qok);
         const float zq4[4] = {qcur.z.x, qcur.z.y, qcur.z.z, qcur.z.w};
@@ -398,11 +394,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         const bool qok = q < p.T;
         (void)qok;
         QOps qnext;
-#ifdef EDGL_NO_PREFETCH   // timing experiment only (wrong results)
-        qnext = qcur;
-#else
         if constexpr (PREF) qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
-#endif
         asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
         PH_MARK(3);
         // consume the tile fetched one iteration ago; rows past the sequence end contribute nothing to dK / dT_
