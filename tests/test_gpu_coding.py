@@ -235,3 +235,76 @@ def test_mark_groups_share_one_dropout_mask(unit):
     gb, gs = big.st_kernel.grad[:, 16 * dh:], small.st_kernel.grad
     assert float((gb - gs).abs().max()) < 5e-5 * (1 + float(gs.abs().max()))
     assert not torch.equal(ob, big(xb, xb, ids_t, spans, marks32, False)[0])       # dropout was on
+
+
+def _bimau_problem(B, Tn, C, H, E, rate, seed):
+    from easydgl_amd.module import temporal as T
+    att = T.BiMAU(C, H, E, rate, in_units=C, gen=_gen(seed)).cuda()
+    with torch.no_grad():
+        att.scaling.add_(0.2 * torch.randn(E, generator=_gen(seed + 1)).cuda())
+        att.dense_kernel.mul_(8.0)                               # scores that spread the softmax
+    rng = np.random.default_rng(seed)
+    x = torch.tensor(rng.standard_normal((B, Tn, C)), dtype=torch.float32).cuda()
+    ids = rng.integers(1, 40, size=(B, Tn)); ids[0, :5] = 0
+    spans = torch.tensor(rng.uniform(0, 5, size=(B, Tn)), dtype=torch.float32).cuda()
+    marks = torch.tensor(O.synthetic_mark_table(40, E, multi_hot=True)[ids].astype(np.uint8)).cuda()
+    return att, x, torch.tensor(ids).cuda(), spans, marks
+
+
+def test_attention_dropout_is_unbiased():
+    """tf.layers.dropout (temporal.py:442) keeps an element with probability 1 - rate and scales it by 1 / (1 - rate): the mean of the
+    outputs over many masks approaches the output without dropout like 1 / sqrt(N).  The keep decisions come from 16-bit fields of one
+    64-bit hash per four neighbouring (query, key) pairs (drop_hash_quad) and the scale rides on lambda — a rate or scale that is off by
+    2 % leaves a bias this test sees."""
+    from easydgl_amd import ops
+    B, Tn, C, H, E, rate, N = 4, 53, 64, 4, 16, 0.1, 1600
+    att, x, ids, spans, marks = _bimau_problem(B, Tn, C, H, E, rate, 21)
+    o0, _ = att(x, x, ids, spans, marks, False)
+    a0 = o0 - x                                                  # the attention term (the residual is not dropped)
+    state = ops.make_rng_state("cuda", seed=5)
+    acc = torch.zeros_like(o0)
+    first = None
+    with torch.no_grad():
+        for i in range(N):
+            t, _ = att(x, x, ids, spans, marks, True, drop=ops.Drop(rate, state, 3))
+            ops.rng_advance(state)
+            acc += t
+            if first is None:
+                first = t.clone()
+        e1 = float((first - o0).norm()) / float(a0.norm())
+        en = float((acc / N - o0).norm()) / float(a0.norm())
+    assert e1 > 0.02                                             # dropout was on
+    assert en < 1.5 * e1 / np.sqrt(N), (e1, en)                  # ~ e1 / sqrt(N); a biased mask or scale floors at the bias
+    assert en < 0.012, (e1, en)                                  # (a 2 % error of the rate or the scale would leave 0.02 here)
+
+
+@pytest.mark.parametrize("flags_unit", ["BiMAU", "MAU"])
+def test_attention_dropout_backward_uses_the_forward_masks(flags_unit):
+    """With a fixed (seed, step, stream) the dropout mask is a pure function of the element index, so the unit is a deterministic
+    function of its input and the gradient of the backward sweeps — which re-derive the masks — must match a central finite
+    difference of the forward (float32 path).  A sweep that dropped other (query, key) pairs than the forward would be off by O(1)."""
+    from easydgl_amd import ops
+    from easydgl_amd.module import temporal as T
+    B, Tn, C, H, E, rate = 2, 37, 64, 4, 16, 0.25
+    att, x, ids, spans, marks = _bimau_problem(B, Tn, C, H, E, rate, 33)
+    if flags_unit == "MAU":
+        att = T.MAU(C, H, E, rate, gen=_gen(34)).cuda()
+        with torch.no_grad():
+            att.scaling.add_(0.2 * torch.randn(E, generator=_gen(35)).cuda())
+    drop = ops.Drop(rate, ops.make_rng_state("cuda", seed=11), 3)
+    rng = np.random.default_rng(3)
+    w = torch.tensor(rng.standard_normal((B, Tn, C)), dtype=torch.float32).cuda()
+    v = torch.tensor(rng.standard_normal((B, Tn, C)), dtype=torch.float32).cuda()
+    v = v / v.norm()
+
+    def f(xx):
+        o, lam = att(xx, xx, ids, spans, marks, True, drop=drop)
+        return (o * w).sum() + 0.1 * lam.sum()
+
+    xg = x.clone().requires_grad_()
+    f(xg).backward()
+    analytic = float((xg.grad * v).sum())
+    eps = 2e-2
+    with torch.no_grad():
+        numeric = float(f(x + eps * v) - f(x - eps * v)) / (2 * eps)
+    assert abs(analytic - numeric) < 2e-2 * max(abs(numeric), float(xg.grad.norm()) * 0.05), (analytic, numeric)
