@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = EC ? EC : p.E;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index through the scalar unit: (b, head) and every base pointer derived from them are then wave-uniform VALUES for
+    // the compiler too — global addresses become scalar base + 32-bit lane offset instead of 64-bit vector arithmetic per load
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long job = (long)blockIdx.x * p.waves + wave;
     if (job >= (long)p.B * p.H) return;
     const int b = (int)(job / p.H), head = (int)(job % p.H);
@@ -134,11 +136,17 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
             o.dof[ub] = frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4);
         }
         o.z = *reinterpret_cast<const float4*>(p.z + row * EP + g4);
+        if constexpr (EC == 16) {   // one 16-byte load each
+            const float4 l4 = *reinterpret_cast<const float4*>(p.lam + row * EC + g4), d4 = *reinterpret_cast<const float4*>(dlx_src + row * EC + g4);
+            o.lam[0] = l4.x; o.lam[1] = l4.y; o.lam[2] = l4.z; o.lam[3] = l4.w;
+            o.dlx[0] = d4.x; o.dlx[1] = d4.y; o.dlx[2] = d4.z; o.dlx[3] = d4.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = EC == 16 ? g4 + i : min(g4 + i, E - 1);
-            o.lam[i] = p.lam[row * E + e];
-            o.dlx[i] = dlx_src[row * E + e];
+            for (int i = 0; i < 4; ++i) {
+                const int e = min(g4 + i, E - 1);
+                o.lam[i] = p.lam[row * E + e];
+                o.dlx[i] = dlx_src[row * E + e];
+            }
         }
         return o;
     };
@@ -301,7 +309,9 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = EC ? EC : p.E;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index through the scalar unit: (b, head) and every base pointer derived from them are then wave-uniform VALUES for
+    // the compiler too — global addresses become scalar base + 32-bit lane offset instead of 64-bit vector arithmetic per load
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long job = (long)blockIdx.x * p.waves + wave;
     if (job >= (long)p.B * p.H) return;
     const int b = (int)(job / p.H), head = (int)(job % p.H);
@@ -365,8 +375,13 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             for (int y = 0; y < NYP; ++y)
                 o.dHp[ub][y] = *reinterpret_cast<const float4*>(p.dh_ws + ((long)y * R + row) * dh + ub * 16 + g4);
         }
+        if constexpr (EC == 16) {
+            const float4 l4 = *reinterpret_cast<const float4*>(p.lam + row * EC + g4);
+            o.lam[0] = l4.x; o.lam[1] = l4.y; o.lam[2] = l4.z; o.lam[3] = l4.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o.lam[i] = p.lam[row * E + (EC == 16 ? g4 + i : min(g4 + i, E - 1))];
+            for (int i = 0; i < 4; ++i) o.lam[i] = p.lam[row * E + min(g4 + i, E - 1)];
+        }
         o.rowdot = p.rowdot_ws[row];
         return o;
     };

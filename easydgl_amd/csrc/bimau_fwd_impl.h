@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
     (void)W1T; (void)W1X; (void)w1s; (void)b1s; (void)wvs; (void)scs; (void)iscs;
     if constexpr (FUSED) __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index through the scalar unit: (b, head) and every base pointer derived from them are then wave-uniform VALUES for
+    // the compiler too — global addresses become scalar base + 32-bit lane offset instead of 64-bit vector arithmetic per load
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long job = (long)blockIdx.x * p.waves + wave;
     if (job >= (long)p.B * p.H) return;
     const int b = (int)(job / p.H), head = (int)(job % p.H);
