@@ -1,4 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_ops.py tests/test_gpu_coding.py -x -q -k "bimau or mau or attention" 2>&1 | tail -2
-EDGL_LABEL_EARLY=1 KT_LINES=14 bash tools/ktrace.sh | cut -c1-150 | grep -i "intens\|bimau\|metric"
+bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
+bash tools/profile_mfma.sh > gpurun_out/mfma.log 2>&1
+python bench.py > gpurun_out/bench_default.log 2>&1
+tail -1 gpurun_out/bench_default.log | cut -c1-600
