@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
-bash tools/profile_mfma.sh > gpurun_out/mfma.log 2>&1
-python bench.py > gpurun_out/bench_default.log 2>&1
-tail -1 gpurun_out/bench_default.log | cut -c1-600
+for L in 0 55000 81000; do
+echo "SW1_LDS=$L"; if [ $L != 0 ]; then export EDGL_SW1_LDS=$L; fi
+EDGL_LABEL_EARLY=1 KT_LINES=14 bash tools/ktrace.sh | cut -c1-150 | grep -i "sweep1"
+done
