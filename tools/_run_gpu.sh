@@ -1,6 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for L in 0 55000 81000; do
-echo "SW1_LDS=$L"; if [ $L != 0 ]; then export EDGL_SW1_LDS=$L; fi
-EDGL_LABEL_EARLY=1 KT_LINES=14 bash tools/ktrace.sh | cut -c1-150 | grep -i "sweep1"
-done
+python -m pytest tests/test_gpu_ops.py -x -q -k "gemm" 2>&1 | tail -2
+EDGL_LABEL_EARLY=1 KT_LINES=16 bash tools/ktrace.sh | cut -c1-150 | grep -i "tile_nn\|metric"
