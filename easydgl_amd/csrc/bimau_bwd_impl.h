@@ -386,6 +386,9 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         return o;
     };
     PH_DECL
+#ifdef EDGL_PHASE_TIMING
+    const unsigned long long clk_m0 = __builtin_readcyclecounter(), clk_r0 = wall_clock64();
+#endif
     QOps qcur = load_q(0);
     touch_regs(qcur);   // complete before the loop (edgl_common.h)
     // dQ of a query tile is stored at the top of the next iteration (see kernel X: the back edge drains vmcnt)
@@ -548,6 +551,9 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     }
     PH_MARK(2);
     PH_FLUSH(8);
+#ifdef EDGL_PHASE_TIMING   // shader cycles and 100 MHz ticks of this wave's life: their ratio is the clock the kernel ran at
+    if (lane == 0) { atomicAdd(&g_phase_cycles[14], __builtin_readcyclecounter() - clk_m0); atomicAdd(&g_phase_cycles[15], wall_clock64() - clk_r0); }
+#endif
 }
 
 

@@ -36,11 +36,13 @@ def main():
     torch.cuda.synchronize()
     raw.edgl_debug_phase_cycles(buf, 0)
     jobs = cfg["batch"] * cfg["num_heads"]
-    tot = sum(buf[:16])
+    tot = sum(buf[:14])
     for i, nm in enumerate(NAMES):
         if nm != "-":
             print(f"{nm:28s} {buf[i] / n / jobs:12.0f} cyc/job  {100.0 * buf[i] / tot:5.1f}%")
     print(f"total {tot / n / jobs:.0f} cycles per (b, head) job")
+    if buf[15]:
+        print(f"sweep 2: {buf[14] / n / jobs:.0f} shader cycles and {buf[15] / n / jobs * 10:.0f} ns per wave -> {buf[14] / buf[15] / 10:.2f} GHz")
 
 
 main()
