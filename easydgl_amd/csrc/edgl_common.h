@@ -281,18 +281,44 @@ __device__ __forceinline__ DropKey make_dropkey(const uint64_t* rng_state, uint3
     k.t16 = rate <= 0.f ? 0u : (uint32_t)(rate * 65536.0f + 0.5f);   // 16-bit threshold for the paired form
     return k;
 }
-__device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t idx) {
-    // one multiply / xor-shift round per element; (seed, step, op) enter through k0/k1, the upper index bits
-    // (tensors beyond 2^32 elements) through the additive term
-    uint32_t h = ((uint32_t)idx ^ k.k0) * 0x9E3779B1u;
-    h += (uint32_t)(idx >> 32) * 0x7feb352du + k.k1;
+// Element-wise dropout (hidden dropouts: encoder, block tail, LayerNorm kernels, edgl_dropout): ONE multiply / xor-shift hash per
+// ALIGNED GROUP OF FOUR consecutive elements, widened to 64 bits by one 32 x 32 -> 64 multiply; element idx owns the 16-bit field
+// (idx & 3) of the hash of idx >> 2 and is kept iff the field is >= t16 (|p_eff - p| <= 8e-6, 2.3e-4 p on the top field;
+// tools/dropout_hash_stats.py).  (seed, step, op) enter through k0 / k1, index bits above 2^34 through the additive term.  Every
+// kernel that draws or re-derives a mask goes through drop_quad64 — a thread that owns four aligned elements hashes once
+// (drop_apply4 / drop_keep4), the per-element forms below give the same decisions.
+__device__ __forceinline__ uint64_t drop_quad64(const DropKey& k, uint64_t idx4) {
+    const uint64_t qi = idx4 >> 2;
+    uint32_t h = ((uint32_t)qi ^ k.k0) * 0x9E3779B1u;
+    h += (uint32_t)(qi >> 32) * 0x7feb352du + k.k1;
     h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
-    return h >= k.thresh;
+    return (uint64_t)h * 0xFFF1AFD7u;
 }
-__device__ __forceinline__ bool drop_keep32(const DropKey& k, uint32_t idx) {   // == drop_keep(k, idx) for idx < 2^32
-    uint32_t h = (idx ^ k.k0) * 0x9E3779B1u + k.k1;
-    h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
-    return h >= k.thresh;
+// keep-decision of element r (compile-time) of a group
+template <int R>
+__device__ __forceinline__ bool drop_quad_keep(const DropKey& k, uint64_t w) {
+    const uint32_t half = R < 2 ? (uint32_t)w : (uint32_t)(w >> 32);
+    return ((R & 1) ? (half >> 16) : (half & 0xffffu)) >= k.t16;
+}
+// x[0..3] = elements idx4 .. idx4 + 3 (idx4 a multiple of 4): dropped ones := 0, kept ones scaled
+__device__ __forceinline__ void drop_apply4(const DropKey& k, uint64_t idx4, float (&x)[4]) {
+    if (k.thresh == 0u) return;
+    const uint64_t w = drop_quad64(k, idx4);
+    x[0] = drop_quad_keep<0>(k, w) ? x[0] * k.scale : 0.f;
+    x[1] = drop_quad_keep<1>(k, w) ? x[1] * k.scale : 0.f;
+    x[2] = drop_quad_keep<2>(k, w) ? x[2] * k.scale : 0.f;
+    x[3] = drop_quad_keep<3>(k, w) ? x[3] * k.scale : 0.f;
+}
+// bit r set: element idx4 + r is kept
+__device__ __forceinline__ uint32_t drop_keep4(const DropKey& k, uint64_t idx4) {
+    if (k.thresh == 0u) return 0xfu;
+    const uint64_t w = drop_quad64(k, idx4);
+    return (drop_quad_keep<0>(k, w) ? 1u : 0u) | (drop_quad_keep<1>(k, w) ? 2u : 0u) | (drop_quad_keep<2>(k, w) ? 4u : 0u) |
+           (drop_quad_keep<3>(k, w) ? 8u : 0u);
+}
+__device__ __forceinline__ bool drop_keep(const DropKey& k, uint64_t idx) {
+    const uint64_t w = drop_quad64(k, idx & ~3ull);
+    return (uint32_t)((w >> (16 * (idx & 3ull))) & 0xffffull) >= k.t16;
 }
 // Paired form for the attention matrix: ONE hash decides two neighbouring elements (idx_even, idx_even+1) with
 // 16-bit thresholds (|p_eff - p| < 8e-6).  Forward and backward kernels must both use it.
@@ -309,12 +335,6 @@ __device__ __forceinline__ uint64_t drop_hash_quad(const DropKey& k, uint32_t id
     uint32_t h = (idx0 ^ k.k0) * 0x9E3779B1u + k.k1;
     h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
     return (uint64_t)h * 0xFFF1AFD7u;
-}
-// keep-decision of element r (compile-time) of a quad
-template <int R>
-__device__ __forceinline__ bool drop_quad_keep(const DropKey& k, uint64_t w) {
-    const uint32_t half = R < 2 ? (uint32_t)w : (uint32_t)(w >> 32);
-    return ((R & 1) ? (half >> 16) : (half & 0xffffu)) >= k.t16;
 }
 __device__ __forceinline__ float drop_apply(const DropKey& k, uint64_t idx, float x) {
     return k.thresh == 0u ? x : (drop_keep(k, idx) ? x * k.scale : 0.f);

@@ -106,18 +106,19 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const uint64_t idx = (uint64_t)row * 3 * p.C + s * p.C + c0;
+        // one hash per four elements (drop_apply4): 24 per-element hashes were half of this kernel's instructions
+        float lo[4] = {v[s][0], v[s][1], v[s][2], v[s][3]}, hi[4] = {v[s][4], v[s][5], v[s][6], v[s][7]};
+        drop_apply4(dk, idx, lo);
+        drop_apply4(dk, idx + 4, hi);
         if constexpr (sizeof(T) == 2) {
             Vec16<T> o;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) o.v[q] = from_f32<T>(drop_apply(dk, idx + q, v[s][q]));
+            for (int q = 0; q < 4; ++q) { o.v[q] = from_f32<T>(lo[q]); o.v[4 + q] = from_f32<T>(hi[q]); }
             st16<T>(out + s * p.C + c0, o);
         } else {
             Vec16<T> o0, o1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                o0.v[q] = from_f32<T>(drop_apply(dk, idx + q, v[s][q]));
-                o1.v[q] = from_f32<T>(drop_apply(dk, idx + 4 + q, v[s][4 + q]));
-            }
+            for (int q = 0; q < 4; ++q) { o0.v[q] = from_f32<T>(lo[q]); o1.v[q] = from_f32<T>(hi[q]); }
             st16<T>(out + s * p.C + c0, o0);
             st16<T>(out + s * p.C + c0 + 4, o1);
         }
@@ -166,12 +167,15 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(EncBwdP p) {
                 const uint64_t base = (uint64_t)row * 3 * p.C;
                 const Frag4<T> g1 = frag_ld<T>(d + p.C + c0), g2 = frag_ld<T>(d + 2 * p.C + c0);
                 const float nm = s_nm[b - bb];
+                float v1[4], v2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v1[j] = to_f32(g1.v[j]); v2[j] = to_f32(g2.v[j]); }
+                drop_apply4(dk, base + p.C + c0, v1);
+                drop_apply4(dk, base + 2 * p.C + c0, v2);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float v1 = drop_apply(dk, base + p.C + c0 + j, to_f32(g1.v[j]));
-                    const float v2 = drop_apply(dk, base + 2 * p.C + c0 + j, to_f32(g2.v[j]));
-                    apos[j] += v1;
-                    amk[j] += nm * v2;
+                    apos[j] += v1[j];
+                    amk[j] += nm * v2[j];
                 }
             }
     }
@@ -256,18 +260,24 @@ __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
             if (r >= SR || s_id[r] == 0) continue;  // padding rows and rows past the end
             const long row = r0 + r;
             float* dst = acc + s_lead[r] * p.C + c0;
+            float gv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                atomicAdd(dst + j, sq * drop_apply(dk, (uint64_t)row * 3 * p.C + c0 + j, to_f32(g[k].v[j])));
+            for (int j = 0; j < 4; ++j) gv[j] = to_f32(g[k].v[j]);
+            drop_apply4(dk, (uint64_t)row * 3 * p.C + c0, gv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(dst + j, sq * gv[j]);
         }
         for (int r = rl + MAXR * rows_par; r < SR; r += rows_par) {   // (C < 128: more than MAXR rows per thread)
             if (s_id[r] == 0) continue;
             const long row = r0 + r;
             const Frag4<T> g0 = item_grad(row);
             float* dst = acc + s_lead[r] * p.C + c0;
+            float gv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                atomicAdd(dst + j, sq * drop_apply(dk, (uint64_t)row * 3 * p.C + c0 + j, to_f32(g0.v[j])));
+            for (int j = 0; j < 4; ++j) gv[j] = to_f32(g0.v[j]);
+            drop_apply4(dk, (uint64_t)row * 3 * p.C + c0, gv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(dst + j, sq * gv[j]);
         }
     }
     __syncthreads();
@@ -341,9 +351,10 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
             for (int j = 0; j < 4; ++j) v.v[j] = from_f32<bf16>(to_f32(v.v[j]) + to_f32(ga[k].v[j]) + to_f32(gb[k].v[j]));
         }
         if (dk.thresh != 0u) {
+            const uint32_t keep = drop_keep4(dk, (uint64_t)row * 3 * CF + coff + c0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (!drop_keep(dk, (uint64_t)row * 3 * CF + coff + c0 + j)) v.v[j] = from_f32<bf16>(0.f);
+                if (!((keep >> j) & 1u)) v.v[j] = from_f32<bf16>(0.f);
         }
         *reinterpret_cast<uint2*>(Gs + r * LDG + c0) = *reinterpret_cast<const uint2*>(&v);
     }

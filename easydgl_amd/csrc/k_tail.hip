@@ -265,11 +265,12 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
                 const int row = rt * 16 + l15;
                 float v[4], xr[4];
                 ld_bf4(bufB + row * LD + nl, xr);
+                float dv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = rbf(acc[rt][r] + bv[r]);
-                    z[rt][r] = drop_apply(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), v[r]) + xr[r];
-                }
+                for (int r = 0; r < 4; ++r) { v[r] = rbf(acc[rt][r] + bv[r]); dv[r] = v[r]; }
+                drop_apply4(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl), dv);   // one hash per four channels
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[rt][r] = dv[r] + xr[r];
                 st_bf4(bufS + row * LD + nl, v);
             }
     }
@@ -333,11 +334,12 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
                 const int row = rt * 16 + l15;
                 float v[4], xr[4];
                 ld_bf4(bufB + row * LD + nl, xr);
+                float dv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = rbf(acc3[rt][r] + bv[r]);
-                    z[rt][r] = drop_apply(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), v[r]) + xr[r];
-                }
+                for (int r = 0; r < 4; ++r) { v[r] = rbf(acc3[rt][r] + bv[r]); dv[r] = v[r]; }
+                drop_apply4(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl), dv);   // one hash per four channels
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[rt][r] = dv[r] + xr[r];
                 st_bf4(bufS + row * LD + nl, v);
             }
     }
@@ -652,8 +654,9 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         float ov[4], av[4];
         ld_bf4(bufA + row * LD + nl, ov);
         ld_bf4(bufB + row * LD + nl, av);
+        drop_apply4(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl), ov);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z[rt][r] = drop_apply(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), ov[r]) + av[r];
+        for (int r = 0; r < 4; ++r) z[rt][r] = ov[r] + av[r];
     }
     RowImage<CT> im_p;            // gelu'(pre_f) half: requested one phase ahead as well
     im_p.load(p.pre_f + row0 * 2 * C, 2 * C, T);
@@ -673,8 +676,9 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 da1[rt][r] = rbf(dz[rt][r]);
-                v[r] = drop_apply(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), dz[rt][r]);
+                v[r] = dz[rt][r];
             }
+            drop_apply4(dk2, (uint64_t)((row0 + min(row, T - 1)) * C + nl), v);
             st_bf4(bufC + row * LD + nl, v);
         }
     lds_barrier();
@@ -731,8 +735,9 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         float ov[4], xv[4];
         ld_bf4(bufA + row * LD + nl, ov);
         ld_bf4(bufB + row * LD + nl, xv);
+        drop_apply4(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl), ov);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z[rt][r] = drop_apply(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), ov[r]) + xv[r];
+        for (int r = 0; r < 4; ++r) z[rt][r] = ov[r] + xv[r];
     }
     PHB_MARK(5);   // ao, x_in -> z1
     {
@@ -748,8 +753,9 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 w[r] = dz[rt][r];
-                v[r] = drop_apply(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl + r), dz[rt][r]);
+                v[r] = dz[rt][r];
             }
+            drop_apply4(dk1, (uint64_t)((row0 + min(row, T - 1)) * C + nl), v);
             st_bf4(bufC + row * LD + nl, v);
             st_bf4(bufS + row * LD + nl, w);
         }

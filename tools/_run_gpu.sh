@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch driver for one gpurun call (edited per experiment): tests of the touched family, then the kernel table of a short bench run
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_ops.py tests/test_gpu_coding.py -x -q -k "bimau or mau or attention" 2>&1 | tail -2
-KT_LINES=14 bash tools/ktrace.sh | cut -c1-150
+python -m pytest tests/test_gpu_ops.py tests/test_gpu_engine.py tests/test_gpu_model.py -x -q 2>&1 | tail -2
+KT_LINES=32 bash tools/ktrace.sh | cut -c1-150 | grep -i "encode\|tail_\|metric"
+for i in 1 2; do python bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['step_ms_hipevents']['median'])"; done
