@@ -1,6 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
-bash tools/profile_mfma.sh > gpurun_out/mfma.log 2>&1
-python bench.py > gpurun_out/bench_default.log 2>&1
-tail -1 gpurun_out/bench_default.log | cut -c1-300
+python -m pytest tests/test_gpu_ops.py -x -q -k "gemm" 2>&1 | tail -2
+KT_LINES=16 bash tools/ktrace.sh | cut -c1-150 | grep -i "tile_nn\|metric"
