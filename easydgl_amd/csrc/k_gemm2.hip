@@ -459,8 +459,9 @@ __global__ __launch_bounds__(W_NT) void strip_stream_kernel(StripP p) {
 // ------------------------------------------------------------------------------------------------
 // The strip kernels give every wave 32 rows x ALL columns: 8 epilogues and 8 workgroup barriers per strip, the 8 waves of a
 // workgroup in lock-step, 202 workgroups for 256 CUs.  Here a 4-wave workgroup (2 x 2 waves, 64 x 64 outputs each = 16
-// accumulator tiles) owns one 128 x 128 output tile and walks K in 64-wide steps: both operand tiles double-buffered in LDS
-// (register prefetch of the next step, one LDS-scoped barrier per step), two independent workgroups per CU, 1616 workgroups
+// accumulator tiles) owns one 128 x 128 output tile and walks K in 64-wide steps: register prefetch of the next step; the general-
+// epilogue form double-buffers both operand tiles in LDS (one LDS-scoped barrier per step, two workgroups per CU), the bias-only
+// form keeps one buffer and runs three workgroups per CU (see the step loop); 1616 workgroups
 // for the QKVT shape; the output tile leaves through LDS as whole 256-byte row segments.  Epilogue: optional bias.
 constexpr int G_BM = 128, G_BN = 128, G_BK = 64, G_NT = 256;
 constexpr int G_LDK = G_BK + 8;      // [rows][k] images (A; B when k-contiguous)
@@ -470,11 +471,11 @@ constexpr int G_LDO = G_BN + 8;      // output staging [128][128]
 // the saved pre-activation, x GELU', accumulate, f32 output) written straight from the accumulator fragments (8 / 16 bytes per
 // lane) — the wide layers of the 512-unit recipes (K = 1024 / 1536 / 2048), which the register-strip kernels (K <= 512) do not take.
 template <bool B_KC, bool EPI = false>
-__global__ __launch_bounds__(G_NT, 2) void tile_nn_kernel(StripP p) {
+__global__ __launch_bounds__(G_NT, EPI ? 2 : 3) void tile_nn_kernel(StripP p) {
     constexpr int A_EL = G_BM * G_LDK, B_EL = B_KC ? G_BN * G_LDK : G_BK * G_LDN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][A_EL]
-    bf16* Bs = As + 2 * A_EL;                                  // [2][B_EL]
+    bf16* Bs = As + (EPI ? 2 : 1) * A_EL;                      // [buffers][B_EL]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int G = lane >> 4, g4 = G * 4, l15 = lane & 15;
     // consecutive workgroups share the row block (its A rows stay in L2 across the N / 128 column tiles)
@@ -510,7 +511,10 @@ __global__ __launch_bounds__(G_NT, 2) void tile_nn_kernel(StripP p) {
     G_STORE(0)
     lds_barrier();
     for (int st = 0; st < nstep; ++st) {
-        const int buf = st & 1;
+        // Bias-only form (the QKVT projection pair of the headline shape): ONE LDS buffer — 37 KB and <= 168 registers, i.e. THREE
+        // workgroups per CU instead of two — and a second barrier per step.  The TA, LDS and MFMA phases of a step take turns within a
+        // workgroup (a deeper register pipeline changed nothing); a third workgroup is what fills them: 43.0 -> 37.3 and 37.2 -> 34.9 us.
+        const int buf = EPI ? (st & 1) : 0;
         if (st + 1 < nstep) G_LOAD((st + 1) * G_BK)
         const bf16* Ab = As + buf * A_EL + (wm * 64) * G_LDK;
         const bf16* Bb = Bs + buf * B_EL;
@@ -537,7 +541,8 @@ __global__ __launch_bounds__(G_NT, 2) void tile_nn_kernel(StripP p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (st + 1 < nstep) G_STORE(buf ^ 1)   // that buffer was last read in step st - 1 (barrier below, one step back)
+        if constexpr (!EPI) lds_barrier();     // every wave is done reading the buffer
+        if (st + 1 < nstep) G_STORE(EPI ? (buf ^ 1) : 0)   // double-buffered: that buffer was last read in step st - 1
         lds_barrier();
     }
     if constexpr (EPI) {
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(G_NT, 2) void tile_nn_kernel(StripP p) {
 template <bool B_KC, bool EPI = false>
 static int launch_tile_nn(const StripP& p, hipStream_t st) {
     constexpr size_t a_el = (size_t)G_BM * G_LDK, b_el = B_KC ? (size_t)G_BN * G_LDK : (size_t)G_BK * G_LDN;
-    const size_t smem = std::max(2 * (a_el + b_el) * sizeof(bf16), (size_t)G_BM * G_LDO * sizeof(bf16));
+    const size_t smem = std::max((EPI ? 2 : 1) * (a_el + b_el) * sizeof(bf16), (size_t)G_BM * G_LDO * sizeof(bf16));
     auto k = tile_nn_kernel<B_KC, EPI>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const int nbm = (p.M + G_BM - 1) / G_BM, nbn = p.N / G_BN;
