@@ -1,5 +1,5 @@
 #!/bin/bash
+# scratch driver for one gpurun call (edited per experiment): tests of the touched family, then the kernel table of a short bench run
 cd $GRAFT_REPO_ROOT
-EDGL_BENCH_DUMP_GROUPS=1 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extras 2>&1 | grep "step groups\|metric" | cut -c1-260
-EDGL_BENCH_DUMP_GROUPS=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>&1 | grep "step groups\|metric" | cut -c1-260
-EDGL_BENCH_DUMP_GROUPS=1 python bench.py --no-cpu-baseline --no-extras 2>&1 | grep "step groups\|metric" | cut -c1-260
+python -m pytest tests/test_gpu_ops.py tests/test_gpu_coding.py -x -q -k "bimau or mau or attention" 2>&1 | tail -2
+KT_LINES=14 bash tools/ktrace.sh | cut -c1-150
