@@ -1,5 +1,7 @@
 #!/bin/bash
-# scratch driver for one gpurun call (edited per experiment): tests of the touched family, then the kernel table of a short bench run
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_ops.py tests/test_gpu_coding.py -x -q -k "bimau or mau or attention" 2>&1 | tail -2
-KT_LINES=14 bash tools/ktrace.sh | cut -c1-150
+for L in none bk32 bk32w3; do
+if [ $L = none ]; then unset EDGL_LIB_PATH; else export EDGL_LIB_PATH=$GRAFT_REPO_ROOT/variants/lib_$L.so; fi
+echo "== $L"; python -m pytest tests/test_gpu_ops.py -x -q -k "gemm" 2>&1 | tail -1
+KT_LINES=16 bash tools/ktrace.sh | cut -c1-150 | grep -i "tile_nn"
+done
