@@ -3,6 +3,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/kt
 rm -rf "$OUT"; mkdir -p "$OUT"
+export EDGL_BENCH_SPIN_MS=0   # per-kernel tables: without the conditioning GEMMs of bench.py
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$OUT" -o k -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras "$@" > "$OUT/log.txt" 2>&1
 python $ROOT/tools/kstats.py "$OUT/k_results.db" 25 | cut -c1-150 | head -${KT_LINES:-28}

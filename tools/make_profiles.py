@@ -38,7 +38,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     prof = os.path.join(ROOT, "profiles")
     steps = 25
-    head = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   ({steps} optimizer steps, engine path, round {tag})"]
+    head = [f"# EDGL_BENCH_SPIN_MS=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline   ({steps} optimizer steps, engine path, round {tag})"]
     bl = os.path.join(SRC, "bench_line.json")
     if os.path.exists(bl):
         head.append("# bench line of the same run: " + open(bl).read().strip())
@@ -46,7 +46,7 @@ def main():
         f.write("\n".join(head + kernel_stats(os.path.join(SRC, "ktrace", "k_results.db"), steps)) + "\n")
     rdb = os.path.join(SRC, "recipe", "k_results.db")
     if os.path.exists(rdb):
-        rhead = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload recipe --steps 20 --warmup 5 --no-cpu-baseline   ({steps} optimizer steps, engine path, round {tag})"]
+        rhead = [f"# EDGL_BENCH_SPIN_MS=0 rocprofv3 --kernel-trace --stats -- python bench.py --workload recipe --steps 20 --warmup 5 --no-cpu-baseline   ({steps} optimizer steps, engine path, round {tag})"]
         rbl = os.path.join(SRC, "recipe_bench_line.json")
         if os.path.exists(rbl):
             rhead.append("# bench line of the same run: " + open(rbl).read().strip())

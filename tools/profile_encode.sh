@@ -6,6 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 IDS=${1:-zipf}     # zipf (the recipe's id distribution) | uniform (every gathered row is a distinct HBM line)
 OUT=$ROOT/gpurun_out/encode_$IDS
 mkdir -p "$OUT"
+export EDGL_BENCH_SPIN_MS=0   # per-kernel tables: without the conditioning GEMMs of bench.py
 cd /tmp && export TMPDIR=/tmp
 CMD="python $ROOT/bench.py --workload encode --ids $IDS --steps 20 --warmup 5"
 rocprofv3 --kernel-trace --stats -d "$OUT/ktrace" -o k -- $CMD > "$OUT/ktrace.log" 2>&1

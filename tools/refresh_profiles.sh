@@ -6,6 +6,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p "$OUT"
+export EDGL_BENCH_SPIN_MS=0   # per-kernel tables: without the conditioning GEMMs of bench.py
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d "$OUT/ktrace" -o k -- $BENCH > "$OUT/ktrace.log" 2>&1
