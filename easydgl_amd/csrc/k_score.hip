@@ -26,7 +26,7 @@
 // csrc/k_score_strip.hip: one-wave-per-SIMD form of the two product passes (bf16, C = 128)
 bool edgl_strip_enabled();
 int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, int R, int I, int i0, int i1, const int32_t* nvalid,
-                    float* slabs, float* part, int G, hipStream_t st);
+                    float* slabs, float* part, int G, int slab16, hipStream_t st);
 int edgl_strip_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
                      int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, hipStream_t st);
 int edgl_strip_label_scatter(const void* rows, const int64_t* labels, const float* coef, const int32_t* nvalid, int R, int i0, int i1,
@@ -811,12 +811,23 @@ __global__ void slab_reduce_rows_kernel(const float* slabs, const int32_t* nvali
     }
 }
 
+// four consecutive slab entries at element offset `off`: f32 slabs, or the bf16 slabs of the strip row pass (StripP::slab16)
+template <bool S16>
+__device__ __forceinline__ float4 ld_slab4(const float* slabs, long off) {
+    if constexpr (S16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16*>(slabs) + off);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(slabs + off);
+    }
+}
+
 // lse_label_kernel + flash_finish_kernel in ONE launch (the training engine: both run back to back between the two product passes,
 // each a few microseconds of work behind a kernel boundary).  LPR = C / 4 lanes own a row (4 consecutive channels each): every lane
 // forms the row's log-sum-exp from the chunk partials itself (<= 16 exponentials), the label logit is the LPR-lane sum of the
 // lanes' 4-channel dot products with the label row of the table — the row this kernel loads anyway for the -table[label] term —
 // then coefficient and d_rows as in the two kernels.  Chunk counts above MAXCH take the rolled loops.
-template <typename TO, int LPR>
+template <typename TO, int LPR, bool S16 = false>
 __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slabs, const float* part, const TO* rows, const TO* table,
                                                                const float* out_bias, const int64_t* labels, const int32_t* nvalid,
                                                                const int32_t* wtotal, int R, int xb, int zb, int G, int ztotal,
@@ -863,7 +874,7 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
 #pragma unroll
         for (int s = 0; s < MAXCH; ++s) {
             const int sc = min(s, nch - 1);
-            sl0[s] = *reinterpret_cast<const float4*>(slabs + (long)sc * stride + (long)rc * C + c);
+            sl0[s] = ld_slab4<S16>(slabs, (long)sc * stride + (long)rc * C + c);
             pm0[s] = part[((long)rc * nch + sc) * 2];
             ps0[s] = part[((long)rc * nch + sc) * 2 + 1];
         }
@@ -890,7 +901,7 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
 #pragma unroll
             for (int s = 0; s < MAXCH; ++s) {
                 const int sc = min(s0 + s, nch - 1);
-                sl[s] = *reinterpret_cast<const float4*>(slabs + (long)sc * stride + (long)rc * C + c);
+                sl[s] = ld_slab4<S16>(slabs, (long)sc * stride + (long)rc * C + c);
                 pm[s] = part[((long)rc * nch + sc) * 2];
                 ps[s] = part[((long)rc * nch + sc) * 2 + 1];
             }
@@ -1403,13 +1414,16 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     const int xb = strip ? 256 : 16 * Cfg::IX * nw;
     const int G = strip ? std::max(xblocks_of(p.R, xb) * plan.y.nchunk, score_target()) : xblocks_of(p.R, xb) * plan.y.nchunk;
     float* part = ws + plan.off_part;
+    // rows finished in one launch (flash_finish_lse_kernel): the strip row pass then leaves bf16 slabs
+    const bool one_launch = MODE == 1 && d_rows && (p.C == 128 || p.C == 64 || p.C == 256) && p.i0 == 0 && p.i1 == p.I;
+    const bool slab16 = strip && one_launch;
     if (MODE != 2) {   // the row-side pass
         constexpr int RY = MODE == 1 ? ROLE_YF : ROLE_Y;
         ScoreP q = p;
         q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY; q.part = part;
         edgl_prof_begin(EDGL_KERNEL_SCORE_BWD_ROWS, st);
         if (strip) {
-            const int rc = edgl_strip_rows(p.rows, p.table, p.out_bias, p.R, p.I, p.i0, p.i1, p.nvalid, q.slabs, part, G, st);
+            const int rc = edgl_strip_rows(p.rows, p.table, p.out_bias, p.R, p.I, p.i0, p.i1, p.nvalid, q.slabs, part, G, slab16 ? 1 : 0, st);
             if (rc) return rc;
         } else if (nw == 8) {
             auto k = score_bwd_kernel<T, CT, RY, 8, CO>;
@@ -1429,17 +1443,17 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
                            ws + plan.off_slabY, p.nvalid, p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
         EDGL_LAUNCH_CHECK();
     } else if (MODE == 1) {
-        if (d_rows && (p.C == 128 || p.C == 64 || p.C == 256) && p.i0 == 0 && p.i1 == p.I) {
+        if (one_launch) {
             // rows finished in one launch: log-sum-exp, label logit, coefficient and d_rows (edgl_score_flash_fwd_rows_w)
             const T* rows_t = reinterpret_cast<const T*>(p.rows);
             const T* tab_t = reinterpret_cast<const T*>(p.table);
             const float* slabY = ws + plan.off_slabY;
             T* out_t = reinterpret_cast<T*>(d_rows);
-#define EDGL_FFL(LPR)                                                                                                          \
-    hipLaunchKernelGGL((flash_finish_lse_kernel<T, LPR>), dim3((unsigned)std::min<long>(((long)p.R * LPR + 255) / 256, 4096)),  \
+#define EDGL_FFL(LPR, S16)                                                                                                     \
+    hipLaunchKernelGGL((flash_finish_lse_kernel<T, LPR, S16>), dim3((unsigned)std::min<long>(((long)p.R * LPR + 255) / 256, 4096)), \
                        dim3(256), 0, st, slabY, part, rows_t, tab_t, p.out_bias, p.labels, p.nvalid, p.wtotal, p.R, xb, ZBK, G, \
                        p.i1 - p.i0, p.gscale, p.row_lse, p.lab_out, p.coef_out, out_t)
-            if (p.C == 128) EDGL_FFL(32); else if (p.C == 64) EDGL_FFL(16); else EDGL_FFL(64);
+            if (p.C == 128 && slab16) EDGL_FFL(32, true); else if (p.C == 128) EDGL_FFL(32, false); else if (p.C == 64) EDGL_FFL(16, false); else EDGL_FFL(64, false);
 #undef EDGL_FFL
             EDGL_LAUNCH_CHECK();
             return EDGL_OK;

@@ -52,6 +52,7 @@ struct StripP {
     const int32_t* nvalid;
     const float* coef; const float* row_lse;     // ROLE_W
     float* slabs; float* bias_slabs; float* part;
+    int slab16;                                  // ROLE_YF: the row slabs are written as bf16 (the one-launch row finish reads them so)
     unsigned long long* stamps;     // -DSTRIP_TIMING builds only: [workgroup][8] shader-clock stamps of wave 0
 };
 #ifdef STRIP_TIMING
@@ -572,11 +573,24 @@ __device__ __forceinline__ void epilogue(const StripP& p, const Geo& g, char* sm
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     float* slab = p.slabs + (long)g.by * g.slab_stride;
+    if (YS && p.slab16) {
+        // bf16 slabs: half of the 33 MB burst that all workgroups write at once, and half of the row finish's read-back; the finish
+        // rounds d_rows to bf16 anyway (one more rounding of each chunk's partial: 2^-9 relative before the weighted sum)
+        bf16* slab_h = reinterpret_cast<bf16*>(p.slabs) + (long)g.by * g.slab_stride;
 #pragma unroll 4
-    for (int i = 0; i < 32; ++i) {
-        const int xr = 2 * i + g.hi, gx = g.xbase + xr;
-        const float4 v = *reinterpret_cast<const float4*>(stg_o + xr * OSTR + 4 * g.l31);
-        if (gx < g.xend) *reinterpret_cast<float4*>(slab + (long)gx * C + 4 * g.l31) = v;
+        for (int i = 0; i < 32; ++i) {
+            const int xr = 2 * i + g.hi, gx = g.xbase + xr;
+            const float4 v = *reinterpret_cast<const float4*>(stg_o + xr * OSTR + 4 * g.l31);
+            const Frag4<bf16> h = frag_from_acc<bf16>(f32x4{v.x, v.y, v.z, v.w});
+            if (gx < g.xend) *reinterpret_cast<uint2*>(slab_h + (long)gx * C + 4 * g.l31) = *reinterpret_cast<const uint2*>(&h);
+        }
+    } else {
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            const int xr = 2 * i + g.hi, gx = g.xbase + xr;
+            const float4 v = *reinterpret_cast<const float4*>(stg_o + xr * OSTR + 4 * g.l31);
+            if (gx < g.xend) *reinterpret_cast<float4*>(slab + (long)gx * C + 4 * g.l31) = v;
+        }
     }
 #pragma unroll
     for (int xt = 0; xt < 2; ++xt) {
@@ -761,8 +775,9 @@ bool edgl_strip_enabled() {
 }
 
 int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, int R, int I, int i0, int i1, const int32_t* nvalid,
-                    float* slabs, float* part, int G, hipStream_t st) {
+                    float* slabs, float* part, int G, int slab16, hipStream_t st) {
     strip::StripP p{};
+    p.slab16 = slab16;
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
     p.nvalid = nvalid; p.slabs = slabs; p.part = part; p.stamps = g_strip_stamps;
     auto k = strip::strip_kernel<strip::ROLE_YF>;
