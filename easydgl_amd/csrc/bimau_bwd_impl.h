@@ -5,6 +5,10 @@
 
 #include "bimau_common.h"
 
+#ifndef EDGL_EXP_SKIP_TILES
+#define EDGL_EXP_SKIP_TILES 0   // timing experiment: query tiles left out at the end (wrong results, bounds the cost of the remainder tile)
+#endif
+
 #ifdef EDGL_PHASE_TIMING
 extern __device__ unsigned long long g_phase_cycles[16];
 #endif
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
             if (lane < 16) p.rowdot_ws[bp * p.T + pend_q] = pend_rowdot;
         }
     };
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < NT - EDGL_EXP_SKIP_TILES; ++qt) {
         asm volatile("" ::: "memory");   // keep loop-invariant LDS operands from being hoisted into registers
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     };
 #pragma unroll
     for (int ut = 0; ut < DT; ++ut) pend_dq[ut] = frag_zero<T>();
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < NT - EDGL_EXP_SKIP_TILES; ++qt) {
         asm volatile("" ::: "memory");
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;

@@ -9,6 +9,10 @@
 
 #include "bimau_common.h"
 
+#ifndef EDGL_EXP_SKIP_TILES
+#define EDGL_EXP_SKIP_TILES 0   // timing experiment: query tiles left out at the end (wrong results, bounds the cost of the remainder tile)
+#endif
+
 #ifndef EDGL_BIMAU_FWD_WAVES
 #define EDGL_BIMAU_FWD_WAVES 2   // waves per SIMD the headline instance (bf16, head dim 16, E = 16) is compiled for (3: 168 registers, 4 spilled — 79 -> 84 us)
 #endif
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
             }
         }
     };
-    for (int qt = 0; qt < NT; ++qt) {
+    for (int qt = 0; qt < NT - EDGL_EXP_SKIP_TILES; ++qt) {
         const int q = qt * 16 + l15;
         const bool qok = q < p.T;
         const QOps qnext = load_q(qt + 1 < NT ? qt + 1 : qt);

@@ -332,6 +332,9 @@ __device__ __forceinline__ uint32_t drop_hash_pair(const DropKey& k, uint32_t id
 // >= t16.  The top field ranges over [0, 0xFFF1] only: |p_eff - p| <= 2.3e-4 p there, 8e-6 on the others (tools/ hash statistics in
 // rates, field / lag / step correlations at the noise level of 2^18 samples).  Half the VALU work of two paired hashes.
 __device__ __forceinline__ uint64_t drop_hash_quad(const DropKey& k, uint32_t idx0) {
+#ifdef EDGL_EXP_NOHASH   // timing experiment (tools/build_variant.sh): the cost of the hash itself — every element kept
+    return ~0ull;
+#endif
     uint32_t h = (idx0 ^ k.k0) * 0x9E3779B1u + k.k1;
     h ^= h >> 15; h *= 0x85ebca6bu; h ^= h >> 13;
     return (uint64_t)h * 0xFFF1AFD7u;

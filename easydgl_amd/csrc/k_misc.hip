@@ -276,7 +276,11 @@ __global__ __launch_bounds__(256) void tpp_rows_kernel(TppP p, const float* sums
     }
     const int b = (int)(bp % p.B);
     const int64_t* mp = (p.mpos && active) ? p.mpos + (long)b * p.M : nullptr;
-    const int pos = !active ? 0 : (p.mpos ? (int)mp[m] : m);
+    const int pos_in = !active ? 0 : (p.mpos ? (int)mp[m] : m);
+    // a masked position outside [0, T) (malformed input, an uninitialised row after bind_batch): the slot is skipped, as the
+    // fused kernel this one replaced did — never an out-of-bounds row of lambda / d lambda
+    active = active && pos_in >= 0 && pos_in < p.T;
+    const int pos = active ? pos_in : 0;
     const int lab = active ? (int)p.labels[(long)b * p.M + m] : 0;
     if (G) {
         s_pos[threadIdx.x] = active ? pos : -1 - (int)threadIdx.x;

@@ -19,6 +19,8 @@
 //   score_bwd<ROLE_Y>: x = rows,  z = items   -> d_rows slabs
 //   score_bwd<ROLE_W>: x = items, z = rows    -> d_table slabs, d_bias slabs
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 #include "edgl_common.h"
 #include "score_plan.h"
@@ -1387,6 +1389,22 @@ int run_fwd(ScoreP p, hipStream_t st) {
 // MODE 0: edgl_score_ce_bwd (transposes, d_rows with the known lse, d_table / d_bias)
 // MODE 1: edgl_score_flash_fwd (transposes, ROLE_YF pass: unnormalised d_rows slabs + per-chunk (max, sum) -> row lse)
 // MODE 2: edgl_score_flash_bwd (finish d_rows from the slabs of MODE 1, then d_table / d_bias)
+// Format of the d_rows slabs a MODE 1 call left in a flash workspace (host-side record keyed by the workspace address: the
+// calls of one step are issued by one host thread in order, and a captured graph replays the checked sequence).  The strip row
+// pass writes bf16 slabs when the rows are finished in the same call; flash_finish_kernel (MODE 2 with d_rows) reads f32 slabs —
+// pairing the two is refused instead of returning garbage row gradients.
+static std::mutex g_slabfmt_mu;
+static std::unordered_map<const void*, int> g_slabfmt;
+static void slab_format_set(const void* ws, int bf16_slabs) {
+    std::lock_guard<std::mutex> lk(g_slabfmt_mu);
+    g_slabfmt[ws] = bf16_slabs;
+}
+static int slab_format_get(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_slabfmt_mu);
+    auto it = g_slabfmt.find(ws);
+    return it == g_slabfmt.end() ? 0 : it->second;
+}
+
 template <typename T, int CT, int MODE>
 int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* d_table, float* d_bias, hipStream_t st) {
     using S = SC<T, CT>;
@@ -1417,6 +1435,11 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     // rows finished in one launch (flash_finish_lse_kernel): the strip row pass then leaves bf16 slabs
     const bool one_launch = MODE == 1 && d_rows && (p.C == 128 || p.C == 64 || p.C == 256) && p.i0 == 0 && p.i1 == p.I;
     const bool slab16 = strip && one_launch;
+    if (MODE == 1) slab_format_set(ws, slab16 ? 1 : 0);
+    if (MODE == 2 && d_rows)
+        EDGL_REQUIRE(slab_format_get(ws) == 0, EDGL_ERR_WORKSPACE,
+                     "edgl_score_flash_bwd: d_rows != NULL, but this workspace holds the bf16 slabs of edgl_score_flash_fwd_rows_w "
+                     "(which has already written d_rows): call with d_rows = NULL, or run edgl_score_flash_fwd_coef for the two-call form");
     if (MODE != 2) {   // the row-side pass
         constexpr int RY = MODE == 1 ? ROLE_YF : ROLE_Y;
         ScoreP q = p;

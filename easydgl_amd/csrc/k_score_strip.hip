@@ -21,6 +21,7 @@
 // LDS image of a tile: row z at byte z*512 + rot(z)*16, rot(z) = ((z&3)<<2) | ((z>>2)&3): both the row-fragment reads (32 rows
 // x 16 B per half wave group) and the transpose reads (4 rows x 64 B per half wave) are bank-conflict free, and every
 // address is one lane register + an immediate.
+#include <atomic>
 #include <cstdlib>
 
 #include "edgl_common.h"
@@ -774,6 +775,21 @@ bool edgl_strip_enabled() {
     return on != 0;
 }
 
+// The dynamic-LDS attribute of a kernel is PER DEVICE: one flag per (kernel, device ordinal), set with an atomic so that two host
+// threads driving different GPUs neither skip nor race it (a process-wide bool left the second device without the attribute).
+static void strip_set_smem_attr(const void* kern, int which) {
+    static std::atomic<uint64_t> done[2];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {   // unknown ordinal: set it on every launch
+        hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, strip::SMEM);
+        return;
+    }
+    const uint64_t bit = 1ull << dev;
+    if (done[which].load(std::memory_order_acquire) & bit) return;
+    hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, strip::SMEM);
+    done[which].fetch_or(bit, std::memory_order_release);
+}
+
 int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, int R, int I, int i0, int i1, const int32_t* nvalid,
                     float* slabs, float* part, int G, int slab16, hipStream_t st) {
     strip::StripP p{};
@@ -781,8 +797,7 @@ int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, 
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
     p.nvalid = nvalid; p.slabs = slabs; p.part = part; p.stamps = g_strip_stamps;
     auto k = strip::strip_kernel<strip::ROLE_YF>;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, strip::SMEM); attr = true; }
+    strip_set_smem_attr((const void*)k, 0);
     hipLaunchKernelGGL(k, dim3(G), dim3(strip::NTHR), strip::SMEM, st, p);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
@@ -794,8 +809,7 @@ int edgl_strip_table(const void* rows, const void* table, const float* out_bias,
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
     p.nvalid = nvalid; p.coef = coef; p.row_lse = row_lse; p.slabs = slabs; p.bias_slabs = bias_slabs; p.stamps = g_strip_stamps;
     auto k = strip::strip_kernel<strip::ROLE_W>;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, strip::SMEM); attr = true; }
+    strip_set_smem_attr((const void*)k, 1);
     hipLaunchKernelGGL(k, dim3((i1 - i0 + strip::XB - 1) / strip::XB, nchunk), dim3(strip::NTHR), strip::SMEM, st, p);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;

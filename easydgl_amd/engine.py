@@ -464,11 +464,31 @@ class TrainEngine:
             for b in self.blk:
                 b["tpp"].view(torch.int32)[4:5] = self.counts[1:2]
 
+    def _dp_allreduce(self) -> torch.Tensor:
+        """Data parallel: ONE SUM all-reduce of the gradient arena per step.  The loss a rank's kernels produce mixes per-rank and
+        global terms — its share of the cross-entropy and of the TPP term (both already divided by the GLOBAL normalisers) plus the
+        full L2 term, which every rank holds — so neither the sum nor the mean of the ranks' values is the loss of the global batch.
+        The share (loss - L2) rides in the arena's first trailing slot through the same collective; what comes back, plus L2, is
+        the loss of the concatenated batch, identical on every rank and equal to the single-process value
+        (tests/test_gpu_distributed.py).  Returns that scalar (also kept as `self.loss_global`)."""
+        from . import parallel
+        m = self.m
+        comm = m._grad_comm
+        n = m._grad_arena.numel()
+        if m.l2_reg != 0.0:
+            torch.sub(self.loss, self.loss_aux, out=comm[n:n + 1])
+        else:
+            comm[n:n + 1].copy_(self.loss)
+        parallel.allreduce_sum_(comm, self.group)
+        self.loss_global = comm[n:n + 1] + self.loss_aux if m.l2_reg != 0.0 else comm[n:n + 1].clone()
+        return self.loss_global
+
     def step(self, features=None, labels=None) -> torch.Tensor:
-        """One optimizer step on the (optionally refreshed) static batch; returns the loss (device scalar; data parallel: this
-        rank's share of the global cross-entropy plus the regularisation terms).  Data parallel: the normalisers of the loss are
-        global (_global_counts), the flat gradient arena is all-reduced with SUM — the result is the gradient of the loss over
-        the concatenated batch, whatever the ranks' numbers of weighted rows."""
+        """One optimizer step on the (optionally refreshed) static batch; returns the loss (device scalar).  Data parallel: the
+        normalisers of the loss are global (_global_counts), the flat gradient arena is all-reduced with SUM — the result is the
+        gradient of the loss over the concatenated batch, whatever the ranks' numbers of weighted rows — and the returned loss
+        is the loss of that concatenated batch, the same number on every rank (_dp_allreduce); `self.loss` stays this rank's
+        share + L2 as its kernels wrote it."""
         if features is not None:
             self.load_batch(features, labels)
         distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
@@ -478,11 +498,11 @@ class TrainEngine:
             if distributed:
                 self._global_counts()
             self._issue()
+            out = self.loss
             if distributed:
-                from . import parallel
-                parallel.allreduce_sum_(self.m._grad_arena, self.group)
+                out = self._dp_allreduce()
             self._optimizer()
-            return self.loss
+            return out
         if self.graph is None:
             # warm-up on a side stream (allocator / lazy module init), then capture
             s = torch.cuda.Stream()
@@ -497,8 +517,7 @@ class TrainEngine:
             torch.cuda.synchronize()
             # the warm-up was a real step; undo nothing: training simply started one step earlier
             if distributed:
-                from . import parallel
-                parallel.allreduce_sum_(self.m._grad_arena, self.group)
+                self._dp_allreduce()
                 self._optimizer()
                 self._global_counts()      # (the capture below reads the counts of the current batch)
             self.graph = torch.cuda.CUDAGraph()
@@ -508,13 +527,13 @@ class TrainEngine:
                     self._optimizer()
             self._distributed = distributed
             if distributed:                # the captured launches have not run: this call is the warm-up step only
-                return self.loss
+                return self.loss_global
             return self.loss
         if self._distributed:
             self._global_counts()
         self.graph.replay()
         if self._distributed:
-            from . import parallel
-            parallel.allreduce_sum_(self.m._grad_arena, self.group)
+            out = self._dp_allreduce()
             self._optimizer()
+            return out
         return self.loss

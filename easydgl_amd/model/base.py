@@ -46,7 +46,10 @@ class Sequential(nn.Module):
             o += (params[n].numel() + 7) // 8 * 8
         total = o
         arena = torch.zeros(total, device=device, dtype=torch.float32)
-        grad = torch.zeros(total, device=device, dtype=torch.float32)
+        # the gradient arena carries 8 trailing floats that are no parameter's gradient: scalars that must travel with the ONE
+        # data-parallel all-reduce of a step (TrainEngine: this rank's share of the cross-entropy + TPP loss)
+        self._grad_comm = torch.zeros(total + 8, device=device, dtype=torch.float32)
+        grad = self._grad_comm[:total]
         for n in order:
             p = params[n]
             view = arena[offs[n]:offs[n] + p.numel()].view(p.shape)

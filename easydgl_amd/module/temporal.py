@@ -120,7 +120,9 @@ class BiMAU(nn.Module):
                 if getattr(self, "_own_rng", None) is None or self._own_rng.device != queries.device:
                     self._own_rng = ops.make_rng_state(queries.device, seed=0x42694d4155)
                 ops.rng_advance(self._own_rng)
-                drop = ops.Drop(self.dropout_rate, self._own_rng, 10)
+                # a SNAPSHOT of (seed, step): the backward re-derives the mask from the state it is handed, and a second call of
+                # this unit before that backward (shared layer, gradient accumulation) must not move it
+                drop = ops.Drop(self.dropout_rate, self._own_rng.clone(), 10)
             else:
                 drop = ops.NO_DROP
         if self.dense_kernel is None:
@@ -165,7 +167,7 @@ class MAU(nn.Module):
                 if getattr(self, "_own_rng", None) is None or self._own_rng.device != queries.device:
                     self._own_rng = ops.make_rng_state(queries.device, seed=0x4d4155)
                 ops.rng_advance(self._own_rng)
-                drop = ops.Drop(self.dropout_rate, self._own_rng, 10)
+                drop = ops.Drop(self.dropout_rate, self._own_rng.clone(), 10)   # snapshot: see BiMAU.forward
             else:
                 drop = ops.NO_DROP
         masks = key_ids_from_masks(masks, queries.shape[0], queries.shape[1], self.num_heads)

@@ -76,7 +76,7 @@ def test_single_process_is_a_noop():
     assert torch.equal(g, torch.ones(4))
 
 
-def _dp_worker(rank, world, port, out):
+def _dp_worker(rank, world, port, out, empty_rank=False):
     """Data-parallel protocol of TrainEngine.step (engine.py: _global_counts + allreduce_sum_) with the fp64 oracle as the step:
     the ranks hold halves of a batch with DIFFERENT numbers of weighted rows; global normalisers + a SUM all-reduce must give the
     gradient of the loss over the whole batch."""
@@ -90,6 +90,8 @@ def _dp_worker(rank, world, port, out):
     cfg, mt = prob["cfg"], prob["mark_table"]
     labels = np.asarray(prob["labels"]).copy()
     labels[0, :3] = 0                                             # rank 0's half carries fewer weighted rows than rank 1's
+    if empty_rank:
+        labels[:3] = 0                                            # ... or none: its cross-entropy share and its gradient of it are 0
     half = slice(rank * 3, rank * 3 + 3)
     feats = {k: np.asarray(v)[half] for k, v in prob["feats"].items()}
     # the two integers the engine all-reduces before the step
@@ -116,7 +118,7 @@ def _dp_worker(rank, world, port, out):
     P.allreduce_mean_(naive)
     err = float((flat - want).abs().max() / want.abs().max())
     err_naive = float((naive - want).abs().max() / want.abs().max())
-    out[rank] = (err < 1e-10, err_naive > 1e-3, err, err_naive)
+    out[rank] = (err < 1e-10 and bool(torch.isfinite(flat).all()), err_naive > 1e-3 or empty_rank, err, err_naive)
     dist.destroy_process_group()
 
 
@@ -128,3 +130,15 @@ def test_data_parallel_gradient_is_the_global_batch_gradient():
     for r in range(world):
         ok, naive_differs, err, err_naive = out[r]
         assert ok and naive_differs, (r, err, err_naive)
+
+
+def test_data_parallel_with_a_rank_that_holds_no_weighted_row():
+    """a rank whose half of the batch has no weighted row contributes a zero cross-entropy gradient (0 / global
+    count, not 0 / 0) and the SUM protocol still gives the gradient of the whole batch."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, _free_port(), out, True), nprocs=world, join=True)
+    for r in range(world):
+        ok, _, err, err_naive = out[r]
+        assert ok, (r, err, err_naive)

@@ -6,7 +6,7 @@ import torch
 
 from oracle import easydgl_oracle as O
 from oracle import torch_ref as R
-from tests._util import assert_close
+from tests._util import assert_close, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -191,6 +191,49 @@ def test_bimau_takes_the_reference_key_mask_and_trains_with_dropout_on_its_own()
     t1, _ = att(x, x, ids_t, spans, marks, True)
     t2, _ = att(x, x, ids_t, spans, marks, True)
     assert not torch.equal(t1, o0) and not torch.equal(t1, t2)                          # dropout is on, and a fresh mask per call
+
+
+@pytest.mark.parametrize("unit", ["BiMAU", "MAU"])
+def test_unit_called_twice_before_backward_keeps_each_calls_mask(unit):
+    """A unit on its own draws from a module-local dropout state that advances per call.  Two calls under ONE loss (shared layer,
+    gradient accumulation) must each differentiate under the mask of their OWN forward: the summed gradient equals the sum of the
+    gradients of the two calls run one after the other with the same two states."""
+    from easydgl_amd.module import temporal as T
+    B, Tn, C, H, E = 2, 21, 64, 4, 6
+    gen = torch.Generator().manual_seed(11)
+    att = (T.BiMAU(C, H, E, 0.3, in_units=C, gen=gen) if unit == "BiMAU" else T.MAU(C, H, E, 0.3, gen=gen)).cuda()
+    rng = np.random.default_rng(3)
+    xs = [torch.tensor(rng.standard_normal((B, Tn, C)), dtype=torch.float32).cuda() for _ in range(2)]
+    ids = rng.integers(1, 30, size=(B, Tn)); ids[0, :4] = 0
+    ids_t = torch.tensor(ids).cuda()
+    spans = torch.tensor(rng.uniform(0, 5, size=(B, Tn)), dtype=torch.float32).cuda()
+    marks = torch.tensor(O.synthetic_mark_table(30, E, multi_hot=True)[ids].astype(np.uint8)).cuda()
+    ws = [torch.tensor(rng.standard_normal((B, Tn, C)), dtype=torch.float32).cuda() for _ in range(2)]
+    params = [p for p in att.parameters()]
+
+    def run(joint):
+        att._own_rng = None                       # both runs start from the same module-local state
+        for p in params:
+            p.grad = None
+        outs = []
+        if joint:                                 # two forwards, then one backward
+            for x in xs:
+                outs.append(att(x, x, ids_t, spans, marks, True)[0])
+            (sum((o * w).sum() for o, w in zip(outs, ws))).backward()
+        else:                                     # forward / backward, forward / backward (gradients accumulate)
+            for x, w in zip(xs, ws):
+                o = att(x, x, ids_t, spans, marks, True)[0]
+                outs.append(o)
+                (o * w).sum().backward()
+        return [o.detach().clone() for o in outs], [p.grad.detach().clone() for p in params]
+
+    o_j, g_j = run(True)
+    o_s, g_s = run(False)
+    for a, b in zip(o_j, o_s):
+        assert torch.equal(a, b)                  # same masks in the forwards
+    assert not torch.equal(o_j[0], att(xs[0], xs[0], ids_t, spans, marks, False)[0])
+    for a, b in zip(g_j, g_s):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("unit", ["BiMAU", "MAU"])

@@ -61,7 +61,7 @@ def test_sharded_eval_and_data_parallel_step_over_rccl():
     assert all(out.get(r, False) for r in range(world)), dict(out)
 
 
-def _dp_engine_worker(rank, world, port, out):
+def _dp_engine_worker(rank, world, port, out, empty_rank=False):
     """Two engine ranks on ONE GPU over gloo (the collective goes through the host: a functional check of the protocol, not of
     RCCL): halves of a batch with different numbers of weighted rows."""
     import torch.distributed as dist
@@ -75,6 +75,8 @@ def _dp_engine_worker(rank, world, port, out):
     prob = make_problem(seed=31, batch=12, num_items=900, seqslen=24, num_units=32, num_heads=2, num_blocks=1, masklen=5, num_events=4)
     labels = torch.as_tensor(prob["labels"]).clone()
     labels[:3, :4] = 0                                    # rank 0's half carries far fewer weighted rows
+    if empty_rank:
+        labels[:6] = 0                                    # ... or none at all: its scoring passes run over zero rows
     feats = to_dev(prob["feats"])
     half = slice(rank * 6, rank * 6 + 6)
     m = build_model(prob, "f32")
@@ -84,9 +86,7 @@ def _dp_engine_worker(rank, world, port, out):
     eng._global_counts()
     m._grad_arena.zero_()                                  # (the flat arena has alignment gaps between the parameters)
     eng._issue()
-    loss_share = eng.loss.clone()
-    parallel.allreduce_sum_(m._grad_arena)
-    dist.all_reduce(loss_share)
+    loss_global = eng._dp_allreduce()                      # the step's ONE collective: gradients + this rank's loss share
     ok, info = True, None
     if rank == 0:
         m1 = build_model(prob, "f32")
@@ -96,11 +96,16 @@ def _dp_engine_worker(rank, world, port, out):
         torch.cuda.synchronize()
         g, w = m._grad_arena, m1._grad_arena
         err = float((g - w).abs().max() / w.abs().max())
-        # the summed loss shares count the (batch-independent) l2 term once per rank
-        l2 = float(e1.loss_aux) if m1.l2_reg != 0.0 else 0.0
-        lerr = abs(float(loss_share) - (world - 1) * l2 - float(e1.loss)) / abs(float(e1.loss))
-        ok, info = bool(err < 1e-5 and lerr < 1e-5), (err, lerr, int(eng.counts[0]), int(e1.nvalid))
-    out[rank] = (ok, info)
+        ok, info = bool(err < 1e-5), (err, int(eng.counts[0]), int(e1.nvalid))
+        want = float(e1.loss)
+    else:
+        want = None
+    # the loss the step returns is the loss of the concatenated batch on EVERY rank (the L2 term counted once)
+    wl = torch.tensor([want if want is not None else 0.0], dtype=torch.float64)
+    dist.broadcast(wl, src=0)
+    lerr = abs(float(loss_global) - float(wl)) / abs(float(wl))
+    ok = ok and lerr < 1e-5 and bool(torch.isfinite(m._grad_arena).all())
+    out[rank] = (ok, (info, lerr))
     dist.destroy_process_group()
 
 
@@ -111,6 +116,17 @@ def test_two_engine_ranks_reproduce_the_global_batch_gradient():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_dp_engine_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), dict(out)
+
+
+def test_a_rank_without_weighted_rows_still_joins_the_step():
+    """one rank's half of the batch has NO weighted row (all labels 0): its scoring passes see zero rows, its
+    share of the cross-entropy is 0, and the two ranks still reproduce the single-process gradient and loss."""
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_engine_worker, args=(world, _free_port(), out, True), nprocs=world, join=True)
     assert all(out[r][0] for r in range(world)), dict(out)
 
 

@@ -581,6 +581,47 @@ def test_tpp_rows_launch_matches_the_reference(E, M, repeat):
     assert_close(dlam.cpu().numpy(), lr.grad.numpy(), 1e-5, "tpp dlam (rows form)")
 
 
+def test_tpp_rows_launch_skips_masked_positions_outside_the_sequence():
+    """A masked position outside [0, T) (malformed input) is a skipped slot, not an out-of-bounds row of lambda / d lambda: guard
+    bands around d lambda stay untouched and the in-range slots of the other samples get the gradient of the clean problem."""
+    from easydgl_amd import _lib
+    lib = _lib.lib
+    rng = np.random.default_rng(77)
+    B, T, H, NI, E, M = 4, 23, 2, 40, 16, 5
+    lam = torch.tensor(rng.uniform(0.2, 2.0, size=(H * B, T, E)), dtype=torch.float32).cuda()
+    mpn = np.stack([rng.choice(T - 1, M, replace=False) + 1 for _ in range(B)])
+    labels = rng.integers(1, NI, size=(B, M))
+    bad = mpn.copy()
+    bad[B - 1, 0] = T + 1000          # the last sample: a row far behind the arrays
+    bad[0, 1] = -7                    # the first sample: a row in front of them
+    ts = np.cumsum(rng.exponential(40.0, size=(B, T)), axis=1).astype(np.float32) + 9.5e8
+    mt = O.synthetic_mark_table(NI, E, multi_hot=True)
+    lab_t, ts_t, mt_t = torch.tensor(labels).cuda(), torch.tensor(ts).cuda(), torch.tensor(mt.astype(np.uint8)).cuda()
+    n = H * B * T * E
+    outs = []
+    for pos in (mpn, bad):
+        buf = torch.full((n + 2 * 4096,), 123.0, device="cuda")
+        dlam = buf[4096:4096 + n].view(H * B, T, E)
+        dlam.zero_()
+        sums = torch.zeros(int(max(lib.edgl_tpp_workspace(), lib.edgl_tpp_rows_workspace(B, H, M))), device="cuda")
+        reg = torch.zeros(1, device="cuda")
+        _lib.check(lib.edgl_tpp_norm(lab_t.data_ptr(), mt_t.data_ptr(), B, M, E, sums.data_ptr(), None), "edgl_tpp_norm")
+        _lib.check(lib.edgl_tpp_fwd_bwd_rows(lam.data_ptr(), torch.tensor(pos).cuda().data_ptr(), lab_t.data_ptr(), ts_t.data_ptr(),
+                                             mt_t.data_ptr(), B, T, H, E, M, 0.3, sums.data_ptr(), reg.data_ptr(), 0, dlam.data_ptr(), None),
+                   "edgl_tpp_fwd_bwd_rows")
+        torch.cuda.synchronize()
+        assert torch.all(buf[:4096] == 123.0) and torch.all(buf[4096 + n:] == 123.0)
+        assert torch.isfinite(reg).all()
+        outs.append(dlam.clone())
+    clean, dirty = outs
+    keep = torch.ones_like(clean, dtype=torch.bool)
+    for h in range(H):                # rows the two skipped slots would have written
+        keep[h * B + B - 1, mpn[B - 1, 0]] = False
+        keep[h * B + 0, mpn[0, 1]] = False
+    assert torch.equal(clean[keep], dirty[keep])
+    assert torch.all(dirty[~keep] == 0)
+
+
 def test_bimau_forward_zero_fills_the_d_lambda_buffer():
     """edgl_bimau_fwd_zr: same outputs as edgl_bimau_fwd, and the extra [H*B, T, E] array comes back all zero (head dims 16 and 64:
     fused kernel / memset in front of the three-launch form)."""
