@@ -55,6 +55,7 @@ struct BwdP {
     float* dz_ws; float* dh_ws; float* rowdot_ws; float* dsc_part; float* wpart;
     int waves;
     int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
+    const uint32_t* dbits;   // optional: keep bits of the attention dropout (edgl_bimau_dropbits, bimau_common.h)
 };
 
 template <typename T>
@@ -71,7 +72,8 @@ __device__ __forceinline__ void st_frag(T* dst, const f32x4& a) {
 // operand set would not fit the register file, so the next tile is fetched at the end of the iteration instead.
 // FL: -1 = MAU_CAUSAL / MAU_NO_DIAG read from p.flags at run time; 0 = the BiMAU configuration compiled in (bidirectional,
 // diagonal set): no per-element causal compares / selects in the softmax, the diagonal as one select on a scalar-and-ed mask
-template <typename T, int DT, int NT, int EC, bool PREF = true, int FL = -1>
+// DB: stored keep bits of the attention dropout instead of the hash (same decisions: bimau_common.h)
+template <typename T, int DT, int NT, int EC, bool PREF = true, int FL = -1, bool DB = false>
 __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (forcing 3 waves / SIMD: 83 spilled registers, 76 -> 239 us)
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
     // so that the prefetch is straight-line code: with per-lane branches around them the wait-count insertion falls
     // back to near-zero counts and every iteration would stall on the loads it has just issued.  Lanes past the end of
     // the sequence (or marks >= E) are zeroed when the values are consumed.
-    struct QOps { Frag4<T> qf[DT], dof[DT]; float4 z; float lam[4], dlx[4]; };
+    struct QOps { Frag4<T> qf[DT], dof[DT]; float4 z; float lam[4], dlx[4]; uint32_t kb; };
     const float* dlx_src = p.d_lam_ext ? p.d_lam_ext : p.lam;   // always a readable [rows, E] array
     const float dlx_on = p.d_lam_ext ? 1.0f : 0.0f;
     auto load_q = [&](int qt) {
@@ -140,6 +142,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
             o.dof[ub] = frag_ld<T>(dout + (long)q * p.C + head * dh + ub * 16 + g4);
         }
         o.z = *reinterpret_cast<const float4*>(p.z + row * EP + g4);
+        if constexpr (DB) o.kb = p.dbits[(bp * NT + qt) * 64 + lane];
         if constexpr (EC == 16) {   // one 16-byte load each
             const float4 l4 = *reinterpret_cast<const float4*>(p.lam + row * EC + g4), d4 = *reinterpret_cast<const float4*>(dlx_src + row * EC + g4);
             o.lam[0] = l4.x; o.lam[1] = l4.y; o.lam[2] = l4.z; o.lam[3] = l4.w;
@@ -242,11 +245,14 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
                 for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? ((p.flags & MAU_DIAG_ZERO) ? 0.0f : 1.0f) : gacc[r];
             }
             // dropout: one hash per four neighbouring elements (drop_hash_quad; rate 0: threshold 0, everything kept, scale 1)
-            const uint64_t hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+            uint64_t hw = 0ull;
+            if constexpr (!DB) hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
             const bool keep[4] = {drop_quad_keep<0>(dk, hw), drop_quad_keep<1>(dk, hw), drop_quad_keep<2>(dk, hw), drop_quad_keep<3>(dk, hw)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float fp = keep[r] ? s[kt][r] : 0.f;  // D*P (with the scale)
+                float fp;                                   // D*P (with the scale)
+                if constexpr (DB) fp = keep_bit(qcur.kb, kt * 4 + r, s[kt][r]);
+                else fp = keep[r] ? s[kt][r] : 0.f;
                 ap[r] = gv[r] * fp;                         // A' = D*G'*P
                 dg[r] = da[r] * fp;                         // dG' = dA' * D * P
                 rowdot = fmaf(dg[r], gv[r], rowdot);        // dP1 * P, dP1 = dA' * D * G'  (before the diagonal of dG' is blocked)
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
 // Z) sweep 2
 // ------------------------------------------------------------------------------------------------------------------
 // NYP: number of dH partial slabs the intensity backward left in dh_ws (KY_NY mark groups at head dims <= 32, 1 above)
-template <typename T, int DT, int NT, int EC, int NYP = KY_NY, bool PREF = true, int FL = -1>
+template <typename T, int DT, int NT, int EC, int NYP = KY_NY, bool PREF = true, int FL = -1, bool DB = false>
 __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         for (int kt = 0; kt < NT; ++kt) { dKa[u][kt] = zero4; dTa[u][kt] = zero4; }
 
     // branch-free one-tile-ahead prefetch (see kernel X); kernel Y's dH partials are summed when consumed
-    struct QOps { Frag4<T> qf[DT], dof[DT], hf[DT]; float4 dHp[DT][NYP]; float lam[4], rowdot; };
+    struct QOps { Frag4<T> qf[DT], dof[DT], hf[DT]; float4 dHp[DT][NYP]; float lam[4], rowdot; uint32_t kb; };
     auto load_q = [&](int qt) {
         QOps o;
         const int q = min(qt * 16 + l15, p.T - 1);
@@ -387,6 +393,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             for (int i = 0; i < 4; ++i) o.lam[i] = p.lam[row * E + min(g4 + i, E - 1)];
         }
         o.rowdot = p.rowdot_ws[row];
+        if constexpr (DB) o.kb = p.dbits[(bp * NT + qt) * 64 + lane];
         return o;
     };
     PH_DECL
@@ -488,11 +495,15 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? ((p.flags & MAU_DIAG_ZERO) ? 0.0f : dk.scale) : gacc[r];
             }
-            const uint64_t hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+            uint64_t hw = 0ull;
+            if constexpr (!DB) hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
             const bool keep[4] = {drop_quad_keep<0>(dk, hw), drop_quad_keep<1>(dk, hw), drop_quad_keep<2>(dk, hw), drop_quad_keep<3>(dk, hw)};
             f32x4 a;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = keep[r] ? da[r] * gv[r] : 0.f;   // dP1 = D * dA' * G'  (kernel X's dP1)
+            for (int r = 0; r < 4; ++r) {                                       // dP1 = D * dA' * G'  (kernel X's dP1)
+                if constexpr (DB) a[r] = keep_bit(qcur.kb, kt * 4 + r, da[r] * gv[r]);
+                else a[r] = keep[r] ? da[r] * gv[r] : 0.f;
+            }
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
                 a = mma16(frag_ld<T>(Ts + (kt * 16 + l15) * dh + ub * 16 + g4), dhf[ub], a);

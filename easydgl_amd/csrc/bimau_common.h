@@ -310,6 +310,41 @@ __device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>
     }
 }
 
+// ---- attention dropout as stored keep bits ---------------------------------------------------------------------------------
+// The three kernels of a training step (forward, sweep 1, sweep 2) take the SAME keep decisions; hashing them three times is a
+// tenth of each kernel (drop_hash_quad: two 32-bit multiplies, a 64-bit multiply-add and an SDWA compare per element).
+// edgl_bimau_dropbits evaluates the hash ONCE per step — exactly the decisions of drop_hash_quad / drop_quad_keep on the kernels'
+// element index (b', q, k) — and stores them in the kernels' own register layout: word [(b' * NT + qt) * 64 + lane], bit
+// kt * 4 + r  <->  query qt*16 + (lane & 15), key kt*16 + (lane >> 4)*4 + r (NT <= 8 key tiles: 32 bits).  A kernel then loads
+// one word per lane and query tile with its other per-tile operands and applies an element's decision with two instructions
+// (sign-extended bit field, AND).  Same masks as the hashed form by construction: kernels without the bits (other head dims /
+// flags / more than 8 key tiles) and kernels with them can be mixed inside one step.
+__device__ __forceinline__ float keep_bit(uint32_t kb, int i, float x) {   // i: a constant after unrolling
+    const int m = __builtin_amdgcn_sbfe((int)kb, (unsigned)i, 1u);   // v_bfe_i32: 0 or -1
+    return __int_as_float(__float_as_int(x) & m);
+}
+template <int NT>
+__global__ __launch_bounds__(256) void dropbits_kernel(const uint64_t* rng, uint32_t stream_id, float rate, int T, long njobs, uint32_t* bits) {
+    static_assert(NT <= 8, "one 32-bit word per lane and query tile");
+    const int lane = threadIdx.x & 63;
+    const long job = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // (b', query tile)
+    if (job >= njobs) return;
+    const long bp = job / NT;
+    const int qt = (int)(job % NT), q = qt * 16 + (lane & 15), g4 = (lane >> 4) * 4;
+    const DropKey dk = make_dropkey(rng, stream_id, rate);
+    const uint32_t dbase = (uint32_t)((bp * T + q) * T);   // as in the kernels (rows q >= T: never used)
+    uint32_t w = 0u;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        const uint64_t hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+        w |= (drop_quad_keep<0>(dk, hw) ? 1u : 0u) << (kt * 4);
+        w |= (drop_quad_keep<1>(dk, hw) ? 1u : 0u) << (kt * 4 + 1);
+        w |= (drop_quad_keep<2>(dk, hw) ? 1u : 0u) << (kt * 4 + 2);
+        w |= (drop_quad_keep<3>(dk, hw) ? 1u : 0u) << (kt * 4 + 3);
+    }
+    bits[job * 64 + lane] = w;
+}
+
 // reduce-scatter of 16 per-lane partials over the 4 lane groups: on return lane group g holds the
 // complete sums for e = 4g + i (i = 0..3) — exactly the MFMA B-operand layout lambda^T[e][q].
 __device__ __forceinline__ void reduce_scatter16(const float (&z)[16], float (&out)[4], int lane) {

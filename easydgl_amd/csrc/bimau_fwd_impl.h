@@ -32,6 +32,7 @@ struct FwdP {
                                    //  edgl_tpp_fwd_bwd_rows then writes the masked positions only); head dims 16 / 32 only
     int waves;
     int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
+    const uint32_t* dbits;   // optional: keep bits of the attention dropout (edgl_bimau_dropbits, bimau_common.h)
 };
 
 // wave-private LDS bytes of a phase (K always; T_ unless values phase; V and marks unless scores phase; the f32 key mask)
@@ -44,7 +45,8 @@ __host__ __device__ constexpr size_t fwd_wave_bytes() {
 
 // DT = dh/16, NT = ceil(T/16); EC = compile-time mark count (16: all LDS offsets are immediates and the mark loop is
 // one straight-line block) or 0 (runtime p.E)
-template <typename T, int DT, int NT, int EC, int PHASE = 0>
+// DB: the attention dropout reads stored keep bits (p.dbits) instead of hashing — same decisions (bimau_common.h)
+template <typename T, int DT, int NT, int EC, int PHASE = 0, bool DB = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHASE == 0) ? EDGL_BIMAU_FWD_WAVES : 1) void bimau_fwd_kernel(FwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
 
     // per-query-tile global operands (Q rows, interval, residual rows) are fetched one tile ahead: their HBM/L2 latency
     // overlaps the previous tile's compute instead of opening every iteration with a stall
-    struct QOps { Frag4<T> qf[DT], rf[DT]; float span; float lam[4]; };
+    struct QOps { Frag4<T> qf[DT], rf[DT]; float span; float lam[4]; uint32_t kb; };
     auto load_q = [&](int qt) {   // unconditional (row clamped): branch-free, so the wait counts around it stay exact
         QOps o;
         const int q = min(qt * 16 + l15, p.T - 1);
@@ -112,6 +114,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
             o.rf[ub] = frag_ld<T>(reinterpret_cast<const T*>(p.resid) + ((long)b * p.T + q) * p.ld_res + head * dh + ub * 16 + g4);
         }
         o.span = p.spans[(long)b * p.T + q];
+        if constexpr (DB) o.kb = p.dbits[(bp * NT + qt) * 64 + lane];
         if constexpr (PHASE == 2) {   // lambda rows written by the intensity kernel between the two phases
 #pragma unroll
             for (int i = 0; i < 4; ++i) o.lam[i] = p.lam[(bp * p.T + q) * E + min(g4 + i, E - 1)];
@@ -333,11 +336,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
                     s[kt][r] = gacc[r] * s[kt][r];     // temporal.py:441
                 }
                 if constexpr (decltype(drop_on)::value) {                       // temporal.py:442 (the scale is in G already)
-                    const uint64_t hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
-                    s[kt][0] = drop_quad_keep<0>(dk, hw) ? s[kt][0] : 0.f;
-                    s[kt][1] = drop_quad_keep<1>(dk, hw) ? s[kt][1] : 0.f;
-                    s[kt][2] = drop_quad_keep<2>(dk, hw) ? s[kt][2] : 0.f;
-                    s[kt][3] = drop_quad_keep<3>(dk, hw) ? s[kt][3] : 0.f;
+                    if constexpr (DB) {   // stored decisions: bit kt*4 + r of this lane's word
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[kt][r] = keep_bit(qcur.kb, kt * 4 + r, s[kt][r]);
+                    } else {
+                        const uint64_t hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+                        s[kt][0] = drop_quad_keep<0>(dk, hw) ? s[kt][0] : 0.f;
+                        s[kt][1] = drop_quad_keep<1>(dk, hw) ? s[kt][1] : 0.f;
+                        s[kt][2] = drop_quad_keep<2>(dk, hw) ? s[kt][2] : 0.f;
+                        s[kt][3] = drop_quad_keep<3>(dk, hw) ? s[kt][3] : 0.f;
+                    }
                 }
                 pf[kt] = frag_from_acc<T>(s[kt]);
             }
@@ -375,6 +383,10 @@ int launch_fwd_e(FwdP p, hipStream_t st) {
                  p.E, p.T);
     p.waves = waves;
     auto kern = bimau_fwd_kernel<T, DT, NT, EC, PHASE>;
+    // stored keep bits: the headline family (bf16, head dim 16, 16 marks, <= 8 key tiles, fused form); elsewhere the hash
+    if constexpr (sizeof(T) == 2 && DT == 1 && EC == 16 && PHASE == 0 && NT <= 8) {
+        if (p.dbits && p.rate > 0.f) kern = bimau_fwd_kernel<T, DT, NT, EC, PHASE, true>;
+    }
     if (smem > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const long jobs = (long)p.B * p.H;
     hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);

@@ -142,6 +142,52 @@ __global__ __launch_bounds__(256) void tpp_norm_kernel(TppP p, int* acc) {
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(acc, cnt);
 }
+// The same count by ONE workgroup (batches up to 64 K labels): strided labels per thread, integer block sum, a plain store — no
+// memset launch in front of it and nothing stale to inherit (the memset of the atomic form was a 6 us launch of its own in the
+// side-stream chain the first attention kernel waits for).
+__global__ __launch_bounds__(1024) void tpp_norm_one_kernel(TppP p, int* acc) {
+    __shared__ int red[16];
+    int cnt = 0;
+    const int n = p.B * p.M;
+    constexpr int NB = 8;   // labels per thread and round: all label loads of a round fly together, then all mark rows (two round
+                            // trips per 8 K labels; one label -> one mark row at a time was a chain of 2 x 10 round trips: 20 us)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * NB) {
+        int64_t lab[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) lab[j] = p.labels[min(i0 + j * 1024, n - 1)];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(lab[j]));
+        if (p.E == 16 && ((uintptr_t)p.mtab & 15) == 0) {
+            uint4 w[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) w[j] = *reinterpret_cast<const uint4*>(p.mtab + lab[j] * 16);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(w[j].x), "+v"(w[j].y), "+v"(w[j].z), "+v"(w[j].w));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (i0 + j * 1024 < n) {
+                    const uint32_t ws[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cnt += (int)((ws[q] & 0xffu) + ((ws[q] >> 8) & 0xffu) + ((ws[q] >> 16) & 0xffu) + (ws[q] >> 24));
+                }
+            }
+        } else {
+            for (int j = 0; j < NB; ++j)
+                if (i0 + j * 1024 < n) {
+                    const uint8_t* nm = p.mtab + lab[j] * p.E;
+                    for (int e = 0; e < p.E; ++e) cnt += nm[e];
+                }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        acc[0] = t;
+    }
+}
 constexpr int TPP_MAXM = 256, TPP_MAXT = 1024, TPP_FUSED_BLOCKS = 2048;   // (4096 one-sequence workgroups measured slower: 24 vs 19 us)
 __global__ __launch_bounds__(128) void tpp_fused_kernel(TppP p, const float* sums, float* part, float* d_lam) {
     __shared__ float red[8];
@@ -357,6 +403,48 @@ __global__ __launch_bounds__(256) void tpp_rows_kernel(TppP p, const float* sums
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     if (e < p.E) dst[e] = gr[e];
+            }
+        }
+    }
+    a = block_sum(a, red); bsum = block_sum(bsum, red);
+    if (threadIdx.x == 0) { part[blockIdx.x * 2] = a; part[blockIdx.x * 2 + 1] = bsum; }
+}
+// tpp_rows_kernel for ANY number of mark types (the static engine with more than 16 marks: a data set's mark.pkl fixes E,
+// EasyDGL.py:45-46): same contract — d lambda pre-zeroed, one thread per masked slot, a repeated position written once by its
+// first slot with the sum over its slots — as plain loops over the marks (not the benchmarked shape: no staging, no vector loads).
+__global__ __launch_bounds__(256) void tpp_rows_wide_kernel(TppP p, const float* sums, float* part, float* d_lam) {
+    __shared__ float red[8];
+    const float c = (float)reinterpret_cast<const int*>(sums)[4] * (float)p.H;
+    const float k = -p.coef / c;
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = j < (long)p.H * p.B * p.M;
+    const long bp = active ? j / p.M : 0;
+    const int m = active ? (int)(j % p.M) : 0, b = (int)(bp % p.B);
+    const int64_t* mp = p.mpos ? p.mpos + (long)b * p.M : nullptr;
+    const int pos_in = !active ? 0 : (mp ? (int)mp[m] : m);
+    active = active && pos_in >= 0 && pos_in < p.T;
+    const int pos = active ? pos_in : 0;
+    float a = 0.f, bsum = 0.f;
+    if (active) {
+        const long row = bp * p.T + pos;
+        const float* lm = p.lam + row * p.E;
+        const float sp = p.mpos ? raw_span(p.ts + (long)b * p.T, pos, p.T)
+                                : p.ts[(long)b * (p.T + 1) + pos + 1] - p.ts[(long)b * (p.T + 1) + pos];
+        bool head = true;
+        if (mp)
+            for (int q = 0; q < m; ++q) head = head && (int)mp[q] != pos;
+        for (int q = m; q < (head ? p.M : m + 1); ++q) {
+            if (q != m && (!mp || (int)mp[q] != pos)) continue;
+            const uint8_t* nm = p.mtab + p.labels[(long)b * p.M + q] * p.E;
+            float cnt = 0.f, ev = 0.f, ent = 0.f;
+            for (int e = 0; e < p.E; ++e) { const float f = (float)nm[e]; cnt += f; ev += lm[e] * f; ent += lm[e]; }
+            const float g = cnt > 0.f ? 1.f : 0.f;
+            ev *= g; ent *= g;
+            if (q == m) { a = __logf(ev == 0.f ? 1.f : ev); bsum = ent * sp * 0.5f; }
+            if (head && d_lam) {
+                const float iev = ev != 0.f ? 1.0f / ev : 0.f, kg = k * g, hs = sp * 0.5f;
+                float* dst = d_lam + row * p.E;
+                for (int e = 0; e < p.E; ++e) dst[e] += kg * ((float)nm[e] * iev - hs);   // this thread owns the row
             }
         }
     }
@@ -733,6 +821,11 @@ extern "C" int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const i
 extern "C" int edgl_tpp_norm(const int64_t* labels, const uint8_t* mark_table, int B, int M, int E, float* sums, void* stream) {
     EDGL_REQUIRE(labels && mark_table && sums, EDGL_ERR_NULL, "edgl_tpp_norm: null pointer");
     TppP p{nullptr, nullptr, labels, nullptr, mark_table, B, 0, 0, E, M, 0.f};
+    if ((long)B * M <= 65536) {   // one workgroup, plain store
+        hipLaunchKernelGGL(tpp_norm_one_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, reinterpret_cast<int*>(sums) + 4);
+        EDGL_LAUNCH_CHECK();
+        return EDGL_OK;
+    }
     // the count is formed from zero every time: a step that aborted between this call and tpp_final2_kernel (which zeroes the slot
     // again) must not leave a stale count behind for the next one
     if (hipMemsetAsync(reinterpret_cast<int*>(sums) + 4, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) {
@@ -766,20 +859,27 @@ extern "C" int edgl_tpp_fwd_bwd_ex(const float* lam, const int64_t* masked_pos, 
 }
 // edgl_tpp_fwd_bwd_ex (with_norm = 0) for a d_lam array that ALREADY HOLDS ZEROS (edgl_bimau_fwd_zr): one thread per masked
 // slot, only the rows of masked positions are written.  `sums` needs edgl_tpp_rows_workspace(B, H, M) floats.
-static long tpp_rows_blocks(int B, int H, int M) {
+static long tpp_rows_blocks(int B, int H, int M) {   // (also an upper bound of the one-slot-per-thread grid of the wide form)
     return M <= 256 ? ((long)H * B + 256 / M - 1) / (256 / M) : ((long)H * B * M + 255) / 256;
 }
-extern "C" long edgl_tpp_rows_workspace(int B, int H, int M) { return (B > 0 && H > 0 && M > 0) ? 8 + 2 * tpp_rows_blocks(B, H, M) : -1; }
+extern "C" long edgl_tpp_rows_workspace(int B, int H, int M) {
+    return (B > 0 && H > 0 && M > 0) ? 8 + 2 * std::max(tpp_rows_blocks(B, H, M), ((long)H * B * M + 255) / 256) : -1;
+}
 extern "C" int edgl_tpp_fwd_bwd_rows(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                                      const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
                                      float* reg_out, int accumulate, float* d_lam, void* stream) {
     EDGL_REQUIRE(lam && labels && ts_raw && mark_table && sums && reg_out, EDGL_ERR_NULL, "edgl_tpp_fwd_bwd_rows: null pointer");
     EDGL_REQUIRE(masked_pos || M == T, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd_rows: all-position mode needs M == T");
-    EDGL_REQUIRE(E >= 1 && E <= 16 && B > 0 && H > 0 && M > 0, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd_rows: bad shape E=%d B=%d H=%d M=%d", E, B, H, M);
+    EDGL_REQUIRE(E >= 1 && E <= 256 && B > 0 && H > 0 && M > 0, EDGL_ERR_SHAPE, "edgl_tpp_fwd_bwd_rows: bad shape E=%d B=%d H=%d M=%d", E, B, H, M);
     TppP p{lam, masked_pos, labels, ts_raw, mark_table, B, T, H, E, M, coef};
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = (int)tpp_rows_blocks(B, H, M);
-    hipLaunchKernelGGL(tpp_rows_kernel, dim3(nblk), dim3(256), 0, st, p, sums, sums + 8, d_lam);
+    int nblk = (int)tpp_rows_blocks(B, H, M);
+    if (E <= 16) {
+        hipLaunchKernelGGL(tpp_rows_kernel, dim3(nblk), dim3(256), 0, st, p, sums, sums + 8, d_lam);
+    } else {   // more than 16 mark types: plain loops over the marks, one slot per thread
+        nblk = (int)(((long)H * B * M + 255) / 256);
+        hipLaunchKernelGGL(tpp_rows_wide_kernel, dim3(nblk), dim3(256), 0, st, p, sums, sums + 8, d_lam);
+    }
     EDGL_LAUNCH_CHECK();
     hipLaunchKernelGGL(tpp_final2_kernel, dim3(1), dim3(256), 0, st, sums + 8, nblk, coef, H, sums, reg_out, accumulate);
     EDGL_LAUNCH_CHECK();

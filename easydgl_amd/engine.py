@@ -39,10 +39,15 @@ class TrainEngine:
         self.code = ops._DT[self.dt]
         B, T, C, H, E, M, I = batch, m.seqslen, m.num_units, m.num_heads, m.num_events, m.masklen, m.num_items
         self.T, self.C, self.H, self.E, self.M, self.I = T, C, H, E, M, I
-        if E > 16:
-            raise _lib.EdglError(f"TrainEngine: num_events={E}: the static engine issues one attention launch per block (<= 16 mark "
-                                 "types); models with more marks train through the autograd path (model.train_loss), which runs the "
-                                 "marks in groups of 16 (module/temporal.py modulated_attention)")
+        # More mark types than one attention launch takes (16; EasyDGL.py:45-46: E is the width of the data set's mark.pkl): the
+        # marks run as groups, as in module/temporal.py modulated_attention — G = sum_e marks.lambda_e is a sum over marks, the
+        # output (G * P) V is linear in G and lambda_e reads only its own dh columns of the intensity MLP.  One attention launch
+        # per group on its column block of the weights, the SAME dropout stream; group 0 carries the residual and the diagonal 1,
+        # the later groups a zero residual and the diagonal 0; outputs and d_qkvt add, lambda / d lambda concatenate.
+        gmax = int(lib.edgl_bimau_mark_group(C, H, self.code))
+        if gmax <= 0:
+            raise _lib.EdglError(f"TrainEngine: head dim {C // H} / {self.dt} unsupported by the attention kernels")
+        self.mgroups = [(e0, min(E, e0 + gmax)) for e0 in range(0, E, gmax)] if E > gmax else []
         self.R = B * M
         self.rows = B * T
         nb = len(m.layers)
@@ -62,11 +67,27 @@ class TrainEngine:
             d = dict(qkvt=e(B, T, 4 * C), att=e(B, T, C), lam=e(H * B, T, E, dtype=f32), ao=e(B, T, C), a1=e(B, T, C),
                      st1=e(B, 2, dtype=f32), pre_f=e(B, T, 2 * C), f=e(B, T, 2 * C), o=e(B, T, C), y=e(B, T, C),
                      st2=e(B, 2, dtype=f32),
-                     pack=e(lib.edgl_bimau_pack_bytes(C, H, E, self.code), dtype=torch.uint8),
-                     saved=e(lib.edgl_bimau_saved_bytes(B, T, C, H, self.code), dtype=torch.uint8),
+                     pack=e(0 if self.mgroups else lib.edgl_bimau_pack_bytes(C, H, E, self.code), dtype=torch.uint8),
+                     saved=e(0 if self.mgroups else lib.edgl_bimau_saved_bytes(B, T, C, H, self.code), dtype=torch.uint8),
                      dlam=e(H * B, T, E, dtype=f32),
                      tpp=torch.zeros(max(lib.edgl_tpp_workspace(), lib.edgl_tpp_rows_workspace(B, H, M)), device=dev, dtype=f32))
+            # stored keep bits of the attention dropout: hashed once per step on the side stream, read by the forward and both
+            # backward sweeps (csrc/bimau_common.h; 0 bytes = no stored-bits form at this T)
+            nb_bits = int(lib.edgl_bimau_dropbits_bytes(B, T, H)) if m.attention_probs_dropout_rate > 0 else 0
+            d["dbits"] = e(nb_bits // 4, dtype=torch.int32) if nb_bits > 0 and os.environ.get("EDGL_DROPBITS", "1") != "0" and os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") != "1" else None
+            if self.mgroups:
+                dh = C // H
+                d["grp"] = []
+                for (e0, e1) in self.mgroups:
+                    eg = e1 - e0
+                    d["grp"].append(dict(
+                        marks=e(B, T, eg, dtype=torch.uint8), W1=e(dh + 1, dh * eg, dtype=f32), dW1=e(dh + 1, dh * eg, dtype=f32),
+                        pack=e(lib.edgl_bimau_pack_bytes(C, H, eg, self.code), dtype=torch.uint8),
+                        saved=e(lib.edgl_bimau_saved_bytes(B, T, C, H, self.code), dtype=torch.uint8),
+                        lam=e(H * B, T, eg, dtype=f32), dlam=e(H * B, T, eg, dtype=f32),
+                        out=e(B, T, C) if e0 else None, dqkvt=e(B, T, 4 * C) if e0 else None))
             self.blk.append(d)
+        self.zero_resid = torch.zeros((B, T, C), device=dev, dtype=self.dt) if self.mgroups else None
         self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
         # fused per-sample block tail (csrc/k_tail.hip): one launch for dense -> LN -> GELU-dense -> dense -> LN (-> head)
         # (the head of the fused tail and the fused TPP kernel hold the masked positions of a sample in LDS: M <= 256, T <= 1024 —
@@ -93,6 +114,7 @@ class TrainEngine:
         self.loss_aux, self.loss_tpp = torch.zeros(1, device=dev, dtype=f32), torch.zeros(1, device=dev, dtype=f32)
         self.ws_l2 = e(1024, dtype=f32)
         self.side = torch.cuda.Stream(device=dev)
+        self.side2 = torch.cuda.Stream(device=dev)
         self._pending_loss = None
         self._pending_label = None
         # data parallel: weighted rows / TPP normaliser of the GLOBAL batch (filled by _global_counts before a step)
@@ -173,42 +195,80 @@ class TrainEngine:
         drop = lambda rate, sid: ops.Drop(rate, m._rng_state, sid) if rate > 0 else ops.NO_DROP  # noqa: E731
         tab = m.item_embs.lookup_table
         tab_c = m.compute(tab)
-        # ---- side stream: launches that depend on the weights only (weight packs, the L2 term) start with the step and
-        # run under the encoder / QKVT projection: few-microsecond kernels that would otherwise sit in the critical path,
-        # each behind a full launch.  (Small kernels next to the one-workgroup-per-CU kernels — block tail, scoring — is what
-        # NOT to do: the fat workgroups cannot be placed while small ones hold registers of a CU; measured 84 -> 247 us.)
-        main, side = torch.cuda.current_stream(), self.side
+        # dropout step counter, Adam step counter and learning rate of this step (one single-thread launch): normally already in
+        # place — _optimizer advances them for the NEXT step behind its last kernel, so that the fork below costs the main stream
+        # nothing (an event record behind a kernel idles the stream ~6-13 us before its next launch) while the side stream can hash
+        # the keep bits of the attention dropout from the advanced counter.  First step, or an _issue() without _optimizer: here.
+        legacy = os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") == "1"   # A/B switch: round-3 order (one side stream, fork first)
+        if not legacy:
+            if not getattr(m, "_state_ahead", False):
+                self._advance_state(st)
+            m._state_ahead = False
+        # ---- side streams: launches that depend on the weights / labels / the step counter only start with the step and run
+        # under the encoder / QKVT projection: few-microsecond kernels that would otherwise sit in the critical path, each behind
+        # a full launch.  (Small kernels next to the one-workgroup-per-CU kernels — block tail, scoring — is what NOT to do: the
+        # fat workgroups cannot be placed while small ones hold registers of a CU; measured 84 -> 247 us.)
+        # The first attention kernel waits for this chain, and a cross-stream edge takes ~12 us to arrive: everything it needs
+        # must be through ~25 us before the QKVT projection ends (timeline of round 4: the chain ended 10 us AFTER it and the
+        # main stream idled 22 us).  Hence: the row-compaction scan — one 1024-thread workgroup, ~24 us — on a stream of its own,
+        # the chain itself without the memset of the normaliser, the L2 term BEHIND the event (its consumer, the loss kernel,
+        # runs on this same side stream at the end of the backward).
+        main, side, side2 = torch.cuda.current_stream(), self.side, self.side2
+        if legacy:
+            side2 = side
         sst = side.cuda_stream
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            # needed by the scoring: row compaction map (labels only).  FIRST on the side stream: its one 1024-thread workgroup
-            # needs a whole CU's worth of free wave slots, which it gets beside the small encoder kernel but not once the QKVT
-            # projection fills the chip (512-unit recipe: 5 .. 516 us, the main stream waiting for it at the join)
+        if not legacy:
+            side2.wait_stream(main)
+        else:
+            if not getattr(m, "_state_ahead", False):
+                self._advance_state(st)
+            m._state_ahead = False
+        with torch.cuda.stream(side2):
+            # needed by the scoring: row compaction map (labels only).  Its one 1024-thread workgroup needs a whole CU's worth of
+            # free wave slots, which it gets beside the small encoder kernel but not once the QKVT projection fills the chip
+            # (512-unit recipe: 5 .. 516 us, the main stream waiting for it at the join)
             check(lib.edgl_compact_scan_labels(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid),
-                                               _ptr(self.labels_c), sst), "edgl_compact_scan_labels")
-            # needed by the first BiMAU forward (the one join of the forward): TPP normaliser (labels only), weight packs
+                                               _ptr(self.labels_c), side2.cuda_stream), "edgl_compact_scan_labels")
+
+        def l2_term():
+            if m.l2_reg != 0.0:
+                check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss_aux), 0,
+                                       _ptr(self.ws_l2), sst), "edgl_l2_loss")
+
+        with torch.cuda.stream(side):
+            # needed by the first BiMAU forward (the one join of the forward): TPP normaliser (labels only), weight packs, keep bits
             for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
                 att = blk.attention
                 if m.ct_reg != 0.0 and not self._dp:    # (data parallel: _global_counts put the all-reduced count there)
                     check(lib.edgl_tpp_norm(_ptr(self.labels), _ptr(m.mark_lookup_table), B, M, E, _ptr(b["tpp"]), sst),
                           "edgl_tpp_norm")
-                check(lib.edgl_bimau_pack(_ptr(att.st_kernel), _ptr(att.st_bias), _ptr(att.weight), _ptr(att.scaling), C, H, E,
-                                          _ptr(b["pack"]), code, sst), "edgl_bimau_pack")
+                if self.mgroups:
+                    dh = C // H
+                    for (e0, e1), gb in zip(self.mgroups, b["grp"]):
+                        gb["W1"].copy_(att.st_kernel[:, e0 * dh:e1 * dh])      # the group's column block, contiguous
+                        check(lib.edgl_bimau_pack(_ptr(gb["W1"]), _ptr(att.st_bias[e0 * dh:e1 * dh]), _ptr(att.weight[e0:e1]),
+                                                  _ptr(att.scaling[e0:e1]), C, H, e1 - e0, _ptr(gb["pack"]), code, sst), "edgl_bimau_pack")
+                else:
+                    check(lib.edgl_bimau_pack(_ptr(att.st_kernel), _ptr(att.st_bias), _ptr(att.weight), _ptr(att.scaling), C, H, E,
+                                              _ptr(b["pack"]), code, sst), "edgl_bimau_pack")
                 if self.fused_tail:
                     check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
                                              _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
                                              _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
-            # L2 term — same join: every cross-stream edge costs the waiting stream ~6 us even when the other side finished long
-            # ago, and all of this ends under the QKVT projection
+                if b["dbits"] is not None and not legacy:
+                    check(lib.edgl_bimau_dropbits(B, T, H, float(ad), _ptr(m._rng_state), 10 + 4 * i, _ptr(b["dbits"]), sst),
+                          "edgl_bimau_dropbits")
+            if not self.blk or legacy:
+                l2_term()      # (no block: the loss kernel runs on the main stream behind this one event)
+            if not legacy:
+                side.wait_stream(side2)
+            ev_pack = side.record_event()
+            # L2 term: not needed before the loss kernel at the end of the backward (same stream)
             # (the transposed table image is NOT prepared here, although it depends on the weights only: written 200 us before
             # its use it has left the L2 by then and the scoring pass measured 109 -> 118 us — edgl_score_prepare_table)
-            if m.l2_reg != 0.0:
-                check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss_aux), 0,
-                                       _ptr(self.ws_l2), sst), "edgl_l2_loss")
-            ev_pack = side.record_event()
-        # dropout step counter, Adam step counter and learning rate of this step: one single-thread launch
-        check(lib.edgl_step_begin(_ptr(m._rng_state), _ptr(m._adam_state), float(m.learning_rate), 0.9, 0.999, st),
-              "edgl_step_begin")
+            if self.blk and not legacy:
+                l2_term()
         # ================= forward (EasyDGL.py:70-151) =================
         d0 = drop(hd, 1)
         check(lib.edgl_encode_fwd(_ptr(self.ids), _ptr(self.ts), _ptr(tab_c), _ptr(m.pcoding.pembs.lookup_table),
@@ -224,10 +284,13 @@ class TrainEngine:
             da = drop(ad, 10 + 4 * i)
             # the forward also zero-fills this block's d lambda buffer (free beside its VALU work): the TPP launch then writes
             # the rows of the masked positions only — 5 MB instead of 26 MB at the headline shape
-            check(lib.edgl_bimau_fwd_zr(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
-                                        _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["att"]),
-                                        _ptr(b["lam"]), _ptr(b["saved"]), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, 0, code, st),
-                  "edgl_bimau_fwd_zr")
+            if self.mgroups:
+                self._attention_fwd_groups(b, x, cin, da, st)
+            else:
+                check(lib.edgl_bimau_fwd_db(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
+                                            _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]),
+                                            _ptr(b["att"]), _ptr(b["lam"]), _ptr(b["saved"]),
+                                            _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, 0, code, st), "edgl_bimau_fwd_db")
             if m.ct_reg != 0.0:   # TPP regulariser of this block: loss term and d lambda (two small launches)
                 check(lib.edgl_tpp_fwd_bwd_rows(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
                                                 _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
@@ -385,13 +448,17 @@ class TrainEngine:
                 self._dense_dx(d_ao, blk.att_out.kernel, self.G2, C, C)          # G2 = d_att
             att = blk.attention
             da = drop(ad, 10 + 4 * i)
-            check(lib.edgl_bimau_bwd(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
-                                     _ptr(self.G2), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, _ptr(b["lam"]),
-                                     _ptr(b["saved"]), B, T, C, H, E,
-                                     float(da.rate), da.ptr(), da.stream_id, _ptr(self.G4c), _ptr(att.st_kernel.grad),
-                                     _ptr(att.st_bias.grad), _ptr(att.weight.grad), _ptr(att.scaling.grad),
-                                     _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), 0, code, st),
-                  "edgl_bimau_bwd")
+            if self.mgroups:
+                self._attention_bwd_groups(att, b, da, st)
+            else:
+                check(lib.edgl_bimau_bwd_db(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
+                                            _ptr(self.G2), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, _ptr(b["lam"]),
+                                            _ptr(b["saved"]), B, T, C, H, E,
+                                            float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), _ptr(self.G4c),
+                                            _ptr(att.st_kernel.grad), _ptr(att.st_bias.grad), _ptr(att.weight.grad),
+                                            _ptr(att.scaling.grad),
+                                            _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), 0, code, st),
+                      "edgl_bimau_bwd_db")
             self._dense_dw(x_in, self.G4c, att.dense_kernel, att.dense_bias, cin, 4 * C)
             if self.fused_tail:
                 check(lib.edgl_gemm_dw_defer(0, st), "edgl_gemm_dw_defer")
@@ -423,12 +490,67 @@ class TrainEngine:
                                       _ptr(m.mark_embs.lookup_table.grad), _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))),
                                       code, st), "edgl_encode_bwd_add")
 
+    # ---- more than 16 mark types: the attention of a block as mark groups (see __init__) -----------------------------------
+    def _attention_fwd_groups(self, b, x, cin, da, st):
+        m = self.m
+        B, T, C, H, E, code = self.B, self.T, self.C, self.H, self.E, self.code
+        for g, ((e0, e1), gb) in enumerate(zip(self.mgroups, b["grp"])):
+            gb["marks"].copy_(self.marks[:, :, e0:e1])
+            first = g == 0
+            check(lib.edgl_bimau_fwd_db(_ptr(b["qkvt"]), x.data_ptr() if first else self.zero_resid.data_ptr(), cin if first else C,
+                                        _ptr(self.ids), _ptr(self.spans), _ptr(gb["marks"]), _ptr(gb["pack"]), B, T, C, H, e1 - e0,
+                                        float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), _ptr(b["att"] if first else gb["out"]),
+                                        _ptr(gb["lam"]), _ptr(gb["saved"]), None, 0 if first else ops.MAU_DIAG_ZERO, code, st),
+                  "edgl_bimau_fwd_db")
+            if not first:
+                check(lib.edgl_add(_ptr(b["att"]), _ptr(gb["out"]), _ptr(b["att"]), b["att"].numel(), code, st), "edgl_add")
+        torch.cat([gb["lam"] for gb in b["grp"]], dim=-1, out=b["lam"])
+        if m.ct_reg != 0.0:
+            b["dlam"].zero_()       # edgl_tpp_fwd_bwd_rows writes the rows of the masked positions only
+
+    def _attention_bwd_groups(self, att, b, da, st):
+        m = self.m
+        B, T, C, H, code = self.B, self.T, self.C, self.H, self.code
+        dh = C // H
+        # the group launches reduce their weight-gradient partials at once (their dW1 block is copied into the strided column
+        # block of st_kernel.grad right behind them): leave the deferred-reduction mode around them
+        check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")
+        for g, ((e0, e1), gb) in enumerate(zip(self.mgroups, b["grp"])):
+            first = g == 0
+            if m.ct_reg != 0.0:
+                gb["dlam"].copy_(b["dlam"][:, :, e0:e1])
+            check(lib.edgl_bimau_bwd_db(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(gb["marks"]), _ptr(gb["pack"]),
+                                     _ptr(self.G2), _ptr(gb["dlam"]) if m.ct_reg != 0.0 else None, _ptr(gb["lam"]), _ptr(gb["saved"]),
+                                     B, T, C, H, e1 - e0, float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]),
+                                     _ptr(self.G4c if first else gb["dqkvt"]), _ptr(gb["dW1"]), _ptr(att.st_bias.grad[e0 * dh:e1 * dh]),
+                                     _ptr(att.weight.grad[e0:e1]), _ptr(att.scaling.grad[e0:e1]),
+                                     _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, e1 - e0, code), torch.uint8)),
+                                     0 if first else ops.MAU_DIAG_ZERO, code, st), "edgl_bimau_bwd")
+            att.st_kernel.grad[:, e0 * dh:e1 * dh].copy_(gb["dW1"])
+            if not first:
+                check(lib.edgl_add(_ptr(self.G4c), _ptr(gb["dqkvt"]), _ptr(self.G4c), self.G4c.numel(), code, st), "edgl_add")
+        check(lib.edgl_reduce_defer(1, st), "edgl_reduce_defer")
+
+    def _advance_state(self, st):
+        m = self.m
+        check(lib.edgl_step_begin(_ptr(m._rng_state), _ptr(m._adam_state), float(m.learning_rate), 0.9, 0.999, st),
+              "edgl_step_begin")
+
     def _optimizer(self):
         m = self.m
+        if os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") == "1":     # A/B switch: no look-ahead of the step counters
+            seg = self.l2_seg if m.l2_reg != 0.0 else None
+            check(lib.edgl_adam_apply(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,
+                                      0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg),
+                                      0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _stream()), "edgl_adam_apply")
+            return
         seg = self.l2_seg if m.l2_reg != 0.0 else None
         check(lib.edgl_adam_apply(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,
                                   0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg),
                                   0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _stream()), "edgl_adam_apply")
+        # the counters of the next step (Sequential.settle_state undoes this for anyone else who reads them)
+        self._advance_state(_stream())
+        m._state_ahead = True
 
     # ---- public API --------------------------------------------------------------------------------------------------------
     def load_batch(self, features: Dict[str, torch.Tensor], labels: torch.Tensor) -> None:
@@ -520,18 +642,25 @@ class TrainEngine:
                 self._dp_allreduce()
                 self._optimizer()
                 self._global_counts()      # (the capture below reads the counts of the current batch)
+            # (the warm-up's optimizer left the counters of the next step in place: the captured sequence starts without the
+            #  single-thread update and — with its own optimizer — ends with it)
+            assert getattr(self.m, "_state_ahead", False)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._issue()
                 if not distributed:
                     self._optimizer()
+            self.m._state_ahead = True      # nothing ran during the capture: still what the warm-up left
             self._distributed = distributed
             if distributed:                # the captured launches have not run: this call is the warm-up step only
                 return self.loss_global
             return self.loss
         if self._distributed:
             self._global_counts()
+        if not getattr(self.m, "_state_ahead", False):   # somebody settled the counters (a checkpoint, an autograd-path step)
+            self._advance_state(_stream())
         self.graph.replay()
+        self.m._state_ahead = not self._distributed       # the captured optimizer ends with the next step's counters
         if self._distributed:
             out = self._dp_allreduce()
             self._optimizer()

@@ -149,9 +149,20 @@ class Sequential(nn.Module):
         step.warmup_loss = warm_loss   # loss of the last eager warm-up step (a real optimizer step on the capture batch)
         return step
 
+    def settle_state(self) -> None:
+        """The static engine leaves the step counters (dropout step, Adam step / learning rate) of the NEXT step in place behind
+        its optimizer kernel — the single-thread update then costs nothing in front of the next step's first kernels
+        (engine.TrainEngine._advance_state).  Anything else that reads or advances them (the autograd path's steps, a checkpoint)
+        calls this first: the counters go back to "steps taken so far"."""
+        if getattr(self, "_state_ahead", False):
+            self._rng_state[1] -= 1
+            self._adam_state[0] -= 1
+            self._state_ahead = False
+
     def optimizer_step(self) -> None:
         """tf.train.AdamOptimizer(lr).minimize (Base.py:142-144) fused over the arena.  The l2 gradient is
         produced by autograd (ops.L2Fn), so no l2 is folded in here."""
+        self.settle_state()
         ops.adam_step(self._arena, self._grad_arena, self._adam_m, self._adam_v, self.learning_rate, self._adam_state,
                       0.0, None, self._shadow)
 

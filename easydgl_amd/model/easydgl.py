@@ -175,6 +175,7 @@ class EasyDGL(Sequential):
 
     def train_step(self, features, labels):
         """One optimizer step: forward, backward, TF-Adam.  Returns the loss tensor (device scalar)."""
+        self.settle_state()
         ops.rng_advance(self._rng_state)
         self.detach_grads()
         loss = self.train_loss(features, labels)

@@ -111,6 +111,7 @@ def save_checkpoint(model, path: str) -> None:
     """Parameters (flat f32 arena), Adam moments and step — everything a resumed run needs."""
     import torch
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    model.settle_state()       # (the static engine keeps the counters one step ahead: the file holds "steps taken")
     torch.save({"arena": model._arena.detach().cpu(), "adam_m": model._adam_m.cpu(), "adam_v": model._adam_v.cpu(),
                 "adam_state": model._adam_state.cpu(), "rng_state": model._rng_state.cpu(),
                 "offsets": dict(model._offsets)}, path)
@@ -127,6 +128,7 @@ def load_checkpoint(model, path: str) -> None:
         model._adam_v.copy_(ck["adam_v"])
         model._adam_state.copy_(ck["adam_state"])
         model._rng_state.copy_(ck["rng_state"])
+    model._state_ahead = False     # the file holds "steps taken" (save_checkpoint settles the engine's look-ahead)
     model.sync_shadow()
 
 

@@ -183,6 +183,20 @@ int edgl_bimau_fwd_zr(const void* qkvt, const void* resid, int ld_res, const int
                       const uint64_t* rng_state, uint32_t stream_id, void* out, float* lam_out, void* saved,
                       float* zero_rows, int flags, int dtype, void* stream);
 
+/* Attention dropout as stored keep bits (temporal.py:442; the three kernels of a training step — forward and the two backward
+ * sweeps — take the same decisions): edgl_bimau_dropbits evaluates the counter hash of (rng_state, stream_id, element (b', q, k))
+ * ONCE and stores the decisions in the kernels' register layout — edgl_bimau_dropbits_bytes(B, T, H) bytes (0: no stored-bits form
+ * at this T, the kernels hash) —, edgl_bimau_fwd_db / edgl_bimau_bwd_db are edgl_bimau_fwd_zr / edgl_bimau_bwd reading them
+ * (dropbits NULL = hash).  Identical masks either way: a kernel without a stored-bits form (head dims other than 16, E != 16, MAU
+ * flags, f32) ignores the argument and hashes. */
+long edgl_bimau_dropbits_bytes(int B, int T, int H);
+int edgl_bimau_dropbits(int B, int T, int H, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, uint32_t* bits,
+                        void* stream);
+int edgl_bimau_fwd_db(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
+                      const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E, float drop_rate,
+                      const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, void* out, float* lam_out,
+                      void* saved, float* zero_rows, int flags, int dtype, void* stream);
+
 /* Backward.  d_out [B,T,C] `dtype`; d_lam_ext f32 [H*B,T,E] or NULL (gradient
  * from the TPP regulariser); lam / saved: the forward's lam_out and `saved` buffer.  Writes d_qkvt [B,T,4C] `dtype` and the f32 weight gradients dW1
  * [dh+1,dh*E], db1 [dh*E], dw [E,dh], dscaling [E] (overwritten; per-workgroup partials in
@@ -194,6 +208,11 @@ int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float* spans, con
                    const void* saved, int B, int T, int C, int H, int E, float drop_rate,
                    const uint64_t* rng_state, uint32_t stream_id, void* d_qkvt, float* dW1, float* db1,
                    float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream);
+int edgl_bimau_bwd_db(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks,
+                      const void* pack, const void* d_out, const float* d_lam_ext, const float* lam,
+                      const void* saved, int B, int T, int C, int H, int E, float drop_rate,
+                      const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, void* d_qkvt, float* dW1,
+                      float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream);
 
 /* ---- K4-LN: y = layernorm_joint(dropout(x) + resid) — Base.py:12-67 (moments over (T,C) per
  * sample, eps 1e-12), EasyDGL.py:114-116,126-128,139.  resid may be NULL (ld_res ignored).
@@ -395,7 +414,7 @@ int edgl_tpp_fwd_bwd_ex(const float* lam, const int64_t* masked_pos, const int64
 long edgl_tpp_rows_workspace(int B, int H, int M);
 int edgl_tpp_fwd_bwd_rows(const float* lam, const int64_t* masked_pos, const int64_t* labels, const float* ts_raw,
                           const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
-                          float* reg_out, int accumulate, float* d_lam, void* stream);
+                          float* reg_out, int accumulate, float* d_lam, void* stream);   /* E <= 256 (E > 16: plain loops over the marks) */
 
 /* ---- optimizer — tf.train.AdamOptimizer (Base.py:142-144) over a flat f32 arena ----------------
  * step_state: device uint64[2]: [0] = step count (incremented by this call, so the first call is

@@ -11,7 +11,11 @@ pytestmark = pytest.mark.gpu
 
 CASES = [dict(), dict(num_units=64, num_heads=2, num_blocks=1, seqslen=30, masklen=6, num_events=7, num_items=300),
          dict(num_units=128, num_heads=8, num_blocks=1, seqslen=100, masklen=20, num_events=16, num_items=2000),
-         dict(num_units=512, num_heads=8, num_blocks=1, seqslen=30, masklen=6, num_events=16, num_items=700)]   # runme.sh:15-23
+         dict(num_units=512, num_heads=8, num_blocks=1, seqslen=30, masklen=6, num_events=16, num_items=700),   # runme.sh:15-23
+         # more than 16 mark types in the STATIC engine: mark groups inside the fixed launch sequence (16 + 8 at dh = 16, two
+         # blocks; 16 + 16 + 8 at dh = 64) — EasyDGL.py:45-46 takes E from the data set's mark.pkl
+         dict(num_units=64, num_heads=4, num_blocks=2, seqslen=20, masklen=5, num_events=24, num_items=300),
+         dict(num_units=128, num_heads=2, num_blocks=1, seqslen=18, masklen=4, num_events=40, num_items=200)]
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
@@ -69,6 +73,22 @@ def test_engine_at_rows_that_reach_the_large_m_kernels():
     assert not bad, (bad, GRAD_TOL["bf16"])
 
 
+def test_engine_with_mark_groups_steps_eager_and_graph():
+    """E = 24 with dropout on: the eager launch sequence and its HIP-graph capture follow the same trajectory (the group copies,
+    the concatenation of lambda and the zero fill of d lambda are part of the captured sequence)."""
+    from easydgl_amd.engine import TrainEngine
+    prob = make_problem(seed=53, batch=6, num_units=64, num_heads=4, num_blocks=1, seqslen=20, masklen=5, num_events=24, num_items=300)
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    runs = []
+    for use_graph in (False, True):
+        m = build_model(prob, "f32", hidden_drop=0.1, att_drop=0.1)
+        eng = TrainEngine(m, 6, use_graph=use_graph)
+        runs.append([float(eng.step(feats, labels)) for _ in range(4)])
+    assert all(np.isfinite(runs[0])) and runs[0][-1] < runs[0][0]
+    for a, b in zip(*runs):
+        assert abs(a - b) <= 1e-5 * abs(a), runs
+
+
 def test_engine_trajectory_eager_and_graph():
     from easydgl_amd.engine import TrainEngine
     prob = make_problem(seed=50, batch=6)
@@ -93,11 +113,13 @@ def test_engine_trajectory_eager_and_graph():
             assert d < 3e-4, (use_graph, name, d)
 
 
-def test_engine_with_dropout_matches_autograd_path_bf16():
-    """Same (seed, step, op-id) -> same dropout masks in both paths -> same loss and gradients."""
+@pytest.mark.parametrize("num_events", [8, 16])
+def test_engine_with_dropout_matches_autograd_path_bf16(num_events):
+    """Same (seed, step, op-id) -> same dropout masks in both paths -> same loss and gradients.  16 marks at head dim 16: the engine
+    reads the STORED keep bits of the attention dropout (edgl_bimau_dropbits), the autograd path hashes — the same masks."""
     from easydgl_amd.engine import TrainEngine
     prob = make_problem(seed=51, batch=8, num_items=400, seqslen=20, num_units=64, num_heads=4, num_blocks=2, masklen=4,
-                        num_events=8)
+                        num_events=num_events)
     feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
     m1 = build_model(prob, "bf16", hidden_drop=0.1, att_drop=0.1)
     m2 = build_model(prob, "bf16", hidden_drop=0.1, att_drop=0.1)

@@ -663,6 +663,76 @@ def test_bimau_forward_zero_fills_the_d_lambda_buffer():
         assert float(outs[1][2].abs().max()) == 0.0, (C, H, E)
 
 
+@pytest.mark.parametrize("T", [19, 101, 128])
+def test_stored_dropout_keep_bits_equal_the_hashed_masks(T):
+    """edgl_bimau_dropbits + edgl_bimau_fwd_db / _bwd_db against the hashing kernels on the same (rng state, stream id): the stored
+    bits ARE the hash decisions, so outputs, lambda, d_qkvt and the weight gradients are identical bit for bit (bf16, head dim 16,
+    16 marks: the family with a stored-bits form; T = 101 is the benchmarked length, 128 the last supported one)."""
+    from easydgl_amd import _lib
+    lib = _lib.lib
+    o = ops()
+    rng = np.random.default_rng(5 + T)
+    B, C, H, E, rate, sid = 3, 64, 4, 16, 0.3, 14
+    dh = C // H
+    qkvt = torch.tensor(rng.standard_normal((B, T, 4 * C)) * 0.4, dtype=torch.bfloat16).cuda()
+    resid = torch.tensor(rng.standard_normal((B, T, C)), dtype=torch.bfloat16).cuda()
+    ids = rng.integers(1, 30, size=(B, T)); ids[1, :5] = 0
+    ids = torch.tensor(ids).cuda()
+    spans = torch.tensor(rng.uniform(0, 5, size=(B, T)), dtype=torch.float32).cuda()
+    marks = torch.tensor(O.synthetic_mark_table(30, E, multi_hot=True)[ids.cpu().numpy()].astype(np.uint8)).cuda()
+    W1 = torch.tensor(rng.standard_normal((dh + 1, dh * E)) * 0.2, dtype=torch.float32).cuda()
+    b1 = torch.tensor(rng.standard_normal(dh * E) * 0.1, dtype=torch.float32).cuda()
+    w = torch.tensor(rng.standard_normal((E, dh)) * 0.3, dtype=torch.float32).cuda()
+    sc = torch.zeros(E, device="cuda")
+    d_out = torch.tensor(rng.standard_normal((B, T, C)), dtype=torch.bfloat16).cuda()
+    d_lam = torch.tensor(rng.standard_normal((H * B, T, E)) * 0.01, dtype=torch.float32).cuda()
+    code = o._code(qkvt)
+    state = o.make_rng_state("cuda", seed=77)
+    o.rng_advance(state)
+    pack = torch.empty(lib.edgl_bimau_pack_bytes(C, H, E, code), device="cuda", dtype=torch.uint8)
+    _lib.check(lib.edgl_bimau_pack(W1.data_ptr(), b1.data_ptr(), w.data_ptr(), sc.data_ptr(), C, H, E, pack.data_ptr(), code, None), "pack")
+    nbits = int(lib.edgl_bimau_dropbits_bytes(B, T, H))
+    assert nbits == B * H * ((T + 15) // 16) * 64 * 4
+    bits = torch.zeros(nbits // 4, device="cuda", dtype=torch.int32)
+    _lib.check(lib.edgl_bimau_dropbits(B, T, H, rate, state.data_ptr(), sid, bits.data_ptr(), None), "edgl_bimau_dropbits")
+    # the keep rate of the stored bits (rows / keys inside the sequence)
+    nt = (T + 15) // 16
+    wds = bits.view(H * B, nt, 64).cpu().numpy().astype(np.uint32)
+    keep = np.zeros((H * B, nt * 16, nt * 16), bool)
+    for lane in range(64):
+        for kt in range(nt):
+            for r in range(4):
+                keep[:, np.arange(nt) * 16 + (lane & 15), kt * 16 + (lane >> 4) * 4 + r] = (wds[:, :, lane] >> (kt * 4 + r)) & 1
+    frac = keep[:, :T, :T].mean()
+    assert abs(frac - (1 - rate)) < 0.01, frac
+    res = []
+    for db in (None, bits):
+        out = torch.empty((B, T, C), device="cuda", dtype=torch.bfloat16)
+        lam = torch.empty((H * B, T, E), device="cuda")
+        saved = torch.empty(lib.edgl_bimau_saved_bytes(B, T, C, H, code), device="cuda", dtype=torch.uint8)
+        _lib.check(lib.edgl_bimau_fwd_db(qkvt.data_ptr(), resid.data_ptr(), C, ids.data_ptr(), spans.data_ptr(), marks.data_ptr(),
+                                         pack.data_ptr(), B, T, C, H, E, rate, state.data_ptr(), sid, None if db is None else db.data_ptr(),
+                                         out.data_ptr(), lam.data_ptr(), saved.data_ptr(), None, 0, code, None), "edgl_bimau_fwd_db")
+        dq = torch.empty_like(qkvt)
+        n1, n2, n3 = (dh + 1) * dh * E, dh * E, E * dh
+        g = torch.empty(n1 + n2 + n3 + E, device="cuda")
+        ws = torch.empty(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), device="cuda", dtype=torch.uint8)
+        _lib.check(lib.edgl_bimau_bwd_db(qkvt.data_ptr(), ids.data_ptr(), spans.data_ptr(), marks.data_ptr(), pack.data_ptr(),
+                                         d_out.data_ptr(), d_lam.data_ptr(), lam.data_ptr(), saved.data_ptr(), B, T, C, H, E, rate,
+                                         state.data_ptr(), sid, None if db is None else db.data_ptr(), dq.data_ptr(), g.data_ptr(),
+                                         g[n1:].data_ptr(), g[n1 + n2:].data_ptr(), g[n1 + n2 + n3:].data_ptr(), ws.data_ptr(), 0, code, None),
+                   "edgl_bimau_bwd_db")
+        torch.cuda.synchronize()
+        res.append((out, lam, dq, g))
+    undropped = torch.empty((B, T, C), device="cuda", dtype=torch.bfloat16)
+    lam0 = torch.empty((H * B, T, E), device="cuda")
+    _lib.check(lib.edgl_bimau_fwd(qkvt.data_ptr(), resid.data_ptr(), C, ids.data_ptr(), spans.data_ptr(), marks.data_ptr(),
+                                  pack.data_ptr(), B, T, C, H, E, 0.0, None, 0, undropped.data_ptr(), lam0.data_ptr(), None, 0, code, None), "fwd")
+    assert not torch.equal(res[0][0], undropped)              # dropout is on
+    for a, b_, what in zip(res[0], res[1], ("out", "lambda", "d_qkvt", "weight gradients")):
+        assert torch.equal(a, b_), what
+
+
 def test_tpp_fused_launch_all_position_mode():
     """edgl_tpp_fwd_bwd without masked positions (CTSMA's form: every position scored, T + 1 raw timestamps per row) against
     the separate forward / backward kernels behind TppFn."""

@@ -1,12 +1,10 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/pytest_gpu.txt
-cat gpurun_out/pytest_gpu.txt
-for v in base nohash skip1; do
-  if [ $v = base ]; then unset EDGL_LIB_PATH; else export EDGL_LIB_PATH=$GRAFT_REPO_ROOT/tools/variants/lib_$v.so; fi
-  KT_LINES=14 bash tools/ktrace.sh > gpurun_out/ab_$v.txt 2>&1
-  echo "== $v"; grep -E "bimau|intensity|metric" gpurun_out/ab_$v.txt | cut -c1-200
+for r in 1 2 3; do
+for v in "0 0" "1 0" "0 1"; do
+  set -- $v
+  EDGL_ENGINE_LEGACY_FORK=$1 EDGL_DROPBITS=$2 python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print('legacy=$1 dropbits=$2', j['ms_per_step'], j['step_ms_hipevents']['median'], j['roofline_attention']['forward']['avg_ms'], j['roofline_attention']['backward']['avg_ms'])"
 done
-unset EDGL_LIB_PATH
-python bench.py > gpurun_out/bench_default.log 2>&1
-tail -1 gpurun_out/bench_default.log | cut -c1-300
+done
