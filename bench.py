@@ -358,12 +358,26 @@ def main():
         dom_flops = dom_exec if flash else 2.0 * R_w * C * I
         dom_ms = ms_dom / max(1, n_dom)
         peak = 2500.0 if args.dtype == "bf16" else 157.3
-        traffic = None   # HBM bytes per launch of the dominant kernel, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        for tp in ("r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+        # HBM bytes per launch of the dominant kernel: NOT measured by this run — PMC counters need their own rocprofv3 passes
+        # (tools/refresh_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); the committed summary of
+        # the latest such pass is quoted and named in `traffic_source`
+        traffic, traffic_source = None, None
+        for tp in ("r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if args.dtype == "bf16" and args.workload == "step" and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/{tp} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2 per the gfx950 guide; not this run)"
                 break
+        # whole-step HBM bytes from the same passes, and the time they would take at the 6.3 TB/s a streaming kernel reaches
+        step_hbm = None
+        for tp in ("r04_step_hbm_bytes.json",):
+            tpath = os.path.join(ROOT, "profiles", tp)
+            if args.dtype == "bf16" and args.workload == "step" and os.path.exists(tpath):
+                sh = json.load(open(tpath))
+                floor_ms = sh["total_bytes"] / 6.3e12 * 1e3
+                step_hbm = {"bytes": sh["total_bytes"], "read_bytes_corrected": sh["read_bytes_corrected"], "write_bytes": sh["write_bytes"],
+                            "floor_ms_at_6.3TBps": round(floor_ms, 4), "step_over_hbm_floor": round(dt / args.steps * 1e3 / floor_ms, 2),
+                            "frac_of_hbm_floor": round(floor_ms / (dt / args.steps * 1e3), 4), "source": f"profiles/{tp} (not this run)"}
         ach = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         flops_done = 3 * flops_per_seq(c, rows_scored=R_w_mean / c["batch"]) * c["batch"]
         ms = res["step_ms"]
@@ -382,7 +396,9 @@ def main():
             att[key] = {"avg_ms": round(t_ms, 4), "algorithmic_gflop": round(fl / 1e9, 2),
                         "achieved": round(fl / (t_ms * 1e-3) / 1e12, 2) if t_ms > 0 else 0.0,
                         "frac": round(fl / (t_ms * 1e-3) / 1e12 / peak, 4) if t_ms > 0 else 0.0, "launches_timed": n_k}
-        pu = os.path.join(ROOT, "profiles", "r03_mfma_valu_util.json")
+        pu = os.path.join(ROOT, "profiles", "r04_mfma_valu_util.json")
+        if not os.path.exists(pu):
+            pu = os.path.join(ROOT, "profiles", "r03_mfma_valu_util.json")
         out = {
             "metric": "sequences/sec (fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K" if args.workload != "recipe" else
                       "sequences/sec (fwd+bwd+Adam) published recipe runme.sh:15-23: B=512 L=30 d=512 h=8 M=6 |I|=17.8K",
@@ -409,7 +425,8 @@ def main():
                          "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "hw_util": round(dom_exec / (dom_ms * 1e-3) / 1e12 / peak, 4) if dom_ms > 0 else 0.0,
                          "avg_launch_ms": round(dom_ms, 4), "algorithmic_flop": dom_flops, "executed_flop": dom_exec,
-                         "rows_scored": round(R_w, 1), "rows_total": R, "traffic": traffic, "launches_timed": n_dom},
+                         "rows_scored": round(R_w, 1), "rows_total": R, "traffic": traffic, "traffic_source": traffic_source,
+                         "launches_timed": n_dom},
             "roofline_attention": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                                    "kernels": "K3 BiMAU: bimau_fwd_kernel | bimau_bwd_sweep1 + intensity_bwd + bimau_bwd_sweep2 "
                                               "(QK^T, softmax, P.T_, intensity MLP, lambda.marks^T, (G.P).V and their backward)",
@@ -417,6 +434,12 @@ def main():
                                    "pipe_utilisation_pmc": json.load(open(pu)) if os.path.exists(pu) else None},
             # whole-step MFMA fraction on the work actually done (weight-0 rows are skipped exactly, so they are not counted)
             "whole_step_mfma_frac": round(flops_done / (dt / args.steps) / 1e12 / peak, 4),
+            "step_hbm_bytes": step_hbm,
+            # what the element-wise parity of this mode rests on: the benchmarked step runs dropout 0.1 / 0.1, whose masks no
+            # oracle can reproduce — tensors are compared with dropout off, the dropout itself statistically
+            "parity_note": "element-wise parity vs the oracle: dropout off (tests/test_gpu_headline_parity.py at this size); dropout on: "
+                           "unbiasedness over 1600 masks, finite-difference backward under a fixed mask, stored keep bits == hashed "
+                           "masks bit for bit (tests/test_gpu_coding.py, test_gpu_ops.py)",
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(c, budget_s=12.0)      # the GPU workload's own batch of 512
@@ -574,15 +597,19 @@ def extras(c, args, dev):
     out = {}
     a2 = copy.copy(args)
 
-    def row(cc, full_rows=False, multi_hot=False, ids="zipf", device_masker=False):
+    def row(cc, full_rows=False, multi_hot=False, ids="zipf", device_masker=False, dtype=None):
         cc = dict(cc, multi_hot=multi_hot)
-        r = run_step_workload(cc, a2, dev, 0, 1, None, 30, 10, bracket=False, full_rows=full_rows, ids=ids, device_masker=device_masker)
+        ar = a2
+        if dtype is not None:
+            ar = copy.copy(a2)
+            ar.dtype = dtype
+        r = run_step_workload(cc, ar, dev, 0, 1, None, 30, 10, bracket=False, full_rows=full_rows, ids=ids, device_masker=device_masker)
         rw = float(np.mean(r["rows_w"]))
         fl = 3 * flops_per_seq(cc, rows_scored=rw / cc["batch"]) * cc["batch"]
         ms = float(np.median(r["step_ms"]))
         return {"ms_per_step": round(r["dt"] / 30 * 1e3, 4), "ms_median": round(ms, 4),
                 "sequences_per_s": round(cc["batch"] * 30 / r["dt"], 1), "rows_scored": round(rw, 1), "rows_total": cc["batch"] * cc["masklen"],
-                "whole_step_mfma_frac": round(fl / (r["dt"] / 30) / 1e12 / (2500.0 if args.dtype == "bf16" else 157.3), 4)}
+                "whole_step_mfma_frac": round(fl / (r["dt"] / 30) / 1e12 / (2500.0 if ar.dtype == "bf16" else 157.3), 4)}
     out["masklen_6"] = row(dict(c, masklen=6))
     out["all_rows_weighted"] = row(c, full_rows=True)
     out["dropout_off"] = row(dict(c, hidden_dropout_rate=0.0, attention_probs_dropout_rate=0.0))
@@ -592,6 +619,11 @@ def extras(c, args, dev):
     out["uniform_ids"] = row(c, ids="uniform")
     # row a-1 inside the step: the masked positions of every batch are drawn on the device (edgl_mask_random) right before it
     out["with_device_masker"] = row(c, device_masker=True)
+    # the reference's own arithmetic: float32 activations and weights end to end (exact-f32 MFMA v_mfma_f32_16x16x4_f32: the parity
+    # mode of every kernel, 157 TFLOP/s peak) — the same engine, launch sequence and step; the headline runs bf16 as BASELINE.json asks
+    if args.dtype == "bf16":
+        out["f32_reference_arithmetic"] = dict(row(c, dtype="f32"), dtype="f32",
+                                               note="whole_step_mfma_frac against the 157.3 TFLOP/s dense f32 MFMA peak")
     # the published recipe's shape (runme.sh:15-23) through the same engine: `python bench.py --workload recipe` prints it as a line
     out["recipe_runme_sh"] = dict(row(dict(RECIPE)), workload="num_units 512, 8 heads, seqslen 30, masklen 6, batch 512, num_items 17771")
     torch.cuda.empty_cache()
@@ -668,8 +700,32 @@ def eval_rows(args, dev, world, rank, dist, steps, warmup, sizes):
             torch.cuda.synchronize()
             ag_ms = a.elapsed_time(b_) / 20
         assert idx.shape == (512, K) and int(idx.min()) >= 0
+        # roofline statement of the evaluation step's own kernel K6 (mask_topk_kernel: seen-mask, 4-pass radix select of the K-th
+        # value, tie pass — 5 sweeps over a row's logits; the [512, n] f32 logits tile of one chunk is written once by the scoring
+        # GEMM and stays L2 / MALL resident): algorithmic bytes = rows x n x 4 B x 5 passes over its launch time, against the
+        # 8 TB/s HBM peak (an upper bound of what the sweeps need from memory: re-reads are served by the caches)
+        from easydgl_amd import ops as _o
+        i0s, i1s = (0, model.num_items) if world == 1 else __import__("easydgl_amd").parallel.shard_bounds(model.num_items, world, rank)
+        nloc = min(i1s - i0s, max(1024, (_o.EVAL_TILE_BYTES // (4 * 512)) // 8 * 8))
+        lg = torch.randn((512, nloc), device=dev, dtype=torch.float32)
+        for _ in range(3):
+            _o.mask_topk(lg, i0s, feats["seqs_i"], K)
+        torch.cuda.synchronize()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(10):
+            _o.mask_topk(lg, i0s, feats["seqs_i"], K)
+        eb.record()
+        torch.cuda.synchronize()
+        k6_ms = ea.elapsed_time(eb) / 10
+        k6_bytes = 512 * nloc * 4 * 5
+        del lg
         rows.append({"num_items": num_items, "num_units": C, "T": cfgd["seqslen"] + 1, "batch": 512, "K": K, "shards": world,
                      "ms_per_eval_step": round(dt / steps * 1e3, 4), "sequences_per_s": round(512 * steps / dt, 1),
+                     "roofline_k6": {"bound": "hbm", "kernel": "mask_topk_kernel (seen mask + radix select + tie pass, one logits chunk)",
+                                     "logits_per_row": nloc, "passes": 5, "algorithmic_bytes": k6_bytes, "avg_launch_ms": round(k6_ms, 4),
+                                     "achieved": round(k6_bytes / (k6_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(k6_bytes / (k6_ms * 1e-3) / 8e12, 4)},
                      "allgather_bytes_per_rank": 512 * 2 * K * 4, "allgather_bytes_gathered": world * 512 * 2 * K * 4,
                      "allgather_ms": None if ag_ms is None else round(ag_ms, 4)})
         del model

@@ -98,3 +98,20 @@ def grad_ok(got, want, mode):
     if not np.any(np.asarray(want)):
         return bool(np.abs(np.asarray(got, dtype=np.float64)).max() < 1e-12), (l2, mx)
     return bool(l2 <= t2 and mx <= tm), (l2, mx)
+
+
+def dump_errors(tag, errs):
+    """EDGL_TEST_DUMP=<dir>: append the measured (rel-L2, rel-max) errors of a parity test to <dir>/tol_<tag>.json — how the
+    tolerances of the tests are set (tools/ run on the GPU box)."""
+    import json
+    import os
+    d = os.environ.get("EDGL_TEST_DUMP")
+    if not d:
+        return
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, f"tol_{tag}.json")
+    old = json.load(open(path)) if os.path.exists(path) else {}
+    for k, v in errs.items():
+        o = old.get(k, [0.0, 0.0])
+        old[k] = [max(o[0], float(v[0])), max(o[1], float(v[1]))]
+    json.dump(old, open(path, "w"), indent=1, sort_keys=True)

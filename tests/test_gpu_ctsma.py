@@ -86,7 +86,7 @@ def test_forward_loss_and_gradients(mode, ltol, gtol, case):
     assert_close(loss.item(), ref_loss.item(), ltol, "train loss")
     got = m.tf_gradients()
     assert set(got) == set(p64)
-    bad = {}
+    bad, errs = {}, {}
     for name, g in got.items():
         ref = p64[name].grad.numpy()
         if name.endswith("modulating_attention/dense_1/bias"):
@@ -106,8 +106,11 @@ def test_forward_loss_and_gradients(mode, ltol, gtol, case):
         # every other gradient is continuous in the activations.  f32 keeps the plain tolerance.
         if mode == "bf16" and "/Inner/" in name:
             e = relu_flip_err(g, ref, gtol)       # tests/_util.py: flipped hidden units are counted, the rest is held to gtol
+        errs[f"{mode}:{name}"] = (grad_errors(g, ref)[0] if np.any(ref) else 0.0, e)
         if e > gtol:
             bad[name] = e
+    from tests._util import dump_errors
+    dump_errors("ctsma", errs)
     assert not bad, f"gradient mismatch (rel to max |ref|): {bad}"
     # ---- evaluation: logits of the last position
     elog = m(feats, False)

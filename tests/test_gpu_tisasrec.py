@@ -81,7 +81,7 @@ def test_tisasrec_forward_loss_and_gradients(mode, ltol, gtol, case):
     assert_close(loss.item(), ref_loss.item(), ltol, "train loss")
     got = m.tf_gradients()
     assert set(got) == set(p64)
-    bad = {}
+    bad, errs = {}, {}
     for name, g in got.items():
         ref = p64[name].grad.numpy()
         if name.endswith("timeinterval/dense_1/bias"):   # a bias on K shifts a whole score row: its true gradient is zero
@@ -96,8 +96,11 @@ def test_tisasrec_forward_loss_and_gradients(mode, ltol, gtol, case):
                 bad[name + " (rel-L2)"] = grad_errors(g, ref)[0]
         if mode == "bf16" and "/Inner/" in name:   # ReLU mask flips, see tests/_util.py:relu_flip_err
             e = relu_flip_err(g, ref, gtol)
+        errs[f"{mode}:{name}"] = (grad_errors(g, ref)[0] if np.any(ref) else 0.0, e)
         if e > gtol:
             bad[name] = e
+    from tests._util import dump_errors
+    dump_errors("tisasrec", errs)
     assert not bad, f"gradient mismatch (rel to max |ref|): {bad}"
     elog = m(feats, False)
     want = BR.tisasrec_eval_logits(_p64(prob), prob["feats"], **prob["kw"])
