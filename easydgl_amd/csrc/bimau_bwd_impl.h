@@ -314,9 +314,15 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
 // Z) sweep 2
 // ------------------------------------------------------------------------------------------------------------------
 // NYP: number of dH partial slabs the intensity backward left in dh_ws (KY_NY mark groups at head dims <= 32, 1 above)
-template <typename T, int DT, int NT, int EC, int NYP = KY_NY, bool PREF = true, int FL = -1, bool DB = false>
+// US / SL: channel slices.  The per-(b, head) accumulators dK, dT_ are DT x NT register tiles each — at head dim 128 and more than
+// four key tiles (T > 64) they alone exceed the register file.  A launch with US = 2 keeps the tiles of channel slice SL only
+// (dQ, dK, dT_ of those dh / US channels); everything that contracts over the whole head (S, P, dP, the row term) is computed by
+// every slice.  One launch per slice (the slice index selects REGISTERS: it has to be a compile-time constant).
+template <typename T, int DT, int NT, int EC, int NYP = KY_NY, bool PREF = true, int FL = -1, bool DB = false, int US = 1, int SL = 0>
 __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
+    static_assert(DT % US == 0 && SL < US, "channel slices");
+    constexpr int DTS = DT / US, U0 = SL * DTS;   // this launch's channel tiles: U0 .. U0 + DTS - 1
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int E = EC ? EC : p.E;
     // the wave index through the scalar unit: (b, head) and every base pointer derived from them are then wave-uniform VALUES for
@@ -364,9 +370,9 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const long R = (long)p.B * p.H * p.T;
 
-    f32x4 dKa[DT][NT], dTa[DT][NT];  // L(first=u, second=k)
+    f32x4 dKa[DTS][NT], dTa[DTS][NT];  // L(first=u, second=k), channel tiles U0 ..
 #pragma unroll
-    for (int u = 0; u < DT; ++u)
+    for (int u = 0; u < DTS; ++u)
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) { dKa[u][kt] = zero4; dTa[u][kt] = zero4; }
 
@@ -403,20 +409,20 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     QOps qcur = load_q(0);
     touch_regs(qcur);   // complete before the loop (edgl_common.h)
     // dQ of a query tile is stored at the top of the next iteration (see kernel X: the back edge drains vmcnt)
-    Frag4<T> pend_dq[DT];
+    Frag4<T> pend_dq[DTS];
     int pend_q = p.T;
     auto flush_pending = [&]() {
         if (pend_q < p.T) {
 #pragma unroll
-            for (int ut = 0; ut < DT; ++ut) {
-                T* dst = dqkvt + (long)pend_q * ldq + head * dh + ut * 16 + g4;
+            for (int ut = 0; ut < DTS; ++ut) {
+                T* dst = dqkvt + (long)pend_q * ldq + head * dh + (U0 + ut) * 16 + g4;
                 if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<uint4*>(&pend_dq[ut]);
                 else *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<uint2*>(&pend_dq[ut]);
             }
         }
     };
 #pragma unroll
-    for (int ut = 0; ut < DT; ++ut) pend_dq[ut] = frag_zero<T>();
+    for (int ut = 0; ut < DTS; ++ut) pend_dq[ut] = frag_zero<T>();
     for (int qt = 0; qt < NT - EDGL_EXP_SKIP_TILES; ++qt) {
         asm volatile("" ::: "memory");
         const int q = qt * 16 + l15;
@@ -464,20 +470,23 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         for (int i = 0; i < 4; ++i) lf.v[i] = from_f32<T>((EC == 16 || (g4 + i) < E) ? qcur.lam[i] * dk.scale : 0.f);
         // rowsum(dP*P) = sum_k dP1*P (kernel X) + sum_k P[q][k] (dH[q].T_[k]) = ... + dH[q].H[q]   (H = P.T_, saved)
         float rowdot = 0.f;
-        Frag4<T> dhf[DT], QT[DT], dHT[DT];
+        Frag4<T> dhf[DT], QT[DTS], dHT[DTS];
 #pragma unroll
         for (int ut = 0; ut < DT; ++ut) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) rowdot = fmaf(dHq[ut][r], to_f32(qcur.hf[ut].v[r]), rowdot);
             dhf[ut] = frag_from_acc<T>(dHq[ut]);
-            QT[ut] = frag_from_acc<T>(mma16(qcur.qf[ut], ident, zero4));            // L(first=q, second=u)
-            dHT[ut] = frag_from_acc<T>(transpose_tile<T>(dHq[ut], ident));
+        }
+#pragma unroll
+        for (int ut = 0; ut < DTS; ++ut) {
+            QT[ut] = frag_from_acc<T>(mma16(qcur.qf[U0 + ut], ident, zero4));      // L(first=q, second=u)
+            dHT[ut] = frag_from_acc<T>(transpose_tile<T>(dHq[U0 + ut], ident));
         }
         rowdot = group_sum4(rowdot) + rowdot1;
         // ---- dP = dP1 + dH.T_^T ; dS = P*(dP - rowsum(dP*P)) * c ; dQ, dK, dT_ -------------------------------------
-        f32x4 dQ[DT];
+        f32x4 dQ[DTS];
 #pragma unroll
-        for (int ut = 0; ut < DT; ++ut) dQ[ut] = zero4;
+        for (int ut = 0; ut < DTS; ++ut) dQ[ut] = zero4;
         const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
@@ -523,18 +532,18 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             }
             const Frag4<T> dsf = frag_from_acc<T>(ds);
 #pragma unroll
-            for (int ut = 0; ut < DT; ++ut)
-                dQ[ut] = mma16(kfrag<T>(Ks, dh, KTs, LDT, kt * 16, ut * 16, lane), dsf, dQ[ut]);
+            for (int ut = 0; ut < DTS; ++ut)
+                dQ[ut] = mma16(kfrag<T>(Ks, dh, KTs, LDT, kt * 16, (U0 + ut) * 16, lane), dsf, dQ[ut]);
             const Frag4<T> dsT = frag_from_acc<T>(transpose_tile<T>(ds, ident));
             const Frag4<T> pT = frag_from_acc<T>(transpose_tile<T>(s[kt], ident));
 #pragma unroll
-            for (int ut = 0; ut < DT; ++ut) {
+            for (int ut = 0; ut < DTS; ++ut) {
                 dKa[ut][kt] = mma16(QT[ut], dsT, dKa[ut][kt]);
                 dTa[ut][kt] = mma16(dHT[ut], pT, dTa[ut][kt]);
             }
         }
 #pragma unroll
-        for (int ut = 0; ut < DT; ++ut) {
+        for (int ut = 0; ut < DTS; ++ut) {
             if constexpr (FL == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dQ[ut][r] *= cz;
@@ -553,8 +562,8 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         const int k = kt * 16 + l15;
         if (k < p.T) {
 #pragma unroll
-            for (int ut = 0; ut < DT; ++ut) {
-                T* row = dqkvt + (long)k * ldq + head * dh + ut * 16 + g4;
+            for (int ut = 0; ut < DTS; ++ut) {
+                T* row = dqkvt + (long)k * ldq + head * dh + (U0 + ut) * 16 + g4;
                 if constexpr (FL == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dKa[ut][kt][r] *= cz;

@@ -424,10 +424,21 @@ int bwd_big(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscaling
         const size_t smem = waves * wave_bytes;
         EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_bwd: sweep 2 needs %zu B of LDS (dh=%d T=%d)", smem, dh, p.T);
         p.waves = waves;
-        auto kern = bimau_bwd_sweep2_kernel<T, DT, NT, 0, 1, false>;
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         edgl_prof_begin(EDGL_KERNEL_BIMAU_BWD, st);
-        hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
+        if constexpr (DT * NT > 32) {
+            // head dim 128 beyond four key tiles (T > 64): the dK / dT_ accumulator tiles of all 128 channels do not fit the
+            // register file (378-521 spilled registers) — two launches, each keeping the tiles of one 64-channel slice
+            auto k0 = bimau_bwd_sweep2_kernel<T, DT, NT, 0, 1, false, -1, false, 2, 0>;
+            auto k1 = bimau_bwd_sweep2_kernel<T, DT, NT, 0, 1, false, -1, false, 2, 1>;
+            hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipLaunchKernelGGL(k0, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
+            hipLaunchKernelGGL(k1, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
+        } else {
+            auto kern = bimau_bwd_sweep2_kernel<T, DT, NT, 0, 1, false>;
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((jobs + waves - 1) / waves)), dim3(64 * waves), smem, st, p);
+        }
         edgl_prof_end(EDGL_KERNEL_BIMAU_BWD, st);
         edgl_prof_end(EDGL_KERNEL_BIMAU_BWD_ALL, st);
         EDGL_LAUNCH_CHECK();
@@ -443,43 +454,51 @@ int bwd_big(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscaling
     return edgl_reduce_rows(p.wpart + NPAR, RS, p.E, NPARX, dscaling, 0, st);
 }
 
-// head dim 64: T <= 112 (7 key tiles); head dim 128: T <= 64 (4 key tiles) — the per-(b, head) accumulators dK, dT_ of
-// sweep 2 are DT*NT register tiles each
+// Head dims 64 and 128: T <= 128 (8 key tiles) in bf16.  The per-(b, head) accumulators dK, dT_ of sweep 2 are DT * NT register
+// tiles each: up to 32 of them fit (head dim 64 at 8 key tiles: 458 registers, no spills), head dim 128 beyond 4 key tiles runs
+// sweep 2 as two channel slices (bwd_big).  f32 stages K / T_ / V in four-byte elements (+ transposed images): head dim 64 up to
+// T = 112 and head dim 128 up to T = 64 as before — the wave-private LDS check of the launchers bounds it.
+constexpr bool big_ok(size_t esize, int DT, int NT) { return esize == 2 ? NT <= 8 : (DT == 4 ? NT <= 7 : NT <= 4); }
+template <typename T, int DT, int NT>
+int fwd_big_or_error(const FwdP& p, hipStream_t st) {
+    if constexpr (big_ok(sizeof(T), DT, NT)) return fwd_big<T, DT, NT>(p, st);
+    edgl_set_error("edgl_bimau_fwd: head dim %d with T=%d in f32 not supported (f32: dh 64: T <= 112, dh 128: T <= 64; bf16: T <= 128)", 16 * DT, p.T);
+    return EDGL_ERR_SHAPE;
+}
 template <typename T>
 int fwd_dispatch(const FwdP& p, hipStream_t st) {
     const int dh = p.C / p.H, nt = (p.T + 15) / 16;
-    if (dh == 64) {
-        switch (nt) {
-            case 1: return fwd_big<T, 4, 1>(p, st); case 2: return fwd_big<T, 4, 2>(p, st); case 3: return fwd_big<T, 4, 3>(p, st);
-            case 4: return fwd_big<T, 4, 4>(p, st); case 5: return fwd_big<T, 4, 5>(p, st); case 6: return fwd_big<T, 4, 6>(p, st);
-            case 7: return fwd_big<T, 4, 7>(p, st);
-        }
-    } else if (dh == 128) {
-        switch (nt) {
-            case 1: return fwd_big<T, 8, 1>(p, st); case 2: return fwd_big<T, 8, 2>(p, st); case 3: return fwd_big<T, 8, 3>(p, st);
-            case 4: return fwd_big<T, 8, 4>(p, st);
-        }
+#define EDGL_BIG_CASES(DT_)                                                                                              \
+    switch (nt) {                                                                                                        \
+        case 1: return fwd_big_or_error<T, DT_, 1>(p, st); case 2: return fwd_big_or_error<T, DT_, 2>(p, st);            \
+        case 3: return fwd_big_or_error<T, DT_, 3>(p, st); case 4: return fwd_big_or_error<T, DT_, 4>(p, st);            \
+        case 5: return fwd_big_or_error<T, DT_, 5>(p, st); case 6: return fwd_big_or_error<T, DT_, 6>(p, st);            \
+        case 7: return fwd_big_or_error<T, DT_, 7>(p, st); case 8: return fwd_big_or_error<T, DT_, 8>(p, st);            \
     }
-    edgl_set_error("edgl_bimau_fwd: head dim %d with T=%d not supported (dh 64: T <= 112; dh 128: T <= 64)", dh, p.T);
+    if (dh == 64) { EDGL_BIG_CASES(4) } else if (dh == 128) { EDGL_BIG_CASES(8) }
+#undef EDGL_BIG_CASES
+    edgl_set_error("edgl_bimau_fwd: head dim %d with T=%d not supported (head dims 64 / 128: T <= 128)", dh, p.T);
+    return EDGL_ERR_SHAPE;
+}
+template <typename T, int DT, int NT>
+int bwd_big_or_error(const BwdP& p, char* ws, float* dW1, float* db1, float* dw, float* dsc, hipStream_t st) {
+    if constexpr (big_ok(sizeof(T), DT, NT)) return bwd_big<T, DT, NT>(p, ws, dW1, db1, dw, dsc, st);
+    edgl_set_error("edgl_bimau_bwd: head dim %d with T=%d in f32 not supported (f32: dh 64: T <= 112, dh 128: T <= 64; bf16: T <= 128)", 16 * DT, p.T);
     return EDGL_ERR_SHAPE;
 }
 template <typename T>
 int bwd_dispatch(const BwdP& p, char* ws, float* dW1, float* db1, float* dw, float* dsc, hipStream_t st) {
     const int dh = p.C / p.H, nt = (p.T + 15) / 16;
-    if (dh == 64) {
-        switch (nt) {
-            case 1: return bwd_big<T, 4, 1>(p, ws, dW1, db1, dw, dsc, st); case 2: return bwd_big<T, 4, 2>(p, ws, dW1, db1, dw, dsc, st);
-            case 3: return bwd_big<T, 4, 3>(p, ws, dW1, db1, dw, dsc, st); case 4: return bwd_big<T, 4, 4>(p, ws, dW1, db1, dw, dsc, st);
-            case 5: return bwd_big<T, 4, 5>(p, ws, dW1, db1, dw, dsc, st); case 6: return bwd_big<T, 4, 6>(p, ws, dW1, db1, dw, dsc, st);
-            case 7: return bwd_big<T, 4, 7>(p, ws, dW1, db1, dw, dsc, st);
-        }
-    } else if (dh == 128) {
-        switch (nt) {
-            case 1: return bwd_big<T, 8, 1>(p, ws, dW1, db1, dw, dsc, st); case 2: return bwd_big<T, 8, 2>(p, ws, dW1, db1, dw, dsc, st);
-            case 3: return bwd_big<T, 8, 3>(p, ws, dW1, db1, dw, dsc, st); case 4: return bwd_big<T, 8, 4>(p, ws, dW1, db1, dw, dsc, st);
-        }
+#define EDGL_BIG_CASES(DT_)                                                                                                            \
+    switch (nt) {                                                                                                                      \
+        case 1: return bwd_big_or_error<T, DT_, 1>(p, ws, dW1, db1, dw, dsc, st); case 2: return bwd_big_or_error<T, DT_, 2>(p, ws, dW1, db1, dw, dsc, st); \
+        case 3: return bwd_big_or_error<T, DT_, 3>(p, ws, dW1, db1, dw, dsc, st); case 4: return bwd_big_or_error<T, DT_, 4>(p, ws, dW1, db1, dw, dsc, st); \
+        case 5: return bwd_big_or_error<T, DT_, 5>(p, ws, dW1, db1, dw, dsc, st); case 6: return bwd_big_or_error<T, DT_, 6>(p, ws, dW1, db1, dw, dsc, st); \
+        case 7: return bwd_big_or_error<T, DT_, 7>(p, ws, dW1, db1, dw, dsc, st); case 8: return bwd_big_or_error<T, DT_, 8>(p, ws, dW1, db1, dw, dsc, st); \
     }
-    edgl_set_error("edgl_bimau_bwd: head dim %d with T=%d not supported (dh 64: T <= 112; dh 128: T <= 64)", dh, p.T);
+    if (dh == 64) { EDGL_BIG_CASES(4) } else if (dh == 128) { EDGL_BIG_CASES(8) }
+#undef EDGL_BIG_CASES
+    edgl_set_error("edgl_bimau_bwd: head dim %d with T=%d not supported (head dims 64 / 128: T <= 128)", dh, p.T);
     return EDGL_ERR_SHAPE;
 }
 

@@ -25,6 +25,7 @@ CASES = [
     dict(B=4, T=100, C=128, h=8, E=16, I=2000, nb=2),      # headline widths
     dict(B=4, T=30, C=512, h=4, E=16, I=700, nb=2),        # the published recipe runme.sh:107-115 (dh = 128, 2 blocks, seqslen 30)
     dict(B=3, T=14, C=64, h=2, E=24, I=90, nb=1),          # more than 16 mark types: two mark groups, MAU keeps the diagonal
+    dict(B=2, T=100, C=256, h=2, E=8, I=400, nb=1),        # CTSMA's head dim 128 at L = 100 (bf16: sweep 2 in two channel slices)
 ]
 
 
@@ -64,6 +65,8 @@ def _p64(prob):
 @pytest.mark.parametrize("mode,ltol,gtol", [("f32", 1e-4, 1e-3), ("bf16", 3e-2, 1e-1)])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_forward_loss_and_gradients(mode, ltol, gtol, case):
+    if mode == "f32" and CASES[case]["C"] // CASES[case]["h"] == 128 and CASES[case]["T"] > 64:
+        pytest.skip("head dim 128 beyond T = 64 is a bf16 shape (f32 staging of K / T_ / V exceeds the LDS)")
     prob = _problem(40 + case, **CASES[case])
     m = _model(prob, mode)
     feats = to_dev(prob["feats"])

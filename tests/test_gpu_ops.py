@@ -229,11 +229,16 @@ def _bimau_case(B, T, C, H, E, seed, cin_mult=3):
                                        # runme.sh:15-23 (C=512, h=8, T=31) and CTSMA's head dim (runme.sh:107-115: h=4) —
                                        # plus the longest sequences each head dim takes and odd mark counts
                                        (3, 31, 512, 8, 16), (2, 31, 512, 4, 16), (2, 101, 128, 2, 5), (1, 112, 64, 1, 16),
-                                       (2, 64, 128, 1, 3), (3, 17, 256, 2, 7)])
+                                       (2, 64, 128, 1, 3), (3, 17, 256, 2, 7),
+                                       # bf16 only: T up to 128 at head dims 64 and 128 (CTSMA's head dim at L = 100: sweep 2 runs
+                                       # as two channel slices beyond 4 key tiles)
+                                       (2, 128, 128, 2, 6), (2, 101, 256, 2, 16), (1, 128, 128, 1, 5)])
 def test_bimau_fwd_bwd(name, dt, tol, B, T, C, H, E):
     o = ops()
     if name == "f32" and T > 128 and C // H == 32:
         pytest.skip("f32 staging of 13 key tiles at head dim 32 needs 241 KB of LDS: T > 128 at dh = 32 is a bf16-only shape")
+    if name == "f32" and ((C // H == 64 and T > 112) or (C // H == 128 and T > 64)):
+        pytest.skip("f32 staging (four-byte elements + transposed images) bounds head dim 64 at T = 112 and head dim 128 at T = 64")
     cfg, x, ids, marks, spans, W = _bimau_case(B, T, C, H, E, seed=T + C)
     xt = torch.tensor(x, dtype=dt).cuda().requires_grad_()
     Wq = torch.tensor(W["Wq"], dtype=torch.float32).cuda().requires_grad_()
