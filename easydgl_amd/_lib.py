@@ -36,6 +36,8 @@ SIGNATURES = {
     "edgl_encode_bwd_workspace": (L, [I, I, I]),
     "edgl_encode_bwd": (I, [P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
     "edgl_encode_bwd_add": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
+    "edgl_encode_fwd_ct": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I64, F, F, P, U32, P, P, P, I, I, I, P]),
+    "edgl_encode_bwd_add_ct": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, I, P]),
     "edgl_embed_pos_fwd": (I, [P, P, P, P, P, I, I, I, I, F, F, P, U32, P, P, P, I, P]),
     "edgl_embed_pos_bwd": (I, [P, P, I, I, I, I, F, P, U32, P, P, I, P]),
     "edgl_gemm": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, I, P]),
@@ -51,13 +53,15 @@ SIGNATURES = {
     "edgl_bimau_fwd_zr": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, I, P]),
     "edgl_bimau_dropbits_bytes": (L, [I, I, I]),
     "edgl_bimau_dropbits": (I, [I, I, I, F, P, U32, P, P]),
-    "edgl_bimau_fwd_db": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, I, I, P]),
-    "edgl_bimau_bwd_db": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, P, I, I, P]),
+    "edgl_bimau_fwd_db": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, F, P, P, P, P, I, I, P]),
+    "edgl_bimau_bwd_db": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, F, P, P, P, P, P, P, I, I, P]),
     "edgl_bimau_bwd_workspace": (L, [I, I, I, I, I, I]),
     "edgl_bimau_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, I, I, P]),
     "edgl_add_layernorm_fwd": (I, [P, P, I, P, P, I, I, I, F, P, U32, P, I, P, P, I, P]),
     "edgl_add_layernorm_bwd": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, P, I, P]),
     "edgl_add_layernorm_bwd_act": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, P, P, I, P]),
+    "edgl_add_layernorm_fwd_ct": (I, [P, P, I, P, P, I, I, I, F, P, U32, P, I, P, P, I, I, I, P]),
+    "edgl_add_layernorm_bwd_act_ct": (I, [P, P, I, P, P, P, I, I, I, F, P, U32, P, I, P, P, P, P, P, P, P, I, I, I, P]),
     "edgl_score_chunks": (I, [I, I]),
     "edgl_compact_rows": (I, [P, P, I, I, P, P, P, P, P, I, P]),
     "edgl_compact_scan": (I, [P, I, P, P, P, P]),

@@ -56,6 +56,7 @@ struct BwdP {
     int waves;
     int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
     const uint32_t* dbits;   // optional: keep bits of the attention dropout (edgl_bimau_dropbits, bimau_common.h)
+    float qk_scale;          // score scale (0: 1 / sqrt(dh)); a zero-padded head of true width d < dh passes 1 / sqrt(d)
 };
 
 template <typename T>
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
 #pragma unroll
     for (int i = 0; i < 4; ++i) isc[i] = iscs_g[g4 + i];
 
-    const float cscale = rsqrtf((float)dh);
+    const float cscale = p.qk_scale > 0.f ? p.qk_scale : rsqrtf((float)dh);
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const Frag4<T> ident = identity_frag<T>(lane);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    const float cscale = rsqrtf((float)dh);
+    const float cscale = p.qk_scale > 0.f ? p.qk_scale : rsqrtf((float)dh);
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     // 1/sqrt(dh) of dS, or 0 when every key of the sequence is padded (uniform softmax: no score takes a gradient, temporal.py:425-426)
     float cz = cscale;

@@ -33,6 +33,7 @@ struct FwdP {
     int waves;
     int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
     const uint32_t* dbits;   // optional: keep bits of the attention dropout (edgl_bimau_dropbits, bimau_common.h)
+    float qk_scale;          // score scale (0: 1 / sqrt(dh), temporal.py:422); a zero-padded head of true width d < dh passes 1 / sqrt(d)
 };
 
 // wave-private LDS bytes of a phase (K always; T_ unless values phase; V and marks unless scores phase; the f32 key mask)
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
     if (p.B > 0) { if (km.pad == 0x1234567ull) reinterpret_cast<T*>(p.out)[0] = Ks[lane] + Ms[lane]; return; }
 #endif
 
-    const float cscale = rsqrtf((float)dh);
+    const float cscale = p.qk_scale > 0.f ? p.qk_scale : rsqrtf((float)dh);
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
 

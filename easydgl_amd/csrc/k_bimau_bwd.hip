@@ -506,22 +506,22 @@ extern "C" int edgl_bimau_mark_group(int C, int H, int dtype) {
 extern "C" int edgl_bimau_bwd_db(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks,
                                  const void* pack, const void* d_out, const float* d_lam_ext, const float* lam,
                                  const void* saved, int B, int T, int C, int H, int E, float drop_rate,
-                                 const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, void* d_qkvt, float* dW1,
-                                 float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream);
+                                 const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* d_qkvt,
+                                 float* dW1, float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream);
 extern "C" int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks,
                               const void* pack, const void* d_out, const float* d_lam_ext, const float* lam,
                               const void* saved, int B, int T, int C, int H, int E, float drop_rate,
                               const uint64_t* rng_state, uint32_t stream_id, void* d_qkvt, float* dW1, float* db1,
                               float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream) {
     return edgl_bimau_bwd_db(qkvt, ids, spans, marks, pack, d_out, d_lam_ext, lam, saved, B, T, C, H, E, drop_rate, rng_state, stream_id,
-                             nullptr, d_qkvt, dW1, db1, dw, dscaling, workspace, flags, dtype, stream);
+                             nullptr, 0.f, d_qkvt, dW1, db1, dw, dscaling, workspace, flags, dtype, stream);
 }
 // edgl_bimau_bwd with the stored keep bits the forward used (edgl_bimau_dropbits; NULL = hash — the same masks either way)
 extern "C" int edgl_bimau_bwd_db(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks,
                                  const void* pack, const void* d_out, const float* d_lam_ext, const float* lam,
                                  const void* saved, int B, int T, int C, int H, int E, float drop_rate,
-                                 const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, void* d_qkvt, float* dW1,
-                                 float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream) {
+                                 const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* d_qkvt,
+                                 float* dW1, float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream) {
     EDGL_REQUIRE(qkvt && ids && spans && marks && pack && d_out && lam && saved && d_qkvt && dW1 && db1 && dw && dscaling && workspace,
                  EDGL_ERR_NULL, "edgl_bimau_bwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
@@ -536,7 +536,7 @@ extern "C" int edgl_bimau_bwd_db(const void* qkvt, const int64_t* ids, const flo
     p.hin = (const char*)saved + sl.off_hin;
     p.z = reinterpret_cast<const float*>((const char*)saved + sl.off_z);
     p.B = B; p.T = T; p.C = C; p.H = H; p.E = E; p.rate = drop_rate; p.rng = rng_state;
-    p.stream_id = stream_id; p.d_qkvt = d_qkvt; p.flags = flags; p.dbits = dropbits;
+    p.stream_id = stream_id; p.d_qkvt = d_qkvt; p.flags = flags; p.dbits = dropbits; p.qk_scale = qk_scale;
     hipStream_t st = (hipStream_t)stream;
     const int dh = C / H;
     char* ws = (char*)workspace;

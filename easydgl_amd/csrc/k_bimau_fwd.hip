@@ -45,8 +45,8 @@ extern "C" int edgl_bimau_fwd_zr(const void* qkvt, const void* resid, int ld_res
                                  float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream);
 extern "C" int edgl_bimau_fwd_db(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
                                  const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
-                                 float drop_rate, const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, void* out,
-                                 float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream);
+                                 float drop_rate, const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale,
+                                 void* out, float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream);
 
 // Keep bits of the attention dropout of one (rng state, stream id): bimau_common.h.  0 bytes: this shape has no stored-bits form
 // (more than 8 key tiles) and the kernels hash.
@@ -85,15 +85,17 @@ extern "C" int edgl_bimau_fwd_zr(const void* qkvt, const void* resid, int ld_res
                                  const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
                                  float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* out,
                                  float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream) {
-    return edgl_bimau_fwd_db(qkvt, resid, ld_res, ids, spans, marks, pack, B, T, C, H, E, drop_rate, rng_state, stream_id, nullptr, out,
+    return edgl_bimau_fwd_db(qkvt, resid, ld_res, ids, spans, marks, pack, B, T, C, H, E, drop_rate, rng_state, stream_id, nullptr, 0.f, out,
                              lam_out, saved, zero_rows, flags, dtype, stream);
 }
 // edgl_bimau_fwd_zr with the stored keep bits of the attention dropout (edgl_bimau_dropbits on the SAME rng state, stream id, rate
 // and shape; NULL = hash): the kernels that have a stored-bits form read them, the others hash — the same masks either way.
+// qk_scale: the score scale (0 = 1 / sqrt(dh), temporal.py:422) — a model whose head dim d is not one the kernels tile (the
+// reference's default --num_units 50 --num_heads 1) runs with zero-padded channels at the next supported head dim and 1 / sqrt(d).
 extern "C" int edgl_bimau_fwd_db(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
                                  const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
-                                 float drop_rate, const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, void* out,
-                                 float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream) {
+                                 float drop_rate, const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale,
+                                 void* out, float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream) {
     EDGL_REQUIRE(qkvt && resid && ids && spans && marks && pack && out && lam_out, EDGL_ERR_NULL,
                  "edgl_bimau_fwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
@@ -102,7 +104,7 @@ extern "C" int edgl_bimau_fwd_db(const void* qkvt, const void* resid, int ld_res
     EDGL_REQUIRE(ld_res % 4 == 0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: ld_res must be a multiple of 4");
     EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: H*B*T*T must be < 2^32");
     FwdP p{qkvt, resid, ld_res, ids, spans, marks, (const char*)pack, B, T, C, H, E, drop_rate, rng_state, stream_id,
-           out, lam_out, nullptr, nullptr, nullptr, 4, flags, dropbits};
+           out, lam_out, nullptr, nullptr, nullptr, 4, flags, dropbits, qk_scale};
     hipStream_t st = (hipStream_t)stream;
     if (C / H == 64 || C / H == 128) {   // three-launch form: lambda is written by the intensity kernel — plain memset there
         if (zero_rows && hipMemsetAsync(zero_rows, 0, (size_t)H * B * T * E * sizeof(float), st) != hipSuccess) {

@@ -12,6 +12,9 @@ struct EncP {
     int B, T, C, E, I; int64_t mask_id; float time_scale;
     float rate; const uint64_t* rng; uint32_t stream_id;
     void* x0; float* spans; uint8_t* marks;
+    // zero-padded channels (a model width whose head dim the attention kernels do not tile: coding.py's sqrt(C) scale and time code
+    // are those of the TRUE width): channel c is real iff c % dhp < dht (dhp == 0: no padding); `sq` = sqrt(true width)
+    int dhp, dht; float sq;
 };
 
 template <typename T>
@@ -80,7 +83,11 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
         }
         v[0][2 * q] = sn; v[0][2 * q + 1] = cs;
     }
-    const float sq = sqrtf((float)p.C);  // coding.py:62-63
+    if (p.dhp) {   // padded channels carry no time code (their item / position / mark entries are zero in the tables)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[0][q] = ((c0 + q) % p.dhp) < p.dht ? v[0][q] : 0.f;
+    }
+    const float sq = p.sq;  // coding.py:62-63
     {   // coding.py:56-57 zero-padded row 0
         const float on = id != 0 ? sq : 0.f;
         if constexpr (sizeof(T) == 2) {
@@ -131,6 +138,7 @@ struct EncBwdP {
     float* d_item; float* part_pos; float* part_mk; int nchunk;
     int srows;
     const void* add1; const void* add2;   // optional [B*T, C] terms added to the item section of dX0 (residual branches)
+    float sq;             // sqrt(true model width): coding.py:62-63 (== sqrt(C) without channel padding)
     float* d_mark_zero;   // [E*C]: cleared by block (0, 0) of the position / mark stage (only row 1 is ever written afterwards)   // rows per block of the scatter stage (<= SROWS; fewer when SROWS*C floats exceed the LDS)
 };
 
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) void encode_scatter_kernel(EncBwdP p) {
     }
     __syncthreads();
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
-    const float sq = sqrtf((float)p.C);
+    const float sq = p.sq;
     if (worker) {
 #pragma unroll
         for (int k = 0; k < MAXR; ++k) {
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
         }
     }
     // acc[mt][ct][r] = sum for leader 32 w + 16 mt + 4G + r, channel 16 ct + l15
-    const float sqs = sqrtf((float)CF) * dk.scale;
+    const float sqs = p.sq * dk.scale;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -408,18 +416,36 @@ constexpr int ENC_NCHUNK = 16;
 
 extern "C" long edgl_encode_bwd_workspace(int B, int T, int C) { (void)B; return 2L * ENC_NCHUNK * T * C; }
 
+extern "C" int edgl_encode_fwd_ct(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
+                                  const float* mark_emb, const uint8_t* mark_table, const float* tscale, int B, int T,
+                                  int C, int E, int I, int64_t mask_id, float time_scale, float drop_rate,
+                                  const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans,
+                                  uint8_t* marks, int dh_pad, int dh_true, int dtype, void* stream);
 extern "C" int edgl_encode_fwd(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
                                const float* mark_emb, const uint8_t* mark_table, const float* tscale, int B, int T,
                                int C, int E, int I, int64_t mask_id, float time_scale, float drop_rate,
                                const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans,
                                uint8_t* marks, int dtype, void* stream) {
+    return edgl_encode_fwd_ct(ids, ts, item_tab, pos_tab, mark_emb, mark_table, tscale, B, T, C, E, I, mask_id, time_scale, drop_rate,
+                              rng_state, stream_id, x0, spans, marks, 0, 0, dtype, stream);
+}
+// edgl_encode_fwd for a channel-padded model: channel c of each C-wide section is real iff c % dh_pad < dh_true (0, 0: none);
+// sqrt(C) of coding.py:62-63 is the square root of the TRUE width C / dh_pad * dh_true, padded channels of the time code are 0.
+extern "C" int edgl_encode_fwd_ct(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
+                                  const float* mark_emb, const uint8_t* mark_table, const float* tscale, int B, int T,
+                                  int C, int E, int I, int64_t mask_id, float time_scale, float drop_rate,
+                                  const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans,
+                                  uint8_t* marks, int dh_pad, int dh_true, int dtype, void* stream) {
+    EDGL_REQUIRE((dh_pad == 0 && dh_true == 0) || (dh_pad > 0 && dh_true > 0 && dh_true <= dh_pad && C % dh_pad == 0), EDGL_ERR_SHAPE,
+                 "edgl_encode_fwd: padded-channel spec dh_pad=%d dh_true=%d does not fit C=%d", dh_pad, dh_true, C);
     EDGL_REQUIRE(ids && ts && item_tab && pos_tab && mark_emb && mark_table && tscale && x0 && spans && marks,
                  EDGL_ERR_NULL, "edgl_encode_fwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && (C % 8) == 0 && E >= 1 && I > 1, EDGL_ERR_SHAPE,
                  "edgl_encode_fwd: bad shape B=%d T=%d C=%d E=%d I=%d (C must be a multiple of 8)", B, T, C, E, I);
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_encode_fwd: dropout without rng_state");
     EncP p{ids, ts, item_tab, pos_tab, mark_emb, mark_table, tscale, B, T, C, E, I, mask_id, time_scale,
-           drop_rate, rng_state, stream_id, x0, spans, marks};
+           drop_rate, rng_state, stream_id, x0, spans, marks, dh_pad, dh_true,
+           sqrtf((float)(dh_pad ? C / dh_pad * dh_true : C))};
     const long total = (long)B * T * (C / 8);
     dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
@@ -433,6 +459,9 @@ extern "C" int edgl_encode_fwd(const int64_t* ids, const float* ts, const void* 
 extern "C" int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
                                    int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
                                    float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int dtype, void* stream);
+extern "C" int edgl_encode_bwd_add_ct(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
+                                      int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                                      float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int c_true, int dtype, void* stream);
 extern "C" int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const void* dx0, int B, int T, int C,
                                int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
                                float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int dtype,
@@ -443,6 +472,15 @@ extern "C" int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const v
 extern "C" int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
                                    int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
                                    float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int dtype, void* stream) {
+    return edgl_encode_bwd_add_ct(ids, marks, dx0, add1, add2, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, d_pos, d_mark_emb,
+                                  workspace, 0, dtype, stream);
+}
+// edgl_encode_bwd_add for a channel-padded model: c_true (0: = C) is the true model width whose square root scales the item
+// gradient (coding.py:62-63); padded channels of dX0 are exact zeros by construction and need no masking here.
+extern "C" int edgl_encode_bwd_add_ct(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
+                                      int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                                      float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int c_true, int dtype, void* stream) {
+    EDGL_REQUIRE(c_true >= 0 && c_true <= C, EDGL_ERR_SHAPE, "edgl_encode_bwd: true width %d exceeds C=%d", c_true, C);
     EDGL_REQUIRE((add1 == nullptr) == (add2 == nullptr), EDGL_ERR_NULL, "edgl_encode_bwd_add: add1 / add2 go together");
     EDGL_REQUIRE(ids && marks && dx0 && d_item && d_pos && d_mark_emb && workspace, EDGL_ERR_NULL,
                  "edgl_encode_bwd: null pointer");
@@ -453,7 +491,7 @@ extern "C" int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, con
     int srows = SROWS;
     while (srows > 8 && (size_t)srows * C * sizeof(float) > 150 * 1024) srows >>= 1;   // C = 512: 64 rows per block
     EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, part_pos, part_mk, ENC_NCHUNK, srows, add1, add2,
-              d_mark_emb};
+              sqrtf((float)(c_true > 0 ? c_true : C)), d_mark_emb};
     hipStream_t st = (hipStream_t)stream;
     const int rows_par = 256 / (C / 4);
     dim3 grid(T, ENC_NCHUNK);

@@ -22,7 +22,16 @@ struct LnP {
     const void* dy; void* dsum; void* dx_drop; float* part;
     const int32_t* dy_rowmap;   // gathered mode: compact row of (b, j), or -1 (row carries no gradient)
     const void* act_pre;        // backward: x = gelu(act_pre); the emitted gradients are multiplied by gelu'(act_pre)
+    // zero-padded channels (a head dim the attention kernels do not tile, run at the next supported one): channel c is real iff
+    // c % dhp < dht; the moments are those of the real channels (pads hold exact zeros and are left out of the centred second
+    // moment and of the divisor), the padded channels of the input gradient are zero.  dhp == 0: no padding.
+    int dhp, dht;
 };
+// 1 for a real channel, 0 for a padded one
+__device__ __forceinline__ float chan_on(const LnP& p, int c) { return (p.dhp == 0 || (c % p.dhp) < p.dht) ? 1.f : 0.f; }
+__device__ __forceinline__ float ln_count(const LnP& p) {
+    return (float)p.T * (float)(p.dhp == 0 ? p.C : (p.C / p.dhp) * p.dht);
+}
 
 template <typename T>
 __device__ __forceinline__ void load_sum(const LnP& p, const DropKey& dk, int b, int t, int c0, float s[ElemTraits<T>::VEC]) {
@@ -48,7 +57,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(LnP p) {
     const bool on = tid < active;
     const int cv = tid % cpv, tr = tid / cpv, c0 = cv * VEC;
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
-    const float n = (float)p.T * (float)p.C;
+    const float n = ln_count(p);
+    float cm[VEC];      // real / padded channel (all ones without padding)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) cm[j] = chan_on(p, c0 + j);
 
     // A thread owns rows tr, tr + rows_par, ...: when there are at most LN_NR of them (T <= LN_NR * rows_par, the usual
     // case) the dropped-out sums are read ONCE into registers and all three passes (mean, variance, output) run from
@@ -87,14 +99,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(LnP p) {
         for (int i = 0; i < LN_NR; ++i)
             if (on && tr + i * rows_par < p.T) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) { const float d = sc[i][j] - mean; acc += d * d; }
+                for (int j = 0; j < VEC; ++j) { const float d = sc[i][j] - mean; acc += cm[j] * (d * d); }
             }
     } else if (on) {
         for (int t = tr; t < p.T; t += rows_par) {
             float s[VEC];
             load_sum<T>(p, dk, b, t, c0, s);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { const float d = s[j] - mean; acc += d * d; }
+            for (int j = 0; j < VEC; ++j) { const float d = s[j] - mean; acc += cm[j] * (d * d); }
         }
     }
     const float var = block_sum(acc, red) / n;
@@ -180,8 +192,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
     const bool on = tid < active;
     const int cv = tid % cpv, tr = tid / cpv, c0 = cv * VEC;
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
-    const float n = (float)p.T * (float)p.C;
+    const float n = ln_count(p);
     const float mean = p.stats[2 * b], rstd = p.stats[2 * b + 1];
+    float cm[VEC];      // real / padded channel: gamma of a padded channel is 0, so the sums below see nothing of it; its dx := 0
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) cm[j] = chan_on(p, c0 + j);
 
     if (p.gpos) {
         for (int t = tid; t < p.T; t += LN_THREADS) rowmap[t] = -1;
@@ -262,7 +277,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(LnP p) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float xh = (s[j] - mean) * rstd;
-            float v = rstd * (d[j] * g[j] - m1 - xh * m2);
+            float v = cm[j] * (rstd * (d[j] * g[j] - m1 - xh * m2));
             if (p.act_pre) v *= dgelu_t<T>(to_f32(reinterpret_cast<const T*>(p.act_pre)[row * p.C + c0 + j]));
             o.v[j] = from_f32<T>(v);
             od.v[j] = from_f32<T>(drop_apply(dk, (uint64_t)(row * p.C + c0 + j), v));
@@ -297,18 +312,35 @@ int check_ln_shape(int B, int T, int C, int dtype, const char* who) {
 
 }  // namespace
 
+static int check_pad(int C, int dhp, int dht, const char* who) {
+    EDGL_REQUIRE((dhp == 0 && dht == 0) || (dhp > 0 && dht > 0 && dht <= dhp && C % dhp == 0), EDGL_ERR_SHAPE,
+                 "%s: padded-channel spec dh_pad=%d dh_true=%d does not fit C=%d", who, dhp, dht, C);
+    return EDGL_OK;
+}
+extern "C" int edgl_add_layernorm_fwd_ct(const void* x, const void* resid, int ld_res, const float* gamma,
+                                         const float* beta, int B, int T, int C, float drop_rate,
+                                         const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                                         int Mg, void* y, float* stats, int dh_pad, int dh_true, int dtype, void* stream);
 extern "C" int edgl_add_layernorm_fwd(const void* x, const void* resid, int ld_res, const float* gamma,
                                       const float* beta, int B, int T, int C, float drop_rate,
                                       const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
                                       int Mg, void* y, float* stats, int dtype, void* stream) {
+    return edgl_add_layernorm_fwd_ct(x, resid, ld_res, gamma, beta, B, T, C, drop_rate, rng_state, stream_id, gather_pos, Mg, y, stats,
+                                     0, 0, dtype, stream);
+}
+extern "C" int edgl_add_layernorm_fwd_ct(const void* x, const void* resid, int ld_res, const float* gamma,
+                                         const float* beta, int B, int T, int C, float drop_rate,
+                                         const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                                         int Mg, void* y, float* stats, int dh_pad, int dh_true, int dtype, void* stream) {
     EDGL_REQUIRE(x && gamma && beta && y && stats, EDGL_ERR_NULL, "edgl_add_layernorm_fwd: null pointer");
+    if (int rcp = check_pad(C, dh_pad, dh_true, "edgl_add_layernorm_fwd")) return rcp;
     int rc = check_ln_shape(B, T, C, dtype, "edgl_add_layernorm_fwd");
     if (rc) return rc;
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_add_layernorm_fwd: dropout without rng_state");
     LnP p{};
     p.x = x; p.resid = resid; p.ld_res = ld_res; p.gamma = gamma; p.beta = beta; p.B = B; p.T = T; p.C = C;
     p.rate = drop_rate; p.rng = rng_state; p.stream_id = stream_id; p.gpos = gather_pos; p.Mg = Mg; p.y = y;
-    p.stats = stats;
+    p.stats = stats; p.dhp = dh_pad; p.dht = dh_true;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == EDGL_F32) hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3(B), dim3(LN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((ln_fwd_kernel<bf16>), dim3(B), dim3(LN_THREADS), 0, st, p);
@@ -325,20 +357,36 @@ extern "C" int edgl_add_layernorm_bwd(const void* x, const void* resid, int ld_r
                                       dy_rowmap, nullptr, dsum, dx_drop, dgamma, dbeta, workspace, dtype, stream);
 }
 
+extern "C" int edgl_add_layernorm_bwd_act_ct(const void* x, const void* resid, int ld_res, const float* gamma,
+                                             const float* stats, const void* dy, int B, int T, int C, float drop_rate,
+                                             const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                                             int Mg, const int32_t* dy_rowmap, const void* act_pre, void* dsum, void* dx_drop,
+                                             float* dgamma, float* dbeta, float* workspace, int dh_pad, int dh_true, int dtype,
+                                             void* stream);
 extern "C" int edgl_add_layernorm_bwd_act(const void* x, const void* resid, int ld_res, const float* gamma,
                                           const float* stats, const void* dy, int B, int T, int C, float drop_rate,
                                           const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
                                           int Mg, const int32_t* dy_rowmap, const void* act_pre, void* dsum, void* dx_drop,
                                           float* dgamma, float* dbeta, float* workspace, int dtype, void* stream) {
+    return edgl_add_layernorm_bwd_act_ct(x, resid, ld_res, gamma, stats, dy, B, T, C, drop_rate, rng_state, stream_id, gather_pos, Mg,
+                                         dy_rowmap, act_pre, dsum, dx_drop, dgamma, dbeta, workspace, 0, 0, dtype, stream);
+}
+extern "C" int edgl_add_layernorm_bwd_act_ct(const void* x, const void* resid, int ld_res, const float* gamma,
+                                             const float* stats, const void* dy, int B, int T, int C, float drop_rate,
+                                             const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                                             int Mg, const int32_t* dy_rowmap, const void* act_pre, void* dsum, void* dx_drop,
+                                             float* dgamma, float* dbeta, float* workspace, int dh_pad, int dh_true, int dtype,
+                                             void* stream) {
     EDGL_REQUIRE(x && gamma && stats && dy && dgamma && dbeta && workspace, EDGL_ERR_NULL,
                  "edgl_add_layernorm_bwd: null pointer");
+    if (int rcp = check_pad(C, dh_pad, dh_true, "edgl_add_layernorm_bwd")) return rcp;
     int rc = check_ln_shape(B, T, C, dtype, "edgl_add_layernorm_bwd");
     if (rc) return rc;
     LnP p{};
     p.x = x; p.resid = resid; p.ld_res = ld_res; p.gamma = gamma; p.B = B; p.T = T; p.C = C;
     p.rate = drop_rate; p.rng = rng_state; p.stream_id = stream_id; p.gpos = gather_pos; p.Mg = Mg;
     p.stats = const_cast<float*>(stats); p.dy = dy; p.dsum = dsum; p.dx_drop = dx_drop; p.part = workspace;
-    p.dy_rowmap = dy_rowmap; p.act_pre = act_pre;
+    p.dy_rowmap = dy_rowmap; p.act_pre = act_pre; p.dhp = dh_pad; p.dht = dh_true;
     const int vec = dtype == EDGL_BF16 ? 8 : 4;
     const int rows_par = LN_THREADS / (C / vec);
     const size_t smem = (8 + (size_t)rows_par * 2 * C) * sizeof(float) + (size_t)(T + (gather_pos ? Mg : 0)) * sizeof(int);

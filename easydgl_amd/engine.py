@@ -41,6 +41,9 @@ class TrainEngine:
         self.code = ops._DT[self.dt]
         B, T, C, H, E, M, I = batch, m.seqslen, m.num_units, m.num_heads, m.num_events, m.masklen, m.num_items
         self.T, self.C, self.H, self.E, self.M, self.I = T, C, H, E, M, I
+        self.pad = tuple(getattr(m, "pad", (0, 0)))             # (dh_pad, dh_true) of a channel-padded model (model/easydgl.py)
+        self.c_true = int(m.width_true) if self.pad[0] else 0
+        self.qk_scale = float(getattr(m, "qk_scale", 0.0))      # 0: 1 / sqrt(head dim); a channel-padded model passes 1 / sqrt(true head dim)
         # More mark types than one attention launch takes (16; EasyDGL.py:45-46: E is the width of the data set's mark.pkl): the
         # marks run as groups, as in module/temporal.py modulated_attention — G = sum_e marks.lambda_e is a sum over marks, the
         # output (G * P) V is linear in G and lambda_e reads only its own dh columns of the intensity MLP.  One attention launch
@@ -96,7 +99,8 @@ class TrainEngine:
         # beyond what the BiMAU kernels take (T <= 208), checked here so that a future relaxation fails at construction)
         if m.ct_reg != 0.0 and (M > 256 or T > 1024):
             raise _lib.EdglError(f"TrainEngine: masklen {M} > 256 or T {T} > 1024 exceeds the fused TPP kernel (edgl_tpp_fwd_bwd_ex)")
-        ok = bool(lib.edgl_tail_supported(T, C, self.code)) and M <= 256 and os.environ.get("EDGL_FUSED_TAIL", "1") != "0"
+        ok = bool(lib.edgl_tail_supported(T, C, self.code)) and M <= 256 and os.environ.get("EDGL_FUSED_TAIL", "1") != "0" \
+            and not self.pad[0]      # (the fused tail's LayerNorms take their moments over all C channels)
         self.fused_tail = ok if fused_tail is None else (bool(fused_tail) and ok)
         self.tail_pack = [e(int(lib.edgl_tail_pack_elems(C))) for _ in range(nb)] if self.fused_tail else []
         if self.fused_tail:   # outputs of the fused backward: the gradients w.r.t. the four dense outputs (operands of the dW GEMMs)
@@ -179,18 +183,18 @@ class TrainEngine:
 
     def _ln_fwd(self, x, resid, ld_res, ln, drop, y, stats, gpos=None):
         B, T, C = self.B, self.T, self.C
-        check(lib.edgl_add_layernorm_fwd(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
-                                         _ptr(ln.beta), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
-                                         _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(y), _ptr(stats),
-                                         self.code, _stream()), "edgl_add_layernorm_fwd")
+        check(lib.edgl_add_layernorm_fwd_ct(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
+                                            _ptr(ln.beta), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
+                                            _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(y), _ptr(stats),
+                                            self.pad[0], self.pad[1], self.code, _stream()), "edgl_add_layernorm_fwd")
 
     def _ln_bwd(self, x, resid, ld_res, ln, stats, dy, drop, dsum, dx_drop, gpos=None, rowmap=None, act_pre=None):
         B, T, C = self.B, self.T, self.C
-        check(lib.edgl_add_layernorm_bwd_act(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
-                                             _ptr(stats), _ptr(dy), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
-                                             _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(rowmap), _ptr(act_pre),
-                                             _ptr(dsum), _ptr(dx_drop), _ptr(ln.gamma.grad), _ptr(ln.beta.grad),
-                                             _ptr(self._ws(B * 2 * C)), self.code, _stream()),
+        check(lib.edgl_add_layernorm_bwd_act_ct(_ptr(x), None if resid is None else resid.data_ptr(), ld_res, _ptr(ln.gamma),
+                                                _ptr(stats), _ptr(dy), B, T, C, float(drop.rate), drop.ptr(), drop.stream_id,
+                                                _ptr(gpos), 0 if gpos is None else gpos.shape[1], _ptr(rowmap), _ptr(act_pre),
+                                                _ptr(dsum), _ptr(dx_drop), _ptr(ln.gamma.grad), _ptr(ln.beta.grad),
+                                                _ptr(self._ws(B * 2 * C)), self.pad[0], self.pad[1], self.code, _stream()),
               "edgl_add_layernorm_bwd_act")
 
     # ---- one optimizer step, as a fixed launch sequence ----------------------------------------------------------------
@@ -278,10 +282,11 @@ class TrainEngine:
                 l2_term()
         # ================= forward (EasyDGL.py:70-151) =================
         d0 = drop(hd, 1)
-        check(lib.edgl_encode_fwd(_ptr(self.ids), _ptr(self.ts), _ptr(tab_c), _ptr(m.pcoding.pembs.lookup_table),
-                                  _ptr(m.mark_embs.lookup_table), _ptr(m.mark_lookup_table), _ptr(m.tcoding.scale), B, T, C,
-                                  E, I, int(m.mask), float(m.time_scale), float(d0.rate), d0.ptr(), d0.stream_id,
-                                  _ptr(self.x0), _ptr(self.spans), _ptr(self.marks), code, st), "edgl_encode_fwd")
+        check(lib.edgl_encode_fwd_ct(_ptr(self.ids), _ptr(self.ts), _ptr(tab_c), _ptr(m.pcoding.pembs.lookup_table),
+                                     _ptr(m.mark_embs.lookup_table), _ptr(m.mark_lookup_table), _ptr(m.tcoding.scale), B, T, C,
+                                     E, I, int(m.mask), float(m.time_scale), float(d0.rate), d0.ptr(), d0.stream_id,
+                                     _ptr(self.x0), _ptr(self.spans), _ptr(self.marks), self.pad[0], self.pad[1], code, st),
+              "edgl_encode_fwd")
         x, cin = self.x0, 3 * C
         for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
             att = blk.attention
@@ -296,7 +301,7 @@ class TrainEngine:
             else:
                 check(lib.edgl_bimau_fwd_db(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
                                             _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]),
-                                            _ptr(b["att"]), _ptr(b["lam"]), _ptr(b["saved"]),
+                                            self.qk_scale, _ptr(b["att"]), _ptr(b["lam"]), _ptr(b["saved"]),
                                             _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, 0, code, st), "edgl_bimau_fwd_db")
             if m.ct_reg != 0.0:   # TPP regulariser of this block: loss term and d lambda (two small launches)
                 check(lib.edgl_tpp_fwd_bwd_rows(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
@@ -461,7 +466,7 @@ class TrainEngine:
                 check(lib.edgl_bimau_bwd_db(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
                                             _ptr(self.G2), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, _ptr(b["lam"]),
                                             _ptr(b["saved"]), B, T, C, H, E,
-                                            float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), _ptr(self.G4c),
+                                            float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), self.qk_scale, _ptr(self.G4c),
                                             _ptr(att.st_kernel.grad), _ptr(att.st_bias.grad), _ptr(att.weight.grad),
                                             _ptr(att.scaling.grad),
                                             _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), 0, code, st),
@@ -492,10 +497,10 @@ class TrainEngine:
                 dY = d_in   # first block: the embedding backward adds the two branches itself (one pass less over dX0)
         d0 = drop(hd, 1)
         add1, add2 = (self.G1, self.G2) if self.blk else (None, None)
-        check(lib.edgl_encode_bwd_add(_ptr(self.ids), _ptr(self.marks), _ptr(dY), _ptr(add1), _ptr(add2), B, T, C, E, I,
-                                      float(d0.rate), d0.ptr(), d0.stream_id, _ptr(tab.grad), _ptr(m.pcoding.pembs.lookup_table.grad),
-                                      _ptr(m.mark_embs.lookup_table.grad), _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))),
-                                      code, st), "edgl_encode_bwd_add")
+        check(lib.edgl_encode_bwd_add_ct(_ptr(self.ids), _ptr(self.marks), _ptr(dY), _ptr(add1), _ptr(add2), B, T, C, E, I,
+                                         float(d0.rate), d0.ptr(), d0.stream_id, _ptr(tab.grad), _ptr(m.pcoding.pembs.lookup_table.grad),
+                                         _ptr(m.mark_embs.lookup_table.grad), _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))),
+                                         self.c_true, code, st), "edgl_encode_bwd_add")
 
     # ---- more than 16 mark types: the attention of a block as mark groups (see __init__) -----------------------------------
     def _attention_fwd_groups(self, b, x, cin, da, st):
@@ -506,7 +511,7 @@ class TrainEngine:
             first = g == 0
             check(lib.edgl_bimau_fwd_db(_ptr(b["qkvt"]), x.data_ptr() if first else self.zero_resid.data_ptr(), cin if first else C,
                                         _ptr(self.ids), _ptr(self.spans), _ptr(gb["marks"]), _ptr(gb["pack"]), B, T, C, H, e1 - e0,
-                                        float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), _ptr(b["att"] if first else gb["out"]),
+                                        float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), self.qk_scale, _ptr(b["att"] if first else gb["out"]),
                                         _ptr(gb["lam"]), _ptr(gb["saved"]), None, 0 if first else ops.MAU_DIAG_ZERO, code, st),
                   "edgl_bimau_fwd_db")
             if not first:
@@ -528,7 +533,7 @@ class TrainEngine:
                 gb["dlam"].copy_(b["dlam"][:, :, e0:e1])
             check(lib.edgl_bimau_bwd_db(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(gb["marks"]), _ptr(gb["pack"]),
                                      _ptr(self.G2), _ptr(gb["dlam"]) if m.ct_reg != 0.0 else None, _ptr(gb["lam"]), _ptr(gb["saved"]),
-                                     B, T, C, H, e1 - e0, float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]),
+                                     B, T, C, H, e1 - e0, float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), self.qk_scale,
                                      _ptr(self.G4c if first else gb["dqkvt"]), _ptr(gb["dW1"]), _ptr(att.st_bias.grad[e0 * dh:e1 * dh]),
                                      _ptr(att.weight.grad[e0:e1]), _ptr(att.scaling.grad[e0:e1]),
                                      _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, e1 - e0, code), torch.uint8)),
@@ -545,6 +550,7 @@ class TrainEngine:
 
     def _optimizer(self):
         m = self.m
+        m.mask_padded_grads()     # (channel-padded models: the one gradient that is not zero on a padded entry by itself)
         if os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") == "1":     # A/B switch: no look-ahead of the step counters
             seg = self.l2_seg if m.l2_reg != 0.0 else None
             check(lib.edgl_adam_apply(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,

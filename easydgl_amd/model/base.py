@@ -28,6 +28,7 @@ class Sequential(nn.Module):
         cd = getattr(FLAGS, "compute_dtype", "bf16")
         self.act_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32}[cd]
         self._arena: Optional[torch.Tensor] = None
+        self.pad = (0, 0)       # (dh_pad, dh_true) of a channel-padded model (EasyDGL at a head dim the kernels do not tile)
 
     # ---- flat parameter arena -------------------------------------------------------------------------
     def finalize(self, device) -> "Sequential":
@@ -148,6 +149,9 @@ class Sequential(nn.Module):
         step.graph = graph
         step.warmup_loss = warm_loss   # loss of the last eager warm-up step (a real optimizer step on the capture batch)
         return step
+
+    def mask_padded_grads(self) -> None:
+        """Channel-padded models zero the few gradients that are not zero on padded entries by themselves (EasyDGL)."""
 
     def settle_state(self) -> None:
         """The static engine leaves the step counters (dropout step, Adam step / learning rate) of the NEXT step in place behind

@@ -79,6 +79,24 @@ class EasyDGL(Sequential):
         self.ct_reg = float(getattr(FLAGS, "ct_reg", 0.0) or 0.0)
 
         gen = torch.Generator().manual_seed(self.seed)
+        # A head dim the attention kernels do not tile (they take 16 / 32 / 64 / 128; the reference's own defaults are
+        # --num_units 50 --num_heads 1, main.py:35-37): the model runs at the next supported head dim with ZERO-PADDED channels —
+        # every parameter is stored at the padded width, its padded rows / columns are zero and stay zero (their gradients are
+        # exactly zero: padded Q / K / V / T_ columns, W1 rows and dense rows are 0; the joint LayerNorm takes its moments over
+        # the real channels and returns no gradient into the padded ones; the one exception, the intensity MLP's output weights
+        # of the padded hidden units, is masked in mask_padded_grads), the score scale 1 / sqrt(dh) and coding.py's sqrt(C) are
+        # those of the TRUE width.  tf_values() / load_tf_variables() / tf_gradients() speak the reference's shapes.
+        self.width_true = self.num_units
+        dh_true = self.num_units // self.num_heads if self.num_heads > 0 and self.num_units % self.num_heads == 0 else 0
+        self.pad = (0, 0)
+        if dh_true and dh_true not in T.SUPPORTED_HEAD_DIMS:
+            dh_pad = next((d for d in T.SUPPORTED_HEAD_DIMS if d >= dh_true), None)
+            if dh_pad is None or dh_true % 2:
+                raise ValueError(f"EasyDGL: head dim num_units/num_heads = {dh_true}: even head dims up to {T.SUPPORTED_HEAD_DIMS[-1]} "
+                                 "run (zero-padded to the next of 16 / 32 / 64 / 128)")
+            self.pad = (dh_pad, dh_true)
+            self.num_units = self.num_heads * dh_pad
+        self.qk_scale = float(dh_true) ** -0.5 if self.pad[0] else 0.0
         C_ = self.num_units
         # variable scope "CSTMA" (EasyDGL.py:49-57)
         self.item_embs = C.Embedding(self.num_items, C_, self.l2_reg, zero_pad=True, scale=True, gen=gen)
@@ -93,6 +111,132 @@ class EasyDGL(Sequential):
         self.transform = _Dense(C_, C_, gen)       # cls/predictions/transform/dense
         self.transform_ln = _LayerNorm(C_)         # cls/predictions/transform/LayerNorm
         self._metrics = None
+        if self.pad[0]:
+            for blk in self.layers:
+                blk.attention.qk_scale = self.qk_scale
+            self._init_padded(gen)
+
+    # ---- channel padding (self.pad = (dh_pad, dh_true)) ---------------------------------------------------------------
+    def _pad_maps(self):
+        """Index maps true -> padded for every axis kind of the parameters."""
+        dhp, dht = self.pad
+        H, E, Ct, Cp = self.num_heads, self.num_events, self.width_true, self.num_units
+        c = torch.arange(Ct)
+        cmap = (c // dht) * dhp + (c % dht)
+        j = torch.arange(dht * E)
+        return dict(c=cmap, c3=torch.cat([cmap + k * Cp for k in range(3)]), c4=torch.cat([cmap + k * Cp for k in range(4)]),
+                    h2=torch.arange(2 * Ct), j=(j // dht) * dhp + (j % dht),
+                    st_rows=torch.cat([torch.arange(dht), torch.tensor([dhp])]), u=torch.arange(dht))
+
+    def _pad_specs(self):
+        """TF variable name -> (parameter, axis maps (None = axis kept), initialiser of the TRUE-shape variable)."""
+        mp = self._pad_maps()
+        sp = {
+            "CSTMA/item_embs/lookup_table": (self.item_embs.lookup_table, (None, mp["c"]), "glorot"),
+            "CSTMA/mark_embs/lookup_table": (self.mark_embs.lookup_table, (None, mp["c"]), "glorot"),
+            "CSTMA/spatial_embs/embedding/lookup_table": (self.pcoding.pembs.lookup_table, (None, mp["c"]), "glorot"),
+            "CSTMA/output_bias": (self.output_bias, (None,), "zeros"),
+            "cls/predictions/transform/dense/kernel": (self.transform.kernel, (mp["c"], mp["c"]), "glorot"),
+            "cls/predictions/transform/dense/bias": (self.transform.bias, (mp["c"],), "zeros"),
+            "cls/predictions/transform/LayerNorm/beta": (self.transform_ln.beta, (mp["c"],), "zeros"),
+            "cls/predictions/transform/LayerNorm/gamma": (self.transform_ln.gamma, (mp["c"],), "ones"),
+        }
+        for i, blk in enumerate(self.layers):
+            pre = f"layer_{i}/"
+            st = pre + "attention/self/TMAU/sequential_temporal_combined/"
+            a = blk.attention
+            sp[pre + "attention/self/TMAU/dense/kernel"] = (a.dense_kernel, (mp["c3"] if i == 0 else mp["c"], mp["c4"]), "normal")
+            sp[pre + "attention/self/TMAU/dense/bias"] = (a.dense_bias, (mp["c4"],), "zeros")
+            sp[st + "dense/kernel"] = (a.st_kernel, (mp["st_rows"], mp["j"]), "glorot")
+            sp[st + "dense/bias"] = (a.st_bias, (mp["j"],), "zeros")
+            sp[st + "weight"] = (a.weight, (None, mp["u"]), "glorot")
+            sp[st + "scaling"] = (a.scaling, (None,), "zeros")
+            sp[pre + "attention/output/dense/kernel"] = (blk.att_out.kernel, (mp["c"], mp["c"]), "glorot")
+            sp[pre + "attention/output/dense/bias"] = (blk.att_out.bias, (mp["c"],), "zeros")
+            sp[pre + "attention/output/LayerNorm/beta"] = (blk.att_ln.beta, (mp["c"],), "zeros")
+            sp[pre + "attention/output/LayerNorm/gamma"] = (blk.att_ln.gamma, (mp["c"],), "ones")
+            sp[pre + "intermediate/dense/kernel"] = (blk.inter.kernel, (mp["c"], mp["h2"]), "glorot")
+            sp[pre + "intermediate/dense/bias"] = (blk.inter.bias, (mp["h2"],), "zeros")
+            sp[pre + "output/dense/kernel"] = (blk.out.kernel, (mp["h2"], mp["c"]), "glorot")
+            sp[pre + "output/dense/bias"] = (blk.out.bias, (mp["c"],), "zeros")
+            sp[pre + "output/LayerNorm/beta"] = (blk.out_ln.beta, (mp["c"],), "zeros")
+            sp[pre + "output/LayerNorm/gamma"] = (blk.out_ln.gamma, (mp["c"],), "ones")
+        return sp
+
+    @staticmethod
+    def _true_shape(p, maps):
+        return tuple(p.shape[a] if m is None else len(m) for a, m in enumerate(maps))
+
+    @staticmethod
+    def _scatter(dst, maps, src):
+        """dst (padded, any device) <- zeros, with src (true shape) at the mapped indices."""
+        idx = [torch.arange(dst.shape[a]) if m is None else m for a, m in enumerate(maps)]
+        dst.zero_()
+        dst[torch.meshgrid(*[i.to(dst.device) for i in idx], indexing="ij")] = src.to(dst.device, dst.dtype)
+
+    @staticmethod
+    def _gather(src, maps):
+        idx = [torch.arange(src.shape[a]) if m is None else m for a, m in enumerate(maps)]
+        return src[torch.meshgrid(*[i.to(src.device) for i in idx], indexing="ij")]
+
+    @torch.no_grad()
+    def _init_padded(self, gen):
+        """The reference's initialisers on the TRUE shapes (glorot limits of the true fans; temporal.py:393 N(0, 0.02)), scattered
+        into the zero-padded storage; the time-code scales are those of the true width (coding.py:132-136)."""
+        for name, (p, maps, kind) in self._pad_specs().items():
+            shp = self._true_shape(p, maps)
+            if kind == "glorot":
+                v = glorot_uniform_(torch.empty(shp), gen)
+            elif kind == "normal":
+                v = torch.randn(shp, generator=gen) * 0.02
+            elif kind == "ones":
+                v = torch.ones(shp)
+            else:
+                v = torch.zeros(shp)
+            self._scatter(p.data, maps, v)
+        dhp, dht = self.pad
+        Ct, Cp = self.width_true, self.num_units
+        true_scale = np.power(10000, np.arange(0, Ct, 2) * 1.0 / Ct).astype(np.float32)      # pair j of the TRUE channels
+        sc = np.ones(Cp // 2, np.float32)
+        for c in range(0, Ct, 2):
+            cp = (c // dht) * dhp + (c % dht)
+            sc[cp // 2] = true_scale[c // 2]
+        self.tcoding.scale = torch.from_numpy(sc).to(self.tcoding.scale.device)
+
+    def mask_padded_grads(self) -> None:
+        """The one gradient that is not zero on a padded entry by itself: the intensity MLP's output weights w[e, u >= dh_true]
+        (their hidden units sit at sigmoid(0) = 1/2 and collect d z).  Zeroed before the optimizer sees them."""
+        if not self.pad[0]:
+            return
+        for blk in self.layers:
+            g = blk.attention.weight.grad
+            if g is not None:
+                g[:, self.pad[1]:].zero_()
+
+    @torch.no_grad()
+    def tf_values(self) -> Dict[str, torch.Tensor]:
+        """Reference variable name -> value in the REFERENCE's shape (a copy; channel-padded models strip the padding)."""
+        if not self.pad[0]:
+            return {k: p.detach().clone() for k, p in self.tf_variable_map().items()}
+        return {k: self._gather(p.detach(), maps).clone() for k, (p, maps, _) in self._pad_specs().items()}
+
+    @torch.no_grad()
+    def tf_gradients(self) -> Dict[str, torch.Tensor]:
+        """Reference variable name -> gradient in the reference's shape (a copy)."""
+        if not self.pad[0]:
+            return {k: p.grad.detach().clone() for k, p in self.tf_variable_map().items()}
+        return {k: self._gather(p.grad.detach(), maps).clone() for k, (p, maps, _) in self._pad_specs().items()}
+
+    @torch.no_grad()
+    def padded_leak(self) -> float:
+        """Largest |value| on a padded entry of any parameter (0.0 for a healthy model; tests)."""
+        worst = 0.0
+        for k, (p, maps, _) in self._pad_specs().items():
+            q = p.detach().clone()
+            idx = [torch.arange(q.shape[a]) if m is None else m for a, m in enumerate(maps)]
+            q[torch.meshgrid(*[i.to(q.device) for i in idx], indexing="ij")] = 0
+            worst = max(worst, float(q.abs().max()))
+        return worst
 
     def l2_param_names(self):
         return ["item_embs.lookup_table", "mark_embs.lookup_table", "pcoding.pembs.lookup_table"]
@@ -118,7 +262,7 @@ class EasyDGL(Sequential):
         tab = self.item_embs.lookup_table
         return ops.EncodeFn.apply(tab, self.pcoding.pembs.lookup_table, self.mark_embs.lookup_table, self.compute(tab),
                                   ids, ts, self.mark_lookup_table, self.tcoding.scale, self.mask, self.time_scale,
-                                  self._drop(self.hidden_dropout_rate, 1, is_training), self.act_dtype)
+                                  self._drop(self.hidden_dropout_rate, 1, is_training), self.act_dtype, self.pad)
 
     def encoder(self, features, is_training, gather_pos):
         """EasyDGL.py:70-146: returns (rows [B*Mg, C] at gather_pos, [lambda per block])."""
@@ -132,15 +276,15 @@ class EasyDGL(Sequential):
                                      drop=self._drop(self.attention_probs_dropout_rate, 10 + 4 * i, is_training))
             att = self._linear(att, blk.att_out)                                                   # :113
             att = ops.AddLayerNormFn.apply(att, layer_in[:, :, :C_], blk.att_ln.gamma, blk.att_ln.beta,
-                                           self._drop(self.hidden_dropout_rate, 11 + 4 * i, is_training), None)  # :114-116
+                                           self._drop(self.hidden_dropout_rate, 11 + 4 * i, is_training), None, self.pad)  # :114-116
             inter = self._linear(att, blk.inter, gelu=True)                                        # :120-121
             out = self._linear(inter, blk.out)                                                     # :125
             x = ops.AddLayerNormFn.apply(out, att, blk.out_ln.gamma, blk.out_ln.beta,
-                                         self._drop(self.hidden_dropout_rate, 12 + 4 * i, is_training), None)   # :126-128
+                                         self._drop(self.hidden_dropout_rate, 12 + 4 * i, is_training), None, self.pad)   # :126-128
             lams.append(lam)
         so = self._linear(x, self.transform, gelu=True)                                           # :138
         rows = ops.AddLayerNormFn.apply(so, None, self.transform_ln.gamma, self.transform_ln.beta, ops.NO_DROP,
-                                        gather_pos)                                                # :139,142-146
+                                        gather_pos, self.pad)                                      # :139,142-146
         return rows, lams
 
     def _gather_pos(self, features, is_training):
@@ -181,6 +325,7 @@ class EasyDGL(Sequential):
         loss = self.train_loss(features, labels)
         loss.backward()
         self.collect_grads()
+        self.mask_padded_grads()
         self.optimizer_step()
         return loss.detach()
 
@@ -267,6 +412,13 @@ class EasyDGL(Sequential):
 
     @torch.no_grad()
     def load_tf_variables(self, values: Dict[str, np.ndarray]) -> None:
-        for name, p in self.tf_variable_map().items():
-            p.copy_(torch.as_tensor(np.asarray(values[name]), dtype=torch.float32).to(p.device))
+        if self.pad[0]:
+            for name, (p, maps, _) in self._pad_specs().items():
+                v = torch.as_tensor(np.asarray(values[name]), dtype=torch.float32)
+                if tuple(v.shape) != self._true_shape(p, maps):
+                    raise ValueError(f"{name}: expected shape {self._true_shape(p, maps)}, got {tuple(v.shape)}")
+                self._scatter(p.data, maps, v)
+        else:
+            for name, p in self.tf_variable_map().items():
+                p.copy_(torch.as_tensor(np.asarray(values[name]), dtype=torch.float32).to(p.device))
         self.sync_shadow()

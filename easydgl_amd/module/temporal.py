@@ -46,7 +46,7 @@ def key_ids_from_masks(masks: torch.Tensor, batch: int, seqlen: int, num_heads: 
                      f"(item ids or 0/1), or the reference's key mask [h*B, T, T] / [B, T, T] / [B, 1, T]")
 
 
-def modulated_attention(qkvt, resid, st_kernel, st_bias, weight, scaling, masks, intervals, marks, num_heads, drop, flags=0):
+def modulated_attention(qkvt, resid, st_kernel, st_bias, weight, scaling, masks, intervals, marks, num_heads, drop, flags=0, qk_scale=0.0):
     """The fused attention of BiMAU / MAU for any number of mark types.  Up to 16 marks: one launch (ops.BiMAUFn).  More: the
     modulation G[q,k] = sum_e marks[k,e] lambda[q,e] (temporal.py:309-313) is a sum over marks and the output (G * P) V is linear
     in G, and lambda_e only reads its own dh columns of the intensity MLP (temporal.py:291: split(Z, dh)), so the marks run as
@@ -58,7 +58,7 @@ def modulated_attention(qkvt, resid, st_kernel, st_bias, weight, scaling, masks,
     if group <= 0:
         raise ValueError(f"BiMAU / MAU: head dim {dh} / {qkvt.dtype} unsupported")
     if E <= group:
-        return ops.BiMAUFn.apply(qkvt, resid, st_kernel, st_bias, weight, scaling, masks, intervals, marks, num_heads, drop, flags)
+        return ops.BiMAUFn.apply(qkvt, resid, st_kernel, st_bias, weight, scaling, masks, intervals, marks, num_heads, drop, flags, qk_scale)
     out, lams = None, []
     zero_resid = torch.zeros_like(resid)
     for e0 in range(0, E, group):
@@ -66,7 +66,7 @@ def modulated_attention(qkvt, resid, st_kernel, st_bias, weight, scaling, masks,
         gflags = flags if e0 == 0 else (flags | (0 if flags & ops.MAU_NO_DIAG else ops.MAU_DIAG_ZERO))
         o, lam = ops.BiMAUFn.apply(qkvt, resid if e0 == 0 else zero_resid, st_kernel[:, e0 * dh:e1 * dh].contiguous(),
                                    st_bias[e0 * dh:e1 * dh].contiguous(), weight[e0:e1].contiguous(), scaling[e0:e1].contiguous(),
-                                   masks, intervals, marks[:, :, e0:e1].contiguous(), num_heads, drop, gflags)
+                                   masks, intervals, marks[:, :, e0:e1].contiguous(), num_heads, drop, gflags, qk_scale)
         out = o if out is None else out + o
         lams.append(lam)
     return out, torch.cat(lams, dim=-1)
@@ -132,7 +132,7 @@ class BiMAU(nn.Module):
         qkvt = ops.LinearFn.apply(queries, self.dense_kernel, self.dense_bias, self.compute(self.dense_kernel), False)
         resid = queries[:, :, :C]
         return modulated_attention(qkvt, resid, self.st_kernel, self.st_bias, self.weight, self.scaling, masks, intervals,
-                                   marks, self.num_heads, drop if is_training else ops.NO_DROP)
+                                   marks, self.num_heads, drop if is_training else ops.NO_DROP, 0, float(getattr(self, "qk_scale", 0.0)))
 
 
 class MAU(nn.Module):

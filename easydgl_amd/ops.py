@@ -133,18 +133,20 @@ class EncodeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, item_master, pos_tab, mark_emb, item_c, ids, ts, mark_table, tscale, mask_id, time_scale,
-                drop: Drop, act_dtype):
+                drop: Drop, act_dtype, pad=(0, 0)):
+        """pad = (dh_pad, dh_true) of a channel-padded model (model/base.py), (0, 0) otherwise."""
         B, T = ids.shape
         I, C = item_c.shape
         E = mark_table.shape[1]
         x0 = torch.empty((B, T, 3 * C), device=ids.device, dtype=act_dtype)
         spans = torch.empty((B, T), device=ids.device, dtype=torch.float32)
         marks = torch.empty((B, T, E), device=ids.device, dtype=torch.uint8)
-        check(lib.edgl_encode_fwd(_ptr(ids), _ptr(ts), _ptr(item_c), _ptr(pos_tab), _ptr(mark_emb), _ptr(mark_table),
-                                  _ptr(tscale), B, T, C, E, I, int(mask_id), float(time_scale), float(drop.rate),
-                                  drop.ptr(), drop.stream_id, _ptr(x0), _ptr(spans), _ptr(marks), _DT[act_dtype],
-                                  _stream()), "edgl_encode_fwd")
+        check(lib.edgl_encode_fwd_ct(_ptr(ids), _ptr(ts), _ptr(item_c), _ptr(pos_tab), _ptr(mark_emb), _ptr(mark_table),
+                                     _ptr(tscale), B, T, C, E, I, int(mask_id), float(time_scale), float(drop.rate),
+                                     drop.ptr(), drop.stream_id, _ptr(x0), _ptr(spans), _ptr(marks), int(pad[0]), int(pad[1]),
+                                     _DT[act_dtype], _stream()), "edgl_encode_fwd")
         ctx.save_for_backward(ids, marks)
+        ctx.c_true = (C // pad[0] * pad[1]) if pad[0] else 0
         ctx.meta = (B, T, C, E, I, drop, item_master.shape, pos_tab.shape, mark_emb.shape)
         ctx.mark_non_differentiable(spans, marks)
         return x0, spans, marks
@@ -158,10 +160,10 @@ class EncodeFn(torch.autograd.Function):
         d_pos = torch.zeros(pshape, device=dx0.device, dtype=torch.float32)
         d_mark = torch.empty(mshape, device=dx0.device, dtype=torch.float32)
         ws = torch.empty(lib.edgl_encode_bwd_workspace(B, T, C), device=dx0.device, dtype=torch.float32)
-        check(lib.edgl_encode_bwd(_ptr(ids), _ptr(marks), _ptr(dx0), B, T, C, E, I, float(drop.rate), drop.ptr(),
-                                  drop.stream_id, _ptr(d_item), _ptr(d_pos), _ptr(d_mark), _ptr(ws), _code(dx0),
-                                  _stream()), "edgl_encode_bwd")
-        return (d_item, d_pos, d_mark) + (None,) * 9
+        check(lib.edgl_encode_bwd_add_ct(_ptr(ids), _ptr(marks), _ptr(dx0), None, None, B, T, C, E, I, float(drop.rate), drop.ptr(),
+                                         drop.stream_id, _ptr(d_item), _ptr(d_pos), _ptr(d_mark), _ptr(ws), int(ctx.c_true),
+                                         _code(dx0), _stream()), "edgl_encode_bwd")
+        return (d_item, d_pos, d_mark) + (None,) * 10
 
 
 class EmbedPosFn(torch.autograd.Function):
@@ -284,7 +286,8 @@ class BiMAUFn(torch.autograd.Function):
     """Fused attention of BiMAU.__call__ (temporal.py:413-447) given qkvt = dense(x)."""
 
     @staticmethod
-    def forward(ctx, qkvt, resid, W1, b1, w, scaling, ids, spans, marks, H, drop: Drop, flags: int = 0):
+    def forward(ctx, qkvt, resid, W1, b1, w, scaling, ids, spans, marks, H, drop: Drop, flags: int = 0, qk_scale: float = 0.0):
+        """qk_scale: the score scale (0 = 1 / sqrt(head dim)); a channel-padded model passes 1 / sqrt(true head dim)."""
         B, T, C4 = qkvt.shape
         C = C4 // 4
         E = w.shape[0]
@@ -305,11 +308,12 @@ class BiMAUFn(torch.autograd.Function):
         # head dims >= 64 run as scores phase -> intensity kernel -> values phase and hand H rows / z through `saved`
         need_saved = need_grad or (C // H) >= 64
         saved = torch.empty(lib.edgl_bimau_saved_bytes(B, T, C, H, code), device=qkvt.device, dtype=torch.uint8) if need_saved else None
-        check(lib.edgl_bimau_fwd(_ptr(qkvt), resid.data_ptr(), resid.stride(1), _ptr(ids), _ptr(spans), _ptr(marks),
-                                 _ptr(pack), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(out),
-                                 _ptr(lam), _ptr(saved), int(flags), code, _stream()), "edgl_bimau_fwd")
+        check(lib.edgl_bimau_fwd_db(_ptr(qkvt), resid.data_ptr(), resid.stride(1), _ptr(ids), _ptr(spans), _ptr(marks),
+                                    _ptr(pack), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, None, float(qk_scale),
+                                    _ptr(out), _ptr(lam), _ptr(saved), None, int(flags), code, _stream()), "edgl_bimau_fwd")
         if need_grad:
             ctx.save_for_backward(qkvt, ids, spans, marks, pack, lam, saved)
+        ctx.qk_scale = float(qk_scale)
         ctx.meta = (B, T, C, H, E, drop, code, W1.shape, b1.shape, w.shape, scaling.shape, int(flags))
         return out, lam
 
@@ -327,10 +331,11 @@ class BiMAUFn(torch.autograd.Function):
         dw, dsc = both[n1 + n2:n1 + n2 + n3].view(s3), both[n1 + n2 + n3:].view(s4)
         ws = torch.empty(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), device=dev, dtype=torch.uint8)
         dl = d_lam.contiguous() if d_lam is not None else None
-        check(lib.edgl_bimau_bwd(_ptr(qkvt), _ptr(ids), _ptr(spans), _ptr(marks), _ptr(pack), _ptr(d_out), _ptr(dl),
-                                 _ptr(lam), _ptr(saved), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(d_qkvt), _ptr(dW1),
-                                 _ptr(db1), _ptr(dw), _ptr(dsc), _ptr(ws), flags, code, _stream()), "edgl_bimau_bwd")
-        return d_qkvt, d_out, dW1, db1, dw, dsc, None, None, None, None, None, None
+        check(lib.edgl_bimau_bwd_db(_ptr(qkvt), _ptr(ids), _ptr(spans), _ptr(marks), _ptr(pack), _ptr(d_out), _ptr(dl),
+                                    _ptr(lam), _ptr(saved), B, T, C, H, E, float(drop.rate), drop.ptr(), drop.stream_id, None,
+                                    ctx.qk_scale, _ptr(d_qkvt), _ptr(dW1), _ptr(db1), _ptr(dw), _ptr(dsc), _ptr(ws), flags, code,
+                                    _stream()), "edgl_bimau_bwd")
+        return d_qkvt, d_out, dW1, db1, dw, dsc, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -341,7 +346,7 @@ class AddLayerNormFn(torch.autograd.Function):
     emitting only the rows gather_pos [B,Mg] (EasyDGL.py:142-146)."""
 
     @staticmethod
-    def forward(ctx, x, resid, gamma, beta, drop: Drop, gather_pos):
+    def forward(ctx, x, resid, gamma, beta, drop: Drop, gather_pos, pad=(0, 0)):
         B, T, C = x.shape
         code = _code(x)
         stats = torch.empty((B, 2), device=x.device, dtype=torch.float32)
@@ -352,10 +357,11 @@ class AddLayerNormFn(torch.autograd.Function):
             if resid.stride(-1) != 1 or resid.stride(0) != T * resid.stride(1):
                 raise _lib.EdglError("layernorm residual must be a row-strided view of a contiguous [B,T,*] tensor")
             rptr, ld = resid.data_ptr(), resid.stride(1)
-        check(lib.edgl_add_layernorm_fwd(_ptr(x), rptr, ld, _ptr(gamma), _ptr(beta), B, T, C, float(drop.rate),
-                                         drop.ptr(), drop.stream_id, _ptr(gather_pos), Mg, _ptr(y), _ptr(stats), code,
-                                         _stream()), "edgl_add_layernorm_fwd")
+        check(lib.edgl_add_layernorm_fwd_ct(_ptr(x), rptr, ld, _ptr(gamma), _ptr(beta), B, T, C, float(drop.rate),
+                                            drop.ptr(), drop.stream_id, _ptr(gather_pos), Mg, _ptr(y), _ptr(stats),
+                                            int(pad[0]), int(pad[1]), code, _stream()), "edgl_add_layernorm_fwd")
         ctx.save_for_backward(x, resid, gamma, stats, gather_pos)
+        ctx.pad = (int(pad[0]), int(pad[1]))
         ctx.meta = (B, T, C, drop, code, Mg)
         return y
 
@@ -370,12 +376,12 @@ class AddLayerNormFn(torch.autograd.Function):
         db, dg = both[:C], both[C:]
         ws = torch.empty(B * 2 * C, device=x.device, dtype=torch.float32)
         rptr, ld = (None, 0) if resid is None else (resid.data_ptr(), resid.stride(1))
-        check(lib.edgl_add_layernorm_bwd(_ptr(x), rptr, ld, _ptr(gamma), _ptr(stats), _ptr(dy), B, T, C,
-                                         float(drop.rate), drop.ptr(), drop.stream_id, _ptr(gather_pos), Mg, None,
-                                         _ptr(dsum), _ptr(dxd), _ptr(dg), _ptr(db), _ptr(ws), code, _stream()),
-              "edgl_add_layernorm_bwd")
+        check(lib.edgl_add_layernorm_bwd_act_ct(_ptr(x), rptr, ld, _ptr(gamma), _ptr(stats), _ptr(dy), B, T, C,
+                                                float(drop.rate), drop.ptr(), drop.stream_id, _ptr(gather_pos), Mg, None, None,
+                                                _ptr(dsum), _ptr(dxd), _ptr(dg), _ptr(db), _ptr(ws), ctx.pad[0], ctx.pad[1], code,
+                                                _stream()), "edgl_add_layernorm_bwd")
         dx = dxd if drop.active else dsum
-        return dx, (dsum if resid is not None else None), dg, db, None, None
+        return dx, (dsum if resid is not None else None), dg, db, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -105,6 +105,17 @@ int edgl_encode_bwd(const int64_t* ids, const uint8_t* marks, const void* dx0, i
 int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
                         int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
                         float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int dtype, void* stream);
+/* Channel-padded models (a model width whose head dim the attention kernels do not tile — the reference's default --num_units 50
+ * --num_heads 1, main.py:35-37 — runs at the next supported head dim with zero-padded channels; channel c of a C-wide section is
+ * real iff c % dh_pad < dh_true): edgl_encode_fwd / edgl_encode_bwd_add with coding.py:62-63's sqrt(C) taken of the TRUE width and
+ * the time code of the padded channels zeroed (dh_pad = dh_true = 0 / c_true = 0: no padding). */
+int edgl_encode_fwd_ct(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab, const float* mark_emb,
+                       const uint8_t* mark_table, const float* tscale, int B, int T, int C, int E, int I, int64_t mask_id,
+                       float time_scale, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans,
+                       uint8_t* marks, int dh_pad, int dh_true, int dtype, void* stream);
+int edgl_encode_bwd_add_ct(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
+                           int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                           float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int c_true, int dtype, void* stream);
 
 /* ---- K1b: CTSMA input encoding — CTSMA.py:48-58, coding.py:60-79 ----------------------------------
  * ids int64 [B,T] (tokens[:-1]), ts f32 [B,T+1] raw seconds.  x0 [B,T,2C] `dtype` =
@@ -188,14 +199,16 @@ int edgl_bimau_fwd_zr(const void* qkvt, const void* resid, int ld_res, const int
  * ONCE and stores the decisions in the kernels' register layout — edgl_bimau_dropbits_bytes(B, T, H) bytes (0: no stored-bits form
  * at this T, the kernels hash) —, edgl_bimau_fwd_db / edgl_bimau_bwd_db are edgl_bimau_fwd_zr / edgl_bimau_bwd reading them
  * (dropbits NULL = hash).  Identical masks either way: a kernel without a stored-bits form (head dims other than 16, E != 16, MAU
- * flags, f32) ignores the argument and hashes. */
+ * flags, f32) ignores the argument and hashes.  qk_scale: the score scale of temporal.py:422 (0 = 1 / sqrt(dh)); a model whose
+ * head dim d is none of {16, 32, 64, 128} — the reference's default --num_units 50 --num_heads 1 (main.py:35-37) — runs with
+ * zero-padded channels at the next supported head dim and qk_scale = 1 / sqrt(d) (exact: padded Q / K / V / T_ columns are 0). */
 long edgl_bimau_dropbits_bytes(int B, int T, int H);
 int edgl_bimau_dropbits(int B, int T, int H, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, uint32_t* bits,
                         void* stream);
 int edgl_bimau_fwd_db(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
                       const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E, float drop_rate,
-                      const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, void* out, float* lam_out,
-                      void* saved, float* zero_rows, int flags, int dtype, void* stream);
+                      const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* out,
+                      float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream);
 
 /* Backward.  d_out [B,T,C] `dtype`; d_lam_ext f32 [H*B,T,E] or NULL (gradient
  * from the TPP regulariser); lam / saved: the forward's lam_out and `saved` buffer.  Writes d_qkvt [B,T,4C] `dtype` and the f32 weight gradients dW1
@@ -211,8 +224,8 @@ int edgl_bimau_bwd(const void* qkvt, const int64_t* ids, const float* spans, con
 int edgl_bimau_bwd_db(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks,
                       const void* pack, const void* d_out, const float* d_lam_ext, const float* lam,
                       const void* saved, int B, int T, int C, int H, int E, float drop_rate,
-                      const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, void* d_qkvt, float* dW1,
-                      float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream);
+                      const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* d_qkvt,
+                      float* dW1, float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream);
 
 /* ---- K4-LN: y = layernorm_joint(dropout(x) + resid) — Base.py:12-67 (moments over (T,C) per
  * sample, eps 1e-12), EasyDGL.py:114-116,126-128,139.  resid may be NULL (ld_res ignored).
@@ -242,6 +255,17 @@ int edgl_add_layernorm_bwd_act(const void* x, const void* resid, int ld_res, con
                                const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
                                int Mg, const int32_t* dy_rowmap, const void* act_pre, void* dsum, void* dx_drop,
                                float* dgamma, float* dbeta, float* workspace, int dtype, void* stream);
+/* The joint LayerNorm of a channel-padded model (see edgl_encode_fwd_ct): moments over the REAL channels only (divisor T * true
+ * width; the padded channels hold exact zeros and stay out of the centred second moment), the input gradient of a padded channel
+ * is zero — so nothing ever flows into the padded rows / columns of the dense kernels (Base.py:12-67 on the true width). */
+int edgl_add_layernorm_fwd_ct(const void* x, const void* resid, int ld_res, const float* gamma, const float* beta, int B, int T,
+                              int C, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, const int64_t* gather_pos,
+                              int Mg, void* y, float* stats, int dh_pad, int dh_true, int dtype, void* stream);
+int edgl_add_layernorm_bwd_act_ct(const void* x, const void* resid, int ld_res, const float* gamma, const float* stats,
+                                  const void* dy, int B, int T, int C, float drop_rate, const uint64_t* rng_state,
+                                  uint32_t stream_id, const int64_t* gather_pos, int Mg, const int32_t* dy_rowmap,
+                                  const void* act_pre, void* dsum, void* dx_drop, float* dgamma, float* dbeta, float* workspace,
+                                  int dh_pad, int dh_true, int dtype, void* stream);
 
 /* ---- K5: tied-embedding scoring + cross-entropy — EasyDGL.py:149-155,177-185, Base.py:106-110 --
  * rows [R,C] `dtype`; table [I,C] `dtype` (row 0 acts as zeros, column 0 logit == -1000); out_bias

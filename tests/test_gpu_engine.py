@@ -73,6 +73,43 @@ def test_engine_at_rows_that_reach_the_large_m_kernels():
     assert not bad, (bad, GRAD_TOL["bf16"])
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_engine_at_the_reference_default_width(mode):
+    """main.py:35-37's defaults — num_units 50, 1 head, 3 blocks (head dim 50: run zero-padded at 64) — through the STATIC engine:
+    loss and every gradient (in the reference's shapes) against the fp64 oracle at width 50, and four optimizer steps (eager and
+    HIP graph, dropout on) that leave every padded entry of every parameter exactly zero."""
+    from easydgl_amd.engine import TrainEngine
+    prob = make_problem(seed=61, batch=6, num_units=50, num_heads=1, num_blocks=3, seqslen=30, masklen=6, num_events=5, num_items=200)
+    cfg = prob["cfg"]
+    m = build_model(prob, mode)
+    assert m.pad == (64, 50)
+    eng = TrainEngine(m, 6, use_graph=False)
+    assert not eng.fused_tail
+    eng.load_batch(to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda())
+    m._grad_arena.fill_(float("nan"))
+    eng._issue()
+    p64 = R.to_torch_params(prob["params"])
+    ref, _ = R.train_loss(cfg, p64, prob["mark_table"], prob["feats"], prob["labels"])
+    ref.backward()
+    assert abs(float(eng.loss) - float(ref)) <= LOSS_TOL[mode] * abs(float(ref))
+    bad = {}
+    for name, g in m.tf_gradients().items():
+        want = p64[name].grad.numpy().copy()
+        if name in ("CSTMA/item_embs/lookup_table", "CSTMA/mark_embs/lookup_table", "CSTMA/spatial_embs/embedding/lookup_table"):
+            want -= cfg.l2_reg * prob["params"][name]      # the engine folds the l2 gradient into the Adam kernel
+        ok, e = grad_ok(g.cpu().numpy(), want, mode)
+        if not ok:
+            bad[name] = e
+    assert not bad, (bad, GRAD_TOL[mode])
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    for use_graph in (False, True):
+        md = build_model(prob, mode, hidden_drop=0.1, att_drop=0.1)
+        e2 = TrainEngine(md, 6, use_graph=use_graph)
+        losses = [float(e2.step(feats, labels)) for _ in range(4)]
+        assert all(np.isfinite(losses)), losses
+        assert md.padded_leak() == 0.0, use_graph
+
+
 def test_engine_with_mark_groups_steps_eager_and_graph():
     """E = 24 with dropout on: the eager launch sequence and its HIP-graph capture follow the same trajectory (the group copies,
     the concatenation of lambda and the zero fill of d lambda are part of the captured sequence)."""

@@ -60,6 +60,72 @@ def test_forward_loss_and_gradients(mode, ltol, case):
     assert_close(elog.detach().cpu().numpy(), want_e, ltol, "eval logits")
 
 
+# head dims the kernels do not tile run zero-padded at the next supported one: the reference's DEFAULT flags (main.py:35-37:
+# --num_units 50 --num_heads 1 --num_blocks 3, seqslen 30, masklen 6), and a two-head case whose real channels interleave with pads
+PADDED = [dict(num_units=50, num_heads=1, num_blocks=3, seqslen=30, masklen=6, num_events=5, num_items=200),
+          dict(num_units=40, num_heads=2, num_blocks=1, seqslen=17, masklen=4, num_events=18, num_items=120)]
+
+
+@pytest.mark.parametrize("mode,ltol", [("f32", 1e-4), ("bf16", 2e-2)])
+@pytest.mark.parametrize("case", range(len(PADDED)))
+def test_widths_the_kernels_do_not_tile_run_channel_padded(mode, ltol, case):
+    """EasyDGL at the reference's default width against the fp64 oracle AT THAT WIDTH: logits, lambda, loss, every gradient (in the
+    reference's shapes: tf_gradients strips the padding), eval logits; then optimizer steps with dropout on leave every padded
+    entry of every parameter exactly zero, and three dropout-free steps follow the oracle's Adam trajectory."""
+    c = PADDED[case]
+    prob = make_problem(seed=70 + case, batch=5, **c)
+    cfg = prob["cfg"]
+    m = build_model(prob, mode)
+    dh = c["num_units"] // c["num_heads"]
+    assert m.pad == (32 if dh <= 32 else 64, dh) and m.num_units == c["num_heads"] * m.pad[0] and m.width_true == c["num_units"]
+    got_vals = m.tf_values()
+    for k, v in prob["params"].items():            # load -> read back: the reference's shapes and values
+        assert tuple(got_vals[k].shape) == np.asarray(v).shape
+        assert np.array_equal(got_vals[k].cpu().numpy(), np.asarray(v, dtype=np.float32))
+    assert m.padded_leak() == 0.0
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    logits = m(feats, True)
+    want_logits, want_lams = O.forward(cfg, prob["params"], prob["mark_table"], prob["feats"], True)
+    assert logits.shape == want_logits.shape
+    assert_close(logits.detach().cpu().numpy(), want_logits, ltol, "train logits")
+    for a, b in zip(m._last_lams, want_lams):
+        assert_close(a.detach().cpu().numpy(), b, ltol, "lambda")
+    m.zero_grad_arena()
+    loss = m.train_loss(feats, labels)
+    loss.backward()
+    p64 = R.to_torch_params(prob["params"])
+    ref_loss, _ = R.train_loss(cfg, p64, prob["mark_table"], prob["feats"], prob["labels"])
+    ref_loss.backward()
+    assert_close(loss.item(), ref_loss.item(), LOSS_TOL[mode], "train loss")
+    bad = {}
+    for name, g in m.tf_gradients().items():
+        ok, e = grad_ok(g.cpu().numpy(), p64[name].grad.numpy(), mode)
+        if not ok:
+            bad[name] = e
+    assert not bad, f"gradient mismatch vs {GRAD_TOL[mode]}: {bad}"
+    elog = m(to_dev(prob["efeats"]), False)
+    want_e, _ = O.forward(cfg, prob["params"], prob["mark_table"], prob["efeats"], False)
+    assert_close(elog.detach().cpu().numpy(), want_e, ltol, "eval logits")
+    # ---- padded entries never leave zero (dropout on: hidden and attention)
+    md = build_model(prob, mode, hidden_drop=0.1, att_drop=0.1)
+    for _ in range(4):
+        assert np.isfinite(float(md.train_step(feats, labels)))
+    assert md.padded_leak() == 0.0
+    if mode == "f32":
+        mt = build_model(prob, "f32")
+        q64 = R.to_torch_params(prob["params"])
+        opt = R.TFAdam(q64, cfg.learning_rate)
+        for step in range(3):
+            got = float(mt.train_step(feats, labels))
+            ref, _ = R.train_loss(cfg, q64, prob["mark_table"], prob["feats"], prob["labels"])
+            ref.backward()
+            opt.step()
+            assert abs(got - float(ref)) <= 2e-4 * abs(float(ref)), (step, got, float(ref))
+        for name, v in mt.tf_values().items():
+            assert np.abs(v.cpu().numpy() - q64[name].detach().numpy()).max() < 3e-4, name
+        assert mt.padded_leak() == 0.0
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_eval_metrics_and_topk(mode):
     prob = make_problem(seed=3, batch=16, num_items=600, seqslen=20, num_units=32, num_heads=2, num_blocks=1)

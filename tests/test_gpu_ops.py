@@ -717,14 +717,14 @@ def test_stored_dropout_keep_bits_equal_the_hashed_masks(T):
         saved = torch.empty(lib.edgl_bimau_saved_bytes(B, T, C, H, code), device="cuda", dtype=torch.uint8)
         _lib.check(lib.edgl_bimau_fwd_db(qkvt.data_ptr(), resid.data_ptr(), C, ids.data_ptr(), spans.data_ptr(), marks.data_ptr(),
                                          pack.data_ptr(), B, T, C, H, E, rate, state.data_ptr(), sid, None if db is None else db.data_ptr(),
-                                         out.data_ptr(), lam.data_ptr(), saved.data_ptr(), None, 0, code, None), "edgl_bimau_fwd_db")
+                                         0.0, out.data_ptr(), lam.data_ptr(), saved.data_ptr(), None, 0, code, None), "edgl_bimau_fwd_db")
         dq = torch.empty_like(qkvt)
         n1, n2, n3 = (dh + 1) * dh * E, dh * E, E * dh
         g = torch.empty(n1 + n2 + n3 + E, device="cuda")
         ws = torch.empty(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), device="cuda", dtype=torch.uint8)
         _lib.check(lib.edgl_bimau_bwd_db(qkvt.data_ptr(), ids.data_ptr(), spans.data_ptr(), marks.data_ptr(), pack.data_ptr(),
                                          d_out.data_ptr(), d_lam.data_ptr(), lam.data_ptr(), saved.data_ptr(), B, T, C, H, E, rate,
-                                         state.data_ptr(), sid, None if db is None else db.data_ptr(), dq.data_ptr(), g.data_ptr(),
+                                         state.data_ptr(), sid, None if db is None else db.data_ptr(), 0.0, dq.data_ptr(), g.data_ptr(),
                                          g[n1:].data_ptr(), g[n1 + n2:].data_ptr(), g[n1 + n2 + n3:].data_ptr(), ws.data_ptr(), 0, code, None),
                    "edgl_bimau_bwd_db")
         torch.cuda.synchronize()
