@@ -34,9 +34,9 @@ def args(argv=None):
     p.add_argument("--test", required=True)
     p.add_argument("--model", required=True, help="algorithm name: EasyDGL, CTSMA, TGAT or TiSASREC (util.ranking keys)")
     p.add_argument("--num_items", type=int, required=True)
-    # reference default: 50 (main.py:30); the MFMA kernels need num_units / num_heads to be a multiple of 16, so the default
-    # here is the nearest supported width (every published recipe passes --num_units=512 explicitly, runme.sh:15-115)
-    p.add_argument("--num_units", type=int, default=64)
+    # reference default: 50 (main.py:35) — head dim 50 with the default single head: EasyDGL runs it zero-padded at head dim 64
+    # (model/easydgl.py: exact, the padded channels stay zero); every published recipe passes --num_units=512 (runme.sh:15-115)
+    p.add_argument("--num_units", type=int, default=50)
     p.add_argument("--num_heads", type=int, default=1)
     p.add_argument("--num_blocks", type=int, default=3)
     p.add_argument("--seqslen", type=int, default=30)

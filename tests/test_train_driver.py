@@ -130,3 +130,28 @@ def test_published_recipe_flags_run_verbatim(tmp_path, name):
     assert set(res) == {"H10", "H50", "H100", "N10", "N50", "N100"}
     assert all(0.0 <= v <= 1.0 and math.isfinite(v) for v in res.values())
     assert res["H10"] <= res["H50"] <= res["H100"]
+
+
+@pytest.mark.gpu
+def test_reference_default_flags_train_end_to_end(tmp_path):
+    """main.py:35-44 with NO model flag given: --num_units 50 --num_heads 1 --num_blocks 3 --seqslen 30 --masklen 6 — head dim 50,
+    which the attention kernels run zero-padded at 64 (model/easydgl.py).  The driver trains and evaluates, the checkpoint round
+    trip restores the padded storage."""
+    sp = pytest.importorskip("scipy.sparse")
+    import torch
+    from easydgl_amd import data as D
+    from easydgl_amd import train as TR
+    num_items, seqslen, E = 500, 30, 12
+    ids, ts = D.synthetic_batch(num_items, seqslen, 700, seed=8)
+
+    def dump(fname, lo, hi):
+        F.write_tfrecord(str(tmp_path / fname), [F.encode_example({"seqs_i": ids[i], "seqs_t": ts[i]}) for i in range(lo, hi)])
+    dump("train000.tfrec", 0, 500); dump("validation.tfrec", 500, 600); dump("test.tfrec", 600, 700)
+    with open(tmp_path / "mark.pkl", "wb") as f:
+        pickle.dump(sp.csr_matrix(D.synthetic_mark_table(num_items, E).astype(np.int64)), f)
+    res = TR.main(["--model", "EasyDGL", "--train", str(tmp_path / "train???.tfrec"), "--valid", str(tmp_path / "validation.tfrec"),
+                   "--test", str(tmp_path / "test.tfrec"), "--num_items", str(num_items), "--mark", str(tmp_path / "mark.pkl"),
+                   "--ct_reg", "1e-7", "--l2_reg", "1e-4", "--batch_size", "128", "--num_epochs", "2", "--mask_seen",
+                   "--ckpt_dir", str(tmp_path / "ckpt")])
+    assert set(res) == {"H10", "H50", "H100", "N10", "N50", "N100"}
+    assert all(0.0 <= v <= 1.0 and math.isfinite(v) for v in res.values())
