@@ -144,3 +144,32 @@ def test_bench_two_ranks_over_gloo_smoke():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["steps"] == 5 and j["config"]["global_batch"] == 1024 and j["value"] > 0 and j["scaling"] == "weak"
+
+
+def test_bench_eight_ranks_over_gloo_smoke():
+    """The launch the driver uses for the scaling curve (`bench.py --gpus 8`: eight ranks, one JSON line, whole-job value) on whatever
+    box this is — EDGL_BENCH_BACKEND=gloo puts all eight ranks on device 0.  A functional check that SCALE works the first time an
+    8-GPU node exists, not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDGL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", EDGL_BENCH_SPIN_MS="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--no-extras",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 8 * 512 and j["config"]["parallelism"] == "dp8" and j["scaling"] == "weak"
+    assert j["value"] > 0 and abs(j["value"] - 8 * 512 / (j["ms_per_step"] * 1e-3)) < 1e-2 * j["value"]
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    """Failure path of the bench contract: a launcher that started WORLD_SIZE ranks for another --gpus value is an error, not a run
+    whose n_gpus lies."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
