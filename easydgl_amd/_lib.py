@@ -38,6 +38,8 @@ SIGNATURES = {
     "edgl_encode_bwd_add": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
     "edgl_encode_fwd_ct": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I64, F, F, P, U32, P, P, P, I, I, I, P]),
     "edgl_encode_bwd_add_ct": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, I, P]),
+    "edgl_encode_bwd_label_fused": (I, [I, I]),
+    "edgl_encode_bwd_add_label": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P, P, P, P, I, P, I, P]),
     "edgl_embed_pos_fwd": (I, [P, P, P, P, P, I, I, I, I, F, F, P, U32, P, P, P, I, P]),
     "edgl_embed_pos_bwd": (I, [P, P, I, I, I, I, F, P, U32, P, P, I, P]),
     "edgl_gemm": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, I, P]),

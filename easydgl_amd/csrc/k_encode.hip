@@ -139,6 +139,12 @@ struct EncBwdP {
     int srows;
     const void* add1; const void* add2;   // optional [B*T, C] terms added to the item section of dX0 (residual branches)
     float sq;             // sqrt(true model width): coding.py:62-63 (== sqrt(C) without channel padding)
+    // Optional second job of the MFMA scatter launch (encode_scatter_mfma_kernel): the one-hot term of the tied table's scoring
+    // gradient, d_table[label[r]] -= coef[r] rows[r], d_bias[label[r] - 1] -= coef[r] over the weighted rows (Appendix C; what
+    // edgl_score_flash_label_term applies as a launch of its own) — the same segmented sum over equal ids, on blocks behind the
+    // embedding's: lab_blk0 = first such block (0: none)
+    const void* lab_rows; const int64_t* lab_ids; const float* lab_coef; const int32_t* lab_nvalid; int lab_R; int lab_blk0;
+    float* d_bias;
     float* d_mark_zero;   // [E*C]: cleared by block (0, 0) of the position / mark stage (only row 1 is ever written afterwards)   // rows per block of the scatter stage (<= SROWS; fewer when SROWS*C floats exceed the LDS)
 };
 
@@ -317,19 +323,36 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
     __shared__ __attribute__((aligned(16))) bf16 Gs[SR * LDG];   // masked gradient rows of the block
     __shared__ __attribute__((aligned(16))) int s_id[SR];
     __shared__ __attribute__((aligned(16))) int s_lead[SR];       // first row with the same id; -1: padding / past the end
-    const long rows = (long)p.B * p.T, r0 = (long)blockIdx.x * SR;
+    // label job (block-uniform): rows = the compacted head rows, ids = their labels, every row scaled by its loss coefficient
+    const bool lab = p.lab_blk0 > 0 && (int)blockIdx.x >= p.lab_blk0;
+    const long rows = lab ? (long)(p.lab_nvalid ? min(p.lab_R, p.lab_nvalid[0]) : p.lab_R) : (long)p.B * p.T;
+    const long r0 = (long)((int)blockIdx.x - (lab ? p.lab_blk0 : 0)) * SR;
+    if (lab && r0 >= rows) return;
+    __shared__ float s_cf[SR], s_cb[SR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, G = lane >> 4, g4 = G * 4, l15 = lane & 15;
-    if (tid < SR) s_id[tid] = (r0 + tid < rows) ? (int)p.ids[r0 + tid] : 0;
+    if (tid < SR) {
+        const bool in = r0 + tid < rows;
+        if (lab) {
+            const float cf = in ? p.lab_coef[r0 + tid] : 0.f;
+            s_id[tid] = (in && cf != 0.f) ? (int)p.lab_ids[r0 + tid] : 0;      // label 0: weight 0 (EasyDGL.py:180)
+            s_cf[tid] = cf;
+            s_cb[tid] = 0.f;
+        } else {
+            s_id[tid] = in ? (int)p.ids[r0 + tid] : 0;
+        }
+    }
     // gradient fragments of this thread's rows, all in flight before anything else (rows clamped)
     constexpr int cpr = C / 4, rows_par = 256 / cpr, NR = SR / rows_par;
     const int cv = tid % cpr, rl = tid / cpr, c0 = cv * 4;
-    const bf16* dx0 = reinterpret_cast<const bf16*>(p.dx0);
+    const bf16* dx0 = reinterpret_cast<const bf16*>(lab ? p.lab_rows : p.dx0);
+    const long ldrow = lab ? CF : 3 * CF;
+    const bool adds = p.add1 && !lab;
     Frag4<bf16> g[NR], ga[NR], gb[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
         const long row = min(r0 + rl + (long)k * rows_par, rows - 1);
-        g[k] = frag_ld<bf16>(dx0 + row * 3 * CF + coff + c0);
-        if (p.add1) {
+        g[k] = frag_ld<bf16>(dx0 + row * ldrow + coff + c0);
+        if (adds) {
             ga[k] = frag_ld<bf16>(reinterpret_cast<const bf16*>(p.add1) + row * CF + coff + c0);
             gb[k] = frag_ld<bf16>(reinterpret_cast<const bf16*>(p.add2) + row * CF + coff + c0);
         }
@@ -347,6 +370,7 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
             if (v.x == id && j < tid) lead = j;
         }
         s_lead[tid] = id == 0 ? -1 : lead;
+        if (lab && id != 0 && blockIdx.y == 0) atomicAdd(&s_cb[lead], s_cf[tid]);     // bias term of the leader's label
     }
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
 #pragma unroll
@@ -354,11 +378,15 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
         const int r = rl + k * rows_par;
         const long row = r0 + r;
         Frag4<bf16> v = g[k];
-        if (p.add1) {
+        if (adds) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v.v[j] = from_f32<bf16>(to_f32(v.v[j]) + to_f32(ga[k].v[j]) + to_f32(gb[k].v[j]));
         }
-        if (dk.thresh != 0u) {
+        if (lab) {   // coef[r] * rows[r], rounded to the operand dtype of the segmented sum (as the product pass rounds its P)
+            const float cf = s_cf[r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v.v[j] = from_f32<bf16>(cf * to_f32(v.v[j]));
+        } else if (dk.thresh != 0u) {
             const uint32_t keep = drop_keep4(dk, (uint64_t)row * 3 * CF + coff + c0);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -397,7 +425,7 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
         }
     }
     // acc[mt][ct][r] = sum for leader 32 w + 16 mt + 4G + r, channel 16 ct + l15
-    const float sqs = p.sq * dk.scale;
+    const float sqs = lab ? -1.0f : p.sq * dk.scale;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -408,6 +436,7 @@ __global__ __launch_bounds__(256) void encode_scatter_mfma_kernel(EncBwdP p) {
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) atomicAdd(dst + ct * 16, sqs * acc[mt][ct][r]);
         }
+    if (lab && blockIdx.y == 0 && tid < SR && s_lead[tid] == tid) atomicAdd(p.d_bias + s_id[tid] - 1, -s_cb[tid]);
 }
 
 constexpr int ENC_NCHUNK = 16;
@@ -477,9 +506,41 @@ extern "C" int edgl_encode_bwd_add(const int64_t* ids, const uint8_t* marks, con
 }
 // edgl_encode_bwd_add for a channel-padded model: c_true (0: = C) is the true model width whose square root scales the item
 // gradient (coding.py:62-63); padded channels of dX0 are exact zeros by construction and need no masking here.
+// The MFMA scatter launch can carry the one-hot term of the tied table's scoring gradient as a second job (EncBwdP::lab_*): bf16,
+// C a multiple of 128 (or 64), 8-byte aligned operands
+extern "C" int edgl_encode_bwd_label_fused(int C, int dtype) { return dtype == EDGL_BF16 && (C % 128 == 0 || C == 64) ? 1 : 0; }
+static int encode_bwd_impl(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
+                           int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                           float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int c_true, const void* lab_rows,
+                           const int64_t* lab_ids, const float* lab_coef, const int32_t* lab_nvalid, int lab_R, float* d_bias,
+                           int dtype, void* stream);
 extern "C" int edgl_encode_bwd_add_ct(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
                                       int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
                                       float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int c_true, int dtype, void* stream) {
+    return encode_bwd_impl(ids, marks, dx0, add1, add2, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, d_pos, d_mark_emb, workspace,
+                           c_true, nullptr, nullptr, nullptr, nullptr, 0, nullptr, dtype, stream);
+}
+// edgl_encode_bwd_add_ct that ALSO applies the one-hot term of the scoring gradient which edgl_score_flash_bwd_ex(defer_label_term = 1)
+// left out — d_item[label[r]] -= coef[r] rows[r], d_bias[label[r] - 1] -= coef[r] over the first min(R, nvalid) compacted rows
+// (EasyDGL.py:177-185 / SURVEY Appendix C: dl = coef (p - onehot)) — as extra blocks of the embedding scatter's MFMA launch: the
+// same segmented sum over equal ids, no launch and no stream fork of its own (edgl_score_flash_label_term is the standalone form).
+// Requires edgl_encode_bwd_label_fused(C, dtype).
+extern "C" int edgl_encode_bwd_add_label(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2,
+                                         int B, int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state,
+                                         uint32_t stream_id, float* d_item, float* d_pos, float* d_mark_emb, float* workspace,
+                                         int c_true, const void* lab_rows, const int64_t* lab_ids, const float* lab_coef,
+                                         const int32_t* lab_nvalid, int lab_R, float* d_bias, int dtype, void* stream) {
+    EDGL_REQUIRE(lab_rows && lab_ids && lab_coef && d_bias && lab_R > 0, EDGL_ERR_NULL, "edgl_encode_bwd_add_label: null label operands");
+    EDGL_REQUIRE(edgl_encode_bwd_label_fused(C, dtype) && (((uintptr_t)lab_rows | (uintptr_t)dx0 | (uintptr_t)add1 | (uintptr_t)add2) & 7) == 0,
+                 EDGL_ERR_SHAPE, "edgl_encode_bwd_add_label: needs bf16, C %% 128 == 0 (or 64) and 8-byte aligned operands (C=%d)", C);
+    return encode_bwd_impl(ids, marks, dx0, add1, add2, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, d_pos, d_mark_emb, workspace,
+                           c_true, lab_rows, lab_ids, lab_coef, lab_nvalid, lab_R, d_bias, dtype, stream);
+}
+static int encode_bwd_impl(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
+                           int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                           float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int c_true, const void* lab_rows,
+                           const int64_t* lab_ids, const float* lab_coef, const int32_t* lab_nvalid, int lab_R, float* d_bias,
+                           int dtype, void* stream) {
     EDGL_REQUIRE(c_true >= 0 && c_true <= C, EDGL_ERR_SHAPE, "edgl_encode_bwd: true width %d exceeds C=%d", c_true, C);
     EDGL_REQUIRE((add1 == nullptr) == (add2 == nullptr), EDGL_ERR_NULL, "edgl_encode_bwd_add: add1 / add2 go together");
     EDGL_REQUIRE(ids && marks && dx0 && d_item && d_pos && d_mark_emb && workspace, EDGL_ERR_NULL,
@@ -491,7 +552,7 @@ extern "C" int edgl_encode_bwd_add_ct(const int64_t* ids, const uint8_t* marks, 
     int srows = SROWS;
     while (srows > 8 && (size_t)srows * C * sizeof(float) > 150 * 1024) srows >>= 1;   // C = 512: 64 rows per block
     EncBwdP p{ids, marks, dx0, B, T, C, E, I, drop_rate, rng_state, stream_id, d_item, part_pos, part_mk, ENC_NCHUNK, srows, add1, add2,
-              sqrtf((float)(c_true > 0 ? c_true : C)), d_mark_emb};
+              sqrtf((float)(c_true > 0 ? c_true : C)), lab_rows, lab_ids, lab_coef, lab_nvalid, lab_R, 0, d_bias, d_mark_emb};
     hipStream_t st = (hipStream_t)stream;
     const int rows_par = 256 / (C / 4);
     dim3 grid(T, ENC_NCHUNK);
@@ -504,7 +565,8 @@ extern "C" int edgl_encode_bwd_add_ct(const int64_t* ids, const uint8_t* marks, 
         EDGL_REQUIRE(smem_s <= 150 * 1024, EDGL_ERR_SHAPE, "edgl_encode_bwd: C=%d too large for the scatter stage", C);
         const unsigned nb = (unsigned)(((long)B * T + srows - 1) / srows);
         if (dtype == EDGL_BF16 && (C % 128 == 0 || C == 64) && (((uintptr_t)dx0 | (uintptr_t)add1 | (uintptr_t)add2) & 7) == 0) {
-            const unsigned nbm = (unsigned)(((long)B * T + SROWS - 1) / SROWS);
+            unsigned nbm = (unsigned)(((long)B * T + SROWS - 1) / SROWS);
+            if (lab_rows) { p.lab_blk0 = (int)nbm; nbm += (unsigned)((lab_R + SROWS - 1) / SROWS); }    // label blocks behind the embedding's
             if (C % 128 == 0) hipLaunchKernelGGL((encode_scatter_mfma_kernel<8>), dim3(nbm, C / 128), dim3(256), 0, st, p);
             else hipLaunchKernelGGL((encode_scatter_mfma_kernel<4>), dim3(nbm), dim3(256), 0, st, p);
         } else if (dtype == EDGL_F32) {

@@ -387,7 +387,11 @@ class TrainEngine:
                                               _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), None,
                                               _ptr(tab.grad), _ptr(m.output_bias.grad), _ptr(self.ws_flash), defer, code, st),
                   "edgl_score_flash_bwd")
-            if defer:
+            # the one-hot term as extra blocks of the embedding scatter's launch at the end of the backward (no launch, no fork)
+            self._label_fused = bool(defer and self.code == _lib.BF16 and C == 128 and lib.edgl_encode_bwd_label_fused(C, code)
+                                     and os.environ.get("EDGL_LABEL_FUSED", "1") != "0"
+                                     and os.environ.get("EDGL_SCORE_STRIP", "1") != "0")    # (only the strip passes leave the term out)
+            if defer and not self._label_fused:
                 self._pending_label = lambda s: check(lib.edgl_score_flash_label_term(
                     _ptr(self.hrows_c), _ptr(lab), _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(tab.grad),
                     _ptr(m.output_bias.grad), code, s), "edgl_score_flash_label_term")
@@ -497,10 +501,18 @@ class TrainEngine:
                 dY = d_in   # first block: the embedding backward adds the two branches itself (one pass less over dX0)
         d0 = drop(hd, 1)
         add1, add2 = (self.G1, self.G2) if self.blk else (None, None)
-        check(lib.edgl_encode_bwd_add_ct(_ptr(self.ids), _ptr(self.marks), _ptr(dY), _ptr(add1), _ptr(add2), B, T, C, E, I,
-                                         float(d0.rate), d0.ptr(), d0.stream_id, _ptr(tab.grad), _ptr(m.pcoding.pembs.lookup_table.grad),
-                                         _ptr(m.mark_embs.lookup_table.grad), _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))),
-                                         self.c_true, code, st), "edgl_encode_bwd_add")
+        if getattr(self, "_label_fused", False):
+            check(lib.edgl_encode_bwd_add_label(_ptr(self.ids), _ptr(self.marks), _ptr(dY), _ptr(add1), _ptr(add2), B, T, C, E, I,
+                                                float(d0.rate), d0.ptr(), d0.stream_id, _ptr(tab.grad),
+                                                _ptr(m.pcoding.pembs.lookup_table.grad), _ptr(m.mark_embs.lookup_table.grad),
+                                                _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))), self.c_true,
+                                                _ptr(self.hrows_c), _ptr(lab), _ptr(self.coef), _ptr(self.nvalid), R,
+                                                _ptr(m.output_bias.grad), code, st), "edgl_encode_bwd_add_label")
+        else:
+            check(lib.edgl_encode_bwd_add_ct(_ptr(self.ids), _ptr(self.marks), _ptr(dY), _ptr(add1), _ptr(add2), B, T, C, E, I,
+                                             float(d0.rate), d0.ptr(), d0.stream_id, _ptr(tab.grad), _ptr(m.pcoding.pembs.lookup_table.grad),
+                                             _ptr(m.mark_embs.lookup_table.grad), _ptr(self._ws(lib.edgl_encode_bwd_workspace(B, T, C))),
+                                             self.c_true, code, st), "edgl_encode_bwd_add")
 
     # ---- more than 16 mark types: the attention of a block as mark groups (see __init__) -----------------------------------
     def _attention_fwd_groups(self, b, x, cin, da, st):

@@ -116,6 +116,17 @@ int edgl_encode_fwd_ct(const int64_t* ids, const float* ts, const void* item_tab
 int edgl_encode_bwd_add_ct(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
                            int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
                            float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int c_true, int dtype, void* stream);
+/* edgl_encode_bwd_add_ct that also applies the one-hot term of the tied table's scoring gradient which
+ * edgl_score_flash_bwd_ex(defer_label_term = 1) left out (EasyDGL.py:177-185: dl = coef (softmax - onehot)):
+ * d_item[label[r]] -= coef[r] rows[r], d_bias[label[r] - 1] -= coef[r] over the first min(lab_R, *lab_nvalid) compacted rows — as
+ * extra blocks of the embedding scatter's launch (the same segmented sum over equal ids), instead of the launch and stream fork
+ * of edgl_score_flash_label_term.  edgl_encode_bwd_label_fused(C, dtype) says whether this shape has the fused form. */
+int edgl_encode_bwd_label_fused(int C, int dtype);
+int edgl_encode_bwd_add_label(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
+                              int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
+                              float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int c_true, const void* lab_rows,
+                              const int64_t* lab_ids, const float* lab_coef, const int32_t* lab_nvalid, int lab_R, float* d_bias,
+                              int dtype, void* stream);
 
 /* ---- K1b: CTSMA input encoding — CTSMA.py:48-58, coding.py:60-79 ----------------------------------
  * ids int64 [B,T] (tokens[:-1]), ts f32 [B,T+1] raw seconds.  x0 [B,T,2C] `dtype` =
