@@ -21,9 +21,15 @@ constexpr int KY_NY = EP / KY_ECH;
 constexpr int KY_BLOCKS = 384;   // workgroups of kernel Y per mark group (x KY_NY = one resident round at 3 WGs/CU)
 
 // head dims >= 64 (k_bimau_big.hip): the weight-gradient kernel runs on a (row splits, channel groups) grid; a group is
-// 32 / (dh/16) channel tiles of 16.  Enough row splits for ~512 workgroups, at least 16.
+// big_nj(dh) channel tiles of 16.  Enough row splits for ~512 workgroups, at least 16.  Head dim 64: four tiles — 64
+// accumulator registers, 253 in all, two waves per SIMD; with eight (402 registers, one wave per SIMD, nothing to hide its
+// LDS / MFMA / sigmoid chain behind) the kernel measured 167 us at the recipe shape against 122.
+#ifndef EDGL_WG_NJ64
+#define EDGL_WG_NJ64 4
+#endif
+constexpr int big_nj(int dh) { return dh == 64 ? EDGL_WG_NJ64 : 32 / (dh / 16); }   // channel tiles of a weight-gradient workgroup
 inline int big_row_splits(int dh, int E) {
-    const int nc = (32 / (dh / 16)) * 16;
+    const int nc = big_nj(dh) * 16;
     const int groups = std::max(1, (dh * E + nc - 1) / nc);
     return std::max(16, 512 / groups);
 }

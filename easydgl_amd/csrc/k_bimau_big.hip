@@ -10,6 +10,7 @@
 // The attention phases are the kernels of bimau_fwd_impl.h / bimau_bwd_impl.h at DT = 4 / 8.
 #include "bimau_bwd_impl.h"
 #include "bimau_fwd_impl.h"
+#include <type_traits>
 
 namespace {
 using namespace bimau;
@@ -28,6 +29,76 @@ __device__ __forceinline__ void copy16(const char* src, char* dst, int bytes) {
         *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
 }
 
+// One mark's weights on their way global -> registers -> LDS (256-thread workgroups): the dh rows of the packed W1^T, the
+// (interval weight | bias | output weight) floats and — backward, row side — the mark's dh x dh block of W1 columns.  fetch()
+// issues every load (clamped, unconditional), put() writes the LDS chunk [W1^T rows | W1 columns | floats].  The kernels
+// fetch mark e + 1 before they compute mark e out of the other of two LDS chunks: one barrier per mark, and the L2 round
+// trip of a chunk runs under the arithmetic of the previous one (with one chunk and a copy loop between two barriers every
+// mark of every row block opened with that round trip: 16 per block at the recipe shape, ~40 % of the kernels' time).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <typename T, int DT, bool WITH_R>
+struct MarkChunk {
+    static constexpr int dh = 16 * DT, LDC = dh + 4;
+    static constexpr int WB = dh * (dh + 4) * (int)sizeof(T);        // bytes of the W1^T rows (LDW = dh + 4)
+    static constexpr int NV = (WB / 16 + 255) / 256;
+    static constexpr int NR = WITH_R ? dh * (dh / 4) / 256 : 1;      // 4-channel fragments of the W1 column block per thread
+    static constexpr int NF = (3 * dh + 255) / 256;
+    static constexpr int BYTES = WB + (WITH_R ? WB : 0) + 3 * dh * (int)sizeof(float);
+    static_assert(!WITH_R || (dh * (dh / 4)) % 256 == 0, "column block: whole rounds of the workgroup");
+    using RFrag = typename std::conditional<sizeof(T) == 4, u32x4, u32x2>::type;   // four channels of the column block
+};
+// (first-class vector types: arrays of HIP's uint4 structs stayed in scratch here — a store and a reload per prefetch)
+template <typename T, int DT, bool WITH_R, int NV, typename RF, int NR, int NF>
+__device__ __forceinline__ void mark_fetch(u32x4 (&v)[NV], RF (&r)[NR], float (&f)[NF], const char* pack, const PackDims& pd, int e) {
+    using MC = MarkChunk<T, DT, WITH_R>;
+    constexpr int dh = MC::dh;
+    const u32x4* src = reinterpret_cast<const u32x4*>(pack + (size_t)e * dh * pd.LDW * sizeof(T));
+#pragma unroll
+    for (int i = 0; i < MC::NV; ++i) v[i] = src[min((int)threadIdx.x + i * 256, MC::WB / 16 - 1)];
+    if constexpr (WITH_R) {
+        const T* W1R = reinterpret_cast<const T*>(pack + pd.off_w1r);
+#pragma unroll
+        for (int i = 0; i < MC::NR; ++i) {
+            const int k = threadIdx.x + i * 256, u = k / (dh / 4), c4 = (k % (dh / 4)) * 4;
+            r[i] = *reinterpret_cast<const typename MC::RFrag*>(W1R + (size_t)u * pd.LDR + e * dh + c4);
+        }
+    }
+    const float* fW = reinterpret_cast<const float*>(pack + pd.off_f32);
+#pragma unroll
+    for (int i = 0; i < MC::NF; ++i) {
+        const int k = min((int)threadIdx.x + i * 256, 3 * dh - 1);
+        f[i] = fW[(k / dh) * pd.JE + e * dh + (k % dh)];
+    }
+}
+template <typename T, int DT, bool WITH_R, int NV, typename RF, int NR, int NF>
+__device__ __forceinline__ void mark_put(const u32x4 (&v)[NV], const RF (&r)[NR], const float (&f)[NF], char* chunk) {
+    using MC = MarkChunk<T, DT, WITH_R>;
+    constexpr int dh = MC::dh;
+#pragma unroll
+    for (int i = 0; i < MC::NV; ++i) {
+        const int k = threadIdx.x + i * 256;
+        if (k < MC::WB / 16) reinterpret_cast<u32x4*>(chunk)[k] = v[i];
+    }
+    if constexpr (WITH_R) {
+        T* Rc = reinterpret_cast<T*>(chunk + MC::WB);
+#pragma unroll
+        for (int i = 0; i < MC::NR; ++i) {
+            const int k = threadIdx.x + i * 256, u = k / (dh / 4), c4 = (k % (dh / 4)) * 4;
+            *reinterpret_cast<typename MC::RFrag*>(Rc + u * MC::LDC + c4) = r[i];
+        }
+    }
+    float* fc = reinterpret_cast<float*>(chunk + MC::WB + (WITH_R ? MC::WB : 0));
+#pragma unroll
+    for (int i = 0; i < MC::NF; ++i) {
+        const int k = threadIdx.x + i * 256;
+        if (k < 3 * dh) fc[k] = f[i];
+    }
+}
+// two LDS chunks where the staging registers are affordable: bf16 at head dim 64 (13 / 21 registers; head dim 128 would stage
+// 38 / 70 and spill, f32 twice that)
+template <typename T, int DT> constexpr bool big_double_buffer() { return sizeof(T) == 2 && DT == 4; }
+
 // ------------------------------------------------------------------------------------------------------------------
 // forward MLP: z[row][e] = sum_u sigmoid([H[row], span] . W1[:, e*dh+u] + b1) * w[e][u]; lambda = s_e softplus(z / s_e)
 // A workgroup (4 waves) walks blocks of 128 rows (2 row tiles of 16 per wave); per mark e it stages that mark's dh rows
@@ -41,8 +112,11 @@ __global__ __launch_bounds__(256) void intensity_fwd_big_kernel(IntP p) {
     const PackDims pd = pack_dims<T>(dh, p.E);
     const int LDW = pd.LDW;
     constexpr int CH_T = dh * (dh + 4);                   // elements of one mark's W1^T rows
-    T* Wc = reinterpret_cast<T*>(smem);
-    float* fc = reinterpret_cast<float*>(smem + (size_t)CH_T * sizeof(T));   // ws | bs | wv, dh floats each
+    using MC = MarkChunk<T, DT, false>;
+    constexpr bool DBUF = big_double_buffer<T, DT>();
+    u32x4 mv[MC::NV]; typename MC::RFrag mr[MC::NR]; float mf[MC::NF];
+    int cur = 0;                                          // LDS chunk of the mark being computed
+    if constexpr (DBUF) mark_fetch<T, DT, false>(mv, mr, mf, p.pack, pd, 0);
     const char* packW = p.pack;
     const float* fW = reinterpret_cast<const float*>(p.pack + pd.off_f32);
     const float* scs = fW + 3 * pd.JE; const float* iscs = scs + EP;
@@ -67,41 +141,63 @@ __global__ __launch_bounds__(256) void intensity_fwd_big_kernel(IntP p) {
             for (int ub = 0; ub < DT; ++ub) hf[t][ub] = frag_ld<T>(hin + row0[t] * dh + ub * 16 + g4);
             span[t] = p.spans[(long)bb * p.T + q];
         }
-        float zp[RT][16];
+        // z of this lane's row: lane group g keeps the marks e = 4g + i (the layout reduce_scatter16 leaves)
+        float z4a[RT][4];
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) zp[t][e] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (e < p.E) {
-                __syncthreads();      // the previous mark's chunk is no longer read
-                copy16(packW + (size_t)e * dh * LDW * sizeof(T), reinterpret_cast<char*>(Wc), CH_T * (int)sizeof(T));
-                for (int i = threadIdx.x; i < 3 * dh; i += blockDim.x) fc[i] = fW[(i / dh) * pd.JE + e * dh + (i % dh)];
+            for (int i = 0; i < 4; ++i) z4a[t][i] = 0.f;
+#pragma unroll 1
+        for (int e = 0; e < p.E; ++e) {
+            const T* Wc = reinterpret_cast<const T*>(smem + (size_t)cur * MC::BYTES);
+            const float* fc = reinterpret_cast<const float*>(smem + (size_t)cur * MC::BYTES + MC::WB);   // ws | bs | wv, dh floats each
+            if constexpr (DBUF) {
+                mark_put<T, DT, false>(mv, mr, mf, smem + (size_t)cur * MC::BYTES);   // (its last readers passed the previous mark's barrier)
+                mark_fetch<T, DT, false>(mv, mr, mf, p.pack, pd, e + 1 < p.E ? e + 1 : 0);   // next mark — or mark 0 of the next row block
                 __syncthreads();
+                cur ^= 1;
+            } else {
+                __syncthreads();      // the previous mark's chunk is no longer read
+                copy16(packW + (size_t)e * dh * LDW * sizeof(T), smem, CH_T * (int)sizeof(T));
+                for (int i = threadIdx.x; i < 3 * dh; i += blockDim.x)
+                    reinterpret_cast<float*>(smem + MC::WB)[i] = fW[(i / dh) * pd.JE + e * dh + (i % dh)];
+                __syncthreads();
+            }
+            float zc[RT];
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    Frag4<T> w[DT];
+            for (int t = 0; t < RT; ++t) zc[t] = 0.f;
 #pragma unroll
-                    for (int ub = 0; ub < DT; ++ub) w[ub] = frag_ld<T>(Wc + (d * 16 + l15) * LDW + ub * 16 + g4);
-                    const float4 ws = *reinterpret_cast<const float4*>(fc + d * 16 + g4);
-                    const float4 bs = *reinterpret_cast<const float4*>(fc + dh + d * 16 + g4);
-                    const float4 wv = *reinterpret_cast<const float4*>(fc + 2 * dh + d * 16 + g4);
+            for (int d = 0; d < DT; ++d) {
+                Frag4<T> w[DT];
 #pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int ub = 0; ub < DT; ++ub) w[ub] = frag_ld<T>(Wc + (d * 16 + l15) * LDW + ub * 16 + g4);
+                const float4 ws = *reinterpret_cast<const float4*>(fc + d * 16 + g4);
+                const float4 bs = *reinterpret_cast<const float4*>(fc + dh + d * 16 + g4);
+                const float4 wv = *reinterpret_cast<const float4*>(fc + 2 * dh + d * 16 + g4);
 #pragma unroll
-                        for (int ub = 0; ub < DT; ++ub) a = mma16(w[ub], hf[t][ub], a);
-                        zp[t][e] += sigmoid_pre(fmaf(span[t], ws.x, a[0]) + bs.x) * wv.x + sigmoid_pre(fmaf(span[t], ws.y, a[1]) + bs.y) * wv.y +
-                                    sigmoid_pre(fmaf(span[t], ws.z, a[2]) + bs.z) * wv.z + sigmoid_pre(fmaf(span[t], ws.w, a[3]) + bs.w) * wv.w;
-                    }
+                for (int t = 0; t < RT; ++t) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ub = 0; ub < DT; ++ub) a = mma16(w[ub], hf[t][ub], a);
+                    zc[t] += sigmoid_pre(fmaf(span[t], ws.x, a[0]) + bs.x) * wv.x + sigmoid_pre(fmaf(span[t], ws.y, a[1]) + bs.y) * wv.y +
+                             sigmoid_pre(fmaf(span[t], ws.z, a[2]) + bs.z) * wv.z + sigmoid_pre(fmaf(span[t], ws.w, a[3]) + bs.w) * wv.w;
                 }
+            }
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {      // sum over the four lane groups (each holds 4 of a tile's 16 channels)
+                FPair s = swap32(zc[t], zc[t]);
+                const float h = s.first + s.second;
+                s = swap16(h, h);
+                const float full = s.first + s.second;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z4a[t][i] = (e == g4 + i) ? full : z4a[t][i];
             }
         }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             float z4[4];
-            reduce_scatter16(zp[t], z4, lane);   // lane group g owns e = 4g + i
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z4[i] = z4a[t][i];
             if (rok[t]) {
                 *reinterpret_cast<float4*>(p.z_out + row0[t] * EP + g4) = make_float4(z4[0], z4[1], z4[2], z4[3]);
 #pragma unroll
@@ -114,7 +210,7 @@ __global__ __launch_bounds__(256) void intensity_fwd_big_kernel(IntP p) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, row side: dH[row][u] = sum_j du[row][j] W1[u][j], du = dz[row][e(j)] w[j] Z (1 - Z).  Same walk as the forward
-// (128 rows per workgroup pass, one mark's W1^T rows and W1 columns in LDS at a time); Zpre[row][j], L(first = row, second = j).
+// (128 rows per workgroup pass, one mark's W1^T rows and W1 columns in LDS at a time).
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, int DT>
 __global__ __launch_bounds__(256) void intensity_bwd_rows_big_kernel(IntP p) {
@@ -122,101 +218,114 @@ __global__ __launch_bounds__(256) void intensity_bwd_rows_big_kernel(IntP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PackDims pd = pack_dims<T>(dh, p.E);
     const int LDW = pd.LDW;
-    constexpr int CH_T = dh * (dh + 4);
-    T* Wc = reinterpret_cast<T*>(smem);                     // W1^T rows of the mark: [dh j][LDW]
-    T* Rc = Wc + CH_T;                                      // W1 columns of the mark: [dh u][LDC]
-    float* fc = reinterpret_cast<float*>(smem + 2 * (size_t)CH_T * sizeof(T));
-    const T* W1R = reinterpret_cast<const T*>(p.pack + pd.off_w1r);
-    const float* fW = reinterpret_cast<const float*>(p.pack + pd.off_f32);
+    using MC = MarkChunk<T, DT, true>;                      // chunk: W1^T rows [dh j][LDW] | W1 columns [dh u][LDC] | floats
+    constexpr bool DBUF = big_double_buffer<T, DT>();
+    u32x4 mv[MC::NV]; typename MC::RFrag mr[MC::NR]; float mf[MC::NF];
+    int cur = 0;
+    if constexpr (DBUF) mark_fetch<T, DT, true>(mv, mr, mf, p.pack, pd, 0);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
-    const Frag4<T> ident = identity_frag<T>(lane);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int ntq = (p.T + 15) / 16;
     const long ntile = (p.R / p.T) * ntq;
     const T* hin = reinterpret_cast<const T*>(p.hin);
     for (long tb = (long)blockIdx.x * 4 * RT; tb < ntile; tb += (long)gridDim.x * 4 * RT) {
-        Frag4<T> hA[RT][DT];
-        float spn[RT][4];
-        long rbase[RT]; int qt0[RT]; bool tok[RT];
-        f32x4 dHt[RT][DT];
+        Frag4<T> hf[RT][DT];
+        float span[RT];
+        long row[RT]; bool rok[RT];
+        const float* dzp[RT];
+        float dzn[RT];
+        f32x4 dHt[RT][DT];       // dH^T[u][row], L(first = u, second = row)
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const long tile = min(tb + wave * RT + t, ntile - 1);
-            tok[t] = tb + wave * RT + t < ntile;
             const long bpq = tile / ntq; const int qt = (int)(tile - bpq * ntq), bb = (int)(bpq % p.B);
-            rbase[t] = bpq * p.T + qt * 16; qt0[t] = qt * 16;
-            const int ql = min(qt * 16 + l15, p.T - 1);
+            const int q = min(qt * 16 + l15, p.T - 1);
+            rok[t] = (tb + wave * RT + t < ntile) && (qt * 16 + l15 < p.T);
+            row[t] = bpq * p.T + q;       // this lane's row (clamped; masked through dz)
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub) {
-                hA[t][ub] = frag_ld<T>(hin + (bpq * p.T + ql) * dh + ub * 16 + g4);
+                hf[t][ub] = frag_ld<T>(hin + row[t] * dh + ub * 16 + g4);
                 dHt[t][ub] = zero4;
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) spn[t][r] = p.spans[(long)bb * p.T + min(qt * 16 + g4 + r, p.T - 1)];
+            span[t] = p.spans[(long)bb * p.T + q];
+            // dz of the lane's row, one mark ahead and requested BEFORE the chunk prefetch (a load behind it could only be
+            // waited for together with it)
+            dzp[t] = p.dz + row[t] * EP;
+            dzn[t] = dzp[t][0];
         }
 #pragma unroll 1
         for (int e = 0; e < p.E; ++e) {
-            __syncthreads();
-            copy16(p.pack + (size_t)e * dh * LDW * sizeof(T), reinterpret_cast<char*>(Wc), CH_T * (int)sizeof(T));
-            for (int i = threadIdx.x; i < dh * (dh / 4); i += blockDim.x) {   // W1R[u][e*dh .. +dh): 4 channels per thread
-                const int u = i / (dh / 4), c4 = (i % (dh / 4)) * 4;
-                const Frag4<T> f = frag_ld<T>(W1R + (size_t)u * pd.LDR + e * dh + c4);
-                if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(Rc + u * LDC + c4) = *reinterpret_cast<const uint4*>(&f);
-                else *reinterpret_cast<uint2*>(Rc + u * LDC + c4) = *reinterpret_cast<const uint2*>(&f);
+            const T* Wc = reinterpret_cast<const T*>(smem + (size_t)cur * MC::BYTES);
+            const T* Rc = reinterpret_cast<const T*>(smem + (size_t)cur * MC::BYTES + MC::WB);
+            const float* fc = reinterpret_cast<const float*>(smem + (size_t)cur * MC::BYTES + 2 * MC::WB);
+            float dzr[RT];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) dzr[t] = rok[t] ? dzn[t] : 0.f;
+            if constexpr (DBUF) {
+                mark_put<T, DT, true>(mv, mr, mf, smem + (size_t)cur * MC::BYTES);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) dzn[t] = dzp[t][min(e + 1, p.E - 1)];
+                mark_fetch<T, DT, true>(mv, mr, mf, p.pack, pd, e + 1 < p.E ? e + 1 : 0);
+                __syncthreads();
+                cur ^= 1;
+            } else {
+                __syncthreads();
+                mark_fetch<T, DT, true>(mv, mr, mf, p.pack, pd, e);
+                mark_put<T, DT, true>(mv, mr, mf, smem);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) dzn[t] = dzp[t][min(e + 1, p.E - 1)];
+                __syncthreads();
             }
-            for (int i = threadIdx.x; i < 3 * dh; i += blockDim.x) fc[i] = fW[(i / dh) * pd.JE + e * dh + (i % dh)];
-            __syncthreads();
-            float dzr[RT][4];
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    dzr[t][r] = (tok[t] && qt0[t] + g4 + r < p.T) ? p.dz[(rbase[t] + g4 + r) * EP + e] : 0.f;
+            // the forward's orientation, Zpre^T[j][row] with L(first = j, second = row): du^T leaves the sigmoid block in the
+            // B-operand layout of dH^T[u][row] = sum_j W1[u][j] du[row][j] (no transposing product), a lane's four u of its
+            // row are one 16-byte store
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 Frag4<T> w[DT];
 #pragma unroll
                 for (int ub = 0; ub < DT; ++ub) w[ub] = frag_ld<T>(Wc + (d * 16 + l15) * LDW + ub * 16 + g4);
-                const float ws = fc[d * 16 + l15], bs = fc[dh + d * 16 + l15], wv = fc[2 * dh + d * 16 + l15];
+                const float4 ws4 = *reinterpret_cast<const float4*>(fc + d * 16 + g4);
+                const float4 bs4 = *reinterpret_cast<const float4*>(fc + dh + d * 16 + g4);
+                const float4 wv4 = *reinterpret_cast<const float4*>(fc + 2 * dh + d * 16 + g4);
+                const float ws[4] = {ws4.x, ws4.y, ws4.z, ws4.w}, bs[4] = {bs4.x, bs4.y, bs4.z, bs4.w}, wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+                Frag4<T> rc[DT];
+#pragma unroll
+                for (int ut = 0; ut < DT; ++ut) rc[ut] = frag_ld<T>(Rc + (ut * 16 + l15) * LDC + d * 16 + g4);
 #pragma unroll
                 for (int t = 0; t < RT; ++t) {
-                    f32x4 a = zero4;   // Zpre[row][j]
+                    f32x4 a = zero4;
 #pragma unroll
-                    for (int ub = 0; ub < DT; ++ub) a = mma16(hA[t][ub], w[ub], a);
+                    for (int ub = 0; ub < DT; ++ub) a = mma16(w[ub], hf[t][ub], a);
                     f32x4 du;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float z = sigmoid_pre(fmaf(spn[t][r], ws, a[r]) + bs);
-                        du[r] = dzr[t][r] * z * wv * (1.0f - z);
+                        const float z = sigmoid_pre(fmaf(span[t], ws[r], a[r]) + bs[r]);
+                        du[r] = dzr[t] * z * wv[r] * (1.0f - z);
                     }
-                    const Frag4<T> duT = frag_from_acc<T>(mma16(frag_from_acc<T>(du), ident, zero4));   // L(first = j, second = row)
+                    const Frag4<T> duB = frag_from_acc<T>(du);
 #pragma unroll
-                    for (int ut = 0; ut < DT; ++ut)
-                        dHt[t][ut] = mma16(duT, frag_ld<T>(Rc + (ut * 16 + l15) * LDC + d * 16 + g4), dHt[t][ut]);
+                    for (int ut = 0; ut < DT; ++ut) dHt[t][ut] = mma16(rc[ut], duB, dHt[t][ut]);
                 }
             }
         }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            if (!tok[t]) continue;
-            float* dst = p.dh_out + rbase[t] * dh;
+            if (!rok[t]) continue;
+            float* dst = p.dh_out + row[t] * dh;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (qt0[t] + g4 + r < p.T) {
-#pragma unroll
-                    for (int ut = 0; ut < DT; ++ut) dst[(long)(g4 + r) * dh + ut * 16 + l15] = dHt[t][ut][r];
-                }
+            for (int ut = 0; ut < DT; ++ut)
+                *reinterpret_cast<float4*>(dst + ut * 16 + g4) = make_float4(dHt[t][ut][0], dHt[t][ut][1], dHt[t][ut][2], dHt[t][ut][3]);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // backward, weight side: dW1[u][j] = sum_row [H, span][row][u] du[row][j], db1[j] = sum du, dw[j] = sum dz Z.
-// grid = (row splits, channel groups): a workgroup owns NJ = 32 / DT channel tiles of 16 (their W1^T rows stay in LDS, the
+// grid = (row splits, channel groups): a workgroup owns NJ = big_nj(dh) channel tiles of 16 (their W1^T rows stay in LDS, the
 // dW1 tiles in registers) and one slice of the row tiles; the per-split partials are reduced by edgl_reduce_rows.
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT> struct WGroup { static constexpr int NJ = 32 / DT; };   // 8 tiles at dh = 64, 4 at dh = 128
+template <int DT> struct WGroup { static constexpr int NJ = big_nj(16 * DT); };   // 4 tiles at dh = 64 and at dh = 128
 
 template <typename T, int DT>
 __global__ __launch_bounds__(256) void intensity_bwd_weights_big_kernel(IntP p) {
@@ -358,7 +467,7 @@ int run_intensity_fwd(const FwdP& p, hipStream_t st) {
     IntP ip{};
     ip.hin = p.hin_out; ip.spans = p.spans; ip.pack = p.pack; ip.R = (long)p.B * p.H * p.T; ip.B = p.B; ip.T = p.T; ip.E = p.E;
     ip.z_out = p.z_out; ip.lam = p.lam;
-    const size_t smem = (size_t)dh * (dh + 4) * sizeof(T) + 3 * dh * sizeof(float);
+    const size_t smem = (size_t)MarkChunk<T, DT, false>::BYTES * (big_double_buffer<T, DT>() ? 2 : 1);
     auto k = intensity_fwd_big_kernel<T, DT>;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const long ntile = (long)p.B * p.H * ((p.T + 15) / 16);
@@ -405,7 +514,7 @@ int bwd_big(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscaling
         ip.hin = p.hin; ip.spans = p.spans; ip.pack = p.pack; ip.dz = p.dz_ws; ip.R = (long)p.B * p.H * p.T; ip.B = p.B; ip.T = p.T;
         ip.E = p.E; ip.dh_out = p.dh_ws; ip.wpart = p.wpart; ip.dsc_part = p.dsc_part; ip.njobs = jobs;
         const long ntile = jobs * ((p.T + 15) / 16);
-        const size_t smem_r = 2 * (size_t)dh * (dh + 4) * sizeof(T) + 3 * dh * sizeof(float);
+        const size_t smem_r = (size_t)MarkChunk<T, DT, true>::BYTES * (big_double_buffer<T, DT>() ? 2 : 1);
         auto kr = intensity_bwd_rows_big_kernel<T, DT>;
         hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r);
         hipLaunchKernelGGL(kr, dim3(row_blocks(ntile, 8)), dim3(256), smem_r, st, ip);
