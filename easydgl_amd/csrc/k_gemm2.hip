@@ -815,14 +815,38 @@ static int tn_tile(int Kf, int N) {
     static const int force = getenv("EDGL_TN_TILE") ? atoi(getenv("EDGL_TN_TILE")) : 0;
     return force == 64 ? 64 : 128;
 }
+// Row splits of a TN product (or of a group of them: `tiles` output tiles in all, `out_elems` f32 of output in all, `flop` =
+// 2 R sum(Kf N)).  The chip takes workgroups in rounds of its CU count: 192 tiles x 2 splits = 384 workgroups run as TWO
+// rounds (the 512-unit QKVT weight gradient: 229 us), x 4 = 768 as three of half the length (143 us) — but every split
+// leaves a [Kf+1, N] f32 slab that a second kernel sums (384 workgroups over a 128 x 128 output meant 25 MB of partials for a
+// 64 KB result).  Both sides priced (rates measured on the part: ~0.6 PFLOP/s of this kernel when every round is full, 3 us
+// of prologue / slab write per workgroup, x1.25 below two resident workgroups per CU, ~4 TB/s of slab reduction), the
+// cheapest split count wins: 4 for that product (768 workgroups), 28 for the headline's grouped launch (504, as before).
+static int tn_choose_splits(int R, int tiles, double flop, double out_elems, int cap) {
+    static const int forced = getenv("EDGL_TN_TARGET") ? atoi(getenv("EDGL_TN_TARGET")) : 0;   // experiments: fixed workgroup target
+    const int smax = std::max(1, std::min(cap, R / 128));
+    if (forced > 0) return std::max(1, std::min(forced / std::max(1, tiles), smax));
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    int best = 1;
+    double best_t = 1e30;
+    for (int sp = 1; sp <= smax; ++sp) {
+        const long wg = (long)tiles * sp;
+        const long rounds = (wg + cus - 1) / cus;
+        double t = (double)rounds * (flop / (double)wg / (0.6e15 / cus) + 3e-6);   // + a workgroup's fixed part (its 64 KB slab)
+        if (4 * wg < 7L * cus) t *= 1.25;   // fewer than ~two workgroups per CU: nothing hides a workgroup's barriers
+        if (sp > 1) t += (double)sp * out_elems * 4.0 / 4e12 + 3e-6;
+        if (t < best_t * 0.999) { best_t = t; best = sp; }
+    }
+    return best;
+}
 static int tn_splits(int R, int Kf, int N) {
     const int tm = tn_tile(Kf, N);
     const int tiles = ((Kf + tm - 1) / tm) * ((N + tm - 1) / tm);
-    // row splits: enough workgroups to fill the chip, but every split leaves a [Kf+1, N] f32 slab behind that a second
-    // kernel sums — 384 workgroups over a 128x128 output meant 25 MB of partials for a 64 KB result
-    static const int target = getenv("EDGL_TN_TARGET") ? atoi(getenv("EDGL_TN_TARGET")) : 384;
-    int splits = std::max(1, std::min(target / tiles, R / 128));
-    return splits;
+    return tn_choose_splits(R, tiles, 2.0 * R * Kf * N, (double)(Kf + 1) * N, 1 << 20);
 }
 long edgl_gemm2_tn_workspace(int R, int Kf, int N) { return (long)tn_splits(R, Kf, N) * (Kf + 1) * N; }
 
@@ -855,8 +879,21 @@ static int tn_flush(hipStream_t st) {
         total_tiles += g.tiles_n[i] * g.tiles_k[i];
     }
     // one split count for the whole group (row ranges of similar length), capped by what each job's workspace was sized for
-    static const int target = getenv("EDGL_TN_GROUP_TARGET") ? atoi(getenv("EDGL_TN_GROUP_TARGET")) : 512;
-    const int group_splits = std::max(1, target / std::max(1, total_tiles));
+    static const int target = getenv("EDGL_TN_GROUP_TARGET") ? atoi(getenv("EDGL_TN_GROUP_TARGET")) : 0;
+    int group_splits;
+    if (target > 0) {
+        group_splits = std::max(1, target / std::max(1, total_tiles));
+    } else {
+        double flop = 0.0, elems = 0.0;
+        int rmin = 1 << 30;
+        for (int i = 0; i < n; ++i) {
+            const TnP& q = g_tn_q[i].p;
+            flop += 2.0 * q.R * q.Kf * q.N;
+            elems += (double)(q.Kf + 1) * q.N;
+            rmin = std::min(rmin, q.R);
+        }
+        group_splits = tn_choose_splits(rmin, total_tiles, flop, elems, 1 << 20);
+    }
     int splits[TN_MAX_JOBS], blocks = 0;
     for (int i = 0; i < n; ++i) {
         TnP& p = g_tn_q[i].p;
