@@ -319,9 +319,24 @@ __device__ __forceinline__ void masked_softmax(f32x4 (&s)[NT], const KeyMask<NT>
 // one word per lane and query tile with its other per-tile operands and applies an element's decision with two instructions
 // (sign-extended bit field, AND).  Same masks as the hashed form by construction: kernels without the bits (other head dims /
 // flags / more than 8 key tiles) and kernels with them can be mixed inside one step.
-__device__ __forceinline__ float keep_bit(uint32_t kb, int i, float x) {   // i: a constant after unrolling
-    const int m = __builtin_amdgcn_sbfe((int)kb, (unsigned)i, 1u);   // v_bfe_i32: 0 or -1
+// (the bit-field extract as asm: from the builtin the compiler knows the mask is 0 / -1 and rewrites the pair as v_and (bit
+// test) + v_cmp_ne + v_cndmask — three issue slots per element in kernels that are bound by exactly those)
+template <int I>
+__device__ __forceinline__ float keep_bit_c(uint32_t kb, float x) {
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(kb), "n"(I));   // 0 or -1
     return __int_as_float(__float_as_int(x) & m);
+}
+__device__ __forceinline__ float keep_bit(uint32_t kb, int i, float x) {   // i: a constant after unrolling (0 .. 31)
+    switch (i) {
+#define EDGL_KB_CASE(n) case n: return keep_bit_c<n>(kb, x);
+        EDGL_KB_CASE(0) EDGL_KB_CASE(1) EDGL_KB_CASE(2) EDGL_KB_CASE(3) EDGL_KB_CASE(4) EDGL_KB_CASE(5) EDGL_KB_CASE(6) EDGL_KB_CASE(7)
+        EDGL_KB_CASE(8) EDGL_KB_CASE(9) EDGL_KB_CASE(10) EDGL_KB_CASE(11) EDGL_KB_CASE(12) EDGL_KB_CASE(13) EDGL_KB_CASE(14) EDGL_KB_CASE(15)
+        EDGL_KB_CASE(16) EDGL_KB_CASE(17) EDGL_KB_CASE(18) EDGL_KB_CASE(19) EDGL_KB_CASE(20) EDGL_KB_CASE(21) EDGL_KB_CASE(22) EDGL_KB_CASE(23)
+        EDGL_KB_CASE(24) EDGL_KB_CASE(25) EDGL_KB_CASE(26) EDGL_KB_CASE(27) EDGL_KB_CASE(28) EDGL_KB_CASE(29) EDGL_KB_CASE(30) EDGL_KB_CASE(31)
+#undef EDGL_KB_CASE
+    }
+    return x;
 }
 template <int NT>
 __global__ __launch_bounds__(256) void dropbits_kernel(const uint64_t* rng, uint32_t stream_id, float rate, int T, long njobs, uint32_t* bits) {

@@ -1,8 +1,12 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_ops.py tests/test_gpu_engine.py -x -q -m gpu -k "gemm or engine" 2>&1 | tail -2
-KT_LINES=40 bash tools/ktrace.sh --workload recipe > gpurun_out/tnp_recipe.txt 2>&1
-grep -E "tn_gemm_kernel|reduce_rows" gpurun_out/tnp_recipe.txt | cut -c1-50,55-140; grep -o '"ms_per_step": [0-9.]*' gpurun_out/tnp_recipe.txt | head -1
-KT_LINES=40 bash tools/ktrace.sh > gpurun_out/tnp_head.txt 2>&1
-grep -E "tn_gemm_group|reduce_rows" gpurun_out/tnp_head.txt | cut -c1-50,55-140; grep -o '"ms_per_step": [0-9.]*' gpurun_out/tnp_head.txt | head -1
-python bench.py --workload recipe --steps 100 --warmup 20 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | cut -c1-400
+export EDGL_LIB_PATH=$GRAFT_REPO_ROOT/tools/variants/lib_kb.so
+python -m pytest tests/test_gpu_ops.py tests/test_gpu_coding.py -x -q -m gpu -k "bimau or keep_bits or dropout" 2>&1 | tail -2
+for v in base kb base kb; do
+  if [ $v = base ]; then unset EDGL_LIB_PATH; else export EDGL_LIB_PATH=$GRAFT_REPO_ROOT/tools/variants/lib_$v.so; fi
+  KT_LINES=40 bash tools/ktrace.sh > gpurun_out/kb_$v.txt 2>&1
+  echo "== $v"; grep -E "bimau_fwd|sweep" gpurun_out/kb_$v.txt | cut -c1-40,95-150
+  python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "
+import json,sys
+j=json.loads(sys.stdin.read()); print('$v', j['ms_per_step'], j['step_ms_hipevents']['median'])"
+done
