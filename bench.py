@@ -626,6 +626,11 @@ def extras(c, args, dev):
                                                note="whole_step_mfma_frac against the 157.3 TFLOP/s dense f32 MFMA peak")
     # the published recipe's shape (runme.sh:15-23) through the same engine: `python bench.py --workload recipe` prints it as a line
     out["recipe_runme_sh"] = dict(row(dict(RECIPE)), workload="num_units 512, 8 heads, seqslen 30, masklen 6, batch 512, num_items 17771")
+    # the reference's DEFAULT flags (main.py:35-38,44,60-66): 50 units in ONE head, 3 blocks, seqslen 30, masklen 6, batch 128, no
+    # dropout / regularisers — head dim 50 runs zero-padded to 64 channels, i.e. on the head-dim-64 kernels
+    out["reference_default_flags"] = dict(row(dict(c, num_units=50, num_heads=1, num_blocks=3, seqslen=30, masklen=6, batch=128, l2_reg=0.0,
+                                                   ct_reg=0.0, hidden_dropout_rate=0.0, attention_probs_dropout_rate=0.0)),
+                                          workload="num_units 50, 1 head, 3 blocks, seqslen 30, masklen 6, batch 128, num_items 20000")
     torch.cuda.empty_cache()
     a3 = copy.copy(args)
     a3.steps, a3.warmup = 50, 10
