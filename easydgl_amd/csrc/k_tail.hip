@@ -59,6 +59,9 @@ struct TailGeom {
     static_assert((size_t)MAXRT * 16 * LDF * sizeof(float) <= 2 * BUF, "f32 staging image exceeds two buffers");
     static constexpr size_t SMEM = 4 * BUF + 64 * sizeof(float);
     static constexpr size_t SMEM_BWD = SMEM + (size_t)(MAXRT * 16 + 512) * sizeof(int);   // + rowmap [112] + nextj, positions [<= 256 each]
+    // forward: + the parameter vectors bo | bout | g1 | b1 | g2 | b2 | g3 | b3 | bt | bi (2C)   (see "waits" in tail_fwd_kernel)
+    static constexpr int PAR_BO = 0, PAR_BOUT = 1, PAR_G1 = 2, PAR_B1 = 3, PAR_G2 = 4, PAR_B2 = 5, PAR_G3 = 6, PAR_B3 = 7, PAR_BT = 8, PAR_BI = 9;
+    static constexpr size_t SMEM_FWD = SMEM + (size_t)11 * C * sizeof(float);
 };
 
 // rows [0, T) of a [T, C] global tensor (row stride ld) -> LDS image [112][LD]; rows >= T are zero.  load() issues every
@@ -122,7 +125,7 @@ __device__ __forceinline__ void gelu_pass(const float* stg, const float* bias, b
     using G = TailGeom<CT>;
     static_assert(G::NTHR % G::CV == 0, "a thread's column group must not change from row to row");
     const int cv = threadIdx.x % G::CV;
-    const float4 b0 = *reinterpret_cast<const float4*>(bias + cv * 8), b1 = *reinterpret_cast<const float4*>(bias + cv * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + cv * 8), b1 = *reinterpret_cast<const float4*>(bias + cv * 8 + 4);   // (LDS)
 #pragma unroll 1
     for (int row = threadIdx.x / G::CV; row < MAXRT * 16; row += G::NTHR / G::CV) {
         const float4 x0 = *reinterpret_cast<const float4*>(stg + row * G::LDF + cv * 8);
@@ -171,6 +174,7 @@ __device__ __forceinline__ void tile_gemm(const WFrags<NKB>& wf, const bf16* Xs,
         }
         // at most two row tiles' operand reads in flight: unbounded, the scheduler hoists all 7 x NKB LDS reads (112+
         // registers) above the first MFMA
+        // (four or all seven tiles per batch: +-0, measured)
         if (rt & 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -244,21 +248,53 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
 
     PH_DECL
-    WFrags<NKB> wf = load_wfrags<NKB>(p.WoT + (long)n0 * C, C, lane);
+    // ---- waits ------------------------------------------------------------------------------------------------------------
+    // Loads and stores share ONE in-order counter (vmcnt) on this part: waiting for a load also waits for every store issued
+    // before it, and behind a store loop of run-time length the compiler can only wait for "everything".  As first written —
+    // parameter vectors loaded where they are used, weight fragments one product ahead — eight points of a sample waited for
+    // the store batch issued just before them (copy_out / the GELU pass: 28-56 KB per workgroup, all 256 workgroups at once).
+    // Now nothing is loaded in front of its use: every parameter vector is requested before the first store of the kernel,
+    // and a product's weight fragments at the START of the segment (the stretch between two store batches) BEFORE the one
+    // that uses them, with their wait pinned (touch_regs) to that segment's end — a whole segment after the last stores.
+    // (The parameter vectors wait in LDS, not in registers: 56 of them per lane spilled the 7-tile instance.)
+    // Measured: 68.5 -> 67 us.  The launch is not bound by its memory side at all — without the GELU passes' global stores
+    // (49 % of the bytes written) it takes 61.5 us — but by the serial chain of a workgroup's phases: three GELU passes
+    // (15 VALU + 2 transcendental instructions per element, ~35 % of a sample), six LDS-fed products (~27 %), the joint
+    // moments and copies.
+    float* par = red + 64;     // parameter vectors [11][C] (G::PAR_*)
+    if ((int)threadIdx.x < C) {
+        const int c = threadIdx.x;
+        const float* bt_or = p.head ? p.bt : p.bo;   // (head parameters: valid pointers to load from when there is no head)
+        const float *g3_or = p.head ? p.g3 : p.g1, *b3_or = p.head ? p.b3 : p.b1;
+        const float x0 = p.bo[c], x1 = p.bout[c], x2 = p.g1[c], x3 = p.b1[c], x4 = p.g2[c], x5 = p.b2[c], x6 = g3_or[c], x7 = b3_or[c],
+                    x8 = bt_or[c], x9 = p.bi[c], x10 = p.bi[C + c];
+        par[G::PAR_BO * C + c] = x0; par[G::PAR_BOUT * C + c] = x1; par[G::PAR_G1 * C + c] = x2; par[G::PAR_B1 * C + c] = x3;
+        par[G::PAR_G2 * C + c] = x4; par[G::PAR_B2 * C + c] = x5; par[G::PAR_G3 * C + c] = x6; par[G::PAR_B3 * C + c] = x7;
+        par[G::PAR_BT * C + c] = x8; par[G::PAR_BI * C + c] = x9; par[(G::PAR_BI + 1) * C + c] = x10;
+    }
+    // first round of the head's row gather (M * C / 8 vectors over the workgroup; later rounds load theirs in the loop)
+    int gat_t = 0; long gat_dst = -1;
+    if (p.head) {
+        const int v = min((int)threadIdx.x, p.M * G::CV - 1), j = v / G::CV;
+        const long src = (long)b * p.M + j;
+        gat_t = (int)p.mpos[src];
+        gat_dst = p.hmap ? (long)p.hmap[src] : src;
+    }
+    WFrags<NKB> wA = load_wfrags<NKB>(p.WoT + (long)n0 * C, C, lane);      // att_out dense
+    WFrags<NKB> wB = load_wfrags<NKB>(p.WiT + (long)n0 * C, C, lane);      // inner dense, first half
+    WFrags<NKB> wC;
     copy_in2<CT>(bufA, p.att + row0 * C, C, bufB, p.xin + row0 * p.ld_x, p.ld_x, T);
     lds_barrier();
     PH_MARK(0);   // inputs in LDS
     float z[MAXRT][4];
-    // ---- ao = att.Wo + bo ; z1 = drop(ao) + x_in (EasyDGL.py:113-115) -------------------------------------------------
+    // ---- segment A: ao = att.Wo + bo ; z1 = drop(ao) + x_in (EasyDGL.py:113-115) ------------------------------------------
     {
         f32x4 acc[MAXRT];
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        tile_gemm<CT, NKB>(wf, bufA, nrt, lane, acc);
-        wf = load_wfrags<NKB>(p.WiT + (long)n0 * C, C, lane);   // first half of the inner dense
-        EDGL_PIN();   // issued here, not sunk to their use
-        const float4 bb = *reinterpret_cast<const float4*>(p.bo + nl);
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+        tile_gemm<CT, NKB>(wA, bufA, nrt, lane, acc);
+        const float4 v_bo = *reinterpret_cast<const float4*>(par + G::PAR_BO * C + nl);
+        const float bv[4] = {v_bo.x, v_bo.y, v_bo.z, v_bo.w};
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
             if (rt < nrt) {
@@ -276,15 +312,17 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     }
     PH_MARK(1);   // G1 + epilogue
     lds_barrier();
+    touch_regs(wB);     // every load so far has arrived: stores may start
     copy_out<CT>(p.ao + row0 * C, C, bufS, T);
     PH_MARK(2);   // barrier + copy_out(ao)
-    // ---- a1 = LN1(z1) (EasyDGL.py:116) -> B, in place of the residual it consumed -----------------------------------------
+    // ---- segment B: a1 = LN1(z1) (EasyDGL.py:116) -> B, in place of the residual it consumed -------------------------------
+    wA = load_wfrags<NKB>(p.WoutT + (long)n0 * 2 * C, 2 * C, lane);        // out dense, first half of its inputs (segment D)
     {
         float mean, rstd;
         joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
         if (threadIdx.x == 0) { p.st1[2 * b] = mean; p.st1[2 * b + 1] = rstd; }
-        const float4 gg = *reinterpret_cast<const float4*>(p.g1 + nl), be = *reinterpret_cast<const float4*>(p.b1 + nl);
-        const float gv[4] = {gg.x, gg.y, gg.z, gg.w}, ev[4] = {be.x, be.y, be.z, be.w};
+        const float4 v_g = *reinterpret_cast<const float4*>(par + G::PAR_G1 * C + nl), v_b = *reinterpret_cast<const float4*>(par + G::PAR_B1 * C + nl);
+        const float gv[4] = {v_g.x, v_g.y, v_g.z, v_g.w}, ev[4] = {v_b.x, v_b.y, v_b.z, v_b.w};
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
             if (rt < nrt) {
@@ -296,38 +334,56 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     }
     PH_MARK(3);   // LN1
     lds_barrier();
+    touch_regs(wA);
     copy_out<CT>(p.a1 + row0 * C, C, bufB, T);
     PH_MARK(4);   // barrier + copy_out(a1)
     // ---- f = gelu(a1.Wi + bi) in two halves of C columns; o accumulates f.Wout half by half (EasyDGL.py:120-125) ----------
     f32x4 acc3[MAXRT];
+    // segment C: first half of the inner dense
+    wC = load_wfrags<NKB>(p.WiT + (long)(C + n0) * C, C, lane);            // inner dense, second half (segment D)
+    {
+        f32x4 acc[MAXRT];
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tile_gemm<CT, NKB>(wB, bufB, nrt, lane, acc);
+#pragma unroll
+        for (int rt = 0; rt < MAXRT; ++rt)   // all 7 tiles, unconditionally (tiles >= nrt hold zeros)
+            *reinterpret_cast<float4*>(stg + (rt * 16 + l15) * G::LDF + nl) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+    }
+    lds_barrier();
+    touch_regs(wC);
+    gelu_pass<CT>(stg, par + G::PAR_BI * C, p.pre_f + row0 * 2 * C, p.f + row0 * 2 * C, 2 * C, bufC, T);
+    PH_MARK(5);   // G2 half + GELU
+    lds_barrier();
+    // segment D: first half of the out dense, second half of the inner dense
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) acc3[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int h = 0; h < 2; ++h) {
-        {
-            f32x4 acc[MAXRT];
+    tile_gemm<CT, NKB>(wA, bufC, nrt, lane, acc3);
+    wA = load_wfrags<NKB>(p.WoutT + (long)n0 * 2 * C + C, 2 * C, lane);    // out dense, second half of its inputs (segment E; a third live set spills)
+    EDGL_PIN();
+    PH_MARK(6);   // G3 half
+    {
+        f32x4 acc[MAXRT];
 #pragma unroll
-            for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            tile_gemm<CT, NKB>(wf, bufB, nrt, lane, acc);
-            wf = load_wfrags<NKB>(p.WoutT + (long)n0 * 2 * C + h * C, 2 * C, lane);
-            EDGL_PIN();
+        for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tile_gemm<CT, NKB>(wC, bufB, nrt, lane, acc);
 #pragma unroll
-            for (int rt = 0; rt < MAXRT; ++rt)   // all 7 tiles, unconditionally (tiles >= nrt hold zeros)
-                *reinterpret_cast<float4*>(stg + (rt * 16 + l15) * G::LDF + nl) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
-        }
-        lds_barrier();   // (every wave is also past its reads of the previous half's f image)
-        gelu_pass<CT>(stg, p.bi + h * C, p.pre_f + row0 * 2 * C + h * C, p.f + row0 * 2 * C + h * C, 2 * C, bufC, T);
-        PH_MARK(5);   // G2 half + GELU
-        lds_barrier();
-        tile_gemm<CT, NKB>(wf, bufC, nrt, lane, acc3);
-        // next: second half of the inner dense, then the head transform (fetched even when this block has no head: cheap)
-        wf = h == 0 ? load_wfrags<NKB>(p.WiT + (long)(C + n0) * C, C, lane) : load_wfrags<NKB>(p.WtT + (long)n0 * C, C, lane);
-        EDGL_PIN();
-        PH_MARK(6);   // G3 half
+        for (int rt = 0; rt < MAXRT; ++rt)
+            *reinterpret_cast<float4*>(stg + (rt * 16 + l15) * G::LDF + nl) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
     }
+    lds_barrier();   // (every wave is also past its reads of the first half's f image)
+    touch_regs(wA);
+    gelu_pass<CT>(stg, par + (G::PAR_BI + 1) * C, p.pre_f + row0 * 2 * C + C, p.f + row0 * 2 * C + C, 2 * C, bufC, T);
+    PH_MARK(5);
+    lds_barrier();
+    // segment E: second half of the out dense
+    wB = load_wfrags<NKB>(p.WtT + (long)n0 * C, C, lane);                  // head transform (fetched even without a head: cheap)
+    tile_gemm<CT, NKB>(wA, bufC, nrt, lane, acc3);
+    PH_MARK(6);
     // ---- o = . + bout ; z2 = drop(o) + a1 ; y = LN2(z2) (EasyDGL.py:126-128) -> A ---------------------------------------------
     {
-        const float4 bb = *reinterpret_cast<const float4*>(p.bout + nl);
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+        const float4 v_bout = *reinterpret_cast<const float4*>(par + G::PAR_BOUT * C + nl);
+        const float bv[4] = {v_bout.x, v_bout.y, v_bout.z, v_bout.w};
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
             if (rt < nrt) {
@@ -344,13 +400,14 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
             }
     }
     lds_barrier();
+    touch_regs(wB);
     copy_out<CT>(p.o + row0 * C, C, bufS, T);
     {
         float mean, rstd;
         joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
         if (threadIdx.x == 0) { p.st2[2 * b] = mean; p.st2[2 * b + 1] = rstd; }
-        const float4 gg = *reinterpret_cast<const float4*>(p.g2 + nl), be = *reinterpret_cast<const float4*>(p.b2 + nl);
-        const float gv[4] = {gg.x, gg.y, gg.z, gg.w}, ev[4] = {be.x, be.y, be.z, be.w};
+        const float4 v_g = *reinterpret_cast<const float4*>(par + G::PAR_G2 * C + nl), v_b = *reinterpret_cast<const float4*>(par + G::PAR_B2 * C + nl);
+        const float gv[4] = {v_g.x, v_g.y, v_g.z, v_g.w}, ev[4] = {v_b.x, v_b.y, v_b.z, v_b.w};
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
             if (rt < nrt) {
@@ -372,14 +429,14 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
         f32x4 acc[MAXRT];
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        tile_gemm<CT, NKB>(wf, bufA, nrt, lane, acc);
+        tile_gemm<CT, NKB>(wB, bufA, nrt, lane, acc);
         lds_barrier();   // y (buffer A) is overwritten by the f32 image
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
             *reinterpret_cast<float4*>(stg + (rt * 16 + l15) * G::LDF + nl) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
     }
     lds_barrier();
-    gelu_pass<CT>(stg, p.bt, p.pre_t + row0 * C, p.so + row0 * C, C, bufC, T);
+    gelu_pass<CT>(stg, par + G::PAR_BT * C, p.pre_t + row0 * C, p.so + row0 * C, C, bufC, T);
     lds_barrier();
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt) ld_bf4(bufC + (rt * 16 + l15) * LD + nl, z[rt]);   // so, rounded through the activation dtype
@@ -387,8 +444,8 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
         float mean, rstd;
         joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
         if (threadIdx.x == 0) { p.st3[2 * b] = mean; p.st3[2 * b + 1] = rstd; }
-        const float4 gg = *reinterpret_cast<const float4*>(p.g3 + nl), be = *reinterpret_cast<const float4*>(p.b3 + nl);
-        const float gv[4] = {gg.x, gg.y, gg.z, gg.w}, ev[4] = {be.x, be.y, be.z, be.w};
+        const float4 v_g = *reinterpret_cast<const float4*>(par + G::PAR_G3 * C + nl), v_b = *reinterpret_cast<const float4*>(par + G::PAR_B3 * C + nl);
+        const float gv[4] = {v_g.x, v_g.y, v_g.z, v_g.w}, ev[4] = {v_b.x, v_b.y, v_b.z, v_b.w};
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
             if (rt < nrt) {
@@ -399,11 +456,15 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
             }
     }
     lds_barrier();
-    for (int v = threadIdx.x; v < p.M * G::CV; v += G::NTHR) {      // batch_gather of the masked positions (EasyDGL.py:142-143)
+    // batch_gather of the masked positions (EasyDGL.py:142-143); dst: row compaction of the scoring (edgl_compact_scan's `inv`)
+    if ((int)threadIdx.x < p.M * G::CV && gat_dst >= 0)
+        *reinterpret_cast<uint4*>(p.hrows + gat_dst * C + (threadIdx.x % G::CV) * 8) =
+            *reinterpret_cast<const uint4*>(bufB + gat_t * LD + (threadIdx.x % G::CV) * 8);
+    for (int v = threadIdx.x + G::NTHR; v < p.M * G::CV; v += G::NTHR) {
         const int j = v / G::CV, cv = v % G::CV;
         const long src = (long)b * p.M + j;
         const int t = (int)p.mpos[src];
-        const long dst = p.hmap ? (long)p.hmap[src] : src;         // row compaction of the scoring (edgl_compact_scan's `inv`)
+        const long dst = p.hmap ? (long)p.hmap[src] : src;
         if (dst >= 0) *reinterpret_cast<uint4*>(p.hrows + dst * C + cv * 8) = *reinterpret_cast<const uint4*>(bufB + t * LD + cv * 8);
     }
 #if defined(EDGL_PHASE_TIMING) && !defined(EDGL_PHASE_BWD)
@@ -834,7 +895,7 @@ extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const v
     const int nrt = (T + 15) / 16;
     auto k = C == 128 ? (nrt <= 2 ? tail_fwd_kernel<8, 2> : nrt <= 4 ? tail_fwd_kernel<8, 4> : tail_fwd_kernel<8, MAXRT>)
                       : (nrt <= 2 ? tail_fwd_kernel<4, 2> : nrt <= 4 ? tail_fwd_kernel<4, 4> : tail_fwd_kernel<4, MAXRT>);
-    const size_t smem = C == 128 ? TailGeom<8>::SMEM : TailGeom<4>::SMEM;
+    const size_t smem = C == 128 ? TailGeom<8>::SMEM_FWD : TailGeom<4>::SMEM_FWD;
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(k, dim3(B), dim3(C == 128 ? 512 : 256), smem, st, p);
     EDGL_LAUNCH_CHECK();

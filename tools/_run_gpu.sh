@@ -1,9 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > gpurun_out/pytest_gpu.txt
-cat gpurun_out/pytest_gpu.txt
-bash tools/refresh_profiles.sh > gpurun_out/refresh.log 2>&1
-bash tools/profile_mfma.sh > gpurun_out/mfma.log 2>&1
-cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/bench_default.log 2> gpurun_out/bench_default.err
-tail -1 gpurun_out/bench_default.log | cut -c1-600
+export EDGL_LIB_PATH=$GRAFT_REPO_ROOT/tools/variants/lib_twb4.so
+python -m pytest tests/test_gpu_engine.py -x -q -m gpu -k tail 2>&1 | tail -2
+for v in tw twb4 twb7 tw twb4 twb7; do
+  export EDGL_LIB_PATH=$GRAFT_REPO_ROOT/tools/variants/lib_$v.so
+  KT_LINES=12 bash tools/ktrace.sh > gpurun_out/tw_$v.txt 2>&1
+  echo "== $v"; grep -E "tail_fwd|tail_bwd" gpurun_out/tw_$v.txt | cut -c1-40,80-150
+done
