@@ -99,6 +99,10 @@ SIGNATURES = {
     "edgl_tpp_fwd_bwd_ex": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P, I, P]),
     "edgl_tpp_rows_workspace": (L, [I, I, I]),
     "edgl_tpp_fwd_bwd_rows": (I, [P, P, P, P, P, I, I, I, I, I, F, P, P, I, P, P]),
+    "edgl_tpp_prep_bytes": (L, [I, I, I]),
+    "edgl_tpp_prep": (I, [P, P, P, P, I, I, I, I, P, P]),
+    "edgl_bimau_bwd_tpp": (I, [P, P, P, P, P, P, P, I, P, F, P, P, P, I, I, I, I, I, F, P, U32, P, F, P, P, P, P, P, P, I, I, P]),
+    "edgl_tpp_finish_parts": (I, [P, I, F, I, P, I, I, I, P, P, I, P]),
     "edgl_adam_step": (I, [P, P, P, P, L, F, F, F, F, P, F, P, I, P, P]),
     "edgl_step_begin": (I, [P, P, F, F, F, P]),
     "edgl_adam_apply": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P]),

@@ -63,6 +63,11 @@ struct BwdP {
     int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
     const uint32_t* dbits;   // optional: keep bits of the attention dropout (edgl_bimau_dropbits, bimau_common.h)
     float qk_scale;          // score scale (0: 1 / sqrt(dh)); a zero-padded head of true width d < dh passes 1 / sqrt(d)
+    // optional (edgl_tpp_prep, bimau_common.h): sweep 1 recomputes the TPP regulariser's d lambda from the slot data instead of
+    // reading d_lam_ext; tpp_sums[4] (int) = next-event mark count of the batch (NULL: the sum of edgl_tpp_prep's per-sample counts),
+    // tpp_coef = ct_reg / H
+    const void* tpp_desc; int tpp_M; const float* tpp_sums; float tpp_coef;
+    float* tpp_part;   // [B*H, 2]: the wave's share of the regulariser's two loss sums (sum log event intensity | sum non-event term)
 };
 
 template <typename T>
@@ -80,7 +85,8 @@ __device__ __forceinline__ void st_frag(T* dst, const f32x4& a) {
 // FL: -1 = MAU_CAUSAL / MAU_NO_DIAG read from p.flags at run time; 0 = the BiMAU configuration compiled in (bidirectional,
 // diagonal set): no per-element causal compares / selects in the softmax, the diagonal as one select on a scalar-and-ed mask
 // DB: stored keep bits of the attention dropout instead of the hash (same decisions: bimau_common.h)
-template <typename T, int DT, int NT, int EC, bool PREF = true, int FL = -1, bool DB = false>
+// TP: d lambda of the TPP regulariser recomputed from p.tpp_desc (bimau_common.h) instead of loaded from p.d_lam_ext
+template <typename T, int DT, int NT, int EC, bool PREF = true, int FL = -1, bool DB = false, bool TP = false>
 __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (forcing 3 waves / SIMD: 83 spilled registers, 76 -> 239 us)
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -136,9 +142,25 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
     // so that the prefetch is straight-line code: with per-lane branches around them the wait-count insertion falls
     // back to near-zero counts and every iteration would stall on the loads it has just issued.  Lanes past the end of
     // the sequence (or marks >= E) are zeroed when the values are consumed.
-    struct QOps { Frag4<T> qf[DT], dof[DT]; float4 z; float lam[4], dlx[4]; uint32_t kb; };
+    struct QOps { Frag4<T> qf[DT], dof[DT]; float4 z; float lam[4], dlx[4]; uint32_t kb; uint32_t nmw; float spr; };
     const float* dlx_src = p.d_lam_ext ? p.d_lam_ext : p.lam;   // always a readable [rows, E] array
     const float dlx_on = p.d_lam_ext ? 1.0f : 0.0f;
+    TppDesc td{};
+    int tp_novf = 0;
+    float tp_k = 0.f, tp_a = 0.f, tp_b = 0.f;
+    if constexpr (TP) {
+        td = tpp_desc(p.tpp_desc, p.B, p.T, p.tpp_M);
+        tp_novf = __builtin_amdgcn_readfirstlane(td.novf[b]);
+        int cnt;    // the regulariser's normaliser: given (edgl_tpp_norm / a data-parallel all-reduce), or the sum of the samples' counts
+        if (p.tpp_sums) {
+            cnt = reinterpret_cast<const int*>(p.tpp_sums)[4];
+        } else {
+            cnt = 0;
+            for (int i = lane; i < p.B; i += 64) cnt += td.cntp[i];
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        }
+        tp_k = -p.tpp_coef / ((float)cnt * (float)p.H);   // temporal.py:331-332
+    }
     auto load_q = [&](int qt) {
         QOps o;
         const int q = min(qt * 16 + l15, p.T - 1);
@@ -150,7 +172,13 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         }
         o.z = *reinterpret_cast<const float4*>(p.z + row * EP + g4);
         if constexpr (DB) o.kb = p.dbits[(bp * NT + qt) * 64 + lane];
-        if constexpr (EC == 16) {   // one 16-byte load each
+        if constexpr (TP) {   // slot data of the row's position instead of a d lambda row
+            const float4 l4 = *reinterpret_cast<const float4*>(p.lam + row * EC + g4);
+            o.lam[0] = l4.x; o.lam[1] = l4.y; o.lam[2] = l4.z; o.lam[3] = l4.w;
+            o.dlx[0] = 0.f; o.dlx[1] = 0.f; o.dlx[2] = 0.f; o.dlx[3] = 0.f;
+            o.nmw = td.nmw[((long)b * p.T + q) * 4 + (lane >> 4)];
+            o.spr = td.spr[(long)b * p.T + q];
+        } else if constexpr (EC == 16) {   // one 16-byte load each
             const float4 l4 = *reinterpret_cast<const float4*>(p.lam + row * EC + g4), d4 = *reinterpret_cast<const float4*>(dlx_src + row * EC + g4);
             o.lam[0] = l4.x; o.lam[1] = l4.y; o.lam[2] = l4.z; o.lam[3] = l4.w;
             o.dlx[0] = d4.x; o.dlx[1] = d4.y; o.dlx[2] = d4.z; o.dlx[3] = d4.w;
@@ -197,6 +225,17 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         if constexpr (PREF) qnext = load_q(qt + 1 < NT ? qt + 1 : qt);
         asm volatile("" ::: "memory");   // the prefetch loads stay here (otherwise they are sunk to their use at the loop end)
         mask_q(qcur, qok);
+        if constexpr (TP) {   // d lambda of the TPP regulariser at the masked positions among these rows (temporal.py:317-333)
+            float gr[4] = {0.f, 0.f, 0.f, 0.f};
+            tpp_slot(qcur.lam, qcur.nmw, qcur.spr, qok && qcur.spr >= 0.f, tp_k, gr, tp_a, tp_b);
+            for (int j = 0; j < tp_novf; ++j) {   // further slots on an already taken position (normally none)
+                const int tj = td.ovf_pos[(long)b * td.M + j];
+                if ((tj >> 4) != qt) continue;
+                tpp_slot(qcur.lam, td.ovf_nm[((long)b * td.M + j) * 4 + (lane >> 4)], qcur.spr, qok && q == tj, tp_k, gr, tp_a, tp_b);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qcur.dlx[i] = gr[i];
+        }
         const float zq4[4] = {qcur.z.x, qcur.z.y, qcur.z.z, qcur.z.w};
         // ---- recompute S, P --------------------------------------------------------------------------------------
         f32x4 s[NT];
@@ -302,7 +341,14 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
         dsc_acc[i] = v;
     }
+    if constexpr (TP) {   // the wave's share of the two loss sums (every lane of a row's four holds the row's terms: one lane writes)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { tp_a += __shfl_xor(tp_a, o, 64); tp_b += __shfl_xor(tp_b, o, 64); }
+    }
     flush_pending();
+    if constexpr (TP) {
+        if (lane == 0) *reinterpret_cast<float2*>(p.tpp_part + job * 2) = make_float2(tp_a, tp_b);
+    }
     if (l15 == 0) *reinterpret_cast<float4*>(p.dsc_part + job * EP + g4) = make_float4(dsc_acc[0], dsc_acc[1], dsc_acc[2], dsc_acc[3]);
     // ---- write dV (L(first=v, second=k): 4 consecutive channels of key row k) -----------------------------------------
 #pragma unroll

@@ -360,6 +360,74 @@ __global__ __launch_bounds__(256) void dropbits_kernel(const uint64_t* rng, uint
     bits[job * 64 + lane] = w;
 }
 
+// ---- TPP regulariser inside the attention kernels (MAU.biased_likelihood, temporal.py:317-333; EasyDGL.py:157-175) ------------
+// The regulariser reads lambda at the masked positions only, and lambda of a query tile is in registers in sweep 1 (qcur.lam:
+// lane group G owns marks 4G .. 4G+3 of query row lane&15).  With the slot data
+// of a position prepared per (b, t) by edgl_tpp_prep — the 16 next-mark bytes of the position's first effective slot (a slot
+// whose label has at least one mark), the raw-second span (negative: the position carries no effective slot) — sweep 1 forms
+// its wave's share of the two loss sums and computes d lambda of the term in place of loading it: no [H*B, T, E] f32 d lambda
+// array (26 MB written and read at the headline shape) and no TPP launch on the step's main stream.
+// A position drawn into several effective slots (padding slots whose label row is not empty, hand-made batches) keeps its
+// first slot in the per-position arrays and the others in a per-sample overflow list that both kernels walk (normally empty).
+struct TppDesc {
+    const uint32_t* nmw;      // [B, T, 4]  next-mark bytes of the first effective slot (mark e = byte e & 3 of word e >> 2)
+    const float* spr;         // [B, T]     raw span (EasyDGL.py:161-162), or -1: no effective slot at this position
+    const int32_t* novf;      // [B]        overflow slots of the sample
+    const int32_t* ovf_pos;   // [B, M]     their positions
+    const uint32_t* ovf_nm;   // [B, M, 4]  their next-mark bytes
+    const int32_t* cntp;      // [B]        marks of ALL labels of the sample: their sum is the regulariser's normaliser (temporal.py:330)
+    int M;
+};
+struct TppLayout { size_t off_spr, off_novf, off_ovf_pos, off_ovf_nm, off_cntp, bytes; };
+__host__ __device__ inline TppLayout tpp_layout(int B, int T, int M) {
+    TppLayout l;
+    l.off_spr = (size_t)B * T * 16;
+    l.off_novf = l.off_spr + (size_t)B * T * 4;
+    l.off_ovf_pos = (l.off_novf + (size_t)B * 4 + 15) & ~(size_t)15;
+    l.off_ovf_nm = (l.off_ovf_pos + (size_t)B * M * 4 + 15) & ~(size_t)15;
+    l.off_cntp = l.off_ovf_nm + (size_t)B * M * 16;      // per-sample mark counts (edgl_tpp_prep's normaliser)
+    l.bytes = l.off_cntp + (((size_t)B * 4 + 15) & ~(size_t)15);
+    return l;
+}
+__host__ __device__ inline TppDesc tpp_desc(const void* base, int B, int T, int M) {
+    const TppLayout l = tpp_layout(B, T, M);
+    const char* c = reinterpret_cast<const char*>(base);
+    return TppDesc{reinterpret_cast<const uint32_t*>(c), reinterpret_cast<const float*>(c + l.off_spr),
+                   reinterpret_cast<const int32_t*>(c + l.off_novf), reinterpret_cast<const int32_t*>(c + l.off_ovf_pos),
+                   reinterpret_cast<const uint32_t*>(c + l.off_ovf_nm), reinterpret_cast<const int32_t*>(c + l.off_cntp), M};
+}
+__device__ __forceinline__ void tpp_bytes(uint32_t w, float (&f)[4]) {
+    f[0] = (float)(w & 0xffu); f[1] = (float)((w >> 8) & 0xffu);      // v_cvt_f32_ubyte0 .. 3
+    f[2] = (float)((w >> 16) & 0xffu); f[3] = (float)(w >> 24);
+}
+// sums of two per-lane partials over the 4 lane groups, both results in every lane (three row swaps instead of four)
+__device__ __forceinline__ void group_sum4_pair(float& x, float& y) {
+    const FPair p = swap16(x, y);          // {x0, y0, x2, y2}, {x1, y1, x3, y3}
+    const float t = p.first + p.second;    // rows 0, 2: pair sums of x; rows 1, 3: of y
+    const FPair q = swap32(t, t);          // {t0, t1, t0, t1}, {t2, t3, t2, t3}
+    const float u = q.first + q.second;    // even rows: sum of x; odd rows: sum of y
+    const FPair r = swap16(u, u);          // {u0, u0, u2, u2}, {u1, u1, u3, u3}
+    x = r.first; y = r.second;
+}
+// One slot of the regulariser on this lane's row (`on`: the row carries the slot and lies inside the sequence; lam4 = this lane's
+// four lambda values): a += log(event intensity), bs += entire intensity * span / 2 (temporal.py:322-328) — every lane of a row's
+// four ends with the row's terms — and the gradient  gr[i] += k (nm[e] / ev - span / 2),  k = -coef / (count H)  (temporal.py:331-332)
+__device__ __forceinline__ void tpp_slot(const float (&lam4)[4], uint32_t w, float sp, bool on, float k, float (&gr)[4], float& a, float& bs) {
+    float f[4];
+    tpp_bytes(w, f);
+    float ev = lam4[0] * f[0], ent = lam4[0] + lam4[1];
+    ev = fmaf(lam4[1], f[1], ev); ev = fmaf(lam4[2], f[2], ev); ev = fmaf(lam4[3], f[3], ev);
+    ent += lam4[2] + lam4[3];
+    group_sum4_pair(ev, ent);
+    ev = on ? ev : 0.f;
+    const float hs = sp * 0.5f, kg = on ? k : 0.f;
+    a += __logf(ev == 0.f ? 1.f : ev);
+    bs = fmaf(on ? ent : 0.f, hs, bs);
+    const float iev = ev != 0.f ? fast_rcp(ev) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gr[i] = fmaf(kg, fmaf(f[i], iev, -hs), gr[i]);
+}
+
 // reduce-scatter of 16 per-lane partials over the 4 lane groups: on return lane group g holds the
 // complete sums for e = 4g + i (i = 0..3) — exactly the MFMA B-operand layout lambda^T[e][q].
 __device__ __forceinline__ void reduce_scatter16(const float (&z)[16], float (&out)[4], int lane) {

@@ -5,6 +5,7 @@
 #include <cstdio>
 
 #include "edgl_common.h"
+#include "bimau_common.h"   // TppDesc / tpp_layout: slot data of the fused TPP form
 
 namespace {
 thread_local char g_err[512] = "";
@@ -451,6 +452,66 @@ __global__ __launch_bounds__(256) void tpp_rows_wide_kernel(TppP p, const float*
     a = block_sum(a, red); bsum = block_sum(bsum, red);
     if (threadIdx.x == 0) { part[blockIdx.x * 2] = a; part[blockIdx.x * 2 + 1] = bsum; }
 }
+// Slot data of the fused TPP form (bimau_common.h: TppDesc): one workgroup per sample, one thread per masked slot.  A slot is
+// EFFECTIVE when its position lies inside the sequence and its label's mark row is not empty (sign(sum nm) = 1, temporal.py:321) —
+// the others add nothing to the regulariser or its gradient.  The first effective slot of a position fills the per-position
+// arrays, further ones go to the sample's overflow list in slot order.  Labels, positions and timestamps only: runs ahead of
+// the step's forward on a side stream.  E = 16 (one 16-byte mark row per label), M <= 256.
+// Also the regulariser's normaliser, the mark count of ALL labels of the batch (temporal.py:330; what edgl_tpp_norm computes), as
+// per-sample counts cntp[B] — every workgroup has its sample's mark rows in registers anyway; the consumers (one wave per (b, head) in
+// sweep 1, the final reduction) add the B numbers up themselves: no launch, no memset, no atomics for it.
+__global__ __launch_bounds__(256) void tpp_prep_kernel(const int64_t* mpos, const int64_t* labels, const float* ts, const uint8_t* mtab,
+                                                       int B, int T, int M, char* desc) {
+    extern __shared__ __attribute__((aligned(16))) char tpp_smem[];
+    uint4* nm_s = reinterpret_cast<uint4*>(tpp_smem);                 // [T] mark rows of the positions' first effective slots
+    int* pos_s = reinterpret_cast<int*>(nm_s + T);                    // [256] position of an effective slot, -1 otherwise
+    int* ovf_s = pos_s + 256;                                         // [256] 1: effective, not the first of its position
+    const bimau::TppLayout lay = bimau::tpp_layout(B, T, M);
+    const int b = blockIdx.x, m = threadIdx.x;
+    for (int t = m; t < T; t += 256) nm_s[t] = make_uint4(0u, 0u, 0u, 0u);
+    int pos = -1;
+    uint4 nm = make_uint4(0u, 0u, 0u, 0u);
+    if (m < M) {
+        const int pin = (int)mpos[(long)b * M + m];
+        const int64_t lab = labels[(long)b * M + m];
+        nm = *reinterpret_cast<const uint4*>(mtab + lab * 16);
+        if (pin >= 0 && pin < T && (nm.x | nm.y | nm.z | nm.w) != 0u) pos = pin;
+    }
+    pos_s[m] = pos;
+    {   // marks of this slot's label (valid position or not, as edgl_tpp_norm counts them)
+        const uint32_t ws[4] = {nm.x, nm.y, nm.z, nm.w};
+        int c = 0;
+        if (m < M) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c += (int)((ws[q] & 0xffu) + ((ws[q] >> 8) & 0xffu) + ((ws[q] >> 16) & 0xffu) + (ws[q] >> 24));
+        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((m & 63) == 0) ovf_s[m >> 6] = c;     // (ovf_s is written for real behind the next barrier)
+    }
+    __syncthreads();
+    const int cnt_b = ovf_s[0] + ovf_s[1] + ovf_s[2] + ovf_s[3];
+    __syncthreads();
+    bool first = pos >= 0;
+    for (int q = 0; q < m; ++q) first = first && pos_s[q] != pos;
+    ovf_s[m] = (pos >= 0 && !first) ? 1 : 0;
+    if (pos >= 0 && first) nm_s[pos] = nm;
+    __syncthreads();
+    uint4* nmw = reinterpret_cast<uint4*>(desc) + (long)b * T;
+    float* spr = reinterpret_cast<float*>(desc + lay.off_spr) + (long)b * T;
+    for (int t = m; t < T; t += 256) {
+        const uint4 w = nm_s[t];
+        nmw[t] = w;
+        spr[t] = (w.x | w.y | w.z | w.w) != 0u ? raw_span(ts + (long)b * T, t, T) : -1.0f;
+    }
+    int rank = 0, total = 0;
+    for (int q = 0; q < M; ++q) { rank += q < m ? ovf_s[q] : 0; total += ovf_s[q]; }
+    if (m == 0) reinterpret_cast<int*>(desc + lay.off_novf)[b] = total;
+    if (m < M && ovf_s[m]) {
+        reinterpret_cast<int*>(desc + lay.off_ovf_pos)[(long)b * M + rank] = pos;
+        reinterpret_cast<uint4*>(desc + lay.off_ovf_nm)[(long)b * M + rank] = nm;
+    }
+    if (m == 0) reinterpret_cast<int*>(desc + lay.off_cntp)[b] = cnt_b;
+}
 __global__ __launch_bounds__(256) void tpp_final2_kernel(const float* part, int nblk, float coef, int H, float* sums, float* reg_out,
                                                          int accumulate) {
     // one workgroup: thread i adds partials i, i+256, ... in index order, then the fixed block_sum tree — deterministic
@@ -464,6 +525,45 @@ __global__ __launch_bounds__(256) void tpp_final2_kernel(const float* part, int 
     const float reg = coef * (-(a - b) / c);  // temporal.py:331-332, EasyDGL.py:175
     reg_out[0] = accumulate ? reg_out[0] + reg : reg;
     reinterpret_cast<int*>(sums)[4] = 0;   // normaliser accumulator back to zero for the next call
+}
+
+// tpp_final2_kernel for the per-(b, head) partial sums of the fused form (thousands of pairs): 1024 threads, every thread's loads
+// in flight together (the 256-thread loop above takes them one round trip at a time), the same fixed summation order per launch
+// shape; the count slot is NOT cleared (sweep 1 of the same step reads it; edgl_tpp_norm stores it afresh every step).
+__global__ __launch_bounds__(1024) void tpp_parts_kernel(const float* part, int nparts, float coef, int H, const int* cntp, int ncnt,
+                                                         float* sums, float* reg_out, int accumulate) {
+    __shared__ float red[16];
+    __shared__ int redi[16];
+    if (cntp) {   // normaliser from the per-sample counts of edgl_tpp_prep (otherwise sums[4] holds it: edgl_tpp_norm, data parallel)
+        int c = 0;
+        for (int i = threadIdx.x; i < ncnt; i += 1024) c += cntp[i];
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((threadIdx.x & 63) == 0) redi[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int i = 0; i < 16; ++i) t += redi[i];
+            reinterpret_cast<int*>(sums)[4] = t;
+        }
+        __syncthreads();
+    }
+    float a = 0.f, b = 0.f;
+    for (int i0 = threadIdx.x; i0 < nparts; i0 += 1024 * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const float2*>(part)[min(i0 + j * 1024, nparts - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j].x), "+v"(v[j].y));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j * 1024 < nparts) { a += v[j].x; b += v[j].y; }
+    }
+    a = block_sum(a, red); b = block_sum(b, red);
+    if (threadIdx.x != 0) return;
+    const float c = (float)reinterpret_cast<const int*>(sums)[4] * (float)H;
+    sums[0] = a; sums[1] = b; sums[2] = c;
+    const float reg = coef * (-(a - b) / c);  // temporal.py:331-332, EasyDGL.py:175
+    reg_out[0] = accumulate ? reg_out[0] + reg : reg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -882,6 +982,39 @@ extern "C" int edgl_tpp_fwd_bwd_rows(const float* lam, const int64_t* masked_pos
     }
     EDGL_LAUNCH_CHECK();
     hipLaunchKernelGGL(tpp_final2_kernel, dim3(1), dim3(256), 0, st, sums + 8, nblk, coef, H, sums, reg_out, accumulate);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+// ---- fused TPP form: the regulariser inside the attention kernels (bimau_common.h: TppDesc) -----------------------------------
+extern "C" long edgl_tpp_prep_bytes(int B, int T, int M) {
+    return (B > 0 && T > 0 && M > 0) ? (long)bimau::tpp_layout(B, T, M).bytes : -1;
+}
+// slot data of one batch for edgl_bimau_bwd_tpp: `desc` = edgl_tpp_prep_bytes(B, T, M) bytes, 16-byte aligned
+extern "C" int edgl_tpp_prep(const int64_t* masked_pos, const int64_t* labels, const float* ts_raw, const uint8_t* mark_table,
+                             int B, int T, int E, int M, void* desc, void* stream) {
+    EDGL_REQUIRE(masked_pos && labels && ts_raw && mark_table && desc, EDGL_ERR_NULL, "edgl_tpp_prep: null pointer");
+    EDGL_REQUIRE(B > 0 && T > 0 && T <= 2048 && E == 16 && M > 0 && M <= 256, EDGL_ERR_SHAPE,
+                 "edgl_tpp_prep: bad shape B=%d T=%d E=%d M=%d (E = 16, M <= 256, T <= 2048)", B, T, E, M);
+    EDGL_REQUIRE((((uintptr_t)mark_table | (uintptr_t)desc) & 15) == 0, EDGL_ERR_SHAPE, "edgl_tpp_prep: mark_table / desc must be 16-byte aligned");
+    const size_t smem = (size_t)T * 16 + 2 * 256 * sizeof(int);
+    hipLaunchKernelGGL(tpp_prep_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, masked_pos, labels, ts_raw, mark_table, B, T, M,
+                       (char*)desc);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+// reduction of the per-(b, head) partial sums edgl_bimau_bwd_tpp left in `part` ([nparts, 2]) into the regulariser
+// reg_out (=|+=) coef * (-(sum log ev - sum non-event) / (count * H))  (temporal.py:331-332, EasyDGL.py:175); `sums` = the array
+// edgl_tpp_norm wrote the batch's mark count into (sums[0..2] receive the two sums and the normaliser, as edgl_tpp_fwd_bwd leaves
+// them).  The normaliser: tpp_desc != NULL — the per-sample counts of edgl_tpp_prep(B, T, M), whose total also goes to sums[4];
+// tpp_desc == NULL — sums[4] as edgl_tpp_norm (or a data-parallel all-reduce) left it; the slot is not cleared.
+extern "C" int edgl_tpp_finish_parts(const float* part, int nparts, float coef, int H, const void* tpp_desc, int B, int T, int M,
+                                     float* sums, float* reg_out, int accumulate, void* stream) {
+    EDGL_REQUIRE(part && sums && reg_out, EDGL_ERR_NULL, "edgl_tpp_finish_parts: null pointer");
+    EDGL_REQUIRE(nparts > 0 && H > 0 && (!tpp_desc || (B > 0 && T > 0 && M > 0)), EDGL_ERR_SHAPE,
+                 "edgl_tpp_finish_parts: bad shape nparts=%d H=%d B=%d T=%d M=%d", nparts, H, B, T, M);
+    const int* cntp = tpp_desc ? reinterpret_cast<const int*>((const char*)tpp_desc + bimau::tpp_layout(B, T, M).off_cntp) : nullptr;
+    hipLaunchKernelGGL(tpp_parts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, nparts, coef, H, cntp, B, sums, reg_out,
+                       accumulate);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

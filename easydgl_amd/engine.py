@@ -56,6 +56,12 @@ class TrainEngine:
         self.R = B * M
         self.rows = B * T
         nb = len(m.layers)
+        # TPP regulariser inside the attention kernels (csrc/bimau_common.h TppDesc): the forward forms the two loss sums from the
+        # lambda rows it holds in registers, sweep 1 recomputes d lambda — no [H*B, T, E] d lambda array, no TPP launch between the
+        # attention forward and the block tail (the loss kernel needs the term at the end of the backward only: flash_ce form)
+        fce = (os.environ.get("EDGL_FLASH_CE", "1") != "0") if flash_ce is None else bool(flash_ce)
+        self.fused_tpp = (self.code == _lib.BF16 and C // H == 16 and E == 16 and not self.mgroups and M <= 256 and T <= 128
+                          and m.ct_reg != 0.0 and fce and nb > 0 and os.environ.get("EDGL_TPP_FUSED", "1") != "0")
         e = lambda *s, dtype=None: torch.empty(s, device=dev, dtype=dtype or self.dt)  # noqa: E731
         f32 = torch.float32
         # ---- static inputs ----------------------------------------------------------------------------------
@@ -74,7 +80,8 @@ class TrainEngine:
                      st2=e(B, 2, dtype=f32),
                      pack=e(0 if self.mgroups else lib.edgl_bimau_pack_bytes(C, H, E, self.code), dtype=torch.uint8),
                      saved=e(0 if self.mgroups else lib.edgl_bimau_saved_bytes(B, T, C, H, self.code), dtype=torch.uint8),
-                     dlam=e(H * B, T, E, dtype=f32),
+                     dlam=None if self.fused_tpp else e(H * B, T, E, dtype=f32),
+                     tpp_part=torch.zeros((B * H, 2), device=dev, dtype=f32) if self.fused_tpp else None,
                      tpp=torch.zeros(max(lib.edgl_tpp_workspace(), lib.edgl_tpp_rows_workspace(B, H, M)), device=dev, dtype=f32))
             # stored keep bits of the attention dropout: hashed once per step on the side stream, read by the forward and both
             # backward sweeps (csrc/bimau_common.h; 0 bytes = no stored-bits form at this T)
@@ -92,6 +99,7 @@ class TrainEngine:
                         lam=e(H * B, T, eg, dtype=f32), dlam=e(H * B, T, eg, dtype=f32),
                         out=e(B, T, C) if e0 else None, dqkvt=e(B, T, 4 * C) if e0 else None))
             self.blk.append(d)
+        self.tpp_desc = torch.zeros(int(lib.edgl_tpp_prep_bytes(B, T, M)), device=dev, dtype=torch.uint8) if self.fused_tpp else None
         self.zero_resid = torch.zeros((B, T, C), device=dev, dtype=self.dt) if self.mgroups else None
         self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
         # fused per-sample block tail (csrc/k_tail.hip): one launch for dense -> LN -> GELU-dense -> dense -> LN (-> head)
@@ -241,19 +249,33 @@ class TrainEngine:
             # (512-unit recipe: 5 .. 516 us, the main stream waiting for it at the join)
             check(lib.edgl_compact_scan_labels(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid),
                                                _ptr(self.labels_c), side2.cuda_stream), "edgl_compact_scan_labels")
+            if self.fused_tpp:
+                # slot data of the batch for the regulariser inside sweep 1 of the attention backward (labels / positions only), with
+                # the per-sample mark counts whose total is the regulariser's normaliser (data parallel: the all-reduced count of
+                # _global_counts is used instead).  Behind the scan: this stream is joined in front of the first attention kernel.
+                check(lib.edgl_tpp_prep(_ptr(self.mpos), _ptr(self.labels), _ptr(self.ts), _ptr(m.mark_lookup_table), B, T, E, M,
+                                        _ptr(self.tpp_desc), side2.cuda_stream), "edgl_tpp_prep")
 
         def l2_term():
             if m.l2_reg != 0.0:
                 check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss_aux), 0,
                                        _ptr(self.ws_l2), sst), "edgl_l2_loss")
 
+        # The fused TPP form has no normaliser launch in this chain (edgl_tpp_prep on the other side stream leaves per-sample counts)
+        split = self.fused_tpp and not legacy
         with torch.cuda.stream(side):
             # needed by the first BiMAU forward (the one join of the forward): TPP normaliser (labels only), weight packs, keep bits
-            for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
-                att = blk.attention
-                if m.ct_reg != 0.0 and not self._dp:    # (data parallel: _global_counts put the all-reduced count there)
+            def late(i, blk, b):
+                if m.ct_reg != 0.0 and not self._dp and not split:    # (data parallel: _global_counts put the all-reduced count there)
                     check(lib.edgl_tpp_norm(_ptr(self.labels), _ptr(m.mark_lookup_table), B, M, E, _ptr(b["tpp"]), sst),
                           "edgl_tpp_norm")
+                if self.fused_tail:
+                    check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
+                                             _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
+                                             _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
+            for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
+                att = blk.attention
+                late(i, blk, b)
                 if self.mgroups:
                     dh = C // H
                     for (e0, e1), gb in zip(self.mgroups, b["grp"]):
@@ -263,10 +285,6 @@ class TrainEngine:
                 else:
                     check(lib.edgl_bimau_pack(_ptr(att.st_kernel), _ptr(att.st_bias), _ptr(att.weight), _ptr(att.scaling), C, H, E,
                                               _ptr(b["pack"]), code, sst), "edgl_bimau_pack")
-                if self.fused_tail:
-                    check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
-                                             _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
-                                             _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
                 if b["dbits"] is not None and not legacy:
                     check(lib.edgl_bimau_dropbits(B, T, H, float(ad), _ptr(m._rng_state), 10 + 4 * i, _ptr(b["dbits"]), sst),
                           "edgl_bimau_dropbits")
@@ -302,8 +320,8 @@ class TrainEngine:
                 check(lib.edgl_bimau_fwd_db(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
                                             _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]),
                                             self.qk_scale, _ptr(b["att"]), _ptr(b["lam"]), _ptr(b["saved"]),
-                                            _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, 0, code, st), "edgl_bimau_fwd_db")
-            if m.ct_reg != 0.0:   # TPP regulariser of this block: loss term and d lambda (two small launches)
+                                            _ptr(b["dlam"]) if (m.ct_reg != 0.0 and not self.fused_tpp) else None, 0, code, st), "edgl_bimau_fwd_db")
+            if m.ct_reg != 0.0 and not self.fused_tpp:   # TPP regulariser of this block: loss term and d lambda (two small launches)
                 check(lib.edgl_tpp_fwd_bwd_rows(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
                                                 _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
                                                 _ptr(self.loss_tpp), 1 if i > 0 else 0, _ptr(b["dlam"]), st), "edgl_tpp_fwd_bwd_rows")
@@ -466,6 +484,15 @@ class TrainEngine:
             da = drop(ad, 10 + 4 * i)
             if self.mgroups:
                 self._attention_bwd_groups(att, b, da, st)
+            elif self.fused_tpp:
+                check(lib.edgl_bimau_bwd_tpp(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
+                                             _ptr(self.G2), _ptr(self.tpp_desc), M, _ptr(b["tpp"]) if self._dp else None, float(m.ct_reg / H), _ptr(b["tpp_part"]),
+                                             _ptr(b["lam"]), _ptr(b["saved"]), B, T, C, H, E,
+                                             float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), self.qk_scale, _ptr(self.G4c),
+                                             _ptr(att.st_kernel.grad), _ptr(att.st_bias.grad), _ptr(att.weight.grad),
+                                             _ptr(att.scaling.grad),
+                                             _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), 0, code, st),
+                      "edgl_bimau_bwd_tpp")
             else:
                 check(lib.edgl_bimau_bwd_db(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
                                             _ptr(self.G2), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, _ptr(b["lam"]),
@@ -484,6 +511,12 @@ class TrainEngine:
                 # every slab reduction queued so far (weight-gradient GEMMs, BiMAU / LayerNorm partials) runs on the side
                 # stream under the embedding backward, whose atomics leave the CUs mostly idle
                 self.side.wait_stream(torch.cuda.current_stream())
+                if self.fused_tpp:    # the regulariser from the forward's partial sums, block by block (every sweep 1 has read its count)
+                    for j, bj in enumerate(self.blk):
+                        check(lib.edgl_tpp_finish_parts(_ptr(bj["tpp_part"]), B * H, float(m.ct_reg / H), H,
+                                                        None if self._dp else _ptr(self.tpp_desc), B, T, M, _ptr(bj["tpp"]),
+                                                        _ptr(self.loss_tpp), 1 if j > 0 else 0, self.side.cuda_stream),
+                              "edgl_tpp_finish_parts")
                 if self._pending_loss is not None:
                     self._pending_loss(self.side.cuda_stream)
                     self._pending_loss = None

@@ -451,6 +451,31 @@ int edgl_tpp_fwd_bwd_rows(const float* lam, const int64_t* masked_pos, const int
                           const uint8_t* mark_table, int B, int T, int H, int E, int M, float coef, float* sums,
                           float* reg_out, int accumulate, float* d_lam, void* stream);   /* E <= 256 (E > 16: plain loops over the marks) */
 
+/* Fused TPP form (bf16, head dim 16, E = 16, T <= 128, M <= 256): the regulariser of MAU.biased_likelihood (temporal.py:317-333)
+ * evaluated at the masked positions (EasyDGL.py:157-175) INSIDE sweep 1 of the attention backward, which holds lambda in registers —
+ * no [H*B,T,E] d lambda array and no TPP launch between the attention forward and the block tail (the forward runs as
+ * edgl_bimau_fwd_db with zero_rows = NULL).
+ *   edgl_tpp_prep         slot data of a batch (labels / positions / raw timestamps only, runs ahead of the forward): per position
+ *                         the next-mark bytes of its first effective slot (a slot whose label's mark row is not empty:
+ *                         temporal.py:321) and the raw span (EasyDGL.py:161-162), further effective slots of a taken position
+ *                         in a per-sample overflow list, and the marks of all labels of a sample (their total is the regulariser's
+ *                         normaliser, temporal.py:330); desc = edgl_tpp_prep_bytes(B, T, M) bytes, 16-byte aligned.
+ *   edgl_bimau_bwd_tpp    edgl_bimau_bwd_db with the regulariser's d lambda (coef = ct_reg / H; count: tpp_sums[4] as edgl_tpp_norm or a
+ *                         data-parallel all-reduce left it, tpp_sums == NULL: the total of the slot data's per-sample counts)
+ *                         computed by sweep 1 from the slot data, and the two loss sums of the wave's (b, head) in tpp_part f32 [B*H, 2]
+ *   edgl_tpp_finish_parts their reduction: reg_out (+)= coef * (-(sum log ev - sum non-event) / (count * H)); sums as edgl_tpp_fwd_bwd
+ *                         (count: tpp_desc != NULL — from the slot data (B, T, M), also stored into sums[4]; NULL — sums[4] as given) */
+long edgl_tpp_prep_bytes(int B, int T, int M);
+int edgl_tpp_prep(const int64_t* masked_pos, const int64_t* labels, const float* ts_raw, const uint8_t* mark_table, int B, int T,
+                  int E, int M, void* desc, void* stream);
+int edgl_bimau_bwd_tpp(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks, const void* pack,
+                       const void* d_out, const void* tpp_desc, int M, const float* tpp_sums, float coef, float* tpp_part,
+                       const float* lam, const void* saved, int B, int T, int C, int H, int E, float drop_rate,
+                       const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* d_qkvt, float* dW1,
+                       float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream);
+int edgl_tpp_finish_parts(const float* part, int nparts, float coef, int H, const void* tpp_desc, int B, int T, int M, float* sums,
+                          float* reg_out, int accumulate, void* stream);
+
 /* ---- optimizer — tf.train.AdamOptimizer (Base.py:142-144) over a flat f32 arena ----------------
  * step_state: device uint64[2]: [0] = step count (incremented by this call, so the first call is
  * t = 1), [1] = scratch holding lr_t = lr*sqrt(1-b2^t)/(1-b1^t).  theta -= lr_t * m/(sqrt(v)+eps).
