@@ -705,10 +705,11 @@ def eval_rows(args, dev, world, rank, dist, steps, warmup, sizes):
             torch.cuda.synchronize()
             ag_ms = a.elapsed_time(b_) / 20
         assert idx.shape == (512, K) and int(idx.min()) >= 0
-        # roofline statement of the evaluation step's own kernel K6 (mask_topk_kernel: seen-mask, 4-pass radix select of the K-th
-        # value, tie pass — 5 sweeps over a row's logits; the [512, n] f32 logits tile of one chunk is written once by the scoring
-        # GEMM and stays L2 / MALL resident): algorithmic bytes = rows x n x 4 B x 5 passes over its launch time, against the
-        # 8 TB/s HBM peak (an upper bound of what the sweeps need from memory: re-reads are served by the caches)
+        # roofline statement of the evaluation step's own kernel K6 (seen mask + top-K of a [512, n] f32 logits tile that the scoring
+        # GEMM wrote just before): algorithmic bytes = ONE read of the tile, rows x n x 4 B, over the launch time, against the 8 TB/s
+        # HBM peak.  Rows of up to 20 472 items run the register form (mask_topk_reg_kernel: the row is read once, candidates above
+        # the K-th largest thread maximum are ranked in LDS); longer chunks the four-pass radix select, which sweeps the row five times
+        # (served by L2 / MALL): `executed_passes`.
         from easydgl_amd import ops as _o
         i0s, i1s = (0, model.num_items) if world == 1 else __import__("easydgl_amd").parallel.shard_bounds(model.num_items, world, rank)
         nloc = min(i1s - i0s, max(1024, (_o.EVAL_TILE_BYTES // (4 * 512)) // 8 * 8))
@@ -723,12 +724,15 @@ def eval_rows(args, dev, world, rank, dist, steps, warmup, sizes):
         eb.record()
         torch.cuda.synchronize()
         k6_ms = ea.elapsed_time(eb) / 10
-        k6_bytes = 512 * nloc * 4 * 5
+        k6_bytes = 512 * nloc * 4
+        k6_reg = nloc <= 256 * 80 - 8 and os.environ.get("EDGL_TOPK_REG", "1") != "0"
         del lg
         rows.append({"num_items": num_items, "num_units": C, "T": cfgd["seqslen"] + 1, "batch": 512, "K": K, "shards": world,
                      "ms_per_eval_step": round(dt / steps * 1e3, 4), "sequences_per_s": round(512 * steps / dt, 1),
-                     "roofline_k6": {"bound": "hbm", "kernel": "mask_topk_kernel (seen mask + radix select + tie pass, one logits chunk)",
-                                     "logits_per_row": nloc, "passes": 5, "algorithmic_bytes": k6_bytes, "avg_launch_ms": round(k6_ms, 4),
+                     "roofline_k6": {"bound": "hbm", "kernel": ("mask_topk_reg_kernel (seen mask, row in registers, candidates ranked in LDS)" if k6_reg else
+                                                                 "mask_topk_kernel (seen mask + 4-pass radix select + tie pass)") + ", one logits chunk",
+                                     "logits_per_row": nloc, "executed_passes": 1 if k6_reg else 5, "algorithmic_bytes": k6_bytes,
+                                     "avg_launch_ms": round(k6_ms, 4),
                                      "achieved": round(k6_bytes / (k6_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                      "frac": round(k6_bytes / (k6_ms * 1e-3) / 8e12, 4)},
                      "allgather_bytes_per_rank": 512 * 2 * K * 4, "allgather_bytes_gathered": world * 512 * 2 * K * 4,

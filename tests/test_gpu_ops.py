@@ -926,3 +926,28 @@ def test_deferred_reductions_match_the_immediate_ones():
     for a, b in zip(res["now"], res["deferred"]):
         assert torch.isfinite(b).all()
         assert float((a - b).abs().max()) <= 1e-5 * (1.0 + float(a.abs().max()))
+
+
+@pytest.mark.parametrize("n", [700, 4088, 4089, 9000, 10232, 20001, 20472, 20473])
+def test_topk_register_form_matches_the_oracle_at_every_row_length(n):
+    """mask_topk_reg_kernel (the row in registers, bitwise search of the K-th largest key) for every register count it is compiled
+    at (n <= 4088 / 10232 / 20472: aligned 16-byte pieces may start three elements in front of a row) and the four-pass kernel behind it: exact indices and values against the oracle's top_k
+    (value descending, index ascending; Base.py:156-163) — ties that exceed the places left, a tie block at the top, both zeros,
+    infinities, masked items among the leaders."""
+    o = ops()
+    rng = np.random.default_rng(n)
+    R_, K, T = 7, 100, 30
+    x = (rng.standard_normal((R_, n)) * 3.0).astype(np.float32)
+    x[0, :] = -1.25                                  # all ties -> lowest indices
+    x[1, n // 3:n // 3 + 150] = 9.0                  # more ties at the top than places
+    x[2, 7] = np.inf; x[2, 9] = -np.inf
+    x[3, ::2] = 0.0; x[3, 1::2] = -0.0               # the two zeros compare equal: index order
+    x[4] = np.round(x[4])                            # few distinct values: a tie block at the K-th place
+    seen = rng.integers(0, n, size=(R_, T))
+    seen[5, :] = np.argsort(-x[5], kind="stable")[:T]
+    want_x = x.copy()
+    want_x[np.arange(R_)[:, None], seen] = -np.inf
+    want = O.top_k(want_x, K)
+    val, idx = o.mask_topk(torch.tensor(x).cuda(), 0, torch.tensor(seen).cuda(), K)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    np.testing.assert_array_equal(val.cpu().numpy(), np.take_along_axis(want_x, want, 1))
