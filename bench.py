@@ -712,7 +712,10 @@ def eval_rows(args, dev, world, rank, dist, steps, warmup, sizes):
         # (served by L2 / MALL): `executed_passes`.
         from easydgl_amd import ops as _o
         i0s, i1s = (0, model.num_items) if world == 1 else __import__("easydgl_amd").parallel.shard_bounds(model.num_items, world, rank)
-        nloc = min(i1s - i0s, max(1024, (_o.EVAL_TILE_BYTES // (4 * 512)) // 8 * 8))
+        nloc = max(1024, (_o.EVAL_TILE_BYTES // (4 * 512)) // 8 * 8)
+        if K <= 128 and nloc > _o.TOPK_REG_ITEMS >= 1024:      # (the chunk rule of ops.score_topk)
+            nloc = _o.TOPK_REG_ITEMS
+        nloc = min(i1s - i0s, nloc)
         lg = torch.randn((512, nloc), device=dev, dtype=torch.float32)
         for _ in range(3):
             _o.mask_topk(lg, i0s, feats["seqs_i"], K)

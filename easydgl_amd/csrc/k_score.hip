@@ -1896,7 +1896,9 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
                                   float* label_logit, float* logits, float* workspace, int dtype, void* stream) {
     int rc = check_score(rows, table, out_bias, R, C, I, i0, i1, dtype, "edgl_score_lse_fwd");
     if (rc) return rc;
-    EDGL_REQUIRE(row_lse && workspace && (!labels || label_logit), EDGL_ERR_NULL, "edgl_score_lse_fwd: null output");
+    // row_lse == NULL (with logits): the logits tile only — the evaluation path (score_topk) has no use for the normaliser, and the
+    // one-thread-per-row merge of the chunk partials is a chain of dependent loads (46 us per tile at 512 rows)
+    EDGL_REQUIRE((row_lse || logits) && workspace && (!labels || label_logit), EDGL_ERR_NULL, "edgl_score_lse_fwd: null output");
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = row_lse; p.part = workspace; p.logits = logits;
@@ -1908,9 +1910,11 @@ extern "C" int edgl_score_lse_fwd(const void* rows, const void* table, const flo
     hipStream_t st = (hipStream_t)stream;
     rc = dtype == EDGL_F32 ? fwd_dispatch<float>(p, C, st) : fwd_dispatch<bf16>(p, C, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(lse_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, st, workspace, R, nvalid, xbf, cf.zb,
-                       xblocks_of(R, xbf) * p.nchunk, i1 - i0, row_lse);
-    EDGL_LAUNCH_CHECK();
+    if (row_lse) {
+        hipLaunchKernelGGL(lse_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, st, workspace, R, nvalid, xbf, cf.zb,
+                           xblocks_of(R, xbf) * p.nchunk, i1 - i0, row_lse);
+        EDGL_LAUNCH_CHECK();
+    }
     if (labels) {
         if (dtype == EDGL_F32)
             hipLaunchKernelGGL((label_logit_kernel<float>), dim3((R + 3) / 4), dim3(256), 0, st, (const float*)rows, (const float*)table, out_bias, labels, R, C, i0, i1, label_logit);

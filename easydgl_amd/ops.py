@@ -401,12 +401,12 @@ def compact_rows(rows, labels):
     return rows_c, labels_c, perm, inv, nvalid
 
 
-def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False, nvalid=None):
+def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False, nvalid=None, want_lse=True):
     R, C = rows.shape
     I = table_c.shape[0]
     dev = rows.device
-    lse = torch.empty(R, device=dev, dtype=torch.float32)
-    lab_logit = torch.zeros(R, device=dev, dtype=torch.float32)
+    lse = torch.empty(R, device=dev, dtype=torch.float32) if want_lse else None     # (None: the logits tile only — evaluation)
+    lab_logit = torch.zeros(R, device=dev, dtype=torch.float32) if labels is not None or want_lse else None
     logits = torch.empty((R, i1 - i0), device=dev, dtype=torch.float32) if want_logits else None
     ws = torch.empty(2 * R * lib.edgl_score_chunks(R, i1 - i0), device=dev, dtype=torch.float32)
     check(lib.edgl_score_lse_fwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), R, C, I, i0, i1, _ptr(nvalid),
@@ -570,6 +570,7 @@ def topk_merge(cand_val: torch.Tensor, cand_idx: torch.Tensor):
 
 
 EVAL_TILE_BYTES = 64 << 20   # logits staging tile of score_topk: [R, chunk] f32, sized to stay L2 / MALL resident
+TOPK_REG_ITEMS = (256 * 80 - 8) // 8 * 8   # longest row of the register form of edgl_mask_topk (csrc/k_score.hip), a multiple of 8
 
 
 def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
@@ -580,13 +581,15 @@ def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
     R = rows.shape[0]
     n = i1 - i0
     chunk = max(1024, (EVAL_TILE_BYTES // (4 * R)) // 8 * 8)
+    if K <= 128 and chunk > TOPK_REG_ITEMS >= 1024:      # rows the top-K kernel keeps in registers: one read of the tile instead of five
+        chunk = TOPK_REG_ITEMS
     if n <= chunk:
-        _, _, logits = score_lse(rows, table_c, out_bias, None, i0, i1, want_logits=True)
+        _, _, logits = score_lse(rows, table_c, out_bias, None, i0, i1, want_logits=True, want_lse=False)
         return mask_topk(logits, i0, seen, K)
     cands = []
     for lo in range(i0, i1, chunk):                      # chunk starts stay multiples of 8 (i0 is one)
         hi = min(i1, lo + chunk)
-        _, _, logits = score_lse(rows, table_c, out_bias, None, lo, hi, want_logits=True)
+        _, _, logits = score_lse(rows, table_c, out_bias, None, lo, hi, want_logits=True, want_lse=False)
         cands.append(mask_topk(logits, lo, seen, K))
         del logits
     if len(range(i0, i1, chunk)) > 1 and K > 512:

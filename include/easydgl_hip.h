@@ -305,6 +305,7 @@ int edgl_compact_gather(const void* rows, const int64_t* labels, const int32_t* 
                         int64_t* labels_c, int dtype, void* stream);
 int edgl_scatter_rows(const void* rows_c, const int32_t* inv, int R, int C, void* rows, int dtype,
                       void* stream);
+/* (row_lse may be NULL when logits is given: the evaluation path wants the logits tile only — Base.py:150-163) */
 int edgl_score_lse_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                        int R, int C, int I, int i0, int i1, const int32_t* nvalid, float* row_lse,
                        float* label_logit, float* logits, float* workspace, int dtype, void* stream);
