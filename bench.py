@@ -757,7 +757,10 @@ def eval_bench(args, world, rank, local):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-    rows = eval_rows(args, dev, world, rank, dist, args.steps, args.warmup, sizes=((20000, 128), (1_000_000, 256)))
+    sizes = ((20000, 128), (1_000_000, 256))
+    if os.environ.get("EDGL_BENCH_EVAL_ROWS"):     # profiling: only the first n catalogue sizes (tools/ktrace.sh --workload eval)
+        sizes = sizes[:int(os.environ["EDGL_BENCH_EVAL_ROWS"])]
+    rows = eval_rows(args, dev, world, rank, dist, args.steps, args.warmup, sizes=sizes)
     if rank == 0:
         head = rows[0]
         print(json.dumps({"metric": "sequences/sec (evaluation: encode + sharded full-catalogue scoring + seen mask + top-100) B=512 L=100 d=128 |I|=20K",

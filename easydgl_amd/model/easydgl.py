@@ -270,10 +270,18 @@ class EasyDGL(Sequential):
         C_ = self.num_units
         x, spans, marks = self.encode(features, is_training)
         lams = []
+        fused_eval = self._eval_tail_ok(is_training, x, gather_pos)
         for i, blk in enumerate(self.layers):
             layer_in = x
             att, lam = blk.attention(layer_in, layer_in, ids, spans, marks, is_training,
                                      drop=self._drop(self.attention_probs_dropout_rate, 10 + 4 * i, is_training))
+            lams.append(lam)
+            if fused_eval:      # inference: the block tail (and the head behind the last block) as ONE launch (csrc/k_tail.hip)
+                last = i == len(self.layers) - 1
+                x, rows = self._eval_tail(blk, att.contiguous(), layer_in, gather_pos, last)
+                if last:
+                    return rows, lams
+                continue
             att = self._linear(att, blk.att_out)                                                   # :113
             att = ops.AddLayerNormFn.apply(att, layer_in[:, :, :C_], blk.att_ln.gamma, blk.att_ln.beta,
                                            self._drop(self.hidden_dropout_rate, 11 + 4 * i, is_training), None, self.pad)  # :114-116
@@ -281,11 +289,52 @@ class EasyDGL(Sequential):
             out = self._linear(inter, blk.out)                                                     # :125
             x = ops.AddLayerNormFn.apply(out, att, blk.out_ln.gamma, blk.out_ln.beta,
                                          self._drop(self.hidden_dropout_rate, 12 + 4 * i, is_training), None, self.pad)   # :126-128
-            lams.append(lam)
         so = self._linear(x, self.transform, gelu=True)                                           # :138
         rows = ops.AddLayerNormFn.apply(so, None, self.transform_ln.gamma, self.transform_ln.beta, ops.NO_DROP,
                                         gather_pos, self.pad)                                      # :139,142-146
         return rows, lams
+
+    # ---- inference through the fused block tail (the training engine's forward kernel; EasyDGL.py:110-146) ---------------------
+    def _eval_tail_ok(self, is_training, x, gather_pos) -> bool:
+        import os
+        from .. import _lib
+        if is_training or torch.is_grad_enabled() or not self.layers or self.pad[0] or x.dtype != torch.bfloat16:
+            return False
+        if os.environ.get("EDGL_EVAL_FUSED_TAIL", "1") == "0" or gather_pos.shape[1] > 256:
+            return False
+        return bool(_lib.lib.edgl_tail_supported(x.shape[1], self.num_units, _lib.BF16))
+
+    def _eval_tail(self, blk, att, layer_in, gather_pos, last):
+        """One block tail in one launch: att_out dense -> +residual -> LN1 -> inner dense + GELU -> out dense -> +residual -> LN2
+        (-> head transform + GELU + LN3 + row gather behind the last block).  The tensors the kernel saves for a backward go to
+        a scratch set kept per (batch, length); dropout rate 0.  Returns (y [B, T, C], head rows [B*Mg, C] or None)."""
+        from .. import _lib
+        lib, P = _lib.lib, ops._ptr
+        B, T, C = att.shape
+        Mg = gather_pos.shape[1]
+        dev, dt = att.device, att.dtype
+        key = (B, T, Mg, str(dev))
+        ws = getattr(self, "_eval_tail_ws", None)
+        if ws is None or ws["key"] != key:
+            e = lambda *sh, d=dt: torch.empty(sh, device=dev, dtype=d)  # noqa: E731
+            ws = dict(key=key, pack=e(int(lib.edgl_tail_pack_elems(C))), ao=e(B, T, C), a1=e(B, T, C), pre_f=e(B, T, 2 * C),
+                      f=e(B, T, 2 * C), o=e(B, T, C), pre_t=e(B, T, C), so=e(B, T, C), st1=e(B, 2, d=torch.float32),
+                      st2=e(B, 2, d=torch.float32), st3=e(B, 2, d=torch.float32))
+            self._eval_tail_ws = ws
+        st = ops._stream()
+        _lib.check(lib.edgl_tail_pack(P(self.compute(blk.att_out.kernel)), P(self.compute(blk.inter.kernel)),
+                                      P(self.compute(blk.out.kernel)), P(self.compute(self.transform.kernel)), C, P(ws["pack"]), st),
+                   "edgl_tail_pack")
+        y = torch.empty((B, T, C), device=dev, dtype=dt)
+        rows = torch.empty((B * Mg, C), device=dev, dtype=dt) if last else None
+        tl = self.transform_ln
+        _lib.check(lib.edgl_tail_fwd(P(att), layer_in.data_ptr(), layer_in.shape[2], P(ws["pack"]), P(blk.att_out.bias),
+                                     P(blk.inter.bias), P(blk.out.bias), P(self.transform.bias), P(blk.att_ln.gamma),
+                                     P(blk.att_ln.beta), P(blk.out_ln.gamma), P(blk.out_ln.beta), P(tl.gamma), P(tl.beta), B, T, C,
+                                     0.0, None, 0, 0, P(gather_pos), Mg, int(last), P(ws["ao"]), P(ws["a1"]), P(ws["st1"]),
+                                     P(ws["pre_f"]), P(ws["f"]), P(ws["o"]), P(y), P(ws["st2"]), P(ws["pre_t"]), P(ws["so"]),
+                                     P(ws["st3"]), P(rows), None, _lib.BF16, st), "edgl_tail_fwd")
+        return y, rows
 
     def _gather_pos(self, features, is_training):
         ids = features["seqs_i"]

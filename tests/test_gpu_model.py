@@ -250,3 +250,28 @@ def test_chunked_eval_scoring_matches_the_single_pass(monkeypatch):
     monkeypatch.setattr(ops, "EVAL_TILE_BYTES", 4 * 12 * 1024 * 3)     # chunks of 3072: the last one is partial
     v2, i2 = m.eval_topk(ef, mask_seen=True, K=100)
     assert torch.equal(i0, i2) and torch.equal(v0, v2)
+
+
+@pytest.mark.parametrize("blocks", [1, 2])
+def test_inference_through_the_fused_block_tail_matches_the_unfused_modules(blocks, monkeypatch):
+    """Sequential.eval's forward (Base.py:150-163) at a shape the fused per-sample block tail takes (bf16, C = 128, T = 101): the head
+    rows of `EasyDGL.encoder` through csrc/k_tail.hip — one launch per block, as in the training engine — against the dense /
+    LayerNorm modules it replaces (equal up to the last bf16 digit of the dense outputs), and the same top-K lists up to near-ties."""
+    prob = make_problem(seed=31, batch=8, num_items=2000, seqslen=100, num_units=128, num_heads=8, num_blocks=blocks, masklen=20,
+                        num_events=16)
+    m = build_model(prob, "bf16")
+    ef = to_dev(prob["efeats"])
+    out = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("EDGL_EVAL_FUSED_TAIL", fused)
+        with torch.no_grad():
+            rows, _ = m.encoder(ef, False, m._gather_pos(ef, False))
+            val, idx = m.eval_topk(ef, mask_seen=True)
+        out[fused] = (rows.float().cpu().numpy(), idx.cpu().numpy(), val.cpu().numpy())
+    assert getattr(m, "_eval_tail_ws", None) is not None          # the fused path did run
+    r0, i0, v0 = out["0"]
+    r1, i1, v1 = out["1"]
+    assert rel_err(r1, r0) < 2.5e-2                                   # bf16 rows: a few ulps of the largest element
+    assert float(np.abs(v1 - v0).max()) < 5e-2 * (1.0 + float(np.abs(v0).max()))
+    overlap = np.mean([len(set(i0[r, :50]) & set(i1[r, :50])) / 50 for r in range(i0.shape[0])])
+    assert overlap > 0.95, overlap
