@@ -499,6 +499,10 @@ def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=Fa
         from easydgl_amd.engine import TrainEngine
         eng = TrainEngine(model, c["batch"], use_graph=(args.path == "graph"), process_group=None)
         eng.load_batch(*batches[0])
+        # the loss of a step is read once, behind the timed region's device-wide synchronisation — as a training loop reads it every
+        # few hundred steps (train.py): the engine then leaves its loss kernels on the side stream instead of joining them in
+        # front of every Adam launch (TrainEngine.sync_loss / join_loss; EDGL_BENCH_SYNC_LOSS=1: the joined form)
+        eng.sync_loss = os.environ.get("EDGL_BENCH_SYNC_LOSS", "0") == "1"
 
         def step(i=0):
             if raw is not None:

@@ -136,6 +136,8 @@ class TrainEngine:
         self.side, self.side2 = TrainEngine._SIDE_STREAMS[key]
         self._pending_loss = None
         self._pending_label = None
+        self._lazy_loss, self._side_has_grads, self._loss_unjoined = False, False, False
+        self.sync_loss = True      # step(): order the returned loss on the caller's stream (a cross-stream wait behind the optimizer)
         # data parallel: weighted rows / TPP normaliser of the GLOBAL batch (filled by _global_counts before a step)
         self.counts = torch.zeros(2, device=dev, dtype=torch.int32)
         self._dp = False
@@ -206,8 +208,13 @@ class TrainEngine:
               "edgl_add_layernorm_bwd_act")
 
     # ---- one optimizer step, as a fixed launch sequence ----------------------------------------------------------------
-    def _issue(self):
+    def _issue(self, lazy_loss: bool = False):
+        """lazy_loss (step() without data parallelism): nothing the optimizer needs runs on the side stream at the end of the
+        backward — every deferred reduction goes into the main stream's last reduction launch — so the main stream does NOT wait
+        for the side stream (the TPP partial reduction and the loss kernel) in front of Adam; step() orders the loss behind the
+        optimizer instead (or leaves it to the caller: `sync_loss`).  A cross-stream join costs the main stream ~12 us there."""
         m, st = self.m, _stream()
+        self._lazy_loss = bool(lazy_loss) and bool(self.blk)
         B, T, C, H, E, M, I, R = self.B, self.T, self.C, self.H, self.E, self.M, self.I, self.R
         code = self.code
         hd, ad = m.hidden_dropout_rate, m.attention_probs_dropout_rate
@@ -239,6 +246,8 @@ class TrainEngine:
         side.wait_stream(main)
         if not legacy:
             side2.wait_stream(main)
+            if getattr(self, "_loss_unjoined", False):
+                side2.wait_stream(side)     # the previous step's loss kernels (side) read buffers that this stream's first kernels rewrite
         else:
             if not getattr(m, "_state_ahead", False):
                 self._advance_state(st)
@@ -390,7 +399,18 @@ class TrainEngine:
         if self._pending_loss is not None:   # (no block: no side-stream join in the backward)
             self._pending_loss(st)
             self._pending_loss = None
-        torch.cuda.current_stream().wait_stream(self.side)
+        if self._lazy_loss and not self._side_has_grads:
+            self._loss_unjoined = True       # (step() joins behind the optimizer, or the caller does: join_loss())
+        else:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._loss_unjoined = False
+
+    def join_loss(self) -> None:
+        """Orders the current stream behind the kernels that write `self.loss` (the side stream) — needed before the loss is
+        read on the current stream when step() ran with `sync_loss = False`."""
+        if getattr(self, "_loss_unjoined", False):
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._loss_unjoined = False
 
     def _issue_backward(self, st, drop, tab, tab_c, lab):
         m = self.m
@@ -520,10 +540,12 @@ class TrainEngine:
                 if self._pending_loss is not None:
                     self._pending_loss(self.side.cuda_stream)
                     self._pending_loss = None
+                self._side_has_grads = self._pending_label is not None      # (the one-hot term's atomics: Adam must wait for them)
                 if self._pending_label is not None:
                     self._pending_label(self.side.cuda_stream)
                     self._pending_label = None
-                check(lib.edgl_reduce_flush(self.side.cuda_stream), "edgl_reduce_flush")
+                if not self._lazy_loss or self._side_has_grads:
+                    check(lib.edgl_reduce_flush(self.side.cuda_stream), "edgl_reduce_flush")
             # both residual branches feed the first C channels of the block input (temporal.py:447, EasyDGL.py:116)
             if i > 0:
                 check(lib.edgl_add_cols(_ptr(d_in), cin, _ptr(self.G1), _ptr(self.G2), C, self.rows, C, code, st), "edgl_add_cols")
@@ -677,11 +699,13 @@ class TrainEngine:
         if not self.use_graph:
             if distributed:
                 self._global_counts()
-            self._issue()
+            self._issue(lazy_loss=not distributed and os.environ.get("EDGL_LAZY_LOSS", "1") != "0")
             out = self.loss
             if distributed:
                 out = self._dp_allreduce()
             self._optimizer()
+            if self.sync_loss:      # the returned loss is ordered on the current stream (False: the caller calls join_loss() / syncs)
+                self.join_loss()
             return out
         if self.graph is None:
             # warm-up on a side stream (allocator / lazy module init), then capture
