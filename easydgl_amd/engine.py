@@ -530,8 +530,9 @@ class TrainEngine:
             if i == 0:
                 # every slab reduction queued so far (weight-gradient GEMMs, BiMAU / LayerNorm partials) runs on the side
                 # stream under the embedding backward, whose atomics leave the CUs mostly idle
+                # (bound of this fork, measured with the loss kernels left out: 6-8 us of the step — the event record behind the dX GEMM)
                 self.side.wait_stream(torch.cuda.current_stream())
-                if self.fused_tpp:    # the regulariser from the forward's partial sums, block by block (every sweep 1 has read its count)
+                if self.fused_tpp:    # the regulariser from sweep 1's partial sums, block by block
                     for j, bj in enumerate(self.blk):
                         check(lib.edgl_tpp_finish_parts(_ptr(bj["tpp_part"]), B * H, float(m.ct_reg / H), H,
                                                         None if self._dp else _ptr(self.tpp_desc), B, T, M, _ptr(bj["tpp"]),
