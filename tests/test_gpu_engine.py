@@ -211,3 +211,32 @@ def test_fused_block_tail_matches_the_unfused_kernels(case, drop):
             assert float(((a[k] - b[k]).abs() > 1e-6 * a[k].abs().max()).float().mean()) < 0.05, k
     assert abs(a["loss"] - b["loss"]) <= 2e-3 * abs(a["loss"])
     assert rel_err(b["grads"].cpu().numpy(), a["grads"].cpu().numpy()) < 2e-2
+
+
+def test_step_with_the_loss_left_on_the_side_stream_gives_the_same_trajectory():
+    """TrainEngine.sync_loss = False: Adam does not wait for the loss kernels (every deferred reduction runs on the main stream), the
+    caller orders the loss with join_loss().  Same losses and the same weights after three steps as the joined form, and the
+    plain _issue() of the other tests (full join at its end) is unchanged."""
+    from easydgl_amd.engine import TrainEngine
+    prob = make_problem(seed=52, batch=6, **CASES[2])
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    out = {}
+    for sync in (True, False):
+        m = build_model(prob, "bf16", hidden_drop=0.1, att_drop=0.1)
+        eng = TrainEngine(m, 6, use_graph=False)
+        eng.sync_loss = sync
+        eng.load_batch(feats, labels)
+        losses = []
+        for _ in range(3):
+            loss = eng.step()
+            if not sync:
+                assert eng._loss_unjoined
+                eng.join_loss()
+            assert not eng._loss_unjoined
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        out[sync] = (losses, m._arena.clone())
+    for a, b in zip(out[True][0], out[False][0]):
+        assert abs(a - b) <= 1e-5 * abs(a)
+    # (not bit for bit: the embedding scatter's f32 atomics commute only up to rounding, in either form)
+    assert float((out[True][1] - out[False][1]).abs().max()) <= 1e-5 * float(out[True][1].abs().max())
