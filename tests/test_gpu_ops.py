@@ -951,3 +951,36 @@ def test_topk_register_form_matches_the_oracle_at_every_row_length(n):
     val, idx = o.mask_topk(torch.tensor(x).cuda(), 0, torch.tensor(seen).cuda(), K)
     np.testing.assert_array_equal(idx.cpu().numpy(), want)
     np.testing.assert_array_equal(val.cpu().numpy(), np.take_along_axis(want_x, want, 1))
+
+
+def test_topk_merge_by_rank_and_by_sort_agree():
+    """edgl_topk_merge: ordered candidate lists are merged by rank (binary searches), lists in any other order by the bitonic sort —
+    the same result, also with invalid entries, fewer valid candidates than K, ties across the lists and a repeated (value, id) pair."""
+    o = ops()
+    rng = np.random.default_rng(8)
+    S, R_, K = 8, 37, 100
+    val = np.sort(rng.standard_normal((S, R_, K)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    val[:, 3] = np.round(val[:, 3])                                        # ties across and inside the lists
+    idx = np.empty((S, R_, K), np.int32)
+    for s in range(S):
+        for r in range(R_):
+            ids = np.sort(rng.choice(5000, K, replace=False)) + 5000 * s      # shard-disjoint global ids
+            order = np.lexsort((ids, -val[s, r]))                               # (value desc, id asc) inside the list
+            val[s, r] = val[s, r][order]; idx[s, r] = ids[order]
+    idx[:, 5, 40:] = -1; val[:, 5, 40:] = -np.inf                           # invalid tails
+    idx[1:, 6, :] = -1; val[1:, 6, :] = -np.inf; idx[0, 6, 30:] = -1; val[0, 6, 30:] = -np.inf   # fewer than K valid candidates
+    val[1, 7, 0] = val[0, 7, 0]; idx[1, 7, 0] = idx[0, 7, 0]                # the same (value, id) in two lists
+    def run(v, i):
+        mv, mi = o.topk_merge(torch.tensor(v).cuda(), torch.tensor(i).cuda())
+        return mv.cpu().numpy(), mi.cpu().numpy()
+    mv, mi = run(val, idx)
+    perm = rng.permutation(K)
+    sv, si = run(val[:, :, perm].copy(), idx[:, :, perm].copy())             # unordered lists: the sorting path
+    np.testing.assert_array_equal(mi, si)
+    np.testing.assert_array_equal(mv, sv)
+    for r in (0, 3, 5, 6):
+        flat_v, flat_i = val[:, r].reshape(-1), idx[:, r].reshape(-1).astype(np.int64)
+        ok = flat_i >= 0
+        order = np.lexsort((flat_i[ok], -flat_v[ok]))[:K]
+        want = np.full(K, -1, np.int64); want[:len(order)] = flat_i[ok][order]
+        np.testing.assert_array_equal(mi[r], want)
