@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns device memory, the stream and the autograd tap
 a call into libeasydgl_hip.so.  There is no CPU path — handing a CPU tensor to any op raises."""
 from __future__ import annotations
 
+import ctypes
 import math
 from dataclasses import dataclass
 from typing import Optional
@@ -571,6 +572,7 @@ def topk_merge(cand_val: torch.Tensor, cand_idx: torch.Tensor):
 
 EVAL_TILE_BYTES = 64 << 20   # logits staging tile of score_topk: [R, chunk] f32, sized to stay L2 / MALL resident
 TOPK_REG_ITEMS = (256 * 80 - 8) // 8 * 8   # longest row of the register form of edgl_mask_topk (csrc/k_score.hip), a multiple of 8
+EVAL_GEMM = True             # full item chunks of the chunked evaluation path score through edgl_gemm (tests switch it off)
 
 
 def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
@@ -582,27 +584,53 @@ def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
     n = i1 - i0
     chunk = max(1024, (EVAL_TILE_BYTES // (4 * R)) // 8 * 8)
     if K <= 128 and chunk > TOPK_REG_ITEMS >= 1024:      # rows the top-K kernel keeps in registers: one read of the tile instead of five
-        chunk = TOPK_REG_ITEMS
+        chunk = TOPK_REG_ITEMS // 128 * 128              # (a multiple of 128: full chunks take the tiled GEMM below)
     if n <= chunk:
         _, _, logits = score_lse(rows, table_c, out_bias, None, i0, i1, want_logits=True, want_lse=False)
         return mask_topk(logits, i0, seen, K)
-    cands = []
-    for lo in range(i0, i1, chunk):                      # chunk starts stay multiples of 8 (i0 is one)
-        hi = min(i1, lo + chunk)
-        _, _, logits = score_lse(rows, table_c, out_bias, None, lo, hi, want_logits=True, want_lse=False)
-        cands.append(mask_topk(logits, lo, seen, K))
-        del logits
-    if len(range(i0, i1, chunk)) > 1 and K > 512:
+    starts = list(range(i0, i1, chunk))                  # chunk starts stay multiples of 8 (i0 is one)
+    if len(starts) > 1 and K > 512:
         raise _lib.EdglError(f"score_topk: K={K} > 512 on the chunked path (the merge kernel orders up to 1024 candidates per row: "
                              f"two K-lists at least)")
-    fan = max(2, 1024 // K)                              # the merge kernel orders up to 1024 candidates per row
-    while len(cands) > 1:
-        nxt = []
-        for g in range(0, len(cands), fan):
-            grp = cands[g:g + fan]
-            nxt.append(grp[0] if len(grp) == 1 else topk_merge(torch.stack([c[0] for c in grp]), torch.stack([c[1] for c in grp])))
-        cands = nxt
-    return cands[0]
+    # One logits tile, one scoring workspace and the candidate lists of ALL chunks are allocated once: per chunk the loop is two
+    # library calls (at 1 M items and 49 chunks the allocations and wrappers of the per-chunk form kept the GPU waiting for the host)
+    C, I, dev, code, st = rows.shape[1], table_c.shape[0], rows.device, _code(rows), _stream()
+    logits = torch.empty((R, chunk), device=dev, dtype=torch.float32)
+    ws = torch.empty(2 * R * lib.edgl_score_chunks(R, chunk), device=dev, dtype=torch.float32)
+    cval = torch.empty((len(starts), R, K), device=dev, dtype=torch.float32)
+    cidx = torch.empty((len(starts), R, K), device=dev, dtype=torch.int32)
+    T = 0 if seen is None else seen.shape[1]
+    esz = rows.element_size()
+    # bias of item z at element z (item 0, the padding item, never read through it): 16-byte aligned for every chunk start
+    bias_z = torch.cat([out_bias.new_zeros(1), out_bias]) if (code == BF16 and EVAL_GEMM and len(starts) > 2) else None
+    for j, lo in enumerate(starts):
+        hi = min(i1, lo + chunk)
+        if bias_z is not None and lo >= 1 and (hi - lo) % 128 == 0 and C % 32 == 0:
+            # a full chunk behind the padding item: logits = rows . table[lo:hi]^T + bias as a plain GEMM with f32 output (the
+            # weights-resident strip kernel against the scoring kernel's 45-85 us at 512 x 20 352 x 128 / 256); bias of item z is
+            # out_bias[z - 1] (EasyDGL.py:149-151), the pad logit -1000 belongs to item 0 — never in these chunks
+            check(lib.edgl_gemm(_ptr(rows), ctypes.c_void_p(table_c.data_ptr() + lo * C * esz), _ptr(logits), R, hi - lo, C, C, C,
+                                hi - lo, 1, 1, ctypes.c_void_p(bias_z.data_ptr() + lo * 4), None,
+                                _lib.EPI_BIAS | _lib.EPI_OUT_F32, 1, None, code, st), "edgl_gemm")
+        else:
+            check(lib.edgl_score_lse_fwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), None, R, C, I, lo, hi, None, None, None,
+                                         _ptr(logits), _ptr(ws), code, st), "edgl_score_lse_fwd")  # logits [R, hi - lo], row stride hi - lo
+        check(lib.edgl_mask_topk(_ptr(logits), R, hi - lo, lo, _ptr(seen), T, K, _ptr(cval[j]), _ptr(cidx[j]), st), "edgl_mask_topk")
+    fan = max(2, 1024 // K)                              # the merge kernel takes up to 1024 candidates per row
+    while cval.shape[0] > 1:
+        n = cval.shape[0]
+        ng = (n + fan - 1) // fan
+        nval = torch.empty((ng, R, K), device=dev, dtype=torch.float32)
+        nidx = torch.empty((ng, R, K), device=dev, dtype=torch.int32)
+        for g in range(ng):
+            a, b = g * fan, min(n, (g + 1) * fan)
+            if b - a == 1:
+                nval[g].copy_(cval[a]); nidx[g].copy_(cidx[a])
+            else:
+                check(lib.edgl_topk_merge(_ptr(cval[a:b]), _ptr(cidx[a:b]), b - a, R, K, _ptr(nval[g]), _ptr(nidx[g]), st),
+                      "edgl_topk_merge")
+        cval, cidx = nval, nidx
+    return cval[0], cidx[0]
 
 
 def rank_metrics(topk_idx: torch.Tensor, label: torch.Tensor, metrics: torch.Tensor) -> None:

@@ -341,8 +341,8 @@ int edgl_score_ce_bwd(const void* rows, const void* table, const float* out_bias
 int edgl_mask_topk(float* logits, int R, int n, int i0, const int64_t* seen, int T, int K, float* out_val,
                    int32_t* out_idx, void* stream);
 /* ---- K7: merge of per-shard candidates (after an RCCL all-gather): cand_val/idx [S, R, K] ->
- * global top-K per row by (value desc, global index asc).  Lists ordered that way (invalid entries, index < 0, last) — what
- * edgl_mask_topk and this call write — are merged by rank (binary searches); any other input is sorted (S*K <= 1024). */
+ * global top-K per row by (value desc, global index asc); entries with index < 0 are ignored; S*K <= 1024.  (Candidates above the
+ * K-th largest thread maximum are ranked by counting; inputs with more than 256 of them — tie blocks — are sorted.) */
 int edgl_topk_merge(const float* cand_val, const int32_t* cand_idx, int S, int R, int K, float* out_val,
                     int32_t* out_idx, void* stream);
 /* HR@k / NDCG@k sums for k in {10,50,100} (Base.py:181-201): metrics f32 [6] += per-batch sums in

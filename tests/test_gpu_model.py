@@ -275,3 +275,24 @@ def test_inference_through_the_fused_block_tail_matches_the_unfused_modules(bloc
     assert float(np.abs(v1 - v0).max()) < 5e-2 * (1.0 + float(np.abs(v0).max()))
     overlap = np.mean([len(set(i0[r, :50]) & set(i1[r, :50])) / 50 for r in range(i0.shape[0])])
     assert overlap > 0.95, overlap
+
+
+def test_chunked_eval_through_the_gemm_matches_the_scoring_kernel(monkeypatch):
+    """bf16, a catalogue of several full chunks: ops.score_topk scores the full chunks behind the padding item through edgl_gemm (f32
+    logits = rows . table^T + bias) and the first / ragged chunks through the scoring kernel — the same top-K as the scoring kernel
+    everywhere, up to near-ties of logits that differ in their last f32 digits (another summation order)."""
+    from easydgl_amd import ops
+    prob = make_problem(seed=14, batch=16, num_items=3000, seqslen=20, num_units=64, num_heads=2, num_blocks=1)
+    m = build_model(prob, "bf16")
+    ef = to_dev(prob["efeats"])
+    monkeypatch.setattr(ops, "EVAL_TILE_BYTES", 4 * 16 * 1024)       # chunks of 1024 items: [0, 1024) kernel, GEMM chunks, a ragged tail
+    monkeypatch.setattr(ops, "EVAL_GEMM", False)
+    v0, i0 = m.eval_topk(ef, mask_seen=True)
+    monkeypatch.setattr(ops, "EVAL_GEMM", True)
+    v1, i1 = m.eval_topk(ef, mask_seen=True)
+    assert float((v0 - v1).abs().max()) <= 1e-5 * (1.0 + float(v0.abs().max()))
+    same = (i0 == i1).float().mean()
+    assert float(same) > 0.99, float(same)
+    seen = prob["efeats"]["seqs_i"]
+    for r in range(i1.shape[0]):
+        assert not (set(i1[r].tolist()) & set(seen[r].tolist()))

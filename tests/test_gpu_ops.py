@@ -954,8 +954,9 @@ def test_topk_register_form_matches_the_oracle_at_every_row_length(n):
 
 
 def test_topk_merge_by_rank_and_by_sort_agree():
-    """edgl_topk_merge: ordered candidate lists are merged by rank (binary searches), lists in any other order by the bitonic sort —
-    the same result, also with invalid entries, fewer valid candidates than K, ties across the lists and a repeated (value, id) pair."""
+    """edgl_topk_merge: candidates above the K-th largest thread maximum ranked by counting (the usual case) against inputs that end
+    in the bitonic sort (a permutation changes nothing; more than 256 candidates above the bound: a tie block) — the same result,
+    also with invalid entries, fewer valid candidates than K, ties across the lists and a repeated (value, id) pair."""
     o = ops()
     rng = np.random.default_rng(8)
     S, R_, K = 8, 37, 100
@@ -978,6 +979,13 @@ def test_topk_merge_by_rank_and_by_sort_agree():
     sv, si = run(val[:, :, perm].copy(), idx[:, :, perm].copy())             # unordered lists: the sorting path
     np.testing.assert_array_equal(mi, si)
     np.testing.assert_array_equal(mv, sv)
+    tv, ti = val.copy(), idx.copy()
+    tv[:, 9, :60] = 2.5                                                     # 480 candidates tie at the top: the sorting path
+    for s in range(S):
+        ti[s, 9] = np.sort(ti[s, 9])
+    bv, bi = run(tv, ti)
+    flat_v, flat_i = tv[:, 9].reshape(-1), ti[:, 9].reshape(-1).astype(np.int64)
+    np.testing.assert_array_equal(bi[9], flat_i[np.lexsort((flat_i, -flat_v))[:K]])
     for r in (0, 3, 5, 6):
         flat_v, flat_i = val[:, r].reshape(-1), idx[:, r].reshape(-1).astype(np.int64)
         ok = flat_i >= 0
