@@ -83,6 +83,9 @@ SIGNATURES = {
     "edgl_score_flash_fwd_coef": (I, [P, P, P, P, I, I, I, P, P, P, P, P, I, P]),
     "edgl_score_flash_fwd_coef_w": (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, I, P]),
     "edgl_score_flash_fwd_rows_w": (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, I, P]),
+    "edgl_score_ce_nparts": (I, [I, I]),
+    "edgl_score_flash_fwd_rows_wp": (I, [P, P, P, P, I, I, I, P, P, P, P, P, P, P, P, P, I, P]),
+    "edgl_ce_loss_parts": (I, [P, I, P, P, P, P, P]),
     "edgl_score_flash_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, P]),
     "edgl_score_flash_bwd_ex": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, I, I, P]),
     "edgl_score_flash_label_term": (I, [P, P, P, P, I, I, I, I, I, P, P, P, I, P]),

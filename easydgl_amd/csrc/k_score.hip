@@ -113,6 +113,7 @@ struct ScoreP {
     int table_ready;                                    // tableT already written by edgl_score_prepare_table
     const int32_t* wtotal;                              // data parallel: weighted rows of the GLOBAL batch (denominator of the loss)
     bool defer_label;                                   // strip path: the caller applies the one-hot term (edgl_score_flash_label_term)
+    float* ce_part;                                     // one-launch row finish: per-workgroup sums of -log(p_label + 1e-5) (edgl_score_ce_nparts)
 };
 
 // ---- streamed tile: global -> registers -> LDS -------------------------------------------------
@@ -834,8 +835,10 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
                                                                const float* out_bias, const int64_t* labels, const int32_t* nvalid,
                                                                const int32_t* wtotal, int R, int xb, int zb, int G, int ztotal,
                                                                const float* gscale, float* row_lse, float* lab_out, float* coef_out,
-                                                               TO* out) {
+                                                               TO* out, float* ce_part) {
     constexpr int C = 4 * LPR, MAXCH = 16;
+    __shared__ float ce_red[8];
+    float ce_num = 0.f;       // this thread's rows: -log(p_label + 1e-5) of the weighted ones (EasyDGL.py:181-185), one lane per row
     const float gs = gscale ? gscale[0] : 1.0f;
     const int Reff = nvalid ? min(R, nvalid[0]) : R;
     const float W = (float)(wtotal ? wtotal[0] : Reff) + 1e-5f;       // EasyDGL.py:184 over the global batch
@@ -925,7 +928,10 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
         const float ll = lab == 0 ? -1000.0f : a + ob;
         const float v = __expf(ll - lse);
         const float cf = (r < Reff && lab != 0) ? (1.f / W) * (v / (v + 1e-5f)) : 0.f;
-        if (live && c == 0) { row_lse[r] = lse; lab_out[r] = ll; coef_out[r] = cf; }
+        if (live && c == 0) {
+            row_lse[r] = lse; lab_out[r] = ll; coef_out[r] = cf;
+            ce_num += (r < Reff && lab != 0) ? -__logf(v + 1e-5f) : 0.f;
+        }
         // ---- d_rows = gs * coef * ( sum_chunks slab_c * exp(m_c - lse)  -  table[label] )
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] *= inv_sm;
@@ -935,6 +941,13 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
         if (live) {
             if constexpr (sizeof(TO) == 2) { const Frag4<TO> f = frag_from_acc<TO>(f32x4{o4[0], o4[1], o4[2], o4[3]}); *reinterpret_cast<uint2*>(out + (long)r * C + c) = *reinterpret_cast<const uint2*>(&f); }
             else *reinterpret_cast<float4*>(out + (long)r * C + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        }
+    }
+    if (ce_part) {      // the loss numerator of this workgroup's rows: the loss kernel then adds <= 4096 numbers instead of sweeping the rows
+        ce_num = block_sum(ce_num, ce_red);
+        if (threadIdx.x == 0) {
+            ce_part[blockIdx.x] = ce_num;
+            if (blockIdx.x == 0) ce_part[gridDim.x] = (float)Reff;      // ... and the weighted-row count behind the sums (exact below 2^24)
         }
     }
 }
@@ -1147,6 +1160,26 @@ __global__ __launch_bounds__(1024) void ce_loss_kernel(const float* row_lse, con
         }
         coef[m] = cf;
     }
+}
+
+// ce_loss_kernel for a forward that left per-workgroup sums of -log(p_label + 1e-5) (flash_finish_lse_kernel: ce_part): the loss is
+// their sum over the weighted-row count (+ the regularisation terms) — a few thousand numbers instead of three arrays of R rows,
+// and nothing of the batch (labels, lse, label logits) is read: the launch may run any time before the next forward rewrites ce_part.
+__global__ __launch_bounds__(1024) void ce_loss_parts_kernel(const float* ce_part, int nparts, float* loss_out,
+                                                             const float* add_in, const float* add_in2, const int32_t* wtotal) {
+    __shared__ float red[16];
+    float num = 0.f;
+    for (int i0 = threadIdx.x; i0 < nparts; i0 += 1024 * 4) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ce_part[min(i0 + j * 1024, nparts - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) num += i0 + j * 1024 < nparts ? v[j] : 0.f;
+    }
+    num = block_sum(num, red);
+    if (threadIdx.x != 0) return;
+    const float W = (wtotal ? (float)wtotal[0] : ce_part[nparts]) + 1e-5f;     // (the count rides behind the sums)
+    loss_out[0] = num / W + (add_in ? add_in[0] : 0.f) + (add_in2 ? add_in2[0] : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1802,7 +1835,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
 #define EDGL_FFL(LPR, S16)                                                                                                     \
     hipLaunchKernelGGL((flash_finish_lse_kernel<T, LPR, S16>), dim3((unsigned)std::min<long>(((long)p.R * LPR + 255) / 256, 4096)), \
                        dim3(256), 0, st, slabY, part, rows_t, tab_t, p.out_bias, p.labels, p.nvalid, p.wtotal, p.R, xb, ZBK, G, \
-                       p.i1 - p.i0, p.gscale, p.row_lse, p.lab_out, p.coef_out, out_t)
+                       p.i1 - p.i0, p.gscale, p.row_lse, p.lab_out, p.coef_out, out_t, p.ce_part)
             if (p.C == 128 && slab16) EDGL_FFL(32, true); else if (p.C == 128) EDGL_FFL(32, false); else if (p.C == 64) EDGL_FFL(16, false); else EDGL_FFL(64, false);
 #undef EDGL_FFL
             EDGL_LAUNCH_CHECK();
@@ -2006,6 +2039,23 @@ extern "C" int edgl_ce_loss_fwd_add_w(const float* row_lse, const float* label_l
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
+// number of per-workgroup loss sums edgl_score_flash_fwd_rows_wp writes (0: this shape has no one-launch row finish)
+extern "C" int edgl_score_ce_nparts(int R, int C) {
+    if (!(C == 128 || C == 64 || C == 256) || R <= 0) return 0;
+    const long lpr = C / 4;
+    return (int)std::min<long>(((long)R * lpr + 255) / 256, 4096);
+}
+// loss (EasyDGL.py:181-188) from the sums edgl_score_flash_fwd_rows_wp left in ce_part: sum / (weighted rows + 1e-5) + add_in + add_in2
+// (ce_part: edgl_score_ce_nparts(R, C) sums and, behind them, the weighted-row count — nparts + 1 floats; wtotal: the global count
+// under data parallelism)
+extern "C" int edgl_ce_loss_parts(const float* ce_part, int nparts, float* loss_out, const float* add_in, const float* add_in2,
+                                  const int32_t* wtotal, void* stream) {
+    EDGL_REQUIRE(ce_part && loss_out && nparts > 0, EDGL_ERR_NULL, "edgl_ce_loss_parts: null pointer / bad size");
+    hipLaunchKernelGGL(ce_loss_parts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ce_part, nparts, loss_out, add_in, add_in2,
+                       wtotal);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
 extern "C" int edgl_ce_loss_fwd_add(const float* row_lse, const float* label_logit, const int64_t* labels, int R, float* loss_out,
                                     float* coef, const float* add_in, const float* add_in2, void* stream) {
     return edgl_ce_loss_fwd_add_w(row_lse, label_logit, labels, R, loss_out, coef, add_in, add_in2, nullptr, stream);
@@ -2124,17 +2174,32 @@ extern "C" int edgl_score_flash_fwd_coef_w(const void* rows, const void* table, 
 // edgl_score_flash_fwd_coef_w that also finishes the rows: d_rows (= gscale * d loss / d rows, what edgl_score_flash_bwd would write)
 // comes out of the same launch as lse / label logits / coefficients; edgl_score_flash_bwd is then called with d_rows = NULL and
 // only runs the table side.
+extern "C" int edgl_score_flash_fwd_rows_wp(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
+                                            int C, int I, const int32_t* nvalid, const int32_t* wtotal, const float* gscale,
+                                            float* row_lse, float* label_logit, float* coef, void* d_rows, float* ce_part,
+                                            float* workspace, int dtype, void* stream);
 extern "C" int edgl_score_flash_fwd_rows_w(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
                                            int C, int I, const int32_t* nvalid, const int32_t* wtotal, const float* gscale,
                                            float* row_lse, float* label_logit, float* coef, void* d_rows, float* workspace,
                                            int dtype, void* stream) {
+    return edgl_score_flash_fwd_rows_wp(rows, table, out_bias, labels, R, C, I, nvalid, wtotal, gscale, row_lse, label_logit, coef, d_rows,
+                                        nullptr, workspace, dtype, stream);
+}
+// ... that also leaves the loss numerator as edgl_score_ce_nparts(R, C) per-workgroup sums in ce_part (NULL: none), for
+// edgl_ce_loss_parts — the loss launch then reads nothing of the batch
+extern "C" int edgl_score_flash_fwd_rows_wp(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R,
+                                            int C, int I, const int32_t* nvalid, const int32_t* wtotal, const float* gscale,
+                                            float* row_lse, float* label_logit, float* coef, void* d_rows, float* ce_part,
+                                            float* workspace, int dtype, void* stream) {
     int rc = check_score(rows, table, out_bias, R, C, I, 0, I, dtype, "edgl_score_flash_fwd_rows");
     if (rc) return rc;
+    EDGL_REQUIRE(!ce_part || edgl_score_ce_nparts(R, C) > 0, EDGL_ERR_SHAPE, "edgl_score_flash_fwd_rows_wp: no per-workgroup loss sums at C=%d", C);
     EDGL_REQUIRE(labels && row_lse && label_logit && workspace && nvalid && coef && d_rows, EDGL_ERR_NULL,
                  "edgl_score_flash_fwd_rows: null pointer (the row count of the compaction is required)");
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = 0;
     p.i1 = I; p.nvalid = nvalid; p.row_lse = row_lse; p.lab_out = label_logit; p.coef_out = coef; p.wtotal = wtotal; p.gscale = gscale;
+    p.ce_part = ce_part;
     const BwdPlan plan = bwd_plan(R, C, I, I, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 1>(p, C, plan, workspace, d_rows, nullptr, nullptr, st)

@@ -124,6 +124,9 @@ class TrainEngine:
         self.nvalid = torch.zeros(1, device=dev, dtype=torch.int32)
         self.lse, self.lab_logit, self.coef = e(self.R, dtype=f32), e(self.R, dtype=f32), e(self.R, dtype=f32)
         self.loss = e(1, dtype=f32)
+        # per-workgroup sums of the loss numerator, left by the one-launch row finish of the scoring forward (0: this width has none)
+        self.ce_nparts = int(lib.edgl_score_ce_nparts(self.R, C)) if (self.flash_ce and os.environ.get("EDGL_CE_PARTS", "1") != "0") else 0
+        self.ce_part = torch.zeros(self.ce_nparts + 1, device=dev, dtype=f32) if self.ce_nparts > 0 else None   # (+ the row count)
         # L2 + TPP terms (accumulated before the cross-entropy kernel, which adds them to its own term)
         self.loss_aux, self.loss_tpp = torch.zeros(1, device=dev, dtype=f32), torch.zeros(1, device=dev, dtype=f32)
         self.ws_l2 = e(1024, dtype=f32)
@@ -138,6 +141,18 @@ class TrainEngine:
         self._pending_label = None
         self._lazy_loss, self._side_has_grads, self._loss_unjoined = False, False, False
         self.sync_loss = True      # step(): order the returned loss on the caller's stream (a cross-stream wait behind the optimizer)
+        # sync_loss False, the loss launches reading nothing of the batch (ce_part): they are not launched at the end of the backward
+        # — the fork for them is an event record behind a kernel of the main stream, 6-8 us of idle — but by the NEXT step on the
+        # side stream, behind the event its first attention kernel waits for (or by join_loss()).  What they read — the sums of the
+        # scoring rows' finish and of sweep 1, the per-sample mark counts — exists twice and alternates step by step: step n + 1
+        # writes the other copy, and step n + 2 is ordered behind the launches by the joins it has anyway (main stream: the event of
+        # the side stream; second side stream: its wait for the side stream at the start of a step).
+        self._deferred_loss = None
+        self._alt = None
+        if self.ce_part is not None:
+            self._alt = dict(ce_part=torch.zeros_like(self.ce_part),
+                             tpp_desc=torch.zeros_like(self.tpp_desc) if self.tpp_desc is not None else None,
+                             tpp_part=[torch.zeros_like(b["tpp_part"]) if b["tpp_part"] is not None else None for b in self.blk])
         # data parallel: weighted rows / TPP normaliser of the GLOBAL batch (filled by _global_counts before a step)
         self.counts = torch.zeros(2, device=dev, dtype=torch.int32)
         self._dp = False
@@ -244,10 +259,17 @@ class TrainEngine:
             side2 = side
         sst = side.cuda_stream
         side.wait_stream(main)
+        if self._deferred_loss is not None and not legacy:
+            # the previous step's loss launches are still to come (behind ev_pack below): this step writes the other copy of their input
+            a = self._alt
+            self.ce_part, a["ce_part"] = a["ce_part"], self.ce_part
+            self.tpp_desc, a["tpp_desc"] = a["tpp_desc"], self.tpp_desc
+            for j, bj in enumerate(self.blk):
+                bj["tpp_part"], a["tpp_part"][j] = a["tpp_part"][j], bj["tpp_part"]
         if not legacy:
             side2.wait_stream(main)
             if getattr(self, "_loss_unjoined", False):
-                side2.wait_stream(side)     # the previous step's loss kernels (side) read buffers that this stream's first kernels rewrite
+                side2.wait_stream(side)     # the previous steps' loss kernels (side) read buffers that this stream's first kernels rewrite
         else:
             if not getattr(m, "_state_ahead", False):
                 self._advance_state(st)
@@ -302,6 +324,10 @@ class TrainEngine:
             if not legacy:
                 side.wait_stream(side2)
             ev_pack = side.record_event()
+            if self._deferred_loss is not None and not legacy:
+                # the previous step's loss: behind the event (nothing of this step waits for it), in front of this step's L2 term
+                self._deferred_loss(sst)
+                self._deferred_loss = None
             # L2 term: not needed before the loss kernel at the end of the backward (same stream)
             # (the transposed table image is NOT prepared here, although it depends on the weights only: written 200 us before
             # its use it has left the L2 by then and the scoring pass measured 109 -> 118 us — edgl_score_prepare_table)
@@ -369,14 +395,20 @@ class TrainEngine:
             # starts behind it, and the loss kernel — a one-workgroup reduction over the rows — leaves the critical path
             wtot = self.counts.data_ptr() if self._dp else None
             # (... and d_rows: log-sum-exp, label logits, coefficients and the row gradients leave ONE finishing launch)
-            check(lib.edgl_score_flash_fwd_rows_w(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I,
-                                                  _ptr(self.nvalid), wtot, None, _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.coef),
-                                                  _ptr(self.d_rows), _ptr(self.ws_flash), code, st), "edgl_score_flash_fwd_rows")
+            check(lib.edgl_score_flash_fwd_rows_wp(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I,
+                                                   _ptr(self.nvalid), wtot, None, _ptr(self.lse), _ptr(self.lab_logit), _ptr(self.coef),
+                                                   _ptr(self.d_rows), _ptr(self.ce_part), _ptr(self.ws_flash), code, st),
+                  "edgl_score_flash_fwd_rows")
             # (launched on the side stream at the join the backward has anyway: an event record of its own costs the main
-            # stream as much as the kernel)
-            self._pending_loss = lambda s: check(lib.edgl_ce_loss_fwd_add_w(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R,
-                                                                            _ptr(self.loss), None, aux, tpp, wtot, s),
-                                                 "edgl_ce_loss_fwd_add")
+            # stream as much as the kernel).  With the row finish's per-workgroup sums the loss launch adds a few thousand numbers
+            # and reads nothing of the batch; other widths: the kernel that sweeps lse / label logits / labels
+            if self.ce_part is not None:
+                self._pending_loss = lambda s, cp=self.ce_part: check(lib.edgl_ce_loss_parts(_ptr(cp), self.ce_nparts, _ptr(self.loss), aux,
+                                                                                             tpp, wtot, s), "edgl_ce_loss_parts")
+            else:
+                self._pending_loss = lambda s: check(lib.edgl_ce_loss_fwd_add_w(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R,
+                                                                                _ptr(self.loss), None, aux, tpp, wtot, s),
+                                                     "edgl_ce_loss_fwd_add")
         else:
             check(lib.edgl_score_lse_fwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), R, C, I, 0, I,
                                          _ptr(self.nvalid), _ptr(self.lse), _ptr(self.lab_logit), None, _ptr(self.ws), code, st),
@@ -406,8 +438,13 @@ class TrainEngine:
             self._loss_unjoined = False
 
     def join_loss(self) -> None:
-        """Orders the current stream behind the kernels that write `self.loss` (the side stream) — needed before the loss is
-        read on the current stream when step() ran with `sync_loss = False`."""
+        """Orders the current stream behind the kernels that write `self.loss` (launching them first if the last step left them
+        for the next one) — needed before the loss is read on the current stream when step() ran with `sync_loss = False`."""
+        if self._deferred_loss is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self._deferred_loss(self.side.cuda_stream)
+            self._deferred_loss = None
+            self._loss_unjoined = True
         if getattr(self, "_loss_unjoined", False):
             torch.cuda.current_stream().wait_stream(self.side)
             self._loss_unjoined = False
@@ -531,17 +568,25 @@ class TrainEngine:
                 # every slab reduction queued so far (weight-gradient GEMMs, BiMAU / LayerNorm partials) runs on the side
                 # stream under the embedding backward, whose atomics leave the CUs mostly idle
                 # (bound of this fork, measured with the loss kernels left out: 6-8 us of the step — the event record behind the dX GEMM)
-                self.side.wait_stream(torch.cuda.current_stream())
-                if self.fused_tpp:    # the regulariser from sweep 1's partial sums, block by block
-                    for j, bj in enumerate(self.blk):
-                        check(lib.edgl_tpp_finish_parts(_ptr(bj["tpp_part"]), B * H, float(m.ct_reg / H), H,
-                                                        None if self._dp else _ptr(self.tpp_desc), B, T, M, _ptr(bj["tpp"]),
-                                                        _ptr(self.loss_tpp), 1 if j > 0 else 0, self.side.cuda_stream),
-                              "edgl_tpp_finish_parts")
-                if self._pending_loss is not None:
-                    self._pending_loss(self.side.cuda_stream)
-                    self._pending_loss = None
+                pending, self._pending_loss = self._pending_loss, None
+
+                def loss_launches(s, pending=pending, parts=[bj["tpp_part"] for bj in self.blk], desc=self.tpp_desc):
+                    if self.fused_tpp:    # the regulariser from sweep 1's partial sums, block by block
+                        for j, bj in enumerate(self.blk):
+                            check(lib.edgl_tpp_finish_parts(_ptr(parts[j]), B * H, float(m.ct_reg / H), H,
+                                                            None if self._dp else _ptr(desc), B, T, M, _ptr(bj["tpp"]),
+                                                            _ptr(self.loss_tpp), 1 if j > 0 else 0, s), "edgl_tpp_finish_parts")
+                    if pending is not None:
+                        pending(s)
+
                 self._side_has_grads = self._pending_label is not None      # (the one-hot term's atomics: Adam must wait for them)
+                if self._lazy_loss and not self.sync_loss and not self._side_has_grads and self.ce_part is not None and \
+                        (self.fused_tpp or m.ct_reg == 0.0) and os.environ.get("EDGL_DEFER_LOSS", "1") != "0" and \
+                        os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") != "1":
+                    self._deferred_loss = loss_launches      # no fork here: _issue() of the next step, or join_loss()
+                else:
+                    self.side.wait_stream(torch.cuda.current_stream())
+                    loss_launches(self.side.cuda_stream)
                 if self._pending_label is not None:
                     self._pending_label(self.side.cuda_stream)
                     self._pending_label = None

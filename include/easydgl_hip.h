@@ -389,6 +389,17 @@ int edgl_score_flash_fwd_coef_w(const void* rows, const void* table, const float
 int edgl_score_flash_fwd_rows_w(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
                                 int I, const int32_t* nvalid, const int32_t* wtotal, const float* gscale, float* row_lse,
                                 float* label_logit, float* coef, void* d_rows, float* workspace, int dtype, void* stream);
+/* edgl_score_flash_fwd_rows_w that also leaves the loss numerator — sum over the weighted rows of -log(p_label + 1e-5),
+ * EasyDGL.py:181-185 — as edgl_score_ce_nparts(R, C) per-workgroup sums in ce_part, the weighted-row count behind them (nparts + 1
+ * floats; 0 parts: this width has no one-launch row finish; ce_part NULL: none).  edgl_ce_loss_parts forms the loss from them: sum / (weighted rows + 1e-5) + add_in + add_in2; it
+ * reads nothing else of the batch, so it may run any time before the next forward rewrites ce_part. */
+int edgl_score_ce_nparts(int R, int C);
+int edgl_score_flash_fwd_rows_wp(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
+                                 int I, const int32_t* nvalid, const int32_t* wtotal, const float* gscale, float* row_lse,
+                                 float* label_logit, float* coef, void* d_rows, float* ce_part, float* workspace, int dtype,
+                                 void* stream);
+int edgl_ce_loss_parts(const float* ce_part, int nparts, float* loss_out, const float* add_in, const float* add_in2,
+                       const int32_t* wtotal, void* stream);      /* ce_part: nparts + 1 floats (the weighted-row count rides last) */
 int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
                          const float* row_lse, const float* coef, const float* gscale, int R, int C, int I, int i0,
                          int i1, const int32_t* nvalid, void* d_rows, float* d_table, float* d_bias, float* workspace,

@@ -240,3 +240,49 @@ def test_step_with_the_loss_left_on_the_side_stream_gives_the_same_trajectory():
         assert abs(a - b) <= 1e-5 * abs(a)
     # (not bit for bit: the embedding scatter's f32 atomics commute only up to rounding, in either form)
     assert float((out[True][1] - out[False][1]).abs().max()) <= 1e-5 * float(out[True][1].abs().max())
+
+
+@pytest.mark.parametrize("parts,defer", [("0", "1"), ("1", "0"), ("1", "1")])
+def test_loss_from_the_row_finish_sums_and_launched_with_the_next_step(parts, defer, monkeypatch):
+    """The loss from the per-workgroup sums of the scoring rows' finish (edgl_ce_loss_parts) against the kernel that sweeps the rows;
+    with sync_loss = False its launches wait for the next step's start (third stream) or for join_loss(): the loss of step n is
+    in place once step n + 1 has run, the last one after join_loss(), and the weights follow the joined form."""
+    from easydgl_amd.engine import TrainEngine
+    prob = make_problem(seed=53, batch=6, **CASES[2])
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+
+    def run(sync):
+        m = build_model(prob, "bf16", hidden_drop=0.1, att_drop=0.1)
+        eng = TrainEngine(m, 6, use_graph=False)
+        eng.sync_loss = sync
+        eng.load_batch(feats, labels)
+        return m, eng
+
+    monkeypatch.setenv("EDGL_CE_PARTS", "0")
+    m0, e0 = run(True)
+    assert e0.ce_part is None
+    want = []
+    for _ in range(4):
+        want.append(float(e0.step()))
+    torch.cuda.synchronize()
+    monkeypatch.setenv("EDGL_CE_PARTS", parts)
+    monkeypatch.setenv("EDGL_DEFER_LOSS", defer)
+    m1, e1 = run(False)
+    assert (e1.ce_part is not None) == (parts == "1")
+    deferred = parts == "1" and defer == "1"
+    got = []
+    for n in range(4):
+        e1.step()
+        assert (e1._deferred_loss is not None) == deferred
+        torch.cuda.synchronize()
+        if deferred and n > 0:
+            got.append(float(e1.loss))      # the previous step's loss: launched at the start of this one
+    e1.join_loss()
+    assert e1._deferred_loss is None and not e1._loss_unjoined
+    got.append(float(e1.loss))
+    if not deferred:
+        want = want[-1:]
+    assert len(got) == len(want)
+    for a, b in zip(want, got):
+        assert abs(a - b) <= 1e-5 * abs(a), (want, got)
+    assert float((m0._arena - m1._arena).abs().max()) <= 1e-5 * float(m0._arena.abs().max())
