@@ -625,7 +625,18 @@ __device__ __forceinline__ void tn_body(const TnP& p, int bx, int by, int bz, bf
     for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float csum = 0.f;   // thread t < TM: column n0 + t of Y
+    // Column sums of Y (db) ride on the matrix pipe: a ones operand against the Y fragments this wave holds anyway, two of the four
+    // n-tiles per wave (wm picks the pair) — +12 % matrix instructions instead of a 64-deep LDS loop on two of the four waves
+    constexpr int NCS = NI / 2;
+    f32x4 acc_cs[NCS];
+#pragma unroll
+    for (int j = 0; j < NCS; ++j) acc_cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_cs = p.with_colsum && by == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    // (A second row tile in flight in registers behind the one in LDS was measured: grouped dW 72 -> 79 us, with these column sums
+    // 106 us — the ~500 workgroups already keep the memory system's queues full, more requests only lengthen them.)
     uint4 px[NLD], py[NLD];
     int r0_cur = 0;
     // unconditional loads (row clamped into the split, column offset into the matrix); rows past the split are zeroed
@@ -666,10 +677,15 @@ __device__ __forceinline__ void tn_body(const TnP& p, int bx, int by, int bz, bf
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf_[j], acc[i][j], 0, 0, 0);
-        }
-        if (p.with_colsum && by == 0 && tid < TM) {
-#pragma unroll 8
-            for (int r = 0; r < T_BR; ++r) csum += to_f32(Ys[r * LDT + tid]);
+            if (do_cs) {
+                if (wm) {
+#pragma unroll
+                    for (int j = 0; j < NCS; ++j) acc_cs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf_[NCS + j], acc_cs[j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NCS; ++j) acc_cs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, bf_[j], acc_cs[j], 0, 0, 0);
+                }
+            }
         }
         lds_barrier();       // all reads of this tile done; the next tile's global loads stay in flight across it
         if (more) store();
@@ -689,7 +705,13 @@ __device__ __forceinline__ void tn_body(const TnP& p, int bx, int by, int bz, bf
                 }
             }
         }
-    if (p.with_colsum && by == 0 && tid < TM && n0 + tid < p.N) out[(long)p.Kf * p.N + n0 + tid] = csum;
+    if (do_cs && lane < 16) {      // (every row of the ones product holds the sums: row 0 writes them)
+#pragma unroll
+        for (int j = 0; j < NCS; ++j) {
+            const int n = n0 + wn * (TM / 2) + (wm * NCS + j) * 16 + lane;
+            if (n < p.N) out[(long)p.Kf * p.N + n] = acc_cs[j][0];
+        }
+    }
 }
 
 template <int TM>
