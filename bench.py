@@ -557,9 +557,10 @@ def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=Fa
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     # HIP events inside the timed region cost ~6 us of launch-stream idle each (measured: kernel timeline): ONE kernel group is
-    # bracketed per step, three steps out of BR_EVERY = 8 (scoring rows pass, BiMAU forward, BiMAU backward), and the step marks are
+    # bracketed per step, three steps out of BR_EVERY = 8 or 16 (scoring rows pass, BiMAU forward, BiMAU backward), and the step marks are
     # recorded every MARK_EVERY steps
-    BR_EVERY = max(4, int(os.environ.get("EDGL_BENCH_BRACKET_EVERY", "8")))   # (4: the brackets cost 1.2 % of the step; 8: 0.6 %)
+    # (4: the brackets cost 1.2 % of the step; 8: 0.6 %; 16 from 64 steps on: 0.3 %, still >= 4 launches per bracketed kernel group)
+    BR_EVERY = max(4, int(os.environ.get("EDGL_BENCH_BRACKET_EVERY", "16" if steps >= 64 else "8")))
     MARK_EVERY = int(os.environ.get("EDGL_BENCH_MARK_EVERY", "5"))
     br_used = {k: [] for k in BRACKETS}
     for i in range(steps):
