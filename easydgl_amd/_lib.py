@@ -37,6 +37,7 @@ SIGNATURES = {
     "edgl_encode_bwd": (I, [P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
     "edgl_encode_bwd_add": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P]),
     "edgl_encode_fwd_ct": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I64, F, F, P, U32, P, P, P, I, I, I, P]),
+    "edgl_encode_fwd_prep": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I64, F, F, P, U32, P, P, P, I, I, P, I, P, P, P, P, P, P, I, P]),
     "edgl_encode_bwd_add_ct": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, I, P]),
     "edgl_encode_bwd_label_fused": (I, [I, I]),
     "edgl_encode_bwd_add_label": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P, P, P, P, I, P, I, P]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "edgl_tpp_prep": (I, [P, P, P, P, I, I, I, I, P, P]),
     "edgl_bimau_bwd_tpp": (I, [P, P, P, P, P, P, P, I, P, F, P, P, P, I, I, I, I, I, F, P, U32, P, F, P, P, P, P, P, P, I, I, P]),
     "edgl_tpp_finish_parts": (I, [P, I, F, I, P, I, I, I, P, P, I, P]),
+    "edgl_tpp_finish_parts_n": (I, [P, I, F, I, P, P, I, P]),
     "edgl_adam_step": (I, [P, P, P, P, L, F, F, F, F, P, F, P, I, P, P]),
     "edgl_step_begin": (I, [P, P, F, F, F, P]),
     "edgl_adam_apply": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P]),

@@ -67,7 +67,8 @@ struct BwdP {
     // reading d_lam_ext; tpp_sums[4] (int) = next-event mark count of the batch (NULL: the sum of edgl_tpp_prep's per-sample counts),
     // tpp_coef = ct_reg / H
     const void* tpp_desc; int tpp_M; const float* tpp_sums; float tpp_coef;
-    float* tpp_part;   // [B*H, 2]: the wave's share of the regulariser's two loss sums (sum log event intensity | sum non-event term)
+    float* tpp_part;   // [B*H + 1, 2]: the wave's share of the regulariser's two loss sums (sum log event intensity | sum non-event
+                       // term); the last pair's first word = the normaliser's mark count (int)
 };
 
 template <typename T>
@@ -160,6 +161,8 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
             for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
         }
         tp_k = -p.tpp_coef / ((float)cnt * (float)p.H);   // temporal.py:331-332
+        // ... and behind the partial sums for the launch that finishes the loss term (it then reads nothing of the batch)
+        if (job == 0 && lane == 0) reinterpret_cast<int*>(p.tpp_part)[2 * p.B * p.H] = cnt;
     }
     auto load_q = [&](int qt) {
         QOps o;

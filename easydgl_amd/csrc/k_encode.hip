@@ -3,6 +3,7 @@
 // pair (2j, 2j+1) of a (b,t) row in all three C-wide sections, so a 64-lane wave covers a whole
 // C=128 row with contiguous 4/8-byte stores and one sincosf per pair.
 #include "edgl_common.h"
+#include "batch_prep.h"
 
 namespace {
 
@@ -18,11 +19,11 @@ struct EncP {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
+__device__ __forceinline__ void encode_fwd_block(const EncP& p, long block) {
     // thread = 8 consecutive channels (4 sin/cos pairs) of one (b,t) row in all three C-wide sections: 16-byte item-row
     // load, 16-byte (bf16) / 2 x 16-byte (f32) stores per section; C/8 threads share the row's id / timestamp / marks.
     const int cpr = p.C >> 3;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long gid = block * blockDim.x + threadIdx.x;
     const long row = gid / cpr;
     if (row >= (long)p.B * p.T) return;
     const int cv = (int)(gid % cpr), c0 = cv * 8, j0 = c0 >> 1;
@@ -129,6 +130,30 @@ __global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) {
             st16<T>(out + s * p.C + c0, o0);
             st16<T>(out + s * p.C + c0 + 4, o1);
         }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void encode_fwd_kernel(EncP p) { encode_fwd_block<T>(p, (long)blockIdx.x); }
+
+// The encoder's launch with the batch preparation of the step as its first workgroups: workgroup 0 = the row compaction map of the
+// scoring, workgroups 1 .. B = the slot data of the TPP regulariser (sample by sample), the rest = the encoder.  What they write is
+// read by later kernels of the same stream only.
+struct PrepP {
+    const int64_t* labels; int R; int32_t* perm; int32_t* inv; int32_t* nvalid; int64_t* labels_c;      // labels [R] = [B * M]
+    const int64_t* mpos; const float* ts_raw; int M; char* desc;                                       // desc == NULL: no slot data
+    int nprep;                                                                                         // 1 + (desc ? B : 0)
+};
+template <typename T>
+__global__ __launch_bounds__(256) void encode_prep_kernel(EncP p, PrepP q) {
+    extern __shared__ __attribute__((aligned(16))) char prep_smem[];
+    const int bid = (int)blockIdx.x;
+    if (bid == 0) {
+        batch_prep::compact_scan_body<256>(q.labels, q.R, q.perm, q.inv, q.nvalid, q.labels_c, reinterpret_cast<int*>(prep_smem));
+    } else if (bid < q.nprep) {
+        batch_prep::tpp_prep_sample(q.mpos, q.labels, q.ts_raw, p.mark_table, p.B, p.T, q.M, q.desc, bid - 1, prep_smem);
+    } else {
+        encode_fwd_block<T>(p, (long)(bid - q.nprep));
     }
 }
 
@@ -481,6 +506,46 @@ extern "C" int edgl_encode_fwd_ct(const int64_t* ids, const float* ts, const voi
     if (dtype == EDGL_F32) hipLaunchKernelGGL((encode_fwd_kernel<float>), grid, dim3(256), 0, st, p);
     else if (dtype == EDGL_BF16) hipLaunchKernelGGL((encode_fwd_kernel<bf16>), grid, dim3(256), 0, st, p);
     else { edgl_set_error("edgl_encode_fwd: bad dtype %d", dtype); return EDGL_ERR_DTYPE; }
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+// edgl_encode_fwd_ct + edgl_compact_scan_labels(labels [B * M]) + (tpp_desc != NULL) edgl_tpp_prep(masked_pos, labels, ts: the raw
+// timestamps the encoder reads, mark_table) in ONE launch: the batch preparation as the first workgroups of the encoder's grid.
+// Same results as the three calls, bit for bit.  tpp_desc needs E = 16, M <= 256, T <= 2048 (edgl_tpp_prep).
+extern "C" int edgl_encode_fwd_prep(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
+                                    const float* mark_emb, const uint8_t* mark_table, const float* tscale, int B, int T,
+                                    int C, int E, int I, int64_t mask_id, float time_scale, float drop_rate,
+                                    const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans,
+                                    uint8_t* marks, int dh_pad, int dh_true, const int64_t* labels, int M, int32_t* perm,
+                                    int32_t* inv, int32_t* nvalid, int64_t* labels_c, const int64_t* masked_pos, void* tpp_desc,
+                                    int dtype, void* stream) {
+    EDGL_REQUIRE((dh_pad == 0 && dh_true == 0) || (dh_pad > 0 && dh_true > 0 && dh_true <= dh_pad && C % dh_pad == 0), EDGL_ERR_SHAPE,
+                 "edgl_encode_fwd_prep: padded-channel spec dh_pad=%d dh_true=%d does not fit C=%d", dh_pad, dh_true, C);
+    EDGL_REQUIRE(ids && ts && item_tab && pos_tab && mark_emb && mark_table && tscale && x0 && spans && marks,
+                 EDGL_ERR_NULL, "edgl_encode_fwd_prep: null pointer");
+    EDGL_REQUIRE(labels && perm && inv && nvalid && labels_c, EDGL_ERR_NULL, "edgl_encode_fwd_prep: null pointer (compaction)");
+    EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && (C % 8) == 0 && E >= 1 && I > 1 && M > 0, EDGL_ERR_SHAPE,
+                 "edgl_encode_fwd_prep: bad shape B=%d T=%d C=%d E=%d I=%d M=%d (C must be a multiple of 8)", B, T, C, E, I, M);
+    EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_encode_fwd_prep: dropout without rng_state");
+    EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_encode_fwd_prep: bad dtype %d", dtype);
+    if (tpp_desc) {
+        EDGL_REQUIRE(masked_pos, EDGL_ERR_NULL, "edgl_encode_fwd_prep: slot data without masked positions");
+        EDGL_REQUIRE(T <= 2048 && E == 16 && M <= 256, EDGL_ERR_SHAPE,
+                     "edgl_encode_fwd_prep: slot data needs E = 16, M <= 256, T <= 2048 (B=%d T=%d E=%d M=%d)", B, T, E, M);
+        EDGL_REQUIRE((((uintptr_t)mark_table | (uintptr_t)tpp_desc) & 15) == 0, EDGL_ERR_SHAPE,
+                     "edgl_encode_fwd_prep: mark_table / tpp_desc must be 16-byte aligned");
+    }
+    EncP p{ids, ts, item_tab, pos_tab, mark_emb, mark_table, tscale, B, T, C, E, I, mask_id, time_scale,
+           drop_rate, rng_state, stream_id, x0, spans, marks, dh_pad, dh_true,
+           sqrtf((float)(dh_pad ? C / dh_pad * dh_true : C))};
+    PrepP q{labels, B * M, perm, inv, nvalid, labels_c, masked_pos, ts, M, (char*)tpp_desc, 1 + (tpp_desc ? B : 0)};
+    const long total = (long)B * T * (C / 8);
+    dim3 grid((unsigned)((total + 255) / 256 + q.nprep));
+    const size_t smem = tpp_desc ? (size_t)T * 16 + 2 * 256 * sizeof(int) : 2 * 16 * 4 * sizeof(int);     // (slot data >= the scan's counts)
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == EDGL_F32) hipLaunchKernelGGL((encode_prep_kernel<float>), grid, dim3(256), smem, st, p, q);
+    else hipLaunchKernelGGL((encode_prep_kernel<bf16>), grid, dim3(256), smem, st, p, q);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

@@ -6,6 +6,7 @@
 
 #include "edgl_common.h"
 #include "bimau_common.h"   // TppDesc / tpp_layout: slot data of the fused TPP form
+#include "batch_prep.h"     // slot data of a sample (also run inside the encoder's launch)
 
 namespace {
 thread_local char g_err[512] = "";
@@ -50,12 +51,7 @@ struct TppP {
     int B, T, H, E, M; float coef;
 };
 
-__device__ __forceinline__ float raw_span(const float* ts_row, int pos, int T) {
-    // EasyDGL.py:161-162 on RAW seconds: span[t] = clip(ts[t]-ts[t-1], 0, 100), span[0] := span[1]
-    if (T < 2) return 0.f;
-    const int t1 = pos == 0 ? 1 : pos;
-    return fminf(fmaxf(ts_row[t1] - ts_row[t1 - 1], 0.f), 100.f);
-}
+using batch_prep::raw_span;   // EasyDGL.py:161-162 on RAW seconds
 
 // per-row terms; returns (event_ll, non_event, n_marks); optionally the pieces needed by the backward
 __device__ __forceinline__ void tpp_row(const TppP& p, long j, float& ev_ll, float& non_ev, float& nmk, float* ev_out,
@@ -463,54 +459,7 @@ __global__ __launch_bounds__(256) void tpp_rows_wide_kernel(TppP p, const float*
 __global__ __launch_bounds__(256) void tpp_prep_kernel(const int64_t* mpos, const int64_t* labels, const float* ts, const uint8_t* mtab,
                                                        int B, int T, int M, char* desc) {
     extern __shared__ __attribute__((aligned(16))) char tpp_smem[];
-    uint4* nm_s = reinterpret_cast<uint4*>(tpp_smem);                 // [T] mark rows of the positions' first effective slots
-    int* pos_s = reinterpret_cast<int*>(nm_s + T);                    // [256] position of an effective slot, -1 otherwise
-    int* ovf_s = pos_s + 256;                                         // [256] 1: effective, not the first of its position
-    const bimau::TppLayout lay = bimau::tpp_layout(B, T, M);
-    const int b = blockIdx.x, m = threadIdx.x;
-    for (int t = m; t < T; t += 256) nm_s[t] = make_uint4(0u, 0u, 0u, 0u);
-    int pos = -1;
-    uint4 nm = make_uint4(0u, 0u, 0u, 0u);
-    if (m < M) {
-        const int pin = (int)mpos[(long)b * M + m];
-        const int64_t lab = labels[(long)b * M + m];
-        nm = *reinterpret_cast<const uint4*>(mtab + lab * 16);
-        if (pin >= 0 && pin < T && (nm.x | nm.y | nm.z | nm.w) != 0u) pos = pin;
-    }
-    pos_s[m] = pos;
-    {   // marks of this slot's label (valid position or not, as edgl_tpp_norm counts them)
-        const uint32_t ws[4] = {nm.x, nm.y, nm.z, nm.w};
-        int c = 0;
-        if (m < M) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c += (int)((ws[q] & 0xffu) + ((ws[q] >> 8) & 0xffu) + ((ws[q] >> 16) & 0xffu) + (ws[q] >> 24));
-        }
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if ((m & 63) == 0) ovf_s[m >> 6] = c;     // (ovf_s is written for real behind the next barrier)
-    }
-    __syncthreads();
-    const int cnt_b = ovf_s[0] + ovf_s[1] + ovf_s[2] + ovf_s[3];
-    __syncthreads();
-    bool first = pos >= 0;
-    for (int q = 0; q < m; ++q) first = first && pos_s[q] != pos;
-    ovf_s[m] = (pos >= 0 && !first) ? 1 : 0;
-    if (pos >= 0 && first) nm_s[pos] = nm;
-    __syncthreads();
-    uint4* nmw = reinterpret_cast<uint4*>(desc) + (long)b * T;
-    float* spr = reinterpret_cast<float*>(desc + lay.off_spr) + (long)b * T;
-    for (int t = m; t < T; t += 256) {
-        const uint4 w = nm_s[t];
-        nmw[t] = w;
-        spr[t] = (w.x | w.y | w.z | w.w) != 0u ? raw_span(ts + (long)b * T, t, T) : -1.0f;
-    }
-    int rank = 0, total = 0;
-    for (int q = 0; q < M; ++q) { rank += q < m ? ovf_s[q] : 0; total += ovf_s[q]; }
-    if (m == 0) reinterpret_cast<int*>(desc + lay.off_novf)[b] = total;
-    if (m < M && ovf_s[m]) {
-        reinterpret_cast<int*>(desc + lay.off_ovf_pos)[(long)b * M + rank] = pos;
-        reinterpret_cast<uint4*>(desc + lay.off_ovf_nm)[(long)b * M + rank] = nm;
-    }
-    if (m == 0) reinterpret_cast<int*>(desc + lay.off_cntp)[b] = cnt_b;
+    batch_prep::tpp_prep_sample(mpos, labels, ts, mtab, B, T, M, desc, (int)blockIdx.x, tpp_smem);
 }
 __global__ __launch_bounds__(256) void tpp_final2_kernel(const float* part, int nblk, float coef, int H, float* sums, float* reg_out,
                                                          int accumulate) {
@@ -534,6 +483,10 @@ __global__ __launch_bounds__(1024) void tpp_parts_kernel(const float* part, int 
                                                          float* sums, float* reg_out, int accumulate) {
     __shared__ float red[16];
     __shared__ int redi[16];
+    if (!cntp && ncnt < 0) {   // normaliser behind the partial sums, as edgl_bimau_bwd_tpp leaves it
+        if (threadIdx.x == 0) reinterpret_cast<int*>(sums)[4] = reinterpret_cast<const int*>(part)[2 * nparts];
+        __syncthreads();
+    }
     if (cntp) {   // normaliser from the per-sample counts of edgl_tpp_prep (otherwise sums[4] holds it: edgl_tpp_norm, data parallel)
         int c = 0;
         for (int i = threadIdx.x; i < ncnt; i += 1024) c += cntp[i];
@@ -1015,6 +968,17 @@ extern "C" int edgl_tpp_finish_parts(const float* part, int nparts, float coef, 
     const int* cntp = tpp_desc ? reinterpret_cast<const int*>((const char*)tpp_desc + bimau::tpp_layout(B, T, M).off_cntp) : nullptr;
     hipLaunchKernelGGL(tpp_parts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, nparts, coef, H, cntp, B, sums, reg_out,
                        accumulate);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+// edgl_tpp_finish_parts with the normaliser edgl_bimau_bwd_tpp left behind the partial sums (part: [nparts + 1, 2]; the count it
+// used — the per-sample counts' total or the data-parallel sums[4] — as an int in the last pair): reads nothing of the batch.
+extern "C" int edgl_tpp_finish_parts_n(const float* part, int nparts, float coef, int H, float* sums, float* reg_out, int accumulate,
+                                       void* stream) {
+    EDGL_REQUIRE(part && sums && reg_out, EDGL_ERR_NULL, "edgl_tpp_finish_parts_n: null pointer");
+    EDGL_REQUIRE(nparts > 0 && H > 0, EDGL_ERR_SHAPE, "edgl_tpp_finish_parts_n: bad shape nparts=%d H=%d", nparts, H);
+    hipLaunchKernelGGL(tpp_parts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, nparts, coef, H, (const int*)nullptr, -1, sums,
+                       reg_out, accumulate);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

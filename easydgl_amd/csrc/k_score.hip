@@ -24,6 +24,7 @@
 
 #include "edgl_common.h"
 #include "score_plan.h"
+#include "batch_prep.h"
 
 // csrc/k_score_strip.hip: one-wave-per-SIMD form of the two product passes (bf16, C = 128)
 bool edgl_strip_enabled();
@@ -1025,40 +1026,8 @@ __global__ void flash_finish_kernel(const float* slabs, const float* part, const
 // scoring kernels can skip the rest exactly.
 __global__ __launch_bounds__(1024) void compact_scan_kernel(const int64_t* labels, int R, int32_t* perm, int32_t* inv,
                                                             int32_t* nvalid, int64_t* labels_c) {
-    // chunks of 1024 consecutive rows: one coalesced label per thread, wave ballots + a 16-entry scan of the wave counts
-    __shared__ int wcnt[16];
-    __shared__ int s_base;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    if (t == 0) s_base = 0;
-    __syncthreads();
-    // labels of 16 chunks are fetched together (clamped, unconditional): one memory round trip per 16 K rows, not per chunk
-    for (int g0 = 0; g0 < R; g0 += 16 * 1024) {
-        int64_t labk[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) labk[k] = labels[min(g0 + k * 1024 + t, R - 1)];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (g0 + k * 1024 >= R) break;
-            const int r = g0 + k * 1024 + t;
-            const bool on = r < R && labk[k] != 0;
-            const unsigned long long bal = __ballot(on);
-            if (lane == 0) wcnt[w] = __popcll(bal);
-            lds_barrier();   // LDS-scoped: __syncthreads() would also wait for the perm / inv stores of the previous chunk
-            int before = s_base, tot = 0;
-            for (int i = 0; i < 16; ++i) { const int c = wcnt[i]; before += i < w ? c : 0; tot += c; }
-            const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
-            if (r < R) {
-                if (on) { perm[pos] = r; inv[r] = pos; if (labels_c) labels_c[pos] = labk[k]; }
-                else inv[r] = -1;
-            }
-            lds_barrier();
-            if (t == 0) s_base += tot;
-        }
-    }
-    __syncthreads();
-    const int total = s_base;
-    for (int j = total + t; j < R; j += 1024) { perm[j] = -1; if (labels_c) labels_c[j] = 0; }
-    if (t == 0) nvalid[0] = total;
+    __shared__ int wcnt[2 * 16 * 16];
+    batch_prep::compact_scan_body<1024>(labels, R, perm, inv, nvalid, labels_c, wcnt);
 }
 template <typename T>
 __global__ void compact_gather_kernel(const T* rows, const int64_t* labels, const int32_t* perm, int R, int C, T* rows_c,

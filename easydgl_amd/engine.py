@@ -81,7 +81,7 @@ class TrainEngine:
                      pack=e(0 if self.mgroups else lib.edgl_bimau_pack_bytes(C, H, E, self.code), dtype=torch.uint8),
                      saved=e(0 if self.mgroups else lib.edgl_bimau_saved_bytes(B, T, C, H, self.code), dtype=torch.uint8),
                      dlam=None if self.fused_tpp else e(H * B, T, E, dtype=f32),
-                     tpp_part=torch.zeros((B * H, 2), device=dev, dtype=f32) if self.fused_tpp else None,
+                     tpp_part=torch.zeros((B * H + 1, 2), device=dev, dtype=f32) if self.fused_tpp else None,   # (+ the count)
                      tpp=torch.zeros(max(lib.edgl_tpp_workspace(), lib.edgl_tpp_rows_workspace(B, H, M)), device=dev, dtype=f32))
             # stored keep bits of the attention dropout: hashed once per step on the side stream, read by the forward and both
             # backward sweeps (csrc/bimau_common.h; 0 bytes = no stored-bits form at this T)
@@ -266,26 +266,32 @@ class TrainEngine:
             self.tpp_desc, a["tpp_desc"] = a["tpp_desc"], self.tpp_desc
             for j, bj in enumerate(self.blk):
                 bj["tpp_part"], a["tpp_part"][j] = a["tpp_part"][j], bj["tpp_part"]
+        # The batch preparation (row compaction map, slot data of the regulariser) as the first workgroups of the encoder's launch:
+        # on a second side stream its join sat in the chain the first attention kernel waits for — a wait costs the waiting stream
+        # ~6 us wherever its event stands (measured without it: -5 us of the step)
+        prep_enc = not legacy and os.environ.get("EDGL_PREP_IN_ENCODER", "1") != "0"
         if not legacy:
-            side2.wait_stream(main)
-            if getattr(self, "_loss_unjoined", False):
-                side2.wait_stream(side)     # the previous steps' loss kernels (side) read buffers that this stream's first kernels rewrite
+            if not prep_enc:
+                side2.wait_stream(main)
+                if getattr(self, "_loss_unjoined", False):
+                    side2.wait_stream(side)     # the previous steps' loss kernels (side) read buffers that this stream's first kernels rewrite
         else:
             if not getattr(m, "_state_ahead", False):
                 self._advance_state(st)
             m._state_ahead = False
-        with torch.cuda.stream(side2):
-            # needed by the scoring: row compaction map (labels only).  Its one 1024-thread workgroup needs a whole CU's worth of
-            # free wave slots, which it gets beside the small encoder kernel but not once the QKVT projection fills the chip
-            # (512-unit recipe: 5 .. 516 us, the main stream waiting for it at the join)
-            check(lib.edgl_compact_scan_labels(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid),
-                                               _ptr(self.labels_c), side2.cuda_stream), "edgl_compact_scan_labels")
-            if self.fused_tpp:
-                # slot data of the batch for the regulariser inside sweep 1 of the attention backward (labels / positions only), with
-                # the per-sample mark counts whose total is the regulariser's normaliser (data parallel: the all-reduced count of
-                # _global_counts is used instead).  Behind the scan: this stream is joined in front of the first attention kernel.
-                check(lib.edgl_tpp_prep(_ptr(self.mpos), _ptr(self.labels), _ptr(self.ts), _ptr(m.mark_lookup_table), B, T, E, M,
-                                        _ptr(self.tpp_desc), side2.cuda_stream), "edgl_tpp_prep")
+        if not prep_enc:
+            with torch.cuda.stream(side2):
+                # needed by the scoring: row compaction map (labels only).  Its one 1024-thread workgroup needs a whole CU's worth of
+                # free wave slots, which it gets beside the small encoder kernel but not once the QKVT projection fills the chip
+                # (512-unit recipe: 5 .. 516 us, the main stream waiting for it at the join)
+                check(lib.edgl_compact_scan_labels(_ptr(self.labels), R, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid),
+                                                   _ptr(self.labels_c), side2.cuda_stream), "edgl_compact_scan_labels")
+                if self.fused_tpp:
+                    # slot data of the batch for the regulariser inside sweep 1 of the attention backward (labels / positions only), with
+                    # the per-sample mark counts whose total is the regulariser's normaliser (data parallel: the all-reduced count of
+                    # _global_counts is used instead).  Behind the scan: this stream is joined in front of the first attention kernel.
+                    check(lib.edgl_tpp_prep(_ptr(self.mpos), _ptr(self.labels), _ptr(self.ts), _ptr(m.mark_lookup_table), B, T, E, M,
+                                            _ptr(self.tpp_desc), side2.cuda_stream), "edgl_tpp_prep")
 
         def l2_term():
             if m.l2_reg != 0.0:
@@ -321,7 +327,7 @@ class TrainEngine:
                           "edgl_bimau_dropbits")
             if not self.blk or legacy:
                 l2_term()      # (no block: the loss kernel runs on the main stream behind this one event)
-            if not legacy:
+            if not legacy and not prep_enc:
                 side.wait_stream(side2)
             ev_pack = side.record_event()
             if self._deferred_loss is not None and not legacy:
@@ -335,11 +341,20 @@ class TrainEngine:
                 l2_term()
         # ================= forward (EasyDGL.py:70-151) =================
         d0 = drop(hd, 1)
-        check(lib.edgl_encode_fwd_ct(_ptr(self.ids), _ptr(self.ts), _ptr(tab_c), _ptr(m.pcoding.pembs.lookup_table),
-                                     _ptr(m.mark_embs.lookup_table), _ptr(m.mark_lookup_table), _ptr(m.tcoding.scale), B, T, C,
-                                     E, I, int(m.mask), float(m.time_scale), float(d0.rate), d0.ptr(), d0.stream_id,
-                                     _ptr(self.x0), _ptr(self.spans), _ptr(self.marks), self.pad[0], self.pad[1], code, st),
-              "edgl_encode_fwd")
+        if prep_enc:
+            check(lib.edgl_encode_fwd_prep(_ptr(self.ids), _ptr(self.ts), _ptr(tab_c), _ptr(m.pcoding.pembs.lookup_table),
+                                           _ptr(m.mark_embs.lookup_table), _ptr(m.mark_lookup_table), _ptr(m.tcoding.scale), B, T, C,
+                                           E, I, int(m.mask), float(m.time_scale), float(d0.rate), d0.ptr(), d0.stream_id,
+                                           _ptr(self.x0), _ptr(self.spans), _ptr(self.marks), self.pad[0], self.pad[1],
+                                           _ptr(self.labels), M, _ptr(self.perm), _ptr(self.inv), _ptr(self.nvalid), _ptr(self.labels_c),
+                                           _ptr(self.mpos), _ptr(self.tpp_desc) if self.fused_tpp else None, code, st),
+                  "edgl_encode_fwd_prep")
+        else:
+            check(lib.edgl_encode_fwd_ct(_ptr(self.ids), _ptr(self.ts), _ptr(tab_c), _ptr(m.pcoding.pembs.lookup_table),
+                                         _ptr(m.mark_embs.lookup_table), _ptr(m.mark_lookup_table), _ptr(m.tcoding.scale), B, T, C,
+                                         E, I, int(m.mask), float(m.time_scale), float(d0.rate), d0.ptr(), d0.stream_id,
+                                         _ptr(self.x0), _ptr(self.spans), _ptr(self.marks), self.pad[0], self.pad[1], code, st),
+                  "edgl_encode_fwd")
         x, cin = self.x0, 3 * C
         for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
             att = blk.attention
@@ -573,9 +588,9 @@ class TrainEngine:
                 def loss_launches(s, pending=pending, parts=[bj["tpp_part"] for bj in self.blk], desc=self.tpp_desc):
                     if self.fused_tpp:    # the regulariser from sweep 1's partial sums, block by block
                         for j, bj in enumerate(self.blk):
-                            check(lib.edgl_tpp_finish_parts(_ptr(parts[j]), B * H, float(m.ct_reg / H), H,
-                                                            None if self._dp else _ptr(desc), B, T, M, _ptr(bj["tpp"]),
-                                                            _ptr(self.loss_tpp), 1 if j > 0 else 0, s), "edgl_tpp_finish_parts")
+                            # (the count sweep 1 used rides behind the sums: nothing of the batch is read here)
+                            check(lib.edgl_tpp_finish_parts_n(_ptr(parts[j]), B * H, float(m.ct_reg / H), H, _ptr(bj["tpp"]),
+                                                              _ptr(self.loss_tpp), 1 if j > 0 else 0, s), "edgl_tpp_finish_parts")
                     if pending is not None:
                         pending(s)
 

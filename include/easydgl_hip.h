@@ -113,6 +113,15 @@ int edgl_encode_fwd_ct(const int64_t* ids, const float* ts, const void* item_tab
                        const uint8_t* mark_table, const float* tscale, int B, int T, int C, int E, int I, int64_t mask_id,
                        float time_scale, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans,
                        uint8_t* marks, int dh_pad, int dh_true, int dtype, void* stream);
+/* edgl_encode_fwd_ct with the batch preparation of a training step as the first workgroups of its launch (EasyDGL.py:70-95 encoder;
+ * EasyDGL.py:177-185: which rows the loss weights — edgl_compact_scan_labels(labels [B * M]); EasyDGL.py:157-175 / temporal.py:317-333:
+ * the slots of the TPP term — edgl_tpp_prep(masked_pos, labels, ts, mark_table) into tpp_desc, NULL: none).  Same results as the
+ * three calls; what it writes is ordered in front of the stream's later kernels without a second stream and its join. */
+int edgl_encode_fwd_prep(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab, const float* mark_emb,
+                         const uint8_t* mark_table, const float* tscale, int B, int T, int C, int E, int I, int64_t mask_id,
+                         float time_scale, float drop_rate, const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans,
+                         uint8_t* marks, int dh_pad, int dh_true, const int64_t* labels, int M, int32_t* perm, int32_t* inv,
+                         int32_t* nvalid, int64_t* labels_c, const int64_t* masked_pos, void* tpp_desc, int dtype, void* stream);
 int edgl_encode_bwd_add_ct(const int64_t* ids, const uint8_t* marks, const void* dx0, const void* add1, const void* add2, int B,
                            int T, int C, int E, int I, float drop_rate, const uint64_t* rng_state, uint32_t stream_id,
                            float* d_item, float* d_pos, float* d_mark_emb, float* workspace, int c_true, int dtype, void* stream);
@@ -475,9 +484,12 @@ int edgl_tpp_fwd_bwd_rows(const float* lam, const int64_t* masked_pos, const int
  *                         normaliser, temporal.py:330); desc = edgl_tpp_prep_bytes(B, T, M) bytes, 16-byte aligned.
  *   edgl_bimau_bwd_tpp    edgl_bimau_bwd_db with the regulariser's d lambda (coef = ct_reg / H; count: tpp_sums[4] as edgl_tpp_norm or a
  *                         data-parallel all-reduce left it, tpp_sums == NULL: the total of the slot data's per-sample counts)
- *                         computed by sweep 1 from the slot data, and the two loss sums of the wave's (b, head) in tpp_part f32 [B*H, 2]
+ *                         computed by sweep 1 from the slot data, and the two loss sums of the wave's (b, head) in tpp_part f32
+ *                         [B*H + 1, 2] — the last pair's first word = the count it used (int32)
  *   edgl_tpp_finish_parts their reduction: reg_out (+)= coef * (-(sum log ev - sum non-event) / (count * H)); sums as edgl_tpp_fwd_bwd
- *                         (count: tpp_desc != NULL — from the slot data (B, T, M), also stored into sums[4]; NULL — sums[4] as given) */
+ *                         (count: tpp_desc != NULL — from the slot data (B, T, M), also stored into sums[4]; NULL — sums[4] as given)
+ *   edgl_tpp_finish_parts_n  the same with the count edgl_bimau_bwd_tpp left behind the sums (part [nparts + 1, 2]): it reads nothing
+ *                         of the batch, a training loop may launch it any time before the next edgl_bimau_bwd_tpp on that array */
 long edgl_tpp_prep_bytes(int B, int T, int M);
 int edgl_tpp_prep(const int64_t* masked_pos, const int64_t* labels, const float* ts_raw, const uint8_t* mark_table, int B, int T,
                   int E, int M, void* desc, void* stream);
@@ -488,6 +500,7 @@ int edgl_bimau_bwd_tpp(const void* qkvt, const int64_t* ids, const float* spans,
                        float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream);
 int edgl_tpp_finish_parts(const float* part, int nparts, float coef, int H, const void* tpp_desc, int B, int T, int M, float* sums,
                           float* reg_out, int accumulate, void* stream);
+int edgl_tpp_finish_parts_n(const float* part, int nparts, float coef, int H, float* sums, float* reg_out, int accumulate, void* stream);
 
 /* ---- optimizer — tf.train.AdamOptimizer (Base.py:142-144) over a flat f32 arena ----------------
  * step_state: device uint64[2]: [0] = step count (incremented by this call, so the first call is

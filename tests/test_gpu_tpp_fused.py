@@ -174,3 +174,52 @@ def test_fused_tpp_shapes_it_does_not_take_are_refused():
     assert lib.edgl_tpp_prep(_ptr(z), _ptr(z), _ptr(z), _ptr(z), 2, 10, 7, 3, _ptr(z), None) != 0     # E != 16
     assert "E = 16" in (lib.edgl_last_error() or b"").decode()
     assert lib.edgl_tpp_prep(_ptr(z), _ptr(z), _ptr(z), _ptr(z), 2, 10, 16, 300, _ptr(z), None) != 0  # M > 256
+
+
+@pytest.mark.parametrize("shape,dt", [(SMALL, "bf16"), (HEADLINE, "bf16"), (SMALL, "f32")])
+def test_batch_preparation_inside_the_encoder_launch_is_the_three_calls(shape, dt, monkeypatch):
+    """edgl_encode_fwd_prep — the row compaction map and the regulariser's slot data as the first workgroups of the encoder's launch
+    — against edgl_encode_fwd_ct + edgl_compact_scan_labels + edgl_tpp_prep on side streams: every array bit for bit, with repeated
+    masked positions and label-0 slots in the batch; the step's loss and gradients follow."""
+    from easydgl_amd.engine import TrainEngine
+    prob = make_problem(seed=17, batch=6, **shape)
+    feats, labels = _with_repeats(prob, np.random.default_rng(4))
+    labels = np.array(labels, copy=True)
+    labels[1, :2] = 0
+    labels[4] = 0          # a sample without weighted rows
+    out = {}
+    for inside in ("0", "1"):
+        monkeypatch.setenv("EDGL_PREP_IN_ENCODER", inside)
+        m = build_model(prob, dt, hidden_drop=0.1, att_drop=0.1)
+        eng = TrainEngine(m, labels.shape[0], use_graph=False)
+        for t in (eng.perm, eng.inv, eng.nvalid, eng.labels_c):
+            t.fill_(-7)
+        if eng.tpp_desc is not None:
+            eng.tpp_desc.fill_(0x5a)
+        eng.load_batch(to_dev(feats), torch.as_tensor(labels).cuda())
+        eng._issue()
+        torch.cuda.synchronize()
+        out[inside] = dict(x0=eng.x0.float().clone(), spans=eng.spans.clone(), marks=eng.marks.clone(), perm=eng.perm.clone(),
+                           inv=eng.inv.clone(), nvalid=eng.nvalid.clone(), labels_c=eng.labels_c.clone(),
+                           desc=None if eng.tpp_desc is None else eng.tpp_desc.clone(), loss=float(eng.loss),
+                           grads={n: q.grad.float().cpu().numpy().copy() for n, q in m.named_parameters()})
+        assert (eng.tpp_desc is not None) == (dt == "bf16" and shape is HEADLINE or eng.fused_tpp)
+    a, b = out["0"], out["1"]
+    assert int(a["nvalid"]) == int((labels != 0).sum())
+    for k in ("x0", "spans", "marks", "perm", "inv", "nvalid", "labels_c", "desc"):
+        if a[k] is None:
+            assert b[k] is None
+            continue
+        assert torch.equal(a[k], b[k]), k
+    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"])
+    for n, ga in a["grads"].items():
+        assert rel_err(b["grads"][n], ga) < 1e-5, n       # (same kernels on the same inputs; f32 atomics of the scatters reorder)
+
+
+def test_encode_fwd_prep_refuses_slot_data_it_cannot_build():
+    from easydgl_amd import _lib
+    lib = _lib.lib
+    z = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    args = [_ptr(z)] * 7 + [2, 10, 16, 7, 50, 49, 1.0, 0.0, None, 0] + [_ptr(z)] * 3 + [0, 0, _ptr(z), 3] + [_ptr(z)] * 6
+    assert lib.edgl_encode_fwd_prep(*args, 1, None) != 0                    # slot data with E != 16
+    assert "E = 16" in (lib.edgl_last_error() or b"").decode()
