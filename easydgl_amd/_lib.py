@@ -108,6 +108,7 @@ SIGNATURES = {
     "edgl_bimau_bwd_tpp": (I, [P, P, P, P, P, P, P, I, P, F, P, P, P, I, I, I, I, I, F, P, U32, P, F, P, P, P, P, P, P, I, I, P]),
     "edgl_tpp_finish_parts": (I, [P, I, F, I, P, I, I, I, P, P, I, P]),
     "edgl_tpp_finish_parts_n": (I, [P, I, F, I, P, P, I, P]),
+    "edgl_dp_counts": (I, [P, P, I, I, I, P, P]),
     "edgl_adam_step": (I, [P, P, P, P, L, F, F, F, F, P, F, P, I, P, P]),
     "edgl_step_begin": (I, [P, P, F, F, F, P]),
     "edgl_adam_apply": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P]),

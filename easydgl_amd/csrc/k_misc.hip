@@ -142,9 +142,10 @@ __global__ __launch_bounds__(256) void tpp_norm_kernel(TppP p, int* acc) {
 // The same count by ONE workgroup (batches up to 64 K labels): strided labels per thread, integer block sum, a plain store — no
 // memset launch in front of it and nothing stale to inherit (the memset of the atomic form was a 6 us launch of its own in the
 // side-stream chain the first attention kernel waits for).
-__global__ __launch_bounds__(1024) void tpp_norm_one_kernel(TppP p, int* acc) {
+// (nz != NULL: also the number of labels != 0 — the weighted rows of the loss, EasyDGL.py:183-185 — for edgl_dp_counts)
+__global__ __launch_bounds__(1024) void tpp_norm_one_kernel(TppP p, int* acc, int* nz) {
     __shared__ int red[16];
-    int cnt = 0;
+    int cnt = 0, cnz = 0;
     const int n = p.B * p.M;
     constexpr int NB = 8;   // labels per thread and round: all label loads of a round fly together, then all mark rows (two round
                             // trips per 8 K labels; one label -> one mark row at a time was a chain of 2 x 10 round trips: 20 us)
@@ -154,6 +155,8 @@ __global__ __launch_bounds__(1024) void tpp_norm_one_kernel(TppP p, int* acc) {
         for (int j = 0; j < NB; ++j) lab[j] = p.labels[min(i0 + j * 1024, n - 1)];
 #pragma unroll
         for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(lab[j]));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) cnz += (i0 + j * 1024 < n && lab[j] != 0) ? 1 : 0;
         if (p.E == 16 && ((uintptr_t)p.mtab & 15) == 0) {
             uint4 w[NB];
 #pragma unroll
@@ -183,6 +186,17 @@ __global__ __launch_bounds__(1024) void tpp_norm_one_kernel(TppP p, int* acc) {
         int t = 0;
         for (int w = 0; w < 16; ++w) t += red[w];
         acc[0] = t;
+    }
+    if (nz) {
+        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) cnz += __shfl_xor(cnz, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnz;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += red[w];
+            nz[0] = t;
+        }
     }
 }
 constexpr int TPP_MAXM = 256, TPP_MAXT = 1024, TPP_FUSED_BLOCKS = 2048;   // (4096 one-sequence workgroups measured slower: 24 vs 19 us)
@@ -869,13 +883,26 @@ extern "C" int edgl_tpp_bwd(const float* lam, const int64_t* masked_pos, const i
     return EDGL_OK;
 }
 
+// The two batch sums that normalise the loss, in one launch — counts[0] = labels != 0 (weighted rows, EasyDGL.py:183-185), counts[1] =
+// marks of all labels (temporal.py:330, what edgl_tpp_norm puts into sums[4]): what a data-parallel step all-reduces before it
+// starts (8 bytes).  B * M <= 65536.
+extern "C" int edgl_dp_counts(const int64_t* labels, const uint8_t* mark_table, int B, int M, int E, int32_t* counts, void* stream) {
+    EDGL_REQUIRE(labels && mark_table && counts, EDGL_ERR_NULL, "edgl_dp_counts: null pointer");
+    EDGL_REQUIRE(B > 0 && M > 0 && E > 0 && (long)B * M <= 65536, EDGL_ERR_SHAPE, "edgl_dp_counts: bad shape B=%d M=%d E=%d (B * M <= 65536)",
+                 B, M, E);
+    TppP p{nullptr, nullptr, labels, nullptr, mark_table, B, 0, 0, E, M, 0.f};
+    hipLaunchKernelGGL(tpp_norm_one_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, counts + 1, counts);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
 // normaliser of the regulariser: integer sum of the mark counts of the batch's labels into sums[4] (labels only: may run
 // ahead of the step's forward, e.g. on a side stream)
 extern "C" int edgl_tpp_norm(const int64_t* labels, const uint8_t* mark_table, int B, int M, int E, float* sums, void* stream) {
     EDGL_REQUIRE(labels && mark_table && sums, EDGL_ERR_NULL, "edgl_tpp_norm: null pointer");
     TppP p{nullptr, nullptr, labels, nullptr, mark_table, B, 0, 0, E, M, 0.f};
     if ((long)B * M <= 65536) {   // one workgroup, plain store
-        hipLaunchKernelGGL(tpp_norm_one_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, reinterpret_cast<int*>(sums) + 4);
+        hipLaunchKernelGGL(tpp_norm_one_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p, reinterpret_cast<int*>(sums) + 4,
+                           (int*)nullptr);
         EDGL_LAUNCH_CHECK();
         return EDGL_OK;
     }

@@ -716,12 +716,18 @@ class TrainEngine:
         Labels only: issued ahead of the step's first kernel (one 8-byte all-reduce, hidden under the encoder)."""
         import torch.distributed as dist
         m = self.m
-        self.counts[0:1] = (self.labels != 0).sum().to(torch.int32)
-        if m.ct_reg != 0.0 and self.blk:
-            tpp0 = self.blk[0]["tpp"]
-            check(lib.edgl_tpp_norm(_ptr(self.labels), _ptr(m.mark_lookup_table), self.B, self.M, self.E, _ptr(tpp0), _stream()),
-                  "edgl_tpp_norm")
-            self.counts[1:2] = tpp0.view(torch.int32)[4:5]
+        if m.ct_reg != 0.0 and self.blk and self.B * self.M <= 65536:
+            # both sums in one launch (as torch ops: compare, sum, cast, two slice copies and the normaliser launch — six launches in
+            # front of the encoder of every data-parallel step)
+            check(lib.edgl_dp_counts(_ptr(self.labels), _ptr(m.mark_lookup_table), self.B, self.M, self.E, _ptr(self.counts), _stream()),
+                  "edgl_dp_counts")
+        else:
+            self.counts[0:1] = (self.labels != 0).sum().to(torch.int32)
+            if m.ct_reg != 0.0 and self.blk:
+                tpp0 = self.blk[0]["tpp"]
+                check(lib.edgl_tpp_norm(_ptr(self.labels), _ptr(m.mark_lookup_table), self.B, self.M, self.E, _ptr(tpp0), _stream()),
+                      "edgl_tpp_norm")
+                self.counts[1:2] = tpp0.view(torch.int32)[4:5]
         dist.all_reduce(self.counts, op=dist.ReduceOp.SUM, group=self.group)
         if m.ct_reg != 0.0:
             for b in self.blk:

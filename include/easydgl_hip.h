@@ -490,6 +490,8 @@ int edgl_tpp_fwd_bwd_rows(const float* lam, const int64_t* masked_pos, const int
  *                         (count: tpp_desc != NULL — from the slot data (B, T, M), also stored into sums[4]; NULL — sums[4] as given)
  *   edgl_tpp_finish_parts_n  the same with the count edgl_bimau_bwd_tpp left behind the sums (part [nparts + 1, 2]): it reads nothing
  *                         of the batch, a training loop may launch it any time before the next edgl_bimau_bwd_tpp on that array */
+/* data parallel: counts[0] = labels != 0, counts[1] = marks of all labels — the two normalisers a step all-reduces (B * M <= 65536) */
+int edgl_dp_counts(const int64_t* labels, const uint8_t* mark_table, int B, int M, int E, int32_t* counts, void* stream);
 long edgl_tpp_prep_bytes(int B, int T, int M);
 int edgl_tpp_prep(const int64_t* masked_pos, const int64_t* labels, const float* ts_raw, const uint8_t* mark_table, int B, int T,
                   int E, int M, void* desc, void* stream);

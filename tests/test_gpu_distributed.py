@@ -193,3 +193,26 @@ def test_bench_refuses_a_world_size_that_differs_from_gpus():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_dp_counts_in_one_launch():
+    """edgl_dp_counts — the two normalisers a data-parallel step all-reduces (weighted rows, EasyDGL.py:183-185; marks of all labels,
+    temporal.py:330) — against the label array itself, at 16 marks (16-byte rows) and at another mark count (byte loop)."""
+    import ctypes
+    import numpy as np
+    from easydgl_amd import _lib
+    lib = _lib.lib
+    rng = np.random.default_rng(3)
+    for (B, M, E, I) in ((512, 20, 16, 2000), (7, 5, 7, 50), (1, 1, 16, 3)):
+        mtab = (rng.random((I + 1, E)) < 0.3).astype(np.uint8)
+        mtab[0] = 0
+        labels = rng.integers(0, I + 1, size=(B, M)).astype(np.int64)
+        labels[rng.random((B, M)) < 0.4] = 0
+        d_lab, d_mt = torch.as_tensor(labels).cuda(), torch.as_tensor(mtab).cuda()
+        counts = torch.full((2,), -5, dtype=torch.int32, device="cuda")
+        rc = lib.edgl_dp_counts(ctypes.c_void_p(d_lab.data_ptr()), ctypes.c_void_p(d_mt.data_ptr()), B, M, E,
+                                ctypes.c_void_p(counts.data_ptr()), None)
+        assert rc == 0, (lib.edgl_last_error() or b"").decode()
+        assert counts.cpu().tolist() == [int((labels != 0).sum()), int(mtab[labels].sum())]
+    assert lib.edgl_dp_counts(ctypes.c_void_p(d_lab.data_ptr()), ctypes.c_void_p(d_mt.data_ptr()), 4096, 32, 16,
+                              ctypes.c_void_p(counts.data_ptr()), None) != 0      # more than 65536 labels: refused
