@@ -1,12 +1,12 @@
 """Kernel timeline of the LAST optimizer step in a rocprofv3 rocpd database: start offset, duration and the idle gap before
-each kernel.  python tools/ktimeline.py DIR/NAME_results.db <name of the first kernel of a step>"""
+each kernel.  python tools/ktimeline.py DIR/NAME_results.db [name of the first kernel of a step, default encode_prep]"""
 import sqlite3
 import sys
 
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    first = sys.argv[2] if len(sys.argv) > 2 else "rng_advance"
+    first = sys.argv[2] if len(sys.argv) > 2 else "encode_prep"
     rows = db.execute('select name, start, "end" from kernels order by start').fetchall()
     starts = [i for i, r in enumerate(rows) if first in r[0]]
     if len(starts) < 2:
