@@ -58,6 +58,9 @@ SIGNATURES = {
     "edgl_bimau_dropbits": (I, [I, I, I, F, P, U32, P, P]),
     "edgl_bimau_fwd_db": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, F, P, P, P, P, I, I, P]),
     "edgl_bimau_bwd_db": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, F, P, P, P, P, P, P, I, I, P]),
+    "edgl_bimau_job_order": (I, [P, I, I, P, P]),
+    "edgl_bimau_fwd_ord": (I, [P, P, I, P, P, P, P, I, I, I, I, I, F, P, U32, P, F, P, P, P, P, P, I, I, P]),
+    "edgl_bimau_bwd_ord": (I, [P, P, P, P, P, P, P, P, I, P, F, P, P, P, I, I, I, I, I, F, P, U32, P, F, P, P, P, P, P, P, P, I, I, P]),
     "edgl_bimau_bwd_workspace": (L, [I, I, I, I, I, I]),
     "edgl_bimau_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, P, P, I, I, P]),
     "edgl_add_layernorm_fwd": (I, [P, P, I, P, P, I, I, I, F, P, U32, P, I, P, P, I, P]),

@@ -67,6 +67,7 @@ struct BwdP {
     // reading d_lam_ext; tpp_sums[4] (int) = next-event mark count of the batch (NULL: the sum of edgl_tpp_prep's per-sample counts),
     // tpp_coef = ct_reg / H
     const void* tpp_desc; int tpp_M; const float* tpp_sums; float tpp_coef;
+    const int32_t* order;   // optional [B]: the samples in launch order (edgl_bimau_job_order); NULL: 0 .. B-1
     float* tpp_part;   // [B*H + 1, 2]: the wave's share of the regulariser's two loss sums (sum log event intensity | sum non-event
                        // term); the last pair's first word = the normaliser's mark count (int)
 };
@@ -87,7 +88,9 @@ __device__ __forceinline__ void st_frag(T* dst, const f32x4& a) {
 // diagonal set): no per-element causal compares / selects in the softmax, the diagonal as one select on a scalar-and-ed mask
 // DB: stored keep bits of the attention dropout instead of the hash (same decisions: bimau_common.h)
 // TP: d lambda of the TPP regulariser recomputed from p.tpp_desc (bimau_common.h) instead of loaded from p.d_lam_ext
-template <typename T, int DT, int NT, int EC, bool PREF = true, int FL = -1, bool DB = false, bool TP = false>
+// SK: the all-padding key tiles in front of the sequence's first real key are left out (FL == 0 only; KeyMask::kt0, bimau_common.h):
+//     the query loop and the dV accumulators exist once per key-tile count NK, dV of the skipped key rows is written as zeros
+template <typename T, int DT, int NT, int EC, bool PREF = true, int FL = -1, bool DB = false, bool TP = false, bool SK = false>
 __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (forcing 3 waves / SIMD: 83 spilled registers, 76 -> 239 us)
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -95,9 +98,13 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
     // the wave index through the scalar unit: (b, head) and every base pointer derived from them are then wave-uniform VALUES for
     // the compiler too — global addresses become scalar base + 32-bit lane offset instead of 64-bit vector arithmetic per load
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long job = (long)blockIdx.x * p.waves + wave;
-    if (job >= (long)p.B * p.H) return;
-    const int b = (int)(job / p.H), head = (int)(job % p.H);
+    // launch slot -> (b, head): p.order (edgl_bimau_job_order) lists the samples by falling key-tile count, so that the long jobs
+    // start first (a launch is two rounds of workgroups: in launch order the slowest CU would get two long ones)
+    const long slot = (long)blockIdx.x * p.waves + wave;
+    if (slot >= (long)p.B * p.H) return;
+    const int sb = (int)(slot / p.H), head = (int)(slot % p.H);
+    const int b = p.order ? __builtin_amdgcn_readfirstlane(p.order[sb]) : sb;
+    const long job = (long)b * p.H + head;   // index of the per-(b, head) partials: independent of the launch order
     const long bp = (long)head * p.B + b;
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
 
@@ -132,13 +139,6 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
     const Frag4<T> ident = identity_frag<T>(lane);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    f32x4 dVa[DT][NT];  // L(first=v, second=k)
-#pragma unroll
-    for (int u = 0; u < DT; ++u)
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) dVa[u][kt] = zero4;
-    float dsc_acc[4] = {0.f, 0.f, 0.f, 0.f};
-
     // Per-query-tile global operands are fetched one tile ahead.  The loads are unconditional (row / mark index clamped)
     // so that the prefetch is straight-line code: with per-lane branches around them the wait-count insertion falls
     // back to near-zero counts and every iteration would stall on the loads it has just issued.  Lanes past the end of
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
     const float dlx_on = p.d_lam_ext ? 1.0f : 0.0f;
     TppDesc td{};
     int tp_novf = 0;
-    float tp_k = 0.f, tp_a = 0.f, tp_b = 0.f;
+    float tp_k = 0.f;
     if constexpr (TP) {
         td = tpp_desc(p.tpp_desc, p.B, p.T, p.tpp_M);
         tp_novf = __builtin_amdgcn_readfirstlane(td.novf[b]);
@@ -208,6 +208,15 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         }
     };
     PH_DECL
+    auto run = [&](auto nk_c) {
+    constexpr int NK = decltype(nk_c)::value, K0 = NT - NK;   // this copy of the loop walks the key tiles K0 .. NT-1
+    const KeyMask<NK> kmk = keymask_tail<NK, NT>(km);
+    float dsc_acc[4] = {0.f, 0.f, 0.f, 0.f}, tp_a = 0.f, tp_b = 0.f;   // (declared in here: state a lambda captures by reference may end up in scratch)
+    f32x4 dVa[DT][NK];  // L(first=v, second=k)
+#pragma unroll
+    for (int u = 0; u < DT; ++u)
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) dVa[u][kt] = zero4;
     QOps qcur = load_q(0);
     touch_regs(qcur);   // complete before the loop (edgl_common.h)
     // Results of a query tile are stored at the TOP of the next iteration: the loop-carried prefetch makes the compiler
@@ -241,22 +250,22 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         }
         const float zq4[4] = {qcur.z.x, qcur.z.y, qcur.z.z, qcur.z.w};
         // ---- recompute S, P --------------------------------------------------------------------------------------
-        f32x4 s[NT];
+        f32x4 s[NK];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+        for (int kt = 0; kt < NK; ++kt) {
             f32x4 a = zero4;
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
+                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
         // s = P^T * (dropout scale), L(first=k, second=q): every use of P in this sweep carries the scale, so it rides on the softmax
         // normalisation (no multiply of its own)
-        if constexpr (FL == 0) masked_softmax_impl<NT, false, false>(s, km, cscale, lane, q, dk.scale);
+        if constexpr (FL == 0) masked_softmax_impl<NK, false, false>(s, kmk, cscale, lane, q, dk.scale);
         else {
-            masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);
+            masked_softmax<NK, 0>(s, kmk, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
+            for (int kt = 0; kt < NK; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[kt][r] *= dk.scale;
         }
@@ -278,14 +287,14 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         f32x4 dlamT = zero4;  // L(first=e, second=q)
         const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);   // dropout element index of (b', q, k=0)
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, zero4);
+        for (int kt = 0; kt < NK; ++kt) {
+            const f32x4 gacc = mma16(frag_ld<T>(Ms + ((K0 + kt) * 16 + l15) * EP + g4), lf, zero4);
             f32x4 da = zero4;
 #pragma unroll
             for (int vb = 0; vb < DT; ++vb)
-                da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
+                da = mma16(frag_ld<T>(Vs + ((K0 + kt) * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
             f32x4 ap, dg, gv = gacc;
-            const bool dtile = kt == qt && (FL == 0 || !(p.flags & MAU_NO_DIAG));   // only this key tile can hold k == q
+            const bool dtile = K0 + kt == qt && (FL == 0 || !(p.flags & MAU_NO_DIAG));   // only this key tile can hold k == q
             if constexpr (FL == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = (dtile && g4 + r == l15) ? 1.0f : gacc[r];   // G' diag := 1 (temporal.py:438-439)
@@ -295,12 +304,12 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
             }
             // dropout: one hash per four neighbouring elements (drop_hash_quad; rate 0: threshold 0, everything kept, scale 1)
             uint64_t hw = 0ull;
-            if constexpr (!DB) hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+            if constexpr (!DB) hw = drop_hash_quad(dk, dbase + (K0 + kt) * 16 + g4);
             const bool keep[4] = {drop_quad_keep<0>(dk, hw), drop_quad_keep<1>(dk, hw), drop_quad_keep<2>(dk, hw), drop_quad_keep<3>(dk, hw)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float fp;                                   // D*P (with the scale)
-                if constexpr (DB) fp = keep_bit(qcur.kb, kt * 4 + r, s[kt][r]);
+                if constexpr (DB) fp = keep_bit(qcur.kb, (K0 + kt) * 4 + r, s[kt][r]);
                 else fp = keep[r] ? s[kt][r] : 0.f;
                 ap[r] = gv[r] * fp;                         // A' = D*G'*P
                 dg[r] = da[r] * fp;                         // dG' = dA' * D * P
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dg[r] = (g4 + r == l15) ? 0.f : dg[r];
             }
-            dlamT = mma16(kfrag<T>(Ms, EP, MTs, LDT, kt * 16, 0, lane), frag_from_acc<T>(dg), dlamT);
+            dlamT = mma16(kfrag<T>(Ms, EP, MTs, LDT, (K0 + kt) * 16, 0, lane), frag_from_acc<T>(dg), dlamT);
             const Frag4<T> apT = frag_from_acc<T>(transpose_tile<T>(ap, ident));  // L(first=q, second=k)
 #pragma unroll
             for (int vt = 0; vt < DT; ++vt) dVa[vt][kt] = mma16(dOT[vt], apT, dVa[vt][kt]);
@@ -359,8 +368,23 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
         const int k = kt * 16 + l15;
         if (k < p.T) {
 #pragma unroll
-            for (int ut = 0; ut < DT; ++ut) st_frag<T>(dqkvt + (long)k * ldq + 2 * p.C + head * dh + ut * 16 + g4, dVa[ut][kt]);
+            for (int ut = 0; ut < DT; ++ut) {
+                T* dst = dqkvt + (long)k * ldq + 2 * p.C + head * dh + ut * 16 + g4;
+                if constexpr (K0 > 0) {   // (kt < K0: a key tile of padding only — its dV rows are exactly 0)
+                    if (kt < K0) st_frag<T>(dst, zero4);
+                    else st_frag<T>(dst, dVa[ut][kt < K0 ? 0 : kt - K0]);
+                } else {
+                    st_frag<T>(dst, dVa[ut][kt]);
+                }
+            }
         }
+    }
+    };   // run
+    if constexpr (SK) {
+        static_assert(FL == 0 && sizeof(T) == 2, "the key-tile skip exists for the bidirectional bf16 form");
+        dispatch_nk<NT>(NT - km.kt0, run);
+    } else {
+        run(std::integral_constant<int, NT>{});
     }
     PH_MARK(3);
     PH_FLUSH(0);
@@ -374,7 +398,8 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
 // four key tiles (T > 64) they alone exceed the register file.  A launch with US = 2 keeps the tiles of channel slice SL only
 // (dQ, dK, dT_ of those dh / US channels); everything that contracts over the whole head (S, P, dP, the row term) is computed by
 // every slice.  One launch per slice (the slice index selects REGISTERS: it has to be a compile-time constant).
-template <typename T, int DT, int NT, int EC, int NYP = KY_NY, bool PREF = true, int FL = -1, bool DB = false, int US = 1, int SL = 0>
+// SK: as in sweep 1 — the all-padding key tiles in front of the first real key are left out, dK / dT_ of their rows are written as zeros
+template <typename T, int DT, int NT, int EC, int NYP = KY_NY, bool PREF = true, int FL = -1, bool DB = false, int US = 1, int SL = 0, bool SK = false>
 __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     static_assert(DT % US == 0 && SL < US, "channel slices");
@@ -384,9 +409,13 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     // the wave index through the scalar unit: (b, head) and every base pointer derived from them are then wave-uniform VALUES for
     // the compiler too — global addresses become scalar base + 32-bit lane offset instead of 64-bit vector arithmetic per load
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long job = (long)blockIdx.x * p.waves + wave;
-    if (job >= (long)p.B * p.H) return;
-    const int b = (int)(job / p.H), head = (int)(job % p.H);
+    // launch slot -> (b, head): p.order (edgl_bimau_job_order) lists the samples by falling key-tile count, so that the long jobs
+    // start first (a launch is two rounds of workgroups: in launch order the slowest CU would get two long ones)
+    const long slot = (long)blockIdx.x * p.waves + wave;
+    if (slot >= (long)p.B * p.H) return;
+    const int sb = (int)(slot / p.H), head = (int)(slot % p.H);
+    const int b = p.order ? __builtin_amdgcn_readfirstlane(p.order[sb]) : sb;
+    const long job = (long)b * p.H + head;   // index of the per-(b, head) partials: independent of the launch order
     const long bp = (long)head * p.B + b;
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
 
@@ -426,12 +455,6 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const long R = (long)p.B * p.H * p.T;
 
-    f32x4 dKa[DTS][NT], dTa[DTS][NT];  // L(first=u, second=k), channel tiles U0 ..
-#pragma unroll
-    for (int u = 0; u < DTS; ++u)
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) { dKa[u][kt] = zero4; dTa[u][kt] = zero4; }
-
     // branch-free one-tile-ahead prefetch (see kernel X); kernel Y's dH partials are summed when consumed
     struct QOps { Frag4<T> qf[DT], dof[DT], hf[DT]; float4 dHp[DT][NYP]; float lam[4], rowdot; uint32_t kb; };
     auto load_q = [&](int qt) {
@@ -462,6 +485,14 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
 #ifdef EDGL_PHASE_TIMING
     const unsigned long long clk_m0 = __builtin_readcyclecounter(), clk_r0 = wall_clock64();
 #endif
+    auto run = [&](auto nk_c) {
+    constexpr int NK = decltype(nk_c)::value, K0 = NT - NK;   // this copy of the loop walks the key tiles K0 .. NT-1
+    const KeyMask<NK> kmk = keymask_tail<NK, NT>(km);
+    f32x4 dKa[DTS][NK], dTa[DTS][NK];  // L(first=u, second=k), channel tiles U0 ..
+#pragma unroll
+    for (int u = 0; u < DTS; ++u)
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) { dKa[u][kt] = zero4; dTa[u][kt] = zero4; }
     QOps qcur = load_q(0);
     touch_regs(qcur);   // complete before the loop (edgl_common.h)
     // dQ of a query tile is stored at the top of the next iteration (see kernel X: the back edge drains vmcnt)
@@ -504,18 +535,18 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         const float rowdot1 = qok ? qcur.rowdot : 0.f;
         PH_MARK(4);
         // ---- recompute S, P --------------------------------------------------------------------------------------
-        f32x4 s[NT];
+        f32x4 s[NK];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+        for (int kt = 0; kt < NK; ++kt) {
             f32x4 a = zero4;
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
+                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4), qcur.qf[ub], a);
             s[kt] = a;
         }
         PH_MARK(5);
-        if constexpr (FL == 0) masked_softmax_impl<NT, false, false>(s, km, cscale, lane, q);
-        else masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
+        if constexpr (FL == 0) masked_softmax_impl<NK, false, false>(s, kmk, cscale, lane, q);
+        else masked_softmax<NK, 0>(s, kmk, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);  // s = P^T, L(first=k, second=q)
         asm volatile("" ::: "memory");
         flush_pending();   // behind the first use of this tile's operands (see kernel X)
         asm volatile("" ::: "memory");
@@ -545,15 +576,15 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
         for (int ut = 0; ut < DTS; ++ut) dQ[ut] = zero4;
         const uint32_t dbase = (uint32_t)((bp * p.T + q) * p.T);
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            const f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, zero4);
+        for (int kt = 0; kt < NK; ++kt) {
+            const f32x4 gacc = mma16(frag_ld<T>(Ms + ((K0 + kt) * 16 + l15) * EP + g4), lf, zero4);
             f32x4 da = zero4;
 #pragma unroll
             for (int vb = 0; vb < DT; ++vb)
-                da = mma16(frag_ld<T>(Vs + (kt * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
+                da = mma16(frag_ld<T>(Vs + ((K0 + kt) * 16 + l15) * dh + vb * 16 + g4), qcur.dof[vb], da);
             f32x4 gv = gacc;
             if constexpr (FL == 0) {
-                const bool dtile = kt == qt;
+                const bool dtile = K0 + kt == qt;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gv[r] = (dtile && g4 + r == l15) ? dk.scale : gacc[r];
             } else if (kt == qt && !(p.flags & MAU_NO_DIAG)) {
@@ -561,17 +592,17 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
                 for (int r = 0; r < 4; ++r) gv[r] = (g4 + r == l15) ? ((p.flags & MAU_DIAG_ZERO) ? 0.0f : dk.scale) : gacc[r];
             }
             uint64_t hw = 0ull;
-            if constexpr (!DB) hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+            if constexpr (!DB) hw = drop_hash_quad(dk, dbase + (K0 + kt) * 16 + g4);
             const bool keep[4] = {drop_quad_keep<0>(dk, hw), drop_quad_keep<1>(dk, hw), drop_quad_keep<2>(dk, hw), drop_quad_keep<3>(dk, hw)};
             f32x4 a;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {                                       // dP1 = D * dA' * G'  (kernel X's dP1)
-                if constexpr (DB) a[r] = keep_bit(qcur.kb, kt * 4 + r, da[r] * gv[r]);
+                if constexpr (DB) a[r] = keep_bit(qcur.kb, (K0 + kt) * 4 + r, da[r] * gv[r]);
                 else a[r] = keep[r] ? da[r] * gv[r] : 0.f;
             }
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ts + (kt * 16 + l15) * dh + ub * 16 + g4), dhf[ub], a);
+                a = mma16(frag_ld<T>(Ts + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4), dhf[ub], a);
             f32x4 ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -589,7 +620,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             const Frag4<T> dsf = frag_from_acc<T>(ds);
 #pragma unroll
             for (int ut = 0; ut < DTS; ++ut)
-                dQ[ut] = mma16(kfrag<T>(Ks, dh, KTs, LDT, kt * 16, (U0 + ut) * 16, lane), dsf, dQ[ut]);
+                dQ[ut] = mma16(kfrag<T>(Ks, dh, KTs, LDT, (K0 + kt) * 16, (U0 + ut) * 16, lane), dsf, dQ[ut]);
             const Frag4<T> dsT = frag_from_acc<T>(transpose_tile<T>(ds, ident));
             const Frag4<T> pT = frag_from_acc<T>(transpose_tile<T>(s[kt], ident));
 #pragma unroll
@@ -620,14 +651,27 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
 #pragma unroll
             for (int ut = 0; ut < DTS; ++ut) {
                 T* row = dqkvt + (long)k * ldq + head * dh + (U0 + ut) * 16 + g4;
-                if constexpr (FL == 0) {
+                if (kt < K0) {   // a key tile of padding only: dK and dT_ of its rows are exactly 0
+                    st_frag<T>(row + p.C, zero4);
+                    st_frag<T>(row + 3 * p.C, zero4);
+                } else {
+                    const int kk = kt < K0 ? 0 : kt - K0;
+                    if constexpr (FL == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dKa[ut][kt][r] *= cz;
+                        for (int r = 0; r < 4; ++r) dKa[ut][kk][r] *= cz;
+                    }
+                    st_frag<T>(row + p.C, dKa[ut][kk]);
+                    st_frag<T>(row + 3 * p.C, dTa[ut][kk]);
                 }
-                st_frag<T>(row + p.C, dKa[ut][kt]);
-                st_frag<T>(row + 3 * p.C, dTa[ut][kt]);
             }
         }
+    }
+    };   // run
+    if constexpr (SK) {
+        static_assert(FL == 0 && sizeof(T) == 2, "the key-tile skip exists for the bidirectional bf16 form");
+        dispatch_nk<NT>(NT - km.kt0, run);
+    } else {
+        run(std::integral_constant<int, NT>{});
     }
     PH_MARK(2);
     PH_FLUSH(8);

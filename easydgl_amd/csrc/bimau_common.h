@@ -13,6 +13,9 @@
 //   as MFMA A operand: contracts over `first`, keeps `second` as the output row
 //   transpose_tile(): one MFMA against the identity turns L(a,b) into L(b,a).
 #pragma once
+#include <cstdlib>
+#include <type_traits>
+
 #include "edgl_common.h"
 
 namespace bimau {
@@ -156,8 +159,43 @@ __global__ void pack_kernel(const float* W1, const float* b1, const float* w, co
 //               tf.where(mask == 0, -2**32+1, s) leaves (temporal.py:425-426)
 //   -inf        k >= T (tile padding: excluded from the softmax)
 // `pad` keeps the padded-key bits for the backward (no gradient flows into a padded score).
+// kt0: the first key tile that holds a real (unpadded, k < T) key; 0 when the sequence has none.  Sequences are left-padded
+// (data/linkpred.py:142-157), so the key tiles in front of kt0 are ENTIRELY padding: their scores are -2^32+1 against a finite row
+// maximum, exp() of that is exactly 0 in f32, and P, G.P, dS, dK, dV, dT_ are exactly 0 there — the kernels that take the
+// `SK` form leave those tiles out (wave-uniform choice of a code path compiled for NK = NT - kt0 key tiles).  A sequence
+// without any real key keeps kt0 = 0: its softmax is uniform over all T keys (temporal.py:425-429).
 template <int NT>
-struct KeyMask { const float* madd; uint64_t pad; };   // pad: one bit per (key tile, register), NT <= 16   // madd: wave-private LDS array [16*NT]
+struct KeyMask { const float* madd; uint64_t pad; int kt0; };   // pad: one bit per (key tile, register), NT <= 16   // madd: wave-private LDS array [16*NT]
+// first key tile with a real key from the ballots of "key k < T and id != 0" (one 64-bit word per round of 64 keys)
+template <int NR>
+__device__ __forceinline__ int first_real_tile(const uint64_t (&real)[NR]) {
+    int first = -1;
+#pragma unroll
+    for (int i = NR - 1; i >= 0; --i)
+        if (real[i] != 0ull) first = 64 * i + (int)__builtin_ctzll(real[i]);
+    return first < 0 ? 0 : first >> 4;
+}
+// the key tiles K0 .. NT-1 of a mask as a mask of NK = NT - K0 tiles
+template <int NK, int NT>
+__device__ __forceinline__ KeyMask<NK> keymask_tail(const KeyMask<NT>& km) {
+    constexpr int K0 = NT - NK;
+    return KeyMask<NK>{km.madd + K0 * 16, km.pad >> (K0 * 4), 0};
+}
+// host side: EDGL_BIMAU_SKIP=0 launches the kernels that walk every key tile (read per launch: tests flip it)
+inline bool bimau_skip_enabled() {
+    const char* e = getenv("EDGL_BIMAU_SKIP");
+    return !(e && e[0] == '0');
+}
+// run f(std::integral_constant<int, NK>) for the wave-uniform nk in 1 .. NT
+template <int N, typename F>
+__device__ __forceinline__ void dispatch_nk(int nk, F&& f) {
+    if constexpr (N <= 1) {
+        f(std::integral_constant<int, 1>{});
+    } else {
+        if (nk >= N) f(std::integral_constant<int, N>{});
+        else dispatch_nk<N - 1>(nk, f);
+    }
+}
 // One id per lane and round (keys lane, lane + 64, ...): the additive mask goes to LDS, the padded-key bits of this lane's
 // (key tile, register) slots are cut out of the wave ballots — no per-slot id loads.
 template <int NT>
@@ -166,15 +204,17 @@ __device__ __forceinline__ KeyMask<NT> load_keymask(const int64_t* ids_row, int 
     km.pad = 0ull;
     km.madd = lds_madd;
     constexpr int NR = (16 * NT + 63) / 64;
-    uint64_t padded[NR];
+    uint64_t padded[NR], real[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int k = lane + 64 * i;
         const int64_t id = ids_row[min(k, T - 1)];
         const bool pd = k < T && id == 0;
         padded[i] = __ballot(pd);
+        real[i] = __ballot(k < T && id != 0);
         if (k < 16 * NT) lds_madd[k] = k >= T ? -INFINITY : (pd ? -4294967296.0f : 0.f);
     }
+    km.kt0 = first_real_tile<NR>(real);
     const int g4 = (lane >> 4) * 4;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
@@ -648,14 +688,16 @@ __device__ __forceinline__ KeyMask<NT> stage_wave(const T* k_src, T* k_rm, T* k_
         KeyMask<NT> km;
         km.pad = 0ull;
         km.madd = lds_madd;
-        uint64_t padded[NR];
+        uint64_t padded[NR], real[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int k = lane + 64 * i;
             const bool pd = k < Tlen && id[i] == 0;
             padded[i] = __ballot(pd);
+            real[i] = __ballot(k < Tlen && id[i] != 0);
             if (k < Tp) lds_madd[k] = k >= Tlen ? -INFINITY : (pd ? -4294967296.0f : 0.f);
         }
+        km.kt0 = first_real_tile<NR>(real);
         const int g4 = (lane >> 4) * 4;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {

@@ -34,6 +34,7 @@ struct FwdP {
     int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
     const uint32_t* dbits;   // optional: keep bits of the attention dropout (edgl_bimau_dropbits, bimau_common.h)
     float qk_scale;          // score scale (0: 1 / sqrt(dh), temporal.py:422); a zero-padded head of true width d < dh passes 1 / sqrt(d)
+    const int32_t* order;    // optional [B]: the samples in launch order (edgl_bimau_job_order); NULL: 0 .. B-1
 };
 
 // wave-private LDS bytes of a phase (K always; T_ unless values phase; V and marks unless scores phase; the f32 key mask)
@@ -47,7 +48,10 @@ __host__ __device__ constexpr size_t fwd_wave_bytes() {
 // DT = dh/16, NT = ceil(T/16); EC = compile-time mark count (16: all LDS offsets are immediates and the mark loop is
 // one straight-line block) or 0 (runtime p.E)
 // DB: the attention dropout reads stored keep bits (p.dbits) instead of hashing — same decisions (bimau_common.h)
-template <typename T, int DT, int NT, int EC, int PHASE = 0, bool DB = false>
+// SK: the key tiles in front of the first real key (left padding: KeyMask::kt0) are left out — exact, see bimau_common.h.  The
+//     query loop exists once per key-tile count NK = 1 .. NT (straight-line code with NK-entry register arrays each); the wave
+//     picks its copy by a scalar branch.  Bidirectional flags only (a causal row's score replacement depends on q).
+template <typename T, int DT, int NT, int EC, int PHASE = 0, bool DB = false, bool SK = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHASE == 0) ? EDGL_BIMAU_FWD_WAVES : 1) void bimau_fwd_kernel(FwdP p) {
     constexpr int dh = 16 * DT, Tp = 16 * NT, LDT = Tp + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,9 +72,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
     // the wave index through the scalar unit: (b, head) and every base pointer derived from them are then wave-uniform VALUES for
     // the compiler too — global addresses become scalar base + 32-bit lane offset instead of 64-bit vector arithmetic per load
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long job = (long)blockIdx.x * p.waves + wave;
-    if (job >= (long)p.B * p.H) return;
-    const int b = (int)(job / p.H), head = (int)(job % p.H);
+    // launch slot -> (b, head): p.order (edgl_bimau_job_order) lists the samples by falling key-tile count, so that the long jobs
+    // start first (a launch is two rounds of workgroups: in launch order the slowest CU would get two long ones)
+    const long slot = (long)blockIdx.x * p.waves + wave;
+    if (slot >= (long)p.B * p.H) return;
+    const int sb = (int)(slot / p.H), head = (int)(slot % p.H);
+    const int b = p.order ? __builtin_amdgcn_readfirstlane(p.order[sb]) : sb;
+    const long job = (long)b * p.H + head;   // index of the per-(b, head) partials: independent of the launch order
     const long bp = (long)head * p.B + b;  // head-major index b' (temporal.py:413-416)
 
     // ---- wave-private LDS.  bf16: K, T_, V row-major [Tp][dh] + marks [Tp][16]; products that contract over the
@@ -122,6 +130,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         }
         return o;
     };
+    auto run = [&](auto nk_c) {
+    constexpr int NK = decltype(nk_c)::value, K0 = NT - NK;   // this copy of the loop walks the key tiles K0 .. NT-1
+    const KeyMask<NK> kmk = keymask_tail<NK, NT>(km);
     QOps qcur = load_q(0);
     touch_regs(qcur);   // complete before the loop (edgl_common.h)
     // The output rows of a query tile (computed last) are stored at the TOP of the next iteration: the loop-carried
@@ -150,13 +161,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         Frag4<T> qf[DT];
 #pragma unroll
         for (int ub = 0; ub < DT; ++ub) qf[ub] = qcur.qf[ub];
-        f32x4 s[NT];
+        f32x4 s[NK];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+        for (int kt = 0; kt < NK; ++kt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ks + (kt * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
+                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
             s[kt] = a;
         }
         // bf16: s := exp(v - max), UNNORMALISED; 1 / sum (`pinv`) rides on the H rows (4 values) and, together with the dropout scale,
@@ -164,10 +175,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         // f32: s := P^T (pinv = 1).
         float pinv = 1.0f;
         if constexpr (TR) {
-            if (p.flags & MAU_CAUSAL) pinv = masked_softmax_impl<NT, true, false, false>(s, km, cscale, lane, q);
-            else pinv = masked_softmax_impl<NT, false, false, false>(s, km, cscale, lane, q);
+            if constexpr (K0 == 0) {
+                if (p.flags & MAU_CAUSAL) pinv = masked_softmax_impl<NT, true, false, false>(s, kmk, cscale, lane, q);
+                else pinv = masked_softmax_impl<NT, false, false, false>(s, kmk, cscale, lane, q);
+            } else {
+                pinv = masked_softmax_impl<NK, false, false, false>(s, kmk, cscale, lane, q);
+            }
         } else {
-            masked_softmax<NT, 0>(s, km, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);
+            masked_softmax<NT, 0>(s, kmk, cscale, lane, q, (p.flags & MAU_CAUSAL) != 0);
         }
         const float gfac = pinv * dk.scale;   // factor of G (and of its diagonal)
         // the previous tile's output rows leave here, behind the first use of this tile's operands: a store in front of the prefetch
@@ -176,17 +191,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         flush_pending();
         asm volatile("" ::: "memory");
         // ---- H^T[u][q] = sum_k T_[k][u] P[q][k] -----------------------------------------------
-        Frag4<T> pf[NT];
+        Frag4<T> pf[NK];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) pf[kt] = frag_from_acc<T>(s[kt]);
+        for (int kt = 0; kt < NK; ++kt) pf[kt] = frag_from_acc<T>(s[kt]);
         Frag4<T> hf[DT];
         if constexpr (HAS_T) {
 #pragma unroll
             for (int ut = 0; ut < DT; ++ut) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kt = 0; kt < NT; ++kt)
-                    a = mma16(kfrag<T>(Ts, dh, Ts, LDT, kt * 16, ut * 16, lane), pf[kt], a);
+                for (int kt = 0; kt < NK; ++kt)
+                    a = mma16(kfrag<T>(Ts, dh, Ts, LDT, (K0 + kt) * 16, ut * 16, lane), pf[kt], a);
                 if constexpr (TR) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a[r] *= pinv;
@@ -328,9 +343,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         const float dval = (p.flags & MAU_DIAG_ZERO) ? 0.0f : gfac;   // later mark groups of a split call (bimau_common.h): 0
         auto modulate = [&](auto drop_on) {
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt) {
-                f32x4 gacc = mma16(frag_ld<T>(Ms + (kt * 16 + l15) * EP + g4), lf, f32x4{0.f, 0.f, 0.f, 0.f});
-                const bool dtile = set_diag && kt == qt;   // only this key tile can contain k == q (temporal.py:438-439)
+            for (int kt = 0; kt < NK; ++kt) {
+                f32x4 gacc = mma16(frag_ld<T>(Ms + ((K0 + kt) * 16 + l15) * EP + g4), lf, f32x4{0.f, 0.f, 0.f, 0.f});
+                const bool dtile = set_diag && K0 + kt == qt;   // only this key tile can contain k == q (temporal.py:438-439)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     gacc[r] = (dtile && g4 + r == l15) ? dval : gacc[r];
@@ -339,9 +354,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
                 if constexpr (decltype(drop_on)::value) {                       // temporal.py:442 (the scale is in G already)
                     if constexpr (DB) {   // stored decisions: bit kt*4 + r of this lane's word
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) s[kt][r] = keep_bit(qcur.kb, kt * 4 + r, s[kt][r]);
+                        for (int r = 0; r < 4; ++r) s[kt][r] = keep_bit(qcur.kb, (K0 + kt) * 4 + r, s[kt][r]);
                     } else {
-                        const uint64_t hw = drop_hash_quad(dk, dbase + kt * 16 + g4);
+                        const uint64_t hw = drop_hash_quad(dk, dbase + (K0 + kt) * 16 + g4);
                         s[kt][0] = drop_quad_keep<0>(dk, hw) ? s[kt][0] : 0.f;
                         s[kt][1] = drop_quad_keep<1>(dk, hw) ? s[kt][1] : 0.f;
                         s[kt][2] = drop_quad_keep<2>(dk, hw) ? s[kt][2] : 0.f;
@@ -358,8 +373,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         for (int vt = 0; vt < DT; ++vt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < NT; ++kt)
-                a = mma16(kfrag<T>(Vs, dh, Vs, LDT, kt * 16, vt * 16, lane), pf[kt], a);
+            for (int kt = 0; kt < NK; ++kt)
+                a = mma16(kfrag<T>(Vs, dh, Vs, LDT, (K0 + kt) * 16, vt * 16, lane), pf[kt], a);
             const Frag4<T> rf = qcur.rf[vt];
             f32x4 o4;
 #pragma unroll
@@ -370,6 +385,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         qcur = qnext;
     }
     flush_pending();
+    };   // run
+    if constexpr (SK) {
+        static_assert(TR && PHASE == 0, "the key-tile skip exists for the fused bf16 form");
+        dispatch_nk<NT>((p.flags & MAU_CAUSAL) ? NT : NT - km.kt0, run);
+    } else {
+        run(std::integral_constant<int, NT>{});
+    }
 }
 
 template <typename T, int DT, int NT, int EC, int PHASE = 0>
@@ -384,9 +406,13 @@ int launch_fwd_e(FwdP p, hipStream_t st) {
                  p.E, p.T);
     p.waves = waves;
     auto kern = bimau_fwd_kernel<T, DT, NT, EC, PHASE>;
-    // stored keep bits: the headline family (bf16, head dim 16, 16 marks, <= 8 key tiles, fused form); elsewhere the hash
+    // stored keep bits: the headline family (bf16, head dim 16, 16 marks, <= 8 key tiles, fused form); elsewhere the hash.
+    // The same family leaves out the all-padding key tiles in front of a sequence's first real key (SK; EDGL_BIMAU_SKIP=0: the
+    // unskipped kernels — the A/B switch and the reference of the bit-equality test)
     if constexpr (sizeof(T) == 2 && DT == 1 && EC == 16 && PHASE == 0 && NT <= 8) {
-        if (p.dbits && p.rate > 0.f) kern = bimau_fwd_kernel<T, DT, NT, EC, PHASE, true>;
+        const bool sk = NT >= 2 && bimau_skip_enabled();
+        if (p.dbits && p.rate > 0.f) kern = sk ? bimau_fwd_kernel<T, DT, NT, EC, PHASE, true, (NT >= 2)> : bimau_fwd_kernel<T, DT, NT, EC, PHASE, true>;
+        else if (sk) kern = bimau_fwd_kernel<T, DT, NT, EC, PHASE, false, (NT >= 2)>;
     }
     if (smem > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const long jobs = (long)p.B * p.H;

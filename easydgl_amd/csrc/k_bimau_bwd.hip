@@ -399,10 +399,15 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
         if constexpr (SPEC) {
             if (p.flags == 0) kern = p.E == 16 ? bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0> : bimau_bwd_sweep1_kernel<T, DT, NT, 0, true, 0>;
             if constexpr (NT <= 8) {   // stored keep bits of the attention dropout (edgl_bimau_dropbits): the headline family
-                if (p.flags == 0 && p.E == 16 && p.dbits && p.rate > 0.f) kern = bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, true>;
+                // ... which also leaves out the all-padding key tiles in front of the first real key (SK, bimau_common.h)
+                constexpr bool SKC = NT >= 2;
+                const bool sk = SKC && p.flags == 0 && p.E == 16 && bimau_skip_enabled();
+                const bool db = p.dbits && p.rate > 0.f;
+                if (p.flags == 0 && p.E == 16 && db) kern = sk ? bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, true, false, SKC> : bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, true>;
+                else if (sk) kern = bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, false, false, SKC>;
                 if (p.tpp_desc) {   // d lambda of the TPP regulariser recomputed in the sweep (edgl_bimau_bwd_tpp checked the shape)
-                    kern = (p.dbits && p.rate > 0.f) ? bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, true, true>
-                                                     : bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, false, true>;
+                    if (sk) kern = db ? bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, true, true, SKC> : bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, false, true, SKC>;
+                    else kern = db ? bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, true, true> : bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, false, true>;
                 }
             }
         }
@@ -439,7 +444,10 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
         if constexpr (SPEC) {
             if (p.flags == 0) kern = p.E == 16 ? bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0> : bimau_bwd_sweep2_kernel<T, DT, NT, 0, KY_NY, true, 0>;
             if constexpr (NT <= 8) {
-                if (p.flags == 0 && p.E == 16 && p.dbits && p.rate > 0.f) kern = bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0, true>;
+                constexpr bool SKC = NT >= 2;
+                const bool sk = SKC && p.flags == 0 && p.E == 16 && bimau_skip_enabled();
+                if (p.flags == 0 && p.E == 16 && p.dbits && p.rate > 0.f) kern = sk ? bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0, true, 1, 0, SKC> : bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0, true>;
+                else if (sk) kern = bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0, false, 1, 0, SKC>;
             }
         }
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -526,7 +534,7 @@ static int bimau_bwd_impl(const void* qkvt, const int64_t* ids, const float* spa
                           const void* saved, int B, int T, int C, int H, int E, float drop_rate,
                           const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* d_qkvt,
                           float* dW1, float* db1, float* dw, float* dscaling, void* workspace, const void* tpp_desc, int tpp_M,
-                          const float* tpp_sums, float tpp_coef, float* tpp_part, int flags, int dtype, void* stream) {
+                          const float* tpp_sums, float tpp_coef, float* tpp_part, const int32_t* order, int flags, int dtype, void* stream) {
     EDGL_REQUIRE(qkvt && ids && spans && marks && pack && d_out && lam && saved && d_qkvt && dW1 && db1 && dw && dscaling && workspace,
                  EDGL_ERR_NULL, "edgl_bimau_bwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
@@ -542,7 +550,7 @@ static int bimau_bwd_impl(const void* qkvt, const int64_t* ids, const float* spa
     p.z = reinterpret_cast<const float*>((const char*)saved + sl.off_z);
     p.B = B; p.T = T; p.C = C; p.H = H; p.E = E; p.rate = drop_rate; p.rng = rng_state;
     p.stream_id = stream_id; p.d_qkvt = d_qkvt; p.flags = flags; p.dbits = dropbits; p.qk_scale = qk_scale;
-    p.tpp_desc = tpp_desc; p.tpp_M = tpp_M; p.tpp_sums = tpp_sums; p.tpp_coef = tpp_coef; p.tpp_part = tpp_part;
+    p.tpp_desc = tpp_desc; p.tpp_M = tpp_M; p.tpp_sums = tpp_sums; p.tpp_coef = tpp_coef; p.tpp_part = tpp_part; p.order = order;
     EDGL_REQUIRE(!tpp_desc || (dtype == EDGL_BF16 && C / H == 16 && E == 16 && T <= 128 && flags == 0 && tpp_part && tpp_M > 0 && !d_lam_ext),
                  EDGL_ERR_SHAPE, "edgl_bimau_bwd_tpp: the fused TPP form exists for bf16, head dim 16, 16 marks, T <= 128, BiMAU flags "
                  "(C/H=%d E=%d T=%d flags=%d)", C / H, E, T, flags);
@@ -566,7 +574,7 @@ extern "C" int edgl_bimau_bwd_db(const void* qkvt, const int64_t* ids, const flo
                                  const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* d_qkvt,
                                  float* dW1, float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream) {
     return bimau_bwd_impl(qkvt, ids, spans, marks, pack, d_out, d_lam_ext, lam, saved, B, T, C, H, E, drop_rate, rng_state, stream_id,
-                          dropbits, qk_scale, d_qkvt, dW1, db1, dw, dscaling, workspace, nullptr, 0, nullptr, 0.f, nullptr, flags, dtype, stream);
+                          dropbits, qk_scale, d_qkvt, dW1, db1, dw, dscaling, workspace, nullptr, 0, nullptr, 0.f, nullptr, nullptr, flags, dtype, stream);
 }
 // edgl_bimau_bwd_db with the TPP regulariser (MAU.biased_likelihood, temporal.py:317-333, at the masked positions of
 // EasyDGL.py:157-175) evaluated by sweep 1, which holds lambda in registers: the term's gradient with respect to lambda
@@ -581,8 +589,21 @@ extern "C" int edgl_bimau_bwd_tpp(const void* qkvt, const int64_t* ids, const fl
                                   float* dW1, float* db1, float* dw, float* dscaling, void* workspace, int flags, int dtype, void* stream) {
     EDGL_REQUIRE(tpp_desc && tpp_part, EDGL_ERR_NULL, "edgl_bimau_bwd_tpp: null pointer");
     return bimau_bwd_impl(qkvt, ids, spans, marks, pack, d_out, nullptr, lam, saved, B, T, C, H, E, drop_rate, rng_state, stream_id,
-                          dropbits, qk_scale, d_qkvt, dW1, db1, dw, dscaling, workspace, tpp_desc, M, tpp_sums, coef, tpp_part, flags, dtype,
+                          dropbits, qk_scale, d_qkvt, dW1, db1, dw, dscaling, workspace, tpp_desc, M, tpp_sums, coef, tpp_part, nullptr, flags, dtype,
                           stream);
+}
+// edgl_bimau_bwd_db (tpp_desc == NULL: d_lam_ext as given, may be NULL) or edgl_bimau_bwd_tpp (tpp_desc != NULL: d_lam_ext must be
+// NULL) with the launch order of the samples the forward used (edgl_bimau_job_order; NULL: index order) for the two sweeps.
+extern "C" int edgl_bimau_bwd_ord(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks, const void* pack,
+                                  const void* d_out, const float* d_lam_ext, const void* tpp_desc, int M, const float* tpp_sums, float coef,
+                                  float* tpp_part, const float* lam, const void* saved, int B, int T, int C, int H, int E, float drop_rate,
+                                  const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* d_qkvt,
+                                  float* dW1, float* db1, float* dw, float* dscaling, void* workspace, const int32_t* order, int flags,
+                                  int dtype, void* stream) {
+    EDGL_REQUIRE(!tpp_desc || tpp_part, EDGL_ERR_NULL, "edgl_bimau_bwd_ord: tpp_desc without tpp_part");
+    return bimau_bwd_impl(qkvt, ids, spans, marks, pack, d_out, d_lam_ext, lam, saved, B, T, C, H, E, drop_rate, rng_state, stream_id,
+                          dropbits, qk_scale, d_qkvt, dW1, db1, dw, dscaling, workspace, tpp_desc, M, tpp_sums, coef, tpp_part, order, flags,
+                          dtype, stream);
 }
 
 #ifdef EDGL_PHASE_TIMING

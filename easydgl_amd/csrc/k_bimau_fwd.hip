@@ -48,6 +48,12 @@ extern "C" int edgl_bimau_fwd_db(const void* qkvt, const void* resid, int ld_res
                                  float drop_rate, const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale,
                                  void* out, float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream);
 
+extern "C" int edgl_bimau_fwd_ord(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
+                                  const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
+                                  float drop_rate, const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale,
+                                  void* out, float* lam_out, void* saved, float* zero_rows, const int32_t* order, int flags, int dtype,
+                                  void* stream);
+
 // Keep bits of the attention dropout of one (rng state, stream id): bimau_common.h.  0 bytes: this shape has no stored-bits form
 // (more than 8 key tiles) and the kernels hash.
 extern "C" long edgl_bimau_dropbits_bytes(int B, int T, int H) {
@@ -96,6 +102,88 @@ extern "C" int edgl_bimau_fwd_db(const void* qkvt, const void* resid, int ld_res
                                  const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
                                  float drop_rate, const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale,
                                  void* out, float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream) {
+    return edgl_bimau_fwd_ord(qkvt, resid, ld_res, ids, spans, marks, pack, B, T, C, H, E, drop_rate, rng_state, stream_id, dropbits, qk_scale,
+                              out, lam_out, saved, zero_rows, nullptr, flags, dtype, stream);
+}
+
+// Launch order of the attention kernels' (sample, head) jobs.  The kernels of the headline family leave out the key tiles in front
+// of a sequence's first real key (bimau_common.h: KeyMask::kt0), so a job's time falls with its left padding — and a launch is
+// two rounds of workgroups (1024 workgroups on 512 resident slots at the headline shape): in index order the slowest slot gets two
+// long jobs and the launch takes as long as without the skip.  order[] lists the samples by falling key-tile count (ties: by
+// index — a stable counting order, the same for every run): the long jobs start first, the short ones fill up behind them.
+// Two small launches: the first real key of every sequence from wave ballots (one wave per sequence), then every sample's rank by
+// counting (one workgroup).  (As ONE 1024-thread workgroup the kernel took 38 us beside the encoder: placement, not work.)
+namespace {
+// a) one wave per sequence: the key tiles from its first real key on (all of them when it has none)
+__global__ __launch_bounds__(256) void job_tiles_kernel(const int64_t* ids, int B, int T, int32_t* nk) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int NT = (T + 15) / 16, NR = (T + 63) / 64;
+    int first = -1;
+    for (int r0 = 0; r0 < NR; r0 += 4) {   // T <= 256 keys per round: four loads in flight
+        int64_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ids[(long)b * T + min(lane + 64 * (r0 + j), T - 1)];
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            const int k = lane + 64 * (r0 + j);
+            const uint64_t real = __ballot(k < T && v[j] != 0);
+            if (real != 0ull && (first < 0 || 64 * (r0 + j) < first)) first = 64 * (r0 + j) + (int)__builtin_ctzll(real);
+        }
+        if (first >= 0) break;
+    }
+    if (lane == 0) nk[b] = first < 0 ? NT : NT - (first >> 4);
+}
+// b) one workgroup: every sample's rank by counting (key-tile count falling, index rising)
+constexpr int ORD_THREADS = 256;
+__global__ __launch_bounds__(ORD_THREADS) void job_rank_kernel(const int32_t* nk, int B, int32_t* order) {
+    extern __shared__ __attribute__((aligned(16))) int nk_s[];
+    for (int b = threadIdx.x; b < B; b += ORD_THREADS) nk_s[b] = nk[b];
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += ORD_THREADS) {
+        const int mine = nk_s[b];
+        int rank = 0;
+        int o = 0;
+        // broadcast reads of 16 bytes, eight in flight (one LDS latency per 32 samples: read one by one the loop was 128 dependent
+        // round trips to an LDS that the GEMM beside it keeps busy — 34 us)
+        for (; o + 32 <= B; o += 32) {
+            int4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const int4*>(nk_s + o + 4 * j);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int oo = o + 4 * j;
+                rank += (v[j].x > mine || (v[j].x == mine && oo < b)) ? 1 : 0;
+                rank += (v[j].y > mine || (v[j].y == mine && oo + 1 < b)) ? 1 : 0;
+                rank += (v[j].z > mine || (v[j].z == mine && oo + 2 < b)) ? 1 : 0;
+                rank += (v[j].w > mine || (v[j].w == mine && oo + 3 < b)) ? 1 : 0;
+            }
+        }
+        for (; o < B; ++o) {
+            const int v = nk_s[o];
+            rank += (v > mine || (v == mine && o < b)) ? 1 : 0;
+        }
+        order[rank] = b;
+    }
+}
+}  // namespace
+// order: int32 [2 * B] — the launch order in the first B entries, the samples' key-tile counts behind them (scratch of the two launches)
+extern "C" int edgl_bimau_job_order(const int64_t* ids, int B, int T, int32_t* order, void* stream) {
+    EDGL_REQUIRE(ids && order, EDGL_ERR_NULL, "edgl_bimau_job_order: null pointer");
+    EDGL_REQUIRE(B > 0 && T > 0 && B <= 16384, EDGL_ERR_SHAPE, "edgl_bimau_job_order: bad shape B=%d T=%d (B <= 16384)", B, T);
+    hipLaunchKernelGGL(job_tiles_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, ids, B, T, order + B);
+    hipLaunchKernelGGL(job_rank_kernel, dim3(1), dim3(ORD_THREADS), (size_t)((B + 3) & ~3) * sizeof(int), (hipStream_t)stream, order + B, B, order);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+// edgl_bimau_fwd_db with the launch order of the samples (edgl_bimau_job_order; NULL: index order).  The order changes WHEN a
+// (sample, head) job runs, nothing of what it computes or where it writes.
+extern "C" int edgl_bimau_fwd_ord(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
+                                  const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E,
+                                  float drop_rate, const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale,
+                                  void* out, float* lam_out, void* saved, float* zero_rows, const int32_t* order, int flags, int dtype,
+                                  void* stream) {
     EDGL_REQUIRE(qkvt && resid && ids && spans && marks && pack && out && lam_out, EDGL_ERR_NULL,
                  "edgl_bimau_fwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && H > 0 && C % H == 0 && E >= 1 && E <= bimau::EP, EDGL_ERR_SHAPE,
@@ -104,7 +192,7 @@ extern "C" int edgl_bimau_fwd_db(const void* qkvt, const void* resid, int ld_res
     EDGL_REQUIRE(ld_res % 4 == 0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: ld_res must be a multiple of 4");
     EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: H*B*T*T must be < 2^32");
     FwdP p{qkvt, resid, ld_res, ids, spans, marks, (const char*)pack, B, T, C, H, E, drop_rate, rng_state, stream_id,
-           out, lam_out, nullptr, nullptr, nullptr, 4, flags, dropbits, qk_scale};
+           out, lam_out, nullptr, nullptr, nullptr, 4, flags, dropbits, qk_scale, order};
     hipStream_t st = (hipStream_t)stream;
     if (C / H == 64 || C / H == 128) {   // three-launch form: lambda is written by the intensity kernel — plain memset there
         if (zero_rows && hipMemsetAsync(zero_rows, 0, (size_t)H * B * T * E * sizeof(float), st) != hipSuccess) {

@@ -99,6 +99,14 @@ class TrainEngine:
                         lam=e(H * B, T, eg, dtype=f32), dlam=e(H * B, T, eg, dtype=f32),
                         out=e(B, T, C) if e0 else None, dqkvt=e(B, T, 4 * C) if e0 else None))
             self.blk.append(d)
+        # launch order of the attention jobs (samples by falling key-tile count: csrc/k_bimau_fwd.hip edgl_bimau_job_order) for the
+        # kernels that leave out the all-padding key tiles.  OFF for training unless EDGL_BIMAU_ORDER=1: MAUPostProcessor.mask_random
+        # (dataloader.py:187-191) draws the masked positions over ALL positions, the MASK token (id num_items != 0) is a real key
+        # (temporal.py:425: the key mask is ids != 0), and with 20 of 100 positions masked hardly any key tile of a training batch is
+        # padding only (0.4 % at the headline shape: DESIGN.md rule 50) — nothing to skip, nothing to balance.  Evaluation batches
+        # (mask_last) keep their left padding: there the skip is real.
+        self.job_order = (torch.arange(2 * B, device=dev, dtype=torch.int32)     # (order | the launches' scratch)
+                          if (not self.mgroups and B <= 16384 and nb > 0 and os.environ.get("EDGL_BIMAU_ORDER", "0") == "1") else None)
         self.tpp_desc = torch.zeros(int(lib.edgl_tpp_prep_bytes(B, T, M)), device=dev, dtype=torch.uint8) if self.fused_tpp else None
         self.zero_resid = torch.zeros((B, T, C), device=dev, dtype=self.dt) if self.mgroups else None
         self.pre_t, self.so, self.st3 = e(B, T, C), e(B, T, C), e(B, 2, dtype=f32)
@@ -310,6 +318,8 @@ class TrainEngine:
                     check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
                                              _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
                                              _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
+            if self.job_order is not None:   # ids only: under the encoder, in front of everything the first attention kernel waits for
+                check(lib.edgl_bimau_job_order(_ptr(self.ids), B, T, _ptr(self.job_order), sst), "edgl_bimau_job_order")
             for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
                 att = blk.attention
                 late(i, blk, b)
@@ -367,10 +377,11 @@ class TrainEngine:
             if self.mgroups:
                 self._attention_fwd_groups(b, x, cin, da, st)
             else:
-                check(lib.edgl_bimau_fwd_db(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
-                                            _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]),
-                                            self.qk_scale, _ptr(b["att"]), _ptr(b["lam"]), _ptr(b["saved"]),
-                                            _ptr(b["dlam"]) if (m.ct_reg != 0.0 and not self.fused_tpp) else None, 0, code, st), "edgl_bimau_fwd_db")
+                check(lib.edgl_bimau_fwd_ord(_ptr(b["qkvt"]), x.data_ptr(), cin, _ptr(self.ids), _ptr(self.spans), _ptr(self.marks),
+                                             _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]),
+                                             self.qk_scale, _ptr(b["att"]), _ptr(b["lam"]), _ptr(b["saved"]),
+                                             _ptr(b["dlam"]) if (m.ct_reg != 0.0 and not self.fused_tpp) else None, _ptr(self.job_order),
+                                             0, code, st), "edgl_bimau_fwd_ord")
             if m.ct_reg != 0.0 and not self.fused_tpp:   # TPP regulariser of this block: loss term and d lambda (two small launches)
                 check(lib.edgl_tpp_fwd_bwd_rows(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
                                                 _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
@@ -556,24 +567,18 @@ class TrainEngine:
             da = drop(ad, 10 + 4 * i)
             if self.mgroups:
                 self._attention_bwd_groups(att, b, da, st)
-            elif self.fused_tpp:
-                check(lib.edgl_bimau_bwd_tpp(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
-                                             _ptr(self.G2), _ptr(self.tpp_desc), M, _ptr(b["tpp"]) if self._dp else None, float(m.ct_reg / H), _ptr(b["tpp_part"]),
+            else:
+                tp = self.fused_tpp
+                check(lib.edgl_bimau_bwd_ord(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
+                                             _ptr(self.G2), None if tp else (_ptr(b["dlam"]) if m.ct_reg != 0.0 else None),
+                                             _ptr(self.tpp_desc) if tp else None, M, (_ptr(b["tpp"]) if self._dp else None) if tp else None,
+                                             float(m.ct_reg / H), _ptr(b["tpp_part"]) if tp else None,
                                              _ptr(b["lam"]), _ptr(b["saved"]), B, T, C, H, E,
                                              float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), self.qk_scale, _ptr(self.G4c),
                                              _ptr(att.st_kernel.grad), _ptr(att.st_bias.grad), _ptr(att.weight.grad),
                                              _ptr(att.scaling.grad),
-                                             _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), 0, code, st),
-                      "edgl_bimau_bwd_tpp")
-            else:
-                check(lib.edgl_bimau_bwd_db(_ptr(b["qkvt"]), _ptr(self.ids), _ptr(self.spans), _ptr(self.marks), _ptr(b["pack"]),
-                                            _ptr(self.G2), _ptr(b["dlam"]) if m.ct_reg != 0.0 else None, _ptr(b["lam"]),
-                                            _ptr(b["saved"]), B, T, C, H, E,
-                                            float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]), self.qk_scale, _ptr(self.G4c),
-                                            _ptr(att.st_kernel.grad), _ptr(att.st_bias.grad), _ptr(att.weight.grad),
-                                            _ptr(att.scaling.grad),
-                                            _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)), 0, code, st),
-                      "edgl_bimau_bwd_db")
+                                             _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)),
+                                             _ptr(self.job_order), 0, code, st), "edgl_bimau_bwd_ord")
             self._dense_dw(x_in, self.G4c, att.dense_kernel, att.dense_bias, cin, 4 * C)
             if self.fused_tail:
                 check(lib.edgl_gemm_dw_defer(0, st), "edgl_gemm_dw_defer")

@@ -230,6 +230,25 @@ int edgl_bimau_fwd_db(const void* qkvt, const void* resid, int ld_res, const int
                       const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* out,
                       float* lam_out, void* saved, float* zero_rows, int flags, int dtype, void* stream);
 
+/* Launch order of the attention kernels' (sample, head) jobs (temporal.py:404-452 computes every head of every sample; the order
+ * only decides WHEN a job runs).  The bf16 / head dim 16 / 16 marks kernels leave out the key tiles that hold nothing but the
+ * left padding of a sequence (data/linkpred.py:142-157; temporal.py:425-429: their probabilities are exactly 0), so a job's time
+ * falls with its padding; edgl_bimau_job_order lists the samples by falling key-tile count (first B entries of `order`, ties by index) and
+ * edgl_bimau_fwd_ord / edgl_bimau_bwd_ord launch the long jobs first.  order == NULL: index order (= edgl_bimau_fwd_db /
+ * edgl_bimau_bwd_db / edgl_bimau_bwd_tpp).  edgl_bimau_bwd_ord: tpp_desc == NULL -> d_lam_ext as in edgl_bimau_bwd_db;
+ * tpp_desc != NULL -> the fused TPP form of edgl_bimau_bwd_tpp (d_lam_ext must be NULL).  Results do not depend on the order. */
+int edgl_bimau_job_order(const int64_t* ids, int B, int T, int32_t* order, void* stream);   /* order: int32 [2 * B] (order | scratch); B <= 16384 */
+int edgl_bimau_fwd_ord(const void* qkvt, const void* resid, int ld_res, const int64_t* ids, const float* spans,
+                       const uint8_t* marks, const void* pack, int B, int T, int C, int H, int E, float drop_rate,
+                       const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* out,
+                       float* lam_out, void* saved, float* zero_rows, const int32_t* order, int flags, int dtype, void* stream);
+int edgl_bimau_bwd_ord(const void* qkvt, const int64_t* ids, const float* spans, const uint8_t* marks, const void* pack,
+                       const void* d_out, const float* d_lam_ext, const void* tpp_desc, int M, const float* tpp_sums, float coef,
+                       float* tpp_part, const float* lam, const void* saved, int B, int T, int C, int H, int E, float drop_rate,
+                       const uint64_t* rng_state, uint32_t stream_id, const uint32_t* dropbits, float qk_scale, void* d_qkvt,
+                       float* dW1, float* db1, float* dw, float* dscaling, void* workspace, const int32_t* order, int flags,
+                       int dtype, void* stream);
+
 /* Backward.  d_out [B,T,C] `dtype`; d_lam_ext f32 [H*B,T,E] or NULL (gradient
  * from the TPP regulariser); lam / saved: the forward's lam_out and `saved` buffer.  Writes d_qkvt [B,T,4C] `dtype` and the f32 weight gradients dW1
  * [dh+1,dh*E], db1 [dh*E], dw [E,dh], dscaling [E] (overwritten; per-workgroup partials in
