@@ -335,8 +335,22 @@ def main():
             dist.init_process_group(backend)
     c = dict(RECIPE if args.workload == "recipe" else HEADLINE)
     from easydgl_amd import _lib
+    if world > 1 and args.path == "autograd":
+        # the loss normalises by sums over the GLOBAL batch (weighted rows, next-event marks: EasyDGL.py:183-185, temporal.py:331-333):
+        # averaging per-rank gradients of per-rank losses is NOT the global-batch gradient (TrainEngine._global_counts
+        # + a SUM all-reduce is) — the autograd path has no such protocol, so it does not pretend to be data parallel
+        raise SystemExit("bench.py: --path autograd is single-GPU only (data-parallel steps run through the engine: --path engine | graph)")
     res = run_step_workload(c, args, dev, rank, world, dist, args.steps, args.warmup, bracket=(args.path != "graph"))
     dt, loss, dom = res["dt"], res["loss"], res["dom"]
+    flash_engine = bool(getattr(res.get("engine"), "flash_ce", False))
+    sync_loss = getattr(res.get("engine"), "sync_loss", None)
+    # north_star's other multi-GPU path in the SAME line: the full-catalogue scoring step with the item table row-sharded over the
+    # ranks and ONE packed RCCL all-gather of the local top-K.  Every rank takes part (collective); rank 0 reports.
+    eval_sharded = None
+    if world > 1 and args.workload == "step" and not args.no_extras:
+        res.pop("engine", None)
+        torch.cuda.empty_cache()
+        eval_sharded = eval_rows(args, dev, world, rank, dist, steps=20, warmup=5, sizes=((20000, 128),))
 
     if rank == 0:
         T, C, I, M = c["seqslen"] + 1, c["num_units"], c["num_items"] + 1, c["masklen"]
@@ -351,7 +365,7 @@ def main():
         # 2*R_w*C*I — F_score of the forward pass) and the row-gradient product d_rows = dl . table (2*R_w*C*I): both are
         # algorithmic, nothing is recomputed.  Round-1 form (EDGL_FLASH_CE=0): only the d_rows product is algorithmic, its
         # logits are a recomputation and count for `hw_util` (what the MFMA pipe did) alone.
-        flash = bool(getattr(res.get("engine"), "flash_ce", False))
+        flash = flash_engine
         n_dom, ms_dom, bidx = dom[0]
         R_w = float(np.mean([rows_w[k] for k in bidx])) if bidx else R_w_mean
         dom_exec = 4.0 * R_w * C * I
@@ -411,6 +425,11 @@ def main():
             "config": {"workload": f"EasyDGL optimizer step, per-GPU batch {c['batch']}, seqslen {c['seqslen']} (T={T}), num_units {C}, {h} heads, "
                                    f"{nb} block, num_items {c['num_items']} (I={I}), masklen {M}, {E} marks, dropout 0.1/0.1, ct_reg 1e-7, l2 1e-4",
                        "global_batch": world * c["batch"], "parallelism": f"dp{world}",
+                       "padding": res.get("padding"),
+                       "loss_mode": ("joined in front of every optimizer launch (TrainEngine.sync_loss = True)" if sync_loss else
+                                     "deferred: the loss launches of step n are issued with step n+1, read once behind the timed steps "
+                                     "(TrainEngine.sync_loss = False + join_loss(); train.py reads the loss at its logging points the same way)")
+                                    if sync_loss is not None else "autograd path",
                        "batches_rotated": NBATCH,
                        "algorithmic_gflop_per_step_all_rows": round(3 * flops_per_seq(c) * c["batch"] / 1e9, 1),
                        "algorithmic_gflop_per_step_rows_scored": round(flops_done / 1e9, 1)},
@@ -447,6 +466,8 @@ def main():
             out["cpu_baseline_1thread_batch16"] = cpu_baseline(c, budget_s=8.0, nthreads=1, bs=16)
         if world == 1 and not args.no_extras and args.path == "engine":
             out["extras"] = extras(c, args, dev)
+        if eval_sharded is not None:
+            out["extras"] = {"eval_sharded": eval_sharded}
         if args.op_table:
             step = res["step"]
             _lib.profiler.start()
@@ -492,8 +513,6 @@ def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=Fa
             model.zero_grad_arena()
             loss = model.train_loss(feats, labels)
             loss.backward()
-            if world > 1:
-                parallel.allreduce_mean_(model._grad_arena)
             model.optimizer_step()
             return loss.detach()
     else:

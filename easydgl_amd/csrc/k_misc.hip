@@ -542,22 +542,32 @@ __global__ void adam_prepare_kernel(uint64_t* st, float lr, float b1, float b2) 
     const float lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
     reinterpret_cast<float*>(st + 1)[0] = lr_t;
 }
+// l2_part (optional, [gridDim.x]): the block's sum of squares of the UPDATED parameters inside the l2 segments — the next step's L2
+// loss term (coding.py:40 on the weights that step reads) needs no pass over the arena of its own (edgl_l2_from_parts)
 template <bool SHADOW>
 __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, long n, float b1,
                                                    float b2, float eps, const uint64_t* st, float l2,
-                                                   const int64_t* seg, int nseg, bf16* shadow) {
+                                                   const int64_t* seg, int nseg, bf16* shadow, float* l2_part) {
+    __shared__ float red[8];
     const float lr_t = reinterpret_cast<const float*>(st + 1)[0];
+    float sq = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float gi = g[i];
         const float wi = w[i];
+        bool in_seg = false;
         if (l2 != 0.f)
             for (int s = 0; s < nseg; ++s)
-                if (i >= seg[2 * s] && i < seg[2 * s + 1]) { gi += l2 * wi; break; }
+                if (i >= seg[2 * s] && i < seg[2 * s + 1]) { gi += l2 * wi; in_seg = true; break; }
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         const float wn = wi - lr_t * mi / (sqrtf(vi) + eps);
         m[i] = mi; v[i] = vi; w[i] = wn;
         if (SHADOW) shadow[i] = (bf16)wn;
+        sq = in_seg ? fmaf(wn, wn, sq) : sq;
+    }
+    if (l2_part) {
+        sq = block_sum(sq, red);
+        if (threadIdx.x == 0) l2_part[blockIdx.x] = sq;
     }
 }
 
@@ -1026,10 +1036,10 @@ extern "C" int edgl_adam_step(float* param, const float* grad, float* m, float* 
     EDGL_LAUNCH_CHECK();
     if (shadow)
         hipLaunchKernelGGL((adam_kernel<true>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
-                           step_state, l2, seg, nseg, (bf16*)shadow);
+                           step_state, l2, seg, nseg, (bf16*)shadow, (float*)nullptr);
     else
         hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
-                           step_state, l2, seg, nseg, (bf16*)nullptr);
+                           step_state, l2, seg, nseg, (bf16*)nullptr, (float*)nullptr);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }
@@ -1056,10 +1066,37 @@ extern "C" int edgl_adam_apply(float* param, const float* grad, float* m, float*
     hipStream_t st = (hipStream_t)stream;
     if (shadow)
         hipLaunchKernelGGL((adam_kernel<true>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
-                           step_state, l2, seg, nseg, (bf16*)shadow);
+                           step_state, l2, seg, nseg, (bf16*)shadow, (float*)nullptr);
     else
         hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
-                           step_state, l2, seg, nseg, (bf16*)nullptr);
+                           step_state, l2, seg, nseg, (bf16*)nullptr, (float*)nullptr);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+// edgl_adam_apply that also leaves the per-block sums of squares of the updated parameters inside the l2 segments in l2_part
+// (edgl_adam_l2_parts(n) floats): the next step's L2 loss term is then edgl_l2_from_parts — one tiny launch that reads nothing
+// of the arena (which the optimizer at the end of that step rewrites).
+extern "C" int edgl_adam_l2_parts(long n) { return n > 0 ? grid_for(n) : -1; }
+extern "C" int edgl_adam_apply_l2p(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
+                                   const uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, float* l2_part,
+                                   void* stream) {
+    EDGL_REQUIRE(param && grad && m && v && step_state && l2_part, EDGL_ERR_NULL, "edgl_adam_apply_l2p: null pointer");
+    EDGL_REQUIRE(nseg == 0 || seg, EDGL_ERR_NULL, "edgl_adam_apply_l2p: segments missing");
+    hipStream_t st = (hipStream_t)stream;
+    if (shadow)
+        hipLaunchKernelGGL((adam_kernel<true>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
+                           step_state, l2, seg, nseg, (bf16*)shadow, l2_part);
+    else
+        hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
+                           step_state, l2, seg, nseg, (bf16*)nullptr, l2_part);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+extern "C" int edgl_l2_from_parts(const float* l2_part, int nparts, float l2, float* out, int accumulate, void* stream) {
+    EDGL_REQUIRE(l2_part && out, EDGL_ERR_NULL, "edgl_l2_from_parts: null pointer");
+    EDGL_REQUIRE(nparts > 0, EDGL_ERR_SHAPE, "edgl_l2_from_parts: nparts=%d", nparts);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, l2_part, nparts, 0.5f * l2, out, accumulate);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

@@ -29,6 +29,9 @@ class TrainEngine:
     _SIDE_STREAMS = {}
 
     def __init__(self, model, batch: int, use_graph: bool = True, process_group=None, fused_tail=None, flash_ce=None):
+        if use_graph and os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") == "1":
+            raise _lib.EdglError("TrainEngine: EDGL_ENGINE_LEGACY_FORK=1 is an A/B switch of the eager path (the captured sequence "
+                                 "relies on the step counters being advanced behind the optimizer)")
         self.m = model
         self.B = batch
         self.use_graph = use_graph
@@ -138,6 +141,16 @@ class TrainEngine:
         # L2 + TPP terms (accumulated before the cross-entropy kernel, which adds them to its own term)
         self.loss_aux, self.loss_tpp = torch.zeros(1, device=dev, dtype=f32), torch.zeros(1, device=dev, dtype=f32)
         self.ws_l2 = e(1024, dtype=f32)
+        # The L2 term of a step from the sums of squares the PREVIOUS step's optimizer kernel left (edgl_adam_apply_l2p): no pass over
+        # the arena on the side stream — a read that nothing ordered against the optimizer launch at the end of the same step once the
+        # lazy-loss mode dropped the join in front of it.  Two copies, alternating: the optimizer of step n writes the copy that step
+        # n + 1 reads, and step n + 2's main stream is behind that read through the forward's join.  Eager path only (a captured
+        # graph bakes one address in); whenever somebody else touched the weights or the step counters (`_state_ahead` False: first
+        # step, checkpoint, an autograd-path step) the term is recomputed from the arena.
+        self.l2_nparts = int(lib.edgl_adam_l2_parts(m._arena.numel()))
+        self.l2_parts = [torch.zeros(self.l2_nparts, device=dev, dtype=f32) for _ in range(2)] \
+            if (m.l2_reg != 0.0 and not use_graph and os.environ.get("EDGL_L2_PARTS", "1") != "0") else None
+        self._l2p_cur, self._l2p_ready = 0, False
         # two side streams per DEVICE, shared by every engine of the process: the runtime multiplexes streams onto a handful of
         # hardware queues, and a process that builds engine after engine (bench.py's extra rows) otherwise ends up with its main
         # and side streams on ONE queue — no overlap and false dependencies (measured: the later rows 5-13 % slower)
@@ -146,6 +159,11 @@ class TrainEngine:
             TrainEngine._SIDE_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         self.side, self.side2 = TrainEngine._SIDE_STREAMS[key]
         self._pending_loss = None
+        # a training loop that reads the loss every few hundred steps runs with sync_loss = False (the loss launches of step n ride
+        # with step n + 1, nothing in the step waits for them) and lets the engine add the step losses up on the device:
+        # join_loss(), then loss_sum / steps (train.py; bench.py times the same mode)
+        self.accumulate_loss = False
+        self.loss_sum = torch.zeros(1, device=dev, dtype=torch.float64)
         self._pending_label = None
         self._lazy_loss, self._side_has_grads, self._loss_unjoined = False, False, False
         self.sync_loss = True      # step(): order the returned loss on the caller's stream (a cross-stream wait behind the optimizer)
@@ -158,7 +176,7 @@ class TrainEngine:
         self._deferred_loss = None
         self._alt = None
         if self.ce_part is not None:
-            self._alt = dict(ce_part=torch.zeros_like(self.ce_part),
+            self._alt = dict(ce_part=torch.zeros_like(self.ce_part), loss_aux=torch.zeros_like(self.loss_aux),
                              tpp_desc=torch.zeros_like(self.tpp_desc) if self.tpp_desc is not None else None,
                              tpp_part=[torch.zeros_like(b["tpp_part"]) if b["tpp_part"] is not None else None for b in self.blk])
         # data parallel: weighted rows / TPP normaliser of the GLOBAL batch (filled by _global_counts before a step)
@@ -249,6 +267,8 @@ class TrainEngine:
         # nothing (an event record behind a kernel idles the stream ~6-13 us before its next launch) while the side stream can hash
         # the keep bits of the attention dropout from the advanced counter.  First step, or an _issue() without _optimizer: here.
         legacy = os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") == "1"   # A/B switch: round-3 order (one side stream, fork first)
+        # the sums of squares the last optimizer launch of THIS engine left are the L2 term's input iff nobody touched the state since
+        l2_from_parts = self.l2_parts is not None and self._l2p_ready and getattr(m, "_state_ahead", False) and not legacy
         if not legacy:
             if not getattr(m, "_state_ahead", False):
                 self._advance_state(st)
@@ -266,11 +286,17 @@ class TrainEngine:
         if legacy:
             side2 = side
         sst = side.cuda_stream
+        if getattr(self, "_loss_unjoined", False) and self.ce_part is None:
+            # the previous step left its loss kernel (the form that sweeps lse / label logits / compacted labels) unjoined on the side
+            # stream, and this step's first launch rewrites the compacted labels and the row count on the main stream
+            main.wait_stream(side)
+            self._loss_unjoined = False
         side.wait_stream(main)
         if self._deferred_loss is not None and not legacy:
             # the previous step's loss launches are still to come (behind ev_pack below): this step writes the other copy of their input
             a = self._alt
             self.ce_part, a["ce_part"] = a["ce_part"], self.ce_part
+            self.loss_aux, a["loss_aux"] = a["loss_aux"], self.loss_aux      # (this step's L2 term is written in front of those launches)
             self.tpp_desc, a["tpp_desc"] = a["tpp_desc"], self.tpp_desc
             for j, bj in enumerate(self.blk):
                 bj["tpp_part"], a["tpp_part"][j] = a["tpp_part"][j], bj["tpp_part"]
@@ -302,7 +328,10 @@ class TrainEngine:
                                             _ptr(self.tpp_desc), side2.cuda_stream), "edgl_tpp_prep")
 
         def l2_term():
-            if m.l2_reg != 0.0:
+            if m.l2_reg != 0.0 and l2_from_parts:
+                check(lib.edgl_l2_from_parts(_ptr(self.l2_parts[self._l2p_cur]), self.l2_nparts, float(m.l2_reg), _ptr(self.loss_aux), 0,
+                                             sst), "edgl_l2_from_parts")
+            elif m.l2_reg != 0.0:
                 check(lib.edgl_l2_loss(_ptr(m._arena), _ptr(self.l2_seg), self.nseg, float(m.l2_reg), _ptr(self.loss_aux), 0,
                                        _ptr(self.ws_l2), sst), "edgl_l2_loss")
 
@@ -335,7 +364,13 @@ class TrainEngine:
                 if b["dbits"] is not None and not legacy:
                     check(lib.edgl_bimau_dropbits(B, T, H, float(ad), _ptr(m._rng_state), 10 + 4 * i, _ptr(b["dbits"]), sst),
                           "edgl_bimau_dropbits")
-            if not self.blk or legacy:
+            # The L2 term reads the parameter arena, which the optimizer at the END of this step rewrites on the main stream — and in
+            # the lazy-loss mode nothing joins the side stream in front of the optimizer any more.  In FRONT of the event the first
+            # attention kernel waits for, the term is ordered before everything the main stream does from there on (round 4 had it
+            # behind the event, when the chain still ended after the QKVT projection; since the batch preparation moved into the
+            # encoder's launch the chain has ~17 us of slack: rule 49).  EDGL_L2_EARLY=0: behind the event (the A/B switch).
+            l2_early = os.environ.get("EDGL_L2_EARLY", "1") != "0" and not l2_from_parts     # (from the optimizer's sums: no arena read, behind the event)
+            if not self.blk or legacy or l2_early:
                 l2_term()      # (no block: the loss kernel runs on the main stream behind this one event)
             if not legacy and not prep_enc:
                 side.wait_stream(side2)
@@ -347,7 +382,7 @@ class TrainEngine:
             # L2 term: not needed before the loss kernel at the end of the backward (same stream)
             # (the transposed table image is NOT prepared here, although it depends on the weights only: written 200 us before
             # its use it has left the L2 by then and the scoring pass measured 109 -> 118 us — edgl_score_prepare_table)
-            if self.blk and not legacy:
+            if self.blk and not legacy and not l2_early:
                 l2_term()
         # ================= forward (EasyDGL.py:70-151) =================
         d0 = drop(hd, 1)
@@ -598,6 +633,9 @@ class TrainEngine:
                                                               _ptr(self.loss_tpp), 1 if j > 0 else 0, s), "edgl_tpp_finish_parts")
                     if pending is not None:
                         pending(s)
+                        if self.accumulate_loss:     # running sum of the step losses where they are produced (train.py reads it at its logging points)
+                            with torch.cuda.stream(self.side):
+                                self.loss_sum.add_(self.loss)
 
                 self._side_has_grads = self._pending_label is not None      # (the one-hot term's atomics: Adam must wait for them)
                 if self._lazy_loss and not self.sync_loss and not self._side_has_grads and self.ce_part is not None and \
@@ -691,9 +729,16 @@ class TrainEngine:
                                       0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _stream()), "edgl_adam_apply")
             return
         seg = self.l2_seg if m.l2_reg != 0.0 else None
-        check(lib.edgl_adam_apply(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,
-                                  0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg),
-                                  0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _stream()), "edgl_adam_apply")
+        if self.l2_parts is not None and seg is not None:
+            self._l2p_cur ^= 1       # the copy the NEXT step reads
+            check(lib.edgl_adam_apply_l2p(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,
+                                          0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg), seg.numel() // 2, _ptr(m._shadow),
+                                          _ptr(self.l2_parts[self._l2p_cur]), _stream()), "edgl_adam_apply_l2p")
+            self._l2p_ready = True
+        else:
+            check(lib.edgl_adam_apply(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,
+                                      0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg),
+                                      0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _stream()), "edgl_adam_apply")
         # the counters of the next step (Sequential.settle_state undoes this for anyone else who reads them)
         self._advance_state(_stream())
         m._state_ahead = True

@@ -167,6 +167,7 @@ class Sequential(nn.Module):
         """tf.train.AdamOptimizer(lr).minimize (Base.py:142-144) fused over the arena.  The l2 gradient is
         produced by autograd (ops.L2Fn), so no l2 is folded in here."""
         self.settle_state()
+        self.mask_padded_grads()     # (channel-padded models; idempotent: every optimizer entry point keeps the padded entries at zero)
         ops.adam_step(self._arena, self._grad_arena, self._adam_m, self._adam_v, self.learning_rate, self._adam_state,
                       0.0, None, self._shadow)
 

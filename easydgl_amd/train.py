@@ -36,7 +36,9 @@ def args(argv=None):
     p.add_argument("--num_items", type=int, required=True)
     # reference default: 50 (main.py:35) — head dim 50 with the default single head: EasyDGL runs it zero-padded at head dim 64
     # (model/easydgl.py: exact, the padded channels stay zero); every published recipe passes --num_units=512 (runme.sh:15-115)
-    p.add_argument("--num_units", type=int, default=50)
+    # CTSMA / TGAT / TiSASREC do not pad yet: their kernels tile head dims {16, 32, 64, 128} (and multiples of 128), so WITHOUT the flag
+    # these three default to 64 — the next width the kernels take — and say so; an explicit --num_units they cannot tile raises.
+    p.add_argument("--num_units", type=int, default=None)
     p.add_argument("--num_heads", type=int, default=1)
     p.add_argument("--num_blocks", type=int, default=3)
     p.add_argument("--seqslen", type=int, default=30)
@@ -60,7 +62,14 @@ def args(argv=None):
     p.add_argument("--patience", type=int, default=10)
     p.add_argument("--graph", action="store_true",
                    help="regressive models: replay the training step of full batches as one HIP graph (Sequential.graphed_train_step)")
-    return p.parse_args(argv)
+    a = p.parse_args(argv)
+    if a.num_units is None:
+        a.num_units = 50
+        if a.model in ("CTSMA", "TGAT", "TiSASREC") and (50 % a.num_heads or (50 // a.num_heads) not in (16, 32, 64, 128)):
+            a.num_units = 64 * a.num_heads if 64 * a.num_heads <= 512 else 128 * ((50 + 127) // 128)
+            logging.warning("--num_units not given: the reference's default 50 (main.py:35) is a head dim the %s kernels do not tile "
+                            "(16 / 32 / 64 / 128; only EasyDGL runs it zero-padded) — using %d", a.model, a.num_units)
+    return a
 
 
 class EarlyStopping:
@@ -182,6 +191,11 @@ def run(FLAGS) -> Dict[str, float]:
             if np.any((np.diff(tt, axis=1) < 0) & (ii[:, :-1] != 0)):
                 raise ValueError(f"{name}: timestamps decrease inside a sequence; TGAT needs time-sorted records")
     engine = TrainEngine(model, bs, use_graph=False) if (masked and len(tr_i) >= bs) else None
+    if engine is not None:
+        # the loss is read every 10 batches (NaN test) and once per epoch: the engine leaves its loss launches off the step
+        # (they ride with the next step) and adds the step losses up on the device — the mode bench.py times
+        engine.sync_loss = False
+        engine.accumulate_loss = True
     ckpt = os.path.join(FLAGS.ckpt_dir, f"{FLAGS.model}.pt")
     stopper = EarlyStopping(FLAGS.model, patience=FLAGS.patience, saver=lambda: save_checkpoint(model, ckpt))
     mask_state = torch.tensor([FLAGS.seed, 0], dtype=torch.int64, device="cuda")   # (seed, batch counter) of the masker
@@ -194,6 +208,9 @@ def run(FLAGS) -> Dict[str, float]:
         # main.py:119-122); accumulated on the device, read back every 10 batches for the NaN test and once per epoch
         loss_sum = torch.zeros((), device="cuda", dtype=torch.float64)
         running_loss, nb = float("nan"), 0
+        if engine is not None:
+            engine.join_loss()
+            engine.loss_sum.zero_()
         for lo in range(0, len(order), bs):
             idx = order[lo:lo + bs]
             tok = torch.as_tensor(tr_i[idx]).cuda()
@@ -204,7 +221,8 @@ def run(FLAGS) -> Dict[str, float]:
             else:
                 feats, labels = regressive_batch(tok, tim, True)
             if engine is not None and len(idx) == bs:
-                loss = engine.step(feats, labels)
+                engine.step(feats, labels)
+                loss = None      # (added to engine.loss_sum by the engine's own loss launches)
             elif not masked and getattr(FLAGS, "graph", False) and len(idx) == bs:
                 if gstep is None:
                     # the warm-up step that precedes the capture IS this batch's optimizer step: no replay for it
@@ -215,9 +233,12 @@ def run(FLAGS) -> Dict[str, float]:
             else:
                 loss = model.train_step(feats, labels)
             nb += 1
-            loss_sum += loss.reshape(()).double()
+            if loss is not None:
+                loss_sum += loss.reshape(()).double()
             if nb % 10 == 0 or lo + bs >= len(order):
-                running_loss = float(loss_sum) / nb
+                if engine is not None:
+                    engine.join_loss()       # orders this stream behind the (deferred) loss launches of the last step
+                running_loss = (float(loss_sum) + (float(engine.loss_sum) if engine is not None else 0.0)) / nb
                 if math.isnan(running_loss):
                     break
         logging.info("%03d: Loss=%.4f", epoch, running_loss)

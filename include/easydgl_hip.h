@@ -538,6 +538,13 @@ int edgl_step_begin(uint64_t* rng_state, uint64_t* adam_state, float lr, float b
 int edgl_adam_apply(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
                     const uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, void* stream);
 /* l2 part of the loss: out[0] (+)= 0.5*l2*sum(w[seg]^2)  (EasyDGL.py:158); workspace >= 1024 floats. */
+/* edgl_adam_apply that also leaves the per-block sums of squares of the UPDATED parameters inside the l2 segments in l2_part
+ * (edgl_adam_l2_parts(n) floats): the next step's L2 loss term (coding.py:40) is then edgl_l2_from_parts(l2_part, nparts, l2_reg, ...)
+ * = l2_reg / 2 * sum — one tiny launch that reads nothing of the parameter arena. */
+int edgl_adam_l2_parts(long n);
+int edgl_adam_apply_l2p(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
+                        const uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, float* l2_part, void* stream);
+int edgl_l2_from_parts(const float* l2_part, int nparts, float l2, float* out, int accumulate, void* stream);
 int edgl_l2_loss(const float* param, const int64_t* seg, int nseg, float l2, float* out, int accumulate,
                  float* workspace, void* stream);
 /* element-wise helpers on `dtype` buffers */

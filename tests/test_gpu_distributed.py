@@ -175,12 +175,29 @@ def test_bench_eight_ranks_over_gloo_smoke():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, EDGL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", EDGL_BENCH_SPIN_MS="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--no-extras",
-                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=1500)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 8 * 512 and j["config"]["parallelism"] == "dp8" and j["scaling"] == "weak"
     assert j["value"] > 0 and abs(j["value"] - 8 * 512 / (j["ms_per_step"] * 1e-3)) < 1e-2 * j["value"]
+    # ... and the SAME line carries north_star's other multi-GPU path: the evaluation step with the item table sharded over the
+    # eight ranks, one packed all-gather of the local top-100 and the merge
+    rows = j["extras"]["eval_sharded"]
+    assert rows and all(r_["shards"] == 8 and r_["ms_per_eval_step"] > 0 and r_["allgather_ms"] is not None for r_ in rows)
+    assert rows[0]["allgather_bytes_gathered"] == 8 * 512 * 2 * 100 * 4
+
+
+def test_bench_autograd_path_is_single_gpu_only():
+    """The autograd path has no global-count protocol: averaging per-rank gradients is not the global-batch gradient,
+    so `--path autograd` refuses a world size above one instead of timing a wrong step."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EDGL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", EDGL_BENCH_SPIN_MS="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--path", "autograd",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and "single-GPU only" in (r.stderr + r.stdout)
 
 
 def test_bench_refuses_a_world_size_that_differs_from_gpus():

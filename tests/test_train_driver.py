@@ -155,3 +155,34 @@ def test_reference_default_flags_train_end_to_end(tmp_path):
                    "--ckpt_dir", str(tmp_path / "ckpt")])
     assert set(res) == {"H10", "H50", "H100", "N10", "N50", "N100"}
     assert all(0.0 <= v <= 1.0 and math.isfinite(v) for v in res.values())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name", ["CTSMA", "TGAT", "TiSASREC"])
+def test_default_flags_of_the_regressive_models_construct_and_train(tmp_path, model_name, caplog):
+    """No model flag given (main.py:35-44: --num_units 50 --num_heads 1 --num_blocks 3 --seqslen 30): the three regressive models do
+    not run zero-padded yet, so the driver resolves the width to the next one their kernels tile (64) and says so; an EXPLICIT
+    --num_units 50 still raises with the flag names (tested in the model tests)."""
+    sp = pytest.importorskip("scipy.sparse")
+    import logging
+    from easydgl_amd import data as D
+    from easydgl_amd import train as TR
+    num_items, seqslen, E = 300, 30, 4
+    ids, ts = D.synthetic_batch(num_items, seqslen, 330, seed=5)
+
+    def dump(name, lo, hi):
+        F.write_tfrecord(str(tmp_path / name), [F.encode_example({"seqs_i": ids[i], "seqs_t": ts[i]}) for i in range(lo, hi)])
+    dump("train000.tfrec", 0, 260); dump("validation.tfrec", 260, 295); dump("test.tfrec", 295, 330)
+    with open(tmp_path / "mark.pkl", "wb") as f:
+        pickle.dump(sp.csr_matrix(D.synthetic_mark_table(num_items, E).astype(np.int64)), f)
+    argv = ["--model", model_name, "--train", str(tmp_path / "train*.tfrec"), "--valid", str(tmp_path / "validation.tfrec"),
+            "--test", str(tmp_path / "test.tfrec"), "--num_items", str(num_items), "--mark", str(tmp_path / "mark.pkl"),
+            "--time_scale", "86400", "--num_epochs", "2", "--mask_seen", "--ckpt_dir", str(tmp_path / "ckpt")]
+    assert TR.args(argv).num_units == 64
+    with caplog.at_level(logging.WARNING):
+        res = TR.main(argv)
+    assert any("does not tile" in r.getMessage() or "do not tile" in r.getMessage() for r in caplog.records)
+    assert set(res) == {"H10", "H50", "H100", "N10", "N50", "N100"}
+    assert all(0.0 <= v <= 1.0 and math.isfinite(v) for v in res.values())
+    with pytest.raises(Exception):
+        TR.main(argv + ["--num_units", "50"])
