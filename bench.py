@@ -676,6 +676,11 @@ def extras(c, args, dev):
     return out
 
 
+def _lib_supported(R, C, n, T, K):
+    from easydgl_amd import _lib
+    return _lib.lib.edgl_score_topk_fused_supported(R, C, n, T, K, _lib.BF16)
+
+
 def eval_rows(args, dev, world, rank, dist, steps, warmup, sizes):
     """Sequential.eval's scoring step (Base.py:150-181) with the item table row-sharded over the ranks: every
     rank holds the SAME evaluation batch of 512 sequences (the encoder is replicated), scores it against its table shard,
@@ -757,6 +762,31 @@ def eval_rows(args, dev, world, rank, dist, steps, warmup, sizes):
         k6_bytes = 512 * nloc * 4
         k6_reg = nloc <= 256 * 80 - 8 and os.environ.get("EDGL_TOPK_REG", "1") != "0"
         del lg
+        # the fused form (csrc/k_eval_topk.hip: two sweeps of rows . table^T on the matrix pipe, candidates above a per-row bound, one
+        # ranking launch — no logits tile): time of the whole op on this rank's shard, ALGORITHMIC FLOPs = one logits computation
+        # 2 R C n (the second sweep is a recomputation: `executed_flop`), against the dense bf16 MFMA peak
+        fused = None
+        if _o.EVAL_FUSED and args.dtype == "bf16":
+            rws = torch.randn((512, C), device=dev).bfloat16()
+            tabc = model.compute(model.item_embs.lookup_table)
+            for _ in range(3):
+                _o.score_topk(rws, tabc, model.output_bias, feats["seqs_i"], K, i0s, i1s)
+            torch.cuda.synchronize()
+            ea.record()
+            for _ in range(10):
+                _o.score_topk(rws, tabc, model.output_bias, feats["seqs_i"], K, i0s, i1s)
+            eb.record()
+            torch.cuda.synchronize()
+            f_ms = ea.elapsed_time(eb) / 10
+            f_alg = 2.0 * 512 * C * (i1s - i0s)
+            taken = bool(_lib_supported(512, C, min(i1s - i0s, 131072 if C == 256 else 262144), feats["seqs_i"].shape[1], K))
+            fused = {"bound": "mfma", "kernel": "eval_sweep_kernel x 2 (group maxima | candidates) + eval_thr_kernel + eval_rank_kernel: scoring + seen "
+                                                "mask + top-K without a logits tile" if taken else "not taken at this shape: logits tile + mask_topk",
+                     "avg_op_ms": round(f_ms, 4), "algorithmic_flop": f_alg, "executed_flop": 2 * f_alg if taken else f_alg,
+                     "achieved": round(f_alg / (f_ms * 1e-3) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": round(f_alg / (f_ms * 1e-3) / 1e12 / 2500.0, 4),
+                     "hbm_bytes_not_written": 512 * (i1s - i0s) * 4}
+            del rws
         rows.append({"num_items": num_items, "num_units": C, "T": cfgd["seqslen"] + 1, "batch": 512, "K": K, "shards": world,
                      "ms_per_eval_step": round(dt / steps * 1e3, 4), "sequences_per_s": round(512 * steps / dt, 1),
                      "roofline_k6": {"bound": "hbm", "kernel": ("mask_topk_reg_kernel (seen mask, row in registers, candidates ranked in LDS)" if k6_reg else
@@ -765,6 +795,7 @@ def eval_rows(args, dev, world, rank, dist, steps, warmup, sizes):
                                      "avg_launch_ms": round(k6_ms, 4),
                                      "achieved": round(k6_bytes / (k6_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                      "frac": round(k6_bytes / (k6_ms * 1e-3) / 8e12, 4)},
+                     "roofline_scoring_fused": fused,
                      "allgather_bytes_per_rank": 512 * 2 * K * 4, "allgather_bytes_gathered": world * 512 * 2 * K * 4,
                      "allgather_ms": None if ag_ms is None else round(ag_ms, 4)})
         del model

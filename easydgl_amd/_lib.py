@@ -96,6 +96,9 @@ SIGNATURES = {
     "edgl_reduce_defer": (I, [I, P]),
     "edgl_reduce_flush": (I, [P]),
     "edgl_mask_topk": (I, [P, I, I, I, P, I, I, P, P, P]),
+    "edgl_score_topk_fused_supported": (I, [I, I, I, I, I, I]),
+    "edgl_score_topk_fused_workspace": (L, [I, I, I, I, I]),
+    "edgl_score_topk_fused": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, P, I, P]),
     "edgl_topk_merge": (I, [P, P, I, I, I, P, P, P]),
     "edgl_rank_metrics": (I, [P, I, I, P, P, P]),
     "edgl_tpp_workspace": (I, []),

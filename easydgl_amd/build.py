@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libeasydgl_hip.so")
 SOURCES = ["k_misc.hip", "k_data.hip", "k_encode.hip", "k_gemm.hip", "k_gemm2.hip", "k_layernorm.hip", "k_bimau_fwd.hip", "k_bimau_bwd.hip", "k_bimau_big.hip",
-           "k_score.hip", "k_score_strip.hip", "k_tattn.hip", "k_coding.hip", "k_tail.hip"]
-HEADERS = ["edgl_common.h", "batch_prep.h", "score_plan.h", "gemm_tile.h", "bimau_common.h", "bimau_fwd_impl.h", "bimau_bwd_impl.h", os.path.join("..", "..", "include", "easydgl_hip.h")]
+           "k_score.hip", "k_score_strip.hip", "k_eval_topk.hip", "k_tattn.hip", "k_coding.hip", "k_tail.hip"]
+HEADERS = ["edgl_common.h", "batch_prep.h", "score_plan.h", "topk_select.h", "gemm_tile.h", "bimau_common.h", "bimau_fwd_impl.h", "bimau_bwd_impl.h", os.path.join("..", "..", "include", "easydgl_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read/write traffic around every VALU consumer);
 # gfx950's register file is unified, so nothing is lost by not using AGPRs.  Per file: hipcc 7.2 crashes on k_score.hip

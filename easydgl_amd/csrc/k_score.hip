@@ -24,6 +24,7 @@
 
 #include "edgl_common.h"
 #include "score_plan.h"
+#include "topk_select.h"
 #include "batch_prep.h"
 
 // csrc/k_score_strip.hip: one-wave-per-SIMD form of the two product passes (bf16, C = 128)
@@ -1154,25 +1155,9 @@ __global__ __launch_bounds__(1024) void ce_loss_parts_kernel(const float* ce_par
 // ---------------------------------------------------------------------------------------------
 // K6: mask seen items + per-row top-K (Base.py:156-163,181); K7 merge; metrics (Base.py:181-201)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t float_key(float f) {  // monotone map float -> uint32 (larger = larger); -0.0 and +0.0 tie
-    uint32_t u = __float_as_uint(f);
-    u = u == 0x80000000u ? 0u : u;
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__device__ __forceinline__ float key_float(uint32_t k) {  // inverse of float_key
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
-// one workgroup per row: 4-pass radix select of the K-th largest key, then ordered compaction
+// one workgroup per row: 4-pass radix select of the K-th largest key, then ordered compaction (topk_select.h)
 __global__ __launch_bounds__(256) void mask_topk_kernel(float* logits, int R, int n, int i0, const int64_t* seen,
                                                         int T, int K, float* out_val, int32_t* out_idx) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sel_prefix, sel_remaining;
-    __shared__ int cnt_gt, cnt_eq;
-    __shared__ float cval[128];
-    __shared__ int cidx[128];
-    __shared__ int wave_eq[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     float* x = logits + (long)row * n;
     if (seen) {
@@ -1182,85 +1167,7 @@ __global__ __launch_bounds__(256) void mask_topk_kernel(float* logits, int R, in
         }
         __syncthreads();
     }
-    const int Keff = min(K, n);
-    uint32_t prefix = 0u, mask = 0u;
-    int remaining = Keff;
-    for (int pass = 3; pass >= 0; --pass) {
-        hist[tid] = 0u;
-        __syncthreads();
-        for (int i = tid; i < n; i += blockDim.x) {
-            const uint32_t k = float_key(x[i]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> (pass * 8)) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0, b = 255;
-            for (; b > 0; --b) {
-                if (acc + (int)hist[b] >= remaining) break;
-                acc += hist[b];
-            }
-            sel_prefix = prefix | ((uint32_t)b << (pass * 8));
-            sel_remaining = remaining - acc;
-        }
-        __syncthreads();
-        prefix = sel_prefix;
-        remaining = sel_remaining;
-        mask |= 255u << (pass * 8);
-        __syncthreads();
-    }
-    // prefix = key of the K-th largest value; `remaining` of the elements equal to it are taken (lowest index first)
-    if (tid == 0) { cnt_gt = 0; cnt_eq = 0; }
-    for (int i = tid; i < 128; i += blockDim.x) { cval[i] = -INFINITY; cidx[i] = 0x7fffffff; }
-    __syncthreads();
-    const int n_gt = Keff - remaining;
-    // elements strictly greater: any order (sorted afterwards); equal: need the `remaining` lowest indices
-    for (int base = 0; base < n; base += blockDim.x) {
-        const int i = base + tid;
-        bool is_gt = false, is_eq = false;
-        float v = 0.f;
-        if (i < n) {
-            v = x[i];
-            const uint32_t k = float_key(v);
-            is_gt = k > prefix; is_eq = k == prefix;
-        }
-        if (is_gt) {
-            const int pos = atomicAdd(&cnt_gt, 1);
-            cval[pos] = v; cidx[pos] = i;
-        }
-        // equal elements in index order: ballot-based ordered append within the block pass
-        const unsigned long long bal = __ballot(is_eq);
-        const int lane = tid & 63, w = tid >> 6;
-        if (lane == 0) wave_eq[w] = __popcll(bal);
-        __syncthreads();
-        int offs = cnt_eq;
-        for (int ww = 0; ww < w; ++ww) offs += wave_eq[ww];
-        if (is_eq) {
-            const int pos = offs + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < remaining) { cval[n_gt + pos] = v; cidx[n_gt + pos] = i; }
-        }
-        __syncthreads();
-        if (tid == 0) cnt_eq += wave_eq[0] + wave_eq[1] + wave_eq[2] + wave_eq[3];
-        __syncthreads();
-    }
-    // bitonic sort of 128 candidates by (value desc, index asc)
-    for (int k = 2; k <= 128; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (tid < 128) {
-                const int ixj = tid ^ j;
-                if (ixj > tid) {
-                    const float a = cval[tid], b = cval[ixj];
-                    const int ia = cidx[tid], ib = cidx[ixj];
-                    const bool a_first = (a > b) || (a == b && ia < ib);  // a should precede b
-                    const bool up = (tid & k) == 0;
-                    if (up ? !a_first : a_first) { cval[tid] = b; cval[ixj] = a; cidx[tid] = ib; cidx[ixj] = ia; }
-                }
-            }
-            __syncthreads();
-        }
-    for (int i = tid; i < K; i += blockDim.x) {
-        out_val[(long)row * K + i] = i < Keff ? cval[i] : -INFINITY;
-        out_idx[(long)row * K + i] = i < Keff ? cidx[i] + i0 : -1;
-    }
+    radix_select_row(x, n, i0, K, out_val + (long)row * K, out_idx + (long)row * K);
 }
 
 // The same selection with the row in REGISTERS (n <= 256 * NJ): the 4-pass form above re-reads the row five times and builds its
@@ -1513,18 +1420,38 @@ __global__ __launch_bounds__(256) void mask_topk_reg_kernel(float* logits, int R
 }
 
 // candidates [S][R][K] -> global top-K by (value desc, index asc); S*K <= 1024
+// counts (optional, [R]): the first counts[row] slots of a row's S*K (slot j = list j / K, place j % K) hold candidates, the rest
+// is unwritten memory (the fused evaluation scoring appends candidates: k_eval_topk.hip); a row whose count exceeds S*K is left
+// to that file's exact fallback kernel and not written here.
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* cand_val, const int32_t* cand_idx, int S, int R,
-                                                         int K, float* out_val, int32_t* out_idx) {
+                                                         int K, float* out_val, int32_t* out_idx, const int32_t* counts) {
     __shared__ float v[1024];
     __shared__ int ix[1024];
-    const int row = blockIdx.x, tid = threadIdx.x, n = S * K;
-    for (int i = tid; i < 1024; i += blockDim.x) {
-        if (i < n) {
-            const int s = i / K, k = i % K;
-            const int id = cand_idx[((long)s * R + row) * K + k];
-            v[i] = id < 0 ? -INFINITY : cand_val[((long)s * R + row) * K + k];
-            ix[i] = id < 0 ? 0x7fffffff : id;
-        } else { v[i] = -INFINITY; ix[i] = 0x7fffffff; }
+    const int row = blockIdx.x, tid = threadIdx.x;
+    int n = S * K;
+    if (counts) {
+        const int c = counts[row];
+        if (c < 0 || c > n) return;
+        n = c;
+    }
+    {   // the four slots of a thread: all eight loads out before the first use (slot index clamped: no load behind a branch)
+        int id4[4]; float v4[4];
+        const int SK = S * K;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = min(tid + 256 * j, SK - 1), s = i / K, k = i - s * K;
+            id4[j] = cand_idx[((long)s * R + row) * K + k];
+            v4[j] = cand_val[((long)s * R + row) * K + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(id4[j]), "+v"(v4[j]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
+            const bool ok = i < n && id4[j] >= 0;
+            v[i] = ok ? v4[j] : -INFINITY;
+            ix[i] = ok ? id4[j] : 0x7fffffff;
+        }
     }
     // Fast path (any input order; as in mask_topk_reg_kernel): a thread looks at its <= 4 candidates, the K-th largest of the 256 thread
     // maxima is a lower bound of the K-th largest candidate, the candidates at or above it — a few hundred — are compacted and each
@@ -2236,7 +2163,15 @@ extern "C" int edgl_topk_merge(const float* cand_val, const int32_t* cand_idx, i
                                int32_t* out_idx, void* stream) {
     EDGL_REQUIRE(cand_val && cand_idx && out_val && out_idx, EDGL_ERR_NULL, "edgl_topk_merge: null pointer");
     EDGL_REQUIRE(S > 0 && R > 0 && K > 0 && S * K <= 1024, EDGL_ERR_SHAPE, "edgl_topk_merge: S*K=%d > 1024", S * K);
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, cand_val, cand_idx, S, R, K, out_val, out_idx);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, cand_val, cand_idx, S, R, K, out_val, out_idx,
+                       (const int32_t*)nullptr);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+// the merge over appended candidate lists (k_eval_topk.hip)
+int edgl_topk_merge_counted(const float* cand_val, const int32_t* cand_idx, const int32_t* counts, int S, int R, int K, float* out_val,
+                            int32_t* out_idx, hipStream_t st) {
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(R), dim3(256), 0, st, cand_val, cand_idx, S, R, K, out_val, out_idx, counts);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

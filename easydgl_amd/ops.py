@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -572,6 +573,7 @@ def topk_merge(cand_val: torch.Tensor, cand_idx: torch.Tensor):
 
 EVAL_TILE_BYTES = 64 << 20   # logits staging tile of score_topk: [R, chunk] f32, sized to stay L2 / MALL resident
 TOPK_REG_ITEMS = (256 * 80 - 8) // 8 * 8   # longest row of the register form of edgl_mask_topk (csrc/k_score.hip), a multiple of 8
+EVAL_FUSED = os.environ.get("EDGL_EVAL_FUSED", "1") != "0"   # scoring + seen mask + top-K without a logits tile (k_eval_topk.hip)
 EVAL_GEMM = True             # full item chunks of the chunked evaluation path score through edgl_gemm (tests switch it off)
 
 
@@ -582,6 +584,26 @@ def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
     merge kernel orders the candidates by (value desc, id asc) — the tie rule of tf.nn.top_k.  Returns (val, idx) [R, K]."""
     R = rows.shape[0]
     n = i1 - i0
+    # the fused form (csrc/k_eval_topk.hip): no logits tile at all — two sweeps on the matrix pipe, candidates above a per-row bound,
+    # one ranking launch; item ranges of <= 262 144 per call, longer catalogues in chunks + the merge kernel
+    if EVAL_FUSED and K <= 128 and rows.dtype == torch.bfloat16:
+        T = 0 if seen is None else seen.shape[1]
+        C, code, st = rows.shape[1], _code(rows), _stream()
+        fchunk = 131072 if C == 256 else 262144      # (64 item slices of <= 2048 / 4096 items: the seen bitmap's LDS)
+        starts = list(range(i0, i1, fchunk))
+        # (a short last chunk joins its neighbour's range when that keeps both callable: the fused form wants >= 4096 items)
+        if len(starts) > 1 and (i1 - starts[-1]) < 4096:
+            starts[-1] = max(starts[-2] + 8, (i1 - 4096) // 8 * 8)
+        bounds = [(lo, (starts[j + 1] if j + 1 < len(starts) else i1)) for j, lo in enumerate(starts)]
+        if all(lib.edgl_score_topk_fused_supported(R, C, hi - lo, T, K, code) for lo, hi in bounds) and (len(bounds) == 1 or K <= 512):
+            wsb = max(int(lib.edgl_score_topk_fused_workspace(R, C, hi - lo, T, K)) for lo, hi in bounds)
+            ws = torch.empty(wsb, device=rows.device, dtype=torch.uint8)
+            cval = torch.empty((len(bounds), R, K), device=rows.device, dtype=torch.float32)
+            cidx = torch.empty((len(bounds), R, K), device=rows.device, dtype=torch.int32)
+            for j, (lo, hi) in enumerate(bounds):
+                check(lib.edgl_score_topk_fused(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(seen), T, R, C, table_c.shape[0], lo, hi, K,
+                                                _ptr(cval[j]), _ptr(cidx[j]), _ptr(ws), code, st), "edgl_score_topk_fused")
+            return _merge_lists(cval, cidx, R, K)
     chunk = max(1024, (EVAL_TILE_BYTES // (4 * R)) // 8 * 8)
     if K <= 128 and chunk > TOPK_REG_ITEMS >= 1024:      # rows the top-K kernel keeps in registers: one read of the tile instead of five
         chunk = TOPK_REG_ITEMS // 128 * 128              # (a multiple of 128: full chunks take the tiled GEMM below)
@@ -616,6 +638,12 @@ def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
             check(lib.edgl_score_lse_fwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), None, R, C, I, lo, hi, None, None, None,
                                          _ptr(logits), _ptr(ws), code, st), "edgl_score_lse_fwd")  # logits [R, hi - lo], row stride hi - lo
         check(lib.edgl_mask_topk(_ptr(logits), R, hi - lo, lo, _ptr(seen), T, K, _ptr(cval[j]), _ptr(cidx[j]), st), "edgl_mask_topk")
+    return _merge_lists(cval, cidx, R, K)
+
+
+def _merge_lists(cval, cidx, R, K):
+    """[S, R, K] candidate lists -> the global top-K by (value desc, index asc): rounds of the merge kernel (<= 1024 candidates each)."""
+    dev, st = cval.device, _stream()
     fan = max(2, 1024 // K)                              # the merge kernel takes up to 1024 candidates per row
     while cval.shape[0] > 1:
         n = cval.shape[0]

@@ -368,6 +368,18 @@ int edgl_score_ce_bwd(const void* rows, const void* table, const float* out_bias
  * out_val f32 [R,K], out_idx int32 [R,K] (GLOBAL item ids = i0 + local). K <= 128. */
 int edgl_mask_topk(float* logits, int R, int n, int i0, const int64_t* seen, int T, int K, float* out_val,
                    int32_t* out_idx, void* stream);
+/* Fused evaluation scoring (Base.py:150-181 + EasyDGL.py:149-151): logits = rows . table[i0:i1]^T + [-1000, out_bias] -> -inf at the
+ * row's seen ids (seen [R,T] int64, may be NULL with T = 0) -> top-K by (value desc, global index asc), WITHOUT the [R, i1-i0] logits
+ * tile in HBM: the logits are computed twice on the matrix pipe — group maxima give every row a lower bound of its K-th best unseen
+ * logit, the second sweep appends the few hundred elements above it to the row's candidate list, one more launch ranks
+ * them; rows whose list overflows (heavy ties) are redone exactly from the row's logits in a scratch row.  bf16; C in {64, 128, 256};
+ * K <= 128; 4096 <= i1 - i0 <= 262144 per call (larger catalogues: item chunks + edgl_topk_merge).  edgl_score_topk_fused_supported
+ * = 1 when the shape is taken — otherwise the call returns EDGL_ERR_SHAPE (no silent fallback): run edgl_score_lse_fwd +
+ * edgl_mask_topk.  workspace: edgl_score_topk_fused_workspace BYTES.  out_val f32 [R,K], out_idx int32 [R,K] (global ids). */
+int edgl_score_topk_fused_supported(int R, int C, int n_items, int T, int K, int dtype);
+long edgl_score_topk_fused_workspace(int R, int C, int n_items, int T, int K);
+int edgl_score_topk_fused(const void* rows, const void* table, const float* out_bias, const int64_t* seen, int T, int R, int C,
+                          int I, int i0, int i1, int K, float* out_val, int32_t* out_idx, void* workspace, int dtype, void* stream);
 /* ---- K7: merge of per-shard candidates (after an RCCL all-gather): cand_val/idx [S, R, K] ->
  * global top-K per row by (value desc, global index asc); entries with index < 0 are ignored; S*K <= 1024.  (Candidates above the
  * K-th largest thread maximum are ranked by counting; inputs with more than 256 of them — tie blocks — are sorted.) */

@@ -1,0 +1,133 @@
+"""Fused evaluation scoring (csrc/k_eval_topk.hip): rows . table^T + bias -> seen mask -> top-K without a logits tile in HBM
+(Sequential.eval, Base.py:150-181; EasyDGL.py:149-151) against an fp64 reference on the same bf16 operands and against the unfused
+kernels (edgl_score_lse_fwd logits tile + edgl_mask_topk).  The two GPU paths accumulate in f32 in different orders, so values agree
+to f32 rounding and the index lists may differ only where the reference's neighbours are closer than that rounding; tie blocks
+(identical table rows) are exact: lower index first (tf.nn.top_k), through the candidate lists' overflow into the exact kernel."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def ops():
+    from easydgl_amd import ops as _ops
+    return _ops
+
+
+def _problem(R, C, I, T, seed, dup=0):
+    rng = np.random.default_rng(seed)
+    rows = torch.tensor(rng.standard_normal((R, C)) * 0.5, dtype=torch.bfloat16).cuda()
+    tab = rng.standard_normal((I, C)) * 0.3
+    if dup:                    # blocks of identical rows: exact ties between different items
+        tab[1 + dup:1 + 2 * dup] = tab[1:1 + dup]
+    table = torch.tensor(tab, dtype=torch.bfloat16).cuda()
+    bias = torch.tensor(rng.standard_normal(I - 1) * 0.2, dtype=torch.float32).cuda()
+    if dup:
+        bias[dup:2 * dup] = bias[:dup]
+    seen = rng.integers(0, I, size=(R, T))
+    seen[:, 0] = 0
+    seen[:, 1] = I - 1         # the MASK column
+    return rows, table, bias, torch.tensor(seen).cuda()
+
+
+def _reference(rows, table, bias, seen, i0, i1, K):
+    t = table.double().cpu().numpy().copy()
+    t[0] = 0.0                                         # coding.py:56-57: the used table's row 0 is the zero constant
+    lg = rows.double().cpu().numpy() @ t.T + np.concatenate([[-1000.0], bias.double().cpu().numpy()])
+    lg = lg[:, i0:i1].copy()
+    s = seen.cpu().numpy()
+    for r in range(lg.shape[0]):
+        ids = s[r][(s[r] >= i0) & (s[r] < i1)] - i0
+        lg[r, ids] = -np.inf
+    return lg
+
+
+def _check(val, idx, lg, seen, i0, K, tol=2e-4):
+    val, idx = val.cpu().numpy(), idx.cpu().numpy()
+    s = seen.cpu().numpy()
+    for r in range(lg.shape[0]):
+        order = np.lexsort((np.arange(lg.shape[1]), -lg[r]))[:K]
+        kth = lg[r, order[-1]]
+        assert len(set(idx[r].tolist())) == K and idx[r].min() >= i0, r
+        assert not np.isin(idx[r], s[r]).any(), r                                    # no seen id
+        got = lg[r, idx[r] - i0]
+        assert np.all(np.abs(got - val[r]) <= tol * max(1.0, np.abs(got).max())), r     # the values ARE those items' logits
+        assert np.all(got >= kth - tol), r                                           # each one belongs to the top K (up to f32 rounding)
+        assert np.all(np.diff(val[r]) <= 0), r                                       # descending
+        # ... and where the reference's order is unambiguous at that resolution, it is the same list
+        gaps = np.abs(np.diff(lg[r, np.lexsort((np.arange(lg.shape[1]), -lg[r]))[:K + 1]]))
+        if gaps.min() > 10 * tol:
+            assert np.array_equal(idx[r] - i0, order), r
+
+
+@pytest.mark.parametrize("R,C,I,T,K,i0,i1", [(512, 128, 20001, 101, 100, 0, 20001), (70, 64, 5000, 20, 10, 0, 5000),
+                                              (200, 256, 40000, 201, 100, 0, 40000), (130, 128, 20001, 101, 100, 2504, 12008),
+                                              (64, 128, 9000, 31, 128, 0, 9000)])
+def test_fused_eval_scoring_matches_the_reference(R, C, I, T, K, i0, i1):
+    o = ops()
+    rows, table, bias, seen = _problem(R, C, I, T, seed=R + I)
+    assert o.EVAL_FUSED
+    val, idx = o.score_topk(rows, table, bias, seen, K, i0, i1)
+    torch.cuda.synchronize()
+    _check(val, idx, _reference(rows, table, bias, seen, i0, i1, K), seen, i0, K)
+    # the unfused kernels on the same operands: same lists wherever f32 rounding cannot reorder neighbours (checked above against
+    # the reference for both), same values to rounding
+    o.EVAL_FUSED = False
+    try:
+        val2, idx2 = o.score_topk(rows, table, bias, seen, K, i0, i1)
+    finally:
+        o.EVAL_FUSED = True
+    _check(val2, idx2, _reference(rows, table, bias, seen, i0, i1, K), seen, i0, K)
+    same = (idx == idx2).float().mean().item()
+    assert same > 0.98, same
+
+
+def test_fused_eval_scoring_breaks_ties_by_index_and_survives_overflow():
+    """Blocks of identical items: (a) pairs of equal logits inside the top K come out lower index first; (b) a table of ONE repeated
+    row makes every logit of a row equal — every element passes the bound, the candidate lists overflow and the exact kernel
+    returns the K lowest unseen indices."""
+    o = ops()
+    from easydgl_amd import _lib
+    R, C, I, T, K = 96, 128, 8192, 40, 100
+    rows, table, bias, seen = _problem(R, C, I, T, seed=3, dup=2000)
+    val, idx = o.score_topk(rows, table, bias, seen, K, 0, I)
+    lg = _reference(rows, table, bias, seen, 0, I, K)
+    _check(val, idx, lg, seen, 0, K)
+    v, ix = val.cpu().numpy(), idx.cpu().numpy()
+    for r in range(R):
+        eq = np.where(v[r][1:] == v[r][:-1])[0]
+        assert np.all(ix[r][eq + 1] > ix[r][eq]), r          # equal values: rising index
+    assert sum(len(np.where(v[r][1:] == v[r][:-1])[0]) for r in range(R)) > R      # (the tie blocks are really there)
+    # (b)
+    table2 = table[5:6].repeat(I, 1).contiguous()
+    bias2 = torch.zeros_like(bias)
+    val, idx = o.score_topk(rows, table2, bias2, seen, K, 0, I)
+    ix, s = idx.cpu().numpy(), seen.cpu().numpy()
+    for r in range(R):
+        lgr = float((rows[r].double() * table2[1].double()).sum())
+        if lgr > -1000.0:
+            want = [i for i in range(1, 3 * K) if i not in set(s[r].tolist())][:K]
+        else:
+            continue
+        assert ix[r].tolist() == want, r
+    # the workspace's counts say the exact kernel was in charge
+    assert int(_lib.lib.edgl_score_topk_fused_supported(R, C, I, T, K, _lib.BF16)) == 1
+
+
+def test_fused_eval_is_refused_for_shapes_it_does_not_take():
+    o = ops()
+    from easydgl_amd import _lib
+    lib = _lib.lib
+    assert lib.edgl_score_topk_fused_supported(512, 128, 3000, 101, 100, _lib.BF16) == 0      # too few items for K + T groups
+    assert lib.edgl_score_topk_fused_supported(512, 512, 20001, 101, 100, _lib.BF16) == 0     # width
+    assert lib.edgl_score_topk_fused_supported(512, 128, 20001, 101, 100, _lib.F32) == 0
+    assert lib.edgl_score_topk_fused_supported(512, 128, 20001, 101, 100, _lib.BF16) == 1
+    rows, table, bias, seen = _problem(8, 128, 3000, 11, seed=1)
+    out_v = torch.empty((8, 10), device="cuda"); out_i = torch.empty((8, 10), device="cuda", dtype=torch.int32)
+    ws = torch.empty(1 << 20, device="cuda", dtype=torch.uint8)
+    rc = lib.edgl_score_topk_fused(rows.data_ptr(), table.data_ptr(), bias.data_ptr(), seen.data_ptr(), 11, 8, 128, 3000, 0, 3000, 10,
+                                   out_v.data_ptr(), out_i.data_ptr(), ws.data_ptr(), _lib.BF16, None)
+    assert rc < 0
+    val, idx = o.score_topk(rows, table, bias, seen, 10, 0, 3000)       # the op runs the unfused kernels there
+    _check(val, idx, _reference(rows, table, bias, seen, 0, 3000, 10), seen, 0, 10)
