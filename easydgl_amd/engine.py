@@ -166,6 +166,10 @@ class TrainEngine:
         self.loss_sum = torch.zeros(1, device=dev, dtype=torch.float64)
         self._pending_label = None
         self._lazy_loss, self._side_has_grads, self._loss_unjoined = False, False, False
+        # weight-gradient GEMMs beside the kernels that do not need them (bit 0: the block tail's four products under the attention
+        # backward; bit 1: the QKVT product beside the dX GEMM / embedding backward): _issue_backward
+        self.dw_overlap = int(os.environ.get("EDGL_DW_OVERLAP", "0"))
+        self._dw_forked = False
         self.sync_loss = True      # step(): order the returned loss on the caller's stream (a cross-stream wait behind the optimizer)
         # sync_loss False, the loss launches reading nothing of the batch (ce_part): they are not launched at the end of the backward
         # — the fork for them is an event record behind a kernel of the main stream, 6-8 us of idle — but by the NEXT step on the
@@ -488,6 +492,9 @@ class TrainEngine:
             self._pending_loss = None
             self._pending_label = None
             raise
+        if self._dw_forked:     # the weight-gradient slabs written on the second side stream
+            torch.cuda.current_stream().wait_stream(self.side2)
+            self._dw_forked = False
         check(lib.edgl_reduce_defer(0, st), "edgl_reduce_defer")   # runs the remaining queued reductions in one launch
         if self._pending_loss is not None:   # (no block: no side-stream join in the backward)
             self._pending_loss(st)
@@ -558,6 +565,9 @@ class TrainEngine:
             x_in, cin = (self.x0, 3 * C) if i == 0 else (self.blk[i - 1]["y"], C)
             dh2, dh1 = drop(hd, 12 + 4 * i), drop(hd, 11 + 4 * i)
             if self.fused_tail:
+                if self._dw_forked:     # the previous block's products on the side stream read what this block's kernels rewrite
+                    torch.cuda.current_stream().wait_stream(self.side2)
+                    self._dw_forked = False
                 # the five weight-gradient products of the block run as one grouped launch after the BiMAU backward
                 check(lib.edgl_gemm_dw_defer(1, st), "edgl_gemm_dw_defer")
                 # one launch: LN3' -> GELU' -> dX(Wt) -> LN2' -> dX(Wout) * GELU' -> dX(Wi) -> LN1' -> dX(Wo)  (csrc/k_tail.hip)
@@ -583,6 +593,15 @@ class TrainEngine:
                 self._dense_dw(b["f"], self.d_o, blk.out.kernel, blk.out.bias, 2 * C, C)
                 self._dense_dw(b["a1"], self.d_pre_f, blk.inter.kernel, blk.inter.bias, C, 2 * C)
                 self._dense_dw(b["att"], self.d_ao, blk.att_out.kernel, blk.att_out.bias, C, C)
+                if self.dw_overlap & 1:
+                    # The tail's weight-gradient products depend on the tail backward only: their grouped launch goes to the second
+                    # side stream, UNDER the attention backward (VALU / transcendental bound, matrix pipe > 80 % idle) instead of
+                    # behind it on the main stream.  Their split slabs are reduced by the step's one reduction launch (the deferred
+                    # reduction queue is not bound to a stream); the main stream joins in front of that launch.
+                    self.side2.wait_stream(torch.cuda.current_stream())
+                    check(lib.edgl_gemm_dw_defer(0, self.side2.cuda_stream), "edgl_gemm_dw_defer")
+                    check(lib.edgl_gemm_dw_defer(1, st), "edgl_gemm_dw_defer")
+                    self._dw_forked = True
             else:
                 # y = LN(drop(o) + a1)
                 self._ln_bwd(b["o"], b["a1"], C, blk.out_ln, b["st2"], dY, dh2, self.G3, self.G4 if dh2.active else None)
@@ -616,7 +635,13 @@ class TrainEngine:
                                              _ptr(self.job_order), 0, code, st), "edgl_bimau_bwd_ord")
             self._dense_dw(x_in, self.G4c, att.dense_kernel, att.dense_bias, cin, 4 * C)
             if self.fused_tail:
-                check(lib.edgl_gemm_dw_defer(0, st), "edgl_gemm_dw_defer")
+                if self.dw_overlap & 2:
+                    # ... and the QKVT product beside the dX GEMM / embedding backward chain that does not need it
+                    self.side2.wait_stream(torch.cuda.current_stream())
+                    check(lib.edgl_gemm_dw_defer(0, self.side2.cuda_stream), "edgl_gemm_dw_defer")
+                    self._dw_forked = True
+                else:
+                    check(lib.edgl_gemm_dw_defer(0, st), "edgl_gemm_dw_defer")
             d_in = self.G3c if i == 0 else self.G3
             self._dense_dx(self.G4c, att.dense_kernel, d_in, cin, 4 * C)
             if i == 0:
@@ -649,6 +674,8 @@ class TrainEngine:
                     self._pending_label(self.side.cuda_stream)
                     self._pending_label = None
                 if not self._lazy_loss or self._side_has_grads:
+                    if self._dw_forked:
+                        self.side.wait_stream(self.side2)
                     check(lib.edgl_reduce_flush(self.side.cuda_stream), "edgl_reduce_flush")
             # both residual branches feed the first C channels of the block input (temporal.py:447, EasyDGL.py:116)
             if i > 0:
