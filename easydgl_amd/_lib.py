@@ -43,6 +43,8 @@ SIGNATURES = {
     "edgl_encode_bwd_add_label": (I, [P, P, P, P, P, I, I, I, I, I, F, P, U32, P, P, P, P, I, P, P, P, P, I, P, I, P]),
     "edgl_embed_pos_fwd": (I, [P, P, P, P, P, I, I, I, I, F, F, P, U32, P, P, P, I, P]),
     "edgl_embed_pos_bwd": (I, [P, P, I, I, I, I, F, P, U32, P, P, I, P]),
+    "edgl_embed_pos_fwd_ct": (I, [P, P, P, P, P, I, I, I, I, F, F, P, U32, P, P, P, I, I, P]),
+    "edgl_embed_pos_bwd_ct": (I, [P, P, I, I, I, I, F, P, U32, P, P, I, I, P]),
     "edgl_gemm": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, I, I, P, I, P]),
     "edgl_colsum": (I, [P, I, I, I, P, I, P, I, I, P]),
     "edgl_gemm_dw_workspace": (L, [I, I, I, I]),

@@ -54,6 +54,7 @@ struct EmbP {
     void* x0; float* spans; uint8_t* marks;
     const void* dx0; float* d_item; float* d_pos;
     int srows;   // rows per block of the backward (<= ESROWS; fewer when ESROWS*C floats exceed the LDS)
+    float sq;    // coding.py:62-63 sqrt(num_units): of the TRUE width for a channel-padded model (the _ct entry points)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(EmbP p) {
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(EmbP p) {
     }
     const int nseg = p.pos_tab ? 2 : 1;   // item | position (CTSMA) or the item embedding alone (TGAT.py:49, TiSASREC.py:52)
     const long ldo = (long)nseg * p.C;
-    const float sq = sqrtf((float)p.C);   // coding.py:62-63
+    const float sq = p.sq;   // coding.py:62-63
     float v[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (id != 0) {   // coding.py:56-57 zero-padded row 0
         const Frag4<T> it = frag_ld<T>(reinterpret_cast<const T*>(p.item_tab) + id * p.C + c0);
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(EmbP p) {
     const int cpr = p.C >> 2, rows_par = 256 / cpr;
     const int cv = tid % cpr, rl = tid / cpr, c0 = cv * 4;
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
-    const float sq = sqrtf((float)p.C);
+    const float sq = p.sq;
     const long ldo = p.d_pos ? 2L * p.C : (long)p.C;
     if (tid < rows_par * cpr)
         for (int r = rl; r < SR; r += rows_par) {
@@ -149,18 +150,19 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(EmbP p) {
 
 }  // namespace
 
-extern "C" int edgl_embed_pos_fwd(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
+extern "C" int edgl_embed_pos_fwd_ct(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
                                   const uint8_t* mark_table, int B, int T, int C, int E, float time_scale, float drop_rate,
                                   const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans, uint8_t* marks,
-                                  int dtype, void* stream) {
+                                  int c_true, int dtype, void* stream) {
     EDGL_REQUIRE(ids && item_tab && x0, EDGL_ERR_NULL, "edgl_embed_pos_fwd: null pointer");
     EDGL_REQUIRE((spans != nullptr) == (marks != nullptr) && (!spans || (ts && mark_table)), EDGL_ERR_NULL,
                  "edgl_embed_pos_fwd: spans and marks go together and need ts and mark_table");
     EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && (E >= 1 || !spans), EDGL_ERR_SHAPE, "edgl_embed_pos_fwd: bad shape B=%d T=%d C=%d E=%d", B, T, C, E);
+    EDGL_REQUIRE(c_true >= 0 && c_true <= C, EDGL_ERR_SHAPE, "edgl_embed_pos_fwd: true width %d exceeds C=%d", c_true, C);
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_embed_pos_fwd: bad dtype %d", dtype);
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_embed_pos_fwd: dropout without rng_state");
     EmbP p{ids, ts, item_tab, pos_tab, mark_table, B, T, C, E, time_scale, drop_rate, rng_state, stream_id, x0, spans, marks,
-           nullptr, nullptr, nullptr, 0};
+           nullptr, nullptr, nullptr, 0, sqrtf((float)(c_true > 0 ? c_true : C))};
     const long total = (long)B * T * (C / 4);
     dim3 grid((unsigned)((total + 255) / 256));
     if (dtype == EDGL_F32) hipLaunchKernelGGL((embed_pos_fwd_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -169,12 +171,21 @@ extern "C" int edgl_embed_pos_fwd(const int64_t* ids, const float* ts, const voi
     return EDGL_OK;
 }
 
-extern "C" int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, int T, int C, int I, float drop_rate,
-                                  const uint64_t* rng_state, uint32_t stream_id, float* d_item, float* d_pos, int dtype,
-                                  void* stream) {
+extern "C" int edgl_embed_pos_fwd(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
+                                  const uint8_t* mark_table, int B, int T, int C, int E, float time_scale, float drop_rate,
+                                  const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans, uint8_t* marks,
+                                  int dtype, void* stream) {
+    return edgl_embed_pos_fwd_ct(ids, ts, item_tab, pos_tab, mark_table, B, T, C, E, time_scale, drop_rate, rng_state, stream_id, x0,
+                                 spans, marks, 0, dtype, stream);
+}
+
+extern "C" int edgl_embed_pos_bwd_ct(const int64_t* ids, const void* dx0, int B, int T, int C, int I, float drop_rate,
+                                  const uint64_t* rng_state, uint32_t stream_id, float* d_item, float* d_pos, int c_true,
+                                  int dtype, void* stream) {
     EDGL_REQUIRE(ids && dx0 && d_item, EDGL_ERR_NULL, "edgl_embed_pos_bwd: null pointer");
     EDGL_REQUIRE(B > 0 && T > 0 && C > 0 && C % 4 == 0 && C / 4 <= 256 && I > 1,
                  EDGL_ERR_SHAPE, "edgl_embed_pos_bwd: bad shape B=%d T=%d C=%d", B, T, C);
+    EDGL_REQUIRE(c_true >= 0 && c_true <= C, EDGL_ERR_SHAPE, "edgl_embed_pos_bwd: true width %d exceeds C=%d", c_true, C);
     int srows = ESROWS;
     while (srows > 8 && (size_t)srows * C * sizeof(float) > 150 * 1024) srows >>= 1;   // C = 512: 64 rows per block
     EDGL_REQUIRE(dtype == EDGL_F32 || dtype == EDGL_BF16, EDGL_ERR_DTYPE, "edgl_embed_pos_bwd: bad dtype %d", dtype);
@@ -185,7 +196,7 @@ extern "C" int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, in
         return EDGL_ERR_LAUNCH;
     }
     EmbP p{ids, nullptr, nullptr, nullptr, nullptr, B, T, C, 0, 1.f, drop_rate, rng_state, stream_id, nullptr, nullptr, nullptr,
-           dx0, d_item, d_pos, srows};
+           dx0, d_item, d_pos, srows, sqrtf((float)(c_true > 0 ? c_true : C))};
     const size_t smem = (size_t)srows * C * sizeof(float);
     dim3 grid((unsigned)(((long)B * T + srows - 1) / srows));
     if (dtype == EDGL_F32) {
@@ -197,6 +208,12 @@ extern "C" int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, in
     }
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
+}
+
+extern "C" int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, int T, int C, int I, float drop_rate,
+                                  const uint64_t* rng_state, uint32_t stream_id, float* d_item, float* d_pos, int dtype,
+                                  void* stream) {
+    return edgl_embed_pos_bwd_ct(ids, dx0, B, T, C, I, drop_rate, rng_state, stream_id, d_item, d_pos, 0, dtype, stream);
 }
 
 extern "C" int edgl_mask_random(const int64_t* tokens, int B, int T, int M, int64_t mask_id, const uint64_t* rng_state,

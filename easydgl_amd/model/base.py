@@ -150,8 +150,127 @@ class Sequential(nn.Module):
         step.warmup_loss = warm_loss   # loss of the last eager warm-up step (a real optimizer step on the capture batch)
         return step
 
+    # ---- channel padding (TGAT / TiSASRec / CTSMA; EasyDGL has its own forms of the same in model/easydgl.py) -----------------
+    # A head dim the attention kernels do not tile (they take 16 / 32 / 64 / 128; the reference's own default is --num_units 50
+    # --num_heads 1, main.py:35-37) runs at the next supported head dim with ZERO-PADDED channels: every parameter is stored at the
+    # padded width, head h's true channels sit at [h * dh_pad, h * dh_pad + dh_true), the padded rows / columns are zero and stay
+    # zero (the projections' padded columns, the dense layers' padded rows and columns and the tables' padded columns are 0, the
+    # LayerNorms take their moments over the real channels and return nothing into the padded ones); the score scale 1 / sqrt(dh)
+    # and coding.py's sqrt(num_units) are those of the TRUE width.  What is not zero on a padded entry by itself (rounding residue
+    # of a softmax backward's row sums against TGAT's constant time code, the intensity MLP's padded hidden units) is zeroed by
+    # mask_padded_grads in front of every optimizer launch.  tf_values() / tf_gradients() / load_tf_variables() speak the
+    # reference's shapes.  A model lists its variables in _pad_specs(): (TF name, parameter, per-axis index map true -> padded or
+    # None, initialiser of the TRUE-shape variable).
+    def _setup_channel_pad(self, who: str, max_pad_dim: int = 128) -> None:
+        from ..module import temporal as T
+        self.width_true = self.num_units
+        self.pad, self.qk_scale = (0, 0), 0.0
+        H = self.num_heads
+        if H <= 0 or self.num_units % H:
+            raise ValueError(f"{who}: num_units={self.num_units} must be a multiple of num_heads={H}")
+        dht = self.num_units // H
+        if dht in T.SUPPORTED_HEAD_DIMS or dht > max_pad_dim:
+            return
+        dhp = next(d for d in T.SUPPORTED_HEAD_DIMS if d >= dht)
+        self.pad = (dhp, dht)
+        self.num_units = H * dhp
+        self.qk_scale = float(dht) ** -0.5
+
+    def _cmap(self, blocks: int = 1) -> torch.Tensor:
+        """True channel -> padded channel, for `blocks` concatenated [C]-wide column blocks (K | V, item | position ...)."""
+        dhp, dht = self.pad
+        c = torch.arange(self.width_true)
+        one = (c // dht) * dhp + (c % dht)
+        return torch.cat([one + k * self.num_units for k in range(blocks)])
+
+    def _pad_specs(self):
+        raise NotImplementedError
+
+    @staticmethod
+    def _spec_index(t, maps):
+        idx = [torch.arange(t.shape[a]) if m is None else m for a, m in enumerate(maps)]
+        return torch.meshgrid(*[i.to(t.device) for i in idx], indexing="ij")
+
+    @staticmethod
+    def _spec_shape(p, maps):
+        return tuple(p.shape[a] if m is None else len(m) for a, m in enumerate(maps))
+
+    @torch.no_grad()
+    def _init_padded(self, gen) -> None:
+        """The reference's initialisers on the TRUE shapes (glorot limits of the true fans), scattered into zeroed padded storage."""
+        import numpy as np
+        from ..module.coding import glorot_uniform_
+        specs = self._pad_specs()
+        for _, p, _, _ in specs:
+            p.data.zero_()
+        for _, p, maps, kind in specs:
+            shp = self._spec_shape(p, maps)
+            if kind == "glorot":
+                v = glorot_uniform_(torch.empty(shp), gen)
+            elif kind == "ones":
+                v = torch.ones(shp)
+            elif kind == "linspace9":      # coding.py:104-108 TimeFunctionCoding.basis_freq
+                v = torch.from_numpy(np.linspace(0, 9, shp[0]).astype(np.float32))
+            else:
+                v = torch.zeros(shp)
+            p.data[self._spec_index(p.data, maps)] = v.to(p.device, p.dtype)
+
     def mask_padded_grads(self) -> None:
-        """Channel-padded models zero the few gradients that are not zero on padded entries by themselves (EasyDGL)."""
+        """Zero every gradient entry of a padded row / column (see above); a model without padding: nothing."""
+        if not self.pad[0]:
+            return
+        plan = getattr(self, "_pad_mask_plan", None)
+        if plan is None:
+            real = {}      # parameter -> per axis: set of real indices (None: all)
+            for _, p, maps, _ in self._pad_specs():
+                cur = real.setdefault(id(p), [p] + [set() if m is not None else None for m in maps])
+                for a, m in enumerate(maps):
+                    if m is not None:
+                        cur[1 + a].update(m.tolist())
+            plan = []
+            for p, *axes in real.values():
+                for a, idxs in enumerate(axes):
+                    if idxs is not None:
+                        padded = sorted(set(range(p.shape[a])) - idxs)
+                        if padded:
+                            plan.append((p, a, torch.tensor(padded, device=p.device, dtype=torch.int64)))
+            self._pad_mask_plan = plan
+        for p, a, idx in plan:
+            if p.grad is not None:
+                p.grad.index_fill_(a, idx, 0.0)
+
+    @torch.no_grad()
+    def padded_leak(self) -> float:
+        """Largest |value| on a padded entry of any parameter (0.0 for a healthy model; tests)."""
+        worst = 0.0
+        clones = {}
+        for _, p, maps, _ in self._pad_specs():
+            q = clones.setdefault(id(p), p.detach().clone())
+            q[self._spec_index(q, maps)] = 0
+        for q in clones.values():
+            worst = max(worst, float(q.abs().max()))
+        return worst
+
+    @torch.no_grad()
+    def _padded_values(self, grad: bool):
+        out = {}
+        for name, p, maps, _ in self._pad_specs():
+            t = p.grad if grad else p
+            out[name] = t.detach()[self._spec_index(t, maps)].clone()
+        return out
+
+    @torch.no_grad()
+    def _load_padded(self, values) -> None:
+        import numpy as np
+        specs = self._pad_specs()
+        for _, p, _, _ in specs:
+            p.data.zero_()
+        for name, p, maps, _ in specs:
+            v = torch.as_tensor(np.asarray(values[name]), dtype=torch.float32)
+            if tuple(v.shape) != self._spec_shape(p, maps):
+                raise ValueError(f"{name}: expected shape {self._spec_shape(p, maps)}, got {tuple(v.shape)}")
+            p.data[self._spec_index(p.data, maps)] = v.to(p.device, p.dtype)
+        self.sync_shadow()
 
     def settle_state(self) -> None:
         """The static engine leaves the step counters (dropout step, Adam step / learning rate) of the NEXT step in place behind

@@ -60,6 +60,7 @@ class CTSMA(Sequential):
         self.register_buffer("mark_lookup_table", torch.from_numpy(table.astype(np.uint8)), persistent=False)
         self.ct_reg = float(getattr(FLAGS, "ct_reg", 0.0) or 0.0)
         gen = torch.Generator().manual_seed(self.seed)
+        self._setup_channel_pad("CTSMA")      # head dims below 128 that the kernels do not tile run zero-padded (model/base.py)
         C_ = self.num_units
         self.item_embs = C.Embedding(self.num_items, C_, self.l2_reg, zero_pad=True, scale=True, gen=gen)   # CTSMA.py:30-31
         self.pcoding = C.PositionCoding(self.seqslen, C_, self.l2_reg, gen=gen)                              # :32
@@ -70,6 +71,44 @@ class CTSMA(Sequential):
                                       self.attention_probs_dropout_rate, gen))
         self.out_ln = _LayerNorm(C_)                                                                         # outln
         self._metrics = None
+        if self.pad[0]:
+            for blk in self.layers:
+                blk.attention.qk_scale = self.qk_scale
+            self._init_padded(gen)
+
+    def _pad_specs(self):
+        """(TF name, parameter, axis maps true -> padded, initialiser) of every variable, for the channel-padded storage."""
+        dhp, dht = self.pad
+        E, Cp = self.num_events, self.num_units
+        c = self._cmap()
+        j = torch.arange(dht * E)
+        jmap = (j // dht) * dhp + (j % dht)                                   # hidden unit (e, u) of the intensity MLP
+        st_rows = torch.cat([torch.arange(dht), torch.tensor([dhp])])        # its inputs: dh channels + the span
+        sp = [("CSTMA/item_embs/lookup_table", self.item_embs.lookup_table, (None, c), "glorot"),
+              ("CSTMA/spatial_embs/embedding/lookup_table", self.pcoding.pembs.lookup_table, (None, c), "glorot"),
+              ("CSTMA/output_bias", self.output_bias, (None,), "zeros"),
+              ("outln/LayerNorm/gamma", self.out_ln.gamma, (c,), "ones"), ("outln/LayerNorm/beta", self.out_ln.beta, (c,), "zeros")]
+        for i, blk in enumerate(self.layers):
+            pre = f"num_blocks_{i}/"
+            a = pre + "attention/modulating_attention/"
+            st = a + "sequential_temporal_combined/"
+            cin = self._cmap(2) if i == 0 else c                               # item | position channels of the first block's input
+            att = blk.attention
+            sp += [(pre + "attention/LayerNorm/gamma", blk.att_ln.gamma, (cin,), "ones"),
+                   (pre + "attention/LayerNorm/beta", blk.att_ln.beta, (cin,), "zeros"),
+                   (a + "dense/kernel", att.q_kernel, (cin, c), "glorot"), (a + "dense/bias", att.q_bias, (c,), "zeros")]
+            for k in (1, 2, 3):
+                sp += [(a + f"dense_{k}/kernel", att.kvt_kernel, (cin, c + (k - 1) * Cp), "glorot"),
+                       (a + f"dense_{k}/bias", att.kvt_bias, (c + (k - 1) * Cp,), "zeros")]
+            sp += [(st + "dense/kernel", att.st_kernel, (st_rows, jmap), "glorot"), (st + "dense/bias", att.st_bias, (jmap,), "zeros"),
+                   (st + "weight", att.weight, (None, torch.arange(dht)), "glorot"), (st + "scaling", att.scaling, (None,), "zeros"),
+                   (pre + "feed-forward/LayerNorm/gamma", blk.ff_ln.gamma, (c,), "ones"),
+                   (pre + "feed-forward/LayerNorm/beta", blk.ff_ln.beta, (c,), "zeros"),
+                   (pre + "feed-forward/Inner/kernel", blk.ff.inner.kernel, (c, c), "glorot"),
+                   (pre + "feed-forward/Inner/bias", blk.ff.inner.bias, (c,), "zeros"),
+                   (pre + "feed-forward/Readout/kernel", blk.ff.readout.kernel, (c, c), "glorot"),
+                   (pre + "feed-forward/Readout/bias", blk.ff.readout.bias, (c,), "zeros")]
+        return sp
 
     def l2_param_names(self):
         return ["item_embs.lookup_table", "pcoding.pembs.lookup_table"]
@@ -92,22 +131,23 @@ class CTSMA(Sequential):
         ids, ts = features["seqs_i"].contiguous(), features["seqs_t"].contiguous()
         tab = self.item_embs.lookup_table
         hd = self.hidden_dropout_rate
+        pad = self.pad
         x, spans, marks = ops.EmbedPosFn.apply(tab, self.pcoding.pembs.lookup_table, self.compute(tab), ids, ts,
                                                self.mark_lookup_table, self.time_scale, self._drop(hd, 1, is_training),
-                                               self.act_dtype)                                      # :50-58
+                                               self.act_dtype, self.width_true if pad[0] else 0)   # :50-58
         lams = []
         for i, blk in enumerate(self.layers):
-            q_in = ops.AddLayerNormFn.apply(x, None, blk.att_ln.gamma, blk.att_ln.beta, ops.NO_DROP, None)       # :70
+            q_in = ops.AddLayerNormFn.apply(x, None, blk.att_ln.gamma, blk.att_ln.beta, ops.NO_DROP, None, pad)  # :70
             att, lam = blk.attention(q_in, x, ids, spans, marks, is_training, True,
                                      drop=self._drop(self.attention_probs_dropout_rate, 10 + 4 * i, is_training))
-            y = ops.AddLayerNormFn.apply(att, None, blk.ff_ln.gamma, blk.ff_ln.beta, ops.NO_DROP, None)          # :75
+            y = ops.AddLayerNormFn.apply(att, None, blk.ff_ln.gamma, blk.ff_ln.beta, ops.NO_DROP, None, pad)     # :75
             inner = self._linear(y, blk.ff.inner, "relu")                                                        # Base.py:79
             if is_training and hd > 0.0:   # Base.py:80: dropout(inner) — an identity LayerNorm-free path: a scaled copy
                 inner = ops.dropout(inner, self._drop(hd, 11 + 4 * i, True))
             out = self._linear(inner, blk.ff.readout)                                                            # Base.py:82
             x = ops.ff_tail(out, y, None, self._drop(hd, 12 + 4 * i, is_training))                               # Base.py:83-86
             lams.append(lam)
-        rows = ops.AddLayerNormFn.apply(x, None, self.out_ln.gamma, self.out_ln.beta, ops.NO_DROP, gather_pos)   # :82-83
+        rows = ops.AddLayerNormFn.apply(x, None, self.out_ln.gamma, self.out_ln.beta, ops.NO_DROP, gather_pos, pad)   # :82-83
         return rows, lams
 
     def forward(self, features: Dict[str, torch.Tensor], is_training: bool):
@@ -146,6 +186,8 @@ class CTSMA(Sequential):
     # ---- interop with the reference's variable naming (tests / checkpoints converted from TF) ------------------------
     def load_tf_variables(self, values: Dict[str, np.ndarray]) -> None:
         """`values`: TF variable name (scope `main/` stripped) -> array, as oracle/ctsma_ref.init_params lists them."""
+        if self.pad[0]:
+            return self._load_padded(values)
         def put(param, arr):
             with torch.no_grad():
                 param.copy_(torch.as_tensor(np.asarray(arr), dtype=param.dtype).reshape(param.shape))
@@ -178,6 +220,8 @@ class CTSMA(Sequential):
 
     def tf_gradients(self) -> Dict[str, np.ndarray]:
         """Gradients of the last backward under the TF variable names (K|V|T_ split back into dense_1..3)."""
+        if self.pad[0]:
+            return {k: v.float().cpu().numpy() for k, v in self._padded_values(True).items()}
         g = lambda q: q.grad.detach().float().cpu().numpy()
         out = {"CSTMA/item_embs/lookup_table": g(self.item_embs.lookup_table),
                "CSTMA/spatial_embs/embedding/lookup_table": g(self.pcoding.pembs.lookup_table), "CSTMA/output_bias": g(self.output_bias)}

@@ -42,13 +42,17 @@ class TGAT(Sequential):
         self.time_scale = float(FLAGS.time_scale)
         self.seed = int(getattr(FLAGS, "seed", 9876))
         gen = torch.Generator().manual_seed(self.seed)
+        # a head dim below 128 that the kernels do not tile (the reference's default --num_units 50, main.py:35) runs zero-padded
+        # to the next of 16 / 32 / 64 / 128 (model/base.py: channel padding)
+        self._setup_channel_pad("TGAT")
         C_ = self.num_units
         dh = C_ // max(1, self.num_heads)
         if C_ % self.num_heads or not (dh in (16, 32, 64, 128) or (dh > 128 and dh % 128 == 0)):
-            raise ValueError(f"TGAT: head dim num_units/num_heads = {dh} unsupported; the HIP attention kernels take 16, 32, 64, "
-                             f"128 or a multiple of 128 (e.g. --num_units=512 --num_heads=1, runme.sh:80-87)")
+            raise ValueError(f"TGAT: head dim num_units/num_heads = {dh} unsupported; the HIP attention kernels take up to 128 "
+                             f"(zero-padded to 16 / 32 / 64 / 128) or a multiple of 128 (e.g. --num_units=512 --num_heads=1, runme.sh:80-87)")
         if C_ > 512 or C_ & (C_ - 1) or C_ < 32:
-            raise ValueError(f"TGAT: num_units={C_} unsupported (a power of two in [32, 512] for the fused scoring kernels)")
+            raise ValueError(f"TGAT: num_units={self.width_true} (stored as {C_}) unsupported: the fused scoring kernels take a "
+                             f"power of two in [32, 512] (with padded heads: a power-of-two head count)")
         self.item_embs = C.Embedding(num_items, C_, self.l2_reg, zero_pad=True, scale=True, gen=gen)     # TGAT.py:27-28
         self.pcoding_K = C.PositionCoding(self.seqslen, C_, self.l2_reg, gen=gen)                         # :29
         self.tcoding_K = C.TimeFunctionCoding(C_)                                                         # :30
@@ -59,6 +63,34 @@ class TGAT(Sequential):
                                       self.tcoding_K, gen))
         self.out_ln = _LayerNorm(C_)
         self._metrics = None
+        self._finish_pad(gen)
+
+    def _finish_pad(self, gen):
+        if self.pad[0]:
+            for blk in self.layers:
+                blk.attention.qk_scale = self.qk_scale
+            self._init_padded(gen)
+
+    def _pad_specs(self):
+        """(TF name, parameter, axis maps, initialiser) of every variable in _tf_map(), for the channel-padded storage."""
+        c = self._cmap()
+        Cp = self.num_units
+        specs = []
+        for name, (param, sl) in self._tf_map().items():
+            leaf = name.rsplit("/", 1)[-1]
+            if leaf == "lookup_table":
+                maps, kind = (None, c), "glorot"
+            elif leaf == "output_bias":
+                maps, kind = (None,), "zeros"
+            elif leaf == "kernel":
+                maps, kind = (c, c if sl is None else c + sl.start), "glorot"      # sl: the K / V column block of kv_kernel
+            elif leaf == "basis_freq":
+                maps, kind = (c,), "linspace9"
+            else:   # bias / beta / gamma / phase
+                maps, kind = (c if sl is None else c + sl.start,), ("ones" if leaf == "gamma" else "zeros")
+            specs.append((name, param, maps, kind))
+        assert Cp == self.num_units
+        return specs
 
     def l2_param_names(self):
         return ["item_embs.lookup_table", "pcoding_K.pembs.lookup_table"]
@@ -92,18 +124,20 @@ class TGAT(Sequential):
         tab = self.item_embs.lookup_table
         hd = self.hidden_dropout_rate
         # :49-62 — `* seqs_masks` is the identity here: row 0 of the table reads as zeros (coding.py:56-57)
-        x = ops.EmbedFn.apply(tab, self.compute(tab), ids, self._drop(hd, 1, is_training), self.act_dtype)
+        pad = self.pad
+        x = ops.EmbedFn.apply(tab, self.compute(tab), ids, self._drop(hd, 1, is_training), self.act_dtype,
+                              self.width_true if pad[0] else 0)
         for i, blk in enumerate(self.layers):
-            qn = ops.AddLayerNormFn.apply(x, None, blk.att_ln.gamma, blk.att_ln.beta, ops.NO_DROP, None)          # :66
+            qn = ops.AddLayerNormFn.apply(x, None, blk.att_ln.gamma, blk.att_ln.beta, ops.NO_DROP, None, pad)     # :66
             att = blk.attention(qn, x, (ids, ts), is_training, True,
                                 self._drop(self.attention_probs_dropout_rate, 10 + 4 * i, is_training))
-            y = ops.AddLayerNormFn.apply(att, None, blk.ff_ln.gamma, blk.ff_ln.beta, ops.NO_DROP, None)           # :69
+            y = ops.AddLayerNormFn.apply(att, None, blk.ff_ln.gamma, blk.ff_ln.beta, ops.NO_DROP, None, pad)      # :69
             inner = self._linear(y, blk.ff.inner, "relu")                                                         # Base.py:79
             if is_training and hd > 0.0:
                 inner = ops.dropout(inner, self._drop(hd, 11 + 4 * i, True))                                      # Base.py:80
             out = self._linear(inner, blk.ff.readout)                                                             # Base.py:82
             x = ops.ff_tail(out, y, ids, self._drop(hd, 12 + 4 * i, is_training))                                 # Base.py:83-86, TGAT.py:70
-        return ops.AddLayerNormFn.apply(x, None, self.out_ln.gamma, self.out_ln.beta, ops.NO_DROP, gather_pos)    # :72-73
+        return ops.AddLayerNormFn.apply(x, None, self.out_ln.gamma, self.out_ln.beta, ops.NO_DROP, gather_pos, pad)   # :72-73
 
     def forward(self, features: Dict[str, torch.Tensor], is_training: bool):
         ids = features["seqs_i"]
@@ -158,13 +192,23 @@ class TGAT(Sequential):
         return m
 
     def load_tf_variables(self, values: Dict[str, np.ndarray]) -> None:
+        if self.pad[0]:
+            return self._load_padded(values)
         with torch.no_grad():
             for name, (param, sl) in self._tf_map().items():
                 src = torch.as_tensor(np.asarray(values[name]), dtype=param.dtype)
                 (param if sl is None else param[..., sl]).copy_(src)
         self.sync_shadow()
 
+    def tf_values(self) -> Dict[str, np.ndarray]:
+        """Reference variable name -> value in the reference's shape (channel-padded models strip the padding)."""
+        if self.pad[0]:
+            return {k: v.float().cpu().numpy() for k, v in self._padded_values(False).items()}
+        return {name: (p if sl is None else p[..., sl]).detach().float().cpu().numpy() for name, (p, sl) in self._tf_map().items()}
+
     def tf_gradients(self) -> Dict[str, np.ndarray]:
+        if self.pad[0]:
+            return {k: v.float().cpu().numpy() for k, v in self._padded_values(True).items()}
         out = {}
         for name, (param, sl) in self._tf_map().items():
             g = param.grad.detach().float().cpu().numpy()

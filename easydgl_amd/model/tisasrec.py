@@ -33,9 +33,13 @@ class TiSASRec(TGAT):
         self.time_scale = float(FLAGS.time_scale)
         self.seed = int(getattr(FLAGS, "seed", 9876))
         gen = torch.Generator().manual_seed(self.seed)
+        self._setup_channel_pad("TiSASRec")      # head dims below 128 that the kernels do not tile run zero-padded (model/base.py)
         C_ = self.num_units
         if C_ % self.num_heads or (C_ // self.num_heads) not in (16, 32, 64, 128):
-            raise ValueError("TiSASRec on the HIP attention kernel needs a head dim of 16, 32, 64 or 128")
+            raise ValueError("TiSASRec on the HIP attention kernel needs a head dim of at most 128 (zero-padded to 16 / 32 / 64 / 128)")
+        if C_ > 512 or C_ & (C_ - 1) or C_ < 32:
+            raise ValueError(f"TiSASRec: num_units={self.width_true} (stored as {C_}) unsupported: the fused scoring kernels take a "
+                             f"power of two in [32, 512]")
         if not (self.seqslen <= self.timelen <= 256):
             raise ValueError("need seqslen <= timelen <= 256 (position rows come from [timelen, C] tables, TiSASREC.py:30-31)")
         self.item_embs = C.Embedding(num_items, C_, self.l2_reg, zero_pad=True, scale=True, gen=gen)     # TiSASREC.py:27-28
@@ -50,6 +54,7 @@ class TiSASRec(TGAT):
             self.layers.append(_Block(C_, self.num_heads, self.attention_probs_dropout_rate, self.l2_reg, codings, gen))
         self.out_ln = _LayerNorm(C_)
         self._metrics = None
+        self._finish_pad(gen)
 
     def l2_param_names(self):
         return ["item_embs.lookup_table", "pcoding_K.pembs.lookup_table", "pcoding_V.pembs.lookup_table",

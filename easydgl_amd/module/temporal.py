@@ -176,7 +176,8 @@ class MAU(nn.Module):
                                       self.kvt_bias, self.compute(self.kvt_kernel))
         flags = ops.MAU_NO_DIAG | (ops.MAU_CAUSAL if causality else 0)
         return modulated_attention(qkvt, queries[:, :, :C], self.st_kernel, self.st_bias, self.weight, self.scaling, masks,
-                                   intervals, marks, self.num_heads, drop if is_training else ops.NO_DROP, flags)
+                                   intervals, marks, self.num_heads, drop if is_training else ops.NO_DROP, flags,
+                                   float(getattr(self, "qk_scale", 0.0)))
 
 
 class TfMultiHeadAttention(nn.Module):
@@ -208,7 +209,7 @@ class TfMultiHeadAttention(nn.Module):
         kv = ops.LinearFn.apply(keys, self.kv_kernel, self.kv_bias, self.compute(self.kv_kernel), False)
         return ops.TfAttnFn.apply(q, kv, queries, self.pcoding_K.pembs.lookup_table, self.tcoding_K.basis_freq,
                                   self.tcoding_K.phase, ids, ts, self.num_heads, self.time_scale,
-                                  drop if is_training else ops.NO_DROP, self.violations)
+                                  drop if is_training else ops.NO_DROP, self.violations, float(getattr(self, "qk_scale", 0.0)))
 
 
 class TiMultiHeadAttention(nn.Module):
@@ -238,4 +239,4 @@ class TiMultiHeadAttention(nn.Module):
         kt, vt = self.tcoding_K.pembs.lookup_table, self.tcoding_V.pembs.lookup_table
         return ops.TiAttnFn.apply(q, kv, queries, self.pcoding_K.pembs.lookup_table, self.pcoding_V.pembs.lookup_table, kt, vt,
                                   self.compute(kt), self.compute(vt), ids, ts, self.num_heads, self.time_scale, self.timelen,
-                                  drop if is_training else ops.NO_DROP)
+                                  drop if is_training else ops.NO_DROP, float(getattr(self, "qk_scale", 0.0)))

@@ -172,17 +172,19 @@ class EmbedPosFn(torch.autograd.Function):
     """CTSMA.py:48-58: X0 = dropout(concat(item[ids]*sqrt(C), pos[0..T))), spans, marks (edgl_embed_pos_fwd/bwd)."""
 
     @staticmethod
-    def forward(ctx, item_master, pos_tab, item_c, ids, ts, mark_table, time_scale, drop: Drop, act_dtype):
+    def forward(ctx, item_master, pos_tab, item_c, ids, ts, mark_table, time_scale, drop: Drop, act_dtype, c_true=0):
+        """c_true: the true width of a channel-padded model (0: = C) — coding.py:62-63's sqrt(num_units)."""
         B, T = ids.shape
         I, C = item_c.shape
         E = mark_table.shape[1]
         x0 = torch.empty((B, T, 2 * C), device=ids.device, dtype=act_dtype)
         spans = torch.empty((B, T), device=ids.device, dtype=torch.float32)
         marks = torch.empty((B, T, E), device=ids.device, dtype=torch.uint8)
-        check(lib.edgl_embed_pos_fwd(_ptr(ids), _ptr(ts), _ptr(item_c), _ptr(pos_tab), _ptr(mark_table), B, T, C, E,
-                                     float(time_scale), float(drop.rate), drop.ptr(), drop.stream_id, _ptr(x0), _ptr(spans),
-                                     _ptr(marks), _DT[act_dtype], _stream()), "edgl_embed_pos_fwd")
+        check(lib.edgl_embed_pos_fwd_ct(_ptr(ids), _ptr(ts), _ptr(item_c), _ptr(pos_tab), _ptr(mark_table), B, T, C, E,
+                                        float(time_scale), float(drop.rate), drop.ptr(), drop.stream_id, _ptr(x0), _ptr(spans),
+                                        _ptr(marks), int(c_true), _DT[act_dtype], _stream()), "edgl_embed_pos_fwd")
         ctx.save_for_backward(ids)
+        ctx.c_true = int(c_true)
         ctx.meta = (B, T, C, I, drop, item_master.shape, pos_tab.shape)
         ctx.mark_non_differentiable(spans, marks)
         return x0, spans, marks
@@ -194,9 +196,9 @@ class EmbedPosFn(torch.autograd.Function):
         dx0 = dx0.contiguous()
         d_item = torch.empty(ishape, device=dx0.device, dtype=torch.float32)
         d_pos = torch.zeros(pshape, device=dx0.device, dtype=torch.float32)
-        check(lib.edgl_embed_pos_bwd(_ptr(ids), _ptr(dx0), B, T, C, I, float(drop.rate), drop.ptr(), drop.stream_id,
-                                     _ptr(d_item), _ptr(d_pos), _code(dx0), _stream()), "edgl_embed_pos_bwd")
-        return (d_item, d_pos) + (None,) * 7
+        check(lib.edgl_embed_pos_bwd_ct(_ptr(ids), _ptr(dx0), B, T, C, I, float(drop.rate), drop.ptr(), drop.stream_id,
+                                        _ptr(d_item), _ptr(d_pos), ctx.c_true, _code(dx0), _stream()), "edgl_embed_pos_bwd")
+        return (d_item, d_pos) + (None,) * 8
 
 
 # ------------------------------------------------------------------------------------------------
@@ -725,12 +727,14 @@ class EmbedFn(torch.autograd.Function):
     no position table."""
 
     @staticmethod
-    def forward(ctx, item_master, item_c, ids, drop: Drop, act_dtype):
+    def forward(ctx, item_master, item_c, ids, drop: Drop, act_dtype, c_true=0):
         B, T = ids.shape
         I, C = item_c.shape
         x0 = torch.empty((B, T, C), device=ids.device, dtype=act_dtype)
-        check(lib.edgl_embed_pos_fwd(_ptr(ids), None, _ptr(item_c), None, None, B, T, C, 0, 1.0, float(drop.rate), drop.ptr(),
-                                     drop.stream_id, _ptr(x0), None, None, _DT[act_dtype], _stream()), "edgl_embed_pos_fwd")
+        check(lib.edgl_embed_pos_fwd_ct(_ptr(ids), None, _ptr(item_c), None, None, B, T, C, 0, 1.0, float(drop.rate), drop.ptr(),
+                                        drop.stream_id, _ptr(x0), None, None, int(c_true), _DT[act_dtype], _stream()),
+              "edgl_embed_pos_fwd")
+        ctx.c_true = int(c_true)
         ctx.save_for_backward(ids)
         ctx.meta = (B, T, C, I, drop, item_master.shape)
         return x0
@@ -741,9 +745,9 @@ class EmbedFn(torch.autograd.Function):
         B, T, C, I, drop, ishape = ctx.meta
         dx0 = dx0.contiguous()
         d_item = torch.empty(ishape, device=dx0.device, dtype=torch.float32)
-        check(lib.edgl_embed_pos_bwd(_ptr(ids), _ptr(dx0), B, T, C, I, float(drop.rate), drop.ptr(), drop.stream_id,
-                                     _ptr(d_item), None, _code(dx0), _stream()), "edgl_embed_pos_bwd")
-        return d_item, None, None, None, None
+        check(lib.edgl_embed_pos_bwd_ct(_ptr(ids), _ptr(dx0), B, T, C, I, float(drop.rate), drop.ptr(), drop.stream_id,
+                                        _ptr(d_item), None, ctx.c_true, _code(dx0), _stream()), "edgl_embed_pos_bwd")
+        return d_item, None, None, None, None, None
 
 
 class MaskRowsFn(torch.autograd.Function):
@@ -776,7 +780,8 @@ class TfAttnFn(torch.autograd.Function):
     int32 counter of positions whose timestamps decrease (see include/easydgl_hip.h)."""
 
     @staticmethod
-    def forward(ctx, q, kv, resid, pos_tab, omega, phi, ids, ts, H, time_scale, drop: Drop, violations):
+    def forward(ctx, q, kv, resid, pos_tab, omega, phi, ids, ts, H, time_scale, drop: Drop, violations, qk_scale=0.0):
+        """qk_scale: the score scale (0 = 1 / sqrt(head dim)); a channel-padded model passes 1 / sqrt(true head dim)."""
         B, T, C = q.shape
         dh = C // H
         q, kv, resid = q.contiguous(), kv.contiguous(), resid.contiguous()
@@ -788,7 +793,7 @@ class TfAttnFn(torch.autograd.Function):
         out = torch.empty((B, T, C), device=q.device, dtype=q.dtype)
         need = any(ctx.needs_input_grad)
         saved = torch.empty(int(lib.edgl_tattn_saved_bytes(B, T, H, dh)), device=q.device, dtype=torch.uint8) if need else None
-        scale = 1.0 / float(dh) ** 0.5                                                   # temporal.py:153
+        scale = float(qk_scale) if qk_scale else 1.0 / float(dh) ** 0.5                  # temporal.py:153
         check(lib.edgl_tattn_fwd(_ptr(qx), 3 * C, _ptr(kx), 3 * C, _vptr(kv[:, :, C:]), 2 * C, _ptr(resid), C, _ptr(ids), B, T, H,
                                  3 * dh, dh, scale, float(drop.rate), drop.ptr(), drop.stream_id, _ptr(out), C, _ptr(saved),
                                  _lib.TATTN_CAUSAL, code, _stream()), "edgl_tattn_fwd")
@@ -820,7 +825,7 @@ class TfAttnFn(torch.autograd.Function):
             full = torch.zeros(pshape, device=q.device, dtype=torch.float32)
             full[:T] = d_pos
             d_pos = full
-        return d_q, d_kv, d_out, d_pos, d_omega, d_phi, None, None, None, None, None, None
+        return d_q, d_kv, d_out, d_pos, d_omega, d_phi, None, None, None, None, None, None, None
 
 
 class TiAttnFn(torch.autograd.Function):
@@ -828,7 +833,8 @@ class TiAttnFn(torch.autograd.Function):
     position tables posK/posV f32 [>=T, C], interval tables (masters f32 + compute-dtype copies) [timelen, C]."""
 
     @staticmethod
-    def forward(ctx, q, kv, resid, posK, posV, ktime, vtime, ktime_c, vtime_c, ids, ts, H, time_scale, timelen, drop: Drop):
+    def forward(ctx, q, kv, resid, posK, posV, ktime, vtime, ktime_c, vtime_c, ids, ts, H, time_scale, timelen, drop: Drop,
+                qk_scale=0.0):
         B, T, C = q.shape
         dh = C // H
         q, kv, resid = q.contiguous(), kv.contiguous(), resid.contiguous()
@@ -841,7 +847,7 @@ class TiAttnFn(torch.autograd.Function):
         if need:
             saved = torch.empty(int(lib.edgl_tattn_saved_bytes(B, T, H, dh)), device=q.device, dtype=torch.uint8)
             wbuf = torch.empty(int(lib.edgl_tiattn_bucket_elems(B, T, H, timelen)), device=q.device, dtype=q.dtype)
-        scale = 1.0 / float(dh) ** 0.5
+        scale = float(qk_scale) if qk_scale else 1.0 / float(dh) ** 0.5
         rows = ktime_c.shape[0]
         check(lib.edgl_tiattn_fwd(_ptr(q), C, _ptr(kvp), 2 * C, _vptr(kvp[:, :, C:]), 2 * C, _ptr(resid), C, _ptr(ids), _ptr(ts),
                                   _ptr(ktime_c), _ptr(vtime_c), rows, B, T, H, dh, scale, float(time_scale), int(timelen),
@@ -871,7 +877,7 @@ class TiAttnFn(torch.autograd.Function):
         d_pv = torch.zeros(pv_shape, device=q.device, dtype=torch.float32)
         d_pk[:T] = d_pos[:, :C]
         d_pv[:T] = d_pos[:, C:]
-        return d_q, d_kv, d_out, d_pk, d_pv, d_kt, d_vt, None, None, None, None, None, None, None, None
+        return d_q, d_kv, d_out, d_pk, d_pv, d_kt, d_vt, None, None, None, None, None, None, None, None, None
 
 
 

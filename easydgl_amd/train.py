@@ -34,11 +34,10 @@ def args(argv=None):
     p.add_argument("--test", required=True)
     p.add_argument("--model", required=True, help="algorithm name: EasyDGL, CTSMA, TGAT or TiSASREC (util.ranking keys)")
     p.add_argument("--num_items", type=int, required=True)
-    # reference default: 50 (main.py:35) — head dim 50 with the default single head: EasyDGL runs it zero-padded at head dim 64
-    # (model/easydgl.py: exact, the padded channels stay zero); every published recipe passes --num_units=512 (runme.sh:15-115)
-    # CTSMA / TGAT / TiSASREC do not pad yet: their kernels tile head dims {16, 32, 64, 128} (and multiples of 128), so WITHOUT the flag
-    # these three default to 64 — the next width the kernels take — and say so; an explicit --num_units they cannot tile raises.
-    p.add_argument("--num_units", type=int, default=None)
+    # reference default: 50 (main.py:35) — head dim 50 with the default single head: every model runs it zero-padded at head dim 64
+    # (model/base.py, model/easydgl.py: exact, the padded channels stay zero); every published recipe passes --num_units=512
+    # (runme.sh:15-115)
+    p.add_argument("--num_units", type=int, default=50)
     p.add_argument("--num_heads", type=int, default=1)
     p.add_argument("--num_blocks", type=int, default=3)
     p.add_argument("--seqslen", type=int, default=30)
@@ -63,12 +62,6 @@ def args(argv=None):
     p.add_argument("--graph", action="store_true",
                    help="regressive models: replay the training step of full batches as one HIP graph (Sequential.graphed_train_step)")
     a = p.parse_args(argv)
-    if a.num_units is None:
-        a.num_units = 50
-        if a.model in ("CTSMA", "TGAT", "TiSASREC") and (50 % a.num_heads or (50 // a.num_heads) not in (16, 32, 64, 128)):
-            a.num_units = 64 * a.num_heads if 64 * a.num_heads <= 512 else 128 * ((50 + 127) // 128)
-            logging.warning("--num_units not given: the reference's default 50 (main.py:35) is a head dim the %s kernels do not tile "
-                            "(16 / 32 / 64 / 128; only EasyDGL runs it zero-padded) — using %d", a.model, a.num_units)
     return a
 
 

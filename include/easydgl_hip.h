@@ -151,6 +151,16 @@ int edgl_embed_pos_fwd(const int64_t* ids, const float* ts, const void* item_tab
 int edgl_embed_pos_bwd(const int64_t* ids, const void* dx0, int B, int T, int C, int I, float drop_rate,
                        const uint64_t* rng_state, uint32_t stream_id, float* d_item, float* d_pos, int dtype,
                        void* stream);
+/* The same for a channel-padded model (TGAT / TiSASRec / CTSMA at a head dim the attention kernels do not tile, e.g. the
+ * reference's default --num_units 50, main.py:35): c_true (0: = C) is the TRUE model width whose square root scales the item
+ * embedding (coding.py:62-63); the padded channels of the tables are zero. */
+int edgl_embed_pos_fwd_ct(const int64_t* ids, const float* ts, const void* item_tab, const float* pos_tab,
+                          const uint8_t* mark_table, int B, int T, int C, int E, float time_scale, float drop_rate,
+                          const uint64_t* rng_state, uint32_t stream_id, void* x0, float* spans, uint8_t* marks,
+                          int c_true, int dtype, void* stream);
+int edgl_embed_pos_bwd_ct(const int64_t* ids, const void* dx0, int B, int T, int C, int I, float drop_rate,
+                          const uint64_t* rng_state, uint32_t stream_id, float* d_item, float* d_pos, int c_true,
+                          int dtype, void* stream);
 
 /* ---- K2/K4: dense layers — tf.layers.dense (temporal.py:409, EasyDGL.py:113,120,125,138) ------
  * C[M,N] = epilogue( sum_k A(m,k) * B(k,n) ).

@@ -159,12 +159,12 @@ def test_reference_default_flags_train_end_to_end(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("model_name", ["CTSMA", "TGAT", "TiSASREC"])
-def test_default_flags_of_the_regressive_models_construct_and_train(tmp_path, model_name, caplog):
-    """No model flag given (main.py:35-44: --num_units 50 --num_heads 1 --num_blocks 3 --seqslen 30): the three regressive models do
-    not run zero-padded yet, so the driver resolves the width to the next one their kernels tile (64) and says so; an EXPLICIT
-    --num_units 50 still raises with the flag names (tested in the model tests)."""
+def test_default_flags_of_the_regressive_models_construct_and_train(tmp_path, model_name):
+    """No model flag given (main.py:35-44: --num_units 50 --num_heads 1 --num_blocks 3 --seqslen 30): head dim 50, which the three
+    regressive models run zero-padded at 64 exactly as EasyDGL does (model/base.py: channel padding).  The driver trains and
+    evaluates at the reference's own width; an explicit --num_units 50 is the same run (the padded entries staying exactly zero through optimizer
+    steps is tested with the models: tests/test_gpu_padded_models.py)."""
     sp = pytest.importorskip("scipy.sparse")
-    import logging
     from easydgl_amd import data as D
     from easydgl_amd import train as TR
     num_items, seqslen, E = 300, 30, 4
@@ -177,12 +177,11 @@ def test_default_flags_of_the_regressive_models_construct_and_train(tmp_path, mo
         pickle.dump(sp.csr_matrix(D.synthetic_mark_table(num_items, E).astype(np.int64)), f)
     argv = ["--model", model_name, "--train", str(tmp_path / "train*.tfrec"), "--valid", str(tmp_path / "validation.tfrec"),
             "--test", str(tmp_path / "test.tfrec"), "--num_items", str(num_items), "--mark", str(tmp_path / "mark.pkl"),
-            "--time_scale", "86400", "--num_epochs", "2", "--mask_seen", "--ckpt_dir", str(tmp_path / "ckpt")]
-    assert TR.args(argv).num_units == 64
-    with caplog.at_level(logging.WARNING):
-        res = TR.main(argv)
-    assert any("does not tile" in r.getMessage() or "do not tile" in r.getMessage() for r in caplog.records)
+            "--time_scale", "86400", "--num_epochs", "2", "--mask_seen", "--ckpt_dir", str(tmp_path / "ckpt"),
+            "--hidden_dropout_rate", "0.1", "--attention_probs_dropout_rate", "0.1", "--l2_reg", "1e-4"]
+    a = TR.args(argv)
+    assert a.num_units == 50 and a.num_heads == 1 and a.num_blocks == 3
+    res = TR.main(argv)
     assert set(res) == {"H10", "H50", "H100", "N10", "N50", "N100"}
     assert all(0.0 <= v <= 1.0 and math.isfinite(v) for v in res.values())
-    with pytest.raises(Exception):
-        TR.main(argv + ["--num_units", "50"])
+    assert TR.args(argv + ["--num_units", "50"]).num_units == 50
