@@ -102,7 +102,15 @@ __global__ __launch_bounds__(128 * NWS) void eval_sweep_kernel(P p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = wave / NWS, sw = wave % NWS, l32 = lane & 31, hi = lane >> 5;
-    const int q0 = blockIdx.x * QB, slice = blockIdx.y;
+    // XCD-aware order (speed only; observed placement: workgroup id b runs on XCD b % 8): the query blocks of ONE item slice are
+    // consecutive workgroups of ONE XCD, so that they run side by side and the slice's table rows come out of that XCD's L2 for all
+    // but the first of them — in (query block, slice) grid order the 8 query blocks of a slice sat on 8 XCDs and every one of them
+    // pulled the slice from HBM (1 M items: 8 x 512 MB per sweep)
+    const int nqb = (p.R + QB - 1) / QB;
+    const int xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
+    const int slice = (jx / nqb) * 8 + xcd;
+    if (slice >= p.nslices) return;
+    const int q0 = (jx % nqb) * QB;
     int* lcount = reinterpret_cast<int*>(smem + G_::OFF_CNT);
     // ---- the 64 query rows: LDS image, then this wave's 32 rows as B fragments in registers ---------------------------------
     for (int pc = tid; pc < QB * (C / 8); pc += NTHR) {
@@ -120,11 +128,15 @@ __global__ __launch_bounds__(128 * NWS) void eval_sweep_kernel(P p) {
     const int tile_lo = slice * p.tps, ntile_all = (p.i1 - p.i0 + NZ - 1) / NZ;
     const int tile_hi = min(ntile_all, tile_lo + p.tps);
     const int tstep = EMIT ? 1 : p.stride;
-    uint4 stg[G_::PIECES];
-    float stb;
+    // Two register staging sets: the loads of tile t + 2 leave while tile t is multiplied and tile t + 1 waits in the other set for
+    // its LDS buffer — with one set a workgroup had ONE 32 KB tile in flight per 2 us memory round trip (the sweep ran at 9 % of
+    // the matrix pipe on a 1 M-item table).  Out-of-range tiles are loaded clamped and never stored.
+    uint4 stg[G_::PIECES], stg2[G_::PIECES];
+    float stb, stb2;
     if (tile_lo < tile_hi) {
         tile_load<C, NZ, NWS>(p, p.i0 + tile_lo * NZ, stg, stb);
         tile_store<C, NZ, NWS>(p, p.i0 + tile_lo * NZ, stg, stb, smem + G_::OFF_Z, reinterpret_cast<float*>(smem + G_::OFF_BIAS));
+        tile_load<C, NZ, NWS>(p, p.i0 + min(tile_lo + tstep, tile_hi - 1) * NZ, stg, stb);      // tile 1 (set A)
     }
     __syncthreads();
     if constexpr (EMIT) {
@@ -166,9 +178,11 @@ __global__ __launch_bounds__(128 * NWS) void eval_sweep_kernel(P p) {
     float thr = 0.f;
     if constexpr (EMIT) thr = p.thr[min(q, p.R - 1)];
     int buf = 0;
-    for (int t = tile_lo; t < tile_hi; t += tstep) {
-        const int tn = t + tstep;
-        if (tn < tile_hi) tile_load<C, NZ, NWS>(p, p.i0 + tn * NZ, stg, stb);
+    // one trip = two tiles: tile t from LDS buffer `buf` with set A holding tile t + 1 and set B taking tile t + 2, then the same with
+    // the sets swapped (static names: register arrays cannot be indexed by the trip's parity)
+    auto one_tile = [&](int t, uint4 (&sa)[G_::PIECES], float& ba, uint4 (&sb)[G_::PIECES], float& bbn) {
+        const int tn = t + tstep, tnn = t + 2 * tstep;
+        if (tnn < tile_hi) tile_load<C, NZ, NWS>(p, p.i0 + tnn * NZ, sb, bbn);
         asm volatile("" ::: "memory");
         const char* zb = smem + G_::OFF_Z + buf * G_::ZB;
         const float* bb = reinterpret_cast<const float*>(smem + G_::OFF_BIAS) + buf * NZ;
@@ -228,10 +242,14 @@ __global__ __launch_bounds__(128 * NWS) void eval_sweep_kernel(P p) {
             }
         }
         if (tn < tile_hi)
-            tile_store<C, NZ, NWS>(p, p.i0 + tn * NZ, stg, stb, smem + G_::OFF_Z + (buf ^ 1) * G_::ZB,
+            tile_store<C, NZ, NWS>(p, p.i0 + tn * NZ, sa, ba, smem + G_::OFF_Z + (buf ^ 1) * G_::ZB,
                               reinterpret_cast<float*>(smem + G_::OFF_BIAS) + (buf ^ 1) * NZ);
         __syncthreads();
         buf ^= 1;
+    };
+    for (int t = tile_lo; t < tile_hi; t += 2 * tstep) {
+        one_tile(t, stg, stb, stg2, stb2);
+        if (t + tstep < tile_hi) one_tile(t + tstep, stg2, stb2, stg, stb);      // (block-uniform)
     }
     if constexpr (!EMIT) {
         if (q < p.R) {
@@ -465,7 +483,7 @@ template <int C, int NZ, int NWS>
 int launch(P p, const Plan& pl, hipStream_t st) {
     using G_ = Geo<C, NZ, NWS>;
     constexpr int NTHR = G_::NTHR;
-    const dim3 grid((p.R + QB - 1) / QB, pl.nslices);
+    const dim3 grid(8 * ((p.R + QB - 1) / QB) * ((pl.nslices + 7) / 8));      // (query block, slice) from the id: see eval_sweep_kernel
     auto k1 = eval_sweep_kernel<C, NZ, NWS, false>;
     auto k2 = eval_sweep_kernel<C, NZ, NWS, true>;
     const int be = G_::bytes_emit(pl.tps * NZ);

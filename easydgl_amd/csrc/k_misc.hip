@@ -544,10 +544,18 @@ __global__ void adam_prepare_kernel(uint64_t* st, float lr, float b1, float b2) 
 }
 // l2_part (optional, [gridDim.x]): the block's sum of squares of the UPDATED parameters inside the l2 segments — the next step's L2
 // loss term (coding.py:40 on the weights that step reads) needs no pass over the arena of its own (edgl_l2_from_parts)
+// (not inlined: the double-precision pow of the bias correction must not cost the memory-bound update loop its registers)
+__device__ __attribute__((noinline)) void advance_step_state(uint64_t* rng, uint64_t* adam, float lr, float b1, float b2) {
+    rng[1] += 1ull;
+    adam[0] += 1ull;
+    const double t = (double)adam[0];
+    reinterpret_cast<float*>(adam + 1)[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+}
 template <bool SHADOW>
 __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, float* m, float* v, long n, float b1,
                                                    float b2, float eps, const uint64_t* st, float l2,
-                                                   const int64_t* seg, int nseg, bf16* shadow, float* l2_part) {
+                                                   const int64_t* seg, int nseg, bf16* shadow, float* l2_part,
+                                                   uint64_t* rng_adv = nullptr, float lr_adv = 0.f, unsigned* ticket = nullptr) {
     __shared__ float red[8];
     const float lr_t = reinterpret_cast<const float*>(st + 1)[0];
     float sq = 0.f;
@@ -568,6 +576,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
     if (l2_part) {
         sq = block_sum(sq, red);
         if (threadIdx.x == 0) l2_part[blockIdx.x] = sq;
+    }
+    if (ticket) {
+        // edgl_adam_apply_l2p_next: the step counters of the NEXT step (step_begin_kernel's update) by the last workgroup to finish —
+        // every workgroup has read this step's learning rate before it takes its ticket, so nobody reads what the update writes
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            *ticket = 0u;
+            advance_step_state(rng_adv, const_cast<uint64_t*>(st), lr_adv, b1, b2);
+        }
     }
 }
 
@@ -1090,6 +1107,24 @@ extern "C" int edgl_adam_apply_l2p(float* param, const float* grad, float* m, fl
     else
         hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
                            step_state, l2, seg, nseg, (bf16*)nullptr, l2_part);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+// ... and advances the dropout step counter, the Adam step and its bias-corrected learning rate for the NEXT step behind the
+// update (edgl_step_begin's work, by the last workgroup to finish: no single-thread launch at the end of the step's chain).
+// ticket: one zero-initialised uint32 owned by the caller (left at zero).
+extern "C" int edgl_adam_apply_l2p_next(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
+                                        uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, float* l2_part,
+                                        uint64_t* rng_state, float lr, uint32_t* ticket, void* stream) {
+    EDGL_REQUIRE(param && grad && m && v && step_state && rng_state && ticket, EDGL_ERR_NULL, "edgl_adam_apply_l2p_next: null pointer");
+    EDGL_REQUIRE(nseg == 0 || seg, EDGL_ERR_NULL, "edgl_adam_apply_l2p_next: segments missing");
+    hipStream_t st = (hipStream_t)stream;
+    if (shadow)
+        hipLaunchKernelGGL((adam_kernel<true>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
+                           (const uint64_t*)step_state, l2, seg, nseg, (bf16*)shadow, l2_part, rng_state, lr, (unsigned*)ticket);
+    else
+        hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
+                           (const uint64_t*)step_state, l2, seg, nseg, (bf16*)nullptr, l2_part, rng_state, lr, (unsigned*)ticket);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

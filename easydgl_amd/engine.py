@@ -756,6 +756,21 @@ class TrainEngine:
                                       0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _stream()), "edgl_adam_apply")
             return
         seg = self.l2_seg if m.l2_reg != 0.0 else None
+        if os.environ.get("EDGL_ADAM_NEXT", "0") == "1":
+            # optimizer + the counters of the next step in ONE launch (the last workgroup to finish advances them)
+            l2p = None
+            if self.l2_parts is not None and seg is not None:
+                self._l2p_cur ^= 1       # the copy the NEXT step reads
+                l2p = self.l2_parts[self._l2p_cur]
+                self._l2p_ready = True
+            if getattr(self, "_adam_ticket", None) is None:
+                self._adam_ticket = torch.zeros(1, device=m._arena.device, dtype=torch.int32)
+            check(lib.edgl_adam_apply_l2p_next(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(),
+                                               0.9, 0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg),
+                                               0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _ptr(l2p), _ptr(m._rng_state),
+                                               float(m.learning_rate), _ptr(self._adam_ticket), _stream()), "edgl_adam_apply_l2p_next")
+            m._state_ahead = True
+            return
         if self.l2_parts is not None and seg is not None:
             self._l2p_cur ^= 1       # the copy the NEXT step reads
             check(lib.edgl_adam_apply_l2p(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,

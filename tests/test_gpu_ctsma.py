@@ -26,8 +26,8 @@ CASES = [
     dict(B=4, T=30, C=512, h=4, E=16, I=700, nb=2),        # the published recipe runme.sh:107-115 (dh = 128, 2 blocks, seqslen 30)
     dict(B=3, T=14, C=64, h=2, E=24, I=90, nb=1),          # more than 16 mark types: two mark groups, MAU keeps the diagonal
     dict(B=2, T=100, C=256, h=2, E=8, I=400, nb=1),        # CTSMA's head dim 128 at L = 100 (bf16: sweep 2 in two channel slices)
-    dict(B=6, T=30, C=50, h=1, E=6, I=300, nb=3),          # the reference's DEFAULT flags (main.py:35-44): head dim 50, zero-padded to 64
-    dict(B=3, T=20, C=100, h=2, E=16, I=120, nb=1),        # two padded heads (50 -> 64 each)
+    dict(B=32, T=30, C=50, h=1, E=6, I=300, nb=3),          # the reference's DEFAULT flags (main.py:35-44): head dim 50, zero-padded to 64
+    dict(B=24, T=20, C=100, h=2, E=16, I=120, nb=1),       # two padded heads (50 -> 64 each)
     dict(B=3, T=16, C=44, h=2, E=20, I=90, nb=1),          # head dim 22 -> 32 with two mark groups
 ]
 

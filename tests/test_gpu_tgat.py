@@ -140,8 +140,8 @@ CASES = [
     dict(B=4, T=100, C=128, h=1, I=2000, nb=3),       # runme.sh:80-87 heads / blocks at d = 128 (h=1, dh=128, 3 blocks)
     dict(B=4, T=30, C=512, h=1, I=700, nb=3),         # the published recipe runme.sh:80-87 itself: ONE head of 512 channels
     dict(B=3, T=40, C=512, h=2, I=300, nb=1),         # dh = 256: two slices per head
-    dict(B=6, T=30, C=50, h=1, I=300, nb=3),          # the reference's DEFAULT flags (main.py:35-44): head dim 50, zero-padded to 64
-    dict(B=3, T=20, C=100, h=2, I=120, nb=1),         # two padded heads (50 -> 64 each), C = 100 stored as 128
+    dict(B=32, T=30, C=50, h=1, I=300, nb=3),          # the reference's DEFAULT flags (main.py:35-44): head dim 50, zero-padded to 64
+    dict(B=24, T=20, C=100, h=2, I=120, nb=1),        # two padded heads (50 -> 64 each), C = 100 stored as 128
 ]
 
 

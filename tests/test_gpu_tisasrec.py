@@ -23,8 +23,8 @@ CASES = [
     dict(B=8, T=30, C=64, h=2, I=300, nb=1, timelen=50),        # dh = 32
     dict(B=4, T=100, C=128, h=8, I=2000, nb=2, timelen=256),     # runme.sh:88-96 shape (8 heads, 2 blocks, timelen 256)
     dict(B=4, T=30, C=512, h=8, I=700, nb=2, timelen=256),       # the published recipe runme.sh:89-96 itself (dh = 64, seqslen 30)
-    dict(B=6, T=30, C=50, h=1, I=300, nb=3, timelen=256),        # the reference's DEFAULT flags (main.py:35-44): head dim 50, zero-padded to 64
-    dict(B=3, T=20, C=100, h=2, I=120, nb=1, timelen=40),        # two padded heads (50 -> 64 each)
+    dict(B=32, T=30, C=50, h=1, I=300, nb=3, timelen=256),        # the reference's DEFAULT flags (main.py:35-44): head dim 50, zero-padded to 64
+    dict(B=24, T=20, C=100, h=2, I=120, nb=1, timelen=40),       # two padded heads (50 -> 64 each)
 ]
 
 
