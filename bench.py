@@ -376,7 +376,7 @@ def main():
         # (tools/refresh_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); the committed summary of
         # the latest such pass is quoted and named in `traffic_source`
         traffic, traffic_source = None, None
-        for tp in ("r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json"):
+        for tp in ("r05_dominant_kernel_traffic.json", "r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if args.dtype == "bf16" and args.workload == "step" and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -384,9 +384,9 @@ def main():
                 break
         # whole-step HBM bytes from the same passes, and the time they would take at the 6.3 TB/s a streaming kernel reaches
         step_hbm = None
-        for tp in ("r04_step_hbm_bytes.json",):
+        for tp in ("r05_step_hbm_bytes.json", "r04_step_hbm_bytes.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
-            if args.dtype == "bf16" and args.workload == "step" and os.path.exists(tpath):
+            if step_hbm is None and args.dtype == "bf16" and args.workload == "step" and os.path.exists(tpath):
                 sh = json.load(open(tpath))
                 floor_ms = sh["total_bytes"] / 6.3e12 * 1e3
                 step_hbm = {"bytes": sh["total_bytes"], "read_bytes_corrected": sh["read_bytes_corrected"], "write_bytes": sh["write_bytes"],
@@ -410,9 +410,7 @@ def main():
             att[key] = {"avg_ms": round(t_ms, 4), "algorithmic_gflop": round(fl / 1e9, 2),
                         "achieved": round(fl / (t_ms * 1e-3) / 1e12, 2) if t_ms > 0 else 0.0,
                         "frac": round(fl / (t_ms * 1e-3) / 1e12 / peak, 4) if t_ms > 0 else 0.0, "launches_timed": n_k}
-        pu = os.path.join(ROOT, "profiles", "r04_mfma_valu_util.json")
-        if not os.path.exists(pu):
-            pu = os.path.join(ROOT, "profiles", "r03_mfma_valu_util.json")
+        pu = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_mfma_valu_util.json") for r in (5, 4, 3)) if os.path.exists(q)), "")
         out = {
             "metric": "sequences/sec (fwd+bwd+Adam) B=512 L=100 d=128 |I|=20K" if args.workload != "recipe" else
                       "sequences/sec (fwd+bwd+Adam) published recipe runme.sh:15-23: B=512 L=30 d=512 h=8 M=6 |I|=17.8K",
@@ -612,7 +610,18 @@ def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=Fa
     if not np.isfinite(float(loss)):
         raise RuntimeError("loss is not finite")
     rows_w = [int((lb != 0).sum().item()) for _, lb in batches]
-    return {"dt": dt, "t_issue": t_issue, "loss": loss, "rows_w": rows_w, "dom": dom, "step_ms": step_ms, "step": step, "model": model,
+    # what padding looks like to the attention kernels in these batches (DESIGN §4.6 rule 50): positions with id 0, and 16-key tiles
+    # in front of a sequence's first non-zero id (the only ones BiMAU can leave out: a MASK token on a padded position is a real key)
+    pad_pos, pad_tiles, n_pos, n_tiles = 0, 0, 0, 0
+    for f, _ in batches:
+        ids = f["seqs_i"]
+        nz = ids != 0
+        first = torch.where(nz.any(dim=1), nz.to(torch.int64).argmax(dim=1), torch.full((ids.shape[0],), ids.shape[1], device=ids.device))
+        pad_pos += int((~nz).sum().item()); n_pos += ids.numel()
+        pad_tiles += int((first // 16).sum().item()); n_tiles += ids.shape[0] * ((ids.shape[1] + 15) // 16)
+    padding = {"positions_with_id_0": round(pad_pos / max(1, n_pos), 4), "key_tiles_bimau_can_skip": round(pad_tiles / max(1, n_tiles), 4),
+               "note": "the reference's masker draws masked positions over padding too (dataloader.py:187-191): MASK tokens are real keys"}
+    return {"padding": padding, "dt": dt, "t_issue": t_issue, "loss": loss, "rows_w": rows_w, "dom": dom, "step_ms": step_ms, "step": step, "model": model,
             "engine": None if args.path == "autograd" else eng}
 
 

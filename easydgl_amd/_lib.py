@@ -122,6 +122,7 @@ SIGNATURES = {
     "edgl_adam_apply": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P]),
     "edgl_adam_l2_parts": (I, [L]),
     "edgl_adam_apply_l2p": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P, P]),
+    "edgl_adam_next_tickets": (I, [L]),
     "edgl_adam_apply_l2p_next": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P, P, F, P, P]),
     "edgl_l2_from_parts": (I, [P, I, F, P, I, P]),
     "edgl_l2_loss": (I, [P, P, I, F, P, I, P, P]),

@@ -764,7 +764,7 @@ class TrainEngine:
                 l2p = self.l2_parts[self._l2p_cur]
                 self._l2p_ready = True
             if getattr(self, "_adam_ticket", None) is None:
-                self._adam_ticket = torch.zeros(1, device=m._arena.device, dtype=torch.int32)
+                self._adam_ticket = torch.zeros(int(lib.edgl_adam_next_tickets(m._arena.numel())), device=m._arena.device, dtype=torch.int32)
             check(lib.edgl_adam_apply_l2p_next(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(),
                                                0.9, 0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg),
                                                0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _ptr(l2p), _ptr(m._rng_state),

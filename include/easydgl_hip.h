@@ -567,8 +567,9 @@ int edgl_adam_l2_parts(long n);
 int edgl_adam_apply_l2p(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
                         const uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, float* l2_part, void* stream);
 /* edgl_adam_apply_l2p (l2_part may be NULL) + edgl_step_begin in ONE launch: the last workgroup to finish advances the dropout step
- * counter, the Adam step and its bias-corrected learning rate (Base.py:142-144's global step) for the NEXT step.  ticket: one
- * zero-initialised uint32 of the caller's, left at zero.  The training engine's last launch of a step. */
+ * counter, the Adam step and its bias-corrected learning rate (Base.py:142-144's global step) for the NEXT step.  ticket:
+ * edgl_adam_next_tickets(n) zero-initialised uint32 of the caller's, left at zero.  An A/B switch of the training engine. */
+int edgl_adam_next_tickets(long n);
 int edgl_adam_apply_l2p_next(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
                              uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, float* l2_part,
                              uint64_t* rng_state, float lr, uint32_t* ticket, void* stream);
