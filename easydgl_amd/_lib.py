@@ -151,6 +151,10 @@ SIGNATURES = {
     "edgl_tail_pack": (I, [P, P, P, P, I, P, P]),
     "edgl_tail_fwd": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, P, I, I, P, P, P, P, P, P, P, P, P, P, P,
                           P, P, I, P]),
+    "edgl_tail_fwd_ct": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, P, I, I, P, P, P, P, P, P, P, P, P, P, P,
+                             P, P, I, I, I, P]),
+    "edgl_tail_bwd_ct": (I, [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, I, P, P, I, P, P, P, P, P, P, P, P,
+                             P, P, P, P, P, P, P, I, I, I, P]),
     "edgl_tail_bwd_workspace": (L, [I, I]),
     "edgl_tail_bwd": (I, [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, I, P, P, I, P, P, P, P, P, P, P, P,
                           P, P, P, P, P, P, P, I, P]),

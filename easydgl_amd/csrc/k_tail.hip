@@ -49,6 +49,8 @@ struct TailP {
     const int64_t* mpos; int M; int head; const int32_t* hmap;   // hmap: optional destination row of head row b*M + j (< 0: dropped)
     bf16 *ao, *a1, *pre_f, *f, *o, *y, *pre_t, *so, *hrows;   // pre_f / pre_t receive gelu'(pre-activation)
     float *st1, *st2, *st3;
+    int dhp, dht;   // channel-padded model (head dim dht stored as dhp, the padded channels all zero): the LayerNorms' moments are
+                    // those of the real channels (edgl_tail_fwd_ct); 0, 0: none
 };
 
 template <int CT>
@@ -204,21 +206,36 @@ __device__ __forceinline__ float block_sum_lds(float v, float* red) {
 }
 
 // joint (T, C) moments of the values z[rt][r] held by the workgroup (rows >= T excluded): two passes, as tf.nn.moments
+// Channel-padded models (dhp > 0: head dim dht stored as dhp; edgl_add_layernorm_*_ct in k_layernorm.hip): the moments are those of
+// the REAL channels — divisor T * C_true, padded entries (exact zeros) left out of the centred second moment.
+struct ChanPad {
+    float rm[4];      // 1 for a real channel of this lane's four, 0 for a padded one
+    float ctrue;      // real channels of the model width
+};
 template <int CT>
-__device__ __forceinline__ void joint_moments(const float (&z)[MAXRT][4], int nrt, int T, int lane, float* red, float& mean, float& rstd) {
+__device__ __forceinline__ ChanPad chan_pad(int nl, int dhp, int dht) {
+    ChanPad cp;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cp.rm[r] = (dhp <= 0 || ((nl + r) & (dhp - 1)) < dht) ? 1.f : 0.f;      // (dhp is a power of two)
+    cp.ctrue = dhp > 0 ? (float)((16 * CT) / dhp * dht) : (float)(16 * CT);
+    return cp;
+}
+template <int CT>
+__device__ __forceinline__ void joint_moments(const float (&z)[MAXRT][4], int nrt, int T, int lane, float* red, float& mean, float& rstd,
+                                              const ChanPad& cp) {
     const int l15 = lane & 15;
-    const float n = (float)T * (float)(16 * CT);
+    const float n = (float)T * cp.ctrue;
     float a = 0.f;
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt)
-        if (rt < nrt && rt * 16 + l15 < T) a += (z[rt][0] + z[rt][1]) + (z[rt][2] + z[rt][3]);
+        if (rt < nrt && rt * 16 + l15 < T) a += (z[rt][0] * cp.rm[0] + z[rt][1] * cp.rm[1]) + (z[rt][2] * cp.rm[2] + z[rt][3] * cp.rm[3]);
     mean = block_sum_lds(a, red) / n;
     a = 0.f;
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt)
         if (rt < nrt && rt * 16 + l15 < T) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float d = z[rt][r] - mean; a += d * d; }
+            for (int r = 0; r < 4; ++r) { const float d = (z[rt][r] - mean) * cp.rm[r]; a += d * d; }
         }
     rstd = rsqrtf(block_sum_lds(a, red) / n + 1e-12f);
 }
@@ -246,6 +263,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     const int n0 = wave * 16, nl = n0 + g4;                 // this lane's 4 output channels: nl .. nl + 3
     const long row0 = (long)b * T;
     const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);
+    const ChanPad cpad = chan_pad<CT>(nl, p.dhp, p.dht);
 
     PH_DECL
     // ---- waits ------------------------------------------------------------------------------------------------------------
@@ -319,7 +337,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     wA = load_wfrags<NKB>(p.WoutT + (long)n0 * 2 * C, 2 * C, lane);        // out dense, first half of its inputs (segment D)
     {
         float mean, rstd;
-        joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
+        joint_moments<CT>(z, nrt, T, lane, red, mean, rstd, cpad);
         if (threadIdx.x == 0) { p.st1[2 * b] = mean; p.st1[2 * b + 1] = rstd; }
         const float4 v_g = *reinterpret_cast<const float4*>(par + G::PAR_G1 * C + nl), v_b = *reinterpret_cast<const float4*>(par + G::PAR_B1 * C + nl);
         const float gv[4] = {v_g.x, v_g.y, v_g.z, v_g.w}, ev[4] = {v_b.x, v_b.y, v_b.z, v_b.w};
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     copy_out<CT>(p.o + row0 * C, C, bufS, T);
     {
         float mean, rstd;
-        joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
+        joint_moments<CT>(z, nrt, T, lane, red, mean, rstd, cpad);
         if (threadIdx.x == 0) { p.st2[2 * b] = mean; p.st2[2 * b + 1] = rstd; }
         const float4 v_g = *reinterpret_cast<const float4*>(par + G::PAR_G2 * C + nl), v_b = *reinterpret_cast<const float4*>(par + G::PAR_B2 * C + nl);
         const float gv[4] = {v_g.x, v_g.y, v_g.z, v_g.w}, ev[4] = {v_b.x, v_b.y, v_b.z, v_b.w};
@@ -442,7 +460,7 @@ __global__ __launch_bounds__(64 * CT) void tail_fwd_kernel(TailP p) {
     for (int rt = 0; rt < MAXRT; ++rt) ld_bf4(bufC + (rt * 16 + l15) * LD + nl, z[rt]);   // so, rounded through the activation dtype
     {
         float mean, rstd;
-        joint_moments<CT>(z, nrt, T, lane, red, mean, rstd);
+        joint_moments<CT>(z, nrt, T, lane, red, mean, rstd, cpad);
         if (threadIdx.x == 0) { p.st3[2 * b] = mean; p.st3[2 * b + 1] = rstd; }
         const float4 v_g = *reinterpret_cast<const float4*>(par + G::PAR_G3 * C + nl), v_b = *reinterpret_cast<const float4*>(par + G::PAR_B3 * C + nl);
         const float gv[4] = {v_g.x, v_g.y, v_g.z, v_g.w}, ev[4] = {v_b.x, v_b.y, v_b.z, v_b.w};
@@ -495,6 +513,7 @@ struct TailBwdP {
     // outputs
     bf16 *d_pre_t, *d_o, *d_pre_f, *d_ao, *d_res1, *d_att;
     float *part1, *part2, *part3;             // [B][2C] (dbeta | dgamma) of LN1 / LN2 / LN3
+    int dhp, dht;                             // channel-padded model: see TailP
 };
 
 // dX tile: acc[rt] += W[k-tile rows][n0 .. n0 + 32*NKB) . G[rows of tile rt][same n]   (W row stride ldw; G image stride LD)
@@ -509,9 +528,9 @@ __device__ __forceinline__ void tile_dx(const WFrags<NKB>& wf, const bf16* Gs, i
 template <int CT>
 __device__ __forceinline__ void ln_bwd_regs(const float (&z)[MAXRT][4], const float (&dy)[MAXRT][4], float mean, float rstd,
                                             const float (&gv)[4], int nrt, int T, int lane, int nl, float* red, float* part_b,
-                                            float (&dz)[MAXRT][4]) {
+                                            float (&dz)[MAXRT][4], const ChanPad& cp) {
     const int l15 = lane & 15;
-    const float n = (float)T * (float)(16 * CT);
+    const float n = (float)T * cp.ctrue;      // (gamma is 0 on padded channels: they add nothing to s1 / s2)
     float s1 = 0.f, s2 = 0.f, dga[4] = {0.f, 0.f, 0.f, 0.f}, dbe[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt)
@@ -538,7 +557,7 @@ __device__ __forceinline__ void ln_bwd_regs(const float (&z)[MAXRT][4], const fl
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float xh = (z[rt][r] - mean) * rstd;
-            dz[rt][r] = rstd * (dy[rt][r] * gv[r] - m1 - xh * m2);
+            dz[rt][r] = cp.rm[r] * (rstd * (dy[rt][r] * gv[r] - m1 - xh * m2));      // nothing flows into a padded channel
         }
 }
 
@@ -559,6 +578,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = (lane >> 4) * 4, l15 = lane & 15;
     const int n0 = wave * 16, nl = n0 + g4;
     const long row0 = (long)b * T;
+    const ChanPad cpad = chan_pad<CT>(nl, p.dhp, p.dht);
     float z[MAXRT][4], dy[MAXRT][4], dz[MAXRT][4];
     // weight fragments of the next product, fetched one product ahead (see load_wfrags)
     WFrags<NKB> wf = p.head ? load_wfrags<NKB>(p.Wt + (long)n0 * C, C, lane) : load_wfrags<NKB>(p.Wout + (long)n0 * C, C, lane);
@@ -664,7 +684,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
         {
             const float4 gg = *reinterpret_cast<const float4*>(p.g3 + nl);
             const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
-            ln_bwd_regs<CT>(z, dy, p.st3[2 * b], p.st3[2 * b + 1], gv, nrt, T, lane, nl, red, p.part3 + (long)b * 2 * C, dz);
+            ln_bwd_regs<CT>(z, dy, p.st3[2 * b], p.st3[2 * b + 1], gv, nrt, T, lane, nl, red, p.part3 + (long)b * 2 * C, dz, cpad);
         }
 #pragma unroll
         for (int rt = 0; rt < MAXRT; ++rt)
@@ -726,7 +746,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     {
         const float4 gg = *reinterpret_cast<const float4*>(p.g2 + nl);
         const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
-        ln_bwd_regs<CT>(z, dy, p.st2[2 * b], p.st2[2 * b + 1], gv, nrt, T, lane, nl, red, p.part2 + (long)b * 2 * C, dz);
+        ln_bwd_regs<CT>(z, dy, p.st2[2 * b], p.st2[2 * b + 1], gv, nrt, T, lane, nl, red, p.part2 + (long)b * 2 * C, dz, cpad);
     }
     float da1[MAXRT][4];   // gradient w.r.t. a1: the residual branch now, + d_pre_f . Wi^T below
 #pragma unroll
@@ -804,7 +824,7 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     {
         const float4 gg = *reinterpret_cast<const float4*>(p.g1 + nl);
         const float gv[4] = {gg.x, gg.y, gg.z, gg.w};
-        ln_bwd_regs<CT>(z, dy, p.st1[2 * b], p.st1[2 * b + 1], gv, nrt, T, lane, nl, red, p.part1 + (long)b * 2 * C, dz);
+        ln_bwd_regs<CT>(z, dy, p.st1[2 * b], p.st1[2 * b + 1], gv, nrt, T, lane, nl, red, p.part1 + (long)b * 2 * C, dz, cpad);
     }
 #pragma unroll
     for (int rt = 0; rt < MAXRT; ++rt)
@@ -873,12 +893,13 @@ extern "C" int edgl_tail_pack(const void* Wo, const void* Wi, const void* Wout, 
     return EDGL_OK;
 }
 
-extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const void* pack, const float* bo, const float* bi,
+extern "C" int edgl_tail_fwd_ct(const void* att, const void* xin, int ld_x, const void* pack, const float* bo, const float* bi,
                              const float* bout, const float* bt, const float* g1, const float* b1, const float* g2,
                              const float* b2, const float* g3, const float* b3, int B, int T, int C, float drop_rate,
                              const uint64_t* rng_state, uint32_t sid1, uint32_t sid2, const int64_t* masked_pos, int M, int head,
                              void* ao, void* a1, float* st1, void* pre_f, void* f, void* o, void* y, float* st2, void* pre_t,
-                             void* so, float* st3, void* hrows, const int32_t* hrow_map, int dtype, void* stream) {
+                             void* so, float* st3, void* hrows, const int32_t* hrow_map, int dh_pad, int dh_true, int dtype,
+                                void* stream) {
     EDGL_REQUIRE(att && xin && pack && bo && bi && bout && g1 && b1 && g2 && b2 && ao && a1 && st1 && pre_f && f && o && y && st2,
                  EDGL_ERR_NULL, "edgl_tail_fwd: null pointer");
     EDGL_REQUIRE(!head || (bt && g3 && b3 && masked_pos && pre_t && so && st3 && hrows && M >= 1), EDGL_ERR_NULL,
@@ -886,11 +907,13 @@ extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const v
     EDGL_REQUIRE(B > 0 && edgl_tail_supported(T, C, dtype) && ld_x % 8 == 0, EDGL_ERR_SHAPE,
                  "edgl_tail_fwd: unsupported shape B=%d T=%d C=%d dtype=%d (bf16, C in {64,128}, T <= 112)", B, T, C, dtype);
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_tail_fwd: dropout without rng_state");
+    EDGL_REQUIRE((dh_pad == 0 && dh_true == 0) || (dh_pad > 0 && (dh_pad & (dh_pad - 1)) == 0 && dh_true > 0 && dh_true <= dh_pad && C % dh_pad == 0),
+                 EDGL_ERR_SHAPE, "edgl_tail_fwd: padded-channel spec dh_pad=%d dh_true=%d does not fit C=%d", dh_pad, dh_true, C);
     const bf16* pk = (const bf16*)pack;
     const long cc = (long)C * C;
     TailP p{(const bf16*)att, (const bf16*)xin, ld_x, pk, pk + cc, pk + 3 * cc, pk + 5 * cc, bo, bi, bout, bt, g1, b1, g2, b2, g3, b3,
             B, T, C, drop_rate, rng_state, sid1, sid2, masked_pos, M, head, hrow_map, (bf16*)ao, (bf16*)a1, (bf16*)pre_f, (bf16*)f, (bf16*)o,
-            (bf16*)y, (bf16*)pre_t, (bf16*)so, (bf16*)hrows, st1, st2, st3};
+            (bf16*)y, (bf16*)pre_t, (bf16*)so, (bf16*)hrows, st1, st2, st3, dh_pad, dh_true};
     hipStream_t st = (hipStream_t)stream;
     const int nrt = (T + 15) / 16;
     auto k = C == 128 ? (nrt <= 2 ? tail_fwd_kernel<8, 2> : nrt <= 4 ? tail_fwd_kernel<8, 4> : tail_fwd_kernel<8, MAXRT>)
@@ -902,14 +925,23 @@ extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const v
     return EDGL_OK;
 }
 
-extern "C" int edgl_tail_bwd(const void* xin, int ld_x, const void* ao, const void* a1, const void* pre_f, const void* o,
+extern "C" int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const void* pack, const float* bo, const float* bi,
+                             const float* bout, const float* bt, const float* g1, const float* b1, const float* g2,
+                             const float* b2, const float* g3, const float* b3, int B, int T, int C, float drop_rate,
+                             const uint64_t* rng_state, uint32_t sid1, uint32_t sid2, const int64_t* masked_pos, int M, int head,
+                             void* ao, void* a1, float* st1, void* pre_f, void* f, void* o, void* y, float* st2, void* pre_t,
+                             void* so, float* st3, void* hrows, const int32_t* hrow_map, int dtype, void* stream) {
+    return edgl_tail_fwd_ct(att, xin, ld_x, pack, bo, bi, bout, bt, g1, b1, g2, b2, g3, b3, B, T, C, drop_rate, rng_state, sid1, sid2,
+                            masked_pos, M, head, ao, a1, st1, pre_f, f, o, y, st2, pre_t, so, st3, hrows, hrow_map, 0, 0, dtype, stream);
+}
+extern "C" int edgl_tail_bwd_ct(const void* xin, int ld_x, const void* ao, const void* a1, const void* pre_f, const void* o,
                              const void* pre_t, const void* so, const float* st1, const float* st2, const float* st3,
                              const void* Wo, const void* Wi, const void* Wout, const void* Wt, const float* g1, const float* g2,
                              const float* g3, int B, int T, int C, float drop_rate, const uint64_t* rng_state, uint32_t sid1,
                              uint32_t sid2, int head, const void* d_rows, const int64_t* masked_pos, int M,
                              const int32_t* dy_rowmap, const void* d_y_in, void* d_pre_t, void* d_o, void* d_pre_f, void* d_ao,
                              void* d_res1, void* d_att, float* dg1, float* db1, float* dg2, float* db2, float* dg3, float* db3,
-                             float* workspace, int dtype, void* stream) {
+                             float* workspace, int dh_pad, int dh_true, int dtype, void* stream) {
     EDGL_REQUIRE(xin && ao && a1 && pre_f && o && st1 && st2 && Wo && Wi && Wout && g1 && g2 && d_o && d_pre_f && d_ao && d_res1 &&
                  d_att && dg1 && db1 && dg2 && db2 && workspace, EDGL_ERR_NULL, "edgl_tail_bwd: null pointer");
     EDGL_REQUIRE(head ? (pre_t && so && st3 && Wt && g3 && d_rows && masked_pos && d_pre_t && dg3 && db3 && M >= 1 && M <= 256) : (d_y_in != nullptr),
@@ -917,11 +949,13 @@ extern "C" int edgl_tail_bwd(const void* xin, int ld_x, const void* ao, const vo
     EDGL_REQUIRE(B > 0 && edgl_tail_supported(T, C, dtype) && ld_x % 8 == 0, EDGL_ERR_SHAPE,
                  "edgl_tail_bwd: unsupported shape B=%d T=%d C=%d dtype=%d", B, T, C, dtype);
     EDGL_REQUIRE(drop_rate == 0.f || rng_state, EDGL_ERR_NULL, "edgl_tail_bwd: dropout without rng_state");
+    EDGL_REQUIRE((dh_pad == 0 && dh_true == 0) || (dh_pad > 0 && (dh_pad & (dh_pad - 1)) == 0 && dh_true > 0 && dh_true <= dh_pad && C % dh_pad == 0),
+                 EDGL_ERR_SHAPE, "edgl_tail_bwd: padded-channel spec dh_pad=%d dh_true=%d does not fit C=%d", dh_pad, dh_true, C);
     float* part1 = workspace; float* part2 = workspace + (long)B * 2 * C; float* part3 = workspace + (long)B * 4 * C;
     TailBwdP p{(const bf16*)xin, ld_x, (const bf16*)ao, (const bf16*)a1, (const bf16*)pre_f, (const bf16*)o, (const bf16*)pre_t,
                (const bf16*)so, st1, st2, st3, (const bf16*)Wo, (const bf16*)Wi, (const bf16*)Wout, (const bf16*)Wt, g1, g2, g3, B, T, C,
                drop_rate, rng_state, sid1, sid2, head, (const bf16*)d_rows, masked_pos, M, dy_rowmap, (const bf16*)d_y_in,
-               (bf16*)d_pre_t, (bf16*)d_o, (bf16*)d_pre_f, (bf16*)d_ao, (bf16*)d_res1, (bf16*)d_att, part1, part2, part3};
+               (bf16*)d_pre_t, (bf16*)d_o, (bf16*)d_pre_f, (bf16*)d_ao, (bf16*)d_res1, (bf16*)d_att, part1, part2, part3, dh_pad, dh_true};
     hipStream_t st = (hipStream_t)stream;
     const int nrt = (T + 15) / 16;
     auto k = C == 128 ? (nrt <= 2 ? tail_bwd_kernel<8, 2> : nrt <= 4 ? tail_bwd_kernel<8, 4> : tail_bwd_kernel<8, MAXRT>)
@@ -943,6 +977,18 @@ extern "C" int edgl_tail_bwd(const void* xin, int ld_x, const void* ao, const vo
     if (rc) return rc;
     if (head) rc = red2(part3, dg3, db3);
     return rc;
+}
+extern "C" int edgl_tail_bwd(const void* xin, int ld_x, const void* ao, const void* a1, const void* pre_f, const void* o,
+                             const void* pre_t, const void* so, const float* st1, const float* st2, const float* st3,
+                             const void* Wo, const void* Wi, const void* Wout, const void* Wt, const float* g1, const float* g2,
+                             const float* g3, int B, int T, int C, float drop_rate, const uint64_t* rng_state, uint32_t sid1,
+                             uint32_t sid2, int head, const void* d_rows, const int64_t* masked_pos, int M,
+                             const int32_t* dy_rowmap, const void* d_y_in, void* d_pre_t, void* d_o, void* d_pre_f, void* d_ao,
+                             void* d_res1, void* d_att, float* dg1, float* db1, float* dg2, float* db2, float* dg3, float* db3,
+                             float* workspace, int dtype, void* stream) {
+    return edgl_tail_bwd_ct(xin, ld_x, ao, a1, pre_f, o, pre_t, so, st1, st2, st3, Wo, Wi, Wout, Wt, g1, g2, g3, B, T, C, drop_rate, rng_state,
+                            sid1, sid2, head, d_rows, masked_pos, M, dy_rowmap, d_y_in, d_pre_t, d_o, d_pre_f, d_ao, d_res1, d_att, dg1, db1,
+                            dg2, db2, dg3, db3, workspace, 0, 0, dtype, stream);
 }
 
 extern "C" long edgl_tail_bwd_workspace(int B, int C) { return 6L * B * C; }

@@ -118,8 +118,9 @@ class TrainEngine:
         # beyond what the BiMAU kernels take (T <= 208), checked here so that a future relaxation fails at construction)
         if m.ct_reg != 0.0 and (M > 256 or T > 1024):
             raise _lib.EdglError(f"TrainEngine: masklen {M} > 256 or T {T} > 1024 exceeds the fused TPP kernel (edgl_tpp_fwd_bwd_ex)")
+        # (channel-padded models: the _ct forms take the LayerNorms' moments over the real channels; EDGL_FUSED_TAIL_PAD=0: unfused)
         ok = bool(lib.edgl_tail_supported(T, C, self.code)) and M <= 256 and os.environ.get("EDGL_FUSED_TAIL", "1") != "0" \
-            and not self.pad[0]      # (the fused tail's LayerNorms take their moments over all C channels)
+            and (not self.pad[0] or os.environ.get("EDGL_FUSED_TAIL_PAD", "1") != "0")
         self.fused_tail = ok if fused_tail is None else (bool(fused_tail) and ok)
         self.tail_pack = [e(int(lib.edgl_tail_pack_elems(C))) for _ in range(nb)] if self.fused_tail else []
         if self.fused_tail:   # outputs of the fused backward: the gradients w.r.t. the four dense outputs (operands of the dW GEMMs)
@@ -429,13 +430,13 @@ class TrainEngine:
                 last = i == len(self.blk) - 1
                 pk = self.tail_pack[i]
                 dh1 = drop(hd, 11 + 4 * i)
-                check(lib.edgl_tail_fwd(_ptr(b["att"]), x.data_ptr(), cin, _ptr(pk), _ptr(blk.att_out.bias), _ptr(blk.inter.bias),
+                check(lib.edgl_tail_fwd_ct(_ptr(b["att"]), x.data_ptr(), cin, _ptr(pk), _ptr(blk.att_out.bias), _ptr(blk.inter.bias),
                                         _ptr(blk.out.bias), _ptr(m.transform.bias), _ptr(blk.att_ln.gamma), _ptr(blk.att_ln.beta),
                                         _ptr(blk.out_ln.gamma), _ptr(blk.out_ln.beta), _ptr(m.transform_ln.gamma),
                                         _ptr(m.transform_ln.beta), B, T, C, float(dh1.rate), dh1.ptr(), 11 + 4 * i, 12 + 4 * i,
                                         _ptr(self.mpos), M, int(last), _ptr(b["ao"]), _ptr(b["a1"]), _ptr(b["st1"]), _ptr(b["pre_f"]),
                                         _ptr(b["f"]), _ptr(b["o"]), _ptr(b["y"]), _ptr(b["st2"]), _ptr(self.pre_t), _ptr(self.so),
-                                        _ptr(self.st3), _ptr(self.hrows_c), _ptr(self.inv), code, st), "edgl_tail_fwd")
+                                        _ptr(self.st3), _ptr(self.hrows_c), _ptr(self.inv), self.pad[0], self.pad[1], code, st), "edgl_tail_fwd")
             else:
                 self._dense_fwd(b["att"], blk.att_out.kernel, blk.att_out.bias, b["ao"], C, C)
                 self._ln_fwd(b["ao"], x, cin, blk.att_ln, drop(hd, 11 + 4 * i), b["a1"], b["st1"])
@@ -573,7 +574,7 @@ class TrainEngine:
                 # one launch: LN3' -> GELU' -> dX(Wt) -> LN2' -> dX(Wout) * GELU' -> dX(Wi) -> LN1' -> dX(Wo)  (csrc/k_tail.hip)
                 last = i == len(self.blk) - 1
                 tl = m.transform_ln
-                check(lib.edgl_tail_bwd(x_in.data_ptr(), cin, _ptr(b["ao"]), _ptr(b["a1"]), _ptr(b["pre_f"]), _ptr(b["o"]),
+                check(lib.edgl_tail_bwd_ct(x_in.data_ptr(), cin, _ptr(b["ao"]), _ptr(b["a1"]), _ptr(b["pre_f"]), _ptr(b["o"]),
                                         _ptr(self.pre_t), _ptr(self.so), _ptr(b["st1"]), _ptr(b["st2"]), _ptr(self.st3),
                                         _ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
                                         _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)),
@@ -583,7 +584,7 @@ class TrainEngine:
                                         _ptr(self.d_pre_f), _ptr(self.d_ao), _ptr(self.G1), _ptr(self.G2),
                                         _ptr(blk.att_ln.gamma.grad), _ptr(blk.att_ln.beta.grad), _ptr(blk.out_ln.gamma.grad),
                                         _ptr(blk.out_ln.beta.grad), _ptr(tl.gamma.grad), _ptr(tl.beta.grad),
-                                        _ptr(self._ws(lib.edgl_tail_bwd_workspace(B, C))), code, st), "edgl_tail_bwd")
+                                        _ptr(self._ws(lib.edgl_tail_bwd_workspace(B, C))), self.pad[0], self.pad[1], code, st), "edgl_tail_bwd")
                 if self._pending_label is not None and os.environ.get("EDGL_LABEL_EARLY", "2") == "2":   # beside the BiMAU sweeps
                     self.side.wait_stream(torch.cuda.current_stream())
                     self._pending_label(self.side.cuda_stream)

@@ -298,7 +298,7 @@ class EasyDGL(Sequential):
     def _eval_tail_ok(self, is_training, x, gather_pos) -> bool:
         import os
         from .. import _lib
-        if is_training or torch.is_grad_enabled() or not self.layers or self.pad[0] or x.dtype != torch.bfloat16:
+        if is_training or torch.is_grad_enabled() or not self.layers or x.dtype != torch.bfloat16:
             return False
         if os.environ.get("EDGL_EVAL_FUSED_TAIL", "1") == "0" or gather_pos.shape[1] > 256:
             return False
@@ -328,12 +328,12 @@ class EasyDGL(Sequential):
         y = torch.empty((B, T, C), device=dev, dtype=dt)
         rows = torch.empty((B * Mg, C), device=dev, dtype=dt) if last else None
         tl = self.transform_ln
-        _lib.check(lib.edgl_tail_fwd(P(att), layer_in.data_ptr(), layer_in.shape[2], P(ws["pack"]), P(blk.att_out.bias),
+        _lib.check(lib.edgl_tail_fwd_ct(P(att), layer_in.data_ptr(), layer_in.shape[2], P(ws["pack"]), P(blk.att_out.bias),
                                      P(blk.inter.bias), P(blk.out.bias), P(self.transform.bias), P(blk.att_ln.gamma),
                                      P(blk.att_ln.beta), P(blk.out_ln.gamma), P(blk.out_ln.beta), P(tl.gamma), P(tl.beta), B, T, C,
                                      0.0, None, 0, 0, P(gather_pos), Mg, int(last), P(ws["ao"]), P(ws["a1"]), P(ws["st1"]),
                                      P(ws["pre_f"]), P(ws["f"]), P(ws["o"]), P(y), P(ws["st2"]), P(ws["pre_t"]), P(ws["so"]),
-                                     P(ws["st3"]), P(rows), None, _lib.BF16, st), "edgl_tail_fwd")
+                                     P(ws["st3"]), P(rows), None, self.pad[0], self.pad[1], _lib.BF16, st), "edgl_tail_fwd")
         return y, rows
 
     def _gather_pos(self, features, is_training):

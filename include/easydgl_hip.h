@@ -713,6 +713,16 @@ int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const void* pack, 
                   const uint64_t* rng_state, uint32_t sid1, uint32_t sid2, const int64_t* masked_pos, int M, int head,
                   void* ao, void* a1, float* st1, void* pre_f, void* f, void* o, void* y, float* st2, void* pre_t,
                   void* so, float* st3, void* hrows, const int32_t* hrow_map, int dtype, void* stream);
+/* The same for a channel-padded model (head dim dh_true stored as dh_pad, a power of two; padded channels of every operand exactly
+ * zero: model/easydgl.py): the three LayerNorms take their joint (T, C) moments over the REAL channels — divisor T * C_true, padded
+ * entries left out of the centred second moment — as edgl_add_layernorm_fwd_ct does.  0, 0 = edgl_tail_fwd. */
+int edgl_tail_fwd_ct(const void* att, const void* xin, int ld_x, const void* pack, const float* bo, const float* bi,
+                     const float* bout, const float* bt, const float* g1, const float* b1, const float* g2,
+                     const float* b2, const float* g3, const float* b3, int B, int T, int C, float drop_rate,
+                     const uint64_t* rng_state, uint32_t sid1, uint32_t sid2, const int64_t* masked_pos, int M, int head,
+                     void* ao, void* a1, float* st1, void* pre_f, void* f, void* o, void* y, float* st2, void* pre_t,
+                     void* so, float* st3, void* hrows, const int32_t* hrow_map, int dh_pad, int dh_true, int dtype,
+                     void* stream);
 
 /* Backward of the same chain, one launch per block: given the gradient of the gathered head rows (head != 0: d_rows [*, C]
  * compact, masked_pos [B, M], dy_rowmap = the `inv` map of edgl_compact_rows or NULL) or of y (head == 0: d_y_in [B,T,C]),
@@ -731,6 +741,16 @@ int edgl_tail_bwd(const void* xin, int ld_x, const void* ao, const void* a1, con
                   const int32_t* dy_rowmap, const void* d_y_in, void* d_pre_t, void* d_o, void* d_pre_f, void* d_ao,
                   void* d_res1, void* d_att, float* dg1, float* db1, float* dg2, float* db2, float* dg3, float* db3,
                   float* workspace, int dtype, void* stream);
+/* ... of a channel-padded model: the LayerNorm backward divides by T * C_true and returns nothing into a padded channel
+ * (edgl_add_layernorm_bwd_act_ct's rule), so every gradient tensor keeps exact zeros there. */
+int edgl_tail_bwd_ct(const void* xin, int ld_x, const void* ao, const void* a1, const void* pre_f, const void* o,
+                     const void* pre_t, const void* so, const float* st1, const float* st2, const float* st3,
+                     const void* Wo, const void* Wi, const void* Wout, const void* Wt, const float* g1, const float* g2,
+                     const float* g3, int B, int T, int C, float drop_rate, const uint64_t* rng_state, uint32_t sid1,
+                     uint32_t sid2, int head, const void* d_rows, const int64_t* masked_pos, int M,
+                     const int32_t* dy_rowmap, const void* d_y_in, void* d_pre_t, void* d_o, void* d_pre_f, void* d_ao,
+                     void* d_res1, void* d_att, float* dg1, float* db1, float* dg2, float* db2, float* dg3, float* db3,
+                     float* workspace, int dh_pad, int dh_true, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -84,7 +84,7 @@ def test_engine_at_the_reference_default_width(mode):
     m = build_model(prob, mode)
     assert m.pad == (64, 50)
     eng = TrainEngine(m, 6, use_graph=False)
-    assert not eng.fused_tail
+    assert eng.fused_tail == (mode == "bf16")      # (bf16: the fused block tail in its channel-padded form, edgl_tail_fwd_ct / _bwd_ct)
     eng.load_batch(to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda())
     m._grad_arena.fill_(float("nan"))
     eng._issue()
@@ -177,14 +177,17 @@ def test_engine_with_dropout_matches_autograd_path_bf16(num_events):
         assert rel_err(p2.grad.float().cpu().numpy(), g1) < 3e-2, n1
 
 
-@pytest.mark.parametrize("case,drop", [(1, 0.0), (2, 0.0), (2, 0.1)])
+PADDED_CASE = dict(num_units=50, num_heads=1, num_blocks=2, seqslen=30, masklen=6, num_events=5, num_items=200)   # head dim 50 stored as 64
+
+
+@pytest.mark.parametrize("case,drop", [(1, 0.0), (2, 0.0), (2, 0.1), ("padded", 0.0), ("padded", 0.1)])
 def test_fused_block_tail_matches_the_unfused_kernels(case, drop):
     """csrc/k_tail.hip (dense -> LN -> GELU-dense -> dense -> LN -> head in one launch per block) against the seven
     launches it replaces, on the same weights, batch and dropout stream: every saved tensor, the gathered head rows, the
     loss and the gradients.  bf16 only (C = 64 and the headline C = 128, T = 101); equal up to the last bf16 digit of the
     dense outputs (the two paths feed the MFMA its K slots in a different order)."""
     from easydgl_amd.engine import TrainEngine
-    prob = make_problem(seed=60 + case, batch=6, **CASES[case])
+    prob = make_problem(seed=67, batch=6, **PADDED_CASE) if case == "padded" else make_problem(seed=60 + case, batch=6, **CASES[case])
     feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
     out = {}
     for fused in (False, True):
@@ -211,6 +214,19 @@ def test_fused_block_tail_matches_the_unfused_kernels(case, drop):
             assert float(((a[k] - b[k]).abs() > 1e-6 * a[k].abs().max()).float().mean()) < 0.05, k
     assert abs(a["loss"] - b["loss"]) <= 2e-3 * abs(a["loss"])
     assert rel_err(b["grads"].cpu().numpy(), a["grads"].cpu().numpy()) < 2e-2
+    if case == "padded":      # the channel-padded forms: every padded channel of every saved tensor and gradient is exactly zero
+        padc = torch.arange(64, device="cuda") >= 50
+        for k in ("ao", "a1", "f", "o", "y", "so", "hrows"):
+            t = b[k]
+            cols = padc if t.shape[-1] == 64 else torch.zeros(t.shape[-1], dtype=torch.bool, device="cuda")
+            assert float(t[..., cols].abs().max() if cols.any() else 0.0) == 0.0, k
+        for name, (prm, maps, _) in m._pad_specs().items():      # gradients: nothing on a padded entry (the intensity MLP's output
+            if name.endswith("sequential_temporal_combined/weight"):   # weights of padded hidden units are the one masked exception)
+                continue
+            g = prm.grad.detach().clone()
+            idx = [torch.arange(g.shape[ax]) if mp is None else mp for ax, mp in enumerate(maps)]
+            g[torch.meshgrid(*[i.to(g.device) for i in idx], indexing="ij")] = 0
+            assert float(g.abs().max()) == 0.0, name
 
 
 def test_step_with_the_loss_left_on_the_side_stream_gives_the_same_trajectory():
