@@ -886,7 +886,8 @@ class TrainEngine:
                 self._global_counts()      # (the capture below reads the counts of the current batch)
             # (the warm-up's optimizer left the counters of the next step in place: the captured sequence starts without the
             #  single-thread update and — with its own optimizer — ends with it)
-            assert getattr(self.m, "_state_ahead", False)
+            # (the A/B switch EDGL_ENGINE_LEGACY_FORK=1 has no look-ahead: its _issue() carries the update itself)
+            assert getattr(self.m, "_state_ahead", False) or os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") == "1"
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._issue()
