@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("EDGL_LIB_PATH") or os.path.join(_HERE, "libeasydgl_hi
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_GELU, EPI_SAVE_PRE, EPI_MUL_DGELU, EPI_ACCUM, EPI_OUT_F32, EPI_RELU = 1, 2, 4, 8, 16, 32, 64
 MAU_CAUSAL, MAU_NO_DIAG, MAU_DIAG_ZERO = 1, 2, 4
+MAU_NO_SKIP = 8      # host-side hint (include/easydgl_hip.h): the unskipped BiMAU kernels
 TATTN_CAUSAL = 1
 
 P, I, F, L, U32, I64 = c_void_p, c_int, c_float, c_long, c_uint32, c_int64

@@ -61,6 +61,7 @@ struct BwdP {
     float* dz_ws; float* dh_ws; float* rowdot_ws; float* dsc_part; float* wpart;
     int waves;
     int flags;   // MAU_CAUSAL | MAU_NO_DIAG | MAU_DIAG_ZERO
+    int noskip;  // EDGL_MAU_NO_SKIP (host side: the unskipped kernels)
     const uint32_t* dbits;   // optional: keep bits of the attention dropout (edgl_bimau_dropbits, bimau_common.h)
     float qk_scale;          // score scale (0: 1 / sqrt(dh)); a zero-padded head of true width d < dh passes 1 / sqrt(d)
     // optional (edgl_tpp_prep, bimau_common.h): sweep 1 recomputes the TPP regulariser's d lambda from the slot data instead of

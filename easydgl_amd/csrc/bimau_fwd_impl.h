@@ -35,6 +35,7 @@ struct FwdP {
     const uint32_t* dbits;   // optional: keep bits of the attention dropout (edgl_bimau_dropbits, bimau_common.h)
     float qk_scale;          // score scale (0: 1 / sqrt(dh), temporal.py:422); a zero-padded head of true width d < dh passes 1 / sqrt(d)
     const int32_t* order;    // optional [B]: the samples in launch order (edgl_bimau_job_order); NULL: 0 .. B-1
+    int noskip;              // EDGL_MAU_NO_SKIP: launch the kernels that walk every key tile (the caller knows there is nothing to skip)
 };
 
 // wave-private LDS bytes of a phase (K always; T_ unless values phase; V and marks unless scores phase; the f32 key mask)
@@ -410,7 +411,7 @@ int launch_fwd_e(FwdP p, hipStream_t st) {
     // The same family leaves out the all-padding key tiles in front of a sequence's first real key (SK; EDGL_BIMAU_SKIP=0: the
     // unskipped kernels — the A/B switch and the reference of the bit-equality test)
     if constexpr (sizeof(T) == 2 && DT == 1 && EC == 16 && PHASE == 0 && NT <= 8) {
-        const bool sk = NT >= 2 && bimau_skip_enabled();
+        const bool sk = NT >= 2 && bimau_skip_enabled() && !p.noskip;
         if (p.dbits && p.rate > 0.f) kern = sk ? bimau_fwd_kernel<T, DT, NT, EC, PHASE, true, (NT >= 2)> : bimau_fwd_kernel<T, DT, NT, EC, PHASE, true>;
         else if (sk) kern = bimau_fwd_kernel<T, DT, NT, EC, PHASE, false, (NT >= 2)>;
     }

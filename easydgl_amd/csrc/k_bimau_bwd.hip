@@ -401,7 +401,7 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
             if constexpr (NT <= 8) {   // stored keep bits of the attention dropout (edgl_bimau_dropbits): the headline family
                 // ... which also leaves out the all-padding key tiles in front of the first real key (SK, bimau_common.h)
                 constexpr bool SKC = NT >= 2;
-                const bool sk = SKC && p.flags == 0 && p.E == 16 && bimau_skip_enabled();
+                const bool sk = SKC && p.flags == 0 && p.E == 16 && bimau_skip_enabled() && !p.noskip;
                 const bool db = p.dbits && p.rate > 0.f;
                 if (p.flags == 0 && p.E == 16 && db) kern = sk ? bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, true, false, SKC> : bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, true>;
                 else if (sk) kern = bimau_bwd_sweep1_kernel<T, DT, NT, 16, true, 0, false, false, SKC>;
@@ -445,7 +445,7 @@ int launch_bwd(BwdP p, char* ws, float* dW1, float* db1, float* dw, float* dscal
             if (p.flags == 0) kern = p.E == 16 ? bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0> : bimau_bwd_sweep2_kernel<T, DT, NT, 0, KY_NY, true, 0>;
             if constexpr (NT <= 8) {
                 constexpr bool SKC = NT >= 2;
-                const bool sk = SKC && p.flags == 0 && p.E == 16 && bimau_skip_enabled();
+                const bool sk = SKC && p.flags == 0 && p.E == 16 && bimau_skip_enabled() && !p.noskip;
                 if (p.flags == 0 && p.E == 16 && p.dbits && p.rate > 0.f) kern = sk ? bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0, true, 1, 0, SKC> : bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0, true>;
                 else if (sk) kern = bimau_bwd_sweep2_kernel<T, DT, NT, 16, KY_NY, true, 0, false, 1, 0, SKC>;
             }
@@ -549,6 +549,7 @@ static int bimau_bwd_impl(const void* qkvt, const int64_t* ids, const float* spa
     p.hin = (const char*)saved + sl.off_hin;
     p.z = reinterpret_cast<const float*>((const char*)saved + sl.off_z);
     p.B = B; p.T = T; p.C = C; p.H = H; p.E = E; p.rate = drop_rate; p.rng = rng_state;
+    p.noskip = (flags & EDGL_MAU_NO_SKIP) ? 1 : 0; flags &= ~EDGL_MAU_NO_SKIP;
     p.stream_id = stream_id; p.d_qkvt = d_qkvt; p.flags = flags; p.dbits = dropbits; p.qk_scale = qk_scale;
     p.tpp_desc = tpp_desc; p.tpp_M = tpp_M; p.tpp_sums = tpp_sums; p.tpp_coef = tpp_coef; p.tpp_part = tpp_part; p.order = order;
     EDGL_REQUIRE(!tpp_desc || (dtype == EDGL_BF16 && C / H == 16 && E == 16 && T <= 128 && flags == 0 && tpp_part && tpp_M > 0 && !d_lam_ext),

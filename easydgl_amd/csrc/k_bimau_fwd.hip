@@ -192,7 +192,8 @@ extern "C" int edgl_bimau_fwd_ord(const void* qkvt, const void* resid, int ld_re
     EDGL_REQUIRE(ld_res % 4 == 0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: ld_res must be a multiple of 4");
     EDGL_REQUIRE((double)B * H * T * T < 4294967296.0, EDGL_ERR_SHAPE, "edgl_bimau_fwd: H*B*T*T must be < 2^32");
     FwdP p{qkvt, resid, ld_res, ids, spans, marks, (const char*)pack, B, T, C, H, E, drop_rate, rng_state, stream_id,
-           out, lam_out, nullptr, nullptr, nullptr, 4, flags, dropbits, qk_scale, order};
+           out, lam_out, nullptr, nullptr, nullptr, 4, flags & ~EDGL_MAU_NO_SKIP, dropbits, qk_scale, order, (flags & EDGL_MAU_NO_SKIP) ? 1 : 0};
+    flags &= ~EDGL_MAU_NO_SKIP;
     hipStream_t st = (hipStream_t)stream;
     if (C / H == 64 || C / H == 128) {   // three-launch form: lambda is written by the intensity kernel — plain memset there
         if (zero_rows && hipMemsetAsync(zero_rows, 0, (size_t)H * B * T * E * sizeof(float), st) != hipSuccess) {

@@ -170,6 +170,9 @@ class TrainEngine:
         # weight-gradient GEMMs beside the kernels that do not need them (bit 0: the block tail's four products under the attention
         # backward; bit 1: the QKVT product beside the dX GEMM / embedding backward): _issue_backward
         self.dw_overlap = int(os.environ.get("EDGL_DW_OVERLAP", "0"))
+        # training batches of the reference's masker leave no key tile of pure padding (MASK tokens sit on padded positions: rule 50),
+        # so the engine launches the BiMAU kernels that walk every tile (identical results; EDGL_ENGINE_SKIP=1: the skipping ones)
+        self.mau_flags = 0 if os.environ.get("EDGL_ENGINE_SKIP", "0") == "1" else _lib.MAU_NO_SKIP
         self._dw_forked = False
         self.sync_loss = True      # step(): order the returned loss on the caller's stream (a cross-stream wait behind the optimizer)
         # sync_loss False, the loss launches reading nothing of the batch (ce_part): they are not launched at the end of the backward
@@ -421,7 +424,7 @@ class TrainEngine:
                                              _ptr(b["pack"]), B, T, C, H, E, float(da.rate), da.ptr(), da.stream_id, _ptr(b["dbits"]),
                                              self.qk_scale, _ptr(b["att"]), _ptr(b["lam"]), _ptr(b["saved"]),
                                              _ptr(b["dlam"]) if (m.ct_reg != 0.0 and not self.fused_tpp) else None, _ptr(self.job_order),
-                                             0, code, st), "edgl_bimau_fwd_ord")
+                                             self.mau_flags, code, st), "edgl_bimau_fwd_ord")
             if m.ct_reg != 0.0 and not self.fused_tpp:   # TPP regulariser of this block: loss term and d lambda (two small launches)
                 check(lib.edgl_tpp_fwd_bwd_rows(_ptr(b["lam"]), _ptr(self.mpos), _ptr(self.labels), _ptr(self.ts),
                                                 _ptr(m.mark_lookup_table), B, T, H, E, M, float(m.ct_reg / H), _ptr(b["tpp"]),
@@ -633,7 +636,7 @@ class TrainEngine:
                                              _ptr(att.st_kernel.grad), _ptr(att.st_bias.grad), _ptr(att.weight.grad),
                                              _ptr(att.scaling.grad),
                                              _ptr(self._ws(lib.edgl_bimau_bwd_workspace(B, T, C, H, E, code), torch.uint8)),
-                                             _ptr(self.job_order), 0, code, st), "edgl_bimau_bwd_ord")
+                                             _ptr(self.job_order), self.mau_flags, code, st), "edgl_bimau_bwd_ord")
             self._dense_dw(x_in, self.G4c, att.dense_kernel, att.dense_bias, cin, 4 * C)
             if self.fused_tail:
                 if self.dw_overlap & 2:

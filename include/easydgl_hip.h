@@ -207,6 +207,11 @@ int edgl_colsum(const void* X, int M, int N, int ld, float* out, int accumulate,
 #define EDGL_MAU_CAUSAL 1
 #define EDGL_MAU_NO_DIAG 2
 #define EDGL_MAU_DIAG_ZERO 4
+/* host-side hint, not a semantic flag: launch the kernels that walk every key tile.  The bf16 / head dim 16 / 16 marks family
+ * otherwise leaves out the all-padding key tiles in front of a sequence's first real key (exact); a caller whose batches cannot
+ * have any — training batches of the reference's masker carry MASK tokens on padded positions, dataloader.py:187-191 — saves the
+ * skip variant's per-tile scalar branch.  Results are identical either way. */
+#define EDGL_MAU_NO_SKIP 8
 long edgl_bimau_pack_bytes(int C, int H, int E, int dtype);
 long edgl_bimau_saved_bytes(int B, int T, int C, int H, int dtype);
 /* largest mark count (<= 16) one launch takes at this head dim / dtype (LDS of the intensity backward); -1: bad arguments */
