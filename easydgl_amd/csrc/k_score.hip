@@ -32,7 +32,8 @@ bool edgl_strip_enabled();
 int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, int R, int I, int i0, int i1, const int32_t* nvalid,
                     float* slabs, float* part, int G, int slab16, hipStream_t st);
 int edgl_strip_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
-                     int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, hipStream_t st);
+                     int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, float* acc_table,
+                     float* acc_bias, hipStream_t st);
 int edgl_strip_label_scatter(const void* rows, const int64_t* labels, const float* coef, const int32_t* nvalid, int R, int i0, int i1,
                              const float* gscale, float* d_table, float* d_bias, hipStream_t st);
 
@@ -115,6 +116,7 @@ struct ScoreP {
     int table_ready;                                    // tableT already written by edgl_score_prepare_table
     const int32_t* wtotal;                              // data parallel: weighted rows of the GLOBAL batch (denominator of the loss)
     bool defer_label;                                   // strip path: the caller applies the one-hot term (edgl_score_flash_label_term)
+    bool acc_atomic;                                    // strip path: d_table / d_bias are zero-filled and take the chunks as f32 atomics
     float* ce_part;                                     // one-launch row finish: per-workgroup sums of -log(p_label + 1e-5) (edgl_score_ce_nparts)
 };
 
@@ -1759,9 +1761,14 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
         ScoreP q = p;
         q.zchunk = plan.w.zchunk; q.nchunk = plan.w.nchunk; q.slabs = ws + plan.off_slabW; q.bias_slabs = ws + plan.off_slabB;
         if (strip) {
+            const bool acc = p.acc_atomic && !p.gscale;
             const int rc = edgl_strip_table(p.rows, p.table, p.out_bias, p.coef, p.row_lse, p.R, p.I, p.i0, p.i1, p.nvalid, q.slabs,
-                                            q.bias_slabs, q.nchunk, st);
+                                            q.bias_slabs, q.nchunk, acc ? d_table : nullptr, acc ? d_bias : nullptr, st);
             if (rc) return rc;
+            if (acc) {      // no slabs, no slab reduction
+                if (!p.defer_label) return edgl_strip_label_scatter(p.rows, p.labels, p.coef, p.nvalid, p.R, p.i0, p.i1, p.gscale, d_table, d_bias, st);
+                return EDGL_OK;
+            }
         } else if (nw == 8) {
             auto k = score_bwd_kernel<T, CT, ROLE_W, 8, CO>;
             hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_nw);
@@ -2138,7 +2145,8 @@ extern "C" int edgl_score_flash_bwd_ex(const void* rows, const void* table, cons
     ScoreP p{};
     p.rows = rows; p.table = table; p.out_bias = out_bias; p.labels = labels; p.R = R; p.C = C; p.I = I; p.i0 = i0;
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
-    p.defer_label = defer_label_term != 0;
+    p.defer_label = (defer_label_term & 1) != 0;
+    p.acc_atomic = (defer_label_term & 2) != 0;      // (bf16, C = 128 strip path only; elsewhere the slabs)
     const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 2>(p, C, plan, workspace, d_rows, d_table, d_bias, st)

@@ -53,6 +53,7 @@ struct StripP {
     const int32_t* nvalid;
     const float* coef; const float* row_lse;     // ROLE_W
     float* slabs; float* bias_slabs; float* part;
+    float* acc_table; float* acc_bias;           // ROLE_W, optional: the outputs go into these zero-initialised arrays as f32 atomics (no slabs)
     int slab16;                                  // ROLE_YF: the row slabs are written as bf16 (the one-launch row finish reads them so)
     unsigned long long* stamps;     // -DSTRIP_TIMING builds only: [workgroup][8] shader-clock stamps of wave 0
 };
@@ -574,6 +575,26 @@ __device__ __forceinline__ void epilogue(const StripP& p, const Geo& g, char* sm
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     float* slab = p.slabs + (long)g.by * g.slab_stride;
+    if (!YS && p.acc_table) {
+        // d_table without slabs: the row chunks of an item block add up in the gradient itself (edgl_score_flash_bwd_ex, bit 1 of
+        // defer_label_term: the caller zero-filled d_table / d_bias; 3 chunks at the headline shape)
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            const int xr = 2 * i + g.hi, gx = g.xbase + xr;
+            const float4 v = *reinterpret_cast<const float4*>(stg_o + xr * OSTR + 4 * g.l31);
+            if (gx < g.xend) {
+                float* d = p.acc_table + (long)gx * C + 4 * g.l31;
+                atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+            }
+        }
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            const float sb = lsum[xt] + __shfl_xor(lsum[xt], 32, 64);
+            const int gx = g.xbase + 32 * xt + g.l31;
+            if (g.hi == 0 && gx < g.xend && gx > 0) atomicAdd(p.acc_bias + gx - 1, sb);
+        }
+        return;
+    }
     if (YS && p.slab16) {
         // bf16 slabs: half of the 33 MB burst that all workgroups write at once, and half of the row finish's read-back; the finish
         // rounds d_rows to bf16 anyway (one more rounding of each chunk's partial: 2^-9 relative before the weighted sum)
@@ -804,8 +825,10 @@ int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, 
 }
 
 int edgl_strip_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
-                     int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, hipStream_t st) {
+                     int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, float* acc_table,
+                     float* acc_bias, hipStream_t st) {
     strip::StripP p{};
+    p.acc_table = acc_table; p.acc_bias = acc_bias;
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
     p.nvalid = nvalid; p.coef = coef; p.row_lse = row_lse; p.slabs = slabs; p.bias_slabs = bias_slabs; p.stamps = g_strip_stamps;
     auto k = strip::strip_kernel<strip::ROLE_W>;

@@ -172,6 +172,10 @@ class TrainEngine:
         self.dw_overlap = int(os.environ.get("EDGL_DW_OVERLAP", "0"))
         # training batches of the reference's masker leave no key tile of pure padding (MASK tokens sit on padded positions: rule 50),
         # so the engine launches the BiMAU kernels that walk every tile (identical results; EDGL_ENGINE_SKIP=1: the skipping ones)
+        # A/B switch: the table-gradient pass adds its row chunks into the zero-filled gradient with f32 atomics (no slabs, no
+        # slab_reduce launch between the scoring and the block-tail backward)
+        self.score_atomic = (os.environ.get("EDGL_SCORE_ATOMIC", "0") == "1" and self.code == _lib.BF16 and self.C == 128
+                             and os.environ.get("EDGL_SCORE_STRIP", "1") != "0" and bool(self.blk))
         self.mau_flags = 0 if os.environ.get("EDGL_ENGINE_SKIP", "0") == "1" else _lib.MAU_NO_SKIP
         self._dw_forked = False
         self.sync_loss = True      # step(): order the returned loss on the caller's stream (a cross-stream wait behind the optimizer)
@@ -355,6 +359,9 @@ class TrainEngine:
                     check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
                                              _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
                                              _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
+            if self.score_atomic:            # (behind the previous step's optimizer: this stream waited for the main stream above)
+                tab.grad.zero_()
+                m.output_bias.grad.zero_()
             if self.job_order is not None:   # ids only: under the encoder, in front of everything the first attention kernel waits for
                 check(lib.edgl_bimau_job_order(_ptr(self.ids), B, T, _ptr(self.job_order), sst), "edgl_bimau_job_order")
             for i, (blk, b) in enumerate(zip(m.layers, self.blk)):
@@ -530,15 +537,17 @@ class TrainEngine:
             # d_rows: written by the forward call.  The one-hot term of the table / bias gradient (a scatter of the weighted rows:
             # f32 atomics that commute with the embedding scatter's) is deferred to the side stream at the end of the backward
             defer = 1 if self.blk else 0
+            if self.score_atomic:
+                defer |= 2      # d_table / d_bias zero-filled under the encoder (below): the row chunks add up in them, no slab reduction
             check(lib.edgl_score_flash_bwd_ex(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
                                               _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), None,
                                               _ptr(tab.grad), _ptr(m.output_bias.grad), _ptr(self.ws_flash), defer, code, st),
                   "edgl_score_flash_bwd")
             # the one-hot term as extra blocks of the embedding scatter's launch at the end of the backward (no launch, no fork)
-            self._label_fused = bool(defer and self.code == _lib.BF16 and C == 128 and lib.edgl_encode_bwd_label_fused(C, code)
+            self._label_fused = bool((defer & 1) and self.code == _lib.BF16 and C == 128 and lib.edgl_encode_bwd_label_fused(C, code)
                                      and os.environ.get("EDGL_LABEL_FUSED", "1") != "0"
                                      and os.environ.get("EDGL_SCORE_STRIP", "1") != "0")    # (only the strip passes leave the term out)
-            if defer and not self._label_fused:
+            if (defer & 1) and not self._label_fused:
                 self._pending_label = lambda s: check(lib.edgl_score_flash_label_term(
                     _ptr(self.hrows_c), _ptr(lab), _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(tab.grad),
                     _ptr(m.output_bias.grad), code, s), "edgl_score_flash_label_term")
