@@ -32,8 +32,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace evk {
 
-constexpr int QB = 64, GPS = 16;               // query rows per workgroup, groups per (row, slice)
-constexpr int RCAP = 1024, RSTR = 24;          // pass 2: a workgroup's LDS list of RUNS — 4 logits of consecutive items | hit mask + row | first item
+constexpr int GPS = 16;                        // groups per (row, slice)
+// query rows per workgroup: 64; 128 at C = 256, where the table no longer fits an L2 at the catalogues this width is used with and
+// every query block reads every slice again (1 M items x 512 B: the sweeps ran on the L2 -> LDS traffic of 8 query blocks)
+__host__ __device__ constexpr int qb_of(int C) { return C == 256 ? 128 : 64; }
+constexpr int RSTR = 24;          // pass 2: a workgroup's LDS list of RUNS — 4 logits of consecutive items | hit mask + row | first item
 constexpr int OVERFLOW = 0x40000000;           // added to a row's count when a list dropped entries
 
 struct P {
@@ -46,15 +49,17 @@ struct P {
     float* out_val; int32_t* out_idx;
 };
 
-// NWS: waves across the items of a tile (the workgroup is 2 x NWS waves: 32 query rows x NZ / NWS items each).  Four at C <= 128 —
+// NWS: waves across the items of a tile (the workgroup is QB / 32 x NWS waves: 32 query rows x NZ / NWS items each).  Four at C <= 128 —
 // two waves per SIMD: the sweep's MFMA chains and the second sweep's hit bookkeeping are one dependent stream per wave, and a lone
 // wave per SIMD has nothing to put into the other's shadow.
 template <int C, int NZ, int NWS>
 struct Geo {
-    static constexpr int NTHR = 128 * NWS;
+    static constexpr int QB = qb_of(C);
+    static constexpr int NTHR = 64 * (QB / 32) * NWS;
+    static constexpr int RCAP = QB == 64 ? 1024 : 1536;       // runs a workgroup's list holds (more of them: every row goes the exact way)
     static constexpr int LDZ = C + 8;                          // bf16 elements per LDS row (16-byte shift per row: conflict-free 16-byte fragment reads)
-    static constexpr int XB = QB * LDZ * 2, ZB = NZ * LDZ * 2;
-    static constexpr int OFF_Z = XB, OFF_BIAS = XB + 2 * ZB, OFF_LIST = OFF_BIAS + 2 * NZ * 4;
+    static constexpr int ZB = NZ * LDZ * 2;
+    static constexpr int OFF_Z = 0, OFF_BIAS = 2 * ZB, OFF_LIST = OFF_BIAS + 2 * NZ * 4;
     static constexpr int LISTB = RCAP * RSTR, DUMB = NTHR * RSTR;   // the run list; one dump slot per thread (stores without a branch)
     static constexpr int OFF_DUM = OFF_LIST + LISTB;
     static constexpr int OFF_CNT = OFF_DUM + DUMB;             // list length, then per-row counts [QB] and global bases [QB]
@@ -62,7 +67,7 @@ struct Geo {
     static constexpr int BYTES_GMAX = OFF_BIAS + 2 * NZ * 4;
     static constexpr int bytes_emit(int slice_items) { return OFF_BMP + QB * ((slice_items + 31) / 32) * 4; }
     static constexpr int PIECES = NZ * C / 8 / NTHR;           // 16-byte pieces of an item tile per thread
-    static_assert(NZ * C / 8 % NTHR == 0 && NZ % (32 * NWS) == 0 && 8 % NWS == 0, "tile geometry");
+    static_assert(NZ * C / 8 % NTHR == 0 && NZ % (32 * NWS) == 0 && 8 % NWS == 0 && PIECES >= 1, "tile geometry");
 };
 
 // one item tile: global -> registers (rows clamped into the table; item 0 is the zero-padded row: coding.py:56-57)
@@ -95,12 +100,12 @@ __device__ __forceinline__ void tile_store(const P& p, int item0, uint4 (&r)[Geo
 
 // EMIT = false: pass 1 (group maxima);  true: pass 2 (candidates)
 template <int C, int NZ, int NWS, bool EMIT>
-__global__ __launch_bounds__(128 * NWS) void eval_sweep_kernel(P p) {
+__global__ __launch_bounds__(64 * (qb_of(C) / 32) * NWS) void eval_sweep_kernel(P p) {
     using G_ = Geo<C, NZ, NWS>;
     constexpr int CK = C / 16, NTW = NZ / (32 * NWS), LDZB = G_::LDZ * 2, NTHR = G_::NTHR;
     constexpr int JG = 8 / NWS;       // group maxima per lane (GPS = 16 groups per slice = NWS waves x 2 lane halves x JG)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* xs = smem;
+    constexpr int QB = G_::QB, RCAP = G_::RCAP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = wave / NWS, sw = wave % NWS, l32 = lane & 31, hi = lane >> 5;
     // XCD-aware order (speed only; observed placement: workgroup id b runs on XCD b % 8): the query blocks of ONE item slice are
     // consecutive workgroups of ONE XCD, so that they run side by side and the slice's table rows come out of that XCD's L2 for all
@@ -112,10 +117,12 @@ __global__ __launch_bounds__(128 * NWS) void eval_sweep_kernel(P p) {
     if (slice >= p.nslices) return;
     const int q0 = (jx % nqb) * QB;
     int* lcount = reinterpret_cast<int*>(smem + G_::OFF_CNT);
-    // ---- the 64 query rows: LDS image, then this wave's 32 rows as B fragments in registers ---------------------------------
-    for (int pc = tid; pc < QB * (C / 8); pc += NTHR) {
-        const int row = pc / (C / 8), c8 = pc % (C / 8);
-        *reinterpret_cast<uint4*>(xs + row * LDZB + c8 * 16) = *reinterpret_cast<const uint4*>(p.rows + (long)min(q0 + row, p.R - 1) * C + c8 * 8);
+    // ---- this wave's 32 query rows as B fragments, straight from global memory (once per workgroup: no LDS image) -------------------
+    bf16x8 xf[CK];
+    {
+        const bf16* xrow = p.rows + (long)min(q0 + 32 * h + l32, p.R - 1) * C + hi * 8;
+#pragma unroll
+        for (int k = 0; k < CK; ++k) xf[k] = *reinterpret_cast<const bf16x8*>(xrow + k * 16);
     }
     int* rowcnt = lcount + 4;                     // [QB] survivors per row, then [QB] the rows' bases in their global lists
     uint32_t* bmp = reinterpret_cast<uint32_t*>(smem + G_::OFF_BMP);
@@ -168,9 +175,6 @@ __global__ __launch_bounds__(128 * NWS) void eval_sweep_kernel(P p) {
         if ((nid & 1) && tid == 0) mark(nid - 1, sbase[nid - 1]);
         __syncthreads();
     }
-    bf16x8 xf[CK];
-#pragma unroll
-    for (int k = 0; k < CK; ++k) xf[k] = *reinterpret_cast<const bf16x8*>(xs + (32 * h + l32) * LDZB + k * 32 + hi * 16);
     const int q = q0 + 32 * h + l32;             // this lane's query row
     float gm[JG];
 #pragma unroll
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(128 * NWS) void eval_sweep_kernel(P p) {
                 const int r = i & 3;
                 const int2 meta = *reinterpret_cast<const int2*>(e + 16);
                 if (!((meta.x >> r) & 1)) continue;
-                const int row = (meta.x >> 8) & 63, item = meta.y + r, o = item - item_lo;
+                const int row = (meta.x >> 8) & (QB - 1), item = meta.y + r, o = item - item_lo;
                 if ((bmp[row * bw + (o >> 5)] >> (o & 31)) & 1u) continue;     // a seen id of this row (Base.py:156-163)
                 f(row, item, reinterpret_cast<const float*>(e)[r]);
             }
@@ -448,6 +452,7 @@ inline bool make_plan(int R, int C, int n_items, int T, int K, Plan& pl) {
     if (!(C == 64 || C == 128 || C == 256) || K < 1 || K > 128 || R < 1 || T < 0 || n_items < 4096 || n_items > (1 << 30)) return false;
     pl.nz = C == 256 ? 64 : 128;
     const int ntile = (n_items + pl.nz - 1) / pl.nz;
+    const int QB = qb_of(C);
     const int nrb = (R + QB - 1) / QB;
     // fill the chip AND keep the bound selective: three times as many groups as the rank of the bound among them
     int want = std::max(256 / std::max(nrb, 1), (3 * (K + T) + GPS - 1) / GPS);
@@ -483,7 +488,7 @@ template <int C, int NZ, int NWS>
 int launch(P p, const Plan& pl, hipStream_t st) {
     using G_ = Geo<C, NZ, NWS>;
     constexpr int NTHR = G_::NTHR;
-    const dim3 grid(8 * ((p.R + QB - 1) / QB) * ((pl.nslices + 7) / 8));      // (query block, slice) from the id: see eval_sweep_kernel
+    const dim3 grid(8 * ((p.R + G_::QB - 1) / G_::QB) * ((pl.nslices + 7) / 8));      // (query block, slice) from the id: see eval_sweep_kernel
     auto k1 = eval_sweep_kernel<C, NZ, NWS, false>;
     auto k2 = eval_sweep_kernel<C, NZ, NWS, true>;
     const int be = G_::bytes_emit(pl.tps * NZ);
