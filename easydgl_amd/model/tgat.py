@@ -74,7 +74,6 @@ class TGAT(Sequential):
     def _pad_specs(self):
         """(TF name, parameter, axis maps, initialiser) of every variable in _tf_map(), for the channel-padded storage."""
         c = self._cmap()
-        Cp = self.num_units
         specs = []
         for name, (param, sl) in self._tf_map().items():
             leaf = name.rsplit("/", 1)[-1]
@@ -89,7 +88,6 @@ class TGAT(Sequential):
             else:   # bias / beta / gamma / phase
                 maps, kind = (c if sl is None else c + sl.start,), ("ones" if leaf == "gamma" else "zeros")
             specs.append((name, param, maps, kind))
-        assert Cp == self.num_units
         return specs
 
     def l2_param_names(self):
