@@ -1588,7 +1588,15 @@ inline Chunking pick_chunks(int xblocks, int ztotal, int target_blocks, int ZB, 
     return Chunking{nchunk, per * ZB};
 }
 inline int xblocks_of(int n, int xb) { return (n + xb - 1) / xb; }
-inline int score_nw() { static const int nw = getenv("EDGL_SCORE_NW") ? atoi(getenv("EDGL_SCORE_NW")) : 8; return nw == 4 ? 4 : 8; }
+// waves per workgroup of the generic product passes where the shape allows both: 8 (two waves per SIMD, bf16 C >= 256: half the
+// output channels per pass, the logits recomputed per half) or 4 (one wave per SIMD, all channels in one pass).  Measured in the
+// engine step (tools/try_shape.py, round 5): C = 256 — equal at 20 K items, 4 waves - 10 % at 100 K, - 13 % at 300 K / 1 M items
+// (config 3: 53.0 -> 45.4 ms); C = 512 — 8 waves - 5..8 % (recipe 1.94 against 2.03 ms).  EDGL_SCORE_NW overrides.
+inline int score_nw(int C, size_t esize) {
+    static const int env = getenv("EDGL_SCORE_NW") ? atoi(getenv("EDGL_SCORE_NW")) : 0;
+    if (env == 4 || env == 8) return env;
+    return (C == 256 && esize == 2) ? 4 : 8;
+}
 inline int score_ftarget() { static const int t = getenv("EDGL_SCORE_FTARGET") ? atoi(getenv("EDGL_SCORE_FTARGET")) : 256; return t; }
 inline int score_target() { static const int t = getenv("EDGL_SCORE_TARGET") ? atoi(getenv("EDGL_SCORE_TARGET")) : 256; return t; }
 inline long up8(long v) { return (v + 7) / 8 * 8; }
@@ -1607,7 +1615,7 @@ inline bool use_strip(int C, size_t esize) { return esize == 2 && C == 128 && ed
 inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize, bool strip = false) {
     BwdPlan b;
     const RtCfg cf = rt_cfg(C, esize);
-    const int nw = strip ? 8 : (cf.nwb == 8 ? score_nw() : cf.nwb), zb = strip ? 128 : cf.zb;   // strip: pairs of its 64-z tiles
+    const int nw = strip ? 8 : (cf.nwb == 8 ? score_nw(C, esize) : cf.nwb), zb = strip ? 128 : cf.zb;   // strip: pairs of its 64-z tiles
     const int xb = strip ? 256 : 16 * cf.ix * nw;
     b.y = pick_chunks(xblocks_of(R, xb), n_items, score_target(), zb, l2_tiles_for(C, esize, 2, zb));
     {   // every chunk writes an [R, C] f32 slab that a later kernel sums: keep that side traffic bounded (1M-item tables would
@@ -1685,7 +1693,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     constexpr int CO = Cfg::CO;
     const bool strip = MODE != 0 && use_strip(p.C, sizeof(T));     // plan built with the same flag by the callers
     const int ZBK = strip ? 128 : S::ZB;
-    const int nw = Cfg::NWB == 8 ? score_nw() : Cfg::NWB;
+    const int nw = Cfg::NWB == 8 ? score_nw(p.C, sizeof(T)) : Cfg::NWB;
     const size_t smem_nw = nw == 8 ? smem : BUF;
     const int xb = strip ? 256 : 16 * Cfg::IX * nw;
     const int G = strip ? std::max(xblocks_of(p.R, xb) * plan.y.nchunk, score_target()) : xblocks_of(p.R, xb) * plan.y.nchunk;
