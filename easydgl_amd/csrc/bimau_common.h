@@ -502,15 +502,25 @@ __device__ __forceinline__ void all_gather16(const float (&in)[4], float (&out)[
     }
 }
 
+// Bank swizzle of the wave-private ROW-MAJOR images with 32-byte rows (bf16, 16 columns: K / T_ / V at head dim 16 and the marks).
+// The 8-byte fragment reads of the products that contract over the channel (row 16 kt + (l & 15), columns 4 (l >> 4) ..) are served
+// 32 lanes at a time over 64 banks: rows r and r + 8 are 256 bytes apart — the same banks — so every such read was a two-way
+// conflict (PMC round 5: SQ_LDS_BANK_CONFLICT 9-14 % of the backward sweeps' wave cycles).  Rows with bit 3 set keep their two
+// 16-byte halves swapped: column c of row r lives at c ^ (r & 8).  Writers (RowStage / stage_rows / the mark rows), the row
+// fragment reads (g4 ^ (l15 & 8)) and the transpose reads (kfrag<T, true>) all go through this one rule.
+template <typename T, int DT>
+__host__ __device__ constexpr bool img_swz() { return sizeof(T) == 2 && DT == 1; }
+
 // A/B fragment with the CONTRACTION index along the rows of a tile: v[j] = X[k0 + 4G + j][z0 + (l&15)].
+// SW: the image is bank-swizzled (img_swz; k0 a multiple of 16, 16-column rows).
 //   bf16: one ds_read_b64_tr_b16 on the ROW-MAJOR tile rm[k][z] (ld_rm elements per row)
 //   f32 : no 32-bit transpose read exists -> plain read of a separately staged transposed image tr[z][k]
-template <typename T>
+template <typename T, bool SW = false>
 __device__ __forceinline__ Frag4<T> kfrag(const T* rm, int ld_rm, const T* tr, int ld_tr, int k0, int z0, int lane) {
     if constexpr (sizeof(T) == 2) {
         const int G = lane >> 4, s = lane & 15;
         typedef __attribute__((ext_vector_type(4))) short s4;
-        const T* p = rm + (k0 + 4 * G + (s >> 2)) * ld_rm + z0 + 4 * (s & 3);
+        const T* p = rm + (k0 + 4 * G + (s >> 2)) * ld_rm + ((z0 + 4 * (s & 3)) ^ (SW ? ((4 * G + (s >> 2)) & 8) : 0));
         s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
         Frag4<T> f;
         *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<uint2*>(&v);
@@ -545,7 +555,7 @@ __device__ __forceinline__ void stage_rows(const T* src, int ld, int Tlen, T* ro
                 if (k >= Tlen) f[j] = frag_zero<T>();
                 if (rowmajor) {
                     if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(rowmajor + k * dh + u4) = *reinterpret_cast<uint4*>(&f[j]);
-                    else *reinterpret_cast<uint2*>(rowmajor + k * dh + u4) = *reinterpret_cast<uint2*>(&f[j]);
+                    else *reinterpret_cast<uint2*>(rowmajor + k * dh + (img_swz<T, DT>() ? (u4 ^ (k & 8)) : u4)) = *reinterpret_cast<uint2*>(&f[j]);
                 }
                 if (transposed) {
 #pragma unroll
@@ -556,7 +566,7 @@ __device__ __forceinline__ void stage_rows(const T* src, int ld, int Tlen, T* ro
 }
 // marks [T][E] uint8 -> [Tp][16] in the activation dtype: one key row per lane and round, its E bytes loaded together
 // (one 16-byte load when E == 16)
-template <typename T, int NT, int EC>
+template <typename T, int NT, int EC, bool SW = false>
 __device__ __forceinline__ void stage_marks(const uint8_t* marks_row, int E, int Tlen, T* rowmajor, T* transposed, int LDT, int lane) {
     constexpr int Tp = 16 * NT, NR = (Tp + 63) / 64;
 #pragma unroll
@@ -586,7 +596,7 @@ __device__ __forceinline__ void stage_marks(const uint8_t* marks_row, int E, int
             if (rowmajor) {
 #pragma unroll
                 for (int j = 0; j < (int)(16 * sizeof(T) / 16); ++j)
-                    reinterpret_cast<uint4*>(rowmajor + k * EP)[j] = reinterpret_cast<const uint4*>(vals)[j];
+                    reinterpret_cast<uint4*>(rowmajor + k * EP)[SW ? (j ^ ((k >> 3) & 1)) : j] = reinterpret_cast<const uint4*>(vals)[j];
             }
             if (transposed) {
 #pragma unroll
@@ -621,7 +631,7 @@ struct RowStage {
         for (int j = 0; j < NI; ++j) {
             const int c = lane + 64 * j, k = c / cpr, u4 = (c % cpr) * 4;
             if (k >= Tlen) f[j] = frag_zero<T>();
-            if (rowmajor) *reinterpret_cast<uint2*>(rowmajor + k * dh + u4) = *reinterpret_cast<uint2*>(&f[j]);
+            if (rowmajor) *reinterpret_cast<uint2*>(rowmajor + k * dh + (img_swz<T, DT>() ? (u4 ^ (k & 8)) : u4)) = *reinterpret_cast<uint2*>(&f[j]);
             if (transposed) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) transposed[(u4 + r) * LDT + k] = f[j].v[r];
@@ -676,7 +686,7 @@ __device__ __forceinline__ KeyMask<NT> stage_wave(const T* k_src, T* k_rm, T* k_
                     if (m_rm) {
 #pragma unroll
                         for (int j = 0; j < (int)(16 * sizeof(T) / 16); ++j)
-                            reinterpret_cast<uint4*>(m_rm + k * EP)[j] = reinterpret_cast<const uint4*>(vals)[j];
+                            reinterpret_cast<uint4*>(m_rm + k * EP)[img_swz<T, DT>() ? (j ^ ((k >> 3) & 1)) : j] = reinterpret_cast<const uint4*>(vals)[j];
                     }
                     if (m_tr) {
 #pragma unroll
@@ -709,7 +719,7 @@ __device__ __forceinline__ KeyMask<NT> stage_wave(const T* k_src, T* k_rm, T* k_
         stage_rows<T, DT, NT>(k_src, ld, Tlen, k_rm, k_tr, LDT, lane);
         if (t_src) stage_rows<T, DT, NT>(t_src, ld, Tlen, t_rm, t_tr, LDT, lane);
         if (v_src) stage_rows<T, DT, NT>(v_src, ld, Tlen, v_rm, v_tr, LDT, lane);
-        if (marks_row) stage_marks<T, NT, EC>(marks_row, E, Tlen, m_rm, m_tr, LDT, lane);
+        if (marks_row) stage_marks<T, NT, EC, img_swz<T, DT>()>(marks_row, E, Tlen, m_rm, m_tr, LDT, lane);
         return load_keymask<NT>(ids_row, Tlen, lane, lds_madd);
     }
 }

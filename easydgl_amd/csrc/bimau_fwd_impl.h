@@ -111,6 +111,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
     const float cscale = p.qk_scale > 0.f ? p.qk_scale : rsqrtf((float)dh);
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
+    constexpr bool SWZ = img_swz<T, DT>();            // bank-swizzled row-major images (bimau_common.h)
+    const int g4s = SWZ ? (g4 ^ (l15 & 8)) : g4;     // column of this lane's row fragment in them
 
     // per-query-tile global operands (Q rows, interval, residual rows) are fetched one tile ahead: their HBM/L2 latency
     // overlaps the previous tile's compute instead of opening every iteration with a stall
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4), qf[ub], a);
+                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4s), qf[ub], a);
             s[kt] = a;
         }
         // bf16: s := exp(v - max), UNNORMALISED; 1 / sum (`pinv`) rides on the H rows (4 values) and, together with the dropout scale,
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kt = 0; kt < NK; ++kt)
-                    a = mma16(kfrag<T>(Ts, dh, Ts, LDT, (K0 + kt) * 16, ut * 16, lane), pf[kt], a);
+                    a = mma16(kfrag<T, SWZ>(Ts, dh, Ts, LDT, (K0 + kt) * 16, ut * 16, lane), pf[kt], a);
                 if constexpr (TR) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a[r] *= pinv;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
         auto modulate = [&](auto drop_on) {
 #pragma unroll
             for (int kt = 0; kt < NK; ++kt) {
-                f32x4 gacc = mma16(frag_ld<T>(Ms + ((K0 + kt) * 16 + l15) * EP + g4), lf, f32x4{0.f, 0.f, 0.f, 0.f});
+                f32x4 gacc = mma16(frag_ld<T>(Ms + ((K0 + kt) * 16 + l15) * EP + g4s), lf, f32x4{0.f, 0.f, 0.f, 0.f});
                 const bool dtile = set_diag && K0 + kt == qt;   // only this key tile can contain k == q (temporal.py:438-439)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NK; ++kt)
-                a = mma16(kfrag<T>(Vs, dh, Vs, LDT, (K0 + kt) * 16, vt * 16, lane), pf[kt], a);
+                a = mma16(kfrag<T, SWZ>(Vs, dh, Vs, LDT, (K0 + kt) * 16, vt * 16, lane), pf[kt], a);
             const Frag4<T> rf = qcur.rf[vt];
             f32x4 o4;
 #pragma unroll
