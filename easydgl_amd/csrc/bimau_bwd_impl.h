@@ -108,8 +108,11 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
     const long job = (long)b * p.H + head;   // index of the per-(b, head) partials: independent of the launch order
     const long bp = (long)head * p.B + b;
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
-    constexpr bool SWZ = img_swz<T, DT>();            // bank-swizzled row-major images (bimau_common.h)
-    const int g4s = SWZ ? (g4 ^ (l15 & 8)) : g4;     // column of this lane's row fragment in them
+    constexpr bool SWZ = img_swz<T>();                // bank-swizzled row-major images (bimau_common.h: swz_col)
+    const int g4s = SWZ ? swz_col<16>(l15, g4) : g4;  // column of this lane's row fragment in the mark image
+    int cw[DT];                                       // ... in the K / T_ / V images (row 16 kt + l15), per 16-channel block
+#pragma unroll
+    for (int ub = 0; ub < DT; ++ub) cw[ub] = SWZ ? swz_col<16 * DT>(l15, ub * 16 + g4) : ub * 16 + g4;
 
     // wave-private LDS: K, V row-major [Tp][dh], marks [Tp][16] (+ transposed marks for f32), additive key mask
     constexpr bool TR = sizeof(T) == 2;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
             f32x4 a = zero4;
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4s), qcur.qf[ub], a);
+                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + cw[ub]), qcur.qf[ub], a);
             s[kt] = a;
         }
         // s = P^T * (dropout scale), L(first=k, second=q): every use of P in this sweep carries the scale, so it rides on the softmax
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
             f32x4 da = zero4;
 #pragma unroll
             for (int vb = 0; vb < DT; ++vb)
-                da = mma16(frag_ld<T>(Vs + ((K0 + kt) * 16 + l15) * dh + vb * 16 + g4s), qcur.dof[vb], da);
+                da = mma16(frag_ld<T>(Vs + ((K0 + kt) * 16 + l15) * dh + cw[vb]), qcur.dof[vb], da);
             f32x4 ap, dg, gv = gacc;
             const bool dtile = K0 + kt == qt && (FL == 0 || !(p.flags & MAU_NO_DIAG));   // only this key tile can hold k == q
             if constexpr (FL == 0) {
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep1_kernel(BwdP p) {   // (f
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dg[r] = (g4 + r == l15) ? 0.f : dg[r];
             }
-            dlamT = mma16(kfrag<T, SWZ>(Ms, EP, MTs, LDT, (K0 + kt) * 16, 0, lane), frag_from_acc<T>(dg), dlamT);
+            dlamT = mma16(kfrag<T, SWZ ? 16 : 0>(Ms, EP, MTs, LDT, (K0 + kt) * 16, 0, lane), frag_from_acc<T>(dg), dlamT);
             const Frag4<T> apT = frag_from_acc<T>(transpose_tile<T>(ap, ident));  // L(first=q, second=k)
 #pragma unroll
             for (int vt = 0; vt < DT; ++vt) dVa[vt][kt] = mma16(dOT[vt], apT, dVa[vt][kt]);
@@ -421,8 +424,11 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
     const long job = (long)b * p.H + head;   // index of the per-(b, head) partials: independent of the launch order
     const long bp = (long)head * p.B + b;
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
-    constexpr bool SWZ = img_swz<T, DT>();            // bank-swizzled row-major images (bimau_common.h)
-    const int g4s = SWZ ? (g4 ^ (l15 & 8)) : g4;     // column of this lane's row fragment in them
+    constexpr bool SWZ = img_swz<T>();                // bank-swizzled row-major images (bimau_common.h: swz_col)
+    const int g4s = SWZ ? swz_col<16>(l15, g4) : g4;  // column of this lane's row fragment in the mark image
+    int cw[DT];                                       // ... in the K / T_ / V images (row 16 kt + l15), per 16-channel block
+#pragma unroll
+    for (int ub = 0; ub < DT; ++ub) cw[ub] = SWZ ? swz_col<16 * DT>(l15, ub * 16 + g4) : ub * 16 + g4;
 
     // wave-private LDS: K, T_, V row-major [Tp][dh], marks [Tp][16]; f32 additionally K^T (no 32-bit transpose read)
     constexpr bool TR = sizeof(T) == 2;
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             f32x4 a = zero4;
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4s), qcur.qf[ub], a);
+                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + cw[ub]), qcur.qf[ub], a);
             s[kt] = a;
         }
         PH_MARK(5);
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             f32x4 da = zero4;
 #pragma unroll
             for (int vb = 0; vb < DT; ++vb)
-                da = mma16(frag_ld<T>(Vs + ((K0 + kt) * 16 + l15) * dh + vb * 16 + g4s), qcur.dof[vb], da);
+                da = mma16(frag_ld<T>(Vs + ((K0 + kt) * 16 + l15) * dh + cw[vb]), qcur.dof[vb], da);
             f32x4 gv = gacc;
             if constexpr (FL == 0) {
                 const bool dtile = K0 + kt == qt;
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             }
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ts + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4s), dhf[ub], a);
+                a = mma16(frag_ld<T>(Ts + ((K0 + kt) * 16 + l15) * dh + cw[ub]), dhf[ub], a);
             f32x4 ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(256) void bimau_bwd_sweep2_kernel(BwdP p) {
             const Frag4<T> dsf = frag_from_acc<T>(ds);
 #pragma unroll
             for (int ut = 0; ut < DTS; ++ut)
-                dQ[ut] = mma16(kfrag<T, SWZ>(Ks, dh, KTs, LDT, (K0 + kt) * 16, (U0 + ut) * 16, lane), dsf, dQ[ut]);
+                dQ[ut] = mma16(kfrag<T, SWZ ? 16 * DT : 0>(Ks, dh, KTs, LDT, (K0 + kt) * 16, (U0 + ut) * 16, lane), dsf, dQ[ut]);
             const Frag4<T> dsT = frag_from_acc<T>(transpose_tile<T>(ds, ident));
             const Frag4<T> pT = frag_from_acc<T>(transpose_tile<T>(s[kt], ident));
 #pragma unroll

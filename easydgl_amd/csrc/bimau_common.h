@@ -502,25 +502,35 @@ __device__ __forceinline__ void all_gather16(const float (&in)[4], float (&out)[
     }
 }
 
-// Bank swizzle of the wave-private ROW-MAJOR images with 32-byte rows (bf16, 16 columns: K / T_ / V at head dim 16 and the marks).
-// The 8-byte fragment reads of the products that contract over the channel (row 16 kt + (l & 15), columns 4 (l >> 4) ..) are served
-// 32 lanes at a time over 64 banks: rows r and r + 8 are 256 bytes apart — the same banks — so every such read was a two-way
-// conflict (PMC round 5: SQ_LDS_BANK_CONFLICT 9-14 % of the backward sweeps' wave cycles).  Rows with bit 3 set keep their two
-// 16-byte halves swapped: column c of row r lives at c ^ (r & 8).  Writers (RowStage / stage_rows / the mark rows), the row
-// fragment reads (g4 ^ (l15 & 8)) and the transpose reads (kfrag<T, true>) all go through this one rule.
-template <typename T, int DT>
-__host__ __device__ constexpr bool img_swz() { return sizeof(T) == 2 && DT == 1; }
+// Bank swizzle of the wave-private ROW-MAJOR bf16 images (K / T_ / V: rows of dh = 16 .. 128 elements; marks: 16).
+// The 8-byte fragment reads of the products that contract over the channel (row 16 kt + (l & 15), columns 16 ub + 4 (l >> 4) ..) are
+// served 32 lanes at a time over 64 banks.  Rows of 32 / 64 / 128 / 256 bytes put rows r and r + 8 / 4 / 2 / 1 on the same banks:
+// every such read was a 2- / 4- / 8- / 16-way conflict (PMC round 5, head dim 16: SQ_LDS_BANK_CONFLICT 9-14 % of the backward
+// sweeps' wave cycles).  The 16-byte chunk c of row r lives at chunk c ^ f(r), f = the bits of r & 15 that the row stride does not
+// already turn into a bank offset: (r >> 3) & 1, (r >> 2) & 3, (r >> 1) & 7, r & 15 for 2 / 4 / 8 / 16 chunks per row.  Then the 16
+// rows of a half wave's read cover 16 distinct 16-byte slots = all 64 banks.  Writers (RowStage / stage_rows / the mark rows), the
+// row fragment reads and the transpose reads (kfrag<T, W>) all go through swz_col.
+template <typename T>
+__host__ __device__ constexpr bool img_swz() { return sizeof(T) == 2; }
+template <int W>      // W: elements per row (16, 32, 64, 128)
+__host__ __device__ __forceinline__ constexpr int swz_col(int row, int col) {
+    constexpr int CH = W / 8, SH = CH == 2 ? 3 : (CH == 4 ? 2 : (CH == 8 ? 1 : 0));
+    static_assert(CH == 2 || CH == 4 || CH == 8 || CH == 16, "row width");
+    return col ^ (((row >> SH) & (CH - 1)) << 3);      // (the chunk index is bits 3.. of the column)
+}
 
 // A/B fragment with the CONTRACTION index along the rows of a tile: v[j] = X[k0 + 4G + j][z0 + (l&15)].
-// SW: the image is bank-swizzled (img_swz; k0 a multiple of 16, 16-column rows).
+// W > 0: the image is bank-swizzled with W elements per row (swz_col; k0 a multiple of 16).
 //   bf16: one ds_read_b64_tr_b16 on the ROW-MAJOR tile rm[k][z] (ld_rm elements per row)
 //   f32 : no 32-bit transpose read exists -> plain read of a separately staged transposed image tr[z][k]
-template <typename T, bool SW = false>
+template <typename T, int W = 0>
 __device__ __forceinline__ Frag4<T> kfrag(const T* rm, int ld_rm, const T* tr, int ld_tr, int k0, int z0, int lane) {
     if constexpr (sizeof(T) == 2) {
         const int G = lane >> 4, s = lane & 15;
         typedef __attribute__((ext_vector_type(4))) short s4;
-        const T* p = rm + (k0 + 4 * G + (s >> 2)) * ld_rm + ((z0 + 4 * (s & 3)) ^ (SW ? ((4 * G + (s >> 2)) & 8) : 0));
+        int col = z0 + 4 * (s & 3);
+        if constexpr (W > 0) col = swz_col<W>(4 * G + (s >> 2), col);
+        const T* p = rm + (k0 + 4 * G + (s >> 2)) * ld_rm + col;
         s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
         Frag4<T> f;
         *reinterpret_cast<uint2*>(&f) = *reinterpret_cast<uint2*>(&v);
@@ -555,7 +565,7 @@ __device__ __forceinline__ void stage_rows(const T* src, int ld, int Tlen, T* ro
                 if (k >= Tlen) f[j] = frag_zero<T>();
                 if (rowmajor) {
                     if constexpr (sizeof(T) == 4) *reinterpret_cast<uint4*>(rowmajor + k * dh + u4) = *reinterpret_cast<uint4*>(&f[j]);
-                    else *reinterpret_cast<uint2*>(rowmajor + k * dh + (img_swz<T, DT>() ? (u4 ^ (k & 8)) : u4)) = *reinterpret_cast<uint2*>(&f[j]);
+                    else *reinterpret_cast<uint2*>(rowmajor + k * dh + (img_swz<T>() ? swz_col<dh>(k, u4) : u4)) = *reinterpret_cast<uint2*>(&f[j]);
                 }
                 if (transposed) {
 #pragma unroll
@@ -631,7 +641,7 @@ struct RowStage {
         for (int j = 0; j < NI; ++j) {
             const int c = lane + 64 * j, k = c / cpr, u4 = (c % cpr) * 4;
             if (k >= Tlen) f[j] = frag_zero<T>();
-            if (rowmajor) *reinterpret_cast<uint2*>(rowmajor + k * dh + (img_swz<T, DT>() ? (u4 ^ (k & 8)) : u4)) = *reinterpret_cast<uint2*>(&f[j]);
+            if (rowmajor) *reinterpret_cast<uint2*>(rowmajor + k * dh + (img_swz<T>() ? swz_col<dh>(k, u4) : u4)) = *reinterpret_cast<uint2*>(&f[j]);
             if (transposed) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) transposed[(u4 + r) * LDT + k] = f[j].v[r];
@@ -686,7 +696,7 @@ __device__ __forceinline__ KeyMask<NT> stage_wave(const T* k_src, T* k_rm, T* k_
                     if (m_rm) {
 #pragma unroll
                         for (int j = 0; j < (int)(16 * sizeof(T) / 16); ++j)
-                            reinterpret_cast<uint4*>(m_rm + k * EP)[img_swz<T, DT>() ? (j ^ ((k >> 3) & 1)) : j] = reinterpret_cast<const uint4*>(vals)[j];
+                            reinterpret_cast<uint4*>(m_rm + k * EP)[img_swz<T>() ? (j ^ ((k >> 3) & 1)) : j] = reinterpret_cast<const uint4*>(vals)[j];
                     }
                     if (m_tr) {
 #pragma unroll
@@ -719,7 +729,7 @@ __device__ __forceinline__ KeyMask<NT> stage_wave(const T* k_src, T* k_rm, T* k_
         stage_rows<T, DT, NT>(k_src, ld, Tlen, k_rm, k_tr, LDT, lane);
         if (t_src) stage_rows<T, DT, NT>(t_src, ld, Tlen, t_rm, t_tr, LDT, lane);
         if (v_src) stage_rows<T, DT, NT>(v_src, ld, Tlen, v_rm, v_tr, LDT, lane);
-        if (marks_row) stage_marks<T, NT, EC, img_swz<T, DT>()>(marks_row, E, Tlen, m_rm, m_tr, LDT, lane);
+        if (marks_row) stage_marks<T, NT, EC, img_swz<T>()>(marks_row, E, Tlen, m_rm, m_tr, LDT, lane);
         return load_keymask<NT>(ids_row, Tlen, lane, lds_madd);
     }
 }

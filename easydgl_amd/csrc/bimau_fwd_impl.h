@@ -111,8 +111,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
     const float cscale = p.qk_scale > 0.f ? p.qk_scale : rsqrtf((float)dh);
     const DropKey dk = make_dropkey(p.rng, p.stream_id, p.rate);
     const int g4 = (lane >> 4) * 4, l15 = lane & 15;
-    constexpr bool SWZ = img_swz<T, DT>();            // bank-swizzled row-major images (bimau_common.h)
-    const int g4s = SWZ ? (g4 ^ (l15 & 8)) : g4;     // column of this lane's row fragment in them
+    constexpr bool SWZ = img_swz<T>();                // bank-swizzled row-major images (bimau_common.h: swz_col)
+    const int g4s = SWZ ? swz_col<16>(l15, g4) : g4;  // column of this lane's row fragment in the mark image
+    int cw[DT];                                       // ... in the K / T_ / V images (row 16 kt + l15), per 16-channel block
+#pragma unroll
+    for (int ub = 0; ub < DT; ++ub) cw[ub] = SWZ ? swz_col<16 * DT>(l15, ub * 16 + g4) : ub * 16 + g4;
 
     // per-query-tile global operands (Q rows, interval, residual rows) are fetched one tile ahead: their HBM/L2 latency
     // overlaps the previous tile's compute instead of opening every iteration with a stall
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ub = 0; ub < DT; ++ub)
-                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + ub * 16 + g4s), qf[ub], a);
+                a = mma16(frag_ld<T>(Ks + ((K0 + kt) * 16 + l15) * dh + cw[ub]), qf[ub], a);
             s[kt] = a;
         }
         // bf16: s := exp(v - max), UNNORMALISED; 1 / sum (`pinv`) rides on the H rows (4 values) and, together with the dropout scale,
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kt = 0; kt < NK; ++kt)
-                    a = mma16(kfrag<T, SWZ>(Ts, dh, Ts, LDT, (K0 + kt) * 16, ut * 16, lane), pf[kt], a);
+                    a = mma16(kfrag<T, SWZ ? 16 * DT : 0>(Ts, dh, Ts, LDT, (K0 + kt) * 16, ut * 16, lane), pf[kt], a);
                 if constexpr (TR) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a[r] *= pinv;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 && DT == 1 && EC == 16 && PHAS
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kt = 0; kt < NK; ++kt)
-                a = mma16(kfrag<T, SWZ>(Vs, dh, Vs, LDT, (K0 + kt) * 16, vt * 16, lane), pf[kt], a);
+                a = mma16(kfrag<T, SWZ ? 16 * DT : 0>(Vs, dh, Vs, LDT, (K0 + kt) * 16, vt * 16, lane), pf[kt], a);
             const Frag4<T> rf = qcur.rf[vt];
             f32x4 o4;
 #pragma unroll
