@@ -280,7 +280,10 @@ class TrainEngine:
         # the keep bits of the attention dropout from the advanced counter.  First step, or an _issue() without _optimizer: here.
         legacy = os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") == "1"   # A/B switch: round-3 order (one side stream, fork first)
         # the sums of squares the last optimizer launch of THIS engine left are the L2 term's input iff nobody touched the state since
-        l2_from_parts = self.l2_parts is not None and self._l2p_ready and getattr(m, "_state_ahead", False) and not legacy
+        # (ownership on the MODEL: another engine of the same model, load_tf_variables / _load_padded / a checkpoint — anything that
+        #  rewrites the arena goes through sync_shadow / settle_state or another engine's _optimizer and takes the token away)
+        l2_from_parts = self.l2_parts is not None and self._l2p_ready and getattr(m, "_state_ahead", False) and not legacy \
+            and getattr(m, "_l2_parts_owner", None) == id(self)
         if not legacy:
             if not getattr(m, "_state_ahead", False):
                 self._advance_state(st)
@@ -491,6 +494,8 @@ class TrainEngine:
                   "edgl_score_lse_fwd")
             check(lib.edgl_ce_loss_fwd_add_w(_ptr(self.lse), _ptr(self.lab_logit), _ptr(lab), R, _ptr(self.loss), _ptr(self.coef),
                                              aux, tpp, self.counts.data_ptr() if self._dp else None, st), "edgl_ce_loss_fwd_add")
+            if self.accumulate_loss:     # (two-pass form: the loss is written inline, on the main stream)
+                self.loss_sum.add_(self.loss)
         # ================= backward =================
         self._ws_i = 0
         check(lib.edgl_reduce_defer(1, st), "edgl_reduce_defer")
@@ -510,6 +515,8 @@ class TrainEngine:
         if self._pending_loss is not None:   # (no block: no side-stream join in the backward)
             self._pending_loss(st)
             self._pending_loss = None
+            if self.accumulate_loss:         # (the loss launch of a model without blocks runs on the main stream)
+                self.loss_sum.add_(self.loss)
         if self._lazy_loss and not self._side_has_grads:
             self._loss_unjoined = True       # (step() joins behind the optimizer, or the caller does: join_loss())
         else:
@@ -776,6 +783,7 @@ class TrainEngine:
                 self._l2p_cur ^= 1       # the copy the NEXT step reads
                 l2p = self.l2_parts[self._l2p_cur]
                 self._l2p_ready = True
+                m._l2_parts_owner = id(self)
             if getattr(self, "_adam_ticket", None) is None:
                 self._adam_ticket = torch.zeros(int(lib.edgl_adam_next_tickets(m._arena.numel())), device=m._arena.device, dtype=torch.int32)
             check(lib.edgl_adam_apply_l2p_next(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(),
@@ -790,10 +798,12 @@ class TrainEngine:
                                           0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg), seg.numel() // 2, _ptr(m._shadow),
                                           _ptr(self.l2_parts[self._l2p_cur]), _stream()), "edgl_adam_apply_l2p")
             self._l2p_ready = True
+            m._l2_parts_owner = id(self)
         else:
             check(lib.edgl_adam_apply(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,
                                       0.999, 1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg),
                                       0 if seg is None else seg.numel() // 2, _ptr(m._shadow), _stream()), "edgl_adam_apply")
+            m._l2_parts_owner = None
         # the counters of the next step (Sequential.settle_state undoes this for anyone else who reads them)
         self._advance_state(_stream())
         m._state_ahead = True

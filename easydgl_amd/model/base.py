@@ -86,6 +86,7 @@ class Sequential(nn.Module):
 
     def sync_shadow(self) -> None:
         """Refresh the low-precision compute copies after the f32 masters were changed outside adam_step."""
+        self._l2_parts_owner = None      # (the weights were rewritten: no engine's sums of squares describe them any more)
         if self._shadow is not None:
             ops.cast_to(self._arena, self.act_dtype, out=self._shadow)
 
@@ -216,7 +217,9 @@ class Sequential(nn.Module):
             p.data[self._spec_index(p.data, maps)] = v.to(p.device, p.dtype)
 
     def mask_padded_grads(self) -> None:
-        """Zero every gradient entry of a padded row / column (see above); a model without padding: nothing."""
+        """Zero every gradient entry of a padded row / column (see above); a model without padding: nothing.  ONE index_fill_ on
+        the flat gradient arena (the padded entries of every parameter as one int64 index, built once) — a launch per (parameter,
+        axis) was dozens of tiny kernels in front of every optimizer step of a 3-block model, captured into the graph step too."""
         if not self.pad[0]:
             return
         plan = getattr(self, "_pad_mask_plan", None)
@@ -227,15 +230,31 @@ class Sequential(nn.Module):
                 for a, m in enumerate(maps):
                     if m is not None:
                         cur[1 + a].update(m.tolist())
-            plan = []
+            per_param, flat = [], []
+            base = self._arena.data_ptr()
             for p, *axes in real.values():
+                mask = torch.zeros(p.shape, dtype=torch.bool)
                 for a, idxs in enumerate(axes):
                     if idxs is not None:
                         padded = sorted(set(range(p.shape[a])) - idxs)
                         if padded:
-                            plan.append((p, a, torch.tensor(padded, device=p.device, dtype=torch.int64)))
+                            idx = torch.tensor(padded, dtype=torch.int64)
+                            mask.index_fill_(a, idx, True)
+                            per_param.append((p, a, idx.to(p.device)))
+                pos = torch.nonzero(mask.reshape(-1)).reshape(-1)
+                if pos.numel():
+                    flat.append(pos + (p.data_ptr() - base) // 4)
+            flat_idx = torch.cat(flat).to(self._arena.device) if flat else None
+            plan = (flat_idx, per_param)
             self._pad_mask_plan = plan
-        for p, a, idx in plan:
+        flat_idx, per_param = plan
+        if flat_idx is None:
+            return
+        g0, n = self._grad_arena.data_ptr(), self._grad_arena.numel()
+        if all(p.grad is not None and g0 <= p.grad.data_ptr() < g0 + 4 * n for p, _, _ in per_param):
+            self._grad_arena.index_fill_(0, flat_idx, 0.0)      # (every gradient is its view of the arena: the engine and collect_grads)
+            return
+        for p, a, idx in per_param:
             if p.grad is not None:
                 p.grad.index_fill_(a, idx, 0.0)
 
@@ -277,6 +296,7 @@ class Sequential(nn.Module):
         its optimizer kernel — the single-thread update then costs nothing in front of the next step's first kernels
         (engine.TrainEngine._advance_state).  Anything else that reads or advances them (the autograd path's steps, a checkpoint)
         calls this first: the counters go back to "steps taken so far"."""
+        self._l2_parts_owner = None      # (whoever settles the counters is about to read or rewrite the state itself)
         if getattr(self, "_state_ahead", False):
             self._rng_state[1] -= 1
             self._adam_state[0] -= 1

@@ -579,6 +579,21 @@ EVAL_FUSED = os.environ.get("EDGL_EVAL_FUSED", "1") != "0"   # scoring + seen ma
 EVAL_GEMM = True             # full item chunks of the chunked evaluation path score through edgl_gemm (tests switch it off)
 
 
+EVAL_FUSED_SCRATCH_BYTES = int(os.environ.get("EDGL_EVAL_FUSED_SCRATCH_BYTES", str(512 << 20)))
+_FUSED_EVAL_WS = {}
+
+
+def _fused_eval_workspace(device, nbytes: int) -> torch.Tensor:
+    """Grow-only workspace of the fused evaluation scoring, one per device and stream (the launches of one stream are ordered, so
+    consecutive calls may share it): no allocation per call."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _FUSED_EVAL_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+        _FUSED_EVAL_WS[key] = ws
+    return ws
+
+
 def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
     """Sequential.eval's scoring + seen-mask + top-K (Base.py:150-181) over the item range [i0, i1) WITHOUT the [R, I]
     logits tensor of the reference: the range is walked in chunks whose [R, chunk] f32 logits tile is bounded by
@@ -588,7 +603,14 @@ def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
     n = i1 - i0
     # the fused form (csrc/k_eval_topk.hip): no logits tile at all — two sweeps on the matrix pipe, candidates above a per-row bound,
     # one ranking launch; item ranges of <= 262 144 per call, longer catalogues in chunks + the merge kernel
-    if EVAL_FUSED and K <= 128 and rows.dtype == torch.bfloat16:
+    if EVAL_FUSED and K <= 128 and rows.dtype == torch.bfloat16 and i0 % 8 == 0:
+        if seen is not None:
+            # the sweep reads a row's seen ids as 16-byte pairs of int64 at a row stride of T (csrc/k_eval_topk.hip eval_sweep_kernel)
+            if seen.dtype != torch.int64:
+                raise _lib.EdglError(f"score_topk: seen ids must be int64 (got {seen.dtype})")
+            seen = seen.contiguous()
+            if seen.data_ptr() % 16 != 0:
+                seen = seen.clone()                     # (an offset view of a larger buffer: a fresh allocation is 256-byte aligned)
         T = 0 if seen is None else seen.shape[1]
         C, code, st = rows.shape[1], _code(rows), _stream()
         fchunk = 131072 if C == 256 else 262144      # (64 item slices of <= 2048 / 4096 items: the seen bitmap's LDS)
@@ -597,14 +619,24 @@ def score_topk(rows, table_c, out_bias, seen, K, i0, i1):
         if len(starts) > 1 and (i1 - starts[-1]) < 4096:
             starts[-1] = max(starts[-2] + 8, (i1 - 4096) // 8 * 8)
         bounds = [(lo, (starts[j + 1] if j + 1 < len(starts) else i1)) for j, lo in enumerate(starts)]
-        if all(lib.edgl_score_topk_fused_supported(R, C, hi - lo, T, K, code) for lo, hi in bounds) and (len(bounds) == 1 or K <= 512):
-            wsb = max(int(lib.edgl_score_topk_fused_workspace(R, C, hi - lo, T, K)) for lo, hi in bounds)
-            ws = torch.empty(wsb, device=rows.device, dtype=torch.uint8)
+        # The plan reserves an [R, items] f32 scratch for the exact fallback of rows whose candidate list overflows (almost never
+        # touched): bounded by walking the rows in blocks, so that a large evaluation batch on a large catalogue holds at most
+        # EVAL_FUSED_SCRATCH_BYTES of it — the unfused path it replaces is bounded by EVAL_TILE_BYTES the same way
+        span = max(hi - lo for lo, hi in bounds)
+        rb = R if R * span * 4 <= EVAL_FUSED_SCRATCH_BYTES else max(128, (EVAL_FUSED_SCRATCH_BYTES // (span * 4)) // 128 * 128)
+        rblocks = [(r0, min(R, r0 + rb)) for r0 in range(0, R, rb)]
+        rsizes = sorted({r1 - r0 for r0, r1 in rblocks})
+        if all(lib.edgl_score_topk_fused_supported(rn, C, hi - lo, T, K, code) for lo, hi in bounds for rn in rsizes) \
+                and (len(bounds) == 1 or K <= 512):
+            wsb = max(int(lib.edgl_score_topk_fused_workspace(rn, C, hi - lo, T, K)) for lo, hi in bounds for rn in rsizes)
+            ws = _fused_eval_workspace(rows.device, wsb)
             cval = torch.empty((len(bounds), R, K), device=rows.device, dtype=torch.float32)
             cidx = torch.empty((len(bounds), R, K), device=rows.device, dtype=torch.int32)
             for j, (lo, hi) in enumerate(bounds):
-                check(lib.edgl_score_topk_fused(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(seen), T, R, C, table_c.shape[0], lo, hi, K,
-                                                _ptr(cval[j]), _ptr(cidx[j]), _ptr(ws), code, st), "edgl_score_topk_fused")
+                for r0, r1 in rblocks:
+                    check(lib.edgl_score_topk_fused(_ptr(rows[r0:r1]), _ptr(table_c), _ptr(out_bias),
+                                                    None if seen is None else _ptr(seen[r0:r1]), T, r1 - r0, C, table_c.shape[0], lo, hi, K,
+                                                    _ptr(cval[j, r0:r1]), _ptr(cidx[j, r0:r1]), _ptr(ws), code, st), "edgl_score_topk_fused")
             return _merge_lists(cval, cidx, R, K)
     chunk = max(1024, (EVAL_TILE_BYTES // (4 * R)) // 8 * 8)
     if K <= 128 and chunk > TOPK_REG_ITEMS >= 1024:      # rows the top-K kernel keeps in registers: one read of the tile instead of five

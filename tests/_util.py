@@ -115,3 +115,22 @@ def dump_errors(tag, errs):
         o = old.get(k, [0.0, 0.0])
         old[k] = [max(o[0], float(v[0])), max(o[1], float(v[1]))]
     json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+
+
+def regressive_bf16_bounds(model: str, name: str, gtol: float, l2_default: float = 8e-2):
+    """(relative-L2 bound, max-norm bound) of one gradient tensor of TGAT / TiSASRec / CTSMA on the bf16 path: per tensor class,
+    <= 2 x the errors measured on the GPU (tests/golden/regressive_bf16_bounds.json, written by make_regressive_bounds.py from
+    profiles/r05_parity_errors.json).  The ReLU-gated Inner tensors keep relu_flip_err's bound."""
+    import json
+    import os
+    from tests.golden.make_regressive_bounds import tensor_class
+    c = tensor_class(name)
+    if c == "ffn_inner":
+        return l2_default, gtol
+    global _REG_BOUNDS
+    try:
+        tab = _REG_BOUNDS
+    except NameError:
+        tab = _REG_BOUNDS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regressive_bf16_bounds.json")))["bounds"]
+    l2, mx = tab[model][c]
+    return min(l2, l2_default), min(mx, gtol)

@@ -9,7 +9,7 @@ import torch
 
 from oracle import ctsma_ref as CR
 from oracle import easydgl_oracle as O
-from tests._util import assert_close, grad_errors, rel_err, relu_flip_err, to_dev
+from tests._util import assert_close, grad_errors, regressive_bf16_bounds, rel_err, relu_flip_err, to_dev
 
 # per-tensor relative L2 bound of the bf16 path beside the max-norm bound `gtol`.  These models gate their feed-forward with a
 # ReLU: a pre-activation within bf16 rounding of 0 flips its mask against the fp64 reference, and the flipped unit's whole
@@ -95,6 +95,8 @@ def test_forward_loss_and_gradients(mode, ltol, gtol, case):
     bad, errs = {}, {}
     for name, g in got.items():
         ref = p64[name].grad.numpy()
+        # bf16: per tensor class, <= 2 x the measured errors (tests/_util.py regressive_bf16_bounds); f32: gtol on everything
+        l2_tol, g_tol = regressive_bf16_bounds("ctsma", name, gtol, BF16_GRAD_L2) if mode == "bf16" else (BF16_GRAD_L2, gtol)
         if name.endswith("modulating_attention/dense_1/bias"):
             # a bias on K shifts every score of a query row by the same amount: its true gradient is identically zero
             # (the oracle holds ~1e-17 there), so measure against the scale of the K kernel's gradient instead
@@ -105,7 +107,7 @@ def test_forward_loss_and_gradients(mode, ltol, gtol, case):
             e = rel_err(g, ref)
             # bf16: the max-norm bound alone lets every small entry of a tensor be wrong — a relative-L2 bound beside it
             # (the ReLU-gated Inner tensors are held by relu_flip_err's own rms bound instead)
-            if mode == "bf16" and "/Inner/" not in name and grad_errors(g, ref)[0] > BF16_GRAD_L2:
+            if mode == "bf16" and "/Inner/" not in name and grad_errors(g, ref)[0] > l2_tol:
                 bad[name + " (rel-L2)"] = grad_errors(g, ref)[0]
         # bf16 only: a pre-activation within bf16 rounding of 0 flips its ReLU mask, which moves one whole term of the
         # row sums behind Inner/kernel and Inner/bias (measured: error ~ 1/sqrt(rows), 0.13 at 120 rows, 0.05 at 3840);
@@ -113,8 +115,8 @@ def test_forward_loss_and_gradients(mode, ltol, gtol, case):
         if mode == "bf16" and "/Inner/" in name:
             e = relu_flip_err(g, ref, gtol)       # tests/_util.py: flipped hidden units are counted, the rest is held to gtol
         errs[f"{mode}:{name}"] = (grad_errors(g, ref)[0] if np.any(ref) else 0.0, e)
-        if e > gtol:
-            bad[name] = e
+        if e > g_tol:
+            bad[name] = (e, g_tol)
     from tests._util import dump_errors
     dump_errors("ctsma", errs)
     assert not bad, f"gradient mismatch (rel to max |ref|): {bad}"

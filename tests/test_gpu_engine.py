@@ -302,3 +302,70 @@ def test_loss_from_the_row_finish_sums_and_launched_with_the_next_step(parts, de
     for a, b in zip(want, got):
         assert abs(a - b) <= 1e-5 * abs(a), (want, got)
     assert float((m0._arena - m1._arena).abs().max()) <= 1e-5 * float(m0._arena.abs().max())
+
+
+@pytest.mark.parametrize("path", ["flash", "no_blocks", "two_pass"])
+def test_accumulated_loss_covers_every_loss_path(path, monkeypatch):
+    """train.py runs the engine with sync_loss = False + accumulate_loss = True and reads engine.loss_sum at its logging points (the
+    NaN guard of util.py:29-30 hangs on it).  The running sum must be fed on all three loss paths: the side-stream launches of the
+    flash form, the main-stream launch of a model without blocks (num_blocks 0) and the inline loss of the two-pass form
+    (EDGL_FLASH_CE=0).  loss_sum == the sum of the step losses the joined form returns."""
+    from easydgl_amd.engine import TrainEngine
+    if path == "two_pass":
+        monkeypatch.setenv("EDGL_FLASH_CE", "0")
+    kw = dict(CASES[1])
+    if path == "no_blocks":
+        kw["num_blocks"] = 0
+    prob = make_problem(seed=61, batch=6, **kw)
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    m0 = build_model(prob, "bf16")
+    e0 = TrainEngine(m0, 6, use_graph=False)
+    e0.load_batch(feats, labels)
+    want = sum(float(e0.step()) for _ in range(4))
+    m1 = build_model(prob, "bf16")
+    e1 = TrainEngine(m1, 6, use_graph=False)
+    e1.sync_loss, e1.accumulate_loss = False, True
+    e1.load_batch(feats, labels)
+    for _ in range(4):
+        e1.step()
+    e1.join_loss()
+    torch.cuda.synchronize()
+    got = float(e1.loss_sum)
+    assert want > 0.0 and abs(got - want) <= 1e-5 * want, (path, got, want)
+
+
+def test_l2_term_from_the_optimizer_sums_only_while_this_engine_owns_the_weights():
+    """The L2 term of a step comes from the sums of squares the engine's previous optimizer launch left (edgl_adam_apply_l2p) — valid
+    only while nobody else rewrote the arena.  Weights reloaded between two steps (load_tf_variables), or another engine of the
+    same model stepping in between, take the ownership token away and the term is recomputed from the arena."""
+    from easydgl_amd.engine import TrainEngine
+    prob = make_problem(seed=62, batch=6, **CASES[1])
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+    p2 = {k: (np.asarray(v) * 3.0 if "lookup_table" in k or "embedding" in k.lower() else np.asarray(v)) for k, v in prob["params"].items()}
+    assert any(not np.array_equal(np.asarray(prob["params"][k]), p2[k]) for k in p2)
+    # reference: a fresh model with the second weight set, first step of its engine (L2 from the arena)
+    mref = build_model(prob, "bf16")
+    mref.load_tf_variables(p2)
+    eref = TrainEngine(mref, 6, use_graph=False)
+    eref.load_batch(feats, labels)
+    want = float(eref.step())
+    # (a) reload between steps
+    m = build_model(prob, "bf16")
+    e = TrainEngine(m, 6, use_graph=False)
+    assert e.l2_parts is not None
+    e.load_batch(feats, labels)
+    e.step(); e.step()
+    assert m._l2_parts_owner == id(e)
+    m.load_tf_variables(p2)
+    assert m._l2_parts_owner is None
+    got = float(e.step())
+    assert abs(got - want) <= 1e-5 * abs(want), (got, want)
+    # (b) two engines on one model alternate: each step's loss equals the single-engine trajectory
+    ma, mb = build_model(prob, "bf16"), build_model(prob, "bf16")
+    ea = TrainEngine(ma, 6, use_graph=False); ea.load_batch(feats, labels)
+    single = [float(ea.step()) for _ in range(4)]
+    e1, e2 = TrainEngine(mb, 6, use_graph=False), TrainEngine(mb, 6, use_graph=False)
+    e1.load_batch(feats, labels); e2.load_batch(feats, labels)
+    both = [float((e1 if n % 2 == 0 else e2).step()) for n in range(4)]
+    for a, b in zip(single, both):
+        assert abs(a - b) <= 1e-5 * abs(a), (single, both)

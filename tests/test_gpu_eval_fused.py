@@ -43,22 +43,34 @@ def _reference(rows, table, bias, seen, i0, i1, K):
     return lg
 
 
-def _check(val, idx, lg, seen, i0, K, tol=2e-4):
+ORDER_GAP = 2e-4      # a reference gap above this cannot be reordered by f32 accumulation order (measured errors: ~1e-6 at |logit| <= 12)
+
+
+def _check(val, idx, lg, seen, i0, K, tol=2e-4, min_cover=0.9, full_lists=False):
+    """Membership, values and ORDER: position p of a row is compared with the reference's position p wherever the reference's
+    gaps to BOTH neighbours (p - 1 and p + 1, the K + 1-th element included) exceed ORDER_GAP — f32 rounding cannot move such an
+    element — and those positions must be >= min_cover of all positions (0.96-0.99 at the shapes below); full_lists: every row's
+    whole list equals the reference's (the K = 10 case, where every gap is resolvable)."""
     val, idx = val.cpu().numpy(), idx.cpu().numpy()
     s = seen.cpu().numpy()
+    covered = total = 0
     for r in range(lg.shape[0]):
-        order = np.lexsort((np.arange(lg.shape[1]), -lg[r]))[:K]
-        kth = lg[r, order[-1]]
+        order = np.lexsort((np.arange(lg.shape[1]), -lg[r]))[:K + 1]
+        kth = lg[r, order[K - 1]]
         assert len(set(idx[r].tolist())) == K and idx[r].min() >= i0, r
         assert not np.isin(idx[r], s[r]).any(), r                                    # no seen id
         got = lg[r, idx[r] - i0]
         assert np.all(np.abs(got - val[r]) <= tol * max(1.0, np.abs(got).max())), r     # the values ARE those items' logits
         assert np.all(got >= kth - tol), r                                           # each one belongs to the top K (up to f32 rounding)
         assert np.all(np.diff(val[r]) <= 0), r                                       # descending
-        # ... and where the reference's order is unambiguous at that resolution, it is the same list
-        gaps = np.abs(np.diff(lg[r, np.lexsort((np.arange(lg.shape[1]), -lg[r]))[:K + 1]]))
-        if gaps.min() > 10 * tol:
-            assert np.array_equal(idx[r] - i0, order), r
+        gaps = np.abs(np.diff(lg[r, order]))                                         # K gaps: gaps[p] between positions p and p + 1
+        fixed = gaps > ORDER_GAP
+        fixed[1:] &= gaps[:-1] > ORDER_GAP
+        assert np.array_equal((idx[r] - i0)[fixed], order[:K][fixed]), (r, np.where(fixed & ((idx[r] - i0) != order[:K]))[0])
+        covered += int(fixed.sum()); total += K
+        if full_lists:
+            assert np.array_equal(idx[r] - i0, order[:K]), r
+    assert covered >= min_cover * total, (covered, total)
 
 
 @pytest.mark.parametrize("R,C,I,T,K,i0,i1", [(512, 128, 20001, 101, 100, 0, 20001), (70, 64, 5000, 20, 10, 0, 5000),
@@ -70,7 +82,7 @@ def test_fused_eval_scoring_matches_the_reference(R, C, I, T, K, i0, i1):
     assert o.EVAL_FUSED
     val, idx = o.score_topk(rows, table, bias, seen, K, i0, i1)
     torch.cuda.synchronize()
-    _check(val, idx, _reference(rows, table, bias, seen, i0, i1, K), seen, i0, K)
+    _check(val, idx, _reference(rows, table, bias, seen, i0, i1, K), seen, i0, K, full_lists=(K == 10))
     # the unfused kernels on the same operands: same lists wherever f32 rounding cannot reorder neighbours (checked above against
     # the reference for both), same values to rounding
     o.EVAL_FUSED = False
@@ -78,7 +90,7 @@ def test_fused_eval_scoring_matches_the_reference(R, C, I, T, K, i0, i1):
         val2, idx2 = o.score_topk(rows, table, bias, seen, K, i0, i1)
     finally:
         o.EVAL_FUSED = True
-    _check(val2, idx2, _reference(rows, table, bias, seen, i0, i1, K), seen, i0, K)
+    _check(val2, idx2, _reference(rows, table, bias, seen, i0, i1, K), seen, i0, K, full_lists=(K == 10))
     same = (idx == idx2).float().mean().item()
     assert same > 0.98, same
 
@@ -93,7 +105,7 @@ def test_fused_eval_scoring_breaks_ties_by_index_and_survives_overflow():
     rows, table, bias, seen = _problem(R, C, I, T, seed=3, dup=2000)
     val, idx = o.score_topk(rows, table, bias, seen, K, 0, I)
     lg = _reference(rows, table, bias, seen, 0, I, K)
-    _check(val, idx, lg, seen, 0, K)
+    _check(val, idx, lg, seen, 0, K, min_cover=0.0)          # (tie blocks: exact ties are checked below, index order)
     v, ix = val.cpu().numpy(), idx.cpu().numpy()
     for r in range(R):
         eq = np.where(v[r][1:] == v[r][:-1])[0]
@@ -131,3 +143,32 @@ def test_fused_eval_is_refused_for_shapes_it_does_not_take():
     assert rc < 0
     val, idx = o.score_topk(rows, table, bias, seen, 10, 0, 3000)       # the op runs the unfused kernels there
     _check(val, idx, _reference(rows, table, bias, seen, 0, 3000, 10), seen, 0, 10)
+
+
+def test_fused_eval_scratch_is_bounded_by_row_blocks(monkeypatch):
+    """The exact-fallback scratch of the fused plan is [rows, items] f32: ops.score_topk walks the rows in blocks so that it never
+    exceeds EVAL_FUSED_SCRATCH_BYTES, with the same lists as the one-call form; the workspace is cached per stream (no allocation
+    per call); a seen-id view that is not 16-byte aligned / contiguous is re-laid, not read through its raw pointer."""
+    o = ops()
+    R, C, I, T, K = 300, 128, 20001, 101, 100
+    rows, table, bias, seen = _problem(R, C, I, T, seed=77)
+    val, idx = o.score_topk(rows, table, bias, seen, K, 0, I)
+    n_ws = {k: v.numel() for k, v in o._FUSED_EVAL_WS.items()}
+    monkeypatch.setattr(o, "EVAL_FUSED_SCRATCH_BYTES", 128 * I * 4)       # three row blocks: 128 + 128 + 44
+    val2, idx2 = o.score_topk(rows, table, bias, seen, K, 0, I)
+    assert torch.equal(idx, idx2) and torch.equal(val, val2)
+    assert {k: v.numel() for k, v in o._FUSED_EVAL_WS.items()} == n_ws    # (the smaller plan fits the cached workspace)
+    # an odd-offset, strided view of the seen ids
+    big = torch.zeros((R, T + 1), dtype=torch.int64, device="cuda")
+    big[:, 1:] = seen
+    view = big[:, 1:]
+    assert not view.is_contiguous()
+    val3, idx3 = o.score_topk(rows, table, bias, view, K, 0, I)
+    assert torch.equal(idx, idx3) and torch.equal(val, val3)
+    flat = torch.zeros(R * T + 1, dtype=torch.int64, device="cuda")
+    flat[1:] = seen.reshape(-1)
+    off = flat[1:].view(R, T)                                            # contiguous, base 8 bytes off a 16-byte boundary
+    assert off.is_contiguous() and off.data_ptr() % 16 == 8
+    val4, idx4 = o.score_topk(rows, table, bias, off, K, 0, I)
+    assert torch.equal(idx, idx4) and torch.equal(val, val4)
+    _check(val, idx, _reference(rows, table, bias, seen, 0, I, K), seen, 0, K)

@@ -69,6 +69,35 @@ def test_driver_end_to_end_from_tfrecords(tmp_path, model_name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("blocks,flash", [("0", "1"), ("1", "0"), ("1", "1")])
+def test_driver_logs_a_real_loss_on_every_loss_path(tmp_path, caplog, monkeypatch, blocks, flash):
+    """The epoch loss the driver logs (and its NaN guard, util.py:29-30) comes from the engine's running sum: non-zero with
+    --num_blocks 0 (loss launch on the main stream) and with the two-pass scoring form (EDGL_FLASH_CE=0), not only on the flash path."""
+    import logging
+    import re
+    sp = pytest.importorskip("scipy.sparse")
+    from easydgl_amd import data as D
+    from easydgl_amd import train as TR
+    monkeypatch.setenv("EDGL_FLASH_CE", flash)
+    num_items, seqslen, E = 300, 20, 4
+    ids, ts = D.synthetic_batch(num_items, seqslen, 200, seed=3)
+
+    def dump(name, lo, hi):
+        F.write_tfrecord(str(tmp_path / name), [F.encode_example({"seqs_i": ids[i], "seqs_t": ts[i]}) for i in range(lo, hi)])
+    dump("train000.tfrec", 0, 140); dump("validation.tfrec", 140, 170); dump("test.tfrec", 170, 200)
+    with open(tmp_path / "mark.pkl", "wb") as f:
+        pickle.dump(sp.csr_matrix(D.synthetic_mark_table(num_items, E).astype(np.int64)), f)
+    with caplog.at_level(logging.INFO):
+        TR.main(["--model", "EasyDGL", "--train", str(tmp_path / "train*.tfrec"), "--valid", str(tmp_path / "validation.tfrec"),
+                 "--test", str(tmp_path / "test.tfrec"), "--num_items", str(num_items), "--num_units", "32", "--num_heads", "2",
+                 "--num_blocks", blocks, "--seqslen", str(seqslen), "--masklen", "4", "--time_scale", "86400", "--mark",
+                 str(tmp_path / "mark.pkl"), "--ct_reg", "1e-7", "--batch_size", "64", "--num_epochs", "2", "--learning_rate",
+                 "1e-3", "--l2_reg", "1e-4", "--mask_seen", "--ckpt_dir", str(tmp_path / "ckpt")])
+    losses = [float(x) for x in re.findall(r"Loss=([0-9.eE+-]+|nan)", caplog.text)]
+    assert len(losses) == 2 and all(math.isfinite(v) and v > 1.0 for v in losses), caplog.text      # (log of 301 items ~ 5.7)
+
+
+@pytest.mark.gpu
 def test_checkpoint_round_trip_resumes_the_same_trajectory(tmp_path):
     """save_checkpoint / load_checkpoint: parameters, Adam moments, step count and the dropout generator state — a restored
     model takes exactly the next step the original takes."""
