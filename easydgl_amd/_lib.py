@@ -149,6 +149,7 @@ SIGNATURES = {
     "edgl_add_pos2": (I, [P, P, P, I, I, I, P, I, P]),
     "edgl_tail_pack_elems": (L, [I]),
     "edgl_tail_supported": (I, [I, I, I]),
+    "edgl_tail_variant": (I, [I]),
     "edgl_tail_pack": (I, [P, P, P, P, I, P, P]),
     "edgl_tail_fwd": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, P, I, I, P, P, P, P, P, P, P, P, P, P, P,
                           P, P, I, P]),

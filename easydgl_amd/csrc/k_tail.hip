@@ -51,6 +51,7 @@ struct TailP {
     float *st1, *st2, *st3;
     int dhp, dht;   // channel-padded model (head dim dht stored as dhp, the padded channels all zero): the LayerNorms' moments are
                     // those of the real channels (edgl_tail_fwd_ct); 0, 0: none
+    int stagger;    // t2 kernels: the second half of the grid starts this many s_sleep(127) later (the two workgroups of a CU out of phase)
 };
 
 template <int CT>
@@ -863,6 +864,333 @@ __global__ __launch_bounds__(64 * CT) void tail_bwd_kernel(TailBwdP p) {
     PHB_FLUSH();
 }
 
+// =========================================================================================================================
+// Two workgroups per CU ("t2", C = 128, T <= 101): the same chain on HALF the CU.
+// The kernels above own a CU — 122 KB of LDS, 256 registers per wave — so the 512 samples of the benchmark run as two lock-stepped
+// rounds of 256 workgroups, every phase of a sample a dependent round trip (L2 / HBM / LDS hand-over / barrier) with nothing on
+// the CU to run in the gaps: 50-53 % of the wave cycles parked, the matrix pipe 6 % busy (DESIGN.md rule 53).  At C = 64 two of the
+// 4-wave workgroups already fit a CU, and there the second one costs 32 % more time, not 100 % (tools/tail_probe.py: 22.9 us for
+// 256 samples, 30.2 us for 512).  This form gives the C = 128 kernel the same second, independent chain:
+//   * three LDS images [101][128] bf16, UNPADDED (256-byte rows) with an XOR swizzle — 16-byte chunk c of row r at c ^ (r & 15) — in
+//     place of four padded ones + an f32 image: 3 x 25 856 + 256 + 4 096 = 81 920 bytes = half the CU's LDS.  The swizzle is
+//     conflict-free for all three access shapes: MFMA operand reads (16 lanes = 16 rows of one chunk column), the 8-byte quads of
+//     the accumulator layout (32 lanes = 16 rows x 2 halves of one chunk), whole rows (any permutation);
+//   * the f32 pre-activations of a GELU pass go through TWO of the images ([101][128] f32, same swizzle on its 16-byte chunks);
+//     the pass loads its values, and — where the f image lands in the staging area itself — waits for everybody's loads before
+//     storing (one more barrier per half of the hidden layer);
+//   * <= 128 registers (4 waves per SIMD): no operand is prefetched a whole segment ahead — the other workgroup of the CU is
+//     what runs while a load is in flight —, the LayerNorm inputs of the backward come straight from global memory in the
+//     accumulator layout (8 bytes per lane and row tile) instead of through LDS images held in registers one phase ahead.
+// Same arithmetic, in the same order, as the kernels above: the outputs are bit-identical (tests/test_gpu_tail2.py).
+// =========================================================================================================================
+namespace t2 {
+constexpr int C = 128, NTHR = 512, NKB = 4, TMAX = 101;
+constexpr int IMG = TMAX * 256;                                      // one bf16 image
+constexpr int OFF_RED = 3 * IMG, OFF_PAR = OFF_RED + 256;
+constexpr int PAR_BOUT = 0, PAR_G2 = 1, PAR_B2 = 2, PAR_G3 = 3, PAR_B3 = 4, PAR_BI = 5, PAR_BT = 7, NPAR = 8;      // (bi: two vectors)
+constexpr int SMEM_FWD = OFF_PAR + NPAR * C * 4;
+static_assert(SMEM_FWD == 81920, "two workgroups per CU");
+constexpr int OFF_ROWMAP = OFF_RED + 256, OFF_NEXTJ = OFF_ROWMAP + MAXRT * 16 * 4, OFF_MPOS = OFF_NEXTJ + 256 * 4;
+constexpr int SMEM_BWD = OFF_MPOS + 256 * 4;
+static_assert(SMEM_BWD <= 81920, "two workgroups per CU");
+
+struct Lane {
+    int lane, wave, q, l15, nl;
+    int frag[NKB];      // byte offset of this lane's MFMA operand chunk of k-block kb in row l15 of an image (+ rt * 4096)
+    int quad;           // byte offset of this lane's 4 channels in row l15 of an image (+ rt * 4096)
+    int squad;          // the same in the f32 staging image (+ rt * 8192)
+};
+__device__ __forceinline__ Lane make_lane() {
+    Lane L;
+    L.lane = threadIdx.x & 63; L.wave = threadIdx.x >> 6; L.q = L.lane >> 4; L.l15 = L.lane & 15; L.nl = L.wave * 16 + L.q * 4;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) L.frag[kb] = L.l15 * 256 + (((kb * 4 + L.q) ^ L.l15) << 4);
+    L.quad = L.l15 * 256 + (((L.wave * 2 + (L.q >> 1)) ^ L.l15) << 4) + ((L.q & 1) << 3);
+    L.squad = L.l15 * 512 + (((L.wave * 4 + L.q) ^ L.l15) << 4);
+    return L;
+}
+__device__ __forceinline__ int vec_off(int row, int cv) { return row * 256 + ((cv ^ (row & 15)) << 4); }
+
+// acc[rt] += W^T[16 output channels][128 k] . X[rows of tile rt][k] over a swizzled image.  Rows >= T of the last tile(s) read
+// whatever lies there (inside the workgroup's LDS): an MFMA output row depends on its own input row only, and every consumer
+// of rows >= T is guarded.
+template <int NRT>
+__device__ __forceinline__ void gemm(const WFrags<NKB>& wf, const char* img, const Lane& L, f32x4 (&acc)[MAXRT]) {
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+            acc[rt] = mma_kblock(wf.w[kb], *reinterpret_cast<const Vec16<bf16>*>(img + L.frag[kb] + rt * 4096), acc[rt]);
+        __builtin_amdgcn_sched_barrier(0);      // one row tile's operand reads in flight (16 registers)
+    }
+}
+template <int NRT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MAXRT]) {
+#pragma unroll
+    for (int rt = 0; rt < MAXRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// global [T, 128] (row stride ld) -> image; every load of BOTH images in flight before the first store (clamped tail vectors
+// repeat the last one: same data to the same address)
+__device__ __forceinline__ void copy_in2(char* d0, const bf16* s0, long ld0, char* d1, const bf16* s1, long ld1, int T) {
+    uint4 a[4], b[4];
+    const int nv = T * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = min((int)threadIdx.x + i * NTHR, nv - 1), row = v >> 4, cv = v & 15;
+        a[i] = *reinterpret_cast<const uint4*>(s0 + (long)row * ld0 + cv * 8);
+        b[i] = *reinterpret_cast<const uint4*>(s1 + (long)row * ld1 + cv * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = min((int)threadIdx.x + i * NTHR, nv - 1), row = v >> 4, cv = v & 15;
+        *reinterpret_cast<uint4*>(d0 + vec_off(row, cv)) = a[i];
+        *reinterpret_cast<uint4*>(d1 + vec_off(row, cv)) = b[i];
+    }
+}
+__device__ __forceinline__ void copy_out(bf16* dst, long ld, const char* img, int T) {
+    const int nv = T * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = threadIdx.x + i * NTHR, row = v >> 4, cv = v & 15;
+        if (v < nv) *reinterpret_cast<uint4*>(dst + (long)row * ld + cv * 8) = *reinterpret_cast<const uint4*>(img + vec_off(row, cv));
+    }
+}
+// accumulators (bias not yet added) -> f32 staging image, rows < T only (the image is exactly two bf16 images long)
+template <int NRT>
+__device__ __forceinline__ void stage_acc(char* stg, const f32x4 (&acc)[MAXRT], const Lane& L, int T) {
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+        if (rt * 16 + L.l15 < T)
+            *reinterpret_cast<float4*>(stg + L.squad + rt * 8192) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+}
+// GELU pass over the staging image: a thread owns 8 columns (cv) of rows rsub + 32 k.  dact = gelu'(pre) and act = gelu(pre) go to
+// global memory at once; act also into image `act_img` — behind a barrier when that image is part of the staging area (SYNC).
+template <bool SYNC>
+__device__ __forceinline__ void gelu_pass(const char* stg, const float* bias_g, bf16* dact_g, bf16* act_g, long ldg, char* act_img, int T) {
+    const int cv = threadIdx.x & 15, rsub = threadIdx.x >> 4;
+    const float4 b0 = *reinterpret_cast<const float4*>(bias_g + cv * 8), b1 = *reinterpret_cast<const float4*>(bias_g + cv * 8 + 4);
+    const int s0 = rsub * 512 + (((2 * cv) ^ (rsub & 15)) << 4);          // (r & 15 == rsub & 15 for r = rsub + 32 k)
+    uint4 keep0 = make_uint4(0, 0, 0, 0), keep1 = keep0, keep2 = keep0, keep3 = keep0;
+    // a ROLLED loop: unrolled, the scheduler interleaves the 32 erf chains of a thread (~80 registers; see gelu_pass above)
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const int r = rsub + 32 * k;
+        if (r < T) {
+            const float4 x0 = *reinterpret_cast<const float4*>(stg + s0 + k * 16384), x1 = *reinterpret_cast<const float4*>(stg + ((s0 + k * 16384) ^ 16));
+            const float x[8] = {x0.x + b0.x, x0.y + b0.y, x0.z + b0.z, x0.w + b0.w, x1.x + b1.x, x1.y + b1.y, x1.z + b1.z, x1.w + b1.w};
+            Vec16<bf16> dact, act;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float e;
+                const float cdf = 0.5f * (1.0f + erf_as(x[j] * 0.70710678118654752440f, e));
+                act.v[j] = from_f32<bf16>(x[j] * cdf);
+                dact.v[j] = from_f32<bf16>(cdf + x[j] * (0.39894228040143267794f * e));
+                // two erf chains in flight, not eight: at four waves per SIMD the other waves hide a chain's latency, and the
+                // registers of six more chains are what this kernel does not have
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            st16<bf16>(dact_g + (long)r * ldg + cv * 8, dact);
+            st16<bf16>(act_g + (long)r * ldg + cv * 8, act);
+            const uint4 a = *reinterpret_cast<const uint4*>(&act);
+            if (!SYNC) *reinterpret_cast<uint4*>(act_img + vec_off(r, cv)) = a;
+            else if (k == 0) keep0 = a;
+            else if (k == 1) keep1 = a;
+            else if (k == 2) keep2 = a;
+            else keep3 = a;
+        }
+    }
+    if (SYNC) {
+        lds_barrier();                      // everybody's staging reads are done: the image may overwrite the staging area
+        if (rsub < T) *reinterpret_cast<uint4*>(act_img + vec_off(rsub, cv)) = keep0;
+        if (rsub + 32 < T) *reinterpret_cast<uint4*>(act_img + vec_off(rsub + 32, cv)) = keep1;
+        if (rsub + 64 < T) *reinterpret_cast<uint4*>(act_img + vec_off(rsub + 64, cv)) = keep2;
+        if (rsub + 96 < T) *reinterpret_cast<uint4*>(act_img + vec_off(rsub + 96, cv)) = keep3;
+    }
+}
+
+// "No load behind a store": loads and stores share ONE in-order counter (vmcnt) on this part, so waiting for a load also waits for every
+// store issued before it — behind a copy_out or a GELU pass that is a full HBM write acknowledge (2-3 us with 512 workgroups storing
+// at once), and a sample has ten such batches.  Hence: the three parameter vectors used before the first store batches go to
+// registers in the prologue, the others wait in the LDS table, and a product's weight fragments are requested BEFORE the store
+// batch in front of it and their wait pinned (touch_regs) in front of that batch's first store — except where 16 more registers do
+// not exist (the out-dense fragments of the second hidden half: one load behind the GELU pass's stores per sample).
+template <int NRT>
+__global__ __launch_bounds__(NTHR, 4) void tail2_fwd_kernel(TailP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const P = smem; char* const Q = smem + IMG; char* const R = smem + 2 * IMG;
+    float* red = reinterpret_cast<float*>(smem + OFF_RED);
+    float* par = reinterpret_cast<float*>(smem + OFF_PAR);
+    const int b = blockIdx.x, T = p.T;
+    if (p.stagger > 0 && 2 * b >= (int)gridDim.x)
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    const Lane L = make_lane();
+    const int n0 = L.wave * 16, nl = L.nl, l15 = L.l15;
+    const long row0 = (long)b * T;
+    const ChanPad cpad = chan_pad<8>(nl, p.dhp, p.dht);
+    if ((int)threadIdx.x < C) {
+        const int c = threadIdx.x;
+        const float *g3_or = p.head ? p.g3 : p.g1, *b3_or = p.head ? p.b3 : p.b1, *bt_or = p.head ? p.bt : p.bo;
+        const float x0 = p.bout[c], x1 = p.g2[c], x2 = p.b2[c], x3 = g3_or[c], x4 = b3_or[c], x5 = p.bi[c], x6 = p.bi[C + c], x7 = bt_or[c];
+        par[PAR_BOUT * C + c] = x0; par[PAR_G2 * C + c] = x1; par[PAR_B2 * C + c] = x2; par[PAR_G3 * C + c] = x3;
+        par[PAR_B3 * C + c] = x4; par[PAR_BI * C + c] = x5; par[(PAR_BI + 1) * C + c] = x6; par[PAR_BT * C + c] = x7;
+    }
+    const float4 v_bo = *reinterpret_cast<const float4*>(p.bo + nl);
+    const float4 v_g1 = *reinterpret_cast<const float4*>(p.g1 + nl), v_b1 = *reinterpret_cast<const float4*>(p.b1 + nl);
+    WFrags<NKB> wf = load_wfrags<NKB>(p.WoT + (long)n0 * C, C, L.lane);      // att_out dense
+    copy_in2(P, p.att + row0 * C, C, Q, p.xin + row0 * p.ld_x, p.ld_x, T);
+    const DropKey dk1 = make_dropkey(p.rng, p.sid1, p.rate), dk2 = make_dropkey(p.rng, p.sid2, p.rate);     // (wave-uniform: scalar registers)
+    // first round of the head's row gather: position and destination row of this thread's vector (later rounds load theirs in the loop)
+    int gat_t = 0; long gat_dst = -1;
+    if (p.head) {
+        const int j = min((int)threadIdx.x, p.M * 16 - 1) >> 4;
+        const long src = (long)b * p.M + j;
+        gat_t = (int)p.mpos[src];
+        gat_dst = p.hmap ? (long)p.hmap[src] : src;
+    }
+    const uint64_t idx0 = (uint64_t)((row0 + l15) * C + nl);       // dropout element index of this lane's quad in row tile 0 (+ rt * 16 * C)
+    lds_barrier();
+    float z[MAXRT][4];
+    f32x4 acc[MAXRT];
+    // ---- ao = att.Wo + bo ; z1 = drop(ao) + x_in (EasyDGL.py:113-115): att in P, x_in in Q, ao -> R ---------------------------------
+    zero_acc<NRT>(acc);
+    gemm<NRT>(wf, P, L, acc);
+    wf = load_wfrags<NKB>(p.WiT + (long)n0 * C, C, L.lane);                   // inner dense, first half (used behind two store batches)
+    {
+        const float bv[4] = {v_bo.x, v_bo.y, v_bo.z, v_bo.w};
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int row = rt * 16 + l15;
+            float v[4], xr[4], dv[4];
+            ld_bf4(reinterpret_cast<const bf16*>(Q + L.quad + rt * 4096), xr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = rbf(acc[rt][r] + bv[r]); dv[r] = v[r]; }
+            drop_apply4(dk1, idx0 + (uint64_t)(rt * 16 * C), dv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[rt][r] = dv[r] + xr[r];
+            if (row < T) st_bf4(reinterpret_cast<bf16*>(R + L.quad + rt * 4096), v);
+        }
+    }
+    lds_barrier();
+    touch_regs(wf);                  // every load so far has arrived: stores may start
+    copy_out(p.ao + row0 * C, C, R, T);
+    // ---- a1 = LN1(z1) (EasyDGL.py:116) -> P (att is consumed) ---------------------------------------------------------------------------
+    {
+        float mean, rstd;
+        joint_moments<8>(z, NRT, T, L.lane, red, mean, rstd, cpad);
+        if (threadIdx.x == 0) { p.st1[2 * b] = mean; p.st1[2 * b + 1] = rstd; }
+        const float gv[4] = {v_g1.x, v_g1.y, v_g1.z, v_g1.w}, ev[4] = {v_b1.x, v_b1.y, v_b1.z, v_b1.w};
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (z[rt][r] - mean) * rstd * gv[r] + ev[r];
+            if (rt * 16 + l15 < T) st_bf4(reinterpret_cast<bf16*>(P + L.quad + rt * 4096), v);
+        }
+    }
+    lds_barrier();
+    copy_out(p.a1 + row0 * C, C, P, T);
+    // ---- f = gelu(a1.Wi + bi), two halves of C hidden channels; o accumulates f.Wout half by half (EasyDGL.py:120-125) ----------------
+    f32x4 acc3[MAXRT];
+    zero_acc<NRT>(acc3);
+    {   // first half: a1 . Wi[:, :C] -> staging Q + R (x_in / ao: consumed) -> f half in R -> acc3 = f . Wout[:C, :]
+        zero_acc<NRT>(acc);
+        gemm<NRT>(wf, P, L, acc);
+        stage_acc<NRT>(Q, acc, L, T);
+        WFrags<NKB> wo = load_wfrags<NKB>(p.WoutT + (long)n0 * 2 * C, 2 * C, L.lane);     // out dense, inputs of the first half
+        wf = load_wfrags<NKB>(p.WiT + (long)(C + n0) * C, C, L.lane);                     // inner dense, second half
+        lds_barrier();
+        touch_regs(wo); touch_regs(wf);          // (acc3 is not live yet: both sets fit across the pass)
+        gelu_pass<true>(Q, par + PAR_BI * C, p.pre_f + row0 * 2 * C, p.f + row0 * 2 * C, 2 * C, R, T);
+        lds_barrier();
+        gemm<NRT>(wo, R, L, acc3);
+    }
+    {   // second half
+        zero_acc<NRT>(acc);
+        gemm<NRT>(wf, P, L, acc);
+        lds_barrier();                               // the first half's f image (R) is still the operand of somebody's product
+        stage_acc<NRT>(Q, acc, L, T);
+        lds_barrier();
+        gelu_pass<true>(Q, par + (PAR_BI + 1) * C, p.pre_f + row0 * 2 * C + C, p.f + row0 * 2 * C + C, 2 * C, R, T);
+        wf = load_wfrags<NKB>(p.WoutT + (long)n0 * 2 * C + C, 2 * C, L.lane);       // out dense, second half (behind the pass's stores: no registers for it earlier)
+        lds_barrier();
+        gemm<NRT>(wf, R, L, acc3);
+    }
+    if (p.head) wf = load_wfrags<NKB>(p.WtT + (long)n0 * C, C, L.lane);       // head transform
+    // ---- o = . + bout ; z2 = drop(o) + a1 ; y = LN2(z2) (EasyDGL.py:126-128): o -> Q, y -> R ------------------------------------------------
+    {
+        const float4 v_bout = *reinterpret_cast<const float4*>(par + PAR_BOUT * C + nl);
+        const float bv[4] = {v_bout.x, v_bout.y, v_bout.z, v_bout.w};
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int row = rt * 16 + l15;
+            float v[4], xr[4], dv[4];
+            ld_bf4(reinterpret_cast<const bf16*>(P + L.quad + rt * 4096), xr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = rbf(acc3[rt][r] + bv[r]); dv[r] = v[r]; }
+            drop_apply4(dk2, idx0 + (uint64_t)(rt * 16 * C), dv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[rt][r] = dv[r] + xr[r];
+            if (row < T) st_bf4(reinterpret_cast<bf16*>(Q + L.quad + rt * 4096), v);
+        }
+    }
+    lds_barrier();
+    if (p.head) touch_regs(wf);
+    copy_out(p.o + row0 * C, C, Q, T);
+    {
+        float mean, rstd;
+        joint_moments<8>(z, NRT, T, L.lane, red, mean, rstd, cpad);
+        if (threadIdx.x == 0) { p.st2[2 * b] = mean; p.st2[2 * b + 1] = rstd; }
+        const float4 v_g = *reinterpret_cast<const float4*>(par + PAR_G2 * C + nl), v_b = *reinterpret_cast<const float4*>(par + PAR_B2 * C + nl);
+        const float gv[4] = {v_g.x, v_g.y, v_g.z, v_g.w}, ev[4] = {v_b.x, v_b.y, v_b.z, v_b.w};
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (z[rt][r] - mean) * rstd * gv[r] + ev[r];
+            if (rt * 16 + l15 < T) st_bf4(reinterpret_cast<bf16*>(R + L.quad + rt * 4096), v);
+        }
+    }
+    lds_barrier();
+    copy_out(p.y + row0 * C, C, R, T);
+    if (!p.head) return;
+    // ---- head: so = gelu(y.Wt + bt) ; rows = LN3(so)[masked positions] (EasyDGL.py:136-146): staging = P + Q, so -> R, rows -> Q ----------
+    zero_acc<NRT>(acc);
+    gemm<NRT>(wf, R, L, acc);
+    stage_acc<NRT>(P, acc, L, T);                    // (a1 and o are consumed: every wave is past the barrier behind LN2)
+    lds_barrier();                                   // ... which also says that nobody reads y (R) any more
+    gelu_pass<false>(P, par + PAR_BT * C, p.pre_t + row0 * C, p.so + row0 * C, C, R, T);
+    lds_barrier();
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) ld_bf4(reinterpret_cast<const bf16*>(R + L.quad + rt * 4096), z[rt]);   // so, rounded through the activation dtype
+    {
+        float mean, rstd;
+        joint_moments<8>(z, NRT, T, L.lane, red, mean, rstd, cpad);
+        if (threadIdx.x == 0) { p.st3[2 * b] = mean; p.st3[2 * b + 1] = rstd; }
+        const float4 v_g = *reinterpret_cast<const float4*>(par + PAR_G3 * C + nl), v_b = *reinterpret_cast<const float4*>(par + PAR_B3 * C + nl);
+        const float gv[4] = {v_g.x, v_g.y, v_g.z, v_g.w}, ev[4] = {v_b.x, v_b.y, v_b.z, v_b.w};
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (z[rt][r] - mean) * rstd * gv[r] + ev[r];
+            if (rt * 16 + l15 < T) st_bf4(reinterpret_cast<bf16*>(Q + L.quad + rt * 4096), v);
+        }
+    }
+    lds_barrier();
+    // batch_gather of the masked positions (EasyDGL.py:142-143); dst: row compaction of the scoring (edgl_compact_scan's `inv`)
+    if ((int)threadIdx.x < p.M * 16 && gat_dst >= 0)
+        *reinterpret_cast<uint4*>(p.hrows + gat_dst * C + (threadIdx.x & 15) * 8) = *reinterpret_cast<const uint4*>(Q + vec_off(gat_t, threadIdx.x & 15));
+    for (int v = threadIdx.x + NTHR; v < p.M * 16; v += NTHR) {
+        const int j = v >> 4, cv = v & 15;
+        const long src = (long)b * p.M + j;
+        const int t = (int)p.mpos[src];
+        const long dst = p.hmap ? (long)p.hmap[src] : src;
+        if (dst >= 0) *reinterpret_cast<uint4*>(p.hrows + dst * C + cv * 8) = *reinterpret_cast<const uint4*>(Q + vec_off(t, cv));
+    }
+}
+
+}  // namespace t2
+
 // dst[n][k] = src[k][n]  (tf.layers.dense kernels are [in, out]; the MFMA A operand wants k contiguous)
 __global__ void tail_pack_kernel(const bf16* Wo, const bf16* Wi, const bf16* Wout, const bf16* Wt, int C, bf16* pack) {
     const long cc = (long)C * C;
@@ -879,6 +1207,22 @@ __global__ void tail_pack_kernel(const bf16* Wo, const bf16* Wi, const bf16* Wou
 }
 
 }  // namespace
+
+// EDGL_TAIL2=0 / edgl_tail_variant(0): the one-workgroup-per-CU kernels for every shape (A/B switch)
+static int g_tail2 = -1;
+static bool tail2_enabled() {
+    if (g_tail2 < 0) { const char* e = getenv("EDGL_TAIL2"); g_tail2 = (e && e[0] == '0') ? 0 : 1; }
+    return g_tail2 != 0;
+}
+static int tail2_stagger() {
+    static const int v = [] { const char* e = getenv("EDGL_TAIL2_STAGGER"); return e ? atoi(e) : 0; }();
+    return v;
+}
+extern "C" int edgl_tail_variant(int variant) {
+    const int prev = tail2_enabled() ? 1 : 0;
+    if (variant >= 0) g_tail2 = variant ? 1 : 0;
+    return prev;
+}
 
 extern "C" long edgl_tail_pack_elems(int C) { return 6L * C * C; }
 
@@ -913,9 +1257,16 @@ extern "C" int edgl_tail_fwd_ct(const void* att, const void* xin, int ld_x, cons
     const long cc = (long)C * C;
     TailP p{(const bf16*)att, (const bf16*)xin, ld_x, pk, pk + cc, pk + 3 * cc, pk + 5 * cc, bo, bi, bout, bt, g1, b1, g2, b2, g3, b3,
             B, T, C, drop_rate, rng_state, sid1, sid2, masked_pos, M, head, hrow_map, (bf16*)ao, (bf16*)a1, (bf16*)pre_f, (bf16*)f, (bf16*)o,
-            (bf16*)y, (bf16*)pre_t, (bf16*)so, (bf16*)hrows, st1, st2, st3, dh_pad, dh_true};
+            (bf16*)y, (bf16*)pre_t, (bf16*)so, (bf16*)hrows, st1, st2, st3, dh_pad, dh_true, tail2_stagger()};
     hipStream_t st = (hipStream_t)stream;
     const int nrt = (T + 15) / 16;
+    if (tail2_enabled() && C == 128 && T <= t2::TMAX) {      // two workgroups per CU (see namespace t2)
+        auto k2 = nrt <= 2 ? t2::tail2_fwd_kernel<2> : nrt <= 4 ? t2::tail2_fwd_kernel<4> : t2::tail2_fwd_kernel<MAXRT>;
+        hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, t2::SMEM_FWD);
+        hipLaunchKernelGGL(k2, dim3(B), dim3(t2::NTHR), t2::SMEM_FWD, st, p);
+        EDGL_LAUNCH_CHECK();
+        return EDGL_OK;
+    }
     auto k = C == 128 ? (nrt <= 2 ? tail_fwd_kernel<8, 2> : nrt <= 4 ? tail_fwd_kernel<8, 4> : tail_fwd_kernel<8, MAXRT>)
                       : (nrt <= 2 ? tail_fwd_kernel<4, 2> : nrt <= 4 ? tail_fwd_kernel<4, 4> : tail_fwd_kernel<4, MAXRT>);
     const size_t smem = C == 128 ? TailGeom<8>::SMEM_FWD : TailGeom<4>::SMEM_FWD;

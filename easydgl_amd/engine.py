@@ -460,7 +460,7 @@ class TrainEngine:
         if not self.blk:
             main.wait_event(ev_pack)
         if not (self.fused_tail and self.blk):
-            self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, C, C, gelu=True, pre=self.pre_t)
+            self._dense_fwd(x, m.transform.kernel, m.transform.bias, self.so, cin, C, gelu=True, pre=self.pre_t)   # (no block: cin = 3C)
             self._ln_fwd(self.so, None, 0, m.transform_ln, ops.NO_DROP, self.hrows, self.st3, gpos=self.mpos)
         # rows whose label is 0 have weight 0 (EasyDGL.py:180): score only the weighted ones
         if not (self.fused_tail and self.blk):   # the fused tail writes its head rows compacted (row map = inv)
@@ -571,15 +571,15 @@ class TrainEngine:
             check(lib.edgl_score_ce_bwd(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
                                         _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), _ptr(self.d_rows), _ptr(tab.grad),
                                         _ptr(m.output_bias.grad), _ptr(self.ws), code, st), "edgl_score_ce_bwd")
-        y_last = self.blk[-1]["y"] if self.blk else self.x0
+        y_last, c_last = (self.blk[-1]["y"], C) if self.blk else (self.x0, 3 * C)    # (no block: the head reads the 3C-wide encoder output)
         if not (self.fused_tail and self.blk):
             # head: LN (gathered rows) -> gelu' -> dense
             # the GELU' of the head transform rides in the LayerNorm backward (G1 = gradient w.r.t. the dense pre-activation)
             self._ln_bwd(self.so, None, 0, m.transform_ln, self.st3, self.d_rows, ops.NO_DROP, self.G1, None, gpos=self.mpos,
                          rowmap=self.inv, act_pre=self.pre_t)
-            self._dense_dw(y_last, self.G1, m.transform.kernel, m.transform.bias, C, C)
-            self._dense_dx(self.G1, m.transform.kernel, self.G2, C, C)
-        dY = self.G2
+            self._dense_dw(y_last, self.G1, m.transform.kernel, m.transform.bias, c_last, C)
+            self._dense_dx(self.G1, m.transform.kernel, self.G2 if self.blk else self.G3c, c_last, C)
+        dY = self.G2 if self.blk else self.G3c
         for i in reversed(range(len(self.blk))):
             blk, b = m.layers[i], self.blk[i]
             x_in, cin = (self.x0, 3 * C) if i == 0 else (self.blk[i - 1]["y"], C)

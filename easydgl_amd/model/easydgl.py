@@ -108,7 +108,12 @@ class EasyDGL(Sequential):
         for i in range(FLAGS.num_blocks):
             self.layers.append(_Block(3 * C_ if i == 0 else C_, C_, self.num_heads, self.num_events,
                                       self.attention_probs_dropout_rate, gen))
-        self.transform = _Dense(C_, C_, gen)       # cls/predictions/transform/dense
+        if FLAGS.num_blocks == 0 and self.pad[0]:
+            raise ValueError("EasyDGL: --num_blocks 0 with a channel-padded width is not supported (the head transform would read the "
+                             "padded 3C-wide encoder output)")
+        # (no block: the head transform reads the 3C-wide encoder output — tf.layers.dense builds its kernel from the input width,
+        #  EasyDGL.py:138)
+        self.transform = _Dense(3 * C_ if FLAGS.num_blocks == 0 else C_, C_, gen)       # cls/predictions/transform/dense
         self.transform_ln = _LayerNorm(C_)         # cls/predictions/transform/LayerNorm
         self._metrics = None
         if self.pad[0]:

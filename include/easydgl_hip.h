@@ -711,6 +711,12 @@ int edgl_time_function_bwd(const float* x, long n, const float* freq, const floa
  * copies) — their [out][in] images, the MFMA operand layout. */
 long edgl_tail_pack_elems(int C);
 int edgl_tail_supported(int T, int C, int dtype);
+/* Launch form of edgl_tail_fwd / edgl_tail_bwd at C = 128, T <= 101 (same results, bit for bit): 1 (default) = TWO 8-wave
+ * workgroups per CU (three unpadded, swizzled LDS images = 80 KB, <= 128 registers: a second independent chain of dependent
+ * phases on every CU), 0 = one workgroup per CU (four padded images + an f32 image, 256 registers — the form of every other
+ * shape).  variant < 0 only queries.  Returns the previous value.  Initial value: environment EDGL_TAIL2 (unset = 1).
+ * Process-wide, not thread-safe against concurrent launches: a development / A-B switch. */
+int edgl_tail_variant(int variant);
 int edgl_tail_pack(const void* Wo, const void* Wi, const void* Wout, const void* Wt, int C, void* pack, void* stream);
 int edgl_tail_fwd(const void* att, const void* xin, int ld_x, const void* pack, const float* bo, const float* bi,
                   const float* bout, const float* bt, const float* g1, const float* b1, const float* g2,

@@ -123,7 +123,8 @@ def init_params(cfg: Config, rng: np.random.Generator, perturb: bool = False) ->
         p[pre + "output/dense/bias"] = small((C,))
         p[pre + "output/LayerNorm/beta"] = small((C,))
         p[pre + "output/LayerNorm/gamma"] = small((C,), 1.0)
-    p["cls/predictions/transform/dense/kernel"] = glorot_uniform(rng, (C, C))
+    # (EasyDGL.py:138: tf.layers.dense sizes its kernel by the input — the 3C-wide encoder output when there is no block)
+    p["cls/predictions/transform/dense/kernel"] = glorot_uniform(rng, (3 * C if cfg.num_blocks == 0 else C, C))
     p["cls/predictions/transform/dense/bias"] = small((C,))
     p["cls/predictions/transform/LayerNorm/beta"] = small((C,))
     p["cls/predictions/transform/LayerNorm/gamma"] = small((C,), 1.0)

@@ -15,7 +15,9 @@ CASES = [dict(), dict(num_units=64, num_heads=2, num_blocks=1, seqslen=30, maskl
          # more than 16 mark types in the STATIC engine: mark groups inside the fixed launch sequence (16 + 8 at dh = 16, two
          # blocks; 16 + 16 + 8 at dh = 64) — EasyDGL.py:45-46 takes E from the data set's mark.pkl
          dict(num_units=64, num_heads=4, num_blocks=2, seqslen=20, masklen=5, num_events=24, num_items=300),
-         dict(num_units=128, num_heads=2, num_blocks=1, seqslen=18, masklen=4, num_events=40, num_items=200)]
+         dict(num_units=128, num_heads=2, num_blocks=1, seqslen=18, masklen=4, num_events=40, num_items=200),
+         # no block at all: the head transform reads the 3C-wide encoder output (EasyDGL.py:138 sizes its dense kernel by the input)
+         dict(num_units=64, num_heads=2, num_blocks=0, seqslen=30, masklen=6, num_events=7, num_items=300)]
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
