@@ -441,7 +441,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"EasyDGL optimizer step, per-GPU batch {c['batch']}, seqslen {c['seqslen']} (T={T}), num_units {C}, {h} heads, "
                                    f"{nb} block, num_items {c['num_items']} (I={I}), masklen {M}, {E} marks, dropout 0.1/0.1, ct_reg 1e-7, l2 1e-4",
-                       "global_batch": world * c["batch"], "parallelism": f"dp{world}",
+                       "global_batch": world * c["batch"], "parallelism": f"dp{world}", "allreduce": res.get("allreduce"),
                        "padding": res.get("padding"),
                        "loss_mode": ("joined in front of every optimizer launch (TrainEngine.sync_loss = True)" if sync_loss else
                                      "deferred: the loss launches of step n are issued with step n+1, read once behind the timed steps "
@@ -638,9 +638,25 @@ def run_step_workload(c, args, dev, rank, world, dist, steps, warmup, bracket=Fa
         first = torch.where(nz.any(dim=1), nz.to(torch.int64).argmax(dim=1), torch.full((ids.shape[0],), ids.shape[1], device=ids.device))
         pad_pos += int((~nz).sum().item()); n_pos += ids.numel()
         pad_tiles += int((first // 16).sum().item()); n_tiles += ids.shape[0] * ((ids.shape[1] + 15) // 16)
+    # N > 1: what the step's ONE collective costs where it stands — the SUM all-reduce of the flat f32 gradient arena between the last
+    # backward kernel and the optimizer, nothing beside it (the item table's gradient receives the embedding scatter's rows in the last
+    # kernel of the backward: DESIGN.md §6) — HIP events around it on 6 further steps OUTSIDE the timed region
+    ar = None
+    if world > 1 and eng is not None:
+        eng._ar_events = []
+        for i in range(6):
+            step(warmup + steps + i)
+        eng.join_loss()
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b_) for a, b_ in eng._ar_events][1:]
+        eng._ar_events = None
+        ar = {"allreduce_bytes_per_rank": int(model._grad_comm.numel() * 4), "allreduce_exposed_ms": round(float(np.mean(ms)), 4) if ms else None,
+              "allreduce_exposed_share_of_step": round(float(np.mean(ms)) / (dt / steps * 1e3), 4) if ms else None,
+              "note": "one SUM all-reduce per step, fully exposed (measured with HIP events on 5 steps behind the timed region); "
+                      "EDGL_BENCH_BACKEND=gloo stages it through the host"}
     padding = {"positions_with_id_0": round(pad_pos / max(1, n_pos), 4), "key_tiles_bimau_can_skip": round(pad_tiles / max(1, n_tiles), 4),
                "note": "the reference's masker draws masked positions over padding too (dataloader.py:187-191): MASK tokens are real keys"}
-    return {"padding": padding, "dt": dt, "t_issue": t_issue, "loss": loss, "rows_w": rows_w, "dom": dom, "step_ms": step_ms, "step": step, "model": model,
+    return {"padding": padding, "allreduce": ar, "dt": dt, "t_issue": t_issue, "loss": loss, "rows_w": rows_w, "dom": dom, "step_ms": step_ms, "step": step, "model": model,
             "engine": None if args.path == "autograd" else eng}
 
 

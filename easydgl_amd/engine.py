@@ -884,7 +884,13 @@ class TrainEngine:
             self._issue(lazy_loss=not distributed and os.environ.get("EDGL_LAZY_LOSS", "1") != "0")
             out = self.loss
             if distributed:
+                evs = getattr(self, "_ar_events", None)      # bench.py: HIP events around the step's one collective (its EXPOSED time:
+                if evs is not None:                         # nothing of the step runs beside it — the last gradients are final only now)
+                    e0 = torch.cuda.Event(enable_timing=True); e0.record()
                 out = self._dp_allreduce()
+                if evs is not None:
+                    e1 = torch.cuda.Event(enable_timing=True); e1.record()
+                    evs.append((e0, e1))
             self._optimizer()
             if self.sync_loss:      # the returned loss is ordered on the current stream (False: the caller calls join_loss() / syncs)
                 self.join_loss()

@@ -419,6 +419,37 @@ def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False, nvalid
     return lse, lab_logit, logits
 
 
+def vocab_parallel_ce(rows, table_c, out_bias, labels, group=None):
+    """parallel.vocab_parallel_ce with the HIP scoring kernels: every rank holds the same rows [R, C] / labels [R] and scores them
+    against its row shard of the (replicated, un-scaled, tied) item table — edgl_score_lse_fwd / edgl_score_ce_bwd over the item
+    range [i0, i1) with the GLOBAL log-sum-exp (the two-pass kernels; the strip form finishes its rows with a local sum and would
+    need a finish kernel that takes the gathered sums).  Returns (loss, d_rows [R, C] f32, d_table [I, C] f32 — zero outside the
+    rank's shard —, d_bias [I - 1] f32 — zero outside it —, (i0, i1)).  EasyDGL.py:149-155,177-185."""
+    from . import parallel
+    rows = rows.contiguous()
+    labels = labels.reshape(-1).contiguous()
+    R, C = rows.shape
+    I = table_c.shape[0]
+    dev, code, st = rows.device, _code(rows), _stream()
+    d_table = torch.zeros((I, C), device=dev, dtype=torch.float32)
+    d_bias = torch.zeros(I - 1, device=dev, dtype=torch.float32)
+
+    def lse_local(i0, i1):
+        lse, lab, _ = score_lse(rows, table_c, out_bias, labels, i0, i1)
+        own = (labels >= i0) & (labels < i1)
+        return lse, torch.where(own, lab, torch.full_like(lab, float("-inf")))
+
+    def grad_local(i0, i1, lse, coef):
+        d_rows = torch.empty_like(rows)
+        ws = torch.empty(int(lib.edgl_score_bwd_workspace(R, C, I, i1 - i0, code)), device=dev, dtype=torch.float32)
+        check(lib.edgl_score_ce_bwd(_ptr(rows), _ptr(table_c), _ptr(out_bias), _ptr(labels), _ptr(lse), _ptr(coef), None, R, C, I,
+                                    i0, i1, None, _ptr(d_rows), _ptr(d_table), _ptr(d_bias), _ptr(ws), code, st), "edgl_score_ce_bwd")
+        return d_rows
+
+    loss, d_rows, (i0, i1) = parallel.vocab_parallel_ce(labels, I, lse_local, grad_local, group)
+    return loss, d_rows, d_table, d_bias, (i0, i1)
+
+
 class ScoreCEFn(torch.autograd.Function):
     """EasyDGL.py:149-155,177-185 without the [R, I] logits tensor.  Rows with label 0 carry weight 0
     (EasyDGL.py:180); they are compacted away before scoring, which changes neither loss nor gradients.

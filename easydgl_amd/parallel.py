@@ -64,3 +64,47 @@ def allreduce_sum_(flat_grad: torch.Tensor, group: Optional[dist.ProcessGroup] =
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+
+
+def vocab_parallel_ce(labels: torch.Tensor, num_rows: int,
+                      lse_local: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]],
+                      grad_local: Callable[[int, int, torch.Tensor, torch.Tensor], torch.Tensor],
+                      group: Optional[dist.ProcessGroup] = None):
+    """Tied-embedding scoring + cross-entropy (EasyDGL.py:149-155,177-185) with the ITEM TABLE ROW-SHARDED over the ranks
+    (SURVEY §8(e) row 3): every rank holds the same R scoring rows and labels and scores them against its shard [i0, i1) only.
+
+      lse_local(i0, i1)              -> (lse_loc [R] f32: log-sum-exp of the row's logits over the shard,
+                                         lab_loc [R] f32: the label's logit where i0 <= label < i1, -inf elsewhere)
+      ONE packed all-gather of [R, 2] f32 per rank  ->  lse = log-sum-exp over the shards, lab = the owner's label logit
+      loss = sum_r w_r (-log(p_y + 1e-5)) / (sum_r w_r + 1e-5),  p_y = exp(lab - lse),  w_r = [label_r != 0]     (the +1e-5 twice: :155, :184)
+      coef_r = (w_r / W) p_y / (p_y + 1e-5)
+      grad_local(i0, i1, lse, coef)  -> d_rows_loc [R, C]: dl . table[i0:i1] with dl = coef (softmax - onehot) on the shard's columns,
+                                         and writes the shard's OWN d_table[i0:i1] / d_bias (no collective: a rank owns its rows' gradient)
+      ONE SUM all-reduce of d_rows_loc (f32)  ->  d_rows
+
+    Returns (loss 0-d f32, d_rows [R, C] f32, (i0, i1)).  world size 1: no collective.  The callables are injected so that the protocol
+    runs on CPU under gloo with the oracle's arithmetic (tests/test_distributed_cpu.py); ops.vocab_parallel_ce passes the HIP kernels."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    i0, i1 = shard_bounds(num_rows, world, rank)
+    lse_loc, lab_loc = lse_local(i0, i1)
+    if world > 1:
+        R = lse_loc.shape[0]
+        packed = torch.stack([lse_loc.to(torch.float32), lab_loc.to(torch.float32)], dim=1).contiguous()
+        flat = torch.empty((world * R, 2), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(flat, packed, group=group)
+        g = flat.view(world, R, 2)
+        m = g[:, :, 0].max(dim=0).values
+        lse = m + torch.log(torch.exp(g[:, :, 0] - m).sum(dim=0))
+        lab = g[:, :, 1].max(dim=0).values                        # exactly one shard owns a label: every other entry is -inf
+    else:
+        lse, lab = lse_loc.to(torch.float32), lab_loc.to(torch.float32)
+    w = (labels.reshape(-1) != 0).to(lse.dtype)
+    W = w.sum() + 1e-5
+    p_y = torch.exp(lab - lse)
+    loss = (w * -torch.log(p_y + 1e-5)).sum() / W
+    coef = (w / W) * p_y / (p_y + 1e-5)
+    d_rows = grad_local(i0, i1, lse.contiguous(), coef.contiguous()).to(torch.float32).contiguous()
+    if world > 1:
+        dist.all_reduce(d_rows, op=dist.ReduceOp.SUM, group=group)
+    return loss, d_rows, (i0, i1)

@@ -142,3 +142,116 @@ def test_data_parallel_with_a_rank_that_holds_no_weighted_row():
     for r in range(world):
         ok, _, err, err_naive = out[r]
         assert ok, (r, err, err_naive)
+
+
+def _vp_problem(R=37, C=16, I=203, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    rows = torch.randn((R, C), generator=g, dtype=torch.float64) * 0.7
+    table = torch.randn((I, C), generator=g, dtype=torch.float64) * 0.5
+    table[0] = 0.0                                        # coding.py:56-57: row 0 of the used table is the zero constant
+    bias = torch.randn(I - 1, generator=g, dtype=torch.float64) * 0.3
+    labels = torch.randint(1, I, (R,), generator=g)
+    labels[::5] = 0                                       # weight-0 rows (EasyDGL.py:180)
+    labels[1] = I - 1; labels[2] = 1                      # both ends of the catalogue
+    return rows, table, bias, labels
+
+
+def _vp_reference(rows, table, bias, labels):
+    """EasyDGL.py:149-155,177-185 unsharded, by autograd in float64."""
+    rows = rows.clone().requires_grad_(True); table = table.clone().requires_grad_(True); bias = bias.clone().requires_grad_(True)
+    used = torch.cat([torch.zeros_like(table[:1]), table[1:]])
+    logits = rows @ used.T + torch.cat([torch.full((1,), -1000.0, dtype=torch.float64), bias])
+    p = torch.softmax(logits, dim=-1)
+    w = (labels != 0).double()
+    loss = (w * -torch.log(p[torch.arange(len(labels)), labels] + 1e-5)).sum() / (w.sum() + 1e-5)
+    loss.backward()
+    return loss.detach(), rows.grad, table.grad, bias.grad
+
+
+def _vp_worker(rank, world, port, out):
+    """parallel.vocab_parallel_ce with float64 callables: the sharded protocol — ONE packed all-gather of
+    (log-sum-exp, label logit), ONE all-reduce of d_rows, the table / bias gradients owned by the shard — against the unsharded
+    autograd loss and every gradient."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from easydgl_amd import parallel as P
+    rows, table, bias, labels = _vp_problem()
+    I = table.shape[0]
+    full_bias = torch.cat([torch.full((1,), -1000.0, dtype=torch.float64), bias])
+    d_table, d_bias_full = torch.zeros_like(table), torch.zeros(I, dtype=torch.float64)
+    calls = {"gather": 0, "reduce": 0}
+    ag, ar = dist.all_gather_into_tensor, dist.all_reduce
+
+    def count_ag(*a, **k):
+        calls["gather"] += 1
+        return ag(*a, **k)
+
+    def count_ar(*a, **k):
+        calls["reduce"] += 1
+        return ar(*a, **k)
+    dist.all_gather_into_tensor, dist.all_reduce = count_ag, count_ar
+
+    def lse_local(i0, i1):
+        lg = rows @ table[i0:i1].T + full_bias[i0:i1]
+        own = (labels >= i0) & (labels < i1)
+        lab = torch.where(own, lg[torch.arange(len(labels)), (labels - i0).clamp(0, i1 - i0 - 1)], torch.full((len(labels),), float("-inf"), dtype=torch.float64))
+        return torch.logsumexp(lg, dim=1).float().double(), lab      # (the protocol moves f32: keep the comparison honest below)
+
+    def grad_local(i0, i1, lse, coef):
+        lg = rows @ table[i0:i1].T + full_bias[i0:i1]
+        dl = torch.exp(lg - lse.double()[:, None])
+        own = (labels >= i0) & (labels < i1)
+        dl[torch.arange(len(labels))[own], (labels - i0)[own]] -= 1.0
+        dl = dl * coef.double()[:, None]
+        d_table[i0:i1] = dl.T @ rows
+        d_bias_full[i0:i1] = dl.sum(0)
+        if i0 == 0:
+            d_table[0] = 0.0                              # (the zero row carries no gradient; the pad logit is a constant)
+        return dl @ table[i0:i1]
+    loss, d_rows, (i0, i1) = P.vocab_parallel_ce(labels, I, lse_local, grad_local)
+    dist.all_gather_into_tensor, dist.all_reduce = ag, ar
+    want_loss, want_rows, want_table, want_bias = _vp_reference(rows, table, bias, labels)
+    # every rank holds the loss and d_rows of the WHOLE catalogue; its table / bias gradient rows are exactly the reference's rows
+    tol = 1e-6          # (lse / label logits travel as f32)
+    ok = abs(float(loss) - float(want_loss)) <= tol * abs(float(want_loss))
+    ok = ok and float((d_rows.double() - want_rows).abs().max()) <= tol * float(want_rows.abs().max())
+    ok = ok and float((d_table[i0:i1] - want_table[i0:i1]).abs().max()) <= tol * float(want_table.abs().max())
+    lo = max(i0, 1)
+    ok = ok and float((d_bias_full[lo:i1] - want_bias[lo - 1:i1 - 1]).abs().max()) <= tol * float(want_bias.abs().max())
+    ok = ok and float(d_table[:i0].abs().max() if i0 else 0.0) == 0.0 and float(d_table[i1:].abs().max() if i1 < I else 0.0) == 0.0
+    out[rank] = (bool(ok), calls["gather"], calls["reduce"], (i0, i1))
+    dist.destroy_process_group()
+
+
+def test_vocab_parallel_cross_entropy_world2_matches_the_unsharded_loss_and_gradients():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_vp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    shards = []
+    for r in range(world):
+        ok, n_gather, n_reduce, shard = out[r]
+        assert ok, (r, out[r])
+        assert n_gather == 1 and n_reduce == 1, out[r]      # ONE packed all-gather + ONE d_rows all-reduce per call
+        shards.append(shard)
+    assert shards[0][0] == 0 and shards[0][1] == shards[1][0] and shards[1][1] == 203
+
+
+def test_vocab_parallel_cross_entropy_single_process_is_the_plain_loss():
+    from easydgl_amd import parallel as P
+    rows, table, bias, labels = _vp_problem(R=11, I=50)
+    full_bias = torch.cat([torch.full((1,), -1000.0, dtype=torch.float64), bias])
+
+    def lse_local(i0, i1):
+        lg = rows @ table[i0:i1].T + full_bias[i0:i1]
+        return torch.logsumexp(lg, dim=1), lg[torch.arange(len(labels)), labels]
+
+    def grad_local(i0, i1, lse, coef):
+        dl = torch.exp(rows @ table[i0:i1].T + full_bias[i0:i1] - lse.double()[:, None])
+        dl[torch.arange(len(labels)), labels] -= 1.0
+        return (dl * coef.double()[:, None]) @ table[i0:i1]
+    loss, d_rows, (i0, i1) = P.vocab_parallel_ce(labels, 50, lse_local, grad_local)
+    want_loss, want_rows, _, _ = _vp_reference(rows, table, bias, labels)
+    assert (i0, i1) == (0, 50) and abs(float(loss) - float(want_loss)) <= 1e-6 * abs(float(want_loss))
+    assert float((d_rows.double() - want_rows).abs().max()) <= 1e-6 * float(want_rows.abs().max())

@@ -181,6 +181,9 @@ def test_bench_eight_ranks_over_gloo_smoke():
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 8 * 512 and j["config"]["parallelism"] == "dp8" and j["scaling"] == "weak"
     assert j["value"] > 0 and abs(j["value"] - 8 * 512 / (j["ms_per_step"] * 1e-3)) < 1e-2 * j["value"]
+    # the step's one collective, timed where it stands (exposed: nothing of the step runs beside it)
+    ar = j["config"]["allreduce"]
+    assert ar["allreduce_bytes_per_rank"] > 11e6 and ar["allreduce_exposed_ms"] > 0 and 0 < ar["allreduce_exposed_share_of_step"] < 1
     # ... and the SAME line carries north_star's other multi-GPU path: the evaluation step with the item table sharded over the
     # eight ranks, one packed all-gather of the local top-100 and the merge
     rows = j["extras"]["eval_sharded"]
@@ -233,3 +236,56 @@ def test_dp_counts_in_one_launch():
         assert counts.cpu().tolist() == [int((labels != 0).sum()), int(mtab[labels].sum())]
     assert lib.edgl_dp_counts(ctypes.c_void_p(d_lab.data_ptr()), ctypes.c_void_p(d_mt.data_ptr()), 4096, 32, 16,
                               ctypes.c_void_p(counts.data_ptr()), None) != 0      # more than 65536 labels: refused
+
+
+def _vp_hip_worker(rank, world, port, out, dtype_name):
+    """ops.vocab_parallel_ce — the HIP scoring kernels over a row shard of the item table per rank, ONE packed all-gather of
+    (log-sum-exp, label logit), ONE all-reduce of d_rows (EasyDGL.py:149-155,177-185) — two ranks on one GPU over
+    gloo against an fp64 reference on the same (rounded) operands."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from easydgl_amd import ops
+    dt = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(17)
+    R, C, I = 300, 128, 5003
+    rows = (torch.randn((R, C), generator=g) * 0.5).to(dt).cuda()
+    table = (torch.randn((I, C), generator=g) * 0.3).to(dt).cuda()
+    bias = (torch.randn(I - 1, generator=g) * 0.2).cuda()
+    labels = torch.randint(1, I, (R,), generator=g)
+    labels[::7] = 0
+    labels[3] = I - 1; labels[4] = 1
+    labels = labels.cuda()
+    loss, d_rows, d_table, d_bias, (i0, i1) = ops.vocab_parallel_ce(rows, table, bias, labels)
+    torch.cuda.synchronize()
+    # fp64 reference on the same operands, unsharded
+    r64 = rows.double().cpu().requires_grad_(True); t64 = table.double().cpu().requires_grad_(True); b64 = bias.double().cpu().requires_grad_(True)
+    lab = labels.cpu()
+    used = torch.cat([torch.zeros_like(t64[:1]), t64[1:]])
+    logits = r64 @ used.T + torch.cat([torch.full((1,), -1000.0, dtype=torch.float64), b64])
+    p = torch.softmax(logits, dim=-1)
+    w = (lab != 0).double()
+    ref = (w * -torch.log(p[torch.arange(R), lab] + 1e-5)).sum() / (w.sum() + 1e-5)
+    ref.backward()
+    tol = 2e-2 if dtype_name == "bf16" else 2e-4          # (bf16: d_rows leaves the kernel in the activation dtype)
+    def rel(a, b):
+        return float((a.double().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+    errs = dict(loss=abs(float(loss) - float(ref)) / abs(float(ref)), d_rows=rel(d_rows, r64.grad),
+                d_table=rel(d_table[i0:i1], t64.grad[i0:i1]), d_bias=rel(d_bias[max(i0, 1) - 1:i1 - 1], b64.grad[max(i0, 1) - 1:i1 - 1]))
+    outside = float(d_table[:i0].abs().max() if i0 else 0.0) + float(d_table[i1:].abs().max() if i1 < I else 0.0)
+    ok = errs["loss"] < (1e-3 if dtype_name == "bf16" else 1e-5) and all(v < tol for k, v in errs.items() if k != "loss") and outside == 0.0
+    out[rank] = (bool(ok), errs, (i0, i1))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
+def test_vocab_parallel_ce_two_ranks_match_the_unsharded_reference(dtype_name):
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_vp_hip_worker, args=(world, _free_port(), out, dtype_name), nprocs=world, join=True)
+    assert all(out[r][0] for r in range(world)), dict(out)
+    assert out[0][2][0] == 0 and out[0][2][1] == out[1][2][0] and out[1][2][1] == 5003
