@@ -150,6 +150,8 @@ SIGNATURES = {
     "edgl_tail_pack_elems": (L, [I]),
     "edgl_tail_supported": (I, [I, I, I]),
     "edgl_tail_variant": (I, [I]),
+    "edgl_adam_apply_ex": (I, [P, P, P, P, L, F, F, F, P, F, P, I, P, P, P, L, L, L, L, P, L, L, L, I, P, P, P, F, P]),
+    "edgl_score_flash_slab_info": (I, [I, I, I, I, I, P]),
     "edgl_tail_pack": (I, [P, P, P, P, I, P, P]),
     "edgl_tail_fwd": (I, [P, P, I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P, U32, U32, P, I, I, P, P, P, P, P, P, P, P, P, P, P,
                           P, P, I, P]),

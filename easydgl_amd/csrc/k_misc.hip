@@ -596,6 +596,120 @@ __global__ __launch_bounds__(256) void adam_kernel(float* w, const float* g, flo
     }
 }
 
+// edgl_adam_apply_ex: the optimizer launch of the static engine's eager step.  Beside adam_kernel's update
+//   * the gradient of arena elements [lo, hi) of up to two ranges is grad[i] + sum_s slabs[s * stride + (i - lo)] — the row-chunk
+//     slabs of the tied table's / the output bias's scoring gradient, which slab_reduce_kernel otherwise sums in a launch of its
+//     own between the scoring and the block-tail backward (the embedding scatter adds its rows into the zero-filled grad);
+//   * thread 0 of workgroup 0 writes the step counters of the NEXT step (step_begin_kernel's update) into OTHER buffers
+//     (rng_next, st_next): nobody reads them during this launch, nobody waits for a last workgroup (tickets measured + 15-40 us,
+//     DESIGN.md rule 55), and the host swaps the two pairs of buffers behind the launch — no single-thread launch at the end of a step.
+struct SlabSum { const float* slabs; long stride, lo, hi, zero_first; };
+// sum of the slabs at arena element i of a range (0 outside it / in its zero_first head): element form, for range borders and
+// ranges whose slab stride is not a multiple of 4 (the bias: I - 1 elements)
+__device__ __forceinline__ float slab_sum1(const SlabSum& s, int nslab, long i) {
+    if (!s.slabs || i < s.lo + s.zero_first || i >= s.hi) return 0.f;
+    float a = 0.f;
+    for (int k = 0; k < nslab; ++k) a += s.slabs[(long)k * s.stride + (i - s.lo)];
+    return a;
+}
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void adam_ex_kernel(float* w, float* g, float* m, float* v, long n, float b1, float b2, float eps,
+                                                      const uint64_t* st, float l2, const int64_t* seg, int nseg, bf16* shadow,
+                                                      float* l2_part, SlabSum s0, SlabSum s1, int nslab, const uint64_t* rng_cur,
+                                                      uint64_t* st_next, uint64_t* rng_next, float lr) {
+    __shared__ float red[8];
+    const float lr_t = reinterpret_cast<const float*>(st + 1)[0];
+    if (st_next && blockIdx.x == 0 && threadIdx.x == 0) {
+        rng_next[0] = rng_cur[0]; rng_next[1] = rng_cur[1] + 1ull;
+        const uint64_t t1 = st[0] + 1ull;
+        st_next[0] = t1;
+        const double t = (double)t1;
+        st_next[1] = 0ull;
+        reinterpret_cast<float*>(st_next + 1)[0] = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+    }
+    float sq = 0.f;
+    // l2 segments of this launch (<= 4 kept in registers; more: the scalar tail handles everything)
+    long slo[4] = {0, 0, 0, 0}, shi[4] = {0, 0, 0, 0};
+    const bool seg_regs = l2 == 0.f || nseg <= 4;
+    if (l2 != 0.f && seg_regs)
+        for (int k = 0; k < 4; ++k) if (k < nseg) { slo[k] = seg[2 * k]; shi[k] = seg[2 * k + 1]; }
+    const bool vec_a = s0.slabs && ((s0.lo | s0.hi | s0.zero_first | s0.stride) & 3) == 0 && ((uintptr_t)s0.slabs & 15) == 0 && nslab <= 4;
+    const long n4 = seg_regs ? n / 4 : 0;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
+        const long i = q * 4;
+        const float4 g0 = *reinterpret_cast<const float4*>(g + i);
+        float4 g4 = g0;
+        const float4 w4 = *reinterpret_cast<const float4*>(w + i), m4 = *reinterpret_cast<const float4*>(m + i), v4 = *reinterpret_cast<const float4*>(v + i);
+        const bool in_a = s0.slabs && i >= s0.lo && i < s0.hi, in_b = s1.slabs && i + 3 >= s1.lo && i < s1.hi;
+        if (in_a && vec_a) {        // (all multiples of 4: a group lies inside the range or outside it)
+            if (i >= s0.lo + s0.zero_first) {
+                float4 x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = *reinterpret_cast<const float4*>(s0.slabs + (long)min(k, nslab - 1) * s0.stride + (i - s0.lo));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nslab) { g4.x += x[k].x; g4.y += x[k].y; g4.z += x[k].z; g4.w += x[k].w; }
+            }
+        } else if (in_a || in_b || (s0.slabs && i + 3 >= s0.lo && i < s0.hi)) {
+            g4.x += slab_sum1(s0, nslab, i) + slab_sum1(s1, nslab, i); g4.y += slab_sum1(s0, nslab, i + 1) + slab_sum1(s1, nslab, i + 1);
+            g4.z += slab_sum1(s0, nslab, i + 2) + slab_sum1(s1, nslab, i + 2); g4.w += slab_sum1(s0, nslab, i + 3) + slab_sum1(s1, nslab, i + 3);
+        }
+        // the partial gradients are consumed: the two ranges start the next step at zero (the embedding scatter / the one-hot term
+        // add into them: no zero-fill launch)
+        if (s0.slabs || s1.slabs) {
+            float4 z4 = g0;
+            bool any = false;
+#define EDGL_ZR(c, off) if ((s0.slabs && i + off >= s0.lo && i + off < s0.hi) || (s1.slabs && i + off >= s1.lo && i + off < s1.hi)) { z4.c = 0.f; any = true; }
+            EDGL_ZR(x, 0) EDGL_ZR(y, 1) EDGL_ZR(z, 2) EDGL_ZR(w, 3)
+#undef EDGL_ZR
+            if (any) *reinterpret_cast<float4*>(g + i) = z4;
+        }
+        float gi[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float wi[4] = {w4.x, w4.y, w4.z, w4.w}, mo[4] = {m4.x, m4.y, m4.z, m4.w}, vo[4] = {v4.x, v4.y, v4.z, v4.w};
+        float wn[4], mn[4], vn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            bool in_seg = false;
+            if (l2 != 0.f) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) in_seg = in_seg || (i + r >= slo[k] && i + r < shi[k]);
+                gi[r] = in_seg ? gi[r] + l2 * wi[r] : gi[r];
+            }
+            mn[r] = b1 * mo[r] + (1.f - b1) * gi[r];
+            vn[r] = b2 * vo[r] + (1.f - b2) * gi[r] * gi[r];
+            wn[r] = wi[r] - lr_t * mn[r] / (sqrtf(vn[r]) + eps);
+            sq = in_seg ? fmaf(wn[r], wn[r], sq) : sq;
+        }
+        *reinterpret_cast<float4*>(m + i) = make_float4(mn[0], mn[1], mn[2], mn[3]);
+        *reinterpret_cast<float4*>(v + i) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+        *reinterpret_cast<float4*>(w + i) = make_float4(wn[0], wn[1], wn[2], wn[3]);
+        if (SHADOW) {
+            const Frag4<bf16> f = frag_from_acc<bf16>(f32x4{wn[0], wn[1], wn[2], wn[3]});
+            *reinterpret_cast<uint2*>(shadow + i) = *reinterpret_cast<const uint2*>(&f);
+        }
+    }
+    // scalar tail (n not a multiple of 4, or more than four l2 segments: everything)
+    for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] + slab_sum1(s0, nslab, i) + slab_sum1(s1, nslab, i);
+        if ((s0.slabs && i >= s0.lo && i < s0.hi) || (s1.slabs && i >= s1.lo && i < s1.hi)) g[i] = 0.f;
+        const float wi = w[i];
+        bool in_seg = false;
+        if (l2 != 0.f)
+            for (int s = 0; s < nseg; ++s)
+                if (i >= seg[2 * s] && i < seg[2 * s + 1]) { gi += l2 * wi; in_seg = true; break; }
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float wn = wi - lr_t * mi / (sqrtf(vi) + eps);
+        m[i] = mi; v[i] = vi; w[i] = wn;
+        if (SHADOW) shadow[i] = (bf16)wn;
+        sq = in_seg ? fmaf(wn, wn, sq) : sq;
+    }
+    if (l2_part) {
+        sq = block_sum(sq, red);
+        if (threadIdx.x == 0) l2_part[blockIdx.x] = sq;
+    }
+}
+
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* w, const int64_t* seg, int nseg, float* part) {
     __shared__ float red[8];
     float a = 0.f;
@@ -1134,6 +1248,35 @@ extern "C" int edgl_adam_apply_l2p_next(float* param, const float* grad, float* 
     else
         hipLaunchKernelGGL((adam_kernel<false>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps,
                            (const uint64_t*)step_state, l2, seg, nseg, (bf16*)nullptr, l2_part, rng_state, lr, (unsigned*)ticket);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+// The eager engine's optimizer launch (see adam_ex_kernel).  slabs_a / slabs_b (either may be NULL): `nslab` slabs of `stride_*` floats
+// whose sum is added to grad[lo_* .. hi_*) (arena element offsets); the first `zero_first_a` elements of range a take no slabs
+// (row 0 of the used table is the zero constant: coding.py:56-57).  rng_cur / step_next / rng_next (all three or none): the
+// counters of the next step are WRITTEN to step_next (Adam step, learning rate) and rng_next (seed, dropout step) — buffers other
+// than step_state / rng_cur, which this launch reads.  l2_part as edgl_adam_apply_l2p (may be NULL).  The two slab ranges of `grad` are
+// ZEROED behind their use (the next step's embedding scatter / one-hot term add into them).  Base.py:142-144.
+extern "C" int edgl_adam_apply_ex(float* param, float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
+                                  const uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, float* l2_part,
+                                  const float* slabs_a, long stride_a, long lo_a, long hi_a, long zero_first_a,
+                                  const float* slabs_b, long stride_b, long lo_b, long hi_b, int nslab,
+                                  const uint64_t* rng_cur, uint64_t* step_next, uint64_t* rng_next, float lr, void* stream) {
+    EDGL_REQUIRE(param && grad && m && v && step_state, EDGL_ERR_NULL, "edgl_adam_apply_ex: null pointer");
+    EDGL_REQUIRE(l2 == 0.f || nseg == 0 || seg, EDGL_ERR_NULL, "edgl_adam_apply_ex: l2 without segments");
+    EDGL_REQUIRE((!rng_cur && !step_next && !rng_next) || (rng_cur && step_next && rng_next && step_next != step_state && rng_next != rng_cur),
+                 EDGL_ERR_NULL, "edgl_adam_apply_ex: the next step's counters go to buffers of their own (all three pointers, or none)");
+    EDGL_REQUIRE(nslab >= 0 && (nslab == 0 || slabs_a || slabs_b) && (!slabs_a || (lo_a >= 0 && lo_a <= hi_a && hi_a <= n && hi_a - lo_a <= stride_a)) &&
+                 (!slabs_b || (lo_b >= 0 && lo_b <= hi_b && hi_b <= n && hi_b - lo_b <= stride_b)), EDGL_ERR_SHAPE, "edgl_adam_apply_ex: bad slab ranges");
+    const SlabSum s0{slabs_a, stride_a, slabs_a ? lo_a : 0, slabs_a ? hi_a : 0, zero_first_a};
+    const SlabSum s1{slabs_b, stride_b, slabs_b ? lo_b : 0, slabs_b ? hi_b : 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    if (shadow)
+        hipLaunchKernelGGL((adam_ex_kernel<true>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps, step_state, l2,
+                           seg, nseg, (bf16*)shadow, l2_part, s0, s1, nslab, rng_cur, step_next, rng_next, lr);
+    else
+        hipLaunchKernelGGL((adam_ex_kernel<false>), dim3(grid_for(n)), dim3(256), 0, st, param, grad, m, v, n, beta1, beta2, eps, step_state, l2,
+                           seg, nseg, (bf16*)nullptr, l2_part, s0, s1, nslab, rng_cur, step_next, rng_next, lr);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

@@ -117,6 +117,7 @@ struct ScoreP {
     const int32_t* wtotal;                              // data parallel: weighted rows of the GLOBAL batch (denominator of the loss)
     bool defer_label;                                   // strip path: the caller applies the one-hot term (edgl_score_flash_label_term)
     bool acc_atomic;                                    // strip path: d_table / d_bias are zero-filled and take the chunks as f32 atomics
+    bool keep_slabs;                                    // the row-chunk slabs of d_table / d_bias stay in the workspace: no slab_reduce launch (edgl_adam_apply_ex sums them)
     float* ce_part;                                     // one-launch row finish: per-workgroup sums of -log(p_label + 1e-5) (edgl_score_ce_nparts)
 };
 
@@ -1787,6 +1788,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
             hipLaunchKernelGGL(k, dim3(xblocks_of(p.i1 - p.i0, xb), q.nchunk), dim3(256), smem_nw, st, q);
         }
         EDGL_LAUNCH_CHECK();
+        if (p.keep_slabs && !p.gscale) return EDGL_OK;      // (the caller asked edgl_score_flash_slab_info where they are; the one-hot term is deferred too)
         const long n = (long)p.I * p.C, lo = (long)p.i0 * p.C, hi = (long)p.i1 * p.C;
         const long nb = p.I - 1, blo = std::max(p.i0, 1) - 1, bhi = p.i1 - 1;
         const int nb0 = (int)std::min<long>(((hi - lo) / 4 + 255) / 256 + 1, 2048), nb1 = bhi > blo ? (int)std::min<long>((bhi - blo + 255) / 256, 256) : 0;
@@ -2155,10 +2157,20 @@ extern "C" int edgl_score_flash_bwd_ex(const void* rows, const void* table, cons
     p.i1 = i1; p.nvalid = nvalid; p.row_lse = const_cast<float*>(row_lse); p.coef = coef; p.gscale = gscale;
     p.defer_label = (defer_label_term & 1) != 0;
     p.acc_atomic = (defer_label_term & 2) != 0;      // (bf16, C = 128 strip path only; elsewhere the slabs)
+    p.keep_slabs = (defer_label_term & 4) != 0 && (defer_label_term & 1) != 0 && !gscale && i0 == 0 && i1 == I;
     const BwdPlan plan = bwd_plan(R, C, I, i1 - i0, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
     hipStream_t st = (hipStream_t)stream;
     return dtype == EDGL_F32 ? bwd_dispatch<float, 2>(p, C, plan, workspace, d_rows, d_table, d_bias, st)
                              : bwd_dispatch<bf16, 2>(p, C, plan, workspace, d_rows, d_table, d_bias, st);
+}
+
+// Where edgl_score_flash_bwd_ex(defer_label_term & 4) leaves the partial table / bias gradients: out[0] / out[1] = float offsets of the
+// [nslab][I * C] and [nslab][I - 1] slabs inside the flash workspace, out[2] = nslab.  Depends on the shape only.
+extern "C" int edgl_score_flash_slab_info(int R, int C, int I, int n_items, int dtype, long* out) {
+    EDGL_REQUIRE(out && (dtype == EDGL_F32 || dtype == EDGL_BF16), EDGL_ERR_NULL, "edgl_score_flash_slab_info: bad arguments");
+    const BwdPlan plan = bwd_plan(R, C, I, n_items, dtype == EDGL_BF16 ? 2 : 4, use_strip(C, dtype == EDGL_BF16 ? 2 : 4));
+    out[0] = plan.off_slabW; out[1] = plan.off_slabB; out[2] = plan.w.nchunk;
+    return EDGL_OK;
 }
 
 extern "C" int edgl_mask_topk(float* logits, int R, int n, int i0, const int64_t* seen, int T, int K, float* out_val,

@@ -177,6 +177,22 @@ class TrainEngine:
         self.score_atomic = (os.environ.get("EDGL_SCORE_ATOMIC", "0") == "1" and self.code == _lib.BF16 and self.C == 128
                              and os.environ.get("EDGL_SCORE_STRIP", "1") != "0" and bool(self.blk))
         self.mau_flags = 0 if os.environ.get("EDGL_ENGINE_SKIP", "0") == "1" else _lib.MAU_NO_SKIP
+        # The optimizer launch of the eager step (edgl_adam_apply_ex): (a) it sums the row-chunk slabs of the tied table's / output bias's
+        # scoring gradient itself — no slab_reduce launch between the scoring and the block-tail backward (the embedding scatter adds
+        # into the gradient zero-filled under the encoder) —, (b) it writes the NEXT step's counters into a second pair of buffers that
+        # the host swaps in behind it — no single-thread step_begin launch at the end of the step's chain.  step() only (a bare
+        # _issue() leaves complete gradients in the arena), single process only (the all-reduce wants complete gradients), never with a
+        # captured graph on the model (a graph bakes the counters' addresses in).  EDGL_ADAM_EX=0: the round-5 launches.
+        self.adam_ex = (not use_graph) and os.environ.get("EDGL_ADAM_EX", "1") != "0" and os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") != "1" \
+            and os.environ.get("EDGL_ADAM_NEXT", "0") != "1"
+        self._rng_alt, self._adam_alt = torch.zeros_like(m._rng_state), torch.zeros_like(m._adam_state)
+        self._slabs = None          # (table slabs ptr, bias slabs ptr, nslab) left by the scoring backward of the current step
+        self._slab_info = None
+        if self.adam_ex and self.flash_ce:
+            import ctypes
+            info = (ctypes.c_long * 4)()
+            check(lib.edgl_score_flash_slab_info(self.R, C, I, I, self.code, info), "edgl_score_flash_slab_info")
+            self._slab_info = (int(info[0]), int(info[1]), int(info[2]))
         self._dw_forked = False
         self.sync_loss = True      # step(): order the returned loss on the caller's stream (a cross-stream wait behind the optimizer)
         # sync_loss False, the loss launches reading nothing of the batch (ce_part): they are not launched at the end of the backward
@@ -261,13 +277,18 @@ class TrainEngine:
               "edgl_add_layernorm_bwd_act")
 
     # ---- one optimizer step, as a fixed launch sequence ----------------------------------------------------------------
-    def _issue(self, lazy_loss: bool = False):
+    def _issue(self, lazy_loss: bool = False, fold_slabs: bool = False):
         """lazy_loss (step() without data parallelism): nothing the optimizer needs runs on the side stream at the end of the
         backward — every deferred reduction goes into the main stream's last reduction launch — so the main stream does NOT wait
         for the side stream (the TPP partial reduction and the loss kernel) in front of Adam; step() orders the loss behind the
         optimizer instead (or leaves it to the caller: `sync_loss`).  A cross-stream join costs the main stream ~12 us there."""
         m, st = self.m, _stream()
         self._lazy_loss = bool(lazy_loss) and bool(self.blk)
+        # (fold_slabs: step() lets the optimizer launch sum the scoring gradient's slabs — see __init__)
+        self._fold = bool(fold_slabs) and self._slab_info is not None and bool(self.blk) and not self.score_atomic and not self._dp
+        self._slabs = None
+        if not self._fold:
+            m._table_grad_zero = None      # (this issue's slab reduction ASSIGNS the table / bias gradient)
         B, T, C, H, E, M, I, R = self.B, self.T, self.C, self.H, self.E, self.M, self.I, self.R
         code = self.code
         hd, ad = m.hidden_dropout_rate, m.attention_probs_dropout_rate
@@ -362,8 +383,10 @@ class TrainEngine:
                     check(lib.edgl_tail_pack(_ptr(m.compute(blk.att_out.kernel)), _ptr(m.compute(blk.inter.kernel)),
                                              _ptr(m.compute(blk.out.kernel)), _ptr(m.compute(m.transform.kernel)), C,
                                              _ptr(self.tail_pack[i]), sst), "edgl_tail_pack")
-            if self.score_atomic:            # (behind the previous step's optimizer: this stream waited for the main stream above)
-                tab.grad.zero_()
+            # (fold: the optimizer launch of the previous step left the two gradients at zero behind its reads — a zero-fill only
+            #  when somebody else wrote them since: first step, a bare _issue(), an autograd-path step)
+            if self.score_atomic or (self._fold and getattr(m, "_table_grad_zero", None) != id(self)):
+                tab.grad.zero_()      # (behind the previous step's optimizer: this stream waited for the main stream above)
                 m.output_bias.grad.zero_()
             if self.job_order is not None:   # ids only: under the encoder, in front of everything the first attention kernel waits for
                 check(lib.edgl_bimau_job_order(_ptr(self.ids), B, T, _ptr(self.job_order), sst), "edgl_bimau_job_order")
@@ -546,6 +569,10 @@ class TrainEngine:
             defer = 1 if self.blk else 0
             if self.score_atomic:
                 defer |= 2      # d_table / d_bias zero-filled under the encoder (below): the row chunks add up in them, no slab reduction
+            if self._fold:
+                defer |= 4      # the slabs stay in the flash workspace: the optimizer launch sums them (no slab_reduce launch)
+                o_t, o_b, ns = self._slab_info
+                self._slabs = (self.ws_flash.data_ptr() + 4 * o_t, self.ws_flash.data_ptr() + 4 * o_b, ns)
             check(lib.edgl_score_flash_bwd_ex(_ptr(self.hrows_c), _ptr(tab_c), _ptr(m.output_bias), _ptr(lab), _ptr(self.lse),
                                               _ptr(self.coef), None, R, C, I, 0, I, _ptr(self.nvalid), None,
                                               _ptr(tab.grad), _ptr(m.output_bias.grad), _ptr(self.ws_flash), defer, code, st),
@@ -792,6 +819,38 @@ class TrainEngine:
                                                float(m.learning_rate), _ptr(self._adam_ticket), _stream()), "edgl_adam_apply_l2p_next")
             m._state_ahead = True
             return
+        if self.adam_ex and not getattr(m, "_state_pinned", False):
+            import ctypes
+            l2p = None
+            if self.l2_parts is not None and seg is not None:
+                self._l2p_cur ^= 1       # the copy the NEXT step reads
+                l2p = self.l2_parts[self._l2p_cur]
+            tab, ob = m.item_embs.lookup_table, m.output_bias
+            a0 = m._arena.data_ptr()
+            sl = self._slabs
+            self._slabs = None
+            lo_a, lo_b = (tab.data_ptr() - a0) // 4, (ob.data_ptr() - a0) // 4
+            check(lib.edgl_adam_apply_ex(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9, 0.999,
+                                         1e-8, _ptr(m._adam_state), float(m.l2_reg), _ptr(seg), 0 if seg is None else seg.numel() // 2,
+                                         _ptr(m._shadow), _ptr(l2p),
+                                         ctypes.c_void_p(sl[0]) if sl else None, tab.numel(), lo_a, lo_a + tab.numel(), self.C,
+                                         ctypes.c_void_p(sl[1]) if sl else None, ob.numel(), lo_b, lo_b + ob.numel(), sl[2] if sl else 0,
+                                         _ptr(m._rng_state), _ptr(self._adam_alt), _ptr(self._rng_alt), float(m.learning_rate), _stream()),
+                  "edgl_adam_apply_ex")
+            if l2p is not None:
+                self._l2p_ready = True
+                m._l2_parts_owner = id(self)
+            else:
+                m._l2_parts_owner = None
+            m._table_grad_zero = id(self) if sl else None      # (the launch zeroed the two slab ranges of the gradient behind its reads)
+            # the counters of the next step were written to the other pair of buffers: swap them in (settle_state undoes the
+            # look-ahead on whichever pair is current)
+            m._rng_state, self._rng_alt = self._rng_alt, m._rng_state
+            m._adam_state, self._adam_alt = self._adam_alt, m._adam_state
+            m._state_ahead = True
+            return
+        if self._slabs is not None:
+            raise _lib.EdglError("TrainEngine: the scoring gradient's slabs were left for edgl_adam_apply_ex, which is not in use")
         if self.l2_parts is not None and seg is not None:
             self._l2p_cur ^= 1       # the copy the NEXT step reads
             check(lib.edgl_adam_apply_l2p(_ptr(m._arena), _ptr(m._grad_arena), _ptr(m._adam_m), _ptr(m._adam_v), m._arena.numel(), 0.9,
@@ -881,7 +940,8 @@ class TrainEngine:
         if not self.use_graph:
             if distributed:
                 self._global_counts()
-            self._issue(lazy_loss=not distributed and os.environ.get("EDGL_LAZY_LOSS", "1") != "0")
+            self._issue(lazy_loss=not distributed and os.environ.get("EDGL_LAZY_LOSS", "1") != "0",
+                        fold_slabs=self.adam_ex and not distributed and not getattr(self.m, "_state_pinned", False))
             out = self.loss
             if distributed:
                 evs = getattr(self, "_ar_events", None)      # bench.py: HIP events around the step's one collective (its EXPOSED time:
@@ -916,6 +976,7 @@ class TrainEngine:
             #  single-thread update and — with its own optimizer — ends with it)
             # (the A/B switch EDGL_ENGINE_LEGACY_FORK=1 has no look-ahead: its _issue() carries the update itself)
             assert getattr(self.m, "_state_ahead", False) or os.environ.get("EDGL_ENGINE_LEGACY_FORK", "0") == "1"
+            self.m._state_pinned = True      # (the captured launches keep the counters' addresses: no engine swaps them from here on)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._issue()

@@ -100,6 +100,7 @@ class Sequential(nn.Module):
         return self._shadow[off:off + p.numel()].view(p.shape)
 
     def zero_grad_arena(self) -> None:
+        self._table_grad_zero = None
         self._grad_arena.zero_()
 
     def detach_grads(self) -> None:
@@ -137,6 +138,7 @@ class Sequential(nn.Module):
                 warm_loss = self.train_step(static_f, static_l).clone()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._state_pinned = True      # (the captured launches keep the step counters' addresses: engine.TrainEngine does not swap them)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss = self.train_step(static_f, static_l)
@@ -297,6 +299,7 @@ class Sequential(nn.Module):
         (engine.TrainEngine._advance_state).  Anything else that reads or advances them (the autograd path's steps, a checkpoint)
         calls this first: the counters go back to "steps taken so far"."""
         self._l2_parts_owner = None      # (whoever settles the counters is about to read or rewrite the state itself)
+        self._table_grad_zero = None     # (... or the gradient arena: engine.TrainEngine zero-fills the tied table's gradient again)
         if getattr(self, "_state_ahead", False):
             self._rng_state[1] -= 1
             self._adam_state[0] -= 1

@@ -578,6 +578,24 @@ int edgl_adam_next_tickets(long n);
 int edgl_adam_apply_l2p_next(float* param, const float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
                              uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, float* l2_part,
                              uint64_t* rng_state, float lr, uint32_t* ticket, void* stream);
+/* The eager engine's optimizer launch: edgl_adam_apply_l2p that also (a) adds the sum of `nslab` partial-gradient slabs to two ranges of
+ * the gradient arena — grad[lo .. hi) += sum_s slabs[s * stride + (i - lo)]; the first `zero_first_a` elements of range a take none (row 0
+ * of the used item table is the zero constant, coding.py:56-57): the row-chunk slabs that edgl_score_flash_bwd_ex(defer_label_term & 4)
+ * leaves in its workspace (edgl_score_flash_slab_info), so that no slab-reduction launch stands between the scoring and the block-tail
+ * backward — and (b) writes the counters of the NEXT step (edgl_step_begin's update: dropout step + 1, Adam step + 1, its bias-corrected
+ * learning rate) into step_next / rng_next, buffers OTHER than step_state / rng_cur, which the launch reads: no single-thread launch at
+ * the end of a step and no last-workgroup ticket; the caller swaps the buffer pairs behind the launch.  With slabs given, the two ranges
+ * of `grad` are ZEROED behind their use: the next step's embedding scatter / one-hot term add into them (no zero-fill launch).  slabs_* / the three counter
+ * pointers may be NULL (then that part is left out); l2_part may be NULL.  Base.py:142-144. */
+int edgl_adam_apply_ex(float* param, float* grad, float* m, float* v, long n, float beta1, float beta2, float eps,
+                       const uint64_t* step_state, float l2, const int64_t* seg, int nseg, void* shadow, float* l2_part,
+                       const float* slabs_a, long stride_a, long lo_a, long hi_a, long zero_first_a,
+                       const float* slabs_b, long stride_b, long lo_b, long hi_b, int nslab,
+                       const uint64_t* rng_cur, uint64_t* step_next, uint64_t* rng_next, float lr, void* stream);
+/* out[0] / out[1]: float offsets of the d_table [nslab][I * C] / d_bias [nslab][I - 1] slabs inside the edgl_score_flash_workspace
+ * buffer, out[2] = nslab — what edgl_score_flash_bwd_ex leaves there with (defer_label_term & 4) (requires & 1, the whole item range
+ * and gscale == NULL; otherwise the flag is ignored and the slabs are reduced as usual).  EasyDGL.py:149-151 backward. */
+int edgl_score_flash_slab_info(int R, int C, int I, int n_items, int dtype, long* out);
 int edgl_l2_from_parts(const float* l2_part, int nparts, float l2, float* out, int accumulate, void* stream);
 int edgl_l2_loss(const float* param, const int64_t* seg, int nseg, float l2, float* out, int accumulate,
                  float* workspace, void* stream);

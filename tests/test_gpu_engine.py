@@ -371,3 +371,51 @@ def test_l2_term_from_the_optimizer_sums_only_while_this_engine_owns_the_weights
     both = [float((e1 if n % 2 == 0 else e2).step()) for n in range(4)]
     for a, b in zip(single, both):
         assert abs(a - b) <= 1e-5 * abs(a), (single, both)
+
+
+def test_optimizer_launch_that_sums_the_slabs_and_writes_the_next_counters(monkeypatch):
+    """edgl_adam_apply_ex (the eager step's optimizer launch): the scoring gradient's row-chunk slabs summed inside the optimizer (no
+    slab_reduce launch) and the next step's counters written to a second pair of buffers that the host swaps in (no step_begin
+    launch) — against the round-5 launch sequence (EDGL_ADAM_EX=0): the same losses and weights over five steps WITH dropout (the
+    dropout step counter and Adam's step / learning rate advance identically), counters that settle to "steps taken", a bare
+    _issue() that still leaves complete gradients, two engines alternating on one model, and a checkpoint round trip in between."""
+    from easydgl_amd.engine import TrainEngine
+    prob = make_problem(seed=63, batch=6, **CASES[2])
+    feats, labels = to_dev(prob["feats"]), torch.as_tensor(prob["labels"]).cuda()
+
+    def run(flag, two_engines=False):
+        monkeypatch.setenv("EDGL_ADAM_EX", flag)
+        m = build_model(prob, "bf16", hidden_drop=0.1, att_drop=0.1)
+        engs = [TrainEngine(m, 6, use_graph=False) for _ in range(2 if two_engines else 1)]
+        assert all(e.adam_ex == (flag == "1") for e in engs)
+        for e in engs:
+            e.load_batch(feats, labels)
+        losses = [float(engs[n % len(engs)].step()) for n in range(5)]
+        torch.cuda.synchronize()
+        return m, engs, losses
+
+    m0, _, l0 = run("0")
+    m1, e1, l1 = run("1")
+    m2, _, l2 = run("1", two_engines=True)
+    for a, b, c in zip(l0, l1, l2):
+        assert abs(a - b) <= 2e-5 * abs(a) and abs(a - c) <= 2e-5 * abs(a), (l0, l1, l2)
+    scale = float(m0._arena.abs().max())
+    assert float((m0._arena - m1._arena).abs().max()) <= 2e-5 * scale and float((m0._arena - m2._arena).abs().max()) <= 2e-5 * scale
+    # the counters: one step ahead while the engine owns them, "steps taken" once settled — on whichever pair of buffers is current
+    for m in (m0, m1, m2):
+        assert m._state_ahead and int(m._adam_state[0]) == 6 and int(m._rng_state[1]) == 6
+        m.settle_state()
+        assert int(m._adam_state[0]) == 5 and int(m._rng_state[1]) == 5
+    assert torch.equal(m0._rng_state, m1._rng_state) and torch.equal(m0._adam_state, m1._adam_state)
+    # a bare _issue() (the parity tests' entry point) leaves COMPLETE gradients in the arena under either setting
+    grads = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("EDGL_ADAM_EX", flag)
+        m = build_model(prob, "bf16")
+        e = TrainEngine(m, 6, use_graph=False)
+        e.load_batch(feats, labels)
+        e.step()                        # (a step with the slabs left to the optimizer in front of it)
+        e._issue()
+        torch.cuda.synchronize()
+        grads[flag] = m._grad_arena.clone()
+    assert float((grads["0"] - grads["1"]).abs().max()) <= 2e-5 * float(grads["0"].abs().max())
