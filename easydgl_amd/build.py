@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libeasydgl_hip.so")
 SOURCES = ["k_misc.hip", "k_data.hip", "k_encode.hip", "k_gemm.hip", "k_gemm2.hip", "k_layernorm.hip", "k_bimau_fwd.hip", "k_bimau_bwd.hip", "k_bimau_big.hip",
-           "k_score.hip", "k_score_strip.hip", "k_eval_topk.hip", "k_tattn.hip", "k_coding.hip", "k_tail.hip"]
+           "k_score.hip", "k_score_strip.hip", "k_score_stripw.hip", "k_eval_topk.hip", "k_tattn.hip", "k_coding.hip", "k_tail.hip"]
 HEADERS = ["edgl_common.h", "batch_prep.h", "score_plan.h", "topk_select.h", "gemm_tile.h", "bimau_common.h", "bimau_fwd_impl.h", "bimau_bwd_impl.h", os.path.join("..", "..", "include", "easydgl_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read/write traffic around every VALU consumer);
@@ -23,7 +23,8 @@ EXTRA_FLAGS = {"k_bimau_fwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "k_bimau_big.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "k_tattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # hand-placed instruction stream: the SLP vectoriser packs the row sums into v_pk_add_f32 (slow beside MFMAs)
-               "k_score_strip.hip": ["-fno-slp-vectorize", "-Wno-unused-value"] + (["-DSTRIP_SAFE"] if os.environ.get("EDGL_STRIP_SAFE") else []) + os.environ.get("EDGL_STRIP_DEFS", "").split()}
+               "k_score_strip.hip": ["-fno-slp-vectorize", "-Wno-unused-value"] + (["-DSTRIP_SAFE"] if os.environ.get("EDGL_STRIP_SAFE") else []) + os.environ.get("EDGL_STRIP_DEFS", "").split(),
+               "k_score_stripw.hip": ["-fno-slp-vectorize", "-Wno-unused-value"] + (["-DSTRIP_SAFE"] if os.environ.get("EDGL_STRIP_SAFE") else []) + os.environ.get("EDGL_STRIPW_DEFS", "").split()}
 
 
 def _hipcc() -> str:

@@ -34,6 +34,15 @@ int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, 
 int edgl_strip_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
                      int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, float* acc_table,
                      float* acc_bias, hipStream_t st);
+// k_score_stripw.hip: the same passes at C = 256 (32 x vectors per wave, 128 per workgroup)
+bool edgl_stripw_enabled();
+bool edgl_stripw_supports(int C);
+int edgl_stripw_rows(const void* rows, const void* table, const float* out_bias, int R, int C, int I, int i0, int i1,
+                     const int32_t* nvalid, float* slabs, float* part, int G, hipStream_t st);
+int edgl_stripw_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
+                      int C, int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, hipStream_t st);
+int edgl_stripw_label_scatter(const void* rows, const int64_t* labels, const float* coef, const int32_t* nvalid, int R, int C, int i0,
+                              int i1, const float* gscale, float* d_table, float* d_bias, hipStream_t st);
 int edgl_strip_label_scatter(const void* rows, const int64_t* labels, const float* coef, const int32_t* nvalid, int R, int i0, int i1,
                              const float* gscale, float* d_table, float* d_bias, hipStream_t st);
 
@@ -1612,12 +1621,19 @@ struct BwdPlan {
 };
 // The flash form (edgl_score_flash_*) at bf16 / C = 128 runs the strip kernels (k_score_strip.hip): 256 x vectors per
 // workgroup as well, 64-z tiles handed out in pairs.
-inline bool use_strip(int C, size_t esize) { return esize == 2 && C == 128 && edgl_strip_enabled(); }
-inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize, bool strip = false) {
+// 0: the generic kernels, 1: k_score_strip.hip (C = 128, 256 x vectors per workgroup), 2: k_score_stripw.hip (C = 256, 128 per workgroup)
+inline int use_strip(int C, size_t esize) {
+    if (esize != 2) return 0;
+    if (C == 128 && edgl_strip_enabled()) return 1;
+    if (edgl_stripw_supports(C) && edgl_stripw_enabled()) return 2;
+    return 0;
+}
+inline int strip_xb(int strip) { return strip == 2 ? 128 : 256; }
+inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize, int strip = 0) {
     BwdPlan b;
     const RtCfg cf = rt_cfg(C, esize);
     const int nw = strip ? 8 : (cf.nwb == 8 ? score_nw(C, esize) : cf.nwb), zb = strip ? 128 : cf.zb;   // strip: pairs of its 64-z tiles
-    const int xb = strip ? 256 : 16 * cf.ix * nw;
+    const int xb = strip ? strip_xb(strip) : 16 * cf.ix * nw;
     b.y = pick_chunks(xblocks_of(R, xb), n_items, score_target(), zb, l2_tiles_for(C, esize, 2, zb));
     {   // every chunk writes an [R, C] f32 slab that a later kernel sums: keep that side traffic bounded (1M-item tables would
         // otherwise ask for hundreds of chunks)
@@ -1692,16 +1708,16 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     p.rowsT = rowsT; p.tableT = tableT;
     using Cfg = ScoreCfg<T, CT>;
     constexpr int CO = Cfg::CO;
-    const bool strip = MODE != 0 && use_strip(p.C, sizeof(T));     // plan built with the same flag by the callers
+    const int strip = MODE != 0 ? use_strip(p.C, sizeof(T)) : 0;     // plan built with the same flag by the callers
     const int ZBK = strip ? 128 : S::ZB;
     const int nw = Cfg::NWB == 8 ? score_nw(p.C, sizeof(T)) : Cfg::NWB;
     const size_t smem_nw = nw == 8 ? smem : BUF;
-    const int xb = strip ? 256 : 16 * Cfg::IX * nw;
+    const int xb = strip ? strip_xb(strip) : 16 * Cfg::IX * nw;
     const int G = strip ? std::max(xblocks_of(p.R, xb) * plan.y.nchunk, score_target()) : xblocks_of(p.R, xb) * plan.y.nchunk;
     float* part = ws + plan.off_part;
     // rows finished in one launch (flash_finish_lse_kernel): the strip row pass then leaves bf16 slabs
     const bool one_launch = MODE == 1 && d_rows && (p.C == 128 || p.C == 64 || p.C == 256) && p.i0 == 0 && p.i1 == p.I;
-    const bool slab16 = strip && one_launch;
+    const bool slab16 = strip == 1 && one_launch;
     if (MODE == 1) slab_format_set(ws, slab16 ? 1 : 0);
     if (MODE == 2 && d_rows)
         EDGL_REQUIRE(slab_format_get(ws) == 0, EDGL_ERR_WORKSPACE,
@@ -1712,7 +1728,10 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
         ScoreP q = p;
         q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY; q.part = part;
         edgl_prof_begin(EDGL_KERNEL_SCORE_BWD_ROWS, st);
-        if (strip) {
+        if (strip == 2) {
+            const int rc = edgl_stripw_rows(p.rows, p.table, p.out_bias, p.R, p.C, p.I, p.i0, p.i1, p.nvalid, q.slabs, part, G, st);
+            if (rc) return rc;
+        } else if (strip) {
             const int rc = edgl_strip_rows(p.rows, p.table, p.out_bias, p.R, p.I, p.i0, p.i1, p.nvalid, q.slabs, part, G, slab16 ? 1 : 0, st);
             if (rc) return rc;
         } else if (nw == 8) {
@@ -1769,7 +1788,11 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     {
         ScoreP q = p;
         q.zchunk = plan.w.zchunk; q.nchunk = plan.w.nchunk; q.slabs = ws + plan.off_slabW; q.bias_slabs = ws + plan.off_slabB;
-        if (strip) {
+        if (strip == 2) {
+            const int rc = edgl_stripw_table(p.rows, p.table, p.out_bias, p.coef, p.row_lse, p.R, p.C, p.I, p.i0, p.i1, p.nvalid, q.slabs,
+                                             q.bias_slabs, q.nchunk, st);
+            if (rc) return rc;
+        } else if (strip) {
             const bool acc = p.acc_atomic && !p.gscale;
             const int rc = edgl_strip_table(p.rows, p.table, p.out_bias, p.coef, p.row_lse, p.R, p.I, p.i0, p.i1, p.nvalid, q.slabs,
                                             q.bias_slabs, q.nchunk, acc ? d_table : nullptr, acc ? d_bias : nullptr, st);
@@ -1797,7 +1820,8 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
                            q.nchunk, p.gscale);
         EDGL_LAUNCH_CHECK();
         if (strip && !p.defer_label) {   // the one-hot part of dl, which the strip product pass leaves out
-            const int rc = edgl_strip_label_scatter(p.rows, p.labels, p.coef, p.nvalid, p.R, p.i0, p.i1, p.gscale, d_table, d_bias, st);
+            const int rc = strip == 2 ? edgl_stripw_label_scatter(p.rows, p.labels, p.coef, p.nvalid, p.R, p.C, p.i0, p.i1, p.gscale, d_table, d_bias, st)
+                                      : edgl_strip_label_scatter(p.rows, p.labels, p.coef, p.nvalid, p.R, p.i0, p.i1, p.gscale, d_table, d_bias, st);
             if (rc) return rc;
         }
     }
@@ -2140,7 +2164,9 @@ extern "C" int edgl_score_flash_label_term(const void* rows, const int64_t* labe
                                            void* stream) {
     EDGL_REQUIRE(rows && labels && coef && d_table && d_bias, EDGL_ERR_NULL, "edgl_score_flash_label_term: null pointer");
     EDGL_REQUIRE(R > 0 && I > 1 && i0 >= 0 && i1 <= I && i0 < i1, EDGL_ERR_SHAPE, "edgl_score_flash_label_term: bad shape");
-    if (!use_strip(C, dtype == EDGL_BF16 ? 2 : 4)) return EDGL_OK;
+    const int strip = use_strip(C, dtype == EDGL_BF16 ? 2 : 4);
+    if (!strip) return EDGL_OK;
+    if (strip == 2) return edgl_stripw_label_scatter(rows, labels, coef, nvalid, R, C, i0, i1, gscale, d_table, d_bias, (hipStream_t)stream);
     return edgl_strip_label_scatter(rows, labels, coef, nvalid, R, i0, i1, gscale, d_table, d_bias, (hipStream_t)stream);
 }
 extern "C" int edgl_score_flash_bwd_ex(const void* rows, const void* table, const float* out_bias, const int64_t* labels,

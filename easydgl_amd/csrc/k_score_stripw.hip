@@ -1,0 +1,655 @@
+// K5 "wide strip" kernels: the two passes of the fused scoring / cross-entropy (EasyDGL.py:149-155,177-185) at the widths above the
+// headline's — bf16, C = 256 (BASELINE.json configs[2]: 1 M items) — in the one-wave-per-SIMD form of k_score_strip.hip.
+//
+//   ROLE_YF (x = compacted rows, z = items) / ROLE_W (x = items, z = rows): the same two sweeps as strip::strip_kernel — logits
+//   D[z][x] = Z[z].X[x] + c[z], P = exp(D - reference), O[x] += P^T Z, l[x] += sum_z P — with the same outputs (row slabs +
+//   (reference, sum) pairs / table slabs + bias slabs), so every finishing kernel of k_score.hip serves both.
+//
+// What the width changes.  A wave's [x][C] f32 accumulator and its x fragments must stay in the register file: at C = 256 that is
+// 32 x vectors per wave (128 + 64 registers, as 64 x vectors are at C = 128), i.e. ONE 32-column MFMA tile, 128 x vectors per
+// workgroup.  A 32-row z unit then costs 16 + 16 MFMAs (v_mfma_f32_32x32x16_bf16) for 16 logits per lane instead of 32: half a
+// logit per MFMA slot, so the VALU stream that bounds the C = 128 loop (54 cycles per 32-cycle MFMA, DESIGN rule 27) fits beside
+// the S half alone and the O half is MFMAs + operand reads.  What becomes scarce instead is the LDS port: every unit is read twice
+// by every wave (row fragments for S, transposed fragments for O) with nothing shared between the two x tiles a C = 128 wave has
+// — 144 of a unit's 256 LDS cycles per wave quartet — so operands are fetched SIX slots ahead through rings of eight.
+//
+// Geometry: 4 waves = one per SIMD, 512 registers each; z streams through LDS in 32-row units, ring of FIVE (a unit is written
+// two iterations before its first read and last read one iteration before the slot's next write + one barrier: four slots would
+// need a second barrier per unit), one barrier per unit; rows are staged global -> registers -> LDS through four register sets,
+// the loads of a unit issued three iterations before its stores.
+// LDS image of a unit: row z at byte z*ROWB + rot(z)*16, ROWB = 2 C + 256, rot(z) = ((z&3)<<2) | ((z>>2)&3) — the layout of the
+// C = 128 kernel (ROWB a multiple of 256: the same banks), every address one lane register + an immediate.
+#include <atomic>
+#include <cstdlib>
+
+#include "edgl_common.h"
+#include "score_plan.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+namespace stripw {
+
+constexpr int NTHR = 256, XW = 32, XB = 128, ZU = 32, ZQ = 128;     // ZQ: chunk granularity (four units = one loop trip)
+constexpr int INFOB = ZU * 4;
+constexpr int NSLOT = 5;
+constexpr int PF = 6, RING = 8;            // operand prefetch distance (MFMA slots) / ring size
+constexpr float L2E = 1.4426950408889634f;
+constexpr float LSUM_LIMIT = 1.2676506e30f;   // 2^100
+
+template <int CW>
+struct W {
+    static constexpr int C = CW;
+    static constexpr int KS = CW / 16;                 // S MFMAs of a unit
+    static constexpr int CT = CW / 32;                 // 32-channel tiles of the accumulator
+    static constexpr int ROWB = 2 * CW + 256;          // LDS bytes per z row
+    static constexpr int UNITB = ZU * ROWB;
+    static constexpr int SLOTB = UNITB + INFOB;
+    static constexpr int OSTR = CW + 4;                // floats per staged output row (epilogue)
+    static constexpr int SMEM_LOOP = NSLOT * SLOTB, SMEM_EPI = 4 * XW * OSTR * 4;
+    static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
+    static constexpr int NP = (ZU * 2 * CW / 16) / NTHR;   // 16-byte staging pieces per thread and unit (4 at C = 256)
+    static_assert(SMEM <= 160 * 1024, "LDS");
+    static_assert(KS == 16 && CT == 8 && NP == 4, "the slot schedule below is written for C = 256");
+};
+
+enum { ROLE_YF = 0, ROLE_W = 1 };
+
+struct StripP {
+    const bf16* rows; const bf16* table; const float* out_bias;
+    int R, I, i0, i1;
+    const int32_t* nvalid;
+    const float* coef; const float* row_lse;     // ROLE_W
+    float* slabs; float* bias_slabs; float* part;
+};
+
+__device__ __forceinline__ int rot16(int z) { return (((z & 3) << 2) | ((z >> 2) & 3)) * 16; }
+#define SPIN() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ v4i lds_b128(const char* p) { return *reinterpret_cast<const v4i*>(p); }
+__device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
+// B operand of a 32x32x16 MFMA contracting along the rows of the unit: two transpose reads (slots 0-3: rows +0..3, slots 4-7:
+// rows +8..11 of this lane half's row group — the order in which P is packed from the logit registers)
+template <int ROWB>
+__device__ __forceinline__ v4i lds_tr(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
+    const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p + 8 * ROWB + 32));
+    const uint2 a = __builtin_bit_cast(uint2, v0), b = __builtin_bit_cast(uint2, v1);
+    return v4i{(int)a.x, (int)a.y, (int)b.x, (int)b.y};
+}
+
+struct LaneOff {
+    int zf;   // row-fragment read: row l&31, k-slot hi        (+ ks*32)
+    int tr;   // transpose read: row 4hi + (s>>2), columns 16*(G&1) + 4*(s&3)   (+ ks2*16*ROWB + ct*64)
+    int ci;   // C operand of the logit rows: info floats 4hi .. 4hi+3   (+ g*32)
+};
+template <int ROWB>
+__device__ __forceinline__ LaneOff lane_off(int lane) {
+    LaneOff o;
+    const int zr = lane & 31, hi = lane >> 5, G = lane >> 4, s = lane & 15;
+    o.zf = zr * ROWB + rot16(zr) + hi * 16;
+    const int tz = 4 * hi + (s >> 2);
+    o.tr = tz * ROWB + rot16(tz) + (16 * (G & 1) + 4 * (s & 3)) * 2;
+    o.ci = 4 * hi * 4;
+    return o;
+}
+
+// global -> registers -> LDS staging of one 32-row unit (+ its per-row C operand) in single-instruction pieces.  Thread t owns
+// 16-byte chunk (t & 15) + 16 j of rows (t >> 4) + 16 i, piece k = i + 2 j: rot(row) is the same for both rows, so a piece is one
+// clamp + one address add + the access.  Rows past the chunk / table row 0 are not zero-filled: their C operand (-inf / -1000)
+// makes every exponential of such a row exactly 0, the DATA only has to be finite (loads clamped to the chunk's last row).
+template <int ROLE, int CW>
+struct Stage {
+    using Cf = W<CW>;
+    uint4 g0, g1, g2, g3;
+    float cinfo, cinfo2;
+    int z0_, zend_;
+    const bf16* Z_;
+    const float* bias_; const float* coef_; const float* lse_;
+    int I_, Reff_, tid_, row0_, goff_, loff_;
+    __device__ __forceinline__ void init(const StripP& p, const bf16* Z, int zend, int Reff, int tid) {
+        Z_ = Z; bias_ = p.out_bias; coef_ = p.coef; lse_ = p.row_lse; I_ = p.I; zend_ = zend; Reff_ = Reff; tid_ = tid;
+        cinfo = 0.f; cinfo2 = 0.f; z0_ = 0;
+        row0_ = tid >> 4;
+        goff_ = (tid & 15) * 8;                                            // elements
+        loff_ = row0_ * Cf::ROWB + rot16(row0_) + (tid & 15) * 16;         // bytes
+    }
+    __device__ __forceinline__ void begin(int z0) { z0_ = z0; }
+    __device__ __forceinline__ void load_piece(int k) {      // k = 0..3: 16 bytes of the unit;  k = 4: the per-row scalars
+        if (k < 4) {
+            const int gz = max(min(z0_ + row0_ + 16 * (k & 1), zend_ - 1), 0);
+            const uint4 v = *reinterpret_cast<const uint4*>(Z_ + (long)gz * CW + goff_ + (k >> 1) * 128);
+            if (k == 0) g0 = v; else if (k == 1) g1 = v; else if (k == 2) g2 = v; else g3 = v;
+        } else {
+            const int z = z0_ + (tid_ & (ZU - 1));      // every wave loads them (no divergent branch); the first 32 threads store
+            if (ROLE == ROLE_YF) {
+                cinfo = bias_[min(max(z, 1), I_ - 1) - 1];
+            } else {
+                const int gc = max(min(z, Reff_ - 1), 0);
+                cinfo = coef_[gc]; cinfo2 = lse_[gc];
+            }
+        }
+    }
+    __device__ __forceinline__ void load(int z0) {
+        begin(z0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) load_piece(k);
+    }
+    __device__ __forceinline__ void store_piece(char* slot, int k) {
+        if (k < 4) {
+            *reinterpret_cast<uint4*>(slot + loff_ + (k & 1) * 16 * Cf::ROWB + (k >> 1) * 256) = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
+        } else {
+            const int z = z0_ + (tid_ & (ZU - 1));
+            float c;
+            if (ROLE == ROLE_YF) c = z >= zend_ ? -INFINITY : (z == 0 ? -1000.0f : cinfo);   // pad logit -1000 (Base.py:110)
+            else c = (z < zend_ && cinfo > 0.f) ? __logf(cinfo) - cinfo2 : -INFINITY;        // -(lse - log coef)
+            if (tid_ < ZU) reinterpret_cast<float*>(slot + Cf::UNITB)[tid_] = c;
+        }
+    }
+    __device__ __forceinline__ void store(char* slot) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) store_piece(slot, k);
+    }
+};
+
+__device__ __forceinline__ void fetch_ci_part(f32x16& ci, const char* info, const LaneOff& lo, int g) {
+    const f32x4 t = lds_f4(info + lo.ci + g * 32);
+    ci[4 * g] = t[0]; ci[4 * g + 1] = t[1]; ci[4 * g + 2] = t[2]; ci[4 * g + 3] = t[3];
+}
+
+// MFMAs and the per-logit VALU work as asm statements (register files and placement: see k_score_strip.hip).  Logits S in VGPRs
+// (exponentiated in place), x fragments XF and the output O in AGPRs, P and the Z fragments in VGPRs.  Every consumer of an MFMA
+// result is either the next MFMA of the same accumulator chain (no wait states) or more than a full slot group later; the places
+// that read MFMA results directly (prologue maxima, epilogue) sit behind settle_s() / settle_o().
+#ifdef STRIP_SAFE
+#define MFMA_PAD "\n\ts_nop 15\n\ts_nop 15"
+#else
+#define MFMA_PAD ""
+#endif
+__device__ __forceinline__ void mfma_s0(f32x16& d, const v4i& a, const v4i& b, const f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" MFMA_PAD : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma_s(f32x16& d, const v4i& a, const v4i& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" MFMA_PAD : "+v"(d) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_o(f32x16& d, const v4i& a, const v4i& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" MFMA_PAD : "+a"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void settle_s(f32x16& s0) { asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s0)); }
+__device__ __forceinline__ void settle_o(f32x16 (&O)[8]) {
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(O[0]), "+a"(O[1]), "+a"(O[2]), "+a"(O[3]), "+a"(O[4]), "+a"(O[5]), "+a"(O[6]), "+a"(O[7]));
+}
+
+// One S slot = ONE asm statement: the MFMA and the VALU work on logit e (0..15) of the unit being exponentiated (the stream of
+// strip::slot: T[e] <- exp2(T[e]); T[e+1] scaled; row sum += T[e-1]; after every odd logit the pair before it is packed).
+#define VALU_E0 "v_fma_f32 %[cur], %[cur], %[l2e], %[add]\n\tv_fma_f32 %[nxt], %[nxt], %[l2e], %[add]\n\tv_exp_f32 %[cur], %[cur]"
+#define VALU_ODD "v_exp_f32 %[cur], %[cur]\n\tv_fma_f32 %[nxt], %[nxt], %[l2e], %[add]\n\tv_add_f32 %[sum], %[sum], %[p1]"
+#define VALU_EVEN VALU_ODD "\n\tv_cvt_pk_bf16_f32 %[pk], %[p2], %[p1]"
+#define VALU_E15 "v_exp_f32 %[cur], %[cur]\n\tv_add_f32 %[sum], %[sum], %[p1]"
+#define MF_S0 "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[c]\n\t"
+#define MF_S "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]\n\t"
+// kind 0: S MFMA with C = ci (D early-clobber VGPR; logit 0), 1: S MFMA accumulating
+template <int KIND>
+__device__ __forceinline__ void slot(f32x16& d, const v4i& a, const v4i& b, const f32x16& c, f32x16& T, int (&pk)[8], float& lsum,
+                                     float add, int e) {
+    float cur = T[e], nxt = T[e < 15 ? e + 1 : 15];
+    int r = 0;
+#define SLOT_ASM(MF, VA, DC)                                                                                                   \
+    asm volatile(MF VA : [d] DC(d), [cur] "+v"(cur), [nxt] "+v"(nxt), [sum] "+v"(lsum), [pk] "=&v"(r)                          \
+                 : [a] "v"(a), [b] "a"(b), [l2e] "s"(L2E), [add] "v"(add), [p1] "v"(T[e >= 1 ? e - 1 : 0]), [p2] "v"(T[e >= 2 ? e - 2 : 0]))
+#define SLOT_ASM_C(MF, VA, DC)                                                                                                 \
+    asm volatile(MF VA : [d] DC(d), [cur] "+v"(cur), [nxt] "+v"(nxt), [sum] "+v"(lsum), [pk] "=&v"(r)                          \
+                 : [a] "v"(a), [b] "a"(b), [c] "v"(c), [l2e] "s"(L2E), [add] "v"(add), [p1] "v"(T[e >= 1 ? e - 1 : 0]),            \
+                   [p2] "v"(T[e >= 2 ? e - 2 : 0]))
+    if (KIND == 0) {
+        SLOT_ASM_C(MF_S0, VALU_E0, "=&v");
+    } else {
+        if (e == 15) SLOT_ASM(MF_S, VALU_E15, "+v");
+        else if (e & 1) SLOT_ASM(MF_S, VALU_ODD, "+v");
+        else SLOT_ASM(MF_S, VALU_EVEN, "+v");
+    }
+#undef SLOT_ASM_C
+#undef SLOT_ASM
+    T[e] = cur;
+    if (e < 15) T[e + 1] = nxt;
+    if (e >= 2 && (e & 1) == 0) pk[(e - 2) >> 1] = r;
+}
+__device__ __forceinline__ void slot_tail(f32x16& T, int (&pk)[8], float& lsum) {
+    int r;
+    asm volatile("v_add_f32 %0, %0, %2\n\tv_cvt_pk_bf16_f32 %1, %3, %2" : "+v"(lsum), "=&v"(r) : "v"(T[15]), "v"(T[14]));
+    pk[7] = r;
+}
+
+struct Carry {            // operands of the next iteration's first PF S slots and the C rows of its logits, fetched in the O half
+    v4i zf[PF];
+    f32x16 ci;
+};
+
+// One pipeline iteration u: S(u+1) -> Sn, P(u) <- exp of Sc, O += P(u-1) . Z(u-1).
+//   s_unit / o_unit: LDS rows of unit u+1 / unit u-1;  nx_unit: unit u+2 — written to `st_slot` (= nx_unit) in the S half from
+//   staging set `stS`, readable behind the barrier between the halves: the O half fetches the next iteration's first operands
+//   from it.  The loads of unit u+5 are issued into staging set `stL` in the O half (stL.begin() called by the caller).
+template <int ROLE, int CW>
+__device__ __forceinline__ void unit_iter(f32x16 (&O)[8], const v4i (&XF)[16], f32x16& Sc, f32x16& Sn, v4i (&Pc)[2], const v4i (&Pp)[2],
+                                          float add, float& lsum, Carry& cy, const char* s_unit, const char* o_unit, char* nx_unit,
+                                          const LaneOff& lo, Stage<ROLE, CW>& stS, Stage<ROLE, CW>& stL) {
+    using Cf = W<CW>;
+    constexpr int ROWB = Cf::ROWB;
+    v4i zf[RING], tf[RING];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) zf[i] = cy.zf[i];
+    int pk[8];
+    // ---- S half: 16 MFMAs beside the 16 logits of P(u) -------------------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        if (ks + PF < 16) zf[(ks + PF) % RING] = lds_b128(s_unit + lo.zf + (ks + PF) * 32);
+        else { const int f = ks + PF - 16; tf[f % RING] = lds_tr<ROWB>(o_unit + lo.tr + (f >> 3) * 16 * ROWB + (f & 7) * 64); }
+        if (ks == 0) slot<0>(Sn, zf[0], XF[0], cy.ci, Sc, pk, lsum, add, 0);
+        else slot<1>(Sn, zf[ks % RING], XF[ks], cy.ci, Sc, pk, lsum, add, ks);
+        // SrcC of the ks = 0 MFMA is read late in its passes: nothing may be allocated over `ci` until it is done
+        if (ks >= 1 && ks <= 3) asm volatile("" ::"v"(cy.ci));
+        // the staged unit: 4 data pieces + the C operands, all before the tf prefetches (ks >= 10) so that the barrier's
+        // lgkmcnt leaves exactly those in flight
+        if (ks >= 1 && ks <= 9 && (ks & 1)) stS.store_piece(nx_unit, (ks - 1) >> 1);
+        SPIN();
+    }
+    slot_tail(Sc, pk, lsum);
+    // Workgroup barrier behind the staged stores: LDS operations retire in order, so the 2 (16 - (16 - PF)) = 12 transpose reads
+    // issued behind the last store piece (ks = 10 .. 15) may stay in flight.
+    asm volatile("s_waitcnt lgkmcnt(12)\n\ts_barrier" ::: "memory");
+    SPIN();
+    // ---- O half: 16 MFMAs; operands of the next S half, the loads of unit u+5 ---------------------------------------------------
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {          // f = ks2 * 8 + ct
+        const int fn = f + PF;
+        if (fn < 16) tf[fn % RING] = lds_tr<ROWB>(o_unit + lo.tr + (fn >> 3) * 16 * ROWB + (fn & 7) * 64);
+        else cy.zf[fn - 16] = lds_b128(nx_unit + lo.zf + (fn - 16) * 32);
+        if (f >= 4 && f < 8) fetch_ci_part(cy.ci, nx_unit + Cf::UNITB, lo, f - 4);
+        if (f < 10 && (f & 1)) stL.load_piece(f >> 1);
+        mfma_o(O[f & 7], Pp[f >> 3], tf[f % RING]);
+        SPIN();
+    }
+    Pc[0] = v4i{pk[0], pk[1], pk[2], pk[3]};
+    Pc[1] = v4i{pk[4], pk[5], pk[6], pk[7]};
+    SPIN();
+}
+
+struct Geo {     // per-wave geometry of a launch
+    const bf16* Z;
+    int tid, lane, wave, hi, l31;
+    int Reff, xbase, xend, z_lo, z_hi, nunit, by, nchunk_dev;
+    long slab_stride;
+    LaneOff lo;
+};
+
+// x fragments X[x = l31][16 ks + 8 hi ..+7] straight into AGPRs (rows past the end are clamped, not zeroed: their outputs are
+// never stored and `add` = -inf makes every exponential of theirs 0)
+template <int CW>
+__device__ __forceinline__ void load_xfrags(v4i (&XF)[16], const bf16* X, const Geo& g) {
+    const bf16* x0 = X + (long)max(min(g.xbase + g.l31, g.xend - 1), 0) * CW + g.hi * 8;
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\t"
+        "global_load_dwordx4 %2, %16, off offset:64\n\tglobal_load_dwordx4 %3, %16, off offset:96\n\t"
+        "global_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
+        "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"
+        "global_load_dwordx4 %8, %16, off offset:256\n\tglobal_load_dwordx4 %9, %16, off offset:288\n\t"
+        "global_load_dwordx4 %10, %16, off offset:320\n\tglobal_load_dwordx4 %11, %16, off offset:352\n\t"
+        "global_load_dwordx4 %12, %16, off offset:384\n\tglobal_load_dwordx4 %13, %16, off offset:416\n\t"
+        "global_load_dwordx4 %14, %16, off offset:448\n\tglobal_load_dwordx4 %15, %16, off offset:480\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&a"(XF[0]), "=&a"(XF[1]), "=&a"(XF[2]), "=&a"(XF[3]), "=&a"(XF[4]), "=&a"(XF[5]), "=&a"(XF[6]), "=&a"(XF[7]), "=&a"(XF[8]),
+          "=&a"(XF[9]), "=&a"(XF[10]), "=&a"(XF[11]), "=&a"(XF[12]), "=&a"(XF[13]), "=&a"(XF[14]), "=&a"(XF[15])
+        : "v"(x0)
+        : "memory");
+}
+
+// One sweep of the wave's 32 x vectors over the workgroup's z chunk: O, lsum (and, ROLE_YF with !EXACT, the reference m2 / add from
+// the chunk's first unit).  LOADX: the x fragments are fetched here, behind the first unit loads (one memory round trip for both).
+template <int ROLE, int CW, bool EXACT, bool LOADX>
+__device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* smem, const bf16* X, v4i (&XF)[16], f32x16 (&O)[8],
+                                          float& add, float& m2, float& lsum) {
+    using Cf = W<CW>;
+    constexpr bool YS = ROLE == ROLE_YF;
+    constexpr int SLOTB = Cf::SLOTB, UNITB = Cf::UNITB;
+    const int tid = g.tid;
+    const LaneOff lo = g.lo;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[ct][r] = 0.f;
+        // the zeros must sit in their AGPRs long before the first MFMA reads them (a write -> MFMA-read hazard hipcc cannot see inside asm)
+        asm volatile("" : "+a"(O[ct]));
+    }
+    lsum = 0.f;
+    if (g.nunit == 0) {
+        if (LOADX) load_xfrags<CW>(XF, X, g);
+        return;
+    }
+    // Four staging register sets: unit v travels through set v % 4, its loads issued three iterations before its stores.
+    Stage<ROLE, CW> st0, st1, st2, st3;
+    st0.init(p, g.Z, g.z_hi, g.Reff, tid); st1.init(p, g.Z, g.z_hi, g.Reff, tid);
+    st2.init(p, g.Z, g.z_hi, g.Reff, tid); st3.init(p, g.Z, g.z_hi, g.Reff, tid);
+    // ---- prologue: units 0 and 1 resident, 2 .. 4 in flight, S(0) --------------------------------------------------------------
+    st0.load(g.z_lo);
+    st1.load(g.z_lo + ZU);           // (rows past the chunk: clamped to its last row; their C operand is -inf)
+    if (LOADX) load_xfrags<CW>(XF, X, g);     // waits for everything issued so far
+    st0.store(smem);
+    st1.store(smem + SLOTB);
+    st2.load(g.z_lo + 2 * ZU);
+    st3.load(g.z_lo + 3 * ZU);
+    st0.load(g.z_lo + 4 * ZU);
+    // iteration 0 multiplies P(-1) = 0 into "unit -1" = ring slot 4: it must hold finite numbers
+#pragma unroll
+    for (int i = 0; i < UNITB / 16 / NTHR; ++i) *reinterpret_cast<uint4*>(smem + 4 * SLOTB + (tid + NTHR * i) * 16) = make_uint4(0, 0, 0, 0);
+    lds_barrier();
+    f32x16 Sa, Sb;
+    v4i Pa[2], Pb[2];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        Pa[k2] = v4i{0, 0, 0, 0}; Pb[k2] = v4i{0, 0, 0, 0};
+        asm volatile("" : "+v"(Pa[k2]), "+v"(Pb[k2]));
+    }
+    Carry cy;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) fetch_ci_part(cy.ci, smem + UNITB, lo, gq);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const v4i zf = lds_b128(smem + lo.zf + ks * 32);
+        if (ks == 0) mfma_s0(Sa, zf, XF[0], cy.ci);
+        else mfma_s(Sa, zf, XF[ks]);
+    }
+    settle_s(Sa);
+    asm volatile("" ::"v"(cy.ci));
+    if (YS && !EXACT) {   // reference of the chunk: maximum of the row's first 32 logits
+        float t = Sa[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) t = fmaxf(t, Sa[r]);
+        m2 = fmaxf(t, __shfl_xor(t, 32, 64)) * L2E;
+        add = -m2;
+    }
+    // carry for iteration 0: unit 1
+#pragma unroll
+    for (int i = 0; i < PF; ++i) cy.zf[i] = lds_b128(smem + SLOTB + lo.zf + i * 32);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) fetch_ci_part(cy.ci, smem + SLOTB + UNITB, lo, gq);
+    // ---- main loop: four iterations per trip (static names for the four staging sets and the two logit / P buffers) ------------
+    const int nunit4 = (g.nunit + 3) & ~3;
+    int sl = 0;                         // ring slot of unit u (u = first iteration of the trip)
+#pragma clang loop unroll(disable)
+    for (int u = 0; u < nunit4; u += 4) {
+        // slots of units u-1 .. u+5 (mod 5)
+        const int q0 = sl, q1 = sl + 1 >= 5 ? sl - 4 : sl + 1, q2 = sl + 2 >= 5 ? sl - 3 : sl + 2, q3 = sl + 3 >= 5 ? sl - 2 : sl + 3,
+                  q4 = sl + 4 >= 5 ? sl - 1 : sl + 4;
+        char* b0 = smem + q0 * SLOTB; char* b1 = smem + q1 * SLOTB; char* b2 = smem + q2 * SLOTB; char* b3 = smem + q3 * SLOTB;
+        char* b4 = smem + q4 * SLOTB;
+        // iteration u: S(u+1) from b1, O(u-1) from b4 (= slot of u-1), stores unit u+2 -> b2 from set (u+2)%4 = 2, loads unit u+5 -> set 1
+        st1.begin(g.z_lo + (u + 5) * ZU);
+        unit_iter<ROLE, CW>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, b1, b4, b2, lo, st2, st1);
+        // u+1: S(u+2) from b2, O(u) from b0, stores unit u+3 -> b3 from set 3, loads unit u+6 -> set 2
+        st2.begin(g.z_lo + (u + 6) * ZU);
+        unit_iter<ROLE, CW>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, b2, b0, b3, lo, st3, st2);
+        // u+2: S(u+3) from b3, O(u+1) from b1, stores unit u+4 -> b4 from set 0, loads unit u+7 -> set 3
+        st3.begin(g.z_lo + (u + 7) * ZU);
+        unit_iter<ROLE, CW>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, b3, b1, b4, lo, st0, st3);
+        // u+3: S(u+4) from b4, O(u+2) from b2, stores unit u+5 -> b0 from set 1, loads unit u+8 -> set 0
+        st0.begin(g.z_lo + (u + 8) * ZU);
+        unit_iter<ROLE, CW>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, b4, b2, b0, lo, st1, st0);
+        sl = q4;                        // unit u+4
+    }
+    // ---- drain: O(nunit4 - 1) ----------------------------------------------------------------------------------------------------
+    {
+        const int ql = sl == 0 ? 4 : sl - 1;
+        const char* o_unit = smem + ql * SLOTB;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            const v4i tf = lds_tr<Cf::ROWB>(o_unit + lo.tr + (f >> 3) * 16 * Cf::ROWB + (f & 7) * 64);
+            mfma_o(O[f & 7], Pb[f >> 3], tf);
+        }
+    }
+    settle_o(O);
+}
+
+// the wave's [32 x C] accumulator -> LDS -> whole rows of the slab; row sums / references
+template <int ROLE, int CW>
+__device__ __forceinline__ void epilogue(const StripP& p, const Geo& g, char* smem, const f32x16 (&O)[8], float m2, float lsum) {
+    using Cf = W<CW>;
+    constexpr bool YS = ROLE == ROLE_YF;
+    constexpr int OSTR = Cf::OSTR;
+    __syncthreads();
+    float* stg_o = reinterpret_cast<float*>(smem) + g.wave * XW * OSTR;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg_o[((r & 3) + 8 * (r >> 2) + 4 * g.hi) * OSTR + 32 * ct + g.l31] = O[ct][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    float* slab = p.slabs + (long)g.by * g.slab_stride;
+#pragma unroll 4
+    for (int xr = 0; xr < XW; ++xr) {
+        const int gx = g.xbase + xr;
+        const float4 v = *reinterpret_cast<const float4*>(stg_o + xr * OSTR + 4 * g.lane);
+        if (gx < g.xend) *reinterpret_cast<float4*>(slab + (long)gx * CW + 4 * g.lane) = v;
+    }
+    const float s = lsum + __shfl_xor(lsum, 32, 64);
+    const int gx = g.xbase + g.l31;
+    if (g.hi == 0 && gx < g.xend) {
+        if (YS) {
+            p.part[((long)gx * g.nchunk_dev + g.by) * 2] = m2 * (1.0f / L2E);
+            p.part[((long)gx * g.nchunk_dev + g.by) * 2 + 1] = s;
+        } else if (gx > 0) {
+            p.bias_slabs[(long)g.by * (p.I - 1) + gx - 1] = s;
+        }
+    }
+}
+
+// S-only sweep over a resident unit (ROLE_YF fallback): the exact maximum of every row's logits, per lane (16 of the unit's 32 rows)
+template <int CW>
+__device__ __forceinline__ void max_unit(float& mx, const v4i (&XF)[16], const char* unit, const LaneOff& lo) {
+    f32x16 ci, S;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) fetch_ci_part(ci, unit + W<CW>::UNITB, lo, gq);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const v4i zf = lds_b128(unit + lo.zf + ks * 32);
+        if (ks == 0) mfma_s0(S, zf, XF[0], ci);
+        else mfma_s(S, zf, XF[ks]);
+    }
+    settle_s(S);
+    asm volatile("" ::"v"(ci));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[r]);
+}
+
+// ROLE_YF, rare: a row sum left the f32-safe range (the chunk's reference is the maximum of its FIRST 32 logits).  Exact row maxima
+// over the whole chunk (S-only sweep), then the sweep again with them as references (exp <= 1).  Not inlined: own register allocation.
+template <int CW>
+__device__ __attribute__((noinline)) void fallback_exact(const StripP* pp, const Geo* gp, char* smem) {
+    const StripP p = *pp;
+    const Geo g = *gp;
+    v4i XF[16];
+    load_xfrags<CW>(XF, p.rows, g);
+    Stage<ROLE_YF, CW> stg;
+    stg.init(p, g.Z, g.z_hi, g.Reff, g.tid);
+    float mx = -INFINITY;
+    for (int u = 0; u < g.nunit; ++u) {
+        __syncthreads();
+        stg.load(g.z_lo + u * ZU);
+        stg.store(smem);
+        __syncthreads();
+        max_unit<CW>(mx, XF, smem, g.lo);
+    }
+    __syncthreads();
+    float m2 = fmaxf(mx, __shfl_xor(mx, 32, 64)) * L2E;
+    float add = -m2, lsum;
+    f32x16 O[8];
+    main_pass<ROLE_YF, CW, true, false>(p, g, smem, p.rows, XF, O, add, m2, lsum);
+    epilogue<ROLE_YF, CW>(p, g, smem, O, m2, lsum);
+}
+
+template <int ROLE, int CW>
+__global__ __launch_bounds__(NTHR, 1) void stripw_kernel(StripP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool YS = ROLE == ROLE_YF;
+    Geo g;
+    g.tid = threadIdx.x; g.lane = g.tid & 63; g.wave = g.tid >> 6; g.hi = g.lane >> 5; g.l31 = g.lane & 31;
+    g.Reff = p.nvalid ? min(p.R, p.nvalid[0]) : p.R;
+    int bx, zchunk;
+    g.nchunk_dev = 1;
+    if (YS) {
+        const DevPlan dp = dev_plan(g.Reff, XB, gridDim.x, p.i1 - p.i0, ZQ);
+        // XCD-aware order (see strip::strip_kernel): chunk-major ids dealt to the XCDs in contiguous runs — the x blocks of an item
+        // chunk stream the same table rows out of one XCD's L2
+        int id = blockIdx.x;
+        if ((gridDim.x & 7) == 0) id = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+        if (id >= dp.nx * dp.nchunk || g.Reff <= 0) return;
+        bx = id % dp.nx; g.by = id / dp.nx; zchunk = dp.zchunk; g.nchunk_dev = dp.nchunk;
+        g.slab_stride = (long)dp.nx * XB * CW;
+    } else {
+        bx = blockIdx.x; g.by = blockIdx.y;
+        const int nq = (g.Reff + ZQ - 1) / ZQ;
+        zchunk = (nq + (int)gridDim.y - 1) / (int)gridDim.y * ZQ;
+        g.slab_stride = (long)p.I * CW;
+    }
+    g.xbase = (YS ? 0 : p.i0) + bx * XB + g.wave * XW;
+    g.xend = YS ? g.Reff : p.i1;
+    const bf16* X = YS ? p.rows : p.table;
+    g.Z = YS ? p.table : p.rows;
+    g.z_lo = (YS ? p.i0 : 0) + g.by * zchunk;
+    g.z_hi = min(YS ? p.i1 : g.Reff, g.z_lo + zchunk);
+    g.nunit = g.z_hi > g.z_lo ? (g.z_hi - g.z_lo + ZU - 1) / ZU : 0;
+    g.lo = lane_off<W<CW>::ROWB>(g.lane);
+    v4i XF[16];
+    float add, lsum = 0.f, m2 = 0.f;
+    {
+        const int gx = g.xbase + g.l31;
+        // ROLE_W: logit + bias[x] rides in the exponent's fma; the pad item's logit is -1000 (Base.py:110), items past the shard give 0
+        const float ob = YS ? 0.f : p.out_bias[min(max(gx, 1), p.I - 1) - 1];
+        add = YS ? 0.f : (gx >= g.xend ? -INFINITY : (gx == 0 ? -1000.0f * L2E : ob * L2E));
+    }
+    {
+        f32x16 O[8];
+        main_pass<ROLE, CW, false, true>(p, g, smem, X, XF, O, add, m2, lsum);
+        bool bad = false;
+        if (YS) {
+            const float s = lsum + __shfl_xor(lsum, 32, 64);
+            bad = (g.xbase + g.l31 < g.xend) && !(s < LSUM_LIMIT);
+        }
+        if (!YS || !__syncthreads_or(bad ? 1 : 0)) {
+            epilogue<ROLE, CW>(p, g, smem, O, m2, lsum);
+            return;
+        }
+    }
+    if (YS) {   // copies: the structs the hot path reads must not be address-taken (they would live in scratch)
+        const StripP p2 = p;
+        const Geo g2 = g;
+        fallback_exact<CW>(&p2, &g2, smem);
+    }
+}
+
+// d_table[label[r]] -= coef[r] rows[r];  d_bias[label[r] - 1] -= coef[r]   over the weighted rows: the one-hot part of
+// dl = coef (p - onehot) that the ROLE_W product pass leaves out (strip::label_scatter_kernel at any width: a block = RB rows x CW
+// channels, equal labels summed in LDS first in row order by one thread per channel, the leaders' sums leave as f32 atomics).
+template <int CW, int RB>
+__global__ __launch_bounds__(CW) void label_scatter_kernel(const bf16* rows, const int64_t* labels, const float* coef,
+                                                           const int32_t* nvalid, int R, int i0, int i1, const float* gscale,
+                                                           float* d_table, float* d_bias) {
+    __shared__ float acc[RB][CW];
+    __shared__ float accb[RB];
+    __shared__ int lab_s[RB], lead_s[RB];
+    __shared__ float cf_s[RB];
+    const int Reff = nvalid ? min(R, nvalid[0]) : R;
+    const int r0 = blockIdx.x * RB, tid = threadIdx.x;
+    if (r0 >= Reff) return;
+    const float gs = gscale ? gscale[0] : 1.0f;
+    float xv[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) xv[j] = (float)rows[(long)min(r0 + j, Reff - 1) * CW + tid];
+    if (tid < RB) {
+        const int r = r0 + tid;
+        const int64_t lb = labels[min(r, Reff - 1)];
+        const float cf = coef[min(r, Reff - 1)];
+        const bool on = r < Reff && lb != 0 && lb >= i0 && lb < i1 && cf != 0.f;
+        lab_s[tid] = on ? (int)lb : -1;
+        cf_s[tid] = on ? cf * gs : 0.f;
+        accb[tid] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) acc[j][tid] = 0.f;
+    __syncthreads();
+    if (tid < RB) {   // leader = first row of the block with the same label
+        int lead = tid;
+        const int lb = lab_s[tid];
+        for (int j = tid - 1; j >= 0; --j)
+            if (lab_s[j] == lb) lead = j;
+        lead_s[tid] = lead;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RB; ++j) acc[lead_s[j]][tid] += cf_s[j] * xv[j];     // column `tid` is private to this thread
+    if (tid == 0)
+        for (int j = 0; j < RB; ++j) accb[lead_s[j]] += cf_s[j];
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < RB; ++j)
+        if (lab_s[j] >= 0 && lead_s[j] == j) atomicAdd(d_table + (long)lab_s[j] * CW + tid, -acc[j][tid]);
+    if (tid < RB && lab_s[tid] >= 0 && lead_s[tid] == tid) atomicAdd(d_bias + lab_s[tid] - 1, -accb[tid]);
+}
+
+}  // namespace stripw
+
+// ---- host side (called from k_score.hip) --------------------------------------------------------------------------------------
+bool edgl_stripw_enabled() {
+    static const int on = getenv("EDGL_SCORE_STRIPW") ? atoi(getenv("EDGL_SCORE_STRIPW")) : 1;
+    return on != 0;
+}
+bool edgl_stripw_supports(int C) { return C == 256; }
+
+// the dynamic-LDS attribute of a kernel is per device (see k_score_strip.hip)
+static void stripw_set_smem_attr(const void* kern, int which, int bytes) {
+    static std::atomic<uint64_t> done[4];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        return;
+    }
+    const uint64_t bit = 1ull << dev;
+    if (done[which].load(std::memory_order_acquire) & bit) return;
+    hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done[which].fetch_or(bit, std::memory_order_release);
+}
+
+int edgl_stripw_rows(const void* rows, const void* table, const float* out_bias, int R, int C, int I, int i0, int i1,
+                     const int32_t* nvalid, float* slabs, float* part, int G, hipStream_t st) {
+    EDGL_REQUIRE(edgl_stripw_supports(C), EDGL_ERR_SHAPE, "edgl_stripw_rows: C=%d unsupported", C);
+    stripw::StripP p{};
+    p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
+    p.nvalid = nvalid; p.slabs = slabs; p.part = part;
+    auto k = stripw::stripw_kernel<stripw::ROLE_YF, 256>;
+    stripw_set_smem_attr((const void*)k, 0, stripw::W<256>::SMEM);
+    hipLaunchKernelGGL(k, dim3(G), dim3(stripw::NTHR), stripw::W<256>::SMEM, st, p);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+int edgl_stripw_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
+                      int C, int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, hipStream_t st) {
+    EDGL_REQUIRE(edgl_stripw_supports(C), EDGL_ERR_SHAPE, "edgl_stripw_table: C=%d unsupported", C);
+    stripw::StripP p{};
+    p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
+    p.nvalid = nvalid; p.coef = coef; p.row_lse = row_lse; p.slabs = slabs; p.bias_slabs = bias_slabs;
+    auto k = stripw::stripw_kernel<stripw::ROLE_W, 256>;
+    stripw_set_smem_attr((const void*)k, 1, stripw::W<256>::SMEM);
+    hipLaunchKernelGGL(k, dim3((i1 - i0 + stripw::XB - 1) / stripw::XB, nchunk), dim3(stripw::NTHR), stripw::W<256>::SMEM, st, p);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}
+
+int edgl_stripw_label_scatter(const void* rows, const int64_t* labels, const float* coef, const int32_t* nvalid, int R, int C, int i0,
+                              int i1, const float* gscale, float* d_table, float* d_bias, hipStream_t st) {
+    EDGL_REQUIRE(edgl_stripw_supports(C), EDGL_ERR_SHAPE, "edgl_stripw_label_scatter: C=%d unsupported", C);
+    hipLaunchKernelGGL((stripw::label_scatter_kernel<256, 32>), dim3((R + 31) / 32), dim3(256), 0, st, (const bf16*)rows, labels, coef,
+                       nvalid, R, i0, i1, gscale, d_table, d_bias);
+    EDGL_LAUNCH_CHECK();
+    return EDGL_OK;
+}

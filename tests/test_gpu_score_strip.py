@@ -1,4 +1,4 @@
-"""K5 strip kernels (csrc/k_score_strip.hip: bf16, C = 128, one wave per SIMD) behind edgl_score_flash_fwd_coef / _bwd, against an
+"""K5 strip kernels (csrc/k_score_strip.hip: bf16, C = 128; csrc/k_score_stripw.hip: C = 256; one wave per SIMD) behind edgl_score_flash_fwd_coef / _bwd, against an
 fp64 restatement of EasyDGL.py:149-155,177-185 (Appendix C of SURVEY.md) computed by torch on the same bf16 operands — at sizes up
 to the benchmarked one (R_w ~ 5.4 K weighted rows x 20001 items = 12 item chunks x 21 row blocks), with the label pile-up of the
 Zipf recipe, and with logit spreads that force the exact-maximum fallback of the row reference."""
@@ -86,10 +86,10 @@ def _check(rows, tab, bias, labels, tol_rows=1.2e-2, tol_tab=6e-3):
     assert float(d_tab[0].abs().max()) == 0.0
 
 
-def _problem(R, I, seed, hot=0.0, zero=0.3, scale_rows=0.6, scale_tab=0.4):
+def _problem(R, I, seed, hot=0.0, zero=0.3, scale_rows=0.6, scale_tab=0.4, C=128):
     g = torch.Generator(device="cuda").manual_seed(seed)
-    rows = (torch.randn(R, 128, device="cuda", generator=g) * scale_rows).bfloat16()
-    tab = (torch.randn(I, 128, device="cuda", generator=g) * scale_tab).bfloat16()
+    rows = (torch.randn(R, C, device="cuda", generator=g) * scale_rows * (128 / C) ** 0.5).bfloat16()     # logits of the same spread at every width
+    tab = (torch.randn(I, C, device="cuda", generator=g) * scale_tab).bfloat16()
     bias = torch.randn(I - 1, device="cuda", generator=g) * 0.3
     labels = torch.randint(1, I, (R,), device="cuda", generator=g)
     u = torch.rand(R, device="cuda", generator=g)
@@ -98,26 +98,40 @@ def _problem(R, I, seed, hot=0.0, zero=0.3, scale_rows=0.6, scale_tab=0.4):
     return rows, tab, bias, labels
 
 
-@pytest.mark.parametrize("R,I,hot", [(70, 130, 0.0), (257, 2701, 0.2), (1000, 20001, 0.35), (640, 4099, 0.0)])
-def test_strip_against_fp64(R, I, hot):
-    _check(*_problem(R, I, seed=R + I, hot=hot))
+WIDTHS = [128, 256]      # k_score_strip.hip / k_score_stripw.hip
 
 
-def test_strip_at_the_benchmarked_size():
+@pytest.mark.parametrize("C", WIDTHS)
+@pytest.mark.parametrize("R,I,hot", [(70, 130, 0.0), (257, 2701, 0.2), (1000, 20001, 0.35), (640, 4099, 0.0), (31, 33, 0.0), (129, 161, 0.5)])
+def test_strip_against_fp64(R, I, hot, C):
+    _check(*_problem(R, I, seed=R + I, hot=hot, C=C))
+
+
+@pytest.mark.parametrize("C", WIDTHS)
+def test_strip_at_the_benchmarked_size(C):
     """B = 512, M = 20 -> 10240 masked slots of which ~52 % are weighted: 21 row blocks x 12 item chunks of the 20001-item table."""
-    rows, tab, bias, labels = _problem(10240, 20001, seed=5, hot=0.35, zero=0.475)
+    rows, tab, bias, labels = _problem(10240, 20001, seed=5, hot=0.35, zero=0.475, C=C)
     _check(rows, tab, bias, labels)
 
 
-def test_strip_all_rows_weighted():
-    rows, tab, bias, labels = _problem(10240, 20001, seed=6, hot=0.0, zero=0.0)
+@pytest.mark.parametrize("C", WIDTHS)
+def test_strip_all_rows_weighted(C):
+    rows, tab, bias, labels = _problem(10240, 20001, seed=6, hot=0.0, zero=0.0, C=C)
     _check(rows, tab, bias, labels)
 
 
-def test_strip_reference_fallback_on_a_wide_logit_spread():
+def test_wide_strip_on_a_table_of_many_chunks():
+    """C = 256 against a 150 K-item table (config 3's width; the slab cap of the planner bounds the item chunks): every chunk count /
+    remainder path of the device plan at a size the fp64 reference still holds (2000 x 150001 logits)."""
+    rows, tab, bias, labels = _problem(2000, 150001, seed=8, hot=0.1, zero=0.3, C=256)
+    _check(rows, tab, bias, labels)
+
+
+@pytest.mark.parametrize("C", WIDTHS)
+def test_strip_reference_fallback_on_a_wide_logit_spread(C):
     """A few rows whose largest logit sits ~150 above the logits of the chunk's first unit: exp(logit - reference) overflows f32
     in the first attempt, the workgroup must redo its chunk with the exact row maxima — results as accurate as everywhere else."""
-    rows, tab, bias, labels = _problem(600, 9001, seed=11, hot=0.0, zero=0.2)
+    rows, tab, bias, labels = _problem(600, 9001, seed=11, hot=0.0, zero=0.2, C=C)
     rows = rows.float(); tab = tab.float()
     for r, z in ((3, 4000), (200, 77), (599, 9000), (300, 8000)):
         v = rows[r] / rows[r].norm()
@@ -127,8 +141,9 @@ def test_strip_reference_fallback_on_a_wide_logit_spread():
     _check(rows, tab, bias, labels, tol_rows=2e-2, tol_tab=1.5e-2)
 
 
-def test_strip_label_scatter_with_every_row_on_one_label():
-    rows, tab, bias, labels = _problem(900, 3001, seed=13, hot=1.0, zero=0.0)
+@pytest.mark.parametrize("C", WIDTHS)
+def test_strip_label_scatter_with_every_row_on_one_label(C):
+    rows, tab, bias, labels = _problem(900, 3001, seed=13, hot=1.0, zero=0.0, C=C)
     _check(rows, tab, bias, labels)
 
 

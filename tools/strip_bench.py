@@ -12,9 +12,9 @@ from easydgl_amd import ops  # noqa: E402
 from easydgl_amd._lib import check, lib  # noqa: E402
 from easydgl_amd.ops import _ptr as p, _stream  # noqa: E402
 
-R, C, I = 10240, 128, 20001
+R, C, I = (int(os.environ.get(k, d)) for k, d in (("R", "10240"), ("C", "128"), ("I", "20001")))      # R=20480 C=256 I=1000001: config 3
 g = torch.Generator(device="cuda").manual_seed(1)
-rows = (torch.randn(R, C, device="cuda", generator=g) * 0.6).bfloat16()
+rows = (torch.randn(R, C, device="cuda", generator=g) * 0.6 * (128 / C) ** 0.5).bfloat16()
 tab = (torch.randn(I, C, device="cuda", generator=g) * 0.4).bfloat16()
 bias = torch.randn(I - 1, device="cuda", generator=g) * 0.3
 labels = torch.randint(1, I, (R,), device="cuda", generator=g)
