@@ -37,10 +37,12 @@ int edgl_strip_table(const void* rows, const void* table, const float* out_bias,
 // k_score_stripw.hip: the same passes at C = 256 (32 x vectors per wave, 128 per workgroup)
 bool edgl_stripw_enabled();
 bool edgl_stripw_supports(int C);
+long edgl_stripw_info_floats(long n);
 int edgl_stripw_rows(const void* rows, const void* table, const float* out_bias, int R, int C, int I, int i0, int i1,
-                     const int32_t* nvalid, float* slabs, float* part, int G, hipStream_t st);
+                     const int32_t* nvalid, float* slabs, float* part, int G, float* info_ws, hipStream_t st);
 int edgl_stripw_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
-                      int C, int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, hipStream_t st);
+                      int C, int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, float* info_ws,
+                      hipStream_t st);
 int edgl_stripw_label_scatter(const void* rows, const int64_t* labels, const float* coef, const int32_t* nvalid, int R, int C, int i0,
                               int i1, const float* gscale, float* d_table, float* d_bias, hipStream_t st);
 int edgl_strip_label_scatter(const void* rows, const int64_t* labels, const float* coef, const int32_t* nvalid, int R, int i0, int i1,
@@ -1617,7 +1619,7 @@ inline int l2_tiles_for(int C, size_t esize, int images, int ZB) { return std::m
 constexpr int F_L2_TILES_MIN = 32;   // smallest value l2_tiles_for(C, esize, 1, zb) takes over the supported (C, dtype): workspace bound
 struct BwdPlan {
     Chunking y, w;
-    long off_rowsT, off_tableT, off_slabY, off_slabW, off_slabB, off_part, total;  // float offsets
+    long off_rowsT, off_tableT, off_slabY, off_slabW, off_slabB, off_part, off_infoY, off_infoW, total;  // float offsets
 };
 // The flash form (edgl_score_flash_*) at bf16 / C = 128 runs the strip kernels (k_score_strip.hip): 256 x vectors per
 // workgroup as well, 64-z tiles handed out in pairs.
@@ -1652,6 +1654,11 @@ inline BwdPlan bwd_plan(int R, int C, int I, int n_items, size_t esize, int stri
     b.off_slabW = take((long)b.w.nchunk * I * C);
     b.off_slabB = take((long)b.w.nchunk * (I - 1));
     b.off_part = take(2L * gy * xb);   // (max, sum) per (row, item chunk) of the ROLE_YF pass
+    b.off_infoY = b.off_infoW = 0;
+    if (strip == 2) {                  // k_score_stripw.hip: the C operands of the z rows of a pass (items / rows), -inf padded
+        b.off_infoY = take(edgl_stripw_info_floats(n_items));
+        b.off_infoW = take(edgl_stripw_info_floats(R));
+    }
     b.total = o;
     return b;
 }
@@ -1729,7 +1736,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
         q.zchunk = plan.y.zchunk; q.nchunk = plan.y.nchunk; q.slabs = ws + plan.off_slabY; q.part = part;
         edgl_prof_begin(EDGL_KERNEL_SCORE_BWD_ROWS, st);
         if (strip == 2) {
-            const int rc = edgl_stripw_rows(p.rows, p.table, p.out_bias, p.R, p.C, p.I, p.i0, p.i1, p.nvalid, q.slabs, part, G, st);
+            const int rc = edgl_stripw_rows(p.rows, p.table, p.out_bias, p.R, p.C, p.I, p.i0, p.i1, p.nvalid, q.slabs, part, G, ws + plan.off_infoY, st);
             if (rc) return rc;
         } else if (strip) {
             const int rc = edgl_strip_rows(p.rows, p.table, p.out_bias, p.R, p.I, p.i0, p.i1, p.nvalid, q.slabs, part, G, slab16 ? 1 : 0, st);
@@ -1790,7 +1797,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
         q.zchunk = plan.w.zchunk; q.nchunk = plan.w.nchunk; q.slabs = ws + plan.off_slabW; q.bias_slabs = ws + plan.off_slabB;
         if (strip == 2) {
             const int rc = edgl_stripw_table(p.rows, p.table, p.out_bias, p.coef, p.row_lse, p.R, p.C, p.I, p.i0, p.i1, p.nvalid, q.slabs,
-                                             q.bias_slabs, q.nchunk, st);
+                                             q.bias_slabs, q.nchunk, ws + plan.off_infoW, st);
             if (rc) return rc;
         } else if (strip) {
             const bool acc = p.acc_atomic && !p.gscale;

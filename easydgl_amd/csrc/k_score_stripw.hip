@@ -8,17 +8,23 @@
 // What the width changes.  A wave's [x][C] f32 accumulator and its x fragments must stay in the register file: at C = 256 that is
 // 32 x vectors per wave (128 + 64 registers, as 64 x vectors are at C = 128), i.e. ONE 32-column MFMA tile, 128 x vectors per
 // workgroup.  A 32-row z unit then costs 16 + 16 MFMAs (v_mfma_f32_32x32x16_bf16) for 16 logits per lane instead of 32: half a
-// logit per MFMA slot, so the VALU stream that bounds the C = 128 loop (54 cycles per 32-cycle MFMA, DESIGN rule 27) fits beside
-// the S half alone and the O half is MFMAs + operand reads.  What becomes scarce instead is the LDS port: every unit is read twice
-// by every wave (row fragments for S, transposed fragments for O) with nothing shared between the two x tiles a C = 128 wave has
-// — 144 of a unit's 256 LDS cycles per wave quartet — so operands are fetched SIX slots ahead through rings of eight.
+// logit per MFMA slot, so the VALU stream that bounds the C = 128 loop (54 cycles per 32-cycle MFMA, DESIGN rule 27) fits with
+// room.  What becomes scarce instead is the way INTO the LDS: a unit (16 KB) feeds only 128 MFMAs, and staging it through
+// registers (global_load -> ds_write_b128, the C = 128 kernel's form) measured 34 % of the kernel — 17 % the loads and their
+// address arithmetic, 25 % the stores (13 cycles of the SIMD pair's LDS path each) — with the MFMA pipe at 55 %.  Hence:
 //
-// Geometry: 4 waves = one per SIMD, 512 registers each; z streams through LDS in 32-row units, ring of FIVE (a unit is written
-// two iterations before its first read and last read one iteration before the slot's next write + one barrier: four slots would
-// need a second barrier per unit), one barrier per unit; rows are staged global -> registers -> LDS through four register sets,
-// the loads of a unit issued three iterations before its stores.
-// LDS image of a unit: row z at byte z*ROWB + rot(z)*16, ROWB = 2 C + 256, rot(z) = ((z&3)<<2) | ((z>>2)&3) — the layout of the
-// C = 128 kernel (ROWB a multiple of 256: the same banks), every address one lane register + an immediate.
+// LDS-direct staging (global_load_lds_dwordx4): a wave instruction moves 64 x 16 bytes from per-lane global addresses to ONE
+// contiguous KB of LDS at M0 — no staging registers, no ds_write, no compiler-visible load in the loop (every vmcnt is placed
+// by hand).  The LDS image is built for that: BLOCK b = 0..15 of a unit holds rows b and b + 16 back to back (1 KB = one
+// instruction: lanes 0-31 fetch row b, lanes 32-63 row b + 16) at byte b*1280 + rot(b)*16, rot(b) = ((b&3)<<2) | ((b>>2)&3) —
+// rows b and b + 16 share rot, 1280 = 5 x 256 keeps the banks of the C = 128 layout (row-fragment reads of 16 rows and transpose
+// reads of 4 rows x 64 bytes conflict free), every read address is one lane register + an immediate.  The per-row C operands
+// (bias / -1000 / -inf;  log coef - lse) come from a small array a pre-kernel writes (info_kernel: -inf padded, so that no
+// masking is left in the loop) through global_load_lds_dword.
+//
+// Geometry: 4 waves = one per SIMD, 512 registers each; z streams through LDS in 32-row units, ring of SEVEN: the loads of unit
+// u+5 are issued in the second half of iteration u (behind the barrier: the slot of unit u-2 is free), unit u+2 must have
+// landed at iteration u's barrier (s_waitcnt vmcnt(8): the two younger units stay in flight) — three iterations ~ 3 us of cover.
 #include <atomic>
 #include <cstdlib>
 
@@ -30,10 +36,22 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 namespace stripw {
 
-constexpr int NTHR = 256, XW = 32, XB = 128, ZU = 32, ZQ = 128;     // ZQ: chunk granularity (four units = one loop trip)
-constexpr int INFOB = ZU * 4;
-constexpr int NSLOT = 5;
-constexpr int PF = 6, RING = 8;            // operand prefetch distance (MFMA slots) / ring size
+constexpr int NTHR = 256, XW = 32, XB = 128, ZU = 32, ZQ = 128;     // ZQ: chunk granularity of the planners
+constexpr int INFOB = 256;                 // one global_load_lds_dword: 64 floats (the unit's 32 + the next unit's, unused)
+#ifndef STRIPW_AHEAD
+#define STRIPW_AHEAD 5
+#endif
+constexpr int AHEAD = STRIPW_AHEAD, NSLOT = AHEAD + 2;     // iteration u issues the loads of unit u + AHEAD; ring slots
+static_assert(AHEAD >= 3 && AHEAD <= 5, "ring of 5 .. 7 units");
+constexpr int CPAD = 512;                  // -inf entries behind the C-operand arrays (units past a chunk's end read them)
+#ifndef STRIPW_PF
+#define STRIPW_PF 6
+#endif
+#ifndef STRIPW_SPREAD
+#define STRIPW_SPREAD 1
+#endif
+constexpr int PF = STRIPW_PF, RING = 8;    // operand prefetch distance (MFMA slots) / ring size
+static_assert(PF >= 2 && PF < RING, "operand rings");
 constexpr float L2E = 1.4426950408889634f;
 constexpr float LSUM_LIMIT = 1.2676506e30f;   // 2^100
 
@@ -42,15 +60,14 @@ struct W {
     static constexpr int C = CW;
     static constexpr int KS = CW / 16;                 // S MFMAs of a unit
     static constexpr int CT = CW / 32;                 // 32-channel tiles of the accumulator
-    static constexpr int ROWB = 2 * CW + 256;          // LDS bytes per z row
-    static constexpr int UNITB = ZU * ROWB;
+    static constexpr int BLKB = 4 * CW + 256;          // LDS bytes per block = rows b, b + 16 (+ the rotation range)
+    static constexpr int UNITB = 16 * BLKB;
     static constexpr int SLOTB = UNITB + INFOB;
     static constexpr int OSTR = CW + 4;                // floats per staged output row (epilogue)
     static constexpr int SMEM_LOOP = NSLOT * SLOTB, SMEM_EPI = 4 * XW * OSTR * 4;
     static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
-    static constexpr int NP = (ZU * 2 * CW / 16) / NTHR;   // 16-byte staging pieces per thread and unit (4 at C = 256)
     static_assert(SMEM <= 160 * 1024, "LDS");
-    static_assert(KS == 16 && CT == 8 && NP == 4, "the slot schedule below is written for C = 256");
+    static_assert(KS == 16 && CT == 8 && 2 * CW * 2 == 1024, "the slot schedule and the one-KB blocks below are written for C = 256");
 };
 
 enum { ROLE_YF = 0, ROLE_W = 1 };
@@ -59,7 +76,8 @@ struct StripP {
     const bf16* rows; const bf16* table; const float* out_bias;
     int R, I, i0, i1;
     const int32_t* nvalid;
-    const float* coef; const float* row_lse;     // ROLE_W
+    const float* cinfo;       // C operand per z row, relative to the pass's first z (info_kernel; CPAD entries of -inf behind the range)
+    int ncinfo;               // its length incl. the padding
     float* slabs; float* bias_slabs; float* part;
 };
 
@@ -70,88 +88,81 @@ __device__ __forceinline__ v4i lds_b128(const char* p) { return *reinterpret_cas
 __device__ __forceinline__ f32x4 lds_f4(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
 // B operand of a 32x32x16 MFMA contracting along the rows of the unit: two transpose reads (slots 0-3: rows +0..3, slots 4-7:
 // rows +8..11 of this lane half's row group — the order in which P is packed from the logit registers)
-template <int ROWB>
+template <int BLKB>
 __device__ __forceinline__ v4i lds_tr(const char* p) {
     typedef __attribute__((ext_vector_type(4))) short s4;
     const s4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
-    const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p + 8 * ROWB + 32));
+    const s4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(p + 8 * BLKB + 32));   // rows + 8: rot + 2
     const uint2 a = __builtin_bit_cast(uint2, v0), b = __builtin_bit_cast(uint2, v1);
     return v4i{(int)a.x, (int)a.y, (int)b.x, (int)b.y};
 }
 
+// Per-lane LDS offsets (bytes, relative to a unit's first block).  Row z of a unit: block z & 15, second half of it for z >= 16.
 struct LaneOff {
     int zf;   // row-fragment read: row l&31, k-slot hi        (+ ks*32)
-    int tr;   // transpose read: row 4hi + (s>>2), columns 16*(G&1) + 4*(s&3)   (+ ks2*16*ROWB + ct*64)
+    int tr;   // transpose read: row 4hi + (s>>2), columns 16*(G&1) + 4*(s&3)   (+ ks2*512 + ct*64; rows + 8: lds_tr)
     int ci;   // C operand of the logit rows: info floats 4hi .. 4hi+3   (+ g*32)
 };
-template <int ROWB>
+template <int BLKB>
 __device__ __forceinline__ LaneOff lane_off(int lane) {
     LaneOff o;
     const int zr = lane & 31, hi = lane >> 5, G = lane >> 4, s = lane & 15;
-    o.zf = zr * ROWB + rot16(zr) + hi * 16;
+    o.zf = (zr & 15) * BLKB + rot16(zr & 15) + (zr >> 4) * 512 + hi * 16;
     const int tz = 4 * hi + (s >> 2);
-    o.tr = tz * ROWB + rot16(tz) + (16 * (G & 1) + 4 * (s & 3)) * 2;
+    o.tr = tz * BLKB + rot16(tz) + (16 * (G & 1) + 4 * (s & 3)) * 2;
     o.ci = 4 * hi * 4;
     return o;
 }
 
-// global -> registers -> LDS staging of one 32-row unit (+ its per-row C operand) in single-instruction pieces.  Thread t owns
-// 16-byte chunk (t & 15) + 16 j of rows (t >> 4) + 16 i, piece k = i + 2 j: rot(row) is the same for both rows, so a piece is one
-// clamp + one address add + the access.  Rows past the chunk / table row 0 are not zero-filled: their C operand (-inf / -1000)
-// makes every exponential of such a row exactly 0, the DATA only has to be finite (loads clamped to the chunk's last row).
-template <int ROLE, int CW>
-struct Stage {
+// LDS-direct staging of one 32-row unit: wave w moves blocks 4w .. 4w+3 (one instruction each: lanes 0-31 row b, lanes 32-63
+// row b + 16; rows past the chunk are clamped to its last row — their C operand is -inf, the data only has to be finite), wave 0
+// also the unit's C operands.  M0 is saved and restored inside each statement (the compiler owns it).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+template <int CW>
+struct Dma {
     using Cf = W<CW>;
-    uint4 g0, g1, g2, g3;
-    float cinfo, cinfo2;
-    int z0_, zend_;
-    const bf16* Z_;
-    const float* bias_; const float* coef_; const float* lse_;
-    int I_, Reff_, tid_, row0_, goff_, loff_;
-    __device__ __forceinline__ void init(const StripP& p, const bf16* Z, int zend, int Reff, int tid) {
-        Z_ = Z; bias_ = p.out_bias; coef_ = p.coef; lse_ = p.row_lse; I_ = p.I; zend_ = zend; Reff_ = Reff; tid_ = tid;
-        cinfo = 0.f; cinfo2 = 0.f; z0_ = 0;
-        row0_ = tid >> 4;
-        goff_ = (tid & 15) * 8;                                            // elements
-        loff_ = row0_ * Cf::ROWB + rot16(row0_) + (tid & 15) * 16;         // bytes
+    const char* Z_;           // first byte of the z operand
+    const float* ci_;         // C operands, entry 0 = the pass's first z
+    int zend_, zrel_, nci_, wave_, lrow_, lcol_, lane_;
+    unsigned boff_[4];        // LDS offset of block 4 wave + j inside a unit (wave-uniform)
+    int z0_;
+    __device__ __forceinline__ void init(const StripP& p, const bf16* Z, int zend, int zfirst, int wave, int lane) {
+        Z_ = reinterpret_cast<const char*>(Z); ci_ = p.cinfo; nci_ = p.ncinfo; zend_ = zend; zrel_ = zfirst; wave_ = __builtin_amdgcn_readfirstlane(wave); lane_ = lane;
+        lrow_ = 16 * (lane >> 5); lcol_ = (lane & 31) * 16; z0_ = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int b = 4 * wave + j; boff_[j] = (unsigned)__builtin_amdgcn_readfirstlane(b * Cf::BLKB + rot16(b)); }
     }
     __device__ __forceinline__ void begin(int z0) { z0_ = z0; }
-    __device__ __forceinline__ void load_piece(int k) {      // k = 0..3: 16 bytes of the unit;  k = 4: the per-row scalars
+    __device__ __forceinline__ void piece(unsigned slot_lds, int k) {       // k = 0..3: one block;  k = 4: the C operands (wave 0)
+#if defined(STRIPW_NOSTAGE)
+        return;
+#endif
         if (k < 4) {
-            const int gz = max(min(z0_ + row0_ + 16 * (k & 1), zend_ - 1), 0);
-            const uint4 v = *reinterpret_cast<const uint4*>(Z_ + (long)gz * CW + goff_ + (k >> 1) * 128);
-            if (k == 0) g0 = v; else if (k == 1) g1 = v; else if (k == 2) g2 = v; else g3 = v;
-        } else {
-            const int z = z0_ + (tid_ & (ZU - 1));      // every wave loads them (no divergent branch); the first 32 threads store
-            if (ROLE == ROLE_YF) {
-                cinfo = bias_[min(max(z, 1), I_ - 1) - 1];
-            } else {
-                const int gc = max(min(z, Reff_ - 1), 0);
-                cinfo = coef_[gc]; cinfo2 = lse_[gc];
-            }
+            const int gz = max(min(z0_ + 4 * wave_ + k + lrow_, zend_ - 1), 0);
+            glds16(Z_ + (long)gz * (CW * 2) + lcol_, slot_lds + boff_[k]);
+        } else if (wave_ == 0) {
+            const int gi = max(min(z0_ - zrel_ + lane_, nci_ - 1), 0);
+            glds4(ci_ + gi, slot_lds + Cf::UNITB);
         }
     }
-    __device__ __forceinline__ void load(int z0) {
+    __device__ __forceinline__ void issue(unsigned slot_lds, int z0) {
         begin(z0);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) load_piece(k);
-    }
-    __device__ __forceinline__ void store_piece(char* slot, int k) {
-        if (k < 4) {
-            *reinterpret_cast<uint4*>(slot + loff_ + (k & 1) * 16 * Cf::ROWB + (k >> 1) * 256) = k == 0 ? g0 : (k == 1 ? g1 : (k == 2 ? g2 : g3));
-        } else {
-            const int z = z0_ + (tid_ & (ZU - 1));
-            float c;
-            if (ROLE == ROLE_YF) c = z >= zend_ ? -INFINITY : (z == 0 ? -1000.0f : cinfo);   // pad logit -1000 (Base.py:110)
-            else c = (z < zend_ && cinfo > 0.f) ? __logf(cinfo) - cinfo2 : -INFINITY;        // -(lse - log coef)
-            if (tid_ < ZU) reinterpret_cast<float*>(slot + Cf::UNITB)[tid_] = c;
-        }
-    }
-    __device__ __forceinline__ void store(char* slot) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) store_piece(slot, k);
+        for (int k = 0; k < 5; ++k) piece(slot_lds, k);
     }
 };
+// vmcnt(N): at most N of this wave's loads still in flight (they retire in order); never more than a wave without the C-operand
+// load has issued since the unit waited for
+#define VM_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 __device__ __forceinline__ void fetch_ci_part(f32x16& ci, const char* info, const LaneOff& lo, int g) {
     const f32x4 t = lds_f4(info + lo.ci + g * 32);
@@ -189,25 +200,29 @@ __device__ __forceinline__ void settle_o(f32x16 (&O)[8]) {
 #define VALU_E15 "v_exp_f32 %[cur], %[cur]\n\tv_add_f32 %[sum], %[sum], %[p1]"
 #define MF_S0 "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[c]\n\t"
 #define MF_S "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[d]\n\t"
-// kind 0: S MFMA with C = ci (D early-clobber VGPR; logit 0), 1: S MFMA accumulating
+// kind 0: S MFMA with C = ci (D early-clobber VGPR; logit 0), 1: S MFMA accumulating, 2: O MFMA (D AGPR, B VGPR)
 template <int KIND>
 __device__ __forceinline__ void slot(f32x16& d, const v4i& a, const v4i& b, const f32x16& c, f32x16& T, int (&pk)[8], float& lsum,
                                      float add, int e) {
     float cur = T[e], nxt = T[e < 15 ? e + 1 : 15];
     int r = 0;
-#define SLOT_ASM(MF, VA, DC)                                                                                                   \
+#define SLOT_ASM(MF, VA, DC, BC)                                                                                               \
     asm volatile(MF VA : [d] DC(d), [cur] "+v"(cur), [nxt] "+v"(nxt), [sum] "+v"(lsum), [pk] "=&v"(r)                          \
-                 : [a] "v"(a), [b] "a"(b), [l2e] "s"(L2E), [add] "v"(add), [p1] "v"(T[e >= 1 ? e - 1 : 0]), [p2] "v"(T[e >= 2 ? e - 2 : 0]))
-#define SLOT_ASM_C(MF, VA, DC)                                                                                                 \
+                 : [a] "v"(a), [b] BC(b), [l2e] "s"(L2E), [add] "v"(add), [p1] "v"(T[e >= 1 ? e - 1 : 0]), [p2] "v"(T[e >= 2 ? e - 2 : 0]))
+#define SLOT_ASM_C(MF, VA, DC, BC)                                                                                             \
     asm volatile(MF VA : [d] DC(d), [cur] "+v"(cur), [nxt] "+v"(nxt), [sum] "+v"(lsum), [pk] "=&v"(r)                          \
-                 : [a] "v"(a), [b] "a"(b), [c] "v"(c), [l2e] "s"(L2E), [add] "v"(add), [p1] "v"(T[e >= 1 ? e - 1 : 0]),            \
+                 : [a] "v"(a), [b] BC(b), [c] "v"(c), [l2e] "s"(L2E), [add] "v"(add), [p1] "v"(T[e >= 1 ? e - 1 : 0]),             \
                    [p2] "v"(T[e >= 2 ? e - 2 : 0]))
     if (KIND == 0) {
-        SLOT_ASM_C(MF_S0, VALU_E0, "=&v");
+        SLOT_ASM_C(MF_S0, VALU_E0, "=&v", "a");
+    } else if (KIND == 1) {
+        if (e == 15) SLOT_ASM(MF_S, VALU_E15, "+v", "a");
+        else if (e & 1) SLOT_ASM(MF_S, VALU_ODD, "+v", "a");
+        else SLOT_ASM(MF_S, VALU_EVEN, "+v", "a");
     } else {
-        if (e == 15) SLOT_ASM(MF_S, VALU_E15, "+v");
-        else if (e & 1) SLOT_ASM(MF_S, VALU_ODD, "+v");
-        else SLOT_ASM(MF_S, VALU_EVEN, "+v");
+        if (e == 15) SLOT_ASM(MF_S, VALU_E15, "+a", "v");
+        else if (e & 1) SLOT_ASM(MF_S, VALU_ODD, "+a", "v");
+        else SLOT_ASM(MF_S, VALU_EVEN, "+a", "v");
     }
 #undef SLOT_ASM_C
 #undef SLOT_ASM
@@ -227,49 +242,67 @@ struct Carry {            // operands of the next iteration's first PF S slots a
 };
 
 // One pipeline iteration u: S(u+1) -> Sn, P(u) <- exp of Sc, O += P(u-1) . Z(u-1).
-//   s_unit / o_unit: LDS rows of unit u+1 / unit u-1;  nx_unit: unit u+2 — written to `st_slot` (= nx_unit) in the S half from
-//   staging set `stS`, readable behind the barrier between the halves: the O half fetches the next iteration's first operands
-//   from it.  The loads of unit u+5 are issued into staging set `stL` in the O half (stL.begin() called by the caller).
-template <int ROLE, int CW>
+//   s_unit / o_unit: LDS rows of unit u+1 / unit u-1;  nx_unit: unit u+2 — its loads (issued three iterations ago) must have landed
+//   at the barrier between the halves, behind which the O half fetches the next iteration's first operands from it and issues the
+//   loads of unit u + AHEAD into `ld_slot` (the slot of unit u-2: every wave is past its last read).
+template <int CW>
 __device__ __forceinline__ void unit_iter(f32x16 (&O)[8], const v4i (&XF)[16], f32x16& Sc, f32x16& Sn, v4i (&Pc)[2], const v4i (&Pp)[2],
-                                          float add, float& lsum, Carry& cy, const char* s_unit, const char* o_unit, char* nx_unit,
-                                          const LaneOff& lo, Stage<ROLE, CW>& stS, Stage<ROLE, CW>& stL) {
+                                          float add, float& lsum, Carry& cy, const char* s_unit, const char* o_unit, const char* nx_unit,
+                                          const LaneOff& lo, Dma<CW>& dma, unsigned ld_slot) {
     using Cf = W<CW>;
-    constexpr int ROWB = Cf::ROWB;
+    constexpr int BLKB = Cf::BLKB;
     v4i zf[RING], tf[RING];
 #pragma unroll
     for (int i = 0; i < PF; ++i) zf[i] = cy.zf[i];
     int pk[8];
-    // ---- S half: 16 MFMAs beside the 16 logits of P(u) -------------------------------------------------------------------------
+    // The 16 logits of P(u) are exponentiated beside every SECOND MFMA of the iteration's 32 (logit e in slot 2e).
+    // ---- S half: 16 MFMAs ----------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
         if (ks + PF < 16) zf[(ks + PF) % RING] = lds_b128(s_unit + lo.zf + (ks + PF) * 32);
-        else { const int f = ks + PF - 16; tf[f % RING] = lds_tr<ROWB>(o_unit + lo.tr + (f >> 3) * 16 * ROWB + (f & 7) * 64); }
+        else { const int f = ks + PF - 16; tf[f % RING] = lds_tr<BLKB>(o_unit + lo.tr + (f >> 3) * 512 + (f & 7) * 64); }
+#if STRIPW_SPREAD
+        if (ks == 0) slot<0>(Sn, zf[0], XF[0], cy.ci, Sc, pk, lsum, add, 0);
+        else if ((ks & 1) == 0) slot<1>(Sn, zf[ks % RING], XF[ks], cy.ci, Sc, pk, lsum, add, ks >> 1);
+        else mfma_s(Sn, zf[ks % RING], XF[ks]);
+#else
         if (ks == 0) slot<0>(Sn, zf[0], XF[0], cy.ci, Sc, pk, lsum, add, 0);
         else slot<1>(Sn, zf[ks % RING], XF[ks], cy.ci, Sc, pk, lsum, add, ks);
-        // SrcC of the ks = 0 MFMA is read late in its passes: nothing may be allocated over `ci` until it is done
-        if (ks >= 1 && ks <= 3) asm volatile("" ::"v"(cy.ci));
-        // the staged unit: 4 data pieces + the C operands, all before the tf prefetches (ks >= 10) so that the barrier's
-        // lgkmcnt leaves exactly those in flight
-        if (ks >= 1 && ks <= 9 && (ks & 1)) stS.store_piece(nx_unit, (ks - 1) >> 1);
+#endif
+        // SrcC of the ks = 0 MFMA is read late in its passes: nothing may be allocated over `ci` until it is done (16 wait states:
+        // the slots without a logit are two instructions long)
+        if (ks >= 1 && ks <= 8) asm volatile("" ::"v"(cy.ci));
         SPIN();
     }
+#if !STRIPW_SPREAD
     slot_tail(Sc, pk, lsum);
-    // Workgroup barrier behind the staged stores: LDS operations retire in order, so the 2 (16 - (16 - PF)) = 12 transpose reads
-    // issued behind the last store piece (ks = 10 .. 15) may stay in flight.
-    asm volatile("s_waitcnt lgkmcnt(12)\n\ts_barrier" ::: "memory");
+#endif
+    // Unit u+2 landed (this wave's share: the loads of units u+3 and u+4 — 2 x 4 — may stay in flight), then the workgroup barrier:
+    // everybody's share landed, and everybody is past the O half of iteration u-1 (the slot the loads below overwrite).
+    // (LDS reads in flight cross the barrier freely: they target other slots.)
+#ifndef STRIPW_NOBAR
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (AHEAD - 3)) : "memory");
+#endif
     SPIN();
-    // ---- O half: 16 MFMAs; operands of the next S half, the loads of unit u+5 ---------------------------------------------------
+    // ---- O half: 16 MFMAs; operands of the next S half, the loads of unit u + AHEAD -----------------------------------------------
 #pragma unroll
     for (int f = 0; f < 16; ++f) {          // f = ks2 * 8 + ct
         const int fn = f + PF;
-        if (fn < 16) tf[fn % RING] = lds_tr<ROWB>(o_unit + lo.tr + (fn >> 3) * 16 * ROWB + (fn & 7) * 64);
+        if (fn < 16) tf[fn % RING] = lds_tr<BLKB>(o_unit + lo.tr + (fn >> 3) * 512 + (fn & 7) * 64);
         else cy.zf[fn - 16] = lds_b128(nx_unit + lo.zf + (fn - 16) * 32);
         if (f >= 4 && f < 8) fetch_ci_part(cy.ci, nx_unit + Cf::UNITB, lo, f - 4);
-        if (f < 10 && (f & 1)) stL.load_piece(f >> 1);
+        if (f < 10 && (f & 1)) dma.piece(ld_slot, f >> 1);
+#if STRIPW_SPREAD
+        if ((f & 1) == 0) slot<2>(O[f & 7], Pp[f >> 3], tf[f % RING], cy.ci, Sc, pk, lsum, add, 8 + (f >> 1));
+        else mfma_o(O[f & 7], Pp[f >> 3], tf[f % RING]);
+#else
         mfma_o(O[f & 7], Pp[f >> 3], tf[f % RING]);
+#endif
         SPIN();
     }
+#if STRIPW_SPREAD
+    slot_tail(Sc, pk, lsum);
+#endif
     Pc[0] = v4i{pk[0], pk[1], pk[2], pk[3]};
     Pc[1] = v4i{pk[4], pk[5], pk[6], pk[7]};
     SPIN();
@@ -278,13 +311,13 @@ __device__ __forceinline__ void unit_iter(f32x16 (&O)[8], const v4i (&XF)[16], f
 struct Geo {     // per-wave geometry of a launch
     const bf16* Z;
     int tid, lane, wave, hi, l31;
-    int Reff, xbase, xend, z_lo, z_hi, nunit, by, nchunk_dev;
+    int Reff, xbase, xend, z_lo, z_hi, z_first, nunit, by, nchunk_dev;
     long slab_stride;
     LaneOff lo;
 };
 
 // x fragments X[x = l31][16 ks + 8 hi ..+7] straight into AGPRs (rows past the end are clamped, not zeroed: their outputs are
-// never stored and `add` = -inf makes every exponential of theirs 0)
+// never stored and `add` = -inf makes every exponential of theirs 0).  Ends with vmcnt(0): everything this wave issued has landed.
 template <int CW>
 __device__ __forceinline__ void load_xfrags(v4i (&XF)[16], const bf16* X, const Geo& g) {
     const bf16* x0 = X + (long)max(min(g.xbase + g.l31, g.xend - 1), 0) * CW + g.hi * 8;
@@ -304,8 +337,11 @@ __device__ __forceinline__ void load_xfrags(v4i (&XF)[16], const bf16* X, const 
         : "memory");
 }
 
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ int ring_next(int q, int k) { const int r = q + k; return r >= NSLOT ? r - NSLOT : r; }
+
 // One sweep of the wave's 32 x vectors over the workgroup's z chunk: O, lsum (and, ROLE_YF with !EXACT, the reference m2 / add from
-// the chunk's first unit).  LOADX: the x fragments are fetched here, behind the first unit loads (one memory round trip for both).
+// the chunk's first unit).  LOADX: the x fragments are fetched here, between the first unit loads and their wait.
 template <int ROLE, int CW, bool EXACT, bool LOADX>
 __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* smem, const bf16* X, v4i (&XF)[16], f32x16 (&O)[8],
                                           float& add, float& m2, float& lsum) {
@@ -326,22 +362,18 @@ __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* s
         if (LOADX) load_xfrags<CW>(XF, X, g);
         return;
     }
-    // Four staging register sets: unit v travels through set v % 4, its loads issued three iterations before its stores.
-    Stage<ROLE, CW> st0, st1, st2, st3;
-    st0.init(p, g.Z, g.z_hi, g.Reff, tid); st1.init(p, g.Z, g.z_hi, g.Reff, tid);
-    st2.init(p, g.Z, g.z_hi, g.Reff, tid); st3.init(p, g.Z, g.z_hi, g.Reff, tid);
-    // ---- prologue: units 0 and 1 resident, 2 .. 4 in flight, S(0) --------------------------------------------------------------
-    st0.load(g.z_lo);
-    st1.load(g.z_lo + ZU);           // (rows past the chunk: clamped to its last row; their C operand is -inf)
-    if (LOADX) load_xfrags<CW>(XF, X, g);     // waits for everything issued so far
-    st0.store(smem);
-    st1.store(smem + SLOTB);
-    st2.load(g.z_lo + 2 * ZU);
-    st3.load(g.z_lo + 3 * ZU);
-    st0.load(g.z_lo + 4 * ZU);
-    // iteration 0 multiplies P(-1) = 0 into "unit -1" = ring slot 4: it must hold finite numbers
+    Dma<CW> dma;
+    dma.init(p, g.Z, g.z_hi, g.z_first, g.wave, g.lane);
+    const unsigned lds0 = lds_addr(smem);
+    // ---- prologue: units 0 .. AHEAD-1 on their way (unit v lives in ring slot v % 7), S(0) --------------------------------------
+    // (the previous user of the LDS — an earlier sweep's epilogue or the fallback's probe — ended with a workgroup barrier)
 #pragma unroll
-    for (int i = 0; i < UNITB / 16 / NTHR; ++i) *reinterpret_cast<uint4*>(smem + 4 * SLOTB + (tid + NTHR * i) * 16) = make_uint4(0, 0, 0, 0);
+    for (int v = 0; v < AHEAD; ++v) dma.issue(lds0 + v * SLOTB, g.z_lo + v * ZU);
+    if (LOADX) load_xfrags<CW>(XF, X, g);     // (waits for everything issued so far)
+    // iteration 0 multiplies P(-1) = 0 into "unit -1" = ring slot 6: it must hold finite numbers
+#pragma unroll
+    for (int i = 0; i < UNITB / 16 / NTHR; ++i) *reinterpret_cast<uint4*>(smem + (NSLOT - 1) * SLOTB + (tid + NTHR * i) * 16) = make_uint4(0, 0, 0, 0);
+    VM_WAIT(4 * (AHEAD - 2));                 // units 0 and 1 (2, 3, 4 may stay in flight)
     lds_barrier();
     f32x16 Sa, Sb;
     v4i Pa[2], Pb[2];
@@ -373,41 +405,32 @@ __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* s
     for (int i = 0; i < PF; ++i) cy.zf[i] = lds_b128(smem + SLOTB + lo.zf + i * 32);
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) fetch_ci_part(cy.ci, smem + SLOTB + UNITB, lo, gq);
-    // ---- main loop: four iterations per trip (static names for the four staging sets and the two logit / P buffers) ------------
-    const int nunit4 = (g.nunit + 3) & ~3;
-    int sl = 0;                         // ring slot of unit u (u = first iteration of the trip)
+    // ---- main loop: two iterations per trip (static names for the two logit / P buffers) ------------------------------------------
+    const int nunit2 = (g.nunit + 1) & ~1;
+    int sl = 0;                         // ring slot of unit u
 #pragma clang loop unroll(disable)
-    for (int u = 0; u < nunit4; u += 4) {
-        // slots of units u-1 .. u+5 (mod 5)
-        const int q0 = sl, q1 = sl + 1 >= 5 ? sl - 4 : sl + 1, q2 = sl + 2 >= 5 ? sl - 3 : sl + 2, q3 = sl + 3 >= 5 ? sl - 2 : sl + 3,
-                  q4 = sl + 4 >= 5 ? sl - 1 : sl + 4;
-        char* b0 = smem + q0 * SLOTB; char* b1 = smem + q1 * SLOTB; char* b2 = smem + q2 * SLOTB; char* b3 = smem + q3 * SLOTB;
-        char* b4 = smem + q4 * SLOTB;
-        // iteration u: S(u+1) from b1, O(u-1) from b4 (= slot of u-1), stores unit u+2 -> b2 from set (u+2)%4 = 2, loads unit u+5 -> set 1
-        st1.begin(g.z_lo + (u + 5) * ZU);
-        unit_iter<ROLE, CW>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, b1, b4, b2, lo, st2, st1);
-        // u+1: S(u+2) from b2, O(u) from b0, stores unit u+3 -> b3 from set 3, loads unit u+6 -> set 2
-        st2.begin(g.z_lo + (u + 6) * ZU);
-        unit_iter<ROLE, CW>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, b2, b0, b3, lo, st3, st2);
-        // u+2: S(u+3) from b3, O(u+1) from b1, stores unit u+4 -> b4 from set 0, loads unit u+7 -> set 3
-        st3.begin(g.z_lo + (u + 7) * ZU);
-        unit_iter<ROLE, CW>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, b3, b1, b4, lo, st0, st3);
-        // u+3: S(u+4) from b4, O(u+2) from b2, stores unit u+5 -> b0 from set 1, loads unit u+8 -> set 0
-        st0.begin(g.z_lo + (u + 8) * ZU);
-        unit_iter<ROLE, CW>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, b4, b2, b0, lo, st1, st0);
-        sl = q4;                        // unit u+4
+    for (int u = 0; u < nunit2; u += 2) {
+        const int qm = ring_next(sl, NSLOT - 1), q1 = ring_next(sl, 1), q2 = ring_next(sl, 2), q3 = ring_next(sl, 3),
+                  q5 = ring_next(sl, AHEAD), q6 = ring_next(sl, AHEAD + 1 >= NSLOT ? AHEAD + 1 - NSLOT : AHEAD + 1);
+        // iteration u: S(u+1), O(u-1), carry from unit u+2; loads unit u+5 into its slot (= the slot of unit u-2)
+        dma.begin(g.z_lo + (u + AHEAD) * ZU);
+        unit_iter<CW>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, smem + q1 * SLOTB, smem + qm * SLOTB, smem + q2 * SLOTB, lo, dma, lds0 + q5 * SLOTB);
+        // iteration u+1: S(u+2), O(u), carry from unit u+3; loads unit u+6 (the slot of unit u-1)
+        dma.begin(g.z_lo + (u + 1 + AHEAD) * ZU);
+        unit_iter<CW>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, smem + q2 * SLOTB, smem + sl * SLOTB, smem + q3 * SLOTB, lo, dma, lds0 + q6 * SLOTB);
+        sl = q2;
     }
-    // ---- drain: O(nunit4 - 1) ----------------------------------------------------------------------------------------------------
+    // ---- drain: O(nunit2 - 1) ----------------------------------------------------------------------------------------------------
     {
-        const int ql = sl == 0 ? 4 : sl - 1;
-        const char* o_unit = smem + ql * SLOTB;
+        const char* o_unit = smem + ring_next(sl, NSLOT - 1) * SLOTB;
 #pragma unroll
         for (int f = 0; f < 16; ++f) {
-            const v4i tf = lds_tr<Cf::ROWB>(o_unit + lo.tr + (f >> 3) * 16 * Cf::ROWB + (f & 7) * 64);
+            const v4i tf = lds_tr<Cf::BLKB>(o_unit + lo.tr + (f >> 3) * 512 + (f & 7) * 64);
             mfma_o(O[f & 7], Pb[f >> 3], tf);
         }
     }
     settle_o(O);
+    VM_WAIT(0);      // the loads issued for units past the chunk's end: nothing of this sweep may land in the LDS after it
 }
 
 // the wave's [32 x C] accumulator -> LDS -> whole rows of the slab; row sums / references
@@ -469,13 +492,14 @@ __device__ __attribute__((noinline)) void fallback_exact(const StripP* pp, const
     const Geo g = *gp;
     v4i XF[16];
     load_xfrags<CW>(XF, p.rows, g);
-    Stage<ROLE_YF, CW> stg;
-    stg.init(p, g.Z, g.z_hi, g.Reff, g.tid);
+    Dma<CW> dma;
+    dma.init(p, g.Z, g.z_hi, g.z_first, g.wave, g.lane);
+    const unsigned lds0 = lds_addr(smem);
     float mx = -INFINITY;
     for (int u = 0; u < g.nunit; ++u) {
         __syncthreads();
-        stg.load(g.z_lo + u * ZU);
-        stg.store(smem);
+        dma.issue(lds0, g.z_lo + u * ZU);
+        VM_WAIT(0);
         __syncthreads();
         max_unit<CW>(mx, XF, smem, g.lo);
     }
@@ -492,7 +516,7 @@ __global__ __launch_bounds__(NTHR, 1) void stripw_kernel(StripP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool YS = ROLE == ROLE_YF;
     Geo g;
-    g.tid = threadIdx.x; g.lane = g.tid & 63; g.wave = g.tid >> 6; g.hi = g.lane >> 5; g.l31 = g.lane & 31;
+    g.tid = threadIdx.x; g.lane = g.tid & 63; g.wave = __builtin_amdgcn_readfirstlane(g.tid >> 6); g.hi = g.lane >> 5; g.l31 = g.lane & 31;
     g.Reff = p.nvalid ? min(p.R, p.nvalid[0]) : p.R;
     int bx, zchunk;
     g.nchunk_dev = 1;
@@ -518,7 +542,8 @@ __global__ __launch_bounds__(NTHR, 1) void stripw_kernel(StripP p) {
     g.z_lo = (YS ? p.i0 : 0) + g.by * zchunk;
     g.z_hi = min(YS ? p.i1 : g.Reff, g.z_lo + zchunk);
     g.nunit = g.z_hi > g.z_lo ? (g.z_hi - g.z_lo + ZU - 1) / ZU : 0;
-    g.lo = lane_off<W<CW>::ROWB>(g.lane);
+    g.z_first = YS ? p.i0 : 0;
+    g.lo = lane_off<W<CW>::BLKB>(g.lane);
     v4i XF[16];
     float add, lsum = 0.f, m2 = 0.f;
     {
@@ -535,6 +560,9 @@ __global__ __launch_bounds__(NTHR, 1) void stripw_kernel(StripP p) {
             const float s = lsum + __shfl_xor(lsum, 32, 64);
             bad = (g.xbase + g.l31 < g.xend) && !(s < LSUM_LIMIT);
         }
+#ifdef STRIPW_T_NOFALLBACK
+        bad = false;
+#endif
         if (!YS || !__syncthreads_or(bad ? 1 : 0)) {
             epilogue<ROLE, CW>(p, g, smem, O, m2, lsum);
             return;
@@ -596,6 +624,24 @@ __global__ __launch_bounds__(CW) void label_scatter_kernel(const bf16* rows, con
     if (tid < RB && lab_s[tid] >= 0 && lead_s[tid] == tid) atomicAdd(d_bias + lab_s[tid] - 1, -accb[tid]);
 }
 
+// C operand of every z row of a pass, entry k = row z_first + k, CPAD entries of -inf behind the range (units past a chunk's end):
+//   ROLE_YF: z = i0 + k:  -1000 for the pad item (Base.py:110), out_bias[z - 1] otherwise;
+//   ROLE_W:  row k: log coef - lse (the row's softmax scale times its loss coefficient, Appendix C); -inf for rows without weight.
+__global__ __launch_bounds__(256) void info_items_kernel(const float* out_bias, int i0, int i1, float* cz) {
+    const int k = blockIdx.x * 256 + threadIdx.x, n = i1 - i0;
+    if (k >= n + CPAD) return;
+    const int z = i0 + k;
+    cz[k] = k >= n ? -INFINITY : (z == 0 ? -1000.0f : out_bias[z - 1]);
+}
+__global__ __launch_bounds__(256) void info_rows_kernel(const float* coef, const float* lse, const int32_t* nvalid, int R, float* rc) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= R + CPAD) return;
+    const int Reff = nvalid ? min(R, nvalid[0]) : R;
+    float c = -INFINITY;
+    if (k < Reff) { const float cf = coef[k]; if (cf > 0.f) c = __logf(cf) - lse[k]; }
+    rc[k] = c;
+}
+
 }  // namespace stripw
 
 // ---- host side (called from k_score.hip) --------------------------------------------------------------------------------------
@@ -619,12 +665,18 @@ static void stripw_set_smem_attr(const void* kern, int which, int bytes) {
     done[which].fetch_or(bit, std::memory_order_release);
 }
 
+// floats of scratch a pass needs for its C operands (edgl_stripw_rows: n = i1 - i0; edgl_stripw_table: n = R)
+long edgl_stripw_info_floats(long n) { return n + stripw::CPAD; }
+
 int edgl_stripw_rows(const void* rows, const void* table, const float* out_bias, int R, int C, int I, int i0, int i1,
-                     const int32_t* nvalid, float* slabs, float* part, int G, hipStream_t st) {
+                     const int32_t* nvalid, float* slabs, float* part, int G, float* info_ws, hipStream_t st) {
     EDGL_REQUIRE(edgl_stripw_supports(C), EDGL_ERR_SHAPE, "edgl_stripw_rows: C=%d unsupported", C);
+    EDGL_REQUIRE(info_ws, EDGL_ERR_NULL, "edgl_stripw_rows: no scratch for the C operands");
+    const int n = i1 - i0 + stripw::CPAD;
+    hipLaunchKernelGGL(stripw::info_items_kernel, dim3((n + 255) / 256), dim3(256), 0, st, out_bias, i0, i1, info_ws);
     stripw::StripP p{};
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
-    p.nvalid = nvalid; p.slabs = slabs; p.part = part;
+    p.nvalid = nvalid; p.slabs = slabs; p.part = part; p.cinfo = info_ws; p.ncinfo = n;
     auto k = stripw::stripw_kernel<stripw::ROLE_YF, 256>;
     stripw_set_smem_attr((const void*)k, 0, stripw::W<256>::SMEM);
     hipLaunchKernelGGL(k, dim3(G), dim3(stripw::NTHR), stripw::W<256>::SMEM, st, p);
@@ -633,11 +685,15 @@ int edgl_stripw_rows(const void* rows, const void* table, const float* out_bias,
 }
 
 int edgl_stripw_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
-                      int C, int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, hipStream_t st) {
+                      int C, int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, float* info_ws,
+                      hipStream_t st) {
     EDGL_REQUIRE(edgl_stripw_supports(C), EDGL_ERR_SHAPE, "edgl_stripw_table: C=%d unsupported", C);
+    EDGL_REQUIRE(info_ws, EDGL_ERR_NULL, "edgl_stripw_table: no scratch for the C operands");
+    const int n = R + stripw::CPAD;
+    hipLaunchKernelGGL(stripw::info_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, coef, row_lse, nvalid, R, info_ws);
     stripw::StripP p{};
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
-    p.nvalid = nvalid; p.coef = coef; p.row_lse = row_lse; p.slabs = slabs; p.bias_slabs = bias_slabs;
+    p.nvalid = nvalid; p.slabs = slabs; p.bias_slabs = bias_slabs; p.cinfo = info_ws; p.ncinfo = n;
     auto k = stripw::stripw_kernel<stripw::ROLE_W, 256>;
     stripw_set_smem_attr((const void*)k, 1, stripw::W<256>::SMEM);
     hipLaunchKernelGGL(k, dim3((i1 - i0 + stripw::XB - 1) / stripw::XB, nchunk), dim3(stripw::NTHR), stripw::W<256>::SMEM, st, p);
