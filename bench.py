@@ -717,8 +717,8 @@ def extras(c, args, dev):
                     "unique_item_rows": enc["config"]["unique_item_rows"], "workload": enc["config"]["workload"]}
     torch.cuda.empty_cache()
     # BASELINE.json configs[2] as a whole optimizer step (|items| = 1 M, L = 200 -> T = 201, d = 256, 8 heads, masklen 40, batch 512,
-    # bf16; the K1 line above is the HBM-bound kernel of this config): engine path, the unfused block tail and the generic scoring
-    # kernels at C = 256.  Short: 3 + 8 steps of ~45 ms.
+    # bf16; the K1 line above is the HBM-bound kernel of this config): engine path, the unfused block tail and the wide strip scoring
+    # kernels of k_score_stripw.hip (DESIGN.md §4.7 rules 65-67).  Short: 3 + 8 steps of ~26 ms.
     if args.dtype == "bf16":
         c3 = dict(c, num_items=1_000_000, seqslen=200, num_units=256, masklen=40)
         out["config3_step"] = dict(row(c3, steps=8, warmup=3),
