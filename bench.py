@@ -376,7 +376,7 @@ def main():
         # (tools/refresh_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); the committed summary of
         # the latest such pass is quoted and named in `traffic_source`
         traffic, traffic_source = None, None
-        for tp in ("r05_dominant_kernel_traffic.json", "r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json"):
+        for tp in ("r06_dominant_kernel_traffic.json", "r05_dominant_kernel_traffic.json", "r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if args.dtype == "bf16" and args.workload == "step" and os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -384,7 +384,7 @@ def main():
                 break
         # whole-step HBM bytes from the same passes, and the time they would take at the 6.3 TB/s a streaming kernel reaches
         step_hbm = None
-        for tp in ("r05_step_hbm_bytes.json", "r04_step_hbm_bytes.json"):
+        for tp in ("r06_step_hbm_bytes.json", "r05_step_hbm_bytes.json", "r04_step_hbm_bytes.json"):
             tpath = os.path.join(ROOT, "profiles", tp)
             if step_hbm is None and args.dtype == "bf16" and args.workload == "step" and os.path.exists(tpath):
                 sh = json.load(open(tpath))
@@ -668,19 +668,26 @@ def extras(c, args, dev):
     out = {}
     a2 = copy.copy(args)
 
-    def row(cc, full_rows=False, multi_hot=False, ids="zipf", device_masker=False, dtype=None, steps=30, warmup=10):
+    def row(cc, full_rows=False, multi_hot=False, ids="zipf", device_masker=False, dtype=None, steps=30, warmup=10, bracket=False):
         cc = dict(cc, multi_hot=multi_hot)
         ar = a2
         if dtype is not None:
             ar = copy.copy(a2)
             ar.dtype = dtype
-        r = run_step_workload(cc, ar, dev, 0, 1, None, steps, warmup, bracket=False, full_rows=full_rows, ids=ids, device_masker=device_masker)
+        r = run_step_workload(cc, ar, dev, 0, 1, None, steps, warmup, bracket=bracket, full_rows=full_rows, ids=ids, device_masker=device_masker)
         rw = float(np.mean(r["rows_w"]))
         fl = 3 * flops_per_seq(cc, rows_scored=rw / cc["batch"]) * cc["batch"]
         ms = float(np.median(r["step_ms"]))
-        return {"ms_per_step": round(r["dt"] / steps * 1e3, 4), "ms_median": round(ms, 4),
-                "sequences_per_s": round(cc["batch"] * steps / r["dt"], 1), "rows_scored": round(rw, 1), "rows_total": cc["batch"] * cc["masklen"],
-                "whole_step_mfma_frac": round(fl / (r["dt"] / steps) / 1e12 / (2500.0 if ar.dtype == "bf16" else 157.3), 4)}
+        out_row = {"ms_per_step": round(r["dt"] / steps * 1e3, 4), "ms_median": round(ms, 4),
+                   "sequences_per_s": round(cc["batch"] * steps / r["dt"], 1), "rows_scored": round(rw, 1), "rows_total": cc["batch"] * cc["masklen"],
+                   "whole_step_mfma_frac": round(fl / (r["dt"] / steps) / 1e12 / (2500.0 if ar.dtype == "bf16" else 157.3), 4)}
+        d0 = r["dom"].get(0) if isinstance(r.get("dom"), dict) else None
+        if d0 and d0[0] > 0 and d0[1] > 0 and ar.dtype == "bf16":
+            # the row pass of the scoring (one launch = 2 products x 2 R_w C I, measured live with HIP events on its stream)
+            dms = d0[1] / d0[0]
+            out_row["scoring_row_pass_ms"] = round(dms, 4)
+            out_row["scoring_row_pass_mfma_frac"] = round(4.0 * rw * cc["num_units"] * (cc["num_items"] + 1) / (dms * 1e-3) / 2.5e15, 4)
+        return out_row
     out["masklen_6"] = row(dict(c, masklen=6))
     out["all_rows_weighted"] = row(c, full_rows=True)
     out["dropout_off"] = row(dict(c, hidden_dropout_rate=0.0, attention_probs_dropout_rate=0.0))
@@ -721,7 +728,7 @@ def extras(c, args, dev):
     # kernels of k_score_stripw.hip (DESIGN.md §4.7 rules 65-67).  Short: 3 + 8 steps of ~26 ms.
     if args.dtype == "bf16":
         c3 = dict(c, num_items=1_000_000, seqslen=200, num_units=256, masklen=40)
-        out["config3_step"] = dict(row(c3, steps=8, warmup=3),
+        out["config3_step"] = dict(row(c3, steps=8, warmup=3, bracket=True),
                                    workload="EasyDGL optimizer step at BASELINE.json configs[2]: num_items 1000000 (I = 1000001), seqslen 200 "
                                             "(T = 201), num_units 256, 8 heads, 1 block, masklen 40, batch 512")
         torch.cuda.empty_cache()

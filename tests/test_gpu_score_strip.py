@@ -186,3 +186,33 @@ def test_rows_finished_in_the_forward_call_match_the_two_call_sequence(dt, C):
     assert _rel_max(cf1, cf0) < 1e-5
     assert _rel_max(dr1.float(), dr0.float()) < (1e-5 if dt == torch.float32 else 1e-2)     # bf16 outputs: an ulp where the coefficient moved
     assert _rel_max(dt1, dt0) < 1e-4 and _rel_max(db1, db0) < 1e-4
+
+
+@pytest.mark.parametrize("C", WIDTHS)
+def test_table_pass_over_item_ranges_adds_up_to_the_full_pass(C):
+    """edgl_score_flash_bwd over [0, h) and [h, I) (the item shards of SURVEY §8e: i0 a multiple of 8) with the GLOBAL log-sum-exp and
+    coefficients of a full-range forward: each call writes its rows of d_table / d_bias and nothing else, together they are the full pass."""
+    from easydgl_amd._lib import check, lib
+    o = _ops()
+    R, I, h = 700, 5001, 2504
+    rows, tab, bias, labels = _problem(R, I, seed=21 + C, hot=0.2, zero=0.3, C=C)
+    rows_c, lab_c, perm, _inv, nvalid = o.compact_rows(rows, labels)
+    p, st, code = o._ptr, o._stream(), o._code(rows)
+    ws = torch.empty(lib.edgl_score_flash_workspace(R, C, I, I, code), device="cuda")
+    lse = torch.empty(R, device="cuda"); ll = torch.zeros(R, device="cuda"); coef = torch.empty(R, device="cuda")
+    check(lib.edgl_score_flash_fwd_coef(p(rows_c), p(tab), p(bias), p(lab_c), R, C, I, p(nvalid), p(lse), p(ll), p(coef), p(ws), code, st), "fwd_coef")
+    full_t = torch.empty((I, C), device="cuda"); full_b = torch.empty(I - 1, device="cuda")
+    check(lib.edgl_score_flash_bwd(p(rows_c), p(tab), p(bias), p(lab_c), p(lse), p(coef), None, R, C, I, 0, I, p(nvalid), None, p(full_t), p(full_b),
+                                   p(ws), code, st), "bwd full")
+    part_t = torch.full((I, C), float("nan"), device="cuda"); part_b = torch.full((I - 1,), float("nan"), device="cuda")
+    check(lib.edgl_score_flash_bwd(p(rows_c), p(tab), p(bias), p(lab_c), p(lse), p(coef), None, R, C, I, 0, h, p(nvalid), None, p(part_t), p(part_b),
+                                   p(ws), code, st), "bwd [0, h)")
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(part_t[h:]).all()) and bool(torch.isnan(part_b[h - 1:]).all())      # the other shard's rows: untouched
+    assert not bool(torch.isnan(part_t[:h]).any()) and not bool(torch.isnan(part_b[:h - 1]).any())
+    check(lib.edgl_score_flash_bwd(p(rows_c), p(tab), p(bias), p(lab_c), p(lse), p(coef), None, R, C, I, h, I, p(nvalid), None, p(part_t), p(part_b),
+                                   p(ws), code, st), "bwd [h, I)")
+    torch.cuda.synchronize()
+    # (the row chunks of a range are summed in another order than those of the full pass)
+    assert _rel_max(part_t, full_t) < 2e-5, _rel_max(part_t, full_t)
+    assert _rel_max(part_b, full_b) < 2e-5, _rel_max(part_b, full_b)
