@@ -407,6 +407,11 @@ int launch_fwd_e(FwdP p, hipStream_t st) {
     constexpr size_t wave_bytes = fwd_wave_bytes<T, DT, NT, PHASE>();
     int waves = 4;
     while (waves > 1 && pack_bytes + waves * wave_bytes > 80 * 1024) waves >>= 1;
+    // Long sequences at head dim 32 (config 3: T = 201 -> 47 KB per wave + 39 KB of intensity weights): not even ONE wave stays under
+    // the two-workgroups-per-CU line, so the CU holds one workgroup whatever its size — then as many waves as the LDS takes beside the
+    // shared weights (one wave per CU measured 1.11 ms at B = 512; two: see DESIGN rule 70)
+    if (waves == 1 && pack_bytes + wave_bytes > 80 * 1024)
+        while (waves < 4 && pack_bytes + (waves + 1) * wave_bytes <= 160 * 1024) ++waves;
     const size_t smem = pack_bytes + waves * wave_bytes;
     EDGL_REQUIRE(smem <= 160 * 1024, EDGL_ERR_SHAPE, "edgl_bimau_fwd: needs %zu B of LDS (dh=%d E=%d T=%d)", smem, dh,
                  p.E, p.T);

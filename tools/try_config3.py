@@ -1,5 +1,11 @@
-import sys, time; sys.path.insert(0, '.')
-import torch, bench
+"""Diagnostic: BASELINE.json configs[2] (1 M items, T = 201, C = 256, batch 512, masklen 40) — autograd and engine step times, the
+library profiler's per-call table, one evaluation batch.   python tools/try_config3.py"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
 c = dict(bench.HEADLINE, num_items=1_000_000, seqslen=200, num_units=256, masklen=40)
 dev = torch.device("cuda", 0)
 t0 = time.time()
