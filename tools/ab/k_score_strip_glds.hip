@@ -1,3 +1,8 @@
+// EXPERIMENT, NOT BUILT INTO THE LIBRARY (round 6, DESIGN.md rule 71): k_score_strip.hip with the LDS-direct staging of the wide
+// kernels (one-KB blocks of rows b, b+16, b+32, b+48; ring of six tiles; hand-placed vmcnt; C operands from edgl_strip_info_*).
+// Parity-green (28 cases of tests/test_gpu_score_strip.py), kernel time +- 0 against the register-staged form, and the pre-kernel that
+// writes the C operands costs a launch on the step's main chain (row pass bracket 64.6 -> 66.4 us, step 0.759 -> 0.771 ms): not kept.
+// It needs edgl_strip_rows / edgl_strip_table with an `info_ws` argument and the plan's off_infoY / off_infoW for strip kind 1.
 // K5 "strip" kernels: the two passes of the fused scoring / cross-entropy (EasyDGL.py:149-155,177-185) at the headline width
 // (bf16, C = 128) in the one-wave-per-SIMD form.
 //
@@ -33,12 +38,19 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 namespace strip {
 
 constexpr int NTHR = 256, XW = 64, XB = 256, ZT = 64, ZU = 32, C = 128;
-constexpr int ROWB = 512;                   // LDS bytes per z row
-constexpr int UNITB = ZU * ROWB;            // 16 KB
-constexpr int TILEB = ZT * ROWB;            // 32 KB
+// LDS image of a tile (round 6: LDS-direct staging, see Dma below): BLOCK b = 0..15 holds rows b, b+16, b+32, b+48 back to back
+// (4 x 256 bytes = the KB one global_load_lds_dwordx4 moves) at byte b*BLKB + rot(b)*16 — the four rows share rot, BLKB = 1280 is a
+// multiple of 256 (the banks of the former 512-byte-row image: row-fragment and transpose reads stay conflict free).  Unit 0 of a
+// tile (rows 0..31) = the first two quarters of every block, unit 1 the last two (+ 512 bytes).
+constexpr int BLKB = 1280;
+constexpr int ROWB = BLKB;                  // address stride between rows z and z + 1 of a 16-row group
+constexpr int QB = 256;                     // bytes of a row inside its block; rows + 16 -> + QB
+constexpr int UNITB = 2 * QB;               // offset of a tile's second unit
+constexpr int TILEB = 16 * BLKB;            // 20 KB
 constexpr int INFOB = ZT * 4;               // one float per z row: the C operand of its logit row
 constexpr int SLOTB = TILEB + INFOB;
-constexpr int NSLOT = 4;
+constexpr int NSLOT = 6, AHEAD = 4;         // ring of tiles; iteration B of tile t issues the loads of tile t + AHEAD
+constexpr int CPAD = 512;                   // -inf entries behind the C-operand arrays (tiles past a chunk's end read them)
 constexpr int OSTR = 132;                   // floats per staged output row (epilogue)
 constexpr int SMEM_LOOP = NSLOT * SLOTB, SMEM_EPI = 4 * XW * OSTR * 4;
 constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
@@ -51,7 +63,8 @@ struct StripP {
     const bf16* rows; const bf16* table; const float* out_bias;
     int R, I, i0, i1;
     const int32_t* nvalid;
-    const float* coef; const float* row_lse;     // ROLE_W
+    const float* cinfo;       // C operand per z row, entry 0 = the pass's first z (-inf padded: edgl_strip_info_items / _rows)
+    int ncinfo;
     float* slabs; float* bias_slabs; float* part;
     float* acc_table; float* acc_bias;           // ROLE_W, optional: the outputs go into these zero-initialised arrays as f32 atomics (no slabs)
     int slab16;                                  // ROLE_YF: the row slabs are written as bf16 (the one-launch row finish reads them so)
@@ -92,80 +105,64 @@ __device__ __forceinline__ v4i lds_tr(const char* p) {
 // Per-lane LDS offsets (bytes, relative to a unit's first row)
 struct LaneOff {
     int zf;   // row-fragment read: row l&31, k-slot hi        (+ ks*32)
-    int tr;   // transpose read: row 4hi + (s>>2), columns 16*(G&1) + 4*(s&3)   (+ ks2*16*ROWB + ct*64)
+    int tr;   // transpose read: row 4hi + (s>>2), columns 16*(G&1) + 4*(s&3)   (+ ks2*QB + ct*64)
     int ci;   // C operand of the logit rows: info floats 4hi .. 4hi+3   (+ g*32)
 };
 __device__ __forceinline__ LaneOff lane_off(int lane) {
     LaneOff o;
     const int zr = lane & 31, hi = lane >> 5, G = lane >> 4, s = lane & 15;
-    o.zf = zr * ROWB + rot16(zr) + hi * 16;
+    o.zf = (zr & 15) * ROWB + rot16(zr & 15) + (zr >> 4) * QB + hi * 16;
     const int tz = 4 * hi + (s >> 2);
     o.tr = tz * ROWB + rot16(tz) + (16 * (G & 1) + 4 * (s & 3)) * 2;
     o.ci = 4 * hi * 4;
     return o;
 }
 
-// global -> registers -> LDS staging of one 64-row tile (+ its per-row C operand), in single-instruction pieces (load_piece /
-// store_piece) that the main loop places one per MFMA slot.  One wave per SIMD issues ~one instruction per 4-5 cycles, i.e.
-// about six besides each 32-cycle MFMA: the loop is ISSUE bound, and every instruction of the staging counts.  Hence
-//   * thread-constant offsets (row = tid/16 + 16 i keeps rot(row): the four pieces of a thread are 8 KB apart in LDS, 4 KB in
-//     global memory): a piece is one min + one address add + the access;
-//   * NO zero-filling of rows past the chunk / of table row 0: their C operand (-inf / -1000) makes every exponential of such a
-//     row exactly 0 (exp2 underflows below -1000 log2 e for any finite reference), so the row's DATA only has to be finite —
-//     the loads are clamped to the last valid row of the chunk.
-template <int ROLE>
-struct Stage {
-    uint4 g0, g1, g2, g3;      // (named members, not an array: the array form ended up in scratch)
-    float cinfo, cinfo2;
-    int z0_, zend_;
-    const bf16* Z_;
-    const float* bias_; const float* coef_; const float* lse_;     // (by value: a pointer to the kernel's parameter struct would
-    int I_, Reff_, tid_, row0_, goff_, loff_;                       //  put that struct — and every access to it — into scratch)
-    __device__ __forceinline__ void init(const StripP& p, const bf16* Z, int zend, int Reff, int tid) {
-        Z_ = Z; bias_ = p.out_bias; coef_ = p.coef; lse_ = p.row_lse; I_ = p.I; zend_ = zend; Reff_ = Reff; tid_ = tid;
-        cinfo = 0.f; cinfo2 = 0.f; z0_ = 0;
-        row0_ = tid >> 4;
-        goff_ = (tid & 15) * 8;                                      // elements
-        loff_ = row0_ * ROWB + rot16(row0_) + (tid & 15) * 16;       // bytes
+// LDS-direct staging of one 64-row tile (global_load_lds_dwordx4: 64 lanes x 16 bytes from per-lane global addresses to ONE
+// contiguous KB at M0; M0 saved and restored inside the statement — the compiler owns it).  Wave w moves blocks 4w .. 4w+3: lanes
+// 16q .. 16q+15 fetch the 256 bytes of row b + 16 q.  Rows past the chunk are clamped to its last row: their C operand is -inf, the
+// data only has to be finite.  Wave 0 also moves the tile's 64 C operands (global_load_lds_dword) from the array a pre-kernel wrote
+// (bias / -1000 / -inf;  log coef - lse).  No staging registers, no ds_write, no compiler-visible load in the loop: every vmcnt is
+// placed by hand (VM_WAIT).  Measured before the change (tools/strip_ab.sh): of the row pass's 61 us the ds_writes cost 10-12 and the
+// waits for the staged registers 6-8.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+#define VM_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+struct Dma {
+    const char* Z_;
+    const float* ci_;
+    int zend_, zrel_, nci_, wave_, lrow_, lcol_, lane_, z0_;
+    unsigned boff_[4];        // LDS offset of block 4 wave + j inside a tile (wave-uniform)
+    __device__ __forceinline__ void init(const StripP& p, const bf16* Z, int zend, int zfirst, int wave, int lane) {
+        Z_ = reinterpret_cast<const char*>(Z); ci_ = p.cinfo; nci_ = p.ncinfo; zend_ = zend; zrel_ = zfirst;
+        wave_ = __builtin_amdgcn_readfirstlane(wave); lane_ = lane; z0_ = 0;
+        lrow_ = 16 * (lane >> 4); lcol_ = (lane & 15) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int b = 4 * wave + j; boff_[j] = (unsigned)__builtin_amdgcn_readfirstlane(b * BLKB + rot16(b)); }
     }
     __device__ __forceinline__ void begin(int z0) { z0_ = z0; }
-    __device__ __forceinline__ void load_piece(int i) {      // i = 0..3: 16 bytes of the tile;  i = 4: the per-row scalars
-        if (i < 4) {
-            const int gz = max(min(z0_ + row0_ + 16 * i, zend_ - 1), 0);
-            const uint4 v = *reinterpret_cast<const uint4*>(Z_ + (long)gz * C + goff_);
-            if (i == 0) g0 = v; else if (i == 1) g1 = v; else if (i == 2) g2 = v; else g3 = v;
-        } else {
-            const int z = z0_ + (tid_ & (ZT - 1));      // every wave loads them (no divergent branch); wave 0 stores them
-            if (ROLE == ROLE_YF) {
-                cinfo = bias_[min(max(z, 1), I_ - 1) - 1];
-            } else {
-                const int gc = max(min(z, Reff_ - 1), 0);
-                cinfo = coef_[gc]; cinfo2 = lse_[gc];
-            }
+    __device__ __forceinline__ void piece(unsigned slot_lds, int k) {       // k = 0..3: one block;  k = 4: the C operands (wave 0)
+        if (k < 4) {
+            const int gz = max(min(z0_ + 4 * wave_ + k + lrow_, zend_ - 1), 0);
+            glds16(Z_ + (long)gz * (C * 2) + lcol_, slot_lds + boff_[k]);
+        } else if (wave_ == 0) {
+            const int gi = max(min(z0_ - zrel_ + lane_, nci_ - 1), 0);
+            glds4(ci_ + gi, slot_lds + TILEB);
         }
     }
-    __device__ __forceinline__ void load(int z0) {
+    __device__ __forceinline__ void issue(unsigned slot_lds, int z0) {
         begin(z0);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) load_piece(i);
-    }
-    __device__ __forceinline__ void store_piece(char* slot, int i) {
-#ifdef STRIP_T_WAITONLY    // (timing experiments only: the staged registers are waited for and consumed, nothing is written)
-        if (z0_ > 128) { const uint4& g = i == 0 ? g0 : (i == 1 ? g1 : (i == 2 ? g2 : g3)); if (i < 4) asm volatile("" ::"v"(g.x), "v"(g.y), "v"(g.z), "v"(g.w)); else asm volatile("" ::"v"(cinfo), "v"(cinfo2)); return; }
-#endif
-        if (i < 4) {
-            *reinterpret_cast<uint4*>(slot + loff_ + i * 16 * ROWB) = i == 0 ? g0 : (i == 1 ? g1 : (i == 2 ? g2 : g3));
-        } else {
-            const int z = z0_ + (tid_ & (ZT - 1));
-            float c;
-            if (ROLE == ROLE_YF) c = z >= zend_ ? -INFINITY : (z == 0 ? -1000.0f : cinfo);   // pad logit -1000 (Base.py:110)
-            else c = (z < zend_ && cinfo > 0.f) ? __logf(cinfo) - cinfo2 : -INFINITY;        // -(lse - log coef)
-            if (tid_ < ZT) reinterpret_cast<float*>(slot + TILEB)[tid_] = c;
-        }
-    }
-    __device__ __forceinline__ void store(char* slot) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) store_piece(slot, i);
+        for (int k = 0; k < 5; ++k) piece(slot_lds, k);
     }
 };
 
@@ -285,12 +282,12 @@ __device__ __forceinline__ void slot_tail(f32x16& T, int (&pk)[8], float& lsum) 
 // One pipeline iteration u: S(u+1) -> Sn, P(u) <- exp of Sc, O += P(u-1) . Z(u-1).
 //   s_unit / o_unit: LDS rows of unit u+1 / unit u-1;  nx_unit / nx_info: unit u+2 (operands of the next iteration's first MFMAs).
 //   STAGE: the staged tile is written to `st_slot` in the S half and the workgroup barrier sits between the halves.
-//   LOAD : the loads of the tile after next are issued in the S half (stg.begin() called by the caller).
+//   LOAD : the LDS-direct loads of tile t + AHEAD are issued in the S half into `st_slot` (dma.begin() called by the caller).
 template <int ROLE, bool STAGE, bool LOAD>
 __device__ __forceinline__ void unit_iter(f32x16 (&O)[2][4], const v4i (&XF)[2][8], f32x16 (&Sc)[2], f32x16 (&Sn)[2],
                                           v4i (&Pc)[2][2], const v4i (&Pp)[2][2], const float (&add)[2], float (&lsum)[2],
                                           Carry& cy, const char* s_unit, const char* o_unit, const char* nx_unit,
-                                          const char* nx_info, const LaneOff& lo, Stage<ROLE>& stg, char* st_slot, int tid
+                                          const char* nx_info, const LaneOff& lo, Dma& dma, unsigned st_slot, int tid
 #ifdef STRIP_TIMING
                                           , unsigned long long (&ph_acc)[12], unsigned long long& ph_t
 #endif
@@ -325,11 +322,8 @@ __device__ __forceinline__ void unit_iter(f32x16 (&O)[2][4], const v4i (&XF)[2][
             // it stays an operand of an (empty) statement for two more MFMA pairs.
             if (ks == 1 || ks == 2) asm volatile("" ::"v"(cy.ci));
             const int sl = 2 * ks + xt;                          // one staging piece per slot
-#ifndef STRIP_T_NOSTORE
-            if (STAGE && sl >= 4 && sl <= 12 && (sl & 1) == 0) stg.store_piece(st_slot, (sl - 4) >> 1);
-#endif
 #ifndef STRIP_T_NOLOADS
-            if (LOAD && sl >= 2 && sl < 7) stg.load_piece(sl - 2);
+            if (LOAD && sl >= 2 && sl <= 10 && (sl & 1) == 0) dma.piece(st_slot, (sl - 2) >> 1);
 #endif
             SPIN();
             if (sl == 3) PHT(STAGE ? 0 : 4);
@@ -343,7 +337,9 @@ __device__ __forceinline__ void unit_iter(f32x16 (&O)[2][4], const v4i (&XF)[2][
     // lgkmcnt(2) lets the two youngest ones — the transpose reads of tf[2], issued at ks = 7 behind the last store piece (slot 12)
     // — stay in flight; a full drain exposed their whole latency once per tile.  The count must never exceed the number of LDS
     // operations issued after the last store piece: 2.
-    if (STAGE) asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
+    // (round 6, LDS-direct staging: what has to be complete is this wave's share of tile t+1 — issued three trips ago; the loads of
+    // tiles t+2 and t+3, 2 x 4 per wave, stay in flight — and, through the barrier, everybody's.  LDS reads cross it freely.)
+    if (STAGE) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * (AHEAD - 2)) : "memory");
 #endif
     SPIN();
     PHT(STAGE ? 3 : 7);
@@ -352,7 +348,7 @@ __device__ __forceinline__ void unit_iter(f32x16 (&O)[2][4], const v4i (&XF)[2][
     for (int f = 0; f < 8; ++f) {          // f = ks2 * 4 + ct
         const int ks2 = f >> 2, ct = f & 3;
 #ifndef STRIP_T_NOTF
-        if (f + 3 < 8) tf[(f + 3) % 4] = lds_tr(o_unit + lo.tr + ((f + 3) >> 2) * 16 * ROWB + ((f + 3) & 3) * 64);
+        if (f + 3 < 8) tf[(f + 3) % 4] = lds_tr(o_unit + lo.tr + ((f + 3) >> 2) * QB + ((f + 3) & 3) * 64);
 #endif
 #ifndef STRIP_T_NOCARRY
         if (f == 4) cy.zf0 = lds_b128(nx_unit + lo.zf);
@@ -408,7 +404,7 @@ constexpr float LSUM_LIMIT = 1.2676506e30f;   // 2^100
 struct Geo {     // per-wave geometry of a launch
     const bf16* Z;
     int tid, lane, wave, hi, l31;
-    int Reff, xbase, xend, z_lo, z_hi, ntile, by, nchunk_dev;
+    int Reff, xbase, xend, z_lo, z_hi, z_first, ntile, by, nchunk_dev;
     long slab_stride;
     LaneOff lo;
 };
@@ -461,20 +457,18 @@ __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* s
         return;
     }
     STAMP(1);
-    // Two staging register sets: the loads of a tile are issued THREE iterations (~5 k cycles) before its LDS stores — with one set
-    // and one iteration of distance every tile waited ~400 cycles for its data (global-load latency under this load > 1 us).
-    Stage<ROLE> stg0, stg1;      // stg1: odd tiles, stg0: even tiles
-    stg0.init(p, g.Z, g.z_hi, g.Reff, tid);
-    stg1.init(p, g.Z, g.z_hi, g.Reff, tid);
-    // ---- prologue: tile 0 (tiles 1 and 2 in flight), S(0) -------------------------------------------------------------------
-    stg0.load(g.z_lo);
-    stg1.load(g.z_lo + ZT);         // (rows past the chunk: clamped to its last row; their C operand is -inf)
-    if (LOADX) load_xfrags(XF, X, g);     // waits for everything issued so far
-    stg0.store(smem);
-    stg0.load(g.z_lo + 2 * ZT);
-    // iteration 0 multiplies P(-1) = 0 into "tile -1" = ring slot 3: its second unit must hold finite numbers
+    Dma dma;
+    dma.init(p, g.Z, g.z_hi, g.z_first, g.wave, g.lane);
+    const unsigned lds0 = lds_addr(smem);
+    // ---- prologue: tiles 0 .. AHEAD-1 on their way (tile v lives in ring slot v % 6), S(0) --------------------------------------
+    // (the previous user of the LDS — an earlier sweep's epilogue, the fallback's probe — ended with a workgroup barrier)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(smem + 3 * SLOTB + UNITB + (tid + NTHR * i) * 16) = make_uint4(0, 0, 0, 0);
+    for (int v = 0; v < AHEAD; ++v) dma.issue(lds0 + v * SLOTB, g.z_lo + v * ZT);
+    if (LOADX) load_xfrags(XF, X, g);     // (waits for everything issued so far)
+    // iteration 0 multiplies P(-1) = 0 into "tile -1" = ring slot 5: it must hold finite numbers
+#pragma unroll
+    for (int i = 0; i < TILEB / 16 / NTHR; ++i) *reinterpret_cast<uint4*>(smem + (NSLOT - 1) * SLOTB + (tid + NTHR * i) * 16) = make_uint4(0, 0, 0, 0);
+    VM_WAIT(4 * (AHEAD - 1));             // tile 0 (1 .. 3 may stay in flight)
     lds_barrier();
     f32x16 Sa[2], Sb[2];
     v4i Pa[2][2], Pb[2][2];
@@ -521,27 +515,23 @@ __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* s
 #else
 #define PH_ARGS
 #endif
-    // Tiles are processed in pairs (static names for the two staging sets); an odd tile count runs one all-padding tile (rows
-    // past the chunk are zero-filled and carry C = -inf: their exponentials are 0).  edgl's planners hand out chunks of an even
-    // number of tiles, so only the last chunk of a launch can be odd.
-    const int ntile2 = (g.ntile + 1) & ~1;
+    // One tile = two iterations per trip (static names for the two logit / P buffers); the ring slots are run-time values.
+    int sl = 0;                         // ring slot of tile t
 #pragma clang loop unroll(disable)
-    for (int t = 0; t < ntile2; t += 2) {
-        char* s0 = smem + (t & 3) * SLOTB;            // tile t
-        char* sm = smem + ((t + 3) & 3) * SLOTB;      // tile t-1 (t = 0: the zeroed unit of slot 3, P(-1) = 0)
-        char* s1 = smem + ((t + 1) & 3) * SLOTB;      // tile t+1
-        char* s2 = smem + ((t + 2) & 3) * SLOTB;      // tile t+2
-        // iteration A (u = 2t): S(2t+1) from the second unit of tile t, O(2t-1) from the second unit of tile t-1; writes the
-        // staged tile t+1 (behind the last tile: a harmless rewrite of stale rows — ONE code path, so that the accumulators
-        // keep their registers: an if / else over two instances made the allocator shuffle 128 AGPRs per trip)
-        unit_iter<ROLE, true, false>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, s0 + UNITB, sm + UNITB, s1, s1 + TILEB, lo, stg1, s1, tid PH_ARGS);
-        // iteration B (u = 2t+1): S(2t+2) from the first unit of tile t+1, O(2t) from tile t; issues the loads of tile t+3
-        stg1.begin(g.z_lo + (t + 3) * ZT);
-        unit_iter<ROLE, false, true>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, s1, s0, s1 + UNITB, s1 + TILEB + ZU * 4, lo, stg1, s1, tid PH_ARGS);
-        // the same for tile t+1: A writes tile t+2, B loads tile t+4
-        unit_iter<ROLE, true, false>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, s1 + UNITB, s0 + UNITB, s2, s2 + TILEB, lo, stg0, s2, tid PH_ARGS);
-        stg0.begin(g.z_lo + (t + 4) * ZT);
-        unit_iter<ROLE, false, true>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, s2, s1, s2 + UNITB, s2 + TILEB + ZU * 4, lo, stg0, s2, tid PH_ARGS);
+    for (int t = 0; t < g.ntile; ++t) {
+        const int qm = sl == 0 ? NSLOT - 1 : sl - 1, q1 = sl + 1 == NSLOT ? 0 : sl + 1;
+        int q4 = sl + AHEAD; q4 = q4 >= NSLOT ? q4 - NSLOT : q4;
+        char* s0 = smem + sl * SLOTB;             // tile t
+        char* sm = smem + qm * SLOTB;             // tile t-1 (t = 0: the zeroed slot, P(-1) = 0)
+        char* s1 = smem + q1 * SLOTB;             // tile t+1
+        // iteration A (u = 2t): S(2t+1) from the second unit of tile t, O(2t-1) from the second unit of tile t-1; tile t+1 has landed at
+        // its barrier, behind which the first operands of S(2t+2) are fetched from it
+        unit_iter<ROLE, true, false>(O, XF, Sa, Sb, Pa, Pb, add, lsum, cy, s0 + UNITB, sm + UNITB, s1, s1 + TILEB, lo, dma, 0u, tid PH_ARGS);
+        // iteration B (u = 2t+1): S(2t+2) from the first unit of tile t+1, O(2t) from tile t; issues the loads of tile t+AHEAD into
+        // the slot of tile t-2 (every wave is past the barrier of iteration A, i.e. past its last read of that slot)
+        dma.begin(g.z_lo + (t + AHEAD) * ZT);
+        unit_iter<ROLE, false, true>(O, XF, Sb, Sa, Pb, Pa, add, lsum, cy, s1, s0, s1 + UNITB, s1 + TILEB + ZU * 4, lo, dma, lds0 + q4 * SLOTB, tid PH_ARGS);
+        sl = q1;
     }
     STAMP(3);
 #ifdef STRIP_TIMING
@@ -549,15 +539,16 @@ __device__ __forceinline__ void main_pass(const StripP& p, const Geo& g, char* s
 #endif
     // ---- drain: O(2 ntile - 1) ----------------------------------------------------------------------------------------------
     {
-        const char* o_unit = smem + ((ntile2 - 1) & 3) * SLOTB + UNITB;
+        const char* o_unit = smem + (sl == 0 ? NSLOT - 1 : sl - 1) * SLOTB + UNITB;
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
-            const v4i tf = lds_tr(o_unit + lo.tr + (f >> 2) * 16 * ROWB + (f & 3) * 64);
+            const v4i tf = lds_tr(o_unit + lo.tr + (f >> 2) * QB + (f & 3) * 64);
 #pragma unroll
             for (int xt = 0; xt < 2; ++xt) mfma_o(O[xt][f & 3], Pb[xt][f >> 2], tf);
         }
     }
     settle_o(O);
+    VM_WAIT(0);      // the loads issued for tiles past the chunk's end: nothing of this sweep may land in the LDS after it
     STAMP(4);
 }
 
@@ -640,13 +631,14 @@ __device__ __attribute__((noinline)) void fallback_exact(const StripP* pp, const
     const Geo g = *gp;
     v4i XF[2][8];
     load_xfrags(XF, p.rows, g);
-    Stage<ROLE_YF> stg;
-    stg.init(p, g.Z, g.z_hi, g.Reff, g.tid);
+    Dma dma;
+    dma.init(p, g.Z, g.z_hi, g.z_first, g.wave, g.lane);
+    const unsigned lds0 = lds_addr(smem);
     float mx[2] = {-INFINITY, -INFINITY};
     for (int t = 0; t < g.ntile; ++t) {
         __syncthreads();
-        stg.load(g.z_lo + t * ZT);
-        stg.store(smem);
+        dma.issue(lds0, g.z_lo + t * ZT);
+        VM_WAIT(0);
         __syncthreads();
         max_unit(mx, XF, smem, smem + TILEB, g.lo);
         max_unit(mx, XF, smem + UNITB, smem + TILEB + ZU * 4, g.lo);
@@ -668,7 +660,7 @@ __global__ __launch_bounds__(NTHR, 1) void strip_kernel(StripP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool YS = ROLE == ROLE_YF;
     Geo g;
-    g.tid = threadIdx.x; g.lane = g.tid & 63; g.wave = g.tid >> 6; g.hi = g.lane >> 5; g.l31 = g.lane & 31;
+    g.tid = threadIdx.x; g.lane = g.tid & 63; g.wave = __builtin_amdgcn_readfirstlane(g.tid >> 6); g.hi = g.lane >> 5; g.l31 = g.lane & 31;
     g.Reff = p.nvalid ? min(p.R, p.nvalid[0]) : p.R;
     int bx, zchunk;
     g.nchunk_dev = 1;
@@ -695,6 +687,7 @@ __global__ __launch_bounds__(NTHR, 1) void strip_kernel(StripP p) {
     g.z_lo = (YS ? p.i0 : 0) + g.by * zchunk;
     g.z_hi = min(YS ? p.i1 : g.Reff, g.z_lo + zchunk);
     g.ntile = g.z_hi > g.z_lo ? (g.z_hi - g.z_lo + ZT - 1) / ZT : 0;
+    g.z_first = YS ? p.i0 : 0;
     g.lo = lane_off(g.lane);
     STAMP(0);
     v4i XF[2][8];
@@ -814,9 +807,16 @@ static void strip_set_smem_attr(const void* kern, int which) {
     done[which].fetch_or(bit, std::memory_order_release);
 }
 
+// k_score_stripw.hip: the C operands of a pass's z rows as an array, -inf padded (n + edgl_stripw_info_floats(0) floats)
+int edgl_strip_info_items(const float* out_bias, int i0, int i1, float* cz, hipStream_t st);
+int edgl_strip_info_rows(const float* coef, const float* lse, const int32_t* nvalid, int R, float* rc, hipStream_t st);
+
 int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, int R, int I, int i0, int i1, const int32_t* nvalid,
-                    float* slabs, float* part, int G, int slab16, hipStream_t st) {
+                    float* slabs, float* part, int G, int slab16, float* info_ws, hipStream_t st) {
+    EDGL_REQUIRE(info_ws, EDGL_ERR_NULL, "edgl_strip_rows: no scratch for the C operands");
+    if (const int rc = edgl_strip_info_items(out_bias, i0, i1, info_ws, st)) return rc;
     strip::StripP p{};
+    p.cinfo = info_ws; p.ncinfo = i1 - i0 + strip::CPAD;
     p.slab16 = slab16;
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
     p.nvalid = nvalid; p.slabs = slabs; p.part = part; p.stamps = g_strip_stamps;
@@ -829,11 +829,14 @@ int edgl_strip_rows(const void* rows, const void* table, const float* out_bias, 
 
 int edgl_strip_table(const void* rows, const void* table, const float* out_bias, const float* coef, const float* row_lse, int R,
                      int I, int i0, int i1, const int32_t* nvalid, float* slabs, float* bias_slabs, int nchunk, float* acc_table,
-                     float* acc_bias, hipStream_t st) {
+                     float* acc_bias, float* info_ws, hipStream_t st) {
+    EDGL_REQUIRE(info_ws, EDGL_ERR_NULL, "edgl_strip_table: no scratch for the C operands");
+    if (const int rc = edgl_strip_info_rows(coef, row_lse, nvalid, R, info_ws, st)) return rc;
     strip::StripP p{};
+    p.cinfo = info_ws; p.ncinfo = R + strip::CPAD;
     p.acc_table = acc_table; p.acc_bias = acc_bias;
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
-    p.nvalid = nvalid; p.coef = coef; p.row_lse = row_lse; p.slabs = slabs; p.bias_slabs = bias_slabs; p.stamps = g_strip_stamps;
+    p.nvalid = nvalid; p.slabs = slabs; p.bias_slabs = bias_slabs; p.stamps = g_strip_stamps;
     auto k = strip::strip_kernel<strip::ROLE_W>;
     strip_set_smem_attr((const void*)k, 1);
     hipLaunchKernelGGL(k, dim3((i1 - i0 + strip::XB - 1) / strip::XB, nchunk), dim3(strip::NTHR), strip::SMEM, st, p);

@@ -51,7 +51,12 @@ def main():
         n_mfma += 1
         d, a, b, c = regs(ops[0]), regs(ops[1]), regs(ops[2]), regs(ops[3])
         src = a | b | c
-        for j in range(max(0, k - near), k):
+        first = max(0, k - near)
+        for j in range(k - 1, first - 1, -1):      # control does not fall through an unconditional branch: what stands in front of
+            if parse(ins[j][1])[0] in ("s_branch", "s_endpgm", "s_setpc_b64"):      # it belongs to another path
+                first = j + 1
+                break
+        for j in range(first, k):
             op2, ops2 = parse(ins[j][1])
             if op2.startswith("v_mfma") or op2.startswith("s_") or op2.startswith("ds_read") or op2.startswith("global_load") or not ops2:
                 continue
