@@ -216,3 +216,25 @@ def test_table_pass_over_item_ranges_adds_up_to_the_full_pass(C):
     # (the row chunks of a range are summed in another order than those of the full pass)
     assert _rel_max(part_t, full_t) < 2e-5, _rel_max(part_t, full_t)
     assert _rel_max(part_b, full_b) < 2e-5, _rel_max(part_b, full_b)
+
+
+@pytest.mark.parametrize("C", WIDTHS)
+def test_no_weighted_row_at_all(C):
+    """Every label 0 (a data-parallel rank whose half of the batch carries no weight): the passes run over zero rows — no NaN, the
+    table / bias gradients are exactly zero, the row outputs are never read."""
+    from easydgl_amd._lib import check, lib
+    o = _ops()
+    R, I = 300, 1201
+    rows, tab, bias, labels = _problem(R, I, seed=3 + C, C=C)
+    labels.zero_()
+    rows_c, lab_c, perm, _inv, nvalid = o.compact_rows(rows, labels)
+    assert int(nvalid.item()) == 0
+    p, st, code = o._ptr, o._stream(), o._code(rows)
+    ws = torch.empty(lib.edgl_score_flash_workspace(R, C, I, I, code), device="cuda")
+    lse = torch.zeros(R, device="cuda"); ll = torch.zeros(R, device="cuda"); coef = torch.zeros(R, device="cuda")
+    check(lib.edgl_score_flash_fwd_coef(p(rows_c), p(tab), p(bias), p(lab_c), R, C, I, p(nvalid), p(lse), p(ll), p(coef), p(ws), code, st), "fwd_coef")
+    d_rows = torch.zeros_like(rows_c); d_tab = torch.full((I, C), float("nan"), device="cuda"); d_b = torch.full((I - 1,), float("nan"), device="cuda")
+    check(lib.edgl_score_flash_bwd(p(rows_c), p(tab), p(bias), p(lab_c), p(lse), p(coef), None, R, C, I, 0, I, p(nvalid), p(d_rows), p(d_tab), p(d_b),
+                                   p(ws), code, st), "bwd")
+    torch.cuda.synchronize()
+    assert float(d_tab.abs().max()) == 0.0 and float(d_b.abs().max()) == 0.0
