@@ -231,7 +231,11 @@ __device__ __forceinline__ void settle_o(f32x16 (&O)[2][4]) {
 //   row sum += T[e-1];  after every odd logit the pair before it is packed
 // slot_tail() finishes the tile (sum / pack of logits 14, 15).
 #define VALU_E0 "v_fma_f32 %[cur], %[cur], %[l2e], %[add]\n\tv_fma_f32 %[nxt], %[nxt], %[l2e], %[add]\n\tv_exp_f32 %[cur], %[cur]"
+#ifdef STRIP_T_NOSUM      // (timing experiment only: the row sums are not formed — bounds what a sum on the matrix pipe could give)
+#define VALU_ODD "v_exp_f32 %[cur], %[cur]\n\tv_fma_f32 %[nxt], %[nxt], %[l2e], %[add]"
+#else
 #define VALU_ODD "v_exp_f32 %[cur], %[cur]\n\tv_fma_f32 %[nxt], %[nxt], %[l2e], %[add]\n\tv_add_f32 %[sum], %[sum], %[p1]"
+#endif
 #define VALU_EVEN VALU_ODD "\n\tv_cvt_pk_bf16_f32 %[pk], %[p2], %[p1]"
 #define VALU_E15 "v_exp_f32 %[cur], %[cur]\n\tv_add_f32 %[sum], %[sum], %[p1]"
 #define MF_S0 "v_mfma_f32_32x32x16_bf16 %[d], %[a], %[b], %[c]\n\t"
