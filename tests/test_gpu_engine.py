@@ -17,7 +17,9 @@ CASES = [dict(), dict(num_units=64, num_heads=2, num_blocks=1, seqslen=30, maskl
          dict(num_units=64, num_heads=4, num_blocks=2, seqslen=20, masklen=5, num_events=24, num_items=300),
          dict(num_units=128, num_heads=2, num_blocks=1, seqslen=18, masklen=4, num_events=40, num_items=200),
          # no block at all: the head transform reads the 3C-wide encoder output (EasyDGL.py:138 sizes its dense kernel by the input)
-         dict(num_units=64, num_heads=2, num_blocks=0, seqslen=30, masklen=6, num_events=7, num_items=300)]
+         dict(num_units=64, num_heads=2, num_blocks=0, seqslen=30, masklen=6, num_events=7, num_items=300),
+         # BASELINE.json configs[2]'s width: 256 units in 8 heads (head dim 32) — the wide strip scoring passes (k_score_stripw.hip)
+         dict(num_units=256, num_heads=8, num_blocks=1, seqslen=40, masklen=8, num_events=16, num_items=1500)]
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
