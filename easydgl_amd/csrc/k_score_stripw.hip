@@ -575,6 +575,337 @@ __global__ __launch_bounds__(NTHR, 1) void stripw_kernel(StripP p) {
     }
 }
 
+// ====================================================================================================================================
+// C = 512 (the published recipe, runme.sh:15-23).  32 x-rows x 512 channels of f32 accumulator are every AGPR a wave has, so a workgroup
+// owns ONE 256-channel half of the output and computes the logits (K = 512) for it: the halves of an x block are two workgroups that both
+// form S — 32 + 16 MFMAs per unit instead of 32 + 32 / 2, 1.5 x the algorithmic products and two exponentials per logit (rule 68: bounded
+// by 2/3 of what the C = 256 form reaches; the generic 8-wave kernels it replaces run at 0.13 of the MFMA peak).  x fragments (128) and the
+// accumulator (128) fill the AGPRs.  A unit is 32 rows x 1 KB: block b = rows b and b + 16, one global_load_lds_dwordx4 each, at byte
+// b*2304 + rot(b)*16 (2304 = 9 x 256: the banks of the other images) — 36 KB, so the ring holds FOUR units and the pipeline is one unit
+// shorter than at C = 256: iteration u forms S(u+1) beside the exponentials of S(u) (one per second slot of 32), and its O half multiplies
+// the P(u) it has just packed into unit u — units u, u+1, u+2 are alive, unit u+3 is issued behind the barrier into the slot of unit u-1.
+template <int DUMMY = 0>
+struct W5 {
+    static constexpr int CW = 512, CO = 256, KS = 32;
+    static constexpr int BLKB = 2 * 1024 + 256;
+    static constexpr int UNITB = 16 * BLKB;
+    static constexpr int SLOTB = UNITB + INFOB;
+    static constexpr int NSLOT5 = 4;
+    static constexpr int OSTR = CO + 4;
+    static constexpr int SMEM_LOOP = NSLOT5 * SLOTB, SMEM_EPI = 4 * XW * OSTR * 4;
+    static constexpr int SMEM = SMEM_LOOP > SMEM_EPI ? SMEM_LOOP : SMEM_EPI;
+    static_assert(SMEM <= 160 * 1024, "LDS");
+};
+using C5 = W5<0>;
+
+struct Geo5 {
+    const bf16* Z;
+    int tid, lane, wave, hi, l31;
+    int Reff, xbase, xend, z_lo, z_hi, z_first, nunit, by, nchunk_dev, half;
+    long slab_stride;
+    LaneOff lo;
+};
+__device__ __forceinline__ LaneOff lane_off5(int lane, int half) {
+    LaneOff o;
+    const int zr = lane & 31, hi = lane >> 5, G = lane >> 4, s = lane & 15;
+    o.zf = (zr & 15) * C5::BLKB + rot16(zr & 15) + (zr >> 4) * 1024 + hi * 16;
+    const int tz = 4 * hi + (s >> 2);
+    o.tr = tz * C5::BLKB + rot16(tz) + (16 * (G & 1) + 4 * (s & 3)) * 2 + half * (C5::CO * 2);
+    o.ci = 4 * hi * 4;
+    return o;
+}
+struct Dma5 {      // wave w moves blocks 4w .. 4w+3 of a unit, two instructions each (row b, row b + 16): pieces 0 .. 7; piece 8: the C operands
+    const char* Z_;
+    const float* ci_;
+    int zend_, zrel_, nci_, wave_, lane_, z0_;
+    unsigned boff_[4];
+    __device__ __forceinline__ void init(const StripP& p, const bf16* Z, int zend, int zfirst, int wave, int lane) {
+        Z_ = reinterpret_cast<const char*>(Z); ci_ = p.cinfo; nci_ = p.ncinfo; zend_ = zend; zrel_ = zfirst;
+        wave_ = __builtin_amdgcn_readfirstlane(wave); lane_ = lane; z0_ = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int b = 4 * wave + j; boff_[j] = (unsigned)__builtin_amdgcn_readfirstlane(b * C5::BLKB + rot16(b)); }
+    }
+    __device__ __forceinline__ void begin(int z0) { z0_ = z0; }
+    __device__ __forceinline__ void piece(unsigned slot_lds, int k) {
+        if (k < 8) {
+            const int gz = max(min(z0_ + 4 * wave_ + (k >> 1) + 16 * (k & 1), zend_ - 1), 0);      // (wave-uniform)
+            glds16(Z_ + (long)gz * (C5::CW * 2) + lane_ * 16, slot_lds + boff_[k >> 1] + (k & 1) * 1024);
+        } else if (wave_ == 0) {
+            const int gi = max(min(z0_ - zrel_ + lane_, nci_ - 1), 0);
+            glds4(ci_ + gi, slot_lds + C5::UNITB);
+        }
+    }
+    __device__ __forceinline__ void issue(unsigned slot_lds, int z0) {
+        begin(z0);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) piece(slot_lds, k);
+    }
+};
+
+// x fragments X[x = l31][16 ks + 8 hi ..+7], ks = 0 .. 31, straight into AGPRs (two statements: an asm takes 30 operands)
+__device__ __forceinline__ void load_xfrags5(v4i (&XF)[32], const bf16* X, const Geo5& g) {
+    const bf16* x0 = X + (long)max(min(g.xbase + g.l31, g.xend - 1), 0) * C5::CW + g.hi * 8;
+#define EDGL_XF16(BASE, PTR)                                                                                                          \
+    asm volatile(                                                                                                                     \
+        "global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\t"                                          \
+        "global_load_dwordx4 %2, %16, off offset:64\n\tglobal_load_dwordx4 %3, %16, off offset:96\n\t"                               \
+        "global_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"                             \
+        "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"                             \
+        "global_load_dwordx4 %8, %16, off offset:256\n\tglobal_load_dwordx4 %9, %16, off offset:288\n\t"                             \
+        "global_load_dwordx4 %10, %16, off offset:320\n\tglobal_load_dwordx4 %11, %16, off offset:352\n\t"                           \
+        "global_load_dwordx4 %12, %16, off offset:384\n\tglobal_load_dwordx4 %13, %16, off offset:416\n\t"                           \
+        "global_load_dwordx4 %14, %16, off offset:448\n\tglobal_load_dwordx4 %15, %16, off offset:480\n\t"                           \
+        "s_waitcnt vmcnt(0)"                                                                                                          \
+        : "=&a"(XF[BASE + 0]), "=&a"(XF[BASE + 1]), "=&a"(XF[BASE + 2]), "=&a"(XF[BASE + 3]), "=&a"(XF[BASE + 4]), "=&a"(XF[BASE + 5]),  \
+          "=&a"(XF[BASE + 6]), "=&a"(XF[BASE + 7]), "=&a"(XF[BASE + 8]), "=&a"(XF[BASE + 9]), "=&a"(XF[BASE + 10]),                    \
+          "=&a"(XF[BASE + 11]), "=&a"(XF[BASE + 12]), "=&a"(XF[BASE + 13]), "=&a"(XF[BASE + 14]), "=&a"(XF[BASE + 15])                 \
+        : "v"(PTR)                                                                                                                    \
+        : "memory")
+    EDGL_XF16(0, x0);
+    const bf16* x1 = x0 + 256;
+    EDGL_XF16(16, x1);
+#undef EDGL_XF16
+}
+
+// One iteration u: S half — S(u+1) -> Sn (32 MFMAs) beside the 16 exponentials of Sc = S(u) (logit e in slot 2e) -> P(u); barrier (unit u+2
+// has landed: vmcnt(0), it is the youngest load); O half — O += P(u) . Z(u) (16 MFMAs), the first operands of the next S half from unit
+// u+2, the loads of unit u+3 into `ld_slot`.
+__device__ __forceinline__ void unit_iter5(f32x16 (&O)[8], const v4i (&XF)[32], f32x16& Sc, f32x16& Sn, float add, float& lsum, Carry& cy,
+                                           const char* s_unit, const char* o_unit, const char* nx_unit, const LaneOff& lo, Dma5& dma,
+                                           unsigned ld_slot) {
+    constexpr int BLKB = C5::BLKB;
+    v4i zf[RING], tf[RING];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) zf[i] = cy.zf[i];
+    int pk[8];
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+        if (ks + PF < 32) zf[(ks + PF) % RING] = lds_b128(s_unit + lo.zf + (ks + PF) * 32);
+        else { const int f = ks + PF - 32; tf[f % RING] = lds_tr<BLKB>(o_unit + lo.tr + (f >> 3) * 1024 + (f & 7) * 64); }
+        if (ks == 0) slot<0>(Sn, zf[0], XF[0], cy.ci, Sc, pk, lsum, add, 0);
+        else if ((ks & 1) == 0) slot<1>(Sn, zf[ks % RING], XF[ks], cy.ci, Sc, pk, lsum, add, ks >> 1);
+        else mfma_s(Sn, zf[ks % RING], XF[ks]);
+        if (ks >= 1 && ks <= 8) asm volatile("" ::"v"(cy.ci));      // SrcC of the ks = 0 MFMA: see unit_iter
+        SPIN();
+    }
+    slot_tail(Sc, pk, lsum);
+    v4i P[2];
+    P[0] = v4i{pk[0], pk[1], pk[2], pk[3]};
+    P[1] = v4i{pk[4], pk[5], pk[6], pk[7]};
+    // unit u+2 landed (it is this wave's youngest load), everybody past the O half of iteration u-1; the s_nop keeps the wait states
+    // between the last v_cvt_pk above and the first MFMA that reads P
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier\n\ts_nop 4" : "+v"(P[0]), "+v"(P[1]) : : "memory");
+    SPIN();
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {          // f = ks2 * 8 + ct
+        const int fn = f + PF;
+        if (fn < 16) tf[fn % RING] = lds_tr<BLKB>(o_unit + lo.tr + (fn >> 3) * 1024 + (fn & 7) * 64);
+        else cy.zf[fn - 16] = lds_b128(nx_unit + lo.zf + (fn - 16) * 32);
+        if (f >= 4 && f < 8) fetch_ci_part(cy.ci, nx_unit + C5::UNITB, lo, f - 4);
+        if (f < 9) dma.piece(ld_slot, f);
+        mfma_o(O[f & 7], P[f >> 3], tf[f % RING]);
+        SPIN();
+    }
+}
+
+template <int ROLE, bool EXACT, bool LOADX>
+__device__ __forceinline__ void main_pass5(const StripP& p, const Geo5& g, char* smem, const bf16* X, v4i (&XF)[32], f32x16 (&O)[8],
+                                           float& add, float& m2, float& lsum) {
+    constexpr bool YS = ROLE == ROLE_YF;
+    constexpr int SLOTB = C5::SLOTB, UNITB = C5::UNITB, NS = C5::NSLOT5;
+    const LaneOff lo = g.lo;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[ct][r] = 0.f;
+        asm volatile("" : "+a"(O[ct]));
+    }
+    lsum = 0.f;
+    if (g.nunit == 0) {
+        if (LOADX) load_xfrags5(XF, X, g);
+        return;
+    }
+    Dma5 dma;
+    dma.init(p, g.Z, g.z_hi, g.z_first, g.wave, g.lane);
+    const unsigned lds0 = lds_addr(smem);
+#pragma unroll
+    for (int v = 0; v < 3; ++v) dma.issue(lds0 + v * SLOTB, g.z_lo + v * ZU);       // units 0 .. 2 -> slots 0 .. 2
+    if (LOADX) load_xfrags5(XF, X, g);
+    VM_WAIT(0);
+    lds_barrier();
+    f32x16 Sa, Sb;
+    Carry cy;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) fetch_ci_part(cy.ci, smem + UNITB, lo, gq);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+        const v4i zf = lds_b128(smem + lo.zf + ks * 32);
+        if (ks == 0) mfma_s0(Sa, zf, XF[0], cy.ci);
+        else mfma_s(Sa, zf, XF[ks]);
+    }
+    settle_s(Sa);
+    asm volatile("" ::"v"(cy.ci));
+    if (YS && !EXACT) {
+        float t = Sa[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) t = fmaxf(t, Sa[r]);
+        m2 = fmaxf(t, __shfl_xor(t, 32, 64)) * L2E;
+        add = -m2;
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) cy.zf[i] = lds_b128(smem + SLOTB + lo.zf + i * 32);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) fetch_ci_part(cy.ci, smem + SLOTB + UNITB, lo, gq);
+    const int nunit2 = (g.nunit + 1) & ~1;
+    int sl = 0;                         // ring slot of unit u
+#pragma clang loop unroll(disable)
+    for (int u = 0; u < nunit2; u += 2) {
+        const int q1 = (sl + 1) & (NS - 1), q2 = (sl + 2) & (NS - 1), q3 = (sl + 3) & (NS - 1);
+        // iteration u: S(u+1) from q1, O(u) from sl, carry from q2 (unit u+2); loads unit u+3 into q3 (the slot of unit u-1)
+        dma.begin(g.z_lo + (u + 3) * ZU);
+        unit_iter5(O, XF, Sa, Sb, add, lsum, cy, smem + q1 * SLOTB, smem + sl * SLOTB, smem + q2 * SLOTB, lo, dma, lds0 + q3 * SLOTB);
+        // iteration u+1: S(u+2) from q2, O(u+1) from q1, carry from q3 (unit u+3); loads unit u+4 into sl (the slot of unit u)
+        dma.begin(g.z_lo + (u + 4) * ZU);
+        unit_iter5(O, XF, Sb, Sa, add, lsum, cy, smem + q2 * SLOTB, smem + q1 * SLOTB, smem + q3 * SLOTB, lo, dma, lds0 + sl * SLOTB);
+        sl = q2;
+    }
+    settle_o(O);
+    VM_WAIT(0);
+}
+
+template <int ROLE>
+__device__ __forceinline__ void epilogue5(const StripP& p, const Geo5& g, char* smem, const f32x16 (&O)[8], float m2, float lsum) {
+    constexpr bool YS = ROLE == ROLE_YF;
+    constexpr int OSTR = C5::OSTR;
+    __syncthreads();
+    float* stg_o = reinterpret_cast<float*>(smem) + g.wave * XW * OSTR;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg_o[((r & 3) + 8 * (r >> 2) + 4 * g.hi) * OSTR + 32 * ct + g.l31] = O[ct][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    float* slab = p.slabs + (long)g.by * g.slab_stride + g.half * C5::CO;
+#pragma unroll 4
+    for (int xr = 0; xr < XW; ++xr) {
+        const int gx = g.xbase + xr;
+        const float4 v = *reinterpret_cast<const float4*>(stg_o + xr * OSTR + 4 * g.lane);
+        if (gx < g.xend) *reinterpret_cast<float4*>(slab + (long)gx * C5::CW + 4 * g.lane) = v;
+    }
+    const float s = lsum + __shfl_xor(lsum, 32, 64);
+    const int gx = g.xbase + g.l31;
+    if (g.hi == 0 && gx < g.xend && g.half == 0) {      // (both halves of an x block form the same sums: the first one writes them)
+        if (YS) {
+            p.part[((long)gx * g.nchunk_dev + g.by) * 2] = m2 * (1.0f / L2E);
+            p.part[((long)gx * g.nchunk_dev + g.by) * 2 + 1] = s;
+        } else if (gx > 0) {
+            p.bias_slabs[(long)g.by * (p.I - 1) + gx - 1] = s;
+        }
+    }
+}
+
+__device__ __forceinline__ void max_unit5(float& mx, const v4i (&XF)[32], const char* unit, const LaneOff& lo) {
+    f32x16 ci, S;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) fetch_ci_part(ci, unit + C5::UNITB, lo, gq);
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) {
+        const v4i zf = lds_b128(unit + lo.zf + ks * 32);
+        if (ks == 0) mfma_s0(S, zf, XF[0], ci);
+        else mfma_s(S, zf, XF[ks]);
+    }
+    settle_s(S);
+    asm volatile("" ::"v"(ci));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[r]);
+}
+
+__device__ __attribute__((noinline)) void fallback_exact5(const StripP* pp, const Geo5* gp, char* smem) {
+    const StripP p = *pp;
+    const Geo5 g = *gp;
+    v4i XF[32];
+    load_xfrags5(XF, p.rows, g);
+    Dma5 dma;
+    dma.init(p, g.Z, g.z_hi, g.z_first, g.wave, g.lane);
+    const unsigned lds0 = lds_addr(smem);
+    float mx = -INFINITY;
+    for (int u = 0; u < g.nunit; ++u) {
+        __syncthreads();
+        dma.issue(lds0, g.z_lo + u * ZU);
+        VM_WAIT(0);
+        __syncthreads();
+        max_unit5(mx, XF, smem, g.lo);
+    }
+    __syncthreads();
+    float m2 = fmaxf(mx, __shfl_xor(mx, 32, 64)) * L2E;
+    float add = -m2, lsum;
+    f32x16 O[8];
+    main_pass5<ROLE_YF, true, false>(p, g, smem, p.rows, XF, O, add, m2, lsum);
+    epilogue5<ROLE_YF>(p, g, smem, O, m2, lsum);
+}
+
+// grid: ROLE_YF 2 G workgroups (id & 1 = channel half, id >> 1 = the (x block, item chunk) of dev_plan over G); ROLE_W (x blocks, row chunks, 2)
+template <int ROLE>
+__global__ __launch_bounds__(NTHR, 1) void stripw5_kernel(StripP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool YS = ROLE == ROLE_YF;
+    Geo5 g;
+    g.tid = threadIdx.x; g.lane = g.tid & 63; g.wave = __builtin_amdgcn_readfirstlane(g.tid >> 6); g.hi = g.lane >> 5; g.l31 = g.lane & 31;
+    g.Reff = p.nvalid ? min(p.R, p.nvalid[0]) : p.R;
+    int bx, zchunk;
+    g.nchunk_dev = 1;
+    if (YS) {
+        const int G = (int)gridDim.x >> 1;
+        const DevPlan dp = dev_plan(g.Reff, XB, G, p.i1 - p.i0, ZQ);
+        int id2 = blockIdx.x;
+        if ((gridDim.x & 7) == 0) id2 = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);      // XCD-aware order (stripw_kernel)
+        g.half = id2 & 1;
+        const int id = id2 >> 1;
+        if (id >= dp.nx * dp.nchunk || g.Reff <= 0) return;
+        bx = id % dp.nx; g.by = id / dp.nx; zchunk = dp.zchunk; g.nchunk_dev = dp.nchunk;
+        g.slab_stride = (long)dp.nx * XB * C5::CW;
+    } else {
+        bx = blockIdx.x; g.by = blockIdx.y; g.half = blockIdx.z;
+        const int nq = (g.Reff + ZQ - 1) / ZQ;
+        zchunk = (nq + (int)gridDim.y - 1) / (int)gridDim.y * ZQ;
+        g.slab_stride = (long)p.I * C5::CW;
+    }
+    g.xbase = (YS ? 0 : p.i0) + bx * XB + g.wave * XW;
+    g.xend = YS ? g.Reff : p.i1;
+    const bf16* X = YS ? p.rows : p.table;
+    g.Z = YS ? p.table : p.rows;
+    g.z_lo = (YS ? p.i0 : 0) + g.by * zchunk;
+    g.z_hi = min(YS ? p.i1 : g.Reff, g.z_lo + zchunk);
+    g.nunit = g.z_hi > g.z_lo ? (g.z_hi - g.z_lo + ZU - 1) / ZU : 0;
+    g.z_first = YS ? p.i0 : 0;
+    g.lo = lane_off5(g.lane, g.half);
+    v4i XF[32];
+    float add, lsum = 0.f, m2 = 0.f;
+    {
+        const int gx = g.xbase + g.l31;
+        const float ob = YS ? 0.f : p.out_bias[min(max(gx, 1), p.I - 1) - 1];
+        add = YS ? 0.f : (gx >= g.xend ? -INFINITY : (gx == 0 ? -1000.0f * L2E : ob * L2E));
+    }
+    {
+        f32x16 O[8];
+        main_pass5<ROLE, false, true>(p, g, smem, X, XF, O, add, m2, lsum);
+        bool bad = false;
+        if (YS) {
+            const float s = lsum + __shfl_xor(lsum, 32, 64);
+            bad = (g.xbase + g.l31 < g.xend) && !(s < LSUM_LIMIT);
+        }
+        if (!YS || !__syncthreads_or(bad ? 1 : 0)) {
+            epilogue5<ROLE>(p, g, smem, O, m2, lsum);
+            return;
+        }
+    }
+    if (YS) {
+        const StripP p2 = p;
+        const Geo5 g2 = g;
+        fallback_exact5(&p2, &g2, smem);
+    }
+}
+
 // d_table[label[r]] -= coef[r] rows[r];  d_bias[label[r] - 1] -= coef[r]   over the weighted rows: the one-hot part of
 // dl = coef (p - onehot) that the ROLE_W product pass leaves out (strip::label_scatter_kernel at any width: a block = RB rows x CW
 // channels, equal labels summed in LDS first in row order by one thread per channel, the leaders' sums leave as f32 atomics).
@@ -649,7 +980,7 @@ bool edgl_stripw_enabled() {
     static const int on = getenv("EDGL_SCORE_STRIPW") ? atoi(getenv("EDGL_SCORE_STRIPW")) : 1;
     return on != 0;
 }
-bool edgl_stripw_supports(int C) { return C == 256; }
+bool edgl_stripw_supports(int C) { return C == 256 || (C == 512 && (getenv("EDGL_SCORE_STRIPW512") ? atoi(getenv("EDGL_SCORE_STRIPW512")) : 1) != 0); }
 
 // the dynamic-LDS attribute of a kernel is per device (see k_score_strip.hip)
 static void stripw_set_smem_attr(const void* kern, int which, int bytes) {
@@ -677,6 +1008,13 @@ int edgl_stripw_rows(const void* rows, const void* table, const float* out_bias,
     stripw::StripP p{};
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
     p.nvalid = nvalid; p.slabs = slabs; p.part = part; p.cinfo = info_ws; p.ncinfo = n;
+    if (C == 512) {
+        auto k5 = stripw::stripw5_kernel<stripw::ROLE_YF>;
+        stripw_set_smem_attr((const void*)k5, 2, stripw::C5::SMEM);
+        hipLaunchKernelGGL(k5, dim3(2 * G), dim3(stripw::NTHR), stripw::C5::SMEM, st, p);
+        EDGL_LAUNCH_CHECK();
+        return EDGL_OK;
+    }
     auto k = stripw::stripw_kernel<stripw::ROLE_YF, 256>;
     stripw_set_smem_attr((const void*)k, 0, stripw::W<256>::SMEM);
     hipLaunchKernelGGL(k, dim3(G), dim3(stripw::NTHR), stripw::W<256>::SMEM, st, p);
@@ -694,6 +1032,13 @@ int edgl_stripw_table(const void* rows, const void* table, const float* out_bias
     stripw::StripP p{};
     p.rows = (const bf16*)rows; p.table = (const bf16*)table; p.out_bias = out_bias; p.R = R; p.I = I; p.i0 = i0; p.i1 = i1;
     p.nvalid = nvalid; p.slabs = slabs; p.bias_slabs = bias_slabs; p.cinfo = info_ws; p.ncinfo = n;
+    if (C == 512) {
+        auto k5 = stripw::stripw5_kernel<stripw::ROLE_W>;
+        stripw_set_smem_attr((const void*)k5, 3, stripw::C5::SMEM);
+        hipLaunchKernelGGL(k5, dim3((i1 - i0 + stripw::XB - 1) / stripw::XB, nchunk, 2), dim3(stripw::NTHR), stripw::C5::SMEM, st, p);
+        EDGL_LAUNCH_CHECK();
+        return EDGL_OK;
+    }
     auto k = stripw::stripw_kernel<stripw::ROLE_W, 256>;
     stripw_set_smem_attr((const void*)k, 1, stripw::W<256>::SMEM);
     hipLaunchKernelGGL(k, dim3((i1 - i0 + stripw::XB - 1) / stripw::XB, nchunk), dim3(stripw::NTHR), stripw::W<256>::SMEM, st, p);
@@ -704,8 +1049,12 @@ int edgl_stripw_table(const void* rows, const void* table, const float* out_bias
 int edgl_stripw_label_scatter(const void* rows, const int64_t* labels, const float* coef, const int32_t* nvalid, int R, int C, int i0,
                               int i1, const float* gscale, float* d_table, float* d_bias, hipStream_t st) {
     EDGL_REQUIRE(edgl_stripw_supports(C), EDGL_ERR_SHAPE, "edgl_stripw_label_scatter: C=%d unsupported", C);
-    hipLaunchKernelGGL((stripw::label_scatter_kernel<256, 32>), dim3((R + 31) / 32), dim3(256), 0, st, (const bf16*)rows, labels, coef,
-                       nvalid, R, i0, i1, gscale, d_table, d_bias);
+    if (C == 512)
+        hipLaunchKernelGGL((stripw::label_scatter_kernel<512, 16>), dim3((R + 15) / 16), dim3(512), 0, st, (const bf16*)rows, labels, coef,
+                           nvalid, R, i0, i1, gscale, d_table, d_bias);
+    else
+        hipLaunchKernelGGL((stripw::label_scatter_kernel<256, 32>), dim3((R + 31) / 32), dim3(256), 0, st, (const bf16*)rows, labels, coef,
+                           nvalid, R, i0, i1, gscale, d_table, d_bias);
     EDGL_LAUNCH_CHECK();
     return EDGL_OK;
 }

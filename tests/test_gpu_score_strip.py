@@ -98,7 +98,7 @@ def _problem(R, I, seed, hot=0.0, zero=0.3, scale_rows=0.6, scale_tab=0.4, C=128
     return rows, tab, bias, labels
 
 
-WIDTHS = [128, 256]      # k_score_strip.hip / k_score_stripw.hip
+WIDTHS = [128, 256, 512]      # k_score_strip.hip / k_score_stripw.hip (256: stripw_kernel; 512: stripw5_kernel, two channel halves)
 
 
 @pytest.mark.parametrize("C", WIDTHS)
