@@ -668,12 +668,15 @@ def extras(c, args, dev):
     out = {}
     a2 = copy.copy(args)
 
-    def row(cc, full_rows=False, multi_hot=False, ids="zipf", device_masker=False, dtype=None, steps=30, warmup=10, bracket=False):
+    def row(cc, full_rows=False, multi_hot=False, ids="zipf", device_masker=False, dtype=None, steps=30, warmup=10, bracket=False, path=None):
         cc = dict(cc, multi_hot=multi_hot)
         ar = a2
         if dtype is not None:
             ar = copy.copy(a2)
             ar.dtype = dtype
+        if path is not None:
+            ar = copy.copy(ar)
+            ar.path = path
         r = run_step_workload(cc, ar, dev, 0, 1, None, steps, warmup, bracket=bracket, full_rows=full_rows, ids=ids, device_masker=device_masker)
         rw = float(np.mean(r["rows_w"]))
         fl = 3 * flops_per_seq(cc, rows_scored=rw / cc["batch"]) * cc["batch"]
@@ -706,9 +709,16 @@ def extras(c, args, dev):
     out["recipe_runme_sh"] = dict(row(dict(RECIPE)), workload="num_units 512, 8 heads, seqslen 30, masklen 6, batch 512, num_items 17771")
     # the reference's DEFAULT flags (main.py:35-38,44,60-66): 50 units in ONE head, 3 blocks, seqslen 30, masklen 6, batch 128, no
     # dropout / regularisers — head dim 50 runs zero-padded to 64 channels, i.e. on the head-dim-64 kernels
-    out["reference_default_flags"] = dict(row(dict(c, num_units=50, num_heads=1, num_blocks=3, seqslen=30, masklen=6, batch=128, l2_reg=0.0,
-                                                   ct_reg=0.0, hidden_dropout_rate=0.0, attention_probs_dropout_rate=0.0)),
-                                          workload="num_units 50, 1 head, 3 blocks, seqslen 30, masklen 6, batch 128, num_items 20000")
+    cdef = dict(c, num_units=50, num_heads=1, num_blocks=3, seqslen=30, masklen=6, batch=128, l2_reg=0.0, ct_reg=0.0,
+                hidden_dropout_rate=0.0, attention_probs_dropout_rate=0.0)
+    out["reference_default_flags"] = dict(row(cdef), workload="num_units 50, 1 head, 3 blocks, seqslen 30, masklen 6, batch 128, num_items 20000",
+                                          path="engine (eager issue)")
+    # the same step replayed as ONE HIP graph (TrainEngine(use_graph=True)): at batch 128 the step is launch bound, where the replay wins
+    # (at the headline shape the eager issue does: DESIGN.md rule 57)
+    try:
+        out["reference_default_flags_graph"] = dict(row(cdef, path="graph"), path="graph (HIP-graph replay of the same launch sequence)")
+    except Exception as e:      # (a capture failure must not cost the line)
+        out["reference_default_flags_graph"] = {"error": repr(e)[:200]}
     torch.cuda.empty_cache()
     a3 = copy.copy(args)
     a3.steps, a3.warmup = 50, 10
