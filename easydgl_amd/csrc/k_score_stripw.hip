@@ -980,7 +980,10 @@ bool edgl_stripw_enabled() {
     static const int on = getenv("EDGL_SCORE_STRIPW") ? atoi(getenv("EDGL_SCORE_STRIPW")) : 1;
     return on != 0;
 }
-bool edgl_stripw_supports(int C) { return C == 256 || (C == 512 && (getenv("EDGL_SCORE_STRIPW512") ? atoi(getenv("EDGL_SCORE_STRIPW512")) : 1) != 0); }
+bool edgl_stripw_supports(int C) {      // 256: stripw_kernel; 512: stripw5_kernel (EDGL_SCORE_STRIPW512=0: the generic kernels, the A/B switch)
+    static const int on512 = getenv("EDGL_SCORE_STRIPW512") ? atoi(getenv("EDGL_SCORE_STRIPW512")) : 1;
+    return C == 256 || (C == 512 && on512 != 0);
+}
 
 // the dynamic-LDS attribute of a kernel is per device (see k_score_strip.hip)
 static void stripw_set_smem_attr(const void* kern, int which, int bytes) {
