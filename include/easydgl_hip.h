@@ -461,7 +461,7 @@ int edgl_score_flash_bwd(const void* rows, const void* table, const float* out_b
                          int dtype, void* stream);
 /* The one-hot part of dl = coef (p - onehot(label)) as a call of its own: d_table[label[r]] -= gscale coef[r] rows[r], d_bias[label[r]-1]
  * -= gscale coef[r] over the weighted rows (f32 atomics: commutes with every other accumulation into the two arrays).
- * edgl_score_flash_bwd_ex(defer_label_term = 1) leaves exactly this out where its product pass does not contain it (bf16, C = 128);
+ * edgl_score_flash_bwd_ex(defer_label_term = 1) leaves exactly this out where its product pass does not contain it (bf16, C = 128 / 256 / 512: the strip kernels);
  * edgl_score_flash_label_term then applies it — and is a no-op for every other configuration.  A training loop may run it off the
  * critical path (any time after the table-side reduction of edgl_score_flash_bwd_ex wrote d_table / d_bias). */
 int edgl_score_flash_bwd_ex(const void* rows, const void* table, const float* out_bias, const int64_t* labels,
