@@ -968,6 +968,151 @@ __global__ __launch_bounds__(256) void flash_finish_lse_kernel(const float* slab
     }
 }
 
+// The same launch at C = 512: eight channels per lane, so that a row's 64 lanes stay within one wave (the label logit is a wave
+// reduction).  A kernel of its own: the instances above — the headline's among them — keep their code.
+template <typename TO, int LPR, bool S16 = false, int CPL = 8>
+__global__ __launch_bounds__(256) void flash_finish_lse_wide_kernel(const float* slabs, const float* part, const TO* rows, const TO* table,
+                                                               const float* out_bias, const int64_t* labels, const int32_t* nvalid,
+                                                               const int32_t* wtotal, int R, int xb, int zb, int G, int ztotal,
+                                                               const float* gscale, float* row_lse, float* lab_out, float* coef_out,
+                                                               TO* out, float* ce_part) {
+    constexpr int C = CPL * LPR, MAXCH = CPL == 4 ? 16 : 8, NQ = CPL / 4;
+    __shared__ float ce_red[8];
+    float ce_num = 0.f;       // this thread's rows: -log(p_label + 1e-5) of the weighted ones (EasyDGL.py:181-185), one lane per row
+    const float gs = gscale ? gscale[0] : 1.0f;
+    const int Reff = nvalid ? min(R, nvalid[0]) : R;
+    const float W = (float)(wtotal ? wtotal[0] : Reff) + 1e-5f;       // EasyDGL.py:184 over the global batch
+    const DevPlan dp = dev_plan(max(Reff, 1), xb, G, ztotal, zb);
+    const long stride = (long)dp.nx * xb * C;
+    const int nch = dp.nchunk;
+    const int nrow_blk = 256 / LPR;
+    for (long r0 = (long)blockIdx.x * nrow_blk; r0 < R; r0 += (long)gridDim.x * nrow_blk) {
+        const int r = (int)min(r0 + threadIdx.x / LPR, (long)R - 1), c = (threadIdx.x % LPR) * CPL, rc = min(r, max(Reff - 1, 0));
+        const bool live = r0 + threadIdx.x / LPR < R;
+        if (r0 >= Reff) {      // (uniform) rows behind the weighted ones — label 0 by construction of the compaction: nothing to load
+            if (live) {
+                if (c == 0) { row_lse[r] = 0.f; lab_out[r] = labels[r] == 0 ? -1000.0f : 0.f; coef_out[r] = 0.f; }
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) {
+                    if constexpr (sizeof(TO) == 2) *reinterpret_cast<uint2*>(out + (long)r * C + c + 4 * h) = make_uint2(0u, 0u);
+                    else *reinterpret_cast<float4*>(out + (long)r * C + c + 4 * h) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            continue;
+        }
+        int64_t lab = labels[r];
+        asm volatile("" : "+v"(lab));
+        const int64_t labc = lab > 0 ? lab : 0;
+        float ob = out_bias[max(labc, (int64_t)1) - 1];
+        float xr[CPL], tb[CPL];
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            if constexpr (sizeof(TO) == 2) {
+                const Frag4<TO> fx = frag_ld<TO>(rows + (long)r * C + c + 4 * h), ft = frag_ld<TO>(table + labc * C + c + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { xr[4 * h + q] = to_f32(fx.v[q]); tb[4 * h + q] = to_f32(ft.v[q]); }
+            } else {
+                const float4 fx = *reinterpret_cast<const float4*>(rows + (long)r * C + c + 4 * h), ft = *reinterpret_cast<const float4*>(table + labc * C + c + 4 * h);
+                xr[4 * h] = fx.x; xr[4 * h + 1] = fx.y; xr[4 * h + 2] = fx.z; xr[4 * h + 3] = fx.w;
+                tb[4 * h] = ft.x; tb[4 * h + 1] = ft.y; tb[4 * h + 2] = ft.z; tb[4 * h + 3] = ft.w;
+            }
+        }
+        // ---- chunk partials in batches of MAXCH (all loads of a batch in flight together; index clamped, the surplus weighted 0):
+        //      the row maximum first, then  sm = sum_c l_c e_c,  a = sum_c slab_c e_c  with e_c = exp(m_c - max);
+        //      lse = max + log sm,  sum_c slab_c exp(m_c - lse) = a / sm
+        float mx = -INFINITY;
+        float4 sl0[MAXCH][NQ];                  // the first batch stays in registers (the benchmark has 11-12 chunks): ONE round trip
+        float pm0[MAXCH], ps0[MAXCH];
+#pragma unroll
+        for (int s = 0; s < MAXCH; ++s) {
+            const int sc = min(s, nch - 1);
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) sl0[s][h] = ld_slab4<S16>(slabs, (long)sc * stride + (long)rc * C + c + 4 * h);
+            pm0[s] = part[((long)rc * nch + sc) * 2];
+            ps0[s] = part[((long)rc * nch + sc) * 2 + 1];
+        }
+#pragma unroll
+        for (int s = 0; s < MAXCH; ++s) mx = s < nch ? fmaxf(mx, pm0[s]) : mx;
+        for (int s0 = MAXCH; s0 < nch; s0 += MAXCH) {
+            float pm[MAXCH];
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) pm[s] = part[((long)rc * nch + min(s0 + s, nch - 1)) * 2];
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) mx = s0 + s < nch ? fmaxf(mx, pm[s]) : mx;
+        }
+        float sm = 0.f, acc[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXCH; ++s) {
+            const float e = (s < nch && pm0[s] > -INFINITY) ? __expf(pm0[s] - mx) : 0.f;
+            sm = fmaf(ps0[s], e, sm);
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) {
+                acc[4 * h] = fmaf(sl0[s][h].x, e, acc[4 * h]); acc[4 * h + 1] = fmaf(sl0[s][h].y, e, acc[4 * h + 1]);
+                acc[4 * h + 2] = fmaf(sl0[s][h].z, e, acc[4 * h + 2]); acc[4 * h + 3] = fmaf(sl0[s][h].w, e, acc[4 * h + 3]);
+            }
+        }
+        for (int s0 = MAXCH; s0 < nch; s0 += MAXCH) {
+            float4 sl[MAXCH][NQ];
+            float pm[MAXCH], ps[MAXCH];
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) {
+                const int sc = min(s0 + s, nch - 1);
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) sl[s][h] = ld_slab4<S16>(slabs, (long)sc * stride + (long)rc * C + c + 4 * h);
+                pm[s] = part[((long)rc * nch + sc) * 2];
+                ps[s] = part[((long)rc * nch + sc) * 2 + 1];
+            }
+#pragma unroll
+            for (int s = 0; s < MAXCH; ++s) {
+                const float e = (s0 + s < nch && pm[s] > -INFINITY) ? __expf(pm[s] - mx) : 0.f;
+                sm = fmaf(ps[s], e, sm);
+#pragma unroll
+                for (int h = 0; h < NQ; ++h) {
+                    acc[4 * h] = fmaf(sl[s][h].x, e, acc[4 * h]); acc[4 * h + 1] = fmaf(sl[s][h].y, e, acc[4 * h + 1]);
+                    acc[4 * h + 2] = fmaf(sl[s][h].z, e, acc[4 * h + 2]); acc[4 * h + 3] = fmaf(sl[s][h].w, e, acc[4 * h + 3]);
+                }
+            }
+        }
+        asm volatile("" : "+v"(ob));
+        const float lse = r < Reff ? mx + __logf(sm) : 0.f;
+        const float inv_sm = (r < Reff && sm > 0.f) ? 1.0f / sm : 0.f;
+        // ---- label logit: LPR-lane sum (a row's lanes are LPR consecutive lanes of one wave)
+        float a = (xr[0] * tb[0] + xr[1] * tb[1]) + (xr[2] * tb[2] + xr[3] * tb[3]);
+        if constexpr (CPL == 8) a += (xr[4] * tb[4] + xr[5] * tb[5]) + (xr[6] * tb[6] + xr[7] * tb[7]);
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        const float ll = lab == 0 ? -1000.0f : a + ob;
+        const float v = __expf(ll - lse);
+        const float cf = (r < Reff && lab != 0) ? (1.f / W) * (v / (v + 1e-5f)) : 0.f;
+        if (live && c == 0) {
+            row_lse[r] = lse; lab_out[r] = ll; coef_out[r] = cf;
+            ce_num += (r < Reff && lab != 0) ? -__logf(v + 1e-5f) : 0.f;
+        }
+        // ---- d_rows = gs * coef * ( sum_chunks slab_c * exp(m_c - lse)  -  table[label] )
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) acc[q] *= inv_sm;
+        float o4[CPL];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) o4[q] = cf != 0.f ? gs * cf * (acc[q] - tb[q]) : 0.f;
+        if (live) {
+#pragma unroll
+            for (int h = 0; h < NQ; ++h) {
+                if constexpr (sizeof(TO) == 2) { const Frag4<TO> f = frag_from_acc<TO>(f32x4{o4[4 * h], o4[4 * h + 1], o4[4 * h + 2], o4[4 * h + 3]}); *reinterpret_cast<uint2*>(out + (long)r * C + c + 4 * h) = *reinterpret_cast<const uint2*>(&f); }
+                else *reinterpret_cast<float4*>(out + (long)r * C + c + 4 * h) = make_float4(o4[4 * h], o4[4 * h + 1], o4[4 * h + 2], o4[4 * h + 3]);
+            }
+        }
+    }
+    if (ce_part) {      // the loss numerator of this workgroup's rows: the loss kernel then adds <= 4096 numbers instead of sweeping the rows
+        ce_num = block_sum(ce_num, ce_red);
+        if (threadIdx.x == 0) {
+            ce_part[blockIdx.x] = ce_num;
+            if (blockIdx.x == 0) ce_part[gridDim.x] = (float)Reff;      // ... and the weighted-row count behind the sums (exact below 2^24)
+        }
+    }
+}
+
 // ROLE_YF finish: d_rows[r] = gs * coef[r] * ( sum_chunks slab_c[r] * exp(m_c - lse[r])  -  table[label[r]] )
 //   = gs * coef * (sum_z p_z T_z - T_label)   (Appendix C: dy_rows = dl . table, dl = coef (p - onehot))
 template <typename TO>
@@ -1723,7 +1868,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     const int G = strip ? std::max(xblocks_of(p.R, xb) * plan.y.nchunk, score_target()) : xblocks_of(p.R, xb) * plan.y.nchunk;
     float* part = ws + plan.off_part;
     // rows finished in one launch (flash_finish_lse_kernel): the strip row pass then leaves bf16 slabs
-    const bool one_launch = MODE == 1 && d_rows && (p.C == 128 || p.C == 64 || p.C == 256) && p.i0 == 0 && p.i1 == p.I;
+    const bool one_launch = MODE == 1 && d_rows && (p.C == 128 || p.C == 64 || p.C == 256 || p.C == 512) && p.i0 == 0 && p.i1 == p.I;
     const bool slab16 = strip == 1 && one_launch;
     if (MODE == 1) slab_format_set(ws, slab16 ? 1 : 0);
     if (MODE == 2 && d_rows)
@@ -1769,7 +1914,7 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
     hipLaunchKernelGGL((flash_finish_lse_kernel<T, LPR, S16>), dim3((unsigned)std::min<long>(((long)p.R * LPR + 255) / 256, 4096)), \
                        dim3(256), 0, st, slabY, part, rows_t, tab_t, p.out_bias, p.labels, p.nvalid, p.wtotal, p.R, xb, ZBK, G, \
                        p.i1 - p.i0, p.gscale, p.row_lse, p.lab_out, p.coef_out, out_t, p.ce_part)
-            if (p.C == 128 && slab16) EDGL_FFL(32, true); else if (p.C == 128) EDGL_FFL(32, false); else if (p.C == 64) EDGL_FFL(16, false); else EDGL_FFL(64, false);
+            if (p.C == 128 && slab16) EDGL_FFL(32, true); else if (p.C == 128) EDGL_FFL(32, false); else if (p.C == 64) EDGL_FFL(16, false); else if (p.C == 512) hipLaunchKernelGGL((flash_finish_lse_wide_kernel<T, 64, false, 8>), dim3((unsigned)std::min<long>(((long)p.R * 64 + 255) / 256, 4096)), dim3(256), 0, st, slabY, part, rows_t, tab_t, p.out_bias, p.labels, p.nvalid, p.wtotal, p.R, xb, ZBK, G, p.i1 - p.i0, p.gscale, p.row_lse, p.lab_out, p.coef_out, out_t, p.ce_part); else EDGL_FFL(64, false);
 #undef EDGL_FFL
             EDGL_LAUNCH_CHECK();
             return EDGL_OK;
@@ -1985,8 +2130,8 @@ extern "C" int edgl_ce_loss_fwd_add_w(const float* row_lse, const float* label_l
 }
 // number of per-workgroup loss sums edgl_score_flash_fwd_rows_wp writes (0: this shape has no one-launch row finish)
 extern "C" int edgl_score_ce_nparts(int R, int C) {
-    if (!(C == 128 || C == 64 || C == 256) || R <= 0) return 0;
-    const long lpr = C / 4;
+    if (!(C == 128 || C == 64 || C == 256 || C == 512) || R <= 0) return 0;
+    const long lpr = C == 512 ? 64 : C / 4;      // (C = 512: eight channels per lane)
     return (int)std::min<long>(((long)R * lpr + 255) / 256, 4096);
 }
 // loss (EasyDGL.py:181-188) from the sums edgl_score_flash_fwd_rows_wp left in ce_part: sum / (weighted rows + 1e-5) + add_in + add_in2
