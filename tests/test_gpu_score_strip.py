@@ -238,3 +238,27 @@ def test_no_weighted_row_at_all(C):
                                    p(ws), code, st), "bwd")
     torch.cuda.synchronize()
     assert float(d_tab.abs().max()) == 0.0 and float(d_b.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C", WIDTHS)
+@pytest.mark.parametrize("i0,i1", [(0, 2504), (2504, 5001), (1000, 1136)])
+def test_row_pass_over_an_item_range(C, i0, i1):
+    """edgl_score_flash_fwd over [i0, i1) (an item shard: i0 a multiple of 8): the log-sum-exp of the RANGE's logits — the pad item's
+    -1000 only where the range holds item 0, nothing of the items outside — against fp64 on the same bf16 operands."""
+    from easydgl_amd._lib import check, lib
+    o = _ops()
+    R, I = 500, 5001
+    rows, tab, bias, labels = _problem(R, I, seed=31 + C + i0, hot=0.1, zero=0.25, C=C)
+    rows_c, lab_c, perm, _inv, nvalid = o.compact_rows(rows, labels)
+    n = int(nvalid.item())
+    p, st, code = o._ptr, o._stream(), o._code(rows)
+    ws = torch.empty(lib.edgl_score_flash_workspace(R, C, I, I, code), device="cuda")
+    lse = torch.empty(R, device="cuda"); ll = torch.zeros(R, device="cuda")
+    check(lib.edgl_score_flash_fwd(p(rows_c), p(tab), p(bias), p(lab_c), R, C, I, i0, i1, p(nvalid), p(lse), p(ll), p(ws), code, st), "flash_fwd")
+    torch.cuda.synchronize()
+    x = rows_c[:n].double()
+    t = tab.double().clone(); t[0] = 0.0
+    b = torch.cat([torch.full((1,), -1000.0, dtype=torch.float64, device="cuda"), bias.double()])
+    logits = (x @ t.T + b)[:, i0:i1]
+    want = torch.logsumexp(logits, dim=1)
+    assert _rel_max(lse[:n], want) < 2e-5, _rel_max(lse[:n], want)
