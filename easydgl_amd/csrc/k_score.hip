@@ -1118,7 +1118,9 @@ __global__ __launch_bounds__(256) void flash_finish_lse_wide_kernel(const float*
 template <typename TO>
 __global__ void flash_finish_kernel(const float* slabs, const float* part, const float* row_lse, const float* coef,
                                     const int64_t* labels, const TO* table, const int32_t* nvalid, int R, int C, int xb, int zb,
-                                    int G, int ztotal, const float* gscale, TO* out) {
+                                    int G, int ztotal, const float* gscale, TO* out, int i0, int i1) {
+    // (i0, i1): the item range the slabs were formed over — the label row leaves only where the label lies in it (an item shard of
+    //  the vocab-parallel loss: every rank finishes its share of d_rows with the GLOBAL log-sum-exp, the shares add up)
     const float gs = gscale ? gscale[0] : 1.0f;
     const int Reff = nvalid ? min(R, nvalid[0]) : R;
     const DevPlan dp = dev_plan(max(Reff, 1), xb, G, ztotal, zb);
@@ -1162,7 +1164,7 @@ __global__ void flash_finish_kernel(const float* slabs, const float* part, const
             }
             const bool on = r < Reff && cf != 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = on ? gs * cf * (a[q] - (lab > 0 ? tb[q] : 0.f)) : 0.f;
+            for (int q = 0; q < 4; ++q) v[q] = on ? gs * cf * (a[q] - ((lab > 0 && lab >= i0 && lab < i1) ? tb[q] : 0.f)) : 0.f;
         } else if (r < Reff) {
             const float cf = coef[r];
             if (cf != 0.f) {
@@ -1171,7 +1173,7 @@ __global__ void flash_finish_kernel(const float* slabs, const float* part, const
                 for (int q = 0; q < 4; ++q) {
                     float a = 0.f;
                     for (int s = 0; s < nch; ++s) a += slabs[(long)s * stride + (long)r * C + c + q] * __expf(part[((long)r * nch + s) * 2] - lse);
-                    v[q] = gs * cf * (a - (lab > 0 ? to_f32(table[lab * C + c + q]) : 0.f));
+                    v[q] = gs * cf * (a - ((lab > 0 && lab >= i0 && lab < i1) ? to_f32(table[lab * C + c + q]) : 0.f));
                 }
             }
         }
@@ -1926,14 +1928,14 @@ int run_bwd_mode(ScoreP p, const BwdPlan& plan, float* ws, void* d_rows, float* 
         if (d_rows) {   // other widths: the two kernels, one after the other
             hipLaunchKernelGGL((flash_finish_kernel<T>), dim3((unsigned)std::min<long>((nrc / 4 + 255) / 256, 2048)), dim3(256), 0, st,
                                ws + plan.off_slabY, part, p.row_lse, p.coef_out, p.labels, reinterpret_cast<const T*>(p.table), p.nvalid,
-                               p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
+                               p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows), p.i0, p.i1);
             EDGL_LAUNCH_CHECK();
         }
         return EDGL_OK;
     } else if (d_rows) {
         hipLaunchKernelGGL((flash_finish_kernel<T>), dim3((unsigned)std::min<long>((nrc / 4 + 255) / 256, 2048)), dim3(256), 0, st,
                            ws + plan.off_slabY, part, p.row_lse, p.coef, p.labels, reinterpret_cast<const T*>(p.table), p.nvalid,
-                           p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows));
+                           p.R, p.C, xb, ZBK, G, p.i1 - p.i0, p.gscale, reinterpret_cast<T*>(d_rows), p.i0, p.i1);
         EDGL_LAUNCH_CHECK();
     }
     // d_table, d_bias

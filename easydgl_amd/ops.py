@@ -419,11 +419,14 @@ def score_lse(rows, table_c, out_bias, labels, i0, i1, want_logits=False, nvalid
     return lse, lab_logit, logits
 
 
+VP_FLASH = os.environ.get("EDGL_VP_FLASH", "1") != "0"      # vocab-parallel loss through the flash / strip kernels (0: the two-pass kernels)
+
+
 def vocab_parallel_ce(rows, table_c, out_bias, labels, group=None):
     """parallel.vocab_parallel_ce with the HIP scoring kernels: every rank holds the same rows [R, C] / labels [R] and scores them
-    against its row shard of the (replicated, un-scaled, tied) item table — edgl_score_lse_fwd / edgl_score_ce_bwd over the item
-    range [i0, i1) with the GLOBAL log-sum-exp (the two-pass kernels; the strip form finishes its rows with a local sum and would
-    need a finish kernel that takes the gathered sums).  Returns (loss, d_rows [R, C] f32, d_table [I, C] f32 — zero outside the
+    against its row shard of the (replicated, un-scaled, tied) item table over the item range [i0, i1) with the GLOBAL log-sum-exp —
+    the flash form (edgl_score_flash_fwd / _bwd: the strip kernels at the bf16 widths they cover; the row finish takes the gathered
+    sums) or, with EDGL_VP_FLASH=0, the two-pass kernels edgl_score_lse_fwd / edgl_score_ce_bwd.  Returns (loss, d_rows [R, C] f32, d_table [I, C] f32 — zero outside the
     rank's shard —, d_bias [I - 1] f32 — zero outside it —, (i0, i1)).  EasyDGL.py:149-155,177-185."""
     from . import parallel
     rows = rows.contiguous()
@@ -433,6 +436,34 @@ def vocab_parallel_ce(rows, table_c, out_bias, labels, group=None):
     dev, code, st = rows.device, _code(rows), _stream()
     d_table = torch.zeros((I, C), device=dev, dtype=torch.float32)
     d_bias = torch.zeros(I - 1, device=dev, dtype=torch.float32)
+    if VP_FLASH:
+        # the flash form over the rank's item range (the strip kernels at bf16 C = 128 / 256 / 512): ONE sweep gives the range's
+        # log-sum-exp and the unnormalised row gradients, the backward call finishes them with the GLOBAL log-sum-exp (the label row
+        # leaves on the rank that owns the label) and runs the table pass over the range — weighted rows first, as the training step
+        rows_c, lab_c, _perm, inv, nvalid = compact_rows(rows, labels)
+        state = {}
+
+        def lse_flash(i0, i1):
+            ws = torch.empty(int(lib.edgl_score_flash_workspace(R, C, I, i1 - i0, code)), device=dev, dtype=torch.float32)
+            lse = torch.empty(R, device=dev, dtype=torch.float32)
+            lab = torch.zeros(R, device=dev, dtype=torch.float32)
+            check(lib.edgl_score_flash_fwd(_ptr(rows_c), _ptr(table_c), _ptr(out_bias), _ptr(lab_c), R, C, I, i0, i1, _ptr(nvalid), _ptr(lse),
+                                           _ptr(lab), _ptr(ws), code, st), "edgl_score_flash_fwd")
+            state["ws"] = ws
+            own = (lab_c >= max(i0, 1)) & (lab_c < i1)
+            live = torch.arange(R, device=dev) < nvalid.to(torch.long)
+            # rows behind the weighted ones carry label 0 (weight 0): a finite log-sum-exp of their own keeps the gathered sums finite
+            return torch.where(live, lse, torch.zeros_like(lse)), torch.where(own, lab, torch.full_like(lab, float("-inf")))
+
+        def grad_flash(i0, i1, lse, coef):
+            d_rows = torch.empty_like(rows_c)
+            check(lib.edgl_score_flash_bwd(_ptr(rows_c), _ptr(table_c), _ptr(out_bias), _ptr(lab_c), _ptr(lse.contiguous()), _ptr(coef.contiguous()),
+                                           None, R, C, I, i0, i1, _ptr(nvalid), _ptr(d_rows), _ptr(d_table), _ptr(d_bias), _ptr(state["ws"]), code, st),
+                  "edgl_score_flash_bwd")
+            return d_rows
+
+        loss, d_rows_c, (i0, i1) = parallel.vocab_parallel_ce(lab_c, I, lse_flash, grad_flash, group)
+        return loss, d_rows_c[inv.long()], d_table, d_bias, (i0, i1)
 
     def lse_local(i0, i1):
         lse, lab, _ = score_lse(rows, table_c, out_bias, labels, i0, i1)

@@ -238,7 +238,7 @@ def test_dp_counts_in_one_launch():
                               ctypes.c_void_p(counts.data_ptr()), None) != 0      # more than 65536 labels: refused
 
 
-def _vp_hip_worker(rank, world, port, out, dtype_name):
+def _vp_hip_worker(rank, world, port, out, dtype_name, C=128):
     """ops.vocab_parallel_ce — the HIP scoring kernels over a row shard of the item table per rank, ONE packed all-gather of
     (log-sum-exp, label logit), ONE all-reduce of d_rows (EasyDGL.py:149-155,177-185) — two ranks on one GPU over
     gloo against an fp64 reference on the same (rounded) operands."""
@@ -250,8 +250,8 @@ def _vp_hip_worker(rank, world, port, out, dtype_name):
     from easydgl_amd import ops
     dt = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     g = torch.Generator().manual_seed(17)
-    R, C, I = 300, 128, 5003
-    rows = (torch.randn((R, C), generator=g) * 0.5).to(dt).cuda()
+    R, I = 300, 5003
+    rows = (torch.randn((R, C), generator=g) * 0.5 * (128 / C) ** 0.5).to(dt).cuda()
     table = (torch.randn((I, C), generator=g) * 0.3).to(dt).cuda()
     bias = (torch.randn(I - 1, generator=g) * 0.2).cuda()
     labels = torch.randint(1, I, (R,), generator=g)
@@ -280,12 +280,13 @@ def _vp_hip_worker(rank, world, port, out, dtype_name):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype_name", ["f32", "bf16"])
-def test_vocab_parallel_ce_two_ranks_match_the_unsharded_reference(dtype_name):
+@pytest.mark.parametrize("dtype_name,C", [("f32", 128), ("bf16", 128), ("bf16", 256), ("bf16", 512)])
+def test_vocab_parallel_ce_two_ranks_match_the_unsharded_reference(dtype_name, C):
+    """(bf16: the flash form over each rank's item range — the strip kernels of all three widths; f32: the generic flash kernels)"""
     import torch.multiprocessing as mp
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_vp_hip_worker, args=(world, _free_port(), out, dtype_name), nprocs=world, join=True)
+    mp.spawn(_vp_hip_worker, args=(world, _free_port(), out, dtype_name, C), nprocs=world, join=True)
     assert all(out[r][0] for r in range(world)), dict(out)
     assert out[0][2][0] == 0 and out[0][2][1] == out[1][2][0] and out[1][2][1] == 5003
