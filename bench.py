@@ -346,11 +346,12 @@ def main():
     sync_loss = getattr(res.get("engine"), "sync_loss", None)
     # north_star's other multi-GPU path in the SAME line: the full-catalogue scoring step with the item table row-sharded over the
     # ranks and ONE packed RCCL all-gather of the local top-K.  Every rank takes part (collective); rank 0 reports.
-    eval_sharded = None
+    eval_sharded = vocab_parallel = None
     if world > 1 and args.workload == "step" and not args.no_extras:
         res.pop("engine", None)
         torch.cuda.empty_cache()
         eval_sharded = eval_rows(args, dev, world, rank, dist, steps=20, warmup=5, sizes=((20000, 128),))
+        vocab_parallel = vocab_parallel_row(args, dev, world, rank, dist)
 
     if rank == 0:
         T, C, I, M = c["seqslen"] + 1, c["num_units"], c["num_items"] + 1, c["masklen"]
@@ -484,7 +485,7 @@ def main():
         if world == 1 and not args.no_extras and args.path == "engine":
             out["extras"] = extras(c, args, dev)
         if eval_sharded is not None:
-            out["extras"] = {"eval_sharded": eval_sharded}
+            out["extras"] = {"eval_sharded": eval_sharded, "vocab_parallel_ce": vocab_parallel}
         if args.op_table:
             step = res["step"]
             _lib.profiler.start()
@@ -743,12 +744,59 @@ def extras(c, args, dev):
                                             "(T = 201), num_units 256, 8 heads, 1 block, masklen 40, batch 512")
         torch.cuda.empty_cache()
     out["eval_sharded"] = eval_rows(args, dev, 1, 0, None, steps=20, warmup=5, sizes=((20000, 128), (1_000_000, 256)))
+    out["vocab_parallel_ce"] = vocab_parallel_row(args, dev, 1, 0, None)
     return out
 
 
 def _lib_supported(R, C, n, T, K):
     from easydgl_amd import _lib
     return _lib.lib.edgl_score_topk_fused_supported(R, C, n, T, K, _lib.BF16)
+
+
+def vocab_parallel_row(args, dev, world, rank, dist, steps=20, warmup=5):
+    """SURVEY §8e row 3 as a timed row: the headline's scoring + cross-entropy step (10240 masked slots of 128 channels, 47.5 % of them
+    without weight, 20001 items; EasyDGL.py:149-155,177-185) with the item table ROW-SHARDED over the ranks — every rank scores the same
+    rows against its shard with the strip kernels (ops.vocab_parallel_ce), ONE packed all-gather of (log-sum-exp, label logit), ONE
+    all-reduce of d_rows.  The rows are shared, so the job does not grow with N: strong scaling.  Every rank takes part; errors are
+    reported in the row instead of costing the line."""
+    try:
+        from easydgl_amd import ops
+        g = torch.Generator(device="cpu").manual_seed(4242)
+        R, C, I = 10240, 128, 20001
+        dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        rows = (torch.randn((R, C), generator=g) * 0.6).to(dt).to(dev)
+        table = (torch.randn((I, C), generator=g) * 0.4).to(dt).to(dev)
+        bias = (torch.randn(I - 1, generator=g) * 0.3).to(dev)
+        labels = torch.randint(1, I, (R,), generator=g)
+        labels[torch.rand(R, generator=g) > 0.525] = 0
+        labels = labels.to(dev)
+
+        def call():
+            return ops.vocab_parallel_ce(rows, table, bias, labels)
+        for _ in range(warmup):
+            loss = call()[0]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = call()[0]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dtm], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtm = float(t.item())
+        return {"rows": R, "weighted_rows": int((labels != 0).sum()), "num_units": C, "num_items": I - 1, "shards": world,
+                "ms_per_call": round(dtm / steps * 1e3, 4), "loss": round(float(loss), 5), "scaling": "strong",
+                "collectives": "one all-gather of [R, 2] f32 + one all-reduce of d_rows [R, C] f32 per call",
+                "note": "loss + d_rows + the shard's d_table / d_bias; host-driven torch ops between the launches included"}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:300]}
 
 
 def eval_rows(args, dev, world, rank, dist, steps, warmup, sizes):

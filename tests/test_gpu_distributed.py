@@ -189,6 +189,11 @@ def test_bench_eight_ranks_over_gloo_smoke():
     rows = j["extras"]["eval_sharded"]
     assert rows and all(r_["shards"] == 8 and r_["ms_per_eval_step"] > 0 and r_["allgather_ms"] is not None for r_ in rows)
     assert rows[0]["allgather_bytes_gathered"] == 8 * 512 * 2 * 100 * 4
+    # ... and the scoring + cross-entropy step with the table row-sharded for TRAINING (vocab-parallel loss through the
+    # strip kernels, one all-gather + one all-reduce)
+    vp = j["extras"]["vocab_parallel_ce"]
+    assert "error" not in vp, vp
+    assert vp["shards"] == 8 and vp["ms_per_call"] > 0 and 3.0 < vp["loss"] < 12.0
 
 
 def test_bench_autograd_path_is_single_gpu_only():
