@@ -120,11 +120,82 @@ def test_strip_all_rows_weighted(C):
     _check(rows, tab, bias, labels)
 
 
-def test_wide_strip_on_a_table_of_many_chunks():
-    """C = 256 against a 150 K-item table (config 3's width; the slab cap of the planner bounds the item chunks): every chunk count /
+@pytest.mark.parametrize("C", [256, 512])
+def test_wide_strip_on_a_table_of_many_chunks(C):
+    """C = 256 / 512 against a 150 K-item table (config 3's width; the slab cap of the planner bounds the item chunks): every chunk count /
     remainder path of the device plan at a size the fp64 reference still holds (2000 x 150001 logits)."""
-    rows, tab, bias, labels = _problem(2000, 150001, seed=8, hot=0.1, zero=0.3, C=256)
+    rows, tab, bias, labels = _problem(2000, 150001, seed=8, hot=0.1, zero=0.3, C=C)
     _check(rows, tab, bias, labels)
+
+
+def _reference_chunked(rows, tab, bias, labels, chunk=16384):
+    """_reference over item chunks (two sweeps: log-sum-exp and label logits, then the three gradients) for tables whose [R, I] fp64
+    logits do not fit: the same arithmetic, the same outputs."""
+    R, C = rows.shape
+    I = tab.shape[0]
+    dev = rows.device
+    x = rows.double()
+    b = torch.cat([torch.full((1,), -1000.0, dtype=torch.float64, device=dev), bias.double()])
+
+    def chunk_logits(i0, i1):
+        t = tab[i0:i1].double()
+        if i0 == 0:
+            t[0] = 0.0
+        return t, x @ t.T + b[i0:i1]
+
+    m = torch.full((R,), -float("inf"), dtype=torch.float64, device=dev)
+    s = torch.zeros(R, dtype=torch.float64, device=dev)
+    ll = torch.zeros(R, dtype=torch.float64, device=dev)
+    for i0 in range(0, I, chunk):
+        i1 = min(I, i0 + chunk)
+        _, lg = chunk_logits(i0, i1)
+        mc = torch.maximum(m, lg.max(dim=1).values)
+        s = s * torch.exp(m - mc) + torch.exp(lg - mc.view(-1, 1)).sum(1)
+        m = mc
+        inside = (labels >= i0) & (labels < i1)
+        r = inside.nonzero().squeeze(1)
+        ll[r] = lg[r, labels[r] - i0]
+    lse = m + torch.log(s)
+    w = (labels != 0).double()
+    py = torch.exp(ll - lse)
+    coef = w * (1.0 / (w.sum() + 1e-5)) * (py / (py + 1e-5))
+    d_rows = torch.zeros(R, C, dtype=torch.float64, device=dev)
+    d_tab = torch.empty(I, C, dtype=torch.float64, device=dev)
+    d_b = torch.empty(I, dtype=torch.float64, device=dev)
+    for i0 in range(0, I, chunk):
+        i1 = min(I, i0 + chunk)
+        t, lg = chunk_logits(i0, i1)
+        dl = torch.exp(lg - lse.view(-1, 1)).mul_(coef.view(-1, 1))
+        r = ((labels >= i0) & (labels < i1)).nonzero().squeeze(1)
+        dl[r, labels[r] - i0] -= coef[r]
+        d_rows += dl @ t
+        d_tab[i0:i1] = dl.T @ x
+        d_b[i0:i1] = dl.sum(0)
+    d_tab[0] = 0.0
+    return lse, ll, coef, d_rows, d_tab, d_b[1:]
+
+
+def test_chunked_reference_is_the_plain_reference():
+    rows, tab, bias, labels = _problem(300, 5001, seed=3, hot=0.2, zero=0.3, C=256)
+    for a, c in zip(_reference(rows, tab, bias, labels), _reference_chunked(rows, tab, bias, labels, chunk=1000)):
+        assert _rel_max(c, a) < 1e-12
+
+
+def test_wide_strip_at_the_full_size_of_config_3():
+    """BASELINE.json configs[2] as the scoring kernels see it: 512 x 40 masked slots (~ 52 % weighted) against the 1 000 001-row table at
+    C = 256 — every weighted row's log-sum-exp / label logit / coefficient, d_rows, and ALL 256 M entries of d_table (+ d_bias) against the
+    chunked fp64 reference on the same bf16 operands.  (10.7 K x 1 M fp64 logits, twice: ~ 20 s.)"""
+    rows, tab, bias, labels = _problem(512 * 40, 1000001, seed=9, hot=0.05, zero=0.475, C=256)
+    n, perm, lse, ll, coef, d_rows, d_tab, d_b = _run_flash(rows, tab, bias, labels)
+    assert n == int((labels != 0).sum())
+    r_lse, r_ll, r_coef, r_drows, r_dtab, r_db = _reference_chunked(rows[perm], tab, bias, labels[perm])
+    assert _rel_max(lse, r_lse) < 2e-5, _rel_max(lse, r_lse)
+    assert float((ll.double() - r_ll).abs().max()) < 1e-4 * (1.0 + float(r_ll.abs().max()))
+    assert _rel_max(coef, r_coef) < 2e-3, _rel_max(coef, r_coef)
+    for name, got, ref, tol in (("d_rows", d_rows.float(), r_drows, 1.2e-2), ("d_table", d_tab, r_dtab, 6e-3), ("d_bias", d_b, r_db, 6e-3)):
+        e2, em = _rel_l2(got, ref), _rel_max(got, ref)
+        assert e2 < tol and em < 2 * tol, (name, e2, em)
+    assert float(d_tab[0].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("C", WIDTHS)
