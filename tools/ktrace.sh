@@ -9,4 +9,4 @@ rocprofv3 --kernel-trace --stats -d "$OUT" -o k -- python $ROOT/bench.py --steps
 python $ROOT/tools/kstats.py "$OUT/k_results.db" 25 | cut -c1-150 | head -${KT_LINES:-28}
 grep -h '"metric"' "$OUT/log.txt" | cut -c1-260
 if [ -n "$KT_TIMELINE" ]; then python $ROOT/tools/ktimeline.py "$OUT/k_results.db" "$KT_TIMELINE"; fi
-rm -f "$OUT/k_results.db"
+if [ -z "${KT_KEEP:-}" ]; then rm -f "$OUT/k_results.db"; fi
