@@ -95,6 +95,43 @@ def test_fused_eval_scoring_matches_the_reference(R, C, I, T, K, i0, i1):
     assert same > 0.98, same
 
 
+def test_fused_eval_at_the_full_size_of_config_3():
+    """BASELINE.json configs[2] as the evaluation scoring sees it: 512 rows x 1 000 001 items x 256 channels, 201 seen ids per row, K = 100 —
+    membership, values and order (wherever the fp64 gaps to both neighbours exceed what f32 accumulation can reorder) of ALL rows against
+    an fp64 reference computed on the GPU (4 GB of logits; torch.topk — no ties in random data)."""
+    o = ops()
+    R, C, I, T, K = 512, 256, 1_000_001, 201, 100
+    g = torch.Generator(device="cuda").manual_seed(77)
+    rows = (torch.randn(R, C, device="cuda", generator=g) * 0.5).bfloat16()
+    table = (torch.randn(I, C, device="cuda", generator=g) * 0.3).bfloat16()
+    bias = torch.randn(I - 1, device="cuda", generator=g) * 0.2
+    seen = torch.randint(0, I, (R, T), device="cuda", generator=g)
+    seen[:, 0] = 0
+    seen[:, 1] = I - 1
+    assert o.EVAL_FUSED
+    val, idx = o.score_topk(rows, table, bias, seen, K, 0, I)
+    torch.cuda.synchronize()
+    t = table.double()
+    t[0] = 0.0
+    lg = rows.double() @ t.T
+    del t
+    lg += torch.cat([torch.full((1,), -1000.0, dtype=torch.float64, device="cuda"), bias.double()])
+    lg.scatter_(1, seen, float("-inf"))
+    ref_val, ref_idx = torch.topk(lg, K + 1, dim=1)
+    idx = idx.long()
+    got = lg.gather(1, idx)
+    assert bool(torch.isfinite(got).all())                                                   # no seen id
+    assert bool(((got - val.double()).abs() <= 2e-4 * got.abs().max().clamp(min=1.0)).all())  # the values ARE those items' logits
+    assert bool((got >= ref_val[:, K - 1:K] - 2e-4).all())                                   # each one belongs to the top K
+    assert bool((val[:, 1:] <= val[:, :-1]).all())                                           # descending
+    assert bool((torch.sort(idx, dim=1).values.diff(dim=1) != 0).all())                      # K different items
+    gaps = ref_val[:, :-1] - ref_val[:, 1:]                                                  # K gaps: gaps[p] between positions p and p + 1
+    fixed = gaps > ORDER_GAP
+    fixed[:, 1:] &= gaps[:, :-1] > ORDER_GAP
+    assert bool((idx[fixed] == ref_idx[:, :K][fixed]).all())
+    assert float(fixed.float().mean()) > 0.9, float(fixed.float().mean())
+
+
 def test_fused_eval_scoring_breaks_ties_by_index_and_survives_overflow():
     """Blocks of identical items: (a) pairs of equal logits inside the top K come out lower index first; (b) a table of ONE repeated
     row makes every logit of a row equal — every element passes the bound, the candidate lists overflow and the exact kernel
