@@ -88,14 +88,14 @@ def bimau(C, h, x, keymask3, spans, marks_f, p, pre, att_drop, training, causal=
     S = torch.where(keymask3 == 0, torch.full_like(S, PAD_SCORE), S)
     T = S.shape[1]
     if causal:  # temporal.py:370-375
-        tril = torch.tril(torch.ones(T, T, dtype=torch.bool))
+        tril = torch.tril(torch.ones(T, T, dtype=torch.bool, device=S.device))
         S = torch.where(tril, S, torch.full_like(S, PAD_SCORE))
     P = torch.softmax(S, dim=-1)
     H = torch.matmul(P, T__)
     Mint, lam = intensity(H, spans, marks_f, p[st + "dense/kernel"], p[st + "dense/bias"],
                           p[st + "weight"], p[st + "scaling"], h)
     if set_diag:
-        eye = torch.eye(T, dtype=torch.bool)
+        eye = torch.eye(T, dtype=torch.bool, device=Mint.device)
         Mint = torch.where(eye, torch.ones_like(Mint), Mint)  # set_diag :438-439
     A = dropout(Mint * P, att_drop, training)
     Ovals = torch.matmul(A, V_)

@@ -278,6 +278,65 @@ def test_bimau_fwd_bwd(name, dt, tol, B, T, C, H, E):
     assert_close(sc.grad.cpu().numpy(), pr["sequential_temporal_combined/scaling"].grad.numpy(), gtol, "dscaling")
 
 
+@pytest.mark.parametrize("B,T,C,H,E", [(512, 101, 128, 8, 16), (512, 201, 256, 8, 16)])
+def test_bimau_at_the_full_batch_against_fp64_on_the_gpu(B, T, C, H, E):
+    """K3 at the benchmarked shape (BASELINE.json configs[1]: 4096 (sample, head) jobs of 101 positions) and at config 3's (201 positions,
+    head dim 32), bf16, the whole batch of 512: outputs, lambda and every gradient against the fp64 restatement (oracle/torch_ref.py,
+    evaluated on the GPU in float64 on the rounded inputs the kernels saw: ~ 50 GB of [h B, T, T] / [h B, T, dh E] tensors at config 3)."""
+    o = ops()
+    dt = torch.bfloat16
+    cfg, x, ids, marks, spans, W = _bimau_case(B, T, C, H, E, seed=T + C)
+    xt = torch.tensor(x, dtype=dt).cuda().requires_grad_()
+    Wq = torch.tensor(W["Wq"], dtype=torch.float32).cuda().requires_grad_()
+    Wq_c = Wq.detach().to(dt)
+    bq = torch.tensor(W["bq"], dtype=torch.float32).cuda().requires_grad_()
+    W1, b1, w, sc = (torch.tensor(W[k], dtype=torch.float32).cuda().requires_grad_() for k in ("W1", "b1", "w", "sc"))
+    ids_d = torch.tensor(ids).cuda()
+    qkvt = o.LinearFn.apply(xt, Wq, bq, Wq_c, False)
+    out, lam = o.BiMAUFn.apply(qkvt, xt[:, :, :C], W1, b1, w, sc, ids_d, torch.tensor(spans, dtype=torch.float32).cuda(),
+                               torch.tensor(marks.astype(np.uint8)).cuda(), H, o.NO_DROP)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    G1 = torch.randn((B, T, C), device="cuda", generator=g).to(dt)
+    G2 = torch.randn((H * B, T, E), device="cuda", generator=g) * 0.3
+    ((out.float() * G1.float()).sum() + (lam * G2).sum()).backward()
+    xr = xt.detach().double().requires_grad_()
+    pr = {"dense/kernel": Wq_c.double().requires_grad_(), "dense/bias": bq.detach().double().requires_grad_(),
+          "sequential_temporal_combined/dense/kernel": W1.detach().double().requires_grad_(),
+          "sequential_temporal_combined/dense/bias": b1.detach().double().requires_grad_(),
+          "sequential_temporal_combined/weight": w.detach().double().requires_grad_(),
+          "sequential_temporal_combined/scaling": sc.detach().double().requires_grad_()}
+    # the samples are independent: the reference runs over chunks of 64 (its [h B, T, T, E] broadcast of lambda is 21 GB at config 3's
+    # full batch); parameter gradients accumulate over the chunks, lambda's head-major rows b' = head * B + b are re-stacked
+    sp_d, mk_d = torch.tensor(spans).cuda(), torch.tensor(marks, dtype=torch.float64).cuda()
+    outs, lams = [], []
+    for b0 in range(0, B, 64):
+        b1_ = min(B, b0 + 64)
+        km3 = (ids_d[b0:b1_] != 0).double().unsqueeze(1).repeat(H, T, 1)
+        o_c, l_c = R.bimau(C, H, xr[b0:b1_], km3, sp_d[b0:b1_], mk_d[b0:b1_], pr, "", 0.0, False)
+        g2 = G2.view(H, B, T, E)[:, b0:b1_].reshape(H * (b1_ - b0), T, E)
+        ((o_c * G1[b0:b1_].double()).sum() + (l_c * g2.double()).sum()).backward()
+        outs.append(o_c.detach()); lams.append(l_c.detach().view(H, b1_ - b0, T, E))
+    out_r, lam_r = torch.cat(outs, dim=0), torch.cat(lams, dim=1).reshape(H * B, T, E)
+    # Max-norm over 6.6 M / 26 M outputs: the tail of what the bf16 rounding of Q and K does to a sharp softmax reaches 4e-2 of the largest
+    # output on a handful of elements (measured: 1e-6 of them above 2e-2; against the restatement fed with the kernel's own bf16 QKVT the
+    # kernel itself is within 6e-3) — so the max-norm bound is 6e-2 here and the relative L2 norm carries the claim
+    ftol, gtol = 6e-2, 6e-2
+    n = lambda t: t.detach().double().cpu().numpy()
+    rel2 = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert rel2(out.detach(), out_r) < 1.5e-2, rel2(out.detach(), out_r)
+    assert rel2(lam.detach(), lam_r) < 1.5e-2, rel2(lam.detach(), lam_r)
+    assert rel2(xt.grad, xr.grad) < 3e-2, rel2(xt.grad, xr.grad)
+    assert_close(n(lam), n(lam_r), ftol, "lambda")
+    assert_close(n(out), n(out_r), ftol, "out")
+    assert_close(n(xt.grad), n(xr.grad), gtol, "dx")
+    assert_close(n(Wq.grad), n(pr["dense/kernel"].grad), gtol, "dWqkvt")
+    assert_close(n(bq.grad), n(pr["dense/bias"].grad), gtol, "dbqkvt")
+    assert_close(n(W1.grad), n(pr["sequential_temporal_combined/dense/kernel"].grad), gtol, "dW1")
+    assert_close(n(b1.grad), n(pr["sequential_temporal_combined/dense/bias"].grad), gtol, "db1")
+    assert_close(n(w.grad), n(pr["sequential_temporal_combined/weight"].grad), gtol, "dw")
+    assert_close(n(sc.grad), n(pr["sequential_temporal_combined/scaling"].grad), gtol, "dscaling")
+
+
 @pytest.mark.parametrize("name,dt,tol", DTYPES)
 @pytest.mark.parametrize("flags", [1, 2, 3])
 @pytest.mark.parametrize("B,T,C,H,E", [(3, 21, 32, 2, 5), (2, 30, 512, 4, 16), (2, 40, 128, 2, 6)])
