@@ -1,0 +1,54 @@
+"""Random model configurations through the static training engine (easydgl_amd/engine.py: one loss + every gradient of a batch of 4)
+against the fp64 oracle — the body of tests/test_gpu_engine.py::test_engine_gradients_match_oracle with drawn widths / heads / blocks /
+sequence and mask lengths / mark counts / catalogue sizes inside the documented limits.   python tools/fuzz_engine.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import tests.test_gpu_engine as T   # noqa: E402
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    bad = ran = 0
+    for k in range(cases):
+        mode = "f32" if rng.random() < 0.5 else "bf16"
+        dh = int(rng.choice([16, 16, 32, 64, 128]))
+        H = int(rng.choice([1, 2, 4, 8])) if dh > 16 else int(rng.choice([2, 4, 8]))     # (the scoring kernels take C in [32, 512])
+        while dh * H > 512:
+            H //= 2
+        C = dh * H
+        tmax = 200 if dh <= 32 else (127 if mode == "bf16" else (111 if dh == 64 else 63))
+        if mode == "f32" and dh == 32:
+            tmax = 127
+        seqslen = int(min(tmax, rng.choice([4, 9, 20, 30, 47, 64, 100, 111, 150, 200])))
+        masklen = int(max(1, min(seqslen // 2, rng.choice([1, 3, 6, 20, 40]))))
+        cfgd = dict(num_units=C, num_heads=H, num_blocks=int(rng.choice([0, 1, 1, 2, 3])), seqslen=seqslen, masklen=masklen,
+                    num_events=int(rng.choice([2, 3, 5, 7, 16, 16, 24, 40])), num_items=int(rng.choice([60, 300, 2000, 5000])))
+        desc = f"case {k}: {mode} {cfgd}"
+        T.CASES.append(cfgd)
+        try:
+            T.test_engine_gradients_match_oracle(mode, len(T.CASES) - 1)
+            ran += 1
+        except AssertionError as e:
+            # f32 (1e-3 bounds) is the bug detector; a bf16 case over its 2e-2 / 5e-2 bounds is reported, not counted, below 8e-2: the
+            # small gradients of the intensity MLP at head dims 64 / 128 reach 4e-2 relative L2 on some draws (the same draws pass in f32)
+            soft = mode == "bf16" and "TMAU/sequential_temporal_combined" in str(e) and all(float(x) < 8e-2 for x in __import__("re").findall(r"\((0\.\d+), ", str(e))[:6])
+            bad += 0 if soft else 1
+            print("OVER-BOUND (bf16, not counted)" if soft else "FAIL", desc, "->", str(e)[:300], flush=True)
+            ran += 1 if soft else 0
+        except Exception as e:   # noqa: BLE001
+            bad += 1
+            print("ERROR", desc, "->", type(e).__name__, str(e)[:300], flush=True)
+        if (k + 1) % 10 == 0:
+            print(f"... {k + 1} draws, {ran} checked, {bad} failures", flush=True)
+    print(f"fuzz_engine: {cases} draws, {ran} checked, {bad} failures (seed {seed})")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
