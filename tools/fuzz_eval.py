@@ -15,8 +15,13 @@ from easydgl_amd import ops as o   # noqa: E402
 ORDER_GAP = 2e-4
 
 
-def check(rows, table, bias, seen, K, i0, i1):
-    val, idx = o.score_topk(rows, table, bias, seen, K, i0, i1)
+def check(rows, table, bias, seen, K, i0, i1, nshard=0):
+    if nshard:      # the sharded protocol in one process: a local top-K per item range (parallel.shard_bounds) + the merge kernel
+        from easydgl_amd import parallel
+        parts = [o.score_topk(rows, table, bias, seen, K, *parallel.shard_bounds(table.shape[0], nshard, r)) for r in range(nshard)]
+        val, idx = o.topk_merge(torch.stack([p[0] for p in parts]).contiguous(), torch.stack([p[1] for p in parts]).contiguous())
+    else:
+        val, idx = o.score_topk(rows, table, bias, seen, K, i0, i1)
     torch.cuda.synchronize()
     if os.environ.get("FUZZ_SELFTEST") == "1" and K >= 2:      # the checker must notice a list with its first two entries swapped
         idx = idx.clone(); idx[:, [0, 1]] = idx[:, [1, 0]]
@@ -80,7 +85,9 @@ def main():
                     lg = rows.float() @ table.float().T
                     top = lg.topk(min(T - 2, 8), dim=1).indices
                     seen[:, 2:2 + top.shape[1]] = top
-            check(rows, table, bias, seen, K, i0, i1)
+            ns = int(rng.choice([2, 3, 8])) if (i0 == 0 and i1 == I and I // 8 >= K + T + 64 and rng.random() < 0.5) else 0
+            desc += f" shards={ns}" if ns else ""
+            check(rows, table, bias, seen, K, i0, i1, ns)
             ran += 1
         except AssertionError as e:
             if "degenerate" in str(e):
