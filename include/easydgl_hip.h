@@ -412,7 +412,12 @@ int edgl_rank_metrics(const int32_t* topk_idx, int R, int K, const int64_t* labe
  * edgl_score_flash_bwd: d_rows = gscale * coef * (that sum / row sum - table[label]) — i.e. dl . table with
  * dl = coef (softmax - onehot), SURVEY Appendix C — then d_table / d_bias exactly as edgl_score_ce_bwd.  `workspace`:
  * edgl_score_flash_workspace floats, untouched between the two calls.  Other arguments as edgl_score_lse_fwd /
- * edgl_score_ce_bwd (EasyDGL.py:149-155,177-185). */
+ * edgl_score_ce_bwd (EasyDGL.py:149-155,177-185).
+ * Item ranges (the item table row-sharded over ranks; i0 a multiple of 8): edgl_score_flash_fwd over [i0, i1) gives the
+ * log-sum-exp of the RANGE's logits (the pad item's -1000 only where the range holds item 0) and label_logit where i0 <= label < i1;
+ * edgl_score_flash_bwd over the same range takes the GLOBAL row_lse / coef (merged over the ranges by the caller) and returns the
+ * range's share of d_rows — its label row subtracted only by the range that owns the label — and writes rows [i0, i1) of d_table /
+ * entries [max(i0,1) - 1, i1 - 1) of d_bias, nothing else: the shares add up to the unsharded result (tests/test_gpu_score_strip.py). */
 long edgl_score_flash_workspace(int R, int C, int I, int n_items, int dtype);
 int edgl_score_flash_fwd(const void* rows, const void* table, const float* out_bias, const int64_t* labels, int R, int C,
                          int I, int i0, int i1, const int32_t* nvalid, float* row_lse, float* label_logit,
