@@ -462,7 +462,13 @@ def vocab_parallel_ce(rows, table_c, out_bias, labels, group=None):
                   "edgl_score_flash_bwd")
             return d_rows
 
-        loss, d_rows_c, (i0, i1) = parallel.vocab_parallel_ce(lab_c, I, lse_flash, grad_flash, group)
+        def ce_hip(lse, lab, labels_c):      # loss + coefficients of the merged sums in one launch (EasyDGL.py:177-185)
+            loss = torch.empty(1, device=dev, dtype=torch.float32)
+            coef = torch.empty(R, device=dev, dtype=torch.float32)
+            check(lib.edgl_ce_loss_fwd(_ptr(lse), _ptr(lab), _ptr(labels_c), R, _ptr(loss), _ptr(coef), st), "edgl_ce_loss_fwd")
+            return loss.reshape(()), coef
+
+        loss, d_rows_c, (i0, i1) = parallel.vocab_parallel_ce(lab_c, I, lse_flash, grad_flash, group, ce_local=ce_hip)
         return loss, d_rows_c[inv.long()], d_table, d_bias, (i0, i1)
 
     def lse_local(i0, i1):

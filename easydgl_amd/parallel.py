@@ -69,7 +69,8 @@ def allreduce_sum_(flat_grad: torch.Tensor, group: Optional[dist.ProcessGroup] =
 def vocab_parallel_ce(labels: torch.Tensor, num_rows: int,
                       lse_local: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]],
                       grad_local: Callable[[int, int, torch.Tensor, torch.Tensor], torch.Tensor],
-                      group: Optional[dist.ProcessGroup] = None):
+                      group: Optional[dist.ProcessGroup] = None,
+                      ce_local: Optional[Callable[[torch.Tensor, torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]]] = None):
     """Tied-embedding scoring + cross-entropy (EasyDGL.py:149-155,177-185) with the ITEM TABLE ROW-SHARDED over the ranks
     (SURVEY §8(e) row 3): every rank holds the same R scoring rows and labels and scores them against its shard [i0, i1) only.
 
@@ -99,11 +100,14 @@ def vocab_parallel_ce(labels: torch.Tensor, num_rows: int,
         lab = g[:, :, 1].max(dim=0).values                        # exactly one shard owns a label: every other entry is -inf
     else:
         lse, lab = lse_loc.to(torch.float32), lab_loc.to(torch.float32)
-    w = (labels.reshape(-1) != 0).to(lse.dtype)
-    W = w.sum() + 1e-5
-    p_y = torch.exp(lab - lse)
-    loss = (w * -torch.log(p_y + 1e-5)).sum() / W
-    coef = (w / W) * p_y / (p_y + 1e-5)
+    if ce_local is not None:      # (lse, lab, labels) -> (loss, coef): the four lines below as one launch (ops passes edgl_ce_loss_fwd)
+        loss, coef = ce_local(lse.contiguous(), lab.contiguous(), labels.reshape(-1))
+    else:
+        w = (labels.reshape(-1) != 0).to(lse.dtype)
+        W = w.sum() + 1e-5
+        p_y = torch.exp(lab - lse)
+        loss = (w * -torch.log(p_y + 1e-5)).sum() / W
+        coef = (w / W) * p_y / (p_y + 1e-5)
     d_rows = grad_local(i0, i1, lse.contiguous(), coef.contiguous()).to(torch.float32).contiguous()
     if world > 1:
         dist.all_reduce(d_rows, op=dist.ReduceOp.SUM, group=group)
