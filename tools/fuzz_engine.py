@@ -31,6 +31,10 @@ def main():
                     num_events=int(rng.choice([2, 3, 5, 7, 16, 16, 24, 40])), num_items=int(rng.choice([60, 300, 2000, 5000])))
         desc = f"case {k}: {mode} {cfgd}"
         T.CASES.append(cfgd)
+        # (a batch of 4 whose masked slots all fell on padding has no weighted row and no next-event mark: the reference's TPP term is
+        #  0 / 0 there — NaN in the oracle and in the engine alike; nothing to compare)
+        if not T.make_problem(seed=40 + len(T.CASES) - 1, batch=4, **cfgd)["labels"].any():
+            continue
         try:
             T.test_engine_gradients_match_oracle(mode, len(T.CASES) - 1)
             ran += 1
